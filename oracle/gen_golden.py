@@ -1,0 +1,209 @@
+"""TEST INFRASTRUCTURE ONLY -- generates tests/golden/*.npz by RUNNING THE REFERENCE.
+
+Run in the build container (where /root/reference is mounted):
+
+    python oracle/gen_golden.py
+
+The reference publishes no tests or golden vectors of its own, so parity is
+pinned by importing its Python here (recipe: oracle/_ref_import.py), feeding
+it deterministic synthetic inputs and storing inputs + the reference's outputs.  Only data
+is stored -- never reference source.  The fixtures travel to the GPU box; this script and
+the reference do not need to.
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from oracle import _ref_import as R          # noqa: E402
+from d3fields_amd import synth               # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+
+
+def pathological_points(pose, n_each=8, seed=11):
+    """Points that exercise |z|<1e-4, behind-camera, far-outside-image and mirror cases."""
+    g = np.random.default_rng(seed)
+    Rt = pose.numpy().astype(np.float64)
+    pts = []
+    for v in range(Rt.shape[0]):
+        R_, t = Rt[v, :, :3], Rt[v, :, 3]
+        c = -R_.T @ t
+        zdir = R_[2]
+        for _ in range(n_each):
+            lateral = R_[0] * g.uniform(-0.2, 0.2) + R_[1] * g.uniform(-0.2, 0.2)
+            pts.append(c + lateral + zdir * g.uniform(-9e-5, 9e-5))       # |z| < 1e-4
+            pts.append(c + lateral - zdir * g.uniform(0.05, 0.5))         # behind the camera
+            pts.append(c + lateral * 20 + zdir * g.uniform(0.2, 1.0))      # far outside image
+    pts.append([5.0, 5.0, 5.0])
+    pts.append([0.0, 0.0, 0.5])                                           # under the table
+    pts.append([0.0, 0.0, 0.0])
+    return torch.tensor(np.array(pts), dtype=torch.float32)
+
+
+def to_np(d):
+    return {k: (v.numpy() if isinstance(v, torch.Tensor) else v) for k, v in d.items()}
+
+
+def save(name, **arrays):
+    os.makedirs(OUT, exist_ok=True)
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **arrays)
+    print("%-28s %8.1f KB" % (name, os.path.getsize(path) / 1024))
+
+
+def scene_case(fusion, name, V, H, W, kind, fmap_hw, C, NI, N, dense_K=False, seed=0):
+    sc = synth.make_scene(V, H, W, kind, seed=seed)
+    if dense_K:
+        g = torch.Generator().manual_seed(77)
+        sc["K"] = sc["K"] + (torch.rand(V, 3, 3, generator=g) - 0.5) * 0.02 * sc["K"].abs().clamp(min=1.0)
+    feats = synth.random_map(V, fmap_hw[0], fmap_hw[1], C, seed=seed + 1)
+    mask = synth.random_onehot_mask(V, H, W, NI, seed=seed + 2)
+    gcol = torch.Generator().manual_seed(seed + 5)
+    color = torch.randint(0, 256, (V, H, W, 3), generator=gcol).to(torch.float32) / 255.0
+    obs = dict(sc)
+    obs.update(dino_feats=feats, mask=mask, color_tensor=color)
+    f = R.make_reference_fusion(fusion, obs, H, W)
+    pts = torch.cat([synth.random_cloud(N, seed=seed + 3), pathological_points(sc["pose"])])
+    with torch.no_grad():
+        full = f.eval(pts, return_names=["dino_feats", "mask", "color_tensor"], return_inter=True)
+        default = f.eval(pts)                                   # default return_names
+        empty = f.eval(pts, return_names=[])
+        dist_only = f.eval_dist(pts)
+        inst = fusion.onehot2instance(full["mask"])
+    assert sorted(default.keys()) == ["dino_feats", "dist", "mask", "valid_mask"]
+    assert sorted(empty.keys()) == ["dist", "valid_mask"]
+    assert torch.equal(default["dino_feats"], full["dino_feats"])
+    assert torch.equal(empty["dist"], full["dist"])
+    arrays = dict(H=H, W=W, mu=f.mu, pts=pts, K=sc["K"], pose=sc["pose"], depth=sc["depth"],
+                  in_dino_feats=feats, in_mask=mask, in_color_tensor=color,
+                  dist=full["dist"], valid_mask=full["valid_mask"],
+                  dino_feats=full["dino_feats"], mask=full["mask"], color_tensor=full["color_tensor"],
+                  dino_feats_inter=full["dino_feats_inter"], mask_inter=full["mask_inter"],
+                  color_tensor_inter=full["color_tensor_inter"],
+                  evaldist_dist=dist_only["dist"], evaldist_valid_mask=dist_only["valid_mask"],
+                  mask_instance=inst)
+    save(name, **to_np(arrays))
+
+
+def batch_case(fusion):
+    """batch_eval across 3 chunks with a ragged tail (fusion.py:526-545), N = 130 001."""
+    V, H, W = 4, 60, 80
+    sc = synth.make_scene(V, H, W, "smooth")
+    feats = synth.random_map(V, 6, 8, 2, seed=21)
+    mask = synth.random_onehot_mask(V, H, W, 3, seed=22)
+    obs = dict(sc)
+    obs.update(dino_feats=feats, mask=mask)
+    f = R.make_reference_fusion(fusion, obs, H, W)
+    N = 130001
+    pts = synth.random_cloud(N, seed=23)
+    with torch.no_grad():
+        out = f.batch_eval(pts, return_names=["dino_feats", "mask"])
+        out_default = f.batch_eval(pts)
+        out_empty = f.batch_eval(pts, return_names=[])
+    assert torch.equal(out_default["mask"], out["mask"])
+    assert sorted(out_empty.keys()) == ["dist", "valid_mask"]
+    sub = slice(0, N, 13)                      # stored subset; full tensors pinned by sums below
+    arrays = dict(H=H, W=W, mu=f.mu, N=N, cloud_seed=23, K=sc["K"], pose=sc["pose"], depth=sc["depth"],
+                  in_dino_feats=feats, in_mask=mask, stride=13,
+                  pts_sub=pts[sub], dist_sub=out["dist"][sub], dino_feats_sub=out["dino_feats"][sub],
+                  mask_sub=out["mask"][sub],
+                  valid_bits=np.packbits(out["valid_mask"].numpy()),
+                  pts_sum=pts.double().sum(0), dist_sum=out["dist"].double().sum(),
+                  dino_feats_sum=out["dino_feats"].double().sum(0), mask_sum=out["mask"].double().sum(0))
+    save("batch_eval_130001", **to_np(arrays))
+
+
+def grid_case(fusion):
+    """create_init_grid on the vis_repr.py boundaries/step (vis_repr.py:36-52,88)."""
+    b = dict(synth.WORK_BOX)
+    for step, tag in [(0.004, "004"), (0.02, "020")]:
+        coords, shape = fusion.create_init_grid(b, step)
+        n = coords.shape[0]
+        sub = slice(0, n, 1009)
+        save("init_grid_" + tag, step=step, shape=np.array(shape), n=n,
+             bounds=np.array([b["x_lower"], b["x_upper"], b["y_lower"], b["y_upper"], b["z_lower"], b["z_upper"]]),
+             head=coords[:128].numpy(), tail=coords[-128:].numpy(), sub=coords[sub].numpy(),
+             colsum=coords.double().sum(0).numpy())
+
+
+def onehot_case(fusion):
+    g = torch.Generator().manual_seed(31)
+    inst = torch.randint(0, 6, (5, 7, 9), generator=g).to(torch.uint8)
+    oh_t = fusion.instance2onehot(inst, 6)
+    oh_n = fusion.instance2onehot(inst.numpy(), 6)
+    assert np.array_equal(oh_t.numpy(), oh_n)
+    soft = torch.rand(300, 6, generator=g)
+    soft[5] = 0.0                                      # all-equal row -> index 0
+    soft[6, 2] = soft[6, 4] = 2.0                      # tie -> first index
+    back_t = fusion.onehot2instance(soft)
+    back_n = fusion.onehot2instance(soft.numpy())
+    assert np.array_equal(back_t.numpy(), back_n)
+    save("onehot", inst=inst.numpy(), NI=6, onehot=oh_t.numpy(), soft=soft.numpy(), soft_inst=back_t.numpy())
+
+
+def corr_case(corr):
+    g = torch.Generator().manual_seed(41)
+    B, Hh, Ww, C = 3, 10, 12, 24
+    fmap = torch.randn(B, Hh, Ww, C, generator=g)
+    tgt = torch.randn(C, generator=g)
+    arrays = dict(fmap_bhwc=fmap.numpy(), tgt=tgt.numpy(), scale=0.7)
+    fmap_bchw = fmap.permute(0, 3, 1, 2).contiguous()
+    for dt in ("l2", "square"):
+        arrays["similarity_" + dt] = corr.compute_similarity(fmap.numpy(), tgt.numpy(), 0.7, dist_type=dt)
+        arrays["similarity_tensor_" + dt] = corr.compute_similarity_tensor(fmap_bchw, tgt, 0.7, dist_type=dt).numpy()
+        arrays["dist_tensor_" + dt] = corr.compute_dist_tensor(fmap_bchw, tgt, dist_type=dt).numpy()
+    # 2-D variant of the tensor helpers ([B, C] with no trailing dims)
+    flat = torch.randn(50, C, generator=g)
+    arrays["flat"] = flat.numpy()
+    arrays["flat_similarity_tensor_l2"] = corr.compute_similarity_tensor(flat, tgt, 0.7).numpy()
+    arrays["flat_dist_tensor_l2"] = corr.compute_dist_tensor(flat, tgt).numpy()
+    B1, B2 = 700, 37
+    src = torch.randn(B1, C, generator=g)
+    tg = torch.randn(B2, C, generator=g)
+    tg[3] = src[100]                                   # an exact match (distance 0)
+    tg[4] = src[101] + 1e-4                            # a near match (cancellation stress)
+    arrays.update(multi_src=src.numpy(), multi_tgt=tg.numpy(), multi_scale=1.3)
+    for dt in ("l2", "square"):
+        o = corr.compute_similarity_tensor_multi(src, tg, None, None, 1.3, dist_type=dt)
+        arrays["multi_" + dt] = o.numpy()
+        arrays["multi_argmax_" + dt] = o.argmax(0).numpy()
+    save("corr_utils", **arrays)
+
+
+def grad_case(fusion):
+    """d(sum(feat) + sum(dist))/d pts through the reference's autograd (for the backward row)."""
+    V, H, W = 3, 48, 64
+    sc = synth.make_scene(V, H, W, "smooth")
+    feats = synth.random_map(V, 12, 16, 4, seed=51)
+    obs = dict(sc)
+    obs.update(dino_feats=feats)
+    f = R.make_reference_fusion(fusion, obs, H, W)
+    pts = synth.random_cloud(500, seed=53).requires_grad_(True)
+    out = f.eval(pts, return_names=["dino_feats"])
+    (out["dino_feats"].sum() + out["dist"].sum()).backward()
+    save("grad_500", H=H, W=W, mu=f.mu, K=sc["K"].numpy(), pose=sc["pose"].numpy(), depth=sc["depth"].numpy(),
+         in_dino_feats=feats.numpy(), pts=pts.detach().numpy(), grad_pts=pts.grad.numpy(),
+         dist=out["dist"].detach().numpy(), dino_feats=out["dino_feats"].detach().numpy())
+
+
+def main():
+    torch.set_num_threads(4)
+    fusion, corr = R.import_reference()
+    scene_case(fusion, "scene_patchres_smooth", V=3, H=48, W=64, kind="smooth", fmap_hw=(12, 16), C=5, NI=8, N=4096)
+    scene_case(fusion, "scene_patchres_stress", V=3, H=48, W=64, kind="stress", fmap_hw=(12, 16), C=5, NI=8, N=4096, seed=3)
+    scene_case(fusion, "scene_fullres_smooth", V=4, H=48, W=64, kind="smooth", fmap_hw=(48, 64), C=12, NI=4, N=2048, seed=5)
+    scene_case(fusion, "scene_denseK_1view", V=1, H=40, W=56, kind="stress", fmap_hw=(7, 9), C=3, NI=2, N=1024, dense_K=True, seed=7)
+    scene_case(fusion, "scene_wideC_9views", V=9, H=30, W=40, kind="smooth", fmap_hw=(5, 7), C=70, NI=3, N=500, seed=9)
+    batch_case(fusion)
+    grid_case(fusion)
+    onehot_case(fusion)
+    corr_case(corr)
+    grad_case(fusion)
+
+
+if __name__ == "__main__":
+    main()
