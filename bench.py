@@ -1,0 +1,223 @@
+#!/usr/bin/env python
+"""bench.py -- fused 3-D query points / second of the d3fields field query on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload NAME]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is ONE pass of the hot path (Fusion.batch_eval == one fused HIP launch) over one
+batch of synthetic query points, with every input already resident in HBM.  Rank 0 prints ONE
+JSON line (contract in the task statement) carrying `roofline` and, at N=1, `cpu_baseline`.
+
+Workloads (BASELINE.json configs; no datasets/checkpoints offline -> random maps of the same
+shape):
+  c2_dense  4 views x 480x640 depth, 480x640x384 fp32 feature maps (what "4x(480x640)x384-d"
+            in the north star implies), 985 600-point voxel grid (step 5 mm)       [default]
+  c2_patch  same, reference-faithful patch-resolution 48x64x384 features (fusion.py:694-697)
+  c3_dense / c3_patch  + 480x640x8 one-hot instance mask, 1 925 000-point grid (step 4 mm)
+  c4_patch  8 views x 720x1280, 72x128x1024 features, 1 000 000 points per GPU
+Multi-GPU: weak scaling -- every rank queries its own shard of N points against replicated
+maps; the only exchange is the RCCL all-gather that reassembles the field (`--gather`).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+WORKLOADS = {
+    "c2_dense": dict(V=4, H=480, W=640, C=384, fhw=(480, 640), NI=0, step=0.005, N=985600),
+    "c2_patch": dict(V=4, H=480, W=640, C=384, fhw=(48, 64), NI=0, step=0.005, N=985600),
+    "c3_dense": dict(V=4, H=480, W=640, C=384, fhw=(480, 640), NI=8, step=0.004, N=1925000),
+    "c3_patch": dict(V=4, H=480, W=640, C=384, fhw=(48, 64), NI=8, step=0.004, N=1925000),
+    "c4_patch": dict(V=8, H=720, W=1280, C=1024, fhw=(72, 128), NI=0, step=None, N=1000000),
+}
+
+
+def algorithmic_bytes(w, n):
+    """read every point once, write every output once, read every map once."""
+    sumC = w["C"] + w["NI"]
+    per_pt = 12 + 4 + 1 + 4 * sumC
+    maps = w["V"] * (4 * w["H"] * w["W"] + 4 * w["fhw"][0] * w["fhw"][1] * w["C"] + 4 * w["H"] * w["W"] * w["NI"])
+    return n * per_pt + maps + 84 * w["V"], per_pt
+
+
+def build_workload(name, dev, rank, world):
+    from d3fields_amd import Fusion, create_init_grid, synth
+    w = WORKLOADS[name]
+    V, H, W = w["V"], w["H"], w["W"]
+    sc = synth.make_scene(V, H, W, "smooth")
+    f = Fusion(num_cam=V, device=str(dev))
+    f.curr_obs_torch = {k: sc[k].to(dev) for k in ("depth", "K", "pose")}
+    f.curr_obs_torch["dino_feats"] = synth.random_map(V, w["fhw"][0], w["fhw"][1], w["C"], seed=1, device=dev)
+    names = ["dino_feats"]
+    if w["NI"]:
+        f.curr_obs_torch["mask"] = synth.random_onehot_mask(V, H, W, w["NI"], seed=2, device=dev)
+        names.append("mask")
+    f.H, f.W = H, W
+    if w["step"] is not None:
+        # weak scaling: the job's grid is `world` times finer along x (step/world); rank r owns the
+        # x-planes congruent to r, i.e. the same box shifted by r*step/world -> N points per rank
+        pts, _ = create_init_grid(synth.WORK_BOX, w["step"])
+        if world > 1:
+            pts[:, 0] += rank * w["step"] / world
+    else:
+        pts = synth.random_cloud(w["N"], seed=3 + rank)
+    return f, pts.to(dev), names, w, sc
+
+
+def time_steps(fn, steps, dist_on, dev):
+    """Barrier + synchronize on both sides of exactly `steps` steps; returns wall seconds (max over ranks)."""
+    import torch.distributed as dist
+    if dist_on:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        fn()
+    torch.cuda.synchronize(dev)
+    if dist_on:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if dist_on:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    return dt
+
+
+def kernel_time_ms(fn, steps, dev):
+    """Average device time of one step measured with HIP events recorded on the stream the
+    kernel is launched on (torch's current stream: the shim passes exactly that stream)."""
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+    for a, b in ev:
+        a.record()
+        fn()
+        b.record()
+    torch.cuda.synchronize(dev)
+    ts = sorted(a.elapsed_time(b) for a, b in ev)
+    return sum(ts) / len(ts), ts[len(ts) // 2], ts[0]
+
+
+def cpu_baseline(sc, w, names, maps_cpu, pts_cpu, budget_pts):
+    """The torch-ops CPU port of Fusion.batch_eval (oracle/torch_port.py) on the host cores,
+    on a bounded sample of the same workload.  Reported beside the GPU number, never a target."""
+    from oracle import torch_port
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    obs = {k: sc[k] for k in ("depth", "K", "pose")}
+    obs.update(maps_cpu)
+    n = min(budget_pts, pts_cpu.shape[0])
+    idx = torch.linspace(0, pts_cpu.shape[0] - 1, n).long()
+    sample = pts_cpu[idx].contiguous()
+    with torch.no_grad():
+        torch_port.batched_field_query(obs, sample[:20000], names, w["H"], w["W"])       # warm-up
+        t0 = time.perf_counter()
+        torch_port.batched_field_query(obs, sample, names, w["H"], w["W"])
+        dt = time.perf_counter() - t0
+    return {"value": n / dt, "unit": "points/s", "cores": cores, "kind": "port",
+            "sample": "%d evenly spaced points of the same grid, same maps, torch-ops port of batch_eval "
+                      "(60000-pt chunks, %d threads), %.1f s" % (n, cores, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="c2_dense", choices=sorted(WORKLOADS))
+    ap.add_argument("--gather", default="dist", choices=["none", "dist", "full"],
+                    help="N>1: what the RCCL all-gather reassembles inside the timed step")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", type=int, default=200000)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    dist_on = world > 1
+    if args.gpus != world and dist_on:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if args.gpus > 1 and not dist_on:
+        raise SystemExit("launch N>1 with: python -m torch.distributed.run --nnodes=1 --nproc-per-node %d "
+                         "--master-addr 127.0.0.1 --master-port 29500 bench.py --gpus %d" % (args.gpus, args.gpus))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback for the product path)")
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+    if dist_on:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)       # "nccl" is RCCL on ROCm
+
+    f, pts, names, w, sc = build_workload(args.workload, dev, rank, world)
+    n = pts.shape[0]
+    from d3fields_amd import sharding
+
+    def compute():
+        return f.batch_eval(pts, return_names=names)
+
+    def step():
+        out = compute()
+        if dist_on and args.gather != "none":
+            keys = ("dist", "valid_mask") if args.gather == "dist" else tuple(out.keys())
+            sharding.all_gather_field(out, keys=keys)
+        return out
+
+    with torch.no_grad():
+        for _ in range(max(args.warmup, 1)):
+            step()
+        wall = time_steps(step, args.steps, dist_on, dev)
+        k_avg, k_med, k_min = kernel_time_ms(compute, max(args.steps, 5), dev)
+        extra = {}
+        if dist_on:
+            extra["compute_only_points_per_s"] = world * n * args.steps / time_steps(compute, args.steps, True, dev)
+            if args.gather != "full":
+                def full():
+                    sharding.all_gather_field(compute(), keys=None)
+                full()
+                fs = max(2, args.steps // 4)
+                extra["full_field_gather_points_per_s"] = world * n * fs / time_steps(full, fs, True, dev)
+
+    total_pts = world * n * args.steps
+    value = total_pts / wall
+    bytes_alg, per_pt = algorithmic_bytes(w, n)
+    achieved = bytes_alg / (k_avg * 1e-3) / 1e9
+    res = {
+        "metric": "fused 3D query-points/sec", "value": value, "unit": "points/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": 1e3 * wall / args.steps, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "%s: %d views x %dx%d depth, %dx%dx%d fp32 features%s, %d query points per GPU, "
+                               "return_names=%s" % (args.workload, w["V"], w["H"], w["W"], w["fhw"][0], w["fhw"][1], w["C"],
+                                                    (" + %dx%dx%d one-hot mask" % (w["H"], w["W"], w["NI"])) if w["NI"] else "",
+                                                    n, names),
+                   "points_per_gpu": n, "views": w["V"], "feature_dim": w["C"], "feature_map": list(w["fhw"]),
+                   "parallelism": "points sharded x%d, maps replicated" % world,
+                   "gather": (args.gather if dist_on else "n/a")},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "kernel": "fused_eval_kernel<0>", "kernel_ms_avg": k_avg, "kernel_ms_median": k_med,
+                     "kernel_ms_min": k_min, "algorithmic_bytes_per_launch": bytes_alg,
+                     "algorithmic_bytes_per_point": per_pt, "kernel_points_per_s": n / (k_avg * 1e-3)},
+    }
+    res.update(extra)
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        maps_cpu = {k: f.curr_obs_torch[k].cpu() for k in names}
+        res["cpu_baseline"] = cpu_baseline(sc, w, names, maps_cpu, pts.cpu(), args.cpu_sample)
+    if rank == 0:
+        print(json.dumps(res))
+    if dist_on:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,105 @@
+"""ctypes binding of libd3fields_hip.so (the C ABI declared in include/d3fields_hip.h).
+
+There is deliberately no fallback: if the shared library cannot be loaded, or a call returns
+an error status, an exception is raised.  Nothing in this package computes the field query on
+the CPU or through torch ops.
+"""
+import ctypes
+import os
+
+from . import build as _build
+
+ABI_VERSION = 1
+
+# status codes (include/d3fields_hip.h)
+OK = 0
+ERR_INVALID_ARG, ERR_BAD_SHAPE, ERR_BAD_DTYPE, ERR_BAD_LAYOUT, ERR_HIP, ERR_WORKSPACE = -1, -2, -3, -4, -5, -6
+FLAG_FINITE_MAPS = 1
+MAX_VIEWS = 64
+MAX_MAPS = 8
+DTYPE_F32 = 0
+DIST_L2, DIST_SQUARE = 0, 1
+SIM_DIST, SIM_EXP, SIM_SOFTMAX_DIM0 = 0, 1, 2
+
+_vp = ctypes.c_void_p
+_i32 = ctypes.c_int32
+_i64 = ctypes.c_int64
+_u32 = ctypes.c_uint32
+_f32 = ctypes.c_float
+
+
+class Views(ctypes.Structure):
+    """struct d3f_views"""
+    _fields_ = [("V", _i32), ("H", _i32), ("W", _i32), ("depth", _vp), ("K", _vp), ("pose", _vp)]
+
+
+class ChannelMap(ctypes.Structure):
+    """struct d3f_channel_map"""
+    _fields_ = [("data", _vp), ("fh", _i32), ("fw", _i32), ("C", _i32), ("dtype", _i32),
+                ("stride_v", _i64), ("stride_y", _i64), ("stride_x", _i64)]
+
+
+# name -> (restype, argtypes); every symbol include/d3fields_hip.h declares
+SIGNATURES = {
+    "d3f_abi_version": (ctypes.c_int, []),
+    "d3f_version": (ctypes.c_char_p, []),
+    "d3f_last_error": (ctypes.c_char_p, []),
+    "d3f_eval": (ctypes.c_int, [ctypes.POINTER(Views), _vp, _i64, ctypes.POINTER(ChannelMap), _i32, _f32, _u32,
+                                _vp, _vp, ctypes.POINTER(_vp), ctypes.POINTER(_vp), _vp]),
+    "d3f_eval_dist": (ctypes.c_int, [ctypes.POINTER(Views), _vp, _i64, _vp, _vp, _vp]),
+    "d3f_onehot2instance": (ctypes.c_int, [_vp, _i64, _i32, _vp, _vp]),
+    "d3f_instance2onehot": (ctypes.c_int, [_vp, _i64, _i32, _vp, _vp]),
+    "d3f_softmax_workspace_bytes": (_i64, [_i64, _i64]),
+    "d3f_similarity_to_target": (ctypes.c_int, [_vp, _i64, _i64, _i32, _i64, _i64, _i64, _vp, _f32, _i32, _i32,
+                                                _vp, _vp, _i64, _vp]),
+    "d3f_pairwise_similarity": (ctypes.c_int, [_vp, _vp, _i64, _i64, _i32, _f32, _i32, _i32, _vp, _vp, _vp, _i64,
+                                               _vp]),
+}
+
+_lib = None
+
+
+class D3FError(RuntimeError):
+    def __init__(self, code, text):
+        super().__init__("libd3fields_hip: status %d: %s" % (code, text))
+        self.code = code
+
+
+def library_path():
+    return _build.LIB_PATH
+
+
+def load():
+    """Loads (building first if the .so is absent and hipcc exists) and type-annotates the ABI."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = library_path()
+    if not os.path.exists(path):
+        _build.build_library()      # raises if hipcc is unavailable: no silent fallback
+    lib = ctypes.CDLL(path)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)     # AttributeError if the .so lacks a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    got = lib.d3f_abi_version()
+    if got != ABI_VERSION:
+        raise ImportError("libd3fields_hip ABI %d != binding ABI %d; rebuild with python -m d3fields_amd.build --force"
+                          % (got, ABI_VERSION))
+    _lib = lib
+    return lib
+
+
+def check(code):
+    if code != OK:
+        raise D3FError(code, load().d3f_last_error().decode("utf-8", "replace"))
+
+
+def ptr(t):
+    """Device (or host) address of a torch tensor as c_void_p; None -> NULL."""
+    return _vp(t.data_ptr()) if t is not None else _vp(None)
+
+
+def current_stream_handle(device):
+    import torch
+    return _vp(torch.cuda.current_stream(device).cuda_stream)

@@ -1,0 +1,230 @@
+// d3f_api.hip -- the extern "C" boundary of libd3fields_hip.so (see include/d3fields_hip.h).
+// Validates arguments, picks the lane mapping of every channel map and enqueues the kernels on
+// the caller's stream.  No allocation, no synchronisation, no state besides the thread-local
+// error text.
+#include <stdarg.h>
+#include <stdio.h>
+
+#include "d3f_internal.h"
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+int hip_fail(hipError_t e, const char *what)
+{
+    return fail(D3F_ERR_HIP, "%s: %s", what, hipGetErrorString(e));
+}
+
+bool aligned(const void *p, size_t a) { return (reinterpret_cast<uintptr_t>(p) % a) == 0; }
+
+int check_views(const d3f_views *v)
+{
+    if (!v) return fail(D3F_ERR_INVALID_ARG, "views is NULL");
+    if (!v->depth || !v->K || !v->pose) return fail(D3F_ERR_INVALID_ARG, "views: depth/K/pose must be non-NULL");
+    if (v->V < 1 || v->V > D3F_MAX_VIEWS) return fail(D3F_ERR_BAD_SHAPE, "views: V=%d outside [1,%d]", v->V, D3F_MAX_VIEWS);
+    if (v->H < 2 || v->W < 2) return fail(D3F_ERR_BAD_SHAPE, "views: H=%d W=%d must be >= 2", v->H, v->W);
+    return D3F_OK;
+}
+
+// Phase-B lane mapping of one map: vector width, lanes per point (2^k) and vectors per lane.
+// Minimises idle lane-slots (passes*lpp*U - cvec), then passes, then prefers wide groups
+// (longer contiguous segments per load instruction).
+void pick_mapping(d3f::MapDesc &m, bool can16, bool can8)
+{
+    m.vw = (m.C % 4 == 0 && can16) ? 4 : ((m.C % 2 == 0 && can8) ? 2 : 1);
+    const int cvec = m.C / m.vw;
+    long best_slots = -1;
+    int best_passes = 0;
+    for (int lg = 6; lg >= 0; --lg) {
+        const int lpp = 1 << lg;
+        for (int u = 4; u >= 1; --u) {
+            const int per = lpp * u;
+            const int passes = (cvec + per - 1) / per;
+            const long slots = (long)passes * per;
+            const bool better = best_slots < 0 || slots < best_slots || (slots == best_slots && passes < best_passes);
+            if (better) {
+                best_slots = slots;
+                best_passes = passes;
+                m.lpp_log2 = lg;
+                m.unroll = u;
+            }
+        }
+    }
+}
+
+int tile_points_for(int V)
+{
+    // LDS per workgroup = tile*V*16 B (+ small); keep it <= 32 KiB so >= 4 workgroups fit a CU
+    int t = 256;
+    while (t > 32 && (long)t * V * 16 > 32 * 1024) t >>= 1;
+    return t;
+}
+
+int eval_common(const d3f_views *views, const float *pts, int64_t n, const d3f_channel_map *maps, int32_t n_maps,
+                float mu, uint32_t flags, float *out_dist, uint8_t *out_valid, float *const *out_fused,
+                float *const *out_inter, void *stream, int mode)
+{
+    int rc = check_views(views);
+    if (rc != D3F_OK) return rc;
+    if (n < 0) return fail(D3F_ERR_INVALID_ARG, "n=%lld is negative", (long long)n);
+    if (n == 0) return D3F_OK;
+    if (!pts || !out_dist || !out_valid) return fail(D3F_ERR_INVALID_ARG, "pts/out_dist/out_valid must be non-NULL");
+    if (n_maps < 0 || n_maps > D3F_MAX_MAPS) return fail(D3F_ERR_BAD_SHAPE, "n_maps=%d outside [0,%d]", n_maps, D3F_MAX_MAPS);
+    if (n_maps > 0 && (!maps || !out_fused)) return fail(D3F_ERR_INVALID_ARG, "maps/out_fused must be non-NULL when n_maps > 0");
+    if (!(mu > 0.0f)) return fail(D3F_ERR_INVALID_ARG, "mu must be > 0");
+
+    d3f::EvalParams P;
+    P.depth = views->depth; P.K = views->K; P.pose = views->pose; P.pts = pts;
+    P.out_dist = out_dist; P.out_valid = out_valid;
+    P.n = n; P.V = views->V; P.H = views->H; P.W = views->W;
+    P.n_maps = n_maps; P.tile_pts = tile_points_for(views->V);
+    P.flags = flags; P.mu = mu;
+    for (int s = 0; s < n_maps; ++s) {
+        const d3f_channel_map &c = maps[s];
+        d3f::MapDesc &m = P.maps[s];
+        if (!c.data || !out_fused[s]) return fail(D3F_ERR_INVALID_ARG, "map %d: data/out pointer is NULL", s);
+        if (c.dtype != D3F_DTYPE_F32) return fail(D3F_ERR_BAD_DTYPE, "map %d: dtype %d unsupported (fp32 only)", s, c.dtype);
+        if (c.fh < 1 || c.fw < 1 || c.C < 1) return fail(D3F_ERR_BAD_SHAPE, "map %d: fh=%d fw=%d C=%d", s, c.fh, c.fw, c.C);
+        if (c.stride_x < c.C || c.stride_y < 0 || c.stride_v < 0)
+            return fail(D3F_ERR_BAD_LAYOUT, "map %d: strides (%lld,%lld,%lld) do not describe a channels-last map", s,
+                        (long long)c.stride_v, (long long)c.stride_y, (long long)c.stride_x);
+        m.data = static_cast<const float *>(c.data);
+        m.out = out_fused[s];
+        m.inter = out_inter ? out_inter[s] : nullptr;
+        m.sv = c.stride_v; m.sy = c.stride_y; m.sx = c.stride_x;
+        m.fh = c.fh; m.fw = c.fw; m.C = c.C;
+        if (!aligned(m.data, 4) || !aligned(m.out, 4)) return fail(D3F_ERR_BAD_LAYOUT, "map %d: pointers must be 4-byte aligned", s);
+        const bool str16 = (c.stride_v % 4 == 0) && (c.stride_y % 4 == 0) && (c.stride_x % 4 == 0);
+        const bool str8 = (c.stride_v % 2 == 0) && (c.stride_y % 2 == 0) && (c.stride_x % 2 == 0);
+        const bool can16 = str16 && aligned(m.data, 16) && aligned(m.out, 16) && (!m.inter || aligned(m.inter, 16));
+        const bool can8 = str8 && aligned(m.data, 8) && aligned(m.out, 8) && (!m.inter || aligned(m.inter, 8));
+        pick_mapping(m, can16, can8);
+    }
+    const int64_t ntiles = (n + P.tile_pts - 1) / P.tile_pts;
+    if (ntiles > 0x7fffffffLL) return fail(D3F_ERR_BAD_SHAPE, "n=%lld needs more than 2^31 workgroups", (long long)n);
+    hipError_t e = d3f::launch_fused_eval(P, mode, static_cast<hipStream_t>(stream));
+    if (e != hipSuccess) return hip_fail(e, "fused_eval launch");
+    return D3F_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int d3f_abi_version(void) { return D3F_ABI_VERSION; }
+const char *d3f_version(void) { return "d3fields-hip 0.1.0 gfx950"; }
+const char *d3f_last_error(void) { return g_err; }
+
+int d3f_eval(const d3f_views *views, const float *pts, int64_t n, const d3f_channel_map *maps, int32_t n_maps,
+             float mu, uint32_t flags, float *out_dist, uint8_t *out_valid, float *const *out_fused,
+             float *const *out_inter, void *stream)
+{
+    return eval_common(views, pts, n, maps, n_maps, mu, flags, out_dist, out_valid, out_fused, out_inter, stream, 0);
+}
+
+int d3f_eval_dist(const d3f_views *views, const float *pts, int64_t n, float *out_dist, uint8_t *out_valid,
+                  void *stream)
+{
+    return eval_common(views, pts, n, nullptr, 0, 1.0f, 0u, out_dist, out_valid, nullptr, nullptr, stream, 1);
+}
+
+int d3f_onehot2instance(const float *onehot, int64_t n, int32_t NI, uint8_t *out, void *stream)
+{
+    if (n < 0 || NI < 1 || NI > 256) return fail(D3F_ERR_BAD_SHAPE, "onehot2instance: n=%lld NI=%d (NI must be in [1,256])", (long long)n, NI);
+    if (n == 0) return D3F_OK;
+    if (!onehot || !out) return fail(D3F_ERR_INVALID_ARG, "onehot2instance: NULL pointer");
+    hipError_t e = d3f::launch_onehot2instance(onehot, n, NI, out, static_cast<hipStream_t>(stream));
+    return e == hipSuccess ? D3F_OK : hip_fail(e, "onehot2instance launch");
+}
+
+int d3f_instance2onehot(const uint8_t *instance, int64_t n, int32_t NI, uint8_t *out_bool, void *stream)
+{
+    if (n < 0 || NI < 1 || NI > 256) return fail(D3F_ERR_BAD_SHAPE, "instance2onehot: n=%lld NI=%d (NI must be in [1,256])", (long long)n, NI);
+    if (n == 0) return D3F_OK;
+    if (!instance || !out_bool) return fail(D3F_ERR_INVALID_ARG, "instance2onehot: NULL pointer");
+    hipError_t e = d3f::launch_instance2onehot(instance, n, NI, out_bool, static_cast<hipStream_t>(stream));
+    return e == hipSuccess ? D3F_OK : hip_fail(e, "instance2onehot launch");
+}
+
+int64_t d3f_softmax_workspace_bytes(int64_t rows, int64_t cols)
+{
+    if (rows <= 0 || cols <= 0) return 0;
+    const int64_t nchunks = (rows + d3f::kSoftmaxRowsPerBlock - 1) / d3f::kSoftmaxRowsPerBlock;
+    return (nchunks + 1) * cols * (int64_t)sizeof(d3f::ColStat);
+}
+
+static int check_sim_enums(int32_t dist_type, int32_t mode)
+{
+    if (dist_type != D3F_DIST_L2 && dist_type != D3F_DIST_SQUARE) return fail(D3F_ERR_INVALID_ARG, "dist_type=%d (expected D3F_DIST_L2 or D3F_DIST_SQUARE)", dist_type);
+    if (mode < D3F_SIM_DIST || mode > D3F_SIM_SOFTMAX_DIM0) return fail(D3F_ERR_INVALID_ARG, "mode=%d is not a D3F_SIM_* value", mode);
+    return D3F_OK;
+}
+
+int d3f_similarity_to_target(const float *src, int64_t B, int64_t inner, int32_t C, int64_t stride_b,
+                             int64_t stride_i, int64_t stride_c, const float *tgt, float scale, int32_t dist_type,
+                             int32_t mode, float *out, void *workspace, int64_t workspace_bytes, void *stream)
+{
+    int rc = check_sim_enums(dist_type, mode);
+    if (rc != D3F_OK) return rc;
+    if (B < 0 || inner < 0 || C < 1) return fail(D3F_ERR_BAD_SHAPE, "similarity_to_target: B=%lld inner=%lld C=%d", (long long)B, (long long)inner, C);
+    if (B == 0 || inner == 0) return D3F_OK;
+    if (!src || !tgt || !out) return fail(D3F_ERR_INVALID_ARG, "similarity_to_target: NULL pointer");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    hipError_t e = d3f::launch_dist_to_target(src, B, inner, C, stride_b, stride_i, stride_c, tgt, dist_type, out, s);
+    if (e != hipSuccess) return hip_fail(e, "dist_to_target launch");
+    if (mode == D3F_SIM_EXP) {
+        e = d3f::launch_exp_neg_scale(out, B * inner, scale, s);
+        if (e != hipSuccess) return hip_fail(e, "exp launch");
+    } else if (mode == D3F_SIM_SOFTMAX_DIM0) {
+        if (!workspace || workspace_bytes < d3f_softmax_workspace_bytes(B, inner))
+            return fail(D3F_ERR_WORKSPACE, "similarity_to_target: softmax needs %lld workspace bytes", (long long)d3f_softmax_workspace_bytes(B, inner));
+        e = d3f::launch_softmax_dim0(out, B, inner, scale, nullptr, static_cast<d3f::ColStat *>(workspace), s);
+        if (e != hipSuccess) return hip_fail(e, "softmax launch");
+    }
+    return D3F_OK;
+}
+
+int d3f_pairwise_similarity(const float *src, const float *tgt, int64_t B1, int64_t B2, int32_t C, float scale,
+                            int32_t dist_type, int32_t mode, float *out, int64_t *argmax_out, void *workspace,
+                            int64_t workspace_bytes, void *stream)
+{
+    int rc = check_sim_enums(dist_type, mode);
+    if (rc != D3F_OK) return rc;
+    if (B1 < 0 || B2 < 0 || C < 1) return fail(D3F_ERR_BAD_SHAPE, "pairwise: B1=%lld B2=%lld C=%d", (long long)B1, (long long)B2, C);
+    if (B1 == 0 || B2 == 0) return D3F_OK;
+    if (!src || !tgt || !out) return fail(D3F_ERR_INVALID_ARG, "pairwise: NULL pointer");
+    if ((B2 + 63) / 64 > 0x7fffffffLL || (B1 + 63) / 64 > 65535) return fail(D3F_ERR_BAD_SHAPE, "pairwise: B1=%lld exceeds 64*65535 rows per call", (long long)B1);
+    const bool need_ws = (mode == D3F_SIM_SOFTMAX_DIM0) || (argmax_out != nullptr);
+    if (need_ws && (!workspace || workspace_bytes < d3f_softmax_workspace_bytes(B1, B2)))
+        return fail(D3F_ERR_WORKSPACE, "pairwise: needs %lld workspace bytes", (long long)d3f_softmax_workspace_bytes(B1, B2));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    hipError_t e = d3f::launch_pairwise_dist(src, tgt, B1, B2, C, dist_type, out, s);
+    if (e != hipSuccess) return hip_fail(e, "pairwise_dist launch");
+    d3f::ColStat *ws = static_cast<d3f::ColStat *>(workspace);
+    if (mode == D3F_SIM_SOFTMAX_DIM0) {
+        e = d3f::launch_softmax_dim0(out, B1, B2, scale, argmax_out, ws, s);
+        if (e != hipSuccess) return hip_fail(e, "softmax launch");
+    } else {
+        if (argmax_out) {   // best match = smallest distance, decided before exp() can tie values
+            e = d3f::launch_argmin_dim0(out, B1, B2, argmax_out, ws, s);
+            if (e != hipSuccess) return hip_fail(e, "argmin launch");
+        }
+        if (mode == D3F_SIM_EXP) {
+            e = d3f::launch_exp_neg_scale(out, B1 * B2, scale, s);
+            if (e != hipSuccess) return hip_fail(e, "exp launch");
+        }
+    }
+    return D3F_OK;
+}
+
+}  // extern "C"

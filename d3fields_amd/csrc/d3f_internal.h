@@ -1,0 +1,63 @@
+// d3f_internal.h -- declarations shared by the kernels and the C-ABI layer (not installed).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/d3fields_hip.h"
+
+namespace d3f {
+
+constexpr int kBlock = 256;                 // 4 waves of 64 lanes
+constexpr uint32_t kFlagFiniteMaps = D3F_FLAG_FINITE_MAPS;
+
+// One channel map as the kernel sees it (strides in elements, channel stride 1).
+struct MapDesc {
+    const float *data;
+    float *out;      // [n, C]
+    float *inter;    // [V, n, C] or nullptr
+    int64_t sv, sy, sx;
+    int32_t fh, fw, C;
+    int32_t vw;        // channel-vector width in floats: 4, 2 or 1
+    int32_t lpp_log2;  // log2(lanes per point) in phase B
+    int32_t unroll;    // channel vectors per lane per pass (1..4)
+};
+
+struct EvalParams {
+    const float *depth, *K, *pose, *pts;
+    float *out_dist;
+    uint8_t *out_valid;
+    int64_t n;
+    int32_t V, H, W;
+    int32_t n_maps;
+    int32_t tile_pts;  // points per workgroup
+    uint32_t flags;
+    float mu;
+    MapDesc maps[D3F_MAX_MAPS];
+};
+
+hipError_t launch_fused_eval(const EvalParams &P, int mode, hipStream_t stream);
+
+// misc_kernels.hip
+hipError_t launch_onehot2instance(const float *onehot, int64_t n, int NI, uint8_t *out, hipStream_t s);
+hipError_t launch_instance2onehot(const uint8_t *inst, int64_t n, int NI, uint8_t *out, hipStream_t s);
+
+// corr_kernels.hip
+struct ColStat {   // running softmax statistics of one column (16 B)
+    float m;       // max of -d*scale
+    float s;       // sum exp(x - m)
+    int64_t arg;   // row index of the first maximum
+};
+constexpr int kSoftmaxRowsPerBlock = 256;
+hipError_t launch_dist_to_target(const float *src, int64_t B, int64_t inner, int C, int64_t sb, int64_t si,
+                                 int64_t sc, const float *tgt, int dist_type, float *out, hipStream_t s);
+hipError_t launch_pairwise_dist(const float *src, const float *tgt, int64_t B1, int64_t B2, int C,
+                                int dist_type, float *out, hipStream_t s);
+hipError_t launch_exp_neg_scale(float *x, int64_t n, float scale, hipStream_t s);
+// softmax(-x*scale, dim=0) of a row-major [rows, cols] matrix in place (+ optional argmax)
+hipError_t launch_softmax_dim0(float *x, int64_t rows, int64_t cols, float scale, int64_t *argmax_out,
+                               ColStat *ws, hipStream_t s);
+// argmin over dim 0 of raw distances (used for D3F_SIM_DIST + argmax_out)
+hipError_t launch_argmin_dim0(const float *x, int64_t rows, int64_t cols, int64_t *arg_out, ColStat *ws,
+                              hipStream_t s);
+
+}  // namespace d3f

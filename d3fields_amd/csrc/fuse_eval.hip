@@ -1,0 +1,293 @@
+// fuse_eval.hip -- the fused 3-D field query of d3fields for gfx950 (MI355X, CDNA4).
+//
+// One launch does what Fusion.eval does with ~20 torch ops and three [V,N,C] temporaries
+// (reference fusion.py:305-394, helpers :32-77): project every query point into the V
+// calibrated views, look the nearest depth pixel up, derive the truncated signed distance,
+// the per-view validity bit and exp weight, bilinearly sample every requested channels-last
+// map and reduce over the views.  The arithmetic contract (operation order, where an fma is
+// and is not used) is stated in DESIGN.md §Arithmetic and restated by oracle/d3f_oracle.c;
+// this file is compiled with -ffp-contract=off so that a*b+c below is two roundings and
+// only fmaf() fuses.
+//
+// Work decomposition (wave = 64 lanes, 256-thread workgroups, no MFMA: this is gather work)
+//   phase A  one LANE per point: projection, depth test, weights for all V views; 'dist' and
+//            'valid_mask' leave coalesced; the per-(point,view) record {gx,gy,wgt,valid}
+//            goes to LDS (16 B, one ds_write_b128).
+//   phase B  per channel map, a GROUP of 2^k lanes per point walks the channel vectors of the
+//            four bilinear corners (16-byte loads, consecutive lanes = consecutive channels, so
+//            every texel is fetched as whole 64-B..1-KiB coalesced segments), accumulates the
+//            V views in registers in view order and stores the fused row once.
+// Nothing of size [V,N,C] ever exists and N is not chunked.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "d3f_internal.h"
+
+namespace d3f {
+
+// ---- per-(point,view) arithmetic: identical, operation for operation, to the oracle -----
+
+struct ViewRec {
+    float gx, gy;   // normalised image coordinates   (fusion.py:72-73)
+    float wgt;      // exp(clamp(mu-|dist|,max=0)/mu)  (fusion.py:347)
+    float valid;    // 1.0f / 0.0f                     (fusion.py:344)
+};
+
+__device__ __forceinline__ float unnormalize(float g, int size)
+{
+    // grid_sample(align_corners=True): ((g+1)/2)*(size-1)
+    return ((g + 1.0f) / 2.0f) * (float)(size - 1);
+}
+
+__device__ __forceinline__ bool in_bounds(float x, float y, int fw, int fh)
+{
+    return (x > -1.0f) && (x < (float)fw) && (y > -1.0f) && (y < (float)fh);
+}
+
+// ---- phase B: bilinear gather + view reduction for one map -----------------------------
+
+template <int VW> struct Vec;
+template <> struct Vec<4> { using T = float4; };
+template <> struct Vec<2> { using T = float2; };
+template <> struct Vec<1> { using T = float; };
+
+template <int VW> __device__ __forceinline__ typename Vec<VW>::T vzero();
+template <> __device__ __forceinline__ float4 vzero<4>() { return make_float4(0.f, 0.f, 0.f, 0.f); }
+template <> __device__ __forceinline__ float2 vzero<2>() { return make_float2(0.f, 0.f); }
+template <> __device__ __forceinline__ float vzero<1>() { return 0.f; }
+
+#define D3F_EW4(expr_x, expr_y, expr_z, expr_w) make_float4(expr_x, expr_y, expr_z, expr_w)
+
+__device__ __forceinline__ float4 v_mul(float4 a, float s) { return make_float4(a.x * s, a.y * s, a.z * s, a.w * s); }
+__device__ __forceinline__ float2 v_mul(float2 a, float s) { return make_float2(a.x * s, a.y * s); }
+__device__ __forceinline__ float v_mul(float a, float s) { return a * s; }
+__device__ __forceinline__ float4 v_fma(float4 a, float s, float4 c) { return make_float4(fmaf(a.x, s, c.x), fmaf(a.y, s, c.y), fmaf(a.z, s, c.z), fmaf(a.w, s, c.w)); }
+__device__ __forceinline__ float2 v_fma(float2 a, float s, float2 c) { return make_float2(fmaf(a.x, s, c.x), fmaf(a.y, s, c.y)); }
+__device__ __forceinline__ float v_fma(float a, float s, float c) { return fmaf(a, s, c); }
+__device__ __forceinline__ float4 v_add(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+__device__ __forceinline__ float2 v_add(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ float v_add(float a, float b) { return a + b; }
+__device__ __forceinline__ float4 v_div(float4 a, float s) { return make_float4(a.x / s, a.y / s, a.z / s, a.w / s); }
+__device__ __forceinline__ float2 v_div(float2 a, float s) { return make_float2(a.x / s, a.y / s); }
+__device__ __forceinline__ float v_div(float a, float s) { return a / s; }
+
+// Gathers map `m` for the points of this workgroup's tile.
+//   VW  channel-vector width in floats (4 when C%4==0 and 16-B aligned, else 2 or 1)
+//   U   channel vectors per lane per pass
+// A group of LPP = 1<<lpp_log2 lanes serves one point; lane g of the group owns channel
+// vectors  pass*LPP*U + u*LPP + g  (u < U), so one load instruction of a group covers
+// LPP*VW*4 contiguous bytes of a texel.
+template <int VW, int U>
+__device__ __forceinline__ void gather_map(const MapDesc &m, const EvalParams &P, const ViewRec *rec,
+                                           const float *cnt_s, const uint32_t *flag_s,
+                                           int64_t tile_base, int tile_n)
+{
+    using VT = typename Vec<VW>::T;
+    const int lpp = 1 << m.lpp_log2;
+    const int g = threadIdx.x & (lpp - 1);
+    const int grp = threadIdx.x >> m.lpp_log2;
+    const int ngrp = kBlock >> m.lpp_log2;
+    const int cvec = m.C / VW;
+    const int V = P.V;
+    const float *__restrict__ data = m.data;
+
+    for (int p = grp; p < tile_n; p += ngrp) {
+        const int64_t i = tile_base + p;
+        const float cnt = cnt_s[p];
+        const bool all_invalid = (cnt == 0.0f);           // fusion.py:366
+        const float denom = cnt + 1e-6f;                  // fusion.py:385
+        const bool strict = (flag_s[p] != 0u) || (m.inter != nullptr);
+        for (int c0 = 0; c0 < cvec; c0 += lpp * U) {
+            VT acc[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) acc[u] = vzero<VW>();
+            for (int v = 0; v < V; ++v) {
+                const ViewRec r = rec[p * V + v];
+                if (!strict && r.valid == 0.0f) continue;  // exact: +0 + (+-0) == +0, x + (+-0) == x
+                const float ix = unnormalize(r.gx, m.fw), iy = unnormalize(r.gy, m.fh);
+                const float x0 = floorf(ix), y0 = floorf(iy);
+                const float tx = ix - x0, ty = iy - y0;
+                const float ex = 1.0f - tx, sy = 1.0f - ty;
+                const float wnw = sy * ex, wne = sy * tx, wsw = ty * ex, wse = ty * tx;
+                const float x1 = x0 + 1.0f, y1 = y0 + 1.0f;
+                const bool inw = in_bounds(x0, y0, m.fw, m.fh), ine = in_bounds(x1, y0, m.fw, m.fh);
+                const bool isw = in_bounds(x0, y1, m.fw, m.fh), ise = in_bounds(x1, y1, m.fw, m.fh);
+                // clamp so that the (unused) address of an out-of-bounds corner stays in the map
+                const int xi0 = (inw || isw) ? (int)x0 : 0, yi0 = (inw || ine) ? (int)y0 : 0;
+                const int xi1 = (ine || ise) ? (int)x1 : 0, yi1 = (isw || ise) ? (int)y1 : 0;
+                const float *bv = data + (int64_t)v * m.sv;
+                const float *pnw = bv + (int64_t)yi0 * m.sy + (int64_t)xi0 * m.sx;
+                const float *pne = bv + (int64_t)yi0 * m.sy + (int64_t)xi1 * m.sx;
+                const float *psw = bv + (int64_t)yi1 * m.sy + (int64_t)xi0 * m.sx;
+                const float *pse = bv + (int64_t)yi1 * m.sy + (int64_t)xi1 * m.sx;
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int cv = c0 + u * lpp + g;
+                    if (cv < cvec) {
+                        const int co = cv * VW;
+                        VT a = inw ? *reinterpret_cast<const VT *>(pnw + co) : vzero<VW>();
+                        VT b = ine ? *reinterpret_cast<const VT *>(pne + co) : vzero<VW>();
+                        VT d = isw ? *reinterpret_cast<const VT *>(psw + co) : vzero<VW>();
+                        VT e = ise ? *reinterpret_cast<const VT *>(pse + co) : vzero<VW>();
+                        VT s = v_mul(a, wnw);              // ATen bilinear: fma chain nw,ne,sw,se
+                        s = v_fma(b, wne, s);
+                        s = v_fma(d, wsw, s);
+                        s = v_fma(e, wse, s);
+                        if (m.inter)                       // '<k>_inter' [V,n,C]  fusion.py:389
+                            *reinterpret_cast<VT *>(m.inter + ((int64_t)v * P.n + i) * m.C + co) = s;
+                        VT t = v_mul(v_mul(s, r.valid), r.wgt);   // fusion.py:385
+                        acc[u] = v_add(acc[u], t);
+                    }
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int cv = c0 + u * lpp + g;
+                if (cv < cvec) {
+                    VT o = all_invalid ? vzero<VW>() : v_div(acc[u], denom);   // fusion.py:385-386
+                    *reinterpret_cast<VT *>(m.out + i * m.C + (int64_t)cv * VW) = o;
+                }
+            }
+        }
+    }
+}
+
+template <int VW>
+__device__ __forceinline__ void gather_map_u(const MapDesc &m, const EvalParams &P, const ViewRec *rec,
+                                             const float *cnt_s, const uint32_t *flag_s,
+                                             int64_t tile_base, int tile_n)
+{
+    switch (m.unroll) {
+    case 1: gather_map<VW, 1>(m, P, rec, cnt_s, flag_s, tile_base, tile_n); break;
+    case 2: gather_map<VW, 2>(m, P, rec, cnt_s, flag_s, tile_base, tile_n); break;
+    case 3: gather_map<VW, 3>(m, P, rec, cnt_s, flag_s, tile_base, tile_n); break;
+    default: gather_map<VW, 4>(m, P, rec, cnt_s, flag_s, tile_base, tile_n); break;
+    }
+}
+
+// XCD-aware tile order: the dispatcher places workgroup b on XCD b%8 (observed, speed only).
+// Giving XCD k the k-th contiguous eighth of the tiles keeps the texel footprints of the
+// eight private L2s (4 MiB each) disjoint instead of replicated.  Bijective for any count.
+__device__ __forceinline__ int64_t xcd_tile(int64_t b, int64_t nb)
+{
+    const int64_t q = nb / 8, r = nb % 8, xcd = b % 8, j = b / 8;
+    const int64_t start = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return start + j;
+}
+
+// MODE 0: Fusion.eval semantics; MODE 1: Fusion.eval_dist semantics (fusion.py:396-436).
+template <int MODE>
+__global__ __launch_bounds__(kBlock) void fused_eval_kernel(const EvalParams P)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int V = P.V;
+    const int TP = P.tile_pts;
+    ViewRec *rec = reinterpret_cast<ViewRec *>(smem);                       // [TP*V]
+    float *cnt_s = reinterpret_cast<float *>(rec + (size_t)TP * V);          // [TP]
+    uint32_t *flag_s = reinterpret_cast<uint32_t *>(cnt_s + TP);             // [TP]
+    float *krt = reinterpret_cast<float *>(flag_s + TP);                     // [V*12]
+
+    // KRt = K @ pose (fusion.py:44): k-sequential, unfused, like the 3x3@3x4 bmm on the host
+    for (int t = threadIdx.x; t < V * 12; t += kBlock) {
+        const int v = t / 12, ij = t % 12, i = ij / 4, j = ij % 4;
+        const float *Kv = P.K + v * 9, *Rv = P.pose + v * 12;
+        float acc = 0.0f;
+        for (int k = 0; k < 3; ++k) {
+            const float pr = Kv[i * 3 + k] * Rv[k * 4 + j];
+            acc = acc + pr;
+        }
+        krt[t] = acc;
+    }
+    __syncthreads();
+
+    const int64_t ntiles = (P.n + TP - 1) / TP;
+    const int64_t tile = xcd_tile(blockIdx.x, ntiles);
+    const int64_t tile_base = tile * TP;
+    const int tile_n = (int)min((int64_t)TP, P.n - tile_base);
+    const float mu = P.mu;
+    const float Wm1 = (float)(P.W - 1), Hm1 = (float)(P.H - 1);
+
+    // ---------------- phase A: one lane per point ----------------
+    for (int p = threadIdx.x; p < tile_n; p += kBlock) {
+        const int64_t i = tile_base + p;
+        const float px = P.pts[i * 3 + 0], py = P.pts[i * 3 + 1], pz = P.pts[i * 3 + 2];
+        float dsum = 0.0f, cnt = 0.0f;
+        bool nonfinite = false;
+        for (int v = 0; v < V; ++v) {
+            const float *M = krt + v * 12;
+            // fusion.py:45-46: 4x4 @ 4x1, four rounded products summed left to right
+            float xc = ((M[0] * px + M[1] * py) + M[2] * pz) + M[3] * 1.0f;
+            float yc = ((M[4] * px + M[5] * py) + M[6] * pz) + M[7] * 1.0f;
+            float zc = ((M[8] * px + M[9] * py) + M[10] * pz) + M[11] * 1.0f;
+            const bool ok = !(fabsf(zc) < 1e-4f);                           // fusion.py:52
+            if (!ok) zc = 1e-3f;                                            // fusion.py:53
+            const float uu = xc / zc, ww = yc / zc;                         // fusion.py:54
+            const float gx = uu / Wm1 * 2.0f - 1.0f;                        // fusion.py:72
+            const float gy = ww / Hm1 * 2.0f - 1.0f;                        // fusion.py:73
+            // nearest depth pixel, zeros padding (fusion.py:327-333)
+            const float rx = rintf(unnormalize(gx, P.W)), ry = rintf(unnormalize(gy, P.H));
+            float d = 0.0f;
+            if (in_bounds(rx, ry, P.W, P.H))
+                d = P.depth[((int64_t)v * P.H + (int64_t)ry) * P.W + (int64_t)rx];
+            float dist = d - zc;                                            // fusion.py:343
+            bool valid;
+            float wgt = 1.0f;
+            if (MODE == 0) {
+                valid = (d > 0.0f) && ok && (dist > -mu);                   // fusion.py:344
+                float t = mu - fabsf(dist);                                 // fusion.py:347
+                t = t > 0.0f ? 0.0f : t;
+                wgt = expf(t / mu);
+                float dc = dist < -mu ? -mu : dist;                         // fusion.py:358
+                dc = dc > mu ? mu : dc;
+                dist = dc;
+            } else {
+                valid = (d > 0.0f) && ok;                                   // fusion.py:426
+            }
+            const float vf = valid ? 1.0f : 0.0f;
+            dsum = dsum + dist * vf;                                        // fusion.py:364
+            cnt = cnt + vf;
+            if (P.n_maps > 0) {
+                nonfinite |= !(isfinite(gx) && isfinite(gy) && isfinite(wgt));
+                ViewRec r;
+                r.gx = gx; r.gy = gy; r.wgt = wgt; r.valid = vf;
+                rec[p * V + v] = r;
+            }
+        }
+        const bool all_invalid = (cnt == 0.0f);                             // fusion.py:366
+        float dist_out = dsum / (cnt + 1e-6f);
+        if (MODE == 0 && all_invalid) dist_out = 1e3f;                      // fusion.py:367
+        P.out_dist[i] = dist_out;
+        P.out_valid[i] = all_invalid ? 0 : 1;
+        if (P.n_maps > 0) {
+            cnt_s[p] = cnt;
+            flag_s[p] = (nonfinite || !(P.flags & kFlagFiniteMaps)) ? 1u : 0u;
+        }
+    }
+    if (P.n_maps == 0) return;
+    __syncthreads();
+
+    // ---------------- phase B: per map, 2^k lanes per point ----------------
+    for (int s = 0; s < P.n_maps; ++s) {
+        const MapDesc &m = P.maps[s];
+        switch (m.vw) {
+        case 4: gather_map_u<4>(m, P, rec, cnt_s, flag_s, tile_base, tile_n); break;
+        case 2: gather_map_u<2>(m, P, rec, cnt_s, flag_s, tile_base, tile_n); break;
+        default: gather_map_u<1>(m, P, rec, cnt_s, flag_s, tile_base, tile_n); break;
+        }
+    }
+}
+
+hipError_t launch_fused_eval(const EvalParams &P, int mode, hipStream_t stream)
+{
+    if (P.n == 0) return hipSuccess;
+    const int64_t ntiles = (P.n + P.tile_pts - 1) / P.tile_pts;
+    const size_t lds = (size_t)P.tile_pts * P.V * sizeof(ViewRec) + (size_t)P.tile_pts * 8 + (size_t)P.V * 48;
+    dim3 grid((unsigned)ntiles), block(kBlock);
+    if (mode == 0)
+        hipLaunchKernelGGL(fused_eval_kernel<0>, grid, block, lds, stream, P);
+    else
+        hipLaunchKernelGGL(fused_eval_kernel<1>, grid, block, lds, stream, P);
+    return hipGetLastError();
+}
+
+}  // namespace d3f

@@ -1,0 +1,280 @@
+"""`Fusion` -- drop-in for the query surface of the reference's ``class Fusion`` (fusion.py:202).
+
+Same method names, argument defaults, dict keys, shapes and dtypes as the reference for
+``update / eval / eval_dist / batch_eval / text_queries_for_inst_mask[_no_track]``; the field
+query itself runs as one HIP launch through libd3fields_hip.so (include/d3fields_hip.h)
+instead of ~20 torch ops.  The 2-D producers (DINOv2, Grounded-SAM, XMem: reference
+fusion.py:223-303) are upstream PyTorch-ROCm models and are *injected* as callables; this
+module never downloads or builds them.
+
+There is no CPU or torch-op fallback: query points must live on the ROCm device and the
+shared library must load, otherwise an exception is raised.
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib
+
+__all__ = ["Fusion", "create_init_grid", "instance2onehot", "onehot2instance"]
+
+_RESERVED = ("depth", "pose", "K", "color")
+
+
+# ----------------------------------------------------------------------------------------
+# grid / mask-format helpers (reference fusion.py:79-116)
+# ----------------------------------------------------------------------------------------
+def create_init_grid(boundaries, step_size):
+    """Voxel-centre grid, z fastest; returns (coords [N,3] float32, (nx,ny,nz)).
+
+    Same values and order as the reference helper (fusion.py:79-88): per-axis
+    ``arange(lower, upper, step) + step/2`` in float32, 'ij' ordering.
+    """
+    axes = []
+    for ax in "xyz":
+        lo, hi = boundaries[ax + "_lower"], boundaries[ax + "_upper"]
+        axes.append(torch.arange(lo, hi, step_size, dtype=torch.float32) + step_size / 2)
+    coords = torch.cartesian_prod(*axes)
+    shape = torch.Size([a.numel() for a in axes])
+    return coords, shape
+
+
+def _as_device_tensor(x, dtype, device):
+    if isinstance(x, np.ndarray):
+        x = torch.from_numpy(x)
+    return x.to(device=device, dtype=dtype)
+
+
+def instance2onehot(instance, N=None):
+    """uint8 instance index -> bool one-hot [..., N] (reference fusion.py:90-107).
+
+    numpy in -> numpy out (host data is tiny here); CUDA tensor in -> HIP kernel.
+    """
+    if N is None:
+        N = int(instance.max()) + 1
+    if isinstance(instance, np.ndarray):
+        assert instance.dtype == np.uint8
+        return instance[..., None] == np.arange(N, dtype=np.uint8)
+    if isinstance(instance, torch.Tensor):
+        assert instance.dtype == torch.uint8
+        if not instance.is_cuda:
+            raise RuntimeError("instance2onehot: torch input must be on the ROCm device (no CPU path)")
+        inst = instance.contiguous()
+        out = torch.empty(inst.shape + (N,), dtype=torch.bool, device=inst.device)
+        with torch.cuda.device(inst.device):
+            _lib.check(_lib.load().d3f_instance2onehot(_lib.ptr(inst), inst.numel(), N, _lib.ptr(out),
+                                                       _lib.current_stream_handle(inst.device)))
+        return out
+    raise NotImplementedError
+
+
+def onehot2instance(one_hot_mask):
+    """[..., N] float/bool (probabilistic or not) -> uint8 argmax (reference fusion.py:109-116)."""
+    if isinstance(one_hot_mask, np.ndarray):
+        return np.argmax(one_hot_mask, axis=-1).astype(np.uint8)
+    if isinstance(one_hot_mask, torch.Tensor):
+        if not one_hot_mask.is_cuda:
+            raise RuntimeError("onehot2instance: torch input must be on the ROCm device (no CPU path)")
+        oh = one_hot_mask.to(torch.float32).contiguous()
+        NI = oh.shape[-1]
+        out = torch.empty(oh.shape[:-1], dtype=torch.uint8, device=oh.device)
+        with torch.cuda.device(oh.device):
+            _lib.check(_lib.load().d3f_onehot2instance(_lib.ptr(oh), out.numel(), NI, _lib.ptr(out),
+                                                       _lib.current_stream_handle(oh.device)))
+        return out
+    raise NotImplementedError
+
+
+# ----------------------------------------------------------------------------------------
+class Fusion:
+    """Multi-view 3-D descriptor field (query side).
+
+    Parameters mirror the reference constructor (fusion.py:203); the keyword-only arguments
+    inject the upstream producers the reference hard-wires:
+
+    feature_extractor(color[V,H,W,3] uint8 ndarray, params{'patch_h','patch_w'}) -> (V,ph,pw,C) tensor
+        stands in for extract_features / DINOv2 (fusion.py:593-629)
+    mask_producer(fusion, queries, thresholds, **kw) -> (V,H,W) uint8 labels or (V,H,W,NI) one-hot
+        stands in for Grounded-SAM + instance association (fusion.py:1112-1171)
+    mask_tracker(fusion, queries, thresholds, **kw) -> same; stands in for XMem (fusion.py:1173-1256)
+    """
+
+    def __init__(self, num_cam, feat_backbone="dinov2", device="cuda:0", dtype=torch.float32, *,
+                 feature_extractor=None, mask_producer=None, mask_tracker=None):
+        if dtype != torch.float32:
+            raise NotImplementedError("the HIP field query is fp32 (parity contract); got %s" % dtype)
+        self.device = torch.device(device)
+        self.dtype = dtype
+        self.mu = 0.02                          # reference fusion.py:208
+        self.curr_obs_torch = {}
+        self.H = -1
+        self.W = -1
+        self.num_cam = num_cam
+        self.feat_backbone = feat_backbone
+        self.feature_extractor = feature_extractor
+        self.mask_producer = mask_producer
+        self.mask_tracker = mask_tracker
+        self.track_ids = [0]
+        self._finite_cache = {}
+        self._lib = _lib.load()                 # fail at construction if the HIP library is missing
+
+    # ---- observation state (reference fusion.py:686-714) --------------------------------
+    def update(self, obs):
+        """obs: 'color' (V,H,W,3) uint8, 'depth' (V,H,W), 'pose' (V,3,4), 'K' (V,3,3) numpy arrays.
+
+        Optional extension: obs['dino_feats'] (V,ph,pw,C) supplies precomputed features when no
+        feature_extractor was injected.
+        """
+        color = obs["color"]
+        self.num_cam = color.shape[0]
+        if self.feature_extractor is not None:
+            params = {"patch_h": color.shape[1] // 10, "patch_w": color.shape[2] // 10}
+            self.curr_obs_torch["dino_feats"] = _as_device_tensor(
+                self.feature_extractor(color, params), self.dtype, self.device)
+        elif "dino_feats" in obs:
+            self.curr_obs_torch["dino_feats"] = _as_device_tensor(obs["dino_feats"], self.dtype, self.device)
+        self.curr_obs_torch["color"] = color
+        self.curr_obs_torch["color_tensor"] = _as_device_tensor(color, self.dtype, self.device) / 255.0
+        for k in ("depth", "pose", "K"):
+            self.curr_obs_torch[k] = _as_device_tensor(obs[k], self.dtype, self.device)
+        _, self.H, self.W = obs["depth"].shape
+        self._finite_cache.clear()
+
+    # ---- the hot path ---------------------------------------------------------------------
+    def _check_query(self, pts):
+        if len(self.curr_obs_torch) == 0:
+            # the reference prints this and calls exit() (fusion.py:313-317); a library raises
+            raise RuntimeError("Please call update() first!")
+        assert type(pts) == torch.Tensor
+        assert len(pts.shape) == 2
+        assert pts.shape[1] == 3
+        if not pts.is_cuda:
+            raise RuntimeError("Fusion.eval: pts must be on the ROCm device (%s); there is no CPU path" % self.device)
+        if pts.requires_grad and torch.is_grad_enabled():
+            raise NotImplementedError("autograd through Fusion.eval (rigid_tracking) is not built yet; "
+                                      "wrap the call in torch.no_grad() or detach pts")
+        if pts.dtype != torch.float32:
+            raise TypeError("Fusion.eval: pts must be float32, got %s" % pts.dtype)
+
+    def _views(self, dev):
+        obs = self.curr_obs_torch
+        depth, K, pose = obs["depth"], obs["K"], obs["pose"]
+        for name, t in (("depth", depth), ("K", K), ("pose", pose)):
+            if t.device != dev or t.dtype != torch.float32:
+                raise RuntimeError("curr_obs_torch[%r] must be float32 on %s (is %s on %s)" % (name, dev, t.dtype, t.device))
+        V = depth.shape[0]
+        if tuple(depth.shape[1:]) != (self.H, self.W):
+            raise RuntimeError("depth is %s but Fusion.H,W = %d,%d" % (tuple(depth.shape), self.H, self.W))
+        pose34 = pose[:, :3, :]                 # the docstring of the reference says (K,4,4); its drivers pass (K,3,4)
+        keep = [depth.contiguous(), K.contiguous(), pose34.contiguous()]
+        return _lib.Views(V, self.H, self.W, _lib.ptr(keep[0]), _lib.ptr(keep[1]), _lib.ptr(keep[2])), keep, V
+
+    def _is_finite(self, key, t):
+        """Cached torch.isfinite(t).all(): lets the kernel skip invalid views exactly (D3F_FLAG_FINITE_MAPS)."""
+        sig = (t.data_ptr(), t._version, tuple(t.shape))
+        hit = self._finite_cache.get(key)
+        if hit is None or hit[0] != sig:
+            hit = (sig, bool(torch.isfinite(t).all().item()))
+            self._finite_cache[key] = hit
+        return hit[1]
+
+    def _run(self, pts, return_names, return_inter, mode):
+        self._check_query(pts)
+        dev = pts.device
+        lib = self._lib
+        n = pts.shape[0]
+        pts_c = pts.detach().contiguous()
+        views, keep, V = self._views(dev)
+        dist = torch.empty(n, dtype=torch.float32, device=dev)
+        valid = torch.empty(n, dtype=torch.bool, device=dev)
+        outputs = {"dist": dist, "valid_mask": valid}
+        with torch.cuda.device(dev):
+            stream = _lib.current_stream_handle(dev)
+            if mode == "eval_dist":
+                _lib.check(lib.d3f_eval_dist(ctypes.byref(views), _lib.ptr(pts_c), n, _lib.ptr(dist), _lib.ptr(valid), stream))
+                return outputs
+            names = list(return_names)
+            if len(names) > _lib.MAX_MAPS:
+                raise ValueError("at most %d return_names per call" % _lib.MAX_MAPS)
+            maps = (_lib.ChannelMap * max(len(names), 1))()
+            fused = (ctypes.c_void_p * max(len(names), 1))()
+            inter = (ctypes.c_void_p * max(len(names), 1))()
+            finite = self._is_finite("depth", keep[0])
+            for s, k in enumerate(names):
+                m = self.curr_obs_torch[k]                 # KeyError for unknown names, like the reference
+                if not isinstance(m, torch.Tensor) or m.dim() != 4 or m.shape[0] != V:
+                    raise ValueError("curr_obs_torch[%r] must be a (V,h,w,C) tensor" % k)
+                if m.device != dev or m.dtype != torch.float32:
+                    raise RuntimeError("curr_obs_torch[%r] must be float32 on %s" % (k, dev))
+                if m.stride(3) != 1:
+                    m = m.contiguous()
+                    keep.append(m)
+                finite = finite and self._is_finite(k, m)
+                C = m.shape[3]
+                o = torch.empty((n, C), dtype=torch.float32, device=dev)
+                outputs[k] = o
+                maps[s] = _lib.ChannelMap(m.data_ptr(), m.shape[1], m.shape[2], C, _lib.DTYPE_F32,
+                                          m.stride(0), m.stride(1), m.stride(2))
+                fused[s] = o.data_ptr()
+                if return_inter:
+                    it = torch.empty((V, n, C), dtype=torch.float32, device=dev)
+                    outputs[k + "_inter"] = it
+                    inter[s] = it.data_ptr()
+            flags = _lib.FLAG_FINITE_MAPS if finite else 0
+            _lib.check(lib.d3f_eval(ctypes.byref(views), _lib.ptr(pts_c), n, maps, len(names), self.mu, flags,
+                                    _lib.ptr(dist), _lib.ptr(valid), fused, inter if return_inter else None, stream))
+        return outputs
+
+    def eval(self, pts, return_names=["dino_feats", "mask"], return_inter=False):
+        """Reference Fusion.eval (fusion.py:305-394).
+
+        pts (N,3) float32 in the world frame.  Returns 'dist' (N), 'valid_mask' (N) bool and, per
+        name in return_names, the fused (N,C) channels; with return_inter also '<name>_inter' (V,N,C).
+        """
+        return self._run(pts, return_names, return_inter, "eval")
+
+    def eval_dist(self, pts):
+        """Reference Fusion.eval_dist (fusion.py:396-436): unclamped mean signed distance."""
+        return self._run(pts, (), False, "eval_dist")
+
+    def batch_eval(self, pts, return_names=["dino_feats", "mask"]):
+        """Reference Fusion.batch_eval (fusion.py:526-545).
+
+        The reference walks 60 000-point chunks only to bound its [V,N,C] temporaries; the fused
+        kernel has none, so the whole batch is one launch with the same concatenated result.
+        """
+        return self._run(pts, return_names, False, "eval")
+
+    # ---- instance masks: upstream producers (reference fusion.py:1112-1256) ----------------
+    def _store_mask(self, produced):
+        m = produced
+        if isinstance(m, np.ndarray):
+            m = torch.from_numpy(m)
+        m = m.to(self.device)
+        if m.dim() == 3:                                           # (V,H,W) uint8 labels
+            label = m.to(torch.uint8)
+            NI = int(label.max().item()) + 1
+            onehot = instance2onehot(label.contiguous(), NI).to(self.dtype)
+        else:                                                      # (V,H,W,NI) one-hot / probabilities
+            onehot = m.to(self.dtype)
+            label = onehot2instance(onehot)
+        self.curr_obs_torch["mask_label"] = label
+        self.curr_obs_torch["mask"] = onehot.contiguous()
+        self._finite_cache.pop("mask", None)
+
+    def text_queries_for_inst_mask_no_track(self, queries, thresholds, boundaries=None, **kwargs):
+        """Reference fusion.py:1112-1171; the Grounded-SAM + multi-view association stage is injected."""
+        if self.mask_producer is None:
+            raise RuntimeError("no mask_producer was injected (Grounded-SAM is an upstream PyTorch-ROCm producer)")
+        self._store_mask(self.mask_producer(self, queries, thresholds, boundaries=boundaries, **kwargs))
+
+    def text_queries_for_inst_mask(self, queries, thresholds, boundaries=None, **kwargs):
+        """Reference fusion.py:1173-1256: first call segments, later calls track (XMem), both injected."""
+        if len(self.curr_obs_torch) == 0:
+            raise RuntimeError("Please call update() first!")
+        first = "mask" not in self.curr_obs_torch
+        producer = self.mask_producer if (first or self.mask_tracker is None) else self.mask_tracker
+        if producer is None:
+            raise RuntimeError("no mask_producer / mask_tracker was injected")
+        self._store_mask(producer(self, queries, thresholds, boundaries=boundaries, **kwargs))

@@ -1,0 +1,119 @@
+"""Multi-GPU sharding of the field query: one process per GPU, torch.distributed over RCCL/xGMI.
+
+Query points are independent (no cross-point term in fusion.py:305-394), so a batch is split
+into contiguous blocks, one per rank, evaluated by the single-GPU HIP kernel against
+*replicated* maps, and the field is reassembled with ONE all-gather per output tensor.  There is
+no other collective on the path.  The reference is single-GPU (fusion.py:203), so the only
+parity statement is: gathered results == single-GPU results, bit for bit (same kernel, same
+per-point arithmetic) -- tests/test_sharding_gloo.py checks the plumbing with world_size 2.
+
+Cost note: gathering the full [N,C] field moves (P-1)/P * N*C*4 bytes into
+every GPU and dwarfs the query itself; consumers that only need the distance volume (marching
+cubes, fusion.py:1313-1330) should gather keys=('dist','valid_mask') and leave features sharded.
+"""
+import torch
+import torch.distributed as dist
+
+__all__ = ["shard_bounds", "shard_points", "all_gather_field", "sharded_eval", "broadcast_observation"]
+
+
+def _world(group=None):
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(group), dist.get_world_size(group)
+    return 0, 1
+
+
+def shard_bounds(n, rank, world):
+    """Contiguous block [lo, hi) of rank `rank`; the first n % world ranks get one extra point."""
+    base, rem = divmod(n, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def shard_points(pts, rank=None, world=None, group=None):
+    r, w = _world(group)
+    rank = r if rank is None else rank
+    world = w if world is None else world
+    lo, hi = shard_bounds(pts.shape[0], rank, world)
+    return pts[lo:hi]
+
+
+def _gather_rows(t, counts, group):
+    """all-gather along dim 0 of per-rank tensors whose dim-0 sizes are `counts` (ragged allowed)."""
+    world = len(counts)
+    as_bool = t.dtype == torch.bool
+    x = t.view(torch.uint8) if as_bool else t
+    x = x.contiguous()
+    if len(set(counts)) == 1:
+        out = x.new_empty((world * counts[0],) + tuple(x.shape[1:]))
+        dist.all_gather_into_tensor(out, x, group=group)
+    else:
+        cap = max(counts)
+        pad = x.new_zeros((cap,) + tuple(x.shape[1:]))
+        pad[:x.shape[0]] = x
+        buf = x.new_empty((world * cap,) + tuple(x.shape[1:]))
+        dist.all_gather_into_tensor(buf, pad, group=group)
+        out = torch.cat([buf[r * cap:r * cap + c] for r, c in enumerate(counts)], dim=0)
+    return out.view(torch.bool) if as_bool else out
+
+
+def all_gather_field(local_out, keys=None, counts=None, group=None):
+    """Reassembles per-rank eval outputs into the full field on every rank.
+
+    local_out: dict from Fusion.eval on this rank's shard.  keys: which entries to gather
+    (default all).  '<k>_inter' entries ([V,n,C]) are gathered along their point axis.
+    counts: per-rank shard sizes if already known (saves a tiny all-gather).
+    """
+    rank, world = _world(group)
+    if world == 1:
+        return dict(local_out) if keys is None else {k: local_out[k] for k in keys}
+    keys = list(local_out.keys()) if keys is None else list(keys)
+    if counts is None:
+        n_local = local_out["dist"].shape[0]
+        c = torch.tensor([n_local], dtype=torch.int64, device=local_out["dist"].device)
+        allc = torch.empty(world, dtype=torch.int64, device=c.device)
+        dist.all_gather_into_tensor(allc, c, group=group)
+        counts = [int(v) for v in allc.tolist()]
+    full = {}
+    for k in keys:
+        t = local_out[k]
+        if k.endswith("_inter"):
+            full[k] = _gather_rows(t.transpose(0, 1), counts, group).transpose(0, 1).contiguous()
+        else:
+            full[k] = _gather_rows(t, counts, group)
+    return full
+
+
+def sharded_eval(fusion, pts, return_names=("dino_feats", "mask"), gather_keys=None, group=None, evaluator=None):
+    """Evaluates the FULL batch `pts` (same tensor on every rank) cooperatively.
+
+    Every rank queries its contiguous block with the HIP kernel (fusion.batch_eval) and the
+    requested keys are all-gathered; keys not gathered are returned as this rank's shard under
+    '<key>_local' together with 'local_range'.  `evaluator` replaces fusion.batch_eval in the
+    CPU plumbing tests (gloo), where no GPU exists.
+    """
+    rank, world = _world(group)
+    n = pts.shape[0]
+    lo, hi = shard_bounds(n, rank, world)
+    run = evaluator if evaluator is not None else (lambda p, names: fusion.batch_eval(p, return_names=list(names)))
+    local = run(pts[lo:hi], return_names)
+    counts = [shard_bounds(n, r, world)[1] - shard_bounds(n, r, world)[0] for r in range(world)]
+    keys = list(local.keys()) if gather_keys is None else list(gather_keys)
+    out = all_gather_field(local, keys=keys, counts=counts, group=group)
+    for k, v in local.items():
+        if k not in out:
+            out[k + "_local"] = v
+    out["local_range"] = (lo, hi)
+    return out
+
+
+def broadcast_observation(fusion, src=0, group=None):
+    """Replicates rank `src`'s curr_obs_torch tensors (maps, depth, K, pose) to every rank: the
+    once-per-update setup cost of the sharded mode."""
+    rank, world = _world(group)
+    if world == 1:
+        return
+    for k in sorted(fusion.curr_obs_torch.keys()):
+        t = fusion.curr_obs_torch[k]
+        if isinstance(t, torch.Tensor):
+            dist.broadcast(t, src=src, group=group)

@@ -1,0 +1,139 @@
+/*
+ * d3fields_hip.h -- C ABI of libd3fields_hip.so (MI355X / gfx950).
+ *
+ * The reference (WangYixuan12/d3fields) has no native/FFI layer: its hot path is the Python
+ * method surface of `class Fusion` (fusion.py:202) plus utils/corr_utils.py, executed as
+ * torch ops.  This header is the boundary a maintainer binds instead of those torch ops;
+ * each entry point names the reference lines it replaces.  INTEGRATION.md shows the ctypes
+ * stub that goes into fusion.py.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer on the device the stream belongs to, unless noted;
+ *   - the library never allocates, frees or retains caller memory and keeps no state between
+ *     calls (re-entrant); work is enqueued on `stream` (a hipStream_t, NULL = default
+ *     stream) and NOT synchronised;
+ *   - all tensors fp32, C-contiguous unless strides are part of the signature;
+ *   - return value: D3F_OK or a negative D3F_ERR_* code; d3f_last_error() gives the text of
+ *     the calling thread's last failure.  Nothing aborts.
+ */
+#ifndef D3FIELDS_HIP_H
+#define D3FIELDS_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define D3F_ABI_VERSION 1
+
+#define D3F_OK 0
+#define D3F_ERR_INVALID_ARG (-1)  /* null pointer, negative count, bad enum               */
+#define D3F_ERR_BAD_SHAPE (-2)    /* V/H/W/C/fh/fw outside the supported range             */
+#define D3F_ERR_BAD_DTYPE (-3)    /* channel map dtype other than D3F_DTYPE_F32            */
+#define D3F_ERR_BAD_LAYOUT (-4)   /* stride/alignment the kernels cannot address           */
+#define D3F_ERR_HIP (-5)          /* a HIP runtime call or kernel launch failed            */
+#define D3F_ERR_WORKSPACE (-6)    /* workspace missing or too small                        */
+
+#define D3F_MAX_VIEWS 64
+#define D3F_MAX_MAPS 8
+
+#define D3F_DTYPE_F32 0
+
+/* d3f_eval flags */
+#define D3F_FLAG_FINITE_MAPS 1u /* caller has verified that depth and every channel map hold   \
+                                   only finite values: views that are invalid for a point are \
+                                   then skipped instead of multiplied by 0 (identical results; \
+                                   without the flag 0*NaN / 0*Inf propagate as in the          \
+                                   reference, fusion.py:385).                                  */
+
+/* Calibrated views: the part of Fusion.curr_obs_torch read by every query
+ * (fusion.py:210-215, 707-712): 'depth' (V,H,W), 'K' (V,3,3), 'pose' (V,3,4) world->camera. */
+typedef struct d3f_views {
+    int32_t V, H, W;
+    const float *depth; /* [V,H,W]                                                     */
+    const float *K;     /* [V,3,3]                                                     */
+    const float *pose;  /* [V,3,4]                                                     */
+} d3f_views;
+
+/* One channels-last per-view map: curr_obs_torch['dino_feats'|'mask'|'color_tensor'|...]
+ * (fusion.py:373 passes these as .permute(0,3,1,2) views; here the channels-last storage is
+ * addressed directly).  Element (v,y,x,c) lives at data[v*stride_v + y*stride_y + x*stride_x + c]
+ * (strides in ELEMENTS; the channel stride must be 1). */
+typedef struct d3f_channel_map {
+    const void *data;
+    int32_t fh, fw, C;
+    int32_t dtype; /* D3F_DTYPE_F32 */
+    int64_t stride_v, stride_y, stride_x;
+} d3f_channel_map;
+
+/* ---- library ---------------------------------------------------------------------- */
+int d3f_abi_version(void);
+const char *d3f_version(void);    /* "d3fields-hip <semver> gfx950" (host memory)          */
+const char *d3f_last_error(void); /* host memory, valid until the thread's next failure    */
+
+/* ---- fused field query --------------------------------------------------------------
+ * Replaces Fusion.eval (fusion.py:305-394) together with project_points_coords
+ * (fusion.py:32-55) and interpolate_feats (fusion.py:57-77); one launch covers any N, so it
+ * also replaces the 60 000-point chunk loop + torch.cat of Fusion.batch_eval (fusion.py:526-545).
+ *   pts        [n,3]
+ *   maps       n_maps descriptors (host array), one per entry of `return_names`
+ *   out_dist   [n]      'dist'        out_valid [n] (0/1 bytes) 'valid_mask'
+ *   out_fused  host array of n_maps device pointers, [n,C_k] each
+ *   out_inter  NULL, or host array of n_maps device pointers (entries may be NULL),
+ *              [V,n,C_k] each: the reference's '<k>_inter' (return_inter=True, fusion.py:389)
+ */
+int d3f_eval(const d3f_views *views, const float *pts, int64_t n, const d3f_channel_map *maps,
+             int32_t n_maps, float mu, uint32_t flags, float *out_dist, uint8_t *out_valid,
+             float *const *out_fused, float *const *out_inter, void *stream);
+
+/* Replaces Fusion.eval_dist (fusion.py:396-436): no -mu gate, no clamp, no 1e3 sentinel. */
+int d3f_eval_dist(const d3f_views *views, const float *pts, int64_t n, float *out_dist,
+                  uint8_t *out_valid, void *stream);
+
+/* ---- instance-mask helpers ----------------------------------------------------------
+ * onehot2instance (fusion.py:109-116): argmax over the last dim -> uint8 (first max wins,
+ * NaN counts as maximum, like torch.argmax).  instance2onehot (fusion.py:90-107). */
+int d3f_onehot2instance(const float *onehot, int64_t n, int32_t NI, uint8_t *out, void *stream);
+int d3f_instance2onehot(const uint8_t *instance, int64_t n, int32_t NI, uint8_t *out_bool,
+                        void *stream);
+
+/* ---- descriptor similarity (utils/corr_utils.py) --------------------------------------- */
+#define D3F_DIST_L2 0     /* dist_type='l2'     : sqrt(sum (a-b)^2)                        */
+#define D3F_DIST_SQUARE 1 /* dist_type='square' : sum (a-b)^2                              */
+
+#define D3F_SIM_DIST 0         /* raw distance            compute_dist_tensor  corr_utils.py:44-61 */
+#define D3F_SIM_EXP 1          /* exp(-d*scale)           compute_similarity   corr_utils.py:4-19  */
+#define D3F_SIM_SOFTMAX_DIM0 2 /* softmax(-d*scale,dim=0) compute_similarity_tensor :21-42,
+                                                          compute_similarity_tensor_multi :63-106 */
+
+/* Device scratch needed by the D3F_SIM_SOFTMAX_DIM0 mode (and by argmax_out) for a
+ * [rows, cols] result: per-column running max / sum-exp / argmax of each 256-row chunk. */
+int64_t d3f_softmax_workspace_bytes(int64_t rows, int64_t cols);
+
+/* Feature map vs ONE target descriptor.  src holds B*inner descriptors of C channels:
+ * descriptor (b,j) channel c at src[b*stride_b + j*stride_i + c*stride_c] (elements), which
+ * covers both [B,H,W,C] (compute_similarity) and [B,C,*dim] (compute_*_tensor).
+ * out [B*inner].  D3F_SIM_SOFTMAX_DIM0 normalises over b for every j and needs
+ * workspace >= d3f_softmax_workspace_bytes(B, inner); other modes accept NULL/0. */
+int d3f_similarity_to_target(const float *src, int64_t B, int64_t inner, int32_t C,
+                             int64_t stride_b, int64_t stride_i, int64_t stride_c,
+                             const float *tgt, float scale, int32_t dist_type, int32_t mode,
+                             float *out, void *workspace, int64_t workspace_bytes, void *stream);
+
+/* compute_similarity_tensor_multi (corr_utils.py:63-106): src [B1,C], tgt [B2,C] ->
+ * out [B1,B2]; the [B1,B2,C] difference tensor of the reference (and its OOM retry,
+ * corr_utils.py:84-94) never exists.  `scale` is ignored by D3F_SIM_DIST.
+ * argmax_out: NULL or [B2] int64, the row index of the best match of each target (largest
+ * similarity == smallest distance; first wins).
+ * workspace: >= d3f_softmax_workspace_bytes(B1, B2) bytes when mode is D3F_SIM_SOFTMAX_DIM0 or
+ * argmax_out is given; only read/written inside the call. */
+int d3f_pairwise_similarity(const float *src, const float *tgt, int64_t B1, int64_t B2, int32_t C,
+                            float scale, int32_t dist_type, int32_t mode, float *out,
+                            int64_t *argmax_out, void *workspace, int64_t workspace_bytes,
+                            void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* D3FIELDS_HIP_H */

@@ -1,0 +1,339 @@
+"""GPU parity: the HIP path (through the C ABI) against the golden vectors written by the
+reference and against the CPU oracle on seeded inputs.  Run with `-m gpu` on an MI355X.
+
+Tolerances (BASELINE.json north_star): valid_mask / instance indices bit-exact; dist bit-exact
+(same IEEE operation sequence as the oracle); fused channels <= 1e-5 relative to
+max(|ref|_inf, 1) (expf implementations differ by <= 1 ulp); raw bilinear samples bit-exact.
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import SCENE_CASES, SET_NAMES, load_golden, rel_err
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    return torch.device("cuda:0")
+
+
+def make_fusion(dev, depth, K, pose, maps, H, W, mu=0.02):
+    from d3fields_amd import Fusion
+    f = Fusion(num_cam=depth.shape[0], device=str(dev))
+    f.mu = mu
+    t = lambda a: torch.as_tensor(np.asarray(a)).to(dev, torch.float32)   # noqa: E731
+    f.curr_obs_torch = {"depth": t(depth), "K": t(K), "pose": t(pose)}
+    for k, m in maps.items():
+        f.curr_obs_torch[k] = t(m) if not isinstance(m, torch.Tensor) else m.to(dev)
+    f.H, f.W = int(H), int(W)
+    return f
+
+
+def cpu(x):
+    return x.detach().cpu().numpy()
+
+
+def check_dist(got, ref, V):
+    if V <= 4:
+        assert np.array_equal(got, ref, equal_nan=True)
+    else:       # reference sum(0) order is position dependent for V > 4 (see test_oracle_golden)
+        assert rel_err(got, ref) <= TOL
+
+
+# ---------------------------------------------------------------------------------------
+@pytest.mark.parametrize("case", SCENE_CASES)
+def test_eval_vs_reference_golden(dev, case):
+    g = load_golden(case)
+    f = make_fusion(dev, g["depth"], g["K"], g["pose"], {k: g["in_" + k] for k in SET_NAMES}, g["H"], g["W"], float(g["mu"]))
+    pts = torch.from_numpy(g["pts"]).to(dev)
+    V = g["depth"].shape[0]
+    with torch.no_grad():
+        out = f.eval(pts, return_names=SET_NAMES, return_inter=True)
+        default = f.eval(pts)
+        empty = f.eval(pts, return_names=[])
+        dd = f.eval_dist(pts)
+    assert sorted(default.keys()) == ["dino_feats", "dist", "mask", "valid_mask"]
+    assert sorted(empty.keys()) == ["dist", "valid_mask"]
+    assert out["valid_mask"].dtype == torch.bool and out["dist"].dtype == torch.float32
+    assert np.array_equal(cpu(out["valid_mask"]), g["valid_mask"])
+    check_dist(cpu(out["dist"]), g["dist"], V)
+    assert np.array_equal(cpu(empty["dist"]), cpu(out["dist"]))
+    for k in SET_NAMES:
+        assert out[k].shape == g[k].shape and out[k + "_inter"].shape == g[k + "_inter"].shape
+        assert np.array_equal(cpu(out[k + "_inter"]), g[k + "_inter"]), k
+        assert rel_err(cpu(out[k]), g[k]) <= TOL, k
+    assert torch.equal(default["dino_feats"], f.eval(pts, return_names=["dino_feats"])["dino_feats"])
+    # bit-exact instance indices (fusion.py:1360,1390 apply onehot2instance to the fused mask)
+    from d3fields_amd import onehot2instance
+    assert np.array_equal(cpu(onehot2instance(out["mask"])), g["mask_instance"])
+    assert np.array_equal(cpu(dd["valid_mask"]), g["evaldist_valid_mask"])
+    check_dist(cpu(dd["dist"]), g["evaldist_dist"], V)
+
+
+def test_batch_eval_vs_reference_golden(dev):
+    from d3fields_amd import synth
+    g = load_golden("batch_eval_130001")
+    N, st = int(g["N"]), int(g["stride"])
+    f = make_fusion(dev, g["depth"], g["K"], g["pose"], {"dino_feats": g["in_dino_feats"], "mask": g["in_mask"]}, g["H"], g["W"], float(g["mu"]))
+    pts = synth.random_cloud(N, seed=int(g["cloud_seed"])).to(dev)
+    with torch.no_grad():
+        out = f.batch_eval(pts)
+        empty = f.batch_eval(pts, return_names=[])
+    assert sorted(out.keys()) == ["dino_feats", "dist", "mask", "valid_mask"]
+    assert sorted(empty.keys()) == ["dist", "valid_mask"]
+    assert out["dino_feats"].shape == (N, 2) and out["mask"].shape == (N, 3)
+    assert np.array_equal(np.packbits(cpu(out["valid_mask"])), g["valid_bits"])
+    assert np.array_equal(cpu(out["dist"])[::st], g["dist_sub"])
+    assert rel_err(cpu(out["dino_feats"])[::st], g["dino_feats_sub"]) <= TOL
+    assert rel_err(cpu(out["mask"])[::st], g["mask_sub"]) <= TOL
+    assert abs(cpu(out["dist"]).astype(np.float64).sum() - float(g["dist_sum"])) <= 1e-6 * abs(float(g["dist_sum"]))
+    assert np.allclose(cpu(out["dino_feats"]).astype(np.float64).sum(0), g["dino_feats_sum"], rtol=1e-6, atol=1e-3)
+
+
+# ---------------------------------------------------------------------------------------
+def oracle_eval(sc, pts, maps, **kw):
+    from oracle import c_oracle as O
+    return O.eval_field(sc["depth"], sc["K"], sc["pose"], pts, maps, **kw)
+
+
+@pytest.mark.parametrize("kind,V,H,W,fhw,C,N", [
+    ("smooth", 4, 480, 640, (48, 64), 384, 50000),        # BASELINE config 1 (patch-res features)
+    ("stress", 4, 480, 640, (48, 64), 384, 20000),
+    ("smooth", 4, 120, 160, (120, 160), 384, 20000),      # dense (full-res) features
+    ("smooth", 8, 72, 128, (9, 16), 1024, 6000),          # config-4 shape, scaled down
+    ("stress", 2, 64, 80, (8, 10), 100, 5000),            # C % 4 == 0, odd vector count
+    ("smooth", 3, 64, 80, (8, 10), 6, 5000),              # float2 path
+    ("smooth", 3, 64, 80, (8, 10), 7, 5000),              # scalar path
+    ("smooth", 17, 32, 40, (4, 5), 12, 3000),             # many views (smaller tiles)
+])
+def test_eval_vs_oracle_seeded(dev, kind, V, H, W, fhw, C, N):
+    from d3fields_amd import synth
+    sc = synth.make_scene(V, H, W, kind)
+    feats = synth.random_map(V, fhw[0], fhw[1], C, seed=1)
+    mask = synth.random_onehot_mask(V, H, W, 8, seed=2)
+    color = torch.rand(V, H, W, 3, generator=torch.Generator().manual_seed(4))
+    pts = synth.random_cloud(N, seed=3)
+    f = make_fusion(dev, sc["depth"], sc["K"], sc["pose"], {"dino_feats": feats, "mask": mask, "color_tensor": color}, H, W)
+    with torch.no_grad():
+        out = f.eval(pts.to(dev), return_names=SET_NAMES)
+    ref = oracle_eval(sc, pts, [feats, mask, color])
+    assert np.array_equal(cpu(out["valid_mask"]), ref["valid_mask"])
+    assert np.array_equal(cpu(out["dist"]), ref["dist"])
+    for i, k in enumerate(SET_NAMES):
+        assert rel_err(cpu(out[k]), ref["sets"][i]) <= TOL, k
+    from d3fields_amd import onehot2instance
+    from oracle import c_oracle as O
+    assert np.array_equal(cpu(onehot2instance(out["mask"])), O.onehot2instance(ref["sets"][1]))
+
+
+@pytest.mark.parametrize("N", [0, 1, 63, 255, 256, 257, 1000])
+def test_ragged_sizes(dev, N):
+    from d3fields_amd import synth
+    V, H, W = 4, 48, 64
+    sc = synth.make_scene(V, H, W, "smooth")
+    feats = synth.random_map(V, 6, 8, 20, seed=1)
+    f = make_fusion(dev, sc["depth"], sc["K"], sc["pose"], {"dino_feats": feats}, H, W)
+    pts = synth.random_cloud(N, seed=5)
+    with torch.no_grad():
+        out = f.eval(pts.to(dev), return_names=["dino_feats"], return_inter=True)
+    assert out["dist"].shape == (N,) and out["dino_feats"].shape == (N, 20) and out["dino_feats_inter"].shape == (V, N, 20)
+    if N:
+        ref = oracle_eval(sc, pts, [feats], return_inter=True)
+        assert np.array_equal(cpu(out["dist"]), ref["dist"])
+        assert np.array_equal(cpu(out["dino_feats_inter"]), ref["inter"][0])
+        assert rel_err(cpu(out["dino_feats"]), ref["sets"][0]) <= TOL
+
+
+def test_nonfinite_maps_propagate_like_reference(dev):
+    """0*NaN through an invalid view must reach the output (fusion.py:385) -- i.e. the
+    invalid-view skip is only taken when the maps were verified finite."""
+    from d3fields_amd import synth
+    V, H, W = 3, 48, 64
+    sc = synth.make_scene(V, H, W, "stress")
+    feats = synth.random_map(V, 12, 16, 8, seed=1)
+    feats[1, 3:9, 4:12, 2] = float("nan")
+    feats[2, 0:4, 0:5, 5] = float("inf")
+    pts = synth.random_cloud(6000, seed=3)
+    f = make_fusion(dev, sc["depth"], sc["K"], sc["pose"], {"dino_feats": feats}, H, W)
+    with torch.no_grad():
+        out = f.eval(pts.to(dev), return_names=["dino_feats"])
+    ref = oracle_eval(sc, pts, [feats])
+    got, want = cpu(out["dino_feats"]), ref["sets"][0]
+    assert np.isnan(want).any()
+    assert np.array_equal(np.isnan(got), np.isnan(want))
+    ok = ~np.isnan(want)
+    assert rel_err(got[ok], want[ok]) <= TOL
+    # and with finite maps the skip changes nothing
+    feats2 = torch.nan_to_num(feats, nan=0.5, posinf=1.0)
+    f2 = make_fusion(dev, sc["depth"], sc["K"], sc["pose"], {"dino_feats": feats2}, H, W)
+    with torch.no_grad():
+        o2 = f2.eval(pts.to(dev), return_names=["dino_feats"])
+    assert rel_err(cpu(o2["dino_feats"]), oracle_eval(sc, pts, [feats2])["sets"][0]) <= TOL
+
+
+def test_nonfinite_points(dev):
+    from d3fields_amd import synth
+    V, H, W = 3, 48, 64
+    sc = synth.make_scene(V, H, W, "smooth")
+    feats = synth.random_map(V, 12, 16, 8, seed=1)
+    pts = synth.random_cloud(600, seed=3)
+    pts[5, 0] = float("nan")
+    pts[77] = float("inf")
+    pts[300, 2] = 1e30
+    f = make_fusion(dev, sc["depth"], sc["K"], sc["pose"], {"dino_feats": feats}, H, W)
+    with torch.no_grad():
+        out = f.eval(pts.to(dev), return_names=["dino_feats"])
+    ref = oracle_eval(sc, pts, [feats])
+    assert np.array_equal(cpu(out["valid_mask"]), ref["valid_mask"])
+    assert np.array_equal(cpu(out["dist"]), ref["dist"], equal_nan=True)
+    got, want = cpu(out["dino_feats"]), ref["sets"][0]
+    assert np.array_equal(np.isnan(got), np.isnan(want))
+    assert rel_err(got[~np.isnan(want)], want[~np.isnan(want)]) <= TOL
+
+
+def test_strided_and_offset_maps(dev):
+    """Maps that are views (channel slice, cropped rows) are addressed through their strides."""
+    from d3fields_amd import synth
+    V, H, W = 4, 48, 64
+    sc = synth.make_scene(V, H, W, "smooth")
+    big = synth.random_map(V, 14, 18, 24, seed=1).to(dev)
+    view = big[:, 1:13, 2:18, 4:16]                       # (V,12,16,12), stride_x 24, 16-B aligned offset
+    odd = big[:, :, :, 1:10]                              # C = 9, misaligned -> scalar path
+    f = make_fusion(dev, sc["depth"], sc["K"], sc["pose"], {}, H, W)
+    f.curr_obs_torch["a"] = view
+    f.curr_obs_torch["b"] = odd
+    pts = synth.random_cloud(4000, seed=3)
+    with torch.no_grad():
+        out = f.eval(pts.to(dev), return_names=["a", "b"])
+    ref = oracle_eval(sc, pts, [cpu(view), cpu(odd)])
+    assert rel_err(cpu(out["a"]), ref["sets"][0]) <= TOL
+    assert rel_err(cpu(out["b"]), ref["sets"][1]) <= TOL
+
+
+# ---------------------------------------------------------------------------------------
+# Full BASELINE sizes: size-independent properties (the oracle would take minutes there)
+# ---------------------------------------------------------------------------------------
+@pytest.mark.parametrize("N,C,fhw", [(985600, 384, (48, 64)), (1925000, 384, (48, 64)), (500000, 384, (480, 640))])
+def test_full_size_properties(dev, N, C, fhw):
+    from d3fields_amd import synth, create_init_grid
+    V, H, W = 4, 480, 640
+    sc = synth.make_scene(V, H, W, "smooth")
+    feats = synth.random_map(V, fhw[0], fhw[1], C, seed=1, device=dev)
+    mask = synth.random_onehot_mask(V, H, W, 8, seed=2, device=dev)
+    f = make_fusion(dev, sc["depth"], sc["K"], sc["pose"], {"dino_feats": feats, "mask": mask}, H, W)
+    step = {985600: 0.005, 1925000: 0.004}.get(N)
+    pts = (create_init_grid(synth.WORK_BOX, step)[0] if step else synth.random_cloud(N, seed=3)).to(dev)
+    assert pts.shape[0] == N
+    with torch.no_grad():
+        out = f.batch_eval(pts)
+        # (1) permutation equivariance, bit-exact: points are independent
+        perm = torch.randperm(N, generator=torch.Generator().manual_seed(9)).to(dev)
+        sub = perm[:200000]
+        o2 = f.eval(pts[sub])
+        for k in ("dist", "valid_mask", "dino_feats", "mask"):
+            assert torch.equal(o2[k], out[k][sub]), k
+        # (2) chunk invariance == batch_eval semantics (60 000-point chunks, ragged tail)
+        lo = N - 150001
+        parts = [f.eval(pts[i:min(i + 60000, N)]) for i in range(lo, N, 60000)]
+        for k in ("dist", "dino_feats"):
+            assert torch.equal(torch.cat([p[k] for p in parts]), out[k][lo:]), k
+        # (3) sentinel / validity coupling (fusion.py:366-370,386)
+        inv = ~out["valid_mask"]
+        assert torch.equal(out["dist"] == 1e3, inv)
+        assert (out["dino_feats"][inv] == 0).all() and (out["mask"][inv] == 0).all()
+        assert (out["dist"][~inv].abs() <= f.mu).all()
+        # (4) one-hot mask channels are convex weights: 0 <= sum_c mask <= 1 (weights <= 1, /count)
+        ms = out["mask"].sum(1)
+        assert (ms >= 0).all() and (ms <= 1 + 1e-5).all()
+        # (5) linearity in the map: eval(2*F + 1) == 2*eval(F) + eval(1)
+        f.curr_obs_torch["lin"] = feats[..., :64] * 2.0 + 1.0
+        f.curr_obs_torch["one"] = torch.ones_like(feats[..., :4])
+        f.curr_obs_torch["f64"] = feats[..., :64].contiguous()
+        o3 = f.eval(pts[sub], return_names=["lin", "one", "f64"])
+        want = 2.0 * o3["f64"] + o3["one"][:, :1]
+        assert (o3["lin"] - want).abs().max().item() <= 1e-5 * max(want.abs().max().item(), 1.0)
+    # (6) a sample of the full-size result against the oracle
+    pick = perm[:3000].cpu()
+    ref = oracle_eval(sc, pts[pick.to(dev)].cpu(), [feats.cpu(), mask.cpu()])
+    assert np.array_equal(cpu(out["valid_mask"][pick.to(dev)]), ref["valid_mask"])
+    assert np.array_equal(cpu(out["dist"][pick.to(dev)]), ref["dist"])
+    assert rel_err(cpu(out["dino_feats"][pick.to(dev)]), ref["sets"][0]) <= TOL
+    assert rel_err(cpu(out["mask"][pick.to(dev)]), ref["sets"][1]) <= TOL
+
+
+# ---------------------------------------------------------------------------------------
+def test_onehot_helpers(dev):
+    from d3fields_amd import instance2onehot, onehot2instance
+    g = load_golden("onehot")
+    inst = torch.from_numpy(g["inst"]).to(dev)
+    oh = instance2onehot(inst, int(g["NI"]))
+    assert oh.dtype == torch.bool and np.array_equal(cpu(oh), g["onehot"])
+    assert np.array_equal(cpu(onehot2instance(torch.from_numpy(g["soft"]).to(dev))), g["soft_inst"])
+    assert np.array_equal(cpu(onehot2instance(oh)), g["inst"])
+    nan_row = torch.tensor([[0.1, float("nan"), 5.0], [3.0, 3.0, 1.0]], device=dev)
+    assert cpu(onehot2instance(nan_row)).tolist() == torch.argmax(nan_row.cpu(), -1).tolist()
+
+
+@pytest.mark.parametrize("dt", ["l2", "square"])
+def test_corr_utils_vs_reference_golden(dev, dt):
+    from d3fields_amd import corr_utils as cu
+    g = load_golden("corr_utils")
+    sc = float(g["scale"])
+    fm = g["fmap_bhwc"]
+    bchw = torch.from_numpy(np.ascontiguousarray(fm.transpose(0, 3, 1, 2))).to(dev)
+    tgt = torch.from_numpy(g["tgt"]).to(dev)
+    sim = cu.compute_similarity(fm, g["tgt"], sc, dist_type=dt)
+    assert isinstance(sim, np.ndarray) and rel_err(sim, g["similarity_" + dt]) <= TOL
+    assert rel_err(cpu(cu.compute_similarity_tensor(bchw, tgt, sc, dist_type=dt)), g["similarity_tensor_" + dt]) <= TOL
+    assert rel_err(cpu(cu.compute_dist_tensor(bchw, tgt, dist_type=dt)), g["dist_tensor_" + dt]) <= TOL
+    src, tg = torch.from_numpy(g["multi_src"]).to(dev), torch.from_numpy(g["multi_tgt"]).to(dev)
+    out = cu.compute_similarity_tensor_multi(src, tg, None, None, float(g["multi_scale"]), dist_type=dt)
+    assert rel_err(cpu(out), g["multi_" + dt]) <= TOL
+    assert np.allclose(cpu(out).sum(0), 1.0, atol=1e-5)
+    sim2, idx = cu.nearest_descriptor(src, tg, float(g["multi_scale"]), dist_type=dt)
+    assert torch.equal(sim2, out) and np.array_equal(cpu(idx), g["multi_argmax_" + dt])
+    if dt == "l2":
+        flat = torch.from_numpy(g["flat"]).to(dev)
+        assert rel_err(cpu(cu.compute_similarity_tensor(flat, tgt, sc)), g["flat_similarity_tensor_l2"]) <= TOL
+        assert rel_err(cpu(cu.compute_dist_tensor(flat, tgt)), g["flat_dist_tensor_l2"]) <= TOL
+    with pytest.raises(NotImplementedError):
+        cu.compute_dist_tensor(bchw, tgt, dist_type="cosine")
+
+
+@pytest.mark.parametrize("B1,B2,C", [(5000, 300, 384), (1, 1, 3), (257, 65, 33), (100000, 300, 384)])
+def test_pairwise_vs_oracle(dev, B1, B2, C):
+    from d3fields_amd import corr_utils as cu
+    from oracle import c_oracle as O
+    g = torch.Generator().manual_seed(B1 + C)
+    src = torch.randn(B1, C, generator=g)
+    tgt = torch.randn(B2, C, generator=g)
+    tgt[0] = src[B1 // 2]
+    out, idx = cu.nearest_descriptor(src.to(dev), tgt.to(dev), 0.9)
+    if B1 <= 5000:
+        ref, am = O.pairwise(src.numpy(), tgt.numpy(), 0.9, "l2", return_argmax=True)
+        assert rel_err(cpu(out), ref) <= TOL
+        assert np.array_equal(cpu(idx), am)
+    else:       # full config-5 size: properties
+        assert torch.allclose(out.sum(0), torch.ones(B2, device=dev), atol=1e-4)
+        assert idx[0].item() == B1 // 2
+        assert torch.equal(out.argmax(0), idx)
+        sl = slice(40000, 41000)
+        d = cu.compute_dist_tensor(src[sl].to(dev), tgt[7].to(dev))
+        assert rel_err(cpu(d), O.dist_to_target(src[sl].numpy(), tgt[7].numpy(), "l2", channel_axis=1)) <= TOL
+
+
+def test_fails_loudly_without_gpu_tensors(dev):
+    from d3fields_amd import synth
+    V, H, W = 2, 32, 40
+    sc = synth.make_scene(V, H, W, "smooth")
+    f = make_fusion(dev, sc["depth"], sc["K"], sc["pose"], {}, H, W)
+    with pytest.raises(RuntimeError):
+        f.eval(torch.zeros(4, 3), return_names=[])
+    with pytest.raises(KeyError):
+        f.eval(torch.zeros(4, 3, device=dev), return_names=["nope"])
+    with pytest.raises(AssertionError):
+        f.eval(torch.zeros(4, 2, device=dev), return_names=[])
