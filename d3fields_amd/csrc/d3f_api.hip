@@ -179,6 +179,8 @@ int d3f_similarity_to_target(const float *src, int64_t B, int64_t inner, int32_t
     if (B < 0 || inner < 0 || C < 1) return fail(D3F_ERR_BAD_SHAPE, "similarity_to_target: B=%lld inner=%lld C=%d", (long long)B, (long long)inner, C);
     if (B == 0 || inner == 0) return D3F_OK;
     if (!src || !tgt || !out) return fail(D3F_ERR_INVALID_ARG, "similarity_to_target: NULL pointer");
+    if (mode == D3F_SIM_SOFTMAX_DIM0 && (!workspace || workspace_bytes < d3f_softmax_workspace_bytes(B, inner)))
+        return fail(D3F_ERR_WORKSPACE, "similarity_to_target: softmax needs %lld workspace bytes", (long long)d3f_softmax_workspace_bytes(B, inner));
     hipStream_t s = static_cast<hipStream_t>(stream);
     hipError_t e = d3f::launch_dist_to_target(src, B, inner, C, stride_b, stride_i, stride_c, tgt, dist_type, out, s);
     if (e != hipSuccess) return hip_fail(e, "dist_to_target launch");
@@ -186,8 +188,6 @@ int d3f_similarity_to_target(const float *src, int64_t B, int64_t inner, int32_t
         e = d3f::launch_exp_neg_scale(out, B * inner, scale, s);
         if (e != hipSuccess) return hip_fail(e, "exp launch");
     } else if (mode == D3F_SIM_SOFTMAX_DIM0) {
-        if (!workspace || workspace_bytes < d3f_softmax_workspace_bytes(B, inner))
-            return fail(D3F_ERR_WORKSPACE, "similarity_to_target: softmax needs %lld workspace bytes", (long long)d3f_softmax_workspace_bytes(B, inner));
         e = d3f::launch_softmax_dim0(out, B, inner, scale, nullptr, static_cast<d3f::ColStat *>(workspace), s);
         if (e != hipSuccess) return hip_fail(e, "softmax launch");
     }

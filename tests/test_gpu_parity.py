@@ -165,7 +165,8 @@ def test_nonfinite_maps_propagate_like_reference(dev):
     got, want = cpu(out["dino_feats"]), ref["sets"][0]
     assert np.isnan(want).any()
     assert np.array_equal(np.isnan(got), np.isnan(want))
-    ok = ~np.isnan(want)
+    assert np.array_equal(np.isinf(got), np.isinf(want)) and np.isinf(want).any()
+    ok = np.isfinite(want)
     assert rel_err(got[ok], want[ok]) <= TOL
     # and with finite maps the skip changes nothing
     feats2 = torch.nan_to_num(feats, nan=0.5, posinf=1.0)

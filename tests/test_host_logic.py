@@ -1,0 +1,106 @@
+"""CPU: host-side mirror of the reference interface (no GPU, no compute calls)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+from d3fields_amd import Fusion, corr_utils, create_init_grid, instance2onehot, onehot2instance, sharding, synth
+
+
+@pytest.mark.parametrize("tag", ["004", "020"])
+def test_create_init_grid_matches_reference(tag):
+    g = load_golden("init_grid_" + tag)
+    b = dict(zip(["x_lower", "x_upper", "y_lower", "y_upper", "z_lower", "z_upper"], g["bounds"].tolist()))
+    coords, shape = create_init_grid(b, float(g["step"]))
+    assert tuple(shape) == tuple(g["shape"]) and coords.shape == (int(g["n"]), 3) and coords.dtype == torch.float32
+    c = coords.numpy()
+    assert np.array_equal(c[:128], g["head"]) and np.array_equal(c[-128:], g["tail"])
+    assert np.array_equal(c[::1009], g["sub"])
+    assert np.allclose(c.astype(np.float64).sum(0), g["colsum"], rtol=0, atol=1e-6)
+    if tag == "004":            # vis_repr.py:88 -> 200 x 175 x 55 = 1 925 000 voxels
+        assert tuple(shape) == (200, 175, 55)
+
+
+def test_onehot_numpy_paths_match_reference():
+    g = load_golden("onehot")
+    assert np.array_equal(instance2onehot(g["inst"], int(g["NI"])), g["onehot"])
+    assert np.array_equal(instance2onehot(g["inst"]), g["onehot"][..., :int(g["inst"].max()) + 1])
+    assert np.array_equal(onehot2instance(g["soft"]), g["soft_inst"])
+    with pytest.raises(NotImplementedError):
+        onehot2instance([1, 2, 3])
+
+
+def test_no_cpu_fallback_anywhere():
+    """The product path must fail loudly on CPU tensors instead of computing somewhere else."""
+    f = Fusion(num_cam=2)
+    with pytest.raises(RuntimeError, match="update"):
+        f.eval(torch.zeros(3, 3))
+    sc = synth.make_scene(2, 16, 20, "stress")
+    f.curr_obs_torch = dict(sc)
+    f.H, f.W = 16, 20
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        f.eval(torch.zeros(3, 3), return_names=[])
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        f.eval_dist(torch.zeros(3, 3))
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        f.batch_eval(torch.zeros(3, 3))
+    with pytest.raises(AssertionError):
+        f.eval(np.zeros((3, 3), np.float32))
+    with pytest.raises(AssertionError):
+        f.eval(torch.zeros(3, 4))
+    with pytest.raises(AssertionError):
+        f.eval(torch.zeros(3))
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        corr_utils.compute_dist_tensor(torch.zeros(2, 4), torch.zeros(4))
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        corr_utils.compute_similarity_tensor_multi(torch.zeros(2, 4), torch.zeros(3, 4), None, None, 1.0)
+    with pytest.raises(AssertionError):
+        corr_utils.compute_similarity_tensor_multi(torch.zeros(2, 4), torch.zeros(3, 5), None, None, 1.0)
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        onehot2instance(torch.zeros(4, 3))
+    with pytest.raises(NotImplementedError):
+        Fusion(num_cam=2, dtype=torch.float16)
+
+
+def test_product_never_imports_the_oracle():
+    import os
+    import re
+    from conftest import ROOT
+    pkg = os.path.join(ROOT, "d3fields_amd")
+    for dp, _, files in os.walk(pkg):
+        for fn in files:
+            if fn.endswith((".py", ".hip", ".h", ".cpp")):
+                text = open(os.path.join(dp, fn)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle", text, flags=re.M), fn
+                assert "libd3f_oracle" not in text and "c_oracle" not in text and "torch_port" not in text, fn
+                assert not re.search(r"#include\s*[<\"][^>\"]*oracle", text), fn
+
+
+def test_update_keeps_reference_state_layout():
+    calls = {}
+
+    def extractor(color, params):
+        calls["params"] = params
+        return torch.ones(color.shape[0], params["patch_h"], params["patch_w"], 6)
+
+    f = Fusion(num_cam=3, device="cpu", feature_extractor=extractor)    # host state only; no query is made
+    V, H, W = 3, 40, 60
+    obs = {"color": np.full((V, H, W, 3), 255, np.uint8), "depth": np.ones((V, H, W), np.float64),
+           "pose": np.zeros((V, 3, 4)), "K": np.zeros((V, 3, 3))}
+    f.update(obs)
+    assert calls["params"] == {"patch_h": 4, "patch_w": 6}          # H//10, W//10 (fusion.py:694-697)
+    assert (f.H, f.W, f.num_cam) == (H, W, V)
+    o = f.curr_obs_torch
+    assert o["dino_feats"].shape == (V, 4, 6, 6) and o["color_tensor"].shape == (V, H, W, 3)
+    assert float(o["color_tensor"].max()) == 1.0 and o["depth"].dtype == torch.float32
+    assert o["pose"].shape == (V, 3, 4) and o["K"].shape == (V, 3, 3) and o["color"] is obs["color"]
+
+
+def test_shard_bounds_cover_everything_once():
+    for n in [0, 1, 7, 8, 9, 130001]:
+        for world in [1, 2, 3, 8]:
+            spans = [sharding.shard_bounds(n, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            sizes = [b - a for a, b in spans]
+            assert max(sizes) - min(sizes) <= 1

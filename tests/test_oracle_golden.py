@@ -88,3 +88,36 @@ def test_corr_utils(dt):
     if dt == "l2":
         assert rel_err(O.similarity_softmax(g["flat"], g["tgt"], sc, dt, channel_axis=1), g["flat_similarity_tensor_l2"]) <= TOL
         assert rel_err(O.dist_to_target(g["flat"], g["tgt"], dt, channel_axis=1), g["flat_dist_tensor_l2"]) <= TOL
+
+
+# ---- the torch-ops port (bench.py's cpu_baseline leg) is the same function as the reference ----
+@pytest.mark.parametrize("case", ["scene_patchres_stress", "scene_fullres_smooth"])
+def test_torch_port_matches_reference(case):
+    import torch
+    from oracle import torch_port
+    g = load_golden(case)
+    obs = {k: torch.from_numpy(g[k]) for k in ("depth", "K", "pose")}
+    for k in SET_NAMES:
+        obs[k] = torch.from_numpy(g["in_" + k])
+    pts = torch.from_numpy(g["pts"])
+    out = torch_port.field_query(obs, pts, SET_NAMES, int(g["H"]), int(g["W"]), float(g["mu"]), keep_inter=True)
+    assert np.array_equal(out["valid_mask"].numpy(), g["valid_mask"])
+    assert np.array_equal(out["dist"].numpy(), g["dist"])
+    for k in SET_NAMES:
+        assert np.array_equal(out[k].numpy(), g[k]) and np.array_equal(out[k + "_inter"].numpy(), g[k + "_inter"])
+    dd = torch_port.dist_query(obs, pts, int(g["H"]), int(g["W"]))
+    assert np.array_equal(dd["dist"].numpy(), g["evaldist_dist"], equal_nan=True)
+    b = torch_port.batched_field_query(obs, pts, ["mask"], int(g["H"]), int(g["W"]), float(g["mu"]), chunk=1000)
+    assert np.array_equal(b["mask"].numpy(), g["mask"])
+
+
+def test_torch_port_gradient_matches_reference():
+    import torch
+    from oracle import torch_port
+    g = load_golden("grad_500")
+    obs = {k: torch.from_numpy(g[k]) for k in ("depth", "K", "pose")}
+    obs["dino_feats"] = torch.from_numpy(g["in_dino_feats"])
+    pts = torch.from_numpy(g["pts"]).requires_grad_(True)
+    out = torch_port.field_query(obs, pts, ["dino_feats"], int(g["H"]), int(g["W"]), float(g["mu"]))
+    (out["dino_feats"].sum() + out["dist"].sum()).backward()
+    assert rel_err(pts.grad.numpy(), g["grad_pts"]) <= TOL
