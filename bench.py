@@ -49,6 +49,16 @@ def algorithmic_bytes(w, n):
     return n * per_pt + maps + 84 * w["V"], per_pt
 
 
+def measured_traffic(workload):
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/traffic.json), or None."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "traffic.json")) as fh:
+            e = json.load(fh).get(workload)
+        return (e["traffic_bytes"], e["source"]) if e else (None, None)
+    except (OSError, ValueError, KeyError):
+        return None, None
+
+
 def build_workload(name, dev, rank, world):
     from d3fields_amd import Fusion, create_init_grid, synth
     w = WORKLOADS[name]
@@ -189,6 +199,7 @@ def main():
     total_pts = world * n * args.steps
     value = total_pts / wall
     bytes_alg, per_pt = algorithmic_bytes(w, n)
+    traffic, traffic_src = measured_traffic(args.workload)
     achieved = bytes_alg / (k_avg * 1e-3) / 1e9
     res = {
         "metric": "fused 3D query-points/sec", "value": value, "unit": "points/s",
@@ -203,7 +214,7 @@ def main():
                    "parallelism": "points sharded x%d, maps replicated" % world,
                    "gather": (args.gather if dist_on else "n/a")},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                      "kernel": "fused_eval_kernel<0>", "kernel_ms_avg": k_avg, "kernel_ms_median": k_med,
                      "kernel_ms_min": k_min, "algorithmic_bytes_per_launch": bytes_alg,
                      "algorithmic_bytes_per_point": per_pt, "kernel_points_per_s": n / (k_avg * 1e-3)},

@@ -18,7 +18,7 @@ for p in find("*kernel_stats.csv"):
     with open(p) as f:
         for i, row in enumerate(csv.reader(f)):
             if i < 12:
-                print(",".join(row))
+                print(",".join(c[:110] for c in row))
 
 print("\n== per-kernel durations from kernel_trace (ns) ==")
 for p in find("trace*kernel_trace.csv"):
