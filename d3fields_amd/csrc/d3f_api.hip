@@ -89,6 +89,10 @@ int eval_common(const d3f_views *views, const float *pts, int64_t n, const d3f_c
     P.n = n; P.V = views->V; P.H = views->H; P.W = views->W;
     P.n_maps = n_maps; P.tile_pts = tile_points_for(views->V);
     P.flags = flags; P.mu = mu;
+    // tuning bits (D3F_TUNE_*): experiments only, results never depend on them
+    const int tl = (int)((flags >> 8) & 0xF);
+    if (tl >= 5 && tl <= 8 && (1 << tl) <= P.tile_pts) P.tile_pts = 1 << tl;
+    P.lds_pad = (int)((flags >> 16) & 0xFF) * 1024;
     for (int s = 0; s < n_maps; ++s) {
         const d3f_channel_map &c = maps[s];
         d3f::MapDesc &m = P.maps[s];

@@ -9,6 +9,7 @@ namespace d3f {
 
 constexpr int kBlock = 256;                 // 4 waves of 64 lanes
 constexpr uint32_t kFlagFiniteMaps = D3F_FLAG_FINITE_MAPS;
+constexpr uint32_t kFlagNoXcdRemap = D3F_TUNE_NO_XCD_REMAP;
 
 // One channel map as the kernel sees it (strides in elements, channel stride 1).
 struct MapDesc {
@@ -30,6 +31,7 @@ struct EvalParams {
     int32_t V, H, W;
     int32_t n_maps;
     int32_t tile_pts;  // points per workgroup
+    int32_t lds_pad;   // extra dynamic LDS bytes (occupancy throttle, tuning only)
     uint32_t flags;
     float mu;
     MapDesc maps[D3F_MAX_MAPS];

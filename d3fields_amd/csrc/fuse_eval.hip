@@ -201,7 +201,7 @@ __global__ __launch_bounds__(kBlock) void fused_eval_kernel(const EvalParams P)
     __syncthreads();
 
     const int64_t ntiles = (P.n + TP - 1) / TP;
-    const int64_t tile = xcd_tile(blockIdx.x, ntiles);
+    const int64_t tile = (P.flags & kFlagNoXcdRemap) ? (int64_t)blockIdx.x : xcd_tile(blockIdx.x, ntiles);
     const int64_t tile_base = tile * TP;
     const int tile_n = (int)min((int64_t)TP, P.n - tile_base);
     const float mu = P.mu;
@@ -281,7 +281,7 @@ hipError_t launch_fused_eval(const EvalParams &P, int mode, hipStream_t stream)
 {
     if (P.n == 0) return hipSuccess;
     const int64_t ntiles = (P.n + P.tile_pts - 1) / P.tile_pts;
-    const size_t lds = (size_t)P.tile_pts * P.V * sizeof(ViewRec) + (size_t)P.tile_pts * 8 + (size_t)P.V * 48;
+    const size_t lds = (size_t)P.tile_pts * P.V * sizeof(ViewRec) + (size_t)P.tile_pts * 8 + (size_t)P.V * 48 + (size_t)P.lds_pad;
     dim3 grid((unsigned)ntiles), block(kBlock);
     if (mode == 0)
         hipLaunchKernelGGL(fused_eval_kernel<0>, grid, block, lds, stream, P);

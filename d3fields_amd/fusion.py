@@ -117,6 +117,7 @@ class Fusion:
         self.mask_tracker = mask_tracker
         self.track_ids = [0]
         self._finite_cache = {}
+        self.tuning_flags = 0                   # D3F_TUNE_* bits (experiments; results do not depend on them)
         self._lib = _lib.load()                 # fail at construction if the HIP library is missing
 
     # ---- observation state (reference fusion.py:686-714) --------------------------------
@@ -221,7 +222,7 @@ class Fusion:
                     it = torch.empty((V, n, C), dtype=torch.float32, device=dev)
                     outputs[k + "_inter"] = it
                     inter[s] = it.data_ptr()
-            flags = _lib.FLAG_FINITE_MAPS if finite else 0
+            flags = (_lib.FLAG_FINITE_MAPS if finite else 0) | int(self.tuning_flags)
             _lib.check(lib.d3f_eval(ctypes.byref(views), _lib.ptr(pts_c), n, maps, len(names), self.mu, flags,
                                     _lib.ptr(dist), _lib.ptr(valid), fused, inter if return_inter else None, stream))
         return outputs

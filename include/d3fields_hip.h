@@ -47,6 +47,14 @@ extern "C" {
                                    without the flag 0*NaN / 0*Inf propagate as in the          \
                                    reference, fusion.py:385).                                  */
 
+/* Tuning bits of `flags` (performance experiments; results never depend on them):
+ *   bits 8..11  log2 of the points per workgroup (5..8), 0 = automatic
+ *   bit  12     do not remap workgroups to XCD-contiguous tile ranges
+ *   bits 16..23 extra dynamic LDS per workgroup in KiB (throttles workgroups per CU)      */
+#define D3F_TUNE_TILE_LOG2(k) (((uint32_t)(k) & 0xFu) << 8)
+#define D3F_TUNE_NO_XCD_REMAP (1u << 12)
+#define D3F_TUNE_LDS_PAD_KIB(k) (((uint32_t)(k) & 0xFFu) << 16)
+
 /* Calibrated views: the part of Fusion.curr_obs_torch read by every query
  * (fusion.py:210-215, 707-712): 'depth' (V,H,W), 'K' (V,3,3), 'pose' (V,3,4) world->camera. */
 typedef struct d3f_views {
