@@ -15,6 +15,7 @@ ABI_VERSION = 1
 OK = 0
 ERR_INVALID_ARG, ERR_BAD_SHAPE, ERR_BAD_DTYPE, ERR_BAD_LAYOUT, ERR_HIP, ERR_WORKSPACE = -1, -2, -3, -4, -5, -6
 FLAG_FINITE_MAPS = 1
+TUNE_XCD_REMAP, TUNE_NO_REORDER, TUNE_FORCE_REORDER = 1 << 12, 1 << 13, 1 << 14
 MAX_VIEWS = 64
 MAX_MAPS = 8
 DTYPE_F32 = 0
@@ -45,7 +46,8 @@ SIGNATURES = {
     "d3f_version": (ctypes.c_char_p, []),
     "d3f_last_error": (ctypes.c_char_p, []),
     "d3f_eval": (ctypes.c_int, [ctypes.POINTER(Views), _vp, _i64, ctypes.POINTER(ChannelMap), _i32, _f32, _u32,
-                                _vp, _vp, ctypes.POINTER(_vp), ctypes.POINTER(_vp), _vp]),
+                                _vp, _vp, ctypes.POINTER(_vp), ctypes.POINTER(_vp), _vp, _i64, _vp]),
+    "d3f_eval_workspace_bytes": (_i64, [_i64]),
     "d3f_eval_dist": (ctypes.c_int, [ctypes.POINTER(Views), _vp, _i64, _vp, _vp, _vp]),
     "d3f_onehot2instance": (ctypes.c_int, [_vp, _i64, _i32, _vp, _vp]),
     "d3f_instance2onehot": (ctypes.c_int, [_vp, _i64, _i32, _vp, _vp]),

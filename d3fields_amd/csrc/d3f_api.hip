@@ -64,15 +64,16 @@ void pick_mapping(d3f::MapDesc &m, bool can16, bool can8)
 
 int tile_points_for(int V)
 {
-    // LDS per workgroup = tile*V*16 B (+ small); keep it <= 32 KiB so >= 4 workgroups fit a CU
-    int t = 256;
+    // LDS per workgroup = tile*V*16 B (+ small); keep it <= 32 KiB so >= 4 workgroups fit a CU.
+    // 128 points measured best (985 600-pt grid, C=384: 128 -> 0.99 ms, 256 -> 1.06 ms patch-res).
+    int t = 128;
     while (t > 32 && (long)t * V * 16 > 32 * 1024) t >>= 1;
     return t;
 }
 
 int eval_common(const d3f_views *views, const float *pts, int64_t n, const d3f_channel_map *maps, int32_t n_maps,
                 float mu, uint32_t flags, float *out_dist, uint8_t *out_valid, float *const *out_fused,
-                float *const *out_inter, void *stream, int mode)
+                float *const *out_inter, void *workspace, int64_t workspace_bytes, void *stream, int mode)
 {
     int rc = check_views(views);
     if (rc != D3F_OK) return rc;
@@ -85,14 +86,15 @@ int eval_common(const d3f_views *views, const float *pts, int64_t n, const d3f_c
 
     d3f::EvalParams P;
     P.depth = views->depth; P.K = views->K; P.pose = views->pose; P.pts = pts;
+    P.order = nullptr; P.lds_pad = 0;
+    int64_t map_bytes = 0;
     P.out_dist = out_dist; P.out_valid = out_valid;
     P.n = n; P.V = views->V; P.H = views->H; P.W = views->W;
     P.n_maps = n_maps; P.tile_pts = tile_points_for(views->V);
     P.flags = flags; P.mu = mu;
     // tuning bits (D3F_TUNE_*): experiments only, results never depend on them
     const int tl = (int)((flags >> 8) & 0xF);
-    if (tl >= 5 && tl <= 8 && (1 << tl) <= P.tile_pts) P.tile_pts = 1 << tl;
-    P.lds_pad = (int)((flags >> 16) & 0xFF) * 1024;
+    const int max_tile = tile_points_for(views->V) * 2;
     for (int s = 0; s < n_maps; ++s) {
         const d3f_channel_map &c = maps[s];
         d3f::MapDesc &m = P.maps[s];
@@ -113,10 +115,26 @@ int eval_common(const d3f_views *views, const float *pts, int64_t n, const d3f_c
         const bool can16 = str16 && aligned(m.data, 16) && aligned(m.out, 16) && (!m.inter || aligned(m.inter, 16));
         const bool can8 = str8 && aligned(m.data, 8) && aligned(m.out, 8) && (!m.inter || aligned(m.inter, 8));
         pick_mapping(m, can16, can8);
+        map_bytes += (int64_t)views->V * c.fh * c.fw * c.C * 4;
+    }
+    // Maps far larger than the 256 MiB Infinity Cache: the kernel is bound by texel re-fetches, and
+    // a smaller in-flight footprint wins (64-point tiles, 2 workgroups per CU: 3.2 -> 2.96 ms on C2
+    // dense; the same throttle costs 60 % on cache-resident maps, hence the size test).
+    const bool huge_maps = map_bytes > (512LL << 20);
+    if (huge_maps && P.tile_pts > 64) { P.tile_pts = 64; P.lds_pad = 64 * 1024; }
+    if (tl >= 5 && tl <= 8) { P.tile_pts = (1 << tl) <= max_tile ? (1 << tl) : max_tile; P.lds_pad = 0; }
+    if ((flags >> 16) & 0xFF) P.lds_pad = (int)((flags >> 16) & 0xFF) * 1024;
+    // Morton point order (performance only) when scratch is supplied and the maps exceed the L2s
+    hipStream_t hs = static_cast<hipStream_t>(stream);
+    const bool may_reorder = workspace && n_maps > 0 && n <= 0x7fffffffLL && !(flags & D3F_TUNE_NO_REORDER) &&
+                             workspace_bytes >= d3f::order_workspace_bytes(n);
+    if (may_reorder && ((flags & D3F_TUNE_FORCE_REORDER) || (n >= 65536 && map_bytes > (64LL << 20)))) {
+        hipError_t eo = d3f::build_point_order(pts, n, workspace, workspace_bytes, &P.order, hs);
+        if (eo != hipSuccess) return hip_fail(eo, "point ordering");
     }
     const int64_t ntiles = (n + P.tile_pts - 1) / P.tile_pts;
     if (ntiles > 0x7fffffffLL) return fail(D3F_ERR_BAD_SHAPE, "n=%lld needs more than 2^31 workgroups", (long long)n);
-    hipError_t e = d3f::launch_fused_eval(P, mode, static_cast<hipStream_t>(stream));
+    hipError_t e = d3f::launch_fused_eval(P, mode, hs);
     if (e != hipSuccess) return hip_fail(e, "fused_eval launch");
     return D3F_OK;
 }
@@ -131,15 +149,18 @@ const char *d3f_last_error(void) { return g_err; }
 
 int d3f_eval(const d3f_views *views, const float *pts, int64_t n, const d3f_channel_map *maps, int32_t n_maps,
              float mu, uint32_t flags, float *out_dist, uint8_t *out_valid, float *const *out_fused,
-             float *const *out_inter, void *stream)
+             float *const *out_inter, void *workspace, int64_t workspace_bytes, void *stream)
 {
-    return eval_common(views, pts, n, maps, n_maps, mu, flags, out_dist, out_valid, out_fused, out_inter, stream, 0);
+    return eval_common(views, pts, n, maps, n_maps, mu, flags, out_dist, out_valid, out_fused, out_inter, workspace,
+                       workspace_bytes, stream, 0);
 }
+
+int64_t d3f_eval_workspace_bytes(int64_t n) { return d3f::order_workspace_bytes(n); }
 
 int d3f_eval_dist(const d3f_views *views, const float *pts, int64_t n, float *out_dist, uint8_t *out_valid,
                   void *stream)
 {
-    return eval_common(views, pts, n, nullptr, 0, 1.0f, 0u, out_dist, out_valid, nullptr, nullptr, stream, 1);
+    return eval_common(views, pts, n, nullptr, 0, 1.0f, 0u, out_dist, out_valid, nullptr, nullptr, nullptr, 0, stream, 1);
 }
 
 int d3f_onehot2instance(const float *onehot, int64_t n, int32_t NI, uint8_t *out, void *stream)

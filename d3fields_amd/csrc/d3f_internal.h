@@ -9,7 +9,7 @@ namespace d3f {
 
 constexpr int kBlock = 256;                 // 4 waves of 64 lanes
 constexpr uint32_t kFlagFiniteMaps = D3F_FLAG_FINITE_MAPS;
-constexpr uint32_t kFlagNoXcdRemap = D3F_TUNE_NO_XCD_REMAP;
+constexpr uint32_t kFlagXcdRemap = D3F_TUNE_XCD_REMAP;
 
 // One channel map as the kernel sees it (strides in elements, channel stride 1).
 struct MapDesc {
@@ -25,6 +25,7 @@ struct MapDesc {
 
 struct EvalParams {
     const float *depth, *K, *pose, *pts;
+    const uint32_t *order;  // nullptr, or n point indices: the kernel processes points in this order
     float *out_dist;
     uint8_t *out_valid;
     int64_t n;
@@ -38,6 +39,11 @@ struct EvalParams {
 };
 
 hipError_t launch_fused_eval(const EvalParams &P, int mode, hipStream_t stream);
+
+// order_kernels.hip
+int64_t order_workspace_bytes(int64_t n);
+hipError_t build_point_order(const float *pts, int64_t n, void *workspace, int64_t workspace_bytes,
+                             const uint32_t **order_out, hipStream_t stream);
 
 // misc_kernels.hip
 hipError_t launch_onehot2instance(const float *onehot, int64_t n, int NI, uint8_t *out, hipStream_t s);

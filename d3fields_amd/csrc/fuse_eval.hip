@@ -46,30 +46,19 @@ __device__ __forceinline__ bool in_bounds(float x, float y, int fw, int fh)
 
 // ---- phase B: bilinear gather + view reduction for one map -----------------------------
 
+// clang extended vectors: elementwise * + / are native, fma is explicit.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 template <int VW> struct Vec;
-template <> struct Vec<4> { using T = float4; };
-template <> struct Vec<2> { using T = float2; };
+template <> struct Vec<4> { using T = f32x4; };
+template <> struct Vec<2> { using T = f32x2; };
 template <> struct Vec<1> { using T = float; };
 
-template <int VW> __device__ __forceinline__ typename Vec<VW>::T vzero();
-template <> __device__ __forceinline__ float4 vzero<4>() { return make_float4(0.f, 0.f, 0.f, 0.f); }
-template <> __device__ __forceinline__ float2 vzero<2>() { return make_float2(0.f, 0.f); }
-template <> __device__ __forceinline__ float vzero<1>() { return 0.f; }
+template <typename VT> __device__ __forceinline__ VT v_fma(VT a, float s, VT c) { return __builtin_elementwise_fma(a, (VT)s, c); }
+template <> __device__ __forceinline__ float v_fma<float>(float a, float s, float c) { return fmaf(a, s, c); }
 
-#define D3F_EW4(expr_x, expr_y, expr_z, expr_w) make_float4(expr_x, expr_y, expr_z, expr_w)
-
-__device__ __forceinline__ float4 v_mul(float4 a, float s) { return make_float4(a.x * s, a.y * s, a.z * s, a.w * s); }
-__device__ __forceinline__ float2 v_mul(float2 a, float s) { return make_float2(a.x * s, a.y * s); }
-__device__ __forceinline__ float v_mul(float a, float s) { return a * s; }
-__device__ __forceinline__ float4 v_fma(float4 a, float s, float4 c) { return make_float4(fmaf(a.x, s, c.x), fmaf(a.y, s, c.y), fmaf(a.z, s, c.z), fmaf(a.w, s, c.w)); }
-__device__ __forceinline__ float2 v_fma(float2 a, float s, float2 c) { return make_float2(fmaf(a.x, s, c.x), fmaf(a.y, s, c.y)); }
-__device__ __forceinline__ float v_fma(float a, float s, float c) { return fmaf(a, s, c); }
-__device__ __forceinline__ float4 v_add(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
-__device__ __forceinline__ float2 v_add(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
-__device__ __forceinline__ float v_add(float a, float b) { return a + b; }
-__device__ __forceinline__ float4 v_div(float4 a, float s) { return make_float4(a.x / s, a.y / s, a.z / s, a.w / s); }
-__device__ __forceinline__ float2 v_div(float2 a, float s) { return make_float2(a.x / s, a.y / s); }
-__device__ __forceinline__ float v_div(float a, float s) { return a / s; }
+template <typename VT> __device__ __forceinline__ VT load_vec(const float *p) { return *reinterpret_cast<const VT *>(p); }
+template <typename VT> __device__ __forceinline__ void store_vec(float *p, VT v) { *reinterpret_cast<VT *>(p) = v; }
 
 // Gathers map `m` for the points of this workgroup's tile.
 //   VW  channel-vector width in floats (4 when C%4==0 and 16-B aligned, else 2 or 1)
@@ -80,7 +69,7 @@ __device__ __forceinline__ float v_div(float a, float s) { return a / s; }
 template <int VW, int U>
 __device__ __forceinline__ void gather_map(const MapDesc &m, const EvalParams &P, const ViewRec *rec,
                                            const float *cnt_s, const uint32_t *flag_s,
-                                           int64_t tile_base, int tile_n)
+                                           const uint32_t *idx_s, int64_t idx_base, int tile_n)
 {
     using VT = typename Vec<VW>::T;
     const int lpp = 1 << m.lpp_log2;
@@ -92,7 +81,7 @@ __device__ __forceinline__ void gather_map(const MapDesc &m, const EvalParams &P
     const float *__restrict__ data = m.data;
 
     for (int p = grp; p < tile_n; p += ngrp) {
-        const int64_t i = tile_base + p;
+        const int64_t i = idx_base + idx_s[p];
         const float cnt = cnt_s[p];
         const bool all_invalid = (cnt == 0.0f);           // fusion.py:366
         const float denom = cnt + 1e-6f;                  // fusion.py:385
@@ -100,7 +89,7 @@ __device__ __forceinline__ void gather_map(const MapDesc &m, const EvalParams &P
         for (int c0 = 0; c0 < cvec; c0 += lpp * U) {
             VT acc[U];
 #pragma unroll
-            for (int u = 0; u < U; ++u) acc[u] = vzero<VW>();
+            for (int u = 0; u < U; ++u) acc[u] = (VT)0.0f;
             for (int v = 0; v < V; ++v) {
                 const ViewRec r = rec[p * V + v];
                 if (!strict && r.valid == 0.0f) continue;  // exact: +0 + (+-0) == +0, x + (+-0) == x
@@ -125,18 +114,18 @@ __device__ __forceinline__ void gather_map(const MapDesc &m, const EvalParams &P
                     const int cv = c0 + u * lpp + g;
                     if (cv < cvec) {
                         const int co = cv * VW;
-                        VT a = inw ? *reinterpret_cast<const VT *>(pnw + co) : vzero<VW>();
-                        VT b = ine ? *reinterpret_cast<const VT *>(pne + co) : vzero<VW>();
-                        VT d = isw ? *reinterpret_cast<const VT *>(psw + co) : vzero<VW>();
-                        VT e = ise ? *reinterpret_cast<const VT *>(pse + co) : vzero<VW>();
-                        VT s = v_mul(a, wnw);              // ATen bilinear: fma chain nw,ne,sw,se
-                        s = v_fma(b, wne, s);
-                        s = v_fma(d, wsw, s);
-                        s = v_fma(e, wse, s);
+                        VT a = inw ? load_vec<VT>(pnw + co) : (VT)0.0f;
+                        VT b = ine ? load_vec<VT>(pne + co) : (VT)0.0f;
+                        VT d = isw ? load_vec<VT>(psw + co) : (VT)0.0f;
+                        VT e = ise ? load_vec<VT>(pse + co) : (VT)0.0f;
+                        VT s = a * wnw;                    // ATen bilinear: fma chain nw,ne,sw,se
+                        s = v_fma<VT>(b, wne, s);
+                        s = v_fma<VT>(d, wsw, s);
+                        s = v_fma<VT>(e, wse, s);
                         if (m.inter)                       // '<k>_inter' [V,n,C]  fusion.py:389
-                            *reinterpret_cast<VT *>(m.inter + ((int64_t)v * P.n + i) * m.C + co) = s;
-                        VT t = v_mul(v_mul(s, r.valid), r.wgt);   // fusion.py:385
-                        acc[u] = v_add(acc[u], t);
+                            store_vec<VT>(m.inter + ((int64_t)v * P.n + i) * m.C + co, s);
+                        VT t = (s * r.valid) * r.wgt;      // fusion.py:385
+                        acc[u] = acc[u] + t;
                     }
                 }
             }
@@ -144,8 +133,8 @@ __device__ __forceinline__ void gather_map(const MapDesc &m, const EvalParams &P
             for (int u = 0; u < U; ++u) {
                 const int cv = c0 + u * lpp + g;
                 if (cv < cvec) {
-                    VT o = all_invalid ? vzero<VW>() : v_div(acc[u], denom);   // fusion.py:385-386
-                    *reinterpret_cast<VT *>(m.out + i * m.C + (int64_t)cv * VW) = o;
+                    VT o = all_invalid ? (VT)0.0f : acc[u] / denom;            // fusion.py:385-386
+                    store_vec<VT>(m.out + i * m.C + (int64_t)cv * VW, o);
                 }
             }
         }
@@ -155,13 +144,13 @@ __device__ __forceinline__ void gather_map(const MapDesc &m, const EvalParams &P
 template <int VW>
 __device__ __forceinline__ void gather_map_u(const MapDesc &m, const EvalParams &P, const ViewRec *rec,
                                              const float *cnt_s, const uint32_t *flag_s,
-                                             int64_t tile_base, int tile_n)
+                                             const uint32_t *idx_s, int64_t idx_base, int tile_n)
 {
     switch (m.unroll) {
-    case 1: gather_map<VW, 1>(m, P, rec, cnt_s, flag_s, tile_base, tile_n); break;
-    case 2: gather_map<VW, 2>(m, P, rec, cnt_s, flag_s, tile_base, tile_n); break;
-    case 3: gather_map<VW, 3>(m, P, rec, cnt_s, flag_s, tile_base, tile_n); break;
-    default: gather_map<VW, 4>(m, P, rec, cnt_s, flag_s, tile_base, tile_n); break;
+    case 1: gather_map<VW, 1>(m, P, rec, cnt_s, flag_s, idx_s, idx_base, tile_n); break;
+    case 2: gather_map<VW, 2>(m, P, rec, cnt_s, flag_s, idx_s, idx_base, tile_n); break;
+    case 3: gather_map<VW, 3>(m, P, rec, cnt_s, flag_s, idx_s, idx_base, tile_n); break;
+    default: gather_map<VW, 4>(m, P, rec, cnt_s, flag_s, idx_s, idx_base, tile_n); break;
     }
 }
 
@@ -185,7 +174,8 @@ __global__ __launch_bounds__(kBlock) void fused_eval_kernel(const EvalParams P)
     ViewRec *rec = reinterpret_cast<ViewRec *>(smem);                       // [TP*V]
     float *cnt_s = reinterpret_cast<float *>(rec + (size_t)TP * V);          // [TP]
     uint32_t *flag_s = reinterpret_cast<uint32_t *>(cnt_s + TP);             // [TP]
-    float *krt = reinterpret_cast<float *>(flag_s + TP);                     // [V*12]
+    uint32_t *idx_s = flag_s + TP;                                           // [TP] global point index
+    float *krt = reinterpret_cast<float *>(idx_s + TP);                      // [V*12]
 
     // KRt = K @ pose (fusion.py:44): k-sequential, unfused, like the 3x3@3x4 bmm on the host
     for (int t = threadIdx.x; t < V * 12; t += kBlock) {
@@ -201,15 +191,16 @@ __global__ __launch_bounds__(kBlock) void fused_eval_kernel(const EvalParams P)
     __syncthreads();
 
     const int64_t ntiles = (P.n + TP - 1) / TP;
-    const int64_t tile = (P.flags & kFlagNoXcdRemap) ? (int64_t)blockIdx.x : xcd_tile(blockIdx.x, ntiles);
+    const int64_t tile = (P.flags & kFlagXcdRemap) ? xcd_tile(blockIdx.x, ntiles) : (int64_t)blockIdx.x;
     const int64_t tile_base = tile * TP;
     const int tile_n = (int)min((int64_t)TP, P.n - tile_base);
+    const int64_t idx_base = P.order ? 0 : tile_base;   // idx_s holds 32-bit offsets from here
     const float mu = P.mu;
     const float Wm1 = (float)(P.W - 1), Hm1 = (float)(P.H - 1);
 
     // ---------------- phase A: one lane per point ----------------
     for (int p = threadIdx.x; p < tile_n; p += kBlock) {
-        const int64_t i = tile_base + p;
+        const int64_t i = P.order ? (int64_t)P.order[tile_base + p] : tile_base + p;
         const float px = P.pts[i * 3 + 0], py = P.pts[i * 3 + 1], pz = P.pts[i * 3 + 2];
         float dsum = 0.0f, cnt = 0.0f;
         bool nonfinite = false;
@@ -260,6 +251,7 @@ __global__ __launch_bounds__(kBlock) void fused_eval_kernel(const EvalParams P)
         P.out_valid[i] = all_invalid ? 0 : 1;
         if (P.n_maps > 0) {
             cnt_s[p] = cnt;
+            idx_s[p] = (uint32_t)(i - idx_base);
             flag_s[p] = (nonfinite || !(P.flags & kFlagFiniteMaps)) ? 1u : 0u;
         }
     }
@@ -270,9 +262,9 @@ __global__ __launch_bounds__(kBlock) void fused_eval_kernel(const EvalParams P)
     for (int s = 0; s < P.n_maps; ++s) {
         const MapDesc &m = P.maps[s];
         switch (m.vw) {
-        case 4: gather_map_u<4>(m, P, rec, cnt_s, flag_s, tile_base, tile_n); break;
-        case 2: gather_map_u<2>(m, P, rec, cnt_s, flag_s, tile_base, tile_n); break;
-        default: gather_map_u<1>(m, P, rec, cnt_s, flag_s, tile_base, tile_n); break;
+        case 4: gather_map_u<4>(m, P, rec, cnt_s, flag_s, idx_s, idx_base, tile_n); break;
+        case 2: gather_map_u<2>(m, P, rec, cnt_s, flag_s, idx_s, idx_base, tile_n); break;
+        default: gather_map_u<1>(m, P, rec, cnt_s, flag_s, idx_s, idx_base, tile_n); break;
         }
     }
 }
@@ -281,7 +273,7 @@ hipError_t launch_fused_eval(const EvalParams &P, int mode, hipStream_t stream)
 {
     if (P.n == 0) return hipSuccess;
     const int64_t ntiles = (P.n + P.tile_pts - 1) / P.tile_pts;
-    const size_t lds = (size_t)P.tile_pts * P.V * sizeof(ViewRec) + (size_t)P.tile_pts * 8 + (size_t)P.V * 48 + (size_t)P.lds_pad;
+    const size_t lds = (size_t)P.tile_pts * P.V * sizeof(ViewRec) + (size_t)P.tile_pts * 12 + (size_t)P.V * 48 + (size_t)P.lds_pad;
     dim3 grid((unsigned)ntiles), block(kBlock);
     if (mode == 0)
         hipLaunchKernelGGL(fused_eval_kernel<0>, grid, block, lds, stream, P);

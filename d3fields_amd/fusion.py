@@ -118,6 +118,7 @@ class Fusion:
         self.track_ids = [0]
         self._finite_cache = {}
         self.tuning_flags = 0                   # D3F_TUNE_* bits (experiments; results do not depend on them)
+        self.reorder_points = True              # hand the library scratch so it may walk points in Morton order
         self._lib = _lib.load()                 # fail at construction if the HIP library is missing
 
     # ---- observation state (reference fusion.py:686-714) --------------------------------
@@ -223,8 +224,13 @@ class Fusion:
                     outputs[k + "_inter"] = it
                     inter[s] = it.data_ptr()
             flags = (_lib.FLAG_FINITE_MAPS if finite else 0) | int(self.tuning_flags)
+            ws, ws_bytes = None, 0
+            if self.reorder_points and names and n >= 65536:
+                ws_bytes = lib.d3f_eval_workspace_bytes(n)
+                ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)   # torch's caching allocator: no hipMalloc per call
             _lib.check(lib.d3f_eval(ctypes.byref(views), _lib.ptr(pts_c), n, maps, len(names), self.mu, flags,
-                                    _lib.ptr(dist), _lib.ptr(valid), fused, inter if return_inter else None, stream))
+                                    _lib.ptr(dist), _lib.ptr(valid), fused, inter if return_inter else None,
+                                    _lib.ptr(ws), ws_bytes, stream))
         return outputs
 
     def eval(self, pts, return_names=["dino_feats", "mask"], return_inter=False):

@@ -49,10 +49,14 @@ extern "C" {
 
 /* Tuning bits of `flags` (performance experiments; results never depend on them):
  *   bits 8..11  log2 of the points per workgroup (5..8), 0 = automatic
- *   bit  12     do not remap workgroups to XCD-contiguous tile ranges
+ *   bit  12     remap workgroups to XCD-contiguous tile ranges (measured slower: off by default)
+ *   bit  13     never reorder points, even when a workspace is supplied
+ *   bit  14     always reorder points when a workspace is supplied
  *   bits 16..23 extra dynamic LDS per workgroup in KiB (throttles workgroups per CU)      */
 #define D3F_TUNE_TILE_LOG2(k) (((uint32_t)(k) & 0xFu) << 8)
-#define D3F_TUNE_NO_XCD_REMAP (1u << 12)
+#define D3F_TUNE_XCD_REMAP (1u << 12)
+#define D3F_TUNE_NO_REORDER (1u << 13)
+#define D3F_TUNE_FORCE_REORDER (1u << 14)
 #define D3F_TUNE_LDS_PAD_KIB(k) (((uint32_t)(k) & 0xFFu) << 16)
 
 /* Calibrated views: the part of Fusion.curr_obs_torch read by every query
@@ -93,7 +97,13 @@ const char *d3f_last_error(void); /* host memory, valid until the thread's next 
  */
 int d3f_eval(const d3f_views *views, const float *pts, int64_t n, const d3f_channel_map *maps,
              int32_t n_maps, float mu, uint32_t flags, float *out_dist, uint8_t *out_valid,
-             float *const *out_fused, float *const *out_inter, void *stream);
+             float *const *out_fused, float *const *out_inter, void *workspace,
+             int64_t workspace_bytes, void *stream);
+
+/* Optional device scratch for d3f_eval (NULL/0 is always accepted).  With at least
+ * d3f_eval_workspace_bytes(n) bytes the library may walk the points in a cache-friendlier
+ * (Morton) order when the maps are much larger than the caches; outputs are unaffected. */
+int64_t d3f_eval_workspace_bytes(int64_t n);
 
 /* Replaces Fusion.eval_dist (fusion.py:396-436): no -mu gate, no clamp, no 1e3 sentinel. */
 int d3f_eval_dist(const d3f_views *views, const float *pts, int64_t n, float *out_dist,

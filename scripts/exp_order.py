@@ -62,14 +62,16 @@ def timeit(p, flags, reps=8):
     return ts[len(ts) // 2]
 
 
-def tune(tile_log2=0, no_xcd=False, pad_kib=0):
-    return (tile_log2 << 8) | ((1 << 12) if no_xcd else 0) | (pad_kib << 16)
+def tune(tile_log2=0, xcd=False, pad_kib=0):
+    return (tile_log2 << 8) | ((1 << 12) if xcd else 0) | (pad_kib << 16)
 
 
 print("workload", which, "N", pts.shape[0])
-for name, perm in orders.items():
+NOR, FOR = 1 << 13, 1 << 14
+cfgs = [("default(auto)", 0), ("no-reorder", NOR), ("force-reorder", FOR), ("noreorder t7 p0", NOR | tune(7, False, 0)),
+        ("reorder t7 p0", FOR | tune(7, False, 0)), ("reorder t6 p64", FOR | tune(6, False, 64)), ("reorder t6 p48", FOR | tune(6, False, 48)),
+        ("reorder t5 p64", FOR | tune(5, False, 64)), ("reorder t6 p96", FOR | tune(6, False, 96))]
+for name in ["grid(z-fast)", "morton", "random"]:
+    perm = orders[name]
     p = pts if perm is None else pts[perm].contiguous()
-    row = []
-    for (tl, nox, pad) in [(0, False, 0), (0, True, 0), (6, True, 0), (7, True, 0), (0, True, 24), (0, True, 64), (6, True, 24), (6, True, 64), (7, False, 24)]:
-        row.append("t%d%s p%d: %.3f" % (tl, "n" if nox else "x", pad, timeit(p, tune(tl, nox, pad))))
-    print("%-16s %s" % (name, " | ".join(row)))
+    print("%-14s %s" % (name, " | ".join("%s: %.3f" % (n, timeit(p, fl)) for n, fl in cfgs)))

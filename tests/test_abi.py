@@ -54,22 +54,22 @@ def test_validation_returns_status_codes_not_aborts():
     lib = _lib.load()
     one = ctypes.c_void_p(16)
     # n == 0 is a no-op success even with NULL buffers (empty batch, reference returns empty tensors)
-    assert lib.d3f_eval(ctypes.byref(_views()), None, 0, None, 0, 0.02, 0, None, None, None, None, None) == 0
-    assert lib.d3f_eval(None, one, 4, None, 0, 0.02, 0, one, one, None, None, None) == _lib.ERR_INVALID_ARG
+    assert lib.d3f_eval(ctypes.byref(_views()), None, 0, None, 0, 0.02, 0, None, None, None, None, None, 0, None) == 0
+    assert lib.d3f_eval(None, one, 4, None, 0, 0.02, 0, one, one, None, None, None, 0, None) == _lib.ERR_INVALID_ARG
     assert b"views" in lib.d3f_last_error()
-    assert lib.d3f_eval(ctypes.byref(_views(V=0)), one, 4, None, 0, 0.02, 0, one, one, None, None, None) == _lib.ERR_BAD_SHAPE
-    assert lib.d3f_eval(ctypes.byref(_views(V=65)), one, 4, None, 0, 0.02, 0, one, one, None, None, None) == _lib.ERR_BAD_SHAPE
-    assert lib.d3f_eval(ctypes.byref(_views(W=1)), one, 4, None, 0, 0.02, 0, one, one, None, None, None) == _lib.ERR_BAD_SHAPE
-    assert lib.d3f_eval(ctypes.byref(_views()), None, 4, None, 0, 0.02, 0, one, one, None, None, None) == _lib.ERR_INVALID_ARG
-    assert lib.d3f_eval(ctypes.byref(_views()), one, -1, None, 0, 0.02, 0, one, one, None, None, None) == _lib.ERR_INVALID_ARG
-    assert lib.d3f_eval(ctypes.byref(_views()), one, 4, None, 0, 0.0, 0, one, one, None, None, None) == _lib.ERR_INVALID_ARG
-    assert lib.d3f_eval(ctypes.byref(_views()), one, 4, None, 9, 0.02, 0, one, one, None, None, None) == _lib.ERR_BAD_SHAPE
+    assert lib.d3f_eval(ctypes.byref(_views(V=0)), one, 4, None, 0, 0.02, 0, one, one, None, None, None, 0, None) == _lib.ERR_BAD_SHAPE
+    assert lib.d3f_eval(ctypes.byref(_views(V=65)), one, 4, None, 0, 0.02, 0, one, one, None, None, None, 0, None) == _lib.ERR_BAD_SHAPE
+    assert lib.d3f_eval(ctypes.byref(_views(W=1)), one, 4, None, 0, 0.02, 0, one, one, None, None, None, 0, None) == _lib.ERR_BAD_SHAPE
+    assert lib.d3f_eval(ctypes.byref(_views()), None, 4, None, 0, 0.02, 0, one, one, None, None, None, 0, None) == _lib.ERR_INVALID_ARG
+    assert lib.d3f_eval(ctypes.byref(_views()), one, -1, None, 0, 0.02, 0, one, one, None, None, None, 0, None) == _lib.ERR_INVALID_ARG
+    assert lib.d3f_eval(ctypes.byref(_views()), one, 4, None, 0, 0.0, 0, one, one, None, None, None, 0, None) == _lib.ERR_INVALID_ARG
+    assert lib.d3f_eval(ctypes.byref(_views()), one, 4, None, 9, 0.02, 0, one, one, None, None, None, 0, None) == _lib.ERR_BAD_SHAPE
     maps = (_lib.ChannelMap * 1)(_lib.ChannelMap(16, 4, 4, 8, 7, 128, 32, 8))
     outs = (ctypes.c_void_p * 1)(16)
-    assert lib.d3f_eval(ctypes.byref(_views()), one, 4, maps, 1, 0.02, 0, one, one, outs, None, None) == _lib.ERR_BAD_DTYPE
+    assert lib.d3f_eval(ctypes.byref(_views()), one, 4, maps, 1, 0.02, 0, one, one, outs, None, None, 0, None) == _lib.ERR_BAD_DTYPE
     maps[0].dtype = 0
     maps[0].stride_x = 4            # stride_x < C: not channels-last
-    assert lib.d3f_eval(ctypes.byref(_views()), one, 4, maps, 1, 0.02, 0, one, one, outs, None, None) == _lib.ERR_BAD_LAYOUT
+    assert lib.d3f_eval(ctypes.byref(_views()), one, 4, maps, 1, 0.02, 0, one, one, outs, None, None, 0, None) == _lib.ERR_BAD_LAYOUT
     assert lib.d3f_onehot2instance(one, 4, 0, one, None) == _lib.ERR_BAD_SHAPE
     assert lib.d3f_instance2onehot(None, 4, 3, one, None) == _lib.ERR_INVALID_ARG
     assert lib.d3f_similarity_to_target(one, 2, 2, 4, 8, 4, 1, one, 1.0, 5, 0, one, None, 0, None) == _lib.ERR_INVALID_ARG
@@ -83,6 +83,8 @@ def test_validation_returns_status_codes_not_aborts():
 
 def test_workspace_size():
     lib = _lib.load()
+    assert lib.d3f_eval_workspace_bytes(0) == 0
+    assert lib.d3f_eval_workspace_bytes(1000000) >= 16 * 1000000
     assert lib.d3f_softmax_workspace_bytes(0, 10) == 0
     assert lib.d3f_softmax_workspace_bytes(1, 1) == 2 * 16
     assert lib.d3f_softmax_workspace_bytes(100000, 300) == (391 + 1) * 300 * 16
