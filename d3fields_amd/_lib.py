@@ -48,6 +48,8 @@ SIGNATURES = {
     "d3f_eval": (ctypes.c_int, [ctypes.POINTER(Views), _vp, _i64, ctypes.POINTER(ChannelMap), _i32, _f32, _u32,
                                 _vp, _vp, ctypes.POINTER(_vp), ctypes.POINTER(_vp), _vp, _i64, _vp]),
     "d3f_eval_workspace_bytes": (_i64, [_i64]),
+    "d3f_eval_backward": (ctypes.c_int, [ctypes.POINTER(Views), _vp, _i64, ctypes.POINTER(ChannelMap), _i32, _f32,
+                                         _vp, ctypes.POINTER(_vp), _vp, _vp]),
     "d3f_eval_dist": (ctypes.c_int, [ctypes.POINTER(Views), _vp, _i64, _vp, _vp, _vp]),
     "d3f_onehot2instance": (ctypes.c_int, [_vp, _i64, _i32, _vp, _vp]),
     "d3f_instance2onehot": (ctypes.c_int, [_vp, _i64, _i32, _vp, _vp]),

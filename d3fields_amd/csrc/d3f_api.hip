@@ -62,6 +62,32 @@ void pick_mapping(d3f::MapDesc &m, bool can16, bool can8)
     }
 }
 
+// Validates one channel map and fills the kernel-side descriptor (out/inter may be NULL for backward).
+int fill_map(const d3f_channel_map &c, int s, int V, float *out, float *inter, const float *extra_aligned,
+             d3f::MapDesc &m, int64_t &map_bytes)
+{
+    if (!c.data) return fail(D3F_ERR_INVALID_ARG, "map %d: data pointer is NULL", s);
+    if (c.dtype != D3F_DTYPE_F32) return fail(D3F_ERR_BAD_DTYPE, "map %d: dtype %d unsupported (fp32 only)", s, c.dtype);
+    if (c.fh < 1 || c.fw < 1 || c.C < 1) return fail(D3F_ERR_BAD_SHAPE, "map %d: fh=%d fw=%d C=%d", s, c.fh, c.fw, c.C);
+    if (c.stride_x < c.C || c.stride_y < 0 || c.stride_v < 0)
+        return fail(D3F_ERR_BAD_LAYOUT, "map %d: strides (%lld,%lld,%lld) do not describe a channels-last map", s,
+                    (long long)c.stride_v, (long long)c.stride_y, (long long)c.stride_x);
+    m.data = static_cast<const float *>(c.data);
+    m.out = out;
+    m.inter = inter;
+    m.sv = c.stride_v; m.sy = c.stride_y; m.sx = c.stride_x;
+    m.fh = c.fh; m.fw = c.fw; m.C = c.C;
+    if (!aligned(m.data, 4) || !aligned(out, 4) || !aligned(extra_aligned, 4))
+        return fail(D3F_ERR_BAD_LAYOUT, "map %d: pointers must be 4-byte aligned", s);
+    const bool str16 = (c.stride_v % 4 == 0) && (c.stride_y % 4 == 0) && (c.stride_x % 4 == 0);
+    const bool str8 = (c.stride_v % 2 == 0) && (c.stride_y % 2 == 0) && (c.stride_x % 2 == 0);
+    const bool can16 = str16 && aligned(m.data, 16) && aligned(out, 16) && aligned(inter, 16) && aligned(extra_aligned, 16);
+    const bool can8 = str8 && aligned(m.data, 8) && aligned(out, 8) && aligned(inter, 8) && aligned(extra_aligned, 8);
+    pick_mapping(m, can16, can8);
+    map_bytes += (int64_t)V * c.fh * c.fw * c.C * 4;
+    return D3F_OK;
+}
+
 int tile_points_for(int V)
 {
     // LDS per workgroup = tile*V*16 B (+ small); keep it <= 32 KiB so >= 4 workgroups fit a CU.
@@ -96,26 +122,9 @@ int eval_common(const d3f_views *views, const float *pts, int64_t n, const d3f_c
     const int tl = (int)((flags >> 8) & 0xF);
     const int max_tile = tile_points_for(views->V) * 2;
     for (int s = 0; s < n_maps; ++s) {
-        const d3f_channel_map &c = maps[s];
-        d3f::MapDesc &m = P.maps[s];
-        if (!c.data || !out_fused[s]) return fail(D3F_ERR_INVALID_ARG, "map %d: data/out pointer is NULL", s);
-        if (c.dtype != D3F_DTYPE_F32) return fail(D3F_ERR_BAD_DTYPE, "map %d: dtype %d unsupported (fp32 only)", s, c.dtype);
-        if (c.fh < 1 || c.fw < 1 || c.C < 1) return fail(D3F_ERR_BAD_SHAPE, "map %d: fh=%d fw=%d C=%d", s, c.fh, c.fw, c.C);
-        if (c.stride_x < c.C || c.stride_y < 0 || c.stride_v < 0)
-            return fail(D3F_ERR_BAD_LAYOUT, "map %d: strides (%lld,%lld,%lld) do not describe a channels-last map", s,
-                        (long long)c.stride_v, (long long)c.stride_y, (long long)c.stride_x);
-        m.data = static_cast<const float *>(c.data);
-        m.out = out_fused[s];
-        m.inter = out_inter ? out_inter[s] : nullptr;
-        m.sv = c.stride_v; m.sy = c.stride_y; m.sx = c.stride_x;
-        m.fh = c.fh; m.fw = c.fw; m.C = c.C;
-        if (!aligned(m.data, 4) || !aligned(m.out, 4)) return fail(D3F_ERR_BAD_LAYOUT, "map %d: pointers must be 4-byte aligned", s);
-        const bool str16 = (c.stride_v % 4 == 0) && (c.stride_y % 4 == 0) && (c.stride_x % 4 == 0);
-        const bool str8 = (c.stride_v % 2 == 0) && (c.stride_y % 2 == 0) && (c.stride_x % 2 == 0);
-        const bool can16 = str16 && aligned(m.data, 16) && aligned(m.out, 16) && (!m.inter || aligned(m.inter, 16));
-        const bool can8 = str8 && aligned(m.data, 8) && aligned(m.out, 8) && (!m.inter || aligned(m.inter, 8));
-        pick_mapping(m, can16, can8);
-        map_bytes += (int64_t)views->V * c.fh * c.fw * c.C * 4;
+        if (!out_fused[s]) return fail(D3F_ERR_INVALID_ARG, "map %d: output pointer is NULL", s);
+        rc = fill_map(maps[s], s, views->V, out_fused[s], out_inter ? out_inter[s] : nullptr, nullptr, P.maps[s], map_bytes);
+        if (rc != D3F_OK) return rc;
     }
     // Maps far larger than the 256 MiB Infinity Cache: the kernel is bound by texel re-fetches, and
     // a smaller in-flight footprint wins (64-point tiles, 2 workgroups per CU: 3.2 -> 2.96 ms on C2
@@ -156,6 +165,35 @@ int d3f_eval(const d3f_views *views, const float *pts, int64_t n, const d3f_chan
 }
 
 int64_t d3f_eval_workspace_bytes(int64_t n) { return d3f::order_workspace_bytes(n); }
+
+int d3f_eval_backward(const d3f_views *views, const float *pts, int64_t n, const d3f_channel_map *maps, int32_t n_maps,
+                      float mu, const float *grad_dist, const float *const *grad_fused, float *grad_pts, void *stream)
+{
+    int rc = check_views(views);
+    if (rc != D3F_OK) return rc;
+    if (n < 0) return fail(D3F_ERR_INVALID_ARG, "n=%lld is negative", (long long)n);
+    if (n == 0) return D3F_OK;
+    if (!pts || !grad_pts) return fail(D3F_ERR_INVALID_ARG, "pts/grad_pts must be non-NULL");
+    if (n_maps < 0 || n_maps > D3F_MAX_MAPS) return fail(D3F_ERR_BAD_SHAPE, "n_maps=%d outside [0,%d]", n_maps, D3F_MAX_MAPS);
+    if (n_maps > 0 && (!maps || !grad_fused)) return fail(D3F_ERR_INVALID_ARG, "maps/grad_fused must be non-NULL when n_maps > 0");
+    if (!(mu > 0.0f)) return fail(D3F_ERR_INVALID_ARG, "mu must be > 0");
+    d3f::BackwardParams P;
+    P.depth = views->depth; P.K = views->K; P.pose = views->pose; P.pts = pts;
+    P.grad_dist = grad_dist; P.grad_pts = grad_pts;
+    P.n = n; P.V = views->V; P.H = views->H; P.W = views->W; P.n_maps = n_maps; P.mu = mu;
+    int64_t map_bytes = 0;
+    for (int s = 0; s < n_maps; ++s) {
+        P.grad_fused[s] = grad_fused[s];
+        rc = fill_map(maps[s], s, views->V, nullptr, nullptr, grad_fused[s], P.maps[s], map_bytes);
+        if (rc != D3F_OK) return rc;
+    }
+    int t = 128;                       // LDS: 44 B per (point, view)
+    while (t > 16 && (long)t * views->V * 44 > 60 * 1024) t >>= 1;
+    P.tile_pts = t;
+    if ((n + t - 1) / t > 0x7fffffffLL) return fail(D3F_ERR_BAD_SHAPE, "n=%lld needs more than 2^31 workgroups", (long long)n);
+    hipError_t e = d3f::launch_fused_backward(P, static_cast<hipStream_t>(stream));
+    return e == hipSuccess ? D3F_OK : hip_fail(e, "fused_eval_backward launch");
+}
 
 int d3f_eval_dist(const d3f_views *views, const float *pts, int64_t n, float *out_dist, uint8_t *out_valid,
                   void *stream)

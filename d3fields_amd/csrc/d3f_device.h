@@ -1,0 +1,85 @@
+// d3f_device.h -- device helpers shared by the forward and backward field-query kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace d3f {
+
+__device__ __forceinline__ float unnormalize(float g, int size)
+{
+    // grid_sample(align_corners=True): ((g+1)/2)*(size-1)
+    return ((g + 1.0f) / 2.0f) * (float)(size - 1);
+}
+
+__device__ __forceinline__ bool in_bounds(float x, float y, int fw, int fh)
+{
+    return (x > -1.0f) && (x < (float)fw) && (y > -1.0f) && (y < (float)fh);
+}
+
+// clang extended vectors: elementwise * + / are native, fma is explicit.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+template <int VW> struct Vec;
+template <> struct Vec<4> { using T = f32x4; };
+template <> struct Vec<2> { using T = f32x2; };
+template <> struct Vec<1> { using T = float; };
+
+template <typename VT> __device__ __forceinline__ VT v_fma(VT a, float s, VT c) { return __builtin_elementwise_fma(a, (VT)s, c); }
+template <> __device__ __forceinline__ float v_fma<float>(float a, float s, float c) { return fmaf(a, s, c); }
+
+template <typename VT> __device__ __forceinline__ VT load_vec(const float *p) { return *reinterpret_cast<const VT *>(p); }
+template <typename VT> __device__ __forceinline__ void store_vec(float *p, VT v) { *reinterpret_cast<VT *>(p) = v; }
+
+
+template <typename VT> __device__ __forceinline__ float hsum(VT v);
+template <> __device__ __forceinline__ float hsum<f32x4>(f32x4 v) { return (v.x + v.y) + (v.z + v.w); }
+template <> __device__ __forceinline__ float hsum<f32x2>(f32x2 v) { return v.x + v.y; }
+template <> __device__ __forceinline__ float hsum<float>(float v) { return v; }
+
+// One view's projection of one point: the arithmetic contract of DESIGN.md section 2
+// (reference fusion.py:45-55, 72-73), shared so that forward and backward agree bit for bit.
+struct Proj {
+    float gx, gy, zc, u, w;
+    bool ok;
+};
+
+__device__ __forceinline__ Proj project_point(const float *M, float px, float py, float pz, float Wm1, float Hm1)
+{
+    Proj r;
+    float xc = ((M[0] * px + M[1] * py) + M[2] * pz) + M[3] * 1.0f;
+    float yc = ((M[4] * px + M[5] * py) + M[6] * pz) + M[7] * 1.0f;
+    float zc = ((M[8] * px + M[9] * py) + M[10] * pz) + M[11] * 1.0f;
+    r.ok = !(fabsf(zc) < 1e-4f);                                    // fusion.py:52
+    if (!r.ok) zc = 1e-3f;                                          // fusion.py:53
+    r.u = xc / zc;                                                  // fusion.py:54
+    r.w = yc / zc;
+    r.gx = r.u / Wm1 * 2.0f - 1.0f;                                 // fusion.py:72
+    r.gy = r.w / Hm1 * 2.0f - 1.0f;                                 // fusion.py:73
+    r.zc = zc;
+    return r;
+}
+
+// KRt = K @ pose (fusion.py:44): k-sequential, unfused, like the 3x3@3x4 bmm on the host
+__device__ __forceinline__ void compute_krt(const float *K, const float *pose, int V, float *krt, int nthreads)
+{
+    for (int t = threadIdx.x; t < V * 12; t += nthreads) {
+        const int v = t / 12, ij = t % 12, i = ij / 4, j = ij % 4;
+        const float *Kv = K + v * 9, *Rv = pose + v * 12;
+        float acc = 0.0f;
+        for (int k = 0; k < 3; ++k) {
+            const float pr = Kv[i * 3 + k] * Rv[k * 4 + j];
+            acc = acc + pr;
+        }
+        krt[t] = acc;
+    }
+}
+
+// nearest depth pixel with zeros padding (fusion.py:327-333)
+__device__ __forceinline__ float nearest_depth(const float *depth, int v, int H, int W, float gx, float gy)
+{
+    const float rx = rintf(unnormalize(gx, W)), ry = rintf(unnormalize(gy, H));
+    float d = 0.0f;
+    if (in_bounds(rx, ry, W, H)) d = depth[((int64_t)v * H + (int64_t)ry) * W + (int64_t)rx];
+    return d;
+}
+
+}  // namespace d3f

@@ -40,6 +40,21 @@ struct EvalParams {
 
 hipError_t launch_fused_eval(const EvalParams &P, int mode, hipStream_t stream);
 
+// fuse_backward.hip
+struct BackwardParams {
+    const float *depth, *K, *pose, *pts;
+    const float *grad_dist;                    // [n] or nullptr
+    const float *grad_fused[D3F_MAX_MAPS];     // [n, C_k] or nullptr
+    float *grad_pts;                           // [n, 3]
+    int64_t n;
+    int32_t V, H, W;
+    int32_t n_maps;
+    int32_t tile_pts;
+    float mu;
+    MapDesc maps[D3F_MAX_MAPS];                // out / inter unused
+};
+hipError_t launch_fused_backward(const BackwardParams &P, hipStream_t stream);
+
 // order_kernels.hip
 int64_t order_workspace_bytes(int64_t n);
 hipError_t build_point_order(const float *pts, int64_t n, void *workspace, int64_t workspace_bytes,

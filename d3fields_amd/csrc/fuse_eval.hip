@@ -22,6 +22,7 @@
 #include <stdint.h>
 
 #include "d3f_internal.h"
+#include "d3f_device.h"
 
 namespace d3f {
 
@@ -32,33 +33,6 @@ struct ViewRec {
     float wgt;      // exp(clamp(mu-|dist|,max=0)/mu)  (fusion.py:347)
     float valid;    // 1.0f / 0.0f                     (fusion.py:344)
 };
-
-__device__ __forceinline__ float unnormalize(float g, int size)
-{
-    // grid_sample(align_corners=True): ((g+1)/2)*(size-1)
-    return ((g + 1.0f) / 2.0f) * (float)(size - 1);
-}
-
-__device__ __forceinline__ bool in_bounds(float x, float y, int fw, int fh)
-{
-    return (x > -1.0f) && (x < (float)fw) && (y > -1.0f) && (y < (float)fh);
-}
-
-// ---- phase B: bilinear gather + view reduction for one map -----------------------------
-
-// clang extended vectors: elementwise * + / are native, fma is explicit.
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-template <int VW> struct Vec;
-template <> struct Vec<4> { using T = f32x4; };
-template <> struct Vec<2> { using T = f32x2; };
-template <> struct Vec<1> { using T = float; };
-
-template <typename VT> __device__ __forceinline__ VT v_fma(VT a, float s, VT c) { return __builtin_elementwise_fma(a, (VT)s, c); }
-template <> __device__ __forceinline__ float v_fma<float>(float a, float s, float c) { return fmaf(a, s, c); }
-
-template <typename VT> __device__ __forceinline__ VT load_vec(const float *p) { return *reinterpret_cast<const VT *>(p); }
-template <typename VT> __device__ __forceinline__ void store_vec(float *p, VT v) { *reinterpret_cast<VT *>(p) = v; }
 
 // Gathers map `m` for the points of this workgroup's tile.
 //   VW  channel-vector width in floats (4 when C%4==0 and 16-B aligned, else 2 or 1)
@@ -177,17 +151,7 @@ __global__ __launch_bounds__(kBlock) void fused_eval_kernel(const EvalParams P)
     uint32_t *idx_s = flag_s + TP;                                           // [TP] global point index
     float *krt = reinterpret_cast<float *>(idx_s + TP);                      // [V*12]
 
-    // KRt = K @ pose (fusion.py:44): k-sequential, unfused, like the 3x3@3x4 bmm on the host
-    for (int t = threadIdx.x; t < V * 12; t += kBlock) {
-        const int v = t / 12, ij = t % 12, i = ij / 4, j = ij % 4;
-        const float *Kv = P.K + v * 9, *Rv = P.pose + v * 12;
-        float acc = 0.0f;
-        for (int k = 0; k < 3; ++k) {
-            const float pr = Kv[i * 3 + k] * Rv[k * 4 + j];
-            acc = acc + pr;
-        }
-        krt[t] = acc;
-    }
+    compute_krt(P.K, P.pose, V, krt, kBlock);
     __syncthreads();
 
     const int64_t ntiles = (P.n + TP - 1) / TP;
@@ -205,21 +169,10 @@ __global__ __launch_bounds__(kBlock) void fused_eval_kernel(const EvalParams P)
         float dsum = 0.0f, cnt = 0.0f;
         bool nonfinite = false;
         for (int v = 0; v < V; ++v) {
-            const float *M = krt + v * 12;
-            // fusion.py:45-46: 4x4 @ 4x1, four rounded products summed left to right
-            float xc = ((M[0] * px + M[1] * py) + M[2] * pz) + M[3] * 1.0f;
-            float yc = ((M[4] * px + M[5] * py) + M[6] * pz) + M[7] * 1.0f;
-            float zc = ((M[8] * px + M[9] * py) + M[10] * pz) + M[11] * 1.0f;
-            const bool ok = !(fabsf(zc) < 1e-4f);                           // fusion.py:52
-            if (!ok) zc = 1e-3f;                                            // fusion.py:53
-            const float uu = xc / zc, ww = yc / zc;                         // fusion.py:54
-            const float gx = uu / Wm1 * 2.0f - 1.0f;                        // fusion.py:72
-            const float gy = ww / Hm1 * 2.0f - 1.0f;                        // fusion.py:73
-            // nearest depth pixel, zeros padding (fusion.py:327-333)
-            const float rx = rintf(unnormalize(gx, P.W)), ry = rintf(unnormalize(gy, P.H));
-            float d = 0.0f;
-            if (in_bounds(rx, ry, P.W, P.H))
-                d = P.depth[((int64_t)v * P.H + (int64_t)ry) * P.W + (int64_t)rx];
+            const Proj pr = project_point(krt + v * 12, px, py, pz, Wm1, Hm1);
+            const float gx = pr.gx, gy = pr.gy, zc = pr.zc;
+            const bool ok = pr.ok;
+            const float d = nearest_depth(P.depth, v, P.H, P.W, gx, gy);
             float dist = d - zc;                                            // fusion.py:343
             bool valid;
             float wgt = 1.0f;

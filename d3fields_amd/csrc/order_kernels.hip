@@ -5,7 +5,8 @@
 // Cache) the fused kernel is bound by texel re-fetches; points that are close in 3-D project
 // close together in EVERY view, so walking the points along a Morton curve keeps the in-flight
 // texel footprint compact (measured 3.2 -> 2.8 ms on the 985 600-point grid, 3.4 -> 2.6 ms on a
-// shuffled cloud).  Keys are 30-bit Morton codes of the 4-mm cell of each point; the pairs
+// shuffled cloud).  Keys are 21-bit Morton codes of the 16-mm cell of each point (a 64..128-point
+// tile spans a few such cells; the stable sort keeps the caller's order inside a cell); the pairs
 // (key, index) are sorted with rocPRIM's device radix sort in caller-provided workspace and the
 // fused kernel then reads its points through the index array.
 #include <cstring>
@@ -19,7 +20,7 @@ namespace d3f {
 
 __device__ __forceinline__ uint32_t spread3(uint32_t x)
 {
-    x &= 0x3ffu;
+    x &= 0x7fu;                       // 7 bits per axis -> 21-bit keys (3 radix passes)
     x = (x | (x << 16)) & 0x030000ffu;
     x = (x | (x << 8)) & 0x0300f00fu;
     x = (x | (x << 4)) & 0x030c30c3u;
@@ -44,6 +45,8 @@ __global__ __launch_bounds__(kBlock) void morton_keys_kernel(const float *__rest
 
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
+constexpr float kCell = 0.016f;          // 16-mm cells x 128 per axis = 2.05 m before keys wrap (harmless)
+constexpr unsigned kKeyBits = 21;
 constexpr size_t kSortScratch = 8u << 20;   // rocPRIM histogram/scan scratch (it needs far less)
 
 int64_t order_workspace_bytes(int64_t n)
@@ -64,15 +67,15 @@ hipError_t build_point_order(const float *pts, int64_t n, void *workspace, int64
     uint32_t *v0 = reinterpret_cast<uint32_t *>(base + 2 * seg), *v1 = reinterpret_cast<uint32_t *>(base + 3 * seg);
     void *scratch = base + 4 * seg;
     hipLaunchKernelGGL(morton_keys_kernel, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream, pts, n,
-                       1.0f / 0.004f, k0, v0);
+                       1.0f / kCell, k0, v0);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     rocprim::double_buffer<uint32_t> keys(k0, k1), vals(v0, v1);
     size_t need = 0;
-    e = rocprim::radix_sort_pairs(nullptr, need, keys, vals, (size_t)n, 0u, 30u, stream);
+    e = rocprim::radix_sort_pairs(nullptr, need, keys, vals, (size_t)n, 0u, kKeyBits, stream);
     if (e != hipSuccess) return e;
     if (need > kSortScratch) return hipErrorOutOfMemory;
-    e = rocprim::radix_sort_pairs(scratch, need, keys, vals, (size_t)n, 0u, 30u, stream);
+    e = rocprim::radix_sort_pairs(scratch, need, keys, vals, (size_t)n, 0u, kKeyBits, stream);
     if (e != hipSuccess) return e;
     *order_out = vals.current();
     return hipSuccess;

@@ -86,6 +86,21 @@ def onehot2instance(one_hot_mask):
     raise NotImplementedError
 
 
+class _FieldQueryFn(torch.autograd.Function):
+    """Fusion.eval as an autograd node: forward = d3f_eval, backward = d3f_eval_backward (both HIP)."""
+
+    @staticmethod
+    def forward(ctx, pts, fusion, names):
+        outputs, saved = fusion._launch(pts.detach(), names, False, "eval")
+        ctx.fusion, ctx.saved = fusion, saved
+        ctx.mark_non_differentiable(outputs["valid_mask"])
+        return (outputs["dist"], outputs["valid_mask"]) + tuple(outputs[k] for k in names)
+
+    @staticmethod
+    def backward(ctx, grad_dist, _grad_valid, *grad_fused):
+        return ctx.fusion._backward(ctx.saved, grad_dist, grad_fused), None, None
+
+
 # ----------------------------------------------------------------------------------------
 class Fusion:
     """Multi-view 3-D descriptor field (query side).
@@ -153,9 +168,6 @@ class Fusion:
         assert pts.shape[1] == 3
         if not pts.is_cuda:
             raise RuntimeError("Fusion.eval: pts must be on the ROCm device (%s); there is no CPU path" % self.device)
-        if pts.requires_grad and torch.is_grad_enabled():
-            raise NotImplementedError("autograd through Fusion.eval (rigid_tracking) is not built yet; "
-                                      "wrap the call in torch.no_grad() or detach pts")
         if pts.dtype != torch.float32:
             raise TypeError("Fusion.eval: pts must be float32, got %s" % pts.dtype)
 
@@ -183,6 +195,20 @@ class Fusion:
 
     def _run(self, pts, return_names, return_inter, mode):
         self._check_query(pts)
+        if pts.requires_grad and torch.is_grad_enabled():
+            # autograd consumer: rigid_tracking back-propagates through eval (fusion.py:1650-1665)
+            if mode != "eval" or return_inter:
+                raise NotImplementedError("gradients are implemented for Fusion.eval(pts, return_names) only "
+                                          "(not eval_dist / return_inter); detach pts or use torch.no_grad()")
+            names = list(return_names)
+            flat = _FieldQueryFn.apply(pts, self, names)
+            out = {"dist": flat[0], "valid_mask": flat[1]}
+            out.update(zip(names, flat[2:]))
+            return out
+        return self._launch(pts, return_names, return_inter, mode)[0]
+
+    def _launch(self, pts, return_names, return_inter, mode):
+        """Enqueues the forward kernel; returns (outputs, tensors the launch read)."""
         dev = pts.device
         lib = self._lib
         n = pts.shape[0]
@@ -195,7 +221,7 @@ class Fusion:
             stream = _lib.current_stream_handle(dev)
             if mode == "eval_dist":
                 _lib.check(lib.d3f_eval_dist(ctypes.byref(views), _lib.ptr(pts_c), n, _lib.ptr(dist), _lib.ptr(valid), stream))
-                return outputs
+                return outputs, None
             names = list(return_names)
             if len(names) > _lib.MAX_MAPS:
                 raise ValueError("at most %d return_names per call" % _lib.MAX_MAPS)
@@ -203,6 +229,7 @@ class Fusion:
             fused = (ctypes.c_void_p * max(len(names), 1))()
             inter = (ctypes.c_void_p * max(len(names), 1))()
             finite = self._is_finite("depth", keep[0])
+            used_maps = []
             for s, k in enumerate(names):
                 m = self.curr_obs_torch[k]                 # KeyError for unknown names, like the reference
                 if not isinstance(m, torch.Tensor) or m.dim() != 4 or m.shape[0] != V:
@@ -213,6 +240,7 @@ class Fusion:
                     m = m.contiguous()
                     keep.append(m)
                 finite = finite and self._is_finite(k, m)
+                used_maps.append(m)
                 C = m.shape[3]
                 o = torch.empty((n, C), dtype=torch.float32, device=dev)
                 outputs[k] = o
@@ -231,7 +259,32 @@ class Fusion:
             _lib.check(lib.d3f_eval(ctypes.byref(views), _lib.ptr(pts_c), n, maps, len(names), self.mu, flags,
                                     _lib.ptr(dist), _lib.ptr(valid), fused, inter if return_inter else None,
                                     _lib.ptr(ws), ws_bytes, stream))
-        return outputs
+        return outputs, (pts_c, keep[0], keep[1], keep[2], used_maps)
+
+    def _backward(self, saved, grad_dist, grad_fused):
+        """d3f_eval_backward on the tensors the forward launch read."""
+        pts_c, depth, K, pose, used_maps = saved
+        dev = pts_c.device
+        n, V = pts_c.shape[0], depth.shape[0]
+        views = _lib.Views(V, depth.shape[1], depth.shape[2], _lib.ptr(depth), _lib.ptr(K), _lib.ptr(pose))
+        grad_pts = torch.empty((n, 3), dtype=torch.float32, device=dev)
+        nm = len(used_maps)
+        maps = (_lib.ChannelMap * max(nm, 1))()
+        gptr = (ctypes.c_void_p * max(nm, 1))()
+        hold = []
+        for s, m in enumerate(used_maps):
+            maps[s] = _lib.ChannelMap(m.data_ptr(), m.shape[1], m.shape[2], m.shape[3], _lib.DTYPE_F32,
+                                      m.stride(0), m.stride(1), m.stride(2))
+            g = grad_fused[s]
+            if g is not None:
+                g = g.to(torch.float32).contiguous()
+                hold.append(g)
+                gptr[s] = g.data_ptr()
+        gd = grad_dist.to(torch.float32).contiguous() if grad_dist is not None else None
+        with torch.cuda.device(dev):
+            _lib.check(self._lib.d3f_eval_backward(ctypes.byref(views), _lib.ptr(pts_c), n, maps, nm, self.mu, _lib.ptr(gd),
+                                                   gptr, _lib.ptr(grad_pts), _lib.current_stream_handle(dev)))
+        return grad_pts
 
     def eval(self, pts, return_names=["dino_feats", "mask"], return_inter=False):
         """Reference Fusion.eval (fusion.py:305-394).

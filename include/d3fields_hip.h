@@ -105,6 +105,15 @@ int d3f_eval(const d3f_views *views, const float *pts, int64_t n, const d3f_chan
  * (Morton) order when the maps are much larger than the caches; outputs are unaffected. */
 int64_t d3f_eval_workspace_bytes(int64_t n);
 
+/* Gradient of d3f_eval's outputs w.r.t. the query points: what autograd through Fusion.eval gives
+ * the reference's rigid_tracking (fusion.py:1643-1665).  grad_dist: [n] or NULL; grad_fused: host
+ * array of n_maps device pointers ([n,C_k], entries may be NULL); grad_pts [n,3] is overwritten.
+ * Differentiable paths: projection -> bilinear coordinates, exp weight, clamped distance;
+ * nearest-depth lookup, validity and the view count carry no gradient (as in torch). */
+int d3f_eval_backward(const d3f_views *views, const float *pts, int64_t n, const d3f_channel_map *maps,
+                      int32_t n_maps, float mu, const float *grad_dist, const float *const *grad_fused,
+                      float *grad_pts, void *stream);
+
 /* Replaces Fusion.eval_dist (fusion.py:396-436): no -mu gate, no clamp, no 1e3 sentinel. */
 int d3f_eval_dist(const d3f_views *views, const float *pts, int64_t n, float *out_dist,
                   uint8_t *out_valid, void *stream);

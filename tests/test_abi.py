@@ -70,6 +70,8 @@ def test_validation_returns_status_codes_not_aborts():
     maps[0].dtype = 0
     maps[0].stride_x = 4            # stride_x < C: not channels-last
     assert lib.d3f_eval(ctypes.byref(_views()), one, 4, maps, 1, 0.02, 0, one, one, outs, None, None, 0, None) == _lib.ERR_BAD_LAYOUT
+    assert lib.d3f_eval_backward(ctypes.byref(_views()), one, 4, None, 0, 0.02, None, None, None, None) == _lib.ERR_INVALID_ARG
+    assert lib.d3f_eval_backward(ctypes.byref(_views()), None, 0, None, 0, 0.02, None, None, None, None) == 0
     assert lib.d3f_onehot2instance(one, 4, 0, one, None) == _lib.ERR_BAD_SHAPE
     assert lib.d3f_instance2onehot(None, 4, 3, one, None) == _lib.ERR_INVALID_ARG
     assert lib.d3f_similarity_to_target(one, 2, 2, 4, 8, 4, 1, one, 1.0, 5, 0, one, None, 0, None) == _lib.ERR_INVALID_ARG

@@ -391,3 +391,83 @@ def _eval_with_workspace(f, pts):
                             _lib.ptr(out["valid_mask"]), fused, inter, _lib.ptr(ws), nb, _lib.current_stream_handle(dev)))
     torch.cuda.synchronize()
     return out
+
+
+# ---------------------------------------------------------------------------------------
+# backward: d(loss)/d(pts) as the reference's autograd gives rigid_tracking
+# ---------------------------------------------------------------------------------------
+GRAD_TOL = 2e-5     # fp32 dot products over C channels in another order than autograd's; rel. to max |grad|
+
+
+def test_backward_vs_reference_golden(dev):
+    g = load_golden("grad_500")
+    f = make_fusion(dev, g["depth"], g["K"], g["pose"], {"dino_feats": g["in_dino_feats"]}, g["H"], g["W"], float(g["mu"]))
+    pts = torch.from_numpy(g["pts"]).to(dev).requires_grad_(True)
+    out = f.eval(pts, return_names=["dino_feats"])
+    assert out["dino_feats"].requires_grad and out["dist"].requires_grad and not out["valid_mask"].requires_grad
+    (out["dino_feats"].sum() + out["dist"].sum()).backward()
+    assert np.array_equal(cpu(out["dist"]), g["dist"])
+    assert rel_err(cpu(pts.grad), g["grad_pts"]) <= GRAD_TOL
+
+
+@pytest.mark.parametrize("kind,V,fhw,C,names", [
+    ("smooth", 4, (12, 16), 384, ["dino_feats"]),
+    ("stress", 3, (48, 64), 10, ["dino_feats", "mask", "color_tensor"]),
+    ("smooth", 9, (6, 8), 7, ["dino_feats", "mask"]),
+])
+def test_backward_vs_torch_port_autograd(dev, kind, V, fhw, C, names):
+    """Random upstream gradients (not just sum()) against autograd through the torch-ops port,
+    which is itself pinned to the reference's gradient (test_torch_port_gradient_matches_reference)."""
+    from d3fields_amd import synth
+    from oracle import torch_port
+    H, W, N = 48, 64, 3000
+    sc = synth.make_scene(V, H, W, kind)
+    maps = {"dino_feats": synth.random_map(V, fhw[0], fhw[1], C, seed=1), "mask": synth.random_onehot_mask(V, H, W, 5, seed=2),
+            "color_tensor": torch.rand(V, H, W, 3, generator=torch.Generator().manual_seed(4))}
+    f = make_fusion(dev, sc["depth"], sc["K"], sc["pose"], maps, H, W)
+    pts = synth.random_cloud(N, seed=6)
+    gen = torch.Generator().manual_seed(7)
+    w_dist = torch.randn(N, generator=gen)
+    w_k = {k: torch.randn(N, maps[k].shape[3], generator=gen) for k in names}
+
+    p_ref = pts.clone().requires_grad_(True)
+    obs = dict(sc)
+    obs.update(maps)
+    o_ref = torch_port.field_query(obs, p_ref, names, H, W)
+    ((o_ref["dist"] * w_dist).sum() + sum((o_ref[k] * w_k[k]).sum() for k in names)).backward()
+
+    p_gpu = pts.to(dev).requires_grad_(True)
+    o = f.eval(p_gpu, return_names=names)
+    ((o["dist"] * w_dist.to(dev)).sum() + sum((o[k] * w_k[k].to(dev)).sum() for k in names)).backward()
+    assert rel_err(cpu(p_gpu.grad), p_ref.grad.numpy()) <= GRAD_TOL
+    # only-dist and only-feature losses (None upstream gradients reach the C ABI as NULL)
+    p2 = pts.to(dev).requires_grad_(True)
+    f.eval(p2, return_names=names)["dist"].sum().backward()
+    p3 = pts.clone().requires_grad_(True)
+    torch_port.field_query(obs, p3, names, H, W)["dist"].sum().backward()
+    assert rel_err(cpu(p2.grad), p3.grad.numpy()) <= GRAD_TOL
+
+
+def test_rigid_tracking_style_loop(dev):
+    """A few Adam steps on a rigid translation, as fusion.py:1643-1665 does, run end to end on the HIP path."""
+    from d3fields_amd import synth
+    V, H, W = 4, 96, 128
+    sc = synth.make_scene(V, H, W, "smooth")
+    feats = synth.random_map(V, 12, 16, 32, seed=1)
+    f = make_fusion(dev, sc["depth"], sc["K"], sc["pose"], {"dino_feats": feats}, H, W)
+    src = synth.random_cloud(400, seed=9).to(dev)
+    with torch.no_grad():
+        tgt = f.eval(src, return_names=["dino_feats"])["dino_feats"]
+    t = torch.tensor([0.004, -0.003, 0.002], device=dev, requires_grad=True)
+    opt = torch.optim.Adam([t], lr=5e-4)
+    losses = []
+    for _ in range(25):
+        opt.zero_grad()
+        out = f.eval(src + t, return_names=["dino_feats"])
+        loss = torch.norm(out["dino_feats"] - tgt, dim=1).mean() + 100 * torch.relu(out["dist"]).mean()
+        loss.backward()
+        opt.step()
+        losses.append(float(loss))
+    assert losses[-1] < losses[0]
+    with pytest.raises(NotImplementedError):
+        f.eval_dist(src.clone().requires_grad_(True))
