@@ -75,6 +75,7 @@ int fill_map(const d3f_channel_map &c, int s, int V, float *out, float *inter, c
     m.data = static_cast<const float *>(c.data);
     m.out = out;
     m.inter = inter;
+    m.staged = 0;
     m.sv = c.stride_v; m.sy = c.stride_y; m.sx = c.stride_x;
     m.fh = c.fh; m.fw = c.fw; m.C = c.C;
     if (!aligned(m.data, 4) || !aligned(out, 4) || !aligned(extra_aligned, 4))
@@ -86,6 +87,31 @@ int fill_map(const d3f_channel_map &c, int s, int V, float *out, float *inter, c
     pick_mapping(m, can16, can8);
     map_bytes += (int64_t)V * c.fh * c.fw * c.C * 4;
     return D3F_OK;
+}
+
+// Staged gather (fuse_eval.hip): 16-B vectors, at most 32 lanes per point and 3 vectors per lane so that
+// 4 points per lane group keep their accumulators in registers; wide (>= 256 B per texel) maps whose
+// texels span >= 4 image pixels, i.e. the patch-resolution feature maps of the reference.
+bool staging_candidate(const d3f::MapDesc &m, int H, int W)
+{
+    return m.vw == 4 && m.C >= 64 && (W - 1) >= 4 * (m.fw - 1) && (H - 1) >= 4 * (m.fh - 1);
+}
+
+void pick_staged_mapping(d3f::MapDesc &m)
+{
+    const int cvec = m.C / 4;
+    long best_slots = -1;
+    int best_passes = 0;
+    for (int lg = 5; lg >= 3; --lg)
+        for (int u = 3; u >= 1; --u) {
+            const int per = (1 << lg) * u;
+            const int passes = (cvec + per - 1) / per;
+            const long slots = (long)passes * per;
+            if (best_slots < 0 || slots < best_slots || (slots == best_slots && passes < best_passes)) {
+                best_slots = slots; best_passes = passes; m.lpp_log2 = lg; m.unroll = u;
+            }
+        }
+    m.staged = 1;
 }
 
 int tile_points_for(int V)
@@ -112,7 +138,7 @@ int eval_common(const d3f_views *views, const float *pts, int64_t n, const d3f_c
 
     d3f::EvalParams P;
     P.depth = views->depth; P.K = views->K; P.pose = views->pose; P.pts = pts;
-    P.order = nullptr; P.lds_pad = 0;
+    P.order = nullptr; P.lds_pad = 0; P.stage_floats = 0;
     int64_t map_bytes = 0;
     P.out_dist = out_dist; P.out_valid = out_valid;
     P.n = n; P.V = views->V; P.H = views->H; P.W = views->W;
@@ -137,10 +163,21 @@ int eval_common(const d3f_views *views, const float *pts, int64_t n, const d3f_c
     hipStream_t hs = static_cast<hipStream_t>(stream);
     const bool may_reorder = workspace && n_maps > 0 && n <= 0x7fffffffLL && !(flags & D3F_TUNE_NO_REORDER) &&
                              workspace_bytes >= d3f::order_workspace_bytes(n);
-    if (may_reorder && ((flags & D3F_TUNE_FORCE_REORDER) || (n >= 65536 && map_bytes > (64LL << 20)))) {
+    bool stage_any = false;
+    if (!(flags & D3F_TUNE_NO_STAGING) && views->V * 16 * 32 <= 16 * 1024)
+        for (int s = 0; s < n_maps; ++s) stage_any |= staging_candidate(P.maps[s], views->H, views->W);
+    if (may_reorder && ((flags & D3F_TUNE_FORCE_REORDER) || (n >= 65536 && (map_bytes > (64LL << 20) || stage_any)))) {
         hipError_t eo = d3f::build_point_order(pts, n, workspace, workspace_bytes, &P.order, hs);
         if (eo != hipSuccess) return hip_fail(eo, "point ordering");
     }
+    // texel windows only fit LDS when the tiles are spatially compact, i.e. on the Morton walk
+    if (stage_any && P.order && !(tl >= 5 && tl <= 8)) {
+        for (int s = 0; s < n_maps; ++s)
+            if (staging_candidate(P.maps[s], views->H, views->W)) pick_staged_mapping(P.maps[s]);
+        P.tile_pts = 32;
+        P.stage_floats = d3f::kStageFloats;
+    }
+    P.stage_offset = d3f::fused_lds_base(P.tile_pts, views->V);
     const int64_t ntiles = (n + P.tile_pts - 1) / P.tile_pts;
     if (ntiles > 0x7fffffffLL) return fail(D3F_ERR_BAD_SHAPE, "n=%lld needs more than 2^31 workgroups", (long long)n);
     hipError_t e = d3f::launch_fused_eval(P, mode, hs);

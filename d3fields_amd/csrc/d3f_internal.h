@@ -21,6 +21,7 @@ struct MapDesc {
     int32_t vw;        // channel-vector width in floats: 4, 2 or 1
     int32_t lpp_log2;  // log2(lanes per point) in phase B
     int32_t unroll;    // channel vectors per lane per pass (1..4)
+    int32_t staged;    // 1: gather through the LDS texel window (low-resolution wide maps, Morton-ordered tiles)
 };
 
 struct EvalParams {
@@ -33,11 +34,16 @@ struct EvalParams {
     int32_t n_maps;
     int32_t tile_pts;  // points per workgroup
     int32_t lds_pad;   // extra dynamic LDS bytes (occupancy throttle, tuning only)
+    int32_t stage_offset;  // byte offset of the two LDS stage buffers (staged maps), 16-B aligned
+    int32_t stage_floats;  // floats per stage buffer, 0 = no staged map
     uint32_t flags;
     float mu;
     MapDesc maps[D3F_MAX_MAPS];
 };
 
+// LDS bytes in front of the stage buffers: records, cnt/flag/idx, KRt, per-view windows
+inline int fused_lds_base(int tile_pts, int V) { return ((tile_pts * V * 16 + tile_pts * 12 + V * 48 + V * 16) + 15) / 16 * 16; }
+constexpr int kStageFloats = 6144;      // 24 KiB per stage buffer: 16 texels of 384 fp32 channels
 hipError_t launch_fused_eval(const EvalParams &P, int mode, hipStream_t stream);
 
 // fuse_backward.hip

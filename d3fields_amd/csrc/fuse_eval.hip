@@ -115,6 +115,165 @@ __device__ __forceinline__ void gather_map(const MapDesc &m, const EvalParams &P
     }
 }
 
+// ---- phase B, staged variant: low-resolution wide maps (patch-resolution DINO features) -----------
+// When a map has far fewer texels than the image has pixels (the reference's dino_feats is
+// (H/10, W/10), fusion.py:694-697) the points of a spatially compact tile fall into a handful of
+// texel cells: 32 Morton-ordered points touch ~9-16 distinct texels per view but issue 128 corner
+// reads.  The direct gather then runs at the L1 rate (measured 23 TB/s of texel reads, 85 % L2 hits);
+// here the tile's texel window of each view is copied ONCE into LDS (coalesced 16-B loads) and the
+// corner reads become ds_read_b128 -- LDS has ~4x the per-CU bandwidth of the vector L1.
+// The arithmetic and its order are exactly those of gather_map, so results are bit-identical; a view
+// whose window does not fit the stage buffer is gathered directly from global memory.
+// Requires VW == 4, 1<<lpp_log2 <= 32 and tile_n <= 32 (host-enforced).
+constexpr int kStagedPPG = 4;               // points per lane group (kStagedTile / (256/32))
+
+template <int U, bool FROM_LDS>
+__device__ __forceinline__ void staged_accumulate(const MapDesc &m, const EvalParams &P, const ViewRec &r, int v, int64_t i,
+                                                  int c0, int lpp, int g, int cvec, const float *__restrict__ buf,
+                                                  int xmin, int ymin, int bw, int pass_vecs, f32x4 (&acc)[U])
+{
+    using VT = f32x4;
+    const float ix = unnormalize(r.gx, m.fw), iy = unnormalize(r.gy, m.fh);
+    const float x0 = floorf(ix), y0 = floorf(iy);
+    const float tx = ix - x0, ty = iy - y0;
+    const float ex = 1.0f - tx, sy = 1.0f - ty;
+    const float wnw = sy * ex, wne = sy * tx, wsw = ty * ex, wse = ty * tx;
+    const float x1 = x0 + 1.0f, y1 = y0 + 1.0f;
+    const bool inw = in_bounds(x0, y0, m.fw, m.fh), ine = in_bounds(x1, y0, m.fw, m.fh);
+    const bool isw = in_bounds(x0, y1, m.fw, m.fh), ise = in_bounds(x1, y1, m.fw, m.fh);
+    const int xi0 = (inw || isw) ? (int)x0 : 0, yi0 = (inw || ine) ? (int)y0 : 0;
+    const int xi1 = (ine || ise) ? (int)x1 : 0, yi1 = (isw || ise) ? (int)y1 : 0;
+    const float *pnw, *pne, *psw, *pse;
+    if (FROM_LDS) {
+        const int tstride = pass_vecs * 4;                      // floats per staged texel
+        pnw = buf + ((yi0 - ymin) * bw + (xi0 - xmin)) * tstride;
+        pne = buf + ((yi0 - ymin) * bw + (xi1 - xmin)) * tstride;
+        psw = buf + ((yi1 - ymin) * bw + (xi0 - xmin)) * tstride;
+        pse = buf + ((yi1 - ymin) * bw + (xi1 - xmin)) * tstride;
+    } else {
+        const float *bv = m.data + (int64_t)v * m.sv + (int64_t)c0 * 4;
+        pnw = bv + (int64_t)yi0 * m.sy + (int64_t)xi0 * m.sx;
+        pne = bv + (int64_t)yi0 * m.sy + (int64_t)xi1 * m.sx;
+        psw = bv + (int64_t)yi1 * m.sy + (int64_t)xi0 * m.sx;
+        pse = bv + (int64_t)yi1 * m.sy + (int64_t)xi1 * m.sx;
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const int lv = u * lpp + g;                             // vector index inside the pass
+        if (c0 + lv < cvec) {
+            const int co = lv * 4;
+            VT a = inw ? load_vec<VT>(pnw + co) : (VT)0.0f;
+            VT b = ine ? load_vec<VT>(pne + co) : (VT)0.0f;
+            VT d = isw ? load_vec<VT>(psw + co) : (VT)0.0f;
+            VT e = ise ? load_vec<VT>(pse + co) : (VT)0.0f;
+            VT s = a * wnw;
+            s = v_fma<VT>(b, wne, s);
+            s = v_fma<VT>(d, wsw, s);
+            s = v_fma<VT>(e, wse, s);
+            if (m.inter) store_vec<VT>(m.inter + ((int64_t)v * P.n + i) * m.C + (int64_t)(c0 + lv) * 4, s);
+            VT t = (s * r.valid) * r.wgt;
+            acc[u] = acc[u] + t;
+        }
+    }
+}
+
+template <int U>
+__device__ __forceinline__ void gather_map_staged(const MapDesc &m, const EvalParams &P, const ViewRec *rec,
+                                                  const float *cnt_s, const uint32_t *flag_s, const uint32_t *idx_s,
+                                                  int64_t idx_base, int tile_n, int *bbox, float *stage, int stage_floats)
+{
+    using VT = f32x4;
+    const int lpp = 1 << m.lpp_log2;
+    const int g = threadIdx.x & (lpp - 1);
+    const int grp = threadIdx.x >> m.lpp_log2;
+    const int ngrp = kBlock >> m.lpp_log2;                      // >= 8
+    const int cvec = m.C / 4;
+    const int V = P.V;
+    const bool want_inter = m.inter != nullptr;
+
+    // 1. texel window of every view: min/max over the corners the tile will actually read
+    for (int t = threadIdx.x; t < V * 4; t += kBlock) bbox[t] = (t & 1) ? INT_MIN : INT_MAX;
+    __syncthreads();
+    for (int p = threadIdx.x; p < tile_n; p += kBlock) {
+        const bool strict = (flag_s[p] != 0u) || want_inter;
+        for (int v = 0; v < V; ++v) {
+            const ViewRec r = rec[p * V + v];
+            if (!strict && r.valid == 0.0f) continue;
+            const float x0 = floorf(unnormalize(r.gx, m.fw)), y0 = floorf(unnormalize(r.gy, m.fh));
+            // in-bounds part of [x0, x0+1] x [y0, y0+1]; float compares keep NaN/huge values out
+            if (!(x0 >= -1.0f && x0 <= (float)(m.fw - 1) && y0 >= -1.0f && y0 <= (float)(m.fh - 1))) continue;
+            const int xa = max((int)x0, 0), xb = min((int)x0 + 1, m.fw - 1);
+            const int ya = max((int)y0, 0), yb = min((int)y0 + 1, m.fh - 1);
+            atomicMin(&bbox[v * 4 + 0], xa);
+            atomicMax(&bbox[v * 4 + 1], xb);
+            atomicMin(&bbox[v * 4 + 2], ya);
+            atomicMax(&bbox[v * 4 + 3], yb);
+        }
+    }
+    __syncthreads();
+
+    // 2. passes over the channels; per pass the views are staged one after the other (2 buffers)
+    for (int c0 = 0; c0 < cvec; c0 += lpp * U) {
+        const int pass_vecs = min(lpp * U, cvec - c0);
+        VT acc[kStagedPPG][U];
+#pragma unroll
+        for (int j = 0; j < kStagedPPG; ++j)
+#pragma unroll
+            for (int u = 0; u < U; ++u) acc[j][u] = (VT)0.0f;
+        for (int v = 0; v < V; ++v) {
+            const int xmin = bbox[v * 4 + 0], xmax = bbox[v * 4 + 1], ymin = bbox[v * 4 + 2], ymax = bbox[v * 4 + 3];
+            const int bw = xmax - xmin + 1, bh = ymax - ymin + 1;
+            const bool nonempty = (xmin <= xmax) && (ymin <= ymax);
+            const bool fits = nonempty && ((int64_t)bw * bh * pass_vecs * 4 <= (int64_t)stage_floats);
+            float *buf = stage + (v & 1) * stage_floats;
+            if (fits) {
+                const int total = bw * bh * pass_vecs;
+                const float *src = m.data + (int64_t)v * m.sv + (int64_t)c0 * 4;
+                for (int e = threadIdx.x; e < total; e += kBlock) {
+                    const int texel = e / pass_vecs, lv = e - texel * pass_vecs;
+                    const int wy = texel / bw, wx = texel - wy * bw;
+                    const VT val = load_vec<VT>(src + (int64_t)(ymin + wy) * m.sy + (int64_t)(xmin + wx) * m.sx + lv * 4);
+                    store_vec<VT>(buf + (int64_t)e * 4, val);
+                }
+            }
+            __syncthreads();        // staged texels visible; also orders this view's writes after view v-2's reads
+#pragma unroll
+            for (int j = 0; j < kStagedPPG; ++j) {
+                const int p = grp + j * ngrp;
+                if (p < tile_n) {
+                    const ViewRec r = rec[p * V + v];
+                    const bool strict = (flag_s[p] != 0u) || want_inter;
+                    if (strict || r.valid != 0.0f) {
+                        const int64_t i = idx_base + idx_s[p];
+                        if (fits)
+                            staged_accumulate<U, true>(m, P, r, v, i, c0, lpp, g, cvec, buf, xmin, ymin, bw, pass_vecs, acc[j]);
+                        else
+                            staged_accumulate<U, false>(m, P, r, v, i, c0, lpp, g, cvec, nullptr, 0, 0, 0, pass_vecs, acc[j]);
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < kStagedPPG; ++j) {
+            const int p = grp + j * ngrp;
+            if (p < tile_n) {
+                const int64_t i = idx_base + idx_s[p];
+                const float cnt = cnt_s[p];
+                const float denom = cnt + 1e-6f;
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int cv = c0 + u * lpp + g;
+                    if (cv < cvec) {
+                        VT o = (cnt == 0.0f) ? (VT)0.0f : acc[j][u] / denom;
+                        store_vec<VT>(m.out + i * m.C + (int64_t)cv * 4, o);
+                    }
+                }
+            }
+        }
+        __syncthreads();            // buffers are reused by the next pass
+    }
+}
+
 template <int VW>
 __device__ __forceinline__ void gather_map_u(const MapDesc &m, const EvalParams &P, const ViewRec *rec,
                                              const float *cnt_s, const uint32_t *flag_s,
@@ -139,7 +298,8 @@ __device__ __forceinline__ int64_t xcd_tile(int64_t b, int64_t nb)
 }
 
 // MODE 0: Fusion.eval semantics; MODE 1: Fusion.eval_dist semantics (fusion.py:396-436).
-template <int MODE>
+// STAGED: compiled with the LDS-window gather (more registers); the plain kernel keeps 4 waves/SIMD.
+template <int MODE, bool STAGED>
 __global__ __launch_bounds__(kBlock) void fused_eval_kernel(const EvalParams P)
 {
     extern __shared__ __align__(16) unsigned char smem[];
@@ -150,6 +310,8 @@ __global__ __launch_bounds__(kBlock) void fused_eval_kernel(const EvalParams P)
     uint32_t *flag_s = reinterpret_cast<uint32_t *>(cnt_s + TP);             // [TP]
     uint32_t *idx_s = flag_s + TP;                                           // [TP] global point index
     float *krt = reinterpret_cast<float *>(idx_s + TP);                      // [V*12]
+    int *bbox_s = reinterpret_cast<int *>(krt + V * 12);                      // [V*4]   (staged maps only)
+    float *stage_s = reinterpret_cast<float *>(smem + P.stage_offset);       // 2 x stage_floats, 16-B aligned
 
     compute_krt(P.K, P.pose, V, krt, kBlock);
     __syncthreads();
@@ -214,6 +376,14 @@ __global__ __launch_bounds__(kBlock) void fused_eval_kernel(const EvalParams P)
     // ---------------- phase B: per map, 2^k lanes per point ----------------
     for (int s = 0; s < P.n_maps; ++s) {
         const MapDesc &m = P.maps[s];
+        if (STAGED && m.staged) {
+            switch (m.unroll) {
+            case 1: gather_map_staged<1>(m, P, rec, cnt_s, flag_s, idx_s, idx_base, tile_n, bbox_s, stage_s, P.stage_floats); break;
+            case 2: gather_map_staged<2>(m, P, rec, cnt_s, flag_s, idx_s, idx_base, tile_n, bbox_s, stage_s, P.stage_floats); break;
+            default: gather_map_staged<3>(m, P, rec, cnt_s, flag_s, idx_s, idx_base, tile_n, bbox_s, stage_s, P.stage_floats); break;
+            }
+            continue;
+        }
         switch (m.vw) {
         case 4: gather_map_u<4>(m, P, rec, cnt_s, flag_s, idx_s, idx_base, tile_n); break;
         case 2: gather_map_u<2>(m, P, rec, cnt_s, flag_s, idx_s, idx_base, tile_n); break;
@@ -226,12 +396,14 @@ hipError_t launch_fused_eval(const EvalParams &P, int mode, hipStream_t stream)
 {
     if (P.n == 0) return hipSuccess;
     const int64_t ntiles = (P.n + P.tile_pts - 1) / P.tile_pts;
-    const size_t lds = (size_t)P.tile_pts * P.V * sizeof(ViewRec) + (size_t)P.tile_pts * 12 + (size_t)P.V * 48 + (size_t)P.lds_pad;
+    const size_t lds = (size_t)fused_lds_base(P.tile_pts, P.V) + (size_t)P.stage_floats * 8 + (size_t)P.lds_pad;
     dim3 grid((unsigned)ntiles), block(kBlock);
-    if (mode == 0)
-        hipLaunchKernelGGL(fused_eval_kernel<0>, grid, block, lds, stream, P);
+    if (mode == 0 && P.stage_floats > 0)
+        hipLaunchKernelGGL((fused_eval_kernel<0, true>), grid, block, lds, stream, P);
+    else if (mode == 0)
+        hipLaunchKernelGGL((fused_eval_kernel<0, false>), grid, block, lds, stream, P);
     else
-        hipLaunchKernelGGL(fused_eval_kernel<1>, grid, block, lds, stream, P);
+        hipLaunchKernelGGL((fused_eval_kernel<1, false>), grid, block, lds, stream, P);
     return hipGetLastError();
 }
 

@@ -67,10 +67,8 @@ def tune(tile_log2=0, xcd=False, pad_kib=0):
 
 
 print("workload", which, "N", pts.shape[0])
-NOR, FOR = 1 << 13, 1 << 14
-cfgs = [("default(auto)", 0), ("no-reorder", NOR), ("force-reorder", FOR), ("noreorder t7 p0", NOR | tune(7, False, 0)),
-        ("reorder t7 p0", FOR | tune(7, False, 0)), ("reorder t6 p64", FOR | tune(6, False, 64)), ("reorder t6 p48", FOR | tune(6, False, 48)),
-        ("reorder t5 p64", FOR | tune(5, False, 64)), ("reorder t6 p96", FOR | tune(6, False, 96))]
+NOR, FOR, NOST = 1 << 13, 1 << 14, 1 << 15
+cfgs = [("auto", 0), ("no-reorder", NOR), ("reorder,nostage", NOST), ("auto again", 0)]
 for name in ["grid(z-fast)", "morton", "random"]:
     perm = orders[name]
     p = pts if perm is None else pts[perm].contiguous()

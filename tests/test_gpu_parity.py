@@ -366,7 +366,7 @@ def test_point_reordering_changes_nothing(dev, N):
     assert rel_err(cpu(outs[1]["dino_feats"]), ref["sets"][0]) <= TOL
 
 
-def _eval_with_workspace(f, pts):
+def _eval_with_workspace(f, pts, names=("dino_feats", "mask"), want_inter=True):
     """Direct C-ABI call with a workspace for a batch below the shim's reorder threshold."""
     import ctypes
     from d3fields_amd import _lib
@@ -374,21 +374,26 @@ def _eval_with_workspace(f, pts):
     dev = pts.device
     n = pts.shape[0]
     views, keep, V = f._views(dev)
-    names = ["dino_feats", "mask"]
-    maps = (_lib.ChannelMap * 2)()
-    fused = (ctypes.c_void_p * 2)()
-    inter = (ctypes.c_void_p * 2)()
+    names = list(names)
+    maps = (_lib.ChannelMap * len(names))()
+    fused = (ctypes.c_void_p * len(names))()
+    inter = (ctypes.c_void_p * len(names))()
     out = {"dist": torch.empty(n, device=dev), "valid_mask": torch.empty(n, dtype=torch.bool, device=dev)}
     for s, k in enumerate(names):
         m = f.curr_obs_torch[k]
         maps[s] = _lib.ChannelMap(m.data_ptr(), m.shape[1], m.shape[2], m.shape[3], 0, m.stride(0), m.stride(1), m.stride(2))
         out[k] = torch.empty(n, m.shape[3], device=dev)
-        out[k + "_inter"] = torch.empty(V, n, m.shape[3], device=dev)
-        fused[s], inter[s] = out[k].data_ptr(), out[k + "_inter"].data_ptr()
+        fused[s] = out[k].data_ptr()
+        if want_inter:
+            out[k + "_inter"] = torch.empty(V, n, m.shape[3], device=dev)
+            inter[s] = out[k + "_inter"].data_ptr()
     nb = lib.d3f_eval_workspace_bytes(n)
     ws = torch.empty(nb, dtype=torch.uint8, device=dev)
-    _lib.check(lib.d3f_eval(ctypes.byref(views), _lib.ptr(pts), n, maps, 2, f.mu, int(f.tuning_flags), _lib.ptr(out["dist"]),
-                            _lib.ptr(out["valid_mask"]), fused, inter, _lib.ptr(ws), nb, _lib.current_stream_handle(dev)))
+    finite = all(bool(torch.isfinite(f.curr_obs_torch[k]).all()) for k in names + ["depth"])
+    flags = int(f.tuning_flags) | (_lib.FLAG_FINITE_MAPS if finite else 0)
+    _lib.check(lib.d3f_eval(ctypes.byref(views), _lib.ptr(pts), n, maps, len(names), f.mu, flags, _lib.ptr(out["dist"]),
+                            _lib.ptr(out["valid_mask"]), fused, inter if want_inter else None, _lib.ptr(ws), nb,
+                            _lib.current_stream_handle(dev)))
     torch.cuda.synchronize()
     return out
 
@@ -471,3 +476,53 @@ def test_rigid_tracking_style_loop(dev):
     assert losses[-1] < losses[0]
     with pytest.raises(NotImplementedError):
         f.eval_dist(src.clone().requires_grad_(True))
+
+
+# ---------------------------------------------------------------------------------------
+# LDS-staged gather (patch-resolution maps on the Morton walk): must be bit-identical to the direct gather
+# ---------------------------------------------------------------------------------------
+@pytest.mark.parametrize("C,fhw,N,box_scale,want_inter", [
+    (384, (12, 16), 6000, 1.0, False),      # compact tiles: windows fit, one pass
+    (384, (12, 16), 6000, 1.0, True),       # + '<k>_inter' (samples every view)
+    (1024, (9, 12), 3000, 1.0, False),      # 4 passes of 256 channels
+    (64, (24, 32), 4000, 1.0, False),       # 16 lanes per point
+    (384, (12, 16), 300, 1.0, False),       # sparse cloud: windows overflow -> per-view direct fallback
+    (100, (6, 8), 2500, 3.0, False),        # odd vector count, many points outside every image
+])
+def test_staged_gather_is_bit_identical(dev, C, fhw, N, box_scale, want_inter):
+    from d3fields_amd import synth, _lib
+    V, H, W = 4, 120, 160
+    sc = synth.make_scene(V, H, W, "smooth")
+    feats = synth.random_map(V, fhw[0], fhw[1], C, seed=1)
+    mask = synth.random_onehot_mask(V, H, W, 4, seed=2)
+    f = make_fusion(dev, sc["depth"], sc["K"], sc["pose"], {"dino_feats": feats, "mask": mask}, H, W)
+    pts = (synth.random_cloud(N, seed=8) * box_scale).to(dev)
+    res = {}
+    for tag, flags in (("direct", _lib.TUNE_NO_REORDER), ("staged", _lib.TUNE_FORCE_REORDER), ("unstaged", _lib.TUNE_FORCE_REORDER | (1 << 15))):
+        f.tuning_flags = flags
+        res[tag] = _eval_with_workspace(f, pts, ("dino_feats", "mask"), want_inter)
+    for k in res["direct"]:
+        assert torch.equal(res["staged"][k], res["direct"][k]), k
+        assert torch.equal(res["unstaged"][k], res["direct"][k]), k
+    ref = oracle_eval(sc, pts.cpu(), [feats, mask], return_inter=want_inter)
+    assert np.array_equal(cpu(res["staged"]["dist"]), ref["dist"])
+    assert rel_err(cpu(res["staged"]["dino_feats"]), ref["sets"][0]) <= TOL
+    if want_inter:
+        assert np.array_equal(cpu(res["staged"]["dino_feats_inter"]), ref["inter"][0])
+
+
+def test_staged_gather_nonfinite_map(dev):
+    from d3fields_amd import synth, _lib
+    V, H, W = 3, 96, 128
+    sc = synth.make_scene(V, H, W, "stress")
+    feats = synth.random_map(V, 12, 16, 128, seed=1)
+    feats[1, 3:9, 4:12, 2] = float("nan")
+    mask = synth.random_onehot_mask(V, H, W, 4, seed=2)
+    f = make_fusion(dev, sc["depth"], sc["K"], sc["pose"], {"dino_feats": feats, "mask": mask}, H, W)
+    pts = synth.random_cloud(5000, seed=3).to(dev)
+    f.tuning_flags = _lib.TUNE_FORCE_REORDER
+    out = _eval_with_workspace(f, pts, ("dino_feats", "mask"), False)
+    ref = oracle_eval(sc, pts.cpu(), [feats, mask])
+    got, want = cpu(out["dino_feats"]), ref["sets"][0]
+    assert np.isnan(want).any() and np.array_equal(np.isnan(got), np.isnan(want))
+    assert rel_err(got[~np.isnan(want)], want[~np.isnan(want)]) <= TOL
