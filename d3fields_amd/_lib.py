@@ -15,7 +15,7 @@ ABI_VERSION = 1
 OK = 0
 ERR_INVALID_ARG, ERR_BAD_SHAPE, ERR_BAD_DTYPE, ERR_BAD_LAYOUT, ERR_HIP, ERR_WORKSPACE = -1, -2, -3, -4, -5, -6
 FLAG_FINITE_MAPS = 1
-TUNE_XCD_REMAP, TUNE_NO_REORDER, TUNE_FORCE_REORDER = 1 << 12, 1 << 13, 1 << 14
+TUNE_XCD_REMAP, TUNE_NO_REORDER, TUNE_FORCE_REORDER, TUNE_NO_STAGING = 1 << 12, 1 << 13, 1 << 14, 1 << 15
 MAX_VIEWS = 64
 MAX_MAPS = 8
 DTYPE_F32 = 0
@@ -40,6 +40,13 @@ class ChannelMap(ctypes.Structure):
                 ("stride_v", _i64), ("stride_y", _i64), ("stride_x", _i64)]
 
 
+class EvalPlan(ctypes.Structure):
+    """struct d3f_eval_plan"""
+    _fields_ = [("tile_points", _i32), ("reorder", _i32), ("lds_bytes", _i32), ("reserved", _i32), ("workgroups", _i64),
+                ("vector_floats", _i32 * MAX_MAPS), ("lanes_per_point", _i32 * MAX_MAPS),
+                ("vectors_per_lane", _i32 * MAX_MAPS), ("staged", _i32 * MAX_MAPS)]
+
+
 # name -> (restype, argtypes); every symbol include/d3fields_hip.h declares
 SIGNATURES = {
     "d3f_abi_version": (ctypes.c_int, []),
@@ -48,6 +55,8 @@ SIGNATURES = {
     "d3f_eval": (ctypes.c_int, [ctypes.POINTER(Views), _vp, _i64, ctypes.POINTER(ChannelMap), _i32, _f32, _u32,
                                 _vp, _vp, ctypes.POINTER(_vp), ctypes.POINTER(_vp), _vp, _i64, _vp]),
     "d3f_eval_workspace_bytes": (_i64, [_i64]),
+    "d3f_eval_plan_query": (ctypes.c_int, [ctypes.POINTER(Views), _i64, ctypes.POINTER(ChannelMap), _i32, _u32, _i32, _i32,
+                                           ctypes.POINTER(EvalPlan)]),
     "d3f_eval_backward": (ctypes.c_int, [ctypes.POINTER(Views), _vp, _i64, ctypes.POINTER(ChannelMap), _i32, _f32,
                                          _vp, ctypes.POINTER(_vp), _vp, _vp]),
     "d3f_eval_dist": (ctypes.c_int, [ctypes.POINTER(Views), _vp, _i64, _vp, _vp, _vp]),

@@ -125,15 +125,17 @@ int tile_points_for(int V)
 
 int eval_common(const d3f_views *views, const float *pts, int64_t n, const d3f_channel_map *maps, int32_t n_maps,
                 float mu, uint32_t flags, float *out_dist, uint8_t *out_valid, float *const *out_fused,
-                float *const *out_inter, void *workspace, int64_t workspace_bytes, void *stream, int mode)
+                float *const *out_inter, void *workspace, int64_t workspace_bytes, void *stream, int mode,
+                d3f_eval_plan *plan_out = nullptr)
 {
+    const bool plan_only = plan_out != nullptr;
     int rc = check_views(views);
     if (rc != D3F_OK) return rc;
     if (n < 0) return fail(D3F_ERR_INVALID_ARG, "n=%lld is negative", (long long)n);
-    if (n == 0) return D3F_OK;
-    if (!pts || !out_dist || !out_valid) return fail(D3F_ERR_INVALID_ARG, "pts/out_dist/out_valid must be non-NULL");
+    if (n == 0 && !plan_only) return D3F_OK;
+    if (!plan_only && (!pts || !out_dist || !out_valid)) return fail(D3F_ERR_INVALID_ARG, "pts/out_dist/out_valid must be non-NULL");
     if (n_maps < 0 || n_maps > D3F_MAX_MAPS) return fail(D3F_ERR_BAD_SHAPE, "n_maps=%d outside [0,%d]", n_maps, D3F_MAX_MAPS);
-    if (n_maps > 0 && (!maps || !out_fused)) return fail(D3F_ERR_INVALID_ARG, "maps/out_fused must be non-NULL when n_maps > 0");
+    if (n_maps > 0 && (!maps || (!out_fused && !plan_only))) return fail(D3F_ERR_INVALID_ARG, "maps/out_fused must be non-NULL when n_maps > 0");
     if (!(mu > 0.0f)) return fail(D3F_ERR_INVALID_ARG, "mu must be > 0");
 
     d3f::EvalParams P;
@@ -148,8 +150,9 @@ int eval_common(const d3f_views *views, const float *pts, int64_t n, const d3f_c
     const int tl = (int)((flags >> 8) & 0xF);
     const int max_tile = tile_points_for(views->V) * 2;
     for (int s = 0; s < n_maps; ++s) {
-        if (!out_fused[s]) return fail(D3F_ERR_INVALID_ARG, "map %d: output pointer is NULL", s);
-        rc = fill_map(maps[s], s, views->V, out_fused[s], out_inter ? out_inter[s] : nullptr, nullptr, P.maps[s], map_bytes);
+        if (!plan_only && !out_fused[s]) return fail(D3F_ERR_INVALID_ARG, "map %d: output pointer is NULL", s);
+        rc = fill_map(maps[s], s, views->V, out_fused ? out_fused[s] : nullptr, out_inter ? out_inter[s] : nullptr, nullptr,
+                      P.maps[s], map_bytes);
         if (rc != D3F_OK) return rc;
     }
     // Maps far larger than the 256 MiB Infinity Cache: the kernel is bound by texel re-fetches, and
@@ -161,17 +164,18 @@ int eval_common(const d3f_views *views, const float *pts, int64_t n, const d3f_c
     if ((flags >> 16) & 0xFF) P.lds_pad = (int)((flags >> 16) & 0xFF) * 1024;
     // Morton point order (performance only) when scratch is supplied and the maps exceed the L2s
     hipStream_t hs = static_cast<hipStream_t>(stream);
-    const bool may_reorder = workspace && n_maps > 0 && n <= 0x7fffffffLL && !(flags & D3F_TUNE_NO_REORDER) &&
+    const bool may_reorder = (workspace || plan_only) && n_maps > 0 && n <= 0x7fffffffLL && !(flags & D3F_TUNE_NO_REORDER) &&
                              workspace_bytes >= d3f::order_workspace_bytes(n);
     bool stage_any = false;
     if (!(flags & D3F_TUNE_NO_STAGING) && views->V * 16 * 32 <= 16 * 1024)
         for (int s = 0; s < n_maps; ++s) stage_any |= staging_candidate(P.maps[s], views->H, views->W);
-    if (may_reorder && ((flags & D3F_TUNE_FORCE_REORDER) || (n >= 65536 && (map_bytes > (64LL << 20) || stage_any)))) {
+    const bool reorder = may_reorder && ((flags & D3F_TUNE_FORCE_REORDER) || (n >= 65536 && (map_bytes > (64LL << 20) || stage_any)));
+    if (reorder && !plan_only) {
         hipError_t eo = d3f::build_point_order(pts, n, workspace, workspace_bytes, &P.order, hs);
         if (eo != hipSuccess) return hip_fail(eo, "point ordering");
     }
     // texel windows only fit LDS when the tiles are spatially compact, i.e. on the Morton walk
-    if (stage_any && P.order && !(tl >= 5 && tl <= 8)) {
+    if (stage_any && reorder && !(tl >= 5 && tl <= 8)) {
         for (int s = 0; s < n_maps; ++s)
             if (staging_candidate(P.maps[s], views->H, views->W)) pick_staged_mapping(P.maps[s]);
         P.tile_pts = 32;
@@ -180,6 +184,20 @@ int eval_common(const d3f_views *views, const float *pts, int64_t n, const d3f_c
     P.stage_offset = d3f::fused_lds_base(P.tile_pts, views->V);
     const int64_t ntiles = (n + P.tile_pts - 1) / P.tile_pts;
     if (ntiles > 0x7fffffffLL) return fail(D3F_ERR_BAD_SHAPE, "n=%lld needs more than 2^31 workgroups", (long long)n);
+    if (plan_only) {
+        plan_out->tile_points = P.tile_pts;
+        plan_out->reorder = reorder ? 1 : 0;
+        plan_out->lds_bytes = d3f::fused_lds_base(P.tile_pts, P.V) + P.stage_floats * 8 + P.lds_pad;
+        plan_out->workgroups = ntiles;
+        for (int s = 0; s < D3F_MAX_MAPS; ++s) {
+            const bool on = s < n_maps;
+            plan_out->vector_floats[s] = on ? P.maps[s].vw : 0;
+            plan_out->lanes_per_point[s] = on ? (1 << P.maps[s].lpp_log2) : 0;
+            plan_out->vectors_per_lane[s] = on ? P.maps[s].unroll : 0;
+            plan_out->staged[s] = on ? P.maps[s].staged : 0;
+        }
+        return D3F_OK;
+    }
     hipError_t e = d3f::launch_fused_eval(P, mode, hs);
     if (e != hipSuccess) return hip_fail(e, "fused_eval launch");
     return D3F_OK;
@@ -202,6 +220,16 @@ int d3f_eval(const d3f_views *views, const float *pts, int64_t n, const d3f_chan
 }
 
 int64_t d3f_eval_workspace_bytes(int64_t n) { return d3f::order_workspace_bytes(n); }
+
+int d3f_eval_plan_query(const d3f_views *views, int64_t n, const d3f_channel_map *maps, int32_t n_maps, uint32_t flags,
+                        int32_t have_workspace, int32_t want_inter, d3f_eval_plan *plan)
+{
+    if (!plan) return fail(D3F_ERR_INVALID_ARG, "plan is NULL");
+    float *inter[D3F_MAX_MAPS];
+    for (int s = 0; s < D3F_MAX_MAPS; ++s) inter[s] = want_inter ? reinterpret_cast<float *>(16) : nullptr;
+    return eval_common(views, nullptr, n, maps, n_maps, 0.02f, flags, nullptr, nullptr, nullptr, want_inter ? inter : nullptr,
+                       nullptr, have_workspace ? d3f::order_workspace_bytes(n) : 0, nullptr, 0, plan);
+}
 
 int d3f_eval_backward(const d3f_views *views, const float *pts, int64_t n, const d3f_channel_map *maps, int32_t n_maps,
                       float mu, const float *grad_dist, const float *const *grad_fused, float *grad_pts, void *stream)

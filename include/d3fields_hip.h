@@ -107,6 +107,22 @@ int d3f_eval(const d3f_views *views, const float *pts, int64_t n, const d3f_chan
  * (Morton) order when the maps are much larger than the caches; outputs are unaffected. */
 int64_t d3f_eval_workspace_bytes(int64_t n);
 
+/* What d3f_eval would launch for these shapes (no device work; usable without a GPU): the launch
+ * geometry and the per-map lane mapping the host logic picked.  For tests and tuning. */
+typedef struct d3f_eval_plan {
+    int32_t tile_points;                    /* query points per 256-thread workgroup                  */
+    int32_t reorder;                        /* 1: points are walked in Morton order                   */
+    int32_t lds_bytes;                      /* dynamic LDS per workgroup                              */
+    int32_t reserved;
+    int64_t workgroups;
+    int32_t vector_floats[D3F_MAX_MAPS];    /* 4 / 2 / 1 floats per load                              */
+    int32_t lanes_per_point[D3F_MAX_MAPS];
+    int32_t vectors_per_lane[D3F_MAX_MAPS];
+    int32_t staged[D3F_MAX_MAPS];           /* 1: texel windows staged through LDS                    */
+} d3f_eval_plan;
+int d3f_eval_plan_query(const d3f_views *views, int64_t n, const d3f_channel_map *maps, int32_t n_maps,
+                        uint32_t flags, int32_t have_workspace, int32_t want_inter, d3f_eval_plan *plan);
+
 /* Gradient of d3f_eval's outputs w.r.t. the query points: what autograd through Fusion.eval gives
  * the reference's rigid_tracking (fusion.py:1643-1665).  grad_dist: [n] or NULL; grad_fused: host
  * array of n_maps device pointers ([n,C_k], entries may be NULL); grad_pts [n,3] is overwritten.
