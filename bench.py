@@ -146,6 +146,7 @@ def main():
     ap.add_argument("--gather", default="dist", choices=["none", "dist", "full"],
                     help="N>1: what the RCCL all-gather reassembles inside the timed step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--tuning", type=lambda x: int(x, 0), default=0, help="D3F_TUNE_* bits (experiments)")
     ap.add_argument("--cpu-sample", type=int, default=200000)
     args = ap.parse_args()
 
@@ -168,6 +169,7 @@ def main():
         dist.init_process_group("nccl", device_id=dev)       # "nccl" is RCCL on ROCm
 
     f, pts, names, w, sc = build_workload(args.workload, dev, rank, world)
+    f.tuning_flags = args.tuning
     n = pts.shape[0]
     from d3fields_amd import sharding
 

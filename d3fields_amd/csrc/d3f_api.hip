@@ -72,6 +72,8 @@ int fill_map(const d3f_channel_map &c, int s, int V, float *out, float *inter, c
     if (c.stride_x < c.C || c.stride_y < 0 || c.stride_v < 0)
         return fail(D3F_ERR_BAD_LAYOUT, "map %d: strides (%lld,%lld,%lld) do not describe a channels-last map", s,
                     (long long)c.stride_v, (long long)c.stride_y, (long long)c.stride_x);
+    if (((int64_t)(c.fh - 1) * c.stride_y + (int64_t)(c.fw - 1) * c.stride_x + c.C) * 4 >= (1LL << 32))
+        return fail(D3F_ERR_BAD_SHAPE, "map %d: one view spans 4 GiB or more (32-bit texel offsets)", s);
     m.data = static_cast<const float *>(c.data);
     m.out = out;
     m.inter = inter;
@@ -116,10 +118,10 @@ void pick_staged_mapping(d3f::MapDesc &m)
 
 int tile_points_for(int V)
 {
-    // LDS per workgroup = tile*V*16 B (+ small); keep it <= 32 KiB so >= 4 workgroups fit a CU.
+    // LDS per workgroup = tile*V*24 B (+ small); keep it <= 32 KiB so >= 4 workgroups fit a CU.
     // 128 points measured best (985 600-pt grid, C=384: 128 -> 0.99 ms, 256 -> 1.06 ms patch-res).
     int t = 128;
-    while (t > 32 && (long)t * V * 16 > 32 * 1024) t >>= 1;
+    while (t > 32 && (long)t * V * 24 > 32 * 1024) t >>= 1;
     return t;
 }
 
@@ -167,7 +169,7 @@ int eval_common(const d3f_views *views, const float *pts, int64_t n, const d3f_c
     const bool may_reorder = (workspace || plan_only) && n_maps > 0 && n <= 0x7fffffffLL && !(flags & D3F_TUNE_NO_REORDER) &&
                              workspace_bytes >= d3f::order_workspace_bytes(n);
     bool stage_any = false;
-    if (!(flags & D3F_TUNE_NO_STAGING) && views->V * 16 * 32 <= 16 * 1024)
+    if ((flags & D3F_TUNE_STAGING) && views->V * 24 * 32 <= 24 * 1024)
         for (int s = 0; s < n_maps; ++s) stage_any |= staging_candidate(P.maps[s], views->H, views->W);
     const bool reorder = may_reorder && ((flags & D3F_TUNE_FORCE_REORDER) || (n >= 65536 && (map_bytes > (64LL << 20) || stage_any)));
     if (reorder && !plan_only) {

@@ -42,7 +42,7 @@ struct EvalParams {
 };
 
 // LDS bytes in front of the stage buffers: records, cnt/flag/idx, KRt, per-view windows
-inline int fused_lds_base(int tile_pts, int V) { return ((tile_pts * V * 16 + tile_pts * 12 + V * 48 + V * 16) + 15) / 16 * 16; }
+inline int fused_lds_base(int tile_pts, int V) { return ((tile_pts * V * 24 + tile_pts * 12 + V * 48 + V * 16) + 15) / 16 * 16; }
 constexpr int kStageFloats = 6144;      // 24 KiB per stage buffer: 16 texels of 384 fp32 channels
 hipError_t launch_fused_eval(const EvalParams &P, int mode, hipStream_t stream);
 

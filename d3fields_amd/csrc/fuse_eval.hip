@@ -53,6 +53,8 @@ __device__ __forceinline__ void gather_map(const MapDesc &m, const EvalParams &P
     const int cvec = m.C / VW;
     const int V = P.V;
     const float *__restrict__ data = m.data;
+    const float fwm1 = (float)(m.fw - 1), fhm1 = (float)(m.fh - 1);
+    const uint32_t sy_b = (uint32_t)m.sy * 4u, sx_b = (uint32_t)m.sx * 4u;   // host guarantees a view spans < 4 GiB
 
     for (int p = grp; p < tile_n; p += ngrp) {
         const int64_t i = idx_base + idx_s[p];
@@ -75,32 +77,35 @@ __device__ __forceinline__ void gather_map(const MapDesc &m, const EvalParams &P
                 const float x1 = x0 + 1.0f, y1 = y0 + 1.0f;
                 const bool inw = in_bounds(x0, y0, m.fw, m.fh), ine = in_bounds(x1, y0, m.fw, m.fh);
                 const bool isw = in_bounds(x0, y1, m.fw, m.fh), ise = in_bounds(x1, y1, m.fw, m.fh);
-                // clamp so that the (unused) address of an out-of-bounds corner stays in the map
-                const int xi0 = (inw || isw) ? (int)x0 : 0, yi0 = (inw || ine) ? (int)y0 : 0;
-                const int xi1 = (ine || ise) ? (int)x1 : 0, yi1 = (isw || ise) ? (int)y1 : 0;
-                const float *bv = data + (int64_t)v * m.sv;
-                const float *pnw = bv + (int64_t)yi0 * m.sy + (int64_t)xi0 * m.sx;
-                const float *pne = bv + (int64_t)yi0 * m.sy + (int64_t)xi1 * m.sx;
-                const float *psw = bv + (int64_t)yi1 * m.sy + (int64_t)xi0 * m.sx;
-                const float *pse = bv + (int64_t)yi1 * m.sy + (int64_t)xi1 * m.sx;
+                // Branch-free corner fetch: coordinates are clamped into the map so that every address is
+                // valid, all 4*U loads are issued unconditionally, and out-of-bounds corners become the zeros
+                // of padding_mode='zeros' by a select.  Offsets are 32-bit BYTE offsets from the view's
+                // (wave-uniform) base: one global_load with an SGPR base per corner vector, no 64-bit math.
+                const int xi0 = (int)fminf(fmaxf(x0, 0.0f), fwm1), xi1 = (int)fminf(fmaxf(x1, 0.0f), fwm1);
+                const int yi0 = (int)fminf(fmaxf(y0, 0.0f), fhm1), yi1 = (int)fminf(fmaxf(y1, 0.0f), fhm1);
+                const char *bv = reinterpret_cast<const char *>(data) + (int64_t)v * m.sv * 4;
+                const uint32_t r0 = (uint32_t)yi0 * sy_b, r1 = (uint32_t)yi1 * sy_b;
+                const uint32_t q0 = (uint32_t)xi0 * sx_b, q1 = (uint32_t)xi1 * sx_b;
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
-                    const int cv = c0 + u * lpp + g;
-                    if (cv < cvec) {
-                        const int co = cv * VW;
-                        VT a = inw ? load_vec<VT>(pnw + co) : (VT)0.0f;
-                        VT b = ine ? load_vec<VT>(pne + co) : (VT)0.0f;
-                        VT d = isw ? load_vec<VT>(psw + co) : (VT)0.0f;
-                        VT e = ise ? load_vec<VT>(pse + co) : (VT)0.0f;
-                        VT s = a * wnw;                    // ATen bilinear: fma chain nw,ne,sw,se
-                        s = v_fma<VT>(b, wne, s);
-                        s = v_fma<VT>(d, wsw, s);
-                        s = v_fma<VT>(e, wse, s);
-                        if (m.inter)                       // '<k>_inter' [V,n,C]  fusion.py:389
-                            store_vec<VT>(m.inter + ((int64_t)v * P.n + i) * m.C + co, s);
-                        VT t = (s * r.valid) * r.wgt;      // fusion.py:385
-                        acc[u] = acc[u] + t;
-                    }
+                    const int cv = min(c0 + u * lpp + g, cvec - 1);     // idle lanes re-read the last vector
+                    const uint32_t co = (uint32_t)cv * (VW * 4);
+                    VT a = *reinterpret_cast<const VT *>(bv + (r0 + q0 + co));
+                    VT b = *reinterpret_cast<const VT *>(bv + (r0 + q1 + co));
+                    VT d = *reinterpret_cast<const VT *>(bv + (r1 + q0 + co));
+                    VT e = *reinterpret_cast<const VT *>(bv + (r1 + q1 + co));
+                    a = inw ? a : (VT)0.0f;
+                    b = ine ? b : (VT)0.0f;
+                    d = isw ? d : (VT)0.0f;
+                    e = ise ? e : (VT)0.0f;
+                    VT s = a * wnw;                        // ATen bilinear: fma chain nw,ne,sw,se
+                    s = v_fma<VT>(b, wne, s);
+                    s = v_fma<VT>(d, wsw, s);
+                    s = v_fma<VT>(e, wse, s);
+                    if (m.inter && c0 + u * lpp + g < cvec)   // '<k>_inter' [V,n,C]  fusion.py:389
+                        store_vec<VT>(m.inter + ((int64_t)v * P.n + i) * m.C + cv * VW, s);
+                    if (strict) s = s * r.valid;           // fusion.py:385; a valid view has valid == 1: s*1 == s
+                    acc[u] = acc[u] + s * r.wgt;
                 }
             }
 #pragma unroll
@@ -194,25 +199,25 @@ __device__ __forceinline__ void gather_map_staged(const MapDesc &m, const EvalPa
     // 1. texel window of every view: min/max over the corners the tile will actually read
     for (int t = threadIdx.x; t < V * 4; t += kBlock) bbox[t] = (t & 1) ? INT_MIN : INT_MAX;
     __syncthreads();
-    for (int p = threadIdx.x; p < tile_n; p += kBlock) {
+    for (int idx = threadIdx.x; idx < tile_n * V; idx += kBlock) {
+        const int v = idx / tile_n, p = idx - v * tile_n;
         const bool strict = (flag_s[p] != 0u) || want_inter;
-        for (int v = 0; v < V; ++v) {
-            const ViewRec r = rec[p * V + v];
-            if (!strict && r.valid == 0.0f) continue;
-            const float x0 = floorf(unnormalize(r.gx, m.fw)), y0 = floorf(unnormalize(r.gy, m.fh));
-            // in-bounds part of [x0, x0+1] x [y0, y0+1]; float compares keep NaN/huge values out
-            if (!(x0 >= -1.0f && x0 <= (float)(m.fw - 1) && y0 >= -1.0f && y0 <= (float)(m.fh - 1))) continue;
-            const int xa = max((int)x0, 0), xb = min((int)x0 + 1, m.fw - 1);
-            const int ya = max((int)y0, 0), yb = min((int)y0 + 1, m.fh - 1);
-            atomicMin(&bbox[v * 4 + 0], xa);
-            atomicMax(&bbox[v * 4 + 1], xb);
-            atomicMin(&bbox[v * 4 + 2], ya);
-            atomicMax(&bbox[v * 4 + 3], yb);
-        }
+        const ViewRec r = rec[p * V + v];
+        if (!strict && r.valid == 0.0f) continue;
+        const float x0 = floorf(unnormalize(r.gx, m.fw)), y0 = floorf(unnormalize(r.gy, m.fh));
+        // in-bounds part of [x0, x0+1] x [y0, y0+1]; float compares keep NaN/huge values out
+        if (!(x0 >= -1.0f && x0 <= (float)(m.fw - 1) && y0 >= -1.0f && y0 <= (float)(m.fh - 1))) continue;
+        atomicMin(&bbox[v * 4 + 0], max((int)x0, 0));
+        atomicMax(&bbox[v * 4 + 1], min((int)x0 + 1, m.fw - 1));
+        atomicMin(&bbox[v * 4 + 2], max((int)y0, 0));
+        atomicMax(&bbox[v * 4 + 3], min((int)y0 + 1, m.fh - 1));
     }
     __syncthreads();
 
-    // 2. passes over the channels; per pass the views are staged one after the other (2 buffers)
+    // 2. passes over the channels.  Per pass the V windows go through a 2-deep LDS ring; the loads of
+    //    view v+1 are issued (into registers) before view v is consumed, so their latency hides
+    //    behind the LDS reads and FMAs of view v.  One barrier per view.
+    constexpr int kRegs = kStageFloats / 4 / kBlock;          // float4 per lane per window (6)
     for (int c0 = 0; c0 < cvec; c0 += lpp * U) {
         const int pass_vecs = min(lpp * U, cvec - c0);
         VT acc[kStagedPPG][U];
@@ -220,23 +225,42 @@ __device__ __forceinline__ void gather_map_staged(const MapDesc &m, const EvalPa
         for (int j = 0; j < kStagedPPG; ++j)
 #pragma unroll
             for (int u = 0; u < U; ++u) acc[j][u] = (VT)0.0f;
-        for (int v = 0; v < V; ++v) {
+        VT tmp[kRegs];
+        auto window_fits = [&](int v) {
             const int xmin = bbox[v * 4 + 0], xmax = bbox[v * 4 + 1], ymin = bbox[v * 4 + 2], ymax = bbox[v * 4 + 3];
-            const int bw = xmax - xmin + 1, bh = ymax - ymin + 1;
-            const bool nonempty = (xmin <= xmax) && (ymin <= ymax);
-            const bool fits = nonempty && ((int64_t)bw * bh * pass_vecs * 4 <= (int64_t)stage_floats);
-            float *buf = stage + (v & 1) * stage_floats;
-            if (fits) {
-                const int total = bw * bh * pass_vecs;
-                const float *src = m.data + (int64_t)v * m.sv + (int64_t)c0 * 4;
-                for (int e = threadIdx.x; e < total; e += kBlock) {
+            return (xmin <= xmax) && (ymin <= ymax) &&
+                   ((int64_t)(xmax - xmin + 1) * (ymax - ymin + 1) * pass_vecs * 4 <= (int64_t)stage_floats);
+        };
+        auto issue_loads = [&](int v) {
+            if (!window_fits(v)) return;
+            const int xmin = bbox[v * 4 + 0], ymin = bbox[v * 4 + 2], bw = bbox[v * 4 + 1] - xmin + 1;
+            const int total = bw * (bbox[v * 4 + 3] - ymin + 1) * pass_vecs;
+            const float *src = m.data + (int64_t)v * m.sv + (int64_t)c0 * 4;
+#pragma unroll
+            for (int k = 0; k < kRegs; ++k) {
+                const int e = threadIdx.x + k * kBlock;
+                if (e < total) {
                     const int texel = e / pass_vecs, lv = e - texel * pass_vecs;
                     const int wy = texel / bw, wx = texel - wy * bw;
-                    const VT val = load_vec<VT>(src + (int64_t)(ymin + wy) * m.sy + (int64_t)(xmin + wx) * m.sx + lv * 4);
-                    store_vec<VT>(buf + (int64_t)e * 4, val);
+                    tmp[k] = load_vec<VT>(src + (int64_t)(ymin + wy) * m.sy + (int64_t)(xmin + wx) * m.sx + lv * 4);
                 }
             }
-            __syncthreads();        // staged texels visible; also orders this view's writes after view v-2's reads
+        };
+        issue_loads(0);
+        for (int v = 0; v < V; ++v) {
+            const int xmin = bbox[v * 4 + 0], ymin = bbox[v * 4 + 2], bw = bbox[v * 4 + 1] - xmin + 1;
+            const bool fits = window_fits(v);
+            float *buf = stage + (v & 1) * stage_floats;
+            if (fits) {
+                const int total = bw * (bbox[v * 4 + 3] - ymin + 1) * pass_vecs;
+#pragma unroll
+                for (int k = 0; k < kRegs; ++k) {
+                    const int e = threadIdx.x + k * kBlock;
+                    if (e < total) store_vec<VT>(buf + (int64_t)e * 4, tmp[k]);
+                }
+            }
+            if (v + 1 < V) issue_loads(v + 1);
+            __syncthreads();        // window v visible; buf[(v+1)&1] was last read two barriers ago
 #pragma unroll
             for (int j = 0; j < kStagedPPG; ++j) {
                 const int p = grp + j * ngrp;
@@ -298,6 +322,38 @@ __device__ __forceinline__ int64_t xcd_tile(int64_t b, int64_t nb)
 }
 
 // MODE 0: Fusion.eval semantics; MODE 1: Fusion.eval_dist semantics (fusion.py:396-436).
+// One (point, view) of the forward: projection, nearest depth, validity, weight.
+struct ViewOut {
+    float gx, gy;
+    float dist;     // clamp(d - zc, -mu, mu) for eval, d - zc for eval_dist
+    float valid;    // 1.0f / 0.0f
+};
+
+template <int MODE>
+__device__ __forceinline__ ViewOut eval_view(const EvalParams &P, const float *M, int v, float px, float py, float pz,
+                                             float Wm1, float Hm1, float mu, float &wgt)
+{
+    const Proj pr = project_point(M, px, py, pz, Wm1, Hm1);
+    const float d = nearest_depth(P.depth, v, P.H, P.W, pr.gx, pr.gy);
+    float dist = d - pr.zc;                                                 // fusion.py:343
+    bool valid;
+    wgt = 1.0f;
+    if (MODE == 0) {
+        valid = (d > 0.0f) && pr.ok && (dist > -mu);                        // fusion.py:344
+        float t = mu - fabsf(dist);                                         // fusion.py:347
+        t = t > 0.0f ? 0.0f : t;
+        wgt = expf(t / mu);
+        float dc = dist < -mu ? -mu : dist;                                 // fusion.py:358
+        dc = dc > mu ? mu : dc;
+        dist = dc;
+    } else {
+        valid = (d > 0.0f) && pr.ok;                                        // fusion.py:426
+    }
+    ViewOut o;
+    o.gx = pr.gx; o.gy = pr.gy; o.dist = dist; o.valid = valid ? 1.0f : 0.0f;
+    return o;
+}
+
 // STAGED: compiled with the LDS-window gather (more registers); the plain kernel keeps 4 waves/SIMD.
 template <int MODE, bool STAGED>
 __global__ __launch_bounds__(kBlock) void fused_eval_kernel(const EvalParams P)
@@ -306,7 +362,9 @@ __global__ __launch_bounds__(kBlock) void fused_eval_kernel(const EvalParams P)
     const int V = P.V;
     const int TP = P.tile_pts;
     ViewRec *rec = reinterpret_cast<ViewRec *>(smem);                       // [TP*V]
-    float *cnt_s = reinterpret_cast<float *>(rec + (size_t)TP * V);          // [TP]
+    float *dcl_s = reinterpret_cast<float *>(rec + (size_t)TP * V);          // [TP*V] clamp(dist_v)*valid_v
+    uint32_t *nfp_s = reinterpret_cast<uint32_t *>(dcl_s + (size_t)TP * V);  // [TP*V] non-finite projection?
+    float *cnt_s = reinterpret_cast<float *>(nfp_s + (size_t)TP * V);        // [TP]
     uint32_t *flag_s = reinterpret_cast<uint32_t *>(cnt_s + TP);             // [TP]
     uint32_t *idx_s = flag_s + TP;                                           // [TP] global point index
     float *krt = reinterpret_cast<float *>(idx_s + TP);                      // [V*12]
@@ -324,53 +382,60 @@ __global__ __launch_bounds__(kBlock) void fused_eval_kernel(const EvalParams P)
     const float mu = P.mu;
     const float Wm1 = (float)(P.W - 1), Hm1 = (float)(P.H - 1);
 
-    // ---------------- phase A: one lane per point ----------------
-    for (int p = threadIdx.x; p < tile_n; p += kBlock) {
+    // ---------------- phase A ----------------
+    if (P.n_maps == 0) {
+        // distance-only query (return_names=[], eval_dist): one lane per point, nothing staged in LDS
+        for (int p = threadIdx.x; p < tile_n; p += kBlock) {
+            const int64_t i = tile_base + p;
+            const float px = P.pts[i * 3 + 0], py = P.pts[i * 3 + 1], pz = P.pts[i * 3 + 2];
+            float dsum = 0.0f, cnt = 0.0f;
+            for (int v = 0; v < V; ++v) {
+                float wgt;
+                const ViewOut o = eval_view<MODE>(P, krt + v * 12, v, px, py, pz, Wm1, Hm1, mu, wgt);
+                dsum = dsum + o.dist * o.valid;                             // fusion.py:364
+                cnt = cnt + o.valid;
+            }
+            const bool all_invalid = (cnt == 0.0f);                         // fusion.py:366
+            float dist_out = dsum / (cnt + 1e-6f);
+            if (MODE == 0 && all_invalid) dist_out = 1e3f;                  // fusion.py:367
+            P.out_dist[i] = dist_out;
+            P.out_valid[i] = all_invalid ? 0 : 1;
+        }
+        return;
+    }
+    // one lane per (point, view) pair: the V depth lookups of a point are in flight together
+    for (int idx = threadIdx.x; idx < tile_n * V; idx += kBlock) {
+        const int v = idx / tile_n, p = idx - v * tile_n;
         const int64_t i = P.order ? (int64_t)P.order[tile_base + p] : tile_base + p;
         const float px = P.pts[i * 3 + 0], py = P.pts[i * 3 + 1], pz = P.pts[i * 3 + 2];
+        float wgt;
+        const ViewOut o = eval_view<MODE>(P, krt + v * 12, v, px, py, pz, Wm1, Hm1, mu, wgt);
+        ViewRec r;
+        r.gx = o.gx; r.gy = o.gy; r.wgt = wgt; r.valid = o.valid;
+        rec[p * V + v] = r;
+        dcl_s[p * V + v] = o.dist * o.valid;                                // fusion.py:364 (product only)
+        nfp_s[p * V + v] = !(isfinite(o.gx) && isfinite(o.gy) && isfinite(wgt)) ? 1u : 0u;
+    }
+    __syncthreads();
+    // per point: sums over the views in view order (fusion.py:364-370), outputs leave coalesced
+    for (int p = threadIdx.x; p < tile_n; p += kBlock) {
+        const int64_t i = P.order ? (int64_t)P.order[tile_base + p] : tile_base + p;
         float dsum = 0.0f, cnt = 0.0f;
-        bool nonfinite = false;
+        uint32_t nonfinite = 0u;
         for (int v = 0; v < V; ++v) {
-            const Proj pr = project_point(krt + v * 12, px, py, pz, Wm1, Hm1);
-            const float gx = pr.gx, gy = pr.gy, zc = pr.zc;
-            const bool ok = pr.ok;
-            const float d = nearest_depth(P.depth, v, P.H, P.W, gx, gy);
-            float dist = d - zc;                                            // fusion.py:343
-            bool valid;
-            float wgt = 1.0f;
-            if (MODE == 0) {
-                valid = (d > 0.0f) && ok && (dist > -mu);                   // fusion.py:344
-                float t = mu - fabsf(dist);                                 // fusion.py:347
-                t = t > 0.0f ? 0.0f : t;
-                wgt = expf(t / mu);
-                float dc = dist < -mu ? -mu : dist;                         // fusion.py:358
-                dc = dc > mu ? mu : dc;
-                dist = dc;
-            } else {
-                valid = (d > 0.0f) && ok;                                   // fusion.py:426
-            }
-            const float vf = valid ? 1.0f : 0.0f;
-            dsum = dsum + dist * vf;                                        // fusion.py:364
-            cnt = cnt + vf;
-            if (P.n_maps > 0) {
-                nonfinite |= !(isfinite(gx) && isfinite(gy) && isfinite(wgt));
-                ViewRec r;
-                r.gx = gx; r.gy = gy; r.wgt = wgt; r.valid = vf;
-                rec[p * V + v] = r;
-            }
+            dsum = dsum + dcl_s[p * V + v];
+            cnt = cnt + rec[p * V + v].valid;
+            nonfinite |= nfp_s[p * V + v];
         }
         const bool all_invalid = (cnt == 0.0f);                             // fusion.py:366
         float dist_out = dsum / (cnt + 1e-6f);
         if (MODE == 0 && all_invalid) dist_out = 1e3f;                      // fusion.py:367
         P.out_dist[i] = dist_out;
         P.out_valid[i] = all_invalid ? 0 : 1;
-        if (P.n_maps > 0) {
-            cnt_s[p] = cnt;
-            idx_s[p] = (uint32_t)(i - idx_base);
-            flag_s[p] = (nonfinite || !(P.flags & kFlagFiniteMaps)) ? 1u : 0u;
-        }
+        cnt_s[p] = cnt;
+        idx_s[p] = (uint32_t)(i - idx_base);
+        flag_s[p] = (nonfinite || !(P.flags & kFlagFiniteMaps)) ? 1u : 0u;
     }
-    if (P.n_maps == 0) return;
     __syncthreads();
 
     // ---------------- phase B: per map, 2^k lanes per point ----------------

@@ -52,13 +52,14 @@ extern "C" {
  *   bit  12     remap workgroups to XCD-contiguous tile ranges (measured slower: off by default)
  *   bit  13     never reorder points, even when a workspace is supplied
  *   bit  14     always reorder points when a workspace is supplied
- *   bit  15     never stage texel windows through LDS (low-resolution wide maps)
+ *   bit  15     stage texel windows of low-resolution wide maps through LDS (experimental:
+ *               bit-identical, measured slower than the direct gather on MI355X, off by default)
  *   bits 16..23 extra dynamic LDS per workgroup in KiB (throttles workgroups per CU)      */
 #define D3F_TUNE_TILE_LOG2(k) (((uint32_t)(k) & 0xFu) << 8)
 #define D3F_TUNE_XCD_REMAP (1u << 12)
 #define D3F_TUNE_NO_REORDER (1u << 13)
 #define D3F_TUNE_FORCE_REORDER (1u << 14)
-#define D3F_TUNE_NO_STAGING (1u << 15)
+#define D3F_TUNE_STAGING (1u << 15)
 #define D3F_TUNE_LDS_PAD_KIB(k) (((uint32_t)(k) & 0xFFu) << 16)
 
 /* Calibrated views: the part of Fusion.curr_obs_torch read by every query

@@ -498,7 +498,7 @@ def test_staged_gather_is_bit_identical(dev, C, fhw, N, box_scale, want_inter):
     f = make_fusion(dev, sc["depth"], sc["K"], sc["pose"], {"dino_feats": feats, "mask": mask}, H, W)
     pts = (synth.random_cloud(N, seed=8) * box_scale).to(dev)
     res = {}
-    for tag, flags in (("direct", _lib.TUNE_NO_REORDER), ("staged", _lib.TUNE_FORCE_REORDER), ("unstaged", _lib.TUNE_FORCE_REORDER | (1 << 15))):
+    for tag, flags in (("direct", _lib.TUNE_NO_REORDER), ("staged", _lib.TUNE_FORCE_REORDER | _lib.TUNE_STAGING), ("unstaged", _lib.TUNE_FORCE_REORDER)):
         f.tuning_flags = flags
         res[tag] = _eval_with_workspace(f, pts, ("dino_feats", "mask"), want_inter)
     for k in res["direct"]:
@@ -520,7 +520,7 @@ def test_staged_gather_nonfinite_map(dev):
     mask = synth.random_onehot_mask(V, H, W, 4, seed=2)
     f = make_fusion(dev, sc["depth"], sc["K"], sc["pose"], {"dino_feats": feats, "mask": mask}, H, W)
     pts = synth.random_cloud(5000, seed=3).to(dev)
-    f.tuning_flags = _lib.TUNE_FORCE_REORDER
+    f.tuning_flags = _lib.TUNE_FORCE_REORDER | _lib.TUNE_STAGING
     out = _eval_with_workspace(f, pts, ("dino_feats", "mask"), False)
     ref = oracle_eval(sc, pts.cpu(), [feats, mask])
     got, want = cpu(out["dino_feats"]), ref["sets"][0]
