@@ -39,7 +39,9 @@ int check_views(const d3f_views *v)
 // Phase-B lane mapping of one map: vector width, lanes per point (2^k) and vectors per lane.
 // Minimises idle lane-slots (passes*lpp*U - cvec), then passes, then prefers wide groups
 // (longer contiguous segments per load instruction).
-void pick_mapping(d3f::MapDesc &m, bool can16, bool can8)
+// batch: issue all 4*U corner loads before the first use (best for cache-resident maps, U <= 3);
+// otherwise load-use per vector, U <= 4 (best when the map misses the caches).
+void pick_mapping(d3f::MapDesc &m, bool can16, bool can8, bool batch)
 {
     m.vw = (m.C % 4 == 0 && can16) ? 4 : ((m.C % 2 == 0 && can8) ? 2 : 1);
     const int cvec = m.C / m.vw;
@@ -47,7 +49,7 @@ void pick_mapping(d3f::MapDesc &m, bool can16, bool can8)
     int best_passes = 0;
     for (int lg = 6; lg >= 0; --lg) {
         const int lpp = 1 << lg;
-        for (int u = 4; u >= 1; --u) {
+        for (int u = batch ? 3 : 4; u >= 1; --u) {
             const int per = lpp * u;
             const int passes = (cvec + per - 1) / per;
             const long slots = (long)passes * per;
@@ -60,6 +62,7 @@ void pick_mapping(d3f::MapDesc &m, bool can16, bool can8)
             }
         }
     }
+    if (!batch) m.unroll = -m.unroll;
 }
 
 // Validates one channel map and fills the kernel-side descriptor (out/inter may be NULL for backward).
@@ -86,8 +89,9 @@ int fill_map(const d3f_channel_map &c, int s, int V, float *out, float *inter, c
     const bool str8 = (c.stride_v % 2 == 0) && (c.stride_y % 2 == 0) && (c.stride_x % 2 == 0);
     const bool can16 = str16 && aligned(m.data, 16) && aligned(out, 16) && aligned(inter, 16) && aligned(extra_aligned, 16);
     const bool can8 = str8 && aligned(m.data, 8) && aligned(out, 8) && aligned(inter, 8) && aligned(extra_aligned, 8);
-    pick_mapping(m, can16, can8);
-    map_bytes += (int64_t)V * c.fh * c.fw * c.C * 4;
+    const int64_t this_bytes = (int64_t)V * c.fh * c.fw * c.C * 4;
+    pick_mapping(m, can16, can8, this_bytes <= (128LL << 20));
+    map_bytes += this_bytes;
     return D3F_OK;
 }
 
@@ -157,13 +161,6 @@ int eval_common(const d3f_views *views, const float *pts, int64_t n, const d3f_c
                       P.maps[s], map_bytes);
         if (rc != D3F_OK) return rc;
     }
-    // Maps far larger than the 256 MiB Infinity Cache: the kernel is bound by texel re-fetches, and
-    // a smaller in-flight footprint wins (64-point tiles, 2 workgroups per CU: 3.2 -> 2.96 ms on C2
-    // dense; the same throttle costs 60 % on cache-resident maps, hence the size test).
-    const bool huge_maps = map_bytes > (512LL << 20);
-    if (huge_maps && P.tile_pts > 64) { P.tile_pts = 64; P.lds_pad = 64 * 1024; }
-    if (tl >= 5 && tl <= 8) { P.tile_pts = (1 << tl) <= max_tile ? (1 << tl) : max_tile; P.lds_pad = 0; }
-    if ((flags >> 16) & 0xFF) P.lds_pad = (int)((flags >> 16) & 0xFF) * 1024;
     // Morton point order (performance only) when scratch is supplied and the maps exceed the L2s
     hipStream_t hs = static_cast<hipStream_t>(stream);
     const bool may_reorder = (workspace || plan_only) && n_maps > 0 && n <= 0x7fffffffLL && !(flags & D3F_TUNE_NO_REORDER) &&
@@ -176,11 +173,27 @@ int eval_common(const d3f_views *views, const float *pts, int64_t n, const d3f_c
         hipError_t eo = d3f::build_point_order(pts, n, workspace, workspace_bytes, &P.order, hs);
         if (eo != hipSuccess) return hip_fail(eo, "point ordering");
     }
+    // Launch geometry (measured on MI355X):
+    //  * Morton walk: 32-point tiles, XCD k takes the k-th contiguous eighth of the walk and ~3 workgroups
+    //    run per CU (40 KiB LDS pad), so the ~3 k points in flight on an XCD form one compact blob whose
+    //    texels stay in that XCD's 4 MiB L2 (C2 dense 2.84 -> 2.48 ms, C4 patch 13.0 -> 5.3 ms);
+    //  * caller order: 128-point tiles, round-robin XCDs (0.80 ms on C2 patch); for maps far beyond the
+    //    256 MiB Infinity Cache 64-point tiles at 2 workgroups per CU (3.2 -> 2.96 ms on C2 dense).
+    bool xcd_remap = false;
+    if (reorder) {
+        P.tile_pts = 32; P.lds_pad = 40 * 1024; xcd_remap = true;
+    } else if (map_bytes > (512LL << 20) && P.tile_pts > 64) {
+        P.tile_pts = 64; P.lds_pad = 64 * 1024;
+    }
+    if (tl >= 5 && tl <= 8) { P.tile_pts = (1 << tl) <= max_tile ? (1 << tl) : max_tile; P.lds_pad = 0; }
+    if ((flags >> 16) & 0xFF) P.lds_pad = ((int)((flags >> 16) & 0xFF) == 0xFF) ? 0 : (int)((flags >> 16) & 0xFF) * 1024;
+    if (flags & D3F_TUNE_XCD_REMAP) xcd_remap = !xcd_remap;
+    P.flags = (flags & ~D3F_TUNE_XCD_REMAP) | (xcd_remap ? D3F_TUNE_XCD_REMAP : 0u);
     // texel windows only fit LDS when the tiles are spatially compact, i.e. on the Morton walk
-    if (stage_any && reorder && !(tl >= 5 && tl <= 8)) {
+    if (stage_any && reorder) {
         for (int s = 0; s < n_maps; ++s)
             if (staging_candidate(P.maps[s], views->H, views->W)) pick_staged_mapping(P.maps[s]);
-        P.tile_pts = 32;
+        P.tile_pts = 32; P.lds_pad = 0;
         P.stage_floats = d3f::kStageFloats;
     }
     P.stage_offset = d3f::fused_lds_base(P.tile_pts, views->V);
@@ -195,7 +208,7 @@ int eval_common(const d3f_views *views, const float *pts, int64_t n, const d3f_c
             const bool on = s < n_maps;
             plan_out->vector_floats[s] = on ? P.maps[s].vw : 0;
             plan_out->lanes_per_point[s] = on ? (1 << P.maps[s].lpp_log2) : 0;
-            plan_out->vectors_per_lane[s] = on ? P.maps[s].unroll : 0;
+            plan_out->vectors_per_lane[s] = on ? P.maps[s].unroll : 0;   /* negative: load-use per vector */
             plan_out->staged[s] = on ? P.maps[s].staged : 0;
         }
         return D3F_OK;

@@ -20,7 +20,7 @@ struct MapDesc {
     int32_t fh, fw, C;
     int32_t vw;        // channel-vector width in floats: 4, 2 or 1
     int32_t lpp_log2;  // log2(lanes per point) in phase B
-    int32_t unroll;    // channel vectors per lane per pass (1..4)
+    int32_t unroll;    // channel vectors per lane per pass: +1..+3 batched loads, -1..-4 load-use per vector
     int32_t staged;    // 1: gather through the LDS texel window (low-resolution wide maps, Morton-ordered tiles)
 };
 

@@ -106,7 +106,7 @@ template <int VW>
 __device__ __forceinline__ void backward_map_u(const MapDesc &m, const float *gout, const BackwardParams &P,
                                                const BwdRec *rec, float *dots, int64_t tile_base, int tile_n)
 {
-    switch (m.unroll) {
+    switch (m.unroll < 0 ? -m.unroll : m.unroll) {
     case 1: backward_map<VW, 1>(m, gout, P, rec, dots, tile_base, tile_n); break;
     case 2: backward_map<VW, 2>(m, gout, P, rec, dots, tile_base, tile_n); break;
     case 3: backward_map<VW, 3>(m, gout, P, rec, dots, tile_base, tile_n); break;

@@ -40,7 +40,7 @@ struct ViewRec {
 // A group of LPP = 1<<lpp_log2 lanes serves one point; lane g of the group owns channel
 // vectors  pass*LPP*U + u*LPP + g  (u < U), so one load instruction of a group covers
 // LPP*VW*4 contiguous bytes of a texel.
-template <int VW, int U>
+template <int VW, int U, bool BATCH>
 __device__ __forceinline__ void gather_map(const MapDesc &m, const EvalParams &P, const ViewRec *rec,
                                            const float *cnt_s, const uint32_t *flag_s,
                                            const uint32_t *idx_s, int64_t idx_base, int tile_n)
@@ -86,26 +86,60 @@ __device__ __forceinline__ void gather_map(const MapDesc &m, const EvalParams &P
                 const char *bv = reinterpret_cast<const char *>(data) + (int64_t)v * m.sv * 4;
                 const uint32_t r0 = (uint32_t)yi0 * sy_b, r1 = (uint32_t)yi1 * sy_b;
                 const uint32_t q0 = (uint32_t)xi0 * sx_b, q1 = (uint32_t)xi1 * sx_b;
+                VT a[U], b[U], d[U], e[U];
+                if (BATCH) {
+                    // cache-resident maps: all 4*U loads in flight before the first use (latency-bound regime)
 #pragma unroll
-                for (int u = 0; u < U; ++u) {
-                    const int cv = min(c0 + u * lpp + g, cvec - 1);     // idle lanes re-read the last vector
-                    const uint32_t co = (uint32_t)cv * (VW * 4);
-                    VT a = *reinterpret_cast<const VT *>(bv + (r0 + q0 + co));
-                    VT b = *reinterpret_cast<const VT *>(bv + (r0 + q1 + co));
-                    VT d = *reinterpret_cast<const VT *>(bv + (r1 + q0 + co));
-                    VT e = *reinterpret_cast<const VT *>(bv + (r1 + q1 + co));
-                    a = inw ? a : (VT)0.0f;
-                    b = ine ? b : (VT)0.0f;
-                    d = isw ? d : (VT)0.0f;
-                    e = ise ? e : (VT)0.0f;
-                    VT s = a * wnw;                        // ATen bilinear: fma chain nw,ne,sw,se
-                    s = v_fma<VT>(b, wne, s);
-                    s = v_fma<VT>(d, wsw, s);
-                    s = v_fma<VT>(e, wse, s);
-                    if (m.inter && c0 + u * lpp + g < cvec)   // '<k>_inter' [V,n,C]  fusion.py:389
-                        store_vec<VT>(m.inter + ((int64_t)v * P.n + i) * m.C + cv * VW, s);
-                    if (strict) s = s * r.valid;           // fusion.py:385; a valid view has valid == 1: s*1 == s
-                    acc[u] = acc[u] + s * r.wgt;
+                    for (int u = 0; u < U; ++u) {
+                        const int cv = min(c0 + u * lpp + g, cvec - 1);     // idle lanes re-read the last vector
+                        const uint32_t co = (uint32_t)cv * (VW * 4);
+                        a[u] = *reinterpret_cast<const VT *>(bv + (r0 + q0 + co));
+                        b[u] = *reinterpret_cast<const VT *>(bv + (r0 + q1 + co));
+                        d[u] = *reinterpret_cast<const VT *>(bv + (r1 + q0 + co));
+                        e[u] = *reinterpret_cast<const VT *>(bv + (r1 + q1 + co));
+                    }
+                }
+                if (!strict) {
+                    // Finite maps, finite coordinates, valid view: a zero WEIGHT is the zeros padding
+                    // (x*0 == +-0 for finite x, and +-0 never changes the sums below), valid_v == 1.
+                    const float w0 = inw ? wnw : 0.0f, w1 = ine ? wne : 0.0f, w2 = isw ? wsw : 0.0f, w3 = ise ? wse : 0.0f;
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {
+                        if (!BATCH) {      // maps larger than the caches: a smaller in-flight footprint measured faster
+                            const uint32_t co = (uint32_t)min(c0 + u * lpp + g, cvec - 1) * (VW * 4);
+                            a[u] = *reinterpret_cast<const VT *>(bv + (r0 + q0 + co));
+                            b[u] = *reinterpret_cast<const VT *>(bv + (r0 + q1 + co));
+                            d[u] = *reinterpret_cast<const VT *>(bv + (r1 + q0 + co));
+                            e[u] = *reinterpret_cast<const VT *>(bv + (r1 + q1 + co));
+                        }
+                        VT s = a[u] * w0;                  // ATen bilinear: fma chain nw,ne,sw,se
+                        s = v_fma<VT>(b[u], w1, s);
+                        s = v_fma<VT>(d[u], w2, s);
+                        s = v_fma<VT>(e[u], w3, s);
+                        acc[u] = acc[u] + s * r.wgt;       // fusion.py:385
+                        if (!BATCH) __builtin_amdgcn_sched_barrier(0);   // keep the next vector's loads behind this use
+                    }
+                } else {
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {
+                        if (!BATCH) {
+                            const uint32_t co = (uint32_t)min(c0 + u * lpp + g, cvec - 1) * (VW * 4);
+                            a[u] = *reinterpret_cast<const VT *>(bv + (r0 + q0 + co));
+                            b[u] = *reinterpret_cast<const VT *>(bv + (r0 + q1 + co));
+                            d[u] = *reinterpret_cast<const VT *>(bv + (r1 + q0 + co));
+                            e[u] = *reinterpret_cast<const VT *>(bv + (r1 + q1 + co));
+                        }
+                        const VT av = inw ? a[u] : (VT)0.0f, bvv = ine ? b[u] : (VT)0.0f;
+                        const VT dv = isw ? d[u] : (VT)0.0f, ev = ise ? e[u] : (VT)0.0f;
+                        VT s = av * wnw;
+                        s = v_fma<VT>(bvv, wne, s);
+                        s = v_fma<VT>(dv, wsw, s);
+                        s = v_fma<VT>(ev, wse, s);
+                        const int cv = c0 + u * lpp + g;
+                        if (m.inter && cv < cvec)          // '<k>_inter' [V,n,C]  fusion.py:389
+                            store_vec<VT>(m.inter + ((int64_t)v * P.n + i) * m.C + cv * VW, s);
+                        acc[u] = acc[u] + (s * r.valid) * r.wgt;        // fusion.py:385
+                    }
                 }
             }
 #pragma unroll
@@ -304,10 +338,13 @@ __device__ __forceinline__ void gather_map_u(const MapDesc &m, const EvalParams 
                                              const uint32_t *idx_s, int64_t idx_base, int tile_n)
 {
     switch (m.unroll) {
-    case 1: gather_map<VW, 1>(m, P, rec, cnt_s, flag_s, idx_s, idx_base, tile_n); break;
-    case 2: gather_map<VW, 2>(m, P, rec, cnt_s, flag_s, idx_s, idx_base, tile_n); break;
-    case 3: gather_map<VW, 3>(m, P, rec, cnt_s, flag_s, idx_s, idx_base, tile_n); break;
-    default: gather_map<VW, 4>(m, P, rec, cnt_s, flag_s, idx_s, idx_base, tile_n); break;
+    case 1: gather_map<VW, 1, true>(m, P, rec, cnt_s, flag_s, idx_s, idx_base, tile_n); break;
+    case 2: gather_map<VW, 2, true>(m, P, rec, cnt_s, flag_s, idx_s, idx_base, tile_n); break;
+    case 3: gather_map<VW, 3, true>(m, P, rec, cnt_s, flag_s, idx_s, idx_base, tile_n); break;
+    case -1: gather_map<VW, 1, false>(m, P, rec, cnt_s, flag_s, idx_s, idx_base, tile_n); break;
+    case -2: gather_map<VW, 2, false>(m, P, rec, cnt_s, flag_s, idx_s, idx_base, tile_n); break;
+    case -3: gather_map<VW, 3, false>(m, P, rec, cnt_s, flag_s, idx_s, idx_base, tile_n); break;
+    default: gather_map<VW, 4, false>(m, P, rec, cnt_s, flag_s, idx_s, idx_base, tile_n); break;
     }
 }
 

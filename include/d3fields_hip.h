@@ -49,12 +49,13 @@ extern "C" {
 
 /* Tuning bits of `flags` (performance experiments; results never depend on them):
  *   bits 8..11  log2 of the points per workgroup (5..8), 0 = automatic
- *   bit  12     remap workgroups to XCD-contiguous tile ranges (measured slower: off by default)
+ *   bit  12     invert the default XCD mapping (default: XCD-contiguous tile ranges on the Morton walk,
+ *               round-robin otherwise)
  *   bit  13     never reorder points, even when a workspace is supplied
  *   bit  14     always reorder points when a workspace is supplied
  *   bit  15     stage texel windows of low-resolution wide maps through LDS (experimental:
  *               bit-identical, measured slower than the direct gather on MI355X, off by default)
- *   bits 16..23 extra dynamic LDS per workgroup in KiB (throttles workgroups per CU)      */
+ *   bits 16..23 extra dynamic LDS per workgroup in KiB (throttles workgroups per CU); 255 = none      */
 #define D3F_TUNE_TILE_LOG2(k) (((uint32_t)(k) & 0xFu) << 8)
 #define D3F_TUNE_XCD_REMAP (1u << 12)
 #define D3F_TUNE_NO_REORDER (1u << 13)

@@ -90,3 +90,43 @@ def test_workspace_size():
     assert lib.d3f_softmax_workspace_bytes(0, 10) == 0
     assert lib.d3f_softmax_workspace_bytes(1, 1) == 2 * 16
     assert lib.d3f_softmax_workspace_bytes(100000, 300) == (391 + 1) * 300 * 16
+
+
+def _plan(V, H, W, n, maps, flags=0, ws=1, inter=0):
+    lib = _lib.load()
+    v = _lib.Views(V, H, W, 16, 16, 16)
+    arr = (_lib.ChannelMap * max(len(maps), 1))()
+    for i, (fh, fw, C) in enumerate(maps):
+        arr[i] = _lib.ChannelMap(16, fh, fw, C, 0, fh * fw * C, fw * C, C)
+    p = _lib.EvalPlan()
+    assert lib.d3f_eval_plan_query(ctypes.byref(v), n, arr, len(maps), flags, ws, inter, ctypes.byref(p)) == 0
+    return p
+
+
+def test_launch_plan_host_logic():
+    """The launch geometry / lane mapping the host picks (no GPU needed: d3f_eval_plan_query)."""
+    # C2 patch-res: cache-resident map -> caller order, 128-point tiles, 32 lanes x 3 float4 per point, batched loads
+    p = _plan(4, 480, 640, 985600, [(48, 64, 384)])
+    assert (p.tile_points, p.reorder, p.workgroups) == (128, 0, 7700)
+    assert (p.vector_floats[0], p.lanes_per_point[0], p.vectors_per_lane[0], p.staged[0]) == (4, 32, 3, 0)
+    # C2 dense: 1.9 GB of maps -> Morton walk, 32-point tiles, load-use per vector; without scratch: 64-point tiles
+    p = _plan(4, 480, 640, 985600, [(480, 640, 384)])
+    assert (p.tile_points, p.reorder, p.vectors_per_lane[0]) == (32, 1, -3)
+    p = _plan(4, 480, 640, 985600, [(480, 640, 384)], ws=0)
+    assert (p.tile_points, p.reorder) == (64, 0)
+    # C4: 8 views x 1024 channels -> whole wave per point, 4 float4 per lane
+    p = _plan(8, 720, 1280, 1000000, [(72, 128, 1024)])
+    assert (p.lanes_per_point[0], abs(p.vectors_per_lane[0]), p.reorder) == (64, 4, 1)
+    # small batches are never reordered; mask (C=8) -> 2 lanes per point; colour (C=3) -> scalar lanes
+    p = _plan(4, 480, 640, 60000, [(48, 64, 384), (480, 640, 8), (480, 640, 3)])
+    assert p.reorder == 0
+    assert (p.vector_floats[1], p.lanes_per_point[1], p.vectors_per_lane[1]) == (4, 2, 1)
+    assert (p.vector_floats[2], p.lanes_per_point[2], p.vectors_per_lane[2]) == (1, 1, 3)
+    # many views shrink the tile so that the per-(point,view) records fit LDS
+    p = _plan(64, 48, 64, 5000, [(6, 8, 16)])
+    assert p.tile_points * 64 * 24 <= 64 * 1024 and p.lds_bytes <= 64 * 1024
+    # opt-in staging only on the Morton walk
+    p = _plan(4, 480, 640, 985600, [(48, 64, 384)], flags=_lib.TUNE_STAGING)
+    assert (p.staged[0], p.reorder, p.tile_points, p.vectors_per_lane[0]) == (1, 1, 32, 3)
+    p = _plan(4, 480, 640, 985600, [(48, 64, 384)], flags=_lib.TUNE_STAGING | _lib.TUNE_NO_REORDER)
+    assert (p.staged[0], p.reorder) == (0, 0)
