@@ -55,6 +55,7 @@ SIGNATURES = {
     "d3f_eval": (ctypes.c_int, [ctypes.POINTER(Views), _vp, _i64, ctypes.POINTER(ChannelMap), _i32, _f32, _u32,
                                 _vp, _vp, ctypes.POINTER(_vp), ctypes.POINTER(_vp), _vp, _i64, _vp]),
     "d3f_eval_workspace_bytes": (_i64, [_i64]),
+    "d3f_profile_next_eval": (None, [_vp, _vp]),
     "d3f_eval_plan_query": (ctypes.c_int, [ctypes.POINTER(Views), _i64, ctypes.POINTER(ChannelMap), _i32, _u32, _i32, _i32,
                                            ctypes.POINTER(EvalPlan)]),
     "d3f_eval_backward": (ctypes.c_int, [ctypes.POINTER(Views), _vp, _i64, ctypes.POINTER(ChannelMap), _i32, _f32,

@@ -10,6 +10,7 @@
 namespace {
 
 thread_local char g_err[512] = "";
+thread_local hipEvent_t g_prof_start = nullptr, g_prof_stop = nullptr;   // one-shot, see d3f_profile_next_eval
 
 int fail(int code, const char *fmt, ...)
 {
@@ -213,7 +214,11 @@ int eval_common(const d3f_views *views, const float *pts, int64_t n, const d3f_c
         }
         return D3F_OK;
     }
+    hipEvent_t ev0 = g_prof_start, ev1 = g_prof_stop;
+    g_prof_start = g_prof_stop = nullptr;
+    if (ev0) (void)hipEventRecord(ev0, hs);
     hipError_t e = d3f::launch_fused_eval(P, mode, hs);
+    if (ev1) (void)hipEventRecord(ev1, hs);
     if (e != hipSuccess) return hip_fail(e, "fused_eval launch");
     return D3F_OK;
 }
@@ -235,6 +240,12 @@ int d3f_eval(const d3f_views *views, const float *pts, int64_t n, const d3f_chan
 }
 
 int64_t d3f_eval_workspace_bytes(int64_t n) { return d3f::order_workspace_bytes(n); }
+
+void d3f_profile_next_eval(void *start_event, void *stop_event)
+{
+    g_prof_start = static_cast<hipEvent_t>(start_event);
+    g_prof_stop = static_cast<hipEvent_t>(stop_event);
+}
 
 int d3f_eval_plan_query(const d3f_views *views, int64_t n, const d3f_channel_map *maps, int32_t n_maps, uint32_t flags,
                         int32_t have_workspace, int32_t want_inter, d3f_eval_plan *plan)

@@ -109,6 +109,11 @@ int d3f_eval(const d3f_views *views, const float *pts, int64_t n, const d3f_chan
  * (Morton) order when the maps are much larger than the caches; outputs are unaffected. */
 int64_t d3f_eval_workspace_bytes(int64_t n);
 
+/* Measurement hook: the calling thread's NEXT d3f_eval / d3f_eval_dist records these two hipEvent_t
+ * (NULL = none) on its stream immediately before and after the fused kernel launch, i.e. around the
+ * dominant kernel only (not the optional point-ordering kernels).  One-shot. */
+void d3f_profile_next_eval(void *start_event, void *stop_event);
+
 /* What d3f_eval would launch for these shapes (no device work; usable without a GPU): the launch
  * geometry and the per-map lane mapping the host logic picked.  For tests and tuning. */
 typedef struct d3f_eval_plan {
