@@ -15,6 +15,7 @@ shape):
   c2_patch  same, reference-faithful patch-resolution 48x64x384 features (fusion.py:694-697)
   c3_dense / c3_patch  + 480x640x8 one-hot instance mask, 1 925 000-point grid (step 4 mm)
   c4_patch  8 views x 720x1280, 72x128x1024 features, 1 000 000 points per GPU
+  c5_track  one tracking frame: eval of 100 000 keypoints (features + mask) + descriptor correspondence
 Multi-GPU: weak scaling -- every rank queries its own shard of N points against replicated
 maps; the only exchange is the RCCL all-gather that reassembles the field (`--gather`).
 """
@@ -39,6 +40,9 @@ WORKLOADS = {
     "c3_dense": dict(V=4, H=480, W=640, C=384, fhw=(480, 640), NI=8, step=0.004, N=1925000),
     "c3_patch": dict(V=4, H=480, W=640, C=384, fhw=(48, 64), NI=8, step=0.004, N=1925000),
     "c4_patch": dict(V=8, H=720, W=1280, C=1024, fhw=(72, 128), NI=0, step=None, N=1000000),
+    # BASELINE config 5: one tracking frame = Fusion.eval of 100 k keypoints (features + instance mask) followed by the
+    # descriptor correspondence of utils/corr_utils.py against 300 reference descriptors (+ fused argmax)
+    "c5_track": dict(V=4, H=480, W=640, C=384, fhw=(48, 64), NI=8, step=None, N=100000, corr_refs=300),
 }
 
 
@@ -203,8 +207,16 @@ def main():
     n = pts.shape[0]
     from d3fields_amd import sharding
 
+    corr_src = None
+    if w.get("corr_refs"):
+        from d3fields_amd import corr_utils
+        corr_src = torch.randn(w["corr_refs"], w["C"], generator=torch.Generator().manual_seed(11)).to(dev)
+
     def compute():
-        return f.batch_eval(pts, return_names=names)
+        out = f.batch_eval(pts, return_names=names)
+        if corr_src is not None:        # keypoint descriptors vs reference descriptors: softmax similarity + best match
+            out["similarity"], out["match"] = corr_utils.nearest_descriptor(out["dino_feats"], corr_src, 1.0)
+        return out
 
     def step():
         out = compute()

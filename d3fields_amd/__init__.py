@@ -6,7 +6,7 @@
 The compute lives in libd3fields_hip.so (hand-written HIP, C ABI in include/d3fields_hip.h);
 this package is the host-side mirror of the reference's Python interface.
 """
-from .fusion import Fusion, create_init_grid, instance2onehot, onehot2instance  # noqa: F401
+from .fusion import Fusion, create_init_grid, fps, instance2onehot, onehot2instance  # noqa: F401
 from . import corr_utils  # noqa: F401
 
 __version__ = "0.1.0"

@@ -40,6 +40,11 @@ class ChannelMap(ctypes.Structure):
                 ("stride_v", _i64), ("stride_y", _i64), ("stride_x", _i64)]
 
 
+class Grid(ctypes.Structure):
+    """struct d3f_grid"""
+    _fields_ = [("x", _vp), ("y", _vp), ("z", _vp), ("nx", _i32), ("ny", _i32), ("nz", _i32), ("reserved", _i32)]
+
+
 class EvalPlan(ctypes.Structure):
     """struct d3f_eval_plan"""
     _fields_ = [("tile_points", _i32), ("reorder", _i32), ("lds_bytes", _i32), ("reserved", _i32), ("workgroups", _i64),
@@ -58,6 +63,10 @@ SIGNATURES = {
     "d3f_profile_next_eval": (None, [_vp, _vp]),
     "d3f_eval_plan_query": (ctypes.c_int, [ctypes.POINTER(Views), _i64, ctypes.POINTER(ChannelMap), _i32, _u32, _i32, _i32,
                                            ctypes.POINTER(EvalPlan)]),
+    "d3f_eval_grid": (ctypes.c_int, [ctypes.POINTER(Views), ctypes.POINTER(Grid), ctypes.POINTER(ChannelMap), _i32, _f32, _u32,
+                                     _vp, _vp, ctypes.POINTER(_vp), _vp]),
+    "d3f_grid_shell": (ctypes.c_int, [ctypes.POINTER(Views), ctypes.POINTER(Grid), _f32, _f32, _i64, _vp, _vp, _vp]),
+    "d3f_farthest_point_sampling": (ctypes.c_int, [_vp, _i64, _i32, _i64, _vp, _vp, _vp, _vp]),
     "d3f_eval_backward": (ctypes.c_int, [ctypes.POINTER(Views), _vp, _i64, ctypes.POINTER(ChannelMap), _i32, _f32,
                                          _vp, ctypes.POINTER(_vp), _vp, _vp]),
     "d3f_eval_dist": (ctypes.c_int, [ctypes.POINTER(Views), _vp, _i64, _vp, _vp, _vp]),

@@ -133,14 +133,14 @@ int tile_points_for(int V)
 int eval_common(const d3f_views *views, const float *pts, int64_t n, const d3f_channel_map *maps, int32_t n_maps,
                 float mu, uint32_t flags, float *out_dist, uint8_t *out_valid, float *const *out_fused,
                 float *const *out_inter, void *workspace, int64_t workspace_bytes, void *stream, int mode,
-                d3f_eval_plan *plan_out = nullptr)
+                d3f_eval_plan *plan_out = nullptr, const d3f_grid *grid = nullptr)
 {
     const bool plan_only = plan_out != nullptr;
     int rc = check_views(views);
     if (rc != D3F_OK) return rc;
     if (n < 0) return fail(D3F_ERR_INVALID_ARG, "n=%lld is negative", (long long)n);
     if (n == 0 && !plan_only) return D3F_OK;
-    if (!plan_only && (!pts || !out_dist || !out_valid)) return fail(D3F_ERR_INVALID_ARG, "pts/out_dist/out_valid must be non-NULL");
+    if (!plan_only && ((!pts && !grid) || !out_dist || !out_valid)) return fail(D3F_ERR_INVALID_ARG, "pts/out_dist/out_valid must be non-NULL");
     if (n_maps < 0 || n_maps > D3F_MAX_MAPS) return fail(D3F_ERR_BAD_SHAPE, "n_maps=%d outside [0,%d]", n_maps, D3F_MAX_MAPS);
     if (n_maps > 0 && (!maps || (!out_fused && !plan_only))) return fail(D3F_ERR_INVALID_ARG, "maps/out_fused must be non-NULL when n_maps > 0");
     if (!(mu > 0.0f)) return fail(D3F_ERR_INVALID_ARG, "mu must be > 0");
@@ -148,6 +148,8 @@ int eval_common(const d3f_views *views, const float *pts, int64_t n, const d3f_c
     d3f::EvalParams P;
     P.depth = views->depth; P.K = views->K; P.pose = views->pose; P.pts = pts;
     P.order = nullptr; P.lds_pad = 0; P.stage_floats = 0;
+    P.grid_x = grid ? grid->x : nullptr; P.grid_y = grid ? grid->y : nullptr; P.grid_z = grid ? grid->z : nullptr;
+    P.grid_ny = grid ? grid->ny : 0; P.grid_nz = grid ? grid->nz : 0;
     int64_t map_bytes = 0;
     P.out_dist = out_dist; P.out_valid = out_valid;
     P.n = n; P.V = views->V; P.H = views->H; P.W = views->W;
@@ -164,7 +166,7 @@ int eval_common(const d3f_views *views, const float *pts, int64_t n, const d3f_c
     }
     // Morton point order (performance only) when scratch is supplied and the maps exceed the L2s
     hipStream_t hs = static_cast<hipStream_t>(stream);
-    const bool may_reorder = (workspace || plan_only) && n_maps > 0 && n <= 0x7fffffffLL && !(flags & D3F_TUNE_NO_REORDER) &&
+    const bool may_reorder = (workspace || plan_only) && !grid && n_maps > 0 && n <= 0x7fffffffLL && !(flags & D3F_TUNE_NO_REORDER) &&
                              workspace_bytes >= d3f::order_workspace_bytes(n);
     bool stage_any = false;
     if ((flags & D3F_TUNE_STAGING) && views->V * 24 * 32 <= 24 * 1024)
@@ -255,6 +257,50 @@ int d3f_eval_plan_query(const d3f_views *views, int64_t n, const d3f_channel_map
     for (int s = 0; s < D3F_MAX_MAPS; ++s) inter[s] = want_inter ? reinterpret_cast<float *>(16) : nullptr;
     return eval_common(views, nullptr, n, maps, n_maps, 0.02f, flags, nullptr, nullptr, nullptr, want_inter ? inter : nullptr,
                        nullptr, have_workspace ? d3f::order_workspace_bytes(n) : 0, nullptr, 0, plan);
+}
+
+static int check_grid(const d3f_grid *g)
+{
+    if (!g) return fail(D3F_ERR_INVALID_ARG, "grid is NULL");
+    if (g->nx < 0 || g->ny < 0 || g->nz < 0) return fail(D3F_ERR_BAD_SHAPE, "grid: negative size");
+    if ((int64_t)g->nx * g->ny * g->nz > 0 && (!g->x || !g->y || !g->z)) return fail(D3F_ERR_INVALID_ARG, "grid: axis arrays must be non-NULL");
+    return D3F_OK;
+}
+
+int d3f_eval_grid(const d3f_views *views, const d3f_grid *grid, const d3f_channel_map *maps, int32_t n_maps, float mu,
+                  uint32_t flags, float *out_dist, uint8_t *out_valid, float *const *out_fused, void *stream)
+{
+    int rc = check_grid(grid);
+    if (rc != D3F_OK) return rc;
+    return eval_common(views, nullptr, (int64_t)grid->nx * grid->ny * grid->nz, maps, n_maps, mu, flags, out_dist, out_valid,
+                       out_fused, nullptr, nullptr, 0, stream, 0, nullptr, grid);
+}
+
+int d3f_grid_shell(const d3f_views *views, const d3f_grid *grid, float mu, float dist_thr, int64_t capacity, int64_t *idx_out,
+                   int64_t *count_out, void *stream)
+{
+    int rc = check_views(views);
+    if (rc != D3F_OK) return rc;
+    rc = check_grid(grid);
+    if (rc != D3F_OK) return rc;
+    if (!count_out || capacity < 0 || (capacity > 0 && !idx_out)) return fail(D3F_ERR_INVALID_ARG, "grid_shell: idx_out/count_out/capacity");
+    if (!(mu > 0.0f)) return fail(D3F_ERR_INVALID_ARG, "mu must be > 0");
+    if (((int64_t)grid->nx * grid->ny * grid->nz + d3f::kBlock - 1) / d3f::kBlock > 0x7fffffffLL) return fail(D3F_ERR_BAD_SHAPE, "grid too large for one launch");
+    hipError_t e = d3f::launch_grid_shell(views->depth, views->K, views->pose, views->V, views->H, views->W, grid->x, grid->y,
+                                          grid->z, grid->nx, grid->ny, grid->nz, mu, dist_thr, capacity, idx_out,
+                                          reinterpret_cast<unsigned long long *>(count_out), static_cast<hipStream_t>(stream));
+    return e == hipSuccess ? D3F_OK : hip_fail(e, "grid_shell launch");
+}
+
+int d3f_farthest_point_sampling(const float *pts, int64_t n, int32_t k, int64_t init_idx, int64_t *out_idx, float *out_maxdist,
+                                float *dist_workspace, void *stream)
+{
+    if (n < 1 || k < 0) return fail(D3F_ERR_BAD_SHAPE, "fps: n=%lld must be >= 1 (fps_np asserts a non-empty cloud), k=%d", (long long)n, k);
+    if (k == 0) return D3F_OK;
+    if (!pts || !out_idx || !dist_workspace) return fail(D3F_ERR_INVALID_ARG, "fps: NULL pointer");
+    if (init_idx < 0 || init_idx >= n) return fail(D3F_ERR_INVALID_ARG, "fps: init_idx=%lld outside [0,%lld)", (long long)init_idx, (long long)n);
+    hipError_t e = d3f::launch_fps(pts, n, k, init_idx, out_idx, out_maxdist, dist_workspace, static_cast<hipStream_t>(stream));
+    return e == hipSuccess ? D3F_OK : hip_fail(e, "fps launch");
 }
 
 int d3f_eval_backward(const d3f_views *views, const float *pts, int64_t n, const d3f_channel_map *maps, int32_t n_maps,

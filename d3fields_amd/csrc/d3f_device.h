@@ -82,4 +82,36 @@ __device__ __forceinline__ float nearest_depth(const float *depth, int v, int H,
     return d;
 }
 
+// One (point, view) of the forward: projection, nearest depth, validity, weight.
+struct ViewOut {
+    float gx, gy;
+    float dist;     // clamp(d - zc, -mu, mu) for eval, d - zc for eval_dist
+    float valid;    // 1.0f / 0.0f
+};
+
+template <int MODE>
+__device__ __forceinline__ ViewOut eval_view(const float *depth, int H, int W, const float *M, int v, float px, float py,
+                                             float pz, float Wm1, float Hm1, float mu, float &wgt)
+{
+    const Proj pr = project_point(M, px, py, pz, Wm1, Hm1);
+    const float d = nearest_depth(depth, v, H, W, pr.gx, pr.gy);
+    float dist = d - pr.zc;                                                 // fusion.py:343
+    bool valid;
+    wgt = 1.0f;
+    if (MODE == 0) {
+        valid = (d > 0.0f) && pr.ok && (dist > -mu);                        // fusion.py:344
+        float t = mu - fabsf(dist);                                         // fusion.py:347
+        t = t > 0.0f ? 0.0f : t;
+        wgt = expf(t / mu);
+        float dc = dist < -mu ? -mu : dist;                                 // fusion.py:358
+        dc = dc > mu ? mu : dc;
+        dist = dc;
+    } else {
+        valid = (d > 0.0f) && pr.ok;                                        // fusion.py:426
+    }
+    ViewOut o;
+    o.gx = pr.gx; o.gy = pr.gy; o.dist = dist; o.valid = valid ? 1.0f : 0.0f;
+    return o;
+}
+
 }  // namespace d3f

@@ -27,6 +27,8 @@ struct MapDesc {
 struct EvalParams {
     const float *depth, *K, *pose, *pts;
     const uint32_t *order;  // nullptr, or n point indices: the kernel processes points in this order
+    const float *grid_x, *grid_y, *grid_z;   // regular-grid mode (pts == nullptr): axis coordinate arrays
+    int32_t grid_ny, grid_nz;
     float *out_dist;
     uint8_t *out_valid;
     int64_t n;
@@ -65,6 +67,13 @@ hipError_t launch_fused_backward(const BackwardParams &P, hipStream_t stream);
 int64_t order_workspace_bytes(int64_t n);
 hipError_t build_point_order(const float *pts, int64_t n, void *workspace, int64_t workspace_bytes,
                              const uint32_t **order_out, hipStream_t stream);
+
+// grid_kernels.hip
+hipError_t launch_grid_shell(const float *depth, const float *K, const float *pose, int V, int H, int W, const float *gx,
+                             const float *gy, const float *gz, int nx, int ny, int nz, float mu, float dist_thr,
+                             int64_t capacity, int64_t *idx_out, unsigned long long *count, hipStream_t s);
+hipError_t launch_fps(const float *pts, int64_t n, int k, int64_t init_idx, int64_t *out_idx, float *out_maxdist,
+                      float *dist_ws, hipStream_t s);
 
 // misc_kernels.hip
 hipError_t launch_onehot2instance(const float *onehot, int64_t n, int NI, uint8_t *out, hipStream_t s);

@@ -359,36 +359,18 @@ __device__ __forceinline__ int64_t xcd_tile(int64_t b, int64_t nb)
 }
 
 // MODE 0: Fusion.eval semantics; MODE 1: Fusion.eval_dist semantics (fusion.py:396-436).
-// One (point, view) of the forward: projection, nearest depth, validity, weight.
-struct ViewOut {
-    float gx, gy;
-    float dist;     // clamp(d - zc, -mu, mu) for eval, d - zc for eval_dist
-    float valid;    // 1.0f / 0.0f
-};
-
-template <int MODE>
-__device__ __forceinline__ ViewOut eval_view(const EvalParams &P, const float *M, int v, float px, float py, float pz,
-                                             float Wm1, float Hm1, float mu, float &wgt)
+// Query point i: from the caller's [n,3] array, or generated from the three axis arrays of a regular
+// grid in the reference's order (create_init_grid, fusion.py:79-88: 'ij' meshgrid, z fastest).
+__device__ __forceinline__ void fetch_point(const EvalParams &P, int64_t i, float &px, float &py, float &pz)
 {
-    const Proj pr = project_point(M, px, py, pz, Wm1, Hm1);
-    const float d = nearest_depth(P.depth, v, P.H, P.W, pr.gx, pr.gy);
-    float dist = d - pr.zc;                                                 // fusion.py:343
-    bool valid;
-    wgt = 1.0f;
-    if (MODE == 0) {
-        valid = (d > 0.0f) && pr.ok && (dist > -mu);                        // fusion.py:344
-        float t = mu - fabsf(dist);                                         // fusion.py:347
-        t = t > 0.0f ? 0.0f : t;
-        wgt = expf(t / mu);
-        float dc = dist < -mu ? -mu : dist;                                 // fusion.py:358
-        dc = dc > mu ? mu : dc;
-        dist = dc;
+    if (P.grid_x) {
+        const int64_t iz = i % P.grid_nz, ixy = i / P.grid_nz;
+        px = P.grid_x[ixy / P.grid_ny];
+        py = P.grid_y[ixy % P.grid_ny];
+        pz = P.grid_z[iz];
     } else {
-        valid = (d > 0.0f) && pr.ok;                                        // fusion.py:426
+        px = P.pts[i * 3 + 0]; py = P.pts[i * 3 + 1]; pz = P.pts[i * 3 + 2];
     }
-    ViewOut o;
-    o.gx = pr.gx; o.gy = pr.gy; o.dist = dist; o.valid = valid ? 1.0f : 0.0f;
-    return o;
 }
 
 // STAGED: compiled with the LDS-window gather (more registers); the plain kernel keeps 4 waves/SIMD.
@@ -424,11 +406,12 @@ __global__ __launch_bounds__(kBlock) void fused_eval_kernel(const EvalParams P)
         // distance-only query (return_names=[], eval_dist): one lane per point, nothing staged in LDS
         for (int p = threadIdx.x; p < tile_n; p += kBlock) {
             const int64_t i = tile_base + p;
-            const float px = P.pts[i * 3 + 0], py = P.pts[i * 3 + 1], pz = P.pts[i * 3 + 2];
+            float px, py, pz;
+            fetch_point(P, i, px, py, pz);
             float dsum = 0.0f, cnt = 0.0f;
             for (int v = 0; v < V; ++v) {
                 float wgt;
-                const ViewOut o = eval_view<MODE>(P, krt + v * 12, v, px, py, pz, Wm1, Hm1, mu, wgt);
+                const ViewOut o = eval_view<MODE>(P.depth, P.H, P.W, krt + v * 12, v, px, py, pz, Wm1, Hm1, mu, wgt);
                 dsum = dsum + o.dist * o.valid;                             // fusion.py:364
                 cnt = cnt + o.valid;
             }
@@ -444,9 +427,10 @@ __global__ __launch_bounds__(kBlock) void fused_eval_kernel(const EvalParams P)
     for (int idx = threadIdx.x; idx < tile_n * V; idx += kBlock) {
         const int v = idx / tile_n, p = idx - v * tile_n;
         const int64_t i = P.order ? (int64_t)P.order[tile_base + p] : tile_base + p;
-        const float px = P.pts[i * 3 + 0], py = P.pts[i * 3 + 1], pz = P.pts[i * 3 + 2];
+        float px, py, pz;
+        fetch_point(P, i, px, py, pz);
         float wgt;
-        const ViewOut o = eval_view<MODE>(P, krt + v * 12, v, px, py, pz, Wm1, Hm1, mu, wgt);
+        const ViewOut o = eval_view<MODE>(P.depth, P.H, P.W, krt + v * 12, v, px, py, pz, Wm1, Hm1, mu, wgt);
         ViewRec r;
         r.gx = o.gx; r.gy = o.gy; r.wgt = wgt; r.valid = o.valid;
         rec[p * V + v] = r;

@@ -1,0 +1,124 @@
+// grid_kernels.hip -- keypoint selection helpers of the reference, kept on the device.
+//
+// select_features_rand (fusion.py:1418-1475) evaluates a 1-mm grid (~1e8 points) with ['mask'], keeps
+// the points with |dist| < 5 mm that are valid and mostly one instance, copies them to the host and runs a
+// numpy farthest-point sampling (utils/my_utils.py:478-497).  Here
+//   grid_shell_kernel   generates the grid points from the axis arrays (nothing of size N is read),
+//                       evaluates dist/valid with the forward's arithmetic and COMPACTS the indices of
+//                       the thin shell |dist| < thr & valid (about 1 % of the grid), so that the wide
+//                       mask query runs on the survivors only and no [N,NI] tensor is ever written;
+//   fps_kernel          farthest point sampling of the survivors, one workgroup, same float32
+//                       arithmetic and first-maximum tie rule as numpy (bit-identical selection).
+#include "d3f_internal.h"
+#include "d3f_device.h"
+
+namespace d3f {
+
+__global__ __launch_bounds__(kBlock) void grid_shell_kernel(const float *__restrict__ depth, const float *__restrict__ K,
+                                                           const float *__restrict__ pose, int V, int H, int W,
+                                                           const float *__restrict__ gx, const float *__restrict__ gy,
+                                                           const float *__restrict__ gz, int ny, int nz, int64_t n, float mu,
+                                                           float dist_thr, int64_t capacity, int64_t *__restrict__ idx_out,
+                                                           unsigned long long *__restrict__ count)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    float *krt = reinterpret_cast<float *>(smem);
+    compute_krt(K, pose, V, krt, kBlock);
+    __syncthreads();
+    const float Wm1 = (float)(W - 1), Hm1 = (float)(H - 1);
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    bool keep = false;
+    if (i < n) {
+        const int64_t iz = i % nz, ixy = i / nz;
+        const float px = gx[ixy / ny], py = gy[ixy % ny], pz = gz[iz];
+        float dsum = 0.0f, cnt = 0.0f;
+        for (int v = 0; v < V; ++v) {
+            float wgt;
+            const ViewOut o = eval_view<0>(depth, H, W, krt + v * 12, v, px, py, pz, Wm1, Hm1, mu, wgt);
+            dsum = dsum + o.dist * o.valid;
+            cnt = cnt + o.valid;
+        }
+        // fusion.py:1430, 1444: |dist| < dist_threshold and valid_mask (an all-invalid point has dist = 1e3)
+        keep = (cnt != 0.0f) && (fabsf(dsum / (cnt + 1e-6f)) < dist_thr);
+    }
+    // wave-level compaction: one atomic per wave, survivors of a wave stay in index order
+    const unsigned long long ballot = __ballot(keep);
+    const int lane = threadIdx.x & 63;
+    unsigned long long base = 0;
+    if (lane == 0 && ballot) base = atomicAdd(count, (unsigned long long)__popcll(ballot));
+    base = __shfl(base, 0, 64);
+    if (keep) {
+        const unsigned long long slot = base + (unsigned long long)__popcll(ballot & ((1ull << lane) - 1ull));
+        if ((int64_t)slot < capacity) idx_out[slot] = i;
+    }
+}
+
+hipError_t launch_grid_shell(const float *depth, const float *K, const float *pose, int V, int H, int W, const float *gx,
+                             const float *gy, const float *gz, int nx, int ny, int nz, float mu, float dist_thr,
+                             int64_t capacity, int64_t *idx_out, unsigned long long *count, hipStream_t s)
+{
+    const int64_t n = (int64_t)nx * ny * nz;
+    hipError_t e = hipMemsetAsync(count, 0, sizeof(unsigned long long), s);
+    if (e != hipSuccess || n == 0) return e;
+    hipLaunchKernelGGL(grid_shell_kernel, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), (size_t)V * 48, s, depth,
+                       K, pose, V, H, W, gx, gy, gz, ny, nz, n, mu, dist_thr, capacity, idx_out, count);
+    return hipGetLastError();
+}
+
+// ---- farthest point sampling (utils/my_utils.py:478-497 fps_np) ---------------------------------------
+// dist_i = min over chosen of sqrt((dx*dx + dy*dy) + dz*dz)   (float32, numpy's summation order, no fma)
+// next   = first index of the maximum.  One 1024-thread workgroup: k sequential rounds over n points.
+constexpr int kFpsBlock = 1024;
+
+__global__ __launch_bounds__(kFpsBlock) void fps_kernel(const float *__restrict__ pts, int64_t n, int k, int64_t init_idx,
+                                                       int64_t *__restrict__ out_idx, float *__restrict__ out_maxdist,
+                                                       float *__restrict__ dist)
+{
+    __shared__ float red_v[kFpsBlock / 64];
+    __shared__ long long red_i[kFpsBlock / 64];
+    __shared__ long long cur_s;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    long long cur = init_idx;
+    float best_v = 0.0f;
+    for (int round = 0; round < k; ++round) {
+        if (tid == 0) out_idx[round] = cur;
+        const float cx = pts[cur * 3 + 0], cy = pts[cur * 3 + 1], cz = pts[cur * 3 + 2];
+        float bv = -1.0f;
+        long long bi = 0x7fffffffffffffffLL;
+        for (int64_t i = tid; i < n; i += kFpsBlock) {
+            const float dx = pts[i * 3 + 0] - cx, dy = pts[i * 3 + 1] - cy, dz = pts[i * 3 + 2] - cz;
+            float d = sqrtf((dx * dx + dy * dy) + dz * dz);
+            if (round > 0) d = fminf(dist[i], d);
+            dist[i] = d;
+            if (d > bv) { bv = d; bi = i; }            // strided scan: smaller i first, so '>' keeps the first maximum
+        }
+        // workgroup argmax with first-index tie rule
+        for (int off = 32; off > 0; off >>= 1) {
+            const float ov = __shfl_xor(bv, off, 64);
+            const long long oi = __shfl_xor(bi, off, 64);
+            if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+        }
+        if (lane == 0) { red_v[wave] = bv; red_i[wave] = bi; }
+        __syncthreads();
+        if (tid == 0) {
+            float v = red_v[0];
+            long long ix = red_i[0];
+            for (int w = 1; w < kFpsBlock / 64; ++w)
+                if (red_v[w] > v || (red_v[w] == v && red_i[w] < ix)) { v = red_v[w]; ix = red_i[w]; }
+            cur_s = ix;
+            best_v = v;
+        }
+        __syncthreads();
+        cur = cur_s;
+    }
+    if (tid == 0 && out_maxdist) *out_maxdist = best_v;    // fps_np's third return value: dist.max() after the last update
+}
+
+hipError_t launch_fps(const float *pts, int64_t n, int k, int64_t init_idx, int64_t *out_idx, float *out_maxdist,
+                      float *dist_ws, hipStream_t s)
+{
+    hipLaunchKernelGGL(fps_kernel, dim3(1), dim3(kFpsBlock), 0, s, pts, n, k, init_idx, out_idx, out_maxdist, dist_ws);
+    return hipGetLastError();
+}
+
+}  // namespace d3f

@@ -17,7 +17,7 @@ import torch
 
 from . import _lib
 
-__all__ = ["Fusion", "create_init_grid", "instance2onehot", "onehot2instance"]
+__all__ = ["Fusion", "create_init_grid", "instance2onehot", "onehot2instance", "fps"]
 
 _RESERVED = ("depth", "pose", "K", "color")
 
@@ -25,16 +25,54 @@ _RESERVED = ("depth", "pose", "K", "color")
 # ----------------------------------------------------------------------------------------
 # grid / mask-format helpers (reference fusion.py:79-116)
 # ----------------------------------------------------------------------------------------
+def _grid_axes(boundaries, step_size):
+    """The three axis tensors of the reference grid (fusion.py:82-84): arange(lower, upper, step) + step/2, float32."""
+    return [torch.arange(boundaries[ax + "_lower"], boundaries[ax + "_upper"], step_size, dtype=torch.float32) + step_size / 2
+            for ax in "xyz"]
+
+
+def fps(pcd, particle_num, init_idx=-1):
+    """Farthest point sampling with the signature and results of the reference's fps_np
+    (utils/my_utils.py:478-497): returns (pcd_fps [k,3], fps_idx list, max remaining distance).
+
+    numpy in -> numpy out like the reference; a CUDA tensor in -> (tensor, index tensor, float).  Runs as
+    one HIP workgroup with numpy's float32 arithmetic and first-maximum tie rule, so for a given init_idx
+    the selection is identical to fps_np's.  init_idx == -1 draws the start with np.random.randint, as
+    the reference does.  (fps_np loops until len == particle_num and would spin forever on clouds smaller
+    than that after exhausting them; here particle_num is clamped to the cloud size.)
+    """
+    as_numpy = isinstance(pcd, np.ndarray)
+    if as_numpy:
+        dev = torch.device("cuda", torch.cuda.current_device())
+        pts = torch.from_numpy(np.ascontiguousarray(pcd, dtype=np.float32)).to(dev)
+    else:
+        if not pcd.is_cuda:
+            raise RuntimeError("fps: torch input must be on the ROCm device (no CPU path)")
+        dev = pcd.device
+        pts = pcd.to(torch.float32).contiguous()
+    n = pts.shape[0]
+    assert n > 0 and pts.dim() == 2 and pts.shape[1] == 3
+    start = int(np.random.randint(n)) if init_idx == -1 else int(init_idx)
+    k = min(int(particle_num), n)
+    idx = torch.empty(k, dtype=torch.int64, device=dev)
+    maxd = torch.empty(1, dtype=torch.float32, device=dev)
+    ws = torch.empty(n, dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(_lib.load().d3f_farthest_point_sampling(_lib.ptr(pts), n, k, start, _lib.ptr(idx), _lib.ptr(maxd),
+                                                           _lib.ptr(ws), _lib.current_stream_handle(dev)))
+    sel = pts[idx]
+    if as_numpy:
+        return sel.cpu().numpy(), idx.cpu().tolist(), float(maxd.item())
+    return sel, idx, float(maxd.item())
+
+
 def create_init_grid(boundaries, step_size):
     """Voxel-centre grid, z fastest; returns (coords [N,3] float32, (nx,ny,nz)).
 
     Same values and order as the reference helper (fusion.py:79-88): per-axis
     ``arange(lower, upper, step) + step/2`` in float32, 'ij' ordering.
     """
-    axes = []
-    for ax in "xyz":
-        lo, hi = boundaries[ax + "_lower"], boundaries[ax + "_upper"]
-        axes.append(torch.arange(lo, hi, step_size, dtype=torch.float32) + step_size / 2)
+    axes = _grid_axes(boundaries, step_size)
     coords = torch.cartesian_prod(*axes)
     shape = torch.Size([a.numel() for a in axes])
     return coords, shape
@@ -305,6 +343,95 @@ class Fusion:
         kernel has none, so the whole batch is one launch with the same concatenated result.
         """
         return self._run(pts, return_names, False, "eval")
+
+    # ---- regular grids and keypoint selection (SURVEY §8f rows 2-3) ---------------------------
+    def _grid(self, boundaries, step_size):
+        axes = [a.to(self.device) for a in _grid_axes(boundaries, step_size)]
+        g = _lib.Grid(_lib.ptr(axes[0]), _lib.ptr(axes[1]), _lib.ptr(axes[2]), axes[0].numel(), axes[1].numel(), axes[2].numel(), 0)
+        return g, axes
+
+    def eval_grid(self, boundaries, step_size, return_names=[]):
+        """batch_eval(create_init_grid(boundaries, step_size)[0].to(device), return_names) without ever
+        materialising the grid (the reference's first pass, vis_repr.py:88-93): the kernel generates each
+        voxel centre from the axis arrays.  Same dict as batch_eval, in flat grid order, plus 'grid_shape'."""
+        if len(self.curr_obs_torch) == 0:
+            raise RuntimeError("Please call update() first!")
+        dev = self.device
+        lib = self._lib
+        grid, axes = self._grid(boundaries, step_size)
+        n = grid.nx * grid.ny * grid.nz
+        views, keep, V = self._views(dev)
+        names = list(return_names)
+        dist = torch.empty(n, dtype=torch.float32, device=dev)
+        valid = torch.empty(n, dtype=torch.bool, device=dev)
+        out = {"dist": dist, "valid_mask": valid, "grid_shape": torch.Size([grid.nx, grid.ny, grid.nz])}
+        maps = (_lib.ChannelMap * max(len(names), 1))()
+        fused = (ctypes.c_void_p * max(len(names), 1))()
+        finite = self._is_finite("depth", keep[0])
+        for s, k in enumerate(names):
+            m = self.curr_obs_torch[k]
+            if m.stride(3) != 1:
+                m = m.contiguous()
+                keep.append(m)
+            finite = finite and self._is_finite(k, m)
+            out[k] = torch.empty((n, m.shape[3]), dtype=torch.float32, device=dev)
+            maps[s] = _lib.ChannelMap(m.data_ptr(), m.shape[1], m.shape[2], m.shape[3], _lib.DTYPE_F32, m.stride(0), m.stride(1), m.stride(2))
+            fused[s] = out[k].data_ptr()
+        flags = (_lib.FLAG_FINITE_MAPS if finite else 0) | int(self.tuning_flags)
+        with torch.cuda.device(dev):
+            _lib.check(lib.d3f_eval_grid(ctypes.byref(views), ctypes.byref(grid), maps, len(names), self.mu, flags,
+                                         _lib.ptr(dist), _lib.ptr(valid), fused, _lib.current_stream_handle(dev)))
+        return out
+
+    def grid_shell(self, boundaries, step_size, dist_threshold=0.005):
+        """Flat indices (ascending) and coordinates of the grid points with valid_mask & |dist| < dist_threshold:
+        the pre-filter of select_features_* (fusion.py:1430,1444) fused into the grid pass, so that no
+        per-point tensor of the ~1e8-point grid is ever written."""
+        if len(self.curr_obs_torch) == 0:
+            raise RuntimeError("Please call update() first!")
+        dev = self.device
+        grid, axes = self._grid(boundaries, step_size)
+        n = grid.nx * grid.ny * grid.nz
+        views, keep, V = self._views(dev)
+        count = torch.zeros(1, dtype=torch.int64, device=dev)
+        capacity = max(1 << 16, n // 16)
+        while True:
+            idx = torch.empty(capacity, dtype=torch.int64, device=dev)
+            with torch.cuda.device(dev):
+                _lib.check(self._lib.d3f_grid_shell(ctypes.byref(views), ctypes.byref(grid), self.mu, float(dist_threshold),
+                                                    capacity, _lib.ptr(idx), _lib.ptr(count), _lib.current_stream_handle(dev)))
+            found = int(count.item())
+            if found <= capacity:
+                break
+            capacity = found                      # rare: the shell is thicker than 1/16 of the grid -> one exact re-run
+        idx = torch.sort(idx[:found]).values      # the reference's boolean-mask order is ascending flat index
+        iz = idx % grid.nz
+        ixy = idx // grid.nz
+        pts = torch.stack((axes[0][ixy // grid.ny], axes[1][ixy % grid.ny], axes[2][iz]), dim=1)
+        return idx, pts
+
+    def select_features_rand(self, boundaries, N, per_instance=False, res=None, init_idx=-1):
+        """Reference Fusion.select_features_rand (fusion.py:1418-1475): N farthest-point-sampled keypoints per
+        instance on the object surfaces, with their descriptors.  Returns (src_feats_list, src_pts_list,
+        img_list); img_list (cv2 debug renderings in the reference) is always empty here."""
+        res = 0.001 if res is None else res
+        dist_threshold = 0.005
+        label = self.curr_obs_torch["consensus_mask_label"]
+        with torch.no_grad():
+            _, shell_pts = self.grid_shell(boundaries, res, dist_threshold)
+            mask = self.eval(shell_pts, return_names=["mask"])["mask"] if shell_pts.shape[0] else shell_pts.new_zeros((0, len(label)))
+            mask = mask / (mask.sum(dim=1, keepdim=True) + 1e-7)
+            src_feats_list, src_pts_list = [], []
+            last_label = label[0]
+            for i in range(1, len(label)):
+                if label[i] == last_label and not per_instance:
+                    continue
+                masked_pts = shell_pts[mask[:, i] > 0.6]
+                sample_pts, _, _ = fps(masked_pts, N, init_idx=init_idx)
+                src_feats_list.append(self.eval(sample_pts)["dino_feats"])
+                src_pts_list.append(sample_pts.cpu().numpy())
+                last_label = label[i]
+        return src_feats_list, src_pts_list, []
 
     # ---- instance masks: upstream producers (reference fusion.py:1112-1256) ----------------
     def _store_mask(self, produced):

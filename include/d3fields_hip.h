@@ -130,6 +130,37 @@ typedef struct d3f_eval_plan {
 int d3f_eval_plan_query(const d3f_views *views, int64_t n, const d3f_channel_map *maps, int32_t n_maps,
                         uint32_t flags, int32_t have_workspace, int32_t want_inter, d3f_eval_plan *plan);
 
+/* ---- regular grids and keypoint selection (reference fusion.py:79-88, 1418-1475) ---------------------
+ * A grid is given by its three axis coordinate arrays, exactly the `arange(lower, upper, step) + step/2`
+ * tensors of create_init_grid (fusion.py:82-84) -- they are tiny, and reading them keeps the points
+ * bit-identical to the reference's on any host.  Point (ix,iy,iz) has flat index (ix*ny + iy)*nz + iz
+ * ('ij' meshgrid, z fastest), which is also the layout of every per-point output. */
+typedef struct d3f_grid {
+    const float *x, *y, *z;   /* device arrays of nx, ny, nz floats */
+    int32_t nx, ny, nz;
+    int32_t reserved;
+} d3f_grid;
+
+/* d3f_eval over all nx*ny*nz grid points without materialising them (replaces
+ * batch_eval(create_init_grid(...)[0].to(device), ...), vis_repr.py:88-93): saves the 12 B/point read that
+ * dominates a distance-only pass.  Outputs as d3f_eval, in flat grid order. */
+int d3f_eval_grid(const d3f_views *views, const d3f_grid *grid, const d3f_channel_map *maps, int32_t n_maps,
+                  float mu, uint32_t flags, float *out_dist, uint8_t *out_valid, float *const *out_fused,
+                  void *stream);
+
+/* Pre-filter of select_features_* (fusion.py:1430,1444): flat indices of the grid points with
+ * valid_mask && |dist| < dist_thr, compacted into idx_out[0..min(count,capacity)) (unordered across waves;
+ * sort them to reproduce the reference's ascending order).  count_out: ONE device int64, the number of
+ * survivors (may exceed capacity: then only `capacity` indices were stored). */
+int d3f_grid_shell(const d3f_views *views, const d3f_grid *grid, float mu, float dist_thr, int64_t capacity,
+                   int64_t *idx_out, int64_t *count_out, void *stream);
+
+/* fps_np (utils/my_utils.py:478-497): k farthest points of pts[n,3] starting from init_idx, float32
+ * Euclidean distances, first maximum wins -> out_idx[k] (int64, device), out_maxdist (device float, may
+ * be NULL).  dist_workspace: n floats of device scratch. */
+int d3f_farthest_point_sampling(const float *pts, int64_t n, int32_t k, int64_t init_idx, int64_t *out_idx,
+                                float *out_maxdist, float *dist_workspace, void *stream);
+
 /* Gradient of d3f_eval's outputs w.r.t. the query points: what autograd through Fusion.eval gives
  * the reference's rigid_tracking (fusion.py:1643-1665).  grad_dist: [n] or NULL; grad_fused: host
  * array of n_maps device pointers ([n,C_k], entries may be NULL); grad_pts [n,3] is overwritten.

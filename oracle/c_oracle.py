@@ -158,3 +158,16 @@ def pairwise(src, tgt, scale=1.0, dist_type="l2", mode="softmax", return_argmax=
                               ctypes.c_int(0 if mode == "softmax" else 1), _fp(out),
                               am.ctypes.data_as(ctypes.POINTER(_i64)) if am is not None else None)
     return (out, am) if return_argmax else out
+
+
+def fps(pts, k, init_idx):
+    """fps_np restated (d3f_oracle_fps): returns (index array [k], max remaining distance)."""
+    pts = _c32(pts)
+    n = pts.shape[0]
+    idx = np.empty(k, np.int64)
+    md = ctypes.c_float(0.0)
+    rc = lib().d3f_oracle_fps(_fp(pts), _i64(n), ctypes.c_int(k), _i64(init_idx),
+                              idx.ctypes.data_as(ctypes.POINTER(_i64)), ctypes.byref(md))
+    if rc != 0:
+        raise ValueError("d3f_oracle_fps rc=%d" % rc)
+    return idx, float(md.value)

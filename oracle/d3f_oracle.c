@@ -345,3 +345,31 @@ int d3f_oracle_pairwise(const float *src, const float *tgt, int64_t B1, int64_t 
         }
     return 0;
 }
+
+/* utils/my_utils.py:478-497 fps_np: farthest point sampling, float32 distances
+ * sqrt((dx*dx + dy*dy) + dz*dz) (numpy's reduction order for 3 terms), first maximum wins.
+ * out_idx [k]; returns dist.max() after the last update through *out_maxdist. */
+int d3f_oracle_fps(const float *pts, int64_t n, int k, int64_t init_idx, int64_t *out_idx, float *out_maxdist)
+{
+    if (n < 1 || k < 1 || init_idx < 0 || init_idx >= n) return -1;
+    float *dist = (float *)malloc(sizeof(float) * (size_t)n);
+    int64_t cur = init_idx;
+    float best = 0.0f;
+    for (int r = 0; r < k; ++r) {
+        out_idx[r] = cur;
+        const float cx = pts[cur * 3], cy = pts[cur * 3 + 1], cz = pts[cur * 3 + 2];
+        int64_t arg = 0;
+        best = -1.0f;
+        for (int64_t i = 0; i < n; ++i) {
+            float dx = pts[i * 3] - cx, dy = pts[i * 3 + 1] - cy, dz = pts[i * 3 + 2] - cz;
+            float d = sqrtf((dx * dx + dy * dy) + dz * dz);
+            if (r > 0 && dist[i] < d) d = dist[i];
+            dist[i] = d;
+            if (d > best) { best = d; arg = i; }
+        }
+        cur = arg;
+    }
+    if (out_maxdist) *out_maxdist = best;
+    free(dist);
+    return 0;
+}

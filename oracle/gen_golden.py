@@ -190,6 +190,38 @@ def grad_case(fusion):
          dist=out["dist"].detach().numpy(), dino_feats=out["dino_feats"].detach().numpy())
 
 
+def select_case(fusion):
+    """select_features_rand (fusion.py:1418-1475) + fps_np (utils/my_utils.py:478-497) on a 1-cm grid."""
+    V, H, W = 4, 96, 128
+    sc = synth.make_scene(V, H, W, "smooth")
+    feats = synth.random_map(V, 12, 16, 16, seed=61)
+    # instance masks with large coherent regions: label = f(pixel column band), 4 instances incl. background 0
+    lab = (torch.arange(W)[None, None, :] // 32 + torch.arange(H)[None, :, None] // 48).expand(V, H, W) % 4
+    mask = torch.nn.functional.one_hot(lab, 4).to(torch.float32)
+    obs = dict(sc)
+    obs.update(dino_feats=feats, mask=mask, consensus_mask_label=["background", "a", "b", "c"],
+               color=np.zeros((V, H, W, 3), np.uint8))
+    f = R.make_reference_fusion(fusion, obs, H, W)
+    box = dict(synth.WORK_BOX)
+    feats_l, pts_l, _ = f.select_features_rand(box, 24, per_instance=True, res=0.01, init_idx=0)
+    grid, shape = fusion.create_init_grid(box, 0.01)
+    with torch.no_grad():
+        out = f.batch_eval(grid, return_names=["mask"])
+    shell = (out["dist"].abs() < 0.005) & out["valid_mask"]
+    g = np.random.default_rng(3).normal(size=(5000, 3)).astype(np.float32)
+    fp, fi, fd = fusion.fps_np(g, 64, init_idx=17)
+    arrays = dict(H=H, W=W, mu=f.mu, K=sc["K"].numpy(), pose=sc["pose"].numpy(), depth=sc["depth"].numpy(),
+                  in_dino_feats=feats.numpy(), in_mask=mask.numpy(), res=0.01, N=24,
+                  bounds=np.array([box["x_lower"], box["x_upper"], box["y_lower"], box["y_upper"], box["z_lower"], box["z_upper"]]),
+                  shell_index=torch.nonzero(shell)[:, 0].numpy(), grid_shape=np.array(shape),
+                  grid_dist=out["dist"].numpy(), grid_valid=np.packbits(out["valid_mask"].numpy()),
+                  n_inst=len(pts_l), fps_cloud=g, fps_idx=np.array(fi), fps_pts=fp, fps_maxdist=np.float32(fd))
+    for i, (a, b) in enumerate(zip(feats_l, pts_l)):
+        arrays["sel_feats_%d" % i] = a.numpy()
+        arrays["sel_pts_%d" % i] = b
+    save("select_features", **arrays)
+
+
 def main():
     torch.set_num_threads(4)
     fusion, corr = R.import_reference()
@@ -203,6 +235,7 @@ def main():
     onehot_case(fusion)
     corr_case(corr)
     grad_case(fusion)
+    select_case(fusion)
 
 
 if __name__ == "__main__":

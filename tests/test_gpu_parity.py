@@ -526,3 +526,68 @@ def test_staged_gather_nonfinite_map(dev):
     got, want = cpu(out["dino_feats"]), ref["sets"][0]
     assert np.isnan(want).any() and np.array_equal(np.isnan(got), np.isnan(want))
     assert rel_err(got[~np.isnan(want)], want[~np.isnan(want)]) <= TOL
+
+
+# ---------------------------------------------------------------------------------------
+# grids, shell pre-filter, farthest point sampling, select_features_rand
+# ---------------------------------------------------------------------------------------
+def _select_fusion(dev):
+    g = load_golden("select_features")
+    f = make_fusion(dev, g["depth"], g["K"], g["pose"], {"dino_feats": g["in_dino_feats"], "mask": g["in_mask"]}, g["H"], g["W"], float(g["mu"]))
+    f.curr_obs_torch["consensus_mask_label"] = ["background", "a", "b", "c"]
+    box = dict(zip(["x_lower", "x_upper", "y_lower", "y_upper", "z_lower", "z_upper"], g["bounds"].tolist()))
+    return g, f, box
+
+
+def test_eval_grid_equals_batch_eval_of_materialised_grid(dev):
+    from d3fields_amd import create_init_grid
+    g, f, box = _select_fusion(dev)
+    res = float(g["res"])
+    with torch.no_grad():
+        a = f.eval_grid(box, res, return_names=["mask", "dino_feats"])
+        grid, shape = create_init_grid(box, res)
+        b = f.batch_eval(grid.to(dev), return_names=["mask", "dino_feats"])
+        d = f.eval_grid(box, res)
+    assert tuple(a["grid_shape"]) == tuple(shape) == tuple(g["grid_shape"])
+    for k in ("dist", "valid_mask", "mask", "dino_feats"):
+        assert torch.equal(a[k], b[k]), k
+    assert sorted(d.keys()) == ["dist", "grid_shape", "valid_mask"] and torch.equal(d["dist"], a["dist"])
+    assert np.array_equal(cpu(a["dist"]), g["grid_dist"])                       # the reference's own batch_eval
+    assert np.array_equal(np.packbits(cpu(a["valid_mask"])), g["grid_valid"])
+
+
+def test_grid_shell_matches_reference_prefilter(dev):
+    from d3fields_amd import create_init_grid
+    g, f, box = _select_fusion(dev)
+    idx, pts = f.grid_shell(box, float(g["res"]), 0.005)
+    assert np.array_equal(cpu(idx), g["shell_index"])
+    grid, _ = create_init_grid(box, float(g["res"]))
+    assert np.array_equal(cpu(pts), grid.numpy()[g["shell_index"]])
+    idx0, pts0 = f.grid_shell(box, float(g["res"]), 0.0)                          # empty shell
+    assert idx0.numel() == 0 and pts0.shape == (0, 3)
+
+
+def test_fps_matches_reference(dev):
+    from d3fields_amd import fps
+    g = load_golden("select_features")
+    p, i, d = fps(g["fps_cloud"], 64, init_idx=17)                               # numpy in / numpy out like fps_np
+    assert isinstance(p, np.ndarray) and i == g["fps_idx"].tolist() and np.array_equal(p, g["fps_pts"])
+    assert d == float(g["fps_maxdist"])
+    pt, it, _ = fps(torch.from_numpy(g["fps_cloud"]).to(dev), 64, init_idx=17)
+    assert np.array_equal(cpu(it), g["fps_idx"]) and np.array_equal(cpu(pt), g["fps_pts"])
+    big = np.random.default_rng(5).normal(size=(200000, 3)).astype(np.float32)
+    from oracle import c_oracle as O
+    _, ib, db = fps(big, 50, init_idx=0)
+    io, do = O.fps(big, 50, 0)
+    assert ib == io.tolist() and db == do
+    ps, isel, _ = fps(big[:10], 64, init_idx=3)                                   # cloud smaller than the request
+    assert len(isel) == 10 and sorted(isel) == list(range(10))
+
+
+def test_select_features_rand_matches_reference(dev):
+    g, f, box = _select_fusion(dev)
+    feats_l, pts_l, imgs = f.select_features_rand(box, int(g["N"]), per_instance=True, res=float(g["res"]), init_idx=0)
+    assert len(pts_l) == int(g["n_inst"]) == len(feats_l) and imgs == []
+    for i in range(len(pts_l)):
+        assert np.array_equal(pts_l[i], g["sel_pts_%d" % i]), i
+        assert rel_err(cpu(feats_l[i]), g["sel_feats_%d" % i]) <= TOL

@@ -121,3 +121,18 @@ def test_torch_port_gradient_matches_reference():
     out = torch_port.field_query(obs, pts, ["dino_feats"], int(g["H"]), int(g["W"]), float(g["mu"]))
     (out["dino_feats"].sum() + out["dist"].sum()).backward()
     assert rel_err(pts.grad.numpy(), g["grad_pts"]) <= TOL
+
+
+def test_fps_and_shell_match_reference():
+    g = load_golden("select_features")
+    idx, md = O.fps(g["fps_cloud"], 64, 17)
+    assert np.array_equal(idx, g["fps_idx"]) and np.array_equal(g["fps_cloud"][idx], g["fps_pts"])
+    assert md == float(g["fps_maxdist"])
+    # the select_features pre-filter is |dist| < 5 mm & valid on the 1-cm grid
+    from d3fields_amd import create_init_grid
+    b = dict(zip(["x_lower", "x_upper", "y_lower", "y_upper", "z_lower", "z_upper"], g["bounds"].tolist()))
+    grid, shape = create_init_grid(b, float(g["res"]))
+    o = O.eval_field(g["depth"], g["K"], g["pose"], grid.numpy(), [g["in_mask"]], mu=float(g["mu"]))
+    assert np.array_equal(o["dist"], g["grid_dist"]) and np.array_equal(np.packbits(o["valid_mask"]), g["grid_valid"])
+    shell = np.nonzero((np.abs(o["dist"]) < 0.005) & o["valid_mask"])[0]
+    assert np.array_equal(shell, g["shell_index"])
