@@ -177,18 +177,22 @@ int eval_common(const d3f_views *views, const float *pts, int64_t n, const d3f_c
         if (eo != hipSuccess) return hip_fail(eo, "point ordering");
     }
     // Launch geometry (measured on MI355X):
-    //  * Morton walk: 32-point tiles, XCD k takes the k-th contiguous eighth of the walk and ~3 workgroups
-    //    run per CU (40 KiB LDS pad), so the ~3 k points in flight on an XCD form one compact blob whose
-    //    texels stay in that XCD's 4 MiB L2 (C2 dense 2.84 -> 2.48 ms, C4 patch 13.0 -> 5.3 ms);
+    //  * Morton walk: 8-point tiles (one point per lane group; 16 when a thin map such as the mask is also
+    //    requested), XCD k takes the k-th contiguous eighth of the walk, so the ~1 k points in flight on an
+    //    XCD form one compact blob whose texels stay in that XCD's 4 MiB L2
+    //    (C2 dense 2.84 -> 2.12 ms, C4 patch 13.0 -> 4.8 ms; 32-point tiles: 2.48 / 5.3 ms);
     //  * caller order: 128-point tiles, round-robin XCDs (0.80 ms on C2 patch); for maps far beyond the
     //    256 MiB Infinity Cache 64-point tiles at 2 workgroups per CU (3.2 -> 2.96 ms on C2 dense).
     bool xcd_remap = false;
     if (reorder) {
-        P.tile_pts = 32; P.lds_pad = 40 * 1024; xcd_remap = true;
+        // one point per lane group: 8 points when every map takes >= 16 lanes per point, else 16
+        bool thin = false;
+        for (int s = 0; s < n_maps; ++s) thin |= P.maps[s].lpp_log2 < 4;
+        P.tile_pts = thin ? 16 : 8; P.lds_pad = 0; xcd_remap = true;
     } else if (map_bytes > (512LL << 20) && P.tile_pts > 64) {
         P.tile_pts = 64; P.lds_pad = 64 * 1024;
     }
-    if (tl >= 5 && tl <= 8) { P.tile_pts = (1 << tl) <= max_tile ? (1 << tl) : max_tile; P.lds_pad = 0; }
+    if (tl >= 3 && tl <= 8) { P.tile_pts = (1 << tl) <= max_tile ? (1 << tl) : max_tile; P.lds_pad = 0; }
     if ((flags >> 16) & 0xFF) P.lds_pad = ((int)((flags >> 16) & 0xFF) == 0xFF) ? 0 : (int)((flags >> 16) & 0xFF) * 1024;
     if (flags & D3F_TUNE_XCD_REMAP) xcd_remap = !xcd_remap;
     P.flags = (flags & ~D3F_TUNE_XCD_REMAP) | (xcd_remap ? D3F_TUNE_XCD_REMAP : 0u);

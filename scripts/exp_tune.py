@@ -22,10 +22,10 @@ for wl in sys.argv[1:]:
         return ts[len(ts) // 2]
 
     print(wl, "auto: %.3f" % t_ms(0), flush=True)
-    for xcd in (0, 1):
-        for pad in (0, 40, 64):
+    for xcd in (0,):            # bit 12 inverts the default (Morton walk: XCD-contiguous)
+        for pad in (24, 32, 40, 48, 56):
             row = []
-            for tl in (5, 6, 7):
+            for tl in (3, 4, 5, 6):
                 fl = (tl << 8) | (xcd << 12) | (pad << 16)
                 row.append("t%d: %.3f" % (1 << tl, t_ms(fl)))
             print("  xcd=%d pad=%2d | %s" % (xcd, pad, " | ".join(row)), flush=True)
