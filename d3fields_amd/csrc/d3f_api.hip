@@ -68,7 +68,7 @@ void pick_mapping(d3f::MapDesc &m, bool can16, bool can8, bool batch)
 
 // Validates one channel map and fills the kernel-side descriptor (out/inter may be NULL for backward).
 int fill_map(const d3f_channel_map &c, int s, int V, float *out, float *inter, const float *extra_aligned,
-             d3f::MapDesc &m, int64_t &map_bytes)
+             d3f::MapDesc &m, int64_t &map_bytes, uint32_t flags = 0)
 {
     if (!c.data) return fail(D3F_ERR_INVALID_ARG, "map %d: data pointer is NULL", s);
     if (c.dtype != D3F_DTYPE_F32) return fail(D3F_ERR_BAD_DTYPE, "map %d: dtype %d unsupported (fp32 only)", s, c.dtype);
@@ -91,7 +91,10 @@ int fill_map(const d3f_channel_map &c, int s, int V, float *out, float *inter, c
     const bool can16 = str16 && aligned(m.data, 16) && aligned(out, 16) && aligned(inter, 16) && aligned(extra_aligned, 16);
     const bool can8 = str8 && aligned(m.data, 8) && aligned(out, 8) && aligned(inter, 8) && aligned(extra_aligned, 8);
     const int64_t this_bytes = (int64_t)V * c.fh * c.fw * c.C * 4;
-    pick_mapping(m, can16, can8, this_bytes <= (128LL << 20));
+    bool batch = this_bytes <= (128LL << 20);
+    if (flags & (1u << 26)) batch = true;
+    if (flags & (1u << 27)) batch = false;
+    pick_mapping(m, can16, can8, batch);
     map_bytes += this_bytes;
     return D3F_OK;
 }
@@ -161,7 +164,7 @@ int eval_common(const d3f_views *views, const float *pts, int64_t n, const d3f_c
     for (int s = 0; s < n_maps; ++s) {
         if (!plan_only && !out_fused[s]) return fail(D3F_ERR_INVALID_ARG, "map %d: output pointer is NULL", s);
         rc = fill_map(maps[s], s, views->V, out_fused ? out_fused[s] : nullptr, out_inter ? out_inter[s] : nullptr, nullptr,
-                      P.maps[s], map_bytes);
+                      P.maps[s], map_bytes, flags);
         if (rc != D3F_OK) return rc;
     }
     // Morton point order (performance only) when scratch is supplied and the maps exceed the L2s
@@ -173,7 +176,7 @@ int eval_common(const d3f_views *views, const float *pts, int64_t n, const d3f_c
         for (int s = 0; s < n_maps; ++s) stage_any |= staging_candidate(P.maps[s], views->H, views->W);
     const bool reorder = may_reorder && ((flags & D3F_TUNE_FORCE_REORDER) || (n >= 65536 && (map_bytes > (64LL << 20) || stage_any)));
     if (reorder && !plan_only) {
-        hipError_t eo = d3f::build_point_order(pts, n, workspace, workspace_bytes, &P.order, hs);
+        hipError_t eo = d3f::build_point_order(pts, n, workspace, workspace_bytes, &P.order, hs, (int)((flags >> 24) & 0x3) % 3);
         if (eo != hipSuccess) return hip_fail(eo, "point ordering");
     }
     // Launch geometry (measured on MI355X):
@@ -185,6 +188,16 @@ int eval_common(const d3f_views *views, const float *pts, int64_t n, const d3f_c
     //    256 MiB Infinity Cache 64-point tiles at 2 workgroups per CU (3.2 -> 2.96 ms on C2 dense).
     bool xcd_remap = false;
     if (reorder) {
+        // on the Morton walk the in-flight footprint is tiny, so batched corner loads win again wherever one pass
+        // of <= 3 vectors per lane covers the channels (C2 dense 2.07 -> 1.99 ms); C = 1024 keeps load-use x 4
+        for (int s = 0; s < n_maps; ++s) {
+            d3f::MapDesc &m = P.maps[s];
+            const bool forced = (flags & ((1u << 26) | (1u << 27))) != 0;
+            if (!forced && m.unroll < 0 && (m.C / m.vw) <= 3 * 64) {
+                const bool a16 = m.vw == 4, a8 = m.vw >= 2;
+                pick_mapping(m, a16, a8, true);
+            }
+        }
         // one point per lane group: 8 points when every map takes >= 16 lanes per point, else 16
         bool thin = false;
         for (int s = 0; s < n_maps; ++s) thin |= P.maps[s].lpp_log2 < 4;

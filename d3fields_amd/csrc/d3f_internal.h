@@ -66,7 +66,7 @@ hipError_t launch_fused_backward(const BackwardParams &P, hipStream_t stream);
 // order_kernels.hip
 int64_t order_workspace_bytes(int64_t n);
 hipError_t build_point_order(const float *pts, int64_t n, void *workspace, int64_t workspace_bytes,
-                             const uint32_t **order_out, hipStream_t stream);
+                             const uint32_t **order_out, hipStream_t stream, int fine = 0);
 
 // grid_kernels.hip
 hipError_t launch_grid_shell(const float *depth, const float *K, const float *pose, int V, int H, int W, const float *gx,

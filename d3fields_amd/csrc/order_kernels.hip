@@ -20,7 +20,7 @@ namespace d3f {
 
 __device__ __forceinline__ uint32_t spread3(uint32_t x)
 {
-    x &= 0x7fu;                       // 7 bits per axis -> 21-bit keys (3 radix passes)
+    x &= 0x3ffu;                      // up to 10 bits per axis
     x = (x | (x << 16)) & 0x030000ffu;
     x = (x | (x << 8)) & 0x0300f00fu;
     x = (x | (x << 4)) & 0x030c30c3u;
@@ -29,7 +29,7 @@ __device__ __forceinline__ uint32_t spread3(uint32_t x)
 }
 
 __global__ __launch_bounds__(kBlock) void morton_keys_kernel(const float *__restrict__ pts, int64_t n,
-                                                            float inv_cell, uint32_t *__restrict__ keys,
+                                                            float inv_cell, uint32_t axis_mask, uint32_t *__restrict__ keys,
                                                             uint32_t *__restrict__ idx)
 {
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
@@ -39,7 +39,7 @@ __global__ __launch_bounds__(kBlock) void morton_keys_kernel(const float *__rest
     const int qx = (int)fminf(fmaxf(floorf(x * inv_cell), -1e9f), 1e9f);
     const int qy = (int)fminf(fmaxf(floorf(y * inv_cell), -1e9f), 1e9f);
     const int qz = (int)fminf(fmaxf(floorf(z * inv_cell), -1e9f), 1e9f);
-    keys[i] = spread3((uint32_t)qx) | (spread3((uint32_t)qy) << 1) | (spread3((uint32_t)qz) << 2);
+    keys[i] = spread3((uint32_t)qx & axis_mask) | (spread3((uint32_t)qy & axis_mask) << 1) | (spread3((uint32_t)qz & axis_mask) << 2);
     idx[i] = (uint32_t)i;
 }
 
@@ -50,7 +50,6 @@ using SortConfig = rocprim::radix_sort_config<rocprim::default_config, rocprim::
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 constexpr float kCell = 0.016f;          // 16-mm cells x 128 per axis = 2.05 m before keys wrap (harmless)
-constexpr unsigned kKeyBits = 21;
 constexpr size_t kSortScratch = 8u << 20;   // rocPRIM histogram/scan scratch (it needs far less)
 
 int64_t order_workspace_bytes(int64_t n)
@@ -61,8 +60,11 @@ int64_t order_workspace_bytes(int64_t n)
 
 // Fills *order_out with a pointer (inside the workspace) to n uint32 indices in Morton order.
 hipError_t build_point_order(const float *pts, int64_t n, void *workspace, int64_t workspace_bytes,
-                             const uint32_t **order_out, hipStream_t stream)
+                             const uint32_t **order_out, hipStream_t stream, int fine)
 {
+    // fine = 0..2: cell = 16 mm >> fine, 7 + fine bits per axis (always ~2 m before the keys wrap)
+    const float cell = kCell / (float)(1 << fine);
+    const unsigned bits_axis = 7u + (unsigned)fine, key_bits = 3u * bits_axis;
     *order_out = nullptr;
     if (n <= 0 || n > 0x7fffffffLL || workspace_bytes < order_workspace_bytes(n)) return hipErrorInvalidValue;
     const size_t seg = align_up((size_t)n * 4, 256);
@@ -71,15 +73,15 @@ hipError_t build_point_order(const float *pts, int64_t n, void *workspace, int64
     uint32_t *v0 = reinterpret_cast<uint32_t *>(base + 2 * seg), *v1 = reinterpret_cast<uint32_t *>(base + 3 * seg);
     void *scratch = base + 4 * seg;
     hipLaunchKernelGGL(morton_keys_kernel, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream, pts, n,
-                       1.0f / kCell, k0, v0);
+                       1.0f / cell, (1u << bits_axis) - 1u, k0, v0);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     rocprim::double_buffer<uint32_t> keys(k0, k1), vals(v0, v1);
     size_t need = 0;
-    e = rocprim::radix_sort_pairs<SortConfig>(nullptr, need, keys, vals, (size_t)n, 0u, kKeyBits, stream);
+    e = rocprim::radix_sort_pairs<SortConfig>(nullptr, need, keys, vals, (size_t)n, 0u, key_bits, stream);
     if (e != hipSuccess) return e;
     if (need > kSortScratch) return hipErrorOutOfMemory;
-    e = rocprim::radix_sort_pairs<SortConfig>(scratch, need, keys, vals, (size_t)n, 0u, kKeyBits, stream);
+    e = rocprim::radix_sort_pairs<SortConfig>(scratch, need, keys, vals, (size_t)n, 0u, key_bits, stream);
     if (e != hipSuccess) return e;
     *order_out = vals.current();
     return hipSuccess;

@@ -22,12 +22,10 @@ for wl in sys.argv[1:]:
         return ts[len(ts) // 2]
 
     print(wl, "auto: %.3f" % t_ms(0), flush=True)
-    for xcd in (0,):            # bit 12 inverts the default (Morton walk: XCD-contiguous)
-        for pad in (24, 32, 40, 48, 56):
-            row = []
-            for tl in (3, 4, 5, 6):
-                fl = (tl << 8) | (xcd << 12) | (pad << 16)
-                row.append("t%d: %.3f" % (1 << tl, t_ms(fl)))
-            print("  xcd=%d pad=%2d | %s" % (xcd, pad, " | ".join(row)), flush=True)
+    for name, bit in (("batch", 1 << 26), ("load-use", 1 << 27)):
+        row = []
+        for tl, pad in ((0, 0), (3, 0), (4, 0), (3, 40), (4, 40), (5, 40)):
+            row.append("t%s p%d: %.3f" % ((1 << tl) if tl else "auto", pad, t_ms((tl << 8) | (pad << 16) | bit)))
+        print("  %-8s | %s" % (name, " | ".join(row)), flush=True)
     del f, pts
     torch.cuda.empty_cache()

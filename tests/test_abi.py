@@ -111,7 +111,7 @@ def test_launch_plan_host_logic():
     assert (p.vector_floats[0], p.lanes_per_point[0], p.vectors_per_lane[0], p.staged[0]) == (4, 32, 3, 0)
     # C2 dense: 1.9 GB of maps -> Morton walk, 32-point tiles, load-use per vector; without scratch: 64-point tiles
     p = _plan(4, 480, 640, 985600, [(480, 640, 384)])
-    assert (p.tile_points, p.reorder, p.vectors_per_lane[0]) == (8, 1, -3)
+    assert (p.tile_points, p.reorder, p.vectors_per_lane[0]) == (8, 1, 3)
     p = _plan(4, 480, 640, 985600, [(480, 640, 384)], ws=0)
     assert (p.tile_points, p.reorder) == (64, 0)
     # C4: 8 views x 1024 channels -> whole wave per point, 4 float4 per lane
