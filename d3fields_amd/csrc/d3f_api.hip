@@ -82,6 +82,7 @@ int fill_map(const d3f_channel_map &c, int s, int V, float *out, float *inter, c
     m.out = out;
     m.inter = inter;
     m.staged = 0;
+    m.pre_slot = -1;
     m.sv = c.stride_v; m.sy = c.stride_y; m.sx = c.stride_x;
     m.fh = c.fh; m.fw = c.fw; m.C = c.C;
     if (!aligned(m.data, 4) || !aligned(out, 4) || !aligned(extra_aligned, 4))
@@ -217,12 +218,18 @@ int eval_common(const d3f_views *views, const float *pts, int64_t n, const d3f_c
         P.stage_floats = d3f::kStageFloats;
     }
     P.stage_offset = d3f::fused_lds_base(P.tile_pts, views->V);
+    // wide maps (>= 16 lanes per point): corner set-up once per (point, view) in phase A, 32 B of LDS each
+    P.n_pre = 0;
+    if (!(flags & (1u << 28)))
+        for (int s = 0; s < n_maps && P.n_pre < 2; ++s)
+            if (!P.maps[s].staged && P.maps[s].lpp_log2 >= 4 && !(out_inter && out_inter[s])) P.maps[s].pre_slot = P.n_pre++;
+    P.crec_offset = P.stage_offset + P.stage_floats * 8;
     const int64_t ntiles = (n + P.tile_pts - 1) / P.tile_pts;
     if (ntiles > 0x7fffffffLL) return fail(D3F_ERR_BAD_SHAPE, "n=%lld needs more than 2^31 workgroups", (long long)n);
     if (plan_only) {
         plan_out->tile_points = P.tile_pts;
         plan_out->reorder = reorder ? 1 : 0;
-        plan_out->lds_bytes = d3f::fused_lds_base(P.tile_pts, P.V) + P.stage_floats * 8 + P.lds_pad;
+        plan_out->lds_bytes = P.crec_offset + P.n_pre * P.tile_pts * P.V * 32 + P.lds_pad;
         plan_out->workgroups = ntiles;
         for (int s = 0; s < D3F_MAX_MAPS; ++s) {
             const bool on = s < n_maps;

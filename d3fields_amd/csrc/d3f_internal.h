@@ -21,6 +21,7 @@ struct MapDesc {
     int32_t vw;        // channel-vector width in floats: 4, 2 or 1
     int32_t lpp_log2;  // log2(lanes per point) in phase B
     int32_t unroll;    // channel vectors per lane per pass: +1..+3 batched loads, -1..-4 load-use per vector
+    int32_t pre_slot;  // >= 0: bilinear corner set-up of this map is precomputed per (point, view) in LDS slot pre_slot
     int32_t staged;    // 1: gather through the LDS texel window (low-resolution wide maps, Morton-ordered tiles)
 };
 
@@ -38,6 +39,8 @@ struct EvalParams {
     int32_t lds_pad;   // extra dynamic LDS bytes (occupancy throttle, tuning only)
     int32_t stage_offset;  // byte offset of the two LDS stage buffers (staged maps), 16-B aligned
     int32_t stage_floats;  // floats per stage buffer, 0 = no staged map
+    int32_t crec_offset;   // byte offset of the precomputed corner records, 16-B aligned
+    int32_t n_pre;         // number of maps with precomputed corner records
     uint32_t flags;
     float mu;
     MapDesc maps[D3F_MAX_MAPS];

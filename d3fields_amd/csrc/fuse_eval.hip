@@ -34,6 +34,43 @@ struct ViewRec {
     float valid;    // 1.0f / 0.0f                     (fusion.py:344)
 };
 
+// Bilinear corner set-up of one (point, view) for one map (grid_sample, align_corners=True, zeros padding).
+struct Corner {
+    uint32_t onw, one, osw, ose;    // 32-bit BYTE offsets of the clamped corner texels from the view's base
+    float wnw, wne, wsw, wse;       // bilinear weights
+    bool inw, ine, isw, ise;        // corner inside the map?
+};
+
+// Coordinates are clamped into the map so that every address is valid; out-of-bounds corners become the
+// zeros of padding_mode='zeros' by zeroing the weight (finite operands) or by a select on the value.
+__device__ __forceinline__ Corner corner_setup(const MapDesc &m, float gx, float gy)
+{
+    Corner c;
+    const float fwm1 = (float)(m.fw - 1), fhm1 = (float)(m.fh - 1);
+    const uint32_t sy_b = (uint32_t)m.sy * 4u, sx_b = (uint32_t)m.sx * 4u;   // host guarantees a view spans < 4 GiB
+    const float ix = unnormalize(gx, m.fw), iy = unnormalize(gy, m.fh);
+    const float x0 = floorf(ix), y0 = floorf(iy);
+    const float tx = ix - x0, ty = iy - y0;
+    const float ex = 1.0f - tx, sy = 1.0f - ty;
+    c.wnw = sy * ex; c.wne = sy * tx; c.wsw = ty * ex; c.wse = ty * tx;
+    const float x1 = x0 + 1.0f, y1 = y0 + 1.0f;
+    c.inw = in_bounds(x0, y0, m.fw, m.fh); c.ine = in_bounds(x1, y0, m.fw, m.fh);
+    c.isw = in_bounds(x0, y1, m.fw, m.fh); c.ise = in_bounds(x1, y1, m.fw, m.fh);
+    const int xi0 = (int)fminf(fmaxf(x0, 0.0f), fwm1), xi1 = (int)fminf(fmaxf(x1, 0.0f), fwm1);
+    const int yi0 = (int)fminf(fmaxf(y0, 0.0f), fhm1), yi1 = (int)fminf(fmaxf(y1, 0.0f), fhm1);
+    const uint32_t r0 = (uint32_t)yi0 * sy_b, r1 = (uint32_t)yi1 * sy_b;
+    const uint32_t q0 = (uint32_t)xi0 * sx_b, q1 = (uint32_t)xi1 * sx_b;
+    c.onw = r0 + q0; c.one = r0 + q1; c.osw = r1 + q0; c.ose = r1 + q1;
+    return c;
+}
+
+// The same set-up computed ONCE per (point, view) in phase A (one lane per pair) for wide maps, so that the
+// 2^k lanes of a point's group read 32 bytes from LDS instead of repeating ~45 VALU instructions each.
+struct __attribute__((aligned(16))) CornerRec {
+    uint32_t o[4];      // onw, one, osw, ose
+    float w[4];         // weights with out-of-bounds corners already zeroed (non-strict path only)
+};
+
 // Gathers map `m` for the points of this workgroup's tile.
 //   VW  channel-vector width in floats (4 when C%4==0 and 16-B aligned, else 2 or 1)
 //   U   channel vectors per lane per pass
@@ -43,7 +80,7 @@ struct ViewRec {
 template <int VW, int U, bool BATCH>
 __device__ __forceinline__ void gather_map(const MapDesc &m, const EvalParams &P, const ViewRec *rec,
                                            const float *cnt_s, const uint32_t *flag_s,
-                                           const uint32_t *idx_s, int64_t idx_base, int tile_n)
+                                           const uint32_t *idx_s, int64_t idx_base, int tile_n, const CornerRec *crec)
 {
     using VT = typename Vec<VW>::T;
     const int lpp = 1 << m.lpp_log2;
@@ -53,8 +90,6 @@ __device__ __forceinline__ void gather_map(const MapDesc &m, const EvalParams &P
     const int cvec = m.C / VW;
     const int V = P.V;
     const float *__restrict__ data = m.data;
-    const float fwm1 = (float)(m.fw - 1), fhm1 = (float)(m.fh - 1);
-    const uint32_t sy_b = (uint32_t)m.sy * 4u, sx_b = (uint32_t)m.sx * 4u;   // host guarantees a view spans < 4 GiB
 
     for (int p = grp; p < tile_n; p += ngrp) {
         const int64_t i = idx_base + idx_s[p];
@@ -69,23 +104,19 @@ __device__ __forceinline__ void gather_map(const MapDesc &m, const EvalParams &P
             for (int v = 0; v < V; ++v) {
                 const ViewRec r = rec[p * V + v];
                 if (!strict && r.valid == 0.0f) continue;  // exact: +0 + (+-0) == +0, x + (+-0) == x
-                const float ix = unnormalize(r.gx, m.fw), iy = unnormalize(r.gy, m.fh);
-                const float x0 = floorf(ix), y0 = floorf(iy);
-                const float tx = ix - x0, ty = iy - y0;
-                const float ex = 1.0f - tx, sy = 1.0f - ty;
-                const float wnw = sy * ex, wne = sy * tx, wsw = ty * ex, wse = ty * tx;
-                const float x1 = x0 + 1.0f, y1 = y0 + 1.0f;
-                const bool inw = in_bounds(x0, y0, m.fw, m.fh), ine = in_bounds(x1, y0, m.fw, m.fh);
-                const bool isw = in_bounds(x0, y1, m.fw, m.fh), ise = in_bounds(x1, y1, m.fw, m.fh);
-                // Branch-free corner fetch: coordinates are clamped into the map so that every address is
-                // valid, all 4*U loads are issued unconditionally, and out-of-bounds corners become the zeros
-                // of padding_mode='zeros' by a select.  Offsets are 32-bit BYTE offsets from the view's
-                // (wave-uniform) base: one global_load with an SGPR base per corner vector, no 64-bit math.
-                const int xi0 = (int)fminf(fmaxf(x0, 0.0f), fwm1), xi1 = (int)fminf(fmaxf(x1, 0.0f), fwm1);
-                const int yi0 = (int)fminf(fmaxf(y0, 0.0f), fhm1), yi1 = (int)fminf(fmaxf(y1, 0.0f), fhm1);
+                // Branch-free corner fetch: all 4*U loads are unconditional `global_load v, v_off32, s[base]`
+                // (wave-uniform per-view base + 32-bit byte offset of a clamped, always valid texel).
+                Corner c;
+                float w0, w1, w2, w3;
+                if (!strict && crec) {
+                    const CornerRec cr = crec[p * V + v];
+                    c.onw = cr.o[0]; c.one = cr.o[1]; c.osw = cr.o[2]; c.ose = cr.o[3];
+                    w0 = cr.w[0]; w1 = cr.w[1]; w2 = cr.w[2]; w3 = cr.w[3];
+                } else {
+                    c = corner_setup(m, r.gx, r.gy);
+                    w0 = c.inw ? c.wnw : 0.0f; w1 = c.ine ? c.wne : 0.0f; w2 = c.isw ? c.wsw : 0.0f; w3 = c.ise ? c.wse : 0.0f;
+                }
                 const char *bv = reinterpret_cast<const char *>(data) + (int64_t)v * m.sv * 4;
-                const uint32_t r0 = (uint32_t)yi0 * sy_b, r1 = (uint32_t)yi1 * sy_b;
-                const uint32_t q0 = (uint32_t)xi0 * sx_b, q1 = (uint32_t)xi1 * sx_b;
                 VT a[U], b[U], d[U], e[U];
                 if (BATCH) {
                     // cache-resident maps: all 4*U loads in flight before the first use (latency-bound regime)
@@ -93,24 +124,23 @@ __device__ __forceinline__ void gather_map(const MapDesc &m, const EvalParams &P
                     for (int u = 0; u < U; ++u) {
                         const int cv = min(c0 + u * lpp + g, cvec - 1);     // idle lanes re-read the last vector
                         const uint32_t co = (uint32_t)cv * (VW * 4);
-                        a[u] = *reinterpret_cast<const VT *>(bv + (r0 + q0 + co));
-                        b[u] = *reinterpret_cast<const VT *>(bv + (r0 + q1 + co));
-                        d[u] = *reinterpret_cast<const VT *>(bv + (r1 + q0 + co));
-                        e[u] = *reinterpret_cast<const VT *>(bv + (r1 + q1 + co));
+                        a[u] = *reinterpret_cast<const VT *>(bv + (c.onw + co));
+                        b[u] = *reinterpret_cast<const VT *>(bv + (c.one + co));
+                        d[u] = *reinterpret_cast<const VT *>(bv + (c.osw + co));
+                        e[u] = *reinterpret_cast<const VT *>(bv + (c.ose + co));
                     }
                 }
                 if (!strict) {
                     // Finite maps, finite coordinates, valid view: a zero WEIGHT is the zeros padding
                     // (x*0 == +-0 for finite x, and +-0 never changes the sums below), valid_v == 1.
-                    const float w0 = inw ? wnw : 0.0f, w1 = ine ? wne : 0.0f, w2 = isw ? wsw : 0.0f, w3 = ise ? wse : 0.0f;
 #pragma unroll
                     for (int u = 0; u < U; ++u) {
                         if (!BATCH) {      // maps larger than the caches: a smaller in-flight footprint measured faster
                             const uint32_t co = (uint32_t)min(c0 + u * lpp + g, cvec - 1) * (VW * 4);
-                            a[u] = *reinterpret_cast<const VT *>(bv + (r0 + q0 + co));
-                            b[u] = *reinterpret_cast<const VT *>(bv + (r0 + q1 + co));
-                            d[u] = *reinterpret_cast<const VT *>(bv + (r1 + q0 + co));
-                            e[u] = *reinterpret_cast<const VT *>(bv + (r1 + q1 + co));
+                            a[u] = *reinterpret_cast<const VT *>(bv + (c.onw + co));
+                            b[u] = *reinterpret_cast<const VT *>(bv + (c.one + co));
+                            d[u] = *reinterpret_cast<const VT *>(bv + (c.osw + co));
+                            e[u] = *reinterpret_cast<const VT *>(bv + (c.ose + co));
                         }
                         VT s = a[u] * w0;                  // ATen bilinear: fma chain nw,ne,sw,se
                         s = v_fma<VT>(b[u], w1, s);
@@ -124,17 +154,17 @@ __device__ __forceinline__ void gather_map(const MapDesc &m, const EvalParams &P
                     for (int u = 0; u < U; ++u) {
                         if (!BATCH) {
                             const uint32_t co = (uint32_t)min(c0 + u * lpp + g, cvec - 1) * (VW * 4);
-                            a[u] = *reinterpret_cast<const VT *>(bv + (r0 + q0 + co));
-                            b[u] = *reinterpret_cast<const VT *>(bv + (r0 + q1 + co));
-                            d[u] = *reinterpret_cast<const VT *>(bv + (r1 + q0 + co));
-                            e[u] = *reinterpret_cast<const VT *>(bv + (r1 + q1 + co));
+                            a[u] = *reinterpret_cast<const VT *>(bv + (c.onw + co));
+                            b[u] = *reinterpret_cast<const VT *>(bv + (c.one + co));
+                            d[u] = *reinterpret_cast<const VT *>(bv + (c.osw + co));
+                            e[u] = *reinterpret_cast<const VT *>(bv + (c.ose + co));
                         }
-                        const VT av = inw ? a[u] : (VT)0.0f, bvv = ine ? b[u] : (VT)0.0f;
-                        const VT dv = isw ? d[u] : (VT)0.0f, ev = ise ? e[u] : (VT)0.0f;
-                        VT s = av * wnw;
-                        s = v_fma<VT>(bvv, wne, s);
-                        s = v_fma<VT>(dv, wsw, s);
-                        s = v_fma<VT>(ev, wse, s);
+                        const VT av = c.inw ? a[u] : (VT)0.0f, bvv = c.ine ? b[u] : (VT)0.0f;
+                        const VT dv = c.isw ? d[u] : (VT)0.0f, ev = c.ise ? e[u] : (VT)0.0f;
+                        VT s = av * c.wnw;
+                        s = v_fma<VT>(bvv, c.wne, s);
+                        s = v_fma<VT>(dv, c.wsw, s);
+                        s = v_fma<VT>(ev, c.wse, s);
                         const int cv = c0 + u * lpp + g;
                         if (m.inter && cv < cvec)          // '<k>_inter' [V,n,C]  fusion.py:389
                             store_vec<VT>(m.inter + ((int64_t)v * P.n + i) * m.C + cv * VW, s);
@@ -332,19 +362,21 @@ __device__ __forceinline__ void gather_map_staged(const MapDesc &m, const EvalPa
     }
 }
 
-template <int VW>
+template <int VW, bool WIDE>
 __device__ __forceinline__ void gather_map_u(const MapDesc &m, const EvalParams &P, const ViewRec *rec,
                                              const float *cnt_s, const uint32_t *flag_s,
-                                             const uint32_t *idx_s, int64_t idx_base, int tile_n)
+                                             const uint32_t *idx_s, int64_t idx_base, int tile_n, const CornerRec *crec)
 {
     switch (m.unroll) {
-    case 1: gather_map<VW, 1, true>(m, P, rec, cnt_s, flag_s, idx_s, idx_base, tile_n); break;
-    case 2: gather_map<VW, 2, true>(m, P, rec, cnt_s, flag_s, idx_s, idx_base, tile_n); break;
-    case 3: gather_map<VW, 3, true>(m, P, rec, cnt_s, flag_s, idx_s, idx_base, tile_n); break;
-    case -1: gather_map<VW, 1, false>(m, P, rec, cnt_s, flag_s, idx_s, idx_base, tile_n); break;
-    case -2: gather_map<VW, 2, false>(m, P, rec, cnt_s, flag_s, idx_s, idx_base, tile_n); break;
-    case -3: gather_map<VW, 3, false>(m, P, rec, cnt_s, flag_s, idx_s, idx_base, tile_n); break;
-    default: gather_map<VW, 4, false>(m, P, rec, cnt_s, flag_s, idx_s, idx_base, tile_n); break;
+    case 1: gather_map<VW, 1, true>(m, P, rec, cnt_s, flag_s, idx_s, idx_base, tile_n, crec); break;
+    case 2: gather_map<VW, 2, true>(m, P, rec, cnt_s, flag_s, idx_s, idx_base, tile_n, crec); break;
+    case 3: gather_map<VW, 3, true>(m, P, rec, cnt_s, flag_s, idx_s, idx_base, tile_n, crec); break;
+    case -1: gather_map<VW, 1, false>(m, P, rec, cnt_s, flag_s, idx_s, idx_base, tile_n, crec); break;
+    case -2: gather_map<VW, 2, false>(m, P, rec, cnt_s, flag_s, idx_s, idx_base, tile_n, crec); break;
+    case -3: gather_map<VW, 3, false>(m, P, rec, cnt_s, flag_s, idx_s, idx_base, tile_n, crec); break;
+    default:
+        if (WIDE) gather_map<VW, 4, false>(m, P, rec, cnt_s, flag_s, idx_s, idx_base, tile_n, crec);
+        break;
     }
 }
 
@@ -374,8 +406,8 @@ __device__ __forceinline__ void fetch_point(const EvalParams &P, int64_t i, floa
 }
 
 // STAGED: compiled with the LDS-window gather (more registers); the plain kernel keeps 4 waves/SIMD.
-template <int MODE, bool STAGED>
-__global__ __launch_bounds__(kBlock) void fused_eval_kernel(const EvalParams P)
+template <int MODE, bool STAGED, bool WIDE>
+__device__ __forceinline__ void fused_eval_body(const EvalParams &P)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     const int V = P.V;
@@ -389,6 +421,7 @@ __global__ __launch_bounds__(kBlock) void fused_eval_kernel(const EvalParams P)
     float *krt = reinterpret_cast<float *>(idx_s + TP);                      // [V*12]
     int *bbox_s = reinterpret_cast<int *>(krt + V * 12);                      // [V*4]   (staged maps only)
     float *stage_s = reinterpret_cast<float *>(smem + P.stage_offset);       // 2 x stage_floats, 16-B aligned
+    CornerRec *crec_s = reinterpret_cast<CornerRec *>(smem + P.crec_offset); // [n_pre][TP*V] (wide maps)
 
     compute_krt(P.K, P.pose, V, krt, kBlock);
     __syncthreads();
@@ -435,6 +468,17 @@ __global__ __launch_bounds__(kBlock) void fused_eval_kernel(const EvalParams P)
         r.gx = o.gx; r.gy = o.gy; r.wgt = wgt; r.valid = o.valid;
         rec[p * V + v] = r;
         dcl_s[p * V + v] = o.dist * o.valid;                                // fusion.py:364 (product only)
+        for (int s = 0; s < P.n_maps; ++s) {
+            const MapDesc &m = P.maps[s];
+            if (m.pre_slot >= 0 && o.valid != 0.0f) {
+                const Corner c = corner_setup(m, o.gx, o.gy);
+                CornerRec cr;
+                cr.o[0] = c.onw; cr.o[1] = c.one; cr.o[2] = c.osw; cr.o[3] = c.ose;
+                cr.w[0] = c.inw ? c.wnw : 0.0f; cr.w[1] = c.ine ? c.wne : 0.0f;
+                cr.w[2] = c.isw ? c.wsw : 0.0f; cr.w[3] = c.ise ? c.wse : 0.0f;
+                crec_s[(size_t)m.pre_slot * TP * V + p * V + v] = cr;
+            }
+        }
         nfp_s[p * V + v] = !(isfinite(o.gx) && isfinite(o.gy) && isfinite(wgt)) ? 1u : 0u;
     }
     __syncthreads();
@@ -470,26 +514,44 @@ __global__ __launch_bounds__(kBlock) void fused_eval_kernel(const EvalParams P)
             }
             continue;
         }
+        const CornerRec *crec = m.pre_slot >= 0 ? crec_s + (size_t)m.pre_slot * TP * V : nullptr;
         switch (m.vw) {
-        case 4: gather_map_u<4>(m, P, rec, cnt_s, flag_s, idx_s, idx_base, tile_n); break;
-        case 2: gather_map_u<2>(m, P, rec, cnt_s, flag_s, idx_s, idx_base, tile_n); break;
-        default: gather_map_u<1>(m, P, rec, cnt_s, flag_s, idx_s, idx_base, tile_n); break;
+        case 4: gather_map_u<4, WIDE>(m, P, rec, cnt_s, flag_s, idx_s, idx_base, tile_n, crec); break;
+        case 2: gather_map_u<2, WIDE>(m, P, rec, cnt_s, flag_s, idx_s, idx_base, tile_n, crec); break;
+        default: gather_map_u<1, WIDE>(m, P, rec, cnt_s, flag_s, idx_s, idx_base, tile_n, crec); break;
         }
     }
 }
+
+// Three entry points over one body: the plain kernel (<= 3 channel vectors per lane) is held to 128 VGPRs
+// = 4 waves per SIMD -- the gather lives on memory-level parallelism; the WIDE variant adds the 4-vector
+// load-use path (C = 1024: a whole wave per point) with its natural register count; the LDS-staging variant
+// needs ~200 registers and is LDS-limited anyway.
+template <int MODE>
+__global__ __launch_bounds__(kBlock, 4) void fused_eval_kernel(const EvalParams P) { fused_eval_body<MODE, false, false>(P); }
+
+template <int MODE>
+__global__ __launch_bounds__(kBlock) void fused_eval_wide_kernel(const EvalParams P) { fused_eval_body<MODE, false, true>(P); }
+
+template <int MODE>
+__global__ __launch_bounds__(kBlock) void fused_eval_staged_kernel(const EvalParams P) { fused_eval_body<MODE, true, true>(P); }
 
 hipError_t launch_fused_eval(const EvalParams &P, int mode, hipStream_t stream)
 {
     if (P.n == 0) return hipSuccess;
     const int64_t ntiles = (P.n + P.tile_pts - 1) / P.tile_pts;
-    const size_t lds = (size_t)fused_lds_base(P.tile_pts, P.V) + (size_t)P.stage_floats * 8 + (size_t)P.lds_pad;
+    const size_t lds = (size_t)P.crec_offset + (size_t)P.n_pre * P.tile_pts * P.V * 32 + (size_t)P.lds_pad;
     dim3 grid((unsigned)ntiles), block(kBlock);
+    bool wide = false;
+    for (int s = 0; s < P.n_maps; ++s) wide |= (P.maps[s].unroll == -4);
     if (mode == 0 && P.stage_floats > 0)
-        hipLaunchKernelGGL((fused_eval_kernel<0, true>), grid, block, lds, stream, P);
+        hipLaunchKernelGGL((fused_eval_staged_kernel<0>), grid, block, lds, stream, P);
+    else if (mode == 0 && wide)
+        hipLaunchKernelGGL((fused_eval_wide_kernel<0>), grid, block, lds, stream, P);
     else if (mode == 0)
-        hipLaunchKernelGGL((fused_eval_kernel<0, false>), grid, block, lds, stream, P);
+        hipLaunchKernelGGL((fused_eval_kernel<0>), grid, block, lds, stream, P);
     else
-        hipLaunchKernelGGL((fused_eval_kernel<1, false>), grid, block, lds, stream, P);
+        hipLaunchKernelGGL((fused_eval_kernel<1>), grid, block, lds, stream, P);
     return hipGetLastError();
 }
 
