@@ -172,11 +172,32 @@ __device__ __forceinline__ void gather_map(const MapDesc &m, const EvalParams &P
                     }
                 }
             }
+            // acc / (cnt + 1e-6)  (fusion.py:385).  All channels of a point share the divisor, so the IEEE
+            // division is unrolled by hand with the reciprocal refined ONCE: the same rcp + fma sequence the
+            // compiler expands `/` into (v_rcp, 2 fma on the reciprocal, then mul + 4 fma per quotient), minus
+            // its operand pre-scaling and special-case fix-up, which cannot trigger here: the divisor lies in
+            // [1, V+1) and on this path every numerator is finite.  Bit-identical quotients, 5 instead of 11
+            // instructions per channel.  Strict points (non-finite operands possible) keep the full division.
+            float rcp_d = 0.0f;
+            if (!strict) {
+                const float r0 = __builtin_amdgcn_rcpf(denom);
+                rcp_d = fmaf(fmaf(-denom, r0, 1.0f), r0, r0);
+            }
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const int cv = c0 + u * lpp + g;
                 if (cv < cvec) {
-                    VT o = all_invalid ? (VT)0.0f : acc[u] / denom;            // fusion.py:385-386
+                    VT o;
+                    if (all_invalid) {
+                        o = (VT)0.0f;                                          // fusion.py:386
+                    } else if (strict) {
+                        o = acc[u] / denom;
+                    } else {
+                        VT q = acc[u] * rcp_d;
+                        q = v_fma<VT>(v_fma<VT>(q, -denom, acc[u]), rcp_d, q);
+                        q = v_fma<VT>(v_fma<VT>(q, -denom, acc[u]), rcp_d, q);
+                        o = q;
+                    }
                     store_vec<VT>(m.out + i * m.C + (int64_t)cv * VW, o);
                 }
             }

@@ -591,3 +591,35 @@ def test_select_features_rand_matches_reference(dev):
     for i in range(len(pts_l)):
         assert np.array_equal(pts_l[i], g["sel_pts_%d" % i]), i
         assert rel_err(cpu(feats_l[i]), g["sel_feats_%d" % i]) <= TOL
+
+
+def test_fast_path_is_bit_identical_to_strict_path(dev):
+    """Finite-map fast path (invalid-view skip, weight-zero padding, precomputed corner set-up, hand-unrolled
+    shared-reciprocal division) against the strict path (every view sampled, value selects, IEEE '/'):
+    identical bits, on a full-size feature width."""
+    import ctypes
+    from d3fields_amd import synth, _lib
+    V, H, W = 4, 120, 160
+    sc = synth.make_scene(V, H, W, "stress")
+    feats = synth.random_map(V, 12, 16, 384, seed=1) * 3.0
+    mask = synth.random_onehot_mask(V, H, W, 8, seed=2)
+    f = make_fusion(dev, sc["depth"], sc["K"], sc["pose"], {"dino_feats": feats, "mask": mask}, H, W)
+    pts = (synth.random_cloud(30000, seed=8) * 1.3).to(dev)
+    with torch.no_grad():
+        fast = f.eval(pts)                                  # shim verified the maps finite -> D3F_FLAG_FINITE_MAPS
+    lib = _lib.load()
+    views, keep, _ = f._views(dev)
+    names = ["dino_feats", "mask"]
+    maps = (_lib.ChannelMap * 2)()
+    fused = (ctypes.c_void_p * 2)()
+    strict = {"dist": torch.empty_like(fast["dist"]), "valid_mask": torch.empty_like(fast["valid_mask"])}
+    for s, k in enumerate(names):
+        m = f.curr_obs_torch[k]
+        maps[s] = _lib.ChannelMap(m.data_ptr(), m.shape[1], m.shape[2], m.shape[3], 0, m.stride(0), m.stride(1), m.stride(2))
+        strict[k] = torch.empty_like(fast[k])
+        fused[s] = strict[k].data_ptr()
+    _lib.check(lib.d3f_eval(ctypes.byref(views), _lib.ptr(pts), pts.shape[0], maps, 2, f.mu, 0, _lib.ptr(strict["dist"]),
+                            _lib.ptr(strict["valid_mask"]), fused, None, None, 0, _lib.current_stream_handle(dev)))
+    torch.cuda.synchronize()
+    for k in fast:
+        assert torch.equal(fast[k], strict[k]), k
