@@ -6,6 +6,7 @@
 // |a|^2+|b|^2-2ab, whose cancellation breaks 1e-5 relative parity for near-identical
 // descriptors -- so this is fp32 VALU work staged through LDS, not an MFMA contraction.
 #include "d3f_internal.h"
+#include "d3f_device.h"
 
 namespace d3f {
 
@@ -49,59 +50,93 @@ hipError_t launch_dist_to_target(const float *src, int64_t B, int64_t inner, int
 }
 
 // ---- pairwise distances src[B1,C] x tgt[B2,C] -> out[B1,B2] (corr_utils.py:78-83) -------
-// 64x64 output tile per workgroup, 4x4 outputs per lane, channels staged 32 at a time through
-// LDS (row stride 33 floats: the 16 distinct tgt rows a wave reads fall on >= 8 banks).
+// 64x64 output tile per workgroup, 4x4 outputs per lane, 32 channels per LDS stage.
+//  * LDS holds the stage as float4 columns [k/4][row]: lane (tx,ty) owns rows ty+16q and columns tx+16w, so
+//    the 16 lanes of a ds_read_b128 group read 16 consecutive float4 (conflict-free) or one address
+//    (broadcast); 8 b128 reads feed 64 (difference, square-accumulate) pairs.
+//  * the arithmetic is packed: d = a - b as two v_pk_add_f32, acc2 += d*d as two v_pk_fma_f32 on a float2
+//    accumulator (even / odd channels), i.e. one VALU instruction per (pair, channel).
+// fp32 VALU bound: 3*B1*B2*C flop (sub, mul, add).
 constexpr int kPT = 64, kPK = 32;
 
 __global__ __launch_bounds__(kBlock) void pairwise_dist_kernel(const float *__restrict__ src,
                                                               const float *__restrict__ tgt, int64_t B1, int64_t B2,
                                                               int C, int dist_type, float *__restrict__ out)
 {
-    __shared__ float As[kPT][kPK + 1];
-    __shared__ float Bs[kPT][kPK + 1];
+    __shared__ f32x4 As[kPK / 4][kPT];
+    __shared__ f32x4 Bs[kPK / 4][kPT];
     const int64_t i0 = (int64_t)blockIdx.y * kPT, j0 = (int64_t)blockIdx.x * kPT;
     const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
-    float acc[4][4];
+    const bool vec_ok = (C % 4 == 0) && ((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(tgt)) % 16 == 0);
+    f32x2 acc[4][4];
 #pragma unroll
-    for (int a = 0; a < 4; ++a)
+    for (int q = 0; q < 4; ++q)
 #pragma unroll
-        for (int b = 0; b < 4; ++b) acc[a][b] = 0.0f;
+        for (int w = 0; w < 4; ++w) acc[q][w] = (f32x2)0.0f;
 
+    // software pipeline: the next stage's global loads are issued (into registers) before the current stage
+    // is consumed; lane -> (row, k/4) pairs e = tid, tid + 256 of the 64 x 8 float4 stage
+    f32x4 pa[2], pb[2];
+    auto fetch = [&](int k0) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int e = threadIdx.x + h * kBlock;
+            const int r = e % kPT, k4 = e / kPT;
+            const int kc = k0 + k4 * 4;
+            f32x4 va = (f32x4)0.0f, vb = (f32x4)0.0f;
+            if (vec_ok && kc + 3 < C) {
+                if (i0 + r < B1) va = *reinterpret_cast<const f32x4 *>(src + (i0 + r) * C + kc);
+                if (j0 + r < B2) vb = *reinterpret_cast<const f32x4 *>(tgt + (j0 + r) * C + kc);
+            } else {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    if (kc + t < C && i0 + r < B1) va[t] = src[(i0 + r) * C + kc + t];
+                    if (kc + t < C && j0 + r < B2) vb[t] = tgt[(j0 + r) * C + kc + t];
+                }
+            }
+            pa[h] = va;
+            pb[h] = vb;
+        }
+    };
+    fetch(0);
     for (int k0 = 0; k0 < C; k0 += kPK) {
-        // 64 rows x 32 channels per operand = 2048 floats, 8 per lane, channel fastest
-        for (int e = threadIdx.x; e < kPT * kPK; e += kBlock) {
-            const int r = e / kPK, kk = e % kPK;
-            const bool kin = (k0 + kk) < C;
-            As[r][kk] = (kin && (i0 + r) < B1) ? src[(i0 + r) * C + k0 + kk] : 0.0f;
-            Bs[r][kk] = (kin && (j0 + r) < B2) ? tgt[(j0 + r) * C + k0 + kk] : 0.0f;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int e = threadIdx.x + h * kBlock;
+            As[e / kPT][e % kPT] = pa[h];
+            Bs[e / kPT][e % kPT] = pb[h];
         }
         __syncthreads();
-#pragma unroll 8
-        for (int kk = 0; kk < kPK; ++kk) {
-            float a[4], b[4];
+        if (k0 + kPK < C) fetch(k0 + kPK);
+#pragma unroll
+        for (int k4 = 0; k4 < kPK / 4; ++k4) {
+            f32x4 a[4], b[4];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                a[q] = As[ty * 4 + q][kk];
-                b[q] = Bs[tx * 4 + q][kk];
+                a[q] = As[k4][ty + 16 * q];
+                b[q] = Bs[k4][tx + 16 * q];
             }
 #pragma unroll
             for (int q = 0; q < 4; ++q)
 #pragma unroll
                 for (int w = 0; w < 4; ++w) {
-                    const float d = a[q] - b[w];
-                    acc[q][w] = fmaf(d, d, acc[q][w]);
+                    const f32x4 d = a[q] - b[w];
+                    const f32x2 lo = __builtin_shufflevector(d, d, 0, 1), hi = __builtin_shufflevector(d, d, 2, 3);
+                    acc[q][w] = __builtin_elementwise_fma(lo, lo, acc[q][w]);
+                    acc[q][w] = __builtin_elementwise_fma(hi, hi, acc[q][w]);
                 }
         }
         __syncthreads();
     }
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-        const int64_t i = i0 + ty * 4 + q;
+        const int64_t i = i0 + ty + 16 * q;
         if (i >= B1) continue;
 #pragma unroll
         for (int w = 0; w < 4; ++w) {
-            const int64_t j = j0 + tx * 4 + w;
-            if (j < B2) out[i * B2 + j] = dist_type == D3F_DIST_L2 ? sqrtf(acc[q][w]) : acc[q][w];
+            const int64_t j = j0 + tx + 16 * w;
+            const float ssum = acc[q][w].x + acc[q][w].y;
+            if (j < B2) out[i * B2 + j] = dist_type == D3F_DIST_L2 ? sqrtf(ssum) : ssum;
         }
     }
 }
@@ -160,26 +195,43 @@ __global__ __launch_bounds__(kBlock) void softmax_stats_kernel(const float *__re
     ws[(int64_t)blockIdx.y * cols + j] = o;
 }
 
+// One WAVE per column: lanes stride over the row chunks, then a shuffle reduction merges the running
+// (max, sum-exp, first-argmax) triples.  (A lane-per-column loop over ~400 chunks was latency-bound: 0.16 ms
+// for 300 columns.)
+__device__ __forceinline__ void merge_stat(float &m, float &s, int64_t &arg, float m2, float s2, int64_t arg2)
+{
+    const bool take2 = (m2 > m) || (m2 == m && arg2 < arg);
+    const float M = fmaxf(m, m2);
+    const float sa = (m == -INFINITY) ? 0.0f : s * expf(m - M);
+    const float sb = (m2 == -INFINITY) ? 0.0f : s2 * expf(m2 - M);
+    s = sa + sb;
+    m = M;
+    arg = take2 ? arg2 : arg;
+}
+
 __global__ __launch_bounds__(kBlock) void softmax_merge_kernel(ColStat *__restrict__ ws, int64_t nchunks,
                                                               int64_t cols, int64_t *__restrict__ argmax_out)
 {
-    const int64_t j = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-    if (j >= cols) return;
-    float m = -INFINITY;
-    int64_t arg = 0;
-    for (int64_t c = 0; c < nchunks; ++c) {
+    const int lane = threadIdx.x & 63;
+    const int64_t j = (int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+    if (j >= cols) return;                       // whole waves exit together
+    float m = -INFINITY, s = 0.0f;
+    int64_t arg = 0x7fffffffffffffffLL;
+    for (int64_t c = lane; c < nchunks; c += 64) {
         const ColStat t = ws[c * cols + j];
-        if (t.m > m) { m = t.m; arg = t.arg; }
+        merge_stat(m, s, arg, t.m, t.s, t.arg);
     }
-    float s = 0.0f;
-    for (int64_t c = 0; c < nchunks; ++c) {
-        const ColStat t = ws[c * cols + j];
-        s += t.s * expf(t.m - m);
+    for (int off = 32; off > 0; off >>= 1) {
+        const float m2 = __shfl_xor(m, off, 64), s2 = __shfl_xor(s, off, 64);
+        const int64_t a2 = __shfl_xor(arg, off, 64);
+        merge_stat(m, s, arg, m2, s2, a2);
     }
-    ColStat o;
-    o.m = m; o.s = s; o.arg = arg;
-    ws[nchunks * cols + j] = o;
-    if (argmax_out) argmax_out[j] = arg;
+    if (lane == 0) {
+        ColStat o;
+        o.m = m; o.s = s; o.arg = arg;
+        ws[nchunks * cols + j] = o;
+        if (argmax_out) argmax_out[j] = arg;
+    }
 }
 
 __global__ __launch_bounds__(kBlock) void softmax_apply_kernel(float *__restrict__ x, int64_t total, int64_t cols,
@@ -198,7 +250,8 @@ static hipError_t softmax_impl(float *x, int64_t rows, int64_t cols, float scale
     const int64_t nchunks = (rows + kSoftmaxRowsPerBlock - 1) / kSoftmaxRowsPerBlock;
     const unsigned gx = (unsigned)((cols + kBlock - 1) / kBlock);
     hipLaunchKernelGGL(softmax_stats_kernel, dim3(gx, (unsigned)nchunks), dim3(kBlock), 0, s, x, rows, cols, scale, ws);
-    hipLaunchKernelGGL(softmax_merge_kernel, dim3(gx), dim3(kBlock), 0, s, ws, nchunks, cols, argmax_out);
+    hipLaunchKernelGGL(softmax_merge_kernel, dim3((unsigned)((cols + kBlock / 64 - 1) / (kBlock / 64))), dim3(kBlock), 0, s, ws,
+                       nchunks, cols, argmax_out);
     if (normalise) {
         const int64_t total = rows * cols;
         hipLaunchKernelGGL(softmax_apply_kernel, dim3((unsigned)((total + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, x,
