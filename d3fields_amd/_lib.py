@@ -69,6 +69,7 @@ SIGNATURES = {
     "d3f_farthest_point_sampling": (ctypes.c_int, [_vp, _i64, _i32, _i64, _vp, _vp, _vp, _vp]),
     "d3f_eval_backward": (ctypes.c_int, [ctypes.POINTER(Views), _vp, _i64, ctypes.POINTER(ChannelMap), _i32, _f32,
                                          _vp, ctypes.POINTER(_vp), _vp, _vp]),
+    "d3f_eval_dist_backward": (ctypes.c_int, [ctypes.POINTER(Views), _vp, _i64, _vp, _vp, _vp]),
     "d3f_eval_dist": (ctypes.c_int, [ctypes.POINTER(Views), _vp, _i64, _vp, _vp, _vp]),
     "d3f_onehot2instance": (ctypes.c_int, [_vp, _i64, _i32, _vp, _vp]),
     "d3f_instance2onehot": (ctypes.c_int, [_vp, _i64, _i32, _vp, _vp]),

@@ -327,8 +327,9 @@ int d3f_farthest_point_sampling(const float *pts, int64_t n, int32_t k, int64_t 
     return e == hipSuccess ? D3F_OK : hip_fail(e, "fps launch");
 }
 
-int d3f_eval_backward(const d3f_views *views, const float *pts, int64_t n, const d3f_channel_map *maps, int32_t n_maps,
-                      float mu, const float *grad_dist, const float *const *grad_fused, float *grad_pts, void *stream)
+static int backward_common(const d3f_views *views, const float *pts, int64_t n, const d3f_channel_map *maps, int32_t n_maps,
+                           float mu, const float *grad_dist, const float *const *grad_fused, float *grad_pts, void *stream,
+                           int mode)
 {
     int rc = check_views(views);
     if (rc != D3F_OK) return rc;
@@ -352,8 +353,20 @@ int d3f_eval_backward(const d3f_views *views, const float *pts, int64_t n, const
     while (t > 16 && (long)t * views->V * 44 > 60 * 1024) t >>= 1;
     P.tile_pts = t;
     if ((n + t - 1) / t > 0x7fffffffLL) return fail(D3F_ERR_BAD_SHAPE, "n=%lld needs more than 2^31 workgroups", (long long)n);
-    hipError_t e = d3f::launch_fused_backward(P, static_cast<hipStream_t>(stream));
+    hipError_t e = d3f::launch_fused_backward(P, mode, static_cast<hipStream_t>(stream));
     return e == hipSuccess ? D3F_OK : hip_fail(e, "fused_eval_backward launch");
+}
+
+int d3f_eval_backward(const d3f_views *views, const float *pts, int64_t n, const d3f_channel_map *maps, int32_t n_maps,
+                      float mu, const float *grad_dist, const float *const *grad_fused, float *grad_pts, void *stream)
+{
+    return backward_common(views, pts, n, maps, n_maps, mu, grad_dist, grad_fused, grad_pts, stream, 0);
+}
+
+int d3f_eval_dist_backward(const d3f_views *views, const float *pts, int64_t n, const float *grad_dist, float *grad_pts,
+                           void *stream)
+{
+    return backward_common(views, pts, n, nullptr, 0, 1.0f, grad_dist, nullptr, grad_pts, stream, 1);
 }
 
 int d3f_eval_dist(const d3f_views *views, const float *pts, int64_t n, float *out_dist, uint8_t *out_valid,

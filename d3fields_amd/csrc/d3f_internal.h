@@ -64,7 +64,7 @@ struct BackwardParams {
     float mu;
     MapDesc maps[D3F_MAX_MAPS];                // out / inter unused
 };
-hipError_t launch_fused_backward(const BackwardParams &P, hipStream_t stream);
+hipError_t launch_fused_backward(const BackwardParams &P, int mode, hipStream_t stream);
 
 // order_kernels.hip
 int64_t order_workspace_bytes(int64_t n);

@@ -114,6 +114,9 @@ __device__ __forceinline__ void backward_map_u(const MapDesc &m, const float *go
     }
 }
 
+// MODE 0: gradient of Fusion.eval; MODE 1: of Fusion.eval_dist (fusion.py:396-436: dist = mean over valid views of
+// d - zc, validity without the -mu gate, no clamp, no weight, no channels).
+template <int MODE>
 __global__ __launch_bounds__(kBlock) void fused_eval_backward_kernel(const BackwardParams P)
 {
     extern __shared__ __align__(16) unsigned char smem[];
@@ -141,7 +144,7 @@ __global__ __launch_bounds__(kBlock) void fused_eval_backward_kernel(const Backw
             const Proj pr = project_point(krt + v * 12, px, py, pz, Wm1, Hm1);
             const float d = nearest_depth(P.depth, v, P.H, P.W, pr.gx, pr.gy);
             const float dist = d - pr.zc;
-            const bool valid = (d > 0.0f) && pr.ok && (dist > -mu);
+            const bool valid = (d > 0.0f) && pr.ok && (MODE == 1 || dist > -mu);
             float t = mu - fabsf(dist);
             t = t > 0.0f ? 0.0f : t;
             BwdRec r;
@@ -173,7 +176,8 @@ __global__ __launch_bounds__(kBlock) void fused_eval_backward_kernel(const Backw
         const int64_t i = tile_base + p;
         const float cnt = cnt_s[p];
         const float inv = 1.0f / (cnt + 1e-6f);
-        const float gd = (P.grad_dist && cnt != 0.0f) ? P.grad_dist[i] : 0.0f;    // all-invalid: dist := 1e3 (constant)
+        // eval: an all-invalid point has dist := 1e3 (constant); eval_dist: 0/(0+1e-6), no valid view contributes
+        const float gd = (P.grad_dist && cnt != 0.0f) ? P.grad_dist[i] : 0.0f;
         float gxw = 0.0f, gyw = 0.0f, gzw = 0.0f;
         for (int v = 0; v < V; ++v) {
             const BwdRec r = rec[p * V + v];
@@ -184,8 +188,8 @@ __global__ __launch_bounds__(kBlock) void fused_eval_backward_kernel(const Backw
             const float g_gx = A * r.wgt * o[1];                   // dL/dgx_v  (o[1] already times d ix / d gx)
             const float g_gy = A * r.wgt * o[2];
             // dL/ddist_v: clamp passes inside [-mu, mu]; weight passes where mu - |dist| <= 0
-            float g_dist = (r.dist >= -mu && r.dist <= mu) ? gd * A : 0.0f;
-            if (mu - fabsf(r.dist) <= 0.0f) {
+            float g_dist = (MODE == 1 || (r.dist >= -mu && r.dist <= mu)) ? gd * A : 0.0f;
+            if (MODE == 0 && mu - fabsf(r.dist) <= 0.0f) {
                 const float sgn = r.dist > 0.0f ? 1.0f : (r.dist < 0.0f ? -1.0f : 0.0f);
                 g_dist += g_wgt * r.wgt * (-sgn) / mu;
             }
@@ -204,12 +208,15 @@ __global__ __launch_bounds__(kBlock) void fused_eval_backward_kernel(const Backw
     }
 }
 
-hipError_t launch_fused_backward(const BackwardParams &P, hipStream_t stream)
+hipError_t launch_fused_backward(const BackwardParams &P, int mode, hipStream_t stream)
 {
     if (P.n == 0) return hipSuccess;
     const int64_t ntiles = (P.n + P.tile_pts - 1) / P.tile_pts;
     const size_t lds = (size_t)P.tile_pts * P.V * (sizeof(BwdRec) + 12) + (size_t)P.tile_pts * 4 + (size_t)P.V * 48;
-    hipLaunchKernelGGL(fused_eval_backward_kernel, dim3((unsigned)ntiles), dim3(kBlock), lds, stream, P);
+    if (mode == 0)
+        hipLaunchKernelGGL(fused_eval_backward_kernel<0>, dim3((unsigned)ntiles), dim3(kBlock), lds, stream, P);
+    else
+        hipLaunchKernelGGL(fused_eval_backward_kernel<1>, dim3((unsigned)ntiles), dim3(kBlock), lds, stream, P);
     return hipGetLastError();
 }
 

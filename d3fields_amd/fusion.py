@@ -139,6 +139,31 @@ class _FieldQueryFn(torch.autograd.Function):
         return ctx.fusion._backward(ctx.saved, grad_dist, grad_fused), None, None
 
 
+class _DistQueryFn(torch.autograd.Function):
+    """Fusion.eval_dist as an autograd node (d3f_eval_dist / d3f_eval_dist_backward)."""
+
+    @staticmethod
+    def forward(ctx, pts, fusion):
+        outputs, _ = fusion._launch(pts.detach(), (), False, "eval_dist")
+        views, keep, _ = fusion._views(pts.device)
+        ctx.fusion, ctx.saved = fusion, (pts.detach().contiguous(), keep)
+        ctx.mark_non_differentiable(outputs["valid_mask"])
+        return outputs["dist"], outputs["valid_mask"]
+
+    @staticmethod
+    def backward(ctx, grad_dist, _grad_valid):
+        pts_c, keep = ctx.saved
+        dev = pts_c.device
+        n, V = pts_c.shape[0], keep[0].shape[0]
+        views = _lib.Views(V, keep[0].shape[1], keep[0].shape[2], _lib.ptr(keep[0]), _lib.ptr(keep[1]), _lib.ptr(keep[2]))
+        grad_pts = torch.empty((n, 3), dtype=torch.float32, device=dev)
+        gd = grad_dist.to(torch.float32).contiguous()
+        with torch.cuda.device(dev):
+            _lib.check(ctx.fusion._lib.d3f_eval_dist_backward(ctypes.byref(views), _lib.ptr(pts_c), n, _lib.ptr(gd),
+                                                              _lib.ptr(grad_pts), _lib.current_stream_handle(dev)))
+        return grad_pts, None
+
+
 # ----------------------------------------------------------------------------------------
 class Fusion:
     """Multi-view 3-D descriptor field (query side).
@@ -235,9 +260,12 @@ class Fusion:
         self._check_query(pts)
         if pts.requires_grad and torch.is_grad_enabled():
             # autograd consumer: rigid_tracking back-propagates through eval (fusion.py:1650-1665)
-            if mode != "eval" or return_inter:
-                raise NotImplementedError("gradients are implemented for Fusion.eval(pts, return_names) only "
-                                          "(not eval_dist / return_inter); detach pts or use torch.no_grad()")
+            if return_inter:
+                raise NotImplementedError("gradients through '<k>_inter' outputs are not implemented; "
+                                          "detach pts or use torch.no_grad()")
+            if mode == "eval_dist":
+                flat = _DistQueryFn.apply(pts, self)
+                return {"dist": flat[0], "valid_mask": flat[1]}
             names = list(return_names)
             flat = _FieldQueryFn.apply(pts, self, names)
             out = {"dist": flat[0], "valid_mask": flat[1]}

@@ -172,6 +172,10 @@ int d3f_eval_backward(const d3f_views *views, const float *pts, int64_t n, const
                       int32_t n_maps, float mu, const float *grad_dist, const float *const *grad_fused,
                       float *grad_pts, void *stream);
 
+/* The same for Fusion.eval_dist: d(dist)/d(pts) = -mean over the valid views of row 2 of K@pose. */
+int d3f_eval_dist_backward(const d3f_views *views, const float *pts, int64_t n, const float *grad_dist,
+                           float *grad_pts, void *stream);
+
 /* Replaces Fusion.eval_dist (fusion.py:396-436): no -mu gate, no clamp, no 1e3 sentinel. */
 int d3f_eval_dist(const d3f_views *views, const float *pts, int64_t n, float *out_dist,
                   uint8_t *out_valid, void *stream);

@@ -475,7 +475,24 @@ def test_rigid_tracking_style_loop(dev):
         losses.append(float(loss))
     assert losses[-1] < losses[0]
     with pytest.raises(NotImplementedError):
-        f.eval_dist(src.clone().requires_grad_(True))
+        f.eval(src.clone().requires_grad_(True), return_names=["dino_feats"], return_inter=True)
+
+
+def test_eval_dist_backward_vs_torch_port(dev):
+    from d3fields_amd import synth
+    from oracle import torch_port
+    V, H, W, N = 5, 48, 64, 4000
+    sc = synth.make_scene(V, H, W, "stress")
+    f = make_fusion(dev, sc["depth"], sc["K"], sc["pose"], {}, H, W)
+    pts = synth.random_cloud(N, seed=6)
+    wgt = torch.randn(N, generator=torch.Generator().manual_seed(7))
+    p_ref = pts.clone().requires_grad_(True)
+    (torch_port.dist_query(dict(sc), p_ref, H, W)["dist"] * wgt).sum().backward()
+    p_gpu = pts.to(dev).requires_grad_(True)
+    o = f.eval_dist(p_gpu)
+    assert o["dist"].requires_grad and not o["valid_mask"].requires_grad
+    (o["dist"] * wgt.to(dev)).sum().backward()
+    assert rel_err(cpu(p_gpu.grad), p_ref.grad.numpy()) <= GRAD_TOL
 
 
 # ---------------------------------------------------------------------------------------
