@@ -67,6 +67,10 @@ SIGNATURES = {
                                      _vp, _vp, ctypes.POINTER(_vp), _vp]),
     "d3f_grid_shell": (ctypes.c_int, [ctypes.POINTER(Views), ctypes.POINTER(Grid), _f32, _f32, _i64, _vp, _vp, _vp]),
     "d3f_farthest_point_sampling": (ctypes.c_int, [_vp, _i64, _i32, _i64, _vp, _vp, _vp, _vp]),
+    "d3f_backproject_workspace_bytes": (_i64, [_i32, _i32]),
+    "d3f_backproject_view": (ctypes.c_int, [_vp, _vp, _i32, _i32, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double),
+                                            ctypes.POINTER(ctypes.c_double), _i64, _vp, _vp, _vp, _vp, _vp]),
+    "d3f_pcd_nearest": (ctypes.c_int, [_vp, _i64, _vp, _i64, _vp, _vp, _vp]),
     "d3f_eval_backward": (ctypes.c_int, [ctypes.POINTER(Views), _vp, _i64, ctypes.POINTER(ChannelMap), _i32, _f32,
                                          _vp, ctypes.POINTER(_vp), _vp, _vp]),
     "d3f_eval_dist_backward": (ctypes.c_int, [ctypes.POINTER(Views), _vp, _i64, _vp, _vp, _vp]),

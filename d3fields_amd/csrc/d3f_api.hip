@@ -283,6 +283,34 @@ int d3f_eval_plan_query(const d3f_views *views, int64_t n, const d3f_channel_map
                        nullptr, have_workspace ? d3f::order_workspace_bytes(n) : 0, nullptr, 0, plan);
 }
 
+int64_t d3f_backproject_workspace_bytes(int32_t H, int32_t W)
+{
+    if (H <= 0 || W <= 0) return 0;
+    return (((int64_t)H * W + d3f::kBlock - 1) / d3f::kBlock + 1) * (int64_t)sizeof(int64_t);
+}
+
+int d3f_backproject_view(const double *depth, const uint8_t *mask, int32_t H, int32_t W, const double *cam_params,
+                         const double *cam_to_world, const double *bounds, int64_t capacity, double *out_pts, int32_t *out_pixel,
+                         int64_t *count_out, void *workspace, void *stream)
+{
+    if (H < 1 || W < 1 || (int64_t)H * W > 0x7fffffffLL) return fail(D3F_ERR_BAD_SHAPE, "backproject: H=%d W=%d", H, W);
+    if (!depth || !cam_params || !cam_to_world || !count_out || !workspace || capacity < 0 || (capacity > 0 && !out_pts))
+        return fail(D3F_ERR_INVALID_ARG, "backproject: NULL pointer or negative capacity");
+    if (!(cam_params[0] != 0.0) || !(cam_params[1] != 0.0)) return fail(D3F_ERR_INVALID_ARG, "backproject: fx/fy must be non-zero");
+    hipError_t e = d3f::launch_backproject(depth, mask, H, W, cam_params, cam_to_world, bounds, capacity, out_pts, out_pixel,
+                                           count_out, static_cast<int64_t *>(workspace), static_cast<hipStream_t>(stream));
+    return e == hipSuccess ? D3F_OK : hip_fail(e, "backproject launch");
+}
+
+int d3f_pcd_nearest(const double *a, int64_t na, const double *b, int64_t nb, double *min_dist, int64_t *argmin, void *stream)
+{
+    if (na < 0 || nb < 1) return fail(D3F_ERR_BAD_SHAPE, "pcd_nearest: na=%lld nb=%lld (nb must be >= 1)", (long long)na, (long long)nb);
+    if (na == 0) return D3F_OK;
+    if (!a || !b || !min_dist || !argmin) return fail(D3F_ERR_INVALID_ARG, "pcd_nearest: NULL pointer");
+    hipError_t e = d3f::launch_nearest(a, na, b, nb, min_dist, argmin, static_cast<hipStream_t>(stream));
+    return e == hipSuccess ? D3F_OK : hip_fail(e, "pcd_nearest launch");
+}
+
 static int check_grid(const d3f_grid *g)
 {
     if (!g) return fail(D3F_ERR_INVALID_ARG, "grid is NULL");

@@ -78,6 +78,12 @@ hipError_t launch_grid_shell(const float *depth, const float *K, const float *po
 hipError_t launch_fps(const float *pts, int64_t n, int k, int64_t init_idx, int64_t *out_idx, float *out_maxdist,
                       float *dist_ws, hipStream_t s);
 
+// pcd_kernels.hip
+hipError_t launch_backproject(const double *depth, const uint8_t *mask, int H, int W, const double *cam, const double *T,
+                              const double *bounds, int64_t capacity, double *out_pts, int32_t *out_pixel, int64_t *count,
+                              int64_t *block_counts, hipStream_t s);
+hipError_t launch_nearest(const double *a, int64_t na, const double *b, int64_t nb, double *min_dist, int64_t *argmin, hipStream_t s);
+
 // misc_kernels.hip
 hipError_t launch_onehot2instance(const float *onehot, int64_t n, int NI, uint8_t *out, hipStream_t s);
 hipError_t launch_instance2onehot(const uint8_t *inst, int64_t n, int NI, uint8_t *out, hipStream_t s);

@@ -461,6 +461,11 @@ class Fusion:
                 last_label = label[i]
         return src_feats_list, src_pts_list, []
 
+    def pcd_iou(self, pcd_1, pcd_2, threshold):
+        """Reference Fusion.pcd_iou (fusion.py:724-741); see d3fields_amd.pcd_utils.pcd_iou."""
+        from . import pcd_utils
+        return pcd_utils.pcd_iou(pcd_1, pcd_2, threshold)
+
     # ---- instance masks: upstream producers (reference fusion.py:1112-1256) ----------------
     def _store_mask(self, produced):
         m = produced

@@ -163,6 +163,24 @@ int d3f_grid_shell(const d3f_views *views, const d3f_grid *grid, float mu, float
 int d3f_farthest_point_sampling(const float *pts, int64_t n, int32_t k, int64_t init_idx, int64_t *out_idx,
                                 float *out_maxdist, float *dist_workspace, void *stream);
 
+/* ---- point clouds on the mask side of the path (fp64, like the reference's numpy) ----------------------
+ * depth2fgpcd (utils/my_utils.py:522-537) + camera->world transform + boundary crop of
+ * aggr_point_cloud_from_data (utils/draw_utils.py:325-413) for one view.  depth [H,W] fp64 (device);
+ * mask [H,W] bytes or NULL (NULL: foreground = 0 < depth < 1.5, as in the reference); cam_params = {fx, fy, cx,
+ * cy}, cam_to_world = inv(pose) as 16 row-major doubles, bounds = {x_lower, x_upper, y_lower, y_upper,
+ * z_lower, z_upper} or NULL -- these three are HOST arrays.  Survivors are written in ascending pixel order
+ * (numpy's boolean-mask order): out_pts [capacity,3] fp64, out_pixel [capacity] int32 (row*W + col) or NULL,
+ * count_out: one device int64 (may exceed capacity).  workspace: d3f_backproject_workspace_bytes(H,W). */
+int64_t d3f_backproject_workspace_bytes(int32_t H, int32_t W);
+int d3f_backproject_view(const double *depth, const uint8_t *mask, int32_t H, int32_t W, const double *cam_params,
+                         const double *cam_to_world, const double *bounds, int64_t capacity, double *out_pts,
+                         int32_t *out_pixel, int64_t *count_out, void *workspace, void *stream);
+
+/* One direction of Fusion.pcd_iou's nearest-neighbour search (fusion.py:731-735): for every point of a[na,3]
+ * the Euclidean distance to, and index of, its nearest point in b[nb,3] (first minimum wins), fp64. */
+int d3f_pcd_nearest(const double *a, int64_t na, const double *b, int64_t nb, double *min_dist, int64_t *argmin,
+                    void *stream);
+
 /* Gradient of d3f_eval's outputs w.r.t. the query points: what autograd through Fusion.eval gives
  * the reference's rigid_tracking (fusion.py:1643-1665).  grad_dist: [n] or NULL; grad_fused: host
  * array of n_maps device pointers ([n,C_k], entries may be NULL); grad_pts [n,3] is overwritten.

@@ -222,6 +222,31 @@ def select_case(fusion):
     save("select_features", **arrays)
 
 
+def pcd_case(fusion):
+    """depth2fgpcd / aggr_point_cloud_from_data (numpy outputs) / Fusion.pcd_iou of the reference."""
+    V, H, W = 3, 60, 80
+    sc = synth.make_scene(V, H, W, "smooth")
+    depths = sc["depth"].numpy().astype(np.float64)
+    depths[0, 10:20, 30:50] = 0.0                                     # holes
+    K = sc["K"].numpy().astype(np.float64)
+    pose44 = np.tile(np.eye(4), (V, 1, 1))
+    pose44[:, :3] = sc["pose"].numpy().astype(np.float64)
+    rng = np.random.default_rng(71)
+    colors = rng.integers(0, 256, size=(V, H, W, 3), dtype=np.uint8)
+    masks = rng.random((V, H, W)) < 0.6
+    box = dict(synth.WORK_BOX)
+    a_pts, a_col = fusion.aggr_point_cloud_from_data(colors, depths, K, pose44, downsample=False, masks=masks, boundaries=box, out_o3d=False)
+    b_pts, b_col = fusion.aggr_point_cloud_from_data(colors, depths, K, pose44, downsample=False, masks=None, boundaries=None, out_o3d=False)
+    fg = fusion.depth2fgpcd(depths[1], masks[1], [K[1, 0, 0], K[1, 1, 1], K[1, 0, 2], K[1, 1, 2]])
+    f = fusion.Fusion.__new__(fusion.Fusion)
+    p1, p2 = a_pts[::7][:1500], a_pts[3::5][:1200] + 0.002
+    iou = f.pcd_iou(p1, p2, 0.005)
+    save("pcd_utils", depths=depths, K=K, pose44=pose44, colors=colors, masks=masks,
+         bounds=np.array([box[k] for k in ("x_lower", "x_upper", "y_lower", "y_upper", "z_lower", "z_upper")]),
+         crop_pts=a_pts, crop_col=a_col, all_pts=b_pts, all_col=b_col, fg_view1=fg, p1=p1, p2=p2,
+         iou=np.array(iou[:3], dtype=np.float64), overlap_1=iou[3], overlap_2=iou[4], idx_12=iou[5], idx_21=iou[6])
+
+
 def main():
     torch.set_num_threads(4)
     fusion, corr = R.import_reference()
@@ -236,6 +261,7 @@ def main():
     corr_case(corr)
     grad_case(fusion)
     select_case(fusion)
+    pcd_case(fusion)
 
 
 if __name__ == "__main__":

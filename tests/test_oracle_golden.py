@@ -136,3 +136,21 @@ def test_fps_and_shell_match_reference():
     assert np.array_equal(o["dist"], g["grid_dist"]) and np.array_equal(np.packbits(o["valid_mask"]), g["grid_valid"])
     shell = np.nonzero((np.abs(o["dist"]) < 0.005) & o["valid_mask"])[0]
     assert np.array_equal(shell, g["shell_index"])
+
+
+def test_pcd_restatement_matches_reference():
+    from oracle import np_pcd
+    g = load_golden("pcd_utils")
+    V = g["depths"].shape[0]
+    pts, cols = [], []
+    for i in range(V):
+        K = g["K"][i]
+        w, pix = np_pcd.backproject_view(g["depths"][i], g["masks"][i], [K[0, 0], K[1, 1], K[0, 2], K[1, 2]],
+                                         np.linalg.inv(g["pose44"][i]), g["bounds"])
+        pts.append(w)
+        cols.append((g["colors"][i] / 255.).reshape(-1, 3)[pix])
+    pts, cols = np.concatenate(pts), np.concatenate(cols)
+    assert pts.shape == g["crop_pts"].shape and np.allclose(pts, g["crop_pts"], rtol=0, atol=1e-12)
+    assert np.array_equal(cols, g["crop_col"])
+    md, am = np_pcd.nearest(g["p1"], g["p2"])
+    assert np.array_equal(am, g["idx_12"]) and np.array_equal(np.where(md < 0.005)[0], g["overlap_1"])
