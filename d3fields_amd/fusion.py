@@ -19,9 +19,6 @@ from . import _lib
 
 __all__ = ["Fusion", "create_init_grid", "instance2onehot", "onehot2instance", "fps"]
 
-_RESERVED = ("depth", "pose", "K", "color")
-
-
 # ----------------------------------------------------------------------------------------
 # grid / mask-format helpers (reference fusion.py:79-116)
 # ----------------------------------------------------------------------------------------
