@@ -221,8 +221,12 @@ int eval_common(const d3f_views *views, const float *pts, int64_t n, const d3f_c
     // wide maps (>= 16 lanes per point): corner set-up once per (point, view) in phase A, 32 B of LDS each
     P.n_pre = 0;
     if (!(flags & (1u << 28)))
-        for (int s = 0; s < n_maps && P.n_pre < 2; ++s)
-            if (!P.maps[s].staged && P.maps[s].lpp_log2 >= 4 && !(out_inter && out_inter[s])) P.maps[s].pre_slot = P.n_pre++;
+        for (int s = 0; s < n_maps && P.n_pre < 2; ++s) {
+            // 32 B per (point, view) and map: only while records + set-ups stay within 48 KiB (>= 3 workgroups per CU)
+            const long lds_after = (long)P.stage_offset + P.stage_floats * 8 + (long)(P.n_pre + 1) * P.tile_pts * views->V * 32;
+            if (!P.maps[s].staged && P.maps[s].lpp_log2 >= 4 && !(out_inter && out_inter[s]) && lds_after <= 48 * 1024)
+                P.maps[s].pre_slot = P.n_pre++;
+        }
     P.crec_offset = P.stage_offset + P.stage_floats * 8;
     const int64_t ntiles = (n + P.tile_pts - 1) / P.tile_pts;
     if (ntiles > 0x7fffffffLL) return fail(D3F_ERR_BAD_SHAPE, "n=%lld needs more than 2^31 workgroups", (long long)n);
