@@ -100,8 +100,8 @@ int fill_map(const d3f_channel_map &c, int s, int V, float *out, float *inter, c
     return D3F_OK;
 }
 
-// Staged gather (fuse_eval.hip): 16-B vectors, at most 32 lanes per point and 3 vectors per lane so that
-// 4 points per lane group keep their accumulators in registers; wide (>= 256 B per texel) maps whose
+// Staged gather (fuse_eval.hip): 16-B vectors, 32 lanes per point and <= 3 vectors per lane so that the
+// 4 points of a half-wave keep their accumulators in registers; wide (>= 256 B per texel) maps whose
 // texels span >= 4 image pixels, i.e. the patch-resolution feature maps of the reference.
 bool staging_candidate(const d3f::MapDesc &m, int H, int W)
 {
@@ -113,7 +113,7 @@ void pick_staged_mapping(d3f::MapDesc &m)
     const int cvec = m.C / 4;
     long best_slots = -1;
     int best_passes = 0;
-    for (int lg = 5; lg >= 3; --lg)
+    for (int lg = 5; lg >= 5; --lg)
         for (int u = 3; u >= 1; --u) {
             const int per = (1 << lg) * u;
             const int passes = (cvec + per - 1) / per;
@@ -122,7 +122,7 @@ void pick_staged_mapping(d3f::MapDesc &m)
                 best_slots = slots; best_passes = passes; m.lpp_log2 = lg; m.unroll = u;
             }
         }
-    m.staged = 1;
+    m.staged = 2;
 }
 
 int tile_points_for(int V)
@@ -215,7 +215,7 @@ int eval_common(const d3f_views *views, const float *pts, int64_t n, const d3f_c
         for (int s = 0; s < n_maps; ++s)
             if (staging_candidate(P.maps[s], views->H, views->W)) pick_staged_mapping(P.maps[s]);
         P.tile_pts = 32; P.lds_pad = 0;
-        P.stage_floats = d3f::kStageFloats;
+        P.stage_floats = d3f::kStageFloats;     // 4 wave-private regions of 13.5 KiB (9 texels of 384 channels)
     }
     P.stage_offset = d3f::fused_lds_base(P.tile_pts, views->V);
     // wide maps (>= 16 lanes per point): corner set-up once per (point, view) in phase A, 32 B of LDS each

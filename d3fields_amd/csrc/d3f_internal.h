@@ -22,7 +22,7 @@ struct MapDesc {
     int32_t lpp_log2;  // log2(lanes per point) in phase B
     int32_t unroll;    // channel vectors per lane per pass: +1..+3 batched loads, -1..-4 load-use per vector
     int32_t pre_slot;  // >= 0: bilinear corner set-up of this map is precomputed per (point, view) in LDS slot pre_slot
-    int32_t staged;    // 1: gather through the LDS texel window (low-resolution wide maps, Morton-ordered tiles)
+    int32_t staged;    // 2: gather through wave-private LDS texel windows (opt-in experiment)
 };
 
 struct EvalParams {
@@ -48,7 +48,7 @@ struct EvalParams {
 
 // LDS bytes in front of the stage buffers: records, cnt/flag/idx, KRt, per-view windows
 inline int fused_lds_base(int tile_pts, int V) { return ((tile_pts * V * 24 + tile_pts * 12 + V * 48 + V * 16) + 15) / 16 * 16; }
-constexpr int kStageFloats = 6144;      // 24 KiB per stage buffer: 16 texels of 384 fp32 channels
+constexpr int kStageFloats = 6912;      // half of the LDS stage area in floats: 4 wave regions of 3456 floats in total
 hipError_t launch_fused_eval(const EvalParams &P, int mode, hipStream_t stream);
 
 // fuse_backward.hip

@@ -205,18 +205,15 @@ __device__ __forceinline__ void gather_map(const MapDesc &m, const EvalParams &P
     }
 }
 
-// ---- phase B, staged variant: low-resolution wide maps (patch-resolution DINO features) -----------
+// ---- phase B, LDS-staged variant (opt-in experiment, D3F_TUNE_STAGING) ---------------------------------
 // When a map has far fewer texels than the image has pixels (the reference's dino_feats is
-// (H/10, W/10), fusion.py:694-697) the points of a spatially compact tile fall into a handful of
-// texel cells: 32 Morton-ordered points touch ~9-16 distinct texels per view but issue 128 corner
-// reads.  The direct gather then runs at the L1 rate (measured 23 TB/s of texel reads, 85 % L2 hits);
-// here the tile's texel window of each view is copied ONCE into LDS (coalesced 16-B loads) and the
-// corner reads become ds_read_b128 -- LDS has ~4x the per-CU bandwidth of the vector L1.
-// The arithmetic and its order are exactly those of gather_map, so results are bit-identical; a view
-// whose window does not fit the stage buffer is gathered directly from global memory.
-// Requires VW == 4, 1<<lpp_log2 <= 32 and tile_n <= 32 (host-enforced).
-constexpr int kStagedPPG = 4;               // points per lane group (kStagedTile / (256/32))
-
+// (H/10, W/10), fusion.py:694-697) spatially close points fall into a handful of texel cells, so a texel
+// window can be copied ONCE into LDS (coalesced 16-B loads) and the corner reads become ds_read_b128.
+// The arithmetic and its order are exactly those of gather_map (bit-identical results, tested); a view
+// whose window does not fit is gathered directly.  Measured on MI355X it LOSES to the direct gather
+// (C2 patch 0.74 -> 1.7-1.9 ms, both as 32-point workgroup windows behind barriers and as the
+// wave-private form below): 5x fewer L1 loads, but the dependent window -> load -> LDS -> read chain runs
+// at 2 waves/SIMD while the direct gather keeps 4 waves x 12 independent loads in flight.  Kept opt-in.
 template <int U, bool FROM_LDS>
 __device__ __forceinline__ void staged_accumulate(const MapDesc &m, const EvalParams &P, const ViewRec &r, int v, int64_t i,
                                                   int c0, int lpp, int g, int cvec, const float *__restrict__ buf,
@@ -267,111 +264,113 @@ __device__ __forceinline__ void staged_accumulate(const MapDesc &m, const EvalPa
     }
 }
 
+// ---- phase B, wave-private staging ------------------------------------------------------------------
+// No workgroup barriers: every WAVE owns 8 consecutive points of
+// the Morton walk (a ~1-cm cube), stages the texel window of those 8 points for one view into its private
+// quarter of the stage area, and reads the 8 x 4 corners back with ds_read_b128.  LDS operations of one
+// wave execute in issue order, so only compiler reordering has to be fenced (wave_barrier), and the waves
+// of a workgroup never wait for each other.  8 points touch ~4-9 distinct texels per view instead of 32
+// corner fetches.  Requires 32 lanes per point (lpp_log2 == 5), VW == 4, tile_n <= 32 (host-enforced).
 template <int U>
-__device__ __forceinline__ void gather_map_staged(const MapDesc &m, const EvalParams &P, const ViewRec *rec,
-                                                  const float *cnt_s, const uint32_t *flag_s, const uint32_t *idx_s,
-                                                  int64_t idx_base, int tile_n, int *bbox, float *stage, int stage_floats)
+__device__ __forceinline__ void gather_map_wave_staged(const MapDesc &m, const EvalParams &P, const ViewRec *rec,
+                                                       const float *cnt_s, const uint32_t *flag_s, const uint32_t *idx_s,
+                                                       int64_t idx_base, int tile_n, float *stage, int region_floats)
 {
     using VT = f32x4;
-    const int lpp = 1 << m.lpp_log2;
-    const int g = threadIdx.x & (lpp - 1);
-    const int grp = threadIdx.x >> m.lpp_log2;
-    const int ngrp = kBlock >> m.lpp_log2;                      // >= 8
+    constexpr int kRegsW = 14;                  // float4 per lane per window: 14 * 64 * 16 B = 14 KiB >= one region
+    const int lane = threadIdx.x & 63, half = lane >> 5, g = lane & 31, wave = threadIdx.x >> 6;
     const int cvec = m.C / 4;
     const int V = P.V;
     const bool want_inter = m.inter != nullptr;
+    float *wbuf = stage + (size_t)wave * region_floats;
+    const int p_base = wave * 8;
 
-    // 1. texel window of every view: min/max over the corners the tile will actually read
-    for (int t = threadIdx.x; t < V * 4; t += kBlock) bbox[t] = (t & 1) ? INT_MIN : INT_MAX;
-    __syncthreads();
-    for (int idx = threadIdx.x; idx < tile_n * V; idx += kBlock) {
-        const int v = idx / tile_n, p = idx - v * tile_n;
-        const bool strict = (flag_s[p] != 0u) || want_inter;
-        const ViewRec r = rec[p * V + v];
-        if (!strict && r.valid == 0.0f) continue;
-        const float x0 = floorf(unnormalize(r.gx, m.fw)), y0 = floorf(unnormalize(r.gy, m.fh));
-        // in-bounds part of [x0, x0+1] x [y0, y0+1]; float compares keep NaN/huge values out
-        if (!(x0 >= -1.0f && x0 <= (float)(m.fw - 1) && y0 >= -1.0f && y0 <= (float)(m.fh - 1))) continue;
-        atomicMin(&bbox[v * 4 + 0], max((int)x0, 0));
-        atomicMax(&bbox[v * 4 + 1], min((int)x0 + 1, m.fw - 1));
-        atomicMin(&bbox[v * 4 + 2], max((int)y0, 0));
-        atomicMax(&bbox[v * 4 + 3], min((int)y0 + 1, m.fh - 1));
-    }
-    __syncthreads();
-
-    // 2. passes over the channels.  Per pass the V windows go through a 2-deep LDS ring; the loads of
-    //    view v+1 are issued (into registers) before view v is consumed, so their latency hides
-    //    behind the LDS reads and FMAs of view v.  One barrier per view.
-    constexpr int kRegs = kStageFloats / 4 / kBlock;          // float4 per lane per window (6)
-    for (int c0 = 0; c0 < cvec; c0 += lpp * U) {
-        const int pass_vecs = min(lpp * U, cvec - c0);
-        VT acc[kStagedPPG][U];
+    for (int c0 = 0; c0 < cvec; c0 += 32 * U) {
+        const int pass_vecs = min(32 * U, cvec - c0);
+        VT acc[4][U];
 #pragma unroll
-        for (int j = 0; j < kStagedPPG; ++j)
+        for (int j = 0; j < 4; ++j)
 #pragma unroll
             for (int u = 0; u < U; ++u) acc[j][u] = (VT)0.0f;
-        VT tmp[kRegs];
-        auto window_fits = [&](int v) {
-            const int xmin = bbox[v * 4 + 0], xmax = bbox[v * 4 + 1], ymin = bbox[v * 4 + 2], ymax = bbox[v * 4 + 3];
-            return (xmin <= xmax) && (ymin <= ymax) &&
-                   ((int64_t)(xmax - xmin + 1) * (ymax - ymin + 1) * pass_vecs * 4 <= (int64_t)stage_floats);
-        };
-        auto issue_loads = [&](int v) {
-            if (!window_fits(v)) return;
-            const int xmin = bbox[v * 4 + 0], ymin = bbox[v * 4 + 2], bw = bbox[v * 4 + 1] - xmin + 1;
-            const int total = bw * (bbox[v * 4 + 3] - ymin + 1) * pass_vecs;
-            const float *src = m.data + (int64_t)v * m.sv + (int64_t)c0 * 4;
-#pragma unroll
-            for (int k = 0; k < kRegs; ++k) {
-                const int e = threadIdx.x + k * kBlock;
-                if (e < total) {
-                    const int texel = e / pass_vecs, lv = e - texel * pass_vecs;
-                    const int wy = texel / bw, wx = texel - wy * bw;
-                    tmp[k] = load_vec<VT>(src + (int64_t)(ymin + wy) * m.sy + (int64_t)(xmin + wx) * m.sx + lv * 4);
-                }
-            }
-        };
-        issue_loads(0);
         for (int v = 0; v < V; ++v) {
-            const int xmin = bbox[v * 4 + 0], ymin = bbox[v * 4 + 2], bw = bbox[v * 4 + 1] - xmin + 1;
-            const bool fits = window_fits(v);
-            float *buf = stage + (v & 1) * stage_floats;
-            if (fits) {
-                const int total = bw * (bbox[v * 4 + 3] - ymin + 1) * pass_vecs;
-#pragma unroll
-                for (int k = 0; k < kRegs; ++k) {
-                    const int e = threadIdx.x + k * kBlock;
-                    if (e < total) store_vec<VT>(buf + (int64_t)e * 4, tmp[k]);
+            // window of the wave's 8 points: lanes 0..7 take one point each, butterfly min/max over 8 lanes
+            int xa = INT_MAX, xb = INT_MIN, ya = INT_MAX, yb = INT_MIN;
+            {
+                const int p = p_base + (lane & 7);
+                if (p < tile_n) {
+                    const ViewRec r = rec[p * V + v];
+                    const bool strict = (flag_s[p] != 0u) || want_inter;
+                    if (strict || r.valid != 0.0f) {
+                        const float x0 = floorf(unnormalize(r.gx, m.fw)), y0 = floorf(unnormalize(r.gy, m.fh));
+                        if (x0 >= -1.0f && x0 <= (float)(m.fw - 1) && y0 >= -1.0f && y0 <= (float)(m.fh - 1)) {
+                            xa = max((int)x0, 0); xb = min((int)x0 + 1, m.fw - 1);
+                            ya = max((int)y0, 0); yb = min((int)y0 + 1, m.fh - 1);
+                        }
+                    }
                 }
             }
-            if (v + 1 < V) issue_loads(v + 1);
-            __syncthreads();        // window v visible; buf[(v+1)&1] was last read two barriers ago
 #pragma unroll
-            for (int j = 0; j < kStagedPPG; ++j) {
-                const int p = grp + j * ngrp;
+            for (int off = 1; off < 8; off <<= 1) {
+                xa = min(xa, __shfl_xor(xa, off, 64)); xb = max(xb, __shfl_xor(xb, off, 64));
+                ya = min(ya, __shfl_xor(ya, off, 64)); yb = max(yb, __shfl_xor(yb, off, 64));
+            }
+            const int xmin = __builtin_amdgcn_readfirstlane(xa), xmax = __builtin_amdgcn_readfirstlane(xb);
+            const int ymin = __builtin_amdgcn_readfirstlane(ya), ymax = __builtin_amdgcn_readfirstlane(yb);
+            const int bw = xmax - xmin + 1, bh = ymax - ymin + 1;
+            const bool nonempty = (xmin <= xmax) && (ymin <= ymax);
+            const bool fits = nonempty && (bw * bh * pass_vecs * 4 <= region_floats);
+            __builtin_amdgcn_wave_barrier();            // previous view's ds_reads stay ahead of these ds_writes
+            if (fits) {
+                const int total = bw * bh * pass_vecs;
+                const float *src = m.data + (int64_t)v * m.sv + (int64_t)c0 * 4;
+                // two batches of 7 float4 per lane (7 KiB in flight per wave) keep the register count at 2 waves/SIMD
+#pragma unroll 1
+                for (int k0 = 0; k0 < kRegsW; k0 += 7) {
+                    if (k0 * 64 >= total) break;
+                    VT tmp[7];
+#pragma unroll
+                    for (int k = 0; k < 7; ++k) {
+                        const int e = lane + (k0 + k) * 64;
+                        if (e < total) {
+                            const int texel = e / pass_vecs, lv = e - texel * pass_vecs;
+                            const int wy = texel / bw, wx = texel - wy * bw;
+                            tmp[k] = load_vec<VT>(src + (int64_t)(ymin + wy) * m.sy + (int64_t)(xmin + wx) * m.sx + lv * 4);
+                        }
+                    }
+#pragma unroll
+                    for (int k = 0; k < 7; ++k) {
+                        const int e = lane + (k0 + k) * 64;
+                        if (e < total) store_vec<VT>(wbuf + (int64_t)e * 4, tmp[k]);
+                    }
+                }
+            }
+            __builtin_amdgcn_wave_barrier();            // ds_writes above stay ahead of the ds_reads below
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int p = p_base + 2 * j + half;
                 if (p < tile_n) {
                     const ViewRec r = rec[p * V + v];
                     const bool strict = (flag_s[p] != 0u) || want_inter;
                     if (strict || r.valid != 0.0f) {
                         const int64_t i = idx_base + idx_s[p];
                         if (fits)
-                            staged_accumulate<U, true>(m, P, r, v, i, c0, lpp, g, cvec, buf, xmin, ymin, bw, pass_vecs, acc[j]);
+                            staged_accumulate<U, true>(m, P, r, v, i, c0, 32, g, cvec, wbuf, xmin, ymin, bw, pass_vecs, acc[j]);
                         else
-                            staged_accumulate<U, false>(m, P, r, v, i, c0, lpp, g, cvec, nullptr, 0, 0, 0, pass_vecs, acc[j]);
+                            staged_accumulate<U, false>(m, P, r, v, i, c0, 32, g, cvec, nullptr, 0, 0, 0, pass_vecs, acc[j]);
                     }
                 }
             }
         }
 #pragma unroll
-        for (int j = 0; j < kStagedPPG; ++j) {
-            const int p = grp + j * ngrp;
+        for (int j = 0; j < 4; ++j) {
+            const int p = p_base + 2 * j + half;
             if (p < tile_n) {
                 const int64_t i = idx_base + idx_s[p];
                 const float cnt = cnt_s[p];
                 const float denom = cnt + 1e-6f;
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
-                    const int cv = c0 + u * lpp + g;
+                    const int cv = c0 + u * 32 + g;
                     if (cv < cvec) {
                         VT o = (cnt == 0.0f) ? (VT)0.0f : acc[j][u] / denom;
                         store_vec<VT>(m.out + i * m.C + (int64_t)cv * 4, o);
@@ -379,7 +378,6 @@ __device__ __forceinline__ void gather_map_staged(const MapDesc &m, const EvalPa
                 }
             }
         }
-        __syncthreads();            // buffers are reused by the next pass
     }
 }
 
@@ -440,7 +438,6 @@ __device__ __forceinline__ void fused_eval_body(const EvalParams &P)
     uint32_t *flag_s = reinterpret_cast<uint32_t *>(cnt_s + TP);             // [TP]
     uint32_t *idx_s = flag_s + TP;                                           // [TP] global point index
     float *krt = reinterpret_cast<float *>(idx_s + TP);                      // [V*12]
-    int *bbox_s = reinterpret_cast<int *>(krt + V * 12);                      // [V*4]   (staged maps only)
     float *stage_s = reinterpret_cast<float *>(smem + P.stage_offset);       // 2 x stage_floats, 16-B aligned
     CornerRec *crec_s = reinterpret_cast<CornerRec *>(smem + P.crec_offset); // [n_pre][TP*V] (wide maps)
 
@@ -527,11 +524,12 @@ __device__ __forceinline__ void fused_eval_body(const EvalParams &P)
     // ---------------- phase B: per map, 2^k lanes per point ----------------
     for (int s = 0; s < P.n_maps; ++s) {
         const MapDesc &m = P.maps[s];
-        if (STAGED && m.staged) {
+        if (STAGED && m.staged == 2) {
+            const int region = (2 * P.stage_floats) / (kBlock / 64);
             switch (m.unroll) {
-            case 1: gather_map_staged<1>(m, P, rec, cnt_s, flag_s, idx_s, idx_base, tile_n, bbox_s, stage_s, P.stage_floats); break;
-            case 2: gather_map_staged<2>(m, P, rec, cnt_s, flag_s, idx_s, idx_base, tile_n, bbox_s, stage_s, P.stage_floats); break;
-            default: gather_map_staged<3>(m, P, rec, cnt_s, flag_s, idx_s, idx_base, tile_n, bbox_s, stage_s, P.stage_floats); break;
+            case 1: gather_map_wave_staged<1>(m, P, rec, cnt_s, flag_s, idx_s, idx_base, tile_n, stage_s, region); break;
+            case 2: gather_map_wave_staged<2>(m, P, rec, cnt_s, flag_s, idx_s, idx_base, tile_n, stage_s, region); break;
+            default: gather_map_wave_staged<3>(m, P, rec, cnt_s, flag_s, idx_s, idx_base, tile_n, stage_s, region); break;
             }
             continue;
         }

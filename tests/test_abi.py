@@ -127,6 +127,6 @@ def test_launch_plan_host_logic():
     assert p.tile_points * 64 * 24 <= 64 * 1024 and p.lds_bytes <= 64 * 1024
     # opt-in staging only on the Morton walk
     p = _plan(4, 480, 640, 985600, [(48, 64, 384)], flags=_lib.TUNE_STAGING)
-    assert (p.staged[0], p.reorder, p.tile_points, p.vectors_per_lane[0]) == (1, 1, 32, 3)
+    assert (p.staged[0], p.reorder, p.tile_points, p.vectors_per_lane[0]) == (2, 1, 32, 3)
     p = _plan(4, 480, 640, 985600, [(48, 64, 384)], flags=_lib.TUNE_STAGING | _lib.TUNE_NO_REORDER)
     assert (p.staged[0], p.reorder) == (0, 0)

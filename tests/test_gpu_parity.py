@@ -502,7 +502,7 @@ def test_eval_dist_backward_vs_torch_port(dev):
     (384, (12, 16), 6000, 1.0, False),      # compact tiles: windows fit, one pass
     (384, (12, 16), 6000, 1.0, True),       # + '<k>_inter' (samples every view)
     (1024, (9, 12), 3000, 1.0, False),      # 4 passes of 256 channels
-    (64, (24, 32), 4000, 1.0, False),       # 16 lanes per point
+    (128, (24, 32), 4000, 1.0, False),      # one vector per lane
     (384, (12, 16), 300, 1.0, False),       # sparse cloud: windows overflow -> per-view direct fallback
     (100, (6, 8), 2500, 3.0, False),        # odd vector count, many points outside every image
 ])
