@@ -203,9 +203,13 @@ int eval_common(const d3f_views *views, const float *pts, int64_t n, const d3f_c
         bool thin = false;
         for (int s = 0; s < n_maps; ++s) thin |= P.maps[s].lpp_log2 < 4;
         P.tile_pts = thin ? 16 : 8; P.lds_pad = 0; xcd_remap = true;
-    } else if (map_bytes > (512LL << 20) && P.tile_pts > 64) {
+    } else if (map_bytes > (512LL << 20) && P.tile_pts > 64 && n >= 65536) {
         P.tile_pts = 64; P.lds_pad = 64 * 1024;
     }
+    // small batches (keypoints, tracking): a 128-point tile is 16-32 serial rounds per lane group, so a few hundred
+    // points would run on 3 CUs for ~200 us; spread them over >= 1024 workgroups instead (N = 300: 170 -> ~25 us)
+    if (!reorder && n_maps > 0)
+        while (P.tile_pts > 8 && n / P.tile_pts < 1024) P.tile_pts >>= 1;
     if (tl >= 3 && tl <= 8) { P.tile_pts = (1 << tl) <= max_tile ? (1 << tl) : max_tile; P.lds_pad = 0; }
     if ((flags >> 16) & 0xFF) P.lds_pad = ((int)((flags >> 16) & 0xFF) == 0xFF) ? 0 : (int)((flags >> 16) & 0xFF) * 1024;
     if (flags & D3F_TUNE_XCD_REMAP) xcd_remap = !xcd_remap;
@@ -383,6 +387,7 @@ static int backward_common(const d3f_views *views, const float *pts, int64_t n, 
     }
     int t = 128;                       // LDS: 44 B per (point, view)
     while (t > 16 && (long)t * views->V * 44 > 60 * 1024) t >>= 1;
+    while (t > 8 && n / t < 1024) t >>= 1;     // small batches: spread over many workgroups (latency, not throughput)
     P.tile_pts = t;
     if ((n + t - 1) / t > 0x7fffffffLL) return fail(D3F_ERR_BAD_SHAPE, "n=%lld needs more than 2^31 workgroups", (long long)n);
     hipError_t e = d3f::launch_fused_backward(P, mode, static_cast<hipStream_t>(stream));

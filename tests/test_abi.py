@@ -119,7 +119,8 @@ def test_launch_plan_host_logic():
     assert (p.lanes_per_point[0], abs(p.vectors_per_lane[0]), p.reorder) == (64, 4, 1)
     # small batches are never reordered; mask (C=8) -> 2 lanes per point; colour (C=3) -> scalar lanes
     p = _plan(4, 480, 640, 60000, [(48, 64, 384), (480, 640, 8), (480, 640, 3)])
-    assert p.reorder == 0
+    assert p.reorder == 0 and p.tile_points == 32            # < 1024 workgroups of 128 -> smaller tiles
+    assert _plan(4, 480, 640, 300, [(48, 64, 384)]).tile_points == 8
     assert (p.vector_floats[1], p.lanes_per_point[1], p.vectors_per_lane[1]) == (4, 2, 1)
     assert (p.vector_floats[2], p.lanes_per_point[2], p.vectors_per_lane[2]) == (1, 1, 3)
     # many views shrink the tile so that the per-(point,view) records fit LDS
