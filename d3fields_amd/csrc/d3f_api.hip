@@ -336,19 +336,27 @@ int d3f_eval_grid(const d3f_views *views, const d3f_grid *grid, const d3f_channe
                        out_fused, nullptr, nullptr, 0, stream, 0, nullptr, grid);
 }
 
+int64_t d3f_grid_shell_workspace_bytes(const d3f_grid *grid)
+{
+    if (!grid || grid->nx <= 0 || grid->ny <= 0 || grid->nz <= 0) return 0;
+    return d3f::grid_shell_workspace_bytes((int64_t)grid->nx * grid->ny * grid->nz);
+}
+
 int d3f_grid_shell(const d3f_views *views, const d3f_grid *grid, float mu, float dist_thr, int64_t capacity, int64_t *idx_out,
-                   int64_t *count_out, void *stream)
+                   int64_t *count_out, void *workspace, int64_t workspace_bytes, void *stream)
 {
     int rc = check_views(views);
     if (rc != D3F_OK) return rc;
     rc = check_grid(grid);
     if (rc != D3F_OK) return rc;
     if (!count_out || capacity < 0 || (capacity > 0 && !idx_out)) return fail(D3F_ERR_INVALID_ARG, "grid_shell: idx_out/count_out/capacity");
+    if ((int64_t)grid->nx * grid->ny * grid->nz > 0 && (!workspace || workspace_bytes < d3f_grid_shell_workspace_bytes(grid)))
+        return fail(D3F_ERR_WORKSPACE, "grid_shell: needs %lld workspace bytes", (long long)d3f_grid_shell_workspace_bytes(grid));
     if (!(mu > 0.0f)) return fail(D3F_ERR_INVALID_ARG, "mu must be > 0");
     if (((int64_t)grid->nx * grid->ny * grid->nz + d3f::kBlock - 1) / d3f::kBlock > 0x7fffffffLL) return fail(D3F_ERR_BAD_SHAPE, "grid too large for one launch");
     hipError_t e = d3f::launch_grid_shell(views->depth, views->K, views->pose, views->V, views->H, views->W, grid->x, grid->y,
                                           grid->z, grid->nx, grid->ny, grid->nz, mu, dist_thr, capacity, idx_out,
-                                          reinterpret_cast<unsigned long long *>(count_out), static_cast<hipStream_t>(stream));
+                                          reinterpret_cast<unsigned long long *>(count_out), workspace, static_cast<hipStream_t>(stream));
     return e == hipSuccess ? D3F_OK : hip_fail(e, "grid_shell launch");
 }
 

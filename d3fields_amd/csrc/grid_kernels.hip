@@ -5,24 +5,32 @@
 // numpy farthest-point sampling (utils/my_utils.py:478-497).  Here
 //   grid_shell_kernel   generates the grid points from the axis arrays (nothing of size N is read),
 //                       evaluates dist/valid with the forward's arithmetic and COMPACTS the indices of
-//                       the thin shell |dist| < thr & valid (about 1 % of the grid), so that the wide
-//                       mask query runs on the survivors only and no [N,NI] tensor is ever written;
+//                       the thin shell |dist| < thr & valid (about 3 % of the grid) IN ASCENDING ORDER (ballot
+//                       words + workgroup counts, exclusive scan, ordered write), so that the wide mask query
+//                       runs on the survivors only and no [N,NI] tensor is ever written;
 //   fps_kernel          farthest point sampling of the survivors, one workgroup, same float32
 //                       arithmetic and first-maximum tie rule as numpy (bit-identical selection).
+#include <cstring>
+#include <string.h>
+
+#include <rocprim/rocprim.hpp>
+
 #include "d3f_internal.h"
 #include "d3f_device.h"
 
 namespace d3f {
 
-__global__ __launch_bounds__(kBlock) void grid_shell_kernel(const float *__restrict__ depth, const float *__restrict__ K,
-                                                           const float *__restrict__ pose, int V, int H, int W,
-                                                           const float *__restrict__ gx, const float *__restrict__ gy,
-                                                           const float *__restrict__ gz, int ny, int nz, int64_t n, float mu,
-                                                           float dist_thr, int64_t capacity, int64_t *__restrict__ idx_out,
-                                                           unsigned long long *__restrict__ count)
+// Pass 1: survivor flag of every grid point as one ballot word per wave + survivor count per workgroup.
+__global__ __launch_bounds__(kBlock) void grid_shell_flag_kernel(const float *__restrict__ depth, const float *__restrict__ K,
+                                                                const float *__restrict__ pose, int V, int H, int W,
+                                                                const float *__restrict__ gx, const float *__restrict__ gy,
+                                                                const float *__restrict__ gz, int ny, int nz, int64_t n, float mu,
+                                                                float dist_thr, unsigned long long *__restrict__ ballots,
+                                                                uint32_t *__restrict__ block_counts)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     float *krt = reinterpret_cast<float *>(smem);
+    __shared__ int wave_cnt[kBlock / 64];
     compute_krt(K, pose, V, krt, kBlock);
     __syncthreads();
     const float Wm1 = (float)(W - 1), Hm1 = (float)(H - 1);
@@ -41,27 +49,70 @@ __global__ __launch_bounds__(kBlock) void grid_shell_kernel(const float *__restr
         // fusion.py:1430, 1444: |dist| < dist_threshold and valid_mask (an all-invalid point has dist = 1e3)
         keep = (cnt != 0.0f) && (fabsf(dsum / (cnt + 1e-6f)) < dist_thr);
     }
-    // wave-level compaction: one atomic per wave, survivors of a wave stay in index order
     const unsigned long long ballot = __ballot(keep);
-    const int lane = threadIdx.x & 63;
-    unsigned long long base = 0;
-    if (lane == 0 && ballot) base = atomicAdd(count, (unsigned long long)__popcll(ballot));
-    base = __shfl(base, 0, 64);
-    if (keep) {
-        const unsigned long long slot = base + (unsigned long long)__popcll(ballot & ((1ull << lane) - 1ull));
-        if ((int64_t)slot < capacity) idx_out[slot] = i;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) {
+        ballots[(int64_t)blockIdx.x * (kBlock / 64) + wave] = ballot;
+        wave_cnt[wave] = __popcll(ballot);
     }
+    __syncthreads();
+    if (threadIdx.x == 0) block_counts[blockIdx.x] = wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
+}
+
+// Pass 2 (after an exclusive scan of the workgroup counts): survivors are written in ascending flat index --
+// the order of the reference's boolean-mask indexing -- so no sort is needed afterwards.
+__global__ __launch_bounds__(kBlock) void grid_shell_write_kernel(const unsigned long long *__restrict__ ballots,
+                                                                 const uint32_t *__restrict__ block_offsets, int64_t n,
+                                                                 int64_t capacity, int64_t *__restrict__ idx_out)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const unsigned long long *bw = ballots + (int64_t)blockIdx.x * (kBlock / 64);
+    int before = 0;
+    for (int w = 0; w < wave; ++w) before += __popcll(bw[w]);
+    const unsigned long long mine = bw[wave];
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i < n && ((mine >> lane) & 1ull)) {
+        const int64_t slot = (int64_t)block_offsets[blockIdx.x] + before + __popcll(mine & ((1ull << lane) - 1ull));
+        if (slot < capacity) idx_out[slot] = i;
+    }
+}
+
+__global__ void grid_shell_total_kernel(const uint32_t *__restrict__ block_counts, const uint32_t *__restrict__ block_offsets,
+                                        int64_t nb, unsigned long long *__restrict__ count)
+{
+    *count = (unsigned long long)block_offsets[nb - 1] + block_counts[nb - 1];
+}
+
+int64_t grid_shell_workspace_bytes(int64_t n)
+{
+    const int64_t nb = (n + kBlock - 1) / kBlock;
+    return nb * (kBlock / 64) * 8 + 2 * ((nb * 4 + 255) / 256 * 256) + (4 << 20);   // ballots + counts + offsets + scan scratch
 }
 
 hipError_t launch_grid_shell(const float *depth, const float *K, const float *pose, int V, int H, int W, const float *gx,
                              const float *gy, const float *gz, int nx, int ny, int nz, float mu, float dist_thr,
-                             int64_t capacity, int64_t *idx_out, unsigned long long *count, hipStream_t s)
+                             int64_t capacity, int64_t *idx_out, unsigned long long *count, void *workspace, hipStream_t s)
 {
     const int64_t n = (int64_t)nx * ny * nz;
     hipError_t e = hipMemsetAsync(count, 0, sizeof(unsigned long long), s);
     if (e != hipSuccess || n == 0) return e;
-    hipLaunchKernelGGL(grid_shell_kernel, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), (size_t)V * 48, s, depth,
-                       K, pose, V, H, W, gx, gy, gz, ny, nz, n, mu, dist_thr, capacity, idx_out, count);
+    const int64_t nb = (n + kBlock - 1) / kBlock;
+    unsigned char *base = static_cast<unsigned char *>(workspace);
+    unsigned long long *ballots = reinterpret_cast<unsigned long long *>(base);
+    const size_t seg = (size_t)((nb * 4 + 255) / 256 * 256);
+    uint32_t *counts = reinterpret_cast<uint32_t *>(base + nb * (kBlock / 64) * 8);
+    uint32_t *offsets = reinterpret_cast<uint32_t *>(base + nb * (kBlock / 64) * 8 + seg);
+    void *scratch = base + nb * (kBlock / 64) * 8 + 2 * seg;
+    hipLaunchKernelGGL(grid_shell_flag_kernel, dim3((unsigned)nb), dim3(kBlock), (size_t)V * 48, s, depth, K, pose, V, H, W, gx, gy,
+                       gz, ny, nz, n, mu, dist_thr, ballots, counts);
+    size_t need = 0;
+    e = rocprim::exclusive_scan(nullptr, need, counts, offsets, 0u, (size_t)nb, rocprim::plus<uint32_t>(), s);
+    if (e != hipSuccess) return e;
+    if (need > (size_t)(4 << 20)) return hipErrorOutOfMemory;
+    e = rocprim::exclusive_scan(scratch, need, counts, offsets, 0u, (size_t)nb, rocprim::plus<uint32_t>(), s);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(grid_shell_write_kernel, dim3((unsigned)nb), dim3(kBlock), 0, s, ballots, offsets, n, capacity, idx_out);
+    hipLaunchKernelGGL(grid_shell_total_kernel, dim3(1), dim3(1), 0, s, counts, offsets, nb, count);
     return hipGetLastError();
 }
 

@@ -420,16 +420,19 @@ class Fusion:
         views, keep, V = self._views(dev)
         count = torch.zeros(1, dtype=torch.int64, device=dev)
         capacity = max(1 << 16, n // 16)
+        ws_bytes = self._lib.d3f_grid_shell_workspace_bytes(ctypes.byref(grid))
+        ws = torch.empty(max(ws_bytes, 16), dtype=torch.uint8, device=dev)
         while True:
             idx = torch.empty(capacity, dtype=torch.int64, device=dev)
             with torch.cuda.device(dev):
                 _lib.check(self._lib.d3f_grid_shell(ctypes.byref(views), ctypes.byref(grid), self.mu, float(dist_threshold),
-                                                    capacity, _lib.ptr(idx), _lib.ptr(count), _lib.current_stream_handle(dev)))
+                                                    capacity, _lib.ptr(idx), _lib.ptr(count), _lib.ptr(ws), ws_bytes,
+                                                    _lib.current_stream_handle(dev)))
             found = int(count.item())
             if found <= capacity:
                 break
             capacity = found                      # rare: the shell is thicker than 1/16 of the grid -> one exact re-run
-        idx = torch.sort(idx[:found]).values      # the reference's boolean-mask order is ascending flat index
+        idx = idx[:found]                         # already ascending: the reference's boolean-mask order
         iz = idx % grid.nz
         ixy = idx // grid.nz
         pts = torch.stack((axes[0][ixy // grid.ny], axes[1][ixy % grid.ny], axes[2][iz]), dim=1)

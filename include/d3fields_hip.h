@@ -151,11 +151,12 @@ int d3f_eval_grid(const d3f_views *views, const d3f_grid *grid, const d3f_channe
                   void *stream);
 
 /* Pre-filter of select_features_* (fusion.py:1430,1444): flat indices of the grid points with
- * valid_mask && |dist| < dist_thr, compacted into idx_out[0..min(count,capacity)) (unordered across waves;
- * sort them to reproduce the reference's ascending order).  count_out: ONE device int64, the number of
- * survivors (may exceed capacity: then only `capacity` indices were stored). */
+ * valid_mask && |dist| < dist_thr, compacted into idx_out[0..min(count,capacity)) in ASCENDING order (the order
+ * of the reference's boolean-mask indexing).  count_out: ONE device int64, the number of survivors (may exceed
+ * capacity: then only the first `capacity` indices were stored).  workspace: d3f_grid_shell_workspace_bytes. */
+int64_t d3f_grid_shell_workspace_bytes(const d3f_grid *grid);
 int d3f_grid_shell(const d3f_views *views, const d3f_grid *grid, float mu, float dist_thr, int64_t capacity,
-                   int64_t *idx_out, int64_t *count_out, void *stream);
+                   int64_t *idx_out, int64_t *count_out, void *workspace, int64_t workspace_bytes, void *stream);
 
 /* fps_np (utils/my_utils.py:478-497): k farthest points of pts[n,3] starting from init_idx, float32
  * Euclidean distances, first maximum wins -> out_idx[k] (int64, device), out_maxdist (device float, may

@@ -104,3 +104,14 @@ def test_shard_bounds_cover_everything_once():
             assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
             sizes = [b - a for a, b in spans]
             assert max(sizes) - min(sizes) <= 1
+
+
+def test_bench_roofline_numerator_matches_survey():
+    """bench.py's algorithmic bytes are SURVEY.md §8d's: N*(12+4+1+4*sum C) + maps read once + 84*V."""
+    import bench
+    b, per = bench.algorithmic_bytes(bench.WORKLOADS["c2_dense"], 985600)
+    assert per == 1553 and b == 985600 * 1553 + 4 * (4 * 480 * 640 + 4 * 480 * 640 * 384) + 84 * 4
+    b, per = bench.algorithmic_bytes(bench.WORKLOADS["c3_patch"], 1925000)
+    assert per == 1585 and b == 1925000 * 1585 + 4 * (4 * 480 * 640 + 4 * 48 * 64 * 384 + 4 * 480 * 640 * 8) + 336
+    assert bench.algorithmic_bytes(bench.WORKLOADS["c4_patch"], 1000000)[1] == 4113
+    assert bench.measured_traffic("c2_dense")[0] > 0 and bench.measured_traffic("nope") == (None, None)
