@@ -221,6 +221,10 @@ int eval_common(const d3f_views *views, const float *pts, int64_t n, const d3f_c
         P.tile_pts = 32; P.lds_pad = 0;
         P.stage_floats = d3f::kStageFloats;     // 4 wave-private regions of 13.5 KiB (9 texels of 384 channels)
     }
+    // Morton walk: all eight XCDs stay inside one macro-brick of ~32 k points at a time (its texel footprint stays in
+    // the 256 MiB Infinity Cache), each taking a contiguous eighth of it (C2 dense 1.97 -> 1.74 ms, C4 patch 4.75 -> 4.17)
+    P.xcd_chunk = reorder ? (int)((32768 / P.tile_pts + 7) / 8 * 8) : 0;
+    if ((flags >> 29) & 0x7) P.xcd_chunk = 1024 << (((flags >> 29) & 0x7) - 1);   // tuning: 1024 .. 65536 tiles
     P.stage_offset = d3f::fused_lds_base(P.tile_pts, views->V);
     // wide maps (>= 16 lanes per point): corner set-up once per (point, view) in phase A, 32 B of LDS each
     P.n_pre = 0;

@@ -41,6 +41,7 @@ struct EvalParams {
     int32_t stage_floats;  // floats per stage buffer, 0 = no staged map
     int32_t crec_offset;   // byte offset of the precomputed corner records, 16-B aligned
     int32_t n_pre;         // number of maps with precomputed corner records
+    int32_t xcd_chunk;     // tiles per XCD-mapping chunk (multiple of 8), 0 = the whole launch
     uint32_t flags;
     float mu;
     MapDesc maps[D3F_MAX_MAPS];

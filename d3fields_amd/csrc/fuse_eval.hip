@@ -445,7 +445,15 @@ __device__ __forceinline__ void fused_eval_body(const EvalParams &P)
     __syncthreads();
 
     const int64_t ntiles = (P.n + TP - 1) / TP;
-    const int64_t tile = (P.flags & kFlagXcdRemap) ? xcd_tile(blockIdx.x, ntiles) : (int64_t)blockIdx.x;
+    int64_t tile = (int64_t)blockIdx.x;
+    if (P.flags & kFlagXcdRemap) {
+        // chunked XCD mapping: the walk is cut into chunks of `xcd_chunk` tiles (0 = one chunk); inside a chunk
+        // XCD k takes the k-th contiguous eighth.  Small chunks keep all eight XCDs inside one region of space.
+        const int64_t ch = P.xcd_chunk > 0 ? (int64_t)P.xcd_chunk : ntiles;
+        const int64_t c0 = ((int64_t)blockIdx.x / ch) * ch;
+        const int64_t len = min(ch, ntiles - c0);
+        tile = c0 + xcd_tile((int64_t)blockIdx.x - c0, len);
+    }
     const int64_t tile_base = tile * TP;
     const int tile_n = (int)min((int64_t)TP, P.n - tile_base);
     const int64_t idx_base = P.order ? 0 : tile_base;   // idx_s holds 32-bit offsets from here

@@ -56,7 +56,7 @@ extern "C" {
  *   bit  15     stage texel windows of low-resolution wide maps through LDS (experimental:
  *               bit-identical, measured slower than the direct gather on MI355X, off by default)
  *   bits 24..25 Morton cell: 16 mm >> k (k = 0..2);  bit 26 / 27 force batched / load-use corner loads;
- *               bit 28 do not precompute corner set-ups in phase A
+ *               bit 28 do not precompute corner set-ups in phase A;  bits 29..31 XCD-mapping chunk = 1024 << (k-1) tiles
  *   bits 16..23 extra dynamic LDS per workgroup in KiB (throttles workgroups per CU); 255 = none      */
 #define D3F_TUNE_TILE_LOG2(k) (((uint32_t)(k) & 0xFu) << 8)
 #define D3F_TUNE_XCD_REMAP (1u << 12)

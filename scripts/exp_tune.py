@@ -22,10 +22,6 @@ for wl in sys.argv[1:]:
         return ts[len(ts) // 2]
 
     print(wl, "auto: %.3f" % t_ms(0), flush=True)
-    for name, bit in (("batch", 1 << 26), ("load-use", 1 << 27)):
-        row = []
-        for tl, pad in ((0, 0), (3, 0), (4, 0), (3, 40), (4, 40), (5, 40)):
-            row.append("t%s p%d: %.3f" % ((1 << tl) if tl else "auto", pad, t_ms((tl << 8) | (pad << 16) | bit)))
-        print("  %-8s | %s" % (name, " | ".join(row)), flush=True)
+    print("  xcd chunk (tiles): " + " | ".join("%d: %.3f" % (1024 << (k - 1), t_ms(k << 29)) for k in range(1, 8)), flush=True)
     del f, pts
     torch.cuda.empty_cache()
