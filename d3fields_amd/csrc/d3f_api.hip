@@ -177,7 +177,7 @@ int eval_common(const d3f_views *views, const float *pts, int64_t n, const d3f_c
         for (int s = 0; s < n_maps; ++s) stage_any |= staging_candidate(P.maps[s], views->H, views->W);
     const bool reorder = may_reorder && ((flags & D3F_TUNE_FORCE_REORDER) || (n >= 65536 && (map_bytes > (64LL << 20) || stage_any)));
     if (reorder && !plan_only) {
-        hipError_t eo = d3f::build_point_order(pts, n, workspace, workspace_bytes, &P.order, hs, (int)((flags >> 24) & 0x3) % 3);
+        hipError_t eo = d3f::build_point_order(pts, n, workspace, workspace_bytes, &P.order, hs, (int)((flags >> 24) & 0x3));
         if (eo != hipSuccess) return hip_fail(eo, "point ordering");
     }
     // Launch geometry (measured on MI355X):
@@ -210,7 +210,7 @@ int eval_common(const d3f_views *views, const float *pts, int64_t n, const d3f_c
     // points would run on 3 CUs for ~200 us; spread them over >= 1024 workgroups instead (N = 300: 170 -> ~25 us)
     if (!reorder && n_maps > 0)
         while (P.tile_pts > 8 && n / P.tile_pts < 1024) P.tile_pts >>= 1;
-    if (tl >= 3 && tl <= 8) { P.tile_pts = (1 << tl) <= max_tile ? (1 << tl) : max_tile; P.lds_pad = 0; }
+    if (tl >= 2 && tl <= 8) { P.tile_pts = (1 << tl) <= max_tile ? (1 << tl) : max_tile; P.lds_pad = 0; }
     if ((flags >> 16) & 0xFF) P.lds_pad = ((int)((flags >> 16) & 0xFF) == 0xFF) ? 0 : (int)((flags >> 16) & 0xFF) * 1024;
     if (flags & D3F_TUNE_XCD_REMAP) xcd_remap = !xcd_remap;
     P.flags = (flags & ~D3F_TUNE_XCD_REMAP) | (xcd_remap ? D3F_TUNE_XCD_REMAP : 0u);

@@ -22,6 +22,7 @@ for wl in sys.argv[1:]:
         return ts[len(ts) // 2]
 
     print(wl, "auto: %.3f" % t_ms(0), flush=True)
-    print("  xcd chunk (tiles): " + " | ".join("%d: %.3f" % (1024 << (k - 1), t_ms(k << 29)) for k in range(1, 8)), flush=True)
+    for tl in (2, 3, 4):
+        print("  tile %d | " % (1 << tl) + " | ".join("chunk %d: %.3f" % (1024 << (k - 1), t_ms((tl << 8) | (k << 29))) for k in (2, 3, 4, 5)), flush=True)
     del f, pts
     torch.cuda.empty_cache()
