@@ -680,3 +680,28 @@ def test_pcd_iou_matches_reference(dev):
     o = pcd_utils.pcd_iou(a, b, 0.05)
     md, am = np_pcd.nearest(a, b)
     assert np.array_equal(o[5], am) and np.array_equal(o[3], np.where(md < 0.05)[0])
+
+
+def test_config4_shard_properties(dev):
+    """BASELINE config 4, one GPU's shard: 8 views x 720x1280, 72x128x1024 features, 1 000 000 points
+    (fused_eval_wide_kernel on the Morton walk): size-independent properties + an oracle sample."""
+    from d3fields_amd import synth, sharding
+    V, H, W, C, N = 8, 720, 1280, 1024, 1000000
+    sc = synth.make_scene(V, H, W, "smooth")
+    feats = synth.random_map(V, 72, 128, C, seed=1, device=dev)
+    f = make_fusion(dev, sc["depth"], sc["K"], sc["pose"], {"dino_feats": feats}, H, W)
+    pts = synth.random_cloud(N, seed=3).to(dev)
+    with torch.no_grad():
+        out = f.batch_eval(pts, return_names=["dino_feats"])
+        # the shard of rank 3 of 8 evaluated alone == the same rows of the full batch (what the all-gather reassembles)
+        lo, hi = sharding.shard_bounds(N, 3, 8)
+        part = f.batch_eval(pts[lo:hi], return_names=["dino_feats"])
+        for k in ("dist", "valid_mask", "dino_feats"):
+            assert torch.equal(part[k], out[k][lo:hi]), k
+        inv = ~out["valid_mask"]
+        assert torch.equal(out["dist"] == 1e3, inv) and (out["dino_feats"][inv] == 0).all()
+    pick = torch.randperm(N, generator=torch.Generator().manual_seed(5))[:1500]
+    ref = oracle_eval(sc, pts[pick.to(dev)].cpu(), [feats.cpu()])
+    assert np.array_equal(cpu(out["valid_mask"][pick.to(dev)]), ref["valid_mask"])
+    assert rel_err(cpu(out["dist"][pick.to(dev)]), ref["dist"]) <= TOL          # V = 8: see check_dist
+    assert rel_err(cpu(out["dino_feats"][pick.to(dev)]), ref["sets"][0]) <= TOL
