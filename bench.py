@@ -64,7 +64,7 @@ def measured_traffic(workload):
         return None, None
 
 
-def build_workload(name, dev, rank, world):
+def build_workload(name, dev, rank, world, points="grid"):
     from d3fields_amd import Fusion, create_init_grid, synth
     w = WORKLOADS[name]
     V, H, W = w["V"], w["H"], w["W"]
@@ -77,13 +77,13 @@ def build_workload(name, dev, rank, world):
         f.curr_obs_torch["mask"] = synth.random_onehot_mask(V, H, W, w["NI"], seed=2, device=dev)
         names.append("mask")
     f.H, f.W = H, W
-    if w["step"] is not None:
+    if w["step"] is not None and points == "grid":
         # weak scaling: the job's grid is `world` times finer along x (step/world); rank r owns the
         # x-planes congruent to r, i.e. the same box shifted by r*step/world -> N points per rank
         pts, _ = create_init_grid(synth.WORK_BOX, w["step"])
         if world > 1:
             pts[:, 0] += rank * w["step"] / world
-    else:
+    else:       # uniformly random cloud of the same N in the same box: no locality in the caller's order
         pts = synth.random_cloud(w["N"], seed=3 + rank)
     return f, pts.to(dev), names, w, sc
 
@@ -159,10 +159,26 @@ def cpu_baseline(sc, w, names, maps_cpu, pts_cpu, budget_pts, threads=0):
             torch_port.batched_field_query(obs, sample, names, w["H"], w["W"])
             times.append(time.perf_counter() - t0)
     dt = sorted(times)[len(times) // 2]
-    return {"value": n / dt, "unit": "points/s", "cores": cores, "kind": "port",
-            "sample": "%d points of the same grid and maps through the torch-ops port of batch_eval (60000-pt chunks, "
-                      "%d threads; 256 threads measured 27x slower), median of %d runs, %.1f s of CPU time in total"
-                      % (n, cores, len(times), sum(times))}
+    res = {"value": n / dt, "unit": "points/s", "cores": cores, "kind": "port",
+           "sample": "%d points of the same workload and maps through the torch-ops port of batch_eval (60000-pt chunks, "
+                     "%d threads; 256 threads measured 27x slower), median of %d runs, %.1f s of CPU time in total"
+                     % (n, cores, len(times), sum(times))}
+    try:        # second CPU reference point: the scalar C restatement, OpenMP over points
+        from oracle import c_oracle
+        np_maps = [maps_cpu[k].numpy() for k in names]
+        args = (sc["depth"].numpy(), sc["K"].numpy(), sc["pose"].numpy(), sample.numpy(), np_maps)
+        c_oracle.eval_field(*args[:3], args[3][:20000], np_maps)
+        ct = []
+        while len(ct) < 3 and (not ct or sum(ct) < 8.0):
+            t0 = time.perf_counter()
+            c_oracle.eval_field(*args)
+            ct.append(time.perf_counter() - t0)
+        res["c_port"] = {"value": n / sorted(ct)[len(ct) // 2], "unit": "points/s", "cores": c_oracle.threads(),
+                         "kind": "port", "sample": "same %d points through oracle/d3f_oracle.c (scalar C, OpenMP over "
+                         "points), median of %d runs" % (n, len(ct))}
+    except Exception as e:                       # the headline baseline above stands on its own
+        res["c_port"] = {"error": repr(e)}
+    return res
 
 
 def main():
@@ -173,6 +189,9 @@ def main():
     ap.add_argument("--workload", default="c2_dense", choices=sorted(WORKLOADS))
     ap.add_argument("--gather", default="dist", choices=["none", "dist", "full"],
                     help="N>1: what the RCCL all-gather reassembles inside the timed step")
+    ap.add_argument("--points", default="grid", choices=["grid", "random"],
+                    help="grid: create_init_grid of the workload (default); random: uniform cloud of the same N in the "
+                         "same box (exposes the dependence on the caller's point order)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--tuning", type=lambda x: int(x, 0), default=0, help="D3F_TUNE_* bits (experiments)")
     ap.add_argument("--cpu-sample", type=int, default=1000000)
@@ -202,7 +221,7 @@ def main():
         else:
             dist.init_process_group(args.backend)
 
-    f, pts, names, w, sc = build_workload(args.workload, dev, rank, world)
+    f, pts, names, w, sc = build_workload(args.workload, dev, rank, world, args.points)
     f.tuning_flags = args.tuning
     n = pts.shape[0]
     from d3fields_amd import sharding
@@ -255,6 +274,7 @@ def main():
                                "return_names=%s" % (args.workload, w["V"], w["H"], w["W"], w["fhw"][0], w["fhw"][1], w["C"],
                                                     (" + %dx%dx%d one-hot mask" % (w["H"], w["W"], w["NI"])) if w["NI"] else "",
                                                     n, names),
+                   "points": ("grid" if (w["step"] is not None and args.points == "grid") else "random cloud"),
                    "points_per_gpu": n, "views": w["V"], "feature_dim": w["C"], "feature_map": list(w["fhw"]),
                    "parallelism": "points sharded x%d, maps replicated" % world,
                    "gather": (args.gather if dist_on else "n/a")},

@@ -15,6 +15,7 @@ ABI_VERSION = 1
 OK = 0
 ERR_INVALID_ARG, ERR_BAD_SHAPE, ERR_BAD_DTYPE, ERR_BAD_LAYOUT, ERR_HIP, ERR_WORKSPACE = -1, -2, -3, -4, -5, -6
 FLAG_FINITE_MAPS = 1
+FLAG_UNORDERED_POINTS = 2
 TUNE_XCD_REMAP, TUNE_NO_REORDER, TUNE_FORCE_REORDER, TUNE_STAGING = 1 << 12, 1 << 13, 1 << 14, 1 << 15
 MAX_VIEWS = 64
 MAX_MAPS = 8
@@ -83,6 +84,11 @@ SIGNATURES = {
                                                 _vp, _vp, _i64, _vp]),
     "d3f_pairwise_similarity": (ctypes.c_int, [_vp, _vp, _i64, _i64, _i32, _f32, _i32, _i32, _vp, _vp, _vp, _i64,
                                                _vp]),
+    "d3f_pairwise_softmax_local": (ctypes.c_int, [_vp, _vp, _i64, _i64, _i32, _f32, _i32, _i64, _vp, _vp, _vp, _i64,
+                                                  _vp]),
+    "d3f_point_order_locality": (ctypes.c_int, [_vp, _i64, _vp, _vp]),
+    "d3f_softmax_merge": (ctypes.c_int, [_vp, _i64, _i64, _vp, _vp, _vp]),
+    "d3f_softmax_apply": (ctypes.c_int, [_vp, _i64, _i64, _f32, _vp, _vp]),
 }
 
 _lib = None

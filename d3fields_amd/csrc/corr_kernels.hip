@@ -209,8 +209,11 @@ __device__ __forceinline__ void merge_stat(float &m, float &s, int64_t &arg, flo
     arg = take2 ? arg2 : arg;
 }
 
-__global__ __launch_bounds__(kBlock) void softmax_merge_kernel(ColStat *__restrict__ ws, int64_t nchunks,
-                                                              int64_t cols, int64_t *__restrict__ argmax_out)
+// `in` [nchunks, cols] -> `out` [cols]; arg_offset shifts the winning row index (a rank's first global row when
+// the rows are sharded over GPUs; 0 otherwise).  nchunks == 0 writes the identity (-inf, 0, INT64_MAX).
+__global__ __launch_bounds__(kBlock) void softmax_merge_kernel(const ColStat *__restrict__ in, int64_t nchunks,
+                                                              int64_t cols, ColStat *__restrict__ out,
+                                                              int64_t *__restrict__ argmax_out, int64_t arg_offset)
 {
     const int lane = threadIdx.x & 63;
     const int64_t j = (int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
@@ -218,7 +221,7 @@ __global__ __launch_bounds__(kBlock) void softmax_merge_kernel(ColStat *__restri
     float m = -INFINITY, s = 0.0f;
     int64_t arg = 0x7fffffffffffffffLL;
     for (int64_t c = lane; c < nchunks; c += 64) {
-        const ColStat t = ws[c * cols + j];
+        const ColStat t = in[c * cols + j];
         merge_stat(m, s, arg, t.m, t.s, t.arg);
     }
     for (int off = 32; off > 0; off >>= 1) {
@@ -227,9 +230,10 @@ __global__ __launch_bounds__(kBlock) void softmax_merge_kernel(ColStat *__restri
         merge_stat(m, s, arg, m2, s2, a2);
     }
     if (lane == 0) {
+        if (arg != 0x7fffffffffffffffLL) arg += arg_offset;
         ColStat o;
         o.m = m; o.s = s; o.arg = arg;
-        ws[nchunks * cols + j] = o;
+        out[j] = o;
         if (argmax_out) argmax_out[j] = arg;
     }
 }
@@ -243,6 +247,13 @@ __global__ __launch_bounds__(kBlock) void softmax_apply_kernel(float *__restrict
     x[k] = expf(-x[k] * scale - t.m) / t.s;
 }
 
+static void merge_launch(const ColStat *in, int64_t nchunks, int64_t cols, ColStat *out, int64_t *argmax_out,
+                         int64_t arg_offset, hipStream_t s)
+{
+    hipLaunchKernelGGL(softmax_merge_kernel, dim3((unsigned)((cols + kBlock / 64 - 1) / (kBlock / 64))), dim3(kBlock), 0, s, in,
+                       nchunks, cols, out, argmax_out, arg_offset);
+}
+
 static hipError_t softmax_impl(float *x, int64_t rows, int64_t cols, float scale, int64_t *argmax_out, ColStat *ws,
                                bool normalise, hipStream_t s)
 {
@@ -250,13 +261,45 @@ static hipError_t softmax_impl(float *x, int64_t rows, int64_t cols, float scale
     const int64_t nchunks = (rows + kSoftmaxRowsPerBlock - 1) / kSoftmaxRowsPerBlock;
     const unsigned gx = (unsigned)((cols + kBlock - 1) / kBlock);
     hipLaunchKernelGGL(softmax_stats_kernel, dim3(gx, (unsigned)nchunks), dim3(kBlock), 0, s, x, rows, cols, scale, ws);
-    hipLaunchKernelGGL(softmax_merge_kernel, dim3((unsigned)((cols + kBlock / 64 - 1) / (kBlock / 64))), dim3(kBlock), 0, s, ws,
-                       nchunks, cols, argmax_out);
+    merge_launch(ws, nchunks, cols, ws + nchunks * cols, argmax_out, 0, s);
     if (normalise) {
         const int64_t total = rows * cols;
         hipLaunchKernelGGL(softmax_apply_kernel, dim3((unsigned)((total + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, x,
                            total, cols, scale, ws + nchunks * cols);
     }
+    return hipGetLastError();
+}
+
+// ---- row-sharded softmax (shard B1 over GPUs, exchange 16 B per column) --------------
+// local statistics of this rank's rows (global row index = row_offset + local row); rows == 0 gives the identity
+hipError_t launch_softmax_local_stats(const float *x, int64_t rows, int64_t cols, float scale, int64_t row_offset,
+                                      ColStat *ws, ColStat *stats_out, hipStream_t s)
+{
+    if (cols == 0) return hipSuccess;
+    const int64_t nchunks = (rows + kSoftmaxRowsPerBlock - 1) / kSoftmaxRowsPerBlock;
+    if (nchunks > 0) {
+        const unsigned gx = (unsigned)((cols + kBlock - 1) / kBlock);
+        hipLaunchKernelGGL(softmax_stats_kernel, dim3(gx, (unsigned)nchunks), dim3(kBlock), 0, s, x, rows, cols, scale, ws);
+    }
+    merge_launch(ws, nchunks, cols, stats_out, nullptr, row_offset, s);
+    return hipGetLastError();
+}
+
+// merges the per-rank statistics [parts, cols] (rank order) into [cols] (+ global argmax)
+hipError_t launch_softmax_merge(const ColStat *parts, int64_t nparts, int64_t cols, ColStat *merged, int64_t *argmax_out,
+                                hipStream_t s)
+{
+    if (cols == 0) return hipSuccess;
+    merge_launch(parts, nparts, cols, merged, argmax_out, 0, s);
+    return hipGetLastError();
+}
+
+hipError_t launch_softmax_apply(float *x, int64_t rows, int64_t cols, float scale, const ColStat *merged, hipStream_t s)
+{
+    const int64_t total = rows * cols;
+    if (total == 0) return hipSuccess;
+    hipLaunchKernelGGL(softmax_apply_kernel, dim3((unsigned)((total + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, x, total, cols,
+                       scale, merged);
     return hipGetLastError();
 }
 

@@ -175,7 +175,7 @@ int eval_common(const d3f_views *views, const float *pts, int64_t n, const d3f_c
     bool stage_any = false;
     if ((flags & D3F_TUNE_STAGING) && views->V * 24 * 32 <= 24 * 1024)
         for (int s = 0; s < n_maps; ++s) stage_any |= staging_candidate(P.maps[s], views->H, views->W);
-    const bool reorder = may_reorder && ((flags & D3F_TUNE_FORCE_REORDER) || (n >= 65536 && (map_bytes > (64LL << 20) || stage_any)));
+    const bool reorder = may_reorder && ((flags & D3F_TUNE_FORCE_REORDER) || (n >= 65536 && (map_bytes > (64LL << 20) || stage_any || (flags & D3F_FLAG_UNORDERED_POINTS))));
     if (reorder && !plan_only) {
         hipError_t eo = d3f::build_point_order(pts, n, workspace, workspace_bytes, &P.order, hs, (int)((flags >> 24) & 0x3));
         if (eo != hipSuccess) return hip_fail(eo, "point ordering");
@@ -203,6 +203,10 @@ int eval_common(const d3f_views *views, const float *pts, int64_t n, const d3f_c
         bool thin = false;
         for (int s = 0; s < n_maps; ++s) thin |= P.maps[s].lpp_log2 < 4;
         P.tile_pts = thin ? 16 : 8; P.lds_pad = 0; xcd_remap = true;
+        // maps that fit the L2s / Infinity Cache anyway (patch-resolution features, the mask): the walk is only there
+        // to give a random cloud L1 locality and the big tiles of the caller-order path stay best
+        // (C2 patch, random cloud: caller order 1.93 ms, walk with 8-point tiles 1.07, with 128-point tiles 0.76)
+        if (map_bytes <= (64LL << 20) && !stage_any) P.tile_pts = tile_points_for(views->V);
     } else if (map_bytes > (512LL << 20) && P.tile_pts > 64 && n >= 65536) {
         P.tile_pts = 64; P.lds_pad = 64 * 1024;
     }
@@ -418,6 +422,14 @@ int d3f_eval_dist_backward(const d3f_views *views, const float *pts, int64_t n, 
     return backward_common(views, pts, n, nullptr, 0, 1.0f, grad_dist, nullptr, grad_pts, stream, 1);
 }
 
+int d3f_point_order_locality(const float *pts, int64_t n, float *out, void *stream)
+{
+    if (n < 0) return fail(D3F_ERR_INVALID_ARG, "n=%lld is negative", (long long)n);
+    if (!out || (n > 0 && !pts)) return fail(D3F_ERR_INVALID_ARG, "point_order_locality: NULL pointer");
+    hipError_t e = d3f::launch_point_locality(pts, n, out, static_cast<hipStream_t>(stream));
+    return e == hipSuccess ? D3F_OK : hip_fail(e, "point locality launch");
+}
+
 int d3f_eval_dist(const d3f_views *views, const float *pts, int64_t n, float *out_dist, uint8_t *out_valid,
                   void *stream)
 {
@@ -511,6 +523,53 @@ int d3f_pairwise_similarity(const float *src, const float *tgt, int64_t B1, int6
         }
     }
     return D3F_OK;
+}
+
+static_assert(sizeof(d3f_col_stat) == sizeof(d3f::ColStat) && sizeof(d3f_col_stat) == 16, "d3f_col_stat layout");
+
+int d3f_pairwise_softmax_local(const float *src, const float *tgt, int64_t B1, int64_t B2, int32_t C, float scale,
+                               int32_t dist_type, int64_t row_offset, float *out, d3f_col_stat *stats, void *workspace,
+                               int64_t workspace_bytes, void *stream)
+{
+    int rc = check_sim_enums(dist_type, D3F_SIM_SOFTMAX_DIM0);
+    if (rc != D3F_OK) return rc;
+    if (B1 < 0 || B2 < 0 || C < 1 || row_offset < 0) return fail(D3F_ERR_BAD_SHAPE, "pairwise_softmax_local: B1=%lld B2=%lld C=%d row_offset=%lld", (long long)B1, (long long)B2, C, (long long)row_offset);
+    if (B2 == 0) return D3F_OK;
+    if (!stats || !tgt) return fail(D3F_ERR_INVALID_ARG, "pairwise_softmax_local: NULL pointer");
+    if (B1 > 0 && (!src || !out)) return fail(D3F_ERR_INVALID_ARG, "pairwise_softmax_local: NULL pointer");
+    if ((B2 + 63) / 64 > 0x7fffffffLL || (B1 + 63) / 64 > 65535) return fail(D3F_ERR_BAD_SHAPE, "pairwise_softmax_local: B1=%lld exceeds 64*65535 rows per call", (long long)B1);
+    if (B1 > 0 && (!workspace || workspace_bytes < d3f_softmax_workspace_bytes(B1, B2)))
+        return fail(D3F_ERR_WORKSPACE, "pairwise_softmax_local: needs %lld workspace bytes", (long long)d3f_softmax_workspace_bytes(B1, B2));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    hipError_t e = hipSuccess;
+    if (B1 > 0) {
+        e = d3f::launch_pairwise_dist(src, tgt, B1, B2, C, dist_type, out, s);
+        if (e != hipSuccess) return hip_fail(e, "pairwise_dist launch");
+    }
+    e = d3f::launch_softmax_local_stats(out, B1, B2, scale, row_offset, static_cast<d3f::ColStat *>(workspace),
+                                        reinterpret_cast<d3f::ColStat *>(stats), s);
+    return e == hipSuccess ? D3F_OK : hip_fail(e, "softmax statistics launch");
+}
+
+int d3f_softmax_merge(const d3f_col_stat *parts, int64_t n_parts, int64_t cols, d3f_col_stat *merged, int64_t *argmax_out,
+                      void *stream)
+{
+    if (n_parts < 0 || cols < 0) return fail(D3F_ERR_BAD_SHAPE, "softmax_merge: n_parts=%lld cols=%lld", (long long)n_parts, (long long)cols);
+    if (cols == 0) return D3F_OK;
+    if (!merged || (n_parts > 0 && !parts)) return fail(D3F_ERR_INVALID_ARG, "softmax_merge: NULL pointer");
+    hipError_t e = d3f::launch_softmax_merge(reinterpret_cast<const d3f::ColStat *>(parts), n_parts, cols,
+                                             reinterpret_cast<d3f::ColStat *>(merged), argmax_out, static_cast<hipStream_t>(stream));
+    return e == hipSuccess ? D3F_OK : hip_fail(e, "softmax merge launch");
+}
+
+int d3f_softmax_apply(float *x, int64_t rows, int64_t cols, float scale, const d3f_col_stat *merged, void *stream)
+{
+    if (rows < 0 || cols < 0) return fail(D3F_ERR_BAD_SHAPE, "softmax_apply: rows=%lld cols=%lld", (long long)rows, (long long)cols);
+    if (rows == 0 || cols == 0) return D3F_OK;
+    if (!x || !merged) return fail(D3F_ERR_INVALID_ARG, "softmax_apply: NULL pointer");
+    hipError_t e = d3f::launch_softmax_apply(x, rows, cols, scale, reinterpret_cast<const d3f::ColStat *>(merged),
+                                             static_cast<hipStream_t>(stream));
+    return e == hipSuccess ? D3F_OK : hip_fail(e, "softmax apply launch");
 }
 
 }  // extern "C"

@@ -71,6 +71,8 @@ hipError_t launch_fused_backward(const BackwardParams &P, int mode, hipStream_t 
 int64_t order_workspace_bytes(int64_t n);
 hipError_t build_point_order(const float *pts, int64_t n, void *workspace, int64_t workspace_bytes,
                              const uint32_t **order_out, hipStream_t stream, int fine = 0);
+// mean L1 step between consecutive points vs between points n/2 apart (out: 2 device floats)
+hipError_t launch_point_locality(const float *pts, int64_t n, float *out, hipStream_t stream);
 
 // grid_kernels.hip
 hipError_t launch_grid_shell(const float *depth, const float *K, const float *pose, int V, int H, int W, const float *gx,
@@ -105,6 +107,12 @@ hipError_t launch_exp_neg_scale(float *x, int64_t n, float scale, hipStream_t s)
 // softmax(-x*scale, dim=0) of a row-major [rows, cols] matrix in place (+ optional argmax)
 hipError_t launch_softmax_dim0(float *x, int64_t rows, int64_t cols, float scale, int64_t *argmax_out,
                                ColStat *ws, hipStream_t s);
+// row-sharded softmax: local column statistics, cross-rank merge, normalisation with merged statistics
+hipError_t launch_softmax_local_stats(const float *x, int64_t rows, int64_t cols, float scale, int64_t row_offset,
+                                      ColStat *ws, ColStat *stats_out, hipStream_t s);
+hipError_t launch_softmax_merge(const ColStat *parts, int64_t nparts, int64_t cols, ColStat *merged, int64_t *argmax_out,
+                                hipStream_t s);
+hipError_t launch_softmax_apply(float *x, int64_t rows, int64_t cols, float scale, const ColStat *merged, hipStream_t s);
 // argmin over dim 0 of raw distances (used for D3F_SIM_DIST + argmax_out)
 hipError_t launch_argmin_dim0(const float *x, int64_t rows, int64_t cols, int64_t *arg_out, ColStat *ws,
                               hipStream_t s);

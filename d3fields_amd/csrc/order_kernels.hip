@@ -87,4 +87,47 @@ hipError_t build_point_order(const float *pts, int64_t n, void *workspace, int64
     return hipSuccess;
 }
 
+// ---- does the caller's order have spatial locality? ------------------------------------------------
+// out[0] = mean L1 step between consecutive points, out[1] = mean L1 distance between points n/2 apart, both
+// over <= kProbeSamples evenly spaced positions (non-finite pairs are left out).  A voxel grid, a mesh or a
+// depth-ordered cloud gives out[0] << out[1]; a shuffled / uniformly random cloud gives out[0] ~ out[1].
+constexpr int kProbeSamples = 4096;
+
+__global__ __launch_bounds__(kBlock) void point_locality_kernel(const float *__restrict__ pts, int64_t n, int samples,
+                                                               float *__restrict__ out)
+{
+    __shared__ float red[3][kBlock / 64];
+    float near_d = 0.0f, far_d = 0.0f, cnt = 0.0f;
+    for (int k = threadIdx.x; k < samples && n >= 2; k += kBlock) {
+        const int64_t i = (int64_t)((double)k * (double)(n - 1) / (double)samples);      // i + 1 <= n - 1
+        const int64_t j = (i + n / 2) % n;
+        const float ax = pts[i * 3], ay = pts[i * 3 + 1], az = pts[i * 3 + 2];
+        const float dn = fabsf(pts[i * 3 + 3] - ax) + fabsf(pts[i * 3 + 4] - ay) + fabsf(pts[i * 3 + 5] - az);
+        const float df = fabsf(pts[j * 3] - ax) + fabsf(pts[j * 3 + 1] - ay) + fabsf(pts[j * 3 + 2] - az);
+        if (dn < INFINITY && df < INFINITY) { near_d += dn; far_d += df; cnt += 1.0f; }  // false for NaN too
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        near_d += __shfl_xor(near_d, off, 64);
+        far_d += __shfl_xor(far_d, off, 64);
+        cnt += __shfl_xor(cnt, off, 64);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        red[0][threadIdx.x >> 6] = near_d; red[1][threadIdx.x >> 6] = far_d; red[2][threadIdx.x >> 6] = cnt;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float t[3] = {0.0f, 0.0f, 0.0f};
+        for (int w = 0; w < kBlock / 64; ++w) { t[0] += red[0][w]; t[1] += red[1][w]; t[2] += red[2][w]; }
+        out[0] = t[2] > 0.0f ? t[0] / t[2] : 0.0f;
+        out[1] = t[2] > 0.0f ? t[1] / t[2] : 0.0f;
+    }
+}
+
+// one workgroup (a few microseconds); out: 2 device floats
+hipError_t launch_point_locality(const float *pts, int64_t n, float *out, hipStream_t stream)
+{
+    hipLaunchKernelGGL(point_locality_kernel, dim3(1), dim3(kBlock), 0, stream, pts, n, kProbeSamples, out);
+    return hipGetLastError();
+}
+
 }  // namespace d3f

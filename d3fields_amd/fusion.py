@@ -194,6 +194,8 @@ class Fusion:
         self._finite_cache = {}
         self.tuning_flags = 0                   # D3F_TUNE_* bits (experiments; results do not depend on them)
         self.reorder_points = True              # hand the library scratch so it may walk points in Morton order
+        self.detect_point_order = True          # probe new query tensors for locality (one host sync each, cached)
+        self._order_cache = None
         self._lib = _lib.load()                 # fail at construction if the HIP library is missing
 
     # ---- observation state (reference fusion.py:686-714) --------------------------------
@@ -251,6 +253,21 @@ class Fusion:
         if hit is None or hit[0] != sig:
             hit = (sig, bool(torch.isfinite(t).all().item()))
             self._finite_cache[key] = hit
+        return hit[1]
+
+    def _is_unordered(self, pts_c, stream):
+        """d3f_point_order_locality on a NEW query tensor (cached by storage / version / length, so a grid queried
+        repeatedly is probed once): True when consecutive points are no closer than points half the batch apart,
+        i.e. a shuffled or random cloud.  Only steers D3F_FLAG_UNORDERED_POINTS -- a stale answer costs time, never
+        correctness."""
+        sig = (pts_c.data_ptr(), pts_c._version, pts_c.shape[0])
+        hit = self._order_cache
+        if hit is None or hit[0] != sig:
+            out = torch.empty(2, dtype=torch.float32, device=pts_c.device)
+            _lib.check(self._lib.d3f_point_order_locality(_lib.ptr(pts_c), pts_c.shape[0], _lib.ptr(out), stream))
+            near, far = out.tolist()
+            hit = (sig, bool(near > 0.25 * far))
+            self._order_cache = hit
         return hit[1]
 
     def _run(self, pts, return_names, return_inter, mode):
@@ -317,6 +334,9 @@ class Fusion:
             flags = (_lib.FLAG_FINITE_MAPS if finite else 0) | int(self.tuning_flags)
             ws, ws_bytes = None, 0
             if self.reorder_points and names and n >= 65536:
+                small = sum(m.shape[0] * m.shape[1] * m.shape[2] * m.shape[3] * 4 for m in used_maps) <= (64 << 20)
+                if small and self.detect_point_order and self._is_unordered(pts_c, stream):
+                    flags |= _lib.FLAG_UNORDERED_POINTS     # larger maps are walked in Morton order anyway
                 ws_bytes = lib.d3f_eval_workspace_bytes(n)
                 ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)   # torch's caching allocator: no hipMalloc per call
             _lib.check(lib.d3f_eval(ctypes.byref(views), _lib.ptr(pts_c), n, maps, len(names), self.mu, flags,

@@ -14,7 +14,8 @@ cubes, fusion.py:1313-1330) should gather keys=('dist','valid_mask') and leave f
 import torch
 import torch.distributed as dist
 
-__all__ = ["shard_bounds", "shard_points", "all_gather_field", "sharded_eval", "broadcast_observation"]
+__all__ = ["shard_bounds", "shard_points", "all_gather_field", "sharded_eval", "broadcast_observation",
+           "sharded_similarity_multi"]
 
 
 def _world(group=None):
@@ -117,3 +118,80 @@ def broadcast_observation(fusion, src=0, group=None):
         t = fusion.curr_obs_torch[k]
         if isinstance(t, torch.Tensor):
             dist.broadcast(t, src=src, group=group)
+
+
+class _HipSoftmaxKernels:
+    """The three device steps of the row-sharded softmax (include/d3fields_hip.h); column records travel as
+    raw [B2,16] uint8 tensors (d3f_col_stat: float max, float sum, int64 argmax)."""
+
+    @staticmethod
+    def local(src, tgt, scale, dist_code, row_offset):
+        from . import _lib
+        from .corr_utils import _workspace
+        dev = src.device
+        B1, C = src.shape
+        B2 = tgt.shape[0]
+        out = torch.empty((B1, B2), dtype=torch.float32, device=dev)
+        stats = torch.empty((B2, 16), dtype=torch.uint8, device=dev)
+        ws, ws_bytes = _workspace(B1, B2, dev) if B1 > 0 else (None, 0)
+        with torch.cuda.device(dev):
+            _lib.check(_lib.load().d3f_pairwise_softmax_local(
+                _lib.ptr(src), _lib.ptr(tgt), B1, B2, C, float(scale), dist_code, int(row_offset), _lib.ptr(out),
+                _lib.ptr(stats), _lib.ptr(ws), ws_bytes, _lib.current_stream_handle(dev)))
+        return out, stats
+
+    @staticmethod
+    def merge(parts):
+        from . import _lib
+        dev = parts.device
+        P, B2 = parts.shape[0], parts.shape[1]
+        merged = torch.empty((B2, 16), dtype=torch.uint8, device=dev)
+        am = torch.empty(B2, dtype=torch.int64, device=dev)
+        with torch.cuda.device(dev):
+            _lib.check(_lib.load().d3f_softmax_merge(_lib.ptr(parts), P, B2, _lib.ptr(merged), _lib.ptr(am),
+                                                     _lib.current_stream_handle(dev)))
+        return merged, am
+
+    @staticmethod
+    def apply(out, scale, merged):
+        from . import _lib
+        dev = out.device
+        with torch.cuda.device(dev):
+            _lib.check(_lib.load().d3f_softmax_apply(_lib.ptr(out), out.shape[0], out.shape[1], float(scale),
+                                                     _lib.ptr(merged), _lib.current_stream_handle(dev)))
+        return out
+
+
+def sharded_similarity_multi(src_local, tgt_feats, scale, dist_type="l2", row_offset=None, group=None, kernels=None):
+    """compute_similarity_tensor_multi (utils/corr_utils.py:63-106) with the B1 source descriptors sharded over ranks.
+
+    src_local [B1_local,C] is THIS rank's contiguous block of rows (e.g. the features Fusion.eval returned for its
+    shard of keypoints), tgt_feats [B2,C] is replicated.  softmax(dim=0) couples all rows, so the ranks exchange one
+    16-byte record per target column (max, sum-exp, first argmax) -- a single all-gather of 16*B2 bytes -- and
+    normalise locally.  Returns (similarity rows of this rank [B1_local,B2], argmax [B2] as GLOBAL row indices).
+    row_offset: global index of this rank's first row (default: exclusive sum of the ranks' row counts).
+    `kernels` replaces the HIP steps in the CPU plumbing tests (gloo)."""
+    from .corr_utils import _dist_code
+    code = _dist_code(dist_type)
+    rank, world = _world(group)
+    k = kernels if kernels is not None else _HipSoftmaxKernels
+    assert src_local.dim() == 2 and tgt_feats.dim() == 2 and src_local.shape[1] == tgt_feats.shape[1]
+    if kernels is None and not src_local.is_cuda:
+        raise RuntimeError("src_local must be on the ROCm device; there is no CPU path")
+    src_local = src_local.to(torch.float32).contiguous()
+    tgt_feats = tgt_feats.to(device=src_local.device, dtype=torch.float32).contiguous()
+    if row_offset is None:
+        row_offset = 0
+        if world > 1:
+            c = torch.tensor([src_local.shape[0]], dtype=torch.int64, device=src_local.device)
+            allc = torch.empty(world, dtype=torch.int64, device=c.device)
+            dist.all_gather_into_tensor(allc, c, group=group)
+            row_offset = int(allc[:rank].sum())
+    out, stats = k.local(src_local, tgt_feats, scale, code, row_offset)
+    if world > 1:
+        parts = stats.new_empty((world,) + tuple(stats.shape))
+        dist.all_gather_into_tensor(parts.view(world * stats.shape[0], 16), stats, group=group)
+    else:
+        parts = stats.unsqueeze(0)
+    merged, am = k.merge(parts)
+    return k.apply(out, scale, merged), am

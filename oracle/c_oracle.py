@@ -45,6 +45,11 @@ def _c32(a):
     return np.ascontiguousarray(a, dtype=np.float32)
 
 
+def threads():
+    """OpenMP threads d3f_oracle_eval runs on."""
+    return int(lib().d3f_oracle_threads())
+
+
 def eval_field(depth, K, Rt, pts, maps=(), mu=0.02, mode="eval", return_inter=False,
                return_margin=False):
     """Fusion.eval / eval_dist restated (see d3f_oracle_eval).

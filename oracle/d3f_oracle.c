@@ -29,6 +29,19 @@
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+/* threads the OpenMP split of d3f_oracle_eval will use (bench.py reports it beside the timing) */
+int d3f_oracle_threads(void)
+{
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
 
 #define ORACLE_MODE_EVAL 0
 #define ORACLE_MODE_EVAL_DIST 1

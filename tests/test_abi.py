@@ -109,6 +109,12 @@ def test_launch_plan_host_logic():
     p = _plan(4, 480, 640, 985600, [(48, 64, 384)])
     assert (p.tile_points, p.reorder, p.workgroups) == (128, 0, 7700)
     assert (p.vector_floats[0], p.lanes_per_point[0], p.vectors_per_lane[0], p.staged[0]) == (4, 32, 3, 0)
+    # the same maps with a cloud the caller declares unordered: Morton walk, but still the big tiles (maps are cache-resident)
+    p = _plan(4, 480, 640, 985600, [(48, 64, 384)], flags=_lib.FLAG_UNORDERED_POINTS)
+    assert (p.tile_points, p.reorder, p.workgroups, p.vectors_per_lane[0]) == (128, 1, 7700, 3)
+    p = _plan(4, 480, 640, 985600, [(48, 64, 384)], flags=_lib.FLAG_UNORDERED_POINTS, ws=0)
+    assert p.reorder == 0                                      # no scratch, no walk
+    assert _plan(4, 480, 640, 60000, [(48, 64, 384)], flags=_lib.FLAG_UNORDERED_POINTS).reorder == 0
     # C2 dense: 1.9 GB of maps -> Morton walk, 32-point tiles, load-use per vector; without scratch: 64-point tiles
     p = _plan(4, 480, 640, 985600, [(480, 640, 384)])
     assert (p.tile_points, p.reorder, p.vectors_per_lane[0]) == (8, 1, 3)

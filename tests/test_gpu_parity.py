@@ -327,6 +327,83 @@ def test_pairwise_vs_oracle(dev, B1, B2, C):
         assert rel_err(cpu(d), O.dist_to_target(src[sl].numpy(), tgt[7].numpy(), "l2", channel_axis=1)) <= TOL
 
 
+@pytest.mark.parametrize("B1,splits", [(5000, (0, 1700, 1700, 5000)), (257, (0, 256, 257)), (1000, (0, 333, 1000))])
+@pytest.mark.parametrize("dist_type", ["l2", "square"])
+def test_row_sharded_softmax_steps(dev, B1, splits, dist_type):
+    """The three device steps of sharding.sharded_similarity_multi, with the ranks' row blocks (one of them empty)
+    processed in one process: rows and global argmax equal the unsharded launch and the oracle."""
+    from d3fields_amd import corr_utils as cu
+    from d3fields_amd.sharding import _HipSoftmaxKernels as K
+    from d3fields_amd import _lib
+    from oracle import c_oracle as O
+    B2, C = 70, 48
+    g = torch.Generator().manual_seed(B1)
+    src = torch.randn(B1, C, generator=g)
+    tgt = torch.randn(B2, C, generator=g)
+    tgt[3] = src[B1 - 1]
+    code = {"l2": _lib.DIST_L2, "square": _lib.DIST_SQUARE}[dist_type]
+    srcd, tgtd = src.to(dev), tgt.to(dev)
+    blocks = [(splits[i], splits[i + 1]) for i in range(len(splits) - 1)]
+    local = [K.local(srcd[lo:hi].contiguous(), tgtd, 0.7, code, lo) for lo, hi in blocks]
+    parts = torch.stack([st for _, st in local])
+    merged, am = K.merge(parts)
+    rows = torch.cat([K.apply(o, 0.7, merged) for o, _ in local])
+    whole = cu.compute_similarity_tensor_multi(srcd, tgtd, None, None, 0.7, dist_type)
+    ref, ref_am = O.pairwise(src.numpy(), tgt.numpy(), 0.7, dist_type, return_argmax=True)
+    assert rel_err(cpu(rows), cpu(whole)) <= 1e-6
+    assert rel_err(cpu(rows), ref) <= TOL
+    assert np.array_equal(cpu(am), ref_am) and am[3].item() == B1 - 1
+    assert torch.allclose(rows.sum(0), torch.ones(B2, device=dev), atol=1e-5)
+
+
+def test_point_order_probe_and_unordered_walk(dev):
+    """d3f_point_order_locality separates grids from random clouds; the shim then asks for the Morton walk on small
+    maps (D3F_FLAG_UNORDERED_POINTS) and every output stays bit-identical to the caller-order launch."""
+    import ctypes
+    from d3fields_amd import synth, create_init_grid, _lib
+    lib = _lib.load()
+    out = torch.empty(2, device=dev)
+
+    def probe(p):
+        p = p.to(dev).contiguous()
+        _lib.check(lib.d3f_point_order_locality(_lib.ptr(p), p.shape[0], _lib.ptr(out), _lib.current_stream_handle(dev)))
+        return out.tolist()
+
+    grid, _ = create_init_grid(synth.WORK_BOX, 0.01)
+    near, far = probe(grid)
+    assert 0 < near < 0.1 * far
+    cloud = synth.random_cloud(200000, seed=3)
+    near, far = probe(cloud)
+    assert near > 0.5 * far
+    bad = cloud.clone()
+    bad[::7] = float("nan")
+    near, far = probe(bad)
+    assert np.isfinite(near) and np.isfinite(far) and near > 0.5 * far
+    assert probe(cloud[:1]) == [0.0, 0.0] and probe(cloud[:0]) == [0.0, 0.0]
+
+    V, H, W = 4, 120, 160
+    sc = synth.make_scene(V, H, W, "stress")
+    maps = {"dino_feats": synth.random_map(V, 12, 16, 96, seed=1), "mask": synth.random_onehot_mask(V, H, W, 5, seed=2)}
+    f = make_fusion(dev, sc["depth"], sc["K"], sc["pose"], maps, H, W)
+    names = ["dino_feats", "mask"]
+    for pts, unordered in ((cloud, True), (grid[:150000], False)):
+        p = pts.to(dev)
+        f.detect_point_order = True
+        a = f.eval(p, return_names=names)
+        assert f._order_cache[1] is unordered
+        f.detect_point_order = False
+        b = f.eval(p, return_names=names)
+        for k in a:
+            assert torch.equal(a[k], b[k]), k
+    f.detect_point_order = True
+    ref = oracle_eval(sc, cloud.numpy(), [maps[k].numpy() for k in names])
+    got = f.eval(cloud.to(dev), return_names=names)
+    assert np.array_equal(cpu(got["valid_mask"]), ref["valid_mask"].astype(bool))
+    assert np.array_equal(cpu(got["dist"]), ref["dist"])
+    for s_, k in enumerate(names):
+        assert rel_err(cpu(got[k]), ref["sets"][s_]) <= TOL
+
+
 def test_fails_loudly_without_gpu_tensors(dev):
     from d3fields_amd import synth
     V, H, W = 2, 32, 40

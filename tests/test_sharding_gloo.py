@@ -70,3 +70,86 @@ def test_sharded_eval_world2(n):
     for rank, ok, is_bool, ishape in res:
         assert ok, "rank %d: gathered field differs from the single-process field" % rank
         assert is_bool and ishape == (3, n, 6)
+
+
+_REC = np.dtype([("m", "<f4"), ("s", "<f4"), ("a", "<i8")])      # d3f_col_stat (include/d3fields_hip.h)
+
+
+class _NumpySoftmaxKernels:
+    """Stand-in for the three HIP steps of sharded_similarity_multi (same record format)."""
+
+    @staticmethod
+    def local(src, tgt, scale, code, row_offset):
+        from oracle import c_oracle as O
+        B1, B2 = src.shape[0], tgt.shape[0]
+        rec = np.zeros(B2, _REC)
+        if B1 == 0:
+            rec["m"], rec["s"], rec["a"] = -np.inf, 0.0, np.iinfo(np.int64).max
+            return torch.empty((0, B2)), torch.from_numpy(rec.view(np.uint8).reshape(B2, 16).copy())
+        d = O.pairwise(src.numpy(), tgt.numpy(), scale, "l2" if code == 0 else "square", mode="dist")
+        lg = (-d * np.float32(scale)).astype(np.float32)
+        rec["m"] = lg.max(0)
+        rec["s"] = np.exp(lg - rec["m"]).sum(0, dtype=np.float32)
+        rec["a"] = lg.argmax(0) + row_offset
+        return torch.from_numpy(d), torch.from_numpy(rec.view(np.uint8).reshape(B2, 16).copy())
+
+    @staticmethod
+    def merge(parts):
+        rec = parts.numpy().reshape(parts.shape[0], parts.shape[1] * 16).view(_REC)      # [P, B2]
+        M = rec["m"].max(0)
+        with np.errstate(invalid="ignore"):
+            w = np.where(np.isneginf(rec["m"]), 0.0, np.exp(rec["m"] - M)).astype(np.float32)
+        out = np.zeros(rec.shape[1], _REC)
+        out["m"], out["s"] = M, (rec["s"] * w).sum(0, dtype=np.float32)
+        out["a"] = np.where(rec["m"] == M, rec["a"], np.iinfo(np.int64).max).min(0)
+        return torch.from_numpy(out.view(np.uint8).reshape(-1, 16).copy()), torch.from_numpy(out["a"].copy())
+
+    @staticmethod
+    def apply(out, scale, merged):
+        rec = merged.numpy().reshape(-1).view(_REC)
+        return torch.from_numpy((np.exp(-out.numpy() * np.float32(scale) - rec["m"]) / rec["s"]).astype(np.float32))
+
+
+def _sim_worker(rank, world, port, b1, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from d3fields_amd import sharding
+        from oracle import c_oracle as O
+        g = torch.Generator().manual_seed(11)
+        src = torch.randn(b1, 24, generator=g)
+        tgt = torch.cat([src[:1] + 0.01, torch.randn(9, 24, generator=g)])          # column 0 matches row 0
+        lo, hi = sharding.shard_bounds(b1, rank, world)
+        res = {}
+        for dt in ("l2", "square"):
+            sim, am = sharding.sharded_similarity_multi(src[lo:hi], tgt, 2.0, dt, kernels=_NumpySoftmaxKernels)
+            ref, ref_am = O.pairwise(src.numpy(), tgt.numpy(), 2.0, dt, mode="softmax", return_argmax=True)
+            err = float(np.abs(sim.numpy() - ref[lo:hi]).max()) if hi > lo else 0.0
+            res[dt] = (tuple(sim.shape), err, bool(np.array_equal(am.numpy(), ref_am)))
+        q.put((rank, res, (lo, hi)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("b1", [257, 7, 1])
+def test_sharded_similarity_world2(b1):
+    """softmax(dim=0) of compute_similarity_tensor_multi with the rows split over two ranks: one 16-B record per
+    column is exchanged; rows and the global argmax equal the single-process result (rank 1 is empty for b1=1)."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_sim_worker, args=(r, world, port, b1, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in range(world)]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for rank, r, (lo, hi) in res:
+        for dt, (shape, err, am_ok) in r.items():
+            assert shape == (hi - lo, 10)
+            assert err <= 1e-6, "rank %d %s: similarity rows differ by %g" % (rank, dt, err)
+            assert am_ok, "rank %d %s: global argmax differs" % (rank, dt)
