@@ -194,6 +194,7 @@ class Fusion:
         self._finite_cache = {}
         self.tuning_flags = 0                   # D3F_TUNE_* bits (experiments; results do not depend on them)
         self.reorder_points = True              # hand the library scratch so it may walk points in Morton order
+        self.use_hip_graph = True               # rigid_tracking: capture the optimiser iteration in a HIP graph
         self.detect_point_order = True          # probe new query tensors for locality (one host sync each, cached)
         self._order_cache = None
         self._lib = _lib.load()                 # fail at construction if the HIP library is missing
@@ -480,6 +481,25 @@ class Fusion:
                 src_pts_list.append(sample_pts.cpu().numpy())
                 last_label = label[i]
         return src_feats_list, src_pts_list, []
+
+    def rigid_tracking(self, src_feat_info, last_match_pts_list, boundaries, rand_ptcl_num):
+        """Per-instance SE(3) tracking of keypoints (reference fusion.py:1608-1685): 100 Adam steps (lr 0.01) on
+        translation + axis-angle parameters, loss = masked descriptor distance + 100 * positive distance + parameter
+        norms, gradients through `eval` on the HIP backward kernel.  Same arguments and return value as the
+        reference ({'match_pts_list': [rand_ptcl_num,3] numpy array per instance}); `boundaries` only feeds the
+        reference's disabled out-of-bounds term (weight 0, fusion.py:1618,1663) and is accepted and ignored.
+        `self.use_hip_graph` replays the iteration as one HIP graph (d3fields_amd/rigid.py)."""
+        from . import rigid
+        dev = torch.device(self.device)
+        src_feats = torch.cat([_as_device_tensor(src_feat_info[k]["src_feats"], torch.float32, dev) for k in src_feat_info.keys()],
+                              dim=0)
+        num_instance = len(last_match_pts_list)
+        last_np = np.stack([np.asarray(p) for p in last_match_pts_list], axis=0)
+        assert last_np.shape[:2] == (num_instance, rand_ptcl_num)
+        last = torch.from_numpy(last_np).to(dev, dtype=torch.float32)
+        cur, _ = rigid.track_rigid(self, src_feats, last, use_graph=self.use_hip_graph)
+        cur = cur.cpu().numpy()
+        return {"match_pts_list": [cur[i * rand_ptcl_num:(i + 1) * rand_ptcl_num] for i in range(num_instance)]}
 
     def pcd_iou(self, pcd_1, pcd_2, threshold):
         """Reference Fusion.pcd_iou (fusion.py:724-741); see d3fields_amd.pcd_utils.pcd_iou."""

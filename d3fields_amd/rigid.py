@@ -1,0 +1,87 @@
+"""Per-instance rigid tracking on the HIP field query (reference: Fusion.rigid_tracking, fusion.py:1608-1685).
+
+The reference optimises one SE(3) transform per instance with 100 Adam steps; every step is one
+`Fusion.eval` of the transformed keypoints with autograd back to the 6 pose parameters.  Here the
+query and its gradient are the HIP kernels (`d3f_eval`, `d3f_eval_backward`); the few 3x3 / [I,3]
+tensor ops around them (exponential map, loss terms, Adam) are torch device ops.  An iteration is
+~25 small launches, i.e. launch-bound, so the whole iteration is captured once in a HIP graph and
+replayed (`use_graph=True`): same kernels, same order, one host call per iteration.
+
+pytorch3d (reference env pins 0.7.5, env.yaml:14) is neither available on ROCm images nor needed:
+the two functions the reference calls are a dozen lines each and are restated below.
+"""
+import numpy as np
+import torch
+
+__all__ = ["so3_exp_map", "rigid_transform", "track_rigid"]
+
+LR, ITERS, REG_W, DIST_W = 0.01, 100, 1.0, 100.0       # fusion.py:1613-1617
+
+
+def so3_exp_map(log_rot, eps=1e-4):
+    """[I,3] axis-angle -> [I,3,3] rotation, Rodrigues' formula with the angle clamped at sqrt(eps)
+    (what pytorch3d.transforms.so3.so3_exp_map computes; fusion.py:1649)."""
+    x, y, z = log_rot[:, 0], log_rot[:, 1], log_rot[:, 2]
+    o = torch.zeros_like(x)
+    skew = torch.stack([o, -z, y, z, o, -x, -y, x, o], dim=1).view(-1, 3, 3)
+    theta = torch.clamp((log_rot * log_rot).sum(1), eps).sqrt()
+    a = (theta.sin() / theta)[:, None, None]
+    b = ((1.0 - theta.cos()) / (theta * theta))[:, None, None]
+    eye = torch.eye(3, dtype=log_rot.dtype, device=log_rot.device)[None]
+    return a * skew + b * torch.bmm(skew, skew) + eye
+
+
+def rigid_transform(points, rot, trans):
+    """pytorch3d's Transform3d().rotate(R).translate(t).transform_points(p) (fusion.py:1650-1651):
+    row-vector convention, p' = p @ R + t per instance.  points [I,n,3], rot [I,3,3], trans [I,3]."""
+    return torch.bmm(points, rot) + trans[:, None, :]
+
+
+def _iteration(fusion, last, src_feats, t_params, log_r, opt):
+    cur = rigid_transform(last, so3_exp_map(log_r), t_params).reshape(-1, 3)
+    out = fusion.eval(cur, return_names=["dino_feats"])
+    valid = out["valid_mask"]
+    feat_loss = (torch.norm(out["dino_feats"] - src_feats, dim=-1) * valid).mean()
+    dist_loss = DIST_W * torch.clamp(out["dist"] * valid, min=0).mean()
+    reg_loss = REG_W * (torch.norm(t_params) + torch.norm(log_r))
+    loss = feat_loss + dist_loss + reg_loss
+    opt.zero_grad(set_to_none=False)
+    loss.backward()
+    opt.step()
+    return cur, loss
+
+
+def track_rigid(fusion, src_feats, last_match_pts, use_graph=True, iters=ITERS, lr=LR):
+    """src_feats [I*n,C] and last_match_pts [I,n,3] on the device -> (current keypoints [I*n,3] as evaluated in
+    the last iteration -- what the reference returns --, last loss)."""
+    dev = last_match_pts.device
+    num_inst = last_match_pts.shape[0]
+    t_params = torch.zeros(num_inst, 3, device=dev, requires_grad=True)
+    log_r = torch.zeros(num_inst, 3, device=dev, requires_grad=True)
+    opt = torch.optim.Adam([t_params, log_r], lr=lr, betas=(0.9, 0.999), capturable=bool(use_graph))
+    if not use_graph:
+        cur = loss = None
+        for _ in range(iters):
+            cur, loss = _iteration(fusion, last_match_pts, src_feats, t_params, log_r, opt)
+        return cur.detach(), loss.detach()
+
+    # warm-up on a side stream (allocator pools, Adam state, the shim's caches), then rewind to the initial state
+    side = torch.cuda.Stream(device=dev)
+    side.wait_stream(torch.cuda.current_stream(dev))
+    with torch.cuda.stream(side):
+        for _ in range(2):
+            _iteration(fusion, last_match_pts, src_feats, t_params, log_r, opt)
+    torch.cuda.current_stream(dev).wait_stream(side)
+    with torch.no_grad():
+        t_params.zero_()
+        log_r.zero_()
+        for st in opt.state.values():
+            for v in st.values():
+                if isinstance(v, torch.Tensor):
+                    v.zero_()
+    graph = torch.cuda.CUDAGraph()          # a hipGraph on ROCm
+    with torch.cuda.graph(graph):
+        cur, loss = _iteration(fusion, last_match_pts, src_feats, t_params, log_r, opt)
+    for _ in range(iters):
+        graph.replay()
+    return cur.detach().clone(), loss.detach().clone()

@@ -39,6 +39,17 @@ def import_reference():
             m = MagicMock(name=name)
             m.__path__ = ["/nonexistent"]
             sys.modules[name] = m
+    # pytorch3d (pinned 0.7.5, env.yaml:14) is absent: rigid_tracking (fusion.py:1627-1628) gets the restated
+    # so3_exp_map / Transform3d of oracle/pytorch3d_restated.py instead of a MagicMock
+    from oracle import pytorch3d_restated as p3d
+    tr = types.ModuleType("pytorch3d.transforms")
+    tr.__path__ = ["/nonexistent"]
+    tr.Transform3d = p3d.Transform3d
+    so3 = types.ModuleType("pytorch3d.transforms.so3")
+    so3.so3_exp_map = p3d.so3_exp_map
+    tr.so3 = so3
+    sys.modules["pytorch3d.transforms"] = tr
+    sys.modules["pytorch3d.transforms.so3"] = so3
     if REF_ROOT not in sys.path:
         sys.path.insert(0, REF_ROOT)
     import importlib

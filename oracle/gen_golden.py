@@ -247,6 +247,52 @@ def pcd_case(fusion):
          iou=np.array(iou[:3], dtype=np.float64), overlap_1=iou[3], overlap_2=iou[4], idx_12=iou[5], idx_21=iou[6])
 
 
+def smooth_feature_map(V, fh, fw, C, seed=71):
+    """Low-frequency sinusoid features (a tracking loss needs a landscape, not white noise)."""
+    g = np.random.default_rng(seed)
+    yy, xx = np.meshgrid(np.arange(fh) / fh, np.arange(fw) / fw, indexing="ij")
+    out = np.zeros((V, fh, fw, C), np.float32)
+    for v in range(V):
+        for c in range(C):
+            a, b = g.uniform(0.5, 2.5, 2) * g.choice([-1, 1], 2)
+            out[v, :, :, c] = np.sin(2 * np.pi * (a * xx + b * yy) + g.uniform(0, 2 * np.pi))
+    return torch.from_numpy(out)
+
+
+def tracking_case(fusion):
+    """Fusion.rigid_tracking (fusion.py:1608-1685) run by the reference on CPU, with pytorch3d's so3_exp_map /
+    Transform3d restated (oracle/pytorch3d_restated.py): two instances x 40 keypoints just above the ground
+    plane, displaced by a small rigid motion that the 100 Adam steps have to undo."""
+    V, H, W = 4, 96, 128
+    sc = synth.make_scene(V, H, W, "smooth")
+    feats = smooth_feature_map(V, 24, 32, 8)
+    obs = dict(sc)
+    obs.update(dino_feats=feats)
+    f = R.make_reference_fusion(fusion, obs, H, W)
+    g = np.random.default_rng(73)
+    n = 40
+    centres = np.array([[-0.22, 0.15, -0.003], [0.15, 0.20, -0.003]], np.float32)   # clear of the spheres
+    true_pts = np.stack([c + np.concatenate([g.uniform(-0.05, 0.05, (n, 2)), np.zeros((n, 1))], 1) for c in centres]).astype(np.float32)
+    with torch.no_grad():
+        src = f.eval(torch.from_numpy(true_pts.reshape(-1, 3)), return_names=["dino_feats"])
+    assert bool(src["valid_mask"].all())
+    # displaced start: rotate each instance about its centre by a few degrees around z and shift it
+    last = []
+    for i, (ang, sh) in enumerate([(4.0, (0.012, -0.009, 0.0)), (-3.0, (-0.008, 0.011, 0.002))]):
+        a = np.deg2rad(ang)
+        Rz = np.array([[np.cos(a), -np.sin(a), 0], [np.sin(a), np.cos(a), 0], [0, 0, 1]], np.float32)
+        last.append(((true_pts[i] - centres[i]) @ Rz.T + centres[i] + np.array(sh, np.float32)).astype(np.float32))
+    info = {"a": {"src_feats": src["dino_feats"][:n]}, "b": {"src_feats": src["dino_feats"][n:]}}
+    res = f.rigid_tracking(info, last, dict(synth.WORK_BOX), n)
+    match = np.stack(res["match_pts_list"])
+    err0 = float(np.abs(np.stack(last) - true_pts).max())
+    err1 = float(np.abs(match - true_pts).max())
+    print("rigid_tracking: max |start - true| = %.4f m, max |tracked - true| = %.4f m" % (err0, err1))
+    save("rigid_tracking", H=H, W=W, mu=f.mu, K=sc["K"].numpy(), pose=sc["pose"].numpy(), depth=sc["depth"].numpy(),
+         in_dino_feats=feats.numpy(), src_feats=src["dino_feats"].numpy(), true_pts=true_pts, last_pts=np.stack(last),
+         match_pts=match, n=n)
+
+
 def main():
     torch.set_num_threads(4)
     fusion, corr = R.import_reference()
@@ -262,6 +308,7 @@ def main():
     grad_case(fusion)
     select_case(fusion)
     pcd_case(fusion)
+    tracking_case(fusion)
 
 
 if __name__ == "__main__":

@@ -72,3 +72,28 @@ def batched_field_query(obs, pts, names, H, W, mu=0.02, chunk=CHUNK):
     """Fusion.batch_eval (fusion.py:526-545): chunk loop + cat."""
     pieces = [field_query(obs, pts[i:i + chunk], names, H, W, mu) for i in range(0, pts.shape[0], chunk)]
     return {k: torch.cat([p[k] for p in pieces], dim=0) for k in pieces[0]} if pieces else {}
+
+
+def rigid_tracking(obs, H, W, src_feats, last_match_pts, mu=0.02, iters=100, lr=0.01, reg_w=1.0, dist_w=100.0):
+    """Fusion.rigid_tracking (fusion.py:1608-1685) in torch ops on the CPU: per-instance translation + axis-angle,
+    Adam, loss = masked descriptor distance + dist_w * positive distance + parameter norms.
+    last_match_pts [I,n,3] -> keypoints [I*n,3] as evaluated in the last iteration (what the reference returns).
+    pytorch3d's so3_exp_map / Transform3d as restated in oracle/pytorch3d_restated.py."""
+    from oracle.pytorch3d_restated import so3_exp_map
+    num_inst = last_match_pts.shape[0]
+    t_params = torch.zeros(num_inst, 3, requires_grad=True)
+    log_r = torch.zeros(num_inst, 3, requires_grad=True)
+    opt = torch.optim.Adam([t_params, log_r], lr=lr, betas=(0.9, 0.999))
+    cur = None
+    for _ in range(iters):
+        rot = so3_exp_map(log_r)
+        cur = (torch.bmm(last_match_pts, rot) + t_params[:, None, :]).reshape(-1, 3)
+        out = field_query(obs, cur, ["dino_feats"], H, W, mu)
+        live = out["valid_mask"]
+        loss = ((torch.norm(out["dino_feats"] - src_feats, dim=-1) * live).mean()
+                + dist_w * torch.clamp(out["dist"] * live, min=0).mean()
+                + reg_w * (torch.norm(t_params) + torch.norm(log_r)))
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+    return cur.detach()

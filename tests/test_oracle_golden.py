@@ -154,3 +154,29 @@ def test_pcd_restatement_matches_reference():
     assert np.array_equal(cols, g["crop_col"])
     md, am = np_pcd.nearest(g["p1"], g["p2"])
     assert np.array_equal(am, g["idx_12"]) and np.array_equal(np.where(md < 0.005)[0], g["overlap_1"])
+
+
+def test_rigid_tracking_restatement_matches_reference():
+    """oracle/torch_port.rigid_tracking vs the reference's Fusion.rigid_tracking (fusion.py:1608-1685; golden written
+    by oracle/gen_golden.py with pytorch3d's two functions restated) -- and the restated so3_exp_map itself."""
+    import torch
+    from scipy.spatial.transform import Rotation
+    from oracle import torch_port as T
+    from oracle.pytorch3d_restated import so3_exp_map, Transform3d
+    g = load_golden("rigid_tracking")
+    obs = {k: torch.from_numpy(g[k]) for k in ("depth", "K", "pose")}
+    obs["dino_feats"] = torch.from_numpy(g["in_dino_feats"])
+    torch.set_num_threads(4)
+    cur = T.rigid_tracking(obs, int(g["H"]), int(g["W"]), torch.from_numpy(g["src_feats"]), torch.from_numpy(g["last_pts"]),
+                           float(g["mu"]))
+    assert np.abs(cur.numpy().reshape(g["match_pts"].shape) - g["match_pts"]).max() <= 1e-5
+    # the tracker moved the keypoints towards the truth (15 mm -> 5 mm in the fixture)
+    assert np.abs(g["match_pts"] - g["true_pts"]).max() < 0.5 * np.abs(g["last_pts"] - g["true_pts"]).max()
+    w = torch.tensor([[0.1, -0.3, 0.2], [0.0, 0.0, 0.0], [1e-3, 0.0, 0.0], [2.0, 1.0, -0.5]])
+    R = so3_exp_map(w)
+    assert np.abs(R.numpy() - Rotation.from_rotvec(w.numpy()).as_matrix()).max() <= 1e-6
+    assert np.abs((R @ R.transpose(1, 2)).numpy() - np.eye(3)).max() <= 1e-6
+    x = torch.randn(4, 5, 3, generator=torch.Generator().manual_seed(0))
+    t = torch.tensor([[1.0, 2.0, 3.0]]).expand(4, 3)
+    got = Transform3d().rotate(R).translate(t).transform_points(x)
+    assert torch.allclose(got, torch.bmm(x, R) + t[:, None, :], atol=1e-6)      # row-vector convention
