@@ -482,6 +482,36 @@ class Fusion:
                 last_label = label[i]
         return src_feats_list, src_pts_list, []
 
+    def select_features_from_pcd(self, pcd, N, per_instance=False, init_idx=-1, vis=False):
+        """Reference Fusion.select_features_from_pcd (fusion.py:1477-1537): like select_features_rand, but the
+        candidates are the points of `pcd` ((M,3) numpy array) instead of a voxel grid: keep |dist| < 5 mm & valid &
+        normalised mask of the instance > 0.6, farthest-point-sample N of them, query their descriptors.  Instances
+        without a candidate are skipped, as in the reference.  Returns (src_feats_list, src_pts_list, img_list);
+        the cv2 debug rendering (vis=True) is upstream tooling and is not provided."""
+        if vis:
+            raise NotImplementedError("vis=True draws keypoints with cv2 in the reference; not part of the field query")
+        dist_threshold = 0.005
+        dev = torch.device(self.device)
+        label = self.curr_obs_torch["consensus_mask_label"]
+        with torch.no_grad():
+            pcd_t = _as_device_tensor(np.asarray(pcd), torch.float32, dev)
+            out = self.batch_eval(pcd_t, return_names=["mask"])
+            near = (out["dist"].abs() < dist_threshold) & out["valid_mask"]
+            mask = out["mask"] / (out["mask"].sum(dim=1, keepdim=True) + 1e-7)
+            src_feats_list, src_pts_list = [], []
+            last_label = label[0]
+            for i in range(1, len(label)):
+                if label[i] == last_label and not per_instance:
+                    continue
+                masked_pts = pcd_t[(mask[:, i] > 0.6) & near]
+                if masked_pts.shape[0] == 0:
+                    continue
+                sample_pts, _, _ = fps(masked_pts, N, init_idx=init_idx)
+                src_feats_list.append(self.eval(sample_pts)["dino_feats"])
+                src_pts_list.append(sample_pts.cpu().numpy())
+                last_label = label[i]
+        return src_feats_list, src_pts_list, []
+
     def rigid_tracking(self, src_feat_info, last_match_pts_list, boundaries, rand_ptcl_num):
         """Per-instance SE(3) tracking of keypoints (reference fusion.py:1608-1685): 100 Adam steps (lr 0.01) on
         translation + axis-angle parameters, loss = masked descriptor distance + 100 * positive distance + parameter

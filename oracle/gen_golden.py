@@ -219,6 +219,13 @@ def select_case(fusion):
     for i, (a, b) in enumerate(zip(feats_l, pts_l)):
         arrays["sel_feats_%d" % i] = a.numpy()
         arrays["sel_pts_%d" % i] = b
+    # select_features_from_pcd (fusion.py:1477-1537) on a jittered copy of the shell points
+    cloud = (grid[shell].numpy() + np.random.default_rng(5).normal(0, 0.002, (int(shell.sum()), 3))).astype(np.float32)
+    pf, pp, _ = f.select_features_from_pcd(cloud, 16, per_instance=True, init_idx=0)
+    arrays.update(pcd_cloud=cloud, pcd_n_inst=len(pp))
+    for i, (a, b) in enumerate(zip(pf, pp)):
+        arrays["pcd_feats_%d" % i] = a.numpy()
+        arrays["pcd_pts_%d" % i] = b
     save("select_features", **arrays)
 
 

@@ -717,6 +717,17 @@ def test_select_features_rand_matches_reference(dev):
         assert rel_err(cpu(feats_l[i]), g["sel_feats_%d" % i]) <= TOL
 
 
+def test_select_features_from_pcd_matches_reference(dev):
+    g, f, _ = _select_fusion(dev)
+    feats_l, pts_l, imgs = f.select_features_from_pcd(g["pcd_cloud"], 16, per_instance=True, init_idx=0)
+    assert len(pts_l) == int(g["pcd_n_inst"]) == len(feats_l) and imgs == []
+    for i in range(len(pts_l)):
+        assert np.array_equal(pts_l[i], g["pcd_pts_%d" % i]), i
+        assert rel_err(cpu(feats_l[i]), g["pcd_feats_%d" % i]) <= TOL
+    with pytest.raises(NotImplementedError):
+        f.select_features_from_pcd(g["pcd_cloud"], 16, vis=True)
+
+
 def test_fast_path_is_bit_identical_to_strict_path(dev):
     """Finite-map fast path (invalid-view skip, weight-zero padding, precomputed corner set-up, hand-unrolled
     shared-reciprocal division) against the strict path (every view sampled, value selects, IEEE '/'):
