@@ -40,6 +40,8 @@ WORKLOADS = {
     "c3_dense": dict(V=4, H=480, W=640, C=384, fhw=(480, 640), NI=8, step=0.004, N=1925000),
     "c3_patch": dict(V=4, H=480, W=640, C=384, fhw=(48, 64), NI=8, step=0.004, N=1925000),
     "c4_patch": dict(V=8, H=720, W=1280, C=1024, fhw=(72, 128), NI=0, step=None, N=1000000),
+    # dense variant of config 4: 30.2 GB of feature maps per GPU (3.77 GB per view, just inside the 32-bit texel offsets)
+    "c4_dense": dict(V=8, H=720, W=1280, C=1024, fhw=(720, 1280), NI=0, step=None, N=1000000),
     # BASELINE config 5: one tracking frame = Fusion.eval of 100 k keypoints (features + instance mask) followed by the
     # descriptor correspondence of utils/corr_utils.py against 300 reference descriptors (+ fused argmax)
     "c5_track": dict(V=4, H=480, W=640, C=384, fhw=(48, 64), NI=8, step=None, N=100000, corr_refs=300),
@@ -234,14 +236,18 @@ def main():
     def compute():
         out = f.batch_eval(pts, return_names=names)
         if corr_src is not None:        # keypoint descriptors vs reference descriptors: softmax similarity + best match
-            out["similarity"], out["match"] = corr_utils.nearest_descriptor(out["dino_feats"], corr_src, 1.0)
+            if dist_on:                 # softmax(dim=0) runs over ALL ranks' keypoints: one 16-B record per reference exchanged
+                out["similarity"], out["match"] = sharding.sharded_similarity_multi(out["dino_feats"], corr_src, 1.0,
+                                                                                    row_offset=rank * n)
+            else:
+                out["similarity"], out["match"] = corr_utils.nearest_descriptor(out["dino_feats"], corr_src, 1.0)
         return out
 
     def step():
         out = compute()
         if dist_on and args.gather != "none":
-            keys = ("dist", "valid_mask") if args.gather == "dist" else tuple(out.keys())
-            sharding.all_gather_field(out, keys=keys, counts=[n] * world)
+            keys = ("dist", "valid_mask") if args.gather == "dist" else tuple(k for k in out if k != "match")
+            sharding.all_gather_field({k: out[k] for k in keys}, keys=keys, counts=[n] * world)
         return out
 
     with torch.no_grad():
@@ -255,7 +261,8 @@ def main():
             extra["compute_only_points_per_s"] = world * n * args.steps / time_steps(compute, args.steps, True, dev)
             if args.gather != "full":
                 def full():
-                    sharding.all_gather_field(compute(), keys=None, counts=[n] * world)
+                    o = compute()
+                    sharding.all_gather_field(o, keys=[k for k in o if k != "match"], counts=[n] * world)
                 full()
                 fs = max(2, args.steps // 4)
                 extra["full_field_gather_points_per_s"] = world * n * fs / time_steps(full, fs, True, dev)

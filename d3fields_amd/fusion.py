@@ -252,6 +252,8 @@ class Fusion:
         sig = (t.data_ptr(), t._version, tuple(t.shape))
         hit = self._finite_cache.get(key)
         if hit is None or hit[0] != sig:
+            if torch.cuda.is_current_stream_capturing():
+                return False                    # no host sync inside a HIP-graph capture: strict path, same results
             hit = (sig, bool(torch.isfinite(t).all().item()))
             self._finite_cache[key] = hit
         return hit[1]
@@ -264,6 +266,8 @@ class Fusion:
         sig = (pts_c.data_ptr(), pts_c._version, pts_c.shape[0])
         hit = self._order_cache
         if hit is None or hit[0] != sig:
+            if torch.cuda.is_current_stream_capturing():
+                return False                    # no host sync inside a HIP-graph capture
             out = torch.empty(2, dtype=torch.float32, device=pts_c.device)
             _lib.check(self._lib.d3f_point_order_locality(_lib.ptr(pts_c), pts_c.shape[0], _lib.ptr(out), stream))
             near, far = out.tolist()

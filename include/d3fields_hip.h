@@ -52,7 +52,7 @@ extern "C" {
                                         only -- results never depend on it.                              */
 
 /* Tuning bits of `flags` (performance experiments; results never depend on them):
- *   bits 8..11  log2 of the points per workgroup (5..8), 0 = automatic
+ *   bits 8..11  log2 of the points per workgroup (2..8), 0 = automatic
  *   bit  12     invert the default XCD mapping (default: XCD-contiguous tile ranges on the Morton walk,
  *               round-robin otherwise)
  *   bit  13     never reorder points, even when a workspace is supplied

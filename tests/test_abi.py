@@ -115,7 +115,7 @@ def test_launch_plan_host_logic():
     p = _plan(4, 480, 640, 985600, [(48, 64, 384)], flags=_lib.FLAG_UNORDERED_POINTS, ws=0)
     assert p.reorder == 0                                      # no scratch, no walk
     assert _plan(4, 480, 640, 60000, [(48, 64, 384)], flags=_lib.FLAG_UNORDERED_POINTS).reorder == 0
-    # C2 dense: 1.9 GB of maps -> Morton walk, 32-point tiles, load-use per vector; without scratch: 64-point tiles
+    # C2 dense: 1.9 GB of maps -> Morton walk, 8-point tiles, 3 batched float4 per lane; without scratch: 64-point tiles
     p = _plan(4, 480, 640, 985600, [(480, 640, 384)])
     assert (p.tile_points, p.reorder, p.vectors_per_lane[0]) == (8, 1, 3)
     p = _plan(4, 480, 640, 985600, [(480, 640, 384)], ws=0)
