@@ -55,13 +55,30 @@ hipError_t launch_dist_to_target(const float *src, int64_t B, int64_t inner, int
 //    the 16 lanes of a ds_read_b128 group read 16 consecutive float4 (conflict-free) or one address
 //    (broadcast); 8 b128 reads feed 64 (difference, square-accumulate) pairs.
 //  * the arithmetic is packed: d = a - b as two v_pk_add_f32, acc2 += d*d as two v_pk_fma_f32 on a float2
-//    accumulator (even / odd channels), i.e. one VALU instruction per (pair, channel).
+//    accumulator (even / odd channels), i.e. one VALU instruction per (pair, channel).  The target stage is
+//    stored NEGATED in LDS: the compiler has no packed form for a vector fsub (it emitted 64 scalar v_sub_f32
+//    per float4 step), while a + (-b) is a v_pk_add_f32 and the same IEEE result bit for bit.
 // fp32 VALU bound: 3*B1*B2*C flop (sub, mul, add).
 constexpr int kPT = 64, kPK = 32;
+static_assert(kPT == kSoftmaxRowsPerBlock, "the fused column statistics use one row tile per statistics chunk");
+
+// merges two running (max, sum-exp, first-argmax) triples of the same column
+__device__ __forceinline__ void merge_stat(float &m, float &s, int64_t &arg, float m2, float s2, int64_t arg2)
+{
+    const bool take2 = (m2 > m) || (m2 == m && arg2 < arg);
+    const float M = fmaxf(m, m2);
+    const float sa = (m == -INFINITY) ? 0.0f : s * expf(m - M);
+    const float sb = (m2 == -INFINITY) ? 0.0f : s2 * expf(m2 - M);
+    s = sa + sb;
+    m = M;
+    arg = take2 ? arg2 : arg;
+}
+
 
 __global__ __launch_bounds__(kBlock) void pairwise_dist_kernel(const float *__restrict__ src,
                                                               const float *__restrict__ tgt, int64_t B1, int64_t B2,
-                                                              int C, int dist_type, float *__restrict__ out)
+                                                              int C, int dist_type, float *__restrict__ out,
+                                                              ColStat *__restrict__ ws, float stat_scale)
 {
     __shared__ f32x4 As[kPK / 4][kPT];
     __shared__ f32x4 Bs[kPK / 4][kPT];
@@ -104,7 +121,7 @@ __global__ __launch_bounds__(kBlock) void pairwise_dist_kernel(const float *__re
         for (int h = 0; h < 2; ++h) {
             const int e = threadIdx.x + h * kBlock;
             As[e / kPT][e % kPT] = pa[h];
-            Bs[e / kPT][e % kPT] = pb[h];
+            Bs[e / kPT][e % kPT] = -pb[h];
         }
         __syncthreads();
         if (k0 + kPK < C) fetch(k0 + kPK);
@@ -116,37 +133,94 @@ __global__ __launch_bounds__(kBlock) void pairwise_dist_kernel(const float *__re
                 a[q] = As[k4][ty + 16 * q];
                 b[q] = Bs[k4][tx + 16 * q];
             }
+            // per row q: the four differences first, then the even-pair FMAs, then the odd-pair FMAs, so the two
+            // dependent v_pk_fma_f32 of one accumulator are four issue slots apart (back to back they cost an s_nop)
 #pragma unroll
-            for (int q = 0; q < 4; ++q)
+            for (int q = 0; q < 4; ++q) {
+                f32x4 d[4];
+#pragma unroll
+                for (int w = 0; w < 4; ++w) d[w] = a[q] + b[w];               // b holds -tgt
 #pragma unroll
                 for (int w = 0; w < 4; ++w) {
-                    const f32x4 d = a[q] - b[w];
-                    const f32x2 lo = __builtin_shufflevector(d, d, 0, 1), hi = __builtin_shufflevector(d, d, 2, 3);
+                    const f32x2 lo = __builtin_shufflevector(d[w], d[w], 0, 1);
                     acc[q][w] = __builtin_elementwise_fma(lo, lo, acc[q][w]);
+                }
+#pragma unroll
+                for (int w = 0; w < 4; ++w) {
+                    const f32x2 hi = __builtin_shufflevector(d[w], d[w], 2, 3);
                     acc[q][w] = __builtin_elementwise_fma(hi, hi, acc[q][w]);
                 }
+            }
         }
         __syncthreads();
     }
+    float dv[4][4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const int64_t i = i0 + ty + 16 * q;
-        if (i >= B1) continue;
 #pragma unroll
         for (int w = 0; w < 4; ++w) {
             const int64_t j = j0 + tx + 16 * w;
             const float ssum = acc[q][w].x + acc[q][w].y;
-            if (j < B2) out[i * B2 + j] = dist_type == D3F_DIST_L2 ? sqrtf(ssum) : ssum;
+            dv[q][w] = dist_type == D3F_DIST_L2 ? sqrtf(ssum) : ssum;
+            if (i < B1 && j < B2) out[i * B2 + j] = dv[q][w];
         }
+    }
+    if (!ws) return;                               // uniform
+    // Fused column statistics of softmax(-d*stat_scale, dim=0) over this tile's 64 rows (what softmax_stats_kernel
+    // would compute in a second pass over `out`): per lane its 4 rows in ascending order, then the 4 lane-rows of
+    // the wave by shuffles, then the 4 waves through LDS; ws[row tile][column].
+    ColStat *red = reinterpret_cast<ColStat *>(&As[0][0]);          // [4 waves][64 columns] = 4 KiB, stage buffer is free
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        float m = -INFINITY, sum = 0.0f;
+        int64_t arg = 0x7fffffffffffffffLL;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int64_t i = i0 + ty + 16 * q;
+            if (i < B1) {
+                const float v = -dv[q][w] * stat_scale;
+                if (v > m) {
+                    sum = sum * expf(m - v) + 1.0f;
+                    m = v;
+                    arg = i;
+                } else {
+                    sum += expf(v - m);
+                }
+            }
+        }
+#pragma unroll
+        for (int off = 16; off <= 32; off <<= 1) {
+            const float m2 = __shfl_xor(m, off, 64), s2 = __shfl_xor(sum, off, 64);
+            const int64_t a2 = __shfl_xor(arg, off, 64);
+            merge_stat(m, sum, arg, m2, s2, a2);
+        }
+        if ((threadIdx.x & 63) < 16) {
+            ColStat o;
+            o.m = m; o.s = sum; o.arg = arg;
+            red[(threadIdx.x >> 6) * kPT + tx + 16 * w] = o;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < kPT && j0 + threadIdx.x < B2) {
+        ColStat t = red[threadIdx.x];
+#pragma unroll
+        for (int wv = 1; wv < kBlock / 64; ++wv) {
+            const ColStat u = red[wv * kPT + threadIdx.x];
+            merge_stat(t.m, t.s, t.arg, u.m, u.s, u.arg);
+        }
+        ws[(int64_t)blockIdx.y * B2 + j0 + threadIdx.x] = t;
     }
 }
 
+// ws != nullptr: also writes the column statistics of softmax(-d*stat_scale, dim=0) per 64-row tile into
+// ws[tile][column] (the layout softmax_merge_kernel reads), saving the separate pass over `out`
 hipError_t launch_pairwise_dist(const float *src, const float *tgt, int64_t B1, int64_t B2, int C, int dist_type,
-                                float *out, hipStream_t s)
+                                float *out, hipStream_t s, ColStat *ws, float stat_scale)
 {
     if (B1 == 0 || B2 == 0) return hipSuccess;
     dim3 grid((unsigned)((B2 + kPT - 1) / kPT), (unsigned)((B1 + kPT - 1) / kPT));
-    hipLaunchKernelGGL(pairwise_dist_kernel, grid, dim3(kBlock), 0, s, src, tgt, B1, B2, C, dist_type, out);
+    hipLaunchKernelGGL(pairwise_dist_kernel, grid, dim3(kBlock), 0, s, src, tgt, B1, B2, C, dist_type, out, ws, stat_scale);
     return hipGetLastError();
 }
 
@@ -174,9 +248,9 @@ hipError_t launch_exp_neg_scale(float *x, int64_t n, float scale, hipStream_t s)
 __global__ __launch_bounds__(kBlock) void softmax_stats_kernel(const float *__restrict__ x, int64_t rows,
                                                               int64_t cols, float scale, ColStat *__restrict__ ws)
 {
-    const int64_t j = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    const int64_t j = (int64_t)blockIdx.y * kBlock + threadIdx.x;
     if (j >= cols) return;
-    const int64_t r0 = (int64_t)blockIdx.y * kSoftmaxRowsPerBlock;
+    const int64_t r0 = (int64_t)blockIdx.x * kSoftmaxRowsPerBlock;
     const int64_t r1 = min(rows, r0 + kSoftmaxRowsPerBlock);
     float m = -INFINITY, s = 0.0f;
     int64_t arg = r0;
@@ -192,22 +266,12 @@ __global__ __launch_bounds__(kBlock) void softmax_stats_kernel(const float *__re
     }
     ColStat o;
     o.m = m; o.s = s; o.arg = arg;
-    ws[(int64_t)blockIdx.y * cols + j] = o;
+    ws[(int64_t)blockIdx.x * cols + j] = o;
 }
 
 // One WAVE per column: lanes stride over the row chunks, then a shuffle reduction merges the running
 // (max, sum-exp, first-argmax) triples.  (A lane-per-column loop over ~400 chunks was latency-bound: 0.16 ms
 // for 300 columns.)
-__device__ __forceinline__ void merge_stat(float &m, float &s, int64_t &arg, float m2, float s2, int64_t arg2)
-{
-    const bool take2 = (m2 > m) || (m2 == m && arg2 < arg);
-    const float M = fmaxf(m, m2);
-    const float sa = (m == -INFINITY) ? 0.0f : s * expf(m - M);
-    const float sb = (m2 == -INFINITY) ? 0.0f : s2 * expf(m2 - M);
-    s = sa + sb;
-    m = M;
-    arg = take2 ? arg2 : arg;
-}
 
 // `in` [nchunks, cols] -> `out` [cols]; arg_offset shifts the winning row index (a rank's first global row when
 // the rows are sharded over GPUs; 0 otherwise).  nchunks == 0 writes the identity (-inf, 0, INT64_MAX).
@@ -254,13 +318,15 @@ static void merge_launch(const ColStat *in, int64_t nchunks, int64_t cols, ColSt
                        nchunks, cols, out, argmax_out, arg_offset);
 }
 
+// have_stats: ws[chunk][column] was already filled by the producer of x (pairwise_dist_kernel's epilogue)
 static hipError_t softmax_impl(float *x, int64_t rows, int64_t cols, float scale, int64_t *argmax_out, ColStat *ws,
-                               bool normalise, hipStream_t s)
+                               bool normalise, bool have_stats, hipStream_t s)
 {
     if (rows == 0 || cols == 0) return hipSuccess;
     const int64_t nchunks = (rows + kSoftmaxRowsPerBlock - 1) / kSoftmaxRowsPerBlock;
     const unsigned gx = (unsigned)((cols + kBlock - 1) / kBlock);
-    hipLaunchKernelGGL(softmax_stats_kernel, dim3(gx, (unsigned)nchunks), dim3(kBlock), 0, s, x, rows, cols, scale, ws);
+    if (!have_stats)
+        hipLaunchKernelGGL(softmax_stats_kernel, dim3((unsigned)nchunks, gx), dim3(kBlock), 0, s, x, rows, cols, scale, ws);
     merge_launch(ws, nchunks, cols, ws + nchunks * cols, argmax_out, 0, s);
     if (normalise) {
         const int64_t total = rows * cols;
@@ -273,13 +339,13 @@ static hipError_t softmax_impl(float *x, int64_t rows, int64_t cols, float scale
 // ---- row-sharded softmax (shard B1 over GPUs, exchange 16 B per column) --------------
 // local statistics of this rank's rows (global row index = row_offset + local row); rows == 0 gives the identity
 hipError_t launch_softmax_local_stats(const float *x, int64_t rows, int64_t cols, float scale, int64_t row_offset,
-                                      ColStat *ws, ColStat *stats_out, hipStream_t s)
+                                      ColStat *ws, ColStat *stats_out, bool have_stats, hipStream_t s)
 {
     if (cols == 0) return hipSuccess;
     const int64_t nchunks = (rows + kSoftmaxRowsPerBlock - 1) / kSoftmaxRowsPerBlock;
-    if (nchunks > 0) {
+    if (nchunks > 0 && !have_stats) {
         const unsigned gx = (unsigned)((cols + kBlock - 1) / kBlock);
-        hipLaunchKernelGGL(softmax_stats_kernel, dim3(gx, (unsigned)nchunks), dim3(kBlock), 0, s, x, rows, cols, scale, ws);
+        hipLaunchKernelGGL(softmax_stats_kernel, dim3((unsigned)nchunks, gx), dim3(kBlock), 0, s, x, rows, cols, scale, ws);
     }
     merge_launch(ws, nchunks, cols, stats_out, nullptr, row_offset, s);
     return hipGetLastError();
@@ -304,15 +370,15 @@ hipError_t launch_softmax_apply(float *x, int64_t rows, int64_t cols, float scal
 }
 
 hipError_t launch_softmax_dim0(float *x, int64_t rows, int64_t cols, float scale, int64_t *argmax_out, ColStat *ws,
-                               hipStream_t s)
+                               bool have_stats, hipStream_t s)
 {
-    return softmax_impl(x, rows, cols, scale, argmax_out, ws, true, s);
+    return softmax_impl(x, rows, cols, scale, argmax_out, ws, true, have_stats, s);
 }
 
 hipError_t launch_argmin_dim0(const float *x, int64_t rows, int64_t cols, int64_t *arg_out, ColStat *ws,
-                              hipStream_t s)
+                              bool have_stats, hipStream_t s)
 {
-    return softmax_impl(const_cast<float *>(x), rows, cols, 1.0f, arg_out, ws, false, s);
+    return softmax_impl(const_cast<float *>(x), rows, cols, 1.0f, arg_out, ws, false, have_stats, s);
 }
 
 }  // namespace d3f

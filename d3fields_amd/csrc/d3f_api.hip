@@ -486,7 +486,7 @@ int d3f_similarity_to_target(const float *src, int64_t B, int64_t inner, int32_t
         e = d3f::launch_exp_neg_scale(out, B * inner, scale, s);
         if (e != hipSuccess) return hip_fail(e, "exp launch");
     } else if (mode == D3F_SIM_SOFTMAX_DIM0) {
-        e = d3f::launch_softmax_dim0(out, B, inner, scale, nullptr, static_cast<d3f::ColStat *>(workspace), s);
+        e = d3f::launch_softmax_dim0(out, B, inner, scale, nullptr, static_cast<d3f::ColStat *>(workspace), false, s);
         if (e != hipSuccess) return hip_fail(e, "softmax launch");
     }
     return D3F_OK;
@@ -506,15 +506,17 @@ int d3f_pairwise_similarity(const float *src, const float *tgt, int64_t B1, int6
     if (need_ws && (!workspace || workspace_bytes < d3f_softmax_workspace_bytes(B1, B2)))
         return fail(D3F_ERR_WORKSPACE, "pairwise: needs %lld workspace bytes", (long long)d3f_softmax_workspace_bytes(B1, B2));
     hipStream_t s = static_cast<hipStream_t>(stream);
-    hipError_t e = d3f::launch_pairwise_dist(src, tgt, B1, B2, C, dist_type, out, s);
-    if (e != hipSuccess) return hip_fail(e, "pairwise_dist launch");
     d3f::ColStat *ws = static_cast<d3f::ColStat *>(workspace);
+    // the column statistics (softmax / best match) come out of the distance kernel's epilogue, per 64-row tile
+    hipError_t e = d3f::launch_pairwise_dist(src, tgt, B1, B2, C, dist_type, out, s, need_ws ? ws : nullptr,
+                                             mode == D3F_SIM_SOFTMAX_DIM0 ? scale : 1.0f);
+    if (e != hipSuccess) return hip_fail(e, "pairwise_dist launch");
     if (mode == D3F_SIM_SOFTMAX_DIM0) {
-        e = d3f::launch_softmax_dim0(out, B1, B2, scale, argmax_out, ws, s);
+        e = d3f::launch_softmax_dim0(out, B1, B2, scale, argmax_out, ws, true, s);
         if (e != hipSuccess) return hip_fail(e, "softmax launch");
     } else {
         if (argmax_out) {   // best match = smallest distance, decided before exp() can tie values
-            e = d3f::launch_argmin_dim0(out, B1, B2, argmax_out, ws, s);
+            e = d3f::launch_argmin_dim0(out, B1, B2, argmax_out, ws, true, s);
             if (e != hipSuccess) return hip_fail(e, "argmin launch");
         }
         if (mode == D3F_SIM_EXP) {
@@ -543,11 +545,11 @@ int d3f_pairwise_softmax_local(const float *src, const float *tgt, int64_t B1, i
     hipStream_t s = static_cast<hipStream_t>(stream);
     hipError_t e = hipSuccess;
     if (B1 > 0) {
-        e = d3f::launch_pairwise_dist(src, tgt, B1, B2, C, dist_type, out, s);
+        e = d3f::launch_pairwise_dist(src, tgt, B1, B2, C, dist_type, out, s, static_cast<d3f::ColStat *>(workspace), scale);
         if (e != hipSuccess) return hip_fail(e, "pairwise_dist launch");
     }
     e = d3f::launch_softmax_local_stats(out, B1, B2, scale, row_offset, static_cast<d3f::ColStat *>(workspace),
-                                        reinterpret_cast<d3f::ColStat *>(stats), s);
+                                        reinterpret_cast<d3f::ColStat *>(stats), true, s);
     return e == hipSuccess ? D3F_OK : hip_fail(e, "softmax statistics launch");
 }
 

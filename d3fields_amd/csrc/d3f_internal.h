@@ -98,23 +98,23 @@ struct ColStat {   // running softmax statistics of one column (16 B)
     float s;       // sum exp(x - m)
     int64_t arg;   // row index of the first maximum
 };
-constexpr int kSoftmaxRowsPerBlock = 256;
+constexpr int kSoftmaxRowsPerBlock = 64;     // = the row tile of pairwise_dist_kernel, whose epilogue emits the statistics
 hipError_t launch_dist_to_target(const float *src, int64_t B, int64_t inner, int C, int64_t sb, int64_t si,
                                  int64_t sc, const float *tgt, int dist_type, float *out, hipStream_t s);
 hipError_t launch_pairwise_dist(const float *src, const float *tgt, int64_t B1, int64_t B2, int C,
-                                int dist_type, float *out, hipStream_t s);
+                                int dist_type, float *out, hipStream_t s, ColStat *ws = nullptr, float stat_scale = 1.0f);
 hipError_t launch_exp_neg_scale(float *x, int64_t n, float scale, hipStream_t s);
 // softmax(-x*scale, dim=0) of a row-major [rows, cols] matrix in place (+ optional argmax)
 hipError_t launch_softmax_dim0(float *x, int64_t rows, int64_t cols, float scale, int64_t *argmax_out,
-                               ColStat *ws, hipStream_t s);
+                               ColStat *ws, bool have_stats, hipStream_t s);
 // row-sharded softmax: local column statistics, cross-rank merge, normalisation with merged statistics
 hipError_t launch_softmax_local_stats(const float *x, int64_t rows, int64_t cols, float scale, int64_t row_offset,
-                                      ColStat *ws, ColStat *stats_out, hipStream_t s);
+                                      ColStat *ws, ColStat *stats_out, bool have_stats, hipStream_t s);
 hipError_t launch_softmax_merge(const ColStat *parts, int64_t nparts, int64_t cols, ColStat *merged, int64_t *argmax_out,
                                 hipStream_t s);
 hipError_t launch_softmax_apply(float *x, int64_t rows, int64_t cols, float scale, const ColStat *merged, hipStream_t s);
 // argmin over dim 0 of raw distances (used for D3F_SIM_DIST + argmax_out)
 hipError_t launch_argmin_dim0(const float *x, int64_t rows, int64_t cols, int64_t *arg_out, ColStat *ws,
-                              hipStream_t s);
+                              bool have_stats, hipStream_t s);
 
 }  // namespace d3f

@@ -227,7 +227,7 @@ int d3f_instance2onehot(const uint8_t *instance, int64_t n, int32_t NI, uint8_t 
                                                           compute_similarity_tensor_multi :63-106 */
 
 /* Device scratch needed by the D3F_SIM_SOFTMAX_DIM0 mode (and by argmax_out) for a
- * [rows, cols] result: per-column running max / sum-exp / argmax of each 256-row chunk. */
+ * [rows, cols] result: per-column running max / sum-exp / argmax of each 64-row chunk. */
 int64_t d3f_softmax_workspace_bytes(int64_t rows, int64_t cols);
 
 /* Feature map vs ONE target descriptor.  src holds B*inner descriptors of C channels:

@@ -89,7 +89,7 @@ def test_workspace_size():
     assert lib.d3f_eval_workspace_bytes(1000000) >= 16 * 1000000
     assert lib.d3f_softmax_workspace_bytes(0, 10) == 0
     assert lib.d3f_softmax_workspace_bytes(1, 1) == 2 * 16
-    assert lib.d3f_softmax_workspace_bytes(100000, 300) == (391 + 1) * 300 * 16
+    assert lib.d3f_softmax_workspace_bytes(100000, 300) == (1563 + 1) * 300 * 16      # one 16-B record per 64-row tile and column
 
 
 def _plan(V, H, W, n, maps, flags=0, ws=1, inter=0):
