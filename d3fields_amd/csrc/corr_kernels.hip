@@ -75,6 +75,11 @@ __device__ __forceinline__ void merge_stat(float &m, float &s, int64_t &arg, flo
 }
 
 
+// FAST (host-checked: 16-B aligned operands, C a multiple of the 32-channel stage, operands below 2^30 floats):
+// every lane's two float4 loads per operand and stage go through a uniform base + a loop-invariant 32-bit offset,
+// with rows beyond the matrix clamped to the last row (their results are never stored), so the fetch costs no
+// per-element bounds or address arithmetic -- the generic path spent 22 % of its VALU instructions there.
+template <bool FAST>
 __global__ __launch_bounds__(kBlock) void pairwise_dist_kernel(const float *__restrict__ src,
                                                               const float *__restrict__ tgt, int64_t B1, int64_t B2,
                                                               int C, int dist_type, float *__restrict__ out,
@@ -94,7 +99,24 @@ __global__ __launch_bounds__(kBlock) void pairwise_dist_kernel(const float *__re
     // software pipeline: the next stage's global loads are issued (into registers) before the current stage
     // is consumed; lane -> (row, k/4) pairs e = tid, tid + 256 of the 64 x 8 float4 stage
     f32x4 pa[2], pb[2];
+    uint32_t aoff[2], boff[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int e = threadIdx.x + h * kBlock;
+        const int r = e % kPT, k4 = e / kPT;
+        aoff[h] = (uint32_t)(min(i0 + r, B1 - 1) * C + k4 * 4);
+        boff[h] = (uint32_t)(min(j0 + r, B2 - 1) * C + k4 * 4);
+    }
     auto fetch = [&](int k0) {
+        if (FAST) {
+            const float *sa = src + k0, *sb = tgt + k0;          // uniform bases
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                pa[h] = *reinterpret_cast<const f32x4 *>(sa + aoff[h]);
+                pb[h] = *reinterpret_cast<const f32x4 *>(sb + boff[h]);
+            }
+            return;
+        }
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             const int e = threadIdx.x + h * kBlock;
@@ -173,27 +195,31 @@ __global__ __launch_bounds__(kBlock) void pairwise_dist_kernel(const float *__re
     ColStat *red = reinterpret_cast<ColStat *>(&As[0][0]);          // [4 waves][64 columns] = 4 KiB, stage buffer is free
 #pragma unroll
     for (int w = 0; w < 4; ++w) {
-        float m = -INFINITY, sum = 0.0f;
-        int64_t arg = 0x7fffffffffffffffLL;
+        // maximum over the wave's 16 rows of this column first (cheap fmax shuffles), then ONE expf per element
+        float v[4], m = -INFINITY;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
+            v[q] = (i0 + ty + 16 * q < B1) ? -dv[q][w] * stat_scale : -INFINITY;
+            m = fmaxf(m, v[q]);                    // NaN rows are caught by the sum below
+        }
+        m = fmaxf(m, __shfl_xor(m, 16, 64));
+        m = fmaxf(m, __shfl_xor(m, 32, 64));
+        float sum = 0.0f;
+        int64_t arg = 0x7fffffffffffffffLL;
+#pragma unroll
+        for (int q = 3; q >= 0; --q) {
             const int64_t i = i0 + ty + 16 * q;
             if (i < B1) {
-                const float v = -dv[q][w] * stat_scale;
-                if (v > m) {
-                    sum = sum * expf(m - v) + 1.0f;
-                    m = v;
-                    arg = i;
-                } else {
-                    sum += expf(v - m);
-                }
+                sum += expf(v[q] - m);             // exp(-inf - -inf) cannot occur: a live row makes m finite or NaN
+                if (v[q] == m) arg = i;            // descending q: the smallest row index wins
             }
         }
+        sum += __shfl_xor(sum, 16, 64);
+        sum += __shfl_xor(sum, 32, 64);
 #pragma unroll
         for (int off = 16; off <= 32; off <<= 1) {
-            const float m2 = __shfl_xor(m, off, 64), s2 = __shfl_xor(sum, off, 64);
             const int64_t a2 = __shfl_xor(arg, off, 64);
-            merge_stat(m, sum, arg, m2, s2, a2);
+            arg = a2 < arg ? a2 : arg;
         }
         if ((threadIdx.x & 63) < 16) {
             ColStat o;
@@ -220,7 +246,12 @@ hipError_t launch_pairwise_dist(const float *src, const float *tgt, int64_t B1, 
 {
     if (B1 == 0 || B2 == 0) return hipSuccess;
     dim3 grid((unsigned)((B2 + kPT - 1) / kPT), (unsigned)((B1 + kPT - 1) / kPT));
-    hipLaunchKernelGGL(pairwise_dist_kernel, grid, dim3(kBlock), 0, s, src, tgt, B1, B2, C, dist_type, out, ws, stat_scale);
+    const bool fast = (C % kPK == 0) && ((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(tgt)) % 16 == 0) &&
+                      B1 * (int64_t)C < (1LL << 30) && B2 * (int64_t)C < (1LL << 30);
+    if (fast)
+        hipLaunchKernelGGL(pairwise_dist_kernel<true>, grid, dim3(kBlock), 0, s, src, tgt, B1, B2, C, dist_type, out, ws, stat_scale);
+    else
+        hipLaunchKernelGGL(pairwise_dist_kernel<false>, grid, dim3(kBlock), 0, s, src, tgt, B1, B2, C, dist_type, out, ws, stat_scale);
     return hipGetLastError();
 }
 
