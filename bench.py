@@ -294,7 +294,8 @@ def main():
                      "kernel_ms_min": k_min, "algorithmic_bytes_per_launch": bytes_alg,
                      "algorithmic_bytes_per_point": per_pt, "kernel_points_per_s": n / (k_avg * 1e-3),
                      "step_device_ms_avg": s_avg, "logical_gather_bytes_per_point": b_gather,
-                     "logical_gather_GBps": n * b_gather / (k_avg * 1e-3) / 1e9, "note": "achieved = algorithmic bytes / kernel_ms_avg (HIP events around the "
+                     "logical_gather_GBps": n * b_gather / (k_avg * 1e-3) / 1e9,
+                     "traffic_GBps": (traffic / (k_avg * 1e-3) / 1e9) if traffic else None, "note": "achieved = algorithmic bytes / kernel_ms_avg (HIP events around the "
                      "fused kernel on its launch stream); step_device_ms_avg also covers the Morton point-ordering kernels"},
     }
     res.update(extra)
