@@ -9,10 +9,10 @@ REPO=$(pwd); OUT=$REPO/gpurun_out/prof_$TAG; mkdir -p $OUT
 export TMPDIR=/tmp
 CMD="python $REPO/bench.py --workload $WL --steps 10 --warmup 2 --no-cpu-baseline"
 cd /tmp
-timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/trace -o trace --output-format csv -- $CMD > $OUT/bench_trace.json 2> $OUT/trace.err
+timeout -k 5 100 rocprofv3 --kernel-trace --stats -d $OUT/trace -o trace --output-format csv -- $CMD > $OUT/bench_trace.json 2> $OUT/trace.err
 for PMC in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "SQ_WAVES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE"; do
   N=$(echo $PMC | tr ' ' '_')
-  timeout 300 rocprofv3 --kernel-trace --pmc $PMC -d $OUT/pmc_$N -o pmc --output-format csv -- $CMD > $OUT/bench_pmc_$N.json 2> $OUT/pmc_$N.err
+  timeout -k 5 100 rocprofv3 --kernel-trace --pmc $PMC -d $OUT/pmc_$N -o pmc --output-format csv -- $CMD > $OUT/bench_pmc_$N.json 2> $OUT/pmc_$N.err
 done
 cd $REPO
 python scripts/summarize_prof.py $OUT > $OUT/summary.txt 2>&1
