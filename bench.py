@@ -90,8 +90,9 @@ def build_workload(name, dev, rank, world, points="grid"):
     return f, pts.to(dev), names, w, sc
 
 
-def time_steps(fn, steps, dist_on, dev):
-    """Barrier + synchronize on both sides of exactly `steps` steps; returns wall seconds (max over ranks)."""
+def time_steps(fn, steps, dist_on, dev, drain=None):
+    """Barrier + synchronize on both sides of exactly `steps` steps; returns wall seconds (max over ranks).
+    `drain` completes collectives still in flight from the last step (inside the timed region)."""
     import torch.distributed as dist
     if dist_on:
         dist.barrier()
@@ -99,6 +100,8 @@ def time_steps(fn, steps, dist_on, dev):
     t0 = time.perf_counter()
     for _ in range(steps):
         fn()
+    if drain is not None:
+        drain()
     torch.cuda.synchronize(dev)
     if dist_on:
         dist.barrier()
@@ -194,6 +197,8 @@ def main():
     ap.add_argument("--points", default="grid", choices=["grid", "random"],
                     help="grid: create_init_grid of the workload (default); random: uniform cloud of the same N in the "
                          "same box (exposes the dependence on the caller's point order)")
+    ap.add_argument("--no-overlap", action="store_true", help="N>1: block on every all-gather instead of overlapping it "
+                    "with the next batch's query")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--tuning", type=lambda x: int(x, 0), default=0, help="D3F_TUNE_* bits (experiments)")
     ap.add_argument("--cpu-sample", type=int, default=1000000)
@@ -243,17 +248,35 @@ def main():
                 out["similarity"], out["match"] = corr_utils.nearest_descriptor(out["dino_feats"], corr_src, 1.0)
         return out
 
+    # N>1: the all-gather of batch k runs on RCCL's stream while batch k+1 is queried (one gather in flight);
+    # `drain` waits for the last one inside the timed region.  --no-overlap blocks on every gather instead.
+    pending, hold = [], []
+
+    def drain():
+        for wk in pending:
+            wk.wait()
+        pending.clear()
+        hold.clear()
+
     def step():
         out = compute()
         if dist_on and args.gather != "none":
             keys = ("dist", "valid_mask") if args.gather == "dist" else tuple(k for k in out if k != "match")
-            sharding.all_gather_field({k: out[k] for k in keys}, keys=keys, counts=[n] * world)
+            if args.no_overlap:
+                sharding.all_gather_field({k: out[k] for k in keys}, keys=keys, counts=[n] * world)
+            else:
+                drain()                                    # gather k-1 must be done before gather k is enqueued
+                full, works = sharding.all_gather_field({k: out[k] for k in keys}, keys=keys, counts=[n] * world,
+                                                        async_op=True)
+                pending.extend(works)
+                hold.extend((out, full))                   # inputs and outputs stay alive until the wait
         return out
 
     with torch.no_grad():
         for _ in range(max(args.warmup, 1)):
             step()
-        wall = time_steps(step, args.steps, dist_on, dev)
+        drain()
+        wall = time_steps(step, args.steps, dist_on, dev, drain)
         s_avg, s_med, s_min = kernel_time_ms(compute, max(args.steps, 5), dev)          # whole step on the device
         k_avg, k_med, k_min = fused_kernel_time_ms(compute, max(args.steps, 5), dev)   # dominant kernel only
         extra = {}
@@ -287,7 +310,8 @@ def main():
                    "points": ("grid" if (w["step"] is not None and args.points == "grid") else "random cloud"),
                    "points_per_gpu": n, "views": w["V"], "feature_dim": w["C"], "feature_map": list(w["fhw"]),
                    "parallelism": "points sharded x%d, maps replicated" % world,
-                   "gather": (args.gather if dist_on else "n/a")},
+                   "gather": (args.gather if dist_on else "n/a"),
+                   "gather_overlap": (not args.no_overlap) if dist_on else "n/a"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                      "kernel": "fused_eval_kernel<0>", "kernel_ms_avg": k_avg, "kernel_ms_median": k_med,

@@ -39,15 +39,18 @@ def shard_points(pts, rank=None, world=None, group=None):
     return pts[lo:hi]
 
 
-def _gather_rows(t, counts, group):
-    """all-gather along dim 0 of per-rank tensors whose dim-0 sizes are `counts` (ragged allowed)."""
+def _gather_rows(t, counts, group, async_op=False):
+    """all-gather along dim 0 of per-rank tensors whose dim-0 sizes are `counts` (ragged allowed).
+    Returns (tensor, work): work is the pending collective when async_op was honoured (equal counts), else None."""
     world = len(counts)
     as_bool = t.dtype == torch.bool
     x = t.view(torch.uint8) if as_bool else t
     x = x.contiguous()
+    work = None
     if len(set(counts)) == 1:
         out = x.new_empty((world * counts[0],) + tuple(x.shape[1:]))
-        dist.all_gather_into_tensor(out, x, group=group)
+        work = dist.all_gather_into_tensor(out, x, group=group, async_op=async_op)
+        work = work if async_op else None
     else:
         cap = max(counts)
         pad = x.new_zeros((cap,) + tuple(x.shape[1:]))
@@ -55,19 +58,23 @@ def _gather_rows(t, counts, group):
         buf = x.new_empty((world * cap,) + tuple(x.shape[1:]))
         dist.all_gather_into_tensor(buf, pad, group=group)
         out = torch.cat([buf[r * cap:r * cap + c] for r, c in enumerate(counts)], dim=0)
-    return out.view(torch.bool) if as_bool else out
+    return (out.view(torch.bool) if as_bool else out), work
 
 
-def all_gather_field(local_out, keys=None, counts=None, group=None):
+def all_gather_field(local_out, keys=None, counts=None, group=None, async_op=False):
     """Reassembles per-rank eval outputs into the full field on every rank.
 
     local_out: dict from Fusion.eval on this rank's shard.  keys: which entries to gather
     (default all).  '<k>_inter' entries ([V,n,C]) are gathered along their point axis.
     counts: per-rank shard sizes if already known (saves a tiny all-gather).
+    async_op=True returns (field, works): the collectives run on RCCL's stream while the caller keeps launching
+    (e.g. the next batch's query); the field -- and `local_out`, which the caller must keep alive -- may only be
+    touched after `for w in works: w.wait()`.  Ragged shards and '<k>_inter' fall back to the blocking form.
     """
     rank, world = _world(group)
     if world == 1:
-        return dict(local_out) if keys is None else {k: local_out[k] for k in keys}
+        full = dict(local_out) if keys is None else {k: local_out[k] for k in keys}
+        return (full, []) if async_op else full
     keys = list(local_out.keys()) if keys is None else list(keys)
     if counts is None:
         n_local = local_out["dist"].shape[0]
@@ -75,14 +82,16 @@ def all_gather_field(local_out, keys=None, counts=None, group=None):
         allc = torch.empty(world, dtype=torch.int64, device=c.device)
         dist.all_gather_into_tensor(allc, c, group=group)
         counts = [int(v) for v in allc.tolist()]
-    full = {}
+    full, works = {}, []
     for k in keys:
         t = local_out[k]
         if k.endswith("_inter"):
-            full[k] = _gather_rows(t.transpose(0, 1), counts, group).transpose(0, 1).contiguous()
+            full[k] = _gather_rows(t.transpose(0, 1), counts, group)[0].transpose(0, 1).contiguous()
         else:
-            full[k] = _gather_rows(t, counts, group)
-    return full
+            full[k], w = _gather_rows(t, counts, group, async_op)
+            if w is not None:
+                works.append(w)
+    return (full, works) if async_op else full
 
 
 def sharded_eval(fusion, pts, return_names=("dino_feats", "mask"), gather_keys=None, group=None, evaluator=None):

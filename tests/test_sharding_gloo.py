@@ -49,6 +49,14 @@ def _worker(rank, world, port, n, q):
         ok = ok and torch.equal(part["dino_feats_local"], single["dino_feats"][lo:hi])
         ok = ok and (lo, hi) == sharding.shard_bounds(n, rank, world)
         ok = ok and torch.equal(sharding.shard_points(pts), pts[lo:hi])
+        # non-blocking form: collectives in flight until wait(); equal shard sizes only, ragged falls back to blocking
+        local = evaluator(pts[lo:hi], None)
+        counts = [sharding.shard_bounds(n, r, world)[1] - sharding.shard_bounds(n, r, world)[0] for r in range(world)]
+        af, works = sharding.all_gather_field(local, keys=("dist", "valid_mask", "dino_feats"), counts=counts, async_op=True)
+        ok = ok and (len(works) == (3 if len(set(counts)) == 1 else 0))
+        for wk in works:
+            wk.wait()
+        ok = ok and all(torch.equal(af[k], single[k]) for k in af) and af["valid_mask"].dtype == torch.bool
         q.put((rank, bool(ok), full["valid_mask"].dtype == torch.bool, tuple(full["dino_feats_inter"].shape)))
     finally:
         dist.destroy_process_group()
