@@ -44,6 +44,9 @@ def test_struct_layouts_match_header():
     # d3f_views: 3 x int32 (+4 pad) + 3 pointers ; d3f_channel_map: ptr + 4 x int32 + 3 x int64
     assert ctypes.sizeof(_lib.Views) == 40 and _lib.Views.depth.offset == 16
     assert ctypes.sizeof(_lib.ChannelMap) == 48 and _lib.ChannelMap.stride_v.offset == 24
+    # d3f_col_stat travels between ranks as raw bytes: float, float, int64 = 16 B (tests/test_sharding_gloo.py uses it)
+    hdr = open(os.path.join(ROOT, "include", "d3fields_hip.h")).read()
+    assert re.search(r"typedef struct d3f_col_stat \{\s*float max_logit;[^}]*float sum_exp;[^}]*int64_t argmax;[^}]*\} d3f_col_stat;", hdr)
 
 
 def _views(V=2, H=8, W=8, depth=1, K=1, pose=1):
@@ -81,6 +84,20 @@ def test_validation_returns_status_codes_not_aborts():
     with pytest.raises(_lib.D3FError) as e:
         _lib.check(lib.d3f_eval_dist(None, one, 1, one, one, None))
     assert e.value.code == _lib.ERR_INVALID_ARG
+    # row-sharded softmax steps and the point-order probe
+    assert lib.d3f_pairwise_softmax_local(one, one, 10, 10, 4, 1.0, 0, 0, one, None, one, 1 << 20, None) == _lib.ERR_INVALID_ARG
+    assert lib.d3f_pairwise_softmax_local(one, one, 10, 10, 4, 1.0, 0, 0, one, one, None, 0, None) == _lib.ERR_WORKSPACE
+    assert lib.d3f_pairwise_softmax_local(one, one, 10, 10, 4, 1.0, 0, -1, one, one, one, 1 << 20, None) == _lib.ERR_BAD_SHAPE
+    assert lib.d3f_pairwise_softmax_local(one, one, 10, 10, 4, 1.0, 3, 0, one, one, one, 1 << 20, None) == _lib.ERR_INVALID_ARG
+    assert lib.d3f_pairwise_softmax_local(None, one, 0, 0, 4, 1.0, 0, 0, None, None, None, 0, None) == 0       # no columns
+    assert lib.d3f_softmax_merge(None, 2, 5, one, None, None) == _lib.ERR_INVALID_ARG
+    assert lib.d3f_softmax_merge(one, -1, 5, one, None, None) == _lib.ERR_BAD_SHAPE
+    assert lib.d3f_softmax_merge(None, 0, 0, None, None, None) == 0
+    assert lib.d3f_softmax_apply(None, 3, 5, 1.0, one, None) == _lib.ERR_INVALID_ARG
+    assert lib.d3f_softmax_apply(None, 0, 5, 1.0, None, None) == 0
+    assert lib.d3f_point_order_locality(None, 5, one, None) == _lib.ERR_INVALID_ARG
+    assert lib.d3f_point_order_locality(one, 5, None, None) == _lib.ERR_INVALID_ARG
+    assert lib.d3f_point_order_locality(one, -5, one, None) == _lib.ERR_INVALID_ARG
 
 
 def test_workspace_size():
