@@ -40,6 +40,10 @@ WORKLOADS = {
     "c3_dense": dict(V=4, H=480, W=640, C=384, fhw=(480, 640), NI=8, step=0.004, N=1925000),
     "c3_patch": dict(V=4, H=480, W=640, C=384, fhw=(48, 64), NI=8, step=0.004, N=1925000),
     "c4_patch": dict(V=8, H=720, W=1280, C=1024, fhw=(72, 128), NI=0, step=None, N=1000000),
+    # config 2 with the feature maps STORED in fp16 (D3F_DTYPE_F16: widened on load, fp32 arithmetic) -- an extension, not
+    # the headline: the reference's own float16 mode computes everything in half
+    "c2_dense_f16": dict(V=4, H=480, W=640, C=384, fhw=(480, 640), NI=0, step=0.005, N=985600, f16=True),
+    "c2_patch_f16": dict(V=4, H=480, W=640, C=384, fhw=(48, 64), NI=0, step=0.005, N=985600, f16=True),
     # dense variant of config 4: 30.2 GB of feature maps per GPU (3.77 GB per view, just inside the 32-bit texel offsets)
     "c4_dense": dict(V=8, H=720, W=1280, C=1024, fhw=(720, 1280), NI=0, step=None, N=1000000),
     # BASELINE config 5: one tracking frame = Fusion.eval of 100 k keypoints (features + instance mask) followed by the
@@ -52,7 +56,8 @@ def algorithmic_bytes(w, n):
     """read every point once, write every output once, read every map once."""
     sumC = w["C"] + w["NI"]
     per_pt = 12 + 4 + 1 + 4 * sumC
-    maps = w["V"] * (4 * w["H"] * w["W"] + 4 * w["fhw"][0] * w["fhw"][1] * w["C"] + 4 * w["H"] * w["W"] * w["NI"])
+    es = 2 if w.get("f16") else 4                                 # stored bytes per feature channel
+    maps = w["V"] * (4 * w["H"] * w["W"] + es * w["fhw"][0] * w["fhw"][1] * w["C"] + 4 * w["H"] * w["W"] * w["NI"])
     return n * per_pt + maps + 84 * w["V"], per_pt
 
 
@@ -74,6 +79,8 @@ def build_workload(name, dev, rank, world, points="grid"):
     f = Fusion(num_cam=V, device=str(dev))
     f.curr_obs_torch = {k: sc[k].to(dev) for k in ("depth", "K", "pose")}
     f.curr_obs_torch["dino_feats"] = synth.random_map(V, w["fhw"][0], w["fhw"][1], w["C"], seed=1, device=dev)
+    if w.get("f16"):
+        f.curr_obs_torch["dino_feats"] = f.curr_obs_torch["dino_feats"].half()
     names = ["dino_feats"]
     if w["NI"]:
         f.curr_obs_torch["mask"] = synth.random_onehot_mask(V, H, W, w["NI"], seed=2, device=dev)
@@ -302,7 +309,7 @@ def main():
         "metric": "fused 3D query-points/sec", "value": value, "unit": "points/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * wall / args.steps, "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "vs_baseline": None, "dtype": ("f32 (feature maps stored as f16)" if w.get("f16") else "f32"), "data": "synthetic",
         "config": {"workload": "%s: %d views x %dx%d depth, %dx%dx%d fp32 features%s, %d query points per GPU, "
                                "return_names=%s" % (args.workload, w["V"], w["H"], w["W"], w["fhw"][0], w["fhw"][1], w["C"],
                                                     (" + %dx%dx%d one-hot mask" % (w["H"], w["W"], w["NI"])) if w["NI"] else "",
@@ -324,7 +331,7 @@ def main():
     }
     res.update(extra)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        maps_cpu = {k: f.curr_obs_torch[k].cpu() for k in names}
+        maps_cpu = {k: f.curr_obs_torch[k].float().cpu() for k in names}
         res["cpu_baseline"] = cpu_baseline(sc, w, names, maps_cpu, pts.cpu(), args.cpu_sample, args.cpu_threads)
     if rank == 0:
         print(json.dumps(res))

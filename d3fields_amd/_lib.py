@@ -20,6 +20,7 @@ TUNE_XCD_REMAP, TUNE_NO_REORDER, TUNE_FORCE_REORDER, TUNE_STAGING = 1 << 12, 1 <
 MAX_VIEWS = 64
 MAX_MAPS = 8
 DTYPE_F32 = 0
+DTYPE_F16 = 1
 DIST_L2, DIST_SQUARE = 0, 1
 SIM_DIST, SIM_EXP, SIM_SOFTMAX_DIM0 = 0, 1, 2
 

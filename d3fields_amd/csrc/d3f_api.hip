@@ -68,35 +68,53 @@ void pick_mapping(d3f::MapDesc &m, bool can16, bool can8, bool batch)
 
 // Validates one channel map and fills the kernel-side descriptor (out/inter may be NULL for backward).
 int fill_map(const d3f_channel_map &c, int s, int V, float *out, float *inter, const float *extra_aligned,
-             d3f::MapDesc &m, int64_t &map_bytes, uint32_t flags = 0)
+             d3f::MapDesc &m, int64_t &map_bytes, uint32_t flags = 0, bool allow_f16 = true)
 {
     if (!c.data) return fail(D3F_ERR_INVALID_ARG, "map %d: data pointer is NULL", s);
-    if (c.dtype != D3F_DTYPE_F32) return fail(D3F_ERR_BAD_DTYPE, "map %d: dtype %d unsupported (fp32 only)", s, c.dtype);
+    if (c.dtype != D3F_DTYPE_F32 && !(c.dtype == D3F_DTYPE_F16 && allow_f16))
+        return fail(D3F_ERR_BAD_DTYPE, "map %d: dtype %d unsupported here (%s)", s, c.dtype,
+                    allow_f16 ? "D3F_DTYPE_F32 or D3F_DTYPE_F16" : "the backward pass takes D3F_DTYPE_F32 maps only");
+    const int es = c.dtype == D3F_DTYPE_F16 ? 2 : 4;          // bytes per stored channel
     if (c.fh < 1 || c.fw < 1 || c.C < 1) return fail(D3F_ERR_BAD_SHAPE, "map %d: fh=%d fw=%d C=%d", s, c.fh, c.fw, c.C);
     if (c.stride_x < c.C || c.stride_y < 0 || c.stride_v < 0)
         return fail(D3F_ERR_BAD_LAYOUT, "map %d: strides (%lld,%lld,%lld) do not describe a channels-last map", s,
                     (long long)c.stride_v, (long long)c.stride_y, (long long)c.stride_x);
-    if (((int64_t)(c.fh - 1) * c.stride_y + (int64_t)(c.fw - 1) * c.stride_x + c.C) * 4 >= (1LL << 32))
+    if (((int64_t)(c.fh - 1) * c.stride_y + (int64_t)(c.fw - 1) * c.stride_x + c.C) * es >= (1LL << 32))
         return fail(D3F_ERR_BAD_SHAPE, "map %d: one view spans 4 GiB or more (32-bit texel offsets)", s);
     m.data = static_cast<const float *>(c.data);
     m.out = out;
     m.inter = inter;
     m.staged = 0;
     m.pre_slot = -1;
+    m.esize = es;
     m.sv = c.stride_v; m.sy = c.stride_y; m.sx = c.stride_x;
     m.fh = c.fh; m.fw = c.fw; m.C = c.C;
-    if (!aligned(m.data, 4) || !aligned(out, 4) || !aligned(extra_aligned, 4))
-        return fail(D3F_ERR_BAD_LAYOUT, "map %d: pointers must be 4-byte aligned", s);
-    const bool str16 = (c.stride_v % 4 == 0) && (c.stride_y % 4 == 0) && (c.stride_x % 4 == 0);
-    const bool str8 = (c.stride_v % 2 == 0) && (c.stride_y % 2 == 0) && (c.stride_x % 2 == 0);
-    const bool can16 = str16 && aligned(m.data, 16) && aligned(out, 16) && aligned(inter, 16) && aligned(extra_aligned, 16);
-    const bool can8 = str8 && aligned(m.data, 8) && aligned(out, 8) && aligned(inter, 8) && aligned(extra_aligned, 8);
-    const int64_t this_bytes = (int64_t)V * c.fh * c.fw * c.C * 4;
+    if (!aligned(m.data, es) || !aligned(out, 4) || !aligned(extra_aligned, 4))
+        return fail(D3F_ERR_BAD_LAYOUT, "map %d: pointers must be aligned to their element size", s);
+    // 4-channel vectors: 16 B of fp32 / 8 B of fp16 per load; outputs are fp32 either way
+    const bool str4 = (c.stride_v % 4 == 0) && (c.stride_y % 4 == 0) && (c.stride_x % 4 == 0);
+    const bool str2 = (c.stride_v % 2 == 0) && (c.stride_y % 2 == 0) && (c.stride_x % 2 == 0);
+    const bool can16 = str4 && aligned(m.data, 4 * es) && aligned(out, 16) && aligned(inter, 16) && aligned(extra_aligned, 16);
+    const bool can8 = str2 && aligned(m.data, 2 * es) && aligned(out, 8) && aligned(inter, 8) && aligned(extra_aligned, 8);
+    const int64_t this_bytes = (int64_t)V * c.fh * c.fw * c.C * es;
+    map_bytes += this_bytes;
+    if (es == 2) {
+        // fp16 storage: 8 channels per 16-B load (fp32 accumulators / 32-B stores), else scalar lanes; batched loads only
+        const bool str8 = (c.stride_v % 8 == 0) && (c.stride_y % 8 == 0) && (c.stride_x % 8 == 0);
+        const bool vec8 = (c.C % 8 == 0) && str8 && aligned(m.data, 16) && aligned(out, 16) && aligned(inter, 16);
+        pick_mapping(m, false, false, true);            // scalar lanes ...
+        if (vec8) {                                     // ... or the same search over 8-channel vectors
+            d3f::MapDesc t = m;
+            t.C = c.C / 2;                               // cvec = C/8 = (C/2)/4: reuse the 4-wide search
+            pick_mapping(t, true, true, true);
+            m.vw = 8; m.lpp_log2 = t.lpp_log2; m.unroll = t.unroll;
+        }
+        return D3F_OK;
+    }
     bool batch = this_bytes <= (128LL << 20);
     if (flags & (1u << 26)) batch = true;
     if (flags & (1u << 27)) batch = false;
     pick_mapping(m, can16, can8, batch);
-    map_bytes += this_bytes;
     return D3F_OK;
 }
 
@@ -105,7 +123,7 @@ int fill_map(const d3f_channel_map &c, int s, int V, float *out, float *inter, c
 // texels span >= 4 image pixels, i.e. the patch-resolution feature maps of the reference.
 bool staging_candidate(const d3f::MapDesc &m, int H, int W)
 {
-    return m.vw == 4 && m.C >= 64 && (W - 1) >= 4 * (m.fw - 1) && (H - 1) >= 4 * (m.fh - 1);
+    return m.esize == 4 && m.vw == 4 && m.C >= 64 && (W - 1) >= 4 * (m.fw - 1) && (H - 1) >= 4 * (m.fh - 1);
 }
 
 void pick_staged_mapping(d3f::MapDesc &m)
@@ -199,9 +217,9 @@ int eval_common(const d3f_views *views, const float *pts, int64_t n, const d3f_c
                 pick_mapping(m, a16, a8, true);
             }
         }
-        // one point per lane group: 8 points when every map takes >= 16 lanes per point, else 16
+        // one point per lane group: 8 points when every map takes 32 lanes per point, else 16
         bool thin = false;
-        for (int s = 0; s < n_maps; ++s) thin |= P.maps[s].lpp_log2 < 4;
+        for (int s = 0; s < n_maps; ++s) thin |= P.maps[s].lpp_log2 < 5;      // < 32 lanes per point: 16 groups have work
         P.tile_pts = thin ? 16 : 8; P.lds_pad = 0; xcd_remap = true;
         // maps that fit the L2s / Infinity Cache anyway (patch-resolution features, the mask): the walk is only there
         // to give a random cloud L1 locality and the big tiles of the caller-order path stay best
@@ -398,7 +416,7 @@ static int backward_common(const d3f_views *views, const float *pts, int64_t n, 
     int64_t map_bytes = 0;
     for (int s = 0; s < n_maps; ++s) {
         P.grad_fused[s] = grad_fused[s];
-        rc = fill_map(maps[s], s, views->V, nullptr, nullptr, grad_fused[s], P.maps[s], map_bytes);
+        rc = fill_map(maps[s], s, views->V, nullptr, nullptr, grad_fused[s], P.maps[s], map_bytes, 0, false);
         if (rc != D3F_OK) return rc;
     }
     int t = 128;                       // LDS: 44 B per (point, view)

@@ -18,7 +18,9 @@ __device__ __forceinline__ bool in_bounds(float x, float y, int fw, int fh)
 // clang extended vectors: elementwise * + / are native, fma is explicit.
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x8 __attribute__((ext_vector_type(8)));
 template <int VW> struct Vec;
+template <> struct Vec<8> { using T = f32x8; };     // fp16-stored maps: 8 channels = one 16-B load
 template <> struct Vec<4> { using T = f32x4; };
 template <> struct Vec<2> { using T = f32x2; };
 template <> struct Vec<1> { using T = float; };
@@ -28,6 +30,26 @@ template <> __device__ __forceinline__ float v_fma<float>(float a, float s, floa
 
 template <typename VT> __device__ __forceinline__ VT load_vec(const float *p) { return *reinterpret_cast<const VT *>(p); }
 template <typename VT> __device__ __forceinline__ void store_vec(float *p, VT v) { *reinterpret_cast<VT *>(p) = v; }
+
+// One channel vector of a texel: fp32 storage as is, fp16 storage (D3F_DTYPE_F16) widened to fp32 on load --
+// all arithmetic stays fp32, so the result equals the fp32 path run on the widened map bit for bit.
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+// Raw (as stored) channel vector and its widening: corner vectors stay in their stored form until they are used, so
+// twelve in-flight fp16 loads cost 48 VGPRs, not 96.
+template <int VW, bool HALF> struct Raw { using T = typename Vec<VW>::T; };
+template <> struct Raw<8, true> { using T = f16x8; };
+template <> struct Raw<1, true> { using T = _Float16; };
+template <int VW, bool HALF> __device__ __forceinline__ typename Raw<VW, HALF>::T load_texel(const char *p)
+{
+    static_assert(!HALF || VW == 8 || VW == 1, "fp16-stored maps use 8-channel (16-B) or scalar lanes");
+    return *reinterpret_cast<const typename Raw<VW, HALF>::T *>(p);
+}
+template <int VW, bool HALF> __device__ __forceinline__ typename Vec<VW>::T widen(typename Raw<VW, HALF>::T r)
+{
+    if constexpr (!HALF) return r;
+    else if constexpr (VW == 8) return __builtin_convertvector(r, f32x8);
+    else return (float)r;
+}
 
 
 template <typename VT> __device__ __forceinline__ float hsum(VT v);

@@ -23,6 +23,7 @@ struct MapDesc {
     int32_t unroll;    // channel vectors per lane per pass: +1..+3 batched loads, -1..-4 load-use per vector
     int32_t pre_slot;  // >= 0: bilinear corner set-up of this map is precomputed per (point, view) in LDS slot pre_slot
     int32_t staged;    // 2: gather through wave-private LDS texel windows (opt-in experiment)
+    int32_t esize;     // bytes per stored channel: 4 (fp32) or 2 (fp16 storage, widened on load)
 };
 
 struct EvalParams {

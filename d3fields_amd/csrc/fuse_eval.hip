@@ -47,7 +47,8 @@ __device__ __forceinline__ Corner corner_setup(const MapDesc &m, float gx, float
 {
     Corner c;
     const float fwm1 = (float)(m.fw - 1), fhm1 = (float)(m.fh - 1);
-    const uint32_t sy_b = (uint32_t)m.sy * 4u, sx_b = (uint32_t)m.sx * 4u;   // host guarantees a view spans < 4 GiB
+    const uint32_t es = (uint32_t)m.esize;
+    const uint32_t sy_b = (uint32_t)m.sy * es, sx_b = (uint32_t)m.sx * es;   // host guarantees a view spans < 4 GiB
     const float ix = unnormalize(gx, m.fw), iy = unnormalize(gy, m.fh);
     const float x0 = floorf(ix), y0 = floorf(iy);
     const float tx = ix - x0, ty = iy - y0;
@@ -77,7 +78,9 @@ struct __attribute__((aligned(16))) CornerRec {
 // A group of LPP = 1<<lpp_log2 lanes serves one point; lane g of the group owns channel
 // vectors  pass*LPP*U + u*LPP + g  (u < U), so one load instruction of a group covers
 // LPP*VW*4 contiguous bytes of a texel.
-template <int VW, int U, bool BATCH>
+//   HALF  the map is stored in fp16 (D3F_DTYPE_F16): VW = 8 channels per 16-B load (or scalar lanes), widened to
+//         fp32 on load; everything after the load is the fp32 path
+template <int VW, int U, bool BATCH, bool HALF = false>
 __device__ __forceinline__ void gather_map(const MapDesc &m, const EvalParams &P, const ViewRec *rec,
                                            const float *cnt_s, const uint32_t *flag_s,
                                            const uint32_t *idx_s, int64_t idx_base, int tile_n, const CornerRec *crec)
@@ -90,6 +93,7 @@ __device__ __forceinline__ void gather_map(const MapDesc &m, const EvalParams &P
     const int cvec = m.C / VW;
     const int V = P.V;
     const float *__restrict__ data = m.data;
+    constexpr int ES = HALF ? 2 : 4;                  // bytes per stored channel
 
     for (int p = grp; p < tile_n; p += ngrp) {
         const int64_t i = idx_base + idx_s[p];
@@ -116,18 +120,18 @@ __device__ __forceinline__ void gather_map(const MapDesc &m, const EvalParams &P
                     c = corner_setup(m, r.gx, r.gy);
                     w0 = c.inw ? c.wnw : 0.0f; w1 = c.ine ? c.wne : 0.0f; w2 = c.isw ? c.wsw : 0.0f; w3 = c.ise ? c.wse : 0.0f;
                 }
-                const char *bv = reinterpret_cast<const char *>(data) + (int64_t)v * m.sv * 4;
-                VT a[U], b[U], d[U], e[U];
+                const char *bv = reinterpret_cast<const char *>(data) + (int64_t)v * m.sv * ES;
+                typename Raw<VW, HALF>::T a[U], b[U], d[U], e[U];      // as stored; widened to fp32 at the use
                 if (BATCH) {
                     // cache-resident maps: all 4*U loads in flight before the first use (latency-bound regime)
 #pragma unroll
                     for (int u = 0; u < U; ++u) {
                         const int cv = min(c0 + u * lpp + g, cvec - 1);     // idle lanes re-read the last vector
-                        const uint32_t co = (uint32_t)cv * (VW * 4);
-                        a[u] = *reinterpret_cast<const VT *>(bv + (c.onw + co));
-                        b[u] = *reinterpret_cast<const VT *>(bv + (c.one + co));
-                        d[u] = *reinterpret_cast<const VT *>(bv + (c.osw + co));
-                        e[u] = *reinterpret_cast<const VT *>(bv + (c.ose + co));
+                        const uint32_t co = (uint32_t)cv * (VW * ES);
+                        a[u] = load_texel<VW, HALF>(bv + (c.onw + co));
+                        b[u] = load_texel<VW, HALF>(bv + (c.one + co));
+                        d[u] = load_texel<VW, HALF>(bv + (c.osw + co));
+                        e[u] = load_texel<VW, HALF>(bv + (c.ose + co));
                     }
                 }
                 if (!strict) {
@@ -136,16 +140,16 @@ __device__ __forceinline__ void gather_map(const MapDesc &m, const EvalParams &P
 #pragma unroll
                     for (int u = 0; u < U; ++u) {
                         if (!BATCH) {      // maps larger than the caches: a smaller in-flight footprint measured faster
-                            const uint32_t co = (uint32_t)min(c0 + u * lpp + g, cvec - 1) * (VW * 4);
-                            a[u] = *reinterpret_cast<const VT *>(bv + (c.onw + co));
-                            b[u] = *reinterpret_cast<const VT *>(bv + (c.one + co));
-                            d[u] = *reinterpret_cast<const VT *>(bv + (c.osw + co));
-                            e[u] = *reinterpret_cast<const VT *>(bv + (c.ose + co));
+                            const uint32_t co = (uint32_t)min(c0 + u * lpp + g, cvec - 1) * (VW * ES);
+                            a[u] = load_texel<VW, HALF>(bv + (c.onw + co));
+                            b[u] = load_texel<VW, HALF>(bv + (c.one + co));
+                            d[u] = load_texel<VW, HALF>(bv + (c.osw + co));
+                            e[u] = load_texel<VW, HALF>(bv + (c.ose + co));
                         }
-                        VT s = a[u] * w0;                  // ATen bilinear: fma chain nw,ne,sw,se
-                        s = v_fma<VT>(b[u], w1, s);
-                        s = v_fma<VT>(d[u], w2, s);
-                        s = v_fma<VT>(e[u], w3, s);
+                        VT s = widen<VW, HALF>(a[u]) * w0; // ATen bilinear: fma chain nw,ne,sw,se
+                        s = v_fma<VT>(widen<VW, HALF>(b[u]), w1, s);
+                        s = v_fma<VT>(widen<VW, HALF>(d[u]), w2, s);
+                        s = v_fma<VT>(widen<VW, HALF>(e[u]), w3, s);
                         acc[u] = acc[u] + s * r.wgt;       // fusion.py:385
                         if (!BATCH) __builtin_amdgcn_sched_barrier(0);   // keep the next vector's loads behind this use
                     }
@@ -153,14 +157,14 @@ __device__ __forceinline__ void gather_map(const MapDesc &m, const EvalParams &P
 #pragma unroll
                     for (int u = 0; u < U; ++u) {
                         if (!BATCH) {
-                            const uint32_t co = (uint32_t)min(c0 + u * lpp + g, cvec - 1) * (VW * 4);
-                            a[u] = *reinterpret_cast<const VT *>(bv + (c.onw + co));
-                            b[u] = *reinterpret_cast<const VT *>(bv + (c.one + co));
-                            d[u] = *reinterpret_cast<const VT *>(bv + (c.osw + co));
-                            e[u] = *reinterpret_cast<const VT *>(bv + (c.ose + co));
+                            const uint32_t co = (uint32_t)min(c0 + u * lpp + g, cvec - 1) * (VW * ES);
+                            a[u] = load_texel<VW, HALF>(bv + (c.onw + co));
+                            b[u] = load_texel<VW, HALF>(bv + (c.one + co));
+                            d[u] = load_texel<VW, HALF>(bv + (c.osw + co));
+                            e[u] = load_texel<VW, HALF>(bv + (c.ose + co));
                         }
-                        const VT av = c.inw ? a[u] : (VT)0.0f, bvv = c.ine ? b[u] : (VT)0.0f;
-                        const VT dv = c.isw ? d[u] : (VT)0.0f, ev = c.ise ? e[u] : (VT)0.0f;
+                        const VT av = c.inw ? widen<VW, HALF>(a[u]) : (VT)0.0f, bvv = c.ine ? widen<VW, HALF>(b[u]) : (VT)0.0f;
+                        const VT dv = c.isw ? widen<VW, HALF>(d[u]) : (VT)0.0f, ev = c.ise ? widen<VW, HALF>(e[u]) : (VT)0.0f;
                         VT s = av * c.wnw;
                         s = v_fma<VT>(bvv, c.wne, s);
                         s = v_fma<VT>(dv, c.wsw, s);
@@ -399,6 +403,19 @@ __device__ __forceinline__ void gather_map_u(const MapDesc &m, const EvalParams 
     }
 }
 
+// fp16-stored maps: the host maps them to 8-channel (16-B) or scalar lanes with batched loads only (1..3 vectors)
+template <int VW>
+__device__ __forceinline__ void gather_map_half_u(const MapDesc &m, const EvalParams &P, const ViewRec *rec,
+                                                  const float *cnt_s, const uint32_t *flag_s,
+                                                  const uint32_t *idx_s, int64_t idx_base, int tile_n, const CornerRec *crec)
+{
+    switch (m.unroll) {
+    case 1: gather_map<VW, 1, true, true>(m, P, rec, cnt_s, flag_s, idx_s, idx_base, tile_n, crec); break;
+    case 2: gather_map<VW, 2, true, true>(m, P, rec, cnt_s, flag_s, idx_s, idx_base, tile_n, crec); break;
+    default: gather_map<VW, 3, true, true>(m, P, rec, cnt_s, flag_s, idx_s, idx_base, tile_n, crec); break;
+    }
+}
+
 // XCD-aware tile order: the dispatcher places workgroup b on XCD b%8 (observed, speed only).
 // Giving XCD k the k-th contiguous eighth of the tiles keeps the texel footprints of the
 // eight private L2s (4 MiB each) disjoint instead of replicated.  Bijective for any count.
@@ -425,7 +442,7 @@ __device__ __forceinline__ void fetch_point(const EvalParams &P, int64_t i, floa
 }
 
 // STAGED: compiled with the LDS-window gather (more registers); the plain kernel keeps 4 waves/SIMD.
-template <int MODE, bool STAGED, bool WIDE>
+template <int MODE, bool STAGED, bool WIDE, bool ANYF16 = false>
 __device__ __forceinline__ void fused_eval_body(const EvalParams &P)
 {
     extern __shared__ __align__(16) unsigned char smem[];
@@ -542,6 +559,11 @@ __device__ __forceinline__ void fused_eval_body(const EvalParams &P)
             continue;
         }
         const CornerRec *crec = m.pre_slot >= 0 ? crec_s + (size_t)m.pre_slot * TP * V : nullptr;
+        if (ANYF16 && m.esize == 2) {
+            if (m.vw == 8) gather_map_half_u<8>(m, P, rec, cnt_s, flag_s, idx_s, idx_base, tile_n, crec);
+            else gather_map_half_u<1>(m, P, rec, cnt_s, flag_s, idx_s, idx_base, tile_n, crec);
+            continue;
+        }
         switch (m.vw) {
         case 4: gather_map_u<4, WIDE>(m, P, rec, cnt_s, flag_s, idx_s, idx_base, tile_n, crec); break;
         case 2: gather_map_u<2, WIDE>(m, P, rec, cnt_s, flag_s, idx_s, idx_base, tile_n, crec); break;
@@ -560,6 +582,12 @@ __global__ __launch_bounds__(kBlock, 4) void fused_eval_kernel(const EvalParams 
 template <int MODE>
 __global__ __launch_bounds__(kBlock) void fused_eval_wide_kernel(const EvalParams P) { fused_eval_body<MODE, false, true>(P); }
 
+// fp16-stored maps get their own entry point (all vector counts, fp32 and fp16 maps may be mixed in one call) so
+// that the fp32 kernels above keep their register allocation (folding both into one body made them spill)
+// (163 VGPR = 3 waves per SIMD; held to 4 it spills 750 B per lane)
+template <int MODE>
+__global__ __launch_bounds__(kBlock) void fused_eval_f16_kernel(const EvalParams P) { fused_eval_body<MODE, false, true, true>(P); }
+
 template <int MODE>
 __global__ __launch_bounds__(kBlock) void fused_eval_staged_kernel(const EvalParams P) { fused_eval_body<MODE, true, true>(P); }
 
@@ -569,9 +597,14 @@ hipError_t launch_fused_eval(const EvalParams &P, int mode, hipStream_t stream)
     const int64_t ntiles = (P.n + P.tile_pts - 1) / P.tile_pts;
     const size_t lds = (size_t)P.crec_offset + (size_t)P.n_pre * P.tile_pts * P.V * 32 + (size_t)P.lds_pad;
     dim3 grid((unsigned)ntiles), block(kBlock);
-    bool wide = false;
-    for (int s = 0; s < P.n_maps; ++s) wide |= (P.maps[s].unroll == -4);
-    if (mode == 0 && P.stage_floats > 0)
+    bool wide = false, f16 = false;
+    for (int s = 0; s < P.n_maps; ++s) {
+        wide |= (P.maps[s].unroll == -4);
+        f16 |= (P.maps[s].esize == 2);
+    }
+    if (mode == 0 && f16)
+        hipLaunchKernelGGL((fused_eval_f16_kernel<0>), grid, block, lds, stream, P);
+    else if (mode == 0 && P.stage_floats > 0)
         hipLaunchKernelGGL((fused_eval_staged_kernel<0>), grid, block, lds, stream, P);
     else if (mode == 0 && wide)
         hipLaunchKernelGGL((fused_eval_wide_kernel<0>), grid, block, lds, stream, P);

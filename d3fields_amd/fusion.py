@@ -177,8 +177,13 @@ class Fusion:
 
     def __init__(self, num_cam, feat_backbone="dinov2", device="cuda:0", dtype=torch.float32, *,
                  feature_extractor=None, mask_producer=None, mask_tracker=None):
-        if dtype != torch.float32:
-            raise NotImplementedError("the HIP field query is fp32 (parity contract); got %s" % dtype)
+        # dtype=torch.float16: the reference then runs EVERYTHING in half (fusion.py:203,227,709-712), whose projection
+        # arithmetic is off by whole pixels (its features differ from its own fp32 run by > 1.0 on the synthetic
+        # scenes).  Here float16 is a STORAGE format of the channel maps only (half the texel traffic): depth / K /
+        # pose / points and every operation of the query stay fp32, and the result equals the fp32 query on the
+        # widened maps bit for bit (D3F_DTYPE_F16, include/d3fields_hip.h).
+        if dtype not in (torch.float32, torch.float16):
+            raise NotImplementedError("channel maps are stored as float32 or float16; got %s" % dtype)
         self.device = torch.device(device)
         self.dtype = dtype
         self.mu = 0.02                          # reference fusion.py:208
@@ -216,8 +221,8 @@ class Fusion:
             self.curr_obs_torch["dino_feats"] = _as_device_tensor(obs["dino_feats"], self.dtype, self.device)
         self.curr_obs_torch["color"] = color
         self.curr_obs_torch["color_tensor"] = _as_device_tensor(color, self.dtype, self.device) / 255.0
-        for k in ("depth", "pose", "K"):
-            self.curr_obs_torch[k] = _as_device_tensor(obs[k], self.dtype, self.device)
+        for k in ("depth", "pose", "K"):                 # geometry is always fp32 (see __init__)
+            self.curr_obs_torch[k] = _as_device_tensor(obs[k], torch.float32, self.device)
         _, self.H, self.W = obs["depth"].shape
         self._finite_cache.clear()
 
@@ -319,8 +324,8 @@ class Fusion:
                 m = self.curr_obs_torch[k]                 # KeyError for unknown names, like the reference
                 if not isinstance(m, torch.Tensor) or m.dim() != 4 or m.shape[0] != V:
                     raise ValueError("curr_obs_torch[%r] must be a (V,h,w,C) tensor" % k)
-                if m.device != dev or m.dtype != torch.float32:
-                    raise RuntimeError("curr_obs_torch[%r] must be float32 on %s" % (k, dev))
+                if m.device != dev or m.dtype not in (torch.float32, torch.float16):
+                    raise RuntimeError("curr_obs_torch[%r] must be float32 or float16 on %s" % (k, dev))
                 if m.stride(3) != 1:
                     m = m.contiguous()
                     keep.append(m)
@@ -329,7 +334,8 @@ class Fusion:
                 C = m.shape[3]
                 o = torch.empty((n, C), dtype=torch.float32, device=dev)
                 outputs[k] = o
-                maps[s] = _lib.ChannelMap(m.data_ptr(), m.shape[1], m.shape[2], C, _lib.DTYPE_F32,
+                maps[s] = _lib.ChannelMap(m.data_ptr(), m.shape[1], m.shape[2], C,
+                                          _lib.DTYPE_F16 if m.dtype == torch.float16 else _lib.DTYPE_F32,
                                           m.stride(0), m.stride(1), m.stride(2))
                 fused[s] = o.data_ptr()
                 if return_inter:
@@ -339,7 +345,7 @@ class Fusion:
             flags = (_lib.FLAG_FINITE_MAPS if finite else 0) | int(self.tuning_flags)
             ws, ws_bytes = None, 0
             if self.reorder_points and names and n >= 65536:
-                small = sum(m.shape[0] * m.shape[1] * m.shape[2] * m.shape[3] * 4 for m in used_maps) <= (64 << 20)
+                small = sum(m.numel() * m.element_size() for m in used_maps) <= (64 << 20)
                 if small and self.detect_point_order and self._is_unordered(pts_c, stream):
                     flags |= _lib.FLAG_UNORDERED_POINTS     # larger maps are walked in Morton order anyway
                 ws_bytes = lib.d3f_eval_workspace_bytes(n)
@@ -361,6 +367,9 @@ class Fusion:
         gptr = (ctypes.c_void_p * max(nm, 1))()
         hold = []
         for s, m in enumerate(used_maps):
+            if m.dtype != torch.float32:
+                raise NotImplementedError("gradients through float16-stored maps are not implemented "
+                                          "(d3f_eval_backward takes float32 maps)")
             maps[s] = _lib.ChannelMap(m.data_ptr(), m.shape[1], m.shape[2], m.shape[3], _lib.DTYPE_F32,
                                       m.stride(0), m.stride(1), m.stride(2))
             g = grad_fused[s]

@@ -30,7 +30,7 @@ extern "C" {
 #define D3F_OK 0
 #define D3F_ERR_INVALID_ARG (-1)  /* null pointer, negative count, bad enum               */
 #define D3F_ERR_BAD_SHAPE (-2)    /* V/H/W/C/fh/fw outside the supported range             */
-#define D3F_ERR_BAD_DTYPE (-3)    /* channel map dtype other than D3F_DTYPE_F32            */
+#define D3F_ERR_BAD_DTYPE (-3)    /* channel map dtype not supported by this entry point   */
 #define D3F_ERR_BAD_LAYOUT (-4)   /* stride/alignment the kernels cannot address           */
 #define D3F_ERR_HIP (-5)          /* a HIP runtime call or kernel launch failed            */
 #define D3F_ERR_WORKSPACE (-6)    /* workspace missing or too small                        */
@@ -39,6 +39,10 @@ extern "C" {
 #define D3F_MAX_MAPS 8
 
 #define D3F_DTYPE_F32 0
+#define D3F_DTYPE_F16 1 /* IEEE half STORAGE of a channel map (a data format of the producer side: DINOv2 run in   \
+                           fp16, fusion.py:203,227,616).  Texels are widened to fp32 on load and every operation of \
+                           the query stays fp32, so the result equals the fp32 query on the widened map bit for bit  \
+                           at half the texel traffic.  Forward entry points only; strides stay in ELEMENTS.         */
 
 /* d3f_eval flags */
 #define D3F_FLAG_FINITE_MAPS 1u /* caller has verified that depth and every channel map hold   \
@@ -85,7 +89,7 @@ typedef struct d3f_views {
 typedef struct d3f_channel_map {
     const void *data;
     int32_t fh, fw, C;
-    int32_t dtype; /* D3F_DTYPE_F32 */
+    int32_t dtype; /* D3F_DTYPE_F32 or D3F_DTYPE_F16 (forward only) */
     int64_t stride_v, stride_y, stride_x;
 } d3f_channel_map;
 

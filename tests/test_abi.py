@@ -84,6 +84,13 @@ def test_validation_returns_status_codes_not_aborts():
     with pytest.raises(_lib.D3FError) as e:
         _lib.check(lib.d3f_eval_dist(None, one, 1, one, one, None))
     assert e.value.code == _lib.ERR_INVALID_ARG
+    # fp16-stored maps: forward entry points take them, the backward pass does not
+    maps[0].dtype, maps[0].stride_x = 1, 8
+    assert lib.d3f_eval_backward(ctypes.byref(_views()), one, 4, maps, 1, 0.02, None, outs, one, None) == _lib.ERR_BAD_DTYPE
+    maps[0].data = 18                # 2-byte aligned is enough for scalar fp16 lanes, 1-byte is not
+    assert lib.d3f_eval(ctypes.byref(_views()), one, 0, maps, 1, 0.02, 0, one, one, outs, None, None, 0, None) == 0
+    maps[0].data = 17
+    assert lib.d3f_eval(ctypes.byref(_views()), one, 4, maps, 1, 0.02, 0, one, one, outs, None, None, 0, None) == _lib.ERR_BAD_LAYOUT
     # row-sharded softmax steps and the point-order probe
     assert lib.d3f_pairwise_softmax_local(one, one, 10, 10, 4, 1.0, 0, 0, one, None, one, 1 << 20, None) == _lib.ERR_INVALID_ARG
     assert lib.d3f_pairwise_softmax_local(one, one, 10, 10, 4, 1.0, 0, 0, one, one, None, 0, None) == _lib.ERR_WORKSPACE
@@ -109,12 +116,12 @@ def test_workspace_size():
     assert lib.d3f_softmax_workspace_bytes(100000, 300) == (1563 + 1) * 300 * 16      # one 16-B record per 64-row tile and column
 
 
-def _plan(V, H, W, n, maps, flags=0, ws=1, inter=0):
+def _plan(V, H, W, n, maps, flags=0, ws=1, inter=0, dtype=0):
     lib = _lib.load()
     v = _lib.Views(V, H, W, 16, 16, 16)
     arr = (_lib.ChannelMap * max(len(maps), 1))()
     for i, (fh, fw, C) in enumerate(maps):
-        arr[i] = _lib.ChannelMap(16, fh, fw, C, 0, fh * fw * C, fw * C, C)
+        arr[i] = _lib.ChannelMap(16, fh, fw, C, dtype, fh * fw * C, fw * C, C)
     p = _lib.EvalPlan()
     assert lib.d3f_eval_plan_query(ctypes.byref(v), n, arr, len(maps), flags, ws, inter, ctypes.byref(p)) == 0
     return p
@@ -132,6 +139,13 @@ def test_launch_plan_host_logic():
     p = _plan(4, 480, 640, 985600, [(48, 64, 384)], flags=_lib.FLAG_UNORDERED_POINTS, ws=0)
     assert p.reorder == 0                                      # no scratch, no walk
     assert _plan(4, 480, 640, 60000, [(48, 64, 384)], flags=_lib.FLAG_UNORDERED_POINTS).reorder == 0
+    # fp16-stored dense maps: 0.94 GB; 8 channels per 16-B load -> 16 lanes x 3 vectors per point, 16-point tiles on the walk
+    p = _plan(4, 480, 640, 985600, [(480, 640, 384)], dtype=_lib.DTYPE_F16)
+    assert (p.tile_points, p.reorder, p.vector_floats[0], p.lanes_per_point[0], p.vectors_per_lane[0]) == (16, 1, 8, 16, 3)
+    p = _plan(4, 480, 640, 1000, [(48, 64, 5)], dtype=_lib.DTYPE_F16)             # odd channel count: scalar fp16 lanes
+    assert (p.vector_floats[0], p.lanes_per_point[0]) == (1, 1)
+    p = _plan(4, 480, 640, 985600, [(48, 64, 384)], dtype=_lib.DTYPE_F16)
+    assert (p.tile_points, p.reorder) == (128, 0)
     # C2 dense: 1.9 GB of maps -> Morton walk, 8-point tiles, 3 batched float4 per lane; without scratch: 64-point tiles
     p = _plan(4, 480, 640, 985600, [(480, 640, 384)])
     assert (p.tile_points, p.reorder, p.vectors_per_lane[0]) == (8, 1, 3)

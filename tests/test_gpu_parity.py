@@ -434,6 +434,62 @@ def test_so3_exp_map_and_rigid_transform(dev):
     assert np.abs(cpu(got) - (torch.bmm(x, R.cpu()) + t[:, None, :]).numpy()).max() <= 1e-5
 
 
+@pytest.mark.parametrize("V,H,W,fhw,C,NI", [(4, 60, 80, (6, 8), 384, 8), (3, 48, 64, (48, 64), 6, 3), (2, 40, 56, (5, 7), 5, 2),
+                                             (8, 36, 64, (9, 16), 1024, 0)])
+def test_fp16_stored_maps_equal_fp32_query_on_widened_maps(dev, V, H, W, fhw, C, NI):
+    """D3F_DTYPE_F16: half is a storage format only.  The query on half maps must equal the query (and the oracle) on
+    the same values widened to fp32: raw samples, dist and valid bit for bit, fused rows within TOL of the oracle --
+    for 16-B, 8-B and scalar lane mappings, the C = 1024 wide kernel, and fp16 / fp32 maps mixed in one call."""
+    from d3fields_amd import synth
+    sc = synth.make_scene(V, H, W, "stress")
+    feats16 = (synth.random_map(V, fhw[0], fhw[1], C, seed=1) * 2.0).half()
+    maps = {"dino_feats": feats16}
+    if NI:
+        maps["mask"] = synth.random_onehot_mask(V, H, W, NI, seed=2)            # stays fp32: mixed call
+    pts = torch.cat([synth.random_cloud(70000 if C <= 384 else 3000, seed=4) * 1.2, torch.from_numpy(
+        np.array([[np.nan, 0, 0], [0, 0, 1e30], [0.0, 0.0, 0.0]], np.float32))])
+    names = list(maps)
+    f16 = make_fusion(dev, sc["depth"], sc["K"], sc["pose"], maps, H, W)
+    wide = dict(maps, dino_feats=feats16.float())
+    f32 = make_fusion(dev, sc["depth"], sc["K"], sc["pose"], wide, H, W)
+    with torch.no_grad():
+        a = f16.eval(pts.to(dev), return_names=names, return_inter=True)
+        b = f32.eval(pts.to(dev), return_names=names, return_inter=True)
+        a2 = f16.batch_eval(pts.to(dev), return_names=names)                     # fast (non-strict) path
+        b2 = f32.batch_eval(pts.to(dev), return_names=names)
+    assert f16.curr_obs_torch["dino_feats"].dtype == torch.float16 and a["dino_feats"].dtype == torch.float32
+    for k in a:
+        assert torch.equal(a[k], b[k]) or (torch.isnan(a[k]) == torch.isnan(b[k])).all() and torch.equal(
+            torch.nan_to_num(a[k]), torch.nan_to_num(b[k])), k
+    for k in a2:
+        assert torch.equal(torch.nan_to_num(a2[k]), torch.nan_to_num(b2[k])), k
+    sl = slice(0, 3000)
+    ref = oracle_eval(sc, pts[sl].numpy(), [wide[k].numpy() for k in names], return_inter=True)
+    assert np.array_equal(cpu(a["valid_mask"][sl]), ref["valid_mask"].astype(bool))
+    for s_, k in enumerate(names):
+        assert np.array_equal(cpu(a[k + "_inter"][:, sl]), ref["inter"][s_], equal_nan=True)
+        assert rel_err(cpu(a2[k][sl]), ref["sets"][s_]) <= TOL
+    with pytest.raises(NotImplementedError):
+        p = pts[:100].to(dev).requires_grad_(True)
+        f16.eval(p, return_names=["dino_feats"])["dino_feats"].sum().backward()
+
+
+def test_fusion_float16_is_a_storage_format(dev):
+    """Fusion(dtype=float16): update() stores the channel maps in half, geometry stays fp32."""
+    from d3fields_amd import Fusion
+    V, H, W = 2, 40, 50
+    from d3fields_amd import synth
+    sc = synth.make_scene(V, H, W, "smooth")
+    feats = synth.random_map(V, 4, 5, 16, seed=1)
+    f = Fusion(num_cam=V, device=str(dev), dtype=torch.float16, feature_extractor=lambda color, params: feats)
+    f.update({"color": np.zeros((V, H, W, 3), np.uint8), "depth": sc["depth"].numpy(), "pose": sc["pose"].numpy(), "K": sc["K"].numpy()})
+    assert f.curr_obs_torch["dino_feats"].dtype == torch.float16 and f.curr_obs_torch["depth"].dtype == torch.float32
+    out = f.eval(synth.random_cloud(500, seed=2).to(dev), return_names=["dino_feats", "color_tensor"])
+    assert out["dino_feats"].dtype == torch.float32 and out["dist"].dtype == torch.float32
+    with pytest.raises(NotImplementedError):
+        Fusion(num_cam=V, device=str(dev), dtype=torch.bfloat16)
+
+
 def test_fails_loudly_without_gpu_tensors(dev):
     from d3fields_amd import synth
     V, H, W = 2, 32, 40

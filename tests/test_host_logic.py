@@ -58,8 +58,9 @@ def test_no_cpu_fallback_anywhere():
         corr_utils.compute_similarity_tensor_multi(torch.zeros(2, 4), torch.zeros(3, 5), None, None, 1.0)
     with pytest.raises(RuntimeError, match="no CPU path"):
         onehot2instance(torch.zeros(4, 3))
+    assert Fusion(num_cam=2, dtype=torch.float16).dtype == torch.float16      # fp16 = storage format of the maps
     with pytest.raises(NotImplementedError):
-        Fusion(num_cam=2, dtype=torch.float16)
+        Fusion(num_cam=2, dtype=torch.bfloat16)
 
 
 def test_product_never_imports_the_oracle():
