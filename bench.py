@@ -321,7 +321,9 @@ def main():
                    "gather_overlap": (not args.no_overlap) if dist_on else "n/a"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                     "kernel": "fused_eval_kernel<0>", "kernel_ms_avg": k_avg, "kernel_ms_median": k_med,
+                     "kernel": ("fused_eval_f16_kernel<0>" if w.get("f16") else
+                                "fused_eval_wide_kernel<0>" if w["C"] > 768 else "fused_eval_kernel<0>"),
+                     "kernel_ms_avg": k_avg, "kernel_ms_median": k_med,
                      "kernel_ms_min": k_min, "algorithmic_bytes_per_launch": bytes_alg,
                      "algorithmic_bytes_per_point": per_pt, "kernel_points_per_s": n / (k_avg * 1e-3),
                      "step_device_ms_avg": s_avg, "logical_gather_bytes_per_point": b_gather,
