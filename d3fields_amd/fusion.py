@@ -429,12 +429,16 @@ class Fusion:
         finite = self._is_finite("depth", keep[0])
         for s, k in enumerate(names):
             m = self.curr_obs_torch[k]
+            if m.device != dev or m.dtype not in (torch.float32, torch.float16):
+                raise RuntimeError("curr_obs_torch[%r] must be float32 or float16 on %s" % (k, dev))
             if m.stride(3) != 1:
                 m = m.contiguous()
                 keep.append(m)
             finite = finite and self._is_finite(k, m)
             out[k] = torch.empty((n, m.shape[3]), dtype=torch.float32, device=dev)
-            maps[s] = _lib.ChannelMap(m.data_ptr(), m.shape[1], m.shape[2], m.shape[3], _lib.DTYPE_F32, m.stride(0), m.stride(1), m.stride(2))
+            maps[s] = _lib.ChannelMap(m.data_ptr(), m.shape[1], m.shape[2], m.shape[3],
+                                      _lib.DTYPE_F16 if m.dtype == torch.float16 else _lib.DTYPE_F32,
+                                      m.stride(0), m.stride(1), m.stride(2))
             fused[s] = out[k].data_ptr()
         flags = (_lib.FLAG_FINITE_MAPS if finite else 0) | int(self.tuning_flags)
         with torch.cuda.device(dev):

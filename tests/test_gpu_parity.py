@@ -488,6 +488,13 @@ def test_fusion_float16_is_a_storage_format(dev):
     assert out["dino_feats"].dtype == torch.float32 and out["dist"].dtype == torch.float32
     with pytest.raises(NotImplementedError):
         Fusion(num_cam=V, device=str(dev), dtype=torch.bfloat16)
+    # the grid entry point takes the half map too: same rows as batch_eval of the materialised grid
+    from d3fields_amd import create_init_grid
+    box = dict(x_lower=-0.2, x_upper=0.2, y_lower=-0.2, y_upper=0.2, z_lower=-0.1, z_upper=0.02)
+    g = f.eval_grid(box, 0.02, return_names=["dino_feats"])
+    pts, _ = create_init_grid(box, 0.02)
+    b = f.batch_eval(pts.to(dev), return_names=["dino_feats"])
+    assert torch.equal(g["dino_feats"].reshape(-1, 16), b["dino_feats"]) and torch.equal(g["dist"].reshape(-1), b["dist"])
 
 
 def test_fails_loudly_without_gpu_tensors(dev):
