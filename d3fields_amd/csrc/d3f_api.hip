@@ -68,12 +68,11 @@ void pick_mapping(d3f::MapDesc &m, bool can16, bool can8, bool batch)
 
 // Validates one channel map and fills the kernel-side descriptor (out/inter may be NULL for backward).
 int fill_map(const d3f_channel_map &c, int s, int V, float *out, float *inter, const float *extra_aligned,
-             d3f::MapDesc &m, int64_t &map_bytes, uint32_t flags = 0, bool allow_f16 = true)
+             d3f::MapDesc &m, int64_t &map_bytes, uint32_t flags = 0)
 {
     if (!c.data) return fail(D3F_ERR_INVALID_ARG, "map %d: data pointer is NULL", s);
-    if (c.dtype != D3F_DTYPE_F32 && !(c.dtype == D3F_DTYPE_F16 && allow_f16))
-        return fail(D3F_ERR_BAD_DTYPE, "map %d: dtype %d unsupported here (%s)", s, c.dtype,
-                    allow_f16 ? "D3F_DTYPE_F32 or D3F_DTYPE_F16" : "the backward pass takes D3F_DTYPE_F32 maps only");
+    if (c.dtype != D3F_DTYPE_F32 && c.dtype != D3F_DTYPE_F16)
+        return fail(D3F_ERR_BAD_DTYPE, "map %d: dtype %d unsupported (D3F_DTYPE_F32 or D3F_DTYPE_F16)", s, c.dtype);
     const int es = c.dtype == D3F_DTYPE_F16 ? 2 : 4;          // bytes per stored channel
     if (c.fh < 1 || c.fw < 1 || c.C < 1) return fail(D3F_ERR_BAD_SHAPE, "map %d: fh=%d fw=%d C=%d", s, c.fh, c.fw, c.C);
     if (c.stride_x < c.C || c.stride_y < 0 || c.stride_v < 0)
@@ -416,7 +415,7 @@ static int backward_common(const d3f_views *views, const float *pts, int64_t n, 
     int64_t map_bytes = 0;
     for (int s = 0; s < n_maps; ++s) {
         P.grad_fused[s] = grad_fused[s];
-        rc = fill_map(maps[s], s, views->V, nullptr, nullptr, grad_fused[s], P.maps[s], map_bytes, 0, false);
+        rc = fill_map(maps[s], s, views->V, nullptr, nullptr, grad_fused[s], P.maps[s], map_bytes);
         if (rc != D3F_OK) return rc;
     }
     int t = 128;                       // LDS: 44 B per (point, view)

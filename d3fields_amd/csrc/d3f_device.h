@@ -53,6 +53,7 @@ template <int VW, bool HALF> __device__ __forceinline__ typename Vec<VW>::T wide
 
 
 template <typename VT> __device__ __forceinline__ float hsum(VT v);
+template <> __device__ __forceinline__ float hsum<f32x8>(f32x8 v) { return ((v.s0 + v.s1) + (v.s2 + v.s3)) + ((v.s4 + v.s5) + (v.s6 + v.s7)); }
 template <> __device__ __forceinline__ float hsum<f32x4>(f32x4 v) { return (v.x + v.y) + (v.z + v.w); }
 template <> __device__ __forceinline__ float hsum<f32x2>(f32x2 v) { return v.x + v.y; }
 template <> __device__ __forceinline__ float hsum<float>(float v) { return v; }

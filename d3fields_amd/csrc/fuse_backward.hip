@@ -27,11 +27,13 @@ struct BwdRec {          // 32 B per (point, view)
     float zc, u, w, dist;   // dist: UNclamped d - zc
 };
 
-template <int VW, int U>
+// HALF: the map is stored in fp16 (8 channels per 16-B load or scalar lanes), widened to fp32 on load like the forward
+template <int VW, int U, bool HALF = false>
 __device__ __forceinline__ void backward_map(const MapDesc &m, const float *__restrict__ gout, const BackwardParams &P,
                                              const BwdRec *rec, float *dots, int64_t tile_base, int tile_n)
 {
     using VT = typename Vec<VW>::T;
+    constexpr int ES = HALF ? 2 : 4;
     const int lpp = 1 << m.lpp_log2;
     const int g = threadIdx.x & (lpp - 1);
     const int grp = threadIdx.x >> m.lpp_log2;
@@ -58,21 +60,22 @@ __device__ __forceinline__ void backward_map(const MapDesc &m, const float *__re
                 const bool isw = in_bounds(x0, y1, m.fw, m.fh), ise = in_bounds(x1, y1, m.fw, m.fh);
                 const int xi0 = (inw || isw) ? (int)x0 : 0, yi0 = (inw || ine) ? (int)y0 : 0;
                 const int xi1 = (ine || ise) ? (int)x1 : 0, yi1 = (isw || ise) ? (int)y1 : 0;
-                const float *bv = m.data + (int64_t)v * m.sv;
-                const float *pnw = bv + (int64_t)yi0 * m.sy + (int64_t)xi0 * m.sx;
-                const float *pne = bv + (int64_t)yi0 * m.sy + (int64_t)xi1 * m.sx;
-                const float *psw = bv + (int64_t)yi1 * m.sy + (int64_t)xi0 * m.sx;
-                const float *pse = bv + (int64_t)yi1 * m.sy + (int64_t)xi1 * m.sx;
+                const char *bv = reinterpret_cast<const char *>(m.data) + (int64_t)v * m.sv * ES;
+                const char *pnw = bv + ((int64_t)yi0 * m.sy + (int64_t)xi0 * m.sx) * ES;
+                const char *pne = bv + ((int64_t)yi0 * m.sy + (int64_t)xi1 * m.sx) * ES;
+                const char *psw = bv + ((int64_t)yi1 * m.sy + (int64_t)xi0 * m.sx) * ES;
+                const char *pse = bv + ((int64_t)yi1 * m.sy + (int64_t)xi1 * m.sx) * ES;
                 for (int c0 = 0; c0 < cvec; c0 += lpp * U) {
 #pragma unroll
                     for (int u = 0; u < U; ++u) {
                         const int cv = c0 + u * lpp + g;
                         if (cv < cvec) {
                             const int co = cv * VW;
-                            const VT a = inw ? load_vec<VT>(pnw + co) : (VT)0.0f;
-                            const VT b = ine ? load_vec<VT>(pne + co) : (VT)0.0f;
-                            const VT d = isw ? load_vec<VT>(psw + co) : (VT)0.0f;
-                            const VT e = ise ? load_vec<VT>(pse + co) : (VT)0.0f;
+                            const int cb = co * ES;
+                            const VT a = inw ? widen<VW, HALF>(load_texel<VW, HALF>(pnw + cb)) : (VT)0.0f;
+                            const VT b = ine ? widen<VW, HALF>(load_texel<VW, HALF>(pne + cb)) : (VT)0.0f;
+                            const VT d = isw ? widen<VW, HALF>(load_texel<VW, HALF>(psw + cb)) : (VT)0.0f;
+                            const VT e = ise ? widen<VW, HALF>(load_texel<VW, HALF>(pse + cb)) : (VT)0.0f;
                             const VT go = load_vec<VT>(gout + i * m.C + co);
                             VT s = a * (sy * ex);
                             s = v_fma<VT>(b, sy * tx, s);
@@ -102,15 +105,17 @@ __device__ __forceinline__ void backward_map(const MapDesc &m, const float *__re
     }
 }
 
-template <int VW>
+template <int VW, bool HALF = false>
 __device__ __forceinline__ void backward_map_u(const MapDesc &m, const float *gout, const BackwardParams &P,
                                                const BwdRec *rec, float *dots, int64_t tile_base, int tile_n)
 {
     switch (m.unroll < 0 ? -m.unroll : m.unroll) {
-    case 1: backward_map<VW, 1>(m, gout, P, rec, dots, tile_base, tile_n); break;
-    case 2: backward_map<VW, 2>(m, gout, P, rec, dots, tile_base, tile_n); break;
-    case 3: backward_map<VW, 3>(m, gout, P, rec, dots, tile_base, tile_n); break;
-    default: backward_map<VW, 4>(m, gout, P, rec, dots, tile_base, tile_n); break;
+    case 1: backward_map<VW, 1, HALF>(m, gout, P, rec, dots, tile_base, tile_n); break;
+    case 2: backward_map<VW, 2, HALF>(m, gout, P, rec, dots, tile_base, tile_n); break;
+    case 3: backward_map<VW, 3, HALF>(m, gout, P, rec, dots, tile_base, tile_n); break;
+    default:
+        if (!HALF) backward_map<VW, 4, false>(m, gout, P, rec, dots, tile_base, tile_n);    // fp16 maps: <= 3 vectors
+        break;
     }
 }
 
@@ -161,7 +166,10 @@ __global__ __launch_bounds__(kBlock) void fused_eval_backward_kernel(const Backw
     for (int s = 0; s < P.n_maps; ++s) {
         const MapDesc &m = P.maps[s];
         const float *gout = P.grad_fused[s];
-        if (gout) {
+        if (gout && m.esize == 2) {
+            if (m.vw == 8) backward_map_u<8, true>(m, gout, P, rec, dots, tile_base, tile_n);
+            else backward_map_u<1, true>(m, gout, P, rec, dots, tile_base, tile_n);
+        } else if (gout) {
             switch (m.vw) {
             case 4: backward_map_u<4>(m, gout, P, rec, dots, tile_base, tile_n); break;
             case 2: backward_map_u<2>(m, gout, P, rec, dots, tile_base, tile_n); break;

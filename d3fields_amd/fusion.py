@@ -367,10 +367,8 @@ class Fusion:
         gptr = (ctypes.c_void_p * max(nm, 1))()
         hold = []
         for s, m in enumerate(used_maps):
-            if m.dtype != torch.float32:
-                raise NotImplementedError("gradients through float16-stored maps are not implemented "
-                                          "(d3f_eval_backward takes float32 maps)")
-            maps[s] = _lib.ChannelMap(m.data_ptr(), m.shape[1], m.shape[2], m.shape[3], _lib.DTYPE_F32,
+            maps[s] = _lib.ChannelMap(m.data_ptr(), m.shape[1], m.shape[2], m.shape[3],
+                                      _lib.DTYPE_F16 if m.dtype == torch.float16 else _lib.DTYPE_F32,
                                       m.stride(0), m.stride(1), m.stride(2))
             g = grad_fused[s]
             if g is not None:

@@ -42,7 +42,7 @@ extern "C" {
 #define D3F_DTYPE_F16 1 /* IEEE half STORAGE of a channel map (a data format of the producer side: DINOv2 run in   \
                            fp16, fusion.py:203,227,616).  Texels are widened to fp32 on load and every operation of \
                            the query stays fp32, so the result equals the fp32 query on the widened map bit for bit  \
-                           at half the texel traffic.  Forward entry points only; strides stay in ELEMENTS.         */
+                           at half the texel traffic.  Strides stay in ELEMENTS.                                    */
 
 /* d3f_eval flags */
 #define D3F_FLAG_FINITE_MAPS 1u /* caller has verified that depth and every channel map hold   \
@@ -89,7 +89,7 @@ typedef struct d3f_views {
 typedef struct d3f_channel_map {
     const void *data;
     int32_t fh, fw, C;
-    int32_t dtype; /* D3F_DTYPE_F32 or D3F_DTYPE_F16 (forward only) */
+    int32_t dtype; /* D3F_DTYPE_F32 or D3F_DTYPE_F16 */
     int64_t stride_v, stride_y, stride_x;
 } d3f_channel_map;
 
