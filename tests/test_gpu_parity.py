@@ -5,6 +5,8 @@ Tolerances (BASELINE.json north_star): valid_mask / instance indices bit-exact; 
 (same IEEE operation sequence as the oracle); fused channels <= 1e-5 relative to
 max(|ref|_inf, 1) (expf implementations differ by <= 1 ulp); raw bilinear samples bit-exact.
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -503,6 +505,41 @@ def test_fusion_float16_is_a_storage_format(dev):
     pts, _ = create_init_grid(box, 0.02)
     b = f.batch_eval(pts.to(dev), return_names=["dino_feats"])
     assert torch.equal(g["dino_feats"].reshape(-1, 16), b["dino_feats"]) and torch.equal(g["dist"].reshape(-1), b["dist"])
+
+
+def test_c_abi_from_cpp_host(dev, tmp_path):
+    """examples/c_abi_demo.cpp: a host program with no Python and no torch drives d3f_eval through include/d3fields_hip.h
+    (hipMalloc'd buffers, its own stream, the optional scratch); its inputs and outputs are re-checked with the oracle."""
+    import shutil
+    import subprocess
+    from conftest import ROOT
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    exe, blob = str(tmp_path / "c_abi_demo"), str(tmp_path / "c_abi_demo.bin")
+    libdir = os.path.join(ROOT, "d3fields_amd")
+    subprocess.run([hipcc, "--offload-arch=gfx950", "-O2", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "examples", "c_abi_demo.cpp"),
+                    "-L", libdir, "-ld3fields_hip", "-Wl,-rpath," + libdir, "-o", exe], check=True, capture_output=True, timeout=600)
+    run = subprocess.run([exe, blob], check=True, capture_output=True, timeout=120, text=True)
+    assert "valid" in run.stdout
+    raw = open(blob, "rb").read()
+    V, H, W, fh, fw, C, n, _ = np.frombuffer(raw[:32], np.int32)
+    off = [32]
+
+    def take(count, dt=np.float32):
+        a = np.frombuffer(raw, dt, count, off[0])
+        off[0] += a.nbytes
+        return a
+
+    K, pose = take(V * 9).reshape(V, 3, 3), take(V * 12).reshape(V, 3, 4)
+    depth, feats = take(V * H * W).reshape(V, H, W), take(V * fh * fw * C).reshape(V, fh, fw, C)
+    pts, dist = take(n * 3).reshape(n, 3), take(n)
+    valid, fused = take(n, np.uint8), take(n * C).reshape(n, C)
+    assert off[0] == len(raw)
+    from oracle import c_oracle as O
+    ref = O.eval_field(depth, K, pose, pts, [feats])
+    assert 0.2 < valid.mean() < 0.95                       # the scene exercises valid and invalid points
+    assert np.array_equal(valid.astype(bool), ref["valid_mask"].astype(bool))
+    assert np.array_equal(dist, ref["dist"])
+    assert rel_err(fused, ref["sets"][0]) <= TOL
 
 
 def test_fails_loudly_without_gpu_tensors(dev):
