@@ -9,5 +9,7 @@ this package is the host-side mirror of the reference's Python interface.
 from .fusion import Fusion, create_init_grid, fps, instance2onehot, onehot2instance  # noqa: F401
 from . import corr_utils  # noqa: F401
 from . import pcd_utils  # noqa: F401
+from . import rigid  # noqa: F401
+from . import sharding  # noqa: F401
 
 __version__ = "0.1.0"

@@ -10,7 +10,6 @@ replayed (`use_graph=True`): same kernels, same order, one host call per iterati
 pytorch3d (reference env pins 0.7.5, env.yaml:14) is neither available on ROCm images nor needed:
 the two functions the reference calls are a dozen lines each and are restated below.
 """
-import numpy as np
 import torch
 
 __all__ = ["so3_exp_map", "rigid_transform", "track_rigid"]
