@@ -1,0 +1,82 @@
+"""GPU, two ranks on ONE device over gloo: the sharded paths of d3fields_amd.sharding running the real HIP kernels
+(RCCL itself needs one GPU per rank; the driver's 8-GPU run covers that).  Each rank evaluates its block with
+Fusion.batch_eval / the row-sharded softmax steps; gathered results must equal the single-process ones."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from d3fields_amd import Fusion, sharding, synth, corr_utils
+        dev = torch.device("cuda:0")
+        V, H, W = 4, 120, 160
+        sc = synth.make_scene(V, H, W, "stress")
+        f = Fusion(num_cam=V, device="cuda:0")
+        f.curr_obs_torch = {k: sc[k].to(dev) for k in ("depth", "K", "pose")}
+        if rank == 0:       # maps exist on rank 0 only until the broadcast
+            f.curr_obs_torch["dino_feats"] = synth.random_map(V, 12, 16, 96, seed=1, device=dev)
+            f.curr_obs_torch["mask"] = synth.random_onehot_mask(V, H, W, 5, seed=2, device=dev)
+        else:
+            f.curr_obs_torch["dino_feats"] = torch.zeros(V, 12, 16, 96, device=dev)
+            f.curr_obs_torch["mask"] = torch.zeros(V, H, W, 5, device=dev)
+        f.H, f.W = H, W
+        sharding.broadcast_observation(f, src=0)
+        pts = synth.random_cloud(70001, seed=3).to(dev)          # ragged: 35001 + 35000
+        names = ["dino_feats", "mask"]
+        with torch.no_grad():
+            full = sharding.sharded_eval(f, pts, names)
+            part = sharding.sharded_eval(f, pts, names, gather_keys=("dist", "valid_mask"))
+            single = f.batch_eval(pts, return_names=names)
+        ok = all(torch.equal(full[k], single[k]) for k in single)
+        lo, hi = part["local_range"]
+        ok = ok and torch.equal(part["dino_feats_local"], single["dino_feats"][lo:hi]) and torch.equal(part["dist"], single["dist"])
+        # descriptor rows sharded: softmax over ALL rows with one 16-B record per target column exchanged
+        tgt = torch.randn(33, 96, generator=torch.Generator().manual_seed(7)).to(dev)
+        tgt[5] = single["dino_feats"][60000]
+        sim, am = sharding.sharded_similarity_multi(single["dino_feats"][lo:hi].contiguous(), tgt, 0.8, row_offset=lo)
+        ref, ref_am = corr_utils.nearest_descriptor(single["dino_feats"], tgt, 0.8)
+        err = float((sim - ref[lo:hi]).abs().max())
+        ok_sim = err <= 1e-6 and torch.equal(am, ref_am) and int(am[5]) == 60000
+        q.put((rank, bool(ok), bool(ok_sim), err))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_one_gpu_hip_kernels():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=600) for _ in range(world)]
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    for rank, ok, ok_sim, err in res:
+        assert ok, "rank %d: sharded field differs from the single-process field" % rank
+        assert ok_sim, "rank %d: row-sharded softmax differs (max err %g)" % (rank, err)
