@@ -507,6 +507,63 @@ def test_fusion_float16_is_a_storage_format(dev):
     assert torch.equal(g["dino_feats"].reshape(-1, 16), b["dino_feats"]) and torch.equal(g["dist"].reshape(-1), b["dist"])
 
 
+@pytest.mark.parametrize("seed", range(6))
+def test_random_configurations_vs_oracle(dev, seed):
+    """Differential sweep: random view counts, image / map sizes, channel counts (16-B, 8-B, scalar lanes), strided map
+    views, fp16 storage, truncation distances and tuning flags, with pathological points mixed in -- every output
+    against the oracle (valid / dist / raw samples bit-exact for V <= 4, fused rows within TOL)."""
+    from d3fields_amd import synth, _lib
+    rng = np.random.default_rng(1000 + seed)
+
+    def same_dist(got, ref, V):          # check_dist, tolerant of the NaN / Inf rows the pathological points produce
+        assert np.array_equal(np.isfinite(got), np.isfinite(ref)) and np.array_equal(np.isnan(got), np.isnan(ref))
+        fin = np.isfinite(ref)
+        check_dist(got[fin], ref[fin], V)
+        assert np.array_equal(got[~fin & ~np.isnan(ref)], ref[~fin & ~np.isnan(ref)])
+
+    for _ in range(7):
+        V = int(rng.integers(1, 7))
+        H, W = int(rng.integers(8, 70)), int(rng.integers(8, 90))
+        sc = synth.make_scene(V, H, W, "stress" if rng.random() < 0.5 else "smooth", seed=int(rng.integers(100)))
+        nm = int(rng.integers(0, 4))
+        maps, names = {}, []
+        for j in range(nm):
+            C = int(rng.choice([1, 2, 3, 4, 5, 6, 8, 12, 16, 33, 64, 96, 384]))
+            full = rng.random() < 0.4
+            fh, fw = (H, W) if full else (int(rng.integers(1, 12)), int(rng.integers(1, 14)))
+            t = synth.random_map(V, fh, fw, C + int(rng.integers(0, 3)) * 4, seed=int(rng.integers(1000)))[..., :C]   # maybe a strided view
+            if rng.random() < 0.3:
+                t = t.half()
+            maps["m%d" % j] = t
+            names.append("m%d" % j)
+        n = int(rng.integers(1, 5000))
+        pts = synth.random_cloud(n, seed=int(rng.integers(1000))) * float(rng.choice([0.5, 1.0, 3.0]))
+        if n > 10:
+            pts[int(rng.integers(n))] = float("nan")
+            pts[int(rng.integers(n)), 2] = float("inf")
+            pts[int(rng.integers(n))] = torch.tensor([0.0, 0.0, -0.6])           # at a camera height: |z| tiny in some views
+        mu = float(rng.choice([0.02, 0.005, 0.1]))
+        f = make_fusion(dev, sc["depth"], sc["K"], sc["pose"], maps, H, W, mu)
+        f.tuning_flags = int(rng.choice([0, _lib.TUNE_FORCE_REORDER, _lib.TUNE_NO_REORDER, 3 << 8, 5 << 8]))
+        with torch.no_grad():
+            got = f.eval(pts.to(dev), return_names=names, return_inter=bool(rng.random() < 0.5))
+            gd = f.eval_dist(pts.to(dev))
+        wide = [maps[k].float().contiguous().numpy() for k in names]
+        want_inter = any(k.endswith("_inter") for k in got)
+        ref = oracle_eval(sc, pts.numpy(), wide, mu=mu, return_inter=want_inter)
+        tag = "seed %d V=%d %dx%d maps=%s n=%d" % (seed, V, H, W, [tuple(m.shape[1:]) + (str(m.dtype),) for m in maps.values()], n)
+        assert np.array_equal(cpu(got["valid_mask"]), ref["valid_mask"].astype(bool)), tag
+        same_dist(cpu(got["dist"]), ref["dist"], V)
+        for j, k in enumerate(names):
+            assert rel_err(np.nan_to_num(cpu(got[k]), posinf=0, neginf=0), np.nan_to_num(ref["sets"][j], posinf=0, neginf=0)) <= TOL, tag
+            assert np.array_equal(np.isnan(cpu(got[k])), np.isnan(ref["sets"][j])), tag
+            if want_inter:
+                assert np.array_equal(cpu(got[k + "_inter"]), ref["inter"][j], equal_nan=True), tag
+        rd = oracle_eval(sc, pts.numpy(), [], mu=mu, mode="eval_dist")
+        assert np.array_equal(cpu(gd["valid_mask"]), rd["valid_mask"].astype(bool)), tag
+        same_dist(cpu(gd["dist"]), rd["dist"], V)
+
+
 def test_c_abi_from_cpp_host(dev, tmp_path):
     """examples/c_abi_demo.cpp: a host program with no Python and no torch drives d3f_eval through include/d3fields_hip.h
     (hipMalloc'd buffers, its own stream, the optional scratch); its inputs and outputs are re-checked with the oracle."""
