@@ -197,6 +197,8 @@ class Fusion:
         self.mask_tracker = mask_tracker
         self.track_ids = [0]
         self._finite_cache = {}
+        self._finite_override = None
+        self._tracker = None                    # rigid_tracking: the captured iteration of the current sequence
         self.tuning_flags = 0                   # D3F_TUNE_* bits (experiments; results do not depend on them)
         self.reorder_points = True              # hand the library scratch so it may walk points in Morton order
         self.use_hip_graph = True               # rigid_tracking: capture the optimiser iteration in a HIP graph
@@ -254,6 +256,8 @@ class Fusion:
 
     def _is_finite(self, key, t):
         """Cached torch.isfinite(t).all(): lets the kernel skip invalid views exactly (D3F_FLAG_FINITE_MAPS)."""
+        if self._finite_override is not None:       # RigidTracker's private observation: the flag must not depend on data
+            return self._finite_override
         sig = (t.data_ptr(), t._version, tuple(t.shape))
         hit = self._finite_cache.get(key)
         if hit is None or hit[0] != sig:
@@ -542,7 +546,14 @@ class Fusion:
         last_np = np.stack([np.asarray(p) for p in last_match_pts_list], axis=0)
         assert last_np.shape[:2] == (num_instance, rand_ptcl_num)
         last = torch.from_numpy(last_np).to(dev, dtype=torch.float32)
-        cur, _ = rigid.track_rigid(self, src_feats, last, use_graph=self.use_hip_graph)
+        if self.use_hip_graph:
+            # one capture per sequence: the graph is kept while instances / keypoints / views / map sizes stay the same
+            key = rigid.RigidTracker.signature(self, num_instance, rand_ptcl_num)
+            if self._tracker is None or self._tracker.key != key:
+                self._tracker = rigid.RigidTracker(self, num_instance, rand_ptcl_num)
+            cur, _ = self._tracker.run(self, src_feats, last)
+        else:
+            cur, _ = rigid.track_rigid(self, src_feats, last, use_graph=False)
         cur = cur.cpu().numpy()
         return {"match_pts_list": [cur[i * rand_ptcl_num:(i + 1) * rand_ptcl_num] for i in range(num_instance)]}
 

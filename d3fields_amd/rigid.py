@@ -12,7 +12,7 @@ the two functions the reference calls are a dozen lines each and are restated be
 """
 import torch
 
-__all__ = ["so3_exp_map", "rigid_transform", "track_rigid"]
+__all__ = ["so3_exp_map", "rigid_transform", "track_rigid", "RigidTracker"]
 
 LR, ITERS, REG_W, DIST_W = 0.01, 100, 1.0, 100.0       # fusion.py:1613-1617
 
@@ -84,3 +84,71 @@ def track_rigid(fusion, src_feats, last_match_pts, use_graph=True, iters=ITERS, 
     for _ in range(iters):
         graph.replay()
     return cur.detach().clone(), loss.detach().clone()
+
+
+class RigidTracker:
+    """The tracking iteration captured ONCE and replayed for every frame of a sequence.
+
+    track_rigid(use_graph=True) warms up and captures per call (~15 of its ~39 ms per frame).  A sequence keeps its shapes
+    -- instances, keypoints, views, map sizes -- so this object owns static device buffers (a private observation the
+    captured kernels point at, the keypoints, the source descriptors, the pose parameters and Adam's state); per frame
+    it copies the new observation and inputs into them, rewinds parameters and optimiser state to the reference's
+    initial values and replays the graph `iters` times.  The captured query runs without D3F_FLAG_FINITE_MAPS
+    (the flag would be baked into the graph; results are identical either way)."""
+
+    def __init__(self, fusion, num_inst, n, iters=ITERS, lr=LR):
+        from .fusion import Fusion
+        dev = torch.device(fusion.device)
+        obs = fusion.curr_obs_torch
+        self.key = self.signature(fusion, num_inst, n)
+        self.iters = iters
+        self.shadow = Fusion(num_cam=fusion.num_cam, device=str(dev), dtype=fusion.dtype)
+        self.shadow.H, self.shadow.W, self.shadow.mu = fusion.H, fusion.W, fusion.mu
+        self.shadow.curr_obs_torch = {k: torch.empty_like(obs[k]) for k in ("depth", "K", "pose", "dino_feats")}
+        self.shadow._finite_override = False
+        C = obs["dino_feats"].shape[3]
+        self.last = torch.empty(num_inst, n, 3, device=dev)
+        self.src = torch.empty(num_inst * n, C, device=dev)
+        self.t_params = torch.zeros(num_inst, 3, device=dev, requires_grad=True)
+        self.log_r = torch.zeros(num_inst, 3, device=dev, requires_grad=True)
+        self.opt = torch.optim.Adam([self.t_params, self.log_r], lr=lr, betas=(0.9, 0.999), capturable=True)
+        self.graph = None
+        self.cur = self.loss = None
+
+    @staticmethod
+    def signature(fusion, num_inst, n):
+        o = fusion.curr_obs_torch
+        return (num_inst, n, float(fusion.mu), fusion.H, fusion.W) + tuple(
+            (tuple(o[k].shape), o[k].dtype) for k in ("depth", "K", "pose", "dino_feats"))
+
+    def _rewind(self):
+        with torch.no_grad():
+            self.t_params.zero_()
+            self.log_r.zero_()
+            for st in self.opt.state.values():
+                for v in st.values():
+                    if isinstance(v, torch.Tensor):
+                        v.zero_()
+
+    def run(self, fusion, src_feats, last_match_pts):
+        dev = self.last.device
+        with torch.no_grad():
+            for k, t in self.shadow.curr_obs_torch.items():
+                t.copy_(fusion.curr_obs_torch[k])
+            self.last.copy_(last_match_pts)
+            self.src.copy_(src_feats)
+        if self.graph is None:
+            side = torch.cuda.Stream(device=dev)
+            side.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(side):
+                for _ in range(2):
+                    _iteration(self.shadow, self.last, self.src, self.t_params, self.log_r, self.opt)
+            torch.cuda.current_stream(dev).wait_stream(side)
+            self._rewind()
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph):
+                self.cur, self.loss = _iteration(self.shadow, self.last, self.src, self.t_params, self.log_r, self.opt)
+        self._rewind()
+        for _ in range(self.iters):
+            self.graph.replay()
+        return self.cur.detach().clone(), self.loss.detach().clone()

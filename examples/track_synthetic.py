@@ -72,13 +72,20 @@ def main():
     pts0 = [p.copy() for p in src_pts]
     last = [p.copy() for p in src_pts]
     pose0 = sc["pose"].numpy().astype(np.float64)
+    tracker = None
     for t in range(1, args.frames + 1):
         M = world_motion(t)
         pose_t = np.stack([np.concatenate([pose0[v], [[0, 0, 0, 1]]]) @ np.linalg.inv(M) for v in range(V)])[:, :3]
         f.curr_obs_torch["pose"] = torch.from_numpy(pose_t.astype(np.float32)).to(dev)   # same images, moved world
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        cur, loss = rigid.track_rigid(f, src, torch.from_numpy(np.stack(last)).to(dev), use_graph=not args.eager, lr=0.003)
+        start = torch.from_numpy(np.stack(last)).to(dev)
+        if args.eager:
+            cur, loss = rigid.track_rigid(f, src, start, use_graph=False, lr=0.003)
+        else:               # one capture for the whole sequence, replayed every frame
+            if tracker is None:
+                tracker = rigid.RigidTracker(f, len(pts0), n_kp, lr=0.003)
+            cur, loss = tracker.run(f, src, start)
         cur = cur.cpu().numpy()
         dt = time.perf_counter() - t0
         last = [cur[i * n_kp:(i + 1) * n_kp] for i in range(len(pts0))]

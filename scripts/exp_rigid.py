@@ -14,7 +14,7 @@ f.H, f.W, f.mu = int(g["H"]), int(g["W"]), float(g["mu"])
 n = int(g["n"])
 info = {"a": {"src_feats": torch.from_numpy(g["src_feats"][:n])}, "b": {"src_feats": torch.from_numpy(g["src_feats"][n:])}}
 last = [p for p in g["last_pts"]]
-for use_graph in (False, True, False, True):
+for use_graph in (False, True, False, True, True, True):
     f.use_hip_graph = use_graph
     torch.cuda.synchronize()
     t0 = time.perf_counter()

@@ -422,6 +422,23 @@ def test_rigid_tracking_matches_reference(dev, use_graph):
     err = np.abs(got - g["match_pts"]).max()
     assert err <= 1e-5, err
     assert np.abs(got - g["true_pts"]).max() < 0.5 * np.abs(g["last_pts"] - g["true_pts"]).max()
+    if use_graph:
+        # the captured iteration is kept for the sequence: a second frame (other start points, shifted cameras) replays
+        # it on fresh inputs and must equal the eager loop; then the first frame again
+        tracker = f._tracker
+        shifted = [p + np.float32(0.002) for p in g["last_pts"]]
+        pose2 = torch.from_numpy(g["pose"]).clone()
+        pose2[:, 0, 3] += 0.003
+        f.curr_obs_torch["pose"] = pose2.to(dev)
+        a = np.stack(f.rigid_tracking(info, shifted, None, n)["match_pts_list"])
+        assert f._tracker is tracker
+        f.use_hip_graph = False
+        b = np.stack(f.rigid_tracking(info, shifted, None, n)["match_pts_list"])
+        assert np.abs(a - b).max() <= 1e-5
+        f.use_hip_graph = True
+        f.curr_obs_torch["pose"] = torch.from_numpy(g["pose"]).to(dev)
+        again = np.stack(f.rigid_tracking(info, [p for p in g["last_pts"]], None, n)["match_pts_list"])
+        assert np.array_equal(again, got) and f._tracker is tracker
 
 
 def test_so3_exp_map_and_rigid_transform(dev):
