@@ -16,6 +16,7 @@ OK = 0
 ERR_INVALID_ARG, ERR_BAD_SHAPE, ERR_BAD_DTYPE, ERR_BAD_LAYOUT, ERR_HIP, ERR_WORKSPACE = -1, -2, -3, -4, -5, -6
 FLAG_FINITE_MAPS = 1
 FLAG_UNORDERED_POINTS = 2
+FLAG_REUSE_POINT_ORDER = 8
 TUNE_XCD_REMAP, TUNE_NO_REORDER, TUNE_FORCE_REORDER, TUNE_STAGING = 1 << 12, 1 << 13, 1 << 14, 1 << 15
 MAX_VIEWS = 64
 MAX_MAPS = 8

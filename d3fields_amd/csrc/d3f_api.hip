@@ -193,7 +193,9 @@ int eval_common(const d3f_views *views, const float *pts, int64_t n, const d3f_c
     if ((flags & D3F_TUNE_STAGING) && views->V * 24 * 32 <= 24 * 1024)
         for (int s = 0; s < n_maps; ++s) stage_any |= staging_candidate(P.maps[s], views->H, views->W);
     const bool reorder = may_reorder && ((flags & D3F_TUNE_FORCE_REORDER) || (n >= 65536 && (map_bytes > (64LL << 20) || stage_any || (flags & D3F_FLAG_UNORDERED_POINTS))));
-    if (reorder && !plan_only) {
+    if (reorder && !plan_only && (flags & D3F_FLAG_REUSE_POINT_ORDER)) {
+        P.order = d3f::stored_point_order(workspace, n);       // written by an earlier call for the same points
+    } else if (reorder && !plan_only) {
         hipError_t eo = d3f::build_point_order(pts, n, workspace, workspace_bytes, &P.order, hs, (int)((flags >> 24) & 0x3));
         if (eo != hipSuccess) return hip_fail(eo, "point ordering");
     }

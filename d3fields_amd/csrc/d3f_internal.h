@@ -72,6 +72,7 @@ hipError_t launch_fused_backward(const BackwardParams &P, int mode, hipStream_t 
 int64_t order_workspace_bytes(int64_t n);
 hipError_t build_point_order(const float *pts, int64_t n, void *workspace, int64_t workspace_bytes,
                              const uint32_t **order_out, hipStream_t stream, int fine = 0);
+const uint32_t *stored_point_order(void *workspace, int64_t n);
 // mean L1 step between consecutive points vs between points n/2 apart (out: 2 device floats)
 hipError_t launch_point_locality(const float *pts, int64_t n, float *out, hipStream_t stream);
 

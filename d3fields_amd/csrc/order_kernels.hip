@@ -83,8 +83,20 @@ hipError_t build_point_order(const float *pts, int64_t n, void *workspace, int64
     if (need > kSortScratch) return hipErrorOutOfMemory;
     e = rocprim::radix_sort_pairs<SortConfig>(scratch, need, keys, vals, (size_t)n, 0u, key_bits, stream);
     if (e != hipSuccess) return e;
-    *order_out = vals.current();
+    // the finished order always ends in the FIRST index buffer, so that a later call can find it again
+    // (D3F_FLAG_REUSE_POINT_ORDER) without knowing how many digit passes ran
+    if (vals.current() != v0) {
+        e = hipMemcpyAsync(v0, vals.current(), (size_t)n * 4, hipMemcpyDeviceToDevice, stream);
+        if (e != hipSuccess) return e;
+    }
+    *order_out = v0;
     return hipSuccess;
+}
+
+// where build_point_order leaves the order inside a workspace of order_workspace_bytes(n)
+const uint32_t *stored_point_order(void *workspace, int64_t n)
+{
+    return reinterpret_cast<const uint32_t *>(static_cast<unsigned char *>(workspace) + 2 * align_up((size_t)n * 4, 256));
 }
 
 // ---- does the caller's order have spatial locality? ------------------------------------------------

@@ -581,6 +581,42 @@ def test_random_configurations_vs_oracle(dev, seed):
         same_dist(cpu(gd["dist"]), rd["dist"], V)
 
 
+def test_cached_point_order_is_reused_and_harmless(dev):
+    """cache_point_order: the Morton order of an unchanged query tensor stays in its scratch (D3F_FLAG_REUSE_POINT_ORDER).
+    Same bits with and without the cache, across map updates, in-place changes of the points and a change of n."""
+    from d3fields_amd import synth, _lib
+    V, H, W = 4, 120, 160
+    sc = synth.make_scene(V, H, W, "smooth")
+    maps = {"dino_feats": synth.random_map(V, 12, 16, 96, seed=1)}
+    f = make_fusion(dev, sc["depth"], sc["K"], sc["pose"], maps, H, W)
+    f.tuning_flags = _lib.TUNE_FORCE_REORDER
+    pts = synth.random_cloud(120000, seed=4).to(dev)
+    with torch.no_grad():
+        f.cache_point_order = False
+        ref = f.batch_eval(pts, return_names=["dino_feats"])
+        f.cache_point_order = True
+        a = f.batch_eval(pts, return_names=["dino_feats"])           # builds and keeps the order
+        held = f._order_ws
+        b = f.batch_eval(pts, return_names=["dino_feats"])           # reuses it
+        assert f._order_ws is held and held[2]
+        for k in ref:
+            assert torch.equal(ref[k], a[k]) and torch.equal(ref[k], b[k]), k
+        f.curr_obs_torch["dino_feats"] = synth.random_map(V, 12, 16, 96, seed=9, device=dev)      # new frame, same grid
+        c = f.batch_eval(pts, return_names=["dino_feats"])
+        f.cache_point_order = False
+        c_ref = f.batch_eval(pts, return_names=["dino_feats"])
+        assert torch.equal(c["dino_feats"], c_ref["dino_feats"])
+        f.cache_point_order = True
+        pts.mul_(0.5)                                                 # in-place change: version bump -> rebuilt
+        d = f.batch_eval(pts, return_names=["dino_feats"])
+        assert f._order_ws is not held
+        f.cache_point_order = False
+        assert torch.equal(d["dino_feats"], f.batch_eval(pts, return_names=["dino_feats"])["dino_feats"])
+        f.cache_point_order = True
+        e = f.batch_eval(pts[:70000], return_names=["dino_feats"])   # other n (a view with the same data_ptr)
+        assert torch.equal(e["dino_feats"], d["dino_feats"][:70000])
+
+
 def test_c_abi_from_cpp_host(dev, tmp_path):
     """examples/c_abi_demo.cpp: a host program with no Python and no torch drives d3f_eval through include/d3fields_hip.h
     (hipMalloc'd buffers, its own stream, the optional scratch); its inputs and outputs are re-checked with the oracle."""
