@@ -355,7 +355,7 @@ class Fusion:
                 if small and self.detect_point_order and self._is_unordered(pts_c, stream):
                     flags |= _lib.FLAG_UNORDERED_POINTS     # larger maps are walked in Morton order anyway
                 ws_bytes = lib.d3f_eval_workspace_bytes(n)
-                sig = (pts_c.data_ptr(), pts_c._version, n)
+                sig = (pts_c.data_ptr(), pts_c._version, n, int(stream.value or 0))   # per stream: the order is written asynchronously
                 held = self._order_ws if self.cache_point_order else None
                 plan = None
                 if self.cache_point_order:
