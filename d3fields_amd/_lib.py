@@ -89,6 +89,9 @@ SIGNATURES = {
     "d3f_pairwise_softmax_local": (ctypes.c_int, [_vp, _vp, _i64, _i64, _i32, _f32, _i32, _i64, _vp, _vp, _vp, _i64,
                                                   _vp]),
     "d3f_point_order_locality": (ctypes.c_int, [_vp, _i64, _vp, _vp]),
+    "d3f_rigid_transform": (ctypes.c_int, [_vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),
+    "d3f_track_loss_grad": (ctypes.c_int, [_vp, _vp, _vp, _vp, _i64, _i32, _f32, _vp, _vp, _vp, _vp]),
+    "d3f_rigid_update": (ctypes.c_int, [_vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f32, _f32, _f32, _f32, _f32, _vp]),
     "d3f_softmax_merge": (ctypes.c_int, [_vp, _i64, _i64, _vp, _vp, _vp]),
     "d3f_softmax_apply": (ctypes.c_int, [_vp, _i64, _i64, _f32, _vp, _vp]),
 }

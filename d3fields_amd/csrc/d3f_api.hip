@@ -593,4 +593,41 @@ int d3f_softmax_apply(float *x, int64_t rows, int64_t cols, float scale, const d
     return e == hipSuccess ? D3F_OK : hip_fail(e, "softmax apply launch");
 }
 
+// ---- rigid tracking step (fusion.py:1643-1665) -----------------------------------------------------------------------
+int d3f_rigid_transform(const float *last, int32_t n_inst, int32_t n, const float *t, const float *w, float *out_pts,
+                        float *norms, void *stream)
+{
+    if (n_inst < 0 || n < 0 || (int64_t)n_inst * n > 0x7fffffffLL) return fail(D3F_ERR_BAD_SHAPE, "rigid_transform: n_inst=%d n=%d", n_inst, n);
+    if (!norms || (n_inst > 0 && (!t || !w)) || ((int64_t)n_inst * n > 0 && (!last || !out_pts)))
+        return fail(D3F_ERR_INVALID_ARG, "rigid_transform: NULL pointer");
+    hipError_t e = d3f::launch_rigid_transform(last, n_inst, n, t, w, 1e-4f, out_pts, norms, static_cast<hipStream_t>(stream));
+    return e == hipSuccess ? D3F_OK : hip_fail(e, "rigid_transform launch");
+}
+
+int d3f_track_loss_grad(const float *feats, const float *src, const float *dist, const uint8_t *valid, int64_t N, int32_t C,
+                        float dist_w, float *grad_feats, float *grad_dist, float *loss, void *stream)
+{
+    if (N < 0 || N > 0x7fffffffLL || C < 1) return fail(D3F_ERR_BAD_SHAPE, "track_loss_grad: N=%lld C=%d", (long long)N, C);
+    if (!loss || (N > 0 && (!feats || !src || !dist || !valid || !grad_feats || !grad_dist)))
+        return fail(D3F_ERR_INVALID_ARG, "track_loss_grad: NULL pointer");
+    hipError_t e = d3f::launch_track_loss_grad(feats, src, dist, valid, (int)N, C, dist_w, grad_feats, grad_dist, loss,
+                                               static_cast<hipStream_t>(stream));
+    return e == hipSuccess ? D3F_OK : hip_fail(e, "track_loss_grad launch");
+}
+
+int d3f_rigid_update(const float *last, int32_t n_inst, int32_t n, const float *grad_pts, float *t, float *w, float *adam_m,
+                     float *adam_v, float *step, const float *norms, float reg_w, float lr, float beta1, float beta2, float eps,
+                     void *stream)
+{
+    if (n_inst < 0 || n < 0) return fail(D3F_ERR_BAD_SHAPE, "rigid_update: n_inst=%d n=%d", n_inst, n);
+    if (n_inst == 0) return D3F_OK;
+    if (!t || !w || !adam_m || !adam_v || !step || !norms || (n > 0 && (!last || !grad_pts)))
+        return fail(D3F_ERR_INVALID_ARG, "rigid_update: NULL pointer");
+    if (!(lr > 0.0f) || !(beta1 >= 0.0f && beta1 < 1.0f) || !(beta2 >= 0.0f && beta2 < 1.0f) || !(eps > 0.0f))
+        return fail(D3F_ERR_INVALID_ARG, "rigid_update: lr=%g beta=(%g,%g) eps=%g", lr, beta1, beta2, eps);
+    hipError_t e = d3f::launch_rigid_update(last, n_inst, n, grad_pts, t, w, adam_m, adam_v, step, norms, 1e-4f, reg_w, lr, beta1,
+                                            beta2, eps, static_cast<hipStream_t>(stream));
+    return e == hipSuccess ? D3F_OK : hip_fail(e, "rigid_update launch");
+}
+
 }  // extern "C"

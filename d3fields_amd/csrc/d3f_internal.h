@@ -119,4 +119,13 @@ hipError_t launch_softmax_apply(float *x, int64_t rows, int64_t cols, float scal
 hipError_t launch_argmin_dim0(const float *x, int64_t rows, int64_t cols, int64_t *arg_out, ColStat *ws,
                               bool have_stats, hipStream_t s);
 
+// track_kernels.hip: the closed-form parts of the rigid-tracking optimiser step
+hipError_t launch_rigid_transform(const float *last, int I, int n, const float *t, const float *w, float eps, float *out_pts,
+                                  float *norms, hipStream_t s);
+hipError_t launch_track_loss_grad(const float *feats, const float *src, const float *dist, const uint8_t *valid, int N, int C,
+                                  float dist_w, float *grad_feats, float *grad_dist, float *loss, hipStream_t s);
+hipError_t launch_rigid_update(const float *last, int I, int n, const float *grad_pts, float *t, float *w, float *adam_m, float *adam_v,
+                               float *step, const float *norms, float eps_rot, float reg_w, float lr, float beta1, float beta2,
+                               float eps_adam, hipStream_t s);
+
 }  // namespace d3f

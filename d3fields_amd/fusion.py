@@ -202,6 +202,7 @@ class Fusion:
         self.tuning_flags = 0                   # D3F_TUNE_* bits (experiments; results do not depend on them)
         self.reorder_points = True              # hand the library scratch so it may walk points in Morton order
         self.use_hip_graph = True               # rigid_tracking: capture the optimiser iteration in a HIP graph
+        self.fused_tracking = True              # ... and run it as five HIP launches (track_kernels.hip) instead of autograd
         self.detect_point_order = True          # probe new query tensors for locality (one host sync each, cached)
         self._order_cache = None
         self.cache_point_order = True           # keep the Morton order of an unchanged query tensor (a grid queried every
@@ -564,8 +565,8 @@ class Fusion:
         if self.use_hip_graph:
             # one capture per sequence: the graph is kept while instances / keypoints / views / map sizes stay the same
             key = rigid.RigidTracker.signature(self, num_instance, rand_ptcl_num)
-            if self._tracker is None or self._tracker.key != key:
-                self._tracker = rigid.RigidTracker(self, num_instance, rand_ptcl_num)
+            if self._tracker is None or self._tracker.key != key or self._tracker.fused != self.fused_tracking:
+                self._tracker = rigid.RigidTracker(self, num_instance, rand_ptcl_num, fused=self.fused_tracking)
             cur, _ = self._tracker.run(self, src_feats, last)
         else:
             cur, _ = rigid.track_rigid(self, src_feats, last, use_graph=False)

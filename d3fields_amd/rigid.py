@@ -94,14 +94,19 @@ class RigidTracker:
     captured kernels point at, the keypoints, the source descriptors, the pose parameters and Adam's state); per frame
     it copies the new observation and inputs into them, rewinds parameters and optimiser state to the reference's
     initial values and replays the graph `iters` times.  The captured query runs without D3F_FLAG_FINITE_MAPS
-    (the flag would be baked into the graph; results are identical either way)."""
+    (the flag would be baked into the graph; results are identical either way).
 
-    def __init__(self, fusion, num_inst, n, iters=ITERS, lr=LR):
+    fused=True (default): the step is FIVE launches -- d3f_rigid_transform, d3f_eval, d3f_track_loss_grad,
+    d3f_eval_backward, d3f_rigid_update (csrc/track_kernels.hip: exponential map, transform, loss gradients, chain
+    rule and Adam in closed form) -- instead of torch autograd's ~90.  fused=False replays the autograd step."""
+
+    def __init__(self, fusion, num_inst, n, iters=ITERS, lr=LR, fused=True):
         from .fusion import Fusion
         dev = torch.device(fusion.device)
         obs = fusion.curr_obs_torch
         self.key = self.signature(fusion, num_inst, n)
-        self.iters = iters
+        self.iters, self.lr, self.fused = iters, lr, fused
+        self.num_inst, self.n = num_inst, n
         self.shadow = Fusion(num_cam=fusion.num_cam, device=str(dev), dtype=fusion.dtype)
         self.shadow.H, self.shadow.W, self.shadow.mu = fusion.H, fusion.W, fusion.mu
         self.shadow.curr_obs_torch = {k: torch.empty_like(obs[k]) for k in ("depth", "K", "pose", "dino_feats")}
@@ -109,9 +114,16 @@ class RigidTracker:
         C = obs["dino_feats"].shape[3]
         self.last = torch.empty(num_inst, n, 3, device=dev)
         self.src = torch.empty(num_inst * n, C, device=dev)
-        self.t_params = torch.zeros(num_inst, 3, device=dev, requires_grad=True)
-        self.log_r = torch.zeros(num_inst, 3, device=dev, requires_grad=True)
-        self.opt = torch.optim.Adam([self.t_params, self.log_r], lr=lr, betas=(0.9, 0.999), capturable=True)
+        self.t_params = torch.zeros(num_inst, 3, device=dev, requires_grad=not fused)
+        self.log_r = torch.zeros(num_inst, 3, device=dev, requires_grad=not fused)
+        if fused:
+            self.state = torch.zeros(num_inst * 13 + 4, device=dev)      # Adam m [I,6], v [I,6], step [I], norms [2], loss [2]
+            self.pts = torch.empty(num_inst * n, 3, device=dev)
+            self.grad_feats = torch.empty(num_inst * n, C, device=dev)
+            self.grad_dist = torch.empty(num_inst * n, device=dev)
+            self.opt = None
+        else:
+            self.opt = torch.optim.Adam([self.t_params, self.log_r], lr=lr, betas=(0.9, 0.999), capturable=True)
         self.graph = None
         self.cur = self.loss = None
 
@@ -125,10 +137,40 @@ class RigidTracker:
         with torch.no_grad():
             self.t_params.zero_()
             self.log_r.zero_()
-            for st in self.opt.state.values():
-                for v in st.values():
-                    if isinstance(v, torch.Tensor):
-                        v.zero_()
+            if self.fused:
+                self.state.zero_()
+            else:
+                for st in self.opt.state.values():
+                    for v in st.values():
+                        if isinstance(v, torch.Tensor):
+                            v.zero_()
+
+    def _fused_iteration(self):
+        """transform -> d3f_eval -> loss gradients -> d3f_eval_backward -> chain rule + Adam: five launches, no autograd."""
+        from . import _lib
+        lib, dev = _lib.load(), self.last.device
+        I, n, N = self.num_inst, self.n, self.num_inst * self.n
+        st = self.state
+        m, v, step, norms, loss = st[:I * 6], st[I * 6:I * 12], st[I * 12:I * 13], st[I * 13:I * 13 + 2], st[I * 13 + 2:I * 13 + 4]
+        with torch.cuda.device(dev), torch.no_grad():
+            stream = _lib.current_stream_handle(dev)
+            _lib.check(lib.d3f_rigid_transform(_lib.ptr(self.last), I, n, _lib.ptr(self.t_params), _lib.ptr(self.log_r),
+                                               _lib.ptr(self.pts), _lib.ptr(norms), stream))
+            out, saved = self.shadow._launch(self.pts, ["dino_feats"], False, "eval")
+            _lib.check(lib.d3f_track_loss_grad(_lib.ptr(out["dino_feats"]), _lib.ptr(self.src), _lib.ptr(out["dist"]),
+                                               _lib.ptr(out["valid_mask"]), N, self.src.shape[1], DIST_W, _lib.ptr(self.grad_feats),
+                                               _lib.ptr(self.grad_dist), _lib.ptr(loss), stream))
+            grad_pts = self.shadow._backward(saved, self.grad_dist, [self.grad_feats])
+            _lib.check(lib.d3f_rigid_update(_lib.ptr(self.last), I, n, _lib.ptr(grad_pts), _lib.ptr(self.t_params), _lib.ptr(self.log_r),
+                                            _lib.ptr(m), _lib.ptr(v), _lib.ptr(step), _lib.ptr(norms), REG_W, self.lr, 0.9, 0.999, 1e-8,
+                                            stream))
+        # total loss of this step as the reference forms it: feature + distance + regulariser (norms are pre-update)
+        return self.pts, loss[0] + loss[1] + REG_W * (norms[0] + norms[1])
+
+    def _step(self):
+        if self.fused:
+            return self._fused_iteration()
+        return _iteration(self.shadow, self.last, self.src, self.t_params, self.log_r, self.opt)
 
     def run(self, fusion, src_feats, last_match_pts):
         dev = self.last.device
@@ -142,12 +184,12 @@ class RigidTracker:
             side.wait_stream(torch.cuda.current_stream(dev))
             with torch.cuda.stream(side):
                 for _ in range(2):
-                    _iteration(self.shadow, self.last, self.src, self.t_params, self.log_r, self.opt)
+                    self._step()
             torch.cuda.current_stream(dev).wait_stream(side)
             self._rewind()
             self.graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.graph):
-                self.cur, self.loss = _iteration(self.shadow, self.last, self.src, self.t_params, self.log_r, self.opt)
+                self.cur, self.loss = self._step()
         self._rewind()
         for _ in range(self.iters):
             self.graph.replay()

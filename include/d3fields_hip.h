@@ -284,6 +284,28 @@ int d3f_softmax_merge(const d3f_col_stat *parts, int64_t n_parts, int64_t cols, 
 int d3f_softmax_apply(float *x, int64_t rows, int64_t cols, float scale, const d3f_col_stat *merged,
                       void *stream);
 
+/* ---- the optimiser step of Fusion.rigid_tracking (fusion.py:1608-1685) ---------------------------------
+ * One step of the reference is  so3_exp_map -> rigid transform -> Fusion.eval -> loss -> autograd -> Adam
+ * (pytorch3d + ~90 torch launches).  Around d3f_eval / d3f_eval_backward the rest is closed-form:
+ *   1. d3f_rigid_transform : per instance i, R_i = so3_exp_map(w_i) (pytorch3d 0.7.5: Rodrigues, angle clamped
+ *      at sqrt(1e-4)), out_pts[i,p] = last[i,p] @ R_i + t_i (row-vector convention); norms[0..1] = |t|_F, |w|_F.
+ *   2. d3f_eval on out_pts (one channel map: the descriptors).
+ *   3. d3f_track_loss_grad : loss[0] = mean(|f - src| * valid), loss[1] = dist_w * mean(max(dist*valid, 0))
+ *      (fusion.py:1654-1657) and their gradients w.r.t. f and dist.
+ *   4. d3f_eval_backward -> grad_pts.
+ *   5. d3f_rigid_update : chain rule through the transform and the exponential map, + reg_w * d(|t|_F + |w|_F)
+ *      (fusion.py:1658), then torch.optim.Adam's update of (t_i, w_i); adam_m / adam_v [n_inst,6] and
+ *      step [n_inst] (float counters) are the optimiser state, zero at the start of a frame.
+ * All arrays are device memory; last [n_inst,n,3], t / w [n_inst,3], valid = the uint8 mask of d3f_eval. */
+int d3f_rigid_transform(const float *last, int32_t n_inst, int32_t n, const float *t, const float *w,
+                        float *out_pts, float *norms, void *stream);
+int d3f_track_loss_grad(const float *feats, const float *src, const float *dist, const uint8_t *valid,
+                        int64_t N, int32_t C, float dist_w, float *grad_feats, float *grad_dist,
+                        float *loss, void *stream);
+int d3f_rigid_update(const float *last, int32_t n_inst, int32_t n, const float *grad_pts, float *t, float *w,
+                     float *adam_m, float *adam_v, float *step, const float *norms, float reg_w, float lr,
+                     float beta1, float beta2, float eps, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -406,14 +406,15 @@ def test_point_order_probe_and_unordered_walk(dev):
         assert rel_err(cpu(got[k]), ref["sets"][s_]) <= TOL
 
 
-@pytest.mark.parametrize("use_graph", [False, True])
+@pytest.mark.parametrize("use_graph", [False, True, "autograd"])
 def test_rigid_tracking_matches_reference(dev, use_graph):
     """Fusion.rigid_tracking (100 Adam steps through d3f_eval / d3f_eval_backward; eager launches or one HIP graph
     replayed) against the keypoints the REFERENCE's loop returned (golden 'rigid_tracking'): measured agreement
     3e-8 m (eager) / 4.5e-8 m (graph) on positions that move 1-15 mm; tolerance 1e-5 m."""
     g = load_golden("rigid_tracking")
     f = make_fusion(dev, g["depth"], g["K"], g["pose"], {"dino_feats": g["in_dino_feats"]}, g["H"], g["W"], float(g["mu"]))
-    f.use_hip_graph = use_graph
+    f.use_hip_graph = bool(use_graph)
+    f.fused_tracking = use_graph is True        # True: five-launch HIP step; "autograd": the autograd step, graph-replayed
     n = int(g["n"])
     info = {"a": {"src_feats": torch.from_numpy(g["src_feats"][:n])}, "b": {"src_feats": torch.from_numpy(g["src_feats"][n:])}}
     res = f.rigid_tracking(info, [p for p in g["last_pts"]], None, n)
