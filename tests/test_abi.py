@@ -104,6 +104,14 @@ def test_validation_returns_status_codes_not_aborts():
     assert lib.d3f_point_order_locality(None, 5, one, None) == _lib.ERR_INVALID_ARG
     assert lib.d3f_point_order_locality(one, 5, None, None) == _lib.ERR_INVALID_ARG
     assert lib.d3f_point_order_locality(one, -5, one, None) == _lib.ERR_INVALID_ARG
+    # tracking step
+    assert lib.d3f_rigid_transform(one, 2, 5, one, one, one, None, None) == _lib.ERR_INVALID_ARG
+    assert lib.d3f_rigid_transform(one, -1, 5, one, one, one, one, None) == _lib.ERR_BAD_SHAPE
+    assert lib.d3f_track_loss_grad(one, one, one, one, 4, 0, 100.0, one, one, one, None) == _lib.ERR_BAD_SHAPE
+    assert lib.d3f_track_loss_grad(one, None, one, one, 4, 8, 100.0, one, one, one, None) == _lib.ERR_INVALID_ARG
+    assert lib.d3f_rigid_update(one, 2, 5, one, one, one, one, one, one, one, 1.0, 0.0, 0.9, 0.999, 1e-8, None) == _lib.ERR_INVALID_ARG
+    assert lib.d3f_rigid_update(one, 2, 5, one, one, None, one, one, one, one, 1.0, 0.01, 0.9, 0.999, 1e-8, None) == _lib.ERR_INVALID_ARG
+    assert lib.d3f_rigid_update(one, 0, 5, None, None, None, None, None, None, None, 1.0, 0.01, 0.9, 0.999, 1e-8, None) == 0
 
 
 def test_workspace_size():

@@ -442,6 +442,63 @@ def test_rigid_tracking_matches_reference(dev, use_graph):
         assert np.array_equal(again, got) and f._tracker is tracker
 
 
+def test_tracking_step_kernels_vs_autograd(dev):
+    """The three closed-form kernels of the tracking step against torch autograd on the same expressions: transform,
+    loss gradients, and one Adam step of (t, w) from an upstream gradient -- incl. an instance with |w|^2 below the
+    clamp (no gradient through the angle) and one far above it."""
+    from d3fields_amd import rigid, _lib
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(3)
+    I, n, C = 4, 37, 48
+    last = (torch.randn(I, n, 3, generator=g) * 0.2).to(dev)
+    t0 = (torch.randn(I, 3, generator=g) * 0.05).to(dev)
+    w0 = torch.tensor([[0.0, 0.0, 0.0], [0.004, -0.003, 0.002], [0.3, -0.2, 0.5], [1.5, 0.4, -0.9]], device=dev)
+    stream = _lib.current_stream_handle(dev)
+
+    # 1. transform
+    pts = torch.empty(I * n, 3, device=dev)
+    norms = torch.empty(2, device=dev)
+    _lib.check(lib.d3f_rigid_transform(_lib.ptr(last), I, n, _lib.ptr(t0), _lib.ptr(w0), _lib.ptr(pts), _lib.ptr(norms), stream))
+    ref_pts = rigid.rigid_transform(last, rigid.so3_exp_map(w0), t0).reshape(-1, 3)
+    assert (pts - ref_pts).abs().max().item() <= 1e-6
+    assert abs(norms[0].item() - t0.norm().item()) <= 1e-6 and abs(norms[1].item() - w0.norm().item()) <= 1e-6
+
+    # 2. loss gradients
+    N = I * n
+    feats = torch.randn(N, C, generator=g).to(dev).requires_grad_(True)
+    src = torch.randn(N, C, generator=g).to(dev)
+    src[3] = feats[3].detach()                                   # zero difference: norm backward gives 0
+    dist = (torch.randn(N, generator=g) * 0.01).to(dev).requires_grad_(True)
+    valid = (torch.rand(N, generator=g) > 0.3).to(dev)
+    feat_loss = (torch.norm(feats - src, dim=-1) * valid).mean()
+    dist_loss = rigid.DIST_W * torch.clamp(dist * valid, min=0).mean()
+    (feat_loss + dist_loss).backward()
+    gf, gd, loss = torch.empty(N, C, device=dev), torch.empty(N, device=dev), torch.empty(2, device=dev)
+    _lib.check(lib.d3f_track_loss_grad(_lib.ptr(feats.detach()), _lib.ptr(src), _lib.ptr(dist.detach()), _lib.ptr(valid), N, C,
+                                       rigid.DIST_W, _lib.ptr(gf), _lib.ptr(gd), _lib.ptr(loss), stream))
+    assert (gf - feats.grad).abs().max().item() <= 1e-7 and (gd - dist.grad).abs().max().item() <= 1e-7
+    assert abs(loss[0].item() - feat_loss.item()) <= 1e-5 and abs(loss[1].item() - dist_loss.item()) <= 1e-6
+
+    # 3. chain rule + regulariser + Adam, two consecutive steps
+    t_ref, w_ref = t0.clone().requires_grad_(True), w0.clone().requires_grad_(True)
+    opt = torch.optim.Adam([t_ref, w_ref], lr=rigid.LR, betas=(0.9, 0.999))
+    t_k, w_k = t0.clone(), w0.clone()
+    state = torch.zeros(I * 13, device=dev)
+    for it in range(2):
+        up = torch.randn(N, 3, generator=g).to(dev)
+        opt.zero_grad()
+        p = rigid.rigid_transform(last, rigid.so3_exp_map(w_ref), t_ref).reshape(-1, 3)
+        ((p * up).sum() + rigid.REG_W * (torch.norm(t_ref) + torch.norm(w_ref))).backward()
+        opt.step()
+        _lib.check(lib.d3f_rigid_transform(_lib.ptr(last), I, n, _lib.ptr(t_k), _lib.ptr(w_k), _lib.ptr(pts), _lib.ptr(norms), stream))
+        _lib.check(lib.d3f_rigid_update(_lib.ptr(last), I, n, _lib.ptr(up), _lib.ptr(t_k), _lib.ptr(w_k), _lib.ptr(state[:I * 6]),
+                                        _lib.ptr(state[I * 6:I * 12]), _lib.ptr(state[I * 12:]), _lib.ptr(norms), rigid.REG_W, rigid.LR,
+                                        0.9, 0.999, 1e-8, stream))
+        assert (t_k - t_ref.detach()).abs().max().item() <= 2e-6, it
+        assert (w_k - w_ref.detach()).abs().max().item() <= 2e-6, it
+    assert state[I * 12:].tolist() == [2.0] * I
+
+
 def test_so3_exp_map_and_rigid_transform(dev):
     from scipy.spatial.transform import Rotation
     from d3fields_amd import rigid
@@ -798,7 +855,7 @@ def test_rigid_tracking_style_loop(dev):
         loss = torch.norm(out["dino_feats"] - tgt, dim=1).mean() + 100 * torch.relu(out["dist"]).mean()
         loss.backward()
         opt.step()
-        losses.append(float(loss))
+        losses.append(float(loss.detach()))
     assert losses[-1] < losses[0]
     with pytest.raises(NotImplementedError):
         f.eval(src.clone().requires_grad_(True), return_names=["dino_feats"], return_inter=True)
