@@ -502,7 +502,8 @@ __device__ __forceinline__ void fused_eval_body(const EvalParams &P)
     // one lane per (point, view) pair: the V depth lookups of a point are in flight together
     for (int idx = threadIdx.x; idx < tile_n * V; idx += kBlock) {
         const int v = idx / tile_n, p = idx - v * tile_n;
-        const int64_t i = P.order ? (int64_t)P.order[tile_base + p] : tile_base + p;
+        // (indices are clamped: a stale buffer passed with D3F_FLAG_REUSE_POINT_ORDER must not fault the device)
+        const int64_t i = P.order ? min((int64_t)P.order[tile_base + p], P.n - 1) : tile_base + p;
         float px, py, pz;
         fetch_point(P, i, px, py, pz);
         float wgt;
@@ -527,7 +528,8 @@ __device__ __forceinline__ void fused_eval_body(const EvalParams &P)
     __syncthreads();
     // per point: sums over the views in view order (fusion.py:364-370), outputs leave coalesced
     for (int p = threadIdx.x; p < tile_n; p += kBlock) {
-        const int64_t i = P.order ? (int64_t)P.order[tile_base + p] : tile_base + p;
+        // (indices are clamped: a stale buffer passed with D3F_FLAG_REUSE_POINT_ORDER must not fault the device)
+        const int64_t i = P.order ? min((int64_t)P.order[tile_base + p], P.n - 1) : tile_base + p;
         float dsum = 0.0f, cnt = 0.0f;
         uint32_t nonfinite = 0u;
         for (int v = 0; v < V; ++v) {

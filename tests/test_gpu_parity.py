@@ -673,6 +673,15 @@ def test_cached_point_order_is_reused_and_harmless(dev):
         f.cache_point_order = True
         e = f.batch_eval(pts[:70000], return_names=["dino_feats"])   # other n (a view with the same data_ptr)
         assert torch.equal(e["dino_feats"], d["dino_feats"][:70000])
+        # a caller passing D3F_FLAG_REUSE_POINT_ORDER with a scratch that holds garbage gets garbage rows, not a device fault
+        f.cache_point_order = False
+        f.tuning_flags = _lib.TUNE_FORCE_REORDER | _lib.FLAG_REUSE_POINT_ORDER
+        torch.randint(0, 255, (64 << 20,), dtype=torch.uint8, device=dev)   # dirty the allocator's blocks
+        f.batch_eval(pts, return_names=["dino_feats"])
+        torch.cuda.synchronize()
+        f.tuning_flags = _lib.TUNE_FORCE_REORDER
+        again = f.batch_eval(pts, return_names=["dino_feats"])
+        assert torch.equal(again["dino_feats"], d["dino_feats"])
 
 
 def test_c_abi_from_cpp_host(dev, tmp_path):
