@@ -684,6 +684,34 @@ def test_cached_point_order_is_reused_and_harmless(dev):
         assert torch.equal(again["dino_feats"], d["dino_feats"])
 
 
+def test_limits_max_views_and_max_maps(dev):
+    """D3F_MAX_VIEWS = 64 views and D3F_MAX_MAPS = 8 channel maps in one call, against the oracle; one more of either is
+    rejected with the documented error."""
+    from d3fields_amd import synth
+    V, H, W, N = 64, 24, 32, 3000
+    sc = synth.make_scene(V, H, W, "stress")
+    maps = {"m%d" % j: synth.random_map(V, 3 + j, 4 + j, [1, 2, 3, 4, 8, 12, 16, 40][j], seed=j) for j in range(8)}
+    f = make_fusion(dev, sc["depth"], sc["K"], sc["pose"], maps, H, W)
+    pts = synth.random_cloud(N, seed=2) * 1.5
+    names = list(maps)
+    with torch.no_grad():
+        got = f.eval(pts.to(dev), return_names=names)
+    ref = oracle_eval(sc, pts.numpy(), [maps[k].numpy() for k in names])
+    assert np.array_equal(cpu(got["valid_mask"]), ref["valid_mask"].astype(bool))
+    check_dist(cpu(got["dist"]), ref["dist"], V)
+    for j, k in enumerate(names):
+        assert rel_err(cpu(got[k]), ref["sets"][j]) <= TOL, k
+    with pytest.raises(ValueError):
+        f.curr_obs_torch["m8"] = maps["m0"]
+        f.eval(pts.to(dev), return_names=names + ["m8"])
+    sc65 = synth.make_scene(65, H, W, "stress")
+    f65 = make_fusion(dev, sc65["depth"], sc65["K"], sc65["pose"], {}, H, W)
+    from d3fields_amd import _lib
+    with pytest.raises(_lib.D3FError) as e:
+        f65.eval(pts.to(dev), return_names=[])
+    assert e.value.code == _lib.ERR_BAD_SHAPE
+
+
 def test_c_abi_from_cpp_host(dev, tmp_path):
     """examples/c_abi_demo.cpp: a host program with no Python and no torch drives d3f_eval through include/d3fields_hip.h
     (hipMalloc'd buffers, its own stream, the optional scratch); its inputs and outputs are re-checked with the oracle."""
