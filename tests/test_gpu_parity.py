@@ -684,6 +684,31 @@ def test_cached_point_order_is_reused_and_harmless(dev):
         assert torch.equal(again["dino_feats"], d["dino_feats"])
 
 
+def test_large_batch_indexing(dev):
+    """16.8 M + 1 points in one launch (ragged last tile, Morton walk over > 2^24 indices): a strided sample of the rows
+    equals the query of just those points, and the oracle."""
+    from d3fields_amd import synth
+    V, H, W = 4, 60, 80
+    sc = synth.make_scene(V, H, W, "smooth")
+    maps = {"dino_feats": synth.random_map(V, 6, 8, 4, seed=1)}
+    f = make_fusion(dev, sc["depth"], sc["K"], sc["pose"], maps, H, W)
+    n = (1 << 24) + 1
+    g = torch.Generator(device=dev).manual_seed(5)
+    pts = (torch.rand(n, 3, generator=g, device=dev) - 0.5) * torch.tensor([0.9, 0.8, 0.3], device=dev)
+    from d3fields_amd import _lib
+    for flags in (0, _lib.TUNE_FORCE_REORDER):
+        f.tuning_flags = flags
+        with torch.no_grad():
+            out = f.batch_eval(pts, return_names=["dino_feats"])
+            idx = torch.cat([torch.arange(0, n, 4099, device=dev), torch.tensor([n - 1], device=dev)])
+            sub = f.eval(pts[idx].contiguous(), return_names=["dino_feats"])
+        for k in sub:
+            assert torch.equal(out[k][idx], sub[k]), (k, flags)
+    ref = oracle_eval(sc, cpu(pts[idx]), [maps["dino_feats"].numpy()])
+    assert np.array_equal(cpu(sub["valid_mask"]), ref["valid_mask"].astype(bool)) and np.array_equal(cpu(sub["dist"]), ref["dist"])
+    assert rel_err(cpu(sub["dino_feats"]), ref["sets"][0]) <= TOL
+
+
 def test_limits_max_views_and_max_maps(dev):
     """D3F_MAX_VIEWS = 64 views and D3F_MAX_MAPS = 8 channel maps in one call, against the oracle; one more of either is
     rejected with the documented error."""
