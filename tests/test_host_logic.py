@@ -139,3 +139,14 @@ def test_rigid_helpers_match_restated_pytorch3d():
     t.requires_grad_(True)
     rigid.rigid_transform(x, rigid.so3_exp_map(w), t).sum().backward()
     assert torch.isfinite(w.grad).all() and torch.isfinite(t.grad).all() and float(t.grad.abs().sum()) > 0
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    """No libd3fields_hip.so and no hipcc: constructing the product raises -- there is nothing to fall back to."""
+    from d3fields_amd import _lib, build
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(build, "LIB_PATH", str(tmp_path / "libd3fields_hip.so"))
+    monkeypatch.setattr(build, "_hipcc", lambda: str(tmp_path / "no_such_hipcc"))
+    with pytest.raises((OSError, RuntimeError)):
+        Fusion(num_cam=2)
+    monkeypatch.setattr(_lib, "_lib", None)      # the real library loads again afterwards (monkeypatch restores the paths)
