@@ -260,7 +260,7 @@ def main():
 
     # N>1: the all-gather of batch k runs on RCCL's stream while batch k+1 is queried (one gather in flight);
     # `drain` waits for the last one inside the timed region.  --no-overlap blocks on every gather instead.
-    pending, hold = [], []
+    pending, hold, overlap_error = [], [], []
 
     def drain():
         for wk in pending:
@@ -276,8 +276,14 @@ def main():
                 sharding.all_gather_field({k: out[k] for k in keys}, keys=keys, counts=[n] * world)
             else:
                 drain()                                    # gather k-1 must be done before gather k is enqueued
-                full, works = sharding.all_gather_field({k: out[k] for k in keys}, keys=keys, counts=[n] * world,
-                                                        async_op=True)
+                try:
+                    full, works = sharding.all_gather_field({k: out[k] for k in keys}, keys=keys, counts=[n] * world,
+                                                            async_op=True)
+                except Exception as exc:                   # a backend without async all-gather: block instead (reported)
+                    args.no_overlap = True
+                    overlap_error.append(repr(exc))
+                    sharding.all_gather_field({k: out[k] for k in keys}, keys=keys, counts=[n] * world)
+                    return out
                 pending.extend(works)
                 hold.extend((out, full))                   # inputs and outputs stay alive until the wait
         return out
@@ -326,7 +332,8 @@ def main():
                    "points_per_gpu": n, "views": w["V"], "feature_dim": w["C"], "feature_map": list(w["fhw"]),
                    "parallelism": "points sharded x%d, maps replicated" % world,
                    "gather": (args.gather if dist_on else "n/a"),
-                   "gather_overlap": (not args.no_overlap) if dist_on else "n/a"},
+                   "gather_overlap": ((not args.no_overlap) if dist_on else "n/a"),
+                   "gather_overlap_error": (overlap_error[0] if overlap_error else None)},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                      "kernel": ("fused_eval_f16_kernel<0>" if w.get("f16") else
