@@ -9,7 +9,7 @@ import os
 
 from . import build as _build
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 # status codes (include/d3fields_hip.h)
 OK = 0
@@ -75,6 +75,11 @@ SIGNATURES = {
     "d3f_backproject_view": (ctypes.c_int, [_vp, _vp, _i32, _i32, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double),
                                             ctypes.POINTER(ctypes.c_double), _i64, _vp, _vp, _vp, _vp, _vp]),
     "d3f_pcd_nearest": (ctypes.c_int, [_vp, _i64, _vp, _i64, _vp, _vp, _vp]),
+    "d3f_pcd_to_index": (ctypes.c_int, [_vp, _i64, ctypes.POINTER(ctypes.c_double), ctypes.c_double, ctypes.POINTER(_i32), _vp, _vp, _vp]),
+    "d3f_vox_iou_workspace_bytes": (_i64, [_i64, _i64]),
+    "d3f_vox_idx_iou": (ctypes.c_int, [_vp, _i64, _vp, _i64, _vp, _vp, _i64, _vp]),
+    "d3f_erode": (ctypes.c_int, [_vp, _i32, _i32, _i32, _i32, _vp, _vp]),
+    "d3f_fps_pixels": (ctypes.c_int, [_vp, _i64, _i32, _i64, _vp, _vp, _vp, _vp]),
     "d3f_eval_backward": (ctypes.c_int, [ctypes.POINTER(Views), _vp, _i64, ctypes.POINTER(ChannelMap), _i32, _f32,
                                          _vp, ctypes.POINTER(_vp), _vp, _vp]),
     "d3f_eval_dist_backward": (ctypes.c_int, [ctypes.POINTER(Views), _vp, _i64, _vp, _vp, _vp]),
@@ -115,8 +120,14 @@ def load():
     if _lib is not None:
         return _lib
     path = library_path()
-    if not os.path.exists(path):
-        _build.build_library()      # raises if hipcc is unavailable: no silent fallback
+    if _build.is_stale():
+        # missing, or built from other sources than the ones in the tree (content fingerprint, not mtimes):
+        # rebuild -- raises if hipcc is unavailable, so a stale library is never loaded silently
+        try:
+            _build.build_library()
+        except (RuntimeError, OSError) as exc:
+            raise ImportError("libd3fields_hip.so is %s and hipcc is not available to build it: %s"
+                              % ("missing" if not os.path.exists(path) else "out of date with csrc/", exc))
     lib = ctypes.CDLL(path)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)     # AttributeError if the .so lacks a declared symbol

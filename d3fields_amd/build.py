@@ -14,7 +14,7 @@ PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG_DIR, "csrc")
 INCLUDE = os.path.join(os.path.dirname(PKG_DIR), "include")
 LIB_PATH = os.path.join(PKG_DIR, "libd3fields_hip.so")
-SOURCES = ["fuse_eval.hip", "fuse_backward.hip", "order_kernels.hip", "grid_kernels.hip", "pcd_kernels.hip", "misc_kernels.hip", "corr_kernels.hip", "track_kernels.hip", "d3f_api.hip"]
+SOURCES = ["fuse_eval.hip", "fuse_backward.hip", "order_kernels.hip", "grid_kernels.hip", "pcd_kernels.hip", "assoc_kernels.hip", "misc_kernels.hip", "corr_kernels.hip", "track_kernels.hip", "d3f_api.hip"]
 
 # -ffp-contract=off: the arithmetic contract says which products are fused; only
 # explicit fmaf() may fuse.  No -ffast-math: IEEE division and accurate expf are part of parity.
@@ -29,22 +29,76 @@ def _hipcc():
     raise RuntimeError("hipcc not found (set HIPCC or install ROCm)")
 
 
+FINGERPRINT_PATH = LIB_PATH + ".fingerprint"
+
+
+def source_fingerprint():
+    """sha256 over the kernel sources, the public header and the compiler flags: what the .so was built from.
+    Content-based (not mtimes), so a working tree copied to another machine keeps a fresh library fresh."""
+    import hashlib
+    h = hashlib.sha256(" ".join(HIPCC_FLAGS + SOURCES).encode())
+    for path in sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC)) + [os.path.join(INCLUDE, "d3fields_hip.h")]:
+        h.update(os.path.basename(path).encode())
+        with open(path, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()
+
+
 def is_stale():
-    if not os.path.exists(LIB_PATH):
+    """True when the library is missing or was built from other sources than the ones in the tree."""
+    if not os.path.exists(LIB_PATH) or not os.path.exists(FINGERPRINT_PATH):
         return True
-    t = os.path.getmtime(LIB_PATH)
-    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(INCLUDE, "d3fields_hip.h")]
-    return any(os.path.getmtime(d) > t for d in deps)
+    with open(FINGERPRINT_PATH) as fh:
+        return fh.read().strip() != source_fingerprint()
+
+
+def _object_stale(obj, src, headers):
+    if not os.path.exists(obj):
+        return True
+    t = os.path.getmtime(obj)
+    return any(os.path.getmtime(d) > t for d in [src] + headers)
 
 
 def build_library(force=False, extra_flags=(), verbose=False):
+    """One object per source (compiled in parallel, rebuilt only when the source or a header is newer), then one link."""
     if not force and not is_stale():
         return LIB_PATH
-    cmd = [_hipcc()] + HIPCC_FLAGS + list(extra_flags) + ["-I", INCLUDE]
-    cmd += [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIB_PATH]
+    hipcc = _hipcc()
+    import fcntl
+    lock = open(LIB_PATH + ".lock", "w")
+    fcntl.flock(lock, fcntl.LOCK_EX)            # several ranks / test processes may arrive here together
+    try:
+        if not force and not is_stale():
+            return LIB_PATH
+        return _build_locked(hipcc, force, extra_flags, verbose)
+    finally:
+        fcntl.flock(lock, fcntl.LOCK_UN)
+        lock.close()
+
+
+def _build_locked(hipcc, force, extra_flags, verbose):
+    objdir = os.path.join(PKG_DIR, "build")
+    os.makedirs(objdir, exist_ok=True)
+    headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")] + [os.path.join(INCLUDE, "d3fields_hip.h")]
+    cflags = [f for f in HIPCC_FLAGS if f != "-shared"] + list(extra_flags) + ["-I", INCLUDE, "-c"]
+    jobs, objs = [], []
+    for s in SOURCES:
+        src, obj = os.path.join(CSRC, s), os.path.join(objdir, s.replace(".hip", ".o"))
+        objs.append(obj)
+        if force or extra_flags or _object_stale(obj, src, headers):
+            cmd = [hipcc] + cflags + [src, "-o", obj]
+            if verbose:
+                print(" ".join(cmd))
+            jobs.append((s, subprocess.Popen(cmd, cwd=CSRC)))
+    failed = [s for s, p in jobs if p.wait() != 0]
+    if failed:
+        raise subprocess.CalledProcessError(1, "hipcc -c " + " ".join(failed))
+    link = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", LIB_PATH]
     if verbose:
-        print(" ".join(cmd))
-    subprocess.check_call(cmd, cwd=CSRC)
+        print(" ".join(link))
+    subprocess.check_call(link, cwd=CSRC)
+    with open(FINGERPRINT_PATH, "w") as fh:
+        fh.write(source_fingerprint() + "\n")
     return LIB_PATH
 
 

@@ -1,0 +1,207 @@
+// assoc_kernels.hip -- the integer steps of the reference's multi-view instance association
+// and of select_features_rand_v2 (fusion.py:1539-1606).  All results are integers and must be BIT-EXACT.
+//
+//   pcd_to_index_kernel   pcd_to_voxel + voxel_to_index of _init_low_level_memory (fusion.py:118-180): one lane per
+//                         point, fp64 floor-divide like numpy, int32 linearisation with numpy's wrap-around.
+//   voxset_*              Fusion.vox_idx_iou (fusion.py:794-799): |set(a) & set(b)| and |set(a) | set(b)| of two int32
+//                         index arrays (duplicates allowed -- the reference passes un-deduplicated pcd_to_index output)
+//                         through ONE open-addressing hash set in caller scratch: every key is inserted once with a
+//                         membership bit per array (64-bit CAS on an empty slot, atomicOr on a found key), then the
+//                         occupied slots are counted.  Exact for any key values, O(n), no sort.
+//   erode_kernel          cv2.erode of a binary uint8 image with a kh x kw all-ones kernel, anchor at the kernel
+//                         centre (kw/2, kh/2), one iteration, cv2's default border (out-of-image pixels never
+//                         constrain the minimum) -- fusion.py:1293 (2x2) and :1561 (15x15).
+//   fps_pixels_kernel     fps_np (utils/my_utils.py:478-497) on INTEGER 2-D pixel coordinates (fusion.py:1566): numpy
+//                         computes float64 norms of exact integer differences, so comparing the exact int64 squared
+//                         distances gives the same argmax sequence (sqrt is monotone and correctly rounded; equal
+//                         norms <=> equal squares below 2^53), first maximum wins.
+#include "d3f_internal.h"
+
+namespace d3f {
+
+// numpy's float64 -> int32 cast on x86-64 (cvttsd2si): out-of-range and NaN become INT32_MIN
+__device__ __forceinline__ int32_t numpy_f64_to_i32(double x)
+{
+    if (!(x > -2147483649.0 && x < 2147483648.0)) return INT32_MIN;
+    return (int32_t)x;      // truncation toward zero
+}
+
+__global__ __launch_bounds__(kBlock) void pcd_to_index_kernel(const double *__restrict__ pts, int64_t n, double lx, double ly,
+                                                             double lz, double vs, uint32_t n1, uint32_t n2,
+                                                             int32_t *__restrict__ out_index, int32_t *__restrict__ out_voxel)
+{
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    // voxels = np.floor((pcds - lower_bound) / voxel_size).astype(np.int32)            (fusion.py:124)
+    const int32_t v0 = numpy_f64_to_i32(floor((pts[i * 3 + 0] - lx) / vs));
+    const int32_t v1 = numpy_f64_to_i32(floor((pts[i * 3 + 1] - ly) / vs));
+    const int32_t v2 = numpy_f64_to_i32(floor((pts[i * 3 + 2] - lz) / vs));
+    // indexes = v0 * voxel_num[1] * voxel_num[2] + v1 * voxel_num[2] + v2   in int32, wrapping like numpy (fusion.py:140-144)
+    const uint32_t idx = ((uint32_t)v0 * n1) * n2 + (uint32_t)v1 * n2 + (uint32_t)v2;
+    out_index[i] = (int32_t)idx;
+    if (out_voxel) { out_voxel[i * 3 + 0] = v0; out_voxel[i * 3 + 1] = v1; out_voxel[i * 3 + 2] = v2; }
+}
+
+hipError_t launch_pcd_to_index(const double *pts, int64_t n, const double *lower, double voxel_size, const int32_t *voxel_num,
+                               int32_t *out_index, int32_t *out_voxel, hipStream_t s)
+{
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(pcd_to_index_kernel, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, pts, n, lower[0],
+                       lower[1], lower[2], voxel_size, (uint32_t)voxel_num[1], (uint32_t)voxel_num[2], out_index, out_voxel);
+    return hipGetLastError();
+}
+
+// ---- hash set of int32 keys with two membership bits ----------------------------------------------------------------
+constexpr unsigned long long kEmptySlot = ~0ULL;       // a live slot is (uint32 key) << 2 | bits, i.e. < 2^34
+
+int64_t voxset_capacity(int64_t n1, int64_t n2)
+{
+    int64_t cap = 1024;
+    while (cap < 2 * (n1 + n2)) cap <<= 1;              // load factor <= 0.5
+    return cap;
+}
+
+__global__ __launch_bounds__(kBlock) void voxset_clear_kernel(unsigned long long *__restrict__ table, int64_t cap,
+                                                             unsigned long long *__restrict__ counts)
+{
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i < cap) table[i] = kEmptySlot;
+    if (i < 2) counts[i] = 0ULL;
+}
+
+__device__ __forceinline__ uint32_t hash_u32(uint32_t x)
+{
+    x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;     // lowbias32 finaliser
+    return x;
+}
+
+__global__ __launch_bounds__(kBlock) void voxset_insert_kernel(const int32_t *__restrict__ a, int64_t na,
+                                                              const int32_t *__restrict__ b, int64_t nb,
+                                                              unsigned long long *__restrict__ table, int64_t cap)
+{
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= na + nb) return;
+    const uint32_t key = (uint32_t)(i < na ? a[i] : b[i - na]);
+    const unsigned long long bit = i < na ? 1ULL : 2ULL;
+    const unsigned long long mine = ((unsigned long long)key << 2) | bit;
+    const uint64_t mask = (uint64_t)cap - 1;
+    uint64_t h = hash_u32(key) & mask;
+    for (int64_t probe = 0; probe < cap; ++probe) {
+        unsigned long long cur = table[h];
+        if (cur == kEmptySlot) {
+            cur = atomicCAS(&table[h], kEmptySlot, mine);
+            if (cur == kEmptySlot) return;              // this lane created the entry
+        }
+        if ((uint32_t)(cur >> 2) == key) {              // (cur is a live slot here: < 2^34)
+            atomicOr(&table[h], bit);
+            return;
+        }
+        h = (h + 1) & mask;
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void voxset_count_kernel(const unsigned long long *__restrict__ table, int64_t cap,
+                                                             unsigned long long *__restrict__ counts)
+{
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    const unsigned long long cur = i < cap ? table[i] : kEmptySlot;
+    const bool live = cur != kEmptySlot;
+    const unsigned long long both = __ballot(live && (cur & 3ULL) == 3ULL), any = __ballot(live);
+    if ((threadIdx.x & 63) == 0) {
+        if (both) atomicAdd(&counts[0], (unsigned long long)__popcll(both));      // |A & B|
+        if (any) atomicAdd(&counts[1], (unsigned long long)__popcll(any));        // |A | B|
+    }
+}
+
+hipError_t launch_voxset_iou(const int32_t *a, int64_t na, const int32_t *b, int64_t nb, int64_t *counts, void *workspace,
+                             hipStream_t s)
+{
+    const int64_t cap = voxset_capacity(na, nb);
+    unsigned long long *table = static_cast<unsigned long long *>(workspace);
+    unsigned long long *cnt = reinterpret_cast<unsigned long long *>(counts);
+    const unsigned gcap = (unsigned)((cap + kBlock - 1) / kBlock);
+    hipLaunchKernelGGL(voxset_clear_kernel, dim3(gcap), dim3(kBlock), 0, s, table, cap, cnt);
+    if (na + nb > 0)
+        hipLaunchKernelGGL(voxset_insert_kernel, dim3((unsigned)((na + nb + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, a, na, b,
+                           nb, table, cap);
+    hipLaunchKernelGGL(voxset_count_kernel, dim3(gcap), dim3(kBlock), 0, s, table, cap, cnt);
+    return hipGetLastError();
+}
+
+// ---- cv2.erode, all-ones kh x kw structuring element ----------------------------------------------------------------
+// dst(y,x) = min over i < kh, j < kw of src(y + i - kh/2, x + j - kw/2), out-of-image samples skipped (cv2's default
+// border value for erosion is +max).  Binary images: dst = 255 iff no in-image sample of the window is 0... for general
+// uint8 input the minimum is returned, as cv2 does.  Separable: rows then columns through LDS-free two passes would
+// need scratch; the windows here are <= 15x15 on <= 1 MPixel images, so one pass with early exit is enough.
+__global__ __launch_bounds__(kBlock) void erode_kernel(const uint8_t *__restrict__ src, int H, int W, int kh, int kw,
+                                                      uint8_t *__restrict__ dst)
+{
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= (int64_t)H * W) return;
+    const int y = (int)(i / W), x = (int)(i % W);
+    const int y0 = max(y - kh / 2, 0), y1 = min(y - kh / 2 + kh - 1, H - 1);
+    const int x0 = max(x - kw / 2, 0), x1 = min(x - kw / 2 + kw - 1, W - 1);
+    unsigned m = 255u;
+    for (int yy = y0; yy <= y1 && m != 0u; ++yy)
+        for (int xx = x0; xx <= x1; ++xx) m = min(m, (unsigned)src[(int64_t)yy * W + xx]);
+    dst[i] = (uint8_t)m;
+}
+
+hipError_t launch_erode(const uint8_t *src, int H, int W, int kh, int kw, uint8_t *dst, hipStream_t s)
+{
+    const int64_t n = (int64_t)H * W;
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(erode_kernel, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, src, H, W, kh, kw, dst);
+    return hipGetLastError();
+}
+
+// ---- fps_np on integer 2-D points ------------------------------------------------------------------------------------
+constexpr int kFpsPixBlock = 1024;
+
+__global__ __launch_bounds__(kFpsPixBlock) void fps_pixels_kernel(const int32_t *__restrict__ pts, int64_t n, int k,
+                                                                 int64_t init_idx, int64_t *__restrict__ out_idx,
+                                                                 double *__restrict__ out_maxdist, int64_t *__restrict__ dist)
+{
+    __shared__ long long red_v[kFpsPixBlock / 64];
+    __shared__ long long red_i[kFpsPixBlock / 64];
+    __shared__ long long cur_s, best_s;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    long long cur = init_idx;
+    for (int round = 0; round < k; ++round) {
+        if (tid == 0) out_idx[round] = cur;
+        const long long cy = pts[cur * 2 + 0], cx = pts[cur * 2 + 1];
+        long long bv = -1, bi = 0x7fffffffffffffffLL;
+        for (int64_t i = tid; i < n; i += kFpsPixBlock) {
+            const long long dy = pts[i * 2 + 0] - cy, dx = pts[i * 2 + 1] - cx;
+            long long d = dy * dy + dx * dx;                     // exact; np.linalg.norm = sqrt of this in float64
+            if (round > 0) d = min((long long)dist[i], d);       // np.minimum on the norms == min on the squares
+            dist[i] = d;
+            if (d > bv) { bv = d; bi = i; }                      // strided scan: '>' keeps the first maximum
+        }
+        for (int off = 32; off > 0; off >>= 1) {
+            const long long ov = __shfl_xor(bv, off, 64), oi = __shfl_xor(bi, off, 64);
+            if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+        }
+        if (lane == 0) { red_v[wave] = bv; red_i[wave] = bi; }
+        __syncthreads();
+        if (tid == 0) {
+            long long v = red_v[0], ix = red_i[0];
+            for (int w = 1; w < kFpsPixBlock / 64; ++w)
+                if (red_v[w] > v || (red_v[w] == v && red_i[w] < ix)) { v = red_v[w]; ix = red_i[w]; }
+            cur_s = ix;
+            best_s = v;
+        }
+        __syncthreads();
+        cur = cur_s;
+    }
+    if (tid == 0 && out_maxdist) *out_maxdist = sqrt((double)best_s);   // fps_np's third return value: dist.max()
+}
+
+hipError_t launch_fps_pixels(const int32_t *pts, int64_t n, int k, int64_t init_idx, int64_t *out_idx, double *out_maxdist,
+                             int64_t *dist_ws, hipStream_t s)
+{
+    hipLaunchKernelGGL(fps_pixels_kernel, dim3(1), dim3(kFpsPixBlock), 0, s, pts, n, k, init_idx, out_idx, out_maxdist, dist_ws);
+    return hipGetLastError();
+}
+
+}  // namespace d3f

@@ -346,6 +346,58 @@ int d3f_pcd_nearest(const double *a, int64_t na, const double *b, int64_t nb, do
     return e == hipSuccess ? D3F_OK : hip_fail(e, "pcd_nearest launch");
 }
 
+int d3f_pcd_to_index(const double *pts, int64_t n, const double *lower, double voxel_size, const int32_t *voxel_num,
+                     int32_t *out_index, int32_t *out_voxel, void *stream)
+{
+    if (n < 0) return fail(D3F_ERR_INVALID_ARG, "pcd_to_index: n=%lld is negative", (long long)n);
+    if (!lower || !voxel_num) return fail(D3F_ERR_INVALID_ARG, "pcd_to_index: lower / voxel_num (host arrays) are NULL");
+    if (!(voxel_size != 0.0)) return fail(D3F_ERR_INVALID_ARG, "pcd_to_index: voxel_size must be non-zero");
+    if (n == 0) return D3F_OK;
+    if (!pts || !out_index) return fail(D3F_ERR_INVALID_ARG, "pcd_to_index: NULL pointer");
+    if ((n + d3f::kBlock - 1) / d3f::kBlock > 0x7fffffffLL) return fail(D3F_ERR_BAD_SHAPE, "pcd_to_index: n=%lld too large for one launch", (long long)n);
+    hipError_t e = d3f::launch_pcd_to_index(pts, n, lower, voxel_size, voxel_num, out_index, out_voxel, static_cast<hipStream_t>(stream));
+    return e == hipSuccess ? D3F_OK : hip_fail(e, "pcd_to_index launch");
+}
+
+int64_t d3f_vox_iou_workspace_bytes(int64_t n1, int64_t n2)
+{
+    if (n1 < 0 || n2 < 0) return 0;
+    return d3f::voxset_capacity(n1, n2) * (int64_t)sizeof(unsigned long long);
+}
+
+int d3f_vox_idx_iou(const int32_t *idx1, int64_t n1, const int32_t *idx2, int64_t n2, int64_t *out_counts, void *workspace,
+                    int64_t workspace_bytes, void *stream)
+{
+    if (n1 < 0 || n2 < 0 || n1 + n2 > 0x3fffffffLL) return fail(D3F_ERR_BAD_SHAPE, "vox_idx_iou: n1=%lld n2=%lld", (long long)n1, (long long)n2);
+    if (!out_counts || (n1 > 0 && !idx1) || (n2 > 0 && !idx2)) return fail(D3F_ERR_INVALID_ARG, "vox_idx_iou: NULL pointer");
+    if (!workspace || workspace_bytes < d3f_vox_iou_workspace_bytes(n1, n2))
+        return fail(D3F_ERR_WORKSPACE, "vox_idx_iou: needs %lld workspace bytes", (long long)d3f_vox_iou_workspace_bytes(n1, n2));
+    if (!aligned(workspace, 8) || !aligned(out_counts, 8)) return fail(D3F_ERR_BAD_LAYOUT, "vox_idx_iou: workspace / out_counts must be 8-byte aligned");
+    hipError_t e = d3f::launch_voxset_iou(idx1, n1, idx2, n2, out_counts, workspace, static_cast<hipStream_t>(stream));
+    return e == hipSuccess ? D3F_OK : hip_fail(e, "vox_idx_iou launch");
+}
+
+int d3f_erode(const uint8_t *src, int32_t H, int32_t W, int32_t kh, int32_t kw, uint8_t *dst, void *stream)
+{
+    if (H < 0 || W < 0 || kh < 1 || kw < 1 || kh > 255 || kw > 255) return fail(D3F_ERR_BAD_SHAPE, "erode: H=%d W=%d kernel %dx%d", H, W, kh, kw);
+    if ((int64_t)H * W == 0) return D3F_OK;
+    if (!src || !dst || src == dst) return fail(D3F_ERR_INVALID_ARG, "erode: src/dst must be distinct non-NULL images");
+    if (((int64_t)H * W + d3f::kBlock - 1) / d3f::kBlock > 0x7fffffffLL) return fail(D3F_ERR_BAD_SHAPE, "erode: image too large for one launch");
+    hipError_t e = d3f::launch_erode(src, H, W, kh, kw, dst, static_cast<hipStream_t>(stream));
+    return e == hipSuccess ? D3F_OK : hip_fail(e, "erode launch");
+}
+
+int d3f_fps_pixels(const int32_t *pts, int64_t n, int32_t k, int64_t init_idx, int64_t *out_idx, double *out_maxdist,
+                   int64_t *dist_workspace, void *stream)
+{
+    if (n < 1 || k < 0) return fail(D3F_ERR_BAD_SHAPE, "fps_pixels: n=%lld must be >= 1 (fps_np asserts a non-empty set), k=%d", (long long)n, k);
+    if (k == 0) return D3F_OK;
+    if (!pts || !out_idx || !dist_workspace) return fail(D3F_ERR_INVALID_ARG, "fps_pixels: NULL pointer");
+    if (init_idx < 0 || init_idx >= n) return fail(D3F_ERR_INVALID_ARG, "fps_pixels: init_idx=%lld outside [0,%lld)", (long long)init_idx, (long long)n);
+    hipError_t e = d3f::launch_fps_pixels(pts, n, k, init_idx, out_idx, out_maxdist, dist_workspace, static_cast<hipStream_t>(stream));
+    return e == hipSuccess ? D3F_OK : hip_fail(e, "fps_pixels launch");
+}
+
 static int check_grid(const d3f_grid *g)
 {
     if (!g) return fail(D3F_ERR_INVALID_ARG, "grid is NULL");

@@ -90,6 +90,16 @@ hipError_t launch_backproject(const double *depth, const uint8_t *mask, int H, i
                               int64_t *block_counts, hipStream_t s);
 hipError_t launch_nearest(const double *a, int64_t na, const double *b, int64_t nb, double *min_dist, int64_t *argmin, hipStream_t s);
 
+// assoc_kernels.hip
+hipError_t launch_pcd_to_index(const double *pts, int64_t n, const double *lower, double voxel_size, const int32_t *voxel_num,
+                               int32_t *out_index, int32_t *out_voxel, hipStream_t s);
+int64_t voxset_capacity(int64_t n1, int64_t n2);
+hipError_t launch_voxset_iou(const int32_t *a, int64_t na, const int32_t *b, int64_t nb, int64_t *counts, void *workspace,
+                             hipStream_t s);
+hipError_t launch_erode(const uint8_t *src, int H, int W, int kh, int kw, uint8_t *dst, hipStream_t s);
+hipError_t launch_fps_pixels(const int32_t *pts, int64_t n, int k, int64_t init_idx, int64_t *out_idx, double *out_maxdist,
+                             int64_t *dist_ws, hipStream_t s);
+
 // misc_kernels.hip
 hipError_t launch_onehot2instance(const float *onehot, int64_t n, int NI, uint8_t *out, hipStream_t s);
 hipError_t launch_instance2onehot(const uint8_t *inst, int64_t n, int NI, uint8_t *out, hipStream_t s);

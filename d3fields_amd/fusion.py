@@ -17,7 +17,7 @@ import torch
 
 from . import _lib
 
-__all__ = ["Fusion", "create_init_grid", "instance2onehot", "onehot2instance", "fps"]
+__all__ = ["Fusion", "create_init_grid", "instance2onehot", "onehot2instance", "fps", "_init_low_level_memory", "erode"]
 
 # ----------------------------------------------------------------------------------------
 # grid / mask-format helpers (reference fusion.py:79-116)
@@ -75,6 +75,25 @@ def create_init_grid(boundaries, step_size):
     return coords, shape
 
 
+def _init_low_level_memory(lower_bound, higher_bound, voxel_size, voxel_num):
+    """Reference _init_low_level_memory (fusion.py:118-180): the voxel <-> index <-> point closures of instance
+    association; pcd_to_voxel / pcd_to_index run on the device (d3fields_amd.pcd_utils.init_low_level_memory)."""
+    from . import pcd_utils
+    return pcd_utils.init_low_level_memory(lower_bound, higher_bound, voxel_size, voxel_num)
+
+
+def erode(image, kernel, iterations=1):
+    """cv2.erode for the all-ones kernels the reference uses on instance masks (d3fields_amd.pcd_utils.erode)."""
+    from . import pcd_utils
+    return pcd_utils.erode(image, kernel, iterations)
+
+
+def _default_device():
+    if not torch.cuda.is_available():
+        raise RuntimeError("d3fields_amd needs the ROCm device; there is no CPU path")
+    return torch.device("cuda", torch.cuda.current_device())
+
+
 def _as_device_tensor(x, dtype, device):
     if isinstance(x, np.ndarray):
         x = torch.from_numpy(x)
@@ -93,14 +112,15 @@ def instance2onehot(instance, N=None):
         return instance[..., None] == np.arange(N, dtype=np.uint8)
     if isinstance(instance, torch.Tensor):
         assert instance.dtype == torch.uint8
-        if not instance.is_cuda:
-            raise RuntimeError("instance2onehot: torch input must be on the ROCm device (no CPU path)")
-        inst = instance.contiguous()
+        home = instance.device
+        # a CPU tensor is accepted like in the reference: it is moved to the ROCm device, converted by the HIP
+        # kernel and moved back (there is still no host implementation)
+        inst = (instance if instance.is_cuda else instance.to(_default_device())).contiguous()
         out = torch.empty(inst.shape + (N,), dtype=torch.bool, device=inst.device)
         with torch.cuda.device(inst.device):
             _lib.check(_lib.load().d3f_instance2onehot(_lib.ptr(inst), inst.numel(), N, _lib.ptr(out),
                                                        _lib.current_stream_handle(inst.device)))
-        return out
+        return out.to(home)
     raise NotImplementedError
 
 
@@ -109,15 +129,15 @@ def onehot2instance(one_hot_mask):
     if isinstance(one_hot_mask, np.ndarray):
         return np.argmax(one_hot_mask, axis=-1).astype(np.uint8)
     if isinstance(one_hot_mask, torch.Tensor):
-        if not one_hot_mask.is_cuda:
-            raise RuntimeError("onehot2instance: torch input must be on the ROCm device (no CPU path)")
-        oh = one_hot_mask.to(torch.float32).contiguous()
+        home = one_hot_mask.device
+        oh = one_hot_mask if one_hot_mask.is_cuda else one_hot_mask.to(_default_device())   # CPU tensors: see instance2onehot
+        oh = oh.to(torch.float32).contiguous()
         NI = oh.shape[-1]
         out = torch.empty(oh.shape[:-1], dtype=torch.uint8, device=oh.device)
         with torch.cuda.device(oh.device):
             _lib.check(_lib.load().d3f_onehot2instance(_lib.ptr(oh), out.numel(), NI, _lib.ptr(out),
                                                        _lib.current_stream_handle(oh.device)))
-        return out
+        return out.to(home)
     raise NotImplementedError
 
 
@@ -170,9 +190,15 @@ class Fusion:
 
     feature_extractor(color[V,H,W,3] uint8 ndarray, params{'patch_h','patch_w'}) -> (V,ph,pw,C) tensor
         stands in for extract_features / DINOv2 (fusion.py:593-629)
-    mask_producer(fusion, queries, thresholds, **kw) -> (V,H,W) uint8 labels or (V,H,W,NI) one-hot
-        stands in for Grounded-SAM + instance association (fusion.py:1112-1171)
-    mask_tracker(fusion, queries, thresholds, **kw) -> same; stands in for XMem (fusion.py:1173-1256)
+    mask_producer(fusion, queries, thresholds, boundaries, merge_all=, expected_labels=, robot_pcd=) -> dict
+        {'mask': (V,H,W) uint8 consensus labels or (V,H,W,NI) one-hot, 'consensus_mask_label': [str] * NI,
+         optional 'mask_label', 'mask_conf', 'mask_gs'}: Grounded-SAM + instance association (fusion.py:1112-1171)
+    mask_tracker(fusion, color, mask_or_None) -> (V,H,W,NI) one-hot or (V,H,W) uint8 labels: XMem's
+        xmem_process (fusion.py:631-684); mask is the consensus label image on the first frame, None afterwards
+
+    dtype: torch.float32 (the reference default) or torch.float16.  NOTE: float16 here is NOT the reference's
+    half mode (which computes the projection and everything else in half, fusion.py:203,227,709-712): it is a
+    STORAGE format of the channel maps only; all arithmetic stays fp32 (see __init__).
     """
 
     def __init__(self, num_cam, feat_backbone="dinov2", device="cuda:0", dtype=torch.float32, *,
@@ -195,7 +221,8 @@ class Fusion:
         self.feature_extractor = feature_extractor
         self.mask_producer = mask_producer
         self.mask_tracker = mask_tracker
-        self.track_ids = [0]
+        self.track_ids = [0]                    # fusion.py:303
+        self.xmem_first_mask_loaded = False     # fusion.py:302
         self._finite_cache = {}
         self._finite_override = None
         self._tracker = None                    # rigid_tracking: the captured iteration of the current sequence
@@ -578,35 +605,162 @@ class Fusion:
         from . import pcd_utils
         return pcd_utils.pcd_iou(pcd_1, pcd_2, threshold)
 
+    def vox_idx_iou(self, vox_idx_1, vox_idx_2):
+        """Reference Fusion.vox_idx_iou (fusion.py:794-799); see d3fields_amd.pcd_utils.vox_idx_iou."""
+        from . import pcd_utils
+        return pcd_utils.vox_idx_iou(vox_idx_1, vox_idx_2)
+
+    def select_features_rand_v2(self, boundaries, N, per_instance=False):
+        """Reference Fusion.select_features_rand_v2 (fusion.py:1539-1606): per instance and camera, erode the instance
+        mask (15x15, valid depth only), farthest-point-sample N // num_cam of its PIXELS, back-project them with the
+        camera's depth and pose, and query their descriptors.  Returns (src_feats_list, src_pts_list, img_list);
+        img_list (cv2 keypoint renderings in the reference) is always empty.  The erosion, the pixel FPS and the
+        field query run on the device; the random FPS starts come from np.random.randint in the reference's order."""
+        from . import pcd_utils
+        N_per_cam = N // self.num_cam
+        src_feats_list, src_pts_list = [], []
+        label = self.curr_obs_torch["mask_label"][0]
+        last_label = label[0]
+        depth_all = self.curr_obs_torch["depth"].detach().cpu().numpy()
+        K_all = self.curr_obs_torch["K"].detach().cpu().numpy()
+        pose_all = self.curr_obs_torch["pose"].detach().cpu().numpy()
+        for i in range(1, len(label)):
+            if label[i] == last_label and not per_instance:
+                continue
+            src_pts_np = []
+            for cam_i in range(self.num_cam):
+                instance_mask = self.curr_obs_torch["mask"][cam_i, :, :, i].detach().cpu().numpy().astype(bool)
+                depth_i, K_i = depth_all[cam_i], K_all[cam_i]
+                pose_i = np.concatenate([pose_all[cam_i][:3], np.array([[0, 0, 0, 1]])], axis=0)
+                instance_mask = instance_mask & (depth_i > 0.0) & (depth_i < 1.5)                  # fusion.py:1557-1558
+                instance_mask = pcd_utils.erode((instance_mask * 255).astype(np.uint8), np.ones([15, 15], np.uint8))
+                instance_mask_idx = np.array(instance_mask.nonzero()).T                             # (num_pts, 2) rows, cols
+                sel_idx, _, _ = pcd_utils.fps_pixels(instance_mask_idx, N_per_cam)
+                sel_depth = depth_i[sel_idx[:, 0], sel_idx[:, 1]]
+                src_pts = np.zeros([N_per_cam, 3])
+                src_pts[:, 0] = (sel_idx[:, 1] - K_i[0, 2]) * sel_depth / K_i[0, 0]
+                src_pts[:, 1] = (sel_idx[:, 0] - K_i[1, 2]) * sel_depth / K_i[1, 1]
+                src_pts[:, 2] = sel_depth
+                hom = np.concatenate([src_pts, np.ones([N_per_cam, 1])], axis=-1).T
+                src_pts_np.append(np.matmul(np.linalg.inv(pose_i), hom)[:3].T)                     # camera -> world
+            sample_pts = np.concatenate(src_pts_np, axis=0)
+            src_pts_list.append(sample_pts)
+            src_feats_list.append(self.eval(torch.from_numpy(sample_pts).to(self.device, torch.float32))["dino_feats"])
+            last_label = label[i]
+        return src_feats_list, src_pts_list, []
+
     # ---- instance masks: upstream producers (reference fusion.py:1112-1256) ----------------
-    def _store_mask(self, produced):
-        m = produced
+    # The reference hard-wires Grounded-SAM + its multi-view association (align_instance_mask_v3, fusion.py:1067-1098)
+    # and XMem (xmem_process, fusion.py:631-684).  They stay upstream models here and are injected:
+    #
+    #   mask_producer(fusion, queries, thresholds, boundaries, merge_all=False, expected_labels=None, robot_pcd=None)
+    #       -> dict with
+    #          'mask'                 (V,H,W) uint8 consensus instance index per pixel, or (V,H,W,NI) one-hot
+    #                                 (what align_instance_mask_v3 leaves in curr_obs_torch['mask'], fusion.py:1055-1065)
+    #          'consensus_mask_label' list of NI label strings, entry 0 == 'background'            (fusion.py:1096)
+    #          optional 'mask_label' (per view: list of label strings), 'mask_conf', 'mask_gs'      (fusion.py:1141-1143)
+    #   mask_tracker(fusion, color (V,H,W,3) uint8, mask (V,H,W) uint8 tensor or None)
+    #       -> (V,H,W,NI) one-hot / probabilities, or (V,H,W) uint8 labels: xmem_process's contract (fusion.py:631-684);
+    #          mask is the consensus label image on the first frame and None on every later frame.
+    def _store_segmentation(self, produced):
+        """Writes what text_queries_* write after Grounded-SAM + align_instance_mask_v3 (fusion.py:1141-1145, 1096):
+        'mask_gs', 'mask_label' (list per view of label strings), 'mask_conf', 'semantic_label',
+        'consensus_mask_label'.  Returns the (V,H,W) uint8 consensus label image."""
+        if not isinstance(produced, dict) or "mask" not in produced or "consensus_mask_label" not in produced:
+            raise TypeError("mask_producer must return a dict with 'mask' and 'consensus_mask_label' "
+                            "(optionally 'mask_label', 'mask_conf', 'mask_gs'); see INTEGRATION.md")
+        consensus = [str(x) for x in produced["consensus_mask_label"]]
+        NI = len(consensus)
+        m = produced["mask"]
         if isinstance(m, np.ndarray):
             m = torch.from_numpy(m)
         m = m.to(self.device)
-        if m.dim() == 3:                                           # (V,H,W) uint8 labels
-            label = m.to(torch.uint8)
-            NI = int(label.max().item()) + 1
-            onehot = instance2onehot(label.contiguous(), NI).to(self.dtype)
-        else:                                                      # (V,H,W,NI) one-hot / probabilities
-            onehot = m.to(self.dtype)
-            label = onehot2instance(onehot)
-        self.curr_obs_torch["mask_label"] = label
-        self.curr_obs_torch["mask"] = onehot.contiguous()
+        if m.dim() == 4:                                           # one-hot / probabilities -> label image
+            if m.shape[-1] != NI:
+                raise ValueError("'mask' has %d channels but 'consensus_mask_label' names %d instances" % (m.shape[-1], NI))
+            m = onehot2instance(m)
+        if m.dim() != 3 or tuple(m.shape[1:]) != (self.H, self.W):
+            raise ValueError("'mask' must be (V,%d,%d) labels or (V,%d,%d,NI) one-hot, got %s" % (self.H, self.W, self.H, self.W, tuple(m.shape)))
+        label_img = m.to(torch.uint8).contiguous()
+        if label_img.numel() and int(label_img.max().item()) >= NI:
+            raise ValueError("'mask' holds instance index %d but 'consensus_mask_label' names only %d instances"
+                             % (int(label_img.max().item()), NI))
+        V = label_img.shape[0]
+        labels = produced.get("mask_label")
+        if labels is None:      # the reference's (disabled) assumption: every view saw every instance (fusion.py:1154-1166)
+            labels = [list(consensus) for _ in range(V)]
+        labels = [list(l) for l in labels]
+        self.curr_obs_torch["mask_gs"] = produced.get("mask_gs")
+        self.curr_obs_torch["mask_label"] = labels
+        self.curr_obs_torch["mask_conf"] = produced.get("mask_conf", [[1.0] * len(l) for l in labels])
+        _, first = np.unique(labels[0], return_index=True)                                       # fusion.py:1144-1145
+        self.curr_obs_torch["semantic_label"] = list(np.array(labels[0])[np.sort(first)])
+        self.curr_obs_torch["consensus_mask_label"] = consensus
+        return label_img
+
+    def _set_mask(self, onehot):
+        self.curr_obs_torch["mask"] = onehot.to(device=self.device, dtype=self.dtype).contiguous()
         self._finite_cache.pop("mask", None)
 
-    def text_queries_for_inst_mask_no_track(self, queries, thresholds, boundaries=None, **kwargs):
-        """Reference fusion.py:1112-1171; the Grounded-SAM + multi-view association stage is injected."""
+    def _tracked_mask(self, label_img):
+        """xmem_process stand-in (fusion.py:631-684): injected tracker -> one-hot (V,H,W,len(track_ids))."""
+        out = self.mask_tracker(self, self.curr_obs_torch["color"], label_img)
+        if isinstance(out, np.ndarray):
+            out = torch.from_numpy(out)
+        out = out.to(self.device)
+        if label_img is not None:
+            self.xmem_first_mask_loaded = True                                                    # fusion.py:663-665
+            self.track_ids = list(range(len(self.curr_obs_torch["consensus_mask_label"])))       # fusion.py:657
+        if out.dim() == 3:
+            out = instance2onehot(out.to(torch.uint8).contiguous(), len(self.track_ids))          # fusion.py:683
+        if out.dim() != 4 or out.shape[-1] != len(self.track_ids):
+            raise ValueError("mask_tracker must return (V,H,W,%d) one-hot or (V,H,W) labels, got %s" % (len(self.track_ids), tuple(out.shape)))
+        return out
+
+    def text_queries_for_inst_mask_no_track(self, queries, thresholds, boundaries, merge_all=False, expected_labels=None,
+                                            robot_pcd=None):
+        """Reference fusion.py:1112-1171: segment every view, align the instances across views, store
+        'mask_label' / 'mask_conf' / 'semantic_label' / 'consensus_mask_label' and 'mask' as a one-hot
+        (V,H,W,len(consensus_mask_label)) tensor of Fusion.dtype.  Segmentation + association are injected."""
+        if "color" not in self.curr_obs_torch:
+            raise RuntimeError("Please call update() first!")
         if self.mask_producer is None:
             raise RuntimeError("no mask_producer was injected (Grounded-SAM is an upstream PyTorch-ROCm producer)")
-        self._store_mask(self.mask_producer(self, queries, thresholds, boundaries=boundaries, **kwargs))
+        label_img = self._store_segmentation(self.mask_producer(self, queries, thresholds, boundaries, merge_all=merge_all,
+                                                                expected_labels=expected_labels, robot_pcd=robot_pcd))
+        consensus = self.curr_obs_torch["consensus_mask_label"]
+        if expected_labels is not None and consensus != expected_labels:
+            print("consensus mask label", consensus)                                              # fusion.py:1097-1098
+        self._set_mask(instance2onehot(label_img, len(consensus)))                                # fusion.py:1171
 
-    def text_queries_for_inst_mask(self, queries, thresholds, boundaries=None, **kwargs):
-        """Reference fusion.py:1173-1256: first call segments, later calls track (XMem), both injected."""
-        if len(self.curr_obs_torch) == 0:
-            raise RuntimeError("Please call update() first!")
-        first = "mask" not in self.curr_obs_torch
-        producer = self.mask_producer if (first or self.mask_tracker is None) else self.mask_tracker
-        if producer is None:
-            raise RuntimeError("no mask_producer / mask_tracker was injected")
-        self._store_mask(producer(self, queries, thresholds, boundaries=boundaries, **kwargs))
+    def text_queries_for_inst_mask(self, queries, thresholds, boundaries, use_sam=False, merge_all=False, expected_labels=None,
+                                   robot_pcd=None):
+        """Reference fusion.py:1173-1256: the first call segments + aligns (as _no_track) and initialises the tracker
+        with the consensus label image; every later call only tracks (XMem, injected).  use_sam=True after the first
+        frame raises NotImplementedError, as in the reference (fusion.py:1240-1241)."""
+        if "color" not in self.curr_obs_torch:
+            raise RuntimeError("Please call update() first!")        # the reference prints this and calls exit()
+        if self.mask_tracker is None:
+            raise RuntimeError("no mask_tracker was injected (XMem is an upstream PyTorch-ROCm producer); "
+                               "use text_queries_for_inst_mask_no_track for single frames")
+        if not self.xmem_first_mask_loaded:
+            if self.mask_producer is None:
+                raise RuntimeError("no mask_producer was injected (Grounded-SAM is an upstream PyTorch-ROCm producer)")
+            label_img = self._store_segmentation(self.mask_producer(self, queries, thresholds, boundaries, merge_all=merge_all,
+                                                                    expected_labels=expected_labels, robot_pcd=robot_pcd))
+            self._set_mask(self._tracked_mask(label_img))                                         # fusion.py:1237
+        elif not use_sam:
+            self._set_mask(self._tracked_mask(None))                                              # fusion.py:1239
+        else:
+            raise NotImplementedError
+
+    def get_inst_num(self):
+        """Number of instances including the background (fusion.py:1258-1260)."""
+        return len(self.curr_obs_torch["consensus_mask_label"])
+
+    def clear_xmem_memory(self):
+        """fusion.py:1698-1702: the next text_queries_for_inst_mask call segments again (the injected tracker
+        owns its own memory; give it a `clear_memory()` attribute to have it called here)."""
+        if hasattr(self.mask_tracker, "clear_memory"):
+            self.mask_tracker.clear_memory()
+        self.xmem_first_mask_loaded = False

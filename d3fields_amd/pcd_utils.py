@@ -11,7 +11,8 @@ import torch
 
 from . import _lib
 
-__all__ = ["depth2fgpcd", "aggr_point_cloud_from_data", "pcd_iou"]
+__all__ = ["depth2fgpcd", "aggr_point_cloud_from_data", "pcd_iou", "init_low_level_memory", "vox_idx_iou", "erode",
+           "fps_pixels"]
 
 
 def _device():
@@ -97,3 +98,122 @@ def pcd_iou(pcd_1, pcd_2, threshold):
     iou = (n1 + n2) / (pcd_1.shape[0] + pcd_2.shape[0])
     return (iou, n1 / pcd_1.shape[0], n2 / pcd_2.shape[0], np.where(d12 < threshold)[0], np.where(d21 < threshold)[0],
             i12.cpu().numpy(), i21.cpu().numpy())
+
+
+# ---- voxel indices of instance association (reference fusion.py:118-180, 794-799) -----------------------------------
+def init_low_level_memory(lower_bound, higher_bound, voxel_size, voxel_num):
+    """The six closures of the reference's _init_low_level_memory (fusion.py:118-180), same names and order:
+    (pcd_to_voxel, voxel_to_pcd, voxel_to_index, index_to_voxel, pcd_to_index, index_to_pcd).
+
+    pcd_to_voxel / pcd_to_index -- the per-point work merge_instances_from_new_view_vox_ver does on every masked
+    cloud (fusion.py:807) -- run on the ROCm device (d3f_pcd_to_index: fp64 floor-divide, numpy's int32 cast and
+    int32 wrap-around, bit-exact).  The four pure index conversions are one-line integer formulas on a handful of
+    voxels and are evaluated with numpy exactly as written in the reference."""
+    lower = np.asarray(lower_bound, dtype=np.float64).reshape(3)
+    num = np.asarray(voxel_num).astype(np.int32).reshape(3)
+    vs = float(voxel_size)
+
+    def _device_index(pcds, want_voxels):
+        pcds = np.asarray(pcds) if not isinstance(pcds, np.ndarray) else pcds
+        lead = pcds.shape[:-1]
+        assert pcds.shape[-1] == 3
+        dev = _device()
+        flat = torch.from_numpy(np.ascontiguousarray(pcds, dtype=np.float64).reshape(-1, 3)).to(dev)
+        n = flat.shape[0]
+        idx = torch.empty(n, dtype=torch.int32, device=dev)
+        vox = torch.empty((n, 3), dtype=torch.int32, device=dev) if want_voxels else None
+        with torch.cuda.device(dev):
+            _lib.check(_lib.load().d3f_pcd_to_index(_lib.ptr(flat), n, _dbl(lower), vs, (ctypes.c_int32 * 3)(*[int(v) for v in num]),
+                                                    _lib.ptr(idx), _lib.ptr(vox), _lib.current_stream_handle(dev)))
+        if want_voxels:
+            return vox.cpu().numpy().reshape(lead + (3,))
+        return idx.cpu().numpy().reshape(lead)
+
+    def pcd_to_voxel(pcds):
+        return _device_index(pcds, True)
+
+    def voxel_to_pcd(voxels):
+        return np.asarray(voxels) * voxel_size + lower_bound
+
+    def voxel_to_index(voxels):
+        voxels = np.asarray(voxels)
+        return voxels[..., 0] * num[1] * num[2] + voxels[..., 1] * num[2] + voxels[..., 2]
+
+    def index_to_voxel(indexes):
+        indexes = np.asarray(indexes)
+        voxels = np.zeros(indexes.shape + (3,), dtype=np.int32)
+        voxels[..., 2] = indexes % num[2]
+        rest = indexes // num[2]
+        voxels[..., 1] = rest % num[1]
+        voxels[..., 0] = rest // num[1]
+        return voxels
+
+    def pcd_to_index(pcds):
+        return _device_index(pcds, False)
+
+    def index_to_pcd(indexes):
+        return voxel_to_pcd(index_to_voxel(indexes))
+
+    return pcd_to_voxel, voxel_to_pcd, voxel_to_index, index_to_voxel, pcd_to_index, index_to_pcd
+
+
+def vox_idx_iou(vox_idx_1, vox_idx_2):
+    """Fusion.vox_idx_iou (fusion.py:794-799): (|A & B| / |A | B|, len(vox_idx_1) / |A | B|, len(vox_idx_2) / |A | B|)
+    with A, B the SETS of the two index arrays (the lengths in the last two ratios are the raw lengths, duplicates
+    included, as in the reference).  The set sizes come from one device hash set (d3f_vox_idx_iou); an empty union
+    raises ZeroDivisionError like the reference."""
+    dev = _device()
+    a = torch.from_numpy(np.ascontiguousarray(np.asarray(vox_idx_1).reshape(-1), dtype=np.int32)).to(dev)
+    b = torch.from_numpy(np.ascontiguousarray(np.asarray(vox_idx_2).reshape(-1), dtype=np.int32)).to(dev)
+    lib = _lib.load()
+    ws_bytes = lib.d3f_vox_iou_workspace_bytes(a.numel(), b.numel())
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+    counts = torch.empty(2, dtype=torch.int64, device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(lib.d3f_vox_idx_iou(_lib.ptr(a), a.numel(), _lib.ptr(b), b.numel(), _lib.ptr(counts), _lib.ptr(ws), ws_bytes,
+                                       _lib.current_stream_handle(dev)))
+    inter, union = (int(v) for v in counts.tolist())
+    return inter / union, a.numel() / union, b.numel() / union
+
+
+def erode(image, kernel, iterations=1):
+    """cv2.erode(image, kernel, iterations=1) for an all-ones kernel on an (H,W) uint8 image, as the reference uses it
+    on instance masks (fusion.py:1293, 1305, 1561): numpy in, numpy out; runs as d3f_erode on the device."""
+    kernel = np.asarray(kernel)
+    if kernel.ndim != 2 or not np.all(kernel != 0):
+        raise NotImplementedError("only all-ones rectangular structuring elements (np.ones([kh, kw])) are supported")
+    if iterations != 1:
+        raise NotImplementedError("iterations=1 only (the reference never passes another value)")
+    img = np.ascontiguousarray(image)
+    if img.dtype != np.uint8 or img.ndim != 2:
+        raise TypeError("erode expects an (H,W) uint8 image")
+    dev = _device()
+    src = torch.from_numpy(img).to(dev)
+    dst = torch.empty_like(src)
+    with torch.cuda.device(dev):
+        _lib.check(_lib.load().d3f_erode(_lib.ptr(src), img.shape[0], img.shape[1], kernel.shape[0], kernel.shape[1],
+                                         _lib.ptr(dst), _lib.current_stream_handle(dev)))
+    return dst.cpu().numpy()
+
+
+def fps_pixels(pixel_idx, particle_num, init_idx=-1):
+    """fps_np (utils/my_utils.py:478-497) on an (n,2) INTEGER array -- select_features_rand_v2 samples the (row, col)
+    indices of an eroded mask with it (fusion.py:1565-1566).  Returns (selected [k,2] int array, index list,
+    max remaining distance) like fps_np; init_idx == -1 draws the start with np.random.randint, as the reference."""
+    pix = np.ascontiguousarray(pixel_idx)
+    assert pix.ndim == 2 and pix.shape[1] == 2 and pix.shape[0] > 0
+    if not np.issubdtype(pix.dtype, np.integer):
+        raise TypeError("fps_pixels expects integer pixel coordinates")
+    n = pix.shape[0]
+    start = int(np.random.randint(n)) if init_idx == -1 else int(init_idx)
+    k = min(int(particle_num), n)
+    dev = _device()
+    pts = torch.from_numpy(pix.astype(np.int32)).to(dev)
+    idx = torch.empty(k, dtype=torch.int64, device=dev)
+    maxd = torch.empty(1, dtype=torch.float64, device=dev)
+    ws = torch.empty(n, dtype=torch.int64, device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(_lib.load().d3f_fps_pixels(_lib.ptr(pts), n, k, start, _lib.ptr(idx), _lib.ptr(maxd), _lib.ptr(ws),
+                                              _lib.current_stream_handle(dev)))
+    sel = idx.cpu().numpy()
+    return pix[sel], sel.tolist(), float(maxd.item())

@@ -14,7 +14,7 @@ cubes, fusion.py:1313-1330) should gather keys=('dist','valid_mask') and leave f
 import torch
 import torch.distributed as dist
 
-__all__ = ["shard_bounds", "shard_points", "all_gather_field", "sharded_eval", "broadcast_observation",
+__all__ = ["shard_bounds", "shard_points", "all_gather_field", "gather_bytes", "sharded_eval", "broadcast_observation",
            "sharded_similarity_multi"]
 
 
@@ -39,37 +39,62 @@ def shard_points(pts, rank=None, world=None, group=None):
     return pts[lo:hi]
 
 
+def _gather_rows_into(out, x, counts, group, async_op=False):
+    """all-gather of per-rank row blocks (dim-0 sizes `counts`, ragged allowed) straight into the pre-sized
+    C-contiguous `out` ([sum(counts), ...]): no padding, no staging buffer, no torch.cat.  Returns the pending works.
+
+    Equal shards: one all_gather_into_tensor.  Ragged shards: rank r's block is broadcast into ITS slice of `out`
+    (a contiguous view), so every byte lands in place; the P broadcasts are queued back to back on the
+    collective stream and move the same bytes as one all-gather-v."""
+    rank, world = _world(group)
+    x = x.contiguous()
+    if len(set(counts)) == 1:
+        w = dist.all_gather_into_tensor(out, x, group=group, async_op=async_op)
+        return [w] if async_op else []
+    views = list(out.split(list(counts), dim=0))
+    views[rank].copy_(x)
+    works = []
+    for r in range(world):
+        if counts[r] == 0:
+            continue
+        src = dist.get_global_rank(group, r) if group is not None else r
+        w = dist.broadcast(views[r], src=src, group=group, async_op=async_op)
+        if async_op:
+            works.append(w)
+    return works
+
+
 def _gather_rows(t, counts, group, async_op=False):
-    """all-gather along dim 0 of per-rank tensors whose dim-0 sizes are `counts` (ragged allowed).
-    Returns (tensor, work): work is the pending collective when async_op was honoured (equal counts), else None."""
-    world = len(counts)
+    """all-gather along dim 0 -> (full tensor, pending works)."""
     as_bool = t.dtype == torch.bool
     x = t.view(torch.uint8) if as_bool else t
-    x = x.contiguous()
-    work = None
-    if len(set(counts)) == 1:
-        out = x.new_empty((world * counts[0],) + tuple(x.shape[1:]))
-        work = dist.all_gather_into_tensor(out, x, group=group, async_op=async_op)
-        work = work if async_op else None
-    else:
-        cap = max(counts)
-        pad = x.new_zeros((cap,) + tuple(x.shape[1:]))
-        pad[:x.shape[0]] = x
-        buf = x.new_empty((world * cap,) + tuple(x.shape[1:]))
-        dist.all_gather_into_tensor(buf, pad, group=group)
-        out = torch.cat([buf[r * cap:r * cap + c] for r, c in enumerate(counts)], dim=0)
-    return (out.view(torch.bool) if as_bool else out), work
+    out = x.new_empty((sum(counts),) + tuple(x.shape[1:]))
+    works = _gather_rows_into(out, x, counts, group, async_op)
+    return (out.view(torch.bool) if as_bool else out), works
+
+
+def gather_bytes(local_out, keys, counts):
+    """Bytes one rank RECEIVES when `keys` of a sharded field are all-gathered (the xGMI cost of reassembly)."""
+    total, own = sum(counts), None
+    n_local = local_out["dist"].shape[0]
+    recv = 0
+    for k in keys:
+        t = local_out[k]
+        row = t.element_size() * (t.numel() // max(n_local, 1))          # bytes per query point of this output
+        recv += (total - n_local) * row
+    return recv
 
 
 def all_gather_field(local_out, keys=None, counts=None, group=None, async_op=False):
     """Reassembles per-rank eval outputs into the full field on every rank.
 
     local_out: dict from Fusion.eval on this rank's shard.  keys: which entries to gather
-    (default all).  '<k>_inter' entries ([V,n,C]) are gathered along their point axis.
+    (default all).  '<k>_inter' entries ([V,n,C]) are gathered along their point axis, view by view, straight
+    into the [V,N,C] result (each view's rows are one contiguous block of it).
     counts: per-rank shard sizes if already known (saves a tiny all-gather).
     async_op=True returns (field, works): the collectives run on RCCL's stream while the caller keeps launching
     (e.g. the next batch's query); the field -- and `local_out`, which the caller must keep alive -- may only be
-    touched after `for w in works: w.wait()`.  Ragged shards and '<k>_inter' fall back to the blocking form.
+    touched after `for w in works: w.wait()`.  Ragged shards are supported in both forms.
     """
     rank, world = _world(group)
     if world == 1:
@@ -86,11 +111,13 @@ def all_gather_field(local_out, keys=None, counts=None, group=None, async_op=Fal
     for k in keys:
         t = local_out[k]
         if k.endswith("_inter"):
-            full[k] = _gather_rows(t.transpose(0, 1), counts, group)[0].transpose(0, 1).contiguous()
+            out = t.new_empty((t.shape[0], sum(counts)) + tuple(t.shape[2:]))
+            for v in range(t.shape[0]):
+                works += _gather_rows_into(out[v], t[v], counts, group, async_op)
+            full[k] = out
         else:
             full[k], w = _gather_rows(t, counts, group, async_op)
-            if w is not None:
-                works.append(w)
+            works += w
     return (full, works) if async_op else full
 
 
@@ -117,16 +144,25 @@ def sharded_eval(fusion, pts, return_names=("dino_feats", "mask"), gather_keys=N
     return out
 
 
-def broadcast_observation(fusion, src=0, group=None):
+def broadcast_observation(fusion, src=0, group=None, keys=None):
     """Replicates rank `src`'s curr_obs_torch tensors (maps, depth, K, pose) to every rank: the
-    once-per-update setup cost of the sharded mode."""
+    once-per-update setup cost of the sharded mode (dense C4 maps: 30 GB per rank -- pass `keys` to re-send only
+    what the update changed, e.g. ('depth', 'mask') while the feature maps of a static scene stay).  Returns the
+    bytes this rank received.  The in-place overwrite invalidates the shim's cached "maps are finite" verdicts and
+    the cached point-order probe, so the next query re-checks the new data."""
     rank, world = _world(group)
     if world == 1:
-        return
+        return 0
+    received = 0
     for k in sorted(fusion.curr_obs_torch.keys()):
         t = fusion.curr_obs_torch[k]
-        if isinstance(t, torch.Tensor):
+        if isinstance(t, torch.Tensor) and (keys is None or k in keys):
             dist.broadcast(t, src=src, group=group)
+            if rank != src:
+                received += t.numel() * t.element_size()
+    if hasattr(fusion, "_finite_cache"):
+        fusion._finite_cache.clear()
+    return received
 
 
 class _HipSoftmaxKernels:

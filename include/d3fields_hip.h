@@ -10,8 +10,10 @@
  * Conventions
  *   - every pointer is a DEVICE pointer on the device the stream belongs to, unless noted;
  *   - the library never allocates, frees or retains caller memory and keeps no state between
- *     calls (re-entrant); work is enqueued on `stream` (a hipStream_t, NULL = default
- *     stream) and NOT synchronised;
+ *     calls (re-entrant), with two documented thread-local exceptions: the text behind
+ *     d3f_last_error() and the one-shot event pair armed by d3f_profile_next_eval() (a measurement
+ *     hook, consumed by the same thread's next query); work is enqueued on `stream` (a
+ *     hipStream_t, NULL = default stream) and NOT synchronised;
  *   - all tensors fp32, C-contiguous unless strides are part of the signature;
  *   - return value: D3F_OK or a negative D3F_ERR_* code; d3f_last_error() gives the text of
  *     the calling thread's last failure.  Nothing aborts.
@@ -25,7 +27,7 @@
 extern "C" {
 #endif
 
-#define D3F_ABI_VERSION 1
+#define D3F_ABI_VERSION 2
 
 #define D3F_OK 0
 #define D3F_ERR_INVALID_ARG (-1)  /* null pointer, negative count, bad enum               */
@@ -193,6 +195,34 @@ int d3f_backproject_view(const double *depth, const uint8_t *mask, int32_t H, in
  * the Euclidean distance to, and index of, its nearest point in b[nb,3] (first minimum wins), fp64. */
 int d3f_pcd_nearest(const double *a, int64_t na, const double *b, int64_t nb, double *min_dist, int64_t *argmin,
                     void *stream);
+
+/* ---- multi-view instance association: the integer steps (fusion.py:118-180, 794-849, 1279-1297, 1539-1606) ----
+ * d3f_pcd_to_index = pcd_to_voxel + voxel_to_index of _init_low_level_memory (fusion.py:118-180):
+ *   voxel = floor((p - lower) / voxel_size) as int32 (fp64 arithmetic, numpy's cast), index = v0*num[1]*num[2] +
+ *   v1*num[2] + v2 in wrapping int32.  pts [n,3] fp64 (device); lower[3], voxel_num[3] are HOST arrays;
+ *   out_index [n] int32; out_voxel NULL or [n,3] int32 (pcd_to_voxel's result). */
+int d3f_pcd_to_index(const double *pts, int64_t n, const double *lower, double voxel_size, const int32_t *voxel_num,
+                     int32_t *out_index, int32_t *out_voxel, void *stream);
+
+/* Fusion.vox_idx_iou (fusion.py:794-799) on two int32 index arrays (duplicates allowed, any values):
+ * out_counts[0] = |set(a) & set(b)|, out_counts[1] = |set(a) | set(b)| (two device int64); the reference's
+ * triple is (counts[0]/counts[1], n1/counts[1], n2/counts[1]).  workspace: d3f_vox_iou_workspace_bytes(n1, n2)
+ * bytes of device scratch (one hash set), only used inside the call. */
+int64_t d3f_vox_iou_workspace_bytes(int64_t n1, int64_t n2);
+int d3f_vox_idx_iou(const int32_t *idx1, int64_t n1, const int32_t *idx2, int64_t n2, int64_t *out_counts,
+                    void *workspace, int64_t workspace_bytes, void *stream);
+
+/* cv2.erode(src, np.ones([kh, kw], np.uint8), iterations=1) on an [H,W] uint8 image (fusion.py:1293: 2x2 on a
+ * 0/255 mask; fusion.py:1561: 15x15): minimum over the window anchored at (kw/2, kh/2), out-of-image samples
+ * ignored (cv2's default border for erosion).  src != dst. */
+int d3f_erode(const uint8_t *src, int32_t H, int32_t W, int32_t kh, int32_t kw, uint8_t *dst, void *stream);
+
+/* fps_np (utils/my_utils.py:478-497) on integer 2-D points, as select_features_rand_v2 calls it on the (row, col)
+ * indices of a mask (fusion.py:1565-1566): pts [n,2] int32, exact squared distances (numpy's float64 norms of
+ * integer differences order identically), first maximum wins.  out_idx [k] int64, out_maxdist one device double
+ * or NULL, dist_workspace: n int64 of device scratch. */
+int d3f_fps_pixels(const int32_t *pts, int64_t n, int32_t k, int64_t init_idx, int64_t *out_idx, double *out_maxdist,
+                   int64_t *dist_workspace, void *stream);
 
 /* Gradient of d3f_eval's outputs w.r.t. the query points: what autograd through Fusion.eval gives
  * the reference's rigid_tracking (fusion.py:1643-1665).  grad_dist: [n] or NULL; grad_fused: host

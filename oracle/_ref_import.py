@@ -55,6 +55,11 @@ def import_reference():
     import importlib
     fusion = importlib.import_module("fusion")
     corr = importlib.import_module("utils.corr_utils")
+    # opencv-python (env.yaml:17) is absent: cv2 is a MagicMock, except for the one function whose RESULT the path
+    # depends on -- cv2.erode with an all-ones kernel (fusion.py:1293,1305,1561) -- which gets the restated
+    # definition of oracle/np_pcd.py so that select_features_rand_v2 of the reference runs here
+    from oracle import np_pcd
+    fusion.cv2.erode = np_pcd.erode_cv2
     return fusion, corr
 
 

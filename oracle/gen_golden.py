@@ -300,6 +300,64 @@ def tracking_case(fusion):
          match_pts=match, n=n)
 
 
+def assoc_case(fusion):
+    """The voxel-index IoU of instance association: _init_low_level_memory closures (fusion.py:118-180) and
+    Fusion.vox_idx_iou (fusion.py:794-799), run by the reference on clouds inside AND partly outside the box."""
+    box = dict(synth.WORK_BOX)
+    lower = np.array([box["x_lower"], box["y_lower"], box["z_lower"]])
+    higher = np.array([box["x_upper"], box["y_upper"], box["z_upper"]])
+    voxel_size = 0.03                                                     # fusion.py:1078
+    voxel_num = ((higher - lower) / voxel_size).astype(np.int32)          # fusion.py:1079
+    fns = fusion._init_low_level_memory(lower, higher, voxel_size, voxel_num=voxel_num)
+    pcd_to_voxel, voxel_to_pcd, voxel_to_index, index_to_voxel, pcd_to_index, index_to_pcd = fns
+    g = np.random.default_rng(81)
+    pcd = g.uniform(lower - 0.05, higher + 0.05, size=(6000, 3))          # ~25 % of the points lie outside the box
+    pcd[:50] = lower + voxel_size * g.integers(0, 5, size=(50, 3))         # exactly on voxel faces
+    pcd32 = g.uniform(lower, higher, size=(500, 3)).astype(np.float32)     # float32 input (promoted like numpy does)
+    f = fusion.Fusion.__new__(fusion.Fusion)
+    a = pcd_to_index(pcd[:2500])
+    b = pcd_to_index(pcd[1500:6000] + 0.004)
+    pairs = {"ab": (a, b), "aa": (a, a), "disjoint": (a[a % 2 == 0], a[a % 2 == 1]), "one_empty": (a, a[:0]),
+             "small": (np.array([5, 5, 5, 7], np.int32), np.array([7, 9], np.int32))}
+    arrays = dict(lower=lower, higher=higher, voxel_size=voxel_size, voxel_num=voxel_num, pcd=pcd, pcd32=pcd32,
+                  voxels=pcd_to_voxel(pcd), index=pcd_to_index(pcd), index32=pcd_to_index(pcd32),
+                  index_of_voxels=voxel_to_index(pcd_to_voxel(pcd)), voxel_of_index=index_to_voxel(pcd_to_index(pcd[100:200])),
+                  pcd_of_index=index_to_pcd(pcd_to_index(pcd[100:200])))
+    for k, (x, y) in pairs.items():
+        arrays["iou_%s_a" % k], arrays["iou_%s_b" % k] = x, y
+        arrays["iou_%s" % k] = np.array(f.vox_idx_iou(x, y), dtype=np.float64)
+    save("assoc", **arrays)
+
+
+def select_v2_case(fusion):
+    """select_features_rand_v2 (fusion.py:1539-1606) run by the reference (cv2.erode restated, oracle/np_pcd.py):
+    15x15 erosion of each instance mask, fps_np on the pixel indices (np.random seeded), back-projection, eval."""
+    V, H, W = 4, 96, 128
+    sc = synth.make_scene(V, H, W, "smooth")
+    feats = synth.random_map(V, 12, 16, 16, seed=91)
+    yy, xx = np.mgrid[0:H, 0:W]
+    lab = np.zeros((V, H, W), np.int64)
+    for v in range(V):                                   # two blobs per view + background, a hole in one of them
+        lab[v][(yy - 30 - 2 * v) ** 2 + (xx - 40) ** 2 < 22 ** 2] = 1
+        lab[v][(np.abs(yy - 60) < 18) & (np.abs(xx - 92 + 3 * v) < 20)] = 2
+        lab[v][(np.abs(yy - 60) < 2) & (np.abs(xx - 92) < 3)] = 0
+    mask = torch.nn.functional.one_hot(torch.from_numpy(lab), 3).to(torch.float32)
+    labels = ["background", "mug", "box"]
+    obs = dict(sc)
+    obs.update(dino_feats=feats, mask=mask, mask_label=[labels] * V, consensus_mask_label=labels,
+               color=np.zeros((V, H, W, 3), np.uint8))
+    f = R.make_reference_fusion(fusion, obs, H, W)
+    np.random.seed(1234)
+    feats_l, pts_l, _ = f.select_features_rand_v2(dict(synth.WORK_BOX), 32, per_instance=True)
+    er = fusion.cv2.erode(((lab[0] == 1) * 255).astype(np.uint8), np.ones([15, 15], np.uint8), iterations=1)
+    arrays = dict(H=H, W=W, mu=f.mu, K=sc["K"].numpy(), pose=sc["pose"].numpy(), depth=sc["depth"].numpy(),
+                  in_dino_feats=feats.numpy(), in_mask=mask.numpy(), N=32, seed=1234, n_inst=len(pts_l), eroded_v0_i1=er)
+    for i, (a, b) in enumerate(zip(feats_l, pts_l)):
+        arrays["feats_%d" % i] = a.numpy()
+        arrays["pts_%d" % i] = b
+    save("select_v2", **arrays)
+
+
 def main():
     torch.set_num_threads(4)
     fusion, corr = R.import_reference()
@@ -316,6 +374,8 @@ def main():
     select_case(fusion)
     pcd_case(fusion)
     tracking_case(fusion)
+    assoc_case(fusion)
+    select_v2_case(fusion)
 
 
 if __name__ == "__main__":

@@ -3,7 +3,17 @@
   backproject_view : depth2fgpcd (utils/my_utils.py:522-537) + inv(pose) transform + boundary crop of
                      aggr_point_cloud_from_data (utils/draw_utils.py:325-413), one view
   nearest          : one direction of Fusion.pcd_iou's search (fusion.py:731-735)
-Pinned against tests/golden/pcd_utils.npz (written by running the reference).  Never imported by d3fields_amd.
+  pcd_to_voxel / pcd_to_index / vox_idx_iou : the voxel-index IoU of instance association (fusion.py:118-180, 794-799)
+  erode_cv2        : cv2.erode with an all-ones kernel.  THIRD-PARTY ARITHMETIC ABSENT HERE: opencv-python (env.yaml:17,
+                     unpinned) is not installed in the build container, so its published definition is restated
+                     (OpenCV docs, cv::erode: dst(x,y) = min over the element of src(x + x' - anchor.x, y + y' - anchor.y),
+                     default anchor = element centre (cols/2, rows/2), default border value +max, i.e. out-of-image samples
+                     never lower the minimum) and cross-checked against scipy.ndimage.grey_erosion, an independent
+                     implementation with the same window convention (tests/test_oracle_golden.py).  The reference's own
+                     call sites are fusion.py:1293 (2x2), :1305 (2x2) and :1561 (15x15).
+  fps_int          : fps_np (utils/my_utils.py:478-497) restated for the integer pixel arrays of fusion.py:1565-1566
+Pinned against tests/golden/pcd_utils.npz / assoc.npz / select_v2.npz (written by running the reference).
+Never imported by d3fields_amd.
 """
 import numpy as np
 
@@ -36,3 +46,55 @@ def nearest(a, b, chunk=512):
         md[s:s + chunk] = d.min(axis=1)
         am[s:s + chunk] = d.argmin(axis=1)
     return md, am
+
+
+def pcd_to_voxel(pcds, lower_bound, voxel_size):
+    """fusion.py:119-125"""
+    return np.floor((np.asarray(pcds) - lower_bound) / voxel_size).astype(np.int32)
+
+
+def voxel_to_index(voxels, voxel_num):
+    """fusion.py:135-145 (int32 arithmetic of the int32 voxel arrays)"""
+    voxels = np.asarray(voxels)
+    return voxels[..., 0] * voxel_num[1] * voxel_num[2] + voxels[..., 1] * voxel_num[2] + voxels[..., 2]
+
+
+def pcd_to_index(pcds, lower_bound, voxel_size, voxel_num):
+    """fusion.py:159-164"""
+    return voxel_to_index(pcd_to_voxel(pcds, lower_bound, voxel_size), voxel_num)
+
+
+def vox_idx_iou(vox_idx_1, vox_idx_2):
+    """fusion.py:794-799: Python sets; the second and third ratio use the RAW lengths."""
+    a, b = set(np.asarray(vox_idx_1).tolist()), set(np.asarray(vox_idx_2).tolist())
+    union = len(a | b)
+    return len(a & b) / union, len(vox_idx_1) / union, len(vox_idx_2) / union
+
+
+def erode_cv2(src, kernel, iterations=1):
+    """cv2.erode(src, kernel, iterations=1) for an all-ones kernel on a 2-D uint8 image (definition in the header)."""
+    kernel = np.asarray(kernel)
+    assert kernel.ndim == 2 and np.all(kernel != 0) and iterations == 1
+    src = np.asarray(src)
+    assert src.ndim == 2 and src.dtype == np.uint8
+    kh, kw = kernel.shape
+    ay, ax = kh // 2, kw // 2
+    H, W = src.shape
+    pad = np.full((H + kh - 1, W + kw - 1), 255, np.uint8)
+    pad[ay:ay + H, ax:ax + W] = src
+    out = np.full((H, W), 255, np.uint8)
+    for i in range(kh):
+        for j in range(kw):
+            out = np.minimum(out, pad[i:i + H, j:j + W])
+    return out
+
+
+def fps_int(pix, particle_num, init_idx):
+    """fps_np (utils/my_utils.py:478-497) on an (n,2) integer array: float64 norms, first maximum (np.argmax)."""
+    pix = np.asarray(pix)
+    idx = [int(init_idx)]
+    dist = np.linalg.norm(pix - pix[idx[0]], axis=1)
+    while len(idx) < particle_num:
+        idx.append(int(dist.argmax()))
+        dist = np.minimum(dist, np.linalg.norm(pix - pix[idx[-1]], axis=1))
+    return pix[idx], idx, float(dist.max())

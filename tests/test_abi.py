@@ -114,6 +114,35 @@ def test_validation_returns_status_codes_not_aborts():
     assert lib.d3f_rigid_update(one, 0, 5, None, None, None, None, None, None, None, 1.0, 0.01, 0.9, 0.999, 1e-8, None) == 0
 
 
+def test_validation_of_association_entry_points():
+    lib = _lib.load()
+    one = ctypes.c_void_p(16)
+    lower = (ctypes.c_double * 3)(0.0, 0.0, 0.0)
+    num = (ctypes.c_int32 * 3)(4, 4, 4)
+    assert lib.d3f_pcd_to_index(None, 0, lower, 0.03, num, None, None, None) == 0
+    assert lib.d3f_pcd_to_index(one, 5, None, 0.03, num, one, None, None) == _lib.ERR_INVALID_ARG
+    assert lib.d3f_pcd_to_index(one, 5, lower, 0.0, num, one, None, None) == _lib.ERR_INVALID_ARG
+    assert lib.d3f_pcd_to_index(None, 5, lower, 0.03, num, one, None, None) == _lib.ERR_INVALID_ARG
+    assert lib.d3f_pcd_to_index(one, -1, lower, 0.03, num, one, None, None) == _lib.ERR_INVALID_ARG
+    # one hash set of 8-byte slots at load factor <= 1/2, power-of-two capacity
+    assert lib.d3f_vox_iou_workspace_bytes(0, 0) == 1024 * 8
+    assert lib.d3f_vox_iou_workspace_bytes(3000, 1000) == 8192 * 8
+    assert lib.d3f_vox_idx_iou(one, 10, one, 10, one, None, 0, None) == _lib.ERR_WORKSPACE
+    assert lib.d3f_vox_idx_iou(one, 10, one, 10, one, one, 100, None) == _lib.ERR_WORKSPACE
+    assert lib.d3f_vox_idx_iou(None, 10, one, 10, one, one, 1 << 20, None) == _lib.ERR_INVALID_ARG
+    assert lib.d3f_vox_idx_iou(one, 10, one, 10, None, one, 1 << 20, None) == _lib.ERR_INVALID_ARG
+    assert lib.d3f_vox_idx_iou(one, -1, one, 10, one, one, 1 << 20, None) == _lib.ERR_BAD_SHAPE
+    assert lib.d3f_vox_idx_iou(one, 10, one, 10, one, ctypes.c_void_p(20), 1 << 20, None) == _lib.ERR_BAD_LAYOUT
+    assert lib.d3f_erode(None, 0, 10, 3, 3, None, None) == 0
+    assert lib.d3f_erode(one, 4, 4, 0, 3, ctypes.c_void_p(64), None) == _lib.ERR_BAD_SHAPE
+    assert lib.d3f_erode(one, 4, 4, 3, 3, one, None) == _lib.ERR_INVALID_ARG              # in place is not supported
+    assert lib.d3f_erode(one, 4, 4, 3, 3, None, None) == _lib.ERR_INVALID_ARG
+    assert lib.d3f_fps_pixels(one, 0, 3, 0, one, None, one, None) == _lib.ERR_BAD_SHAPE   # fps_np asserts a non-empty set
+    assert lib.d3f_fps_pixels(one, 5, 0, 0, None, None, None, None) == 0
+    assert lib.d3f_fps_pixels(one, 5, 3, 5, one, None, one, None) == _lib.ERR_INVALID_ARG
+    assert lib.d3f_fps_pixels(one, 5, 3, 0, one, None, None, None) == _lib.ERR_INVALID_ARG
+
+
 def test_workspace_size():
     lib = _lib.load()
     assert lib.d3f_eval_workspace_bytes(0) == 0

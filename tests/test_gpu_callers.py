@@ -1,0 +1,228 @@
+"""GPU parity of the callers either side of the field query (SURVEY §8f row 4 and the judge-added rows): voxel-index
+IoU of instance association, cv2.erode / pixel FPS / select_features_rand_v2, and the text_queries_* state contract
+driven end to end (update -> text_queries -> select_features -> tracking) with stub producers.  Every expected value
+comes from a golden written by running the reference (oracle/gen_golden.py) or from the CPU oracle."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, rel_err
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    return torch.device("cuda:0")
+
+
+def cpu(x):
+    return x.detach().cpu().numpy()
+
+
+# ---- voxel indices / voxel-set IoU (fusion.py:118-180, 794-799): integers, bit-exact ---------------------------------
+def test_pcd_to_index_matches_reference(dev):
+    from d3fields_amd.fusion import _init_low_level_memory
+    g = load_golden("assoc")
+    fns = _init_low_level_memory(g["lower"], g["higher"], float(g["voxel_size"]), g["voxel_num"])
+    pcd_to_voxel, voxel_to_pcd, voxel_to_index, index_to_voxel, pcd_to_index, index_to_pcd = fns
+    vox, idx = pcd_to_voxel(g["pcd"]), pcd_to_index(g["pcd"])
+    assert vox.dtype == np.int32 and idx.dtype == np.int32
+    assert np.array_equal(vox, g["voxels"]) and np.array_equal(idx, g["index"])
+    assert np.array_equal(pcd_to_index(g["pcd32"]), g["index32"])                     # float32 clouds are promoted
+    assert np.array_equal(pcd_to_index(g["pcd"].reshape(60, 100, 3)), g["index"].reshape(60, 100))   # (..., 3) shapes
+    assert np.array_equal(pcd_to_index(g["pcd"][:7].tolist()), g["index"][:7])        # lists, like the reference
+    assert np.array_equal(voxel_to_index(g["voxels"]), g["index_of_voxels"])
+    assert np.array_equal(index_to_voxel(g["index"][100:200]), g["voxel_of_index"])
+    assert np.array_equal(index_to_pcd(g["index"][100:200]), g["pcd_of_index"])
+    assert pcd_to_index(np.zeros((0, 3))).shape == (0,)
+
+
+def test_pcd_to_index_large_and_wraparound(dev):
+    """2 M points, huge voxel counts (int32 wrap-around of the linearisation) and non-finite / far-away points
+    (numpy's float64 -> int32 cast): equal to the numpy restatement, which the golden test pins."""
+    from d3fields_amd.fusion import _init_low_level_memory
+    from oracle import np_pcd
+    rng = np.random.default_rng(3)
+    pcd = rng.uniform(-50.0, 50.0, size=(2_000_000, 3))
+    pcd[:4] = [[np.nan, 0, 0], [np.inf, 1, 1], [-1e30, 2, 2], [1e12, -3, 3]]
+    lower, vs, num = np.array([-1.0, -2.0, -3.0]), 0.001, np.array([70000, 70000, 70000], np.int32)
+    with np.errstate(invalid="ignore", over="ignore"):
+        want = np_pcd.pcd_to_index(pcd, lower, vs, num)
+    got = _init_low_level_memory(lower, lower + 1, vs, num)[4](pcd)
+    assert np.array_equal(got, want)
+
+
+def test_vox_idx_iou_matches_reference(dev):
+    from d3fields_amd import Fusion
+    f = Fusion(num_cam=1, device=str(dev))
+    g = load_golden("assoc")
+    for k in ("ab", "aa", "disjoint", "one_empty", "small"):
+        got = f.vox_idx_iou(g["iou_%s_a" % k], g["iou_%s_b" % k])
+        assert isinstance(got[0], float) and np.array_equal(np.array(got), g["iou_" + k]), k
+    with pytest.raises(ZeroDivisionError):                                             # like the reference on two empty sets
+        f.vox_idx_iou(np.zeros(0, np.int32), np.zeros(0, np.int32))
+
+
+def test_vox_idx_iou_large_random_keys(dev):
+    """1.5 M + 1 M indices over the whole int32 range (negative keys, heavy duplication, hash collisions)."""
+    from d3fields_amd import pcd_utils
+    from oracle import np_pcd
+    rng = np.random.default_rng(5)
+    a = rng.integers(-2**31, 2**31, size=1_500_000, dtype=np.int64).astype(np.int32)
+    b = np.concatenate([a[::3], rng.integers(-1000, 1000, size=500_000).astype(np.int32)])
+    a[:100000] = a[0]
+    assert pcd_utils.vox_idx_iou(a, b) == np_pcd.vox_idx_iou(a, b)
+
+
+# ---- cv2.erode / fps_np on pixels / select_features_rand_v2 (fusion.py:1539-1606) ------------------------------------
+@pytest.mark.parametrize("shape,k", [((96, 128), (15, 15)), ((480, 640), (15, 15)), ((33, 17), (2, 2)), ((20, 20), (3, 5)),
+                                     ((9, 9), (15, 15)), ((5, 7), (1, 1))])
+def test_erode_matches_oracle(dev, shape, k):
+    from d3fields_amd.fusion import erode
+    from oracle import np_pcd
+    rng = np.random.default_rng(shape[0] * 31 + k[0])
+    img = ((rng.random(shape) < 0.93) * 255).astype(np.uint8)
+    img[: shape[0] // 3] = rng.integers(0, 256, size=(shape[0] // 3, shape[1]), dtype=np.uint8)   # grey values: true minimum
+    kern = np.ones(list(k), np.uint8)
+    assert np.array_equal(erode(img, kern, iterations=1), np_pcd.erode_cv2(img, kern))
+
+
+def test_erode_matches_reference_fixture(dev):
+    from d3fields_amd.fusion import erode
+    g = load_golden("select_v2")
+    m = ((g["in_mask"][0, :, :, 1] > 0) * 255).astype(np.uint8)
+    assert np.array_equal(erode(m, np.ones([15, 15], np.uint8)), g["eroded_v0_i1"])
+
+
+def test_fps_pixels_matches_oracle(dev):
+    from d3fields_amd import pcd_utils
+    from oracle import np_pcd
+    rng = np.random.default_rng(9)
+    mask = rng.random((480, 640)) < 0.3
+    pix = np.array(mask.nonzero()).T                                                    # ~92 k pixels, many equal distances
+    sel, idx, md = pcd_utils.fps_pixels(pix, 40, init_idx=123)
+    wsel, widx, wmd = np_pcd.fps_int(pix, 40, 123)
+    assert idx == widx and np.array_equal(sel, wsel) and md == wmd
+    line = np.stack([np.zeros(11, np.int64), np.arange(11)], 1)                         # exact ties: first maximum wins
+    assert pcd_utils.fps_pixels(line, 3, init_idx=5)[1] == np_pcd.fps_int(line, 3, 5)[1] == [5, 0, 10]
+
+
+def _v2_fusion(dev):
+    from d3fields_amd import Fusion
+    g = load_golden("select_v2")
+    V, H, W = g["depth"].shape
+    f = Fusion(num_cam=V, device=str(dev), mask_producer=lambda fusion, q, t, b, **kw: {
+        "mask": g["in_mask"], "consensus_mask_label": ["background", "mug", "box"]})
+    f.mu = float(g["mu"])
+    f.update({"color": np.zeros((V, H, W, 3), np.uint8), "depth": g["depth"], "pose": g["pose"], "K": g["K"],
+              "dino_feats": g["in_dino_feats"]})
+    f.text_queries_for_inst_mask_no_track(["mug", "box"], [0.3, 0.3], None)
+    return g, f
+
+
+def test_select_features_rand_v2_matches_reference(dev):
+    g, f = _v2_fusion(dev)
+    np.random.seed(int(g["seed"]))
+    feats_l, pts_l, imgs = f.select_features_rand_v2(None, int(g["N"]), per_instance=True)
+    assert len(pts_l) == int(g["n_inst"]) == len(feats_l) and imgs == []
+    for i in range(len(pts_l)):
+        assert pts_l[i].dtype == np.float64 and np.array_equal(pts_l[i], g["pts_%d" % i]), i
+        assert rel_err(cpu(feats_l[i]), g["feats_%d" % i]) <= TOL
+
+
+# ---- text_queries_* state contract (fusion.py:1112-1256) -------------------------------------------------------------
+def test_text_queries_no_track_state_contract(dev):
+    g, f = _v2_fusion(dev)
+    obs = f.curr_obs_torch
+    V, H, W = g["depth"].shape
+    assert obs["consensus_mask_label"] == ["background", "mug", "box"] and f.get_inst_num() == 3
+    assert isinstance(obs["mask_label"], list) and len(obs["mask_label"]) == V and obs["mask_label"][0] == ["background", "mug", "box"]
+    assert all(isinstance(x, str) for x in obs["mask_label"][0])
+    assert obs["semantic_label"] == ["background", "mug", "box"] and len(obs["mask_conf"]) == V
+    assert obs["mask"].shape == (V, H, W, 3) and obs["mask"].dtype == torch.float32 and obs["mask"].is_cuda
+    assert np.array_equal(cpu(obs["mask"]), g["in_mask"])
+    # an instance that is visible in NO view keeps its channel (the one-hot is sized by the label list, fusion.py:1171)
+    lab = g["in_mask"].argmax(-1).astype(np.uint8)
+    f.mask_producer = lambda fusion, q, t, b, **kw: {
+        "mask": lab, "consensus_mask_label": ["background", "mug", "box", "spoon"],
+        "mask_label": [["background", "mug", "mug", "box"]] * V, "mask_conf": [[1.0, 0.9, 0.8, 0.7]] * V}
+    f.text_queries_for_inst_mask_no_track(["mug", "box", "spoon"], [0.3] * 3, None, expected_labels=["background", "mug", "box", "spoon"])
+    assert f.curr_obs_torch["mask"].shape == (V, H, W, 4) and float(f.curr_obs_torch["mask"][..., 3].sum()) == 0.0
+    assert f.curr_obs_torch["semantic_label"] == ["background", "mug", "box"]          # first-occurrence order of view 0
+    assert f.curr_obs_torch["mask_conf"][0] == [1.0, 0.9, 0.8, 0.7]
+    out = f.eval(torch.zeros(5, 3, device=dev), return_names=["mask"])
+    assert out["mask"].shape == (5, 4)
+    # contract violations are reported, not guessed around
+    f.mask_producer = lambda fusion, q, t, b, **kw: lab
+    with pytest.raises(TypeError):
+        f.text_queries_for_inst_mask_no_track(["mug"], [0.3], None)
+    f.mask_producer = lambda fusion, q, t, b, **kw: {"mask": lab, "consensus_mask_label": ["background"]}
+    with pytest.raises(ValueError):
+        f.text_queries_for_inst_mask_no_track(["mug"], [0.3], None)
+
+
+def test_onehot_helpers_accept_cpu_tensors(dev):
+    """The reference's helpers take CPU tensors (fusion.py:90-116); here they are converted on the device and
+    returned on the caller's device."""
+    from d3fields_amd import instance2onehot, onehot2instance
+    g = load_golden("onehot")
+    inst = torch.from_numpy(g["inst"])
+    oh = instance2onehot(inst, int(g["NI"]))
+    assert not oh.is_cuda and oh.dtype == torch.bool and np.array_equal(oh.numpy(), g["onehot"])
+    back = onehot2instance(torch.from_numpy(g["soft"]))
+    assert not back.is_cuda and back.dtype == torch.uint8 and np.array_equal(back.numpy(), g["soft_inst"])
+    assert instance2onehot(inst.to(dev), int(g["NI"])).is_cuda
+
+
+def test_driver_sequence_segment_select_track(dev):
+    """The call sequence of the reference's drivers with stub producers (vis_repr.py:81-103, vis_tracking.py:86-131):
+    update -> text_queries_for_inst_mask_no_track -> select_features_rand, then per frame
+    update -> text_queries_for_inst_mask -> rigid_tracking; keypoints / descriptors / tracked points against the
+    goldens the reference itself produced ('select_features', 'rigid_tracking')."""
+    from d3fields_amd import Fusion
+    gs, gt = load_golden("select_features"), load_golden("rigid_tracking")
+    V, H, W = gs["depth"].shape
+    labels = ["background", "a", "b", "c"]
+    calls = {"producer": 0, "tracker_init": 0, "tracker_step": 0}
+
+    def producer(fusion, queries, thresholds, boundaries, merge_all=False, expected_labels=None, robot_pcd=None):
+        calls["producer"] += 1
+        assert fusion.curr_obs_torch["color"].shape == (V, H, W, 3)
+        return {"mask": torch.from_numpy(gs["in_mask"].argmax(-1).astype(np.uint8)), "consensus_mask_label": labels}
+
+    def tracker(fusion, color, mask):
+        calls["tracker_init" if mask is not None else "tracker_step"] += 1
+        if mask is not None:
+            assert mask.shape == (V, H, W) and mask.dtype == torch.uint8
+        return torch.from_numpy(gs["in_mask"])                                          # (V,H,W,NI) one-hot, like xmem_process
+
+    f = Fusion(num_cam=V, device=str(dev), mask_producer=producer, mask_tracker=tracker)
+    f.mu = float(gs["mu"])
+    box = dict(zip(["x_lower", "x_upper", "y_lower", "y_upper", "z_lower", "z_upper"], gs["bounds"].tolist()))
+    color = np.zeros((V, H, W, 3), np.uint8)
+    with pytest.raises(RuntimeError):
+        f.text_queries_for_inst_mask(labels[1:], [0.3] * 3, box)                       # 'Please call update() first!'
+    f.update({"color": color, "depth": gs["depth"], "pose": gs["pose"], "K": gs["K"], "dino_feats": gs["in_dino_feats"]})
+    f.text_queries_for_inst_mask_no_track(labels[1:], [0.3] * 3, box)
+    feats_l, pts_l, _ = f.select_features_rand(box, int(gs["N"]), per_instance=True, res=float(gs["res"]), init_idx=0)
+    assert len(pts_l) == int(gs["n_inst"])
+    for i in range(len(pts_l)):
+        assert np.array_equal(pts_l[i], gs["sel_pts_%d" % i]) and rel_err(cpu(feats_l[i]), gs["sel_feats_%d" % i]) <= TOL
+    # tracking frames on the scene of the 'rigid_tracking' golden (same cameras and image size)
+    n = int(gt["n"])
+    info = {"a": {"src_feats": gt["src_feats"][:n]}, "b": {"src_feats": gt["src_feats"][n:]}}
+    for frame in range(3):
+        f.update({"color": color, "depth": gt["depth"], "pose": gt["pose"], "K": gt["K"], "dino_feats": gt["in_dino_feats"]})
+        f.text_queries_for_inst_mask(labels[1:], [0.3] * 3, box)
+        assert f.curr_obs_torch["mask"].shape == (V, H, W, 4) and f.xmem_first_mask_loaded and f.track_ids == [0, 1, 2, 3]
+        res = f.rigid_tracking(info, [p for p in gt["last_pts"]], box, n)
+        assert np.abs(np.stack(res["match_pts_list"]) - gt["match_pts"]).max() <= 1e-5, frame
+    assert calls == {"producer": 2, "tracker_init": 1, "tracker_step": 2}
+    with pytest.raises(NotImplementedError):                                            # fusion.py:1240-1241
+        f.text_queries_for_inst_mask(labels[1:], [0.3] * 3, box, use_sam=True)
+    f.clear_xmem_memory()
+    f.text_queries_for_inst_mask(labels[1:], [0.3] * 3, box)
+    assert calls["producer"] == 3 and calls["tracker_init"] == 2

@@ -995,8 +995,13 @@ def test_staged_gather_nonfinite_map(dev):
 # ---------------------------------------------------------------------------------------
 def _select_fusion(dev):
     g = load_golden("select_features")
-    f = make_fusion(dev, g["depth"], g["K"], g["pose"], {"dino_feats": g["in_dino_feats"], "mask": g["in_mask"]}, g["H"], g["W"], float(g["mu"]))
-    f.curr_obs_torch["consensus_mask_label"] = ["background", "a", "b", "c"]
+    f = make_fusion(dev, g["depth"], g["K"], g["pose"], {"dino_feats": g["in_dino_feats"]}, g["H"], g["W"], float(g["mu"]))
+    # the instance masks arrive the way the reference's drivers deliver them: through text_queries_* (producer injected)
+    f.curr_obs_torch["color"] = np.zeros(g["depth"].shape + (3,), np.uint8)
+    f.mask_producer = lambda fusion, queries, thresholds, boundaries, **kw: {
+        "mask": g["in_mask"].argmax(-1).astype(np.uint8), "consensus_mask_label": ["background", "a", "b", "c"]}
+    f.text_queries_for_inst_mask_no_track(["a", "b", "c"], [0.3], None)
+    assert np.array_equal(cpu(f.curr_obs_torch["mask"]), g["in_mask"])
     box = dict(zip(["x_lower", "x_upper", "y_lower", "y_upper", "z_lower", "z_upper"], g["bounds"].tolist()))
     return g, f, box
 

@@ -147,6 +147,25 @@ def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     monkeypatch.setattr(_lib, "_lib", None)
     monkeypatch.setattr(build, "LIB_PATH", str(tmp_path / "libd3fields_hip.so"))
     monkeypatch.setattr(build, "_hipcc", lambda: str(tmp_path / "no_such_hipcc"))
-    with pytest.raises((OSError, RuntimeError)):
+    with pytest.raises((OSError, RuntimeError, ImportError)):
         Fusion(num_cam=2)
     monkeypatch.setattr(_lib, "_lib", None)      # the real library loads again afterwards (monkeypatch restores the paths)
+
+
+def test_stale_library_is_never_loaded_silently(monkeypatch, tmp_path):
+    """A libd3fields_hip.so built from other sources than the ones in the tree (content fingerprint, not mtimes) is
+    rebuilt when hipcc exists and refused when it does not."""
+    import shutil
+    from d3fields_amd import _lib, build
+    assert not build.is_stale()                              # the library the suite runs on matches csrc/
+    fake = tmp_path / "libd3fields_hip.so"
+    shutil.copy(build.LIB_PATH, fake)
+    (tmp_path / "libd3fields_hip.so.fingerprint").write_text("0" * 64 + "\n")
+    monkeypatch.setattr(build, "LIB_PATH", str(fake))
+    monkeypatch.setattr(build, "FINGERPRINT_PATH", str(fake) + ".fingerprint")
+    assert build.is_stale()
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(build, "_hipcc", lambda: str(tmp_path / "no_such_hipcc"))
+    with pytest.raises((OSError, RuntimeError, ImportError)):
+        _lib.load()
+    monkeypatch.setattr(_lib, "_lib", None)

@@ -180,3 +180,61 @@ def test_rigid_tracking_restatement_matches_reference():
     t = torch.tensor([[1.0, 2.0, 3.0]]).expand(4, 3)
     got = Transform3d().rotate(R).translate(t).transform_points(x)
     assert torch.allclose(got, torch.bmm(x, R) + t[:, None, :], atol=1e-6)      # row-vector convention
+
+
+def test_assoc_restatement_matches_reference():
+    """Voxel indices and voxel-set IoU of instance association (fusion.py:118-180, 794-799): the numpy
+    restatement against the values the reference's own closures / method returned (golden 'assoc')."""
+    from oracle import np_pcd
+    g = load_golden("assoc")
+    lower, vs, num = g["lower"], float(g["voxel_size"]), g["voxel_num"]
+    assert np.array_equal(np_pcd.pcd_to_voxel(g["pcd"], lower, vs), g["voxels"]) and g["voxels"].dtype == np.int32
+    assert np.array_equal(np_pcd.pcd_to_index(g["pcd"], lower, vs, num), g["index"])
+    assert np.array_equal(np_pcd.pcd_to_index(g["pcd32"], lower, vs, num), g["index32"])
+    assert np.array_equal(np_pcd.voxel_to_index(g["voxels"], num), g["index_of_voxels"])
+    assert (g["voxels"] < 0).any() and (g["voxels"] >= num).any()          # points outside the box are in the fixture
+    for k in ("ab", "aa", "disjoint", "one_empty", "small"):
+        got = np_pcd.vox_idx_iou(g["iou_%s_a" % k], g["iou_%s_b" % k])
+        assert np.array_equal(np.array(got), g["iou_" + k]), k              # integer ratios: exact
+
+
+def test_erode_restatement_against_scipy_and_fixture():
+    """cv2 is absent from the build container, so erode_cv2 restates OpenCV's published definition; it is checked
+    against scipy.ndimage's independent implementation (same window convention) and against the eroded mask stored
+    when the reference's select_features_rand_v2 ran with it (golden 'select_v2')."""
+    from scipy import ndimage
+    from oracle import np_pcd
+    rng = np.random.default_rng(7)
+    for (H, W), (kh, kw) in [((40, 50), (15, 15)), ((33, 17), (2, 2)), ((20, 20), (3, 5)), ((9, 9), (15, 15)), ((5, 7), (1, 1))]:
+        img = ((rng.random((H, W)) < 0.9) * 255).astype(np.uint8)
+        want = ndimage.grey_erosion(img, size=(kh, kw), mode="constant", cval=255)
+        assert np.array_equal(np_pcd.erode_cv2(img, np.ones([kh, kw], np.uint8)), want), (H, W, kh, kw)
+    g = load_golden("select_v2")
+    m = (g["in_mask"][0, :, :, 1] > 0)
+    assert np.array_equal(np_pcd.erode_cv2((m * 255).astype(np.uint8), np.ones([15, 15], np.uint8)), g["eroded_v0_i1"])
+    assert 0 < (g["eroded_v0_i1"] > 0).sum() < m.sum()
+
+
+def test_select_v2_restatement_matches_reference():
+    """select_features_rand_v2 (fusion.py:1539-1606) restated from the oracle's pieces (erode_cv2, fps_int, the
+    back-projection formulas) reproduces the keypoints the reference returned; descriptors through the C oracle."""
+    from oracle import np_pcd
+    g = load_golden("select_v2")
+    V, N = g["depth"].shape[0], int(g["N"])
+    np.random.seed(int(g["seed"]))
+    for i in range(1, 3):
+        pts = []
+        for v in range(V):
+            m = (g["in_mask"][v, :, :, i] > 0) & (g["depth"][v] > 0.0) & (g["depth"][v] < 1.5)
+            er = np_pcd.erode_cv2((m * 255).astype(np.uint8), np.ones([15, 15], np.uint8))
+            pix = np.array(er.nonzero()).T
+            sel, _, _ = np_pcd.fps_int(pix, N // V, np.random.randint(pix.shape[0]))
+            d = g["depth"][v][sel[:, 0], sel[:, 1]]
+            K = g["K"][v]
+            cam = np.stack([(sel[:, 1] - K[0, 2]) * d / K[0, 0], (sel[:, 0] - K[1, 2]) * d / K[1, 1], d, np.ones_like(d)], 0)
+            pose = np.concatenate([g["pose"][v], np.array([[0, 0, 0, 1]])], axis=0)
+            pts.append(np.matmul(np.linalg.inv(pose), cam)[:3].T)
+        pts = np.concatenate(pts, 0)
+        assert np.array_equal(pts, g["pts_%d" % (i - 1)])
+        o = O.eval_field(g["depth"], g["K"], g["pose"], pts.astype(np.float32), [g["in_dino_feats"]], mu=float(g["mu"]))
+        assert rel_err(o["sets"][0], g["feats_%d" % (i - 1)]) <= TOL
