@@ -120,6 +120,26 @@ def time_steps(fn, steps, dist_on, dev, drain=None):
     return dt
 
 
+def verify_against_oracle(f, pts, names, w, sc, out, sample=2000):
+    """After the timed region: a `sample`-point sample of the output of the timed launch configuration against the CPU
+    oracle (oracle/d3f_oracle.c): valid_mask and dist bit-exact, fused channels <= 1e-5 relative (tests/ tolerance)."""
+    import numpy as np
+    from oracle import c_oracle
+    n = pts.shape[0]
+    pick = torch.randperm(n, generator=torch.Generator().manual_seed(17))[:sample].to(pts.device)
+    ref = c_oracle.eval_field(sc["depth"], sc["K"], sc["pose"], pts[pick].cpu(), [f.curr_obs_torch[k].float().cpu() for k in names],
+                              mu=f.mu)
+    ok = bool(np.array_equal(out["valid_mask"][pick].cpu().numpy(), ref["valid_mask"]))
+    ok = ok and bool(np.array_equal(out["dist"][pick].cpu().numpy(), ref["dist"]))
+    worst = 0.0
+    for i, k in enumerate(names):
+        r = ref["sets"][i]
+        err = float(np.abs(out[k][pick].cpu().numpy().astype(np.float64) - r).max() / max(float(np.abs(r).max()), 1.0))
+        worst = max(worst, err)
+    return ok and worst <= 1e-5, {"sample_points": int(pick.numel()), "max_rel_err_fused": worst,
+                                  "dist_and_valid_mask_bit_exact": ok, "tolerance": 1e-5}
+
+
 def kernel_time_ms(fn, steps, dev):
     """Average device time of one step measured with HIP events recorded on the stream the
     kernel is launched on (torch's current stream: the shim passes exactly that stream)."""
@@ -207,6 +227,7 @@ def main():
     ap.add_argument("--no-overlap", action="store_true", help="N>1: block on every all-gather instead of overlapping it "
                     "with the next batch's query")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-verify", action="store_true", help="skip the post-run oracle check of a 2000-point sample")
     ap.add_argument("--tuning", type=lambda x: int(x, 0), default=0, help="D3F_TUNE_* bits (experiments)")
     ap.add_argument("--cpu-sample", type=int, default=1000000)
     ap.add_argument("--cpu-threads", type=int, default=0, help="0 = min(host cores, 64)")
@@ -237,8 +258,9 @@ def main():
 
     f, pts, names, w, sc = build_workload(args.workload, dev, rank, world, args.points)
     f.tuning_flags = args.tuning
-    # the shim can keep the Morton order of an unchanged query tensor between calls; every timed step here re-sorts
-    # (the steps would otherwise share one sort) -- the cached figure is reported separately below
+    # The shim can keep what it learned about an unchanged query tensor between calls (its lattice dims, or its Morton
+    # order): every timed step here starts from scratch instead -- the lattice probe (one tiny kernel + one host sync)
+    # or the Morton sort is INSIDE every step -- and the cached figure is reported separately below.
     f.cache_point_order = False
     n = pts.shape[0]
     from d3fields_amd import sharding
@@ -258,24 +280,28 @@ def main():
                 out["similarity"], out["match"] = corr_utils.nearest_descriptor(out["dino_feats"], corr_src, 1.0)
         return out
 
-    # N>1: the all-gather of batch k runs on RCCL's stream while batch k+1 is queried (one gather in flight);
-    # `drain` waits for the last one inside the timed region.  --no-overlap blocks on every gather instead.
-    pending, hold, overlap_error = [], [], []
+    # N>1: the all-gathers of batches k-1 and k run on RCCL's stream while batch k+1 is queried (two gathers in
+    # flight); `drain` waits for what is left inside the timed region.  --no-overlap blocks on every gather instead.
+    from collections import deque
+    pending, overlap_error = deque(), []
+    gather_keys = {}
 
-    def drain():
-        for wk in pending:
-            wk.wait()
-        pending.clear()
-        hold.clear()
+    def drain(keep=0):
+        while len(pending) > keep:
+            works, _hold = pending.popleft()
+            for wk in works:
+                wk.wait()
 
     def step():
         out = compute()
         if dist_on and args.gather != "none":
             keys = ("dist", "valid_mask") if args.gather == "dist" else tuple(k for k in out if k != "match")
+            gather_keys["keys"] = keys
+            gather_keys["bytes"] = sharding.gather_bytes(out, keys, [n] * world)
             if args.no_overlap:
                 sharding.all_gather_field({k: out[k] for k in keys}, keys=keys, counts=[n] * world)
             else:
-                drain()                                    # gather k-1 must be done before gather k is enqueued
+                drain(keep=1)                              # gather k-2 must be done before gather k is enqueued
                 try:
                     full, works = sharding.all_gather_field({k: out[k] for k in keys}, keys=keys, counts=[n] * world,
                                                             async_op=True)
@@ -284,8 +310,7 @@ def main():
                     overlap_error.append(repr(exc))
                     sharding.all_gather_field({k: out[k] for k in keys}, keys=keys, counts=[n] * world)
                     return out
-                pending.extend(works)
-                hold.extend((out, full))                   # inputs and outputs stay alive until the wait
+                pending.append((works, (out, full)))       # inputs and outputs stay alive until the wait
         return out
 
     with torch.no_grad():
@@ -300,6 +325,8 @@ def main():
             f.cache_point_order = True          # a static grid queried every frame: the order is built once
             compute(); compute()
             extra["points_per_s_with_cached_point_order"] = n * args.steps / time_steps(compute, args.steps, False, dev)
+            extra["cached_point_order_note"] = ("the shim's default: lattice dims / Morton order of an UNCHANGED query tensor are kept "
+                                                "between calls; `value` re-derives them inside every step")
             f.cache_point_order = False
         if dist_on:
             extra["compute_only_points_per_s"] = world * n * args.steps / time_steps(compute, args.steps, True, dev)
@@ -310,6 +337,14 @@ def main():
                 full()
                 fs = max(2, args.steps // 4)
                 extra["full_field_gather_points_per_s"] = world * n * fs / time_steps(full, fs, True, dev)
+
+        verified, verify_info = None, None
+        if rank == 0 and not w.get("f16") and not args.no_verify:
+            verified, verify_info = verify_against_oracle(f, pts, names, w, sc, compute())
+        f.record_plans = True
+        compute()
+        plan = f.last_plan()
+        f.record_plans = False
 
     total_pts = world * n * args.steps
     value = total_pts / wall
@@ -333,20 +368,30 @@ def main():
                    "parallelism": "points sharded x%d, maps replicated" % world,
                    "gather": (args.gather if dist_on else "n/a"),
                    "gather_overlap": ((not args.no_overlap) if dist_on else "n/a"),
-                   "gather_overlap_error": (overlap_error[0] if overlap_error else None)},
+                   "gather_overlap_error": (overlap_error[0] if overlap_error else None),
+                   # bytes every rank RECEIVES per step for the gathered keys, and the time they need at one xGMI link
+                   # per peer (153 GB/s each, direct peer exchange: every peer's shard travels on its own link)
+                   "gather_keys": (list(gather_keys.get("keys", ())) if dist_on else "n/a"),
+                   "gather_bytes_received_per_rank": (gather_keys.get("bytes") if dist_on else "n/a"),
+                   "gather_xgmi_floor_ms": ((gather_keys.get("bytes", 0) / max(world - 1, 1)) / 153e9 * 1e3 if dist_on else "n/a")},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                     "kernel": ("fused_eval_f16_kernel<0>" if w.get("f16") else
-                                "fused_eval_wide_kernel<0>" if w["C"] > 768 else "fused_eval_kernel<0>"),
+                     "traffic_measured_in_run": False,      # a copy of the committed rocprofv3 PMC passes, not of this run
+                     "kernel": (plan or {}).get("kernel", "fused_eval_kernel<0>"),
                      "kernel_ms_avg": k_avg, "kernel_ms_median": k_med,
                      "kernel_ms_min": k_min, "algorithmic_bytes_per_launch": bytes_alg,
                      "algorithmic_bytes_per_point": per_pt, "kernel_points_per_s": n / (k_avg * 1e-3),
                      "step_device_ms_avg": s_avg, "logical_gather_bytes_per_point": b_gather,
                      "logical_gather_GBps": n * b_gather / (k_avg * 1e-3) / 1e9,
                      "traffic_GBps": (traffic / (k_avg * 1e-3) / 1e9) if traffic else None, "note": "achieved = algorithmic bytes / kernel_ms_avg (HIP events around the "
-                     "fused kernel on its launch stream); step_device_ms_avg also covers the Morton point-ordering kernels"},
+                     "fused kernel on its launch stream); step_device_ms_avg also covers the per-step lattice probe / Morton ordering kernels"},
     }
     res.update(extra)
+    res["verified"] = verified
+    res["verify"] = verify_info
+    if plan:
+        res["config"]["point_order"] = plan["point_order"]
+        res["config"]["tile_points"] = plan["tile_points"]
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         maps_cpu = {k: f.curr_obs_torch[k].float().cpu() for k in names}
         res["cpu_baseline"] = cpu_baseline(sc, w, names, maps_cpu, pts.cpu(), args.cpu_sample, args.cpu_threads)

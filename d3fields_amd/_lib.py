@@ -68,6 +68,11 @@ SIGNATURES = {
                                            ctypes.POINTER(EvalPlan)]),
     "d3f_eval_grid": (ctypes.c_int, [ctypes.POINTER(Views), ctypes.POINTER(Grid), ctypes.POINTER(ChannelMap), _i32, _f32, _u32,
                                      _vp, _vp, ctypes.POINTER(_vp), _vp]),
+    "d3f_eval_lattice": (ctypes.c_int, [ctypes.POINTER(Views), _vp, _i32, _i32, _i32, ctypes.POINTER(ChannelMap), _i32, _f32, _u32,
+                                        _vp, _vp, ctypes.POINTER(_vp), ctypes.POINTER(_vp), _vp]),
+    "d3f_eval_plan_query_lattice": (ctypes.c_int, [ctypes.POINTER(Views), _i32, _i32, _i32, ctypes.POINTER(ChannelMap), _i32, _u32, _i32,
+                                                   ctypes.POINTER(EvalPlan)]),
+    "d3f_lattice_probe": (ctypes.c_int, [_vp, _i64, _vp, _vp]),
     "d3f_grid_shell_workspace_bytes": (_i64, [ctypes.POINTER(Grid)]),
     "d3f_grid_shell": (ctypes.c_int, [ctypes.POINTER(Views), ctypes.POINTER(Grid), _f32, _f32, _i64, _vp, _vp, _vp, _i64, _vp]),
     "d3f_farthest_point_sampling": (ctypes.c_int, [_vp, _i64, _i32, _i64, _vp, _vp, _vp, _vp]),

@@ -4,6 +4,7 @@
 // error text.
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 
 #include "d3f_internal.h"
 
@@ -42,7 +43,7 @@ int check_views(const d3f_views *v)
 // (longer contiguous segments per load instruction).
 // batch: issue all 4*U corner loads before the first use (best for cache-resident maps, U <= 3);
 // otherwise load-use per vector, U <= 4 (best when the map misses the caches).
-void pick_mapping(d3f::MapDesc &m, bool can16, bool can8, bool batch)
+void pick_mapping(d3f::MapDesc &m, bool can16, bool can8, bool batch, int max_u = 4)
 {
     m.vw = (m.C % 4 == 0 && can16) ? 4 : ((m.C % 2 == 0 && can8) ? 2 : 1);
     const int cvec = m.C / m.vw;
@@ -50,7 +51,7 @@ void pick_mapping(d3f::MapDesc &m, bool can16, bool can8, bool batch)
     int best_passes = 0;
     for (int lg = 6; lg >= 0; --lg) {
         const int lpp = 1 << lg;
-        for (int u = batch ? 3 : 4; u >= 1; --u) {
+        for (int u = (batch ? 3 : 4) < max_u ? (batch ? 3 : 4) : max_u; u >= 1; --u) {
             const int per = lpp * u;
             const int passes = (cvec + per - 1) / per;
             const long slots = (long)passes * per;
@@ -84,6 +85,7 @@ int fill_map(const d3f_channel_map &c, int s, int V, float *out, float *inter, c
     m.out = out;
     m.inter = inter;
     m.staged = 0;
+    m.runs = 0;
     m.pre_slot = -1;
     m.esize = es;
     m.sv = c.stride_v; m.sy = c.stride_y; m.sx = c.stride_x;
@@ -142,6 +144,35 @@ void pick_staged_mapping(d3f::MapDesc &m)
     m.staged = 2;
 }
 
+// Experiment knobs read from the environment (integers; results never depend on them):
+//   D3F_EXP_RUNS   cell-run gather on patch-resolution wide maps: -1 off, 0 automatic (default), 4 / 8 / 16 = run length
+//   D3F_EXP_WALK   lattice brick walk for grids on large maps: -1 off, 0 automatic (default)
+int exp_knob(const char *name)
+{
+    const char *v = getenv(name);
+    return v ? atoi(v) : 0;
+}
+
+// Cell-run gather (fuse_eval.hip gather_map_runs): fp32 maps read as 16-byte vectors with >= 32 vectors per texel whose
+// texels span >= 4 image pixels -- the patch-resolution feature maps of the reference (fusion.py:694-697).
+bool runs_candidate(const d3f::MapDesc &m, int H, int W)
+{
+    return m.esize == 4 && m.vw == 4 && m.C >= 128 && (W - 1) >= 4 * (m.fw - 1) && (H - 1) >= 4 * (m.fh - 1);
+}
+
+void pick_runs_mapping(d3f::MapDesc &m, int K)
+{
+    const int cvec = m.C / 4;
+    long best_slots = -1;
+    for (int lg = 6; lg >= 5; --lg) {           // one 16-byte vector per lane: 64 or 32 lanes per point
+        const int lpp = 1 << lg;
+        const long slots = (long)((cvec + lpp - 1) / lpp) * lpp;
+        if (best_slots < 0 || slots < best_slots) { best_slots = slots; m.lpp_log2 = lg; }
+    }
+    m.unroll = 1;
+    m.runs = K;
+}
+
 int tile_points_for(int V)
 {
     // LDS per workgroup = tile*V*24 B (+ small); keep it <= 32 KiB so >= 4 workgroups fit a CU.
@@ -154,7 +185,7 @@ int tile_points_for(int V)
 int eval_common(const d3f_views *views, const float *pts, int64_t n, const d3f_channel_map *maps, int32_t n_maps,
                 float mu, uint32_t flags, float *out_dist, uint8_t *out_valid, float *const *out_fused,
                 float *const *out_inter, void *workspace, int64_t workspace_bytes, void *stream, int mode,
-                d3f_eval_plan *plan_out = nullptr, const d3f_grid *grid = nullptr)
+                d3f_eval_plan *plan_out = nullptr, const d3f_grid *grid = nullptr, const int32_t *lattice = nullptr)
 {
     const bool plan_only = plan_out != nullptr;
     int rc = check_views(views);
@@ -171,6 +202,8 @@ int eval_common(const d3f_views *views, const float *pts, int64_t n, const d3f_c
     P.order = nullptr; P.lds_pad = 0; P.stage_floats = 0;
     P.grid_x = grid ? grid->x : nullptr; P.grid_y = grid ? grid->y : nullptr; P.grid_z = grid ? grid->z : nullptr;
     P.grid_ny = grid ? grid->ny : 0; P.grid_nz = grid ? grid->nz : 0;
+    P.walk_nx = P.walk_ny = P.walk_nz = 0; P.walk_tx = P.walk_ty = P.walk_tz = 1;
+    P.runs_occ = exp_knob("D3F_EXP_RUNS_OCC");
     int64_t map_bytes = 0;
     P.out_dist = out_dist; P.out_valid = out_valid;
     P.n = n; P.V = views->V; P.H = views->H; P.W = views->W;
@@ -192,41 +225,74 @@ int eval_common(const d3f_views *views, const float *pts, int64_t n, const d3f_c
     bool stage_any = false;
     if ((flags & D3F_TUNE_STAGING) && views->V * 24 * 32 <= 24 * 1024)
         for (int s = 0; s < n_maps; ++s) stage_any |= staging_candidate(P.maps[s], views->H, views->W);
-    const bool reorder = may_reorder && ((flags & D3F_TUNE_FORCE_REORDER) || (n >= 65536 && (map_bytes > (64LL << 20) || stage_any || (flags & D3F_FLAG_UNORDERED_POINTS))));
-    if (reorder && !plan_only && (flags & D3F_FLAG_REUSE_POINT_ORDER)) {
+    // Cell-run gather for patch-resolution wide maps (at most two per launch: one corner-record slot each): consecutive
+    // points of the processing order (a grid column in caller order, the Morton walk of a cloud) mostly stay inside one
+    // texel cell of a view, so a lane group keeps the four corner vectors in registers across a run of points
+    // (fuse_eval.hip).  Needs the exact invalid-view skip (finite maps), no '<k>_inter' output and fp32 maps only.
+    bool any_runs = false;
+    {
+        const int knob = exp_knob("D3F_EXP_RUNS");
+        bool blocked = knob < 0 || !(flags & D3F_FLAG_FINITE_MAPS) || stage_any || n < 65536 || tl != 0;
+        for (int s = 0; s < n_maps; ++s)
+            blocked |= P.maps[s].esize == 2 || (out_inter && out_inter[s]) ||
+                       (P.maps[s].unroll == -4 && !runs_candidate(P.maps[s], views->H, views->W));
+        int taken = 0;
+        for (int s = 0; s < n_maps && !blocked && taken < 2; ++s)
+            if (runs_candidate(P.maps[s], views->H, views->W)) {
+                pick_runs_mapping(P.maps[s], knob == 4 ? 4 : 8);
+                any_runs = true;
+                ++taken;
+            }
+        if (any_runs)       // the cell-run kernel is built for <= 2 vectors per lane on its other maps (register budget)
+            for (int s = 0; s < n_maps; ++s)
+                if (P.maps[s].runs == 0 && (P.maps[s].unroll > 2 || P.maps[s].unroll < -2))
+                    pick_mapping(P.maps[s], P.maps[s].vw == 4, P.maps[s].vw >= 2, P.maps[s].unroll > 0, 2);
+    }
+    // Points on a regular lattice (a d3f_grid, or d3f_eval_lattice's dims): the brick walk is closed form -- no keys, no
+    // sort, no index array, no scratch -- and replaces the Morton sort wherever that would be used.  (With the cell-run
+    // gather the caller's z-fastest order is the one wanted: a grid column is one long run.)
+    const bool walk = lattice && n_maps > 0 && n >= 65536 && n <= 0x7fffffffLL && !(flags & D3F_TUNE_NO_REORDER) &&
+                      exp_knob("D3F_EXP_WALK") >= 0 && !stage_any && !any_runs &&
+                      ((flags & D3F_TUNE_FORCE_REORDER) || map_bytes > (64LL << 20));
+    const bool reorder = walk || (may_reorder && ((flags & D3F_TUNE_FORCE_REORDER) || (n >= 65536 && (map_bytes > (64LL << 20) || stage_any || (flags & D3F_FLAG_UNORDERED_POINTS)))));
+    if (walk) {
+        P.walk_nx = lattice[0]; P.walk_ny = lattice[1]; P.walk_nz = lattice[2];
+    } else if (reorder && !plan_only && (flags & D3F_FLAG_REUSE_POINT_ORDER)) {
         P.order = d3f::stored_point_order(workspace, n);       // written by an earlier call for the same points
     } else if (reorder && !plan_only) {
         hipError_t eo = d3f::build_point_order(pts, n, workspace, workspace_bytes, &P.order, hs, (int)((flags >> 24) & 0x3));
         if (eo != hipSuccess) return hip_fail(eo, "point ordering");
     }
     // Launch geometry (measured on MI355X):
-    //  * Morton walk: 8-point tiles (one point per lane group; 16 when a thin map such as the mask is also
+    //  * Morton / lattice walk: 8-point tiles (one point per lane group; 16 when a thin map such as the mask is also
     //    requested), XCD k takes the k-th contiguous eighth of the walk, so the ~1 k points in flight on an
     //    XCD form one compact blob whose texels stay in that XCD's 4 MiB L2
     //    (C2 dense 2.84 -> 2.12 ms, C4 patch 13.0 -> 4.8 ms; 32-point tiles: 2.48 / 5.3 ms);
     //  * caller order: 128-point tiles, round-robin XCDs (0.80 ms on C2 patch); for maps far beyond the
-    //    256 MiB Infinity Cache 64-point tiles at 2 workgroups per CU (3.2 -> 2.96 ms on C2 dense).
+    //    256 MiB Infinity Cache 64-point tiles at 2 workgroups per CU (3.2 -> 2.96 ms on C2 dense);
+    //  * cell-run gather: 8 runs per workgroup (64 points with 32 lanes per point), either order.
     bool xcd_remap = false;
     if (reorder) {
-        // on the Morton walk the in-flight footprint is tiny, so batched corner loads win again wherever one pass
+        // on the walk the in-flight footprint is tiny, so batched corner loads win again wherever one pass
         // of <= 3 vectors per lane covers the channels (C2 dense 2.07 -> 1.99 ms); C = 1024 keeps load-use x 4
         for (int s = 0; s < n_maps; ++s) {
             d3f::MapDesc &m = P.maps[s];
             const bool forced = (flags & ((1u << 26) | (1u << 27))) != 0;
             if (!forced && m.unroll < 0 && (m.C / m.vw) <= 3 * 64) {
                 const bool a16 = m.vw == 4, a8 = m.vw >= 2;
-                pick_mapping(m, a16, a8, true);
+                pick_mapping(m, a16, a8, true, any_runs ? 2 : 4);
             }
         }
         // one point per lane group: 8 points when every map takes 32 lanes per point, else 16
         bool thin = false;
         for (int s = 0; s < n_maps; ++s) thin |= P.maps[s].lpp_log2 < 5;      // < 32 lanes per point: 16 groups have work
         P.tile_pts = thin ? 16 : 8; P.lds_pad = 0; xcd_remap = true;
+        if (walk) { P.walk_tx = 2; P.walk_ty = 2; P.walk_tz = thin ? 4 : 2; }     // the tile is a brick of the lattice
         // maps that fit the L2s / Infinity Cache anyway (patch-resolution features, the mask): the walk is only there
         // to give a random cloud L1 locality and the big tiles of the caller-order path stay best
         // (C2 patch, random cloud: caller order 1.93 ms, walk with 8-point tiles 1.07, with 128-point tiles 0.76)
-        if (map_bytes <= (64LL << 20) && !stage_any) P.tile_pts = tile_points_for(views->V);
-    } else if (map_bytes > (512LL << 20) && P.tile_pts > 64 && n >= 65536) {
+        if (map_bytes <= (64LL << 20) && !stage_any && !walk) P.tile_pts = tile_points_for(views->V);
+    } else if (map_bytes > (512LL << 20) && P.tile_pts > 64 && n >= 65536 && !any_runs) {
         P.tile_pts = 64; P.lds_pad = 64 * 1024;
     }
     // small batches (keypoints, tracking): a 128-point tile is 16-32 serial rounds per lane group, so a few hundred
@@ -244,26 +310,40 @@ int eval_common(const d3f_views *views, const float *pts, int64_t n, const d3f_c
         P.tile_pts = 32; P.lds_pad = 0;
         P.stage_floats = d3f::kStageFloats;     // 4 wave-private regions of 13.5 KiB (9 texels of 384 channels)
     }
-    // Morton walk: all eight XCDs stay inside one macro-brick of ~32 k points at a time (its texel footprint stays in
+    if (any_runs) {
+        int k = 8, lg = 6;
+        for (int s = 0; s < n_maps; ++s)
+            if (P.maps[s].runs > 0) { k = P.maps[s].runs; lg = P.maps[s].lpp_log2 < lg ? P.maps[s].lpp_log2 : lg; }
+        P.tile_pts = (d3f::kBlock >> lg) * k;         // every lane group of the mapping with the most groups owns one run
+        while ((long)P.tile_pts * views->V * 88 > 40 * 1024 && P.tile_pts > 16) P.tile_pts >>= 1;   // records + 2 corner slots
+        P.lds_pad = 0;
+    }
+    // walks: all eight XCDs stay inside one macro-brick of ~32 k points at a time (its texel footprint stays in
     // the 256 MiB Infinity Cache), each taking a contiguous eighth of it (C2 dense 1.97 -> 1.74 ms, C4 patch 4.75 -> 4.17)
-    P.xcd_chunk = reorder ? (int)((32768 / P.tile_pts + 7) / 8 * 8) : 0;
+    P.xcd_chunk = (reorder && xcd_remap) ? (int)((32768 / P.tile_pts + 7) / 8 * 8) : 0;
     if ((flags >> 29) & 0x7) P.xcd_chunk = 1024 << (((flags >> 29) & 0x7) - 1);   // tuning: 1024 .. 65536 tiles
     P.stage_offset = d3f::fused_lds_base(P.tile_pts, views->V);
-    // wide maps (>= 16 lanes per point): corner set-up once per (point, view) in phase A, 32 B of LDS each
+    // wide maps (>= 16 lanes per point): corner set-up once per (point, view) in phase A, 32 B of LDS each; the
+    // cell-run maps come first -- they read their corners from these records
     P.n_pre = 0;
+    for (int s = 0; s < n_maps; ++s)
+        if (P.maps[s].runs > 0) P.maps[s].pre_slot = P.n_pre++;
     if (!(flags & (1u << 28)))
         for (int s = 0; s < n_maps && P.n_pre < 2; ++s) {
             // 32 B per (point, view) and map: only while records + set-ups stay within 48 KiB (>= 3 workgroups per CU)
             const long lds_after = (long)P.stage_offset + P.stage_floats * 8 + (long)(P.n_pre + 1) * P.tile_pts * views->V * 32;
-            if (!P.maps[s].staged && P.maps[s].lpp_log2 >= 4 && !(out_inter && out_inter[s]) && lds_after <= 48 * 1024)
+            if (P.maps[s].pre_slot < 0 && !P.maps[s].staged && P.maps[s].lpp_log2 >= 4 && !(out_inter && out_inter[s]) && lds_after <= 48 * 1024)
                 P.maps[s].pre_slot = P.n_pre++;
         }
     P.crec_offset = P.stage_offset + P.stage_floats * 8;
-    const int64_t ntiles = (n + P.tile_pts - 1) / P.tile_pts;
+    int64_t ntiles = (n + P.tile_pts - 1) / P.tile_pts;
+    if (walk)
+        ntiles = (int64_t)((P.walk_nx + P.walk_tx - 1) / P.walk_tx) * ((P.walk_ny + P.walk_ty - 1) / P.walk_ty) *
+                 ((P.walk_nz + P.walk_tz - 1) / P.walk_tz);
     if (ntiles > 0x7fffffffLL) return fail(D3F_ERR_BAD_SHAPE, "n=%lld needs more than 2^31 workgroups", (long long)n);
     if (plan_only) {
         plan_out->tile_points = P.tile_pts;
-        plan_out->reorder = reorder ? 1 : 0;
+        plan_out->reorder = walk ? 2 : (reorder ? 1 : 0);
         plan_out->lds_bytes = P.crec_offset + P.n_pre * P.tile_pts * P.V * 32 + P.lds_pad;
         plan_out->workgroups = ntiles;
         for (int s = 0; s < D3F_MAX_MAPS; ++s) {
@@ -271,7 +351,7 @@ int eval_common(const d3f_views *views, const float *pts, int64_t n, const d3f_c
             plan_out->vector_floats[s] = on ? P.maps[s].vw : 0;
             plan_out->lanes_per_point[s] = on ? (1 << P.maps[s].lpp_log2) : 0;
             plan_out->vectors_per_lane[s] = on ? P.maps[s].unroll : 0;   /* negative: load-use per vector */
-            plan_out->staged[s] = on ? P.maps[s].staged : 0;
+            plan_out->staged[s] = on ? (P.maps[s].runs > 0 ? 16 + P.maps[s].runs : P.maps[s].staged) : 0;
         }
         return D3F_OK;
     }
@@ -316,6 +396,18 @@ int d3f_eval_plan_query(const d3f_views *views, int64_t n, const d3f_channel_map
     for (int s = 0; s < D3F_MAX_MAPS; ++s) inter[s] = want_inter ? reinterpret_cast<float *>(16) : nullptr;
     return eval_common(views, nullptr, n, maps, n_maps, 0.02f, flags, nullptr, nullptr, nullptr, want_inter ? inter : nullptr,
                        nullptr, have_workspace ? d3f::order_workspace_bytes(n) : 0, nullptr, 0, plan);
+}
+
+int d3f_eval_plan_query_lattice(const d3f_views *views, int32_t nx, int32_t ny, int32_t nz, const d3f_channel_map *maps,
+                                int32_t n_maps, uint32_t flags, int32_t want_inter, d3f_eval_plan *plan)
+{
+    if (!plan) return fail(D3F_ERR_INVALID_ARG, "plan is NULL");
+    if (nx < 0 || ny < 0 || nz < 0) return fail(D3F_ERR_BAD_SHAPE, "plan_query_lattice: negative size");
+    float *inter[D3F_MAX_MAPS];
+    for (int s = 0; s < D3F_MAX_MAPS; ++s) inter[s] = want_inter ? reinterpret_cast<float *>(16) : nullptr;
+    const int32_t dims[3] = {nx, ny, nz};
+    return eval_common(views, nullptr, (int64_t)nx * ny * nz, maps, n_maps, 0.02f, flags, nullptr, nullptr, nullptr,
+                       want_inter ? inter : nullptr, nullptr, 0, nullptr, 0, plan, nullptr, dims);
 }
 
 int64_t d3f_backproject_workspace_bytes(int32_t H, int32_t W)
@@ -411,8 +503,19 @@ int d3f_eval_grid(const d3f_views *views, const d3f_grid *grid, const d3f_channe
 {
     int rc = check_grid(grid);
     if (rc != D3F_OK) return rc;
+    const int32_t dims[3] = {grid->nx, grid->ny, grid->nz};
     return eval_common(views, nullptr, (int64_t)grid->nx * grid->ny * grid->nz, maps, n_maps, mu, flags, out_dist, out_valid,
-                       out_fused, nullptr, nullptr, 0, stream, 0, nullptr, grid);
+                       out_fused, nullptr, nullptr, 0, stream, 0, nullptr, grid, dims);
+}
+
+int d3f_eval_lattice(const d3f_views *views, const float *pts, int32_t nx, int32_t ny, int32_t nz, const d3f_channel_map *maps,
+                     int32_t n_maps, float mu, uint32_t flags, float *out_dist, uint8_t *out_valid, float *const *out_fused,
+                     float *const *out_inter, void *stream)
+{
+    if (nx < 0 || ny < 0 || nz < 0) return fail(D3F_ERR_BAD_SHAPE, "eval_lattice: negative size");
+    const int32_t dims[3] = {nx, ny, nz};
+    return eval_common(views, pts, (int64_t)nx * ny * nz, maps, n_maps, mu, flags, out_dist, out_valid, out_fused, out_inter,
+                       nullptr, 0, stream, 0, nullptr, nullptr, dims);
 }
 
 int64_t d3f_grid_shell_workspace_bytes(const d3f_grid *grid)
@@ -499,6 +602,14 @@ int d3f_point_order_locality(const float *pts, int64_t n, float *out, void *stre
     if (!out || (n > 0 && !pts)) return fail(D3F_ERR_INVALID_ARG, "point_order_locality: NULL pointer");
     hipError_t e = d3f::launch_point_locality(pts, n, out, static_cast<hipStream_t>(stream));
     return e == hipSuccess ? D3F_OK : hip_fail(e, "point locality launch");
+}
+
+int d3f_lattice_probe(const float *pts, int64_t n, int32_t *out_dims, void *stream)
+{
+    if (n < 0) return fail(D3F_ERR_INVALID_ARG, "n=%lld is negative", (long long)n);
+    if (!out_dims || (n > 0 && !pts)) return fail(D3F_ERR_INVALID_ARG, "lattice_probe: NULL pointer");
+    hipError_t e = d3f::launch_lattice_probe(pts, n, out_dims, static_cast<hipStream_t>(stream));
+    return e == hipSuccess ? D3F_OK : hip_fail(e, "lattice probe launch");
 }
 
 int d3f_eval_dist(const d3f_views *views, const float *pts, int64_t n, float *out_dist, uint8_t *out_valid,

@@ -24,6 +24,7 @@ struct MapDesc {
     int32_t pre_slot;  // >= 0: bilinear corner set-up of this map is precomputed per (point, view) in LDS slot pre_slot
     int32_t staged;    // 2: gather through wave-private LDS texel windows (opt-in experiment)
     int32_t esize;     // bytes per stored channel: 4 (fp32) or 2 (fp16 storage, widened on load)
+    int32_t runs;      // > 0: cell-run gather (gather_map_runs): a lane group walks `runs` consecutive points view by view
 };
 
 struct EvalParams {
@@ -43,6 +44,12 @@ struct EvalParams {
     int32_t crec_offset;   // byte offset of the precomputed corner records, 16-B aligned
     int32_t n_pre;         // number of maps with precomputed corner records
     int32_t xcd_chunk;     // tiles per XCD-mapping chunk (multiple of 8), 0 = the whole launch
+    // lattice walk: the n = walk_nx*walk_ny*walk_nz points form a regular lattice in index space (flat index
+    // (ix*ny + iy)*nz + iz); workgroups take bricks of walk_tx x walk_ty x walk_tz points in a blocked order computed
+    // from blockIdx alone (no keys, no sort, no index array).  walk_nx == 0: off.
+    int32_t walk_nx, walk_ny, walk_nz;
+    int32_t walk_tx, walk_ty, walk_tz;
+    int32_t runs_occ;      // experiment: 5 = cell-run kernel variant held to 5 waves per SIMD
     uint32_t flags;
     float mu;
     MapDesc maps[D3F_MAX_MAPS];
@@ -73,6 +80,8 @@ int64_t order_workspace_bytes(int64_t n);
 hipError_t build_point_order(const float *pts, int64_t n, void *workspace, int64_t workspace_bytes,
                              const uint32_t **order_out, hipStream_t stream, int fine = 0);
 const uint32_t *stored_point_order(void *workspace, int64_t n);
+// is pts a z-fastest lattice?  out: 3 device int32 (nx, ny, nz), zeros when not
+hipError_t launch_lattice_probe(const float *pts, int64_t n, int32_t *out_dims, hipStream_t stream);
 // mean L1 step between consecutive points vs between points n/2 apart (out: 2 device floats)
 hipError_t launch_point_locality(const float *pts, int64_t n, float *out, hipStream_t stream);
 

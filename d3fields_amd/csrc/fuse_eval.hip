@@ -83,7 +83,8 @@ struct __attribute__((aligned(16))) CornerRec {
 template <int VW, int U, bool BATCH, bool HALF = false>
 __device__ __forceinline__ void gather_map(const MapDesc &m, const EvalParams &P, const ViewRec *rec,
                                            const float *cnt_s, const uint32_t *flag_s,
-                                           const uint32_t *idx_s, int64_t idx_base, int tile_n, const CornerRec *crec)
+                                           const uint32_t *idx_s, int64_t idx_base, int tile_n, const CornerRec *crec,
+                                           bool only_strict = false)
 {
     using VT = typename Vec<VW>::T;
     const int lpp = 1 << m.lpp_log2;
@@ -101,6 +102,7 @@ __device__ __forceinline__ void gather_map(const MapDesc &m, const EvalParams &P
         const bool all_invalid = (cnt == 0.0f);           // fusion.py:366
         const float denom = cnt + 1e-6f;                  // fusion.py:385
         const bool strict = (flag_s[p] != 0u) || (m.inter != nullptr);
+        if (only_strict && !strict) continue;             // the cell-run gather already wrote this point
         for (int c0 = 0; c0 < cvec; c0 += lpp * U) {
             VT acc[U];
 #pragma unroll
@@ -385,7 +387,88 @@ __device__ __forceinline__ void gather_map_wave_staged(const MapDesc &m, const E
     }
 }
 
-template <int VW, bool WIDE>
+// ---- phase B, cell-run gather (patch-resolution wide maps) ------------------------------------------------
+// When a texel spans many image pixels (the reference's dino_feats is (H/10, W/10), fusion.py:694-697) consecutive
+// query points of a grid column / a Morton walk fall into the SAME texel cell of a view most of the time, and the
+// direct gather above is bound by the vector-L1 request rate (64 B/clk/CU), not by misses.  Here a lane group owns a
+// RUN of K consecutive points and ONE 16-byte channel vector per lane, and walks the run view by view: the four corner
+// vectors of a view stay in registers (16 VGPRs) and are re-fetched only when the cell changes; the K accumulators
+// (4 VGPRs each) carry the view sums.  Per (point, view) the operations and their order are exactly those of
+// gather_map's fast path -- acc += (fma chain over nw,ne,sw,se) * wgt in view order, then the shared-reciprocal
+// division -- so the results are bit-identical.  Points that need the strict path (non-finite projection) are left to
+// gather_map(only_strict).  One vector per lane keeps the kernel at >= 5 waves per SIMD, which the register cell-run
+// experiment of round 1 (3 vectors per lane, 4-point runs, 167-179 VGPR) could not.
+template <int K>
+__device__ __forceinline__ void gather_map_runs(const MapDesc &m, const EvalParams &P, const ViewRec *rec,
+                                                const float *cnt_s, const uint32_t *flag_s, const uint32_t *idx_s,
+                                                int64_t idx_base, int tile_n, const CornerRec *crec)
+{
+    using VT = f32x4;
+    const int lpp = 1 << m.lpp_log2;
+    const int g = threadIdx.x & (lpp - 1);
+    const int grp = threadIdx.x >> m.lpp_log2;
+    const int ngrp = kBlock >> m.lpp_log2;
+    const int cvec = m.C / 4;
+    const int V = P.V;
+    const char *__restrict__ data = reinterpret_cast<const char *>(m.data);
+
+    for (int run0 = grp * K; run0 < tile_n; run0 += ngrp * K) {
+        for (int c0 = 0; c0 < cvec; c0 += lpp) {
+            const int cv = c0 + g;
+            const uint32_t co = (uint32_t)min(cv, cvec - 1) * 16u;      // idle lanes re-read the last vector
+            VT acc[K];
+#pragma unroll
+            for (int k = 0; k < K; ++k) acc[k] = (VT)0.0f;
+            for (int v = 0; v < V; ++v) {
+                const char *bv = data + (int64_t)v * m.sv * 4;
+                uint32_t p0 = 0xffffffffu, p1 = 0xffffffffu, p2 = 0xffffffffu, p3 = 0xffffffffu;
+                VT a = (VT)0.0f, b = (VT)0.0f, d = (VT)0.0f, e = (VT)0.0f;
+#pragma unroll
+                for (int k = 0; k < K; ++k) {
+                    const int p = run0 + k;
+                    if (p >= tile_n) break;
+                    const ViewRec r = rec[p * V + v];
+                    if (r.valid == 0.0f || flag_s[p] != 0u) continue;   // exact skip (see gather_map); strict points later
+                    const CornerRec cr = crec[p * V + v];
+                    if (cr.o[0] != p0 || cr.o[1] != p1 || cr.o[2] != p2 || cr.o[3] != p3) {     // another texel cell
+                        p0 = cr.o[0]; p1 = cr.o[1]; p2 = cr.o[2]; p3 = cr.o[3];
+                        a = load_texel<4, false>(bv + (p0 + co));
+                        b = load_texel<4, false>(bv + (p1 + co));
+                        d = load_texel<4, false>(bv + (p2 + co));
+                        e = load_texel<4, false>(bv + (p3 + co));
+                    }
+                    VT s = a * cr.w[0];                                  // ATen bilinear: fma chain nw,ne,sw,se
+                    s = v_fma<VT>(b, cr.w[1], s);
+                    s = v_fma<VT>(d, cr.w[2], s);
+                    s = v_fma<VT>(e, cr.w[3], s);
+                    acc[k] = acc[k] + s * r.wgt;                         // fusion.py:385
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                const int p = run0 + k;
+                if (p >= tile_n) break;
+                if (flag_s[p] != 0u || cv >= cvec) continue;
+                const float cnt = cnt_s[p];
+                const float denom = cnt + 1e-6f;                          // fusion.py:385
+                VT o = (VT)0.0f;                                          // fusion.py:386 when no view is valid
+                if (cnt != 0.0f) {
+                    // the shared-reciprocal IEEE division of gather_map's fast path (bit-identical quotients)
+                    const float r0 = __builtin_amdgcn_rcpf(denom);
+                    const float rcp_d = fmaf(fmaf(-denom, r0, 1.0f), r0, r0);
+                    VT q = acc[k] * rcp_d;
+                    q = v_fma<VT>(v_fma<VT>(q, -denom, acc[k]), rcp_d, q);
+                    q = v_fma<VT>(v_fma<VT>(q, -denom, acc[k]), rcp_d, q);
+                    o = q;
+                }
+                store_vec<VT>(m.out + (idx_base + idx_s[p]) * m.C + (int64_t)cv * 4, o);
+            }
+        }
+    }
+}
+
+// SMALL: the cell-run kernel keeps <= 96 VGPRs; its other maps (the mask, colours) are mapped to <= 2 vectors per lane
+template <int VW, bool WIDE, bool SMALL = false>
 __device__ __forceinline__ void gather_map_u(const MapDesc &m, const EvalParams &P, const ViewRec *rec,
                                              const float *cnt_s, const uint32_t *flag_s,
                                              const uint32_t *idx_s, int64_t idx_base, int tile_n, const CornerRec *crec)
@@ -393,10 +476,10 @@ __device__ __forceinline__ void gather_map_u(const MapDesc &m, const EvalParams 
     switch (m.unroll) {
     case 1: gather_map<VW, 1, true>(m, P, rec, cnt_s, flag_s, idx_s, idx_base, tile_n, crec); break;
     case 2: gather_map<VW, 2, true>(m, P, rec, cnt_s, flag_s, idx_s, idx_base, tile_n, crec); break;
-    case 3: gather_map<VW, 3, true>(m, P, rec, cnt_s, flag_s, idx_s, idx_base, tile_n, crec); break;
+    case 3: if (!SMALL) gather_map<VW, 3, true>(m, P, rec, cnt_s, flag_s, idx_s, idx_base, tile_n, crec); break;
     case -1: gather_map<VW, 1, false>(m, P, rec, cnt_s, flag_s, idx_s, idx_base, tile_n, crec); break;
     case -2: gather_map<VW, 2, false>(m, P, rec, cnt_s, flag_s, idx_s, idx_base, tile_n, crec); break;
-    case -3: gather_map<VW, 3, false>(m, P, rec, cnt_s, flag_s, idx_s, idx_base, tile_n, crec); break;
+    case -3: if (!SMALL) gather_map<VW, 3, false>(m, P, rec, cnt_s, flag_s, idx_s, idx_base, tile_n, crec); break;
     default:
         if (WIDE) gather_map<VW, 4, false>(m, P, rec, cnt_s, flag_s, idx_s, idx_base, tile_n, crec);
         break;
@@ -441,8 +524,66 @@ __device__ __forceinline__ void fetch_point(const EvalParams &P, int64_t i, floa
     }
 }
 
+// ---- lattice walk: blockIdx -> brick of points, closed form ----------------------------------------------------
+// The points of a regular grid (create_init_grid, fusion.py:79-88) need no keys, no sort and no index array to be
+// walked brick by brick: the flat walk position t decodes to a tile of walk_tx x walk_ty x walk_tz points through a
+// three-level BLOCKED row-major order over the tile lattice -- 16^3-tile macro-bricks (32 k points with 2x2x2 tiles:
+// the Infinity-Cache window all eight XCDs share), 8^3-tile sub-bricks (the contiguous eighth one XCD takes, its L2
+// window), 4^3-tile mini-bricks, tiles row-major inside.  Blocks at the upper faces are clipped, not padded, so every
+// workgroup has work and the count is exactly ceil(nx/tx)*ceil(ny/ty)*ceil(nz/tz).  Wave-uniform integer arithmetic.
+struct TileBox {
+    int ox, oy, oz;     // first point of the tile (lattice coordinates)
+    int sx, sy, sz;     // clipped size in points
+};
+
+__device__ __forceinline__ void walk_level(uint32_t &rem, int b, int &ox, int &oy, int &oz, int &ex, int &ey, int &ez)
+{
+    // the box at (ox,oy,oz) with extents (ex,ey,ez) tiles is cut into b^3 blocks (upper ones clipped), row-major;
+    // on return the box is the block holding position `rem`, and rem is the position inside it
+    const uint32_t slab = (uint32_t)b * (uint32_t)ey * (uint32_t)ez;
+    const uint32_t i = rem / slab;
+    rem -= i * slab;
+    const int bx = min(b, ex - (int)i * b);
+    const uint32_t col = (uint32_t)bx * (uint32_t)b * (uint32_t)ez;
+    const uint32_t j = rem / col;
+    rem -= j * col;
+    const int by = min(b, ey - (int)j * b);
+    const uint32_t cell = (uint32_t)bx * (uint32_t)by * (uint32_t)b;
+    const uint32_t k = rem / cell;
+    rem -= k * cell;
+    ox += (int)i * b; oy += (int)j * b; oz += (int)k * b;
+    ex = bx; ey = by; ez = min(b, ez - (int)k * b);
+}
+
+__device__ __forceinline__ TileBox walk_tile(const EvalParams &P, int64_t t)
+{
+    int ex = (P.walk_nx + P.walk_tx - 1) / P.walk_tx, ey = (P.walk_ny + P.walk_ty - 1) / P.walk_ty,
+        ez = (P.walk_nz + P.walk_tz - 1) / P.walk_tz;
+    int ox = 0, oy = 0, oz = 0;
+    uint32_t rem = (uint32_t)t;
+    walk_level(rem, 16, ox, oy, oz, ex, ey, ez);
+    walk_level(rem, 8, ox, oy, oz, ex, ey, ez);
+    walk_level(rem, 4, ox, oy, oz, ex, ey, ez);
+    const uint32_t yz = (uint32_t)ey * (uint32_t)ez;
+    const uint32_t lx = rem / yz, r2 = rem - lx * yz;
+    const uint32_t ly = r2 / (uint32_t)ez, lz = r2 - ly * (uint32_t)ez;
+    TileBox tb;
+    tb.ox = (ox + (int)lx) * P.walk_tx; tb.oy = (oy + (int)ly) * P.walk_ty; tb.oz = (oz + (int)lz) * P.walk_tz;
+    tb.sx = min(P.walk_tx, P.walk_nx - tb.ox); tb.sy = min(P.walk_ty, P.walk_ny - tb.oy); tb.sz = min(P.walk_tz, P.walk_nz - tb.oz);
+    return tb;
+}
+
+// flat index of the p-th point of a tile (z fastest inside the tile, like the lattice itself)
+__device__ __forceinline__ int64_t walk_point(const EvalParams &P, const TileBox &tb, int p)
+{
+    const int yz = tb.sy * tb.sz;
+    const int dx = p / yz, r = p - dx * yz;
+    const int dy = r / tb.sz, dz = r - dy * tb.sz;
+    return ((int64_t)(tb.ox + dx) * P.walk_ny + (tb.oy + dy)) * P.walk_nz + (tb.oz + dz);
+}
+
 // STAGED: compiled with the LDS-window gather (more registers); the plain kernel keeps 4 waves/SIMD.
-template <int MODE, bool STAGED, bool WIDE, bool ANYF16 = false>
+template <int MODE, bool STAGED, bool WIDE, bool ANYF16 = false, bool RUNS = false>
 __device__ __forceinline__ void fused_eval_body(const EvalParams &P)
 {
     extern __shared__ __align__(16) unsigned char smem[];
@@ -461,7 +602,8 @@ __device__ __forceinline__ void fused_eval_body(const EvalParams &P)
     compute_krt(P.K, P.pose, V, krt, kBlock);
     __syncthreads();
 
-    const int64_t ntiles = (P.n + TP - 1) / TP;
+    const bool walk = P.walk_nx > 0;
+    const int64_t ntiles = walk ? (int64_t)gridDim.x : (P.n + TP - 1) / TP;
     int64_t tile = (int64_t)blockIdx.x;
     if (P.flags & kFlagXcdRemap) {
         // chunked XCD mapping: the walk is cut into chunks of `xcd_chunk` tiles (0 = one chunk); inside a chunk
@@ -472,8 +614,10 @@ __device__ __forceinline__ void fused_eval_body(const EvalParams &P)
         tile = c0 + xcd_tile((int64_t)blockIdx.x - c0, len);
     }
     const int64_t tile_base = tile * TP;
-    const int tile_n = (int)min((int64_t)TP, P.n - tile_base);
-    const int64_t idx_base = P.order ? 0 : tile_base;   // idx_s holds 32-bit offsets from here
+    TileBox tb = {0, 0, 0, 0, 0, 0};
+    if (walk) tb = walk_tile(P, tile);
+    const int tile_n = walk ? tb.sx * tb.sy * tb.sz : (int)min((int64_t)TP, P.n - tile_base);
+    const int64_t idx_base = (P.order || walk) ? 0 : tile_base;   // idx_s holds 32-bit offsets from here
     const float mu = P.mu;
     const float Wm1 = (float)(P.W - 1), Hm1 = (float)(P.H - 1);
 
@@ -503,7 +647,7 @@ __device__ __forceinline__ void fused_eval_body(const EvalParams &P)
     for (int idx = threadIdx.x; idx < tile_n * V; idx += kBlock) {
         const int v = idx / tile_n, p = idx - v * tile_n;
         // (indices are clamped: a stale buffer passed with D3F_FLAG_REUSE_POINT_ORDER must not fault the device)
-        const int64_t i = P.order ? min((int64_t)P.order[tile_base + p], P.n - 1) : tile_base + p;
+        const int64_t i = walk ? walk_point(P, tb, p) : (P.order ? min((int64_t)P.order[tile_base + p], P.n - 1) : tile_base + p);
         float px, py, pz;
         fetch_point(P, i, px, py, pz);
         float wgt;
@@ -529,7 +673,7 @@ __device__ __forceinline__ void fused_eval_body(const EvalParams &P)
     // per point: sums over the views in view order (fusion.py:364-370), outputs leave coalesced
     for (int p = threadIdx.x; p < tile_n; p += kBlock) {
         // (indices are clamped: a stale buffer passed with D3F_FLAG_REUSE_POINT_ORDER must not fault the device)
-        const int64_t i = P.order ? min((int64_t)P.order[tile_base + p], P.n - 1) : tile_base + p;
+        const int64_t i = walk ? walk_point(P, tb, p) : (P.order ? min((int64_t)P.order[tile_base + p], P.n - 1) : tile_base + p);
         float dsum = 0.0f, cnt = 0.0f;
         uint32_t nonfinite = 0u;
         for (int v = 0; v < V; ++v) {
@@ -561,15 +705,23 @@ __device__ __forceinline__ void fused_eval_body(const EvalParams &P)
             continue;
         }
         const CornerRec *crec = m.pre_slot >= 0 ? crec_s + (size_t)m.pre_slot * TP * V : nullptr;
+        if (RUNS && m.runs > 0) {
+            // non-strict points through the cell-run gather, the (rare) strict ones through the generic path
+            // (the host gives such a map 16-byte vectors, one per lane, and a corner-record slot)
+            if (m.runs == 4) gather_map_runs<4>(m, P, rec, cnt_s, flag_s, idx_s, idx_base, tile_n, crec);
+            else gather_map_runs<8>(m, P, rec, cnt_s, flag_s, idx_s, idx_base, tile_n, crec);
+            gather_map<4, 1, true>(m, P, rec, cnt_s, flag_s, idx_s, idx_base, tile_n, crec, true);
+            continue;
+        }
         if (ANYF16 && m.esize == 2) {
             if (m.vw == 8) gather_map_half_u<8>(m, P, rec, cnt_s, flag_s, idx_s, idx_base, tile_n, crec);
             else gather_map_half_u<1>(m, P, rec, cnt_s, flag_s, idx_s, idx_base, tile_n, crec);
             continue;
         }
         switch (m.vw) {
-        case 4: gather_map_u<4, WIDE>(m, P, rec, cnt_s, flag_s, idx_s, idx_base, tile_n, crec); break;
-        case 2: gather_map_u<2, WIDE>(m, P, rec, cnt_s, flag_s, idx_s, idx_base, tile_n, crec); break;
-        default: gather_map_u<1, WIDE>(m, P, rec, cnt_s, flag_s, idx_s, idx_base, tile_n, crec); break;
+        case 4: gather_map_u<4, WIDE, RUNS>(m, P, rec, cnt_s, flag_s, idx_s, idx_base, tile_n, crec); break;
+        case 2: gather_map_u<2, WIDE, RUNS>(m, P, rec, cnt_s, flag_s, idx_s, idx_base, tile_n, crec); break;
+        default: gather_map_u<1, WIDE, RUNS>(m, P, rec, cnt_s, flag_s, idx_s, idx_base, tile_n, crec); break;
         }
     }
 }
@@ -593,18 +745,33 @@ __global__ __launch_bounds__(kBlock) void fused_eval_f16_kernel(const EvalParams
 template <int MODE>
 __global__ __launch_bounds__(kBlock) void fused_eval_staged_kernel(const EvalParams P) { fused_eval_body<MODE, true, true>(P); }
 
+// cell-run gather for patch-resolution wide maps: one channel vector per lane (104 VGPR = 4 waves per SIMD; the
+// variant held to 5 waves per SIMD spills 6 registers -- experiment knob D3F_EXP_RUNS_OCC=5)
+template <int MODE>
+__global__ __launch_bounds__(kBlock) void fused_eval_runs_kernel(const EvalParams P) { fused_eval_body<MODE, false, false, false, true>(P); }
+template <int MODE>
+__global__ __launch_bounds__(kBlock, 5) void fused_eval_runs5_kernel(const EvalParams P) { fused_eval_body<MODE, false, false, false, true>(P); }
+
 hipError_t launch_fused_eval(const EvalParams &P, int mode, hipStream_t stream)
 {
     if (P.n == 0) return hipSuccess;
-    const int64_t ntiles = (P.n + P.tile_pts - 1) / P.tile_pts;
+    int64_t ntiles = (P.n + P.tile_pts - 1) / P.tile_pts;
+    if (P.walk_nx > 0)
+        ntiles = (int64_t)((P.walk_nx + P.walk_tx - 1) / P.walk_tx) * ((P.walk_ny + P.walk_ty - 1) / P.walk_ty) *
+                 ((P.walk_nz + P.walk_tz - 1) / P.walk_tz);
     const size_t lds = (size_t)P.crec_offset + (size_t)P.n_pre * P.tile_pts * P.V * 32 + (size_t)P.lds_pad;
     dim3 grid((unsigned)ntiles), block(kBlock);
-    bool wide = false, f16 = false;
+    bool wide = false, f16 = false, runs = false;
     for (int s = 0; s < P.n_maps; ++s) {
         wide |= (P.maps[s].unroll == -4);
         f16 |= (P.maps[s].esize == 2);
+        runs |= (P.maps[s].runs > 0);
     }
-    if (mode == 0 && f16)
+    if (mode == 0 && runs && !f16 && !wide && P.stage_floats == 0 && P.runs_occ == 5)
+        hipLaunchKernelGGL((fused_eval_runs5_kernel<0>), grid, block, lds, stream, P);
+    else if (mode == 0 && runs && !f16 && !wide && P.stage_floats == 0)
+        hipLaunchKernelGGL((fused_eval_runs_kernel<0>), grid, block, lds, stream, P);
+    else if (mode == 0 && f16)
         hipLaunchKernelGGL((fused_eval_f16_kernel<0>), grid, block, lds, stream, P);
     else if (mode == 0 && P.stage_floats > 0)
         hipLaunchKernelGGL((fused_eval_staged_kernel<0>), grid, block, lds, stream, P);

@@ -234,6 +234,10 @@ class Fusion:
         self._order_cache = None
         self.cache_point_order = True           # keep the Morton order of an unchanged query tensor (a grid queried every
         self._order_ws = None                   # frame) in its scratch and skip the ~0.12 ms re-sort
+        self._lattice_cache = None
+        self._last_plan = None
+        self.record_plans = False               # last_plan(): query the launch plan of every eval (bench.py, tests)
+        self.detect_lattice = True              # probe new query tensors for create_init_grid's layout (brick walk, no sort)
         self._lib = _lib.load()                 # fail at construction if the HIP library is missing
 
     # ---- observation state (reference fusion.py:686-714) --------------------------------
@@ -314,6 +318,51 @@ class Fusion:
             self._order_cache = hit
         return hit[1]
 
+    def _lattice_dims(self, pts_c, stream):
+        """(nx, ny, nz) when the query tensor is a z-fastest lattice -- the materialised create_init_grid output the
+        reference's drivers hand to batch_eval (vis_repr.py:88-93) -- else None.  d3f_lattice_probe on a NEW query
+        tensor (one host sync; cached by storage / version / length when cache_point_order is on).  The dims only
+        select the walk order of d3f_eval_lattice, which reads every coordinate from the tensor itself: a stale
+        answer costs time, never correctness."""
+        sig = (pts_c.data_ptr(), pts_c._version, pts_c.shape[0])
+        hit = self._lattice_cache if self.cache_point_order else None
+        if hit is None or hit[0] != sig:
+            if torch.cuda.is_current_stream_capturing():
+                return None                     # no host sync inside a HIP-graph capture
+            out = torch.empty(3, dtype=torch.int32, device=pts_c.device)
+            _lib.check(self._lib.d3f_lattice_probe(_lib.ptr(pts_c), pts_c.shape[0], _lib.ptr(out), stream))
+            dims = tuple(int(v) for v in out.tolist())
+            hit = (sig, dims if dims[0] > 0 else None)
+            self._lattice_cache = hit
+        return hit[1]
+
+    def last_plan(self):
+        """What the last eval / batch_eval launched (for bench.py and tests): kernel entry point, tile size and how the
+        points were ordered -- from d3f_eval_plan_query on the same shapes and flags."""
+        return self._last_plan
+
+    def _record_plan(self, views, n, maps, n_maps, flags, have_ws, want_inter, lattice):
+        plan = _lib.EvalPlan()
+        if lattice is not None:
+            rc = self._lib.d3f_eval_plan_query_lattice(ctypes.byref(views), lattice[0], lattice[1], lattice[2], maps, n_maps, flags,
+                                                       1 if want_inter else 0, ctypes.byref(plan))
+        else:
+            rc = self._lib.d3f_eval_plan_query(ctypes.byref(views), n, maps, n_maps, flags, 1 if have_ws else 0,
+                                               1 if want_inter else 0, ctypes.byref(plan))
+        if rc != 0:
+            return
+        runs = any(plan.staged[s] >= 16 for s in range(n_maps))
+        wide = any(plan.vectors_per_lane[s] == -4 for s in range(n_maps))
+        f16 = any(maps[s].dtype == _lib.DTYPE_F16 for s in range(n_maps))
+        kernel = ("fused_eval_f16_kernel<0>" if f16 else "fused_eval_runs_kernel<0>" if runs else
+                  "fused_eval_wide_kernel<0>" if wide else "fused_eval_kernel<0>")
+        order = {2: "closed-form brick walk of the lattice (no keys, no sort)", 1: "Morton order (21-bit keys, radix sort)",
+                 0: "caller order"}[int(plan.reorder)]
+        if runs:
+            order += "; cell runs of %d consecutive points" % (max(plan.staged[s] for s in range(n_maps)) - 16)
+        self._last_plan = {"kernel": kernel, "tile_points": int(plan.tile_points), "point_order": order,
+                           "workgroups": int(plan.workgroups), "lattice": lattice}
+
     def _run(self, pts, return_names, return_inter, mode):
         self._check_query(pts)
         if pts.requires_grad and torch.is_grad_enabled():
@@ -378,6 +427,17 @@ class Fusion:
                     inter[s] = it.data_ptr()
             flags = (_lib.FLAG_FINITE_MAPS if finite else 0) | int(self.tuning_flags)
             ws, ws_bytes = None, 0
+            dims = None
+            if self.reorder_points and self.detect_lattice and names and n >= 65536:
+                dims = self._lattice_dims(pts_c, stream)
+            if dims is not None:
+                # a regular grid: closed-form brick walk on large maps / column runs on patch-resolution maps; no scratch
+                if self.record_plans:
+                    self._record_plan(views, n, maps, len(names), flags, False, return_inter, dims)
+                _lib.check(lib.d3f_eval_lattice(ctypes.byref(views), _lib.ptr(pts_c), dims[0], dims[1], dims[2], maps, len(names),
+                                                self.mu, flags, _lib.ptr(dist), _lib.ptr(valid), fused,
+                                                inter if return_inter else None, stream))
+                return outputs, (pts_c, keep[0], keep[1], keep[2], used_maps)
             if self.reorder_points and names and n >= 65536:
                 small = sum(m.numel() * m.element_size() for m in used_maps) <= (64 << 20)
                 if small and self.detect_point_order and self._is_unordered(pts_c, stream):
@@ -397,6 +457,8 @@ class Fusion:
                     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)   # torch's caching allocator: no hipMalloc per call
                     if self.cache_point_order:
                         self._order_ws = (sig, ws, bool(plan.reorder))      # filled by this call iff the library reorders
+            if self.record_plans:
+                self._record_plan(views, n, maps, len(names), flags, ws is not None, return_inter, None)
             _lib.check(lib.d3f_eval(ctypes.byref(views), _lib.ptr(pts_c), n, maps, len(names), self.mu, flags,
                                     _lib.ptr(dist), _lib.ptr(valid), fused, inter if return_inter else None,
                                     _lib.ptr(ws), ws_bytes, stream))

@@ -134,14 +134,16 @@ void d3f_profile_next_eval(void *start_event, void *stop_event);
  * geometry and the per-map lane mapping the host logic picked.  For tests and tuning. */
 typedef struct d3f_eval_plan {
     int32_t tile_points;                    /* query points per 256-thread workgroup                  */
-    int32_t reorder;                        /* 1: points are walked in Morton order                   */
+    int32_t reorder;                        /* 1: points are walked in Morton order (sorted keys); 2: closed-form brick
+                                               walk of a lattice (d3f_eval_grid / d3f_eval_lattice)    */
     int32_t lds_bytes;                      /* dynamic LDS per workgroup                              */
     int32_t reserved;
     int64_t workgroups;
     int32_t vector_floats[D3F_MAX_MAPS];    /* 4 / 2 / 1 floats per load                              */
     int32_t lanes_per_point[D3F_MAX_MAPS];
     int32_t vectors_per_lane[D3F_MAX_MAPS];
-    int32_t staged[D3F_MAX_MAPS];           /* 1: texel windows staged through LDS                    */
+    int32_t staged[D3F_MAX_MAPS];           /* 2: texel windows staged through LDS (experiment); 16 + K: cell-run gather
+                                               with runs of K points (patch-resolution wide maps)      */
 } d3f_eval_plan;
 int d3f_eval_plan_query(const d3f_views *views, int64_t n, const d3f_channel_map *maps, int32_t n_maps,
                         uint32_t flags, int32_t have_workspace, int32_t want_inter, d3f_eval_plan *plan);
@@ -163,6 +165,25 @@ typedef struct d3f_grid {
 int d3f_eval_grid(const d3f_views *views, const d3f_grid *grid, const d3f_channel_map *maps, int32_t n_maps,
                   float mu, uint32_t flags, float *out_dist, uint8_t *out_valid, float *const *out_fused,
                   void *stream);
+
+/* d3f_eval for points that the caller has ARRANGED as a regular lattice -- pts[(ix*ny + iy)*nz + iz], e.g. the
+ * materialised output of create_init_grid (fusion.py:79-88) handed to batch_eval (vis_repr.py:88-93) -- with n =
+ * nx*ny*nz.  Coordinates are read from `pts` exactly as in d3f_eval and the outputs are identical; the dims only let
+ * the library walk the index space brick by brick in closed form when the maps are large (no Morton keys, no sort, no
+ * index array, no workspace).  Any dims whose product is n are correct -- a wrong guess can only cost speed. */
+int d3f_eval_lattice(const d3f_views *views, const float *pts, int32_t nx, int32_t ny, int32_t nz,
+                     const d3f_channel_map *maps, int32_t n_maps, float mu, uint32_t flags, float *out_dist,
+                     uint8_t *out_valid, float *const *out_fused, float *const *out_inter, void *stream);
+
+/* d3f_eval_plan_query for d3f_eval_lattice / d3f_eval_grid launches. */
+int d3f_eval_plan_query_lattice(const d3f_views *views, int32_t nx, int32_t ny, int32_t nz, const d3f_channel_map *maps,
+                                int32_t n_maps, uint32_t flags, int32_t want_inter, d3f_eval_plan *plan);
+
+/* Is pts[n,3] a z-fastest lattice (every point = (x[ix], y[iy], z[iz]) with strictly increasing axes, flat index
+ * (ix*ny + iy)*nz + iz: the layout of create_init_grid, fusion.py:79-88)?  One workgroup finds where the z and y
+ * axes restart and spot-checks <= 4096 points; out_dims: 3 DEVICE int32 = (nx, ny, nz), zeros when it is not (or an
+ * axis is longer than 65536).  The shim feeds the answer to d3f_eval_lattice, where it only selects the walk order. */
+int d3f_lattice_probe(const float *pts, int64_t n, int32_t *out_dims, void *stream);
 
 /* Pre-filter of select_features_* (fusion.py:1430,1444): flat indices of the grid points with
  * valid_mask && |dist| < dist_thr, compacted into idx_out[0..min(count,capacity)) in ASCENDING order (the order

@@ -1,0 +1,234 @@
+"""GPU parity of the two launch paths added in round 2 -- the closed-form lattice brick walk (grids on large maps) and
+the cell-run gather (patch-resolution wide maps) -- and of the BENCH workloads themselves.  Both paths only change the
+ORDER in which points are processed / corner texels are fetched, never an arithmetic operation, so the bar is
+bit-identity with the caller-order direct gather (torch.equal), which the other GPU tests pin to the oracle and the
+reference goldens; a sample of each full-size result is compared with the CPU oracle as well."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import rel_err
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    return torch.device("cuda:0")
+
+
+def cpu(x):
+    return x.detach().cpu().numpy()
+
+
+class knobs:
+    """Experiment knobs of the library are environment variables read at every call."""
+
+    def __init__(self, **kv):
+        self.kv = {k: str(v) for k, v in kv.items()}
+
+    def __enter__(self):
+        self.old = {k: os.environ.get(k) for k in self.kv}
+        os.environ.update(self.kv)
+
+    def __exit__(self, *a):
+        for k, v in self.old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+def fusion_for(dev, V, H, W, maps, kind="smooth"):
+    from d3fields_amd import Fusion, synth
+    sc = synth.make_scene(V, H, W, kind)
+    f = Fusion(num_cam=V, device=str(dev))
+    f.curr_obs_torch = {k: sc[k].to(dev) for k in ("depth", "K", "pose")}
+    f.curr_obs_torch.update(maps)
+    f.H, f.W = H, W
+    return f, sc
+
+
+def oracle_sample(sc, pts, maps, mu=0.02):
+    from oracle import c_oracle as O
+    return O.eval_field(sc["depth"], sc["K"], sc["pose"], pts, [m.float().cpu() for m in maps], mu=mu)
+
+
+def box_for(nx, ny, nz, step):
+    """boundaries whose create_init_grid has exactly (nx, ny, nz) points around the scene centre"""
+    return dict(x_lower=-nx * step / 2, x_upper=nx * step / 2 - step / 4, y_lower=-ny * step / 2, y_upper=ny * step / 2 - step / 4,
+                z_lower=-0.2, z_upper=-0.2 + nz * step - step / 4)
+
+
+# ---- lattice probe --------------------------------------------------------------------------------------------------
+def test_lattice_probe(dev):
+    from d3fields_amd import Fusion, create_init_grid, synth
+    f = Fusion(num_cam=1, device=str(dev))
+    f.cache_point_order = False                 # every call below probes (the cache is keyed by storage address)
+    s = torch.cuda.current_stream(dev).cuda_stream
+    import ctypes
+    st = ctypes.c_void_p(s)
+    for dims in [(40, 35, 11), (3, 5, 7000), (1, 300, 300), (129, 2, 300), (160, 140, 44)]:
+        grid, shape = create_init_grid(box_for(*dims, 0.004), 0.004)
+        assert tuple(shape) == dims
+        assert f._lattice_dims(grid.to(dev), st) == dims
+    grid = create_init_grid(box_for(40, 35, 11, 0.01), 0.01)[0]
+    assert f._lattice_dims(synth.random_cloud(100000, seed=1).to(dev), st) is None
+    assert f._lattice_dims(grid[torch.randperm(grid.shape[0])].to(dev), st) is None            # shuffled grid
+    bent = grid.clone(); bent[7777, 1] += 1e-6
+    assert f._lattice_dims(bent.to(dev), st) in (None, (40, 35, 11))                            # spot check: either is harmless
+    assert f._lattice_dims(grid[:-1].to(dev), st) is None                                       # ragged
+    assert f._lattice_dims(grid[:, [2, 1, 0]].contiguous().to(dev), st) is None                 # x fastest: not this layout
+    assert f._lattice_dims(torch.zeros(70000, 3, device=dev), st) is None
+
+
+# ---- lattice brick walk == caller order, bit for bit -------------------------------------------------------------------
+@pytest.mark.parametrize("dims,C,mask", [((64, 33, 37), 96, False), ((47, 53, 29), 384, True), ((130, 9, 61), 132, False),
+                                         ((2, 2, 20000), 64, True), ((70, 70, 17), 1024, False)])
+def test_lattice_walk_is_bit_identical(dev, dims, C, mask):
+    from d3fields_amd import create_init_grid, synth, _lib
+    V, H, W = 4, 96, 128
+    maps = {"dino_feats": synth.random_map(V, H, W, C, seed=1, device=dev)}          # dense maps: texel = pixel
+    names = ["dino_feats"]
+    if mask:
+        maps["mask"] = synth.random_onehot_mask(V, H, W, 8, seed=2, device=dev)
+        names.append("mask")
+    f, sc = fusion_for(dev, V, H, W, maps)
+    box = box_for(*dims, 0.004)
+    grid, shape = create_init_grid(box, 0.004)
+    assert tuple(shape) == dims and grid.shape[0] >= 65536
+    pts = grid.to(dev)
+    with torch.no_grad():
+        f.tuning_flags = _lib.TUNE_NO_REORDER
+        base = f.batch_eval(pts, return_names=names)                                  # caller order, direct gather
+        f.tuning_flags = _lib.TUNE_FORCE_REORDER                                      # maps are small here: force the walk
+        walk = f.batch_eval(pts, return_names=names)
+        viag = f.eval_grid(box, 0.004, return_names=names)                            # axes instead of the point array
+        f.detect_lattice = False
+        sort = f.batch_eval(pts, return_names=names)                                  # Morton sort of the same points
+        f.detect_lattice = True
+    for k in ["dist", "valid_mask"] + names:
+        assert torch.equal(walk[k], base[k]), k
+        assert torch.equal(viag[k], base[k]), k
+        assert torch.equal(sort[k], base[k]), k
+    pick = torch.randperm(pts.shape[0], generator=torch.Generator().manual_seed(3))[:1500]
+    ref = oracle_sample(sc, grid[pick], [maps[k] for k in names])
+    assert np.array_equal(cpu(walk["dist"])[pick], ref["dist"]) and np.array_equal(cpu(walk["valid_mask"])[pick], ref["valid_mask"])
+    assert rel_err(cpu(walk["dino_feats"])[pick], ref["sets"][0]) <= TOL
+
+
+def test_lattice_walk_return_inter_and_nonfinite(dev):
+    """'<k>_inter' outputs and non-finite maps / points take the strict path on the walk as in caller order."""
+    from d3fields_amd import create_init_grid, synth, _lib
+    V, H, W = 3, 64, 80
+    feats = synth.random_map(V, H, W, 40, seed=1, device=dev)
+    feats[1, 20:30, 30:50, 3] = float("nan")
+    f, sc = fusion_for(dev, V, H, W, {"dino_feats": feats})
+    grid = create_init_grid(box_for(50, 40, 36, 0.006), 0.006)[0]
+    grid[12345] = float("nan")
+    pts = grid.to(dev)
+    with torch.no_grad():
+        f.tuning_flags = _lib.TUNE_NO_REORDER
+        base = f.eval(pts, return_names=["dino_feats"], return_inter=True)
+        f.tuning_flags = _lib.TUNE_FORCE_REORDER
+        walk = f.eval(pts, return_names=["dino_feats"], return_inter=True)
+    for k in base:
+        a, b = walk[k], base[k]
+        assert torch.equal(torch.isnan(a), torch.isnan(b)) and torch.equal(torch.nan_to_num(a.float()), torch.nan_to_num(b.float())), k
+    assert torch.isnan(base["dino_feats"]).any()
+
+
+# ---- cell-run gather == direct gather, bit for bit ---------------------------------------------------------------------
+@pytest.mark.parametrize("C,V,fhw,mask,points", [(384, 4, (48, 64), False, "grid"), (384, 4, (48, 64), True, "grid"),
+                                                 (1024, 8, (24, 32), False, "cloud"), (132, 3, (12, 16), True, "grid"),
+                                                 (128, 4, (48, 64), False, "cloud")])
+def test_cell_run_gather_is_bit_identical(dev, C, V, fhw, mask, points):
+    from d3fields_amd import create_init_grid, synth, _lib
+    H, W = 480, 640
+    maps = {"dino_feats": synth.random_map(V, fhw[0], fhw[1], C, seed=1, device=dev)}
+    names = ["dino_feats"]
+    if mask:
+        maps["mask"] = synth.random_onehot_mask(V, H, W, 8, seed=2, device=dev)
+        names.append("mask")
+    f, sc = fusion_for(dev, V, H, W, maps)
+    if points == "grid":
+        pts_c = create_init_grid(synth.WORK_BOX, 0.0107)[0]                            # 74 x 65 x 20 points
+    else:
+        pts_c = synth.random_cloud(150001, seed=3)
+    pts_c[1000, 1] = float("inf")                                                       # a strict point inside a run
+    pts = pts_c.to(dev)
+    import ctypes
+    plan = _lib.EvalPlan()
+    views, keep, _ = f._views(dev)
+    m = maps["dino_feats"]
+    cm = (_lib.ChannelMap * 1)(_lib.ChannelMap(m.data_ptr(), m.shape[1], m.shape[2], C, 0, m.stride(0), m.stride(1), m.stride(2)))
+    _lib.check(f._lib.d3f_eval_plan_query(ctypes.byref(views), pts.shape[0], cm, 1, _lib.FLAG_FINITE_MAPS, 1, 0, ctypes.byref(plan)))
+    assert plan.staged[0] == 16 + 8, "the cell-run gather must be what runs here"
+    with torch.no_grad():
+        outs = {}
+        for tag, env in (("direct", dict(D3F_EXP_RUNS=-1)), ("runs8", dict(D3F_EXP_RUNS=0)), ("runs4", dict(D3F_EXP_RUNS=4)),
+                         ("runs8_occ5", dict(D3F_EXP_RUNS=8, D3F_EXP_RUNS_OCC=5))):
+            with knobs(**env):
+                outs[tag] = f.batch_eval(pts, return_names=names)
+    for tag in ("runs8", "runs4", "runs8_occ5"):
+        for k in outs["direct"]:
+            a, b = outs[tag][k], outs["direct"][k]
+            assert torch.equal(torch.isnan(a), torch.isnan(b)) and torch.equal(torch.nan_to_num(a.float()), torch.nan_to_num(b.float())), (tag, k)
+    pick = torch.randperm(pts.shape[0], generator=torch.Generator().manual_seed(3))[:1500]
+    pick = pick[pick != 1000]
+    ref = oracle_sample(sc, pts_c[pick], [maps[k] for k in names])
+    assert np.array_equal(cpu(outs["runs8"]["dist"])[pick], ref["dist"])
+    assert rel_err(cpu(outs["runs8"]["dino_feats"])[pick], ref["sets"][0]) <= TOL
+
+
+def test_cell_run_gather_not_used_when_it_must_not(dev):
+    """'<k>_inter', non-finite maps and fp16-stored maps keep the direct gather (the plan says so) and the results
+    still agree with the run path's on the same finite fp32 data."""
+    from d3fields_amd import synth, _lib
+    import ctypes
+    V, H, W, C = 4, 480, 640, 384
+    feats = synth.random_map(V, 48, 64, C, seed=1, device=dev)
+    f, sc = fusion_for(dev, V, H, W, {"dino_feats": feats})
+    views, keep, _ = f._views(dev)
+    cm = (_lib.ChannelMap * 1)(_lib.ChannelMap(feats.data_ptr(), 48, 64, C, 0, feats.stride(0), feats.stride(1), feats.stride(2)))
+    plan = _lib.EvalPlan()
+    for flags, inter, want in ((_lib.FLAG_FINITE_MAPS, 0, 24), (0, 0, 0), (_lib.FLAG_FINITE_MAPS, 1, 0)):
+        _lib.check(f._lib.d3f_eval_plan_query(ctypes.byref(views), 200000, cm, 1, flags, 1, inter, ctypes.byref(plan)))
+        assert plan.staged[0] == want, (flags, inter)
+    _lib.check(f._lib.d3f_eval_plan_query(ctypes.byref(views), 3000, cm, 1, _lib.FLAG_FINITE_MAPS, 1, 0, ctypes.byref(plan)))
+    assert plan.staged[0] == 0                                                          # small batches: many small tiles instead
+    pts = synth.random_cloud(100000, seed=5).to(dev)
+    with torch.no_grad():
+        a = f.eval(pts, return_names=["dino_feats"])
+        b = f.eval(pts, return_names=["dino_feats"], return_inter=True)
+    assert torch.equal(a["dino_feats"], b["dino_feats"])
+
+
+# ---- the BENCH workloads themselves ---------------------------------------------------------------
+@pytest.mark.parametrize("workload", ["c2_dense", "c3_dense", "c2_patch", "c3_patch"])
+def test_bench_workload_matches_oracle(dev, workload):
+    """Exactly what bench.py times (same builder, same launch geometry: lattice walk with 8- / 16-point tiles on the
+    dense maps, cell runs on the patch-resolution maps) against the CPU oracle on a 3000-point sample, plus
+    bit-identity with the caller-order direct gather on 200 000 points."""
+    import bench
+    from d3fields_amd import _lib
+    f, pts, names, w, sc = bench.build_workload(workload, dev, 0, 1)
+    assert pts.shape[0] == w["N"]
+    with torch.no_grad():
+        out = f.batch_eval(pts, return_names=names)
+        sub = torch.randperm(pts.shape[0], generator=torch.Generator().manual_seed(9))[:200000].to(dev)
+        f.tuning_flags = _lib.TUNE_NO_REORDER
+        with knobs(D3F_EXP_RUNS=-1):
+            ref_gpu = f.eval(pts[sub], return_names=names)
+    for k in ["dist", "valid_mask"] + names:
+        assert torch.equal(out[k][sub], ref_gpu[k]), k
+    pick = sub[:3000]
+    ref = oracle_sample(sc, pts[pick].cpu(), [f.curr_obs_torch[k] for k in names])
+    assert np.array_equal(cpu(out["valid_mask"][pick]), ref["valid_mask"])
+    assert np.array_equal(cpu(out["dist"][pick]), ref["dist"])
+    for i, k in enumerate(names):
+        assert rel_err(cpu(out[k][pick]), ref["sets"][i]) <= TOL, k
