@@ -102,7 +102,8 @@ int fill_map(const d3f_channel_map &c, int s, int V, float *out, float *inter, c
     if (es == 2) {
         // fp16 storage: 8 channels per 16-B load (fp32 accumulators / 32-B stores), else scalar lanes; batched loads only
         const bool str8 = (c.stride_v % 8 == 0) && (c.stride_y % 8 == 0) && (c.stride_x % 8 == 0);
-        const bool vec8 = (c.C % 8 == 0) && str8 && aligned(m.data, 16) && aligned(out, 16) && aligned(inter, 16);
+        const bool vec8 = (c.C % 8 == 0) && str8 && aligned(m.data, 16) && aligned(out, 16) && aligned(inter, 16) &&
+                          aligned(extra_aligned, 16);      // backward: grad_fused is read as 32-byte f32x8 pieces of 16-B aligned rows
         pick_mapping(m, false, false, true);            // scalar lanes ...
         if (vec8) {                                     // ... or the same search over 8-channel vectors
             d3f::MapDesc t = m;
@@ -145,7 +146,9 @@ void pick_staged_mapping(d3f::MapDesc &m)
 }
 
 // Experiment knobs read from the environment (integers; results never depend on them):
-//   D3F_EXP_RUNS   cell-run gather on patch-resolution wide maps: -1 off, 0 automatic (default), 4 / 8 / 16 = run length
+//   D3F_EXP_RUNS   cell-run gather on patch-resolution wide maps: -1 off, 0 automatic (default), 2 / 4 / 8 = run length
+//   D3F_EXP_RUNS_U vectors per lane of the cell-run gather: 0 automatic, 1 / 2 / 3;  D3F_EXP_RUNS_OCC=5: the (1,8) variant
+//                  held to 5 waves per SIMD
 //   D3F_EXP_WALK   lattice brick walk for grids on large maps: -1 off, 0 automatic (default)
 int exp_knob(const char *name)
 {
@@ -160,16 +163,23 @@ bool runs_candidate(const d3f::MapDesc &m, int H, int W)
     return m.esize == 4 && m.vw == 4 && m.C >= 128 && (W - 1) >= 4 * (m.fw - 1) && (H - 1) >= 4 * (m.fh - 1);
 }
 
-void pick_runs_mapping(d3f::MapDesc &m, int K)
+// (vectors per lane U, run length K) of the cell-run gather: the built variants are (1,8) (2,4) (2,8) (3,2) (3,4)
+void pick_runs_mapping(d3f::MapDesc &m, int U, int K)
 {
     const int cvec = m.C / 4;
+    if (U <= 0 || U > 3) U = 1;      // one vector per lane measured fastest (more waves beat fewer passes)
     long best_slots = -1;
-    for (int lg = 6; lg >= 5; --lg) {           // one 16-byte vector per lane: 64 or 32 lanes per point
-        const int lpp = 1 << lg;
-        const long slots = (long)((cvec + lpp - 1) / lpp) * lpp;
+    for (int lg = 6; lg >= 5; --lg) {           // 64 or 32 lanes per point; ties go to the wider group (fewer passes)
+        const long per = (long)(1 << lg) * U;
+        const long slots = (cvec + per - 1) / per * per;
         if (best_slots < 0 || slots < best_slots) { best_slots = slots; m.lpp_log2 = lg; }
     }
-    m.unroll = 1;
+    // run length (MI355X r2d): 32-lane groups (C = 384) -> 4-point runs at 6 waves per SIMD (C2 patch 0.724 -> 0.638 ms,
+    // C3 patch 1.544 -> 1.333); 64-lane groups (C = 1024) -> 8-point runs at 5 waves per SIMD (C4 patch 4.13 -> 3.84)
+    if (U == 3 && K != 2) K = 4;
+    if (U == 2 && K != 8) K = 4;
+    if (U == 1 && K != 4 && K != 8) K = m.lpp_log2 == 5 ? 4 : 8;
+    m.unroll = U;
     m.runs = K;
 }
 
@@ -236,17 +246,16 @@ int eval_common(const d3f_views *views, const float *pts, int64_t n, const d3f_c
         for (int s = 0; s < n_maps; ++s)
             blocked |= P.maps[s].esize == 2 || (out_inter && out_inter[s]) ||
                        (P.maps[s].unroll == -4 && !runs_candidate(P.maps[s], views->H, views->W));
-        int taken = 0;
-        for (int s = 0; s < n_maps && !blocked && taken < 2; ++s)
+        // one cell-run map per launch (phase A keeps one "same cell as the previous point" flag per (point, view))
+        for (int s = 0; s < n_maps && !blocked && !any_runs; ++s)
             if (runs_candidate(P.maps[s], views->H, views->W)) {
-                pick_runs_mapping(P.maps[s], knob == 4 ? 4 : 8);
+                pick_runs_mapping(P.maps[s], exp_knob("D3F_EXP_RUNS_U"), knob);
                 any_runs = true;
-                ++taken;
             }
-        if (any_runs)       // the cell-run kernel is built for <= 2 vectors per lane on its other maps (register budget)
+        if (any_runs)       // the cell-run kernel is built for one batched vector per lane on its other maps (register budget)
             for (int s = 0; s < n_maps; ++s)
-                if (P.maps[s].runs == 0 && (P.maps[s].unroll > 2 || P.maps[s].unroll < -2))
-                    pick_mapping(P.maps[s], P.maps[s].vw == 4, P.maps[s].vw >= 2, P.maps[s].unroll > 0, 2);
+                if (P.maps[s].runs == 0 && P.maps[s].unroll != 1)
+                    pick_mapping(P.maps[s], P.maps[s].vw == 4, P.maps[s].vw >= 2, true, 1);
     }
     // Points on a regular lattice (a d3f_grid, or d3f_eval_lattice's dims): the brick walk is closed form -- no keys, no
     // sort, no index array, no scratch -- and replaces the Morton sort wherever that would be used.  (With the cell-run
@@ -260,7 +269,11 @@ int eval_common(const d3f_views *views, const float *pts, int64_t n, const d3f_c
     } else if (reorder && !plan_only && (flags & D3F_FLAG_REUSE_POINT_ORDER)) {
         P.order = d3f::stored_point_order(workspace, n);       // written by an earlier call for the same points
     } else if (reorder && !plan_only) {
-        hipError_t eo = d3f::build_point_order(pts, n, workspace, workspace_bytes, &P.order, hs, (int)((flags >> 24) & 0x3));
+        // the cell-run gather lives on consecutive points sharing texel cells: sort clouds by 4-mm cells (27-bit keys,
+        // one more radix pass) instead of 16-mm ones (C4 patch 3.84 -> 3.38 ms, C2 patch random cloud 0.73 -> 0.66)
+        int fine = (int)((flags >> 24) & 0x3);
+        if (fine == 0 && any_runs) fine = 2;
+        hipError_t eo = d3f::build_point_order(pts, n, workspace, workspace_bytes, &P.order, hs, fine);
         if (eo != hipSuccess) return hip_fail(eo, "point ordering");
     }
     // Launch geometry (measured on MI355X):
@@ -280,7 +293,7 @@ int eval_common(const d3f_views *views, const float *pts, int64_t n, const d3f_c
             const bool forced = (flags & ((1u << 26) | (1u << 27))) != 0;
             if (!forced && m.unroll < 0 && (m.C / m.vw) <= 3 * 64) {
                 const bool a16 = m.vw == 4, a8 = m.vw >= 2;
-                pick_mapping(m, a16, a8, true, any_runs ? 2 : 4);
+                pick_mapping(m, a16, a8, true, any_runs ? 1 : 4);
             }
         }
         // one point per lane group: 8 points when every map takes 32 lanes per point, else 16
@@ -313,9 +326,10 @@ int eval_common(const d3f_views *views, const float *pts, int64_t n, const d3f_c
     if (any_runs) {
         int k = 8, lg = 6;
         for (int s = 0; s < n_maps; ++s)
-            if (P.maps[s].runs > 0) { k = P.maps[s].runs; lg = P.maps[s].lpp_log2 < lg ? P.maps[s].lpp_log2 : lg; }
-        P.tile_pts = (d3f::kBlock >> lg) * k;         // every lane group of the mapping with the most groups owns one run
-        while ((long)P.tile_pts * views->V * 88 > 40 * 1024 && P.tile_pts > 16) P.tile_pts >>= 1;   // records + 2 corner slots
+            if (P.maps[s].runs > 0) { k = P.maps[s].runs; lg = P.maps[s].lpp_log2; }
+        const int round = (d3f::kBlock >> lg) * k;    // one run per lane group
+        P.tile_pts = round < 64 ? 64 : round;         // >= 64 points per workgroup (a lane group then takes several runs)
+        while ((long)P.tile_pts * views->V * 88 > 40 * 1024 && P.tile_pts > round) P.tile_pts >>= 1;   // records + 2 corner slots
         P.lds_pad = 0;
     }
     // walks: all eight XCDs stay inside one macro-brick of ~32 k points at a time (its texel footprint stays in

@@ -390,18 +390,20 @@ __device__ __forceinline__ void gather_map_wave_staged(const MapDesc &m, const E
 // ---- phase B, cell-run gather (patch-resolution wide maps) ------------------------------------------------
 // When a texel spans many image pixels (the reference's dino_feats is (H/10, W/10), fusion.py:694-697) consecutive
 // query points of a grid column / a Morton walk fall into the SAME texel cell of a view most of the time, and the
-// direct gather above is bound by the vector-L1 request rate (64 B/clk/CU), not by misses.  Here a lane group owns a
-// RUN of K consecutive points and ONE 16-byte channel vector per lane, and walks the run view by view: the four corner
-// vectors of a view stay in registers (16 VGPRs) and are re-fetched only when the cell changes; the K accumulators
-// (4 VGPRs each) carry the view sums.  Per (point, view) the operations and their order are exactly those of
-// gather_map's fast path -- acc += (fma chain over nw,ne,sw,se) * wgt in view order, then the shared-reciprocal
-// division -- so the results are bit-identical.  Points that need the strict path (non-finite projection) are left to
-// gather_map(only_strict).  One vector per lane keeps the kernel at >= 5 waves per SIMD, which the register cell-run
-// experiment of round 1 (3 vectors per lane, 4-point runs, 167-179 VGPR) could not.
-template <int K>
+// direct gather above is limited by the vector-L1 request rate (64 B/clk/CU), not by misses.  Here a lane group owns a
+// RUN of K consecutive points and U 16-byte channel vectors per lane, and walks the run view by view: the four corner
+// vectors of a view stay in registers and are re-fetched only when the cell changes (a flag phase A computes once per
+// (point, view) by comparing the four corner offsets with the previous point's); the K accumulators carry the view
+// sums.  Per (point, view) the operations and their order are exactly those of gather_map's fast path -- acc +=
+// (fma chain over nw,ne,sw,se) * wgt in view order, then the shared-reciprocal division -- so the results are
+// bit-identical.  Points that need the strict path (non-finite projection) are left to gather_map(only_strict).
+constexpr uint32_t kRunNonFinite = 1u;     // bits of the per-(point, view) state word (nfp_s)
+constexpr uint32_t kRunNewCell = 2u;       // the four corner texels differ from those of the previous point of the run
+
+template <int U, int K>
 __device__ __forceinline__ void gather_map_runs(const MapDesc &m, const EvalParams &P, const ViewRec *rec,
-                                                const float *cnt_s, const uint32_t *flag_s, const uint32_t *idx_s,
-                                                int64_t idx_base, int tile_n, const CornerRec *crec)
+                                                const uint32_t *state_s, const float *cnt_s, const uint32_t *flag_s,
+                                                const uint32_t *idx_s, int64_t idx_base, int tile_n, const CornerRec *crec)
 {
     using VT = f32x4;
     const int lpp = 1 << m.lpp_log2;
@@ -413,61 +415,83 @@ __device__ __forceinline__ void gather_map_runs(const MapDesc &m, const EvalPara
     const char *__restrict__ data = reinterpret_cast<const char *>(m.data);
 
     for (int run0 = grp * K; run0 < tile_n; run0 += ngrp * K) {
-        for (int c0 = 0; c0 < cvec; c0 += lpp) {
-            const int cv = c0 + g;
-            const uint32_t co = (uint32_t)min(cv, cvec - 1) * 16u;      // idle lanes re-read the last vector
-            VT acc[K];
+        uint32_t live = 0u;                         // bit k: point run0+k exists and takes the fast path
 #pragma unroll
-            for (int k = 0; k < K; ++k) acc[k] = (VT)0.0f;
+        for (int k = 0; k < K; ++k)
+            if (run0 + k < tile_n && flag_s[run0 + k] == 0u) live |= 1u << k;
+        for (int c0 = 0; c0 < cvec; c0 += lpp * U) {
+            uint32_t co[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) co[u] = (uint32_t)min(c0 + u * lpp + g, cvec - 1) * 16u;   // idle lanes re-read the last vector
+            VT acc[K][U];
+#pragma unroll
+            for (int k = 0; k < K; ++k)
+#pragma unroll
+                for (int u = 0; u < U; ++u) acc[k][u] = (VT)0.0f;
             for (int v = 0; v < V; ++v) {
                 const char *bv = data + (int64_t)v * m.sv * 4;
-                uint32_t p0 = 0xffffffffu, p1 = 0xffffffffu, p2 = 0xffffffffu, p3 = 0xffffffffu;
-                VT a = (VT)0.0f, b = (VT)0.0f, d = (VT)0.0f, e = (VT)0.0f;
+                VT a[U], b[U], d[U], e[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) { a[u] = (VT)0.0f; b[u] = (VT)0.0f; d[u] = (VT)0.0f; e[u] = (VT)0.0f; }
+                bool have = false;                  // corner registers hold the cell of the last processed point
 #pragma unroll
                 for (int k = 0; k < K; ++k) {
-                    const int p = run0 + k;
-                    if (p >= tile_n) break;
-                    const ViewRec r = rec[p * V + v];
-                    if (r.valid == 0.0f || flag_s[p] != 0u) continue;   // exact skip (see gather_map); strict points later
-                    const CornerRec cr = crec[p * V + v];
-                    if (cr.o[0] != p0 || cr.o[1] != p1 || cr.o[2] != p2 || cr.o[3] != p3) {     // another texel cell
-                        p0 = cr.o[0]; p1 = cr.o[1]; p2 = cr.o[2]; p3 = cr.o[3];
-                        a = load_texel<4, false>(bv + (p0 + co));
-                        b = load_texel<4, false>(bv + (p1 + co));
-                        d = load_texel<4, false>(bv + (p2 + co));
-                        e = load_texel<4, false>(bv + (p3 + co));
+                    const int q = (run0 + k) * V + v;
+                    const ViewRec r = rec[min(q, tile_n * V - 1)];
+                    if ((live >> k & 1u) && r.valid != 0.0f) {       // exact skip of invalid views (see gather_map)
+                        const CornerRec cr = crec[q];
+                        if (!have || (state_s[q] & kRunNewCell)) {
+#pragma unroll
+                            for (int u = 0; u < U; ++u) {
+                                a[u] = load_texel<4, false>(bv + (cr.o[0] + co[u]));
+                                b[u] = load_texel<4, false>(bv + (cr.o[1] + co[u]));
+                                d[u] = load_texel<4, false>(bv + (cr.o[2] + co[u]));
+                                e[u] = load_texel<4, false>(bv + (cr.o[3] + co[u]));
+                            }
+                        }
+                        have = true;
+#pragma unroll
+                        for (int u = 0; u < U; ++u) {
+                            VT s = a[u] * cr.w[0];                       // ATen bilinear: fma chain nw,ne,sw,se
+                            s = v_fma<VT>(b[u], cr.w[1], s);
+                            s = v_fma<VT>(d[u], cr.w[2], s);
+                            s = v_fma<VT>(e[u], cr.w[3], s);
+                            acc[k][u] = acc[k][u] + s * r.wgt;           // fusion.py:385
+                        }
+                    } else {
+                        have = false;       // the chain of "same cell as the previous point" flags is broken here
                     }
-                    VT s = a * cr.w[0];                                  // ATen bilinear: fma chain nw,ne,sw,se
-                    s = v_fma<VT>(b, cr.w[1], s);
-                    s = v_fma<VT>(d, cr.w[2], s);
-                    s = v_fma<VT>(e, cr.w[3], s);
-                    acc[k] = acc[k] + s * r.wgt;                         // fusion.py:385
                 }
             }
 #pragma unroll
             for (int k = 0; k < K; ++k) {
+                if (!(live >> k & 1u)) continue;
                 const int p = run0 + k;
-                if (p >= tile_n) break;
-                if (flag_s[p] != 0u || cv >= cvec) continue;
                 const float cnt = cnt_s[p];
                 const float denom = cnt + 1e-6f;                          // fusion.py:385
-                VT o = (VT)0.0f;                                          // fusion.py:386 when no view is valid
-                if (cnt != 0.0f) {
-                    // the shared-reciprocal IEEE division of gather_map's fast path (bit-identical quotients)
-                    const float r0 = __builtin_amdgcn_rcpf(denom);
-                    const float rcp_d = fmaf(fmaf(-denom, r0, 1.0f), r0, r0);
-                    VT q = acc[k] * rcp_d;
-                    q = v_fma<VT>(v_fma<VT>(q, -denom, acc[k]), rcp_d, q);
-                    q = v_fma<VT>(v_fma<VT>(q, -denom, acc[k]), rcp_d, q);
-                    o = q;
+                // the shared-reciprocal IEEE division of gather_map's fast path (bit-identical quotients)
+                const float r0 = __builtin_amdgcn_rcpf(denom);
+                const float rcp_d = fmaf(fmaf(-denom, r0, 1.0f), r0, r0);
+                const int64_t row = (idx_base + idx_s[p]) * m.C;
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int cv = c0 + u * lpp + g;
+                    if (cv >= cvec) continue;
+                    VT o = (VT)0.0f;                                      // fusion.py:386 when no view is valid
+                    if (cnt != 0.0f) {
+                        VT q = acc[k][u] * rcp_d;
+                        q = v_fma<VT>(v_fma<VT>(q, -denom, acc[k][u]), rcp_d, q);
+                        q = v_fma<VT>(v_fma<VT>(q, -denom, acc[k][u]), rcp_d, q);
+                        o = q;
+                    }
+                    store_vec<VT>(m.out + row + (int64_t)cv * 4, o);
                 }
-                store_vec<VT>(m.out + (idx_base + idx_s[p]) * m.C + (int64_t)cv * 4, o);
             }
         }
     }
 }
 
-// SMALL: the cell-run kernel keeps <= 96 VGPRs; its other maps (the mask, colours) are mapped to <= 2 vectors per lane
+// SMALL: the cell-run kernel keeps <= 96 VGPRs; its other maps (the mask, colours) are mapped to one vector per lane, batched
 template <int VW, bool WIDE, bool SMALL = false>
 __device__ __forceinline__ void gather_map_u(const MapDesc &m, const EvalParams &P, const ViewRec *rec,
                                              const float *cnt_s, const uint32_t *flag_s,
@@ -475,10 +499,10 @@ __device__ __forceinline__ void gather_map_u(const MapDesc &m, const EvalParams 
 {
     switch (m.unroll) {
     case 1: gather_map<VW, 1, true>(m, P, rec, cnt_s, flag_s, idx_s, idx_base, tile_n, crec); break;
-    case 2: gather_map<VW, 2, true>(m, P, rec, cnt_s, flag_s, idx_s, idx_base, tile_n, crec); break;
+    case 2: if (!SMALL) gather_map<VW, 2, true>(m, P, rec, cnt_s, flag_s, idx_s, idx_base, tile_n, crec); break;
     case 3: if (!SMALL) gather_map<VW, 3, true>(m, P, rec, cnt_s, flag_s, idx_s, idx_base, tile_n, crec); break;
-    case -1: gather_map<VW, 1, false>(m, P, rec, cnt_s, flag_s, idx_s, idx_base, tile_n, crec); break;
-    case -2: gather_map<VW, 2, false>(m, P, rec, cnt_s, flag_s, idx_s, idx_base, tile_n, crec); break;
+    case -1: if (!SMALL) gather_map<VW, 1, false>(m, P, rec, cnt_s, flag_s, idx_s, idx_base, tile_n, crec); break;
+    case -2: if (!SMALL) gather_map<VW, 2, false>(m, P, rec, cnt_s, flag_s, idx_s, idx_base, tile_n, crec); break;
     case -3: if (!SMALL) gather_map<VW, 3, false>(m, P, rec, cnt_s, flag_s, idx_s, idx_base, tile_n, crec); break;
     default:
         if (WIDE) gather_map<VW, 4, false>(m, P, rec, cnt_s, flag_s, idx_s, idx_base, tile_n, crec);
@@ -583,9 +607,10 @@ __device__ __forceinline__ int64_t walk_point(const EvalParams &P, const TileBox
 }
 
 // STAGED: compiled with the LDS-window gather (more registers); the plain kernel keeps 4 waves/SIMD.
-template <int MODE, bool STAGED, bool WIDE, bool ANYF16 = false, bool RUNS = false>
+template <int MODE, bool STAGED, bool WIDE, bool ANYF16 = false, int RU = 0, int RK = 0>
 __device__ __forceinline__ void fused_eval_body(const EvalParams &P)
 {
+    constexpr bool RUNS = RU > 0;
     extern __shared__ __align__(16) unsigned char smem[];
     const int V = P.V;
     const int TP = P.tile_pts;
@@ -667,7 +692,22 @@ __device__ __forceinline__ void fused_eval_body(const EvalParams &P)
                 crec_s[(size_t)m.pre_slot * TP * V + p * V + v] = cr;
             }
         }
-        nfp_s[p * V + v] = !(isfinite(o.gx) && isfinite(o.gy) && isfinite(wgt)) ? 1u : 0u;
+        uint32_t st = !(isfinite(o.gx) && isfinite(o.gy) && isfinite(wgt)) ? kRunNonFinite : 0u;
+        if (RUNS) {
+            // cell-run gather: does this pair address the same four texels (of the first cell-run map) as the previous
+            // point of the tile?  The previous point is the previous lane (idx = v*tile_n + p); it counts only if it
+            // is valid too -- an invalid or strict predecessor is handled by the consumer (the chain breaks there).
+            uint32_t o0 = 0u, o1 = 0u, o2 = 0u, o3 = 0u;
+            if (o.valid != 0.0f) {
+                const CornerRec &cr = crec_s[p * V + v];        // slot 0 = the first cell-run map (written just above)
+                o0 = cr.o[0]; o1 = cr.o[1]; o2 = cr.o[2]; o3 = cr.o[3];
+            }
+            const uint32_t q0 = __shfl_up(o0, 1, 64), q1 = __shfl_up(o1, 1, 64), q2 = __shfl_up(o2, 1, 64), q3 = __shfl_up(o3, 1, 64);
+            const float pv = __shfl_up(o.valid, 1, 64);
+            const bool same = (threadIdx.x & 63) != 0 && p != 0 && pv != 0.0f && q0 == o0 && q1 == o1 && q2 == o2 && q3 == o3;
+            if (!same) st |= kRunNewCell;
+        }
+        nfp_s[p * V + v] = st;
     }
     __syncthreads();
     // per point: sums over the views in view order (fusion.py:364-370), outputs leave coalesced
@@ -679,7 +719,7 @@ __device__ __forceinline__ void fused_eval_body(const EvalParams &P)
         for (int v = 0; v < V; ++v) {
             dsum = dsum + dcl_s[p * V + v];
             cnt = cnt + rec[p * V + v].valid;
-            nonfinite |= nfp_s[p * V + v];
+            nonfinite |= nfp_s[p * V + v] & kRunNonFinite;
         }
         const bool all_invalid = (cnt == 0.0f);                             // fusion.py:366
         float dist_out = dsum / (cnt + 1e-6f);
@@ -708,9 +748,8 @@ __device__ __forceinline__ void fused_eval_body(const EvalParams &P)
         if (RUNS && m.runs > 0) {
             // non-strict points through the cell-run gather, the (rare) strict ones through the generic path
             // (the host gives such a map 16-byte vectors, one per lane, and a corner-record slot)
-            if (m.runs == 4) gather_map_runs<4>(m, P, rec, cnt_s, flag_s, idx_s, idx_base, tile_n, crec);
-            else gather_map_runs<8>(m, P, rec, cnt_s, flag_s, idx_s, idx_base, tile_n, crec);
-            gather_map<4, 1, true>(m, P, rec, cnt_s, flag_s, idx_s, idx_base, tile_n, crec, true);
+            gather_map_runs<(RU > 0 ? RU : 1), (RK > 0 ? RK : 1)>(m, P, rec, nfp_s, cnt_s, flag_s, idx_s, idx_base, tile_n, crec);
+            gather_map<4, (RU > 0 ? RU : 1), true>(m, P, rec, cnt_s, flag_s, idx_s, idx_base, tile_n, crec, true);
             continue;
         }
         if (ANYF16 && m.esize == 2) {
@@ -745,12 +784,16 @@ __global__ __launch_bounds__(kBlock) void fused_eval_f16_kernel(const EvalParams
 template <int MODE>
 __global__ __launch_bounds__(kBlock) void fused_eval_staged_kernel(const EvalParams P) { fused_eval_body<MODE, true, true>(P); }
 
-// cell-run gather for patch-resolution wide maps: one channel vector per lane (104 VGPR = 4 waves per SIMD; the
-// variant held to 5 waves per SIMD spills 6 registers -- experiment knob D3F_EXP_RUNS_OCC=5)
-template <int MODE>
-__global__ __launch_bounds__(kBlock) void fused_eval_runs_kernel(const EvalParams P) { fused_eval_body<MODE, false, false, false, true>(P); }
-template <int MODE>
-__global__ __launch_bounds__(kBlock, 5) void fused_eval_runs5_kernel(const EvalParams P) { fused_eval_body<MODE, false, false, false, true>(P); }
+// cell-run gather for patch-resolution wide maps, one entry point per (vectors per lane, run length) so that every
+// variant gets its own register allocation: <1,8> one vector per lane and 8-point runs, held to 5 waves per SIMD (the
+// default: fastest on every patch-resolution workload measured, MI355X r2c: C2 0.724 -> 0.645 ms, C3 1.544 -> 1.338,
+// C4 4.13 -> 3.82); <3,4> / <3,2> the 3-vector mapping of C = 384 with 4- / 2-point runs and <2,4> / <2,8> two vectors
+// per lane are kept as experiment variants (they spill at 4 waves per SIMD and measured 2-5 % slower).
+template <int MODE, int RU, int RK, int WAVES>
+__global__ __launch_bounds__(kBlock, WAVES) void fused_eval_runs_kernel(const EvalParams P)
+{
+    fused_eval_body<MODE, false, false, false, RU, RK>(P);
+}
 
 hipError_t launch_fused_eval(const EvalParams &P, int mode, hipStream_t stream)
 {
@@ -767,10 +810,19 @@ hipError_t launch_fused_eval(const EvalParams &P, int mode, hipStream_t stream)
         f16 |= (P.maps[s].esize == 2);
         runs |= (P.maps[s].runs > 0);
     }
-    if (mode == 0 && runs && !f16 && !wide && P.stage_floats == 0 && P.runs_occ == 5)
-        hipLaunchKernelGGL((fused_eval_runs5_kernel<0>), grid, block, lds, stream, P);
-    else if (mode == 0 && runs && !f16 && !wide && P.stage_floats == 0)
-        hipLaunchKernelGGL((fused_eval_runs_kernel<0>), grid, block, lds, stream, P);
+    if (mode == 0 && runs && !f16 && !wide && P.stage_floats == 0) {
+        int ru = 1, rk = 8;
+        for (int s = 0; s < P.n_maps; ++s)
+            if (P.maps[s].runs > 0) { ru = P.maps[s].unroll; rk = P.maps[s].runs; }
+        if (ru == 3 && rk == 4) hipLaunchKernelGGL((fused_eval_runs_kernel<0, 3, 4, 4>), grid, block, lds, stream, P);
+        else if (ru == 3 && rk == 2) hipLaunchKernelGGL((fused_eval_runs_kernel<0, 3, 2, 4>), grid, block, lds, stream, P);
+        else if (ru == 2 && rk == 4) hipLaunchKernelGGL((fused_eval_runs_kernel<0, 2, 4, 4>), grid, block, lds, stream, P);
+        else if (ru == 2 && rk == 8) hipLaunchKernelGGL((fused_eval_runs_kernel<0, 2, 8, 4>), grid, block, lds, stream, P);
+        else if (ru == 1 && rk == 4) hipLaunchKernelGGL((fused_eval_runs_kernel<0, 1, 4, 6>), grid, block, lds, stream, P);
+        else if (P.runs_occ == 4) hipLaunchKernelGGL((fused_eval_runs_kernel<0, 1, 8, 4>), grid, block, lds, stream, P);
+        else if (P.runs_occ == 6) hipLaunchKernelGGL((fused_eval_runs_kernel<0, 1, 8, 6>), grid, block, lds, stream, P);
+        else hipLaunchKernelGGL((fused_eval_runs_kernel<0, 1, 8, 5>), grid, block, lds, stream, P);
+    }
     else if (mode == 0 && f16)
         hipLaunchKernelGGL((fused_eval_f16_kernel<0>), grid, block, lds, stream, P);
     else if (mode == 0 && P.stage_floats > 0)

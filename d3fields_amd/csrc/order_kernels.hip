@@ -141,57 +141,59 @@ __global__ __launch_bounds__(kBlock) void point_locality_kernel(const float *__r
 // first column / row / plane.  out = (nx, ny, nz), or zeros when the array is not such a lattice.  The answer only
 // steers the walk order of d3f_eval_lattice (coordinates are always read from pts), so a wrong answer costs time only.
 constexpr int kProbeSpan = 1 << 16;      // axes longer than this are not recognised
+constexpr int kProbeBlocks = 16;         // 16 x 256 threads: one sample per thread
 
+// first i in [1, count) with !(a[i*stride] > a[(i-1)*stride]) for coordinate `axis`, or count; whole workgroup
+__device__ __forceinline__ int first_restart(const float *__restrict__ pts, int64_t stride, int64_t count, int axis, int *first_s)
+{
+    const int span = (int)min((int64_t)kProbeSpan, count);
+    if (threadIdx.x == 0) *first_s = span;
+    __syncthreads();
+    for (int base = 1; base < span; base += kBlock) {
+        const int i = base + threadIdx.x;
+        if (i < span && !(pts[(int64_t)i * stride * 3 + axis] > pts[(int64_t)(i - 1) * stride * 3 + axis])) atomicMin(first_s, i);
+        __syncthreads();
+        if (*first_s < base + kBlock) break;            // found inside this chunk (uniform: read after the barrier)
+    }
+    __syncthreads();
+    const int found = *first_s;
+    __syncthreads();
+    return found;
+}
+
+// out[0..2] = dims (written by workgroup 0), out[3] |= 1 by any workgroup whose samples contradict the lattice.
+// The caller zeroes out[3] before the launch and accepts the dims only when out[0] > 0 and out[3] == 0.
 __global__ __launch_bounds__(kBlock) void lattice_probe_kernel(const float *__restrict__ pts, int64_t n, int32_t *__restrict__ out)
 {
     __shared__ int first_s;
-    __shared__ int bad_s;
-    int nz = 0, ny = 0;
-    for (int axis = 2; axis >= 1; --axis) {
-        const int64_t stride = axis == 2 ? 1 : nz;
-        const int64_t count = axis == 2 ? n : n / nz;
-        const int span = (int)min((int64_t)kProbeSpan, count);
-        if (threadIdx.x == 0) first_s = span;
-        __syncthreads();
-        for (int i = 1 + threadIdx.x; i < span; i += kBlock) {
-            if (i >= first_s) break;
-            if (!(pts[(int64_t)i * stride * 3 + axis] > pts[(int64_t)(i - 1) * stride * 3 + axis])) atomicMin(&first_s, i);
-        }
-        __syncthreads();
-        const int found = first_s;
-        __syncthreads();
-        if (axis == 2) nz = found; else ny = found;
-        if (found < 2 || (axis == 2 && n % found != 0)) { nz = 0; break; }
-    }
+    int nz = n >= 2 ? first_restart(pts, 1, n, 2, &first_s) : 0;
+    bool ok = nz >= 2 && n % nz == 0;
+    int ny = ok ? first_restart(pts, nz, n / nz, 1, &first_s) : 0;
+    ok = ok && ny >= 1 && (n / nz) % ny == 0 && (ny >= 2 || n / nz == 1);
     int64_t nx = 0;
-    bool ok = nz >= 2 && ny >= 2 && (n % ((int64_t)nz * ny) == 0);
     if (ok) {
         nx = n / ((int64_t)nz * ny);
         ok = nx >= 1 && nx <= 0x7fffffffLL;
     }
-    if (threadIdx.x == 0) bad_s = 0;
-    __syncthreads();
-    if (ok) {
-        const int samples = (int)min((int64_t)kProbeSamples, n);
-        for (int k = threadIdx.x; k < samples; k += kBlock) {
-            const int64_t i = (int64_t)((double)k * (double)(n - 1) / (double)max(samples - 1, 1));
-            const int64_t iz = i % nz, ixy = i / nz, iy = ixy % ny, ix = ixy / ny;
-            const uint32_t *p = reinterpret_cast<const uint32_t *>(pts);
-            const bool same = p[i * 3 + 2] == p[iz * 3 + 2] && p[i * 3 + 1] == p[iy * nz * 3 + 1] &&
-                              p[i * 3 + 0] == p[ix * ny * nz * 3 + 0];
-            if (!same) bad_s = 1;
-        }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        out[0] = ok ? (int32_t)nx : 0; out[1] = ok ? ny : 0; out[2] = ok ? nz : 0;
     }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const bool good = ok && bad_s == 0;
-        out[0] = good ? (int32_t)nx : 0; out[1] = good ? ny : 0; out[2] = good ? nz : 0;
+    if (!ok) return;
+    const int64_t samples = min((int64_t)kProbeBlocks * kBlock, n);
+    const int64_t k = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (k < samples) {
+        const int64_t i = samples > 1 ? (int64_t)((double)k * (double)(n - 1) / (double)(samples - 1)) : 0;
+        const int64_t iz = i % nz, ixy = i / nz, iy = ixy % ny, ix = ixy / ny;
+        const uint32_t *p = reinterpret_cast<const uint32_t *>(pts);
+        const bool same = p[i * 3 + 2] == p[iz * 3 + 2] && p[i * 3 + 1] == p[iy * nz * 3 + 1] &&
+                          p[i * 3 + 0] == p[ix * ny * nz * 3 + 0];
+        if (!same) atomicOr(&out[3], 1);
     }
 }
 
 hipError_t launch_lattice_probe(const float *pts, int64_t n, int32_t *out_dims, hipStream_t stream)
 {
-    hipLaunchKernelGGL(lattice_probe_kernel, dim3(1), dim3(kBlock), 0, stream, pts, n, out_dims);
+    hipLaunchKernelGGL(lattice_probe_kernel, dim3(kProbeBlocks), dim3(kBlock), 0, stream, pts, n, out_dims);
     return hipGetLastError();
 }
 

@@ -329,10 +329,10 @@ class Fusion:
         if hit is None or hit[0] != sig:
             if torch.cuda.is_current_stream_capturing():
                 return None                     # no host sync inside a HIP-graph capture
-            out = torch.empty(3, dtype=torch.int32, device=pts_c.device)
+            out = torch.zeros(4, dtype=torch.int32, device=pts_c.device)
             _lib.check(self._lib.d3f_lattice_probe(_lib.ptr(pts_c), pts_c.shape[0], _lib.ptr(out), stream))
-            dims = tuple(int(v) for v in out.tolist())
-            hit = (sig, dims if dims[0] > 0 else None)
+            got = [int(v) for v in out.tolist()]
+            hit = (sig, tuple(got[:3]) if (got[0] > 0 and got[3] == 0) else None)
             self._lattice_cache = hit
         return hit[1]
 

@@ -180,9 +180,11 @@ int d3f_eval_plan_query_lattice(const d3f_views *views, int32_t nx, int32_t ny, 
                                 int32_t n_maps, uint32_t flags, int32_t want_inter, d3f_eval_plan *plan);
 
 /* Is pts[n,3] a z-fastest lattice (every point = (x[ix], y[iy], z[iz]) with strictly increasing axes, flat index
- * (ix*ny + iy)*nz + iz: the layout of create_init_grid, fusion.py:79-88)?  One workgroup finds where the z and y
- * axes restart and spot-checks <= 4096 points; out_dims: 3 DEVICE int32 = (nx, ny, nz), zeros when it is not (or an
- * axis is longer than 65536).  The shim feeds the answer to d3f_eval_lattice, where it only selects the walk order. */
+ * (ix*ny + iy)*nz + iz: the layout of create_init_grid, fusion.py:79-88)?  Sixteen workgroups find where the z and y
+ * axes restart and 4096 evenly spaced points are compared with the implied axis values.  out_dims: FOUR device int32,
+ * the caller zeroes out_dims[3] before the call; afterwards (nx, ny, nz) = out_dims[0..2] is a lattice iff out_dims[0] > 0
+ * and out_dims[3] == 0 (axes longer than 65536 are not recognised).  The shim feeds the answer to d3f_eval_lattice,
+ * where it only selects the walk order. */
 int d3f_lattice_probe(const float *pts, int64_t n, int32_t *out_dims, void *stream);
 
 /* Pre-filter of select_features_* (fusion.py:1430,1444): flat indices of the grid points with

@@ -388,6 +388,7 @@ def test_point_order_probe_and_unordered_walk(dev):
     maps = {"dino_feats": synth.random_map(V, 12, 16, 96, seed=1), "mask": synth.random_onehot_mask(V, H, W, 5, seed=2)}
     f = make_fusion(dev, sc["depth"], sc["K"], sc["pose"], maps, H, W)
     names = ["dino_feats", "mask"]
+    f.detect_lattice = False                    # this test is about the locality probe of NON-lattice inputs
     for pts, unordered in ((cloud, True), (grid[:150000], False)):
         p = pts.to(dev)
         f.detect_point_order = True

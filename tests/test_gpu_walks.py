@@ -167,22 +167,26 @@ def test_cell_run_gather_is_bit_identical(dev, C, V, fhw, mask, points):
     m = maps["dino_feats"]
     cm = (_lib.ChannelMap * 1)(_lib.ChannelMap(m.data_ptr(), m.shape[1], m.shape[2], C, 0, m.stride(0), m.stride(1), m.stride(2)))
     _lib.check(f._lib.d3f_eval_plan_query(ctypes.byref(views), pts.shape[0], cm, 1, _lib.FLAG_FINITE_MAPS, 1, 0, ctypes.byref(plan)))
-    assert plan.staged[0] == 16 + 8, "the cell-run gather must be what runs here"
+    assert plan.staged[0] > 16, "the cell-run gather must be what runs here"
+    variants = (("direct", dict(D3F_EXP_RUNS=-1)), ("auto", dict(D3F_EXP_RUNS=0)), ("u1k8", dict(D3F_EXP_RUNS_U=1)),
+                ("u1k8occ4", dict(D3F_EXP_RUNS_U=1, D3F_EXP_RUNS=8, D3F_EXP_RUNS_OCC=4)), ("u1k8occ6", dict(D3F_EXP_RUNS_U=1, D3F_EXP_RUNS=8, D3F_EXP_RUNS_OCC=6)),
+                ("u1k4", dict(D3F_EXP_RUNS_U=1, D3F_EXP_RUNS=4)), ("u1k8", dict(D3F_EXP_RUNS_U=1, D3F_EXP_RUNS=8)), ("u3k2", dict(D3F_EXP_RUNS_U=3, D3F_EXP_RUNS=2)),
+                ("u3k4", dict(D3F_EXP_RUNS_U=3, D3F_EXP_RUNS=4)), ("u2k4", dict(D3F_EXP_RUNS_U=2, D3F_EXP_RUNS=4)),
+                ("u2k8", dict(D3F_EXP_RUNS_U=2, D3F_EXP_RUNS=8)))
     with torch.no_grad():
         outs = {}
-        for tag, env in (("direct", dict(D3F_EXP_RUNS=-1)), ("runs8", dict(D3F_EXP_RUNS=0)), ("runs4", dict(D3F_EXP_RUNS=4)),
-                         ("runs8_occ5", dict(D3F_EXP_RUNS=8, D3F_EXP_RUNS_OCC=5))):
+        for tag, env in variants:
             with knobs(**env):
                 outs[tag] = f.batch_eval(pts, return_names=names)
-    for tag in ("runs8", "runs4", "runs8_occ5"):
+    for tag in [t for t, _ in variants[1:]]:
         for k in outs["direct"]:
             a, b = outs[tag][k], outs["direct"][k]
             assert torch.equal(torch.isnan(a), torch.isnan(b)) and torch.equal(torch.nan_to_num(a.float()), torch.nan_to_num(b.float())), (tag, k)
     pick = torch.randperm(pts.shape[0], generator=torch.Generator().manual_seed(3))[:1500]
     pick = pick[pick != 1000]
     ref = oracle_sample(sc, pts_c[pick], [maps[k] for k in names])
-    assert np.array_equal(cpu(outs["runs8"]["dist"])[pick], ref["dist"])
-    assert rel_err(cpu(outs["runs8"]["dino_feats"])[pick], ref["sets"][0]) <= TOL
+    assert np.array_equal(cpu(outs["auto"]["dist"])[pick], ref["dist"])
+    assert rel_err(cpu(outs["auto"]["dino_feats"])[pick], ref["sets"][0]) <= TOL
 
 
 def test_cell_run_gather_not_used_when_it_must_not(dev):
@@ -196,7 +200,7 @@ def test_cell_run_gather_not_used_when_it_must_not(dev):
     views, keep, _ = f._views(dev)
     cm = (_lib.ChannelMap * 1)(_lib.ChannelMap(feats.data_ptr(), 48, 64, C, 0, feats.stride(0), feats.stride(1), feats.stride(2)))
     plan = _lib.EvalPlan()
-    for flags, inter, want in ((_lib.FLAG_FINITE_MAPS, 0, 24), (0, 0, 0), (_lib.FLAG_FINITE_MAPS, 1, 0)):
+    for flags, inter, want in ((_lib.FLAG_FINITE_MAPS, 0, 16 + 4), (0, 0, 0), (_lib.FLAG_FINITE_MAPS, 1, 0)):
         _lib.check(f._lib.d3f_eval_plan_query(ctypes.byref(views), 200000, cm, 1, flags, 1, inter, ctypes.byref(plan)))
         assert plan.staged[0] == want, (flags, inter)
     _lib.check(f._lib.d3f_eval_plan_query(ctypes.byref(views), 3000, cm, 1, _lib.FLAG_FINITE_MAPS, 1, 0, ctypes.byref(plan)))
