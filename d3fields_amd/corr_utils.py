@@ -129,3 +129,32 @@ def nearest_descriptor(src_feat_map, tgt_feats, scale=1.0, dist_type="l2"):
     same launch sequence.  Returns (similarity [B1,B2], index [B2] int64)."""
     assert src_feat_map.shape[1] == tgt_feats.shape[1]
     return _pairwise(src_feat_map, tgt_feats, scale, dist_type, _lib.SIM_SOFTMAX_DIM0, True)
+
+
+def knn_descriptors(src_feat_map, tgt_feats, k, scale=1.0, dist_type="l2"):
+    """Build-defined extension (the north star's "KNN correspondence lookup"): for every target
+    descriptor the k (<= 8) nearest source descriptors, i.e. the k-NN generalisation of the reference's best match
+    ``compute_similarity_tensor_multi(...).argmax(0)``.  Returns (similarity [B1,B2] -- the reference's softmax matrix,
+    index [k,B2] int64 with row j = the j-th nearest source row, similarity at those rows [k,B2]).  Neighbours are
+    ranked by distance (ties -> lower row index); one launch sequence, no [B1,B2,C] tensor, no torch.topk pass."""
+    assert src_feat_map.shape[1] == tgt_feats.shape[1]
+    if not 1 <= int(k) <= 8:
+        raise ValueError("k must be in [1, 8]")
+    code = _dist_code(dist_type)
+    _need_cuda(src_feat_map, "src_feat_map")
+    dev = src_feat_map.device
+    src = src_feat_map.to(torch.float32).contiguous()
+    tgt = tgt_feats.to(device=dev, dtype=torch.float32).contiguous()
+    B1, C = src.shape
+    B2 = tgt.shape[0]
+    lib = _lib.load()
+    out = torch.empty((B1, B2), dtype=torch.float32, device=dev)
+    idx = torch.empty((int(k), B2), dtype=torch.int64, device=dev)
+    val = torch.empty((int(k), B2), dtype=torch.float32, device=dev)
+    ws_bytes = lib.d3f_pairwise_topk_workspace_bytes(B1, B2)
+    ws = torch.empty(max(ws_bytes, 16), dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(lib.d3f_pairwise_similarity_topk(_lib.ptr(src), _lib.ptr(tgt), B1, B2, C, float(scale), code,
+                                                    _lib.SIM_SOFTMAX_DIM0, int(k), _lib.ptr(out), _lib.ptr(idx), _lib.ptr(val),
+                                                    _lib.ptr(ws), ws_bytes, _lib.current_stream_handle(dev)))
+    return out, idx, val

@@ -412,4 +412,126 @@ hipError_t launch_argmin_dim0(const float *x, int64_t rows, int64_t cols, int64_
     return softmax_impl(const_cast<float *>(x), rows, cols, 1.0f, arg_out, ws, false, have_stats, s);
 }
 
+// ---- k nearest descriptors per target column (k <= 8) ------------------------------------------------------------------
+// The north star names a "KNN correspondence lookup"; the reference has none: its best match is
+// compute_similarity_tensor_multi(...).argmax(0), i.e. the smallest distance of a column.  The k-NN extension keeps that
+// definition: per column of the [rows, cols] DISTANCE matrix the k smallest entries, ties -> lower row index, NaN last;
+// selection happens on the distances, before exp()/softmax can round neighbours into ties.
+// Two steps, both reading the matrix row-wise (lanes = consecutive columns, coalesced):
+//   topk_chunk_kernel  64 columns x 256 rows per workgroup; thread (c, r) scans rows r, r+4, ... with an 8-entry sorted
+//                      list in registers, the four row lanes of a column merge through LDS -> 8 candidates per chunk;
+//   topk_merge_kernel  the same scan over the candidates of all chunks of a column.
+constexpr int kTopK = 8;
+constexpr int kTopkRows = 256;
+
+struct Cand {
+    float v;
+    int32_t i;
+};
+
+__device__ __forceinline__ bool cand_before(float v, int32_t i, const Cand &o) { return v < o.v || (v == o.v && i < o.i); }
+
+__device__ __forceinline__ void cand_insert(Cand (&best)[kTopK], float v, int32_t i)
+{
+    if (!cand_before(v, i, best[kTopK - 1])) return;
+    best[kTopK - 1].v = v; best[kTopK - 1].i = i;
+#pragma unroll
+    for (int j = kTopK - 1; j > 0; --j) {
+        if (cand_before(best[j].v, best[j].i, best[j - 1])) {
+            const Cand t = best[j - 1]; best[j - 1] = best[j]; best[j] = t;
+        }
+    }
+}
+
+// in: dist != nullptr -> rows of the matrix (row index = global row); else cand_in [n_in, cols] candidate lists
+__global__ __launch_bounds__(kBlock) void topk_chunk_kernel(const float *__restrict__ dist, const Cand *__restrict__ cand_in,
+                                                           int64_t rows, int64_t cols, Cand *__restrict__ out)
+{
+    __shared__ Cand lds[4][64][kTopK + 1];          // +1: 9 x 8 B rows spread the banks
+    const int c_local = threadIdx.x & 63, r_lane = threadIdx.x >> 6;
+    const int64_t col = (int64_t)blockIdx.x * 64 + c_local;
+    const int64_t row0 = (int64_t)blockIdx.y * kTopkRows, row1 = min(rows, row0 + kTopkRows);
+    Cand best[kTopK];
+#pragma unroll
+    for (int j = 0; j < kTopK; ++j) { best[j].v = INFINITY; best[j].i = 0x7fffffff; }
+    if (col < cols) {
+        for (int64_t r = row0 + r_lane; r < row1; r += 4) {
+            float v;
+            int32_t i;
+            if (dist) { v = dist[r * cols + col]; i = (int32_t)r; }
+            else { const Cand cnd = cand_in[r * cols + col]; v = cnd.v; i = cnd.i; }
+            if (v != v) v = INFINITY;               // NaN sorts last (by row index among the infinities)
+            cand_insert(best, v, i);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < kTopK; ++j) lds[r_lane][c_local][j] = best[j];
+    __syncthreads();
+    if (r_lane == 0 && col < cols) {
+        for (int q = 1; q < 4; ++q)
+#pragma unroll
+            for (int j = 0; j < kTopK; ++j) {
+                const Cand cnd = lds[q][c_local][j];
+                cand_insert(best, cnd.v, cnd.i);
+            }
+#pragma unroll
+        for (int j = 0; j < kTopK; ++j) out[((int64_t)blockIdx.y * kTopK + j) * cols + col] = best[j];
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void topk_write_kernel(const Cand *__restrict__ best, const float *__restrict__ x, int64_t rows,
+                                                           int64_t cols, int k, int64_t *__restrict__ idx_out,
+                                                           float *__restrict__ val_out)
+{
+    const int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (t >= (int64_t)k * cols) return;
+    const int64_t j = t / cols, col = t - j * cols;
+    const bool real = j < rows;                    // fewer rows than k: the tail is (-1, NaN)
+    Cand cnd = {INFINITY, 0};
+    if (real) cnd = best[j * cols + col];
+    idx_out[t] = real ? (int64_t)cnd.i : -1;
+    if (val_out) val_out[t] = real ? x[(int64_t)cnd.i * cols + col] : NAN;     // the matrix AFTER exp / softmax was applied
+}
+
+int64_t topk_workspace_bytes(int64_t rows, int64_t cols)
+{
+    if (rows <= 0 || cols <= 0) return 0;
+    int64_t total = 0, n = rows;
+    while (true) {                                  // levels of 256-fold reduction until one candidate list per column
+        const int64_t chunks = (n + kTopkRows - 1) / kTopkRows;
+        total += chunks * kTopK * cols * (int64_t)sizeof(Cand);
+        if (chunks == 1) break;
+        n = chunks * kTopK;
+    }
+    return total;
+}
+
+// dist [rows, cols] -> workspace ends with the final [kTopK, cols] list; returns a pointer to it
+hipError_t launch_topk_select(const float *dist, int64_t rows, int64_t cols, void *workspace, const void **final_list, hipStream_t s)
+{
+    Cand *level = static_cast<Cand *>(workspace);
+    const Cand *in = nullptr;
+    int64_t n = rows;
+    while (true) {
+        const int64_t chunks = (n + kTopkRows - 1) / kTopkRows;
+        hipLaunchKernelGGL(topk_chunk_kernel, dim3((unsigned)((cols + 63) / 64), (unsigned)chunks), dim3(kBlock), 0, s,
+                           in ? nullptr : dist, in, n, cols, level);
+        if (chunks == 1) break;
+        in = level;
+        n = chunks * kTopK;
+        level += chunks * kTopK * cols;
+    }
+    *final_list = level;
+    return hipGetLastError();
+}
+
+hipError_t launch_topk_write(const void *final_list, const float *x, int64_t rows, int64_t cols, int k, int64_t *idx_out,
+                             float *val_out, hipStream_t s)
+{
+    const int64_t total = (int64_t)k * cols;
+    hipLaunchKernelGGL(topk_write_kernel, dim3((unsigned)((total + kBlock - 1) / kBlock)), dim3(kBlock), 0, s,
+                       static_cast<const Cand *>(final_list), x, rows, cols, k, idx_out, val_out);
+    return hipGetLastError();
+}
+
 }  // namespace d3f

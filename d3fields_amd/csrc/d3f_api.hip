@@ -149,6 +149,8 @@ void pick_staged_mapping(d3f::MapDesc &m)
 //   D3F_EXP_RUNS   cell-run gather on patch-resolution wide maps: -1 off, 0 automatic (default), 2 / 4 / 8 = run length
 //   D3F_EXP_RUNS_U vectors per lane of the cell-run gather: 0 automatic, 1 / 2 / 3;  D3F_EXP_RUNS_OCC=5: the (1,8) variant
 //                  held to 5 waves per SIMD
+//   D3F_EXP_STORE  -1: write the fused rows with plain stores instead of sc1 ones (see store_out in fuse_eval.hip)
+//   D3F_EXP_WALK_TILE  shape of the walk's tile as digits x y z with the same point count (222 default; 224 with a thin map)
 //   D3F_EXP_WALK   lattice brick walk for grids on large maps: -1 off, 0 automatic (default)
 int exp_knob(const char *name)
 {
@@ -214,6 +216,7 @@ int eval_common(const d3f_views *views, const float *pts, int64_t n, const d3f_c
     P.grid_ny = grid ? grid->ny : 0; P.grid_nz = grid ? grid->nz : 0;
     P.walk_nx = P.walk_ny = P.walk_nz = 0; P.walk_tx = P.walk_ty = P.walk_tz = 1;
     P.runs_occ = exp_knob("D3F_EXP_RUNS_OCC");
+    P.store_policy = exp_knob("D3F_EXP_STORE") < 0 ? 0 : 1;
     int64_t map_bytes = 0;
     P.out_dist = out_dist; P.out_valid = out_valid;
     P.n = n; P.V = views->V; P.H = views->H; P.W = views->W;
@@ -300,7 +303,13 @@ int eval_common(const d3f_views *views, const float *pts, int64_t n, const d3f_c
         bool thin = false;
         for (int s = 0; s < n_maps; ++s) thin |= P.maps[s].lpp_log2 < 5;      // < 32 lanes per point: 16 groups have work
         P.tile_pts = thin ? 16 : 8; P.lds_pad = 0; xcd_remap = true;
-        if (walk) { P.walk_tx = 2; P.walk_ty = 2; P.walk_tz = thin ? 4 : 2; }     // the tile is a brick of the lattice
+        if (walk) {                                   // the tile is a brick of the lattice
+            P.walk_tx = 2; P.walk_ty = 2; P.walk_tz = thin ? 4 : 2;
+            const int shape = exp_knob("D3F_EXP_WALK_TILE");      // experiment: digits x y z, e.g. 224, 144, 422
+            if (shape >= 111 && shape <= 888 && (shape / 100) * (shape / 10 % 10) * (shape % 10) == P.tile_pts && shape / 10 % 10 > 0 && shape % 10 > 0) {
+                P.walk_tx = shape / 100; P.walk_ty = shape / 10 % 10; P.walk_tz = shape % 10;
+            }
+        }
         // maps that fit the L2s / Infinity Cache anyway (patch-resolution features, the mask): the walk is only there
         // to give a random cloud L1 locality and the big tiles of the caller-order path stay best
         // (C2 patch, random cloud: caller order 1.93 ms, walk with 8-point tiles 1.07, with 128-point tiles 0.76)
@@ -360,6 +369,12 @@ int eval_common(const d3f_views *views, const float *pts, int64_t n, const d3f_c
         plan_out->reorder = walk ? 2 : (reorder ? 1 : 0);
         plan_out->lds_bytes = P.crec_offset + P.n_pre * P.tile_pts * P.V * 32 + P.lds_pad;
         plan_out->workgroups = ntiles;
+        plan_out->reserved = 0;
+        for (int s = 0; s < n_maps; ++s)
+            if (P.maps[s].runs > 0) {        // waves per SIMD the chosen cell-run kernel variant is built for
+                const int ru = P.maps[s].unroll, rk = P.maps[s].runs;
+                plan_out->reserved = (ru == 1 && rk == 4) ? 6 : (ru == 1 ? ((P.runs_occ == 4 || P.runs_occ == 6) ? P.runs_occ : 5) : 4);
+            }
         for (int s = 0; s < D3F_MAX_MAPS; ++s) {
             const bool on = s < n_maps;
             plan_out->vector_floats[s] = on ? P.maps[s].vw : 0;
@@ -721,6 +736,47 @@ int d3f_pairwise_similarity(const float *src, const float *tgt, int64_t B1, int6
         }
     }
     return D3F_OK;
+}
+
+int64_t d3f_pairwise_topk_workspace_bytes(int64_t B1, int64_t B2)
+{
+    if (B1 <= 0 || B2 <= 0) return 0;
+    return d3f_softmax_workspace_bytes(B1, B2) + d3f::topk_workspace_bytes(B1, B2) + 256;
+}
+
+int d3f_pairwise_similarity_topk(const float *src, const float *tgt, int64_t B1, int64_t B2, int32_t C, float scale,
+                                 int32_t dist_type, int32_t mode, int32_t k, float *out, int64_t *topk_idx, float *topk_val,
+                                 void *workspace, int64_t workspace_bytes, void *stream)
+{
+    int rc = check_sim_enums(dist_type, mode);
+    if (rc != D3F_OK) return rc;
+    if (k < 1 || k > 8) return fail(D3F_ERR_INVALID_ARG, "pairwise_topk: k=%d outside [1,8]", k);
+    if (B1 < 0 || B2 < 0 || C < 1) return fail(D3F_ERR_BAD_SHAPE, "pairwise_topk: B1=%lld B2=%lld C=%d", (long long)B1, (long long)B2, C);
+    if (B2 == 0) return D3F_OK;
+    if (!topk_idx) return fail(D3F_ERR_INVALID_ARG, "pairwise_topk: topk_idx is NULL");
+    if (B1 > 0 && (!src || !tgt || !out)) return fail(D3F_ERR_INVALID_ARG, "pairwise_topk: NULL pointer");
+    if (B1 > 0x7fffffffLL || (B2 + 63) / 64 > 0x7fffffffLL || (B1 + 63) / 64 > 65535)
+        return fail(D3F_ERR_BAD_SHAPE, "pairwise_topk: B1=%lld exceeds 64*65535 rows per call", (long long)B1);
+    if (B1 > 0 && (!workspace || workspace_bytes < d3f_pairwise_topk_workspace_bytes(B1, B2) || !aligned(workspace, 16)))
+        return fail(D3F_ERR_WORKSPACE, "pairwise_topk: needs %lld bytes of 16-byte aligned workspace", (long long)d3f_pairwise_topk_workspace_bytes(B1, B2));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    hipError_t e = hipSuccess;
+    const void *final_list = nullptr;
+    if (B1 > 0) {
+        d3f::ColStat *ws = static_cast<d3f::ColStat *>(workspace);
+        unsigned char *tk = static_cast<unsigned char *>(workspace) + (d3f_softmax_workspace_bytes(B1, B2) + 255) / 256 * 256;
+        const bool stats = mode == D3F_SIM_SOFTMAX_DIM0;
+        e = d3f::launch_pairwise_dist(src, tgt, B1, B2, C, dist_type, out, s, stats ? ws : nullptr, stats ? scale : 1.0f);
+        if (e != hipSuccess) return hip_fail(e, "pairwise_dist launch");
+        // neighbours are chosen on the raw distances, before exp() / softmax can round close values into ties
+        e = d3f::launch_topk_select(out, B1, B2, tk, &final_list, s);
+        if (e != hipSuccess) return hip_fail(e, "topk launch");
+        if (mode == D3F_SIM_SOFTMAX_DIM0) e = d3f::launch_softmax_dim0(out, B1, B2, scale, nullptr, ws, true, s);
+        else if (mode == D3F_SIM_EXP) e = d3f::launch_exp_neg_scale(out, B1 * B2, scale, s);
+        if (e != hipSuccess) return hip_fail(e, "similarity launch");
+    }
+    e = d3f::launch_topk_write(final_list, out, B1, B2, k, topk_idx, topk_val, s);
+    return e == hipSuccess ? D3F_OK : hip_fail(e, "topk write launch");
 }
 
 static_assert(sizeof(d3f_col_stat) == sizeof(d3f::ColStat) && sizeof(d3f_col_stat) == 16, "d3f_col_stat layout");

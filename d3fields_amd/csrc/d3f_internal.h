@@ -49,7 +49,8 @@ struct EvalParams {
     // from blockIdx alone (no keys, no sort, no index array).  walk_nx == 0: off.
     int32_t walk_nx, walk_ny, walk_nz;
     int32_t walk_tx, walk_ty, walk_tz;
-    int32_t runs_occ;      // experiment: 5 = cell-run kernel variant held to 5 waves per SIMD
+    int32_t runs_occ;      // experiment: waves per SIMD of the (1,8) cell-run kernel variant (4 / 5 / 6)
+    int32_t store_policy;  // 1 (default) = fused rows leave as sc1 (write-through, line dropped from L2) stores, 0 = plain
     uint32_t flags;
     float mu;
     MapDesc maps[D3F_MAX_MAPS];
@@ -137,6 +138,12 @@ hipError_t launch_softmax_apply(float *x, int64_t rows, int64_t cols, float scal
 // argmin over dim 0 of raw distances (used for D3F_SIM_DIST + argmax_out)
 hipError_t launch_argmin_dim0(const float *x, int64_t rows, int64_t cols, int64_t *arg_out, ColStat *ws,
                               bool have_stats, hipStream_t s);
+
+// k smallest entries per column of a [rows, cols] distance matrix (k <= 8), ties -> lower row, NaN last
+int64_t topk_workspace_bytes(int64_t rows, int64_t cols);
+hipError_t launch_topk_select(const float *dist, int64_t rows, int64_t cols, void *workspace, const void **final_list, hipStream_t s);
+hipError_t launch_topk_write(const void *final_list, const float *x, int64_t rows, int64_t cols, int k, int64_t *idx_out,
+                             float *val_out, hipStream_t s);
 
 // track_kernels.hip: the closed-form parts of the rigid-tracking optimiser step
 hipError_t launch_rigid_transform(const float *last, int I, int n, const float *t, const float *w, float eps, float *out_pts,

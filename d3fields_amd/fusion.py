@@ -354,8 +354,10 @@ class Fusion:
         runs = any(plan.staged[s] >= 16 for s in range(n_maps))
         wide = any(plan.vectors_per_lane[s] == -4 for s in range(n_maps))
         f16 = any(maps[s].dtype == _lib.DTYPE_F16 for s in range(n_maps))
-        kernel = ("fused_eval_f16_kernel<0>" if f16 else "fused_eval_runs_kernel<0>" if runs else
-                  "fused_eval_wide_kernel<0>" if wide else "fused_eval_kernel<0>")
+        kernel = ("fused_eval_f16_kernel<0>" if f16 else "fused_eval_wide_kernel<0>" if wide else "fused_eval_kernel<0>")
+        if runs and not f16 and not wide:
+            s0 = [s for s in range(n_maps) if plan.staged[s] >= 16][0]
+            kernel = "fused_eval_runs_kernel<0, %d, %d, %d>" % (plan.vectors_per_lane[s0], plan.staged[s0] - 16, plan.reserved)
         order = {2: "closed-form brick walk of the lattice (no keys, no sort)", 1: "Morton order (21-bit keys, radix sort)",
                  0: "caller order"}[int(plan.reorder)]
         if runs:

@@ -137,7 +137,7 @@ typedef struct d3f_eval_plan {
     int32_t reorder;                        /* 1: points are walked in Morton order (sorted keys); 2: closed-form brick
                                                walk of a lattice (d3f_eval_grid / d3f_eval_lattice)    */
     int32_t lds_bytes;                      /* dynamic LDS per workgroup                              */
-    int32_t reserved;
+    int32_t reserved;                       /* cell-run gather: waves per SIMD its kernel variant is built for, else 0 */
     int64_t workgroups;
     int32_t vector_floats[D3F_MAX_MAPS];    /* 4 / 2 / 1 floats per load                              */
     int32_t lanes_per_point[D3F_MAX_MAPS];
@@ -312,6 +312,17 @@ int d3f_pairwise_similarity(const float *src, const float *tgt, int64_t B1, int6
                             float scale, int32_t dist_type, int32_t mode, float *out,
                             int64_t *argmax_out, void *workspace, int64_t workspace_bytes,
                             void *stream);
+
+/* k-nearest-descriptor lookup (k <= 8): d3f_pairwise_similarity plus, per target column, the rows of the k SMALLEST
+ * distances -- the k-NN generalisation of the reference's best match, compute_similarity_tensor_multi(...).argmax(0)
+ * (the reference has no KNN of its own; this is what the north star's "KNN correspondence lookup" maps
+ * to).  Neighbours are chosen on the raw distances (ties -> lower row index, NaN last), before exp / softmax can round
+ * close values into ties.  topk_idx [k,B2] int64 (row j = the j-th nearest; -1 where B1 < k), topk_val [k,B2] or NULL:
+ * the entries of `out` (in `mode`) at those rows.  workspace >= d3f_pairwise_topk_workspace_bytes(B1, B2), 16-B aligned. */
+int64_t d3f_pairwise_topk_workspace_bytes(int64_t B1, int64_t B2);
+int d3f_pairwise_similarity_topk(const float *src, const float *tgt, int64_t B1, int64_t B2, int32_t C, float scale,
+                                 int32_t dist_type, int32_t mode, int32_t k, float *out, int64_t *topk_idx,
+                                 float *topk_val, void *workspace, int64_t workspace_bytes, void *stream);
 
 /* ---- the same softmax with B1 sharded over GPUs -------------------------------
  * softmax(dim=0) of compute_similarity_tensor_multi (corr_utils.py:102) couples all B1 rows.  With the

@@ -143,6 +143,38 @@ def test_validation_of_association_entry_points():
     assert lib.d3f_fps_pixels(one, 5, 3, 0, one, None, None, None) == _lib.ERR_INVALID_ARG
 
 
+def test_validation_of_topk_and_lattice_entry_points():
+    lib = _lib.load()
+    one = ctypes.c_void_p(16)
+    assert lib.d3f_pairwise_topk_workspace_bytes(0, 10) == 0
+    assert lib.d3f_pairwise_topk_workspace_bytes(100000, 300) > lib.d3f_softmax_workspace_bytes(100000, 300)
+    assert lib.d3f_pairwise_similarity_topk(one, one, 10, 10, 4, 1.0, 0, 2, 9, one, one, one, one, 1 << 30, None) == _lib.ERR_INVALID_ARG
+    assert lib.d3f_pairwise_similarity_topk(one, one, 10, 10, 4, 1.0, 0, 2, 0, one, one, one, one, 1 << 30, None) == _lib.ERR_INVALID_ARG
+    assert lib.d3f_pairwise_similarity_topk(one, one, 10, 10, 4, 1.0, 0, 2, 3, one, None, one, one, 1 << 30, None) == _lib.ERR_INVALID_ARG
+    assert lib.d3f_pairwise_similarity_topk(one, one, 10, 10, 4, 1.0, 0, 2, 3, one, one, one, None, 0, None) == _lib.ERR_WORKSPACE
+    assert lib.d3f_pairwise_similarity_topk(one, one, 10, 0, 4, 1.0, 0, 2, 3, one, one, one, None, 0, None) == 0
+    assert lib.d3f_pairwise_similarity_topk(one, one, 10, 10, 4, 1.0, 7, 2, 3, one, one, one, one, 1 << 30, None) == _lib.ERR_INVALID_ARG
+    assert lib.d3f_lattice_probe(None, 5, one, None) == _lib.ERR_INVALID_ARG
+    assert lib.d3f_lattice_probe(one, 5, None, None) == _lib.ERR_INVALID_ARG
+    assert lib.d3f_lattice_probe(one, -1, one, None) == _lib.ERR_INVALID_ARG
+    assert lib.d3f_eval_lattice(ctypes.byref(_views()), None, 0, 4, 4, None, 0, 0.02, 0, None, None, None, None, None) == 0
+    assert lib.d3f_eval_lattice(ctypes.byref(_views()), one, -1, 4, 4, None, 0, 0.02, 0, one, one, None, None, None) == _lib.ERR_BAD_SHAPE
+    assert lib.d3f_eval_lattice(ctypes.byref(_views()), None, 4, 4, 4, None, 0, 0.02, 0, one, one, None, None, None) == _lib.ERR_INVALID_ARG
+    # launch plans of lattices (host logic only): brick walk on large maps, cell runs in caller order on patch-res maps
+    plan = _lib.EvalPlan()
+    big = (_lib.ChannelMap * 1)(_lib.ChannelMap(1 << 20, 480, 640, 384, 0, 480 * 640 * 384, 640 * 384, 384))
+    v = _views(V=4, H=480, W=640)
+    assert lib.d3f_eval_plan_query_lattice(ctypes.byref(v), 160, 140, 44, big, 1, _lib.FLAG_FINITE_MAPS, 0, ctypes.byref(plan)) == 0
+    assert plan.reorder == 2 and plan.tile_points == 8 and plan.workgroups == 80 * 70 * 22 and plan.staged[0] == 0
+    assert lib.d3f_eval_plan_query_lattice(ctypes.byref(v), 161, 141, 45, big, 1, _lib.FLAG_FINITE_MAPS, 0, ctypes.byref(plan)) == 0
+    assert plan.workgroups == 81 * 71 * 23                     # clipped tiles at the upper faces, no padding
+    patch = (_lib.ChannelMap * 1)(_lib.ChannelMap(1 << 20, 48, 64, 384, 0, 48 * 64 * 384, 64 * 384, 384))
+    assert lib.d3f_eval_plan_query_lattice(ctypes.byref(v), 160, 140, 44, patch, 1, _lib.FLAG_FINITE_MAPS, 0, ctypes.byref(plan)) == 0
+    assert plan.reorder == 0 and plan.staged[0] == 16 + 4 and plan.tile_points == 64 and plan.lanes_per_point[0] == 32
+    assert lib.d3f_eval_plan_query_lattice(ctypes.byref(v), 160, 140, 44, patch, 1, 0, 0, ctypes.byref(plan)) == 0
+    assert plan.staged[0] == 0 and plan.tile_points == 128     # maps not known to be finite: the direct gather
+
+
 def test_workspace_size():
     lib = _lib.load()
     assert lib.d3f_eval_workspace_bytes(0) == 0

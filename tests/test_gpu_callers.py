@@ -226,3 +226,58 @@ def test_driver_sequence_segment_select_track(dev):
     f.clear_xmem_memory()
     f.text_queries_for_inst_mask(labels[1:], [0.3] * 3, box)
     assert calls["producer"] == 3 and calls["tracker_init"] == 2
+
+
+# ---- k nearest descriptors (the north star's "KNN correspondence lookup"; extension of argmax(0)) ---------------------
+def _knn_reference(dist, k):
+    """numpy: per column the k smallest distances, ties -> lower row, NaN last"""
+    d = np.where(np.isnan(dist), np.inf, dist)
+    rows = np.arange(d.shape[0])
+    idx = np.stack([np.lexsort((rows, d[:, c]))[:k] for c in range(d.shape[1])], axis=1)
+    return idx
+
+
+@pytest.mark.parametrize("B1,B2,C,k", [(700, 37, 24, 5), (100000, 300, 384, 8), (5, 3, 16, 8), (257, 65, 8, 1), (70000, 2, 32, 3)])
+def test_knn_descriptors_matches_numpy(dev, B1, B2, C, k):
+    from d3fields_amd import corr_utils as cu
+    g = torch.Generator().manual_seed(B1 + k)
+    src = torch.randn(B1, C, generator=g)
+    tgt = torch.randn(B2, C, generator=g)
+    src[B1 // 2] = src[0]                                      # exact duplicate rows: ties broken by the lower index
+    tgt[0] = src[0]
+    sim, idx, val = cu.knn_descriptors(src.to(dev), tgt.to(dev), k, scale=1.3)
+    full = cu.compute_similarity_tensor_multi(src.to(dev), tgt.to(dev), None, None, 1.3)
+    assert torch.equal(sim, full)                              # the similarity matrix is the reference function's
+    dist = cpu(cu._pairwise(src.to(dev), tgt.to(dev), 1.0, "l2", 0, False)[0])    # D3F_SIM_DIST of the same kernel
+    want = _knn_reference(dist, k)
+    got = cpu(idx)
+    kk = min(k, B1)
+    assert np.array_equal(got[:kk], want[:kk])
+    assert (got[kk:] == -1).all() and np.isnan(cpu(val)[kk:]).all()
+    assert np.array_equal(cpu(val)[:kk], np.take_along_axis(cpu(sim), want[:kk], axis=0))
+    assert np.array_equal(got[0], cpu(cu.nearest_descriptor(src.to(dev), tgt.to(dev), 1.3)[1]))   # k = 1 == the fused argmax
+    assert got[0, 0] == 0 and (B1 < 2 or k < 2 or got[1, 0] == B1 // 2)
+
+
+def test_knn_descriptors_vs_reference_golden(dev):
+    """On the reference's own compute_similarity_tensor_multi output (golden 'corr_utils'): torch.topk of the golden
+    similarity gives the same neighbours wherever the golden values are distinct."""
+    from d3fields_amd import corr_utils as cu
+    g = load_golden("corr_utils")
+    src, tg = torch.from_numpy(g["multi_src"]).to(dev), torch.from_numpy(g["multi_tgt"]).to(dev)
+    sim, idx, val = cu.knn_descriptors(src, tg, 4, float(g["multi_scale"]))
+    ref = torch.from_numpy(g["multi_l2"])
+    tv, ti = ref.topk(4, dim=0)
+    distinct = (tv[:-1] > tv[1:]).all(0) & (tv[-1] > ref.kthvalue(ref.shape[0] - 4, dim=0).values)
+    assert distinct.sum() > 30
+    assert torch.equal(idx.cpu()[:, distinct], ti[:, distinct])
+    assert rel_err(cpu(val), tv.numpy()) <= TOL
+
+
+def test_knn_with_nan_rows(dev):
+    from d3fields_amd import corr_utils as cu
+    src = torch.randn(300, 16, generator=torch.Generator().manual_seed(1))
+    src[5] = float("nan")
+    tgt = torch.randn(7, 16, generator=torch.Generator().manual_seed(2))
+    _, idx, _ = cu.knn_descriptors(src.to(dev), tgt.to(dev), 8)
+    assert not (cpu(idx) == 5).any()                            # a NaN distance sorts last
