@@ -76,6 +76,10 @@ struct BackwardParams {
 };
 hipError_t launch_fused_backward(const BackwardParams &P, int mode, hipStream_t stream);
 
+// scan_kernels.hip: exclusive prefix sum of uint32 counters (in == out allowed); scratch >= scan_scratch_bytes(n)
+int64_t scan_scratch_bytes(int64_t n);
+hipError_t launch_exclusive_scan_u32(const uint32_t *in, uint32_t *out, int64_t n, void *scratch, hipStream_t s);
+
 // order_kernels.hip
 int64_t order_workspace_bytes(int64_t n);
 hipError_t build_point_order(const float *pts, int64_t n, void *workspace, int64_t workspace_bytes,

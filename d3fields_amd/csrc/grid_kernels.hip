@@ -13,8 +13,6 @@
 #include <cstring>
 #include <string.h>
 
-#include <rocprim/rocprim.hpp>
-
 #include "d3f_internal.h"
 #include "d3f_device.h"
 
@@ -86,7 +84,7 @@ __global__ void grid_shell_total_kernel(const uint32_t *__restrict__ block_count
 int64_t grid_shell_workspace_bytes(int64_t n)
 {
     const int64_t nb = (n + kBlock - 1) / kBlock;
-    return nb * (kBlock / 64) * 8 + 2 * ((nb * 4 + 255) / 256 * 256) + (4 << 20);   // ballots + counts + offsets + scan scratch
+    return nb * (kBlock / 64) * 8 + 2 * ((nb * 4 + 255) / 256 * 256) + scan_scratch_bytes(nb);   // ballots + counts + offsets + scan scratch
 }
 
 hipError_t launch_grid_shell(const float *depth, const float *K, const float *pose, int V, int H, int W, const float *gx,
@@ -105,11 +103,7 @@ hipError_t launch_grid_shell(const float *depth, const float *K, const float *po
     void *scratch = base + nb * (kBlock / 64) * 8 + 2 * seg;
     hipLaunchKernelGGL(grid_shell_flag_kernel, dim3((unsigned)nb), dim3(kBlock), (size_t)V * 48, s, depth, K, pose, V, H, W, gx, gy,
                        gz, ny, nz, n, mu, dist_thr, ballots, counts);
-    size_t need = 0;
-    e = rocprim::exclusive_scan(nullptr, need, counts, offsets, 0u, (size_t)nb, rocprim::plus<uint32_t>(), s);
-    if (e != hipSuccess) return e;
-    if (need > (size_t)(4 << 20)) return hipErrorOutOfMemory;
-    e = rocprim::exclusive_scan(scratch, need, counts, offsets, 0u, (size_t)nb, rocprim::plus<uint32_t>(), s);
+    e = launch_exclusive_scan_u32(counts, offsets, nb, scratch, s);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(grid_shell_write_kernel, dim3((unsigned)nb), dim3(kBlock), 0, s, ballots, offsets, n, capacity, idx_out);
     hipLaunchKernelGGL(grid_shell_total_kernel, dim3(1), dim3(1), 0, s, counts, offsets, nb, count);

@@ -5,15 +5,22 @@
 // Cache) the fused kernel is bound by texel re-fetches; points that are close in 3-D project
 // close together in EVERY view, so walking the points along a Morton curve keeps the in-flight
 // texel footprint compact (measured 3.2 -> 2.8 ms on the 985 600-point grid, 3.4 -> 2.6 ms on a
-// shuffled cloud).  Keys are 21-bit Morton codes of the 16-mm cell of each point (a 64..128-point
-// tile spans a few such cells; the stable sort keeps the caller's order inside a cell); the pairs
-// (key, index) are sorted with rocPRIM's device radix sort in caller-provided workspace and the
-// fused kernel then reads its points through the index array.
-#include <cstring>
-#include <string.h>
-
-#include <rocprim/rocprim.hpp>
-
+// shuffled cloud).  Grids do not come here at all (closed-form brick walk, fuse_eval.hip); this is the path of clouds.
+//
+// Hand-written since round 2 (round 1 sorted (key, index) pairs with rocPRIM's Onesweep radix sort: histogram +
+// 3-4 digit passes + 7 memset launches = 0.12-0.16 ms per 1 M points).  The fused kernel needs locality, not a total
+// order, so a counting sort by cell plus a local refinement is enough:
+//   1. morton_count_kernel   27-bit Morton key of the 4-mm cell of every point (kept for step 4) and a histogram of its
+//                            top 21 bits = the 16-mm cell (2 M counters in caller scratch, cleared by order_clear_kernel);
+//                            the returning atomic also gives the point its arrival rank inside the cell -- the only
+//                            atomic per point (device-scope atomics run at ~17 per ns chip-wide: 59 us per 1 M)
+//   2. exclusive scan of the counters (scan_kernels.hip, three small launches)
+//   3. scatter_kernel        index i goes to slot offset[cell] + rank -- cells in Morton order, arrival order inside
+//   4. window_rank_kernel    every wave re-orders its 64 consecutive slots by (27-bit key, index): inside a 16-mm
+//                            cell (~30 points at 1 M points per 0.12 m^3) the walk follows the 4-mm sub-cells, which is
+//                            what the cell-run gather lives on; runs of equal cells that straddle a window are simply
+//                            refined piecewise.
+// Seven launches; the order inside a cell depends on atomic arrival, the results do not.
 #include "d3f_internal.h"
 
 namespace d3f {
@@ -28,68 +35,89 @@ __device__ __forceinline__ uint32_t spread3(uint32_t x)
     return x;
 }
 
-__global__ __launch_bounds__(kBlock) void morton_keys_kernel(const float *__restrict__ pts, int64_t n,
-                                                            float inv_cell, uint32_t axis_mask, uint32_t *__restrict__ keys,
-                                                            uint32_t *__restrict__ idx)
-{
-    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-    if (i >= n) return;
-    const float x = pts[i * 3 + 0], y = pts[i * 3 + 1], z = pts[i * 3 + 2];
-    // non-finite / huge coordinates just land in some cell: only locality is at stake
-    const int qx = (int)fminf(fmaxf(floorf(x * inv_cell), -1e9f), 1e9f);
-    const int qy = (int)fminf(fmaxf(floorf(y * inv_cell), -1e9f), 1e9f);
-    const int qz = (int)fminf(fmaxf(floorf(z * inv_cell), -1e9f), 1e9f);
-    keys[i] = spread3((uint32_t)qx & axis_mask) | (spread3((uint32_t)qy & axis_mask) << 1) | (spread3((uint32_t)qz & axis_mask) << 2);
-    idx[i] = (uint32_t)i;
-}
-
-// rocPRIM's default switches to a ~20-launch merge sort below 1M items (measured 160 us at n = 985 600);
-// Onesweep (histogram + 3 digit passes for 21-bit keys) is the right algorithm from a few 10k items up.
-using SortConfig = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config, rocprim::default_config, 32768>;
+constexpr float kFineCell = 0.004f;       // 4-mm sub-cells x 512 per axis = 2.05 m before the keys wrap (harmless)
+constexpr int kFineBits = 6;              // 27-bit fine key = 21-bit key of the 16-mm cell << 6 | sub-cell
+constexpr int64_t kCells = 1 << 21;
 
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
-constexpr float kCell = 0.016f;          // 16-mm cells x 128 per axis = 2.05 m before keys wrap (harmless)
-constexpr size_t kSortScratch = 8u << 20;   // rocPRIM histogram/scan scratch (it needs far less)
+__global__ __launch_bounds__(kBlock) void order_clear_kernel(uint32_t *__restrict__ table)
+{
+    reinterpret_cast<uint4 *>(table)[(int64_t)blockIdx.x * kBlock + threadIdx.x] = make_uint4(0u, 0u, 0u, 0u);
+}
+
+__global__ __launch_bounds__(kBlock) void morton_count_kernel(const float *__restrict__ pts, int64_t n, uint32_t *__restrict__ keys,
+                                                             uint32_t *__restrict__ ranks, uint32_t *__restrict__ table)
+{
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const float inv = 1.0f / kFineCell;
+    // non-finite / huge coordinates just land in some cell: only locality is at stake
+    const int qx = (int)fminf(fmaxf(floorf(pts[i * 3 + 0] * inv), -1e9f), 1e9f);
+    const int qy = (int)fminf(fmaxf(floorf(pts[i * 3 + 1] * inv), -1e9f), 1e9f);
+    const int qz = (int)fminf(fmaxf(floorf(pts[i * 3 + 2] * inv), -1e9f), 1e9f);
+    const uint32_t key = spread3((uint32_t)qx & 511u) | (spread3((uint32_t)qy & 511u) << 1) | (spread3((uint32_t)qz & 511u) << 2);
+    keys[i] = key;
+    ranks[i] = atomicAdd(&table[key >> kFineBits], 1u);
+}
+
+__global__ __launch_bounds__(kBlock) void scatter_kernel(const uint32_t *__restrict__ keys, const uint32_t *__restrict__ ranks, int64_t n,
+                                                        const uint32_t *__restrict__ offsets, uint32_t *__restrict__ slots)
+{
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    slots[offsets[keys[i] >> kFineBits] + ranks[i]] = (uint32_t)i;
+}
+
+__global__ __launch_bounds__(kBlock) void window_rank_kernel(const uint32_t *__restrict__ keys, const uint32_t *__restrict__ slots,
+                                                            int64_t n, uint32_t *__restrict__ order)
+{
+    const int64_t base = ((int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6)) * 64;
+    const int lane = threadIdx.x & 63;
+    const int64_t pos = base + lane;
+    const bool live = pos < n;
+    const uint32_t idx = live ? slots[pos] : 0xffffffffu;
+    const uint32_t key = live ? keys[idx] : 0xffffffffu;
+    const unsigned long long mine = ((unsigned long long)key << 32) | idx;      // (key, index): a strict total order
+    int rank = 0;
+#pragma unroll 8
+    for (int j = 0; j < 64; ++j) {
+        const unsigned long long other = __shfl(mine, j, 64);
+        rank += other < mine ? 1 : 0;
+    }
+    if (live) order[base + rank] = idx;            // dead lanes hold the maximum and rank last
+}
 
 int64_t order_workspace_bytes(int64_t n)
 {
     if (n <= 0) return 0;
-    return (int64_t)(4 * align_up((size_t)n * 4, 256) + kSortScratch);
+    // keys | ranks | order | slots | cell counters + scan scratch
+    return (int64_t)(4 * align_up((size_t)n * 4, 256) + (size_t)kCells * 4 + (size_t)scan_scratch_bytes(kCells));
 }
 
-// Fills *order_out with a pointer (inside the workspace) to n uint32 indices in Morton order.
+// Fills *order_out with a pointer (inside the workspace) to n uint32 indices in Morton-cell order.
 hipError_t build_point_order(const float *pts, int64_t n, void *workspace, int64_t workspace_bytes,
-                             const uint32_t **order_out, hipStream_t stream, int fine)
+                             const uint32_t **order_out, hipStream_t stream, int /*fine: the walk is always refined to 4 mm*/)
 {
-    // fine = 0..2: cell = 16 mm >> fine, 7 + fine bits per axis (always ~2 m before the keys wrap)
-    const float cell = kCell / (float)(1 << fine);
-    const unsigned bits_axis = 7u + (unsigned)fine, key_bits = 3u * bits_axis;
     *order_out = nullptr;
     if (n <= 0 || n > 0x7fffffffLL || workspace_bytes < order_workspace_bytes(n)) return hipErrorInvalidValue;
     const size_t seg = align_up((size_t)n * 4, 256);
     unsigned char *base = static_cast<unsigned char *>(workspace);
-    uint32_t *k0 = reinterpret_cast<uint32_t *>(base), *k1 = reinterpret_cast<uint32_t *>(base + seg);
-    uint32_t *v0 = reinterpret_cast<uint32_t *>(base + 2 * seg), *v1 = reinterpret_cast<uint32_t *>(base + 3 * seg);
-    void *scratch = base + 4 * seg;
-    hipLaunchKernelGGL(morton_keys_kernel, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream, pts, n,
-                       1.0f / cell, (1u << bits_axis) - 1u, k0, v0);
-    hipError_t e = hipGetLastError();
+    uint32_t *keys = reinterpret_cast<uint32_t *>(base), *ranks = reinterpret_cast<uint32_t *>(base + seg);
+    uint32_t *order = reinterpret_cast<uint32_t *>(base + 2 * seg), *slots = reinterpret_cast<uint32_t *>(base + 3 * seg);
+    uint32_t *table = reinterpret_cast<uint32_t *>(base + 4 * seg);
+    void *scan_scratch = base + 4 * seg + (size_t)kCells * 4;
+    const unsigned nb = (unsigned)((n + kBlock - 1) / kBlock);
+    hipLaunchKernelGGL(order_clear_kernel, dim3((unsigned)(kCells / 4 / kBlock)), dim3(kBlock), 0, stream, table);
+    hipLaunchKernelGGL(morton_count_kernel, dim3(nb), dim3(kBlock), 0, stream, pts, n, keys, ranks, table);
+    hipError_t e = launch_exclusive_scan_u32(table, table, kCells, scan_scratch, stream);
     if (e != hipSuccess) return e;
-    rocprim::double_buffer<uint32_t> keys(k0, k1), vals(v0, v1);
-    size_t need = 0;
-    e = rocprim::radix_sort_pairs<SortConfig>(nullptr, need, keys, vals, (size_t)n, 0u, key_bits, stream);
+    hipLaunchKernelGGL(scatter_kernel, dim3(nb), dim3(kBlock), 0, stream, keys, ranks, n, table, slots);
+    hipLaunchKernelGGL(window_rank_kernel, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream, keys, slots, n, order);
+    e = hipGetLastError();
     if (e != hipSuccess) return e;
-    if (need > kSortScratch) return hipErrorOutOfMemory;
-    e = rocprim::radix_sort_pairs<SortConfig>(scratch, need, keys, vals, (size_t)n, 0u, key_bits, stream);
-    if (e != hipSuccess) return e;
-    // the finished order always ends in the FIRST index buffer, so that a later call can find it again
-    // (D3F_FLAG_REUSE_POINT_ORDER) without knowing how many digit passes ran
-    if (vals.current() != v0) {
-        e = hipMemcpyAsync(v0, vals.current(), (size_t)n * 4, hipMemcpyDeviceToDevice, stream);
-        if (e != hipSuccess) return e;
-    }
-    *order_out = v0;
+    // the finished order always sits in the same place, so that a later call can find it again (D3F_FLAG_REUSE_POINT_ORDER)
+    *order_out = order;
     return hipSuccess;
 }
 

@@ -358,7 +358,7 @@ class Fusion:
         if runs and not f16 and not wide:
             s0 = [s for s in range(n_maps) if plan.staged[s] >= 16][0]
             kernel = "fused_eval_runs_kernel<0, %d, %d, %d>" % (plan.vectors_per_lane[s0], plan.staged[s0] - 16, plan.reserved)
-        order = {2: "closed-form brick walk of the lattice (no keys, no sort)", 1: "Morton order (21-bit keys, radix sort)",
+        order = {2: "closed-form brick walk of the lattice (no keys, no sort)", 1: "Morton-cell order (counting sort by 16-mm cell + 4-mm refinement, hand-written)",
                  0: "caller order"}[int(plan.reorder)]
         if runs:
             order += "; cell runs of %d consecutive points" % (max(plan.staged[s] for s in range(n_maps)) - 16)
