@@ -281,3 +281,38 @@ def test_knn_with_nan_rows(dev):
     tgt = torch.randn(7, 16, generator=torch.Generator().manual_seed(2))
     _, idx, _ = cu.knn_descriptors(src.to(dev), tgt.to(dev), 8)
     assert not (cpu(idx) == 5).any()                            # a NaN distance sorts last
+
+
+# ---- BASELINE config 5 as a sequence -------------------------------------------------------------
+def test_config5_thirty_frame_sequence(dev):
+    """4 views x 30 frames: every frame refreshes depth + feature + mask maps (update), queries 100 000 keypoints with
+    ['dino_feats', 'mask'] and matches them against 300 reference descriptors (softmax similarity + best match + 4-NN).
+    Every frame: instance indices / validity / dist of a 1500-point sample bit-exact against the CPU oracle, features
+    <= 1e-5, the fused best match equal to argmax(0) of the similarity and to row 0 of the k-NN lookup."""
+    from d3fields_amd import Fusion, synth, onehot2instance, corr_utils as cu
+    from oracle import c_oracle as O
+    V, H, W, C, NI, N = 4, 480, 640, 384, 8, 100000
+    f = Fusion(num_cam=V, device=str(dev))
+    ref_desc = torch.randn(300, C, generator=torch.Generator().manual_seed(11)).to(dev)
+    keypoints = synth.random_cloud(N, seed=5).to(dev)
+    pick = torch.randperm(N, generator=torch.Generator().manual_seed(6))[:1500]
+    for frame in range(30):
+        sc = synth.make_scene(V, H, W, "smooth" if frame % 2 == 0 else "stress", seed=frame)
+        feats = synth.random_map(V, 48, 64, C, seed=100 + frame)
+        mask = synth.random_onehot_mask(V, H, W, NI, seed=200 + frame)
+        f.update({"color": np.zeros((V, H, W, 3), np.uint8), "depth": sc["depth"].numpy(), "pose": sc["pose"].numpy(),
+                  "K": sc["K"].numpy(), "dino_feats": feats})
+        f.curr_obs_torch["mask"] = mask.to(dev)
+        moved = keypoints + 0.001 * frame                          # a new query tensor every frame (no cached order)
+        with torch.no_grad():
+            out = f.eval(moved, return_names=["dino_feats", "mask"])
+            sim, match = cu.nearest_descriptor(out["dino_feats"], ref_desc, 1.0)
+            _, knn, _ = cu.knn_descriptors(out["dino_feats"], ref_desc, 4, 1.0)
+        if frame % 5 == 0 or frame == 29:
+            ref = O.eval_field(sc["depth"], sc["K"], sc["pose"], moved[pick.to(dev)].cpu(), [feats, mask], mu=f.mu)
+            assert np.array_equal(cpu(out["valid_mask"][pick.to(dev)]), ref["valid_mask"]), frame
+            assert np.array_equal(cpu(out["dist"][pick.to(dev)]), ref["dist"]), frame
+            assert rel_err(cpu(out["dino_feats"][pick.to(dev)]), ref["sets"][0]) <= TOL, frame
+            assert np.array_equal(cpu(onehot2instance(out["mask"][pick.to(dev)])), O.onehot2instance(ref["sets"][1])), frame
+        assert torch.equal(match, sim.argmax(0)) and torch.equal(match, knn[0]), frame
+        assert abs(float(sim.sum(0).mean()) - 1.0) < 1e-4
