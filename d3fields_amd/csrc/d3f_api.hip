@@ -169,17 +169,28 @@ bool runs_candidate(const d3f::MapDesc &m, int H, int W)
 void pick_runs_mapping(d3f::MapDesc &m, int U, int K)
 {
     const int cvec = m.C / 4;
-    if (U <= 0 || U > 3) U = 1;      // one vector per lane measured fastest (more waves beat fewer passes)
+    // Defaults from the MI355X sweeps (gpurun_out/r2h): 32-lane groups (C = 384) -> one vector per lane,
+    // 4-point runs, 69 VGPR = 7 waves per SIMD (C2 patch 0.750 -> 0.633 ms, C3 patch 1.537 -> 1.288); 64-lane groups
+    // (C = 1024) -> two vectors per lane x two passes, 8-point runs at 4 waves per SIMD (C4 patch 4.32 -> 3.35).
+    const bool auto_u = U <= 0 || U > 3;
+    if (auto_u) U = (cvec % 128 == 0) ? 2 : 1;
     long best_slots = -1;
     for (int lg = 6; lg >= 5; --lg) {           // 64 or 32 lanes per point; ties go to the wider group (fewer passes)
         const long per = (long)(1 << lg) * U;
         const long slots = (cvec + per - 1) / per * per;
         if (best_slots < 0 || slots < best_slots) { best_slots = slots; m.lpp_log2 = lg; }
     }
-    // run length (MI355X r2d): 32-lane groups (C = 384) -> 4-point runs at 6 waves per SIMD (C2 patch 0.724 -> 0.638 ms,
-    // C3 patch 1.544 -> 1.333); 64-lane groups (C = 1024) -> 8-point runs at 5 waves per SIMD (C4 patch 4.13 -> 3.84)
+    if (auto_u && U == 2 && m.lpp_log2 != 6) {   // two vectors per lane only pays on full 64-lane groups
+        U = 1;
+        best_slots = -1;
+        for (int lg = 6; lg >= 5; --lg) {
+            const long per = (long)(1 << lg);
+            const long slots = (cvec + per - 1) / per * per;
+            if (best_slots < 0 || slots < best_slots) { best_slots = slots; m.lpp_log2 = lg; }
+        }
+    }
     if (U == 3 && K != 2) K = 4;
-    if (U == 2 && K != 8) K = 4;
+    if (U == 2 && K != 4) K = 8;
     if (U == 1 && K != 4 && K != 8) K = m.lpp_log2 == 5 ? 4 : 8;
     m.unroll = U;
     m.runs = K;
@@ -373,7 +384,7 @@ int eval_common(const d3f_views *views, const float *pts, int64_t n, const d3f_c
         for (int s = 0; s < n_maps; ++s)
             if (P.maps[s].runs > 0) {        // waves per SIMD the chosen cell-run kernel variant is built for
                 const int ru = P.maps[s].unroll, rk = P.maps[s].runs;
-                plan_out->reserved = (ru == 1 && rk == 4) ? 6 : (ru == 1 ? ((P.runs_occ == 4 || P.runs_occ == 6) ? P.runs_occ : 5) : 4);
+                plan_out->reserved = (ru == 1 && rk == 4) ? (P.runs_occ == 6 ? 6 : 7) : (ru == 1 ? ((P.runs_occ == 4 || P.runs_occ == 6) ? P.runs_occ : 5) : 4);
             }
         for (int s = 0; s < D3F_MAX_MAPS; ++s) {
             const bool on = s < n_maps;

@@ -415,7 +415,13 @@ __device__ __forceinline__ void gather_map_wave_staged(const MapDesc &m, const E
 // bit-identical.  Points that need the strict path (non-finite projection) are left to gather_map(only_strict).
 constexpr uint32_t kRunNonFinite = 1u;     // bits of the per-(point, view) state word (nfp_s)
 constexpr uint32_t kRunNewCell = 2u;       // the four corner texels differ from those of the previous point of the run
+constexpr uint32_t kRunValid = 4u;         // the view is valid for the point (its corner record is meaningful)
 
+// Branch structure: only the FOUR LOADS of a new cell are conditional.  The arithmetic runs for every (point, view):
+// phase A leaves an all-zero corner record for an invalid pair, so its term is (+-0) * wgt = +-0 and adding it to a sum
+// that started at +0 changes no bit (the argument of gather_map's exact skip) -- fewer exec-mask
+// round trips and LDS waits than skipping it.  A strict point (non-finite projection) takes part like any other and is
+// simply not stored here.
 template <int U, int K>
 __device__ __forceinline__ void gather_map_runs(const MapDesc &m, const EvalParams &P, const ViewRec *rec,
                                                 const uint32_t *state_s, const float *cnt_s, const uint32_t *flag_s,
@@ -429,12 +435,9 @@ __device__ __forceinline__ void gather_map_runs(const MapDesc &m, const EvalPara
     const int cvec = m.C / 4;
     const int V = P.V;
     const char *__restrict__ data = reinterpret_cast<const char *>(m.data);
+    const int last = tile_n * V - 1;
 
     for (int run0 = grp * K; run0 < tile_n; run0 += ngrp * K) {
-        uint32_t live = 0u;                         // bit k: point run0+k exists and takes the fast path
-#pragma unroll
-        for (int k = 0; k < K; ++k)
-            if (run0 + k < tile_n && flag_s[run0 + k] == 0u) live |= 1u << k;
         for (int c0 = 0; c0 < cvec; c0 += lpp * U) {
             uint32_t co[U];
 #pragma unroll
@@ -449,40 +452,43 @@ __device__ __forceinline__ void gather_map_runs(const MapDesc &m, const EvalPara
                 VT a[U], b[U], d[U], e[U];
 #pragma unroll
                 for (int u = 0; u < U; ++u) { a[u] = (VT)0.0f; b[u] = (VT)0.0f; d[u] = (VT)0.0f; e[u] = (VT)0.0f; }
-                bool have = false;                  // corner registers hold the cell of the last processed point
 #pragma unroll
                 for (int k = 0; k < K; ++k) {
-                    const int q = (run0 + k) * V + v;
-                    const ViewRec r = rec[min(q, tile_n * V - 1)];
-                    if ((live >> k & 1u) && r.valid != 0.0f) {       // exact skip of invalid views (see gather_map)
-                        const CornerRec cr = crec[q];
-                        if (!have || (state_s[q] & kRunNewCell)) {
-#pragma unroll
-                            for (int u = 0; u < U; ++u) {
-                                a[u] = load_texel<4, false>(bv + (cr.o[0] + co[u]));
-                                b[u] = load_texel<4, false>(bv + (cr.o[1] + co[u]));
-                                d[u] = load_texel<4, false>(bv + (cr.o[2] + co[u]));
-                                e[u] = load_texel<4, false>(bv + (cr.o[3] + co[u]));
-                            }
-                        }
-                        have = true;
+                    const bool inside = run0 + k < tile_n;
+                    const int q = min((run0 + k) * V + v, last);      // beyond the tile: some valid record, result unused
+                    const uint32_t st = state_s[q];
+                    const CornerRec &cr = crec[q];
+                    if (inside && (st & (kRunValid | kRunNewCell)) == (kRunValid | kRunNewCell)) {     // another texel cell
+                        const uint32_t o0 = cr.o[0], o1 = cr.o[1], o2 = cr.o[2], o3 = cr.o[3];
 #pragma unroll
                         for (int u = 0; u < U; ++u) {
-                            VT s = a[u] * cr.w[0];                       // ATen bilinear: fma chain nw,ne,sw,se
-                            s = v_fma<VT>(b[u], cr.w[1], s);
-                            s = v_fma<VT>(d[u], cr.w[2], s);
-                            s = v_fma<VT>(e[u], cr.w[3], s);
-                            acc[k][u] = acc[k][u] + s * r.wgt;           // fusion.py:385
+                            a[u] = load_texel<4, false>(bv + (o0 + co[u]));
+                            b[u] = load_texel<4, false>(bv + (o1 + co[u]));
+                            d[u] = load_texel<4, false>(bv + (o2 + co[u]));
+                            e[u] = load_texel<4, false>(bv + (o3 + co[u]));
                         }
-                    } else {
-                        have = false;       // the chain of "same cell as the previous point" flags is broken here
                     }
+                    const float w0 = cr.w[0], w1 = cr.w[1], w2 = cr.w[2], w3 = cr.w[3];
+                    const float wgt = rec[q].wgt;
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {
+                        VT s = a[u] * w0;                                // ATen bilinear: fma chain nw,ne,sw,se
+                        s = v_fma<VT>(b[u], w1, s);
+                        s = v_fma<VT>(d[u], w2, s);
+                        s = v_fma<VT>(e[u], w3, s);
+                        acc[k][u] = acc[k][u] + s * wgt;                 // fusion.py:385
+                    }
+                    // keep this point's arithmetic ahead of the next point's fetch: left alone, the optimiser sinks it below
+                    // the next conditional load block, which needs a second set of corner registers (and spills).  The
+                    // empty asm pins the accumulators (register operands) and, as a memory clobber, the later loads.
+#pragma unroll
+                    for (int u = 0; u < U; ++u) asm volatile("" : "+v"(acc[k][u]) : : "memory");
                 }
             }
 #pragma unroll
             for (int k = 0; k < K; ++k) {
-                if (!(live >> k & 1u)) continue;
                 const int p = run0 + k;
+                if (p >= tile_n || flag_s[p] != 0u) continue;            // strict points: gather_map(only_strict) writes them
                 const float cnt = cnt_s[p];
                 const float denom = cnt + 1e-6f;                          // fusion.py:385
                 // the shared-reciprocal IEEE division of gather_map's fast path (bit-identical quotients)
@@ -707,6 +713,12 @@ __device__ __forceinline__ void fused_eval_body(const EvalParams &P)
                 cr.w[0] = c.inw ? c.wnw : 0.0f; cr.w[1] = c.ine ? c.wne : 0.0f;
                 cr.w[2] = c.isw ? c.wsw : 0.0f; cr.w[3] = c.ise ? c.wse : 0.0f;
                 crec_s[(size_t)m.pre_slot * TP * V + p * V + v] = cr;
+            } else if (RUNS && m.runs > 0) {
+                // the cell-run gather multiplies instead of branching: an invalid pair contributes (+-0) * wgt
+                CornerRec cr;
+                cr.o[0] = cr.o[1] = cr.o[2] = cr.o[3] = 0u;
+                cr.w[0] = cr.w[1] = cr.w[2] = cr.w[3] = 0.0f;
+                crec_s[(size_t)m.pre_slot * TP * V + p * V + v] = cr;
             }
         }
         uint32_t st = !(isfinite(o.gx) && isfinite(o.gy) && isfinite(wgt)) ? kRunNonFinite : 0u;
@@ -721,8 +733,10 @@ __device__ __forceinline__ void fused_eval_body(const EvalParams &P)
             }
             const uint32_t q0 = __shfl_up(o0, 1, 64), q1 = __shfl_up(o1, 1, 64), q2 = __shfl_up(o2, 1, 64), q3 = __shfl_up(o3, 1, 64);
             const float pv = __shfl_up(o.valid, 1, 64);
-            const bool same = (threadIdx.x & 63) != 0 && p != 0 && pv != 0.0f && q0 == o0 && q1 == o1 && q2 == o2 && q3 == o3;
+            // a run starts at every RK-th point of the tile: its first valid pair always fetches
+            const bool same = (threadIdx.x & 63) != 0 && (p % (RK > 0 ? RK : 1)) != 0 && pv != 0.0f && q0 == o0 && q1 == o1 && q2 == o2 && q3 == o3;
             if (!same) st |= kRunNewCell;
+            if (o.valid != 0.0f) st |= kRunValid;
         }
         nfp_s[p * V + v] = st;
     }
@@ -835,7 +849,8 @@ hipError_t launch_fused_eval(const EvalParams &P, int mode, hipStream_t stream)
         else if (ru == 3 && rk == 2) hipLaunchKernelGGL((fused_eval_runs_kernel<0, 3, 2, 4>), grid, block, lds, stream, P);
         else if (ru == 2 && rk == 4) hipLaunchKernelGGL((fused_eval_runs_kernel<0, 2, 4, 4>), grid, block, lds, stream, P);
         else if (ru == 2 && rk == 8) hipLaunchKernelGGL((fused_eval_runs_kernel<0, 2, 8, 4>), grid, block, lds, stream, P);
-        else if (ru == 1 && rk == 4) hipLaunchKernelGGL((fused_eval_runs_kernel<0, 1, 4, 6>), grid, block, lds, stream, P);
+        else if (ru == 1 && rk == 4 && P.runs_occ == 6) hipLaunchKernelGGL((fused_eval_runs_kernel<0, 1, 4, 6>), grid, block, lds, stream, P);
+        else if (ru == 1 && rk == 4) hipLaunchKernelGGL((fused_eval_runs_kernel<0, 1, 4, 7>), grid, block, lds, stream, P);
         else if (P.runs_occ == 4) hipLaunchKernelGGL((fused_eval_runs_kernel<0, 1, 8, 4>), grid, block, lds, stream, P);
         else if (P.runs_occ == 6) hipLaunchKernelGGL((fused_eval_runs_kernel<0, 1, 8, 6>), grid, block, lds, stream, P);
         else hipLaunchKernelGGL((fused_eval_runs_kernel<0, 1, 8, 5>), grid, block, lds, stream, P);

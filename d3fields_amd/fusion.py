@@ -292,14 +292,23 @@ class Fusion:
         """Cached torch.isfinite(t).all(): lets the kernel skip invalid views exactly (D3F_FLAG_FINITE_MAPS)."""
         if self._finite_override is not None:       # RigidTracker's private observation: the flag must not depend on data
             return self._finite_override
-        sig = (t.data_ptr(), t._version, tuple(t.shape))
+        # keyed on the tensor OBJECT (weak reference) and its version counter: a new tensor that happens to be allocated
+        # at the address of a checked one is re-checked.  Writers that bypass torch (custom kernels writing into the map
+        # in place) must call invalidate_map_checks() -- a stale "finite" verdict would skip 0*NaN terms the reference keeps.
+        sig = (t._version, tuple(t.shape), t.data_ptr())
         hit = self._finite_cache.get(key)
-        if hit is None or hit[0] != sig:
+        if hit is None or hit[0]() is not t or hit[1] != sig:
             if torch.cuda.is_current_stream_capturing():
                 return False                    # no host sync inside a HIP-graph capture: strict path, same results
-            hit = (sig, bool(torch.isfinite(t).all().item()))
+            import weakref
+            hit = (weakref.ref(t), sig, bool(torch.isfinite(t).all().item()))
             self._finite_cache[key] = hit
-        return hit[1]
+        return hit[2]
+
+    def invalidate_map_checks(self):
+        """Forget the cached 'this map holds only finite values' verdicts (D3F_FLAG_FINITE_MAPS): call after writing into
+        a curr_obs_torch tensor in place from outside torch."""
+        self._finite_cache.clear()
 
     def _is_unordered(self, pts_c, stream):
         """d3f_point_order_locality on a NEW query tensor (cached by storage / version / length, so a grid queried

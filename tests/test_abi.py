@@ -171,6 +171,11 @@ def test_validation_of_topk_and_lattice_entry_points():
     patch = (_lib.ChannelMap * 1)(_lib.ChannelMap(1 << 20, 48, 64, 384, 0, 48 * 64 * 384, 64 * 384, 384))
     assert lib.d3f_eval_plan_query_lattice(ctypes.byref(v), 160, 140, 44, patch, 1, _lib.FLAG_FINITE_MAPS, 0, ctypes.byref(plan)) == 0
     assert plan.reorder == 0 and plan.staged[0] == 16 + 4 and plan.tile_points == 64 and plan.lanes_per_point[0] == 32
+    assert plan.vectors_per_lane[0] == 1 and plan.reserved == 7          # the (1,4) variant built for 7 waves per SIMD
+    wide = (_lib.ChannelMap * 1)(_lib.ChannelMap(1 << 20, 72, 128, 1024, 0, 72 * 128 * 1024, 128 * 1024, 1024))
+    v8 = _views(V=8, H=720, W=1280)
+    assert lib.d3f_eval_plan_query(ctypes.byref(v8), 1000000, wide, 1, _lib.FLAG_FINITE_MAPS, 1, 0, ctypes.byref(plan)) == 0
+    assert plan.reorder == 1 and plan.staged[0] == 16 + 8 and plan.vectors_per_lane[0] == 2 and plan.lanes_per_point[0] == 64
     assert lib.d3f_eval_plan_query_lattice(ctypes.byref(v), 160, 140, 44, patch, 1, 0, 0, ctypes.byref(plan)) == 0
     assert plan.staged[0] == 0 and plan.tile_points == 128     # maps not known to be finite: the direct gather
 
