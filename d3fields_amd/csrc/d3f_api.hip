@@ -150,6 +150,7 @@ void pick_staged_mapping(d3f::MapDesc &m)
 //   D3F_EXP_RUNS_U vectors per lane of the cell-run gather: 0 automatic, 1 / 2 / 3;  D3F_EXP_RUNS_OCC=5: the (1,8) variant
 //                  held to 5 waves per SIMD
 //   D3F_EXP_STORE  -1: write the fused rows with plain stores instead of sc1 ones (see store_out in fuse_eval.hip)
+//   D3F_EXP_SLICED 1 / 2: channel-sliced launch for a dense wide map on a lattice (128- / 256-byte slices, fuse_eval.hip)
 //   D3F_EXP_WALK_TILE  shape of the walk's tile as digits x y z with the same point count (222 default; 224 with a thin map)
 //   D3F_EXP_WALK   lattice brick walk for grids on large maps: -1 off, 0 automatic (default)
 int exp_knob(const char *name)
@@ -226,6 +227,7 @@ int eval_common(const d3f_views *views, const float *pts, int64_t n, const d3f_c
     P.grid_x = grid ? grid->x : nullptr; P.grid_y = grid ? grid->y : nullptr; P.grid_z = grid ? grid->z : nullptr;
     P.grid_ny = grid ? grid->ny : 0; P.grid_nz = grid ? grid->nz : 0;
     P.walk_nx = P.walk_ny = P.walk_nz = 0; P.walk_tx = P.walk_ty = P.walk_tz = 1;
+    P.sl_slices = 0; P.sl_lg = 3; P.sl_vc = 4; P.sl_tiles = P.sl_groups = P.sl_chunks = 0;
     P.runs_occ = exp_knob("D3F_EXP_RUNS_OCC");
     P.store_policy = exp_knob("D3F_EXP_STORE") < 0 ? 0 : 1;
     int64_t map_bytes = 0;
@@ -352,6 +354,28 @@ int eval_common(const d3f_views *views, const float *pts, int64_t n, const d3f_c
         while ((long)P.tile_pts * views->V * 88 > 40 * 1024 && P.tile_pts > round) P.tile_pts >>= 1;   // records + 2 corner slots
         P.lds_pad = 0;
     }
+    // Channel-sliced launch (experiment, D3F_EXP_SLICED = 1: 128-byte slices, 2: 256-byte slices): a lattice on a dense
+    // wide fp32 map that is the FIRST map of the call; any other map must be thin (it rides along with slice 0).
+    {
+        const int sl = exp_knob("D3F_EXP_SLICED");
+        bool ok = walk && (sl >= 1 && sl <= 3) && mode == 0 && n_maps >= 1 && P.maps[0].esize == 4 && P.maps[0].vw == 4 &&
+                  !(out_inter && out_inter[0]) && tl == 0;
+        const int lg = sl + 2, lanes = 1 << lg;      // 1: 8 lanes (128-byte slices), 2: 16 lanes, 3: 32 lanes (512 bytes)
+        P.sl_vc = exp_knob("D3F_EXP_SLICED_VC") > 0 ? exp_knob("D3F_EXP_SLICED_VC") : 4;
+        ok = ok && P.maps[0].C % (4 * lanes) == 0 && P.maps[0].C >= 128;
+        for (int s = 1; s < n_maps && ok; ++s) ok = P.maps[s].C * P.maps[s].esize <= 256 && !(out_inter && out_inter[s]) && P.maps[s].esize == 4;
+        if (ok) {
+            P.walk_tx = P.walk_ty = P.walk_tz = 2;
+            P.sl_lg = lg;
+            P.sl_slices = P.maps[0].C / (4 * lanes);
+            P.sl_tiles = (int64_t)((P.walk_nx + 1) / 2) * ((P.walk_ny + 1) / 2) * ((P.walk_nz + 1) / 2);
+            P.sl_groups = (P.sl_tiles + 3) / 4;
+            P.sl_chunks = (P.sl_groups + 127) / 128;
+            P.tile_pts = 32; P.lds_pad = 0;
+            for (int s = 1; s < n_maps; ++s) pick_mapping(P.maps[s], P.maps[s].vw == 4, P.maps[s].vw >= 2, true, 1);
+            if (((P.sl_chunks * P.sl_slices + 7) / 8) * 8 * 128 > 0x7fffffffLL) P.sl_slices = 0;
+        }
+    }
     // walks: all eight XCDs stay inside one macro-brick of ~32 k points at a time (its texel footprint stays in
     // the 256 MiB Infinity Cache), each taking a contiguous eighth of it (C2 dense 1.97 -> 1.74 ms, C4 patch 4.75 -> 4.17)
     P.xcd_chunk = (reorder && xcd_remap) ? (int)((32768 / P.tile_pts + 7) / 8 * 8) : 0;
@@ -362,7 +386,9 @@ int eval_common(const d3f_views *views, const float *pts, int64_t n, const d3f_c
     P.n_pre = 0;
     for (int s = 0; s < n_maps; ++s)
         if (P.maps[s].runs > 0) P.maps[s].pre_slot = P.n_pre++;
-    if (!(flags & (1u << 28)))
+    if (P.sl_slices > 0) {
+        P.maps[0].pre_slot = 0; P.n_pre = 1;             // the sliced kernel keeps the wide map's corner records itself
+    } else if (!(flags & (1u << 28)))
         for (int s = 0; s < n_maps && P.n_pre < 2; ++s) {
             // 32 B per (point, view) and map: only while records + set-ups stay within 48 KiB (>= 3 workgroups per CU)
             const long lds_after = (long)P.stage_offset + P.stage_floats * 8 + (long)(P.n_pre + 1) * P.tile_pts * views->V * 32;
@@ -379,7 +405,7 @@ int eval_common(const d3f_views *views, const float *pts, int64_t n, const d3f_c
         plan_out->tile_points = P.tile_pts;
         plan_out->reorder = walk ? 2 : (reorder ? 1 : 0);
         plan_out->lds_bytes = P.crec_offset + P.n_pre * P.tile_pts * P.V * 32 + P.lds_pad;
-        plan_out->workgroups = ntiles;
+        plan_out->workgroups = P.sl_slices > 0 ? ((P.sl_chunks * P.sl_slices + 7) / 8) * 8 * 128 : ntiles;
         plan_out->reserved = 0;
         for (int s = 0; s < n_maps; ++s)
             if (P.maps[s].runs > 0) {        // waves per SIMD the chosen cell-run kernel variant is built for

@@ -49,6 +49,9 @@ struct EvalParams {
     // from blockIdx alone (no keys, no sort, no index array).  walk_nx == 0: off.
     int32_t walk_nx, walk_ny, walk_nz;
     int32_t walk_tx, walk_ty, walk_tz;
+    // channel-sliced launch (fused_eval_sliced_kernel): sl_slices > 0 selects it
+    int32_t sl_slices, sl_lg, sl_vc;   // slices per texel of map 0, log2(lanes per point), views with loads in flight
+    int64_t sl_tiles, sl_groups, sl_chunks;   // walk tiles, groups of 4 tiles, chunks of 128 groups
     int32_t runs_occ;      // experiment: waves per SIMD of the (1,8) cell-run kernel variant (4 / 5 / 6)
     int32_t store_policy;  // 1 (default) = fused rows leave as sc1 (write-through, line dropped from L2) stores, 0 = plain
     uint32_t flags;

@@ -796,6 +796,216 @@ __device__ __forceinline__ void fused_eval_body(const EvalParams &P)
     }
 }
 
+// ---- channel-sliced launch for dense maps on a lattice (round 2 experiment, D3F_EXP_SLICED) ----------------------------
+// On maps much larger than the caches the kernel is bound by L2 misses, and an L2 holds only a ~512-point window of
+// whole texels.  Here a workgroup handles 32 points x ONE 128-byte (or 256-byte) channel slice of the
+// wide map, and all the slices of a ~4096-point stretch of the brick walk (a "chunk") are spread over the XCDs as units
+// (chunk, slice): the XCD that owns a unit has its 128 workgroups in flight together and its 4 MiB L2 sees 1/12 (1/6)
+// of every texel, i.e. a 4096-point window -- ideal read hit rate 72 % instead of 57 % (scripts/sim_reuse.py).  The
+// price: phase A (projection, depth test, weights, corner set-up) runs once per (point, slice) instead of once per
+// point.  Arithmetic per (point, view, channel) is that of gather_map (fast or strict form), so results are identical.
+constexpr int kSlicedTile = 32;            // points per workgroup = 4 tiles of the brick walk
+constexpr int kSlicedGroups = 128;         // workgroups per unit = 4096 points per chunk
+
+template <int LG, int VC>                  // lanes per point = 1 << LG: 8 (128-byte slices), 16 (256 B) or 32 (512 B)
+__device__ __forceinline__ void fused_eval_sliced_body(const EvalParams &P)
+{
+    constexpr int LP = 1 << LG, PTS = kBlock / LP, TP = kSlicedTile;
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int V = P.V;
+    ViewRec *rec = reinterpret_cast<ViewRec *>(smem);                       // same layout as fused_eval_body
+    float *dcl_s = reinterpret_cast<float *>(rec + (size_t)TP * V);
+    uint32_t *nfp_s = reinterpret_cast<uint32_t *>(dcl_s + (size_t)TP * V);
+    float *cnt_s = reinterpret_cast<float *>(nfp_s + (size_t)TP * V);
+    uint32_t *flag_s = reinterpret_cast<uint32_t *>(cnt_s + TP);
+    uint32_t *idx_s = flag_s + TP;
+    float *krt = reinterpret_cast<float *>(idx_s + TP);
+    CornerRec *crec_s = reinterpret_cast<CornerRec *>(smem + P.crec_offset);
+    __shared__ TileBox tbs[4];
+
+    // unit (chunk, slice) -> XCD blockIdx % 8; the unit's workgroups are consecutive in that XCD's stream
+    const int xcd = (int)(blockIdx.x & 7u);
+    const int64_t j = (int64_t)(blockIdx.x >> 3);
+    const int64_t unit = (j / kSlicedGroups) * 8 + xcd;
+    const int wg = (int)(j % kSlicedGroups);
+    if (unit >= (int64_t)P.sl_chunks * P.sl_slices) return;
+    const int64_t chunk = unit / P.sl_slices;
+    const int slice = (int)(unit - chunk * P.sl_slices);
+    const int64_t grp4 = chunk * kSlicedGroups + wg;                         // group of four consecutive walk tiles
+    if (grp4 >= P.sl_groups) return;
+    if (threadIdx.x < 4) {
+        const int64_t t = grp4 * 4 + threadIdx.x;
+        TileBox tb = {0, 0, 0, 0, 0, 0};
+        if (t < P.sl_tiles) tb = walk_tile(P, t);
+        tbs[threadIdx.x] = tb;
+    }
+    compute_krt(P.K, P.pose, V, krt, kBlock);
+    __syncthreads();
+    int start[5];
+    start[0] = 0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) start[q + 1] = start[q] + tbs[q].sx * tbs[q].sy * tbs[q].sz;
+    const int tile_n = start[4];
+    auto point_of = [&](int p) -> int64_t {
+        int q = 0;
+        if (p >= start[1]) q = 1;
+        if (p >= start[2]) q = 2;
+        if (p >= start[3]) q = 3;
+        return walk_point(P, tbs[q], p - start[q]);
+    };
+    const float mu = P.mu;
+    const float Wm1 = (float)(P.W - 1), Hm1 = (float)(P.H - 1);
+    const MapDesc &m0 = P.maps[0];                                           // the sliced wide map
+
+    // ---------------- phase A (as fused_eval_body) ----------------
+    for (int idx = threadIdx.x; idx < tile_n * V; idx += kBlock) {
+        const int v = idx / tile_n, p = idx - v * tile_n;
+        const int64_t i = point_of(p);
+        float px, py, pz;
+        fetch_point(P, i, px, py, pz);
+        float wgt;
+        const ViewOut o = eval_view<0>(P.depth, P.H, P.W, krt + v * 12, v, px, py, pz, Wm1, Hm1, mu, wgt);
+        ViewRec r;
+        r.gx = o.gx; r.gy = o.gy; r.wgt = wgt; r.valid = o.valid;
+        rec[p * V + v] = r;
+        dcl_s[p * V + v] = o.dist * o.valid;
+        if (o.valid != 0.0f) {
+            const Corner c = corner_setup(m0, o.gx, o.gy);
+            CornerRec cr;
+            cr.o[0] = c.onw; cr.o[1] = c.one; cr.o[2] = c.osw; cr.o[3] = c.ose;
+            cr.w[0] = c.inw ? c.wnw : 0.0f; cr.w[1] = c.ine ? c.wne : 0.0f;
+            cr.w[2] = c.isw ? c.wsw : 0.0f; cr.w[3] = c.ise ? c.wse : 0.0f;
+            crec_s[p * V + v] = cr;
+        } else {
+            CornerRec cr;                           // invalid pair: texel 0 with zero weights (see phase B)
+            cr.o[0] = cr.o[1] = cr.o[2] = cr.o[3] = 0u;
+            cr.w[0] = cr.w[1] = cr.w[2] = cr.w[3] = 0.0f;
+            crec_s[p * V + v] = cr;
+        }
+        nfp_s[p * V + v] = !(isfinite(o.gx) && isfinite(o.gy) && isfinite(wgt)) ? 1u : 0u;
+    }
+    __syncthreads();
+    for (int p = threadIdx.x; p < tile_n; p += kBlock) {
+        const int64_t i = point_of(p);
+        float dsum = 0.0f, cnt = 0.0f;
+        uint32_t nonfinite = 0u;
+        for (int v = 0; v < V; ++v) {
+            dsum = dsum + dcl_s[p * V + v];
+            cnt = cnt + rec[p * V + v].valid;
+            nonfinite |= nfp_s[p * V + v];
+        }
+        const bool all_invalid = (cnt == 0.0f);
+        float dist_out = dsum / (cnt + 1e-6f);
+        if (all_invalid) dist_out = 1e3f;
+        if (slice == 0) {                                                    // one slice writes the per-point outputs
+            P.out_dist[i] = dist_out;
+            P.out_valid[i] = all_invalid ? 0 : 1;
+        }
+        cnt_s[p] = cnt;
+        idx_s[p] = (uint32_t)i;
+        flag_s[p] = (nonfinite || !(P.flags & kFlagFiniteMaps)) ? 1u : 0u;
+    }
+    __syncthreads();
+
+    // ---------------- phase B: the slice of the wide map, LP lanes per point ----------------
+    {
+        using VT = f32x4;
+        const MapDesc &m = m0;
+        const int lg = threadIdx.x & (LP - 1), grp = threadIdx.x >> LG;
+        const uint32_t co = (uint32_t)(slice * LP + lg) * 16u;               // byte offset of this lane's vector in a texel
+        const char *__restrict__ data = reinterpret_cast<const char *>(m.data);
+        for (int p = grp; p < tile_n; p += PTS) {
+            const int64_t i = idx_s[p];
+            const float cnt = cnt_s[p];
+            const float denom = cnt + 1e-6f;
+            const bool strict = flag_s[p] != 0u;
+            VT acc = (VT)0.0f;
+            if (!strict) {
+                // fast path, branch-free: phase A left an all-zero corner record for an invalid (point, view), so its
+                // loads hit texel 0 of the view and its term is (+-0) * wgt -- adding it changes no bit.
+                // The corner loads of VC views are in flight together, then the views are consumed in view order.
+                int v0 = 0;
+                for (; v0 + VC <= V; v0 += VC) {
+                    VT a[VC], b[VC], d[VC], e[VC];
+                    f32x4 w[VC];
+                    float wg[VC];
+#pragma unroll
+                    for (int q = 0; q < VC; ++q) {
+                        const CornerRec cr = crec_s[p * V + v0 + q];
+                        const char *bv = data + (int64_t)(v0 + q) * m.sv * 4;
+                        a[q] = load_texel<4, false>(bv + (cr.o[0] + co));
+                        b[q] = load_texel<4, false>(bv + (cr.o[1] + co));
+                        d[q] = load_texel<4, false>(bv + (cr.o[2] + co));
+                        e[q] = load_texel<4, false>(bv + (cr.o[3] + co));
+                        w[q] = f32x4{cr.w[0], cr.w[1], cr.w[2], cr.w[3]};
+                        wg[q] = rec[p * V + v0 + q].wgt;
+                    }
+#pragma unroll
+                    for (int q = 0; q < VC; ++q) {
+                        VT s_ = a[q] * w[q].x;
+                        s_ = v_fma<VT>(b[q], w[q].y, s_);
+                        s_ = v_fma<VT>(d[q], w[q].z, s_);
+                        s_ = v_fma<VT>(e[q], w[q].w, s_);
+                        acc = acc + s_ * wg[q];
+                    }
+                }
+                for (; v0 < V; ++v0) {
+                    const CornerRec cr = crec_s[p * V + v0];
+                    const char *bv = data + (int64_t)v0 * m.sv * 4;
+                    const VT a = load_texel<4, false>(bv + (cr.o[0] + co)), b = load_texel<4, false>(bv + (cr.o[1] + co));
+                    const VT d = load_texel<4, false>(bv + (cr.o[2] + co)), e = load_texel<4, false>(bv + (cr.o[3] + co));
+                    VT s_ = a * cr.w[0];
+                    s_ = v_fma<VT>(b, cr.w[1], s_);
+                    s_ = v_fma<VT>(d, cr.w[2], s_);
+                    s_ = v_fma<VT>(e, cr.w[3], s_);
+                    acc = acc + s_ * rec[p * V + v0].wgt;
+                }
+            } else {
+                for (int v = 0; v < V; ++v) {
+                    const ViewRec r = rec[p * V + v];
+                    const char *bv = data + (int64_t)v * m.sv * 4;
+                    const Corner c = corner_setup(m, r.gx, r.gy);
+                    const VT a = load_texel<4, false>(bv + (c.onw + co)), b = load_texel<4, false>(bv + (c.one + co));
+                    const VT d = load_texel<4, false>(bv + (c.osw + co)), e = load_texel<4, false>(bv + (c.ose + co));
+                    const VT av = c.inw ? a : (VT)0.0f, bvv = c.ine ? b : (VT)0.0f, dv = c.isw ? d : (VT)0.0f, ev = c.ise ? e : (VT)0.0f;
+                    VT s_ = av * c.wnw;
+                    s_ = v_fma<VT>(bvv, c.wne, s_);
+                    s_ = v_fma<VT>(dv, c.wsw, s_);
+                    s_ = v_fma<VT>(ev, c.wse, s_);
+                    acc = acc + (s_ * r.valid) * r.wgt;
+                }
+            }
+            VT o = (VT)0.0f;
+            if (cnt != 0.0f) {
+                if (strict) {
+                    o = acc / denom;
+                } else {
+                    const float r0 = __builtin_amdgcn_rcpf(denom);
+                    const float rcp_d = fmaf(fmaf(-denom, r0, 1.0f), r0, r0);
+                    VT q = acc * rcp_d;
+                    q = v_fma<VT>(v_fma<VT>(q, -denom, acc), rcp_d, q);
+                    q = v_fma<VT>(v_fma<VT>(q, -denom, acc), rcp_d, q);
+                    o = q;
+                }
+            }
+            store_out<VT>(m.out + i * m.C + (co >> 2), o, P.store_policy);
+        }
+    }
+    // the other (thin) maps of the launch ride along with slice 0
+    if (slice == 0)
+        for (int s = 1; s < P.n_maps; ++s) {
+            const MapDesc &m = P.maps[s];
+            switch (m.vw) {
+            case 4: gather_map_u<4, false, true>(m, P, rec, cnt_s, flag_s, idx_s, 0, tile_n, nullptr); break;
+            case 2: gather_map_u<2, false, true>(m, P, rec, cnt_s, flag_s, idx_s, 0, tile_n, nullptr); break;
+            default: gather_map_u<1, false, true>(m, P, rec, cnt_s, flag_s, idx_s, 0, tile_n, nullptr); break;
+            }
+        }
+}
+
+template <int LG, int VC, int WAVES>
+__global__ __launch_bounds__(kBlock, WAVES) void fused_eval_sliced_kernel(const EvalParams P) { fused_eval_sliced_body<LG, VC>(P); }
+
 // Three entry points over one body: the plain kernel (<= 3 channel vectors per lane) is held to 128 VGPRs
 // = 4 waves per SIMD -- the gather lives on memory-level parallelism; the WIDE variant adds the 4-vector
 // load-use path (C = 1024: a whole wave per point) with its natural register count; the LDS-staging variant
@@ -840,6 +1050,20 @@ hipError_t launch_fused_eval(const EvalParams &P, int mode, hipStream_t stream)
         wide |= (P.maps[s].unroll == -4);
         f16 |= (P.maps[s].esize == 2);
         runs |= (P.maps[s].runs > 0);
+    }
+    if (mode == 0 && P.sl_slices > 0) {
+        const int64_t units = (int64_t)P.sl_chunks * P.sl_slices;
+        const int64_t wgs = (units + 7) / 8 * 8 * kSlicedGroups;
+        const size_t lds_s = (size_t)P.crec_offset + (size_t)kSlicedTile * P.V * 32;
+        const dim3 gs((unsigned)wgs);
+        if (P.sl_lg == 5 && P.sl_vc == 2) hipLaunchKernelGGL((fused_eval_sliced_kernel<5, 2, 7>), gs, block, lds_s, stream, P);
+        else if (P.sl_lg == 5) hipLaunchKernelGGL((fused_eval_sliced_kernel<5, 4, 5>), gs, block, lds_s, stream, P);
+        else if (P.sl_lg == 4 && P.sl_vc == 2) hipLaunchKernelGGL((fused_eval_sliced_kernel<4, 2, 7>), gs, block, lds_s, stream, P);
+        else if (P.sl_lg == 4 && P.sl_vc == 1) hipLaunchKernelGGL((fused_eval_sliced_kernel<4, 1, 8>), gs, block, lds_s, stream, P);
+        else if (P.sl_lg == 4) hipLaunchKernelGGL((fused_eval_sliced_kernel<4, 4, 5>), gs, block, lds_s, stream, P);
+        else if (P.sl_vc == 2) hipLaunchKernelGGL((fused_eval_sliced_kernel<3, 2, 7>), gs, block, lds_s, stream, P);
+        else hipLaunchKernelGGL((fused_eval_sliced_kernel<3, 4, 5>), gs, block, lds_s, stream, P);
+        return hipGetLastError();
     }
     if (mode == 0 && runs && !f16 && !wide && P.stage_floats == 0) {
         int ru = 1, rk = 8;

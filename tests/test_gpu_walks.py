@@ -236,3 +236,36 @@ def test_bench_workload_matches_oracle(dev, workload):
     assert np.array_equal(cpu(out["dist"][pick]), ref["dist"])
     for i, k in enumerate(names):
         assert rel_err(cpu(out[k][pick]), ref["sets"][i]) <= TOL, k
+
+
+# ---- channel-sliced launch (experiment knob) == default launch, bit for bit -------------------------------------------
+@pytest.mark.parametrize("dims,C,mask", [((47, 53, 29), 384, True), ((64, 33, 37), 128, False), ((70, 70, 17), 1024, False),
+                                         ((33, 35, 61), 192, True)])
+def test_channel_sliced_launch_is_bit_identical(dev, dims, C, mask):
+    from d3fields_amd import create_init_grid, synth, _lib
+    V, H, W = 4, 96, 128
+    maps = {"dino_feats": synth.random_map(V, H, W, C, seed=1, device=dev)}
+    names = ["dino_feats"]
+    if mask:
+        maps["mask"] = synth.random_onehot_mask(V, H, W, 8, seed=2, device=dev)
+        names.append("mask")
+    f, sc = fusion_for(dev, V, H, W, maps)
+    grid = create_init_grid(box_for(*dims, 0.004), 0.004)[0]
+    grid[4321, 0] = float("nan")                                                       # a strict point
+    pts = grid.to(dev)
+    with torch.no_grad():
+        f.tuning_flags = _lib.TUNE_NO_REORDER
+        base = f.batch_eval(pts, return_names=names)
+        f.tuning_flags = _lib.TUNE_FORCE_REORDER
+        outs = {}
+        for sl in (1, 2, 3):
+            if C % (32 << (sl - 1)):
+                continue
+            for vc in (1, 2, 4):
+                with knobs(D3F_EXP_SLICED=sl, D3F_EXP_SLICED_VC=vc):
+                    outs[(sl, vc)] = f.batch_eval(pts, return_names=names)
+    assert outs
+    for sl, o in outs.items():
+        for k in ["dist", "valid_mask"] + names:
+            a, b = o[k], base[k]
+            assert torch.equal(torch.isnan(a), torch.isnan(b)) and torch.equal(torch.nan_to_num(a.float()), torch.nan_to_num(b.float())), (sl, k)
