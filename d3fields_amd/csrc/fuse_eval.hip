@@ -422,7 +422,9 @@ constexpr uint32_t kRunValid = 4u;         // the view is valid for the point (i
 // that started at +0 changes no bit (the argument of gather_map's exact skip) -- fewer exec-mask
 // round trips and LDS waits than skipping it.  A strict point (non-finite projection) takes part like any other and is
 // simply not stored here.
-template <int U, int K>
+// VFIX: the view count as a compile-time constant (4 = the reference's camera rig: LDS record addresses become
+// immediates and the view loop unrolls), 0 = read it from the launch parameters.
+template <int U, int K, int VFIX>
 __device__ __forceinline__ void gather_map_runs(const MapDesc &m, const EvalParams &P, const ViewRec *rec,
                                                 const uint32_t *state_s, const float *cnt_s, const uint32_t *flag_s,
                                                 const uint32_t *idx_s, int64_t idx_base, int tile_n, const CornerRec *crec)
@@ -433,7 +435,7 @@ __device__ __forceinline__ void gather_map_runs(const MapDesc &m, const EvalPara
     const int grp = threadIdx.x >> m.lpp_log2;
     const int ngrp = kBlock >> m.lpp_log2;
     const int cvec = m.C / 4;
-    const int V = P.V;
+    const int V = VFIX > 0 ? VFIX : P.V;
     const char *__restrict__ data = reinterpret_cast<const char *>(m.data);
     const int last = tile_n * V - 1;
 
@@ -447,7 +449,8 @@ __device__ __forceinline__ void gather_map_runs(const MapDesc &m, const EvalPara
             for (int k = 0; k < K; ++k)
 #pragma unroll
                 for (int u = 0; u < U; ++u) acc[k][u] = (VT)0.0f;
-            for (int v = 0; v < V; ++v) {
+#pragma unroll 1
+            for (int v = 0; v < V; ++v) {          // kept rolled: unrolled views let the scheduler interleave them and spill
                 const char *bv = data + (int64_t)v * m.sv * 4;
                 VT a[U], b[U], d[U], e[U];
 #pragma unroll
@@ -779,7 +782,8 @@ __device__ __forceinline__ void fused_eval_body(const EvalParams &P)
         if (RUNS && m.runs > 0) {
             // non-strict points through the cell-run gather, the (rare) strict ones through the generic path
             // (the host gives such a map 16-byte vectors, one per lane, and a corner-record slot)
-            gather_map_runs<(RU > 0 ? RU : 1), (RK > 0 ? RK : 1)>(m, P, rec, nfp_s, cnt_s, flag_s, idx_s, idx_base, tile_n, crec);
+            if (V == 4) gather_map_runs<(RU > 0 ? RU : 1), (RK > 0 ? RK : 1), 4>(m, P, rec, nfp_s, cnt_s, flag_s, idx_s, idx_base, tile_n, crec);
+            else gather_map_runs<(RU > 0 ? RU : 1), (RK > 0 ? RK : 1), 0>(m, P, rec, nfp_s, cnt_s, flag_s, idx_s, idx_base, tile_n, crec);
             gather_map<4, (RU > 0 ? RU : 1), true>(m, P, rec, cnt_s, flag_s, idx_s, idx_base, tile_n, crec, true);
             continue;
         }
