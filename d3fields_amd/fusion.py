@@ -235,6 +235,10 @@ class Fusion:
         self.cache_point_order = True           # keep the Morton order of an unchanged query tensor (a grid queried every
         self._order_ws = None                   # frame) in its scratch and skip the ~0.12 ms re-sort
         self._lattice_cache = None
+        self.async_probes = True                # without a per-tensor cache hit: probe asynchronously, launch on the previous verdict
+        self._hints = {}                        # n -> [lattice dims or None, unordered?]: what the last finished probes of a
+        self._pending = []                      #      query of that size said; _pending: probes still in flight
+        self._pinned = []                       # reusable pinned host buffers for the probe results
         self._last_plan = None
         self.record_plans = False               # last_plan(): query the launch plan of every eval (bench.py, tests)
         self.detect_lattice = True              # probe new query tensors for create_init_grid's layout (brick walk, no sort)
@@ -345,6 +349,54 @@ class Fusion:
             self._lattice_cache = hit
         return hit[1]
 
+    # ---- probes without a host sync ------------------------------------------------------------------------
+    # Both probes (is the tensor create_init_grid's lattice? has the caller's order any locality?) only choose the ORDER
+    # in which points are processed; no result depends on them (d3f_eval_lattice is correct for any dims whose product
+    # is n).  So a query whose tensor is not in the per-tensor cache does not wait for its own probes: they are enqueued,
+    # their results land in pinned host memory, and the launch uses the verdict of the most recent FINISHED probes of
+    # a query of the same size (per-frame grids / clouds repeat their layout).  Only the first query of a size waits.
+    def _poll_probes(self):
+        still = []
+        for n, out_host, ev in self._pending:
+            if ev.query():
+                li = out_host[:4].view(torch.int32).tolist()
+                near, far = out_host[4:6].tolist()
+                dims = tuple(li[:3]) if (li[0] > 0 and li[3] == 0) else None
+                self._hints[n] = [dims, bool(near > 0.25 * far)]
+                self._pinned.append(out_host)
+            else:
+                still.append((n, out_host, ev))
+        self._pending = still
+
+    def _enqueue_probes(self, pts_c, stream):
+        """lattice probe + locality probe of pts_c on the current stream; results -> pinned host memory, asynchronously"""
+        dev = pts_c.device
+        n = pts_c.shape[0]
+        out = torch.zeros(6, dtype=torch.float32, device=dev)           # [0:4] int32 lattice verdict, [4:6] near / far
+        _lib.check(self._lib.d3f_lattice_probe(_lib.ptr(pts_c), n, _lib.ptr(out), stream))
+        _lib.check(self._lib.d3f_point_order_locality(_lib.ptr(pts_c), n, ctypes.c_void_p(out.data_ptr() + 16), stream))
+        host = self._pinned.pop() if self._pinned else torch.empty(6, dtype=torch.float32).pin_memory()
+        host.copy_(out, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(dev))
+        self._pending.append((n, host, ev))
+        return ev
+
+    def _order_hint(self, pts_c, stream):
+        """(lattice dims or None, unordered?) for this query without waiting for its own probes (see above)"""
+        n = pts_c.shape[0]
+        self._poll_probes()
+        if len(self._pending) < 8:                                       # bounded queue: a stalled stream must not pile up probes
+            ev = self._enqueue_probes(pts_c, stream)
+        else:
+            ev = None
+        if n not in self._hints:
+            if ev is None:
+                ev = self._pending[-1][2]
+            ev.synchronize()                                             # first query of this size: wait once
+            self._poll_probes()
+        return tuple(self._hints.get(n, [None, False]))
+
     def last_plan(self):
         """What the last eval / batch_eval launched (for bench.py and tests): kernel entry point, tile size and how the
         points were ordered -- from d3f_eval_plan_query on the same shapes and flags."""
@@ -438,9 +490,15 @@ class Fusion:
                     inter[s] = it.data_ptr()
             flags = (_lib.FLAG_FINITE_MAPS if finite else 0) | int(self.tuning_flags)
             ws, ws_bytes = None, 0
-            dims = None
-            if self.reorder_points and self.detect_lattice and names and n >= 65536:
-                dims = self._lattice_dims(pts_c, stream)
+            dims, hinted_unordered = None, None
+            if self.reorder_points and names and n >= 65536 and not torch.cuda.is_current_stream_capturing():
+                if self.async_probes and not self.cache_point_order:
+                    # no per-tensor cache: probes run asynchronously, the launch follows the last finished verdict
+                    dims, hinted_unordered = self._order_hint(pts_c, stream)
+                    if not self.detect_lattice:
+                        dims = None
+                elif self.detect_lattice:
+                    dims = self._lattice_dims(pts_c, stream)
             if dims is not None:
                 # a regular grid: closed-form brick walk on large maps / column runs on patch-resolution maps; no scratch
                 if self.record_plans:
@@ -451,7 +509,8 @@ class Fusion:
                 return outputs, (pts_c, keep[0], keep[1], keep[2], used_maps)
             if self.reorder_points and names and n >= 65536:
                 small = sum(m.numel() * m.element_size() for m in used_maps) <= (64 << 20)
-                if small and self.detect_point_order and self._is_unordered(pts_c, stream):
+                if small and self.detect_point_order and (hinted_unordered if hinted_unordered is not None
+                                                          else self._is_unordered(pts_c, stream)):
                     flags |= _lib.FLAG_UNORDERED_POINTS     # larger maps are walked in Morton order anyway
                 ws_bytes = lib.d3f_eval_workspace_bytes(n)
                 sig = (pts_c.data_ptr(), pts_c._version, n, int(stream.value or 0))   # per stream: the order is written asynchronously

@@ -269,3 +269,35 @@ def test_channel_sliced_launch_is_bit_identical(dev, dims, C, mask):
         for k in ["dist", "valid_mask"] + names:
             a, b = o[k], base[k]
             assert torch.equal(torch.isnan(a), torch.isnan(b)) and torch.equal(torch.nan_to_num(a.float()), torch.nan_to_num(b.float())), (sl, k)
+
+
+def test_async_probes_follow_the_data_and_never_change_results(dev):
+    """Without the per-tensor cache (bench.py's mode) the shim launches on the verdict of the last FINISHED probes of a
+    query of the same size and refreshes it asynchronously: a cloud that follows a grid of the same size is walked with
+    the grid's (now meaningless) dims once -- still bit-identical -- and the hint then turns."""
+    from d3fields_amd import create_init_grid, synth, _lib
+    V, H, W, C = 4, 96, 128, 96
+    maps = {"dino_feats": synth.random_map(V, H, W, C, seed=1, device=dev)}
+    f, sc = fusion_for(dev, V, H, W, maps)
+    f.cache_point_order = False
+    grid = create_init_grid(box_for(64, 33, 37, 0.004), 0.004)[0].to(dev)
+    n = grid.shape[0]
+    cloud = (synth.random_cloud(n, seed=4) * 0.3).to(dev)
+    shuffled = grid[torch.randperm(n, generator=torch.Generator().manual_seed(2)).to(dev)].contiguous()
+    with torch.no_grad():
+        f.tuning_flags = _lib.TUNE_NO_REORDER
+        want = {id(t): f.batch_eval(t, return_names=["dino_feats"]) for t in (grid, cloud, shuffled)}
+        f.tuning_flags = _lib.TUNE_FORCE_REORDER
+        f._hints.clear()
+        seen = []
+        for t in (grid, grid, cloud, cloud, cloud, shuffled, shuffled, grid, grid):
+            got = f.batch_eval(t, return_names=["dino_feats"])
+            for k in got:
+                assert torch.equal(got[k], want[id(t)][k]), k
+            torch.cuda.synchronize(dev)
+            f._poll_probes()
+            seen.append(f._hints[n][0])
+    assert seen[0] == (64, 33, 37) and seen[1] == (64, 33, 37)
+    assert seen[2] is None and seen[4] is None and seen[6] is None           # the probes of the cloud / shuffled grid finished
+    assert seen[8] == (64, 33, 37)
+    assert len(f._pending) == 0
