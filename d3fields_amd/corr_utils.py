@@ -62,7 +62,8 @@ def _to_target(src, tgt, scale, dist_type, mode, channel_axis):
 
 
 def compute_similarity(src_feat_map, tgt_feat, scale, dist_type="l2"):
-    """[B,H,W,C] numpy, [C] numpy -> [B,H,W] numpy: exp(-dist*scale)  (corr_utils.py:4-19)."""
+    """[B,H,W,C] numpy, [C] numpy -> [B,H,W] numpy: exp(-dist*scale)  (corr_utils.py:4-19).  Output dtype follows the
+    inputs like the reference's; the arithmetic is fp32 on the device."""
     assert src_feat_map.shape[-1] == tgt_feat.shape[0]
     _dist_code(dist_type)
     dev = torch.device("cuda", torch.cuda.current_device())
@@ -71,7 +72,9 @@ def compute_similarity(src_feat_map, tgt_feat, scale, dist_type="l2"):
     out = _to_target(src, tgt, scale, dist_type, _lib.SIM_EXP, channel_axis=-1)
     res = out.cpu().numpy()
     assert res.shape == src_feat_map.shape[:3]
-    return res
+    # the numpy reference returns its input's dtype (float64 in -> float64 out); the values here are computed in fp32 on
+    # the device (relative difference ~1e-7 from a float64 evaluation) and handed back in that dtype
+    return res.astype(np.result_type(src_feat_map.dtype, tgt_feat.dtype), copy=False) if np.issubdtype(src_feat_map.dtype, np.floating) else res
 
 
 def compute_similarity_tensor(src_feat_map, tgt_feat, scale, dist_type="l2"):
