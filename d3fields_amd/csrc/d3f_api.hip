@@ -150,7 +150,9 @@ void pick_staged_mapping(d3f::MapDesc &m)
 //   D3F_EXP_RUNS_U vectors per lane of the cell-run gather: 0 automatic, 1 / 2 / 3;  D3F_EXP_RUNS_OCC=5: the (1,8) variant
 //                  held to 5 waves per SIMD
 //   D3F_EXP_STORE  -1: write the fused rows with plain stores instead of sc1 ones (see store_out in fuse_eval.hip)
-//   D3F_EXP_SLICED 1 / 2: channel-sliced launch for a dense wide map on a lattice (128- / 256-byte slices, fuse_eval.hip)
+//   D3F_EXP_SLICED 1 / 2 / 3: force the channel-sliced launch for a dense wide map on a lattice (128- / 256- / 512-byte
+//                  slices, fuse_eval.hip); -1: never (default: only with thin companion maps); _VC views in flight, _UNIT
+//                  workgroups per unit
 //   D3F_EXP_WALK_TILE  shape of the walk's tile as digits x y z with the same point count (222 default; 224 with a thin map)
 //   D3F_EXP_WALK   lattice brick walk for grids on large maps: -1 off, 0 automatic (default)
 int exp_knob(const char *name)
@@ -227,7 +229,7 @@ int eval_common(const d3f_views *views, const float *pts, int64_t n, const d3f_c
     P.grid_x = grid ? grid->x : nullptr; P.grid_y = grid ? grid->y : nullptr; P.grid_z = grid ? grid->z : nullptr;
     P.grid_ny = grid ? grid->ny : 0; P.grid_nz = grid ? grid->nz : 0;
     P.walk_nx = P.walk_ny = P.walk_nz = 0; P.walk_tx = P.walk_ty = P.walk_tz = 1;
-    P.sl_slices = 0; P.sl_lg = 3; P.sl_vc = 4; P.sl_tiles = P.sl_groups = P.sl_chunks = 0;
+    P.sl_unit = 128; P.sl_slices = 0; P.sl_lg = 3; P.sl_vc = 4; P.sl_tiles = P.sl_groups = P.sl_chunks = 0;
     P.runs_occ = exp_knob("D3F_EXP_RUNS_OCC");
     P.store_policy = exp_knob("D3F_EXP_STORE") < 0 ? 0 : 1;
     int64_t map_bytes = 0;
@@ -354,14 +356,22 @@ int eval_common(const d3f_views *views, const float *pts, int64_t n, const d3f_c
         while ((long)P.tile_pts * views->V * 88 > 40 * 1024 && P.tile_pts > round) P.tile_pts >>= 1;   // records + 2 corner slots
         P.lds_pad = 0;
     }
-    // Channel-sliced launch (experiment, D3F_EXP_SLICED = 1: 128-byte slices, 2: 256-byte slices): a lattice on a dense
-    // wide fp32 map that is the FIRST map of the call; any other map must be thin (it rides along with slice 0).
+    // Channel-sliced launch (fuse_eval.hip): a lattice on a dense wide fp32 map that is the FIRST map of the call; any
+    // other map must be thin (it rides along with slice 0).  Default only where it measured faster: a wide map WITH thin
+    // companions (C3-dense, features + 8-channel mask: 3.04 -> 2.80 ms with 512-byte slices, two views in flight --
+    // there the whole-texel kernel stalls on the thin map's gather, 16 points x 2 lanes per workgroup); for a wide map
+    // alone slicing removes 20-29 % of the L2 fills and no time.  D3F_EXP_SLICED = 1 / 2 / 3 forces
+    // 128- / 256- / 512-byte slices, -1 disables.
     {
-        const int sl = exp_knob("D3F_EXP_SLICED");
+        int sl = exp_knob("D3F_EXP_SLICED");
+        bool thin_rest = n_maps >= 2;
+        for (int s = 1; s < n_maps; ++s) thin_rest = thin_rest && P.maps[s].C * P.maps[s].esize <= 256 && P.maps[s].esize == 4;
+        const bool automatic = sl == 0 && thin_rest && n_maps >= 1 && P.maps[0].C % 128 == 0 && P.maps[0].C <= 512;
+        if (automatic) sl = 3;
         bool ok = walk && (sl >= 1 && sl <= 3) && mode == 0 && n_maps >= 1 && P.maps[0].esize == 4 && P.maps[0].vw == 4 &&
                   !(out_inter && out_inter[0]) && tl == 0;
         const int lg = sl + 2, lanes = 1 << lg;      // 1: 8 lanes (128-byte slices), 2: 16 lanes, 3: 32 lanes (512 bytes)
-        P.sl_vc = exp_knob("D3F_EXP_SLICED_VC") > 0 ? exp_knob("D3F_EXP_SLICED_VC") : 4;
+        P.sl_vc = exp_knob("D3F_EXP_SLICED_VC") > 0 ? exp_knob("D3F_EXP_SLICED_VC") : (automatic ? 2 : 4);
         ok = ok && P.maps[0].C % (4 * lanes) == 0 && P.maps[0].C >= 128;
         for (int s = 1; s < n_maps && ok; ++s) ok = P.maps[s].C * P.maps[s].esize <= 256 && !(out_inter && out_inter[s]) && P.maps[s].esize == 4;
         if (ok) {
@@ -370,10 +380,11 @@ int eval_common(const d3f_views *views, const float *pts, int64_t n, const d3f_c
             P.sl_slices = P.maps[0].C / (4 * lanes);
             P.sl_tiles = (int64_t)((P.walk_nx + 1) / 2) * ((P.walk_ny + 1) / 2) * ((P.walk_nz + 1) / 2);
             P.sl_groups = (P.sl_tiles + 3) / 4;
-            P.sl_chunks = (P.sl_groups + 127) / 128;
+            P.sl_unit = exp_knob("D3F_EXP_SLICED_UNIT") > 0 ? exp_knob("D3F_EXP_SLICED_UNIT") : 128;   // 4096 points per unit (smaller: slower)
+            P.sl_chunks = (P.sl_groups + P.sl_unit - 1) / P.sl_unit;
             P.tile_pts = 32; P.lds_pad = 0;
             for (int s = 1; s < n_maps; ++s) pick_mapping(P.maps[s], P.maps[s].vw == 4, P.maps[s].vw >= 2, true, 1);
-            if (((P.sl_chunks * P.sl_slices + 7) / 8) * 8 * 128 > 0x7fffffffLL) P.sl_slices = 0;
+            if (((P.sl_chunks * P.sl_slices + 7) / 8) * 8 * P.sl_unit > 0x7fffffffLL) P.sl_slices = 0;
         }
     }
     // walks: all eight XCDs stay inside one macro-brick of ~32 k points at a time (its texel footprint stays in
@@ -405,8 +416,8 @@ int eval_common(const d3f_views *views, const float *pts, int64_t n, const d3f_c
         plan_out->tile_points = P.tile_pts;
         plan_out->reorder = walk ? 2 : (reorder ? 1 : 0);
         plan_out->lds_bytes = P.crec_offset + P.n_pre * P.tile_pts * P.V * 32 + P.lds_pad;
-        plan_out->workgroups = P.sl_slices > 0 ? ((P.sl_chunks * P.sl_slices + 7) / 8) * 8 * 128 : ntiles;
-        plan_out->reserved = 0;
+        plan_out->workgroups = P.sl_slices > 0 ? ((P.sl_chunks * P.sl_slices + 7) / 8) * 8 * P.sl_unit : ntiles;
+        plan_out->reserved = P.sl_slices > 0 ? 100 + P.sl_lg * 10 + P.sl_vc : 0;      // 1LV: sliced launch, L = log2(lanes per point), V = views in flight
         for (int s = 0; s < n_maps; ++s)
             if (P.maps[s].runs > 0) {        // waves per SIMD the chosen cell-run kernel variant is built for
                 const int ru = P.maps[s].unroll, rk = P.maps[s].runs;

@@ -50,6 +50,7 @@ struct EvalParams {
     int32_t walk_nx, walk_ny, walk_nz;
     int32_t walk_tx, walk_ty, walk_tz;
     // channel-sliced launch (fused_eval_sliced_kernel): sl_slices > 0 selects it
+    int32_t sl_unit;                   // workgroups (of 32 points) per unit
     int32_t sl_slices, sl_lg, sl_vc;   // slices per texel of map 0, log2(lanes per point), views with loads in flight
     int64_t sl_tiles, sl_groups, sl_chunks;   // walk tiles, groups of 4 tiles, chunks of 128 groups
     int32_t runs_occ;      // experiment: waves per SIMD of the (1,8) cell-run kernel variant (4 / 5 / 6)

@@ -809,7 +809,8 @@ __device__ __forceinline__ void fused_eval_body(const EvalParams &P)
 // price: phase A (projection, depth test, weights, corner set-up) runs once per (point, slice) instead of once per
 // point.  Arithmetic per (point, view, channel) is that of gather_map (fast or strict form), so results are identical.
 constexpr int kSlicedTile = 32;            // points per workgroup = 4 tiles of the brick walk
-constexpr int kSlicedGroups = 128;         // workgroups per unit = 4096 points per chunk
+// workgroups per unit (EvalParams::sl_unit): 128 = 4096 points per chunk for 128-byte slices, fewer for wider slices so
+// that a unit's texel slices still fit one L2
 
 template <int LG, int VC>                  // lanes per point = 1 << LG: 8 (128-byte slices), 16 (256 B) or 32 (512 B)
 __device__ __forceinline__ void fused_eval_sliced_body(const EvalParams &P)
@@ -830,12 +831,12 @@ __device__ __forceinline__ void fused_eval_sliced_body(const EvalParams &P)
     // unit (chunk, slice) -> XCD blockIdx % 8; the unit's workgroups are consecutive in that XCD's stream
     const int xcd = (int)(blockIdx.x & 7u);
     const int64_t j = (int64_t)(blockIdx.x >> 3);
-    const int64_t unit = (j / kSlicedGroups) * 8 + xcd;
-    const int wg = (int)(j % kSlicedGroups);
+    const int64_t unit = (j / P.sl_unit) * 8 + xcd;
+    const int wg = (int)(j % P.sl_unit);
     if (unit >= (int64_t)P.sl_chunks * P.sl_slices) return;
     const int64_t chunk = unit / P.sl_slices;
     const int slice = (int)(unit - chunk * P.sl_slices);
-    const int64_t grp4 = chunk * kSlicedGroups + wg;                         // group of four consecutive walk tiles
+    const int64_t grp4 = chunk * P.sl_unit + wg;                              // group of four consecutive walk tiles
     if (grp4 >= P.sl_groups) return;
     if (threadIdx.x < 4) {
         const int64_t t = grp4 * 4 + threadIdx.x;
@@ -1057,7 +1058,7 @@ hipError_t launch_fused_eval(const EvalParams &P, int mode, hipStream_t stream)
     }
     if (mode == 0 && P.sl_slices > 0) {
         const int64_t units = (int64_t)P.sl_chunks * P.sl_slices;
-        const int64_t wgs = (units + 7) / 8 * 8 * kSlicedGroups;
+        const int64_t wgs = (units + 7) / 8 * 8 * P.sl_unit;
         const size_t lds_s = (size_t)P.crec_offset + (size_t)kSlicedTile * P.V * 32;
         const dim3 gs((unsigned)wgs);
         if (P.sl_lg == 5 && P.sl_vc == 2) hipLaunchKernelGGL((fused_eval_sliced_kernel<5, 2, 7>), gs, block, lds_s, stream, P);

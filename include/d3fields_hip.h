@@ -137,7 +137,8 @@ typedef struct d3f_eval_plan {
     int32_t reorder;                        /* 1: points are walked in Morton order (sorted keys); 2: closed-form brick
                                                walk of a lattice (d3f_eval_grid / d3f_eval_lattice)    */
     int32_t lds_bytes;                      /* dynamic LDS per workgroup                              */
-    int32_t reserved;                       /* cell-run gather: waves per SIMD its kernel variant is built for, else 0 */
+    int32_t reserved;                       /* cell-run gather: waves per SIMD its kernel variant is built for; channel-sliced
+                                               launch: 100 + 10*log2(lanes per point) + views in flight; else 0 */
     int64_t workgroups;
     int32_t vector_floats[D3F_MAX_MAPS];    /* 4 / 2 / 1 floats per load                              */
     int32_t lanes_per_point[D3F_MAX_MAPS];

@@ -168,6 +168,11 @@ def test_validation_of_topk_and_lattice_entry_points():
     assert plan.reorder == 2 and plan.tile_points == 8 and plan.workgroups == 80 * 70 * 22 and plan.staged[0] == 0
     assert lib.d3f_eval_plan_query_lattice(ctypes.byref(v), 161, 141, 45, big, 1, _lib.FLAG_FINITE_MAPS, 0, ctypes.byref(plan)) == 0
     assert plan.workgroups == 81 * 71 * 23                     # clipped tiles at the upper faces, no padding
+    both = (_lib.ChannelMap * 2)(_lib.ChannelMap(1 << 20, 480, 640, 384, 0, 480 * 640 * 384, 640 * 384, 384),
+                                 _lib.ChannelMap(1 << 20, 480, 640, 8, 0, 480 * 640 * 8, 640 * 8, 8))
+    assert lib.d3f_eval_plan_query_lattice(ctypes.byref(v), 200, 175, 55, both, 2, _lib.FLAG_FINITE_MAPS, 0, ctypes.byref(plan)) == 0
+    # a wide map with a thin companion on a lattice: channel-sliced launch, 512-byte slices (32 lanes), two views in flight
+    assert plan.reorder == 2 and plan.reserved == 152 and plan.tile_points == 32 and plan.workgroups % 1024 == 0
     patch = (_lib.ChannelMap * 1)(_lib.ChannelMap(1 << 20, 48, 64, 384, 0, 48 * 64 * 384, 64 * 384, 384))
     assert lib.d3f_eval_plan_query_lattice(ctypes.byref(v), 160, 140, 44, patch, 1, _lib.FLAG_FINITE_MAPS, 0, ctypes.byref(plan)) == 0
     assert plan.reorder == 0 and plan.staged[0] == 16 + 4 and plan.tile_points == 64 and plan.lanes_per_point[0] == 32
