@@ -516,12 +516,113 @@ __device__ __forceinline__ void gather_map_runs(const MapDesc &m, const EvalPara
     }
 }
 
+// ---- thin maps (the instance mask, colours: <= 4 lanes per point): the views in parallel across lanes ----------------
+// gather_map walks the views one after the other, which for a map of one vector per lane is V dependent
+// load round trips per point with next to nothing to overlap them.  Here a lane owns (point, view, vector): the
+// 4 corner loads of all views of a point are in flight together, and the ordered sum over the views
+// (((0 + t_0) + t_1) + ...) is rebuilt with V wave shuffles -- the same operands in the same order as the
+// sequential loop (a skipped invalid view adds +0, which is exact, see gather_map), bit-identical results.
+template <typename VT> __device__ __forceinline__ VT shfl_vec(VT x, int src);
+template <> __device__ __forceinline__ float shfl_vec<float>(float x, int src) { return __shfl(x, src, 64); }
+template <> __device__ __forceinline__ f32x2 shfl_vec<f32x2>(f32x2 x, int src)
+{
+    f32x2 r; r.x = __shfl(x.x, src, 64); r.y = __shfl(x.y, src, 64); return r;
+}
+template <> __device__ __forceinline__ f32x4 shfl_vec<f32x4>(f32x4 x, int src)
+{
+    f32x4 r; r.x = __shfl(x.x, src, 64); r.y = __shfl(x.y, src, 64); r.z = __shfl(x.z, src, 64); r.w = __shfl(x.w, src, 64);
+    return r;
+}
+
+__device__ __forceinline__ bool thin_map(const MapDesc &m, const EvalParams &P, int VW)
+{
+    return m.unroll == 1 && m.lpp_log2 <= 2 && m.C / VW <= (1 << m.lpp_log2) && P.V >= 2 && P.V <= 8;
+}
+
+template <int VW>
+__device__ __forceinline__ void gather_map_thin(const MapDesc &m, const EvalParams &P, const ViewRec *rec,
+                                                const float *cnt_s, const uint32_t *flag_s,
+                                                const uint32_t *idx_s, int64_t idx_base, int tile_n)
+{
+    using VT = typename Vec<VW>::T;
+    const int V = P.V;
+    const int vp_log2 = V <= 2 ? 1 : V <= 4 ? 2 : 3;
+    const int sh = m.lpp_log2 + vp_log2;               // lanes of one point: <= 32, inside one wave
+    const int lpp = 1 << m.lpp_log2;
+    const int g = threadIdx.x & (lpp - 1);
+    const int v = (threadIdx.x >> m.lpp_log2) & ((1 << vp_log2) - 1);
+    const int npts = kBlock >> sh;
+    const int base = (threadIdx.x & 63) & ~((1 << sh) - 1);
+    const int cvec = m.C / VW;
+    const uint32_t co = (uint32_t)min(g, cvec - 1) * (VW * 4);
+
+    for (int p = threadIdx.x >> sh; p < tile_n; p += npts) {
+        const int64_t i = idx_base + idx_s[p];
+        const float cnt = cnt_s[p];
+        const bool strict = (flag_s[p] != 0u) || (m.inter != nullptr);
+        VT t = (VT)0.0f;
+        if (v < V) {
+            const ViewRec r = rec[p * V + v];
+            if (strict || r.valid != 0.0f) {
+                const Corner c = corner_setup(m, r.gx, r.gy);
+                const char *bv = reinterpret_cast<const char *>(m.data) + (int64_t)v * m.sv * 4;
+                const VT a = load_texel<VW, false>(bv + (c.onw + co));
+                const VT b = load_texel<VW, false>(bv + (c.one + co));
+                const VT d = load_texel<VW, false>(bv + (c.osw + co));
+                const VT e = load_texel<VW, false>(bv + (c.ose + co));
+                if (!strict) {
+                    const float w0 = c.inw ? c.wnw : 0.0f, w1 = c.ine ? c.wne : 0.0f;
+                    const float w2 = c.isw ? c.wsw : 0.0f, w3 = c.ise ? c.wse : 0.0f;
+                    VT s = a * w0;
+                    s = v_fma<VT>(b, w1, s);
+                    s = v_fma<VT>(d, w2, s);
+                    s = v_fma<VT>(e, w3, s);
+                    t = s * r.wgt;
+                } else {
+                    const VT av = c.inw ? a : (VT)0.0f, bvv = c.ine ? b : (VT)0.0f;
+                    const VT dv = c.isw ? d : (VT)0.0f, ev = c.ise ? e : (VT)0.0f;
+                    VT s = av * c.wnw;
+                    s = v_fma<VT>(bvv, c.wne, s);
+                    s = v_fma<VT>(dv, c.wsw, s);
+                    s = v_fma<VT>(ev, c.wse, s);
+                    if (m.inter && g < cvec)
+                        store_vec<VT>(m.inter + ((int64_t)v * P.n + i) * m.C + g * VW, s);
+                    t = (s * r.valid) * r.wgt;
+                }
+            }
+        }
+        VT acc = (VT)0.0f;
+        for (int vv = 0; vv < V; ++vv) acc = acc + shfl_vec<VT>(t, base + (vv << m.lpp_log2) + g);
+        if (v == 0 && g < cvec) {
+            const float denom = cnt + 1e-6f;
+            VT o;
+            if (cnt == 0.0f) {
+                o = (VT)0.0f;
+            } else if (strict) {
+                o = acc / denom;
+            } else {
+                const float r0 = __builtin_amdgcn_rcpf(denom);
+                const float rcp_d = fmaf(fmaf(-denom, r0, 1.0f), r0, r0);
+                VT q = acc * rcp_d;
+                q = v_fma<VT>(v_fma<VT>(q, -denom, acc), rcp_d, q);
+                q = v_fma<VT>(v_fma<VT>(q, -denom, acc), rcp_d, q);
+                o = q;
+            }
+            store_out<VT>(m.out + i * m.C + (int64_t)g * VW, o, P.store_policy);
+        }
+    }
+}
+
 // SMALL: the cell-run kernel keeps <= 96 VGPRs; its other maps (the mask, colours) are mapped to one vector per lane, batched
 template <int VW, bool WIDE, bool SMALL = false>
 __device__ __forceinline__ void gather_map_u(const MapDesc &m, const EvalParams &P, const ViewRec *rec,
                                              const float *cnt_s, const uint32_t *flag_s,
                                              const uint32_t *idx_s, int64_t idx_base, int tile_n, const CornerRec *crec)
 {
+    if (thin_map(m, P, VW)) {
+        gather_map_thin<VW>(m, P, rec, cnt_s, flag_s, idx_s, idx_base, tile_n);
+        return;
+    }
     switch (m.unroll) {
     case 1: gather_map<VW, 1, true>(m, P, rec, cnt_s, flag_s, idx_s, idx_base, tile_n, crec); break;
     case 2: if (!SMALL) gather_map<VW, 2, true>(m, P, rec, cnt_s, flag_s, idx_s, idx_base, tile_n, crec); break;
