@@ -199,6 +199,23 @@ void pick_runs_mapping(d3f::MapDesc &m, int U, int K)
     m.runs = K;
 }
 
+// Brick of the lattice one window workgroup takes: T points with power-of-two sides (the kernel decodes a slot with
+// shifts), as few padded slots as possible, then as cubic as possible
+void pick_window_brick(int nx, int ny, int nz, int T, int &bx, int &by, int &bz)
+{
+    double best = -1.0;
+    bx = by = 1; bz = T;
+    for (int x = 1; x <= T; x <<= 1)
+        for (int y = 1; x * y <= T; y <<= 1) {
+            const int z = T / (x * y);
+            const double blocks = (double)((nx + x - 1) / x) * ((ny + y - 1) / y) * ((nz + z - 1) / z);
+            const double eff = (double)nx * ny * nz / (blocks * T);
+            const int hi = x > y ? (x > z ? x : z) : (y > z ? y : z), lo = x < y ? (x < z ? x : z) : (y < z ? y : z);
+            const double score = eff * (1.0 - 0.03 * ((double)hi / lo - 1.0));
+            if (score > best) { best = score; bx = x; by = y; bz = z; }
+        }
+}
+
 int tile_points_for(int V)
 {
     // LDS per workgroup = tile*V*24 B (+ small); keep it <= 32 KiB so >= 4 workgroups fit a CU.
@@ -231,6 +248,7 @@ int eval_common(const d3f_views *views, const float *pts, int64_t n, const d3f_c
     P.walk_nx = P.walk_ny = P.walk_nz = 0; P.walk_tx = P.walk_ty = P.walk_tz = 1;
     P.sl_unit = 128; P.sl_slices = 0; P.sl_lg = 3; P.sl_vc = 4; P.sl_tiles = P.sl_groups = P.sl_chunks = 0;
     P.runs_occ = exp_knob("D3F_EXP_RUNS_OCC");
+    P.win_slices = 0; P.win_u = 1; P.win_vc = 1; P.win_pool_offset = 0; P.win_pool_texels = 0; P.win_occ = 4;
     P.store_policy = exp_knob("D3F_EXP_STORE") < 0 ? 0 : 1;
     int64_t map_bytes = 0;
     P.out_dist = out_dist; P.out_valid = out_valid;
@@ -257,10 +275,47 @@ int eval_common(const d3f_views *views, const float *pts, int64_t n, const d3f_c
     // points of the processing order (a grid column in caller order, the Morton walk of a cloud) mostly stay inside one
     // texel cell of a view, so a lane group keeps the four corner vectors in registers across a run of points
     // (fuse_eval.hip).  Needs the exact invalid-view skip (finite maps), no '<k>_inter' output and fp32 maps only.
+    // LDS texel windows (fuse_eval.hip, fused_eval_window_kernel): the FIRST map is a patch-resolution wide fp32 map with
+    // whole 512-byte slices, every other map is thin; same preconditions as the cell-run gather, which it replaces.
+    bool window = false;
+    const int win_knob = exp_knob("D3F_EXP_WINDOW");          // 0 automatic (see below), -1 off, 64 / 128: points per workgroup
+    {
+        window = win_knob > 0 && mode == 0 && n_maps >= 1 && (flags & D3F_FLAG_FINITE_MAPS) && !stage_any && n >= 65536 &&
+                 n <= 0x7fffffffLL && tl == 0 && views->V <= 8 && runs_candidate(P.maps[0], views->H, views->W) &&
+                 P.maps[0].C % 128 == 0 && (P.maps[0].sx % 4) == 0 && (P.maps[0].sy % 4) == 0 && (P.maps[0].sv % 4) == 0 &&
+                 (!plan_only ? (reinterpret_cast<uintptr_t>(P.maps[0].data) % 16 == 0) : true);
+        for (int s = 0; s < n_maps; ++s) window = window && !(out_inter && out_inter[s]);
+        for (int s = 1; s < n_maps; ++s) window = window && P.maps[s].esize == 4 && P.maps[s].C * 4 <= 256;
+        if (window) {
+            const int T = (win_knob == 32 || win_knob == 64 || win_knob == 128) ? win_knob : 64;
+            const int VP = views->V <= 1 ? 1 : views->V <= 2 ? 2 : views->V <= 4 ? 4 : 8;
+            int U = exp_knob("D3F_EXP_WINDOW_U");
+            const int cv = P.maps[0].C / 128;                  // 512-byte granules per texel
+            if (U < 1 || U > 4 || cv % U != 0) U = 1;
+            // per (point, view): 16-byte view record + 32-byte window record; per point 12 bytes
+            const int base = T * views->V * 48 + T * 12 + views->V * 48;
+            const int pool_offset = (base + 511) / 512 * 512;
+            int occ = exp_knob("D3F_EXP_WINDOW_OCC");
+            if (occ < 2 || occ > 4) occ = 4;
+            if (U > 1) occ = 2;                                 // those variants are built for 2 workgroups per CU
+            int texels = 0;
+            for (;; --occ) {
+                const int budget = 160 * 1024 / occ - 1024;     // the kernel's static LDS (corner points, windows) is < 0.5 KiB
+                texels = (budget - pool_offset) / (512 * U) - 2;
+                if (texels >= 2 * views->V || occ == 2) break;  // room for a 2-texel window per view at least
+            }
+            if (exp_knob("D3F_EXP_WINDOW_POOL") > 0 && exp_knob("D3F_EXP_WINDOW_POOL") < texels) texels = exp_knob("D3F_EXP_WINDOW_POOL");
+            texels &= ~1;
+            window = texels >= 2 && (T * VP) % 64 == 0 && n / T < 0x7fffffffLL;
+            P.win_u = U; P.win_occ = occ; P.win_pool_offset = pool_offset; P.win_pool_texels = texels;
+            P.win_vc = exp_knob("D3F_EXP_WINDOW_VC") == 2 ? 2 : 1;
+            P.win_slices = window ? cv / U : 0;
+        }
+    }
     bool any_runs = false;
     {
         const int knob = exp_knob("D3F_EXP_RUNS");
-        bool blocked = knob < 0 || !(flags & D3F_FLAG_FINITE_MAPS) || stage_any || n < 65536 || tl != 0;
+        bool blocked = window || knob < 0 || !(flags & D3F_FLAG_FINITE_MAPS) || stage_any || n < 65536 || tl != 0;
         for (int s = 0; s < n_maps; ++s)
             blocked |= P.maps[s].esize == 2 || (out_inter && out_inter[s]) ||
                        (P.maps[s].unroll == -4 && !runs_candidate(P.maps[s], views->H, views->W));
@@ -280,7 +335,7 @@ int eval_common(const d3f_views *views, const float *pts, int64_t n, const d3f_c
     // gather the caller's z-fastest order is the one wanted: a grid column is one long run.)
     const bool walk = lattice && n_maps > 0 && n >= 65536 && n <= 0x7fffffffLL && !(flags & D3F_TUNE_NO_REORDER) &&
                       exp_knob("D3F_EXP_WALK") >= 0 && !stage_any && !any_runs &&
-                      ((flags & D3F_TUNE_FORCE_REORDER) || map_bytes > (64LL << 20));
+                      ((flags & D3F_TUNE_FORCE_REORDER) || map_bytes > (64LL << 20) || window);
     const bool reorder = walk || (may_reorder && ((flags & D3F_TUNE_FORCE_REORDER) || (n >= 65536 && (map_bytes > (64LL << 20) || stage_any || (flags & D3F_FLAG_UNORDERED_POINTS)))));
     if (walk) {
         P.walk_nx = lattice[0]; P.walk_ny = lattice[1]; P.walk_nz = lattice[2];
@@ -290,7 +345,7 @@ int eval_common(const d3f_views *views, const float *pts, int64_t n, const d3f_c
         // the cell-run gather lives on consecutive points sharing texel cells: sort clouds by 4-mm cells (27-bit keys,
         // one more radix pass) instead of 16-mm ones (C4 patch 3.84 -> 3.38 ms, C2 patch random cloud 0.73 -> 0.66)
         int fine = (int)((flags >> 24) & 0x3);
-        if (fine == 0 && any_runs) fine = 2;
+        if (fine == 0 && (any_runs || window)) fine = 2;
         hipError_t eo = d3f::build_point_order(pts, n, workspace, workspace_bytes, &P.order, hs, fine);
         if (eo != hipSuccess) return hip_fail(eo, "point ordering");
     }
@@ -368,7 +423,7 @@ int eval_common(const d3f_views *views, const float *pts, int64_t n, const d3f_c
         for (int s = 1; s < n_maps; ++s) thin_rest = thin_rest && P.maps[s].C * P.maps[s].esize <= 256 && P.maps[s].esize == 4;
         const bool automatic = sl == 0 && thin_rest && n_maps >= 1 && P.maps[0].C % 128 == 0 && P.maps[0].C <= 512;
         if (automatic) sl = 3;
-        bool ok = walk && (sl >= 1 && sl <= 3) && mode == 0 && n_maps >= 1 && P.maps[0].esize == 4 && P.maps[0].vw == 4 &&
+        bool ok = walk && !window && (sl >= 1 && sl <= 3) && mode == 0 && n_maps >= 1 && P.maps[0].esize == 4 && P.maps[0].vw == 4 &&
                   !(out_inter && out_inter[0]) && tl == 0;
         const int lg = sl + 2, lanes = 1 << lg;      // 1: 8 lanes (128-byte slices), 2: 16 lanes, 3: 32 lanes (512 bytes)
         P.sl_vc = exp_knob("D3F_EXP_SLICED_VC") > 0 ? exp_knob("D3F_EXP_SLICED_VC") : (automatic ? 2 : 4);
@@ -386,6 +441,14 @@ int eval_common(const d3f_views *views, const float *pts, int64_t n, const d3f_c
             for (int s = 1; s < n_maps; ++s) pick_mapping(P.maps[s], P.maps[s].vw == 4, P.maps[s].vw >= 2, true, 1);
             if (((P.sl_chunks * P.sl_slices + 7) / 8) * 8 * P.sl_unit > 0x7fffffffLL) P.sl_slices = 0;
         }
+    }
+    if (window) {
+        const int T = (win_knob == 32 || win_knob == 64 || win_knob == 128) ? win_knob : 64;
+        P.tile_pts = T; P.lds_pad = 0;
+        if (walk) pick_window_brick(P.walk_nx, P.walk_ny, P.walk_nz, T, P.walk_tx, P.walk_ty, P.walk_tz);
+        for (int s = 1; s < n_maps; ++s) pick_mapping(P.maps[s], P.maps[s].vw == 4, P.maps[s].vw >= 2, true, 1);
+        xcd_remap = false;
+        P.flags &= ~D3F_TUNE_XCD_REMAP;
     }
     // walks: all eight XCDs stay inside one macro-brick of ~32 k points at a time (its texel footprint stays in
     // the 256 MiB Infinity Cache), each taking a contiguous eighth of it (C2 dense 1.97 -> 1.74 ms, C4 patch 4.75 -> 4.17)
@@ -417,7 +480,11 @@ int eval_common(const d3f_views *views, const float *pts, int64_t n, const d3f_c
         plan_out->reorder = walk ? 2 : (reorder ? 1 : 0);
         plan_out->lds_bytes = P.crec_offset + P.n_pre * P.tile_pts * P.V * 32 + P.lds_pad;
         plan_out->workgroups = P.sl_slices > 0 ? ((P.sl_chunks * P.sl_slices + 7) / 8) * 8 * P.sl_unit : ntiles;
-        plan_out->reserved = P.sl_slices > 0 ? 100 + P.sl_lg * 10 + P.sl_vc : 0;      // 1LV: sliced launch, L = log2(lanes per point), V = views in flight
+        if (P.win_slices > 0) {
+            plan_out->lds_bytes = P.win_pool_offset + (2 + P.win_pool_texels) * 512 * P.win_u;
+            plan_out->workgroups = ntiles;
+        }
+        plan_out->reserved = P.sl_slices > 0 ? 100 + P.sl_lg * 10 + P.sl_vc : (P.win_slices > 0 ? 200 + P.win_occ : 0);      // 1LV: sliced launch, L = log2(lanes per point), V = views in flight
         for (int s = 0; s < n_maps; ++s)
             if (P.maps[s].runs > 0) {        // waves per SIMD the chosen cell-run kernel variant is built for
                 const int ru = P.maps[s].unroll, rk = P.maps[s].runs;
@@ -428,7 +495,7 @@ int eval_common(const d3f_views *views, const float *pts, int64_t n, const d3f_c
             plan_out->vector_floats[s] = on ? P.maps[s].vw : 0;
             plan_out->lanes_per_point[s] = on ? (1 << P.maps[s].lpp_log2) : 0;
             plan_out->vectors_per_lane[s] = on ? P.maps[s].unroll : 0;   /* negative: load-use per vector */
-            plan_out->staged[s] = on ? (P.maps[s].runs > 0 ? 16 + P.maps[s].runs : P.maps[s].staged) : 0;
+            plan_out->staged[s] = on ? (P.win_slices > 0 && s == 0 ? 3 : (P.maps[s].runs > 0 ? 16 + P.maps[s].runs : P.maps[s].staged)) : 0;
         }
         return D3F_OK;
     }

@@ -53,6 +53,12 @@ struct EvalParams {
     int32_t sl_unit;                   // workgroups (of 32 points) per unit
     int32_t sl_slices, sl_lg, sl_vc;   // slices per texel of map 0, log2(lanes per point), views with loads in flight
     int64_t sl_tiles, sl_groups, sl_chunks;   // walk tiles, groups of 4 tiles, chunks of 128 groups
+    // LDS texel windows (fused_eval_window_kernel): win_slices > 0 selects it
+    int32_t win_slices;        // channel slices of 128 * win_u channels per texel of map 0 (looped inside the workgroup)
+    int32_t win_u, win_vc;     // 16-byte vectors per lane (1..4), views with corner reads in flight
+    int32_t win_pool_offset;   // byte offset of the two all-zero slices; the pool follows them
+    int32_t win_pool_texels;   // pool capacity in texel slices of 512 * win_u bytes
+    int32_t win_occ;           // workgroups per CU the kernel variant is built for (2 / 3 / 4)
     int32_t runs_occ;      // experiment: waves per SIMD of the (1,8) cell-run kernel variant (4 / 5 / 6)
     int32_t store_policy;  // 1 (default) = fused rows leave as sc1 (write-through, line dropped from L2) stores, 0 = plain
     uint32_t flags;

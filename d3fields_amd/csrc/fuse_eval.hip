@@ -89,11 +89,24 @@ __device__ __forceinline__ void store_out(float *p, VT v, int policy)
 {
     if constexpr (sizeof(VT) == 16) {
         if (policy == 1) {
-            asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+            // s_nop 1: a VMEM store of more than 64 bits reads its data registers for two more cycles on gfx940+; the
+            // compiler inserts those wait states for its own stores but cannot see inside the asm, and a VALU write
+            // to v scheduled right behind it tore dwords of some lanes (found with the 2-vector window kernel)
+            asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
             return;
         }
     }
     store_vec<VT>(p, v);
+}
+
+// The full IEEE division of the strict path.  The empty volatile asm keeps it inside its (rare) branch: without it the
+// compiler if-converts `strict ? a / d : fast` and every point pays the ~11 instructions per channel of the division
+// it does not use (44 of ~120 VALU instructions per point and channel vector in the epilogues, measured round 2).
+template <typename VT>
+__device__ __forceinline__ VT strict_div(VT a, float d)
+{
+    asm volatile("" ::);
+    return a / d;
 }
 
 template <int VW, int U, bool BATCH, bool HALF = false>
@@ -213,7 +226,7 @@ __device__ __forceinline__ void gather_map(const MapDesc &m, const EvalParams &P
                     if (all_invalid) {
                         o = (VT)0.0f;                                          // fusion.py:386
                     } else if (strict) {
-                        o = acc[u] / denom;
+                        o = strict_div<VT>(acc[u], denom);
                     } else {
                         VT q = acc[u] * rcp_d;
                         q = v_fma<VT>(v_fma<VT>(q, -denom, acc[u]), rcp_d, q);
@@ -599,7 +612,7 @@ __device__ __forceinline__ void gather_map_thin(const MapDesc &m, const EvalPara
             if (cnt == 0.0f) {
                 o = (VT)0.0f;
             } else if (strict) {
-                o = acc / denom;
+                o = strict_div<VT>(acc, denom);
             } else {
                 const float r0 = __builtin_amdgcn_rcpf(denom);
                 const float rcp_d = fmaf(fmaf(-denom, r0, 1.0f), r0, r0);
@@ -1084,7 +1097,7 @@ __device__ __forceinline__ void fused_eval_sliced_body(const EvalParams &P)
             VT o = (VT)0.0f;
             if (cnt != 0.0f) {
                 if (strict) {
-                    o = acc / denom;
+                    o = strict_div<VT>(acc, denom);
                 } else {
                     const float r0 = __builtin_amdgcn_rcpf(denom);
                     const float rcp_d = fmaf(fmaf(-denom, r0, 1.0f), r0, r0);
@@ -1111,6 +1124,438 @@ __device__ __forceinline__ void fused_eval_sliced_body(const EvalParams &P)
 
 template <int LG, int VC, int WAVES>
 __global__ __launch_bounds__(kBlock, WAVES) void fused_eval_sliced_kernel(const EvalParams P) { fused_eval_sliced_body<LG, VC>(P); }
+
+// ---- texel windows in LDS for small wide maps (round 2) ---------------------------------------------------------------
+// Patch-resolution feature maps (the reference's dino_feats, fusion.py:694-697) sit in the caches, and the direct gather
+// of them is bound by the vector-L1 path (64 B/clk per CU, every (point, view) re-reading four whole texels) and by the
+// VALU work around every load.  The LDS reads 256 B/clk.  Here a workgroup takes a compact set of tile_pts points (a
+// power-of-two brick of a lattice, or that many consecutive points of the Morton order of a cloud):
+//   1. the eight corners of the set's bounding box are projected into every view (one lane per (view, corner)); the
+//      texel rectangle they span is the view's window (a projective map sends the box into the convex hull of its
+//      projected corners);
+//   2. phase A, one lane per (point, view) with the views of a point in adjacent lanes: the per-point sums over the
+//      views are rebuilt in view order with wave shuffles (no second pass); besides the 16-byte view record it writes a
+//      32-byte window record: LDS offset of the nw corner, row pitch, weight of the view, the four bilinear weights.
+//      Every corner is CHECKED against the window -- a pair whose corners are not all inside the map and the window
+//      (rounding at the rim, an overflowing pool, a box behind the camera, the image border) is marked direct and
+//      gathered from global memory as before, so the result never depends on step 1 being right;
+//   3. per channel slice of 128*U channels: the windows' texel slices are copied global -> LDS by the DMA path
+//      (global_load_lds_dwordx4: no registers, no ds_write), then 32 lanes per point read records and corners with
+//      ds_read_b128 and run the arithmetic of gather_map (same operands, same order: bit-identical results).  Invalid
+//      pairs point at an all-zero texel with zero weights (exact skip); strict points take the strict
+//      form on global loads.
+// Slots of a clipped brick (or of the last, short tile of a cloud) repeat a neighbouring point: same inputs, same
+// outputs, written twice.
+constexpr uint32_t kWinDirect = 0xffffffffu;
+struct __attribute__((aligned(16))) WinRec {
+    uint32_t nw;        // LDS byte offset of the nw corner's slice; ne = nw + slice bytes, sw = nw + row, se = sw + slice bytes
+    uint32_t row;       // bytes between the window's rows
+    float wgt;          // copy of ViewRec::wgt
+    uint32_t pad;
+    float w[4];         // bilinear weights nw, ne, sw, se
+};
+struct WinView {
+    int xmin, ymin, bw, bh;     // texel rectangle
+    int base;                   // first pool slot
+    int ok;                     // 0: no window for this view (every pair of it goes direct)
+};
+constexpr int kWinMaxViews = 8;
+constexpr uint32_t kWinStrict = 1u, kWinHasDirect = 2u;
+
+// all views of one point from the pool: VC views' corner reads in flight together
+template <int U, int VC>
+__device__ __forceinline__ void window_point(f32x4 (&acc)[U], const unsigned char *smem, const WinRec *wr_p, int V,
+                                             uint32_t lane_off)
+{
+    using VT = f32x4;
+    int v0 = 0;
+    for (; v0 + VC <= V; v0 += VC) {
+        WinRec wr[VC];
+#pragma unroll
+        for (int q = 0; q < VC; ++q) wr[q] = wr_p[v0 + q];
+        VT a[VC][U], b[VC][U], d[VC][U], e[VC][U];
+#pragma unroll
+        for (int q = 0; q < VC; ++q) {
+            const unsigned char *nw = smem + (wr[q].nw + lane_off);
+            const unsigned char *sw = nw + wr[q].row;
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                a[q][u] = *reinterpret_cast<const VT *>(nw + u * 512);
+                b[q][u] = *reinterpret_cast<const VT *>(nw + (U + u) * 512);
+                d[q][u] = *reinterpret_cast<const VT *>(sw + u * 512);
+                e[q][u] = *reinterpret_cast<const VT *>(sw + (U + u) * 512);
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < VC; ++q)
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                VT s_ = a[q][u] * wr[q].w[0];
+                s_ = v_fma<VT>(b[q][u], wr[q].w[1], s_);
+                s_ = v_fma<VT>(d[q][u], wr[q].w[2], s_);
+                s_ = v_fma<VT>(e[q][u], wr[q].w[3], s_);
+                acc[u] = acc[u] + s_ * wr[q].wgt;
+            }
+    }
+    if constexpr (VC > 1) {
+        for (; v0 < V; ++v0) {
+            const WinRec wr = wr_p[v0];
+            const unsigned char *nw = smem + (wr.nw + lane_off);
+            const unsigned char *sw = nw + wr.row;
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const VT a = *reinterpret_cast<const VT *>(nw + u * 512), b = *reinterpret_cast<const VT *>(nw + (U + u) * 512);
+                const VT d = *reinterpret_cast<const VT *>(sw + u * 512), e = *reinterpret_cast<const VT *>(sw + (U + u) * 512);
+                VT s_ = a * wr.w[0];
+                s_ = v_fma<VT>(b, wr.w[1], s_);
+                s_ = v_fma<VT>(d, wr.w[2], s_);
+                s_ = v_fma<VT>(e, wr.w[3], s_);
+                acc[u] = acc[u] + s_ * wr.wgt;
+            }
+        }
+    }
+}
+
+template <int U, int VC>
+__device__ __forceinline__ void fused_eval_window_body(const EvalParams &P)
+{
+    using VT = f32x4;
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int V = P.V;
+    const int TP = P.tile_pts;
+    ViewRec *rec = reinterpret_cast<ViewRec *>(smem);                        // [TP*V]
+    WinRec *wrec = reinterpret_cast<WinRec *>(rec + (size_t)TP * V);         // [TP*V]
+    float *cnt_s = reinterpret_cast<float *>(wrec + (size_t)TP * V);         // [TP]
+    uint32_t *flag_s = reinterpret_cast<uint32_t *>(cnt_s + TP);             // [TP]
+    uint32_t *idx_s = flag_s + TP;                                           // [TP]
+    float *krt = reinterpret_cast<float *>(idx_s + TP);                      // [V*12]
+    constexpr uint32_t SB = 512u * U;                                        // bytes of one texel slice
+    const uint32_t zero_off = (uint32_t)P.win_pool_offset;                   // two all-zero slices, then the pool
+    const uint32_t pool_off = zero_off + 2u * SB;
+    __shared__ float cpt_s[8][3];
+    __shared__ float red_s[kBlock / 64][6];
+    __shared__ WinView win_s[kWinMaxViews];
+    __shared__ int total_s;
+
+    const bool walk = P.walk_nx > 0;
+    const MapDesc &m0 = P.maps[0];
+    // the set of points: a brick of the lattice (blockIdx = (z, y, x) brick coordinates) or tile_pts consecutive points
+    // (XCD k = blockIdx % 8 takes the k-th contiguous eighth of the bricks, z fastest: the ~128 workgroups an XCD has in
+    // flight are neighbours, so the window copies of one are L2 hits left behind by the others)
+    const int lbz = __ffs(P.walk_tz) - 1, lby = __ffs(P.walk_ty) - 1;
+    int ox = 0, oy = 0, oz = 0;
+    if (walk) {
+        const uint32_t nbz = (uint32_t)((P.walk_nz + P.walk_tz - 1) / P.walk_tz), nby = (uint32_t)((P.walk_ny + P.walk_ty - 1) / P.walk_ty);
+        const uint32_t b = (uint32_t)xcd_tile((int64_t)blockIdx.x, (int64_t)gridDim.x);
+        const uint32_t bxy = b / nbz;
+        oz = (int)(b - bxy * nbz) * P.walk_tz;
+        const uint32_t bx = bxy / nby;
+        oy = (int)(bxy - bx * nby) * P.walk_ty;
+        ox = (int)bx * P.walk_tx;
+    }
+    const int bsx = min(P.walk_tx, P.walk_nx - ox), bsy = min(P.walk_ty, P.walk_ny - oy), bsz = min(P.walk_tz, P.walk_nz - oz);
+    const int64_t tile_base = (int64_t)blockIdx.x * TP;
+    const int tile_n = walk ? TP : (int)min((int64_t)TP, P.n - tile_base);
+    auto slot_point = [&](int p) -> int64_t {
+        if (walk) {
+            const int lz = min(p & (P.walk_tz - 1), bsz - 1), ly = min((p >> lbz) & (P.walk_ty - 1), bsy - 1);
+            const int lx = min(p >> (lbz + lby), bsx - 1);
+            return ((int64_t)(ox + lx) * P.walk_ny + (oy + ly)) * P.walk_nz + (oz + lz);
+        }
+        const int64_t q = tile_base + min(p, tile_n - 1);
+        return P.order ? min((int64_t)P.order[q], P.n - 1) : q;
+    };
+    const float mu = P.mu;
+    const float Wm1 = (float)(P.W - 1), Hm1 = (float)(P.H - 1);
+
+    // ---- 1. KRt, the zero slices, the eight corner points of the set's bounding box ----
+    compute_krt(P.K, P.pose, V, krt, kBlock);
+    for (uint32_t t = threadIdx.x; t < 2u * SB / 4u; t += kBlock) reinterpret_cast<uint32_t *>(smem + zero_off)[t] = 0u;
+    if (walk) {
+        if (threadIdx.x < 8) {
+            const int c = threadIdx.x;
+            const int lx = (c & 1) ? bsx - 1 : 0, ly = (c & 2) ? bsy - 1 : 0, lz = (c & 4) ? bsz - 1 : 0;
+            const int64_t i = ((int64_t)(ox + lx) * P.walk_ny + (oy + ly)) * P.walk_nz + (oz + lz);
+            float px, py, pz;
+            fetch_point(P, i, px, py, pz);
+            cpt_s[c][0] = px; cpt_s[c][1] = py; cpt_s[c][2] = pz;
+        }
+    } else {
+        float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+        for (int p = threadIdx.x; p < tile_n; p += kBlock) {
+            float q[3];
+            fetch_point(P, slot_point(p), q[0], q[1], q[2]);
+#pragma unroll
+            for (int k = 0; k < 3; ++k) { lo[k] = fminf(lo[k], q[k]); hi[k] = fmaxf(hi[k], q[k]); }
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1)
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                lo[k] = fminf(lo[k], __shfl_xor(lo[k], off, 64));
+                hi[k] = fmaxf(hi[k], __shfl_xor(hi[k], off, 64));
+            }
+        if ((threadIdx.x & 63) == 0)
+#pragma unroll
+            for (int k = 0; k < 3; ++k) { red_s[threadIdx.x >> 6][k] = lo[k]; red_s[threadIdx.x >> 6][3 + k] = hi[k]; }
+        __syncthreads();
+        if (threadIdx.x < 8) {
+            const int c = threadIdx.x;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                float a = red_s[0][k], b = red_s[0][3 + k];
+                for (int w = 1; w < kBlock / 64; ++w) { a = fminf(a, red_s[w][k]); b = fmaxf(b, red_s[w][3 + k]); }
+                cpt_s[c][k] = ((c >> k) & 1) ? b : a;      // a NaN coordinate is dropped by fmin/fmax: such a point is strict
+            }
+        }
+    }
+    __syncthreads();
+    // ---- 2. one window per view: wave 0, lane = view * 8 + corner ----
+    if (threadIdx.x < 64) {
+        const int lane = threadIdx.x, v = lane >> 3, c = lane & 7;
+        const bool act = v < V && V <= kWinMaxViews;
+        float xl = 0.0f, xh = 0.0f, yl = 0.0f, yh = 0.0f;
+        int ok = 0;
+        if (act) {
+            const Proj pr = project_point(krt + v * 12, cpt_s[c][0], cpt_s[c][1], cpt_s[c][2], Wm1, Hm1);
+            const float ix = unnormalize(pr.gx, m0.fw), iy = unnormalize(pr.gy, m0.fh);
+            ok = (pr.ok && pr.zc > 1e-4f && isfinite(ix) && isfinite(iy)) ? 1 : 0;      // the whole box in front of the camera
+            xl = xh = ix; yl = yh = iy;
+        }
+#pragma unroll
+        for (int off = 1; off < 8; off <<= 1) {
+            xl = fminf(xl, __shfl_xor(xl, off, 64)); xh = fmaxf(xh, __shfl_xor(xh, off, 64));
+            yl = fminf(yl, __shfl_xor(yl, off, 64)); yh = fmaxf(yh, __shfl_xor(yh, off, 64));
+            ok &= __shfl_xor(ok, off, 64);
+        }
+        WinView w = {0, 0, 1, 1, 0, 0};
+        int ntex = 0;
+        if (ok) {
+            const float fwm1 = (float)(m0.fw - 1), fhm1 = (float)(m0.fh - 1);
+            const int x0 = (int)fminf(fmaxf(floorf(xl - 1e-3f), 0.0f), fwm1), x1 = (int)fminf(fmaxf(floorf(xh + 1e-3f) + 1.0f, 0.0f), fwm1);
+            const int y0 = (int)fminf(fmaxf(floorf(yl - 1e-3f), 0.0f), fhm1), y1 = (int)fminf(fmaxf(floorf(yh + 1e-3f) + 1.0f, 0.0f), fhm1);
+            w.xmin = x0; w.ymin = y0; w.bw = x1 - x0 + 1; w.bh = y1 - y0 + 1;
+            ntex = w.bw * w.bh;
+        }
+        // pool slots in view order; a window that does not fit is dropped (its pairs go direct)
+        int run = 0;
+        for (int vv = 0; vv < V && vv < kWinMaxViews; ++vv) {
+            const int nv = __shfl(ntex, vv * 8, 64);
+            const bool fits = nv > 0 && run + nv <= P.win_pool_texels;
+            if (vv == v) { w.base = run; w.ok = fits ? 1 : 0; }
+            if (fits) run += nv;
+        }
+        if (act && c == 0) win_s[v] = w;
+        if (lane == 0) total_s = run;
+    }
+    __syncthreads();
+
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    // copy of slice `sl` of every window into the pool: 512-byte granules, two per wave instruction
+    auto stage = [&](int sl) {
+        const int total = total_s * U;              // granules
+        const int h = lane >> 5, l = lane & 31;
+        const char *data = reinterpret_cast<const char *>(m0.data);
+        for (int g2 = wave; g2 * 2 < total; g2 += kBlock / 64) {
+            const int hk = min(g2 * 2 + h, total - 1);
+            const int t = hk / U, part = hk - t * U;
+            int v = 0;
+            for (int vv = 1; vv < V && vv < kWinMaxViews; ++vv)
+                if (win_s[vv].ok && t >= win_s[vv].base) v = vv;      // bases ascend over the views that have a window
+            const WinView w = win_s[v];
+            const int local = t - w.base;
+            const int y = local / w.bw, x = local - y * w.bw;
+            const char *src = data + ((int64_t)v * m0.sv + (int64_t)(w.ymin + y) * m0.sy + (int64_t)(w.xmin + x) * m0.sx) * 4 +
+                              (size_t)sl * SB + (size_t)part * 512 + (size_t)l * 16;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                             (__attribute__((address_space(3))) void *)(smem + pool_off + (size_t)g2 * 1024),
+                                             16, 0, 0);
+        }
+    };
+    stage(0);
+
+    // ---- 3. phase A: lane = (point, view), the views of a point adjacent ----
+    {
+        const int vp_log2 = V <= 1 ? 0 : (V <= 2 ? 1 : (V <= 4 ? 2 : 3));
+        const int VP = 1 << vp_log2;
+        const int base = lane & ~(VP - 1);
+        for (int idx = threadIdx.x; idx < TP * VP; idx += kBlock) {
+            const int p = idx >> vp_log2, v = idx & (VP - 1);
+            const int64_t i = slot_point(p);
+            float dv = 0.0f, valid = 0.0f;
+            uint32_t st = 0u;
+            if (v < V) {
+                float px, py, pz;
+                fetch_point(P, i, px, py, pz);
+                float wgt;
+                const ViewOut o = eval_view<0>(P.depth, P.H, P.W, krt + v * 12, v, px, py, pz, Wm1, Hm1, mu, wgt);
+                ViewRec r;
+                r.gx = o.gx; r.gy = o.gy; r.wgt = wgt; r.valid = o.valid;
+                rec[p * V + v] = r;
+                dv = o.dist * o.valid;                                          // fusion.py:364 (product only)
+                valid = o.valid;
+                if (!(isfinite(o.gx) && isfinite(o.gy) && isfinite(wgt))) st |= kWinStrict;
+                WinRec wr;
+                wr.nw = zero_off; wr.row = 0u; wr.wgt = wgt; wr.pad = 0u;
+                wr.w[0] = wr.w[1] = wr.w[2] = wr.w[3] = 0.0f;
+                if (o.valid != 0.0f) {
+                    // the corner set-up of corner_setup(), in texel coordinates
+                    const float ix = unnormalize(o.gx, m0.fw), iy = unnormalize(o.gy, m0.fh);
+                    const float x0 = floorf(ix), y0 = floorf(iy);
+                    const float tx = ix - x0, ty = iy - y0;
+                    const float ex = 1.0f - tx, sy = 1.0f - ty;
+                    const WinView w = win_s[v];
+                    // all four corners inside the map (x0 in [0, fw-2]) and inside the window?
+                    const bool inmap = x0 >= 0.0f && x0 <= (float)(m0.fw - 2) && y0 >= 0.0f && y0 <= (float)(m0.fh - 2);
+                    const int ax = (int)fminf(fmaxf(x0, 0.0f), (float)m0.fw) - w.xmin, ay = (int)fminf(fmaxf(y0, 0.0f), (float)m0.fh) - w.ymin;
+                    const bool inside = inmap && w.ok && ax >= 0 && ax + 1 < w.bw && ay >= 0 && ay + 1 < w.bh;
+                    if (inside) {
+                        wr.nw = pool_off + (uint32_t)(w.base + ay * w.bw + ax) * SB;
+                        wr.row = (uint32_t)w.bw * SB;
+                        wr.w[0] = sy * ex; wr.w[1] = sy * tx; wr.w[2] = ty * ex; wr.w[3] = ty * tx;
+                    } else {
+                        wr.nw = kWinDirect;
+                        st |= kWinHasDirect;
+                    }
+                }
+                wrec[p * V + v] = wr;
+            }
+            // sums over the views in view order (fusion.py:364-370)
+            float dsum = 0.0f, cnt = 0.0f;
+            uint32_t stp = 0u;
+            for (int vv = 0; vv < V; ++vv) {
+                dsum = dsum + __shfl(dv, base + vv, 64);
+                cnt = cnt + __shfl(valid, base + vv, 64);
+                stp |= (uint32_t)__shfl((int)st, base + vv, 64);
+            }
+            if (v == 0) {
+                const bool all_invalid = (cnt == 0.0f);                         // fusion.py:366
+                float dist_out = dsum / (cnt + 1e-6f);
+                if (all_invalid) dist_out = 1e3f;                               // fusion.py:367
+                P.out_dist[i] = dist_out;
+                P.out_valid[i] = all_invalid ? 0 : 1;
+                cnt_s[p] = cnt;
+                idx_s[p] = (uint32_t)i;
+                if (!(P.flags & kFlagFiniteMaps)) stp |= kWinStrict;
+                flag_s[p] = stp;
+            }
+        }
+    }
+
+    // ---- 4. phase B per slice: 32 lanes per point ----
+    const MapDesc &m = m0;
+    const int l = threadIdx.x & 31, grp = threadIdx.x >> 5;
+    const uint32_t lane_off = (uint32_t)l * 16u;
+    const char *__restrict__ data = reinterpret_cast<const char *>(m.data);
+    const int S = P.win_slices;
+    for (int sl = 0; sl < S; ++sl) {
+        if (sl > 0) {
+            __syncthreads();                        // everyone is done with the previous slice's pool
+            stage(sl);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                            // records (first slice) and pool are complete
+        const uint32_t co = (uint32_t)sl * SB + lane_off;               // byte offset of this lane's first vector in a texel
+        for (int p = grp; p < TP; p += kBlock / 32) {
+            const int64_t i = idx_s[p];
+            const float cnt = cnt_s[p];
+            const float denom = cnt + 1e-6f;
+            const uint32_t fl = flag_s[p];
+            const bool strict = (fl & kWinStrict) != 0u;
+            VT acc[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) acc[u] = (VT)0.0f;
+            if (fl == 0u) {
+                window_point<U, VC>(acc, smem, wrec + p * V, V, lane_off);
+            } else if (!strict) {
+                // some pair of this point is gathered from global memory (fast arithmetic, zeroed weights)
+                for (int v = 0; v < V; ++v) {
+                    const WinRec wr = wrec[p * V + v];
+                    if (wr.nw != kWinDirect) {
+                        const unsigned char *nw = smem + (wr.nw + lane_off);
+                        const unsigned char *sw = nw + wr.row;
+#pragma unroll
+                        for (int u = 0; u < U; ++u) {
+                            const VT a = *reinterpret_cast<const VT *>(nw + u * 512), b = *reinterpret_cast<const VT *>(nw + (U + u) * 512);
+                            const VT d = *reinterpret_cast<const VT *>(sw + u * 512), e = *reinterpret_cast<const VT *>(sw + (U + u) * 512);
+                            VT s_ = a * wr.w[0];
+                            s_ = v_fma<VT>(b, wr.w[1], s_);
+                            s_ = v_fma<VT>(d, wr.w[2], s_);
+                            s_ = v_fma<VT>(e, wr.w[3], s_);
+                            acc[u] = acc[u] + s_ * wr.wgt;
+                        }
+                    } else {
+                        const ViewRec r = rec[p * V + v];
+                        const Corner c = corner_setup(m, r.gx, r.gy);
+                        const char *bv = data + (int64_t)v * m.sv * 4;
+                        const float w0 = c.inw ? c.wnw : 0.0f, w1 = c.ine ? c.wne : 0.0f, w2 = c.isw ? c.wsw : 0.0f, w3 = c.ise ? c.wse : 0.0f;
+#pragma unroll
+                        for (int u = 0; u < U; ++u) {
+                            const uint32_t cu = co + (uint32_t)u * 512u;
+                            const VT a = load_texel<4, false>(bv + (c.onw + cu)), b = load_texel<4, false>(bv + (c.one + cu));
+                            const VT d = load_texel<4, false>(bv + (c.osw + cu)), e = load_texel<4, false>(bv + (c.ose + cu));
+                            VT s_ = a * w0;
+                            s_ = v_fma<VT>(b, w1, s_);
+                            s_ = v_fma<VT>(d, w2, s_);
+                            s_ = v_fma<VT>(e, w3, s_);
+                            acc[u] = acc[u] + s_ * r.wgt;
+                        }
+                    }
+                }
+            } else {
+                for (int v = 0; v < V; ++v) {
+                    const ViewRec r = rec[p * V + v];
+                    const char *bv = data + (int64_t)v * m.sv * 4;
+                    const Corner c = corner_setup(m, r.gx, r.gy);
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {
+                        const uint32_t cu = co + (uint32_t)u * 512u;
+                        const VT a = load_texel<4, false>(bv + (c.onw + cu)), b = load_texel<4, false>(bv + (c.one + cu));
+                        const VT d = load_texel<4, false>(bv + (c.osw + cu)), e = load_texel<4, false>(bv + (c.ose + cu));
+                        const VT av = c.inw ? a : (VT)0.0f, bvv = c.ine ? b : (VT)0.0f, dv = c.isw ? d : (VT)0.0f, ev = c.ise ? e : (VT)0.0f;
+                        VT s_ = av * c.wnw;
+                        s_ = v_fma<VT>(bvv, c.wne, s_);
+                        s_ = v_fma<VT>(dv, c.wsw, s_);
+                        s_ = v_fma<VT>(ev, c.wse, s_);
+                        acc[u] = acc[u] + (s_ * r.valid) * r.wgt;
+                    }
+                }
+            }
+            float rcp_d = 0.0f;
+            if (!strict) {
+                const float r0 = __builtin_amdgcn_rcpf(denom);
+                rcp_d = fmaf(fmaf(-denom, r0, 1.0f), r0, r0);
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                VT o = (VT)0.0f;
+                if (cnt != 0.0f) {
+                    if (strict) {
+                        o = strict_div<VT>(acc[u], denom);
+                    } else {
+                        VT q = acc[u] * rcp_d;
+                        q = v_fma<VT>(v_fma<VT>(q, -denom, acc[u]), rcp_d, q);
+                        q = v_fma<VT>(v_fma<VT>(q, -denom, acc[u]), rcp_d, q);
+                        o = q;
+                    }
+                }
+                store_out<VT>(m.out + i * m.C + ((co + (uint32_t)u * 512u) >> 2), o, P.store_policy);
+            }
+        }
+    }
+    // the other (thin) maps of the call
+    for (int s = 1; s < P.n_maps; ++s) {
+        const MapDesc &mt = P.maps[s];
+        switch (mt.vw) {
+        case 4: gather_map_u<4, false, true>(mt, P, rec, cnt_s, flag_s, idx_s, 0, TP, nullptr); break;
+        case 2: gather_map_u<2, false, true>(mt, P, rec, cnt_s, flag_s, idx_s, 0, TP, nullptr); break;
+        default: gather_map_u<1, false, true>(mt, P, rec, cnt_s, flag_s, idx_s, 0, TP, nullptr); break;
+        }
+    }
+}
+
+template <int U, int VC, int WAVES>
+__global__ __launch_bounds__(kBlock, WAVES) void fused_eval_window_kernel(const EvalParams P) { fused_eval_window_body<U, VC>(P); }
 
 // Three entry points over one body: the plain kernel (<= 3 channel vectors per lane) is held to 128 VGPRs
 // = 4 waves per SIMD -- the gather lives on memory-level parallelism; the WIDE variant adds the 4-vector
@@ -1156,6 +1601,30 @@ hipError_t launch_fused_eval(const EvalParams &P, int mode, hipStream_t stream)
         wide |= (P.maps[s].unroll == -4);
         f16 |= (P.maps[s].esize == 2);
         runs |= (P.maps[s].runs > 0);
+    }
+    if (mode == 0 && P.win_slices > 0) {
+        const size_t lds_w = (size_t)P.win_pool_offset + (size_t)(2 + P.win_pool_texels) * 512 * P.win_u;
+        dim3 gw((unsigned)((P.n + P.tile_pts - 1) / P.tile_pts));
+        if (P.walk_nx > 0) gw = dim3((unsigned)ntiles);
+#define D3F_WIN_LAUNCH(U_, VC_, W_)                                                                                            \
+        do {                                                                                                                       \
+            if (lds_w > 64 * 1024) {                                                                                               \
+                hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void *>(&fused_eval_window_kernel<U_, VC_, W_>),        \
+                                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_w);                      \
+                if (ea != hipSuccess) return ea;                                                                                   \
+            }                                                                                                                      \
+            hipLaunchKernelGGL((fused_eval_window_kernel<U_, VC_, W_>), gw, block, lds_w, stream, P);                              \
+        } while (0)
+        if (P.win_u == 1 && P.win_occ >= 4) D3F_WIN_LAUNCH(1, 4, 4);
+        else if (P.win_u == 1 && P.win_occ == 3) D3F_WIN_LAUNCH(1, 4, 3);
+        else if (P.win_u == 1) D3F_WIN_LAUNCH(1, 4, 2);
+        else if (P.win_u == 2 && P.win_vc == 2) D3F_WIN_LAUNCH(2, 2, 2);
+        else if (P.win_u == 2) D3F_WIN_LAUNCH(2, 1, 2);
+        else if (P.win_u == 3 && P.win_vc == 2) D3F_WIN_LAUNCH(3, 2, 2);
+        else if (P.win_u == 3) D3F_WIN_LAUNCH(3, 1, 2);
+        else D3F_WIN_LAUNCH(4, 1, 2);
+#undef D3F_WIN_LAUNCH
+        return hipGetLastError();
     }
     if (mode == 0 && P.sl_slices > 0) {
         const int64_t units = (int64_t)P.sl_chunks * P.sl_slices;

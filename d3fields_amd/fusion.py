@@ -416,15 +416,20 @@ class Fusion:
         wide = any(plan.vectors_per_lane[s] == -4 for s in range(n_maps))
         f16 = any(maps[s].dtype == _lib.DTYPE_F16 for s in range(n_maps))
         kernel = ("fused_eval_f16_kernel<0>" if f16 else "fused_eval_wide_kernel<0>" if wide else "fused_eval_kernel<0>")
-        if plan.reserved >= 100:
+        window = plan.reserved >= 200
+        if window:
+            kernel = "fused_eval_window_kernel<occupancy %d>" % (plan.reserved - 200)
+        elif plan.reserved >= 100:
             lg, vc = (plan.reserved - 100) // 10, (plan.reserved - 100) % 10
             kernel = "fused_eval_sliced_kernel<%d, %d, %d>" % (lg, vc, {1: 8, 2: 7, 4: 5}.get(vc, 5))
         elif runs and not f16 and not wide:
             s0 = [s for s in range(n_maps) if plan.staged[s] >= 16][0]
             kernel = "fused_eval_runs_kernel<0, %d, %d, %d>" % (plan.vectors_per_lane[s0], plan.staged[s0] - 16, plan.reserved)
-        order = {2: "closed-form brick walk of the lattice (no keys, no sort)" + ("; channel-sliced over the XCDs" if plan.reserved >= 100 else ""), 1: "Morton-cell order (counting sort by 16-mm cell + 4-mm refinement, hand-written)",
+        order = {2: "closed-form brick walk of the lattice (no keys, no sort)" + ("; channel-sliced over the XCDs" if 100 <= plan.reserved < 200 else ""), 1: "Morton-cell order (counting sort by 16-mm cell + 4-mm refinement, hand-written)",
                  0: "caller order"}[int(plan.reorder)]
-        if runs:
+        if window:
+            order += "; texel windows in LDS (experiment)"
+        elif runs:
             order += "; cell runs of %d consecutive points" % (max(plan.staged[s] for s in range(n_maps)) - 16)
         self._last_plan = {"kernel": kernel, "tile_points": int(plan.tile_points), "point_order": order,
                            "workgroups": int(plan.workgroups), "lattice": lattice}

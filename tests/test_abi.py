@@ -246,3 +246,38 @@ def test_launch_plan_host_logic():
     assert (p.staged[0], p.reorder, p.tile_points, p.vectors_per_lane[0]) == (2, 1, 32, 3)
     p = _plan(4, 480, 640, 985600, [(48, 64, 384)], flags=_lib.TUNE_STAGING | _lib.TUNE_NO_REORDER)
     assert (p.staged[0], p.reorder) == (0, 0)
+
+
+def test_window_launch_plan(monkeypatch):
+    """D3F_EXP_WINDOW (opt-in experiment): LDS texel windows replace the cell-run gather for a patch-resolution wide
+    map; infeasible shapes fall back instead of failing."""
+    lib = _lib.load()
+
+    def plan_lattice(V, dims, maps, flags=_lib.FLAG_FINITE_MAPS):
+        v = _lib.Views(V, 480, 640, 16, 16, 16)
+        arr = (_lib.ChannelMap * len(maps))()
+        for i, (fh, fw, C) in enumerate(maps):
+            arr[i] = _lib.ChannelMap(16, fh, fw, C, 0, fh * fw * C, fw * C, C)
+        p = _lib.EvalPlan()
+        assert lib.d3f_eval_plan_query_lattice(ctypes.byref(v), dims[0], dims[1], dims[2], arr, len(maps), flags, 0, ctypes.byref(p)) == 0
+        return p
+
+    p = plan_lattice(4, (160, 140, 44), [(48, 64, 384)])
+    assert p.staged[0] == 16 + 4                                    # default: cell runs, caller order
+    monkeypatch.setenv("D3F_EXP_WINDOW", "64")
+    p = plan_lattice(4, (160, 140, 44), [(48, 64, 384), (480, 640, 8)])
+    assert (p.staged[0], p.tile_points, p.reorder, p.workgroups, p.reserved) == (3, 64, 2, 40 * 35 * 11, 204)
+    assert p.lds_bytes <= 160 * 1024 // 4
+    monkeypatch.setenv("D3F_EXP_WINDOW_U", "3")
+    p = plan_lattice(4, (160, 140, 44), [(48, 64, 384)])
+    assert (p.staged[0], p.reserved) == (3, 202) and 64 * 1024 < p.lds_bytes <= 80 * 1024
+    monkeypatch.delenv("D3F_EXP_WINDOW_U")
+    assert plan_lattice(4, (160, 140, 44), [(48, 64, 384)], flags=0).staged[0] == 0      # maps not known finite: direct gather
+    assert plan_lattice(4, (160, 140, 44), [(48, 64, 200)]).staged[0] != 3               # no whole 512-byte slices
+    assert plan_lattice(4, (160, 140, 44), [(480, 640, 384)]).staged[0] == 0             # dense map: not a window case
+    assert plan_lattice(16, (160, 140, 44), [(48, 64, 384)]).staged[0] != 3              # more than 8 views
+    p = _plan(8, 720, 1280, 1000000, [(72, 128, 1024)], flags=_lib.FLAG_FINITE_MAPS | _lib.FLAG_UNORDERED_POINTS)
+    assert (p.staged[0], p.reorder, p.workgroups) == (3, 1, 15625)                       # clouds: 64 consecutive points of the Morton order
+    monkeypatch.setenv("D3F_EXP_WINDOW", "128")
+    p = _plan(8, 720, 1280, 1000000, [(72, 128, 1024)], flags=_lib.FLAG_FINITE_MAPS | _lib.FLAG_UNORDERED_POINTS)
+    assert p.staged[0] == 3 and p.reserved == 202 and p.lds_bytes <= 80 * 1024          # records of 128 x 8 pairs: 2 workgroups per CU

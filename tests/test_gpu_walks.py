@@ -271,6 +271,65 @@ def test_channel_sliced_launch_is_bit_identical(dev, dims, C, mask):
             assert torch.equal(torch.isnan(a), torch.isnan(b)) and torch.equal(torch.nan_to_num(a.float()), torch.nan_to_num(b.float())), (sl, k)
 
 
+# ---- LDS texel windows (experiment knob D3F_EXP_WINDOW) == direct gather, bit for bit -----------------------------------
+@pytest.mark.parametrize("C,V,fhw,mask,points", [(384, 4, (48, 64), True, "grid"), (256, 3, (24, 32), False, "cloud"),
+                                                 (1024, 8, (36, 64), False, "cloud"), (128, 2, (48, 64), True, "grid")])
+def test_window_gather_is_bit_identical(dev, C, V, fhw, mask, points):
+    """Every (tile, vectors per lane, pool) variant of fused_eval_window_kernel, incl. pools too small for the windows
+    (pairs then go direct), clipped bricks (74 x 65 x 20 is no multiple of the brick), a strict point and points whose
+    corners leave the map; the plan says the window kernel is what runs."""
+    from d3fields_amd import create_init_grid, synth, _lib
+    import ctypes
+    H, W = 480, 640
+    maps = {"dino_feats": synth.random_map(V, fhw[0], fhw[1], C, seed=1, device=dev)}
+    names = ["dino_feats"]
+    if mask:
+        maps["mask"] = synth.random_onehot_mask(V, H, W, 8, seed=2, device=dev)
+        names.append("mask")
+    f, sc = fusion_for(dev, V, H, W, maps)
+    if points == "grid":
+        pts_c = create_init_grid(synth.WORK_BOX, 0.0107)[0]                            # 74 x 65 x 20 points
+    else:
+        pts_c = synth.random_cloud(150001, seed=3)
+    pts_c[1000, 1] = float("inf")                                                       # a strict point
+    pts = pts_c.to(dev)
+    views, keep, _ = f._views(dev)
+    m = maps["dino_feats"]
+    cm = (_lib.ChannelMap * 1)(_lib.ChannelMap(m.data_ptr(), m.shape[1], m.shape[2], C, 0, m.stride(0), m.stride(1), m.stride(2)))
+    plan = _lib.EvalPlan()
+    with knobs(D3F_EXP_WINDOW=64):
+        if points == "grid":
+            _lib.check(f._lib.d3f_eval_plan_query_lattice(ctypes.byref(views), 74, 65, 20, cm, 1, _lib.FLAG_FINITE_MAPS, 0, ctypes.byref(plan)))
+            assert plan.reorder == 2 and plan.workgroups == 19 * 17 * 5
+        else:
+            _lib.check(f._lib.d3f_eval_plan_query(ctypes.byref(views), pts.shape[0], cm, 1, _lib.FLAG_FINITE_MAPS, 1, 0, ctypes.byref(plan)))
+        assert plan.staged[0] == 3 and plan.tile_points == 64 and plan.reserved == 204, "the window kernel must be what runs here"
+    variants = [("direct", dict(D3F_EXP_RUNS=-1))]
+    for T in (32, 64, 128):
+        if (T * (1 if V <= 1 else 2 if V <= 2 else 4 if V <= 4 else 8)) % 64:
+            continue
+        for U in (1, 2, 3, 4):
+            if (C // 128) % U:
+                continue
+            variants.append(("T%d U%d" % (T, U), dict(D3F_EXP_WINDOW=T, D3F_EXP_WINDOW_U=U)))
+    variants += [("T64 occ3", dict(D3F_EXP_WINDOW=64, D3F_EXP_WINDOW_OCC=3)), ("T64 pool 6", dict(D3F_EXP_WINDOW=64, D3F_EXP_WINDOW_POOL=6)),
+                 ("T64 pool 2", dict(D3F_EXP_WINDOW=64, D3F_EXP_WINDOW_POOL=2)), ("T64 vc2", dict(D3F_EXP_WINDOW=64, D3F_EXP_WINDOW_VC=2))]
+    with torch.no_grad():
+        outs = {}
+        for tag, env in variants:
+            with knobs(**env):
+                outs[tag] = f.batch_eval(pts, return_names=names)
+    for tag in [t for t, _ in variants[1:]]:
+        for k in outs["direct"]:
+            a, b = outs[tag][k], outs["direct"][k]
+            assert torch.equal(torch.isnan(a), torch.isnan(b)) and torch.equal(torch.nan_to_num(a.float()), torch.nan_to_num(b.float())), (tag, k)
+    pick = torch.randperm(pts.shape[0], generator=torch.Generator().manual_seed(3))[:1500]
+    pick = pick[pick != 1000]
+    ref = oracle_sample(sc, pts_c[pick], [maps[k] for k in names])
+    assert np.array_equal(cpu(outs["T64 U1"]["dist"])[pick], ref["dist"])
+    assert rel_err(cpu(outs["T64 U1"]["dino_feats"])[pick], ref["sets"][0]) <= TOL
+
+
 def test_async_probes_follow_the_data_and_never_change_results(dev):
     """Without the per-tensor cache (bench.py's mode) the shim launches on the verdict of the last FINISHED probes of a
     query of the same size and refreshes it asynchronously: a cloud that follows a grid of the same size is walked with
