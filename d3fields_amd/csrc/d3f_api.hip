@@ -488,7 +488,7 @@ int eval_common(const d3f_views *views, const float *pts, int64_t n, const d3f_c
         for (int s = 0; s < n_maps; ++s)
             if (P.maps[s].runs > 0) {        // waves per SIMD the chosen cell-run kernel variant is built for
                 const int ru = P.maps[s].unroll, rk = P.maps[s].runs;
-                plan_out->reserved = (ru == 1 && rk == 4) ? (P.runs_occ == 6 ? 6 : 7) : (ru == 1 ? ((P.runs_occ == 4 || P.runs_occ == 6) ? P.runs_occ : 5) : 4);
+                plan_out->reserved = (ru == 1 && rk == 4) ? (P.runs_occ == 6 ? 6 : 7) : (ru == 1 ? ((P.runs_occ == 4 || P.runs_occ == 6) ? P.runs_occ : 5) : ((ru == 2 && rk == 8 && P.runs_occ != 4) ? 3 : 4));
             }
         for (int s = 0; s < D3F_MAX_MAPS; ++s) {
             const bool on = s < n_maps;

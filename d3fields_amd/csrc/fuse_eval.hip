@@ -1581,6 +1581,7 @@ __global__ __launch_bounds__(kBlock) void fused_eval_staged_kernel(const EvalPar
 // default: fastest on every patch-resolution workload measured, MI355X r2c: C2 0.724 -> 0.645 ms, C3 1.544 -> 1.338,
 // C4 4.13 -> 3.82); <3,4> / <3,2> the 3-vector mapping of C = 384 with 4- / 2-point runs and <2,4> / <2,8> two vectors
 // per lane are kept as experiment variants (they spill at 4 waves per SIMD and measured 2-5 % slower).
+// <2,8> (the C = 1024 default) runs at 3 waves per SIMD: held to 4 it spills 48 bytes per lane (C4 patch 3.40 -> 3.31 ms).
 template <int MODE, int RU, int RK, int WAVES>
 __global__ __launch_bounds__(kBlock, WAVES) void fused_eval_runs_kernel(const EvalParams P)
 {
@@ -1647,7 +1648,8 @@ hipError_t launch_fused_eval(const EvalParams &P, int mode, hipStream_t stream)
         if (ru == 3 && rk == 4) hipLaunchKernelGGL((fused_eval_runs_kernel<0, 3, 4, 4>), grid, block, lds, stream, P);
         else if (ru == 3 && rk == 2) hipLaunchKernelGGL((fused_eval_runs_kernel<0, 3, 2, 4>), grid, block, lds, stream, P);
         else if (ru == 2 && rk == 4) hipLaunchKernelGGL((fused_eval_runs_kernel<0, 2, 4, 4>), grid, block, lds, stream, P);
-        else if (ru == 2 && rk == 8) hipLaunchKernelGGL((fused_eval_runs_kernel<0, 2, 8, 4>), grid, block, lds, stream, P);
+        else if (ru == 2 && rk == 8 && P.runs_occ == 4) hipLaunchKernelGGL((fused_eval_runs_kernel<0, 2, 8, 4>), grid, block, lds, stream, P);
+        else if (ru == 2 && rk == 8) hipLaunchKernelGGL((fused_eval_runs_kernel<0, 2, 8, 3>), grid, block, lds, stream, P);
         else if (ru == 1 && rk == 4 && P.runs_occ == 6) hipLaunchKernelGGL((fused_eval_runs_kernel<0, 1, 4, 6>), grid, block, lds, stream, P);
         else if (ru == 1 && rk == 4) hipLaunchKernelGGL((fused_eval_runs_kernel<0, 1, 4, 7>), grid, block, lds, stream, P);
         else if (P.runs_occ == 4) hipLaunchKernelGGL((fused_eval_runs_kernel<0, 1, 8, 4>), grid, block, lds, stream, P);

@@ -181,6 +181,7 @@ def test_validation_of_topk_and_lattice_entry_points():
     v8 = _views(V=8, H=720, W=1280)
     assert lib.d3f_eval_plan_query(ctypes.byref(v8), 1000000, wide, 1, _lib.FLAG_FINITE_MAPS, 1, 0, ctypes.byref(plan)) == 0
     assert plan.reorder == 1 and plan.staged[0] == 16 + 8 and plan.vectors_per_lane[0] == 2 and plan.lanes_per_point[0] == 64
+    assert plan.reserved == 3                                            # (2,8) at 3 waves per SIMD: spill-free
     assert lib.d3f_eval_plan_query_lattice(ctypes.byref(v), 160, 140, 44, patch, 1, 0, 0, ctypes.byref(plan)) == 0
     assert plan.staged[0] == 0 and plan.tile_points == 128     # maps not known to be finite: the direct gather
 

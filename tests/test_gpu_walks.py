@@ -172,7 +172,7 @@ def test_cell_run_gather_is_bit_identical(dev, C, V, fhw, mask, points):
                 ("u1k8occ4", dict(D3F_EXP_RUNS_U=1, D3F_EXP_RUNS=8, D3F_EXP_RUNS_OCC=4)), ("u1k8occ6", dict(D3F_EXP_RUNS_U=1, D3F_EXP_RUNS=8, D3F_EXP_RUNS_OCC=6)),
                 ("u1k4", dict(D3F_EXP_RUNS_U=1, D3F_EXP_RUNS=4)), ("u1k8", dict(D3F_EXP_RUNS_U=1, D3F_EXP_RUNS=8)), ("u3k2", dict(D3F_EXP_RUNS_U=3, D3F_EXP_RUNS=2)),
                 ("u3k4", dict(D3F_EXP_RUNS_U=3, D3F_EXP_RUNS=4)), ("u2k4", dict(D3F_EXP_RUNS_U=2, D3F_EXP_RUNS=4)),
-                ("u2k8", dict(D3F_EXP_RUNS_U=2, D3F_EXP_RUNS=8)))
+                ("u2k8", dict(D3F_EXP_RUNS_U=2, D3F_EXP_RUNS=8)), ("u2k8occ4", dict(D3F_EXP_RUNS_U=2, D3F_EXP_RUNS=8, D3F_EXP_RUNS_OCC=4)))
     with torch.no_grad():
         outs = {}
         for tag, env in variants:
