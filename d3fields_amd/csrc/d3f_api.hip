@@ -155,6 +155,10 @@ void pick_staged_mapping(d3f::MapDesc &m)
 //                  workgroups per unit
 //   D3F_EXP_WALK_TILE  shape of the walk's tile as digits x y z with the same point count (222 default; 224 with a thin map)
 //   D3F_EXP_WALK   lattice brick walk for grids on large maps: -1 off, 0 automatic (default)
+//   D3F_EXP_WINDOW 32 / 64 / 128: LDS texel-window kernel (points per workgroup) instead of the cell-run gather for a
+//                  patch-resolution wide first map (fuse_eval.hip, DESIGN.md 5.5: 5-9 % slower, hence opt-in); _U vectors
+//                  per lane (1..4), _VC views in flight (U = 2 / 3), _OCC workgroups per CU (2..4), _POOL pool texels
+//   D3F_EXP_RUNS_OCC also: 4 = the (2,8) cell-run variant held to 4 waves per SIMD (default 3, spill-free)
 int exp_knob(const char *name)
 {
     const char *v = getenv(name);
