@@ -36,7 +36,7 @@ __device__ __forceinline__ uint32_t spread3(uint32_t x)
 }
 
 constexpr float kFineCell = 0.004f;       // 4-mm sub-cells x 512 per axis = 2.05 m before the keys wrap (harmless)
-constexpr int kFineBits = 6;              // 27-bit fine key = 21-bit key of the 16-mm cell << 6 | sub-cell
+// 27-bit fine key = key of the counting cell (15 .. 21 bits, chosen per call) << shift | sub-cell
 constexpr int64_t kCells = 1 << 21;
 
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
@@ -47,7 +47,7 @@ __global__ __launch_bounds__(kBlock) void order_clear_kernel(uint32_t *__restric
 }
 
 __global__ __launch_bounds__(kBlock) void morton_count_kernel(const float *__restrict__ pts, int64_t n, uint32_t *__restrict__ keys,
-                                                             uint32_t *__restrict__ ranks, uint32_t *__restrict__ table)
+                                                             uint32_t *__restrict__ ranks, uint32_t *__restrict__ table, int shift)
 {
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (i >= n) return;
@@ -58,15 +58,15 @@ __global__ __launch_bounds__(kBlock) void morton_count_kernel(const float *__res
     const int qz = (int)fminf(fmaxf(floorf(pts[i * 3 + 2] * inv), -1e9f), 1e9f);
     const uint32_t key = spread3((uint32_t)qx & 511u) | (spread3((uint32_t)qy & 511u) << 1) | (spread3((uint32_t)qz & 511u) << 2);
     keys[i] = key;
-    ranks[i] = atomicAdd(&table[key >> kFineBits], 1u);
+    ranks[i] = atomicAdd(&table[key >> shift], 1u);
 }
 
 __global__ __launch_bounds__(kBlock) void scatter_kernel(const uint32_t *__restrict__ keys, const uint32_t *__restrict__ ranks, int64_t n,
-                                                        const uint32_t *__restrict__ offsets, uint32_t *__restrict__ slots)
+                                                        const uint32_t *__restrict__ offsets, uint32_t *__restrict__ slots, int shift)
 {
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (i >= n) return;
-    slots[offsets[keys[i] >> kFineBits] + ranks[i]] = (uint32_t)i;
+    slots[offsets[keys[i] >> shift] + ranks[i]] = (uint32_t)i;
 }
 
 __global__ __launch_bounds__(kBlock) void window_rank_kernel(const uint32_t *__restrict__ keys, const uint32_t *__restrict__ slots,
@@ -108,11 +108,19 @@ hipError_t build_point_order(const float *pts, int64_t n, void *workspace, int64
     uint32_t *table = reinterpret_cast<uint32_t *>(base + 4 * seg);
     void *scan_scratch = base + 4 * seg + (size_t)kCells * 4;
     const unsigned nb = (unsigned)((n + kBlock - 1) / kBlock);
-    hipLaunchKernelGGL(order_clear_kernel, dim3((unsigned)(kCells / 4 / kBlock)), dim3(kBlock), 0, stream, table);
-    hipLaunchKernelGGL(morton_count_kernel, dim3(nb), dim3(kBlock), 0, stream, pts, n, keys, ranks, table);
-    hipError_t e = launch_exclusive_scan_u32(table, table, kCells, scan_scratch, stream);
+    // counters: >= 4 per point (any prefix of the Morton key is a valid coarser Z-order cell), 2^15 .. 2^21: 16-mm cells
+    // for 1 M points, 16 x 32 x 32 mm for 100 k -- the 64-slot refinement below still resolves them, and clearing +
+    // scanning the table stops dominating small batches (fewer counters than that and the atomics start to collide:
+    // 2.6 per point measured 7 -> 14 us in morton_count_kernel at 100 k points)
+    int bits = 15;
+    while (bits < 21 && (1LL << bits) < 4 * n) bits += 1;
+    const int shift = 27 - bits;
+    const int64_t cells = 1LL << bits;
+    hipLaunchKernelGGL(order_clear_kernel, dim3((unsigned)(cells / 4 / kBlock)), dim3(kBlock), 0, stream, table);
+    hipLaunchKernelGGL(morton_count_kernel, dim3(nb), dim3(kBlock), 0, stream, pts, n, keys, ranks, table, shift);
+    hipError_t e = launch_exclusive_scan_u32(table, table, cells, scan_scratch, stream);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(scatter_kernel, dim3(nb), dim3(kBlock), 0, stream, keys, ranks, n, table, slots);
+    hipLaunchKernelGGL(scatter_kernel, dim3(nb), dim3(kBlock), 0, stream, keys, ranks, n, table, slots, shift);
     hipLaunchKernelGGL(window_rank_kernel, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream, keys, slots, n, order);
     e = hipGetLastError();
     if (e != hipSuccess) return e;
@@ -133,18 +141,34 @@ const uint32_t *stored_point_order(void *workspace, int64_t n)
 // depth-ordered cloud gives out[0] << out[1]; a shuffled / uniformly random cloud gives out[0] ~ out[1].
 constexpr int kProbeSamples = 4096;
 
-__global__ __launch_bounds__(kBlock) void point_locality_kernel(const float *__restrict__ pts, int64_t n, int samples,
-                                                               float *__restrict__ out)
+// One workgroup of 1024 lanes, four samples per lane with all their loads in flight together: one memory round trip
+// (~3 us; the first version walked 16 dependent rounds in a 256-lane workgroup and took 25 us -- 4 % of a C2-patch step).
+constexpr int kProbeBlock = 1024;
+constexpr int kProbePerLane = kProbeSamples / kProbeBlock;
+
+__global__ __launch_bounds__(kProbeBlock) void point_locality_kernel(const float *__restrict__ pts, int64_t n, int samples,
+                                                                    float *__restrict__ out)
 {
-    __shared__ float red[3][kBlock / 64];
+    __shared__ float red[3][kProbeBlock / 64];
     float near_d = 0.0f, far_d = 0.0f, cnt = 0.0f;
-    for (int k = threadIdx.x; k < samples && n >= 2; k += kBlock) {
-        const int64_t i = (int64_t)((double)k * (double)(n - 1) / (double)samples);      // i + 1 <= n - 1
-        const int64_t j = (i + n / 2) % n;
-        const float ax = pts[i * 3], ay = pts[i * 3 + 1], az = pts[i * 3 + 2];
-        const float dn = fabsf(pts[i * 3 + 3] - ax) + fabsf(pts[i * 3 + 4] - ay) + fabsf(pts[i * 3 + 5] - az);
-        const float df = fabsf(pts[j * 3] - ax) + fabsf(pts[j * 3 + 1] - ay) + fabsf(pts[j * 3 + 2] - az);
-        if (dn < INFINITY && df < INFINITY) { near_d += dn; far_d += df; cnt += 1.0f; }  // false for NaN too
+    if (n >= 2) {
+        float a[kProbePerLane][3], b[kProbePerLane][3], c[kProbePerLane][3];
+        bool on[kProbePerLane];
+#pragma unroll
+        for (int q = 0; q < kProbePerLane; ++q) {
+            const int k = threadIdx.x + q * kProbeBlock;
+            on[q] = k < samples;
+            const int64_t i = on[q] ? (int64_t)((double)k * (double)(n - 1) / (double)samples) : 0;      // i + 1 <= n - 1
+            const int64_t j = (i + n / 2) % n;
+#pragma unroll
+            for (int d = 0; d < 3; ++d) { a[q][d] = pts[i * 3 + d]; b[q][d] = pts[i * 3 + 3 + d]; c[q][d] = pts[j * 3 + d]; }
+        }
+#pragma unroll
+        for (int q = 0; q < kProbePerLane; ++q) {
+            const float dn = fabsf(b[q][0] - a[q][0]) + fabsf(b[q][1] - a[q][1]) + fabsf(b[q][2] - a[q][2]);
+            const float df = fabsf(c[q][0] - a[q][0]) + fabsf(c[q][1] - a[q][1]) + fabsf(c[q][2] - a[q][2]);
+            if (on[q] && dn < INFINITY && df < INFINITY) { near_d += dn; far_d += df; cnt += 1.0f; }  // false for NaN too
+        }
     }
     for (int off = 32; off > 0; off >>= 1) {
         near_d += __shfl_xor(near_d, off, 64);
@@ -157,7 +181,7 @@ __global__ __launch_bounds__(kBlock) void point_locality_kernel(const float *__r
     __syncthreads();
     if (threadIdx.x == 0) {
         float t[3] = {0.0f, 0.0f, 0.0f};
-        for (int w = 0; w < kBlock / 64; ++w) { t[0] += red[0][w]; t[1] += red[1][w]; t[2] += red[2][w]; }
+        for (int w = 0; w < kProbeBlock / 64; ++w) { t[0] += red[0][w]; t[1] += red[1][w]; t[2] += red[2][w]; }
         out[0] = t[2] > 0.0f ? t[0] / t[2] : 0.0f;
         out[1] = t[2] > 0.0f ? t[1] / t[2] : 0.0f;
     }
@@ -228,7 +252,7 @@ hipError_t launch_lattice_probe(const float *pts, int64_t n, int32_t *out_dims, 
 // one workgroup (a few microseconds); out: 2 device floats
 hipError_t launch_point_locality(const float *pts, int64_t n, float *out, hipStream_t stream)
 {
-    hipLaunchKernelGGL(point_locality_kernel, dim3(1), dim3(kBlock), 0, stream, pts, n, kProbeSamples, out);
+    hipLaunchKernelGGL(point_locality_kernel, dim3(1), dim3(kProbeBlock), 0, stream, pts, n, kProbeSamples, out);
     return hipGetLastError();
 }
 
