@@ -155,9 +155,10 @@ void pick_staged_mapping(d3f::MapDesc &m)
 //                  workgroups per unit
 //   D3F_EXP_WALK_TILE  shape of the walk's tile as digits x y z with the same point count (222 default; 224 with a thin map)
 //   D3F_EXP_WALK   lattice brick walk for grids on large maps: -1 off, 0 automatic (default)
-//   D3F_EXP_WINDOW 32 / 64 / 128: LDS texel-window kernel (points per workgroup) instead of the cell-run gather for a
-//                  patch-resolution wide first map (fuse_eval.hip, DESIGN.md 5.5: 5-9 % slower, hence opt-in); _U vectors
-//                  per lane (1..4), _VC views in flight (U = 2 / 3), _OCC workgroups per CU (2..4), _POOL pool texels
+//   D3F_EXP_WINDOW LDS texel-window kernel instead of the cell-run gather for a patch-resolution wide first map
+//                  (fuse_eval.hip): 0 automatic = on lattices (64 points per workgroup), -1 never,
+//                  32 / 64 / 128 = always, with that many points per workgroup; _U vectors per lane (1..4), _VC views
+//                  in flight (U = 2 / 3), _OCC workgroups per CU (2..4), _POOL pool texels
 //   D3F_EXP_RUNS_OCC also: 4 = the (2,8) cell-run variant held to 4 waves per SIMD (default 3, spill-free)
 int exp_knob(const char *name)
 {
@@ -282,11 +283,14 @@ int eval_common(const d3f_views *views, const float *pts, int64_t n, const d3f_c
     // LDS texel windows (fuse_eval.hip, fused_eval_window_kernel): the FIRST map is a patch-resolution wide fp32 map with
     // whole 512-byte slices, every other map is thin; same preconditions as the cell-run gather, which it replaces.
     bool window = false;
-    const int win_knob = exp_knob("D3F_EXP_WINDOW");          // 0 automatic (see below), -1 off, 64 / 128: points per workgroup
+    const int win_knob = exp_knob("D3F_EXP_WINDOW");          // 0 automatic (see below), -1 off, 32 / 64 / 128: points per workgroup
     {
-        window = win_knob > 0 && mode == 0 && n_maps >= 1 && (flags & D3F_FLAG_FINITE_MAPS) && !stage_any && n >= 65536 &&
+        // default: lattices only (a brick's windows are compact; 64 consecutive points of a cloud's Morton order are not:
+        // C5 0.120 -> 0.170 ms), and not when a cell-run variant is asked for explicitly
+        const bool automatic = win_knob == 0 && lattice != nullptr && exp_knob("D3F_EXP_RUNS") == 0 && exp_knob("D3F_EXP_RUNS_U") == 0;
+        window = (win_knob > 0 || automatic) && mode == 0 && n_maps >= 1 && (flags & D3F_FLAG_FINITE_MAPS) && !stage_any && n >= 65536 &&
                  n <= 0x7fffffffLL && tl == 0 && views->V <= 8 && runs_candidate(P.maps[0], views->H, views->W) &&
-                 P.maps[0].C % 128 == 0 && (P.maps[0].sx % 4) == 0 && (P.maps[0].sy % 4) == 0 && (P.maps[0].sv % 4) == 0 &&
+                 P.maps[0].C % 128 == 0 && (int64_t)views->V * P.maps[0].sv * 4 < (1LL << 31) && (P.maps[0].sx % 4) == 0 && (P.maps[0].sy % 4) == 0 && (P.maps[0].sv % 4) == 0 &&
                  (!plan_only ? (reinterpret_cast<uintptr_t>(P.maps[0].data) % 16 == 0) : true);
         for (int s = 0; s < n_maps; ++s) window = window && !(out_inter && out_inter[s]);
         for (int s = 1; s < n_maps; ++s) window = window && P.maps[s].esize == 4 && P.maps[s].C * 4 <= 256;
@@ -296,19 +300,20 @@ int eval_common(const d3f_views *views, const float *pts, int64_t n, const d3f_c
             int U = exp_knob("D3F_EXP_WINDOW_U");
             const int cv = P.maps[0].C / 128;                  // 512-byte granules per texel
             if (U < 1 || U > 4 || cv % U != 0) U = 1;
-            // per (point, view): 16-byte view record + 32-byte window record; per point 12 bytes
-            const int base = T * views->V * 48 + T * 12 + views->V * 48;
+            // per (point, view): 32-byte window record (+ the 16-byte view record when thin maps ride along); per point 20 bytes
+            const int base = T * views->V * (n_maps > 1 ? 48 : 32) + T * 20 + views->V * 48;
             const int pool_offset = (base + 511) / 512 * 512;
             int occ = exp_knob("D3F_EXP_WINDOW_OCC");
             if (occ < 2 || occ > 4) occ = 4;
             if (U > 1) occ = 2;                                 // those variants are built for 2 workgroups per CU
             int texels = 0;
             for (;; --occ) {
-                const int budget = 160 * 1024 / occ - 1024;     // the kernel's static LDS (corner points, windows) is < 0.5 KiB
+                const int budget = 160 * 1024 / occ - 2048;     // the kernel's static LDS (corner points, windows, slot table) is 1.7 KiB
                 texels = (budget - pool_offset) / (512 * U) - 2;
                 if (texels >= 2 * views->V || occ == 2) break;  // room for a 2-texel window per view at least
             }
             if (exp_knob("D3F_EXP_WINDOW_POOL") > 0 && exp_knob("D3F_EXP_WINDOW_POOL") < texels) texels = exp_knob("D3F_EXP_WINDOW_POOL");
+            if (texels > 320) texels = 320;                      // kWinMaxTexels (fuse_eval.hip)
             texels &= ~1;
             window = texels >= 2 && (T * VP) % 64 == 0 && n / T < 0x7fffffffLL;
             P.win_u = U; P.win_occ = occ; P.win_pool_offset = pool_offset; P.win_pool_texels = texels;

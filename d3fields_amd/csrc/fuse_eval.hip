@@ -102,6 +102,16 @@ __device__ __forceinline__ void store_out(float *p, VT v, int policy)
 // The full IEEE division of the strict path.  The empty volatile asm keeps it inside its (rare) branch: without it the
 // compiler if-converts `strict ? a / d : fast` and every point pays the ~11 instructions per channel of the division
 // it does not use (44 of ~120 VALU instructions per point and channel vector in the epilogues, measured round 2).
+// the same store addressed as (uniform base, 32-bit byte offset): rows of outputs below 4 GiB need no 64-bit arithmetic
+__device__ __forceinline__ void store_out_off(float *base, uint32_t off, f32x4 v, int policy)
+{
+    if (policy == 1) {
+        asm volatile("global_store_dwordx4 %0, %1, %2 sc1\n\ts_nop 1" ::"v"(off), "v"(v), "s"(base) : "memory");
+        return;
+    }
+    *reinterpret_cast<f32x4 *>(reinterpret_cast<char *>(base) + off) = v;
+}
+
 template <typename VT>
 __device__ __forceinline__ VT strict_div(VT a, float d)
 {
@@ -1150,9 +1160,10 @@ constexpr uint32_t kWinDirect = 0xffffffffu;
 struct __attribute__((aligned(16))) WinRec {
     uint32_t nw;        // LDS byte offset of the nw corner's slice; ne = nw + slice bytes, sw = nw + row, se = sw + slice bytes
     uint32_t row;       // bytes between the window's rows
-    float wgt;          // copy of ViewRec::wgt
-    uint32_t pad;
-    float w[4];         // bilinear weights nw, ne, sw, se
+    float wgt;          // ViewRec::wgt
+    float valid;        // ViewRec::valid
+    float w[4];         // bilinear weights nw, ne, sw, se; a direct pair (and every pair of a strict point) keeps
+                        // gx, gy here instead -- the 16-byte view records exist only when thin maps ride along
 };
 struct WinView {
     int xmin, ymin, bw, bh;     // texel rectangle
@@ -1160,6 +1171,7 @@ struct WinView {
     int ok;                     // 0: no window for this view (every pair of it goes direct)
 };
 constexpr int kWinMaxViews = 8;
+constexpr int kWinMaxTexels = 320;       // pool slots (host: win_pool_texels <= this)
 constexpr uint32_t kWinStrict = 1u, kWinHasDirect = 2u;
 
 // all views of one point from the pool: VC views' corner reads in flight together
@@ -1223,12 +1235,14 @@ __device__ __forceinline__ void fused_eval_window_body(const EvalParams &P)
     extern __shared__ __align__(16) unsigned char smem[];
     const int V = P.V;
     const int TP = P.tile_pts;
-    ViewRec *rec = reinterpret_cast<ViewRec *>(smem);                        // [TP*V]
-    WinRec *wrec = reinterpret_cast<WinRec *>(rec + (size_t)TP * V);         // [TP*V]
-    float *cnt_s = reinterpret_cast<float *>(wrec + (size_t)TP * V);         // [TP]
+    const bool has_rec = P.n_maps > 1;                                       // thin maps read the view records
+    WinRec *wrec = reinterpret_cast<WinRec *>(smem);                         // [TP*V]
+    ViewRec *rec = reinterpret_cast<ViewRec *>(wrec + (size_t)TP * V);       // [TP*V] if has_rec
+    float *cnt_s = reinterpret_cast<float *>(rec + (has_rec ? (size_t)TP * V : 0));   // [TP]
     uint32_t *flag_s = reinterpret_cast<uint32_t *>(cnt_s + TP);             // [TP]
     uint32_t *idx_s = flag_s + TP;                                           // [TP]
-    float *krt = reinterpret_cast<float *>(idx_s + TP);                      // [V*12]
+    float *aux_s = reinterpret_cast<float *>(idx_s + TP);                    // [TP][2]: refined 1/(cnt + 1e-6), cnt + 1e-6
+    float *krt = aux_s + 2 * TP;                                             // [V*12]
     constexpr uint32_t SB = 512u * U;                                        // bytes of one texel slice
     const uint32_t zero_off = (uint32_t)P.win_pool_offset;                   // two all-zero slices, then the pool
     const uint32_t pool_off = zero_off + 2u * SB;
@@ -1236,6 +1250,7 @@ __device__ __forceinline__ void fused_eval_window_body(const EvalParams &P)
     __shared__ float red_s[kBlock / 64][6];
     __shared__ WinView win_s[kWinMaxViews];
     __shared__ int total_s;
+    __shared__ uint32_t texsrc_s[kWinMaxTexels];     // byte offset (from the map's base) of every pool slot's texel
 
     const bool walk = P.walk_nx > 0;
     const MapDesc &m0 = P.maps[0];
@@ -1337,13 +1352,15 @@ __device__ __forceinline__ void fused_eval_window_body(const EvalParams &P)
             w.xmin = x0; w.ymin = y0; w.bw = x1 - x0 + 1; w.bh = y1 - y0 + 1;
             ntex = w.bw * w.bh;
         }
-        // pool slots in view order; a window that does not fit is dropped (its pairs go direct)
+        // pool slots in view order; a window that does not fit keeps the rows that do (pairs in the other rows go
+        // direct, like every pair of a view left without a window)
         int run = 0;
         for (int vv = 0; vv < V && vv < kWinMaxViews; ++vv) {
-            const int nv = __shfl(ntex, vv * 8, 64);
-            const bool fits = nv > 0 && run + nv <= P.win_pool_texels;
-            if (vv == v) { w.base = run; w.ok = fits ? 1 : 0; }
-            if (fits) run += nv;
+            const int nv = __shfl(ntex, vv * 8, 64), bwv = __shfl(w.bw, vv * 8, 64);
+            int rows = nv > 0 ? min(nv, P.win_pool_texels - run) / bwv : 0;
+            if (rows < 2) rows = 0;                              // a bilinear footprint needs two rows
+            if (vv == v) { w.base = run; w.ok = rows > 0 ? 1 : 0; w.bh = rows > 0 ? rows : w.bh; }
+            run += rows * bwv;
         }
         if (act && c == 0) win_s[v] = w;
         if (lane == 0) total_s = run;
@@ -1351,22 +1368,28 @@ __device__ __forceinline__ void fused_eval_window_body(const EvalParams &P)
     __syncthreads();
 
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    // where every pool slot's texel lives in the map: one lane per slot, once per workgroup (the view search and the
+    // division by the window width cost ~100 VALU instructions; done per copy instruction and slice they were a third
+    // of the kernel's VALU work)
+    for (int t = threadIdx.x; t < total_s; t += kBlock) {
+        int v = 0;
+        for (int vv = 1; vv < V && vv < kWinMaxViews; ++vv)
+            if (win_s[vv].ok && t >= win_s[vv].base) v = vv;          // bases ascend over the views that have a window
+        const WinView w = win_s[v];
+        const int local = t - w.base;
+        const int y = local / w.bw, x = local - y * w.bw;
+        texsrc_s[t] = (uint32_t)(((int64_t)v * m0.sv + (int64_t)(w.ymin + y) * m0.sy + (int64_t)(w.xmin + x) * m0.sx) * 4);
+    }
+    __syncthreads();
     // copy of slice `sl` of every window into the pool: 512-byte granules, two per wave instruction
     auto stage = [&](int sl) {
         const int total = total_s * U;              // granules
         const int h = lane >> 5, l = lane & 31;
-        const char *data = reinterpret_cast<const char *>(m0.data);
+        const char *data = reinterpret_cast<const char *>(m0.data) + (size_t)sl * SB + (size_t)l * 16;
         for (int g2 = wave; g2 * 2 < total; g2 += kBlock / 64) {
             const int hk = min(g2 * 2 + h, total - 1);
             const int t = hk / U, part = hk - t * U;
-            int v = 0;
-            for (int vv = 1; vv < V && vv < kWinMaxViews; ++vv)
-                if (win_s[vv].ok && t >= win_s[vv].base) v = vv;      // bases ascend over the views that have a window
-            const WinView w = win_s[v];
-            const int local = t - w.base;
-            const int y = local / w.bw, x = local - y * w.bw;
-            const char *src = data + ((int64_t)v * m0.sv + (int64_t)(w.ymin + y) * m0.sy + (int64_t)(w.xmin + x) * m0.sx) * 4 +
-                              (size_t)sl * SB + (size_t)part * 512 + (size_t)l * 16;
+            const char *src = data + texsrc_s[t] + (uint32_t)part * 512u;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
                                              (__attribute__((address_space(3))) void *)(smem + pool_off + (size_t)g2 * 1024),
                                              16, 0, 0);
@@ -1382,22 +1405,25 @@ __device__ __forceinline__ void fused_eval_window_body(const EvalParams &P)
         for (int idx = threadIdx.x; idx < TP * VP; idx += kBlock) {
             const int p = idx >> vp_log2, v = idx & (VP - 1);
             const int64_t i = slot_point(p);
-            float dv = 0.0f, valid = 0.0f;
+            float dv = 0.0f, valid = 0.0f, gx = 0.0f, gy = 0.0f;
             uint32_t st = 0u;
+            WinRec wr;
+            wr.nw = zero_off; wr.row = 0u; wr.wgt = 0.0f; wr.valid = 0.0f;
+            wr.w[0] = wr.w[1] = wr.w[2] = wr.w[3] = 0.0f;
             if (v < V) {
                 float px, py, pz;
                 fetch_point(P, i, px, py, pz);
                 float wgt;
                 const ViewOut o = eval_view<0>(P.depth, P.H, P.W, krt + v * 12, v, px, py, pz, Wm1, Hm1, mu, wgt);
-                ViewRec r;
-                r.gx = o.gx; r.gy = o.gy; r.wgt = wgt; r.valid = o.valid;
-                rec[p * V + v] = r;
+                if (has_rec) {
+                    ViewRec r;
+                    r.gx = o.gx; r.gy = o.gy; r.wgt = wgt; r.valid = o.valid;
+                    rec[p * V + v] = r;
+                }
                 dv = o.dist * o.valid;                                          // fusion.py:364 (product only)
-                valid = o.valid;
+                valid = o.valid; gx = o.gx; gy = o.gy;
                 if (!(isfinite(o.gx) && isfinite(o.gy) && isfinite(wgt))) st |= kWinStrict;
-                WinRec wr;
-                wr.nw = zero_off; wr.row = 0u; wr.wgt = wgt; wr.pad = 0u;
-                wr.w[0] = wr.w[1] = wr.w[2] = wr.w[3] = 0.0f;
+                wr.wgt = wgt; wr.valid = o.valid;
                 if (o.valid != 0.0f) {
                     // the corner set-up of corner_setup(), in texel coordinates
                     const float ix = unnormalize(o.gx, m0.fw), iy = unnormalize(o.gy, m0.fh);
@@ -1414,11 +1440,10 @@ __device__ __forceinline__ void fused_eval_window_body(const EvalParams &P)
                         wr.row = (uint32_t)w.bw * SB;
                         wr.w[0] = sy * ex; wr.w[1] = sy * tx; wr.w[2] = ty * ex; wr.w[3] = ty * tx;
                     } else {
-                        wr.nw = kWinDirect;
+                        wr.nw = kWinDirect; wr.w[0] = gx; wr.w[1] = gy;
                         st |= kWinHasDirect;
                     }
                 }
-                wrec[p * V + v] = wr;
             }
             // sums over the views in view order (fusion.py:364-370)
             float dsum = 0.0f, cnt = 0.0f;
@@ -1427,6 +1452,10 @@ __device__ __forceinline__ void fused_eval_window_body(const EvalParams &P)
                 dsum = dsum + __shfl(dv, base + vv, 64);
                 cnt = cnt + __shfl(valid, base + vv, 64);
                 stp |= (uint32_t)__shfl((int)st, base + vv, 64);
+            }
+            if (v < V) {
+                if (stp & kWinStrict) { wr.nw = kWinDirect; wr.w[0] = gx; wr.w[1] = gy; }     // strict point: every pair from global
+                wrec[p * V + v] = wr;
             }
             if (v == 0) {
                 const bool all_invalid = (cnt == 0.0f);                         // fusion.py:366
@@ -1438,6 +1467,11 @@ __device__ __forceinline__ void fused_eval_window_body(const EvalParams &P)
                 idx_s[p] = (uint32_t)i;
                 if (!(P.flags & kFlagFiniteMaps)) stp |= kWinStrict;
                 flag_s[p] = stp;
+                // the shared reciprocal of the fast division (gather_map), once per point instead of once per slice
+                const float denom = cnt + 1e-6f;
+                const float r0 = __builtin_amdgcn_rcpf(denom);
+                aux_s[2 * p] = fmaf(fmaf(-denom, r0, 1.0f), r0, r0);
+                aux_s[2 * p + 1] = denom;
             }
         }
     }
@@ -1448,6 +1482,7 @@ __device__ __forceinline__ void fused_eval_window_body(const EvalParams &P)
     const uint32_t lane_off = (uint32_t)l * 16u;
     const char *__restrict__ data = reinterpret_cast<const char *>(m.data);
     const int S = P.win_slices;
+    const bool out32 = (uint64_t)P.n * (uint64_t)m.C * 4u <= 0xffffffffull;     // uniform: the whole fused output below 4 GiB
     for (int sl = 0; sl < S; ++sl) {
         if (sl > 0) {
             __syncthreads();                        // everyone is done with the previous slice's pool
@@ -1458,8 +1493,6 @@ __device__ __forceinline__ void fused_eval_window_body(const EvalParams &P)
         const uint32_t co = (uint32_t)sl * SB + lane_off;               // byte offset of this lane's first vector in a texel
         for (int p = grp; p < TP; p += kBlock / 32) {
             const int64_t i = idx_s[p];
-            const float cnt = cnt_s[p];
-            const float denom = cnt + 1e-6f;
             const uint32_t fl = flag_s[p];
             const bool strict = (fl & kWinStrict) != 0u;
             VT acc[U];
@@ -1485,8 +1518,7 @@ __device__ __forceinline__ void fused_eval_window_body(const EvalParams &P)
                             acc[u] = acc[u] + s_ * wr.wgt;
                         }
                     } else {
-                        const ViewRec r = rec[p * V + v];
-                        const Corner c = corner_setup(m, r.gx, r.gy);
+                        const Corner c = corner_setup(m, wr.w[0], wr.w[1]);
                         const char *bv = data + (int64_t)v * m.sv * 4;
                         const float w0 = c.inw ? c.wnw : 0.0f, w1 = c.ine ? c.wne : 0.0f, w2 = c.isw ? c.wsw : 0.0f, w3 = c.ise ? c.wse : 0.0f;
 #pragma unroll
@@ -1498,15 +1530,15 @@ __device__ __forceinline__ void fused_eval_window_body(const EvalParams &P)
                             s_ = v_fma<VT>(b, w1, s_);
                             s_ = v_fma<VT>(d, w2, s_);
                             s_ = v_fma<VT>(e, w3, s_);
-                            acc[u] = acc[u] + s_ * r.wgt;
+                            acc[u] = acc[u] + s_ * wr.wgt;
                         }
                     }
                 }
             } else {
                 for (int v = 0; v < V; ++v) {
-                    const ViewRec r = rec[p * V + v];
+                    const WinRec wr = wrec[p * V + v];
                     const char *bv = data + (int64_t)v * m.sv * 4;
-                    const Corner c = corner_setup(m, r.gx, r.gy);
+                    const Corner c = corner_setup(m, wr.w[0], wr.w[1]);
 #pragma unroll
                     for (int u = 0; u < U; ++u) {
                         const uint32_t cu = co + (uint32_t)u * 512u;
@@ -1517,29 +1549,26 @@ __device__ __forceinline__ void fused_eval_window_body(const EvalParams &P)
                         s_ = v_fma<VT>(bvv, c.wne, s_);
                         s_ = v_fma<VT>(dv, c.wsw, s_);
                         s_ = v_fma<VT>(ev, c.wse, s_);
-                        acc[u] = acc[u] + (s_ * r.valid) * r.wgt;
+                        acc[u] = acc[u] + (s_ * wr.valid) * wr.wgt;
                     }
                 }
             }
-            float rcp_d = 0.0f;
-            if (!strict) {
-                const float r0 = __builtin_amdgcn_rcpf(denom);
-                rcp_d = fmaf(fmaf(-denom, r0, 1.0f), r0, r0);
-            }
+            const float rcp_d = aux_s[2 * p], denom = aux_s[2 * p + 1];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                VT o = (VT)0.0f;
-                if (cnt != 0.0f) {
-                    if (strict) {
-                        o = strict_div<VT>(acc[u], denom);
-                    } else {
-                        VT q = acc[u] * rcp_d;
-                        q = v_fma<VT>(v_fma<VT>(q, -denom, acc[u]), rcp_d, q);
-                        q = v_fma<VT>(v_fma<VT>(q, -denom, acc[u]), rcp_d, q);
-                        o = q;
-                    }
+                VT o;
+                if (strict) {
+                    o = (VT)0.0f;                                          // fusion.py:386 when no view is valid
+                    if (cnt_s[p] != 0.0f) o = strict_div<VT>(acc[u], denom);
+                } else {
+                    // no view valid: every term was (+-0) * wgt, acc is +0 and so is the quotient -- fusion.py:386 for free
+                    VT q = acc[u] * rcp_d;
+                    q = v_fma<VT>(v_fma<VT>(q, -denom, acc[u]), rcp_d, q);
+                    q = v_fma<VT>(v_fma<VT>(q, -denom, acc[u]), rcp_d, q);
+                    o = q;
                 }
-                store_out<VT>(m.out + i * m.C + ((co + (uint32_t)u * 512u) >> 2), o, P.store_policy);
+                if (out32) store_out_off(m.out, (uint32_t)i * (uint32_t)(m.C * 4) + co + (uint32_t)u * 512u, o, P.store_policy);
+                else store_out<VT>(m.out + i * m.C + ((co + (uint32_t)u * 512u) >> 2), o, P.store_policy);
             }
         }
     }

@@ -428,7 +428,7 @@ class Fusion:
         order = {2: "closed-form brick walk of the lattice (no keys, no sort)" + ("; channel-sliced over the XCDs" if 100 <= plan.reserved < 200 else ""), 1: "Morton-cell order (counting sort by 16-mm cell + 4-mm refinement, hand-written)",
                  0: "caller order"}[int(plan.reorder)]
         if window:
-            order += "; texel windows in LDS (experiment)"
+            order += "; %d-point bricks through texel windows in LDS" % int(plan.tile_points)
         elif runs:
             order += "; cell runs of %d consecutive points" % (max(plan.staged[s] for s in range(n_maps)) - 16)
         self._last_plan = {"kernel": kernel, "tile_points": int(plan.tile_points), "point_order": order,
