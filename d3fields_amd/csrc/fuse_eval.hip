@@ -1228,7 +1228,7 @@ __device__ __forceinline__ void window_point(f32x4 (&acc)[U], const unsigned cha
     }
 }
 
-template <int U, int VC>
+template <int U, int VC, int NT>
 __device__ __forceinline__ void fused_eval_window_body(const EvalParams &P)
 {
     using VT = f32x4;
@@ -1247,7 +1247,7 @@ __device__ __forceinline__ void fused_eval_window_body(const EvalParams &P)
     const uint32_t zero_off = (uint32_t)P.win_pool_offset;                   // two all-zero slices, then the pool
     const uint32_t pool_off = zero_off + 2u * SB;
     __shared__ float cpt_s[8][3];
-    __shared__ float red_s[kBlock / 64][6];
+    __shared__ float red_s[NT / 64][6];
     __shared__ WinView win_s[kWinMaxViews];
     __shared__ int total_s;
     __shared__ uint32_t texsrc_s[kWinMaxTexels];     // byte offset (from the map's base) of every pool slot's texel
@@ -1284,8 +1284,8 @@ __device__ __forceinline__ void fused_eval_window_body(const EvalParams &P)
     const float Wm1 = (float)(P.W - 1), Hm1 = (float)(P.H - 1);
 
     // ---- 1. KRt, the zero slices, the eight corner points of the set's bounding box ----
-    compute_krt(P.K, P.pose, V, krt, kBlock);
-    for (uint32_t t = threadIdx.x; t < 2u * SB / 4u; t += kBlock) reinterpret_cast<uint32_t *>(smem + zero_off)[t] = 0u;
+    compute_krt(P.K, P.pose, V, krt, NT);
+    for (uint32_t t = threadIdx.x; t < 2u * SB / 4u; t += NT) reinterpret_cast<uint32_t *>(smem + zero_off)[t] = 0u;
     if (walk) {
         if (threadIdx.x < 8) {
             const int c = threadIdx.x;
@@ -1297,7 +1297,7 @@ __device__ __forceinline__ void fused_eval_window_body(const EvalParams &P)
         }
     } else {
         float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
-        for (int p = threadIdx.x; p < tile_n; p += kBlock) {
+        for (int p = threadIdx.x; p < tile_n; p += NT) {
             float q[3];
             fetch_point(P, slot_point(p), q[0], q[1], q[2]);
 #pragma unroll
@@ -1319,7 +1319,7 @@ __device__ __forceinline__ void fused_eval_window_body(const EvalParams &P)
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
                 float a = red_s[0][k], b = red_s[0][3 + k];
-                for (int w = 1; w < kBlock / 64; ++w) { a = fminf(a, red_s[w][k]); b = fmaxf(b, red_s[w][3 + k]); }
+                for (int w = 1; w < NT / 64; ++w) { a = fminf(a, red_s[w][k]); b = fmaxf(b, red_s[w][3 + k]); }
                 cpt_s[c][k] = ((c >> k) & 1) ? b : a;      // a NaN coordinate is dropped by fmin/fmax: such a point is strict
             }
         }
@@ -1371,7 +1371,7 @@ __device__ __forceinline__ void fused_eval_window_body(const EvalParams &P)
     // where every pool slot's texel lives in the map: one lane per slot, once per workgroup (the view search and the
     // division by the window width cost ~100 VALU instructions; done per copy instruction and slice they were a third
     // of the kernel's VALU work)
-    for (int t = threadIdx.x; t < total_s; t += kBlock) {
+    for (int t = threadIdx.x; t < total_s; t += NT) {
         int v = 0;
         for (int vv = 1; vv < V && vv < kWinMaxViews; ++vv)
             if (win_s[vv].ok && t >= win_s[vv].base) v = vv;          // bases ascend over the views that have a window
@@ -1386,7 +1386,7 @@ __device__ __forceinline__ void fused_eval_window_body(const EvalParams &P)
         const int total = total_s * U;              // granules
         const int h = lane >> 5, l = lane & 31;
         const char *data = reinterpret_cast<const char *>(m0.data) + (size_t)sl * SB + (size_t)l * 16;
-        for (int g2 = wave; g2 * 2 < total; g2 += kBlock / 64) {
+        for (int g2 = wave; g2 * 2 < total; g2 += NT / 64) {
             const int hk = min(g2 * 2 + h, total - 1);
             const int t = hk / U, part = hk - t * U;
             const char *src = data + texsrc_s[t] + (uint32_t)part * 512u;
@@ -1402,7 +1402,7 @@ __device__ __forceinline__ void fused_eval_window_body(const EvalParams &P)
         const int vp_log2 = V <= 1 ? 0 : (V <= 2 ? 1 : (V <= 4 ? 2 : 3));
         const int VP = 1 << vp_log2;
         const int base = lane & ~(VP - 1);
-        for (int idx = threadIdx.x; idx < TP * VP; idx += kBlock) {
+        for (int idx = threadIdx.x; idx < TP * VP; idx += NT) {
             const int p = idx >> vp_log2, v = idx & (VP - 1);
             const int64_t i = slot_point(p);
             float dv = 0.0f, valid = 0.0f, gx = 0.0f, gy = 0.0f;
@@ -1491,7 +1491,7 @@ __device__ __forceinline__ void fused_eval_window_body(const EvalParams &P)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();                            // records (first slice) and pool are complete
         const uint32_t co = (uint32_t)sl * SB + lane_off;               // byte offset of this lane's first vector in a texel
-        for (int p = grp; p < TP; p += kBlock / 32) {
+        for (int p = grp; p < TP; p += NT / 32) {
             const int64_t i = idx_s[p];
             const uint32_t fl = flag_s[p];
             const bool strict = (fl & kWinStrict) != 0u;
@@ -1572,7 +1572,8 @@ __device__ __forceinline__ void fused_eval_window_body(const EvalParams &P)
             }
         }
     }
-    // the other (thin) maps of the call
+    // the other (thin) maps of the call (their gather is written for kBlock lanes)
+    if (NT > kBlock && threadIdx.x >= kBlock) return;
     for (int s = 1; s < P.n_maps; ++s) {
         const MapDesc &mt = P.maps[s];
         switch (mt.vw) {
@@ -1583,8 +1584,10 @@ __device__ __forceinline__ void fused_eval_window_body(const EvalParams &P)
     }
 }
 
-template <int U, int VC, int WAVES>
-__global__ __launch_bounds__(kBlock, WAVES) void fused_eval_window_kernel(const EvalParams P) { fused_eval_window_body<U, VC>(P); }
+// (NT lanes per workgroup: 512 lanes over the same 64-point brick -- twice the waves per pool -- measured no faster
+// at 2, 3 or 4 workgroups per CU: 0.58-0.71 ms on C2 patch against 0.58; only the 256-lane form is built)
+template <int U, int VC, int WAVES, int NT = kBlock>
+__global__ __launch_bounds__(NT, WAVES) void fused_eval_window_kernel(const EvalParams P) { fused_eval_window_body<U, VC, NT>(P); }
 
 // Three entry points over one body: the plain kernel (<= 3 channel vectors per lane) is held to 128 VGPRs
 // = 4 waves per SIMD -- the gather lives on memory-level parallelism; the WIDE variant adds the 4-vector
@@ -1636,23 +1639,23 @@ hipError_t launch_fused_eval(const EvalParams &P, int mode, hipStream_t stream)
         const size_t lds_w = (size_t)P.win_pool_offset + (size_t)(2 + P.win_pool_texels) * 512 * P.win_u;
         dim3 gw((unsigned)((P.n + P.tile_pts - 1) / P.tile_pts));
         if (P.walk_nx > 0) gw = dim3((unsigned)ntiles);
-#define D3F_WIN_LAUNCH(U_, VC_, W_)                                                                                            \
+#define D3F_WIN_LAUNCH(U_, VC_, W_, NT_)                                                                                       \
         do {                                                                                                                       \
             if (lds_w > 64 * 1024) {                                                                                               \
-                hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void *>(&fused_eval_window_kernel<U_, VC_, W_>),        \
+                hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void *>(&fused_eval_window_kernel<U_, VC_, W_, NT_>),   \
                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_w);                      \
                 if (ea != hipSuccess) return ea;                                                                                   \
             }                                                                                                                      \
-            hipLaunchKernelGGL((fused_eval_window_kernel<U_, VC_, W_>), gw, block, lds_w, stream, P);                              \
+            hipLaunchKernelGGL((fused_eval_window_kernel<U_, VC_, W_, NT_>), gw, dim3(NT_), lds_w, stream, P);                     \
         } while (0)
-        if (P.win_u == 1 && P.win_occ >= 4) D3F_WIN_LAUNCH(1, 4, 4);
-        else if (P.win_u == 1 && P.win_occ == 3) D3F_WIN_LAUNCH(1, 4, 3);
-        else if (P.win_u == 1) D3F_WIN_LAUNCH(1, 4, 2);
-        else if (P.win_u == 2 && P.win_vc == 2) D3F_WIN_LAUNCH(2, 2, 2);
-        else if (P.win_u == 2) D3F_WIN_LAUNCH(2, 1, 2);
-        else if (P.win_u == 3 && P.win_vc == 2) D3F_WIN_LAUNCH(3, 2, 2);
-        else if (P.win_u == 3) D3F_WIN_LAUNCH(3, 1, 2);
-        else D3F_WIN_LAUNCH(4, 1, 2);
+        if (P.win_u == 1 && P.win_occ >= 4) D3F_WIN_LAUNCH(1, 4, 4, 256);
+        else if (P.win_u == 1 && P.win_occ == 3) D3F_WIN_LAUNCH(1, 4, 3, 256);
+        else if (P.win_u == 1) D3F_WIN_LAUNCH(1, 4, 2, 256);
+        else if (P.win_u == 2 && P.win_vc == 2) D3F_WIN_LAUNCH(2, 2, 2, 256);
+        else if (P.win_u == 2) D3F_WIN_LAUNCH(2, 1, 2, 256);
+        else if (P.win_u == 3 && P.win_vc == 2) D3F_WIN_LAUNCH(3, 2, 2, 256);
+        else if (P.win_u == 3) D3F_WIN_LAUNCH(3, 1, 2, 256);
+        else D3F_WIN_LAUNCH(4, 1, 2, 256);
 #undef D3F_WIN_LAUNCH
         return hipGetLastError();
     }
