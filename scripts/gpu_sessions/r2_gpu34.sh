@@ -7,7 +7,7 @@ B="python $REPO/bench.py --no-cpu-baseline --steps 20"
 run() { TAG=$1; WL=$2; shift 2; env "$@" timeout -k 5 300 $B --workload $WL > $OUT/bench_${WL}_$TAG.json 2>$OUT/bench_${WL}_$TAG.err; }
 for WL in c2_patch c3_patch; do
   run o4 $WL D3F_EXP_WINDOW_OCC=4
-  run o3 $WL D3F_EXP_WINDOW_OCC=3
+  run o4c $WL D3F_EXP_WINDOW_OCC=4
   run o4b $WL D3F_EXP_WINDOW_OCC=4
 done
 for f in $OUT/bench_*.json; do echo "$(basename $f .json): $(python - "$f" <<'PY'
