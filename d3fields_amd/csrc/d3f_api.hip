@@ -497,7 +497,7 @@ int eval_common(const d3f_views *views, const float *pts, int64_t n, const d3f_c
             plan_out->lds_bytes = P.win_pool_offset + (2 + P.win_pool_texels) * 512 * P.win_u;
             plan_out->workgroups = ntiles;
         }
-        plan_out->reserved = P.sl_slices > 0 ? 100 + P.sl_lg * 10 + P.sl_vc : (P.win_slices > 0 ? 200 + P.win_occ : 0);      // 1LV: sliced launch, L = log2(lanes per point), V = views in flight
+        plan_out->reserved = P.sl_slices > 0 ? 100 + P.sl_lg * 10 + P.sl_vc : (P.win_slices > 0 ? 2000 + 100 * P.win_u + 10 * (P.win_u == 1 ? 4 : (P.win_u == 4 ? 1 : P.win_vc)) + (P.win_u == 1 ? (P.win_occ >= 4 ? 4 : P.win_occ) : 2) : 0);   // 2UVW: the window kernel's template arguments      // 1LV: sliced launch, L = log2(lanes per point), V = views in flight
         for (int s = 0; s < n_maps; ++s)
             if (P.maps[s].runs > 0) {        // waves per SIMD the chosen cell-run kernel variant is built for
                 const int ru = P.maps[s].unroll, rk = P.maps[s].runs;

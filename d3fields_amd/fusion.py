@@ -416,9 +416,10 @@ class Fusion:
         wide = any(plan.vectors_per_lane[s] == -4 for s in range(n_maps))
         f16 = any(maps[s].dtype == _lib.DTYPE_F16 for s in range(n_maps))
         kernel = ("fused_eval_f16_kernel<0>" if f16 else "fused_eval_wide_kernel<0>" if wide else "fused_eval_kernel<0>")
-        window = plan.reserved >= 200
+        window = plan.reserved >= 2000
         if window:
-            kernel = "fused_eval_window_kernel<occupancy %d>" % (plan.reserved - 200)
+            r = plan.reserved - 2000
+            kernel = "fused_eval_window_kernel<%d, %d, %d, 256>" % (r // 100, r // 10 % 10, r % 10)
         elif plan.reserved >= 100:
             lg, vc = (plan.reserved - 100) // 10, (plan.reserved - 100) % 10
             kernel = "fused_eval_sliced_kernel<%d, %d, %d>" % (lg, vc, {1: 8, 2: 7, 4: 5}.get(vc, 5))

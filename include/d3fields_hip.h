@@ -138,13 +138,15 @@ typedef struct d3f_eval_plan {
                                                walk of a lattice (d3f_eval_grid / d3f_eval_lattice)    */
     int32_t lds_bytes;                      /* dynamic LDS per workgroup                              */
     int32_t reserved;                       /* cell-run gather: waves per SIMD its kernel variant is built for; channel-sliced
-                                               launch: 100 + 10*log2(lanes per point) + views in flight; else 0 */
+                                               launch: 100 + 10*log2(lanes per point) + views in flight; LDS texel-window
+                                               kernel: 2000 + 100*U + 10*VC + W (its template arguments); else 0 */
     int64_t workgroups;
     int32_t vector_floats[D3F_MAX_MAPS];    /* 4 / 2 / 1 floats per load                              */
     int32_t lanes_per_point[D3F_MAX_MAPS];
     int32_t vectors_per_lane[D3F_MAX_MAPS];
-    int32_t staged[D3F_MAX_MAPS];           /* 2: texel windows staged through LDS (experiment); 16 + K: cell-run gather
-                                               with runs of K points (patch-resolution wide maps)      */
+    int32_t staged[D3F_MAX_MAPS];           /* 2: wave-private LDS staging (experiment); 3: LDS texel windows per brick
+                                               (patch-resolution wide map on a lattice); 16 + K: cell-run gather with
+                                               runs of K points (patch-resolution wide maps)           */
 } d3f_eval_plan;
 int d3f_eval_plan_query(const d3f_views *views, int64_t n, const d3f_channel_map *maps, int32_t n_maps,
                         uint32_t flags, int32_t have_workspace, int32_t want_inter, d3f_eval_plan *plan);
