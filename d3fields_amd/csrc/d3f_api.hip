@@ -158,7 +158,7 @@ void pick_staged_mapping(d3f::MapDesc &m)
 //   D3F_EXP_WINDOW LDS texel-window kernel instead of the cell-run gather for a patch-resolution wide first map
 //                  (fuse_eval.hip): 0 automatic = on lattices (64 points per workgroup), -1 never,
 //                  32 / 64 / 128 = always, with that many points per workgroup; _U vectors per lane (1..4), _VC views
-//                  in flight (U = 2 / 3), _OCC workgroups per CU (2..4), _POOL pool texels
+//                  in flight (U = 2 / 3), _OCC workgroups per CU (2..4), _POOL pool texels, _LPP 32: one vector per lane (default 16 x 2)
 //   D3F_EXP_RUNS_OCC also: 4 = the (2,8) cell-run variant held to 4 waves per SIMD (default 3, spill-free)
 int exp_knob(const char *name)
 {
@@ -253,6 +253,7 @@ int eval_common(const d3f_views *views, const float *pts, int64_t n, const d3f_c
     P.walk_nx = P.walk_ny = P.walk_nz = 0; P.walk_tx = P.walk_ty = P.walk_tz = 1;
     P.sl_unit = 128; P.sl_slices = 0; P.sl_lg = 3; P.sl_vc = 4; P.sl_tiles = P.sl_groups = P.sl_chunks = 0;
     P.runs_occ = exp_knob("D3F_EXP_RUNS_OCC");
+    P.win_lpp = exp_knob("D3F_EXP_WINDOW_LPP") == 32 ? 32 : 16;     // 16 lanes x 2 vectors per point (C2 patch 0.565 -> 0.54 ms); U > 1: 32
     P.win_slices = 0; P.win_u = 1; P.win_vc = 1; P.win_pool_offset = 0; P.win_pool_texels = 0; P.win_occ = 4;
     P.store_policy = exp_knob("D3F_EXP_STORE") < 0 ? 0 : 1;
     int64_t map_bytes = 0;
@@ -316,6 +317,7 @@ int eval_common(const d3f_views *views, const float *pts, int64_t n, const d3f_c
             if (texels > 320) texels = 320;                      // kWinMaxTexels (fuse_eval.hip)
             texels &= ~1;
             window = texels >= 2 && (T * VP) % 64 == 0 && n / T < 0x7fffffffLL;
+            if (U > 1) P.win_lpp = 32;
             P.win_u = U; P.win_occ = occ; P.win_pool_offset = pool_offset; P.win_pool_texels = texels;
             P.win_vc = exp_knob("D3F_EXP_WINDOW_VC") == 2 ? 2 : 1;
             P.win_slices = window ? cv / U : 0;
@@ -497,7 +499,7 @@ int eval_common(const d3f_views *views, const float *pts, int64_t n, const d3f_c
             plan_out->lds_bytes = P.win_pool_offset + (2 + P.win_pool_texels) * 512 * P.win_u;
             plan_out->workgroups = ntiles;
         }
-        plan_out->reserved = P.sl_slices > 0 ? 100 + P.sl_lg * 10 + P.sl_vc : (P.win_slices > 0 ? 2000 + 100 * P.win_u + 10 * (P.win_u == 1 ? 4 : (P.win_u == 4 ? 1 : P.win_vc)) + (P.win_u == 1 ? (P.win_occ >= 4 ? 4 : P.win_occ) : 2) : 0);   // 2UVW: the window kernel's template arguments      // 1LV: sliced launch, L = log2(lanes per point), V = views in flight
+        plan_out->reserved = P.sl_slices > 0 ? 100 + P.sl_lg * 10 + P.sl_vc : (P.win_slices > 0 ? 2000 + 100 * P.win_u + 10 * (P.win_u == 1 ? (P.win_lpp == 16 ? 2 : 4) : (P.win_u == 4 ? 1 : P.win_vc)) + (P.win_u == 1 ? (P.win_occ >= 4 ? 4 : (P.win_lpp == 16 ? 3 : P.win_occ)) : 2) : 0);   // 2UVW: the window kernel's template arguments      // 1LV: sliced launch, L = log2(lanes per point), V = views in flight
         for (int s = 0; s < n_maps; ++s)
             if (P.maps[s].runs > 0) {        // waves per SIMD the chosen cell-run kernel variant is built for
                 const int ru = P.maps[s].unroll, rk = P.maps[s].runs;
@@ -506,8 +508,8 @@ int eval_common(const d3f_views *views, const float *pts, int64_t n, const d3f_c
         for (int s = 0; s < D3F_MAX_MAPS; ++s) {
             const bool on = s < n_maps;
             plan_out->vector_floats[s] = on ? P.maps[s].vw : 0;
-            plan_out->lanes_per_point[s] = on ? (1 << P.maps[s].lpp_log2) : 0;
-            plan_out->vectors_per_lane[s] = on ? P.maps[s].unroll : 0;   /* negative: load-use per vector */
+            plan_out->lanes_per_point[s] = on ? ((P.win_slices > 0 && s == 0) ? P.win_lpp : (1 << P.maps[s].lpp_log2)) : 0;
+            plan_out->vectors_per_lane[s] = on ? ((P.win_slices > 0 && s == 0) ? P.win_u * (32 / P.win_lpp) : P.maps[s].unroll) : 0;   /* negative: load-use per vector */
             plan_out->staged[s] = on ? (P.win_slices > 0 && s == 0 ? 3 : (P.maps[s].runs > 0 ? 16 + P.maps[s].runs : P.maps[s].staged)) : 0;
         }
         return D3F_OK;

@@ -1175,8 +1175,9 @@ constexpr int kWinMaxTexels = 320;       // pool slots (host: win_pool_texels <=
 constexpr uint32_t kWinStrict = 1u, kWinHasDirect = 2u;
 
 // all views of one point from the pool: VC views' corner reads in flight together
-template <int U, int VC>
-__device__ __forceinline__ void window_point(f32x4 (&acc)[U], const unsigned char *smem, const WinRec *wr_p, int V,
+// NV vectors per lane, VS bytes apart inside a slice of SBB bytes (the ne / se corners are one slice further)
+template <int NV, int VC, int VS, int SBB>
+__device__ __forceinline__ void window_point(f32x4 (&acc)[NV], const unsigned char *smem, const WinRec *wr_p, int V,
                                              uint32_t lane_off)
 {
     using VT = f32x4;
@@ -1193,23 +1194,23 @@ __device__ __forceinline__ void window_point(f32x4 (&acc)[U], const unsigned cha
             wr[q].nw = __float_as_uint(h0.x); wr[q].row = __float_as_uint(h0.y); wr[q].wgt = h0.z; wr[q].valid = h0.w;
             wr[q].w[0] = h1.x; wr[q].w[1] = h1.y; wr[q].w[2] = h1.z; wr[q].w[3] = h1.w;
         }
-        VT a[VC][U], b[VC][U], d[VC][U], e[VC][U];
+        VT a[VC][NV], b[VC][NV], d[VC][NV], e[VC][NV];
 #pragma unroll
         for (int q = 0; q < VC; ++q) {
             const unsigned char *nw = smem + (wr[q].nw + lane_off);
             const unsigned char *sw = nw + wr[q].row;
 #pragma unroll
-            for (int u = 0; u < U; ++u) {
-                a[q][u] = *reinterpret_cast<const VT *>(nw + u * 512);
-                b[q][u] = *reinterpret_cast<const VT *>(nw + (U + u) * 512);
-                d[q][u] = *reinterpret_cast<const VT *>(sw + u * 512);
-                e[q][u] = *reinterpret_cast<const VT *>(sw + (U + u) * 512);
+            for (int u = 0; u < NV; ++u) {
+                a[q][u] = *reinterpret_cast<const VT *>(nw + u * VS);
+                b[q][u] = *reinterpret_cast<const VT *>(nw + SBB + u * VS);
+                d[q][u] = *reinterpret_cast<const VT *>(sw + u * VS);
+                e[q][u] = *reinterpret_cast<const VT *>(sw + SBB + u * VS);
             }
         }
 #pragma unroll
         for (int q = 0; q < VC; ++q)
 #pragma unroll
-            for (int u = 0; u < U; ++u) {
+            for (int u = 0; u < NV; ++u) {
                 VT s_ = a[q][u] * wr[q].w[0];
                 s_ = v_fma<VT>(b[q][u], wr[q].w[1], s_);
                 s_ = v_fma<VT>(d[q][u], wr[q].w[2], s_);
@@ -1223,9 +1224,9 @@ __device__ __forceinline__ void window_point(f32x4 (&acc)[U], const unsigned cha
             const unsigned char *nw = smem + (wr.nw + lane_off);
             const unsigned char *sw = nw + wr.row;
 #pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const VT a = *reinterpret_cast<const VT *>(nw + u * 512), b = *reinterpret_cast<const VT *>(nw + (U + u) * 512);
-                const VT d = *reinterpret_cast<const VT *>(sw + u * 512), e = *reinterpret_cast<const VT *>(sw + (U + u) * 512);
+            for (int u = 0; u < NV; ++u) {
+                const VT a = *reinterpret_cast<const VT *>(nw + u * VS), b = *reinterpret_cast<const VT *>(nw + SBB + u * VS);
+                const VT d = *reinterpret_cast<const VT *>(sw + u * VS), e = *reinterpret_cast<const VT *>(sw + SBB + u * VS);
                 VT s_ = a * wr.w[0];
                 s_ = v_fma<VT>(b, wr.w[1], s_);
                 s_ = v_fma<VT>(d, wr.w[2], s_);
@@ -1236,10 +1237,15 @@ __device__ __forceinline__ void window_point(f32x4 (&acc)[U], const unsigned cha
     }
 }
 
-template <int U, int VC, int NT>
+// LPP lanes per point in phase B: 32 (U vectors per lane, 512 bytes apart, slices of 512*U bytes) or 16 (U == 1: two
+// vectors per lane 256 bytes apart inside the 512-byte slice, four points per wave instruction)
+template <int U, int VC, int NT, int LPP>
 __device__ __forceinline__ void fused_eval_window_body(const EvalParams &P)
 {
     using VT = f32x4;
+    static_assert(LPP == 32 || (LPP == 16 && U == 1), "16 lanes per point only with 512-byte slices");
+    constexpr int NV = U * (32 / LPP);                 // vectors per lane
+    constexpr int VS = 16 * LPP;                       // bytes between a lane's vectors
     extern __shared__ __align__(16) unsigned char smem[];
     const int V = P.V;
     const int TP = P.tile_pts;
@@ -1486,7 +1492,7 @@ __device__ __forceinline__ void fused_eval_window_body(const EvalParams &P)
 
     // ---- 4. phase B per slice: 32 lanes per point ----
     const MapDesc &m = m0;
-    const int l = threadIdx.x & 31, grp = threadIdx.x >> 5;
+    const int l = threadIdx.x & (LPP - 1), grp = threadIdx.x / LPP;
     const uint32_t lane_off = (uint32_t)l * 16u;
     const char *__restrict__ data = reinterpret_cast<const char *>(m.data);
     const int S = P.win_slices;
@@ -1499,15 +1505,15 @@ __device__ __forceinline__ void fused_eval_window_body(const EvalParams &P)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();                            // records (first slice) and pool are complete
         const uint32_t co = (uint32_t)sl * SB + lane_off;               // byte offset of this lane's first vector in a texel
-        for (int p = grp; p < TP; p += NT / 32) {
+        for (int p = grp; p < TP; p += NT / LPP) {
             const int64_t i = idx_s[p];
             const uint32_t fl = flag_s[p];
             const bool strict = (fl & kWinStrict) != 0u;
-            VT acc[U];
+            VT acc[NV];
 #pragma unroll
-            for (int u = 0; u < U; ++u) acc[u] = (VT)0.0f;
+            for (int u = 0; u < NV; ++u) acc[u] = (VT)0.0f;
             if (fl == 0u) {
-                window_point<U, VC>(acc, smem, wrec + p * V, V, lane_off);
+                window_point<NV, VC, VS, (int)SB>(acc, smem, wrec + p * V, V, lane_off);
             } else if (!strict) {
                 // some pair of this point is gathered from global memory (fast arithmetic, zeroed weights)
                 for (int v = 0; v < V; ++v) {
@@ -1516,9 +1522,9 @@ __device__ __forceinline__ void fused_eval_window_body(const EvalParams &P)
                         const unsigned char *nw = smem + (wr.nw + lane_off);
                         const unsigned char *sw = nw + wr.row;
 #pragma unroll
-                        for (int u = 0; u < U; ++u) {
-                            const VT a = *reinterpret_cast<const VT *>(nw + u * 512), b = *reinterpret_cast<const VT *>(nw + (U + u) * 512);
-                            const VT d = *reinterpret_cast<const VT *>(sw + u * 512), e = *reinterpret_cast<const VT *>(sw + (U + u) * 512);
+                        for (int u = 0; u < NV; ++u) {
+                            const VT a = *reinterpret_cast<const VT *>(nw + u * VS), b = *reinterpret_cast<const VT *>(nw + SB + u * VS);
+                            const VT d = *reinterpret_cast<const VT *>(sw + u * VS), e = *reinterpret_cast<const VT *>(sw + SB + u * VS);
                             VT s_ = a * wr.w[0];
                             s_ = v_fma<VT>(b, wr.w[1], s_);
                             s_ = v_fma<VT>(d, wr.w[2], s_);
@@ -1530,8 +1536,8 @@ __device__ __forceinline__ void fused_eval_window_body(const EvalParams &P)
                         const char *bv = data + (int64_t)v * m.sv * 4;
                         const float w0 = c.inw ? c.wnw : 0.0f, w1 = c.ine ? c.wne : 0.0f, w2 = c.isw ? c.wsw : 0.0f, w3 = c.ise ? c.wse : 0.0f;
 #pragma unroll
-                        for (int u = 0; u < U; ++u) {
-                            const uint32_t cu = co + (uint32_t)u * 512u;
+                        for (int u = 0; u < NV; ++u) {
+                            const uint32_t cu = co + (uint32_t)u * (uint32_t)VS;
                             const VT a = load_texel<4, false>(bv + (c.onw + cu)), b = load_texel<4, false>(bv + (c.one + cu));
                             const VT d = load_texel<4, false>(bv + (c.osw + cu)), e = load_texel<4, false>(bv + (c.ose + cu));
                             VT s_ = a * w0;
@@ -1548,8 +1554,8 @@ __device__ __forceinline__ void fused_eval_window_body(const EvalParams &P)
                     const char *bv = data + (int64_t)v * m.sv * 4;
                     const Corner c = corner_setup(m, wr.w[0], wr.w[1]);
 #pragma unroll
-                    for (int u = 0; u < U; ++u) {
-                        const uint32_t cu = co + (uint32_t)u * 512u;
+                    for (int u = 0; u < NV; ++u) {
+                        const uint32_t cu = co + (uint32_t)u * (uint32_t)VS;
                         const VT a = load_texel<4, false>(bv + (c.onw + cu)), b = load_texel<4, false>(bv + (c.one + cu));
                         const VT d = load_texel<4, false>(bv + (c.osw + cu)), e = load_texel<4, false>(bv + (c.ose + cu));
                         const VT av = c.inw ? a : (VT)0.0f, bvv = c.ine ? b : (VT)0.0f, dv = c.isw ? d : (VT)0.0f, ev = c.ise ? e : (VT)0.0f;
@@ -1563,7 +1569,7 @@ __device__ __forceinline__ void fused_eval_window_body(const EvalParams &P)
             }
             const float rcp_d = aux_s[2 * p], denom = aux_s[2 * p + 1];
 #pragma unroll
-            for (int u = 0; u < U; ++u) {
+            for (int u = 0; u < NV; ++u) {
                 VT o;
                 if (strict) {
                     o = (VT)0.0f;                                          // fusion.py:386 when no view is valid
@@ -1575,8 +1581,8 @@ __device__ __forceinline__ void fused_eval_window_body(const EvalParams &P)
                     q = v_fma<VT>(v_fma<VT>(q, -denom, acc[u]), rcp_d, q);
                     o = q;
                 }
-                if (out32) store_out_off(m.out, (uint32_t)i * (uint32_t)(m.C * 4) + co + (uint32_t)u * 512u, o, P.store_policy);
-                else store_out<VT>(m.out + i * m.C + ((co + (uint32_t)u * 512u) >> 2), o, P.store_policy);
+                if (out32) store_out_off(m.out, (uint32_t)i * (uint32_t)(m.C * 4) + co + (uint32_t)u * (uint32_t)VS, o, P.store_policy);
+                else store_out<VT>(m.out + i * m.C + ((co + (uint32_t)u * (uint32_t)VS) >> 2), o, P.store_policy);
             }
         }
     }
@@ -1594,8 +1600,8 @@ __device__ __forceinline__ void fused_eval_window_body(const EvalParams &P)
 
 // (NT lanes per workgroup: 512 lanes over the same 64-point brick -- twice the waves per pool -- measured no faster
 // at 2, 3 or 4 workgroups per CU: 0.58-0.71 ms on C2 patch against 0.58; only the 256-lane form is built)
-template <int U, int VC, int WAVES, int NT = kBlock>
-__global__ __launch_bounds__(NT, WAVES) void fused_eval_window_kernel(const EvalParams P) { fused_eval_window_body<U, VC, NT>(P); }
+template <int U, int VC, int WAVES, int NT = kBlock, int LPP = 32>
+__global__ __launch_bounds__(NT, WAVES) void fused_eval_window_kernel(const EvalParams P) { fused_eval_window_body<U, VC, NT, LPP>(P); }
 
 // Three entry points over one body: the plain kernel (<= 3 channel vectors per lane) is held to 128 VGPRs
 // = 4 waves per SIMD -- the gather lives on memory-level parallelism; the WIDE variant adds the 4-vector
@@ -1647,23 +1653,25 @@ hipError_t launch_fused_eval(const EvalParams &P, int mode, hipStream_t stream)
         const size_t lds_w = (size_t)P.win_pool_offset + (size_t)(2 + P.win_pool_texels) * 512 * P.win_u;
         dim3 gw((unsigned)((P.n + P.tile_pts - 1) / P.tile_pts));
         if (P.walk_nx > 0) gw = dim3((unsigned)ntiles);
-#define D3F_WIN_LAUNCH(U_, VC_, W_, NT_)                                                                                       \
+#define D3F_WIN_LAUNCH(U_, VC_, W_, LPP_)                                                                                      \
         do {                                                                                                                       \
             if (lds_w > 64 * 1024) {                                                                                               \
-                hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void *>(&fused_eval_window_kernel<U_, VC_, W_, NT_>),   \
+                hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void *>(&fused_eval_window_kernel<U_, VC_, W_, kBlock, LPP_>), \
                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_w);                      \
                 if (ea != hipSuccess) return ea;                                                                                   \
             }                                                                                                                      \
-            hipLaunchKernelGGL((fused_eval_window_kernel<U_, VC_, W_, NT_>), gw, dim3(NT_), lds_w, stream, P);                     \
+            hipLaunchKernelGGL((fused_eval_window_kernel<U_, VC_, W_, kBlock, LPP_>), gw, block, lds_w, stream, P);                \
         } while (0)
-        if (P.win_u == 1 && P.win_occ >= 4) D3F_WIN_LAUNCH(1, 4, 4, 256);
-        else if (P.win_u == 1 && P.win_occ == 3) D3F_WIN_LAUNCH(1, 4, 3, 256);
-        else if (P.win_u == 1) D3F_WIN_LAUNCH(1, 4, 2, 256);
-        else if (P.win_u == 2 && P.win_vc == 2) D3F_WIN_LAUNCH(2, 2, 2, 256);
-        else if (P.win_u == 2) D3F_WIN_LAUNCH(2, 1, 2, 256);
-        else if (P.win_u == 3 && P.win_vc == 2) D3F_WIN_LAUNCH(3, 2, 2, 256);
-        else if (P.win_u == 3) D3F_WIN_LAUNCH(3, 1, 2, 256);
-        else D3F_WIN_LAUNCH(4, 1, 2, 256);
+        if (P.win_u == 1 && P.win_lpp == 16 && P.win_occ >= 4) D3F_WIN_LAUNCH(1, 2, 4, 16);
+        else if (P.win_u == 1 && P.win_lpp == 16) D3F_WIN_LAUNCH(1, 2, 3, 16);
+        else if (P.win_u == 1 && P.win_occ >= 4) D3F_WIN_LAUNCH(1, 4, 4, 32);
+        else if (P.win_u == 1 && P.win_occ == 3) D3F_WIN_LAUNCH(1, 4, 3, 32);
+        else if (P.win_u == 1) D3F_WIN_LAUNCH(1, 4, 2, 32);
+        else if (P.win_u == 2 && P.win_vc == 2) D3F_WIN_LAUNCH(2, 2, 2, 32);
+        else if (P.win_u == 2) D3F_WIN_LAUNCH(2, 1, 2, 32);
+        else if (P.win_u == 3 && P.win_vc == 2) D3F_WIN_LAUNCH(3, 2, 2, 32);
+        else if (P.win_u == 3) D3F_WIN_LAUNCH(3, 1, 2, 32);
+        else D3F_WIN_LAUNCH(4, 1, 2, 32);
 #undef D3F_WIN_LAUNCH
         return hipGetLastError();
     }

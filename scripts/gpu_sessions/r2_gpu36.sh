@@ -1,0 +1,24 @@
+#!/bin/bash
+set -u
+REPO=$(pwd); OUT=$REPO/gpurun_out/r3h; mkdir -p $OUT
+export TMPDIR=/tmp
+timeout -k 5 600 env D3F_EXP_WINDOW_LPP=16 python -m pytest tests/test_gpu_walks.py -m gpu -q -x -k "window or bench_workload" > $OUT/pytest.log 2>&1; echo "pytest(lpp16) rc=$?" | tee -a $OUT/pytest.log; tail -3 $OUT/pytest.log
+B="python $REPO/bench.py --no-cpu-baseline --steps 20"
+run() { TAG=$1; WL=$2; shift 2; env "$@" timeout -k 5 300 $B --workload $WL > $OUT/bench_${WL}_$TAG.json 2>$OUT/bench_${WL}_$TAG.err; }
+for WL in c2_patch c3_patch; do
+  run lpp32 $WL D3F_EXP_WINDOW_LPP=32
+  run lpp16 $WL D3F_EXP_WINDOW_LPP=16
+  run lpp16o3 $WL D3F_EXP_WINDOW_LPP=16 D3F_EXP_WINDOW_OCC=3
+  run lpp32b $WL D3F_EXP_WINDOW_LPP=32
+  run lpp16b $WL D3F_EXP_WINDOW_LPP=16
+done
+for f in $OUT/bench_*.json; do echo "$(basename $f .json): $(python - "$f" <<'PY'
+import json,sys
+try:
+    t=[l for l in open(sys.argv[1]) if l.startswith('{')][-1]; d=json.loads(t)
+    r=d["roofline"]
+    print("step %.3f ms | kernel %.3f ms (min %.3f) | frac %.3f | verified %s | %s" % (d["ms_per_step"], r["kernel_ms_avg"], r["kernel_ms_min"], r["frac"], d.get("verified"), r["kernel"]))
+except Exception as e:
+    print("ERR", e, open(sys.argv[1]).read()[-300:])
+PY
+)"; done

@@ -176,7 +176,7 @@ def test_validation_of_topk_and_lattice_entry_points():
     patch = (_lib.ChannelMap * 1)(_lib.ChannelMap(1 << 20, 48, 64, 384, 0, 48 * 64 * 384, 64 * 384, 384))
     assert lib.d3f_eval_plan_query_lattice(ctypes.byref(v), 160, 140, 44, patch, 1, _lib.FLAG_FINITE_MAPS, 0, ctypes.byref(plan)) == 0
     # a patch-resolution wide map on a lattice: 4 x 4 x 4 bricks through LDS texel windows, 4 workgroups per CU
-    assert (plan.reorder, plan.staged[0], plan.tile_points, plan.reserved, plan.workgroups) == (2, 3, 64, 2144, 40 * 35 * 11)
+    assert (plan.reorder, plan.staged[0], plan.tile_points, plan.reserved, plan.workgroups) == (2, 3, 64, 2124, 40 * 35 * 11)
     assert lib.d3f_eval_plan_query(ctypes.byref(v), 985600, patch, 1, _lib.FLAG_FINITE_MAPS, 1, 0, ctypes.byref(plan)) == 0
     # the same map without lattice dims (a cloud in caller order): the cell-run gather
     assert plan.reorder == 0 and plan.staged[0] == 16 + 4 and plan.tile_points == 64 and plan.lanes_per_point[0] == 32
@@ -273,7 +273,7 @@ def test_window_launch_plan(monkeypatch):
     assert plan_lattice(4, (160, 140, 44), [(48, 64, 384)]).staged[0] == 16 + 4      # switched off: cell runs, caller order
     monkeypatch.setenv("D3F_EXP_WINDOW", "64")
     p = plan_lattice(4, (160, 140, 44), [(48, 64, 384), (480, 640, 8)])
-    assert (p.staged[0], p.tile_points, p.reorder, p.workgroups, p.reserved) == (3, 64, 2, 40 * 35 * 11, 2144)
+    assert (p.staged[0], p.tile_points, p.reorder, p.workgroups, p.reserved) == (3, 64, 2, 40 * 35 * 11, 2124)
     assert p.lds_bytes <= 160 * 1024 // 4
     monkeypatch.setenv("D3F_EXP_WINDOW_U", "3")
     p = plan_lattice(4, (160, 140, 44), [(48, 64, 384)])
@@ -287,4 +287,4 @@ def test_window_launch_plan(monkeypatch):
     assert (p.staged[0], p.reorder, p.workgroups) == (3, 1, 15625)                       # clouds: 64 consecutive points of the Morton order
     monkeypatch.setenv("D3F_EXP_WINDOW", "128")
     p = _plan(8, 720, 1280, 1000000, [(72, 128, 1024)], flags=_lib.FLAG_FINITE_MAPS | _lib.FLAG_UNORDERED_POINTS)
-    assert p.staged[0] == 3 and p.reserved == 2143 and p.lds_bytes <= 160 * 1024 // 3    # 32 KB of records for 128 x 8 pairs: 3 workgroups per CU
+    assert p.staged[0] == 3 and p.reserved == 2123 and p.lds_bytes <= 160 * 1024 // 3    # 32 KB of records for 128 x 8 pairs: 3 workgroups per CU
