@@ -331,6 +331,38 @@ def test_window_gather_is_bit_identical(dev, C, V, fhw, mask, points):
     assert rel_err(cpu(outs["T64 U1"]["dino_feats"])[pick], ref["sets"][0]) <= TOL
 
 
+def test_window_kernel_with_wrong_lattice_dims_is_still_exact(dev):
+    """d3f_eval_lattice promises that ANY dims whose product is n are correct.  The window kernel estimates its texel
+    windows from the eight 'corner' slots of a brick -- meaningless for a cloud or a shuffled grid passed with made-up
+    dims -- and every pair is checked against its window, so such launches must still be bit-identical to the direct
+    gather (they only lose the windows)."""
+    from d3fields_amd import create_init_grid, synth
+    V, H, W, C = 4, 480, 640, 384
+    maps = {"dino_feats": synth.random_map(V, 48, 64, C, seed=1, device=dev), "mask": synth.random_onehot_mask(V, H, W, 8, seed=2, device=dev)}
+    names = ["dino_feats", "mask"]
+    f, sc = fusion_for(dev, V, H, W, maps)
+    f.cache_point_order = True                                                         # _launch asks _lattice_dims
+    grid, shape = create_init_grid(synth.WORK_BOX, 0.0107)
+    nx, ny, nz = (int(v) for v in shape)
+    n = nx * ny * nz
+    assert grid.shape[0] == n and n >= 65536
+    cases = [(synth.random_cloud(n, seed=4), (nx, ny, nz)),                            # a cloud with a grid's dims
+             (grid[torch.randperm(n, generator=torch.Generator().manual_seed(1))], (nx, ny, nz)),   # shuffled grid
+             (grid, (nz, ny, nx)), (grid, (n, 1, 1)), (grid, (1, 1, n)), (grid, (nx * ny, 1, nz))]  # wrong factorizations
+    for pts_c, dims in cases:
+        pts = pts_c.to(dev)
+        with torch.no_grad():
+            f._lattice_dims = lambda p, st: None
+            with knobs(D3F_EXP_RUNS=-1):
+                ref = f.batch_eval(pts, return_names=names)
+            f._lattice_dims = lambda p, st, d=dims: d
+            f.record_plans = True
+            out = f.batch_eval(pts, return_names=names)
+            assert "window" in f.last_plan()["kernel"], f.last_plan()
+        for k in ref:
+            assert torch.equal(out[k], ref[k]), (dims, k)
+
+
 def test_async_probes_follow_the_data_and_never_change_results(dev):
     """Without the per-tensor cache (bench.py's mode) the shim launches on the verdict of the last FINISHED probes of a
     query of the same size and refreshes it asynchronously: a cloud that follows a grid of the same size is walked with
