@@ -363,6 +363,27 @@ def test_window_kernel_with_wrong_lattice_dims_is_still_exact(dev):
             assert torch.equal(out[k], ref[k]), (dims, k)
 
 
+def test_window_kernel_above_4_gib_of_output(dev):
+    """2.99 M lattice points x 384 channels = 4.6 GB of fused rows: the window kernel's 32-bit store offsets must give way
+    to 64-bit addressing (and the 1.9 M-point workloads below 4 GiB use the 32-bit form: test_bench_workload_matches_oracle)."""
+    from d3fields_amd import create_init_grid, synth
+    V, H, W, C = 4, 480, 640, 384
+    maps = {"dino_feats": synth.random_map(V, 48, 64, C, seed=1, device=dev)}
+    f, sc = fusion_for(dev, V, H, W, maps)
+    grid, shape = create_init_grid(box_for(144, 144, 144, 0.004), 0.004)
+    assert tuple(int(v) for v in shape) == (144, 144, 144) and grid.shape[0] * C * 4 > (1 << 32)
+    pts = grid.to(dev)
+    with torch.no_grad():
+        f.record_plans = True
+        out = f.batch_eval(pts, return_names=["dino_feats"])
+        assert "window" in f.last_plan()["kernel"]
+        with knobs(D3F_EXP_WINDOW=-1, D3F_EXP_RUNS=-1):
+            ref = f.batch_eval(pts, return_names=["dino_feats"])
+    for k in ref:
+        assert torch.equal(out[k], ref[k]), k
+    assert float(out["dino_feats"][-1].abs().sum()) >= 0.0 and bool(out["valid_mask"].any())
+
+
 def test_async_probes_follow_the_data_and_never_change_results(dev):
     """Without the per-tensor cache (bench.py's mode) the shim launches on the verdict of the last FINISHED probes of a
     query of the same size and refreshes it asynchronously: a cloud that follows a grid of the same size is walked with
