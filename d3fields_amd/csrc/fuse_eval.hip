@@ -1144,16 +1144,21 @@ __global__ __launch_bounds__(kBlock, WAVES) void fused_eval_sliced_kernel(const 
 //      texel rectangle they span is the view's window (a projective map sends the box into the convex hull of its
 //      projected corners);
 //   2. phase A, one lane per (point, view) with the views of a point in adjacent lanes: the per-point sums over the
-//      views are rebuilt in view order with wave shuffles (no second pass); besides the 16-byte view record it writes a
-//      32-byte window record: LDS offset of the nw corner, row pitch, weight of the view, the four bilinear weights.
+//      views are rebuilt in view order with wave shuffles (no second pass); it writes a 32-byte window record per
+//      pair: LDS offset of the nw corner, row pitch, weight and validity of the view, the four bilinear weights (the
+//      16-byte view records of the other kernels only when thin maps ride along), and per point the refined reciprocal
+//      of the shared-divisor division.
 //      Every corner is CHECKED against the window -- a pair whose corners are not all inside the map and the window
 //      (rounding at the rim, an overflowing pool, a box behind the camera, the image border) is marked direct and
 //      gathered from global memory as before, so the result never depends on step 1 being right;
 //   3. per channel slice of 128*U channels: the windows' texel slices are copied global -> LDS by the DMA path
-//      (global_load_lds_dwordx4: no registers, no ds_write), then 32 lanes per point read records and corners with
+//      (global_load_lds_dwordx4: no registers, no ds_write; the source offset of every pool slot is tabulated once
+//      per workgroup), then 16 lanes x two vectors per point (32 x U with wider slices) read records and corners with
 //      ds_read_b128 and run the arithmetic of gather_map (same operands, same order: bit-identical results).  Invalid
 //      pairs point at an all-zero texel with zero weights (exact skip); strict points take the strict
 //      form on global loads.
+// XCD k takes the k-th contiguous eighth of the bricks (window copies are then L2 hits left by the neighbours).
+// Measured history, counters and the variants that lost: DESIGN.md 5.5.
 // Slots of a clipped brick (or of the last, short tile of a cloud) repeat a neighbouring point: same inputs, same
 // outputs, written twice.
 constexpr uint32_t kWinDirect = 0xffffffffu;
