@@ -216,7 +216,7 @@ def test_cell_run_gather_not_used_when_it_must_not(dev):
 @pytest.mark.parametrize("workload", ["c2_dense", "c3_dense", "c2_patch", "c3_patch"])
 def test_bench_workload_matches_oracle(dev, workload):
     """Exactly what bench.py times (same builder, same launch geometry: lattice walk with 8- / 16-point tiles on the
-    dense maps, cell runs on the patch-resolution maps) against the CPU oracle on a 3000-point sample, plus
+    dense maps, bricks through LDS texel windows on the patch-resolution maps) against the CPU oracle on a 3000-point sample, plus
     bit-identity with the caller-order direct gather on 200 000 points."""
     import bench
     from d3fields_amd import _lib
