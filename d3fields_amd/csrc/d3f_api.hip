@@ -271,6 +271,22 @@ int eval_common(const d3f_views *views, const float *pts, int64_t n, const d3f_c
                       P.maps[s], map_bytes, flags);
         if (rc != D3F_OK) return rc;
     }
+    // The channel-sliced and the LDS-window kernels want THE wide map first (the thin ones ride along).  A map descriptor
+    // carries its own output pointers, so the launch may take the maps in any order: return_names=['mask', 'dino_feats']
+    // gets the same kernels as the reference's default ['dino_feats', 'mask'].  caller_map[k] = caller's index of P.maps[k].
+    int caller_map[D3F_MAX_MAPS];
+    bool want_inter[D3F_MAX_MAPS];
+    for (int s = 0; s < D3F_MAX_MAPS; ++s) { caller_map[s] = s; want_inter[s] = false; }
+    {
+        int wide = -1, nwide = 0;
+        for (int s = 0; s < n_maps; ++s)
+            if ((int64_t)P.maps[s].C * P.maps[s].esize > 256) { if (wide < 0) wide = s; ++nwide; }
+        if (nwide == 1 && wide > 0) {
+            const d3f::MapDesc t = P.maps[0]; P.maps[0] = P.maps[wide]; P.maps[wide] = t;
+            caller_map[0] = wide; caller_map[wide] = 0;
+        }
+        for (int s = 0; s < n_maps; ++s) want_inter[s] = out_inter && out_inter[caller_map[s]];
+    }
     // Morton point order (performance only) when scratch is supplied and the maps exceed the L2s
     hipStream_t hs = static_cast<hipStream_t>(stream);
     const bool may_reorder = (workspace || plan_only) && !grid && n_maps > 0 && n <= 0x7fffffffLL && !(flags & D3F_TUNE_NO_REORDER) &&
@@ -294,7 +310,7 @@ int eval_common(const d3f_views *views, const float *pts, int64_t n, const d3f_c
                  n <= 0x7fffffffLL && tl == 0 && views->V <= 8 && runs_candidate(P.maps[0], views->H, views->W) &&
                  P.maps[0].C % 128 == 0 && (int64_t)views->V * P.maps[0].sv * 4 < (1LL << 31) && (P.maps[0].sx % 4) == 0 && (P.maps[0].sy % 4) == 0 && (P.maps[0].sv % 4) == 0 &&
                  (!plan_only ? (reinterpret_cast<uintptr_t>(P.maps[0].data) % 16 == 0) : true);
-        for (int s = 0; s < n_maps; ++s) window = window && !(out_inter && out_inter[s]);
+        for (int s = 0; s < n_maps; ++s) window = window && !want_inter[s];
         for (int s = 1; s < n_maps; ++s) window = window && P.maps[s].esize == 4 && P.maps[s].C * 4 <= 256;
         if (window) {
             const int T = (win_knob == 32 || win_knob == 64 || win_knob == 128) ? win_knob : 64;
@@ -329,7 +345,7 @@ int eval_common(const d3f_views *views, const float *pts, int64_t n, const d3f_c
         const int knob = exp_knob("D3F_EXP_RUNS");
         bool blocked = window || knob < 0 || !(flags & D3F_FLAG_FINITE_MAPS) || stage_any || n < 65536 || tl != 0;
         for (int s = 0; s < n_maps; ++s)
-            blocked |= P.maps[s].esize == 2 || (out_inter && out_inter[s]) ||
+            blocked |= P.maps[s].esize == 2 || want_inter[s] ||
                        (P.maps[s].unroll == -4 && !runs_candidate(P.maps[s], views->H, views->W));
         // one cell-run map per launch (phase A keeps one "same cell as the previous point" flag per (point, view))
         for (int s = 0; s < n_maps && !blocked && !any_runs; ++s)
@@ -440,11 +456,11 @@ int eval_common(const d3f_views *views, const float *pts, int64_t n, const d3f_c
         const bool automatic = sl == 0 && thin_rest && n_maps >= 1 && P.maps[0].C % 128 == 0 && P.maps[0].C <= 512;
         if (automatic) sl = 3;
         bool ok = walk && !window && (sl >= 1 && sl <= 3) && mode == 0 && n_maps >= 1 && P.maps[0].esize == 4 && P.maps[0].vw == 4 &&
-                  !(out_inter && out_inter[0]) && tl == 0;
+                  !want_inter[0] && tl == 0;
         const int lg = sl + 2, lanes = 1 << lg;      // 1: 8 lanes (128-byte slices), 2: 16 lanes, 3: 32 lanes (512 bytes)
         P.sl_vc = exp_knob("D3F_EXP_SLICED_VC") > 0 ? exp_knob("D3F_EXP_SLICED_VC") : (automatic ? 2 : 4);
         ok = ok && P.maps[0].C % (4 * lanes) == 0 && P.maps[0].C >= 128;
-        for (int s = 1; s < n_maps && ok; ++s) ok = P.maps[s].C * P.maps[s].esize <= 256 && !(out_inter && out_inter[s]) && P.maps[s].esize == 4;
+        for (int s = 1; s < n_maps && ok; ++s) ok = P.maps[s].C * P.maps[s].esize <= 256 && !want_inter[s] && P.maps[s].esize == 4;
         if (ok) {
             P.walk_tx = P.walk_ty = P.walk_tz = 2;
             P.sl_lg = lg;
@@ -485,7 +501,7 @@ int eval_common(const d3f_views *views, const float *pts, int64_t n, const d3f_c
         for (int s = 0; s < n_maps && P.n_pre < 2; ++s) {
             // 32 B per (point, view) and map: only while records + set-ups stay within 48 KiB (>= 3 workgroups per CU)
             const long lds_after = (long)P.stage_offset + P.stage_floats * 8 + (long)(P.n_pre + 1) * P.tile_pts * views->V * 32;
-            if (P.maps[s].pre_slot < 0 && !P.maps[s].staged && P.maps[s].lpp_log2 >= 4 && !(out_inter && out_inter[s]) && lds_after <= 48 * 1024)
+            if (P.maps[s].pre_slot < 0 && !P.maps[s].staged && P.maps[s].lpp_log2 >= 4 && !want_inter[s] && lds_after <= 48 * 1024)
                 P.maps[s].pre_slot = P.n_pre++;
         }
     P.crec_offset = P.stage_offset + P.stage_floats * 8;
@@ -511,10 +527,11 @@ int eval_common(const d3f_views *views, const float *pts, int64_t n, const d3f_c
             }
         for (int s = 0; s < D3F_MAX_MAPS; ++s) {
             const bool on = s < n_maps;
-            plan_out->vector_floats[s] = on ? P.maps[s].vw : 0;
-            plan_out->lanes_per_point[s] = on ? ((P.win_slices > 0 && s == 0) ? P.win_lpp : (1 << P.maps[s].lpp_log2)) : 0;
-            plan_out->vectors_per_lane[s] = on ? ((P.win_slices > 0 && s == 0) ? P.win_u * (32 / P.win_lpp) : P.maps[s].unroll) : 0;   /* negative: load-use per vector */
-            plan_out->staged[s] = on ? (P.win_slices > 0 && s == 0 ? 3 : (P.maps[s].runs > 0 ? 16 + P.maps[s].runs : P.maps[s].staged)) : 0;
+            const int c = on ? caller_map[s] : s;         // reported in the caller's map order
+            plan_out->vector_floats[c] = on ? P.maps[s].vw : 0;
+            plan_out->lanes_per_point[c] = on ? ((P.win_slices > 0 && s == 0) ? P.win_lpp : (1 << P.maps[s].lpp_log2)) : 0;
+            plan_out->vectors_per_lane[c] = on ? ((P.win_slices > 0 && s == 0) ? P.win_u * (32 / P.win_lpp) : P.maps[s].unroll) : 0;   /* negative: load-use per vector */
+            plan_out->staged[c] = on ? (P.win_slices > 0 && s == 0 ? 3 : (P.maps[s].runs > 0 ? 16 + P.maps[s].runs : P.maps[s].staged)) : 0;
         }
         return D3F_OK;
     }

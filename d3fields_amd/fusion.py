@@ -419,7 +419,8 @@ class Fusion:
         window = plan.reserved >= 2000
         if window:
             r = plan.reserved - 2000
-            kernel = "fused_eval_window_kernel<%d, %d, %d, 256, %d>" % (r // 100, r // 10 % 10, r % 10, plan.lanes_per_point[0])
+            w0 = [s for s in range(n_maps) if plan.staged[s] == 3][0]           # the windowed map (any position in the call)
+            kernel = "fused_eval_window_kernel<%d, %d, %d, 256, %d>" % (r // 100, r // 10 % 10, r % 10, plan.lanes_per_point[w0])
         elif plan.reserved >= 100:
             lg, vc = (plan.reserved - 100) // 10, (plan.reserved - 100) % 10
             kernel = "fused_eval_sliced_kernel<%d, %d, %d>" % (lg, vc, {1: 8, 2: 7, 4: 5}.get(vc, 5))

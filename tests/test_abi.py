@@ -269,6 +269,12 @@ def test_window_launch_plan(monkeypatch):
 
     p = plan_lattice(4, (160, 140, 44), [(48, 64, 384)])
     assert p.staged[0] == 3 and p.tile_points == 64                 # default on a lattice
+    # the wide map need not come first in the call (return_names=['mask', 'dino_feats']): same launch, reported in caller order
+    p = plan_lattice(4, (160, 140, 44), [(480, 640, 8), (48, 64, 384)])
+    assert (p.staged[0], p.staged[1], p.lanes_per_point[0], p.lanes_per_point[1], p.reserved) == (0, 3, 2, 16, 2124)
+    big_first = plan_lattice(4, (200, 175, 55), [(480, 640, 384), (480, 640, 8)])
+    big_last = plan_lattice(4, (200, 175, 55), [(480, 640, 8), (480, 640, 384)])
+    assert big_first.reserved == big_last.reserved == 152 and big_first.workgroups == big_last.workgroups
     monkeypatch.setenv("D3F_EXP_WINDOW", "-1")
     assert plan_lattice(4, (160, 140, 44), [(48, 64, 384)]).staged[0] == 16 + 4      # switched off: cell runs, caller order
     monkeypatch.setenv("D3F_EXP_WINDOW", "64")

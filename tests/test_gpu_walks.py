@@ -363,6 +363,28 @@ def test_window_kernel_with_wrong_lattice_dims_is_still_exact(dev):
             assert torch.equal(out[k], ref[k]), (dims, k)
 
 
+def test_map_order_in_the_call_does_not_matter(dev):
+    """return_names=['mask', 'dino_feats'] gets the launch of ['dino_feats', 'mask'] (the library moves the wide map to the
+    front for the window / channel-sliced kernels) and the same bits, on a patch-resolution and on a dense feature map."""
+    from d3fields_amd import create_init_grid, synth
+    V, H, W, C = 4, 480, 640, 384
+    for fhw in ((48, 64), (240, 320)):
+        maps = {"dino_feats": synth.random_map(V, fhw[0], fhw[1], C, seed=1, device=dev),
+                "mask": synth.random_onehot_mask(V, H, W, 8, seed=2, device=dev),
+                "color_tensor": synth.random_map(V, H, W, 3, seed=5, device=dev)}
+        f, sc = fusion_for(dev, V, H, W, maps)
+        pts = create_init_grid(synth.WORK_BOX, 0.0107)[0].to(dev)
+        with torch.no_grad():
+            f.record_plans = True
+            a = f.batch_eval(pts, return_names=["dino_feats", "mask", "color_tensor"])
+            ka = f.last_plan()["kernel"]
+            b = f.batch_eval(pts, return_names=["color_tensor", "mask", "dino_feats"])
+            kb = f.last_plan()["kernel"]
+        assert ka == kb and ("window" in ka or "sliced" in ka), (ka, kb)
+        for k in a:
+            assert torch.equal(a[k], b[k]), (fhw, k)
+
+
 def test_window_kernel_above_4_gib_of_output(dev):
     """2.99 M lattice points x 384 channels = 4.6 GB of fused rows: the window kernel's 32-bit store offsets must give way
     to 64-bit addressing (and the 1.9 M-point workloads below 4 GiB use the 32-bit form: test_bench_workload_matches_oracle)."""
