@@ -1273,7 +1273,7 @@ __device__ __forceinline__ void fused_eval_window_body(const EvalParams &P)
 
     const bool walk = P.walk_nx > 0;
     const MapDesc &m0 = P.maps[0];
-    // the set of points: a brick of the lattice (blockIdx = (z, y, x) brick coordinates) or tile_pts consecutive points
+    // the set of points: a brick of the lattice (bricks numbered z fastest) or tile_pts consecutive points
     // (XCD k = blockIdx % 8 takes the k-th contiguous eighth of the bricks, z fastest: the ~128 workgroups an XCD has in
     // flight are neighbours, so the window copies of one are L2 hits left behind by the others)
     const int lbz = __ffs(P.walk_tz) - 1, lby = __ffs(P.walk_ty) - 1;
@@ -1472,6 +1472,7 @@ __device__ __forceinline__ void fused_eval_window_body(const EvalParams &P)
                 cnt = cnt + __shfl(valid, base + vv, 64);
                 stp |= (uint32_t)__shfl((int)st, base + vv, 64);
             }
+            if (!(P.flags & kFlagFiniteMaps)) stp |= kWinStrict;               // (the host only picks this kernel for finite maps)
             if (v < V) {
                 if (stp & kWinStrict) { wr.nw = kWinDirect; wr.w[0] = gx; wr.w[1] = gy; }     // strict point: every pair from global
                 wrec[p * V + v] = wr;
@@ -1484,7 +1485,6 @@ __device__ __forceinline__ void fused_eval_window_body(const EvalParams &P)
                 P.out_valid[i] = all_invalid ? 0 : 1;
                 cnt_s[p] = cnt;
                 idx_s[p] = (uint32_t)i;
-                if (!(P.flags & kFlagFiniteMaps)) stp |= kWinStrict;
                 flag_s[p] = stp;
                 // the shared reciprocal of the fast division (gather_map), once per point instead of once per slice
                 const float denom = cnt + 1e-6f;
@@ -1495,7 +1495,7 @@ __device__ __forceinline__ void fused_eval_window_body(const EvalParams &P)
         }
     }
 
-    // ---- 4. phase B per slice: 32 lanes per point ----
+    // ---- 4. phase B per slice: LPP lanes per point ----
     const MapDesc &m = m0;
     const int l = threadIdx.x & (LPP - 1), grp = threadIdx.x / LPP;
     const uint32_t lane_off = (uint32_t)l * 16u;
