@@ -385,6 +385,33 @@ def test_map_order_in_the_call_does_not_matter(dev):
             assert torch.equal(a[k], b[k]), (fhw, k)
 
 
+def test_window_kernel_in_grid_mode(dev):
+    """Fusion.eval_grid (axis arrays instead of a point tensor, d3f_eval_grid) takes the window kernel too for a
+    patch-resolution wide map; bits equal batch_eval of the materialised grid with windows and cell runs switched off."""
+    from d3fields_amd import create_init_grid, synth
+    V, H, W, C = 4, 480, 640, 384
+    maps = {"dino_feats": synth.random_map(V, 48, 64, C, seed=1, device=dev), "mask": synth.random_onehot_mask(V, H, W, 8, seed=2, device=dev)}
+    f, sc = fusion_for(dev, V, H, W, maps)
+    box, step = synth.WORK_BOX, 0.0107
+    with torch.no_grad():
+        a = f.eval_grid(box, step, return_names=["dino_feats", "mask"])
+        grid, shape = create_init_grid(box, step)
+        assert tuple(a["grid_shape"]) == tuple(shape) and grid.shape[0] >= 65536
+        with knobs(D3F_EXP_WINDOW=-1, D3F_EXP_RUNS=-1):
+            b = f.batch_eval(grid.to(dev), return_names=["dino_feats", "mask"])
+    for k in ("dist", "valid_mask", "dino_feats", "mask"):
+        assert torch.equal(a[k], b[k]), k
+    import ctypes
+    from d3fields_amd import _lib
+    views, keep, _ = f._views(dev)
+    m = maps["dino_feats"]
+    cm = (_lib.ChannelMap * 1)(_lib.ChannelMap(m.data_ptr(), m.shape[1], m.shape[2], C, 0, m.stride(0), m.stride(1), m.stride(2)))
+    plan = _lib.EvalPlan()
+    nx, ny, nz = (int(v) for v in shape)
+    _lib.check(f._lib.d3f_eval_plan_query_lattice(ctypes.byref(views), nx, ny, nz, cm, 1, _lib.FLAG_FINITE_MAPS, 0, ctypes.byref(plan)))
+    assert plan.staged[0] == 3
+
+
 def test_window_kernel_above_4_gib_of_output(dev):
     """2.99 M lattice points x 384 channels = 4.6 GB of fused rows: the window kernel's 32-bit store offsets must give way
     to 64-bit addressing (and the 1.9 M-point workloads below 4 GiB use the 32-bit form: test_bench_workload_matches_oracle)."""
