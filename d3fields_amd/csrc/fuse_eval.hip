@@ -1299,6 +1299,17 @@ __device__ __forceinline__ void fused_eval_window_body(const EvalParams &P)
         const int64_t q = tile_base + min(p, tile_n - 1);
         return P.order ? min((int64_t)P.order[q], P.n - 1) : q;
     };
+    // coordinates of slot p; on a d3f_grid they come straight from the axis arrays at the brick coordinates (fetch_point
+    // would divide the flat index apart again: two 64-bit divisions per lane)
+    auto slot_coords = [&](int p, int64_t i, float &px, float &py, float &pz) {
+        if (walk && P.grid_x) {
+            const int lz = min(p & (P.walk_tz - 1), bsz - 1), ly = min((p >> lbz) & (P.walk_ty - 1), bsy - 1);
+            const int lx = min(p >> (lbz + lby), bsx - 1);
+            px = P.grid_x[ox + lx]; py = P.grid_y[oy + ly]; pz = P.grid_z[oz + lz];
+        } else {
+            fetch_point(P, i, px, py, pz);
+        }
+    };
     const float mu = P.mu;
     const float Wm1 = (float)(P.W - 1), Hm1 = (float)(P.H - 1);
 
@@ -1431,7 +1442,7 @@ __device__ __forceinline__ void fused_eval_window_body(const EvalParams &P)
             wr.w[0] = wr.w[1] = wr.w[2] = wr.w[3] = 0.0f;
             if (v < V) {
                 float px, py, pz;
-                fetch_point(P, i, px, py, pz);
+                slot_coords(p, i, px, py, pz);
                 float wgt;
                 const ViewOut o = eval_view<0>(P.depth, P.H, P.W, krt + v * 12, v, px, py, pz, Wm1, Hm1, mu, wgt);
                 if (has_rec) {
