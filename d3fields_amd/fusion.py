@@ -230,6 +230,7 @@ class Fusion:
         self.reorder_points = True              # hand the library scratch so it may walk points in Morton order
         self.use_hip_graph = True               # rigid_tracking: capture the optimiser iteration in a HIP graph
         self.fused_tracking = True              # ... and run it as five HIP launches (track_kernels.hip) instead of autograd
+        self.graph_whole_tracking_loop = True   # ... with all 100 steps in ONE graph (False: one step replayed 100 times)
         self.detect_point_order = True          # probe new query tensors for locality (one host sync each, cached)
         self._order_cache = None
         self.cache_point_order = True           # keep the Morton order of an unchanged query tensor (a grid queried every
@@ -734,8 +735,10 @@ class Fusion:
         if self.use_hip_graph:
             # one capture per sequence: the graph is kept while instances / keypoints / views / map sizes stay the same
             key = rigid.RigidTracker.signature(self, num_instance, rand_ptcl_num)
-            if self._tracker is None or self._tracker.key != key or self._tracker.fused != self.fused_tracking:
-                self._tracker = rigid.RigidTracker(self, num_instance, rand_ptcl_num, fused=self.fused_tracking)
+            if (self._tracker is None or self._tracker.key != key or self._tracker.fused != self.fused_tracking or
+                    self._tracker.whole_loop != (self.graph_whole_tracking_loop and self.fused_tracking)):
+                self._tracker = rigid.RigidTracker(self, num_instance, rand_ptcl_num, fused=self.fused_tracking,
+                                                   whole_loop=self.graph_whole_tracking_loop)
             cur, _ = self._tracker.run(self, src_feats, last)
         else:
             cur, _ = rigid.track_rigid(self, src_feats, last, use_graph=False)

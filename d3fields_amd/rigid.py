@@ -100,12 +100,15 @@ class RigidTracker:
     d3f_eval_backward, d3f_rigid_update (csrc/track_kernels.hip: exponential map, transform, loss gradients, chain
     rule and Adam in closed form) -- instead of torch autograd's ~90.  fused=False replays the autograd step."""
 
-    def __init__(self, fusion, num_inst, n, iters=ITERS, lr=LR, fused=True):
+    def __init__(self, fusion, num_inst, n, iters=ITERS, lr=LR, fused=True, whole_loop=True):
         from .fusion import Fusion
         dev = torch.device(fusion.device)
         obs = fusion.curr_obs_torch
         self.key = self.signature(fusion, num_inst, n)
         self.iters, self.lr, self.fused = iters, lr, fused
+        # whole_loop: ALL `iters` steps are captured into one HIP graph (5 x iters kernel nodes, one launch per frame)
+        # instead of one step replayed `iters` times (a graph launch per step)
+        self.whole_loop = bool(whole_loop) and fused
         self.num_inst, self.n = num_inst, n
         self.shadow = Fusion(num_cam=fusion.num_cam, device=str(dev), dtype=fusion.dtype)
         self.shadow.H, self.shadow.W, self.shadow.mu = fusion.H, fusion.W, fusion.mu
@@ -189,8 +192,9 @@ class RigidTracker:
             self._rewind()
             self.graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.graph):
-                self.cur, self.loss = self._step()
+                for _ in range(self.iters if self.whole_loop else 1):
+                    self.cur, self.loss = self._step()
         self._rewind()
-        for _ in range(self.iters):
+        for _ in range(1 if self.whole_loop else self.iters):
             self.graph.replay()
         return self.cur.detach().clone(), self.loss.detach().clone()

@@ -14,12 +14,13 @@ f.H, f.W, f.mu = int(g["H"]), int(g["W"]), float(g["mu"])
 n = int(g["n"])
 info = {"a": {"src_feats": torch.from_numpy(g["src_feats"][:n])}, "b": {"src_feats": torch.from_numpy(g["src_feats"][n:])}}
 last = [p for p in g["last_pts"]]
-for use_graph, fused in ((False, False), (True, False), (True, False), (True, True), (True, True), (True, True)):
-    f.use_hip_graph, f.fused_tracking = use_graph, fused
+for use_graph, fused, whole in ((False, False, False), (True, False, False), (True, False, False), (True, True, False), (True, True, False), (True, True, False),
+                               (True, True, True), (True, True, True), (True, True, True), (True, True, True)):
+    f.use_hip_graph, f.fused_tracking, f.graph_whole_tracking_loop = use_graph, fused, whole
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     res = f.rigid_tracking(info, last, None, n)
     dt = time.perf_counter() - t0
     got = np.stack(res["match_pts_list"])
-    print("graph=%s fused=%s: %.1f ms per call (100 iterations), max |got - reference| = %.3e m, max |got - true| = %.4f m"
-          % (use_graph, fused, dt * 1e3, np.abs(got - g["match_pts"]).max(), np.abs(got - g["true_pts"]).max()), flush=True)
+    print("graph=%s fused=%s whole-loop=%s: %.1f ms per call (100 iterations), max |got - reference| = %.3e m, max |got - true| = %.4f m"
+          % (use_graph, fused, whole, dt * 1e3, np.abs(got - g["match_pts"]).max(), np.abs(got - g["true_pts"]).max()), flush=True)
