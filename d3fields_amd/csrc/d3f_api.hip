@@ -156,6 +156,7 @@ void pick_staged_mapping(d3f::MapDesc &m)
 //                  workgroups per unit
 //   D3F_EXP_WALK_TILE  shape of the walk's tile as digits x y z with the same point count (222 default; 224 with a thin map)
 //   D3F_EXP_WALK   lattice brick walk for grids on large maps: -1 off, 0 automatic (default)
+//   D3F_EXP_THIN   -1: thin maps (mask, colours) through the view-sequential gather_map instead of gather_map_thin
 //   D3F_EXP_WINDOW LDS texel-window kernel instead of the cell-run gather for a patch-resolution wide first map
 //                  (fuse_eval.hip): 0 automatic = on lattices (64 points per workgroup), -1 never,
 //                  32 / 64 / 128 = always, with that many points per workgroup; _U vectors per lane (1..4), _VC views
@@ -254,6 +255,7 @@ int eval_common(const d3f_views *views, const float *pts, int64_t n, const d3f_c
     P.walk_nx = P.walk_ny = P.walk_nz = 0; P.walk_tx = P.walk_ty = P.walk_tz = 1;
     P.sl_unit = 128; P.sl_slices = 0; P.sl_lg = 3; P.sl_vc = 4; P.sl_tiles = P.sl_groups = P.sl_chunks = 0;
     P.runs_occ = exp_knob("D3F_EXP_RUNS_OCC");
+    P.thin_views = exp_knob("D3F_EXP_THIN") < 0 ? 0 : 1;
     P.win_lpp = exp_knob("D3F_EXP_WINDOW_LPP") == 32 ? 32 : 16;     // 16 lanes x 2 vectors per point (C2 patch 0.565 -> 0.54 ms); U > 1: 32
     P.win_slices = 0; P.win_u = 1; P.win_vc = 1; P.win_pool_offset = 0; P.win_pool_texels = 0; P.win_occ = 4;
     P.store_policy = exp_knob("D3F_EXP_STORE") < 0 ? 0 : 1;

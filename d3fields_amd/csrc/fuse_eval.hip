@@ -559,7 +559,7 @@ template <> __device__ __forceinline__ f32x4 shfl_vec<f32x4>(f32x4 x, int src)
 
 __device__ __forceinline__ bool thin_map(const MapDesc &m, const EvalParams &P, int VW)
 {
-    return m.unroll == 1 && m.lpp_log2 <= 2 && m.C / VW <= (1 << m.lpp_log2) && P.V >= 2 && P.V <= 8;
+    return P.thin_views && m.unroll == 1 && m.lpp_log2 <= 2 && m.C / VW <= (1 << m.lpp_log2) && P.V >= 2 && P.V <= 8;
 }
 
 template <int VW>

@@ -271,6 +271,38 @@ def test_channel_sliced_launch_is_bit_identical(dev, dims, C, mask):
             assert torch.equal(torch.isnan(a), torch.isnan(b)) and torch.equal(torch.nan_to_num(a.float()), torch.nan_to_num(b.float())), (sl, k)
 
 
+# ---- thin maps: views in parallel across lanes == view-sequential gather, bit for bit -------------------------------------
+@pytest.mark.parametrize("V,C,N", [(4, 8, 70000), (2, 3, 5000), (3, 5, 130001), (8, 16, 66000), (5, 1, 3000), (4, 12, 90000)])
+def test_thin_map_gather_is_bit_identical(dev, V, C, N):
+    """gather_map_thin (one lane per (point, view, vector), ordered sum rebuilt with shuffles) against gather_map's
+    view-sequential loop (D3F_EXP_THIN=-1): fused rows and '<k>_inter', with strict points (a NaN coordinate, non-finite
+    map values) and in the kernels that carry thin maps along (direct, cell runs, windows, channel slices)."""
+    from d3fields_amd import create_init_grid, synth
+    H, W = 120, 160
+    thin = synth.random_map(V, H, W, C, seed=3, device=dev)
+    wide = synth.random_map(V, 12, 16, 384, seed=1, device=dev)
+    f, sc = fusion_for(dev, V, H, W, {"thin": thin, "dino_feats": wide}, kind="stress")
+    pts_c = synth.random_cloud(N, seed=5) * 1.2
+    pts_c[N // 2, 2] = float("nan")
+    pts = pts_c.to(dev)
+    grid = create_init_grid(synth.WORK_BOX, 0.0107)[0].to(dev)
+    with torch.no_grad():
+        for names, inter, q in ((["thin"], False, pts), (["thin"], True, pts), (["dino_feats", "thin"], False, pts), (["dino_feats", "thin"], False, grid)):
+            with knobs(D3F_EXP_THIN=-1):
+                ref = f.eval(q, return_names=names, return_inter=inter) if inter else f.batch_eval(q, return_names=names)
+            out = f.eval(q, return_names=names, return_inter=inter) if inter else f.batch_eval(q, return_names=names)
+            for k in ref:
+                a, b = out[k], ref[k]
+                assert torch.equal(torch.isnan(a), torch.isnan(b)) and torch.equal(torch.nan_to_num(a.float()), torch.nan_to_num(b.float())), (names, inter, k)
+        bad = thin.clone(); bad[0, 7, 9, 0] = float("inf")                 # non-finite map: everything strict
+        f.curr_obs_torch["thin"] = bad
+        f.invalidate_map_checks()
+        with knobs(D3F_EXP_THIN=-1):
+            ref = f.eval(pts, return_names=["thin"])
+        out = f.eval(pts, return_names=["thin"])
+        assert torch.equal(torch.nan_to_num(out["thin"], nan=7.0, posinf=8.0, neginf=9.0), torch.nan_to_num(ref["thin"], nan=7.0, posinf=8.0, neginf=9.0))
+
+
 # ---- LDS texel windows (experiment knob D3F_EXP_WINDOW) == direct gather, bit for bit -----------------------------------
 @pytest.mark.parametrize("C,V,fhw,mask,points", [(384, 4, (48, 64), True, "grid"), (256, 3, (24, 32), False, "cloud"),
                                                  (1024, 8, (36, 64), False, "cloud"), (128, 2, (48, 64), True, "grid")])
