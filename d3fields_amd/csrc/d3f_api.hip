@@ -255,7 +255,7 @@ int eval_common(const d3f_views *views, const float *pts, int64_t n, const d3f_c
     P.walk_nx = P.walk_ny = P.walk_nz = 0; P.walk_tx = P.walk_ty = P.walk_tz = 1;
     P.sl_unit = 128; P.sl_slices = 0; P.sl_lg = 3; P.sl_vc = 4; P.sl_tiles = P.sl_groups = P.sl_chunks = 0;
     P.runs_occ = exp_knob("D3F_EXP_RUNS_OCC");
-    P.thin_views = exp_knob("D3F_EXP_THIN") < 0 ? 0 : 1;
+    P.thin_max_views = exp_knob("D3F_EXP_THIN") < 0 ? 0 : 8;
     P.win_lpp = exp_knob("D3F_EXP_WINDOW_LPP") == 32 ? 32 : 16;     // 16 lanes x 2 vectors per point (C2 patch 0.565 -> 0.54 ms); U > 1: 32
     P.win_slices = 0; P.win_u = 1; P.win_vc = 1; P.win_pool_offset = 0; P.win_pool_texels = 0; P.win_occ = 4;
     P.store_policy = exp_knob("D3F_EXP_STORE") < 0 ? 0 : 1;
@@ -445,15 +445,16 @@ int eval_common(const d3f_views *views, const float *pts, int64_t n, const d3f_c
         while ((long)P.tile_pts * views->V * 88 > 40 * 1024 && P.tile_pts > round) P.tile_pts >>= 1;   // records + 2 corner slots
         P.lds_pad = 0;
     }
-    // Channel-sliced launch (fuse_eval.hip): a lattice on a dense wide fp32 map that is the FIRST map of the call; any
-    // other map must be thin (it rides along with slice 0).  Default only where it measured faster: a wide map WITH thin
-    // companions (C3-dense, features + 8-channel mask: 3.04 -> 2.80 ms with 512-byte slices, two views in flight --
-    // there the whole-texel kernel stalls on the thin map's gather, 16 points x 2 lanes per workgroup); for a wide map
-    // alone slicing removes 20-29 % of the L2 fills and no time.  D3F_EXP_SLICED = 1 / 2 / 3 forces
-    // 128- / 256- / 512-byte slices, -1 disables.
+    // Channel-sliced launch (fuse_eval.hip): a lattice on a dense wide fp32 map that is the FIRST map of the launch; any
+    // other map must be thin (it rides along with slice 0).  512-byte slices, two views in flight; a wide map WITH thin
+    // companions takes 32 points per workgroup (C3-dense, features + 8-channel mask: 3.04 -> 2.80 ms -- the whole-texel
+    // kernel stalls on the thin map's gather, 16 points x 2 lanes per workgroup), a wide map ALONE 16 points per workgroup
+    // (C2-dense 1.62 -> 1.52 ms: with 32 the slicing removed 20-29 % of the L2 fills and no time, with 64 it lost 20 %:
+    // the points in flight per XCD are what the L2 window is made of).  D3F_EXP_SLICED = 1 / 2 / 3 forces
+    // 128- / 256- / 512-byte slices, -1 disables; _TILE 8 / 16 / 32 / 64 points per workgroup.
     {
         int sl = exp_knob("D3F_EXP_SLICED");
-        bool thin_rest = n_maps >= 2;
+        bool thin_rest = true;
         for (int s = 1; s < n_maps; ++s) thin_rest = thin_rest && P.maps[s].C * P.maps[s].esize <= 256 && P.maps[s].esize == 4;
         const bool automatic = sl == 0 && thin_rest && n_maps >= 1 && P.maps[0].C % 128 == 0 && P.maps[0].C <= 512;
         if (automatic) sl = 3;
@@ -464,14 +465,18 @@ int eval_common(const d3f_views *views, const float *pts, int64_t n, const d3f_c
         ok = ok && P.maps[0].C % (4 * lanes) == 0 && P.maps[0].C >= 128;
         for (int s = 1; s < n_maps && ok; ++s) ok = P.maps[s].C * P.maps[s].esize <= 256 && !want_inter[s] && P.maps[s].esize == 4;
         if (ok) {
-            P.walk_tx = P.walk_ty = P.walk_tz = 2;
+            const int tile_knob = exp_knob("D3F_EXP_SLICED_TILE");
+            const bool big = tile_knob == 64;                            // experiment: 64 points per workgroup (four 2x2x4 tiles)
+            const bool tiny = tile_knob == 16 || (tile_knob == 0 && n_maps == 1);   // 16 points per workgroup (four 2x2x1 tiles)
+            const bool mini = tile_knob == 8;                            // experiment: 8 points per workgroup (four 2x1x1 tiles)
+            P.walk_tx = 2; P.walk_ty = mini ? 1 : 2; P.walk_tz = big ? 4 : ((tiny || mini) ? 1 : 2);
             P.sl_lg = lg;
             P.sl_slices = P.maps[0].C / (4 * lanes);
-            P.sl_tiles = (int64_t)((P.walk_nx + 1) / 2) * ((P.walk_ny + 1) / 2) * ((P.walk_nz + 1) / 2);
+            P.sl_tiles = (int64_t)((P.walk_nx + 1) / 2) * ((P.walk_ny + P.walk_ty - 1) / P.walk_ty) * ((P.walk_nz + P.walk_tz - 1) / P.walk_tz);
             P.sl_groups = (P.sl_tiles + 3) / 4;
-            P.sl_unit = exp_knob("D3F_EXP_SLICED_UNIT") > 0 ? exp_knob("D3F_EXP_SLICED_UNIT") : 128;   // 4096 points per unit (smaller: slower)
+            P.sl_unit = exp_knob("D3F_EXP_SLICED_UNIT") > 0 ? exp_knob("D3F_EXP_SLICED_UNIT") : (big ? 64 : (tiny ? 256 : (mini ? 512 : 128)));   // 4096 points per unit (smaller: slower)
             P.sl_chunks = (P.sl_groups + P.sl_unit - 1) / P.sl_unit;
-            P.tile_pts = 32; P.lds_pad = 0;
+            P.tile_pts = big ? 64 : (tiny ? 16 : (mini ? 8 : 32)); P.lds_pad = exp_knob("D3F_EXP_SLICED_PAD") > 0 ? exp_knob("D3F_EXP_SLICED_PAD") * 1024 : 0;
             for (int s = 1; s < n_maps; ++s) pick_mapping(P.maps[s], P.maps[s].vw == 4, P.maps[s].vw >= 2, true, 1);
             if (((P.sl_chunks * P.sl_slices + 7) / 8) * 8 * P.sl_unit > 0x7fffffffLL) P.sl_slices = 0;
         }

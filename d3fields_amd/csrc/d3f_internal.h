@@ -60,7 +60,8 @@ struct EvalParams {
     int32_t win_pool_texels;   // pool capacity in texel slices of 512 * win_u bytes
     int32_t win_occ;           // workgroups per CU the kernel variant is built for (2 / 3 / 4)
     int32_t win_lpp;           // lanes per point in phase B: 32, or 16 (two vectors per lane inside a 512-byte slice)
-    int32_t thin_views;    // 1 (default): thin maps are gathered with the views in parallel across lanes (gather_map_thin)
+    int32_t thin_max_views;    // 8 (default): thin maps with 2..8 views are gathered with the views in parallel across lanes
+                               // (gather_map_thin); 0 switches that off (D3F_EXP_THIN=-1, tests)
     int32_t runs_occ;      // experiment: waves per SIMD of the (1,8) cell-run kernel variant (4 / 5 / 6)
     int32_t store_policy;  // 1 (default) = fused rows leave as sc1 (write-through, line dropped from L2) stores, 0 = plain
     uint32_t flags;

@@ -559,7 +559,7 @@ template <> __device__ __forceinline__ f32x4 shfl_vec<f32x4>(f32x4 x, int src)
 
 __device__ __forceinline__ bool thin_map(const MapDesc &m, const EvalParams &P, int VW)
 {
-    return P.thin_views && m.unroll == 1 && m.lpp_log2 <= 2 && m.C / VW <= (1 << m.lpp_log2) && P.V >= 2 && P.V <= 8;
+    return m.unroll == 1 && m.lpp_log2 <= 2 && m.C / VW <= (1 << m.lpp_log2) && P.V >= 2 && P.V <= P.thin_max_views;
 }
 
 template <int VW>
@@ -939,7 +939,8 @@ constexpr int kSlicedTile = 32;            // points per workgroup = 4 tiles of 
 template <int LG, int VC>                  // lanes per point = 1 << LG: 8 (128-byte slices), 16 (256 B) or 32 (512 B)
 __device__ __forceinline__ void fused_eval_sliced_body(const EvalParams &P)
 {
-    constexpr int LP = 1 << LG, PTS = kBlock / LP, TP = kSlicedTile;
+    constexpr int LP = 1 << LG, PTS = kBlock / LP;
+    const int TP = P.tile_pts;                 // 32 (four 2x2x2 walk tiles) or 64 (four 2x2x4 ones)
     extern __shared__ __align__(16) unsigned char smem[];
     const int V = P.V;
     ViewRec *rec = reinterpret_cast<ViewRec *>(smem);                       // same layout as fused_eval_body
@@ -1694,7 +1695,7 @@ hipError_t launch_fused_eval(const EvalParams &P, int mode, hipStream_t stream)
     if (mode == 0 && P.sl_slices > 0) {
         const int64_t units = (int64_t)P.sl_chunks * P.sl_slices;
         const int64_t wgs = (units + 7) / 8 * 8 * P.sl_unit;
-        const size_t lds_s = (size_t)P.crec_offset + (size_t)kSlicedTile * P.V * 32;
+        const size_t lds_s = (size_t)P.crec_offset + (size_t)P.tile_pts * P.V * 32 + (size_t)P.lds_pad;
         const dim3 gs((unsigned)wgs);
         if (P.sl_lg == 5 && P.sl_vc == 2) hipLaunchKernelGGL((fused_eval_sliced_kernel<5, 2, 7>), gs, block, lds_s, stream, P);
         else if (P.sl_lg == 5) hipLaunchKernelGGL((fused_eval_sliced_kernel<5, 4, 5>), gs, block, lds_s, stream, P);

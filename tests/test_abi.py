@@ -165,9 +165,17 @@ def test_validation_of_topk_and_lattice_entry_points():
     big = (_lib.ChannelMap * 1)(_lib.ChannelMap(1 << 20, 480, 640, 384, 0, 480 * 640 * 384, 640 * 384, 384))
     v = _views(V=4, H=480, W=640)
     assert lib.d3f_eval_plan_query_lattice(ctypes.byref(v), 160, 140, 44, big, 1, _lib.FLAG_FINITE_MAPS, 0, ctypes.byref(plan)) == 0
-    assert plan.reorder == 2 and plan.tile_points == 8 and plan.workgroups == 80 * 70 * 22 and plan.staged[0] == 0
+    # a dense wide map alone: channel-sliced launch, 16 points (four 2 x 2 x 1 tiles) x one 512-byte slice per workgroup,
+    # units of 256 workgroups spread over the XCDs
+    assert (plan.reorder, plan.tile_points, plan.reserved, plan.staged[0]) == (2, 16, 152, 0)
+    assert plan.workgroups == ((80 * 70 * 44 // 4 + 255) // 256 * 3 + 7) // 8 * 8 * 256
     assert lib.d3f_eval_plan_query_lattice(ctypes.byref(v), 161, 141, 45, big, 1, _lib.FLAG_FINITE_MAPS, 0, ctypes.byref(plan)) == 0
-    assert plan.workgroups == 81 * 71 * 23                     # clipped tiles at the upper faces, no padding
+    assert plan.tile_points == 16 and plan.workgroups == ((81 * 71 * 45 // 4 + 1 + 255) // 256 * 3 + 7) // 8 * 8 * 256
+    odd = (_lib.ChannelMap * 1)(_lib.ChannelMap(1 << 20, 480, 640, 200, 0, 480 * 640 * 200, 640 * 200, 200))
+    assert lib.d3f_eval_plan_query_lattice(ctypes.byref(v), 161, 141, 45, odd, 1, _lib.FLAG_FINITE_MAPS, 0, ctypes.byref(plan)) == 0
+    # no whole 512-byte slices: the whole-texel kernel on 2 x 2 x 4 bricks (16 lanes per point), clipped at the upper
+    # faces, no padding
+    assert (plan.reorder, plan.tile_points, plan.reserved, plan.workgroups) == (2, 16, 0, 81 * 71 * 12)
     both = (_lib.ChannelMap * 2)(_lib.ChannelMap(1 << 20, 480, 640, 384, 0, 480 * 640 * 384, 640 * 384, 384),
                                  _lib.ChannelMap(1 << 20, 480, 640, 8, 0, 480 * 640 * 8, 640 * 8, 8))
     assert lib.d3f_eval_plan_query_lattice(ctypes.byref(v), 200, 175, 55, both, 2, _lib.FLAG_FINITE_MAPS, 0, ctypes.byref(plan)) == 0

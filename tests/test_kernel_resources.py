@@ -1,0 +1,41 @@
+"""Register / scratch budget of the default kernel variants (hipcc's kernel-resource-usage remarks, no GPU needed).
+
+A harmless-looking source change can push a kernel over an occupancy step (round 2: one extra flag test took the fp16
+kernel from 165 to 212 VGPRs = 3 -> 2 waves per SIMD and 25 % of its speed); this test pins the allocations the
+measured numbers in DESIGN.md were taken with."""
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+# kernel (substring of the mangled name) -> (max VGPRs, max scratch bytes per lane)
+BUDGET = {
+    "17fused_eval_kernelILi0E": (128, 0),                       # dense maps, 4 waves per SIMD
+    "17fused_eval_kernelILi1E": (128, 0),
+    "22fused_eval_wide_kernelILi0E": (168, 0),                  # C = 1024 dense, 3 waves
+    "21fused_eval_f16_kernelILi0E": (168, 0),                   # fp16-stored maps, 3 waves
+    "22fused_eval_runs_kernelILi0ELi1ELi4ELi7E": (72, 0),       # cell runs (1,4), 7 waves
+    "22fused_eval_runs_kernelILi0ELi2ELi8ELi3E": (168, 0),      # cell runs (2,8), 3 waves
+    "24fused_eval_sliced_kernelILi5ELi2ELi7E": (72, 0),         # channel-sliced, 7 waves
+    "24fused_eval_window_kernelILi1ELi2ELi4ELi256ELi16E": (128, 0),   # LDS texel windows, 4 workgroups per CU
+}
+
+
+@pytest.mark.skipif(shutil.which("hipcc") is None and not os.path.exists("/opt/rocm/bin/hipcc"), reason="needs hipcc")
+def test_default_kernels_keep_their_register_budget():
+    out = subprocess.run(["bash", os.path.join(ROOT, "scripts", "kernel_resources.sh")], capture_output=True, text=True, timeout=600).stdout
+    seen = {}
+    for line in out.splitlines():
+        m = re.match(r"(\S+)\s+vgpr\s+(\d+)\s+scratch\s+(\d+)\s+occ\s+(\d+)", line)
+        if m:
+            seen[m.group(1)] = (int(m.group(2)), int(m.group(3)))
+    assert seen, out[-500:]
+    for key, (max_vgpr, max_scratch) in BUDGET.items():
+        hits = [v for k, v in seen.items() if k.startswith(key)]
+        assert hits, "kernel %s not found among %s" % (key, sorted(seen))
+        vgpr, scratch = hits[0]
+        assert vgpr <= max_vgpr and scratch <= max_scratch, "%s: %d VGPRs / %d B scratch, budget %d / %d" % (key, vgpr, scratch, max_vgpr, max_scratch)
