@@ -9,7 +9,7 @@ import os
 
 from . import build as _build
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 # status codes (include/d3fields_hip.h)
 OK = 0
@@ -17,7 +17,8 @@ ERR_INVALID_ARG, ERR_BAD_SHAPE, ERR_BAD_DTYPE, ERR_BAD_LAYOUT, ERR_HIP, ERR_WORK
 FLAG_FINITE_MAPS = 1
 FLAG_UNORDERED_POINTS = 2
 FLAG_REUSE_POINT_ORDER = 8
-TUNE_XCD_REMAP, TUNE_NO_REORDER, TUNE_FORCE_REORDER, TUNE_STAGING = 1 << 12, 1 << 13, 1 << 14, 1 << 15
+TUNE_XCD_REMAP, TUNE_NO_REORDER, TUNE_FORCE_REORDER = 1 << 12, 1 << 13, 1 << 14
+TUNE_DIRECT_GATHER = 1 << 4
 MAX_VIEWS = 64
 MAX_MAPS = 8
 DTYPE_F32 = 0
@@ -60,6 +61,7 @@ SIGNATURES = {
     "d3f_abi_version": (ctypes.c_int, []),
     "d3f_version": (ctypes.c_char_p, []),
     "d3f_last_error": (ctypes.c_char_p, []),
+    "d3f_build_has_experiments": (ctypes.c_int, []),
     "d3f_eval": (ctypes.c_int, [ctypes.POINTER(Views), _vp, _i64, ctypes.POINTER(ChannelMap), _i32, _f32, _u32,
                                 _vp, _vp, ctypes.POINTER(_vp), ctypes.POINTER(_vp), _vp, _i64, _vp]),
     "d3f_eval_workspace_bytes": (_i64, [_i64]),

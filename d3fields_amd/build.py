@@ -32,12 +32,28 @@ def _hipcc():
 FINGERPRINT_PATH = LIB_PATH + ".fingerprint"
 
 
+# kernels measured and rejected, kept for reproducing the tuning sessions: compiled ONLY with D3F_BUILD_EXPERIMENTS=1
+EXPERIMENT_SOURCES = ["experiments/fuse_stream.hip"]
+
+
+def _sources():
+    return SOURCES + (EXPERIMENT_SOURCES if _experiments() else [])
+
+
+def _experiments():
+    """D3F_BUILD_EXPERIMENTS=1 (or --experiments) compiles the environment knobs of tuning sessions in (-DD3F_EXPERIMENTS);
+    the product build has none (d3f_api.hip: exp_knob)."""
+    return os.environ.get("D3F_BUILD_EXPERIMENTS", "0") not in ("", "0")
+
+
 def source_fingerprint():
     """sha256 over the kernel sources, the public header and the compiler flags: what the .so was built from.
     Content-based (not mtimes), so a working tree copied to another machine keeps a fresh library fresh."""
     import hashlib
-    h = hashlib.sha256(" ".join(HIPCC_FLAGS + SOURCES).encode())
-    for path in sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC)) + [os.path.join(INCLUDE, "d3fields_hip.h")]:
+    h = hashlib.sha256(" ".join(HIPCC_FLAGS + _sources() + (["-DD3F_EXPERIMENTS"] if _experiments() else [])).encode())
+    files = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if os.path.isfile(os.path.join(CSRC, f))]
+    files += [os.path.join(CSRC, s) for s in EXPERIMENT_SOURCES if _experiments()]
+    for path in sorted(files) + [os.path.join(INCLUDE, "d3fields_hip.h")]:
         h.update(os.path.basename(path).encode())
         with open(path, "rb") as fh:
             h.update(fh.read())
@@ -77,13 +93,13 @@ def build_library(force=False, extra_flags=(), verbose=False):
 
 
 def _build_locked(hipcc, force, extra_flags, verbose):
-    objdir = os.path.join(PKG_DIR, "build")
+    objdir = os.path.join(PKG_DIR, "build_exp" if _experiments() else "build")
     os.makedirs(objdir, exist_ok=True)
     headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")] + [os.path.join(INCLUDE, "d3fields_hip.h")]
-    cflags = [f for f in HIPCC_FLAGS if f != "-shared"] + list(extra_flags) + ["-I", INCLUDE, "-c"]
+    cflags = [f for f in HIPCC_FLAGS if f != "-shared"] + list(extra_flags) + (["-DD3F_EXPERIMENTS"] if _experiments() else []) + ["-I", INCLUDE, "-I", CSRC, "-c"]
     jobs, objs = [], []
-    for s in SOURCES:
-        src, obj = os.path.join(CSRC, s), os.path.join(objdir, s.replace(".hip", ".o"))
+    for s in _sources():
+        src, obj = os.path.join(CSRC, s), os.path.join(objdir, os.path.basename(s).replace(".hip", ".o"))
         objs.append(obj)
         if force or extra_flags or _object_stale(obj, src, headers):
             cmd = [hipcc] + cflags + [src, "-o", obj]
@@ -104,6 +120,8 @@ def _build_locked(hipcc, force, extra_flags, verbose):
 
 if __name__ == "__main__":
     flags = []
+    if "--experiments" in sys.argv:
+        os.environ["D3F_BUILD_EXPERIMENTS"] = "1"
     if "--save-temps" in sys.argv:
         flags.append("-save-temps")
     if "--resource-usage" in sys.argv:

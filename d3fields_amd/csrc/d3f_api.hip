@@ -67,6 +67,19 @@ void pick_mapping(d3f::MapDesc &m, bool can16, bool can8, bool batch, int max_u 
     if (!batch) m.unroll = -m.unroll;
 }
 
+// ---- launch-plan thresholds (every row has a test in tests/test_abi.py::test_plan_table) ---------------------------------
+//  kSmallBatch          fewer points than this: no reordering, no window / cell-run / sliced launch -- the set-up of those
+//                       paths costs more than it saves, and small batches are spread over >= 1024 workgroups instead
+//  kCacheResidentBytes  all requested maps together at most this big live in the L2s / Infinity Cache anyway: the caller's
+//                       order is kept (unless the cloud has no locality at all), 128-point tiles
+//  kBatchedLoadBytes    a map at most this big issues all 4*U corner loads of a view before the first use; bigger maps
+//                       in caller order use load-use per vector (a smaller in-flight footprint measured faster)
+//  kBeyondLlcBytes      maps beyond this in CALLER order without scratch: 64-point tiles at 2 workgroups per CU
+constexpr int64_t kSmallBatch = 65536;
+constexpr int64_t kCacheResidentBytes = 64LL << 20;
+constexpr int64_t kBatchedLoadBytes = 128LL << 20;
+constexpr int64_t kBeyondLlcBytes = 512LL << 20;
+
 // Validates one channel map and fills the kernel-side descriptor (out/inter may be NULL for backward).
 int fill_map(const d3f_channel_map &c, int s, int V, float *out, float *inter, const float *extra_aligned,
              d3f::MapDesc &m, int64_t &map_bytes, uint32_t flags = 0)
@@ -84,7 +97,6 @@ int fill_map(const d3f_channel_map &c, int s, int V, float *out, float *inter, c
     m.data = static_cast<const float *>(c.data);
     m.out = out;
     m.inter = inter;
-    m.staged = 0;
     m.runs = 0;
     m.pre_slot = -1;
     m.esize = es;
@@ -113,36 +125,11 @@ int fill_map(const d3f_channel_map &c, int s, int V, float *out, float *inter, c
         }
         return D3F_OK;
     }
-    bool batch = this_bytes <= (128LL << 20);
+    bool batch = this_bytes <= kBatchedLoadBytes;
     if (flags & (1u << 26)) batch = true;
     if (flags & (1u << 27)) batch = false;
     pick_mapping(m, can16, can8, batch);
     return D3F_OK;
-}
-
-// Staged gather (fuse_eval.hip): 16-B vectors, 32 lanes per point and <= 3 vectors per lane so that the
-// 4 points of a half-wave keep their accumulators in registers; wide (>= 256 B per texel) maps whose
-// texels span >= 4 image pixels, i.e. the patch-resolution feature maps of the reference.
-bool staging_candidate(const d3f::MapDesc &m, int H, int W)
-{
-    return m.esize == 4 && m.vw == 4 && m.C >= 64 && (W - 1) >= 4 * (m.fw - 1) && (H - 1) >= 4 * (m.fh - 1);
-}
-
-void pick_staged_mapping(d3f::MapDesc &m)
-{
-    const int cvec = m.C / 4;
-    long best_slots = -1;
-    int best_passes = 0;
-    for (int lg = 5; lg >= 5; --lg)
-        for (int u = 3; u >= 1; --u) {
-            const int per = (1 << lg) * u;
-            const int passes = (cvec + per - 1) / per;
-            const long slots = (long)passes * per;
-            if (best_slots < 0 || slots < best_slots || (slots == best_slots && passes < best_passes)) {
-                best_slots = slots; best_passes = passes; m.lpp_log2 = lg; m.unroll = u;
-            }
-        }
-    m.staged = 2;
 }
 
 // Experiment knobs read from the environment (integers; results never depend on them):
@@ -162,11 +149,17 @@ void pick_staged_mapping(d3f::MapDesc &m)
 //                  32 / 64 / 128 = always, with that many points per workgroup; _U vectors per lane (1..4), _VC views
 //                  in flight (U = 2 / 3), _OCC workgroups per CU (2..4), _POOL pool texels, _LPP 32: one vector per lane (default 16 x 2)
 //   D3F_EXP_RUNS_OCC also: 4 = the (2,8) cell-run variant held to 4 waves per SIMD (default 3, spill-free)
+#ifdef D3F_EXPERIMENTS
+// built with -DD3F_EXPERIMENTS (python -m d3fields_amd.build --experiments): tuning sessions only
 int exp_knob(const char *name)
 {
     const char *v = getenv(name);
     return v ? atoi(v) : 0;
 }
+#else
+// the product build reads no environment: every knob is its default (0), the library keeps no hidden state
+constexpr int exp_knob(const char *) { return 0; }
+#endif
 
 // Cell-run gather (fuse_eval.hip gather_map_runs): fp32 maps read as 16-byte vectors with >= 32 vectors per texel whose
 // texels span >= 4 image pixels -- the patch-resolution feature maps of the reference (fusion.py:694-697).
@@ -249,13 +242,14 @@ int eval_common(const d3f_views *views, const float *pts, int64_t n, const d3f_c
 
     d3f::EvalParams P;
     P.depth = views->depth; P.K = views->K; P.pose = views->pose; P.pts = pts;
-    P.order = nullptr; P.lds_pad = 0; P.stage_floats = 0;
+    P.order = nullptr; P.lds_pad = 0;
     P.grid_x = grid ? grid->x : nullptr; P.grid_y = grid ? grid->y : nullptr; P.grid_z = grid ? grid->z : nullptr;
     P.grid_ny = grid ? grid->ny : 0; P.grid_nz = grid ? grid->nz : 0;
     P.walk_nx = P.walk_ny = P.walk_nz = 0; P.walk_tx = P.walk_ty = P.walk_tz = 1;
     P.sl_unit = 128; P.sl_slices = 0; P.sl_lg = 3; P.sl_vc = 4; P.sl_tiles = P.sl_groups = P.sl_chunks = 0;
+    P.st_on = 0; P.st_R = 8; P.st_lty = 1; P.st_ltz = 1; P.st_variant = 0; P.st_grid = 0; P.st_tickets = nullptr; P.st_debug = 0; P.st_rec = nullptr; P.st_aux = nullptr;
     P.runs_occ = exp_knob("D3F_EXP_RUNS_OCC");
-    P.thin_max_views = exp_knob("D3F_EXP_THIN") < 0 ? 0 : 8;
+    P.thin_max_views = (exp_knob("D3F_EXP_THIN") < 0 || (flags & D3F_TUNE_DIRECT_GATHER)) ? 0 : 8;
     P.win_lpp = exp_knob("D3F_EXP_WINDOW_LPP") == 32 ? 32 : 16;     // 16 lanes x 2 vectors per point (C2 patch 0.565 -> 0.54 ms); U > 1: 32
     P.win_slices = 0; P.win_u = 1; P.win_vc = 1; P.win_pool_offset = 0; P.win_pool_texels = 0; P.win_occ = 4;
     P.store_policy = exp_knob("D3F_EXP_STORE") < 0 ? 0 : 1;
@@ -293,9 +287,9 @@ int eval_common(const d3f_views *views, const float *pts, int64_t n, const d3f_c
     hipStream_t hs = static_cast<hipStream_t>(stream);
     const bool may_reorder = (workspace || plan_only) && !grid && n_maps > 0 && n <= 0x7fffffffLL && !(flags & D3F_TUNE_NO_REORDER) &&
                              workspace_bytes >= d3f::order_workspace_bytes(n);
-    bool stage_any = false;
-    if ((flags & D3F_TUNE_STAGING) && views->V * 24 * 32 <= 24 * 1024)
-        for (int s = 0; s < n_maps; ++s) stage_any |= staging_candidate(P.maps[s], views->H, views->W);
+    // D3F_TUNE_DIRECT_GATHER: the plain direct gather in the chosen point order -- no texel windows, no cell runs, no channel
+    // slices, thin maps view by view.  The reference the bit-identity tests compare every fast path with.
+    const bool direct = (flags & D3F_TUNE_DIRECT_GATHER) != 0;
     // Cell-run gather for patch-resolution wide maps (at most two per launch: one corner-record slot each): consecutive
     // points of the processing order (a grid column in caller order, the Morton walk of a cloud) mostly stay inside one
     // texel cell of a view, so a lane group keeps the four corner vectors in registers across a run of points
@@ -308,7 +302,7 @@ int eval_common(const d3f_views *views, const float *pts, int64_t n, const d3f_c
         // default: lattices only (a brick's windows are compact; 64 consecutive points of a cloud's Morton order are not:
         // C5 0.120 -> 0.170 ms), and not when a cell-run variant is asked for explicitly
         const bool automatic = win_knob == 0 && lattice != nullptr && exp_knob("D3F_EXP_RUNS") == 0 && exp_knob("D3F_EXP_RUNS_U") == 0;
-        window = (win_knob > 0 || automatic) && mode == 0 && n_maps >= 1 && (flags & D3F_FLAG_FINITE_MAPS) && !stage_any && n >= 65536 &&
+        window = (win_knob > 0 || automatic) && !direct && mode == 0 && n_maps >= 1 && (flags & D3F_FLAG_FINITE_MAPS) && n >= kSmallBatch &&
                  n <= 0x7fffffffLL && tl == 0 && views->V <= 8 && runs_candidate(P.maps[0], views->H, views->W) &&
                  P.maps[0].C % 128 == 0 && (int64_t)views->V * P.maps[0].sv * 4 < (1LL << 31) && (P.maps[0].sx % 4) == 0 && (P.maps[0].sy % 4) == 0 && (P.maps[0].sv % 4) == 0 &&
                  (!plan_only ? (reinterpret_cast<uintptr_t>(P.maps[0].data) % 16 == 0) : true);
@@ -345,7 +339,7 @@ int eval_common(const d3f_views *views, const float *pts, int64_t n, const d3f_c
     bool any_runs = false;
     {
         const int knob = exp_knob("D3F_EXP_RUNS");
-        bool blocked = window || knob < 0 || !(flags & D3F_FLAG_FINITE_MAPS) || stage_any || n < 65536 || tl != 0;
+        bool blocked = window || direct || knob < 0 || !(flags & D3F_FLAG_FINITE_MAPS) || n < kSmallBatch || tl != 0;
         for (int s = 0; s < n_maps; ++s)
             blocked |= P.maps[s].esize == 2 || want_inter[s] ||
                        (P.maps[s].unroll == -4 && !runs_candidate(P.maps[s], views->H, views->W));
@@ -363,10 +357,12 @@ int eval_common(const d3f_views *views, const float *pts, int64_t n, const d3f_c
     // Points on a regular lattice (a d3f_grid, or d3f_eval_lattice's dims): the brick walk is closed form -- no keys, no
     // sort, no index array, no scratch -- and replaces the Morton sort wherever that would be used.  (With the cell-run
     // gather the caller's z-fastest order is the one wanted: a grid column is one long run.)
-    const bool walk = lattice && n_maps > 0 && n >= 65536 && n <= 0x7fffffffLL && !(flags & D3F_TUNE_NO_REORDER) &&
-                      exp_knob("D3F_EXP_WALK") >= 0 && !stage_any && !any_runs &&
-                      ((flags & D3F_TUNE_FORCE_REORDER) || map_bytes > (64LL << 20) || window);
-    const bool reorder = walk || (may_reorder && ((flags & D3F_TUNE_FORCE_REORDER) || (n >= 65536 && (map_bytes > (64LL << 20) || stage_any || (flags & D3F_FLAG_UNORDERED_POINTS)))));
+    // (a flat lattice with more than 2^28 tiles per 16-tile slab would overflow the walk's 32-bit level arithmetic)
+    const bool walk_fits = lattice && 16.0 * ((lattice[1] + 1) / 2) * ((lattice[2] + 1) / 2) < 4294967296.0;
+    const bool walk = lattice && walk_fits && n_maps > 0 && n >= kSmallBatch && n <= 0x7fffffffLL && !(flags & D3F_TUNE_NO_REORDER) &&
+                      exp_knob("D3F_EXP_WALK") >= 0 && !any_runs &&
+                      ((flags & D3F_TUNE_FORCE_REORDER) || map_bytes > kCacheResidentBytes || window);
+    const bool reorder = walk || (may_reorder && ((flags & D3F_TUNE_FORCE_REORDER) || (n >= kSmallBatch && (map_bytes > kCacheResidentBytes || (flags & D3F_FLAG_UNORDERED_POINTS)))));
     if (walk) {
         P.walk_nx = lattice[0]; P.walk_ny = lattice[1]; P.walk_nz = lattice[2];
     } else if (reorder && !plan_only && (flags & D3F_FLAG_REUSE_POINT_ORDER)) {
@@ -413,8 +409,8 @@ int eval_common(const d3f_views *views, const float *pts, int64_t n, const d3f_c
         // maps that fit the L2s / Infinity Cache anyway (patch-resolution features, the mask): the walk is only there
         // to give a random cloud L1 locality and the big tiles of the caller-order path stay best
         // (C2 patch, random cloud: caller order 1.93 ms, walk with 8-point tiles 1.07, with 128-point tiles 0.76)
-        if (map_bytes <= (64LL << 20) && !stage_any && !walk) P.tile_pts = tile_points_for(views->V);
-    } else if (map_bytes > (512LL << 20) && P.tile_pts > 64 && n >= 65536 && !any_runs) {
+        if (map_bytes <= kCacheResidentBytes && !walk) P.tile_pts = tile_points_for(views->V);
+    } else if (map_bytes > kBeyondLlcBytes && P.tile_pts > 64 && n >= kSmallBatch && !any_runs) {
         P.tile_pts = 64; P.lds_pad = 64 * 1024;
     }
     // small batches (keypoints, tracking): a 128-point tile is 16-32 serial rounds per lane group, so a few hundred
@@ -425,13 +421,6 @@ int eval_common(const d3f_views *views, const float *pts, int64_t n, const d3f_c
     if ((flags >> 16) & 0xFF) P.lds_pad = ((int)((flags >> 16) & 0xFF) == 0xFF) ? 0 : (int)((flags >> 16) & 0xFF) * 1024;
     if (flags & D3F_TUNE_XCD_REMAP) xcd_remap = !xcd_remap;
     P.flags = (flags & ~D3F_TUNE_XCD_REMAP) | (xcd_remap ? D3F_TUNE_XCD_REMAP : 0u);
-    // texel windows only fit LDS when the tiles are spatially compact, i.e. on the Morton walk
-    if (stage_any && reorder) {
-        for (int s = 0; s < n_maps; ++s)
-            if (staging_candidate(P.maps[s], views->H, views->W)) pick_staged_mapping(P.maps[s]);
-        P.tile_pts = 32; P.lds_pad = 0;
-        P.stage_floats = d3f::kStageFloats;     // 4 wave-private regions of 13.5 KiB (9 texels of 384 channels)
-    }
     if (any_runs) {
         int k = 8, lg = 6;
         for (int s = 0; s < n_maps; ++s)
@@ -458,7 +447,7 @@ int eval_common(const d3f_views *views, const float *pts, int64_t n, const d3f_c
         for (int s = 1; s < n_maps; ++s) thin_rest = thin_rest && P.maps[s].C * P.maps[s].esize <= 256 && P.maps[s].esize == 4;
         const bool automatic = sl == 0 && thin_rest && n_maps >= 1 && P.maps[0].C % 128 == 0 && P.maps[0].C <= 512;
         if (automatic) sl = 3;
-        bool ok = walk && !window && (sl >= 1 && sl <= 3) && mode == 0 && n_maps >= 1 && P.maps[0].esize == 4 && P.maps[0].vw == 4 &&
+        bool ok = walk && !window && !direct && (sl >= 1 && sl <= 3) && mode == 0 && n_maps >= 1 && P.maps[0].esize == 4 && P.maps[0].vw == 4 &&
                   !want_inter[0] && tl == 0;
         const int lg = sl + 2, lanes = 1 << lg;      // 1: 8 lanes (128-byte slices), 2: 16 lanes, 3: 32 lanes (512 bytes)
         P.sl_vc = exp_knob("D3F_EXP_SLICED_VC") > 0 ? exp_knob("D3F_EXP_SLICED_VC") : (automatic ? 2 : 4);
@@ -481,6 +470,44 @@ int eval_common(const d3f_views *views, const float *pts, int64_t n, const d3f_c
             if (((P.sl_chunks * P.sl_slices + 7) / 8) * 8 * P.sl_unit > 0x7fffffffLL) P.sl_slices = 0;
         }
     }
+#ifdef D3F_EXPERIMENTS
+    // EXPERIMENTS BUILD ONLY (round 3, measured and rejected): the persistent producer / consumer form of the
+    // channel-sliced launch (experiments/fuse_stream.hip): same eligibility, four views, finite maps.  D3F_EXP_STREAM=1 selects it; _T 12 / 16 / 24 points per
+    // tile, _VAR register-set variant, _R tiles per workgroup, _UNIT workgroups per unit, _LG 5 / 4 (512- / 256-byte slices).
+    if (P.sl_slices > 0 && exp_knob("D3F_EXP_STREAM") > 0 && views->V == 4 && (flags & D3F_FLAG_FINITE_MAPS) && P.maps[0].C % 128 == 0) {
+        int T = exp_knob("D3F_EXP_STREAM_T");
+        if (T != 12 && T != 16 && T != 24) T = 12;
+        int lg = exp_knob("D3F_EXP_STREAM_LG");
+        if (lg != 3 && lg != 4 && lg != 5) lg = 5;
+        if (P.maps[0].C % (4 << lg) != 0) lg = 5;
+        P.st_variant = exp_knob("D3F_EXP_STREAM_VAR");
+        P.walk_tx = T == 16 ? 2 : 3; P.walk_ty = 2; P.walk_tz = T == 12 ? 2 : 4;
+        P.st_lty = 1; P.st_ltz = T == 12 ? 1 : 2;
+        P.sl_lg = lg;
+        P.sl_slices = P.maps[0].C / (4 << lg);
+        P.sl_tiles = (int64_t)((P.walk_nx + P.walk_tx - 1) / P.walk_tx) * ((P.walk_ny + P.walk_ty - 1) / P.walk_ty) * ((P.walk_nz + P.walk_tz - 1) / P.walk_tz);
+        P.st_R = exp_knob("D3F_EXP_STREAM_R") > 0 ? exp_knob("D3F_EXP_STREAM_R") : 8;
+        P.sl_unit = exp_knob("D3F_EXP_STREAM_UNIT") > 0 ? exp_knob("D3F_EXP_STREAM_UNIT") : 192;
+        // small lattices: keep >= ~16 workgroups per CU slot in the launch
+        while (P.st_R > 1 && P.sl_tiles * P.sl_slices / P.st_R < 256 * 6 * 4) P.st_R >>= 1;
+        const int64_t per_chunk = (int64_t)P.sl_unit * P.st_R;
+        P.sl_chunks = (P.sl_tiles + per_chunk - 1) / per_chunk;
+        P.sl_groups = 0;
+        P.tile_pts = T; P.lds_pad = exp_knob("D3F_EXP_SLICED_PAD") > 0 ? exp_knob("D3F_EXP_SLICED_PAD") * 1024 : 0;
+        P.st_debug = exp_knob("D3F_EXP_STREAM_DEBUG");
+        if (exp_knob("D3F_EXP_STREAM_TICKETS") > 0 && !plan_only) {
+            P.st_tickets = d3f::stream_exp_tickets();
+            P.st_grid = exp_knob("D3F_EXP_STREAM_G") > 0 ? exp_knob("D3F_EXP_STREAM_G") : 96;
+            if (exp_knob("D3F_EXP_STREAM_PRE") > 0) {
+                const int64_t slots = P.sl_tiles * T;
+                char *buf = static_cast<char *>(d3f::stream_exp_scratch(slots * (views->V * 16 + 16)));
+                if (buf) { P.st_rec = buf; P.st_aux = buf + slots * views->V * 16; }
+            }
+        }
+        P.st_on = ((P.sl_chunks * P.sl_slices + 7) / 8) * 8 * P.sl_unit <= 0x7fffffffLL ? 1 : 0;
+        if (!P.st_on) P.sl_slices = 0;
+    }
+#endif
     if (window) {
         const int T = (win_knob == 32 || win_knob == 64 || win_knob == 128) ? win_knob : 64;
         P.tile_pts = T; P.lds_pad = 0;
@@ -496,7 +523,7 @@ int eval_common(const d3f_views *views, const float *pts, int64_t n, const d3f_c
     // the 256 MiB Infinity Cache), each taking a contiguous eighth of it (C2 dense 1.97 -> 1.74 ms, C4 patch 4.75 -> 4.17)
     P.xcd_chunk = (reorder && xcd_remap) ? (int)((32768 / P.tile_pts + 7) / 8 * 8) : 0;
     if ((flags >> 29) & 0x7) P.xcd_chunk = 1024 << (((flags >> 29) & 0x7) - 1);   // tuning: 1024 .. 65536 tiles
-    P.stage_offset = d3f::fused_lds_base(P.tile_pts, views->V);
+    P.crec_offset = d3f::fused_lds_base(P.tile_pts, views->V);
     // wide maps (>= 16 lanes per point): corner set-up once per (point, view) in phase A, 32 B of LDS each; the
     // cell-run maps come first -- they read their corners from these records
     P.n_pre = 0;
@@ -507,11 +534,10 @@ int eval_common(const d3f_views *views, const float *pts, int64_t n, const d3f_c
     } else if (!(flags & (1u << 28)))
         for (int s = 0; s < n_maps && P.n_pre < 2; ++s) {
             // 32 B per (point, view) and map: only while records + set-ups stay within 48 KiB (>= 3 workgroups per CU)
-            const long lds_after = (long)P.stage_offset + P.stage_floats * 8 + (long)(P.n_pre + 1) * P.tile_pts * views->V * 32;
-            if (P.maps[s].pre_slot < 0 && !P.maps[s].staged && P.maps[s].lpp_log2 >= 4 && !want_inter[s] && lds_after <= 48 * 1024)
+            const long lds_after = (long)P.crec_offset + (long)(P.n_pre + 1) * P.tile_pts * views->V * 32;
+            if (P.maps[s].pre_slot < 0 && P.maps[s].lpp_log2 >= 4 && !want_inter[s] && lds_after <= 48 * 1024)
                 P.maps[s].pre_slot = P.n_pre++;
         }
-    P.crec_offset = P.stage_offset + P.stage_floats * 8;
     int64_t ntiles = (n + P.tile_pts - 1) / P.tile_pts;
     if (walk)
         ntiles = (int64_t)((P.walk_nx + P.walk_tx - 1) / P.walk_tx) * ((P.walk_ny + P.walk_ty - 1) / P.walk_ty) *
@@ -522,11 +548,14 @@ int eval_common(const d3f_views *views, const float *pts, int64_t n, const d3f_c
         plan_out->reorder = walk ? 2 : (reorder ? 1 : 0);
         plan_out->lds_bytes = P.crec_offset + P.n_pre * P.tile_pts * P.V * 32 + P.lds_pad;
         plan_out->workgroups = P.sl_slices > 0 ? ((P.sl_chunks * P.sl_slices + 7) / 8) * 8 * P.sl_unit : ntiles;
+#ifdef D3F_EXPERIMENTS
+        if (P.st_on) plan_out->lds_bytes = d3f::stream_lds_bytes(P.tile_pts, P.V) + P.lds_pad;
+#endif
         if (P.win_slices > 0) {
             plan_out->lds_bytes = P.win_pool_offset + (2 + P.win_pool_texels) * 512 * P.win_u;
             plan_out->workgroups = ntiles;
         }
-        plan_out->reserved = P.sl_slices > 0 ? 100 + P.sl_lg * 10 + P.sl_vc : (P.win_slices > 0 ? 2000 + 100 * P.win_u + 10 * (P.win_u == 1 ? (P.win_lpp == 16 ? 2 : 4) : (P.win_u == 4 ? 1 : P.win_vc)) + (P.win_u == 1 ? (P.win_occ >= 4 ? 4 : (P.win_lpp == 16 ? 3 : P.win_occ)) : 2) : 0);   // 2UVW: the window kernel's template arguments      // 1LV: sliced launch, L = log2(lanes per point), V = views in flight
+        plan_out->reserved = P.st_on ? 3000 + P.sl_lg * 100 + P.st_variant : P.sl_slices > 0 ? 100 + P.sl_lg * 10 + P.sl_vc : (P.win_slices > 0 ? 2000 + 100 * P.win_u + 10 * (P.win_u == 1 ? (P.win_lpp == 16 ? 2 : 4) : (P.win_u == 4 ? 1 : P.win_vc)) + (P.win_u == 1 ? (P.win_occ >= 4 ? 4 : (P.win_lpp == 16 ? 3 : P.win_occ)) : 2) : 0);   // 2UVW: the window kernel's template arguments      // 1LV: sliced launch, L = log2(lanes per point), V = views in flight
         for (int s = 0; s < n_maps; ++s)
             if (P.maps[s].runs > 0) {        // waves per SIMD the chosen cell-run kernel variant is built for
                 const int ru = P.maps[s].unroll, rk = P.maps[s].runs;
@@ -538,14 +567,18 @@ int eval_common(const d3f_views *views, const float *pts, int64_t n, const d3f_c
             plan_out->vector_floats[c] = on ? P.maps[s].vw : 0;
             plan_out->lanes_per_point[c] = on ? ((P.win_slices > 0 && s == 0) ? P.win_lpp : (1 << P.maps[s].lpp_log2)) : 0;
             plan_out->vectors_per_lane[c] = on ? ((P.win_slices > 0 && s == 0) ? P.win_u * (32 / P.win_lpp) : P.maps[s].unroll) : 0;   /* negative: load-use per vector */
-            plan_out->staged[c] = on ? (P.win_slices > 0 && s == 0 ? 3 : (P.maps[s].runs > 0 ? 16 + P.maps[s].runs : P.maps[s].staged)) : 0;
+            plan_out->staged[c] = on ? (P.win_slices > 0 && s == 0 ? 3 : (P.maps[s].runs > 0 ? 16 + P.maps[s].runs : 0)) : 0;
         }
         return D3F_OK;
     }
     hipEvent_t ev0 = g_prof_start, ev1 = g_prof_stop;
     g_prof_start = g_prof_stop = nullptr;
     if (ev0) (void)hipEventRecord(ev0, hs);
+#ifdef D3F_EXPERIMENTS
+    hipError_t e = P.st_on ? d3f::launch_fused_stream(P, hs) : d3f::launch_fused_eval(P, mode, hs);
+#else
     hipError_t e = d3f::launch_fused_eval(P, mode, hs);
+#endif
     if (ev1) (void)hipEventRecord(ev1, hs);
     if (e != hipSuccess) return hip_fail(e, "fused_eval launch");
     return D3F_OK;
@@ -556,7 +589,15 @@ int eval_common(const d3f_views *views, const float *pts, int64_t n, const d3f_c
 extern "C" {
 
 int d3f_abi_version(void) { return D3F_ABI_VERSION; }
-const char *d3f_version(void) { return "d3fields-hip 0.1.0 gfx950"; }
+const char *d3f_version(void) { return "d3fields-hip 0.3.0 gfx950"; }
+int d3f_build_has_experiments(void)
+{
+#ifdef D3F_EXPERIMENTS
+    return 1;
+#else
+    return 0;
+#endif
+}
 const char *d3f_last_error(void) { return g_err; }
 
 int d3f_eval(const d3f_views *views, const float *pts, int64_t n, const d3f_channel_map *maps, int32_t n_maps,

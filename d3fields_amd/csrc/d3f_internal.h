@@ -22,7 +22,6 @@ struct MapDesc {
     int32_t lpp_log2;  // log2(lanes per point) in phase B
     int32_t unroll;    // channel vectors per lane per pass: +1..+3 batched loads, -1..-4 load-use per vector
     int32_t pre_slot;  // >= 0: bilinear corner set-up of this map is precomputed per (point, view) in LDS slot pre_slot
-    int32_t staged;    // 2: gather through wave-private LDS texel windows (opt-in experiment)
     int32_t esize;     // bytes per stored channel: 4 (fp32) or 2 (fp16 storage, widened on load)
     int32_t runs;      // > 0: cell-run gather (gather_map_runs): a lane group walks `runs` consecutive points view by view
 };
@@ -39,8 +38,6 @@ struct EvalParams {
     int32_t n_maps;
     int32_t tile_pts;  // points per workgroup
     int32_t lds_pad;   // extra dynamic LDS bytes (occupancy throttle, tuning only)
-    int32_t stage_offset;  // byte offset of the two LDS stage buffers (staged maps), 16-B aligned
-    int32_t stage_floats;  // floats per stage buffer, 0 = no staged map
     int32_t crec_offset;   // byte offset of the precomputed corner records, 16-B aligned
     int32_t n_pre;         // number of maps with precomputed corner records
     int32_t xcd_chunk;     // tiles per XCD-mapping chunk (multiple of 8), 0 = the whole launch
@@ -53,6 +50,15 @@ struct EvalParams {
     int32_t sl_unit;                   // workgroups (of 32 points) per unit
     int32_t sl_slices, sl_lg, sl_vc;   // slices per texel of map 0, log2(lanes per point), views with loads in flight
     int64_t sl_tiles, sl_groups, sl_chunks;   // walk tiles, groups of 4 tiles, chunks of 128 groups
+    // persistent producer / consumer form of the channel-sliced launch (fuse_stream.hip): st_on > 0 selects it.  It reuses
+    // sl_slices / sl_lg / sl_tiles / sl_chunks / sl_unit (workgroups per unit); a unit's chunk is sl_unit * st_R tiles
+    int32_t st_on, st_R;               // tiles per workgroup
+    int32_t st_lty, st_ltz;            // log2 of the tile brick's y and z sides (walk_ty, walk_tz; walk_tx is free)
+    int32_t st_variant;                // 0: two register sets (pipelined rounds), 1: one set, 2: one set of four views
+    int32_t st_debug;                  // experiments: 1 consumers idle, 2 producer idle after three tiles (results wrong)
+    int32_t st_grid;                   // ticket mode: persistent workgroups per XCD
+    void *st_rec, *st_aux;             // geometry pre-pass record stream (experiment), or nullptr
+    unsigned int *st_tickets;          // eight device counters (one per XCD stream), or nullptr: static tile assignment
     // LDS texel windows (fused_eval_window_kernel): win_slices > 0 selects it
     int32_t win_slices;        // channel slices of 128 * win_u channels per texel of map 0 (looped inside the workgroup)
     int32_t win_u, win_vc;     // 16-byte vectors per lane (1..4), views with corner reads in flight
@@ -71,8 +77,14 @@ struct EvalParams {
 
 // LDS bytes in front of the stage buffers: records, cnt/flag/idx, KRt, per-view windows
 inline int fused_lds_base(int tile_pts, int V) { return ((tile_pts * V * 24 + tile_pts * 12 + V * 48 + V * 16) + 15) / 16 * 16; }
-constexpr int kStageFloats = 6912;      // half of the LDS stage area in floats: 4 wave regions of 3456 floats in total
 hipError_t launch_fused_eval(const EvalParams &P, int mode, hipStream_t stream);
+// fuse_stream.hip
+int stream_lds_bytes(int tile_pts, int V);
+hipError_t launch_fused_stream(const EvalParams &P, hipStream_t stream);
+#ifdef D3F_EXPERIMENTS
+unsigned int *stream_exp_tickets();
+void *stream_exp_scratch(int64_t bytes);
+#endif
 
 // fuse_backward.hip
 struct BackwardParams {

@@ -23,408 +23,10 @@
 
 #include "d3f_internal.h"
 #include "d3f_device.h"
+#include "fuse_common.h"
 
 namespace d3f {
 
-// ---- per-(point,view) arithmetic: identical, operation for operation, to the oracle -----
-
-struct ViewRec {
-    float gx, gy;   // normalised image coordinates   (fusion.py:72-73)
-    float wgt;      // exp(clamp(mu-|dist|,max=0)/mu)  (fusion.py:347)
-    float valid;    // 1.0f / 0.0f                     (fusion.py:344)
-};
-
-// Bilinear corner set-up of one (point, view) for one map (grid_sample, align_corners=True, zeros padding).
-struct Corner {
-    uint32_t onw, one, osw, ose;    // 32-bit BYTE offsets of the clamped corner texels from the view's base
-    float wnw, wne, wsw, wse;       // bilinear weights
-    bool inw, ine, isw, ise;        // corner inside the map?
-};
-
-// Coordinates are clamped into the map so that every address is valid; out-of-bounds corners become the
-// zeros of padding_mode='zeros' by zeroing the weight (finite operands) or by a select on the value.
-__device__ __forceinline__ Corner corner_setup(const MapDesc &m, float gx, float gy)
-{
-    Corner c;
-    const float fwm1 = (float)(m.fw - 1), fhm1 = (float)(m.fh - 1);
-    const uint32_t es = (uint32_t)m.esize;
-    const uint32_t sy_b = (uint32_t)m.sy * es, sx_b = (uint32_t)m.sx * es;   // host guarantees a view spans < 4 GiB
-    const float ix = unnormalize(gx, m.fw), iy = unnormalize(gy, m.fh);
-    const float x0 = floorf(ix), y0 = floorf(iy);
-    const float tx = ix - x0, ty = iy - y0;
-    const float ex = 1.0f - tx, sy = 1.0f - ty;
-    c.wnw = sy * ex; c.wne = sy * tx; c.wsw = ty * ex; c.wse = ty * tx;
-    const float x1 = x0 + 1.0f, y1 = y0 + 1.0f;
-    c.inw = in_bounds(x0, y0, m.fw, m.fh); c.ine = in_bounds(x1, y0, m.fw, m.fh);
-    c.isw = in_bounds(x0, y1, m.fw, m.fh); c.ise = in_bounds(x1, y1, m.fw, m.fh);
-    const int xi0 = (int)fminf(fmaxf(x0, 0.0f), fwm1), xi1 = (int)fminf(fmaxf(x1, 0.0f), fwm1);
-    const int yi0 = (int)fminf(fmaxf(y0, 0.0f), fhm1), yi1 = (int)fminf(fmaxf(y1, 0.0f), fhm1);
-    const uint32_t r0 = (uint32_t)yi0 * sy_b, r1 = (uint32_t)yi1 * sy_b;
-    const uint32_t q0 = (uint32_t)xi0 * sx_b, q1 = (uint32_t)xi1 * sx_b;
-    c.onw = r0 + q0; c.one = r0 + q1; c.osw = r1 + q0; c.ose = r1 + q1;
-    return c;
-}
-
-// The same set-up computed ONCE per (point, view) in phase A (one lane per pair) for wide maps, so that the
-// 2^k lanes of a point's group read 32 bytes from LDS instead of repeating ~45 VALU instructions each.
-struct __attribute__((aligned(16))) CornerRec {
-    uint32_t o[4];      // onw, one, osw, ose
-    float w[4];         // weights with out-of-bounds corners already zeroed (non-strict path only)
-};
-
-// Gathers map `m` for the points of this workgroup's tile.
-//   VW  channel-vector width in floats (4 when C%4==0 and 16-B aligned, else 2 or 1)
-//   U   channel vectors per lane per pass
-// A group of LPP = 1<<lpp_log2 lanes serves one point; lane g of the group owns channel
-// vectors  pass*LPP*U + u*LPP + g  (u < U), so one load instruction of a group covers
-// LPP*VW*4 contiguous bytes of a texel.
-//   HALF  the map is stored in fp16 (D3F_DTYPE_F16): VW = 8 channels per 16-B load (or scalar lanes), widened to
-//         fp32 on load; everything after the load is the fp32 path
-// Output rows are written once and never read again by the launch: they leave as `sc1` stores, which drop the line from
-// the XCD's L2 after the write instead of occupying capacity the texels could use (MI355X_MICROARCH.md, stores of each
-// flavour; measured r2f: C2 dense 1.631 -> 1.620 ms, C3 dense 3.103 -> 3.059, C2 patch 0.645 -> 0.634).
-// D3F_EXP_STORE=-1 restores plain stores.
-template <typename VT>
-__device__ __forceinline__ void store_out(float *p, VT v, int policy)
-{
-    if constexpr (sizeof(VT) == 16) {
-        if (policy == 1) {
-            // s_nop 1: a VMEM store of more than 64 bits reads its data registers for two more cycles on gfx940+; the
-            // compiler inserts those wait states for its own stores but cannot see inside the asm, and a VALU write
-            // to v scheduled right behind it tore dwords of some lanes (found with the 2-vector window kernel)
-            asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
-            return;
-        }
-    }
-    store_vec<VT>(p, v);
-}
-
-// The full IEEE division of the strict path.  The empty volatile asm keeps it inside its (rare) branch: without it the
-// compiler if-converts `strict ? a / d : fast` and every point pays the ~11 instructions per channel of the division
-// it does not use (44 of ~120 VALU instructions per point and channel vector in the epilogues, measured round 2).
-// the same store addressed as (uniform base, 32-bit byte offset): rows of outputs below 4 GiB need no 64-bit arithmetic
-__device__ __forceinline__ void store_out_off(float *base, uint32_t off, f32x4 v, int policy)
-{
-    if (policy == 1) {
-        asm volatile("global_store_dwordx4 %0, %1, %2 sc1\n\ts_nop 1" ::"v"(off), "v"(v), "s"(base) : "memory");
-        return;
-    }
-    *reinterpret_cast<f32x4 *>(reinterpret_cast<char *>(base) + off) = v;
-}
-
-template <typename VT>
-__device__ __forceinline__ VT strict_div(VT a, float d)
-{
-    asm volatile("" ::);
-    return a / d;
-}
-
-template <int VW, int U, bool BATCH, bool HALF = false>
-__device__ __forceinline__ void gather_map(const MapDesc &m, const EvalParams &P, const ViewRec *rec,
-                                           const float *cnt_s, const uint32_t *flag_s,
-                                           const uint32_t *idx_s, int64_t idx_base, int tile_n, const CornerRec *crec,
-                                           bool only_strict = false)
-{
-    using VT = typename Vec<VW>::T;
-    const int lpp = 1 << m.lpp_log2;
-    const int g = threadIdx.x & (lpp - 1);
-    const int grp = threadIdx.x >> m.lpp_log2;
-    const int ngrp = kBlock >> m.lpp_log2;
-    const int cvec = m.C / VW;
-    const int V = P.V;
-    const float *__restrict__ data = m.data;
-    constexpr int ES = HALF ? 2 : 4;                  // bytes per stored channel
-
-    for (int p = grp; p < tile_n; p += ngrp) {
-        const int64_t i = idx_base + idx_s[p];
-        const float cnt = cnt_s[p];
-        const bool all_invalid = (cnt == 0.0f);           // fusion.py:366
-        const float denom = cnt + 1e-6f;                  // fusion.py:385
-        const bool strict = (flag_s[p] != 0u) || (m.inter != nullptr);
-        if (only_strict && !strict) continue;             // the cell-run gather already wrote this point
-        for (int c0 = 0; c0 < cvec; c0 += lpp * U) {
-            VT acc[U];
-#pragma unroll
-            for (int u = 0; u < U; ++u) acc[u] = (VT)0.0f;
-            for (int v = 0; v < V; ++v) {
-                const ViewRec r = rec[p * V + v];
-                if (!strict && r.valid == 0.0f) continue;  // exact: +0 + (+-0) == +0, x + (+-0) == x
-                // Branch-free corner fetch: all 4*U loads are unconditional `global_load v, v_off32, s[base]`
-                // (wave-uniform per-view base + 32-bit byte offset of a clamped, always valid texel).
-                Corner c;
-                float w0, w1, w2, w3;
-                if (!strict && crec) {
-                    const CornerRec cr = crec[p * V + v];
-                    c.onw = cr.o[0]; c.one = cr.o[1]; c.osw = cr.o[2]; c.ose = cr.o[3];
-                    w0 = cr.w[0]; w1 = cr.w[1]; w2 = cr.w[2]; w3 = cr.w[3];
-                } else {
-                    c = corner_setup(m, r.gx, r.gy);
-                    w0 = c.inw ? c.wnw : 0.0f; w1 = c.ine ? c.wne : 0.0f; w2 = c.isw ? c.wsw : 0.0f; w3 = c.ise ? c.wse : 0.0f;
-                }
-                const char *bv = reinterpret_cast<const char *>(data) + (int64_t)v * m.sv * ES;
-                typename Raw<VW, HALF>::T a[U], b[U], d[U], e[U];      // as stored; widened to fp32 at the use
-                if (BATCH) {
-                    // cache-resident maps: all 4*U loads in flight before the first use (latency-bound regime)
-#pragma unroll
-                    for (int u = 0; u < U; ++u) {
-                        const int cv = min(c0 + u * lpp + g, cvec - 1);     // idle lanes re-read the last vector
-                        const uint32_t co = (uint32_t)cv * (VW * ES);
-                        a[u] = load_texel<VW, HALF>(bv + (c.onw + co));
-                        b[u] = load_texel<VW, HALF>(bv + (c.one + co));
-                        d[u] = load_texel<VW, HALF>(bv + (c.osw + co));
-                        e[u] = load_texel<VW, HALF>(bv + (c.ose + co));
-                    }
-                }
-                if (!strict) {
-                    // Finite maps, finite coordinates, valid view: a zero WEIGHT is the zeros padding
-                    // (x*0 == +-0 for finite x, and +-0 never changes the sums below), valid_v == 1.
-#pragma unroll
-                    for (int u = 0; u < U; ++u) {
-                        if (!BATCH) {      // maps larger than the caches: a smaller in-flight footprint measured faster
-                            const uint32_t co = (uint32_t)min(c0 + u * lpp + g, cvec - 1) * (VW * ES);
-                            a[u] = load_texel<VW, HALF>(bv + (c.onw + co));
-                            b[u] = load_texel<VW, HALF>(bv + (c.one + co));
-                            d[u] = load_texel<VW, HALF>(bv + (c.osw + co));
-                            e[u] = load_texel<VW, HALF>(bv + (c.ose + co));
-                        }
-                        VT s = widen<VW, HALF>(a[u]) * w0; // ATen bilinear: fma chain nw,ne,sw,se
-                        s = v_fma<VT>(widen<VW, HALF>(b[u]), w1, s);
-                        s = v_fma<VT>(widen<VW, HALF>(d[u]), w2, s);
-                        s = v_fma<VT>(widen<VW, HALF>(e[u]), w3, s);
-                        acc[u] = acc[u] + s * r.wgt;       // fusion.py:385
-                        if (!BATCH) __builtin_amdgcn_sched_barrier(0);   // keep the next vector's loads behind this use
-                    }
-                } else {
-#pragma unroll
-                    for (int u = 0; u < U; ++u) {
-                        if (!BATCH) {
-                            const uint32_t co = (uint32_t)min(c0 + u * lpp + g, cvec - 1) * (VW * ES);
-                            a[u] = load_texel<VW, HALF>(bv + (c.onw + co));
-                            b[u] = load_texel<VW, HALF>(bv + (c.one + co));
-                            d[u] = load_texel<VW, HALF>(bv + (c.osw + co));
-                            e[u] = load_texel<VW, HALF>(bv + (c.ose + co));
-                        }
-                        const VT av = c.inw ? widen<VW, HALF>(a[u]) : (VT)0.0f, bvv = c.ine ? widen<VW, HALF>(b[u]) : (VT)0.0f;
-                        const VT dv = c.isw ? widen<VW, HALF>(d[u]) : (VT)0.0f, ev = c.ise ? widen<VW, HALF>(e[u]) : (VT)0.0f;
-                        VT s = av * c.wnw;
-                        s = v_fma<VT>(bvv, c.wne, s);
-                        s = v_fma<VT>(dv, c.wsw, s);
-                        s = v_fma<VT>(ev, c.wse, s);
-                        const int cv = c0 + u * lpp + g;
-                        if (m.inter && cv < cvec)          // '<k>_inter' [V,n,C]  fusion.py:389
-                            store_vec<VT>(m.inter + ((int64_t)v * P.n + i) * m.C + cv * VW, s);
-                        acc[u] = acc[u] + (s * r.valid) * r.wgt;        // fusion.py:385
-                    }
-                }
-            }
-            // acc / (cnt + 1e-6)  (fusion.py:385).  All channels of a point share the divisor, so the IEEE
-            // division is unrolled by hand with the reciprocal refined ONCE: the same rcp + fma sequence the
-            // compiler expands `/` into (v_rcp, 2 fma on the reciprocal, then mul + 4 fma per quotient), minus
-            // its operand pre-scaling and special-case fix-up, which cannot trigger here: the divisor lies in
-            // [1, V+1) and on this path every numerator is finite.  Bit-identical quotients, 5 instead of 11
-            // instructions per channel.  Strict points (non-finite operands possible) keep the full division.
-            float rcp_d = 0.0f;
-            if (!strict) {
-                const float r0 = __builtin_amdgcn_rcpf(denom);
-                rcp_d = fmaf(fmaf(-denom, r0, 1.0f), r0, r0);
-            }
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const int cv = c0 + u * lpp + g;
-                if (cv < cvec) {
-                    VT o;
-                    if (all_invalid) {
-                        o = (VT)0.0f;                                          // fusion.py:386
-                    } else if (strict) {
-                        o = strict_div<VT>(acc[u], denom);
-                    } else {
-                        VT q = acc[u] * rcp_d;
-                        q = v_fma<VT>(v_fma<VT>(q, -denom, acc[u]), rcp_d, q);
-                        q = v_fma<VT>(v_fma<VT>(q, -denom, acc[u]), rcp_d, q);
-                        o = q;
-                    }
-                    store_out<VT>(m.out + i * m.C + (int64_t)cv * VW, o, P.store_policy);
-                }
-            }
-        }
-    }
-}
-
-// ---- phase B, LDS-staged variant (opt-in experiment, D3F_TUNE_STAGING) ---------------------------------
-// When a map has far fewer texels than the image has pixels (the reference's dino_feats is
-// (H/10, W/10), fusion.py:694-697) spatially close points fall into a handful of texel cells, so a texel
-// window can be copied ONCE into LDS (coalesced 16-B loads) and the corner reads become ds_read_b128.
-// The arithmetic and its order are exactly those of gather_map (bit-identical results, tested); a view
-// whose window does not fit is gathered directly.  Measured on MI355X it LOSES to the direct gather
-// (C2 patch 0.74 -> 1.7-1.9 ms, both as 32-point workgroup windows behind barriers and as the
-// wave-private form below): 5x fewer L1 loads, but the dependent window -> load -> LDS -> read chain runs
-// at 2 waves/SIMD while the direct gather keeps 4 waves x 12 independent loads in flight.  Kept opt-in.
-template <int U, bool FROM_LDS>
-__device__ __forceinline__ void staged_accumulate(const MapDesc &m, const EvalParams &P, const ViewRec &r, int v, int64_t i,
-                                                  int c0, int lpp, int g, int cvec, const float *__restrict__ buf,
-                                                  int xmin, int ymin, int bw, int pass_vecs, f32x4 (&acc)[U])
-{
-    using VT = f32x4;
-    const float ix = unnormalize(r.gx, m.fw), iy = unnormalize(r.gy, m.fh);
-    const float x0 = floorf(ix), y0 = floorf(iy);
-    const float tx = ix - x0, ty = iy - y0;
-    const float ex = 1.0f - tx, sy = 1.0f - ty;
-    const float wnw = sy * ex, wne = sy * tx, wsw = ty * ex, wse = ty * tx;
-    const float x1 = x0 + 1.0f, y1 = y0 + 1.0f;
-    const bool inw = in_bounds(x0, y0, m.fw, m.fh), ine = in_bounds(x1, y0, m.fw, m.fh);
-    const bool isw = in_bounds(x0, y1, m.fw, m.fh), ise = in_bounds(x1, y1, m.fw, m.fh);
-    const int xi0 = (inw || isw) ? (int)x0 : 0, yi0 = (inw || ine) ? (int)y0 : 0;
-    const int xi1 = (ine || ise) ? (int)x1 : 0, yi1 = (isw || ise) ? (int)y1 : 0;
-    const float *pnw, *pne, *psw, *pse;
-    if (FROM_LDS) {
-        const int tstride = pass_vecs * 4;                      // floats per staged texel
-        pnw = buf + ((yi0 - ymin) * bw + (xi0 - xmin)) * tstride;
-        pne = buf + ((yi0 - ymin) * bw + (xi1 - xmin)) * tstride;
-        psw = buf + ((yi1 - ymin) * bw + (xi0 - xmin)) * tstride;
-        pse = buf + ((yi1 - ymin) * bw + (xi1 - xmin)) * tstride;
-    } else {
-        const float *bv = m.data + (int64_t)v * m.sv + (int64_t)c0 * 4;
-        pnw = bv + (int64_t)yi0 * m.sy + (int64_t)xi0 * m.sx;
-        pne = bv + (int64_t)yi0 * m.sy + (int64_t)xi1 * m.sx;
-        psw = bv + (int64_t)yi1 * m.sy + (int64_t)xi0 * m.sx;
-        pse = bv + (int64_t)yi1 * m.sy + (int64_t)xi1 * m.sx;
-    }
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-        const int lv = u * lpp + g;                             // vector index inside the pass
-        if (c0 + lv < cvec) {
-            const int co = lv * 4;
-            VT a = inw ? load_vec<VT>(pnw + co) : (VT)0.0f;
-            VT b = ine ? load_vec<VT>(pne + co) : (VT)0.0f;
-            VT d = isw ? load_vec<VT>(psw + co) : (VT)0.0f;
-            VT e = ise ? load_vec<VT>(pse + co) : (VT)0.0f;
-            VT s = a * wnw;
-            s = v_fma<VT>(b, wne, s);
-            s = v_fma<VT>(d, wsw, s);
-            s = v_fma<VT>(e, wse, s);
-            if (m.inter) store_vec<VT>(m.inter + ((int64_t)v * P.n + i) * m.C + (int64_t)(c0 + lv) * 4, s);
-            VT t = (s * r.valid) * r.wgt;
-            acc[u] = acc[u] + t;
-        }
-    }
-}
-
-// ---- phase B, wave-private staging ------------------------------------------------------------------
-// No workgroup barriers: every WAVE owns 8 consecutive points of
-// the Morton walk (a ~1-cm cube), stages the texel window of those 8 points for one view into its private
-// quarter of the stage area, and reads the 8 x 4 corners back with ds_read_b128.  LDS operations of one
-// wave execute in issue order, so only compiler reordering has to be fenced (wave_barrier), and the waves
-// of a workgroup never wait for each other.  8 points touch ~4-9 distinct texels per view instead of 32
-// corner fetches.  Requires 32 lanes per point (lpp_log2 == 5), VW == 4, tile_n <= 32 (host-enforced).
-template <int U>
-__device__ __forceinline__ void gather_map_wave_staged(const MapDesc &m, const EvalParams &P, const ViewRec *rec,
-                                                       const float *cnt_s, const uint32_t *flag_s, const uint32_t *idx_s,
-                                                       int64_t idx_base, int tile_n, float *stage, int region_floats)
-{
-    using VT = f32x4;
-    constexpr int kRegsW = 14;                  // float4 per lane per window: 14 * 64 * 16 B = 14 KiB >= one region
-    const int lane = threadIdx.x & 63, half = lane >> 5, g = lane & 31, wave = threadIdx.x >> 6;
-    const int cvec = m.C / 4;
-    const int V = P.V;
-    const bool want_inter = m.inter != nullptr;
-    float *wbuf = stage + (size_t)wave * region_floats;
-    const int p_base = wave * 8;
-
-    for (int c0 = 0; c0 < cvec; c0 += 32 * U) {
-        const int pass_vecs = min(32 * U, cvec - c0);
-        VT acc[4][U];
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int u = 0; u < U; ++u) acc[j][u] = (VT)0.0f;
-        for (int v = 0; v < V; ++v) {
-            // window of the wave's 8 points: lanes 0..7 take one point each, butterfly min/max over 8 lanes
-            int xa = INT_MAX, xb = INT_MIN, ya = INT_MAX, yb = INT_MIN;
-            {
-                const int p = p_base + (lane & 7);
-                if (p < tile_n) {
-                    const ViewRec r = rec[p * V + v];
-                    const bool strict = (flag_s[p] != 0u) || want_inter;
-                    if (strict || r.valid != 0.0f) {
-                        const float x0 = floorf(unnormalize(r.gx, m.fw)), y0 = floorf(unnormalize(r.gy, m.fh));
-                        if (x0 >= -1.0f && x0 <= (float)(m.fw - 1) && y0 >= -1.0f && y0 <= (float)(m.fh - 1)) {
-                            xa = max((int)x0, 0); xb = min((int)x0 + 1, m.fw - 1);
-                            ya = max((int)y0, 0); yb = min((int)y0 + 1, m.fh - 1);
-                        }
-                    }
-                }
-            }
-#pragma unroll
-            for (int off = 1; off < 8; off <<= 1) {
-                xa = min(xa, __shfl_xor(xa, off, 64)); xb = max(xb, __shfl_xor(xb, off, 64));
-                ya = min(ya, __shfl_xor(ya, off, 64)); yb = max(yb, __shfl_xor(yb, off, 64));
-            }
-            const int xmin = __builtin_amdgcn_readfirstlane(xa), xmax = __builtin_amdgcn_readfirstlane(xb);
-            const int ymin = __builtin_amdgcn_readfirstlane(ya), ymax = __builtin_amdgcn_readfirstlane(yb);
-            const int bw = xmax - xmin + 1, bh = ymax - ymin + 1;
-            const bool nonempty = (xmin <= xmax) && (ymin <= ymax);
-            const bool fits = nonempty && (bw * bh * pass_vecs * 4 <= region_floats);
-            __builtin_amdgcn_wave_barrier();            // previous view's ds_reads stay ahead of these ds_writes
-            if (fits) {
-                const int total = bw * bh * pass_vecs;
-                const float *src = m.data + (int64_t)v * m.sv + (int64_t)c0 * 4;
-                // two batches of 7 float4 per lane (7 KiB in flight per wave) keep the register count at 2 waves/SIMD
-#pragma unroll 1
-                for (int k0 = 0; k0 < kRegsW; k0 += 7) {
-                    if (k0 * 64 >= total) break;
-                    VT tmp[7];
-#pragma unroll
-                    for (int k = 0; k < 7; ++k) {
-                        const int e = lane + (k0 + k) * 64;
-                        if (e < total) {
-                            const int texel = e / pass_vecs, lv = e - texel * pass_vecs;
-                            const int wy = texel / bw, wx = texel - wy * bw;
-                            tmp[k] = load_vec<VT>(src + (int64_t)(ymin + wy) * m.sy + (int64_t)(xmin + wx) * m.sx + lv * 4);
-                        }
-                    }
-#pragma unroll
-                    for (int k = 0; k < 7; ++k) {
-                        const int e = lane + (k0 + k) * 64;
-                        if (e < total) store_vec<VT>(wbuf + (int64_t)e * 4, tmp[k]);
-                    }
-                }
-            }
-            __builtin_amdgcn_wave_barrier();            // ds_writes above stay ahead of the ds_reads below
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int p = p_base + 2 * j + half;
-                if (p < tile_n) {
-                    const ViewRec r = rec[p * V + v];
-                    const bool strict = (flag_s[p] != 0u) || want_inter;
-                    if (strict || r.valid != 0.0f) {
-                        const int64_t i = idx_base + idx_s[p];
-                        if (fits)
-                            staged_accumulate<U, true>(m, P, r, v, i, c0, 32, g, cvec, wbuf, xmin, ymin, bw, pass_vecs, acc[j]);
-                        else
-                            staged_accumulate<U, false>(m, P, r, v, i, c0, 32, g, cvec, nullptr, 0, 0, 0, pass_vecs, acc[j]);
-                    }
-                }
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int p = p_base + 2 * j + half;
-            if (p < tile_n) {
-                const int64_t i = idx_base + idx_s[p];
-                const float cnt = cnt_s[p];
-                const float denom = cnt + 1e-6f;
-#pragma unroll
-                for (int u = 0; u < U; ++u) {
-                    const int cv = c0 + u * 32 + g;
-                    if (cv < cvec) {
-                        VT o = (cnt == 0.0f) ? (VT)0.0f : acc[j][u] / denom;
-                        store_vec<VT>(m.out + i * m.C + (int64_t)cv * 4, o);
-                    }
-                }
-            }
-        }
-    }
-}
 
 // ---- phase B, cell-run gather (patch-resolution wide maps) ------------------------------------------------
 // When a texel spans many image pixels (the reference's dino_feats is (H/10, W/10), fusion.py:694-697) consecutive
@@ -539,125 +141,6 @@ __device__ __forceinline__ void gather_map_runs(const MapDesc &m, const EvalPara
     }
 }
 
-// ---- thin maps (the instance mask, colours: <= 4 lanes per point): the views in parallel across lanes ----------------
-// gather_map walks the views one after the other, which for a map of one vector per lane is V dependent
-// load round trips per point with next to nothing to overlap them.  Here a lane owns (point, view, vector): the
-// 4 corner loads of all views of a point are in flight together, and the ordered sum over the views
-// (((0 + t_0) + t_1) + ...) is rebuilt with V wave shuffles -- the same operands in the same order as the
-// sequential loop (a skipped invalid view adds +0, which is exact, see gather_map), bit-identical results.
-template <typename VT> __device__ __forceinline__ VT shfl_vec(VT x, int src);
-template <> __device__ __forceinline__ float shfl_vec<float>(float x, int src) { return __shfl(x, src, 64); }
-template <> __device__ __forceinline__ f32x2 shfl_vec<f32x2>(f32x2 x, int src)
-{
-    f32x2 r; r.x = __shfl(x.x, src, 64); r.y = __shfl(x.y, src, 64); return r;
-}
-template <> __device__ __forceinline__ f32x4 shfl_vec<f32x4>(f32x4 x, int src)
-{
-    f32x4 r; r.x = __shfl(x.x, src, 64); r.y = __shfl(x.y, src, 64); r.z = __shfl(x.z, src, 64); r.w = __shfl(x.w, src, 64);
-    return r;
-}
-
-__device__ __forceinline__ bool thin_map(const MapDesc &m, const EvalParams &P, int VW)
-{
-    return m.unroll == 1 && m.lpp_log2 <= 2 && m.C / VW <= (1 << m.lpp_log2) && P.V >= 2 && P.V <= P.thin_max_views;
-}
-
-template <int VW>
-__device__ __forceinline__ void gather_map_thin(const MapDesc &m, const EvalParams &P, const ViewRec *rec,
-                                                const float *cnt_s, const uint32_t *flag_s,
-                                                const uint32_t *idx_s, int64_t idx_base, int tile_n)
-{
-    using VT = typename Vec<VW>::T;
-    const int V = P.V;
-    const int vp_log2 = V <= 2 ? 1 : V <= 4 ? 2 : 3;
-    const int sh = m.lpp_log2 + vp_log2;               // lanes of one point: <= 32, inside one wave
-    const int lpp = 1 << m.lpp_log2;
-    const int g = threadIdx.x & (lpp - 1);
-    const int v = (threadIdx.x >> m.lpp_log2) & ((1 << vp_log2) - 1);
-    const int npts = kBlock >> sh;
-    const int base = (threadIdx.x & 63) & ~((1 << sh) - 1);
-    const int cvec = m.C / VW;
-    const uint32_t co = (uint32_t)min(g, cvec - 1) * (VW * 4);
-
-    for (int p = threadIdx.x >> sh; p < tile_n; p += npts) {
-        const int64_t i = idx_base + idx_s[p];
-        const float cnt = cnt_s[p];
-        const bool strict = (flag_s[p] != 0u) || (m.inter != nullptr);
-        VT t = (VT)0.0f;
-        if (v < V) {
-            const ViewRec r = rec[p * V + v];
-            if (strict || r.valid != 0.0f) {
-                const Corner c = corner_setup(m, r.gx, r.gy);
-                const char *bv = reinterpret_cast<const char *>(m.data) + (int64_t)v * m.sv * 4;
-                const VT a = load_texel<VW, false>(bv + (c.onw + co));
-                const VT b = load_texel<VW, false>(bv + (c.one + co));
-                const VT d = load_texel<VW, false>(bv + (c.osw + co));
-                const VT e = load_texel<VW, false>(bv + (c.ose + co));
-                if (!strict) {
-                    const float w0 = c.inw ? c.wnw : 0.0f, w1 = c.ine ? c.wne : 0.0f;
-                    const float w2 = c.isw ? c.wsw : 0.0f, w3 = c.ise ? c.wse : 0.0f;
-                    VT s = a * w0;
-                    s = v_fma<VT>(b, w1, s);
-                    s = v_fma<VT>(d, w2, s);
-                    s = v_fma<VT>(e, w3, s);
-                    t = s * r.wgt;
-                } else {
-                    const VT av = c.inw ? a : (VT)0.0f, bvv = c.ine ? b : (VT)0.0f;
-                    const VT dv = c.isw ? d : (VT)0.0f, ev = c.ise ? e : (VT)0.0f;
-                    VT s = av * c.wnw;
-                    s = v_fma<VT>(bvv, c.wne, s);
-                    s = v_fma<VT>(dv, c.wsw, s);
-                    s = v_fma<VT>(ev, c.wse, s);
-                    if (m.inter && g < cvec)
-                        store_vec<VT>(m.inter + ((int64_t)v * P.n + i) * m.C + g * VW, s);
-                    t = (s * r.valid) * r.wgt;
-                }
-            }
-        }
-        VT acc = (VT)0.0f;
-        for (int vv = 0; vv < V; ++vv) acc = acc + shfl_vec<VT>(t, base + (vv << m.lpp_log2) + g);
-        if (v == 0 && g < cvec) {
-            const float denom = cnt + 1e-6f;
-            VT o;
-            if (cnt == 0.0f) {
-                o = (VT)0.0f;
-            } else if (strict) {
-                o = strict_div<VT>(acc, denom);
-            } else {
-                const float r0 = __builtin_amdgcn_rcpf(denom);
-                const float rcp_d = fmaf(fmaf(-denom, r0, 1.0f), r0, r0);
-                VT q = acc * rcp_d;
-                q = v_fma<VT>(v_fma<VT>(q, -denom, acc), rcp_d, q);
-                q = v_fma<VT>(v_fma<VT>(q, -denom, acc), rcp_d, q);
-                o = q;
-            }
-            store_out<VT>(m.out + i * m.C + (int64_t)g * VW, o, P.store_policy);
-        }
-    }
-}
-
-// SMALL: the cell-run kernel keeps <= 96 VGPRs; its other maps (the mask, colours) are mapped to one vector per lane, batched
-template <int VW, bool WIDE, bool SMALL = false>
-__device__ __forceinline__ void gather_map_u(const MapDesc &m, const EvalParams &P, const ViewRec *rec,
-                                             const float *cnt_s, const uint32_t *flag_s,
-                                             const uint32_t *idx_s, int64_t idx_base, int tile_n, const CornerRec *crec)
-{
-    if (thin_map(m, P, VW)) {
-        gather_map_thin<VW>(m, P, rec, cnt_s, flag_s, idx_s, idx_base, tile_n);
-        return;
-    }
-    switch (m.unroll) {
-    case 1: gather_map<VW, 1, true>(m, P, rec, cnt_s, flag_s, idx_s, idx_base, tile_n, crec); break;
-    case 2: if (!SMALL) gather_map<VW, 2, true>(m, P, rec, cnt_s, flag_s, idx_s, idx_base, tile_n, crec); break;
-    case 3: if (!SMALL) gather_map<VW, 3, true>(m, P, rec, cnt_s, flag_s, idx_s, idx_base, tile_n, crec); break;
-    case -1: if (!SMALL) gather_map<VW, 1, false>(m, P, rec, cnt_s, flag_s, idx_s, idx_base, tile_n, crec); break;
-    case -2: if (!SMALL) gather_map<VW, 2, false>(m, P, rec, cnt_s, flag_s, idx_s, idx_base, tile_n, crec); break;
-    case -3: if (!SMALL) gather_map<VW, 3, false>(m, P, rec, cnt_s, flag_s, idx_s, idx_base, tile_n, crec); break;
-    default:
-        if (WIDE) gather_map<VW, 4, false>(m, P, rec, cnt_s, flag_s, idx_s, idx_base, tile_n, crec);
-        break;
-    }
-}
 
 // fp16-stored maps: the host maps them to 8-channel (16-B) or scalar lanes with batched loads only (1..3 vectors)
 template <int VW>
@@ -672,91 +155,8 @@ __device__ __forceinline__ void gather_map_half_u(const MapDesc &m, const EvalPa
     }
 }
 
-// XCD-aware tile order: the dispatcher places workgroup b on XCD b%8 (observed, speed only).
-// Giving XCD k the k-th contiguous eighth of the tiles keeps the texel footprints of the
-// eight private L2s (4 MiB each) disjoint instead of replicated.  Bijective for any count.
-__device__ __forceinline__ int64_t xcd_tile(int64_t b, int64_t nb)
-{
-    const int64_t q = nb / 8, r = nb % 8, xcd = b % 8, j = b / 8;
-    const int64_t start = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
-    return start + j;
-}
 
-// MODE 0: Fusion.eval semantics; MODE 1: Fusion.eval_dist semantics (fusion.py:396-436).
-// Query point i: from the caller's [n,3] array, or generated from the three axis arrays of a regular
-// grid in the reference's order (create_init_grid, fusion.py:79-88: 'ij' meshgrid, z fastest).
-__device__ __forceinline__ void fetch_point(const EvalParams &P, int64_t i, float &px, float &py, float &pz)
-{
-    if (P.grid_x) {
-        const int64_t iz = i % P.grid_nz, ixy = i / P.grid_nz;
-        px = P.grid_x[ixy / P.grid_ny];
-        py = P.grid_y[ixy % P.grid_ny];
-        pz = P.grid_z[iz];
-    } else {
-        px = P.pts[i * 3 + 0]; py = P.pts[i * 3 + 1]; pz = P.pts[i * 3 + 2];
-    }
-}
-
-// ---- lattice walk: blockIdx -> brick of points, closed form ----------------------------------------------------
-// The points of a regular grid (create_init_grid, fusion.py:79-88) need no keys, no sort and no index array to be
-// walked brick by brick: the flat walk position t decodes to a tile of walk_tx x walk_ty x walk_tz points through a
-// three-level BLOCKED row-major order over the tile lattice -- 16^3-tile macro-bricks (32 k points with 2x2x2 tiles:
-// the Infinity-Cache window all eight XCDs share), 8^3-tile sub-bricks (the contiguous eighth one XCD takes, its L2
-// window), 4^3-tile mini-bricks, tiles row-major inside.  Blocks at the upper faces are clipped, not padded, so every
-// workgroup has work and the count is exactly ceil(nx/tx)*ceil(ny/ty)*ceil(nz/tz).  Wave-uniform integer arithmetic.
-struct TileBox {
-    int ox, oy, oz;     // first point of the tile (lattice coordinates)
-    int sx, sy, sz;     // clipped size in points
-};
-
-__device__ __forceinline__ void walk_level(uint32_t &rem, int b, int &ox, int &oy, int &oz, int &ex, int &ey, int &ez)
-{
-    // the box at (ox,oy,oz) with extents (ex,ey,ez) tiles is cut into b^3 blocks (upper ones clipped), row-major;
-    // on return the box is the block holding position `rem`, and rem is the position inside it
-    const uint32_t slab = (uint32_t)b * (uint32_t)ey * (uint32_t)ez;
-    const uint32_t i = rem / slab;
-    rem -= i * slab;
-    const int bx = min(b, ex - (int)i * b);
-    const uint32_t col = (uint32_t)bx * (uint32_t)b * (uint32_t)ez;
-    const uint32_t j = rem / col;
-    rem -= j * col;
-    const int by = min(b, ey - (int)j * b);
-    const uint32_t cell = (uint32_t)bx * (uint32_t)by * (uint32_t)b;
-    const uint32_t k = rem / cell;
-    rem -= k * cell;
-    ox += (int)i * b; oy += (int)j * b; oz += (int)k * b;
-    ex = bx; ey = by; ez = min(b, ez - (int)k * b);
-}
-
-__device__ __forceinline__ TileBox walk_tile(const EvalParams &P, int64_t t)
-{
-    int ex = (P.walk_nx + P.walk_tx - 1) / P.walk_tx, ey = (P.walk_ny + P.walk_ty - 1) / P.walk_ty,
-        ez = (P.walk_nz + P.walk_tz - 1) / P.walk_tz;
-    int ox = 0, oy = 0, oz = 0;
-    uint32_t rem = (uint32_t)t;
-    walk_level(rem, 16, ox, oy, oz, ex, ey, ez);
-    walk_level(rem, 8, ox, oy, oz, ex, ey, ez);
-    walk_level(rem, 4, ox, oy, oz, ex, ey, ez);
-    const uint32_t yz = (uint32_t)ey * (uint32_t)ez;
-    const uint32_t lx = rem / yz, r2 = rem - lx * yz;
-    const uint32_t ly = r2 / (uint32_t)ez, lz = r2 - ly * (uint32_t)ez;
-    TileBox tb;
-    tb.ox = (ox + (int)lx) * P.walk_tx; tb.oy = (oy + (int)ly) * P.walk_ty; tb.oz = (oz + (int)lz) * P.walk_tz;
-    tb.sx = min(P.walk_tx, P.walk_nx - tb.ox); tb.sy = min(P.walk_ty, P.walk_ny - tb.oy); tb.sz = min(P.walk_tz, P.walk_nz - tb.oz);
-    return tb;
-}
-
-// flat index of the p-th point of a tile (z fastest inside the tile, like the lattice itself)
-__device__ __forceinline__ int64_t walk_point(const EvalParams &P, const TileBox &tb, int p)
-{
-    const int yz = tb.sy * tb.sz;
-    const int dx = p / yz, r = p - dx * yz;
-    const int dy = r / tb.sz, dz = r - dy * tb.sz;
-    return ((int64_t)(tb.ox + dx) * P.walk_ny + (tb.oy + dy)) * P.walk_nz + (tb.oz + dz);
-}
-
-// STAGED: compiled with the LDS-window gather (more registers); the plain kernel keeps 4 waves/SIMD.
-template <int MODE, bool STAGED, bool WIDE, bool ANYF16 = false, int RU = 0, int RK = 0>
+template <int MODE, bool WIDE, bool ANYF16 = false, int RU = 0, int RK = 0>
 __device__ __forceinline__ void fused_eval_body(const EvalParams &P)
 {
     constexpr bool RUNS = RU > 0;
@@ -770,7 +170,6 @@ __device__ __forceinline__ void fused_eval_body(const EvalParams &P)
     uint32_t *flag_s = reinterpret_cast<uint32_t *>(cnt_s + TP);             // [TP]
     uint32_t *idx_s = flag_s + TP;                                           // [TP] global point index
     float *krt = reinterpret_cast<float *>(idx_s + TP);                      // [V*12]
-    float *stage_s = reinterpret_cast<float *>(smem + P.stage_offset);       // 2 x stage_floats, 16-B aligned
     CornerRec *crec_s = reinterpret_cast<CornerRec *>(smem + P.crec_offset); // [n_pre][TP*V] (wide maps)
 
     __shared__ TileBox tb_s;                // lattice walk: decoded by one lane (12 integer divisions), read by all
@@ -893,15 +292,6 @@ __device__ __forceinline__ void fused_eval_body(const EvalParams &P)
     // ---------------- phase B: per map, 2^k lanes per point ----------------
     for (int s = 0; s < P.n_maps; ++s) {
         const MapDesc &m = P.maps[s];
-        if (STAGED && m.staged == 2) {
-            const int region = (2 * P.stage_floats) / (kBlock / 64);
-            switch (m.unroll) {
-            case 1: gather_map_wave_staged<1>(m, P, rec, cnt_s, flag_s, idx_s, idx_base, tile_n, stage_s, region); break;
-            case 2: gather_map_wave_staged<2>(m, P, rec, cnt_s, flag_s, idx_s, idx_base, tile_n, stage_s, region); break;
-            default: gather_map_wave_staged<3>(m, P, rec, cnt_s, flag_s, idx_s, idx_base, tile_n, stage_s, region); break;
-            }
-            continue;
-        }
         const CornerRec *crec = m.pre_slot >= 0 ? crec_s + (size_t)m.pre_slot * TP * V : nullptr;
         if (RUNS && m.runs > 0) {
             // non-strict points through the cell-run gather, the (rare) strict ones through the generic path
@@ -924,18 +314,17 @@ __device__ __forceinline__ void fused_eval_body(const EvalParams &P)
     }
 }
 
-// ---- channel-sliced launch for dense maps on a lattice (round 2 experiment, D3F_EXP_SLICED) ----------------------------
+// ---- channel-sliced launch for a dense wide map on a lattice (the default there since round 2) -------------------------
 // On maps much larger than the caches the kernel is bound by L2 misses, and an L2 holds only a ~512-point window of
-// whole texels.  Here a workgroup handles 32 points x ONE 128-byte (or 256-byte) channel slice of the
-// wide map, and all the slices of a ~4096-point stretch of the brick walk (a "chunk") are spread over the XCDs as units
-// (chunk, slice): the XCD that owns a unit has its 128 workgroups in flight together and its 4 MiB L2 sees 1/12 (1/6)
-// of every texel, i.e. a 4096-point window -- ideal read hit rate 72 % instead of 57 % (scripts/sim_reuse.py).  The
-// price: phase A (projection, depth test, weights, corner set-up) runs once per (point, slice) instead of once per
-// point.  Arithmetic per (point, view, channel) is that of gather_map (fast or strict form), so results are identical.
-constexpr int kSlicedTile = 32;            // points per workgroup = 4 tiles of the brick walk
-// workgroups per unit (EvalParams::sl_unit): 128 = 4096 points per chunk for 128-byte slices, fewer for wider slices so
-// that a unit's texel slices still fit one L2
-
+// whole texels.  Here a workgroup handles 16 points (four 2x2x1 tiles of the brick walk; 32 when thin
+// maps ride along) x ONE 512-byte channel slice of the wide map, and the slices of a 4096-point stretch of the walk (a
+// "chunk") are units (chunk, slice) spread over the XCDs: the XCD that owns a unit has its 256 workgroups in flight
+// together and its 4 MiB L2 sees a third of every texel, i.e. a ~3x larger window in points (read hit rate 58 -> 66 %,
+// C2-dense 1.62 -> 1.52 ms).  The price: phase A (projection, depth test, weights, corner set-up) runs once per (point,
+// slice).  512 bytes is the finest slice that pays: a C = 384 fp32 texel is 12 lines, so a narrower slice of every texel
+// lands on a half / a quarter of the L2's channels and sets and the capacity it wins is lost again (round 3 counters:
+// 61 M line fills at 512, 256 and 128 bytes alike, profiles/r3_stream).  Arithmetic per (point, view, channel) is that of
+// gather_map (fast or strict form), so results are identical.
 template <int LG, int VC>                  // lanes per point = 1 << LG: 8 (128-byte slices), 16 (256 B) or 32 (512 B)
 __device__ __forceinline__ void fused_eval_sliced_body(const EvalParams &P)
 {
@@ -1620,35 +1009,30 @@ __device__ __forceinline__ void fused_eval_window_body(const EvalParams &P)
 template <int U, int VC, int WAVES, int NT = kBlock, int LPP = 32>
 __global__ __launch_bounds__(NT, WAVES) void fused_eval_window_kernel(const EvalParams P) { fused_eval_window_body<U, VC, NT, LPP>(P); }
 
-// Three entry points over one body: the plain kernel (<= 3 channel vectors per lane) is held to 128 VGPRs
-// = 4 waves per SIMD -- the gather lives on memory-level parallelism; the WIDE variant adds the 4-vector
-// load-use path (C = 1024: a whole wave per point) with its natural register count; the LDS-staging variant
-// needs ~200 registers and is LDS-limited anyway.
+// Entry points over one body: the plain kernel (<= 3 channel vectors per lane) is held to 128 VGPRs = 4 waves per SIMD
+// (125 allocated) -- the gather lives on memory-level parallelism; the WIDE variant adds the 4-vector load-use path
+// (C = 1024: a whole wave per point) with its natural register count.
 template <int MODE>
-__global__ __launch_bounds__(kBlock, 4) void fused_eval_kernel(const EvalParams P) { fused_eval_body<MODE, false, false>(P); }
+__global__ __launch_bounds__(kBlock, 4) void fused_eval_kernel(const EvalParams P) { fused_eval_body<MODE, false>(P); }
 
 template <int MODE>
-__global__ __launch_bounds__(kBlock) void fused_eval_wide_kernel(const EvalParams P) { fused_eval_body<MODE, false, true>(P); }
+__global__ __launch_bounds__(kBlock) void fused_eval_wide_kernel(const EvalParams P) { fused_eval_body<MODE, true>(P); }
 
 // fp16-stored maps get their own entry point (all vector counts, fp32 and fp16 maps may be mixed in one call) so
 // that the fp32 kernels above keep their register allocation (folding both into one body made them spill)
 // (163 VGPR = 3 waves per SIMD; held to 4 it spills 750 B per lane)
 template <int MODE>
-__global__ __launch_bounds__(kBlock) void fused_eval_f16_kernel(const EvalParams P) { fused_eval_body<MODE, false, true, true>(P); }
+__global__ __launch_bounds__(kBlock) void fused_eval_f16_kernel(const EvalParams P) { fused_eval_body<MODE, true, true>(P); }
 
-template <int MODE>
-__global__ __launch_bounds__(kBlock) void fused_eval_staged_kernel(const EvalParams P) { fused_eval_body<MODE, true, true>(P); }
-
-// cell-run gather for patch-resolution wide maps, one entry point per (vectors per lane, run length) so that every
-// variant gets its own register allocation: <1,8> one vector per lane and 8-point runs, held to 5 waves per SIMD (the
-// default: fastest on every patch-resolution workload measured, MI355X r2c: C2 0.724 -> 0.645 ms, C3 1.544 -> 1.338,
-// C4 4.13 -> 3.82); <3,4> / <3,2> the 3-vector mapping of C = 384 with 4- / 2-point runs and <2,4> / <2,8> two vectors
-// per lane are kept as experiment variants (they spill at 4 waves per SIMD and measured 2-5 % slower).
-// <2,8> (the C = 1024 default) runs at 3 waves per SIMD: held to 4 it spills 48 bytes per lane (C4 patch 3.40 -> 3.31 ms).
+// cell-run gather for patch-resolution wide maps, one entry point per (vectors per lane, run length, waves per SIMD) so
+// that every variant gets its own register allocation.  The planner's choices (launch_fused_eval): <1,4,7> for 32-lane
+// groups (C = 384: C2 patch clouds 0.750 -> 0.633 ms), <2,8,3> for 64-lane groups x two vectors (C = 1024: C4 patch
+// 4.32 -> 3.31 ms; held to 4 waves it spills 48 bytes per lane), <1,8,5> otherwise; all three are spill-free.  The other
+// instantiations (some spill) are compiled into experiments builds only.
 template <int MODE, int RU, int RK, int WAVES>
 __global__ __launch_bounds__(kBlock, WAVES) void fused_eval_runs_kernel(const EvalParams P)
 {
-    fused_eval_body<MODE, false, false, false, RU, RK>(P);
+    fused_eval_body<MODE, false, false, RU, RK>(P);
 }
 
 hipError_t launch_fused_eval(const EvalParams &P, int mode, hipStream_t stream)
@@ -1679,8 +1063,11 @@ hipError_t launch_fused_eval(const EvalParams &P, int mode, hipStream_t stream)
             }                                                                                                                      \
             hipLaunchKernelGGL((fused_eval_window_kernel<U_, VC_, W_, kBlock, LPP_>), gw, block, lds_w, stream, P);                \
         } while (0)
+        // the product library holds the two variants the planner picks by itself (16 lanes x two vectors per point, 4 or 3
+        // workgroups per CU); the others exist in experiments builds only (measured and dropped)
         if (P.win_u == 1 && P.win_lpp == 16 && P.win_occ >= 4) D3F_WIN_LAUNCH(1, 2, 4, 16);
         else if (P.win_u == 1 && P.win_lpp == 16) D3F_WIN_LAUNCH(1, 2, 3, 16);
+#ifdef D3F_EXPERIMENTS
         else if (P.win_u == 1 && P.win_occ >= 4) D3F_WIN_LAUNCH(1, 4, 4, 32);
         else if (P.win_u == 1 && P.win_occ == 3) D3F_WIN_LAUNCH(1, 4, 3, 32);
         else if (P.win_u == 1) D3F_WIN_LAUNCH(1, 4, 2, 32);
@@ -1689,6 +1076,9 @@ hipError_t launch_fused_eval(const EvalParams &P, int mode, hipStream_t stream)
         else if (P.win_u == 3 && P.win_vc == 2) D3F_WIN_LAUNCH(3, 2, 2, 32);
         else if (P.win_u == 3) D3F_WIN_LAUNCH(3, 1, 2, 32);
         else D3F_WIN_LAUNCH(4, 1, 2, 32);
+#else
+        else return hipErrorInvalidValue;
+#endif
 #undef D3F_WIN_LAUNCH
         return hipGetLastError();
     }
@@ -1698,33 +1088,41 @@ hipError_t launch_fused_eval(const EvalParams &P, int mode, hipStream_t stream)
         const size_t lds_s = (size_t)P.crec_offset + (size_t)P.tile_pts * P.V * 32 + (size_t)P.lds_pad;
         const dim3 gs((unsigned)wgs);
         if (P.sl_lg == 5 && P.sl_vc == 2) hipLaunchKernelGGL((fused_eval_sliced_kernel<5, 2, 7>), gs, block, lds_s, stream, P);
+#ifndef D3F_EXPERIMENTS
+        else return hipErrorInvalidValue;          // (other slice widths / views in flight: experiments builds only)
+#else
         else if (P.sl_lg == 5) hipLaunchKernelGGL((fused_eval_sliced_kernel<5, 4, 5>), gs, block, lds_s, stream, P);
         else if (P.sl_lg == 4 && P.sl_vc == 2) hipLaunchKernelGGL((fused_eval_sliced_kernel<4, 2, 7>), gs, block, lds_s, stream, P);
         else if (P.sl_lg == 4 && P.sl_vc == 1) hipLaunchKernelGGL((fused_eval_sliced_kernel<4, 1, 8>), gs, block, lds_s, stream, P);
         else if (P.sl_lg == 4) hipLaunchKernelGGL((fused_eval_sliced_kernel<4, 4, 5>), gs, block, lds_s, stream, P);
         else if (P.sl_vc == 2) hipLaunchKernelGGL((fused_eval_sliced_kernel<3, 2, 7>), gs, block, lds_s, stream, P);
         else hipLaunchKernelGGL((fused_eval_sliced_kernel<3, 4, 5>), gs, block, lds_s, stream, P);
+#endif
         return hipGetLastError();
     }
-    if (mode == 0 && runs && !f16 && !wide && P.stage_floats == 0) {
+    if (mode == 0 && runs && !f16 && !wide) {
         int ru = 1, rk = 8;
         for (int s = 0; s < P.n_maps; ++s)
             if (P.maps[s].runs > 0) { ru = P.maps[s].unroll; rk = P.maps[s].runs; }
-        if (ru == 3 && rk == 4) hipLaunchKernelGGL((fused_eval_runs_kernel<0, 3, 4, 4>), grid, block, lds, stream, P);
+        // product library: the three spill-free variants the planner picks by itself -- (2,8) at 3 waves per SIMD (64-lane
+        // groups x 2 vectors, C = 1024), (1,4) at 7 waves (32-lane groups, C = 384), (1,8) at 5 waves (64-lane groups x 1)
+        if (ru == 2 && rk == 8 && P.runs_occ != 4) hipLaunchKernelGGL((fused_eval_runs_kernel<0, 2, 8, 3>), grid, block, lds, stream, P);
+        else if (ru == 1 && rk == 4 && P.runs_occ != 6) hipLaunchKernelGGL((fused_eval_runs_kernel<0, 1, 4, 7>), grid, block, lds, stream, P);
+        else if (ru == 1 && rk == 8 && P.runs_occ != 4 && P.runs_occ != 6) hipLaunchKernelGGL((fused_eval_runs_kernel<0, 1, 8, 5>), grid, block, lds, stream, P);
+#ifdef D3F_EXPERIMENTS
+        else if (ru == 3 && rk == 4) hipLaunchKernelGGL((fused_eval_runs_kernel<0, 3, 4, 4>), grid, block, lds, stream, P);
         else if (ru == 3 && rk == 2) hipLaunchKernelGGL((fused_eval_runs_kernel<0, 3, 2, 4>), grid, block, lds, stream, P);
         else if (ru == 2 && rk == 4) hipLaunchKernelGGL((fused_eval_runs_kernel<0, 2, 4, 4>), grid, block, lds, stream, P);
-        else if (ru == 2 && rk == 8 && P.runs_occ == 4) hipLaunchKernelGGL((fused_eval_runs_kernel<0, 2, 8, 4>), grid, block, lds, stream, P);
-        else if (ru == 2 && rk == 8) hipLaunchKernelGGL((fused_eval_runs_kernel<0, 2, 8, 3>), grid, block, lds, stream, P);
-        else if (ru == 1 && rk == 4 && P.runs_occ == 6) hipLaunchKernelGGL((fused_eval_runs_kernel<0, 1, 4, 6>), grid, block, lds, stream, P);
-        else if (ru == 1 && rk == 4) hipLaunchKernelGGL((fused_eval_runs_kernel<0, 1, 4, 7>), grid, block, lds, stream, P);
+        else if (ru == 2 && rk == 8) hipLaunchKernelGGL((fused_eval_runs_kernel<0, 2, 8, 4>), grid, block, lds, stream, P);
+        else if (ru == 1 && rk == 4) hipLaunchKernelGGL((fused_eval_runs_kernel<0, 1, 4, 6>), grid, block, lds, stream, P);
         else if (P.runs_occ == 4) hipLaunchKernelGGL((fused_eval_runs_kernel<0, 1, 8, 4>), grid, block, lds, stream, P);
-        else if (P.runs_occ == 6) hipLaunchKernelGGL((fused_eval_runs_kernel<0, 1, 8, 6>), grid, block, lds, stream, P);
-        else hipLaunchKernelGGL((fused_eval_runs_kernel<0, 1, 8, 5>), grid, block, lds, stream, P);
+        else hipLaunchKernelGGL((fused_eval_runs_kernel<0, 1, 8, 6>), grid, block, lds, stream, P);
+#else
+        else return hipErrorInvalidValue;
+#endif
     }
     else if (mode == 0 && f16)
         hipLaunchKernelGGL((fused_eval_f16_kernel<0>), grid, block, lds, stream, P);
-    else if (mode == 0 && P.stage_floats > 0)
-        hipLaunchKernelGGL((fused_eval_staged_kernel<0>), grid, block, lds, stream, P);
     else if (mode == 0 && wide)
         hipLaunchKernelGGL((fused_eval_wide_kernel<0>), grid, block, lds, stream, P);
     else if (mode == 0)

@@ -201,6 +201,8 @@ class Fusion:
     STORAGE format of the channel maps only; all arithmetic stays fp32 (see __init__).
     """
 
+    extra_tuning_flags = 0      # D3F_TUNE_* bits OR-ed into every launch of every object (tests: _lib.TUNE_DIRECT_GATHER)
+
     def __init__(self, num_cam, feat_backbone="dinov2", device="cuda:0", dtype=torch.float32, *,
                  feature_extractor=None, mask_producer=None, mask_tracker=None):
         # dtype=torch.float16: the reference then runs EVERYTHING in half (fusion.py:203,227,709-712), whose projection
@@ -417,8 +419,14 @@ class Fusion:
         wide = any(plan.vectors_per_lane[s] == -4 for s in range(n_maps))
         f16 = any(maps[s].dtype == _lib.DTYPE_F16 for s in range(n_maps))
         kernel = ("fused_eval_f16_kernel<0>" if f16 else "fused_eval_wide_kernel<0>" if wide else "fused_eval_kernel<0>")
-        window = plan.reserved >= 2000
-        if window:
+        window = 2000 <= plan.reserved < 3000
+        stream = plan.reserved >= 3000
+        if stream:
+            lg, var = (plan.reserved - 3000) // 100, (plan.reserved - 3000) % 100
+            T = int(plan.tile_points)
+            kernel = "fused_eval_stream_kernel<%d, %d, %d, %d, %s, %d>" % (lg, T, 4 if T == 16 else 3, 4 if var == 2 else 2,
+                                                                            "true" if var == 0 else "false", 7 if (var == 1 and T != 16) else 5)
+        elif window:
             r = plan.reserved - 2000
             w0 = [s for s in range(n_maps) if plan.staged[s] == 3][0]           # the windowed map (any position in the call)
             kernel = "fused_eval_window_kernel<%d, %d, %d, 256, %d>" % (r // 100, r // 10 % 10, r % 10, plan.lanes_per_point[w0])
@@ -428,7 +436,7 @@ class Fusion:
         elif runs and not f16 and not wide:
             s0 = [s for s in range(n_maps) if plan.staged[s] >= 16][0]
             kernel = "fused_eval_runs_kernel<0, %d, %d, %d>" % (plan.vectors_per_lane[s0], plan.staged[s0] - 16, plan.reserved)
-        order = {2: "closed-form brick walk of the lattice (no keys, no sort)" + ("; channel-sliced over the XCDs" if 100 <= plan.reserved < 200 else ""), 1: "Morton-cell order (counting sort by 16-mm cell + 4-mm refinement, hand-written)",
+        order = {2: "closed-form brick walk of the lattice (no keys, no sort)" + ("; channel-sliced over the XCDs" if (100 <= plan.reserved < 200 or stream) else "") + ("; persistent producer / consumer workgroups" if stream else ""), 1: "Morton-cell order (counting sort by 16-mm cell + 4-mm refinement, hand-written)",
                  0: "caller order"}[int(plan.reorder)]
         if window:
             order += "; %d-point bricks through texel windows in LDS" % int(plan.tile_points)
@@ -499,7 +507,7 @@ class Fusion:
                     it = torch.empty((V, n, C), dtype=torch.float32, device=dev)
                     outputs[k + "_inter"] = it
                     inter[s] = it.data_ptr()
-            flags = (_lib.FLAG_FINITE_MAPS if finite else 0) | int(self.tuning_flags)
+            flags = (_lib.FLAG_FINITE_MAPS if finite else 0) | int(self.tuning_flags) | int(Fusion.extra_tuning_flags) | int(Fusion.extra_tuning_flags)
             ws, ws_bytes = None, 0
             dims, hinted_unordered = None, None
             if self.reorder_points and names and n >= 65536 and not torch.cuda.is_current_stream_capturing():
@@ -628,7 +636,7 @@ class Fusion:
                                       _lib.DTYPE_F16 if m.dtype == torch.float16 else _lib.DTYPE_F32,
                                       m.stride(0), m.stride(1), m.stride(2))
             fused[s] = out[k].data_ptr()
-        flags = (_lib.FLAG_FINITE_MAPS if finite else 0) | int(self.tuning_flags)
+        flags = (_lib.FLAG_FINITE_MAPS if finite else 0) | int(self.tuning_flags) | int(Fusion.extra_tuning_flags)
         with torch.cuda.device(dev):
             _lib.check(lib.d3f_eval_grid(ctypes.byref(views), ctypes.byref(grid), maps, len(names), self.mu, flags,
                                          _lib.ptr(dist), _lib.ptr(valid), fused, _lib.current_stream_handle(dev)))

@@ -9,8 +9,8 @@
  *
  * Conventions
  *   - every pointer is a DEVICE pointer on the device the stream belongs to, unless noted;
- *   - the library never allocates, frees or retains caller memory and keeps no state between
- *     calls (re-entrant), with two documented thread-local exceptions: the text behind
+ *   - the library never allocates, frees or retains caller memory, reads no environment variable and keeps no
+ *     state between calls (re-entrant), with two documented thread-local exceptions: the text behind
  *     d3f_last_error() and the one-shot event pair armed by d3f_profile_next_eval() (a measurement
  *     hook, consumed by the same thread's next query); work is enqueued on `stream` (a
  *     hipStream_t, NULL = default stream) and NOT synchronised;
@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define D3F_ABI_VERSION 2
+#define D3F_ABI_VERSION 3
 
 #define D3F_OK 0
 #define D3F_ERR_INVALID_ARG (-1)  /* null pointer, negative count, bad enum               */
@@ -67,8 +67,8 @@ extern "C" {
  *               round-robin otherwise)
  *   bit  13     never reorder points, even when a workspace is supplied
  *   bit  14     always reorder points when a workspace is supplied
- *   bit  15     stage texel windows of low-resolution wide maps through LDS (experimental:
- *               bit-identical, measured slower than the direct gather on MI355X, off by default)
+ *   bit   4     D3F_TUNE_DIRECT_GATHER: the plain direct gather in the chosen point order -- no LDS texel windows, no cell
+ *               runs, no channel slices, thin maps view by view.  Every fast path is bit-identical to it (tests/).
  *   bits 24..25 Morton cell: 16 mm >> k (k = 0..2);  bit 26 / 27 force batched / load-use corner loads;
  *               bit 28 do not precompute corner set-ups in phase A;  bits 29..31 XCD-mapping chunk = 1024 << (k-1) tiles
  *   bits 16..23 extra dynamic LDS per workgroup in KiB (throttles workgroups per CU); 255 = none      */
@@ -76,7 +76,7 @@ extern "C" {
 #define D3F_TUNE_XCD_REMAP (1u << 12)
 #define D3F_TUNE_NO_REORDER (1u << 13)
 #define D3F_TUNE_FORCE_REORDER (1u << 14)
-#define D3F_TUNE_STAGING (1u << 15)
+#define D3F_TUNE_DIRECT_GATHER (1u << 4)
 #define D3F_TUNE_LDS_PAD_KIB(k) (((uint32_t)(k) & 0xFFu) << 16)
 
 /* Calibrated views: the part of Fusion.curr_obs_torch read by every query
@@ -103,6 +103,9 @@ typedef struct d3f_channel_map {
 int d3f_abi_version(void);
 const char *d3f_version(void);    /* "d3fields-hip <semver> gfx950" (host memory)          */
 const char *d3f_last_error(void); /* host memory, valid until the thread's next failure    */
+/* 1 when the library was compiled with -DD3F_EXPERIMENTS (tuning sessions: D3F_EXP_* environment variables select
+ * kernel variants); 0 for the product build, which reads no environment variable at all. */
+int d3f_build_has_experiments(void);
 
 /* ---- fused field query --------------------------------------------------------------
  * Replaces Fusion.eval (fusion.py:305-394) together with project_points_coords
@@ -144,9 +147,9 @@ typedef struct d3f_eval_plan {
     int32_t vector_floats[D3F_MAX_MAPS];    /* 4 / 2 / 1 floats per load                              */
     int32_t lanes_per_point[D3F_MAX_MAPS];
     int32_t vectors_per_lane[D3F_MAX_MAPS];
-    int32_t staged[D3F_MAX_MAPS];           /* 2: wave-private LDS staging (experiment); 3: LDS texel windows per brick
-                                               (patch-resolution wide map on a lattice); 16 + K: cell-run gather with
-                                               runs of K points (patch-resolution wide maps)           */
+    int32_t staged[D3F_MAX_MAPS];           /* 0: direct gather; 3: LDS texel windows per brick (patch-resolution wide
+                                               map on a lattice); 16 + K: cell-run gather with runs of K points
+                                               (patch-resolution wide maps)                            */
 } d3f_eval_plan;
 int d3f_eval_plan_query(const d3f_views *views, int64_t n, const d3f_channel_map *maps, int32_t n_maps,
                         uint32_t flags, int32_t have_workspace, int32_t want_inter, d3f_eval_plan *plan);

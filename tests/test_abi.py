@@ -254,17 +254,19 @@ def test_launch_plan_host_logic():
     # many views shrink the tile so that the per-(point,view) records fit LDS
     p = _plan(64, 48, 64, 5000, [(6, 8, 16)])
     assert p.tile_points * 64 * 24 <= 64 * 1024 and p.lds_bytes <= 64 * 1024
-    # opt-in staging only on the Morton walk
-    p = _plan(4, 480, 640, 985600, [(48, 64, 384)], flags=_lib.TUNE_STAGING)
-    assert (p.staged[0], p.reorder, p.tile_points, p.vectors_per_lane[0]) == (2, 1, 32, 3)
-    p = _plan(4, 480, 640, 985600, [(48, 64, 384)], flags=_lib.TUNE_STAGING | _lib.TUNE_NO_REORDER)
-    assert (p.staged[0], p.reorder) == (0, 0)
+    # D3F_TUNE_DIRECT_GATHER: no cell runs / windows / slices, the chosen point order stays
+    p = _plan(4, 480, 640, 985600, [(48, 64, 384)], flags=_lib.FLAG_FINITE_MAPS)
+    assert p.staged[0] == 16 + 4
+    p = _plan(4, 480, 640, 985600, [(48, 64, 384)], flags=_lib.FLAG_FINITE_MAPS | _lib.TUNE_DIRECT_GATHER)
+    assert (p.staged[0], p.reorder, p.tile_points, p.reserved) == (0, 0, 128, 0)
 
 
 def test_window_launch_plan(monkeypatch):
-    """LDS texel windows replace the cell-run gather for a patch-resolution wide map on a lattice (D3F_EXP_WINDOW forces
-    them for clouds too / switches them off); infeasible shapes fall back instead of failing."""
+    """LDS texel windows replace the cell-run gather for a patch-resolution wide map on a lattice (D3F_TUNE_DIRECT_GATHER
+    switches them off; in experiments builds D3F_EXP_WINDOW forces them for clouds too); infeasible shapes fall back
+    instead of failing."""
     lib = _lib.load()
+    exp = bool(lib.d3f_build_has_experiments())
 
     def plan_lattice(V, dims, maps, flags=_lib.FLAG_FINITE_MAPS):
         v = _lib.Views(V, 480, 640, 16, 16, 16)
@@ -283,22 +285,30 @@ def test_window_launch_plan(monkeypatch):
     big_first = plan_lattice(4, (200, 175, 55), [(480, 640, 384), (480, 640, 8)])
     big_last = plan_lattice(4, (200, 175, 55), [(480, 640, 8), (480, 640, 384)])
     assert big_first.reserved == big_last.reserved == 152 and big_first.workgroups == big_last.workgroups
-    monkeypatch.setenv("D3F_EXP_WINDOW", "-1")
-    assert plan_lattice(4, (160, 140, 44), [(48, 64, 384)]).staged[0] == 16 + 4      # switched off: cell runs, caller order
-    monkeypatch.setenv("D3F_EXP_WINDOW", "64")
+    p = plan_lattice(4, (160, 140, 44), [(48, 64, 384)], flags=_lib.FLAG_FINITE_MAPS | _lib.TUNE_DIRECT_GATHER)
+    assert (p.staged[0], p.reorder, p.reserved) == (0, 0, 0)                          # switched off: direct gather, caller order
     p = plan_lattice(4, (160, 140, 44), [(48, 64, 384), (480, 640, 8)])
     assert (p.staged[0], p.tile_points, p.reorder, p.workgroups, p.reserved) == (3, 64, 2, 40 * 35 * 11, 2124)
     assert p.lds_bytes <= 160 * 1024 // 4
-    monkeypatch.setenv("D3F_EXP_WINDOW_U", "3")
-    p = plan_lattice(4, (160, 140, 44), [(48, 64, 384)])
-    assert (p.staged[0], p.reserved) == (3, 2312) and 64 * 1024 < p.lds_bytes <= 80 * 1024
-    monkeypatch.delenv("D3F_EXP_WINDOW_U")
+    if exp:
+        monkeypatch.setenv("D3F_EXP_WINDOW", "-1")
+        assert plan_lattice(4, (160, 140, 44), [(48, 64, 384)]).staged[0] == 16 + 4      # windows off: cell runs, caller order
+        monkeypatch.setenv("D3F_EXP_WINDOW", "64")
+        monkeypatch.setenv("D3F_EXP_WINDOW_U", "3")
+        p = plan_lattice(4, (160, 140, 44), [(48, 64, 384)])
+        assert (p.staged[0], p.reserved) == (3, 2312) and 64 * 1024 < p.lds_bytes <= 80 * 1024
+        monkeypatch.delenv("D3F_EXP_WINDOW_U")
+        monkeypatch.delenv("D3F_EXP_WINDOW")
     assert plan_lattice(4, (160, 140, 44), [(48, 64, 384)], flags=0).staged[0] == 0      # maps not known finite: direct gather
     assert plan_lattice(4, (160, 140, 44), [(48, 64, 200)]).staged[0] != 3               # no whole 512-byte slices
     assert plan_lattice(4, (160, 140, 44), [(480, 640, 384)]).staged[0] == 0             # dense map: not a window case
     assert plan_lattice(16, (160, 140, 44), [(48, 64, 384)]).staged[0] != 3              # more than 8 views
     p = _plan(8, 720, 1280, 1000000, [(72, 128, 1024)], flags=_lib.FLAG_FINITE_MAPS | _lib.FLAG_UNORDERED_POINTS)
-    assert (p.staged[0], p.reorder, p.workgroups) == (3, 1, 15625)                       # clouds: 64 consecutive points of the Morton order
-    monkeypatch.setenv("D3F_EXP_WINDOW", "128")
-    p = _plan(8, 720, 1280, 1000000, [(72, 128, 1024)], flags=_lib.FLAG_FINITE_MAPS | _lib.FLAG_UNORDERED_POINTS)
-    assert p.staged[0] == 3 and p.reserved == 2123 and p.lds_bytes <= 160 * 1024 // 3    # 32 KB of records for 128 x 8 pairs: 3 workgroups per CU
+    assert (p.staged[0], p.reorder) == (16 + 8, 1)                                       # clouds keep the cell-run gather on the Morton walk
+    if exp:
+        monkeypatch.setenv("D3F_EXP_WINDOW", "64")
+        p = _plan(8, 720, 1280, 1000000, [(72, 128, 1024)], flags=_lib.FLAG_FINITE_MAPS | _lib.FLAG_UNORDERED_POINTS)
+        assert (p.staged[0], p.reorder, p.workgroups) == (3, 1, 15625)                   # forced: 64 consecutive points of the Morton order
+        monkeypatch.setenv("D3F_EXP_WINDOW", "128")
+        p = _plan(8, 720, 1280, 1000000, [(72, 128, 1024)], flags=_lib.FLAG_FINITE_MAPS | _lib.FLAG_UNORDERED_POINTS)
+        assert p.staged[0] == 3 and p.reserved == 2123 and p.lds_bytes <= 160 * 1024 // 3    # 32 KB of records for 128 x 8 pairs: 3 workgroups per CU

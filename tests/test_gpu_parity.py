@@ -952,7 +952,7 @@ def test_eval_dist_backward_vs_torch_port(dev):
     (384, (12, 16), 300, 1.0, False),       # sparse cloud: windows overflow -> per-view direct fallback
     (100, (6, 8), 2500, 3.0, False),        # odd vector count, many points outside every image
 ])
-def test_staged_gather_is_bit_identical(dev, C, fhw, N, box_scale, want_inter):
+def test_morton_walk_paths_are_bit_identical(dev, C, fhw, N, box_scale, want_inter):
     from d3fields_amd import synth, _lib
     V, H, W = 4, 120, 160
     sc = synth.make_scene(V, H, W, "smooth")
@@ -961,12 +961,15 @@ def test_staged_gather_is_bit_identical(dev, C, fhw, N, box_scale, want_inter):
     f = make_fusion(dev, sc["depth"], sc["K"], sc["pose"], {"dino_feats": feats, "mask": mask}, H, W)
     pts = (synth.random_cloud(N, seed=8) * box_scale).to(dev)
     res = {}
-    for tag, flags in (("direct", _lib.TUNE_NO_REORDER), ("staged", _lib.TUNE_FORCE_REORDER | _lib.TUNE_STAGING), ("unstaged", _lib.TUNE_FORCE_REORDER)):
+    # caller order / Morton walk, each with the planner's fast paths and as the plain direct gather
+    for tag, flags in (("direct", _lib.TUNE_NO_REORDER | _lib.TUNE_DIRECT_GATHER), ("staged", _lib.TUNE_FORCE_REORDER), ("unstaged", _lib.TUNE_FORCE_REORDER | _lib.TUNE_DIRECT_GATHER),
+                       ("caller", _lib.TUNE_NO_REORDER)):
         f.tuning_flags = flags
         res[tag] = _eval_with_workspace(f, pts, ("dino_feats", "mask"), want_inter)
     for k in res["direct"]:
         assert torch.equal(res["staged"][k], res["direct"][k]), k
         assert torch.equal(res["unstaged"][k], res["direct"][k]), k
+        assert torch.equal(res["caller"][k], res["direct"][k]), k
     ref = oracle_eval(sc, pts.cpu(), [feats, mask], return_inter=want_inter)
     assert np.array_equal(cpu(res["staged"]["dist"]), ref["dist"])
     assert rel_err(cpu(res["staged"]["dino_feats"]), ref["sets"][0]) <= TOL
@@ -974,7 +977,7 @@ def test_staged_gather_is_bit_identical(dev, C, fhw, N, box_scale, want_inter):
         assert np.array_equal(cpu(res["staged"]["dino_feats_inter"]), ref["inter"][0])
 
 
-def test_staged_gather_nonfinite_map(dev):
+def test_morton_walk_nonfinite_map(dev):
     from d3fields_amd import synth, _lib
     V, H, W = 3, 96, 128
     sc = synth.make_scene(V, H, W, "stress")
@@ -983,7 +986,7 @@ def test_staged_gather_nonfinite_map(dev):
     mask = synth.random_onehot_mask(V, H, W, 4, seed=2)
     f = make_fusion(dev, sc["depth"], sc["K"], sc["pose"], {"dino_feats": feats, "mask": mask}, H, W)
     pts = synth.random_cloud(5000, seed=3).to(dev)
-    f.tuning_flags = _lib.TUNE_FORCE_REORDER | _lib.TUNE_STAGING
+    f.tuning_flags = _lib.TUNE_FORCE_REORDER
     out = _eval_with_workspace(f, pts, ("dino_feats", "mask"), False)
     ref = oracle_eval(sc, pts.cpu(), [feats, mask])
     got, want = cpu(out["dino_feats"]), ref["sets"][0]

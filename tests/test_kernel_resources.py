@@ -30,12 +30,16 @@ def test_default_kernels_keep_their_register_budget():
     out = subprocess.run(["bash", os.path.join(ROOT, "scripts", "kernel_resources.sh")], capture_output=True, text=True, timeout=600).stdout
     seen = {}
     for line in out.splitlines():
-        m = re.match(r"(\S+)\s+vgpr\s+(\d+)\s+scratch\s+(\d+)\s+occ\s+(\d+)", line)
+        m = re.match(r"(\S+)\s+vgpr\s+(\d+)\s+sgpr\s+(\d+)\s+scratch\s+(\d+)\s+occ\s+(\d+)", line)
         if m:
-            seen[m.group(1)] = (int(m.group(2)), int(m.group(3)))
+            seen[m.group(1)] = (int(m.group(2)), int(m.group(4)))
     assert seen, out[-500:]
     for key, (max_vgpr, max_scratch) in BUDGET.items():
         hits = [v for k, v in seen.items() if k.startswith(key)]
         assert hits, "kernel %s not found among %s" % (key, sorted(seen))
         vgpr, scratch = hits[0]
         assert vgpr <= max_vgpr and scratch <= max_scratch, "%s: %d VGPRs / %d B scratch, budget %d / %d" % (key, vgpr, scratch, max_vgpr, max_scratch)
+    # the product build compiles only the variants the planner picks by itself, and none of them spills
+    spilling = {k: v for k, v in seen.items() if v[1] > 0}
+    assert not spilling, spilling
+    assert len(seen) <= 12, "experiment variants leaked into the product build: %s" % sorted(seen)
