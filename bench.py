@@ -213,6 +213,25 @@ def cpu_baseline(sc, w, names, maps_cpu, pts_cpu, budget_pts, threads=0):
     return res
 
 
+def spawn_command(n, argv, port=None):
+    """The launch line of an N-rank run on this node (what the driver itself uses for N > 1)."""
+    if port is None:
+        import socket
+        with socket.socket() as s:                       # a free port: several benches may share a host
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+            "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+
+
+def spawn_ranks(n, argv):
+    """Runs this script as n ranks; returns the launcher's exit status (non-zero if any rank failed)."""
+    import subprocess
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")    # dmabuf IPC: RCCL between processes needs it on this driver
+    return subprocess.call(spawn_command(n, argv), env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -242,8 +261,9 @@ def main():
     if args.gpus != world and dist_on:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if args.gpus > 1 and not dist_on:
-        raise SystemExit("launch N>1 with: python -m torch.distributed.run --nnodes=1 --nproc-per-node %d "
-                         "--master-addr 127.0.0.1 --master-port 29500 bench.py --gpus %d" % (args.gpus, args.gpus))
+        # `python bench.py --gpus N` is ONE command: it re-launches itself as N ranks (one per GPU) under
+        # torch.distributed.run and hands back their exit status; rank 0's JSON line goes to this process's stdout
+        raise SystemExit(spawn_ranks(args.gpus, sys.argv[1:]))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the product path)")
     dev = torch.device("cuda", local % torch.cuda.device_count())
@@ -349,6 +369,12 @@ def main():
         if rank == 0 and not w.get("f16") and not args.no_verify:
             verified, verify_info = verify_against_oracle(f, pts, names, w, sc, out_check)
 
+    rank_devices = [torch.cuda.get_device_name(dev)]
+    if dist_on:
+        import torch.distributed as dist
+        names_all = [None] * world
+        dist.all_gather_object(names_all, "rank %d: cuda:%d %s" % (rank, dev.index, torch.cuda.get_device_name(dev)))
+        rank_devices = names_all
     total_pts = world * n * args.steps
     value = total_pts / wall
     bytes_alg, per_pt = algorithmic_bytes(w, n)
@@ -369,6 +395,9 @@ def main():
                    "points": ("grid" if (w["step"] is not None and args.points == "grid") else "random cloud"),
                    "points_per_gpu": n, "views": w["V"], "feature_dim": w["C"], "feature_map": list(w["fhw"]),
                    "parallelism": "points sharded x%d, maps replicated" % world,
+                   # what torch.distributed itself reports (backend "nccl" is RCCL on ROCm), and where every rank ran
+                   "rccl_world_size": (dist.get_world_size() if dist_on else 1), "backend": (args.backend if dist_on else "n/a"),
+                   "rank_devices": rank_devices,
                    "gather": (args.gather if dist_on else "n/a"),
                    "gather_overlap": ((not args.no_overlap) if dist_on else "n/a"),
                    "gather_overlap_error": (overlap_error[0] if overlap_error else None),

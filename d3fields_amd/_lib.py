@@ -86,6 +86,8 @@ SIGNATURES = {
     "d3f_vox_iou_workspace_bytes": (_i64, [_i64, _i64]),
     "d3f_vox_idx_iou": (ctypes.c_int, [_vp, _i64, _vp, _i64, _vp, _vp, _i64, _vp]),
     "d3f_erode": (ctypes.c_int, [_vp, _i32, _i32, _i32, _i32, _vp, _vp]),
+    "d3f_mask_gate": (ctypes.c_int, [_vp, _i64, _i64, _vp, _i32, _i32, _f32, _f32, _vp, _vp]),
+    "d3f_nonzero_pixels": (ctypes.c_int, [_vp, _i32, _i32, _i64, _vp, _vp, _vp, _vp]),
     "d3f_fps_pixels": (ctypes.c_int, [_vp, _i64, _i32, _i64, _vp, _vp, _vp, _vp]),
     "d3f_eval_backward": (ctypes.c_int, [ctypes.POINTER(Views), _vp, _i64, ctypes.POINTER(ChannelMap), _i32, _f32,
                                          _vp, ctypes.POINTER(_vp), _vp, _vp]),

@@ -155,6 +155,84 @@ hipError_t launch_erode(const uint8_t *src, int H, int W, int kh, int kw, uint8_
     return hipGetLastError();
 }
 
+// ---- instance-mask gate and row-major nonzero (select_features_rand_v2, fusion.py:1554-1565) ------------------------------
+// gate:    out(y,x) = 255 if mask(y,x) != 0 && depth(y,x) > lo && depth(y,x) < hi else 0 -- the reference's
+//          `mask.astype(bool) & (depth > 0.0) & (depth < 1.5)` scaled to the uint8 image cv2.erode takes (fusion.py:1557-1561);
+//          the mask channel is read in place from the channels-last one-hot tensor (element strides).
+// nonzero: np.array(img.nonzero()).T -- the (row, col) pairs of the nonzero pixels in ascending (row-major) order, by the
+//          two-pass order-preserving compaction of pcd_kernels.hip (per-workgroup counts, then prefix + in-workgroup rank).
+__global__ __launch_bounds__(kBlock) void mask_gate_kernel(const float *__restrict__ mask, int64_t sy, int64_t sx,
+                                                          const float *__restrict__ depth, int H, int W, float lo, float hi,
+                                                          uint8_t *__restrict__ out)
+{
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= (int64_t)H * W) return;
+    const int y = (int)(i / W), x = (int)(i % W);
+    const float d = depth[i];
+    out[i] = (mask[y * sy + x * sx] != 0.0f && d > lo && d < hi) ? 255 : 0;
+}
+
+hipError_t launch_mask_gate(const float *mask, int64_t sy, int64_t sx, const float *depth, int H, int W, float lo, float hi,
+                            uint8_t *out, hipStream_t s)
+{
+    const int64_t n = (int64_t)H * W;
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(mask_gate_kernel, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, mask, sy, sx, depth, H, W, lo, hi, out);
+    return hipGetLastError();
+}
+
+__global__ __launch_bounds__(kBlock) void nonzero_count_kernel(const uint8_t *__restrict__ img, int64_t npix, int64_t *__restrict__ counts)
+{
+    __shared__ int wave_cnt[kBlock / 64];
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    const bool keep = i < npix && img[i] != 0;
+    const unsigned long long b = __ballot(keep);
+    if ((threadIdx.x & 63) == 0) wave_cnt[threadIdx.x >> 6] = __popcll(b);
+    __syncthreads();
+    if (threadIdx.x == 0) counts[blockIdx.x] = wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
+}
+
+__global__ __launch_bounds__(kBlock) void nonzero_write_kernel(const uint8_t *__restrict__ img, int64_t npix, int W,
+                                                              const int64_t *__restrict__ counts, int64_t capacity,
+                                                              int32_t *__restrict__ out_rc, int64_t *__restrict__ total)
+{
+    __shared__ long long part[kBlock];
+    __shared__ int wave_cnt[kBlock / 64];
+    long long acc = 0;
+    for (int64_t b = threadIdx.x; b < (int64_t)blockIdx.x; b += kBlock) acc += counts[b];
+    part[threadIdx.x] = acc;
+    __syncthreads();
+    for (int s = kBlock / 2; s > 0; s >>= 1) {
+        if (threadIdx.x < s) part[threadIdx.x] += part[threadIdx.x + s];
+        __syncthreads();
+    }
+    const long long prefix = part[0];
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    const bool keep = i < npix && img[i] != 0;
+    const unsigned long long b = __ballot(keep);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) wave_cnt[wave] = __popcll(b);
+    __syncthreads();
+    int before = 0;
+    for (int w = 0; w < wave; ++w) before += wave_cnt[w];
+    if (keep) {
+        const long long slot = prefix + before + __popcll(b & ((1ull << lane) - 1ull));
+        if (slot < capacity) { out_rc[slot * 2 + 0] = (int32_t)(i / W); out_rc[slot * 2 + 1] = (int32_t)(i % W); }
+    }
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0)
+        *total = prefix + wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
+}
+
+hipError_t launch_nonzero_pixels(const uint8_t *img, int H, int W, int64_t capacity, int32_t *out_rc, int64_t *count,
+                                 int64_t *block_counts, hipStream_t s)
+{
+    const int64_t npix = (int64_t)H * W;
+    const unsigned nb = (unsigned)((npix + kBlock - 1) / kBlock);
+    hipLaunchKernelGGL(nonzero_count_kernel, dim3(nb), dim3(kBlock), 0, s, img, npix, block_counts);
+    hipLaunchKernelGGL(nonzero_write_kernel, dim3(nb), dim3(kBlock), 0, s, img, npix, W, block_counts, capacity, out_rc, count);
+    return hipGetLastError();
+}
+
 // ---- fps_np on integer 2-D points ------------------------------------------------------------------------------------
 constexpr int kFpsPixBlock = 1024;
 

@@ -707,6 +707,27 @@ int d3f_erode(const uint8_t *src, int32_t H, int32_t W, int32_t kh, int32_t kw, 
     return e == hipSuccess ? D3F_OK : hip_fail(e, "erode launch");
 }
 
+int d3f_mask_gate(const float *mask_channel, int64_t stride_y, int64_t stride_x, const float *depth, int32_t H, int32_t W,
+                  float depth_lo, float depth_hi, uint8_t *out, void *stream)
+{
+    if (H < 0 || W < 0 || (int64_t)H * W > 0x7fffffffLL) return fail(D3F_ERR_BAD_SHAPE, "mask_gate: H=%d W=%d", H, W);
+    if ((int64_t)H * W == 0) return D3F_OK;
+    if (!mask_channel || !depth || !out) return fail(D3F_ERR_INVALID_ARG, "mask_gate: NULL pointer");
+    hipError_t e = d3f::launch_mask_gate(mask_channel, stride_y, stride_x, depth, H, W, depth_lo, depth_hi, out, static_cast<hipStream_t>(stream));
+    return e == hipSuccess ? D3F_OK : hip_fail(e, "mask_gate launch");
+}
+
+int d3f_nonzero_pixels(const uint8_t *image, int32_t H, int32_t W, int64_t capacity, int32_t *out_row_col, int64_t *count_out,
+                       void *workspace, void *stream)
+{
+    if (H < 1 || W < 1 || (int64_t)H * W > 0x7fffffffLL) return fail(D3F_ERR_BAD_SHAPE, "nonzero_pixels: H=%d W=%d", H, W);
+    if (!image || !count_out || !workspace || capacity < 0 || (capacity > 0 && !out_row_col))
+        return fail(D3F_ERR_INVALID_ARG, "nonzero_pixels: NULL pointer or negative capacity");
+    hipError_t e = d3f::launch_nonzero_pixels(image, H, W, capacity, out_row_col, count_out, static_cast<int64_t *>(workspace),
+                                              static_cast<hipStream_t>(stream));
+    return e == hipSuccess ? D3F_OK : hip_fail(e, "nonzero_pixels launch");
+}
+
 int d3f_fps_pixels(const int32_t *pts, int64_t n, int32_t k, int64_t init_idx, int64_t *out_idx, double *out_maxdist,
                    int64_t *dist_workspace, void *stream)
 {

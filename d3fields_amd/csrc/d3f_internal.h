@@ -136,6 +136,10 @@ int64_t voxset_capacity(int64_t n1, int64_t n2);
 hipError_t launch_voxset_iou(const int32_t *a, int64_t na, const int32_t *b, int64_t nb, int64_t *counts, void *workspace,
                              hipStream_t s);
 hipError_t launch_erode(const uint8_t *src, int H, int W, int kh, int kw, uint8_t *dst, hipStream_t s);
+hipError_t launch_mask_gate(const float *mask, int64_t sy, int64_t sx, const float *depth, int H, int W, float lo, float hi,
+                            uint8_t *out, hipStream_t s);
+hipError_t launch_nonzero_pixels(const uint8_t *img, int H, int W, int64_t capacity, int32_t *out_rc, int64_t *count,
+                                 int64_t *block_counts, hipStream_t s);
 hipError_t launch_fps_pixels(const int32_t *pts, int64_t n, int k, int64_t init_idx, int64_t *out_idx, double *out_maxdist,
                              int64_t *dist_ws, hipStream_t s);
 

@@ -212,6 +212,11 @@ class Fusion:
         # widened maps bit for bit (D3F_DTYPE_F16, include/d3fields_hip.h).
         if dtype not in (torch.float32, torch.float16):
             raise NotImplementedError("channel maps are stored as float32 or float16; got %s" % dtype)
+        if dtype == torch.float16:
+            import warnings
+            warnings.warn("d3fields_amd.Fusion(dtype=torch.float16) STORES the channel maps in half and computes in float32 (the "
+                          "query equals the float32 query on the widened maps bit for bit); the reference's float16 mode "
+                          "computes everything in half (fusion.py:203,227,709-712) and gives different numbers.", stacklevel=2)
         self.device = torch.device(device)
         self.dtype = dtype
         self.mu = 0.02                          # reference fusion.py:208
@@ -365,7 +370,10 @@ class Fusion:
                 li = out_host[:4].view(torch.int32).tolist()
                 near, far = out_host[4:6].tolist()
                 dims = tuple(li[:3]) if (li[0] > 0 and li[3] == 0) else None
+                self._hints.pop(n, None)                           # (re-)insert as the most recent entry
                 self._hints[n] = [dims, bool(near > 0.25 * far)]
+                while len(self._hints) > 64:                        # bounded: sizes come and go in long-running trackers
+                    self._hints.pop(next(iter(self._hints)))
                 self._pinned.append(out_host)
             else:
                 still.append((n, out_host, ev))
@@ -483,7 +491,7 @@ class Fusion:
             maps = (_lib.ChannelMap * max(len(names), 1))()
             fused = (ctypes.c_void_p * max(len(names), 1))()
             inter = (ctypes.c_void_p * max(len(names), 1))()
-            finite = self._is_finite("depth", keep[0])
+            finite = self._is_finite("depth", self.curr_obs_torch["depth"])     # the caller's tensor, not the contiguous fp32 copy
             used_maps = []
             for s, k in enumerate(names):
                 m = self.curr_obs_torch[k]                 # KeyError for unknown names, like the reference
@@ -491,10 +499,10 @@ class Fusion:
                     raise ValueError("curr_obs_torch[%r] must be a (V,h,w,C) tensor" % k)
                 if m.device != dev or m.dtype not in (torch.float32, torch.float16):
                     raise RuntimeError("curr_obs_torch[%r] must be float32 or float16 on %s" % (k, dev))
-                if m.stride(3) != 1:
+                finite = finite and self._is_finite(k, m)      # keyed on the caller's tensor object: a contiguous copy made
+                if m.stride(3) != 1:                           # below is a NEW tensor on every call and would never hit
                     m = m.contiguous()
                     keep.append(m)
-                finite = finite and self._is_finite(k, m)
                 used_maps.append(m)
                 C = m.shape[3]
                 o = torch.empty((n, C), dtype=torch.float32, device=dev)
@@ -507,7 +515,7 @@ class Fusion:
                     it = torch.empty((V, n, C), dtype=torch.float32, device=dev)
                     outputs[k + "_inter"] = it
                     inter[s] = it.data_ptr()
-            flags = (_lib.FLAG_FINITE_MAPS if finite else 0) | int(self.tuning_flags) | int(Fusion.extra_tuning_flags) | int(Fusion.extra_tuning_flags)
+            flags = (_lib.FLAG_FINITE_MAPS if finite else 0) | int(self.tuning_flags) | int(Fusion.extra_tuning_flags)
             ws, ws_bytes = None, 0
             dims, hinted_unordered = None, None
             if self.reorder_points and names and n >= 65536 and not torch.cuda.is_current_stream_capturing():
@@ -622,15 +630,15 @@ class Fusion:
         out = {"dist": dist, "valid_mask": valid, "grid_shape": torch.Size([grid.nx, grid.ny, grid.nz])}
         maps = (_lib.ChannelMap * max(len(names), 1))()
         fused = (ctypes.c_void_p * max(len(names), 1))()
-        finite = self._is_finite("depth", keep[0])
+        finite = self._is_finite("depth", self.curr_obs_torch["depth"])     # the caller's tensor, not the contiguous fp32 copy
         for s, k in enumerate(names):
             m = self.curr_obs_torch[k]
             if m.device != dev or m.dtype not in (torch.float32, torch.float16):
                 raise RuntimeError("curr_obs_torch[%r] must be float32 or float16 on %s" % (k, dev))
+            finite = finite and self._is_finite(k, m)          # on the caller's tensor object, before any contiguous copy
             if m.stride(3) != 1:
                 m = m.contiguous()
                 keep.append(m)
-            finite = finite and self._is_finite(k, m)
             out[k] = torch.empty((n, m.shape[3]), dtype=torch.float32, device=dev)
             maps[s] = _lib.ChannelMap(m.data_ptr(), m.shape[1], m.shape[2], m.shape[3],
                                       _lib.DTYPE_F16 if m.dtype == torch.float16 else _lib.DTYPE_F32,
@@ -764,43 +772,45 @@ class Fusion:
         return pcd_utils.vox_idx_iou(vox_idx_1, vox_idx_2)
 
     def select_features_rand_v2(self, boundaries, N, per_instance=False):
-        """Reference Fusion.select_features_rand_v2 (fusion.py:1539-1606): per instance and camera, erode the instance
-        mask (15x15, valid depth only), farthest-point-sample N // num_cam of its PIXELS, back-project them with the
-        camera's depth and pose, and query their descriptors.  Returns (src_feats_list, src_pts_list, img_list);
-        img_list (cv2 keypoint renderings in the reference) is always empty.  The erosion, the pixel FPS and the
-        field query run on the device; the random FPS starts come from np.random.randint in the reference's order."""
+        """Reference Fusion.select_features_rand_v2 (fusion.py:1539-1606): for every instance (every mask channel whose
+        label differs from its predecessor's, or all of them with per_instance) and camera, erode the instance mask
+        (15x15, valid depth only), farthest-point-sample N // num_cam of its PIXELS, lift them to world points with the
+        camera's depth and pose, and query their descriptors.  Returns (src_feats_list, src_pts_list, img_list); img_list
+        (cv2 keypoint renderings in the reference) is always empty.
+
+        Per (instance, camera) the gate, the erosion, the row-major nonzero, the pixel FPS and the gather of the selected
+        pixels' depths are one device pipeline (pcd_utils.masked_pixel_fps: the nonzero count and the k selected pixels are
+        the only host traffic -- the count because fps_np seeds itself with np.random.randint(count), so the reference's
+        random stream is reproduced draw for draw); the lift of those k pixels is float64 on the host exactly as the
+        reference writes it (a 4x4 inverse and a [4,k] product), which keeps the keypoints bit-identical to its own."""
         from . import pcd_utils
-        N_per_cam = N // self.num_cam
-        src_feats_list, src_pts_list = [], []
-        label = self.curr_obs_torch["mask_label"][0]
-        last_label = label[0]
-        depth_all = self.curr_obs_torch["depth"].detach().cpu().numpy()
-        K_all = self.curr_obs_torch["K"].detach().cpu().numpy()
-        pose_all = self.curr_obs_torch["pose"].detach().cpu().numpy()
-        for i in range(1, len(label)):
-            if label[i] == last_label and not per_instance:
+        per_cam = N // self.num_cam
+        obs = self.curr_obs_torch
+        labels = obs["mask_label"][0]
+        depth = obs["depth"].float()
+        intrinsics = obs["K"].detach().cpu().numpy()
+        cam_to_world = [np.linalg.inv(np.concatenate([p[:3], np.array([[0, 0, 0, 1]])], axis=0))
+                        for p in obs["pose"].detach().cpu().numpy()]                       # fusion.py:1552, 1573
+        feats_out, pts_out = [], []
+        previous = labels[0]
+        for inst in range(1, len(labels)):
+            if labels[inst] == previous and not per_instance:
                 continue
-            src_pts_np = []
-            for cam_i in range(self.num_cam):
-                instance_mask = self.curr_obs_torch["mask"][cam_i, :, :, i].detach().cpu().numpy().astype(bool)
-                depth_i, K_i = depth_all[cam_i], K_all[cam_i]
-                pose_i = np.concatenate([pose_all[cam_i][:3], np.array([[0, 0, 0, 1]])], axis=0)
-                instance_mask = instance_mask & (depth_i > 0.0) & (depth_i < 1.5)                  # fusion.py:1557-1558
-                instance_mask = pcd_utils.erode((instance_mask * 255).astype(np.uint8), np.ones([15, 15], np.uint8))
-                instance_mask_idx = np.array(instance_mask.nonzero()).T                             # (num_pts, 2) rows, cols
-                sel_idx, _, _ = pcd_utils.fps_pixels(instance_mask_idx, N_per_cam)
-                sel_depth = depth_i[sel_idx[:, 0], sel_idx[:, 1]]
-                src_pts = np.zeros([N_per_cam, 3])
-                src_pts[:, 0] = (sel_idx[:, 1] - K_i[0, 2]) * sel_depth / K_i[0, 0]
-                src_pts[:, 1] = (sel_idx[:, 0] - K_i[1, 2]) * sel_depth / K_i[1, 1]
-                src_pts[:, 2] = sel_depth
-                hom = np.concatenate([src_pts, np.ones([N_per_cam, 1])], axis=-1).T
-                src_pts_np.append(np.matmul(np.linalg.inv(pose_i), hom)[:3].T)                     # camera -> world
-            sample_pts = np.concatenate(src_pts_np, axis=0)
-            src_pts_list.append(sample_pts)
-            src_feats_list.append(self.eval(torch.from_numpy(sample_pts).to(self.device, torch.float32))["dino_feats"])
-            last_label = label[i]
-        return src_feats_list, src_pts_list, []
+            world = []
+            for cam in range(self.num_cam):
+                pix, z = pcd_utils.masked_pixel_fps(obs["mask"][cam, :, :, inst], depth[cam], per_cam)   # fusion.py:1554-1568
+                fx, fy, cx, cy = intrinsics[cam][0, 0], intrinsics[cam][1, 1], intrinsics[cam][0, 2], intrinsics[cam][1, 2]
+                lifted = np.zeros([per_cam, 3])                                           # float64, like the reference
+                lifted[:, 0] = (pix[:, 1] - cx) * z / fx
+                lifted[:, 1] = (pix[:, 0] - cy) * z / fy
+                lifted[:, 2] = z
+                homog = np.concatenate([lifted, np.ones([per_cam, 1])], axis=-1).T
+                world.append(np.matmul(cam_to_world[cam], homog)[:3].T)
+            cloud = np.concatenate(world, axis=0)
+            pts_out.append(cloud)
+            feats_out.append(self.eval(torch.from_numpy(cloud).to(self.device, torch.float32))["dino_feats"])
+            previous = labels[inst]
+        return feats_out, pts_out, []
 
     # ---- instance masks: upstream producers (reference fusion.py:1112-1256) ----------------
     # The reference hard-wires Grounded-SAM + its multi-view association (align_instance_mask_v3, fusion.py:1067-1098)
@@ -861,13 +871,17 @@ class Fusion:
         if isinstance(out, np.ndarray):
             out = torch.from_numpy(out)
         out = out.to(self.device)
+        # validate against the ids this call WOULD install, commit the tracker state only once the output is accepted:
+        # a tracker that fails on the first frame must leave the object in "no first mask yet" (the reference reaches
+        # the tracking-only branch only after a successful first frame, fusion.py:1240)
+        track_ids = list(range(len(self.curr_obs_torch["consensus_mask_label"]))) if label_img is not None else self.track_ids   # fusion.py:657
+        if out.dim() == 3:
+            out = instance2onehot(out.to(torch.uint8).contiguous(), len(track_ids))               # fusion.py:683
+        if out.dim() != 4 or out.shape[-1] != len(track_ids):
+            raise ValueError("mask_tracker must return (V,H,W,%d) one-hot or (V,H,W) labels, got %s" % (len(track_ids), tuple(out.shape)))
         if label_img is not None:
             self.xmem_first_mask_loaded = True                                                    # fusion.py:663-665
-            self.track_ids = list(range(len(self.curr_obs_torch["consensus_mask_label"])))       # fusion.py:657
-        if out.dim() == 3:
-            out = instance2onehot(out.to(torch.uint8).contiguous(), len(self.track_ids))          # fusion.py:683
-        if out.dim() != 4 or out.shape[-1] != len(self.track_ids):
-            raise ValueError("mask_tracker must return (V,H,W,%d) one-hot or (V,H,W) labels, got %s" % (len(self.track_ids), tuple(out.shape)))
+            self.track_ids = track_ids
         return out
 
     def text_queries_for_inst_mask_no_track(self, queries, thresholds, boundaries, merge_all=False, expected_labels=None,

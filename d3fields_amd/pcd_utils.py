@@ -206,8 +206,8 @@ def fps_pixels(pixel_idx, particle_num, init_idx=-1):
         raise TypeError("fps_pixels expects integer pixel coordinates")
     n = pix.shape[0]
     start = int(np.random.randint(n)) if init_idx == -1 else int(init_idx)
-    k = min(int(particle_num), n)
-    dev = _device()
+    k = int(particle_num)       # NOT clamped to n: fps_np keeps appending (index 0 once every distance is 0) and always returns
+    dev = _device()             # particle_num points, which select_features_rand_v2 relies on for small eroded masks
     pts = torch.from_numpy(pix.astype(np.int32)).to(dev)
     idx = torch.empty(k, dtype=torch.int64, device=dev)
     maxd = torch.empty(1, dtype=torch.float64, device=dev)
@@ -217,3 +217,39 @@ def fps_pixels(pixel_idx, particle_num, init_idx=-1):
                                               _lib.current_stream_handle(dev)))
     sel = idx.cpu().numpy()
     return pix[sel], sel.tolist(), float(maxd.item())
+
+
+def masked_pixel_fps(mask_channel, depth, particle_num, depth_lo=0.0, depth_hi=1.5, kernel=(15, 15), init_idx=-1):
+    """The pixel side of select_features_rand_v2 for one (instance, camera) (fusion.py:1554-1568) as ONE device pipeline:
+    gate (mask != 0 & depth_lo < depth < depth_hi) -> cv2.erode with an all-ones kernel -> row-major nonzero -> fps_np on
+    the pixel indices -> the selected pixels and their depths.  mask_channel: (H,W) float32 DEVICE view (any strides, e.g.
+    curr_obs_torch['mask'][cam, :, :, i]); depth: (H,W) float32 device tensor.  Host traffic: the nonzero COUNT (fps_np
+    draws its start with np.random.randint(count), so the count has to reach the host first) and the result --
+    (sel_idx [k,2] int64 rows/cols, sel_depth [k] float32) as numpy arrays.  Raises like fps_np's assert when the eroded
+    mask is empty."""
+    lib = _lib.load()
+    dev = mask_channel.device
+    H, W = int(depth.shape[0]), int(depth.shape[1])
+    assert mask_channel.shape == (H, W) and mask_channel.dtype == torch.float32 and depth.dtype == torch.float32
+    depth = depth.contiguous()
+    gated = torch.empty((H, W), dtype=torch.uint8, device=dev)
+    eroded = torch.empty_like(gated)
+    rc = torch.empty((H * W, 2), dtype=torch.int32, device=dev)
+    count = torch.empty(1, dtype=torch.int64, device=dev)
+    ws = torch.empty(lib.d3f_backproject_workspace_bytes(H, W), dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev):
+        st = _lib.current_stream_handle(dev)
+        _lib.check(lib.d3f_mask_gate(_lib.ptr(mask_channel), mask_channel.stride(0), mask_channel.stride(1), _lib.ptr(depth), H, W,
+                                     float(depth_lo), float(depth_hi), _lib.ptr(gated), st))
+        _lib.check(lib.d3f_erode(_lib.ptr(gated), H, W, int(kernel[0]), int(kernel[1]), _lib.ptr(eroded), st))
+        _lib.check(lib.d3f_nonzero_pixels(_lib.ptr(eroded), H, W, H * W, _lib.ptr(rc), _lib.ptr(count), _lib.ptr(ws), st))
+        n = int(count.item())                                   # the one sync: np.random.randint(n) needs it
+        assert n > 0, "fps_np asserts a non-empty point set (the eroded instance mask is empty)"
+        start = int(np.random.randint(n)) if init_idx == -1 else int(init_idx)
+        k = int(particle_num)
+        idx = torch.empty(k, dtype=torch.int64, device=dev)
+        dist_ws = torch.empty(n, dtype=torch.int64, device=dev)
+        _lib.check(lib.d3f_fps_pixels(_lib.ptr(rc), n, k, start, _lib.ptr(idx), None, _lib.ptr(dist_ws), st))
+        sel = rc[idx].to(torch.int64)                            # [k,2] rows, cols
+        sel_depth = depth[sel[:, 0], sel[:, 1]]
+        return sel.cpu().numpy(), sel_depth.cpu().numpy()

@@ -246,6 +246,19 @@ int d3f_vox_idx_iou(const int32_t *idx1, int64_t n1, const int32_t *idx2, int64_
  * ignored (cv2's default border for erosion).  src != dst. */
 int d3f_erode(const uint8_t *src, int32_t H, int32_t W, int32_t kh, int32_t kw, uint8_t *dst, void *stream);
 
+/* The pixel side of select_features_rand_v2 (fusion.py:1554-1565), on the device:
+ *   d3f_mask_gate       out(y,x) = 255 where mask(y,x) != 0 and depth_lo < depth(y,x) < depth_hi, else 0 -- the reference's
+ *                       `mask.astype(bool) & (depth > 0.0) & (depth < 1.5)` as the uint8 image cv2.erode takes.  The mask
+ *                       channel is read in place from the channels-last one-hot tensor: element (y,x) at
+ *                       mask_channel[y*stride_y + x*stride_x] (ELEMENT strides); depth, out: [H,W] contiguous.
+ *   d3f_nonzero_pixels  np.array(image.nonzero()).T: the (row, col) int32 pairs of the nonzero pixels in ascending row-major
+ *                       order (order-preserving compaction).  out_row_col [capacity,2]; *count_out (device int64) = the
+ *                       number found, also when it exceeds capacity; workspace: d3f_backproject_workspace_bytes(H, W). */
+int d3f_mask_gate(const float *mask_channel, int64_t stride_y, int64_t stride_x, const float *depth, int32_t H, int32_t W,
+                  float depth_lo, float depth_hi, uint8_t *out, void *stream);
+int d3f_nonzero_pixels(const uint8_t *image, int32_t H, int32_t W, int64_t capacity, int32_t *out_row_col, int64_t *count_out,
+                       void *workspace, void *stream);
+
 /* fps_np (utils/my_utils.py:478-497) on integer 2-D points, as select_features_rand_v2 calls it on the (row, col)
  * indices of a mask (fusion.py:1565-1566): pts [n,2] int32, exact squared distances (numpy's float64 norms of
  * integer differences order identically), first maximum wins.  out_idx [k] int64, out_maxdist one device double

@@ -108,6 +108,39 @@ def test_fps_pixels_matches_oracle(dev):
     assert idx == widx and np.array_equal(sel, wsel) and md == wmd
     line = np.stack([np.zeros(11, np.int64), np.arange(11)], 1)                         # exact ties: first maximum wins
     assert pcd_utils.fps_pixels(line, 3, init_idx=5)[1] == np_pcd.fps_int(line, 3, 5)[1] == [5, 0, 10]
+    # more samples than points (a small instance after the 15x15 erosion): fps_np does NOT stop at n, it keeps appending
+    # (every distance is 0 by then: argmax = index 0) and returns particle_num points -- so does the kernel
+    sel, idx, md = pcd_utils.fps_pixels(line, 15, init_idx=5)
+    wsel, widx, wmd = np_pcd.fps_int(line, 15, 5)
+    assert len(idx) == 15 and idx == widx and idx[11:] == [0, 0, 0, 0] and np.array_equal(sel, wsel) and md == wmd == 0.0
+
+
+def test_masked_pixel_fps_pipeline(dev):
+    """gate -> erode -> row-major nonzero -> pixel FPS on the device == the reference's numpy sequence (fusion.py:1554-1568),
+    including an instance that erodes to fewer pixels than are sampled from it."""
+    import torch
+    from d3fields_amd import pcd_utils
+    from oracle import np_pcd
+    rng = np.random.default_rng(4)
+    H, W = 120, 160
+    depth = rng.uniform(0.4, 1.7, (H, W)).astype(np.float32)
+    depth[rng.random((H, W)) < 0.002] = 0.0
+    onehot = np.zeros((H, W, 3), np.float32)
+    onehot[20:90, 30:120, 1] = 1.0                      # a big instance
+    onehot[95:112, 10:28, 2] = 1.0                      # a small one: 17 x 18 pixels, 3 x 4 after the 15 x 15 erosion at best
+    depth[95:112, 10:28] = 0.8
+    m_dev, d_dev = torch.from_numpy(onehot).to(dev), torch.from_numpy(depth).to(dev)
+    for ch, k, start in ((1, 50, 7), (2, 25, 0)):
+        gate = onehot[:, :, ch].astype(bool) & (depth > 0.0) & (depth < 1.5)
+        er = np_pcd.erode_cv2((gate * 255).astype(np.uint8), np.ones([15, 15], np.uint8))
+        pix = np.array(er.nonzero()).T
+        assert 0 < pix.shape[0] and (ch == 1 or pix.shape[0] < k)
+        wsel, widx, _ = np_pcd.fps_int(pix, k, start)
+        sel, z = pcd_utils.masked_pixel_fps(m_dev[:, :, ch], d_dev, k, init_idx=start)
+        assert sel.shape == (k, 2) and np.array_equal(sel, wsel)
+        assert z.dtype == np.float32 and np.array_equal(z, depth[wsel[:, 0], wsel[:, 1]])
+    with pytest.raises(AssertionError):
+        pcd_utils.masked_pixel_fps(m_dev[:, :, 0], d_dev, 5)                            # empty mask: fps_np asserts
 
 
 def _v2_fusion(dev):

@@ -169,3 +169,45 @@ def test_stale_library_is_never_loaded_silently(monkeypatch, tmp_path):
     with pytest.raises((OSError, RuntimeError, ImportError)):
         _lib.load()
     monkeypatch.setattr(_lib, "_lib", None)
+
+
+def test_bench_gpus_n_is_a_single_command(monkeypatch):
+    """`python bench.py --gpus N` without a launcher around it must not die on plumbing: it re-launches itself as N ranks
+    under torch.distributed.run (127.0.0.1 rendezvous), passes its own arguments through and returns the launcher's status."""
+    import subprocess
+    import sys
+    import bench
+    cmd = bench.spawn_command(8, ["--gpus", "8", "--steps", "20", "--warmup", "5"], port=29512)
+    assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"]
+    assert cmd[3:11] == ["--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1", "--master-port", "29512", bench.__file__ if False else cmd[10]]
+    assert cmd[10].endswith("bench.py") and cmd[11:] == ["--gpus", "8", "--steps", "20", "--warmup", "5"]
+    seen = {}
+
+    def fake_call(c, env=None):
+        seen["cmd"], seen["env"] = c, env
+        return 3                                            # a rank failed
+
+    monkeypatch.setattr(subprocess, "call", fake_call)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        monkeypatch.delenv(k, raising=False)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "2", "--steps", "3"])
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert e.value.code == 3                                # the launcher's status is the command's status
+    assert seen["cmd"][4:6] == ["--nproc-per-node", "2"] and seen["cmd"][-4:] == ["--gpus", "2", "--steps", "3"]
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    # free ports are picked per launch
+    assert bench.spawn_command(2, [])[9] != "0"
+
+
+def test_fusion_float16_warns_about_its_meaning():
+    """Fusion(dtype=float16) keeps the reference's constructor argument but means fp16 STORAGE with fp32 arithmetic: say so."""
+    import warnings
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        Fusion(num_cam=2, dtype=torch.float16)
+    assert any("STORES the channel maps in half" in str(x.message) for x in w)
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        Fusion(num_cam=2)
+    assert not w
