@@ -39,13 +39,15 @@ WORKLOADS = {
     "c2_patch": dict(V=4, H=480, W=640, C=384, fhw=(48, 64), NI=0, step=0.005, N=985600),
     "c3_dense": dict(V=4, H=480, W=640, C=384, fhw=(480, 640), NI=8, step=0.004, N=1925000),
     "c3_patch": dict(V=4, H=480, W=640, C=384, fhw=(48, 64), NI=8, step=0.004, N=1925000),
-    "c4_patch": dict(V=8, H=720, W=1280, C=1024, fhw=(72, 128), NI=0, step=None, N=1000000),
+    # config 4: an 8 M-point lattice (2.5 mm: 320 x 280 x 88) cut into eight x-slabs of 40 planes, one per GPU (985 600 points
+    # each); --points random: a uniform cloud of 1 000 000 points per GPU instead (rounds 1-2 measured only that)
+    "c4_patch": dict(V=8, H=720, W=1280, C=1024, fhw=(72, 128), NI=0, step=0.0025, slabs=8, N=985600, N_cloud=1000000),
     # config 2 with the feature maps STORED in fp16 (D3F_DTYPE_F16: widened on load, fp32 arithmetic) -- an extension, not
     # the headline: the reference's own float16 mode computes everything in half
     "c2_dense_f16": dict(V=4, H=480, W=640, C=384, fhw=(480, 640), NI=0, step=0.005, N=985600, f16=True),
     "c2_patch_f16": dict(V=4, H=480, W=640, C=384, fhw=(48, 64), NI=0, step=0.005, N=985600, f16=True),
     # dense variant of config 4: 30.2 GB of feature maps per GPU (3.77 GB per view, just inside the 32-bit texel offsets)
-    "c4_dense": dict(V=8, H=720, W=1280, C=1024, fhw=(720, 1280), NI=0, step=None, N=1000000),
+    "c4_dense": dict(V=8, H=720, W=1280, C=1024, fhw=(720, 1280), NI=0, step=0.0025, slabs=8, N=985600, N_cloud=1000000),
     # BASELINE config 5: one tracking frame = Fusion.eval of 100 k keypoints (features + instance mask) followed by the
     # descriptor correspondence of utils/corr_utils.py against 300 reference descriptors (+ fused argmax)
     "c5_track": dict(V=4, H=480, W=640, C=384, fhw=(48, 64), NI=8, step=None, N=100000, corr_refs=300),
@@ -86,14 +88,25 @@ def build_workload(name, dev, rank, world, points="grid"):
         f.curr_obs_torch["mask"] = synth.random_onehot_mask(V, H, W, w["NI"], seed=2, device=dev)
         names.append("mask")
     f.H, f.W = H, W
-    if w["step"] is not None and points == "grid":
+    if w["step"] is not None and points == "grid" and w.get("slabs"):
+        # one x-slab of the job's lattice per rank (north star: "8M points sharded across 8 GPUs"); fewer ranks than slabs
+        # take slabs spread over the box (one GPU: a middle slab, the representative one)
+        S = w["slabs"]
+        slab = (S // 2 - 1) if world == 1 else (rank * S // world) % S
+        box = dict(synth.WORK_BOX)
+        width = (box["x_upper"] - box["x_lower"]) / S
+        box["x_lower"] = synth.WORK_BOX["x_lower"] + slab * width
+        box["x_upper"] = box["x_lower"] + width - w["step"] / 4          # arange(lower, upper, step): exactly width/step planes
+        pts, shape = create_init_grid(box, w["step"])
+        assert pts.shape[0] == w["N"], (tuple(shape), pts.shape[0], w["N"])
+    elif w["step"] is not None and points == "grid":
         # weak scaling: the job's grid is `world` times finer along x (step/world); rank r owns the
         # x-planes congruent to r, i.e. the same box shifted by r*step/world -> N points per rank
         pts, _ = create_init_grid(synth.WORK_BOX, w["step"])
         if world > 1:
             pts[:, 0] += rank * w["step"] / world
     else:       # uniformly random cloud of the same N in the same box: no locality in the caller's order
-        pts = synth.random_cloud(w["N"], seed=3 + rank)
+        pts = synth.random_cloud(w.get("N_cloud", w["N"]), seed=3 + rank)
     return f, pts.to(dev), names, w, sc
 
 

@@ -252,6 +252,7 @@ int eval_common(const d3f_views *views, const float *pts, int64_t n, const d3f_c
     P.thin_max_views = (exp_knob("D3F_EXP_THIN") < 0 || (flags & D3F_TUNE_DIRECT_GATHER)) ? 0 : 8;
     P.win_lpp = exp_knob("D3F_EXP_WINDOW_LPP") == 32 ? 32 : 16;     // 16 lanes x 2 vectors per point (C2 patch 0.565 -> 0.54 ms); U > 1: 32
     P.win_slices = 0; P.win_u = 1; P.win_vc = 1; P.win_pool_offset = 0; P.win_pool_texels = 0; P.win_occ = 4;
+    P.wp_on = 0; P.wp_ctx_bytes = 0; P.wp_grid = 0; P.wp_gather = 8;
     P.store_policy = exp_knob("D3F_EXP_STORE") < 0 ? 0 : 1;
     int64_t map_bytes = 0;
     P.out_dist = out_dist; P.out_valid = out_valid;
@@ -324,7 +325,12 @@ int eval_common(const d3f_views *views, const float *pts, int64_t n, const d3f_c
             for (;; --occ) {
                 const int budget = 160 * 1024 / occ - 2048;     // the kernel's static LDS (corner points, windows, slot table) is 1.7 KiB
                 texels = (budget - pool_offset) / (512 * U) - 2;
-                if (texels >= 2 * views->V || occ == 2) break;  // room for a 2-texel window per view at least
+                // A 4x4x4 brick's window is ~3x4 texels per view once a texel is at least as wide as the brick's footprint
+                // (config 4's slab: 2.5-mm lattice, 10-px texels), and a pool that cannot hold the views' windows sends the
+                // overflowing pairs to the global gather: give every view ~11 slots, at the price of workgroups per CU
+                // (MI355X, config 4 lattice slab: 4 / 3 / 2 workgroups per CU = 3.15 / 3.54 / 2.43 ms; config 2, four
+                // views, fits at 4 and loses 18 % at 2)
+                if (texels >= 11 * views->V || occ == 2) break;
             }
             if (exp_knob("D3F_EXP_WINDOW_POOL") > 0 && exp_knob("D3F_EXP_WINDOW_POOL") < texels) texels = exp_knob("D3F_EXP_WINDOW_POOL");
             if (texels > 320) texels = 320;                      // kWinMaxTexels (fuse_eval.hip)
@@ -334,6 +340,26 @@ int eval_common(const d3f_views *views, const float *pts, int64_t n, const d3f_c
             P.win_u = U; P.win_occ = occ; P.win_pool_offset = pool_offset; P.win_pool_texels = texels;
             P.win_vc = exp_knob("D3F_EXP_WINDOW_VC") == 2 ? 2 : 1;
             P.win_slices = window ? cv / U : 0;
+            // Pipelined form (fused_eval_winpipe_kernel: one producer wave + four gather waves per persistent workgroup, two
+            // record contexts and two pool buffers in LDS): lattices, 512-byte slices, 64-point bricks.  Two workgroups per
+            // CU when both pool buffers then still give every view ~11 slots, else one.
+            if (window && lattice && U == 1 && P.win_lpp == 16 && T == 64 && exp_knob("D3F_EXP_WINPIPE") >= 0) {
+                const int ctx = (T * views->V * (n_maps > 1 ? 48 : 32) + T * 20 + 8 * 24 + 16 + 320 * 4 + 15) / 16 * 16;
+                const int pool0 = (2 * ctx + views->V * 48 + 511) / 512 * 512;
+                int wocc = exp_knob("D3F_EXP_WINPIPE_OCC") == 1 ? 1 : 2, wtex = 0;
+                for (;; --wocc) {
+                    wtex = ((160 * 1024 / wocc - 1024 - pool0) / 2) / 512 - 2;
+                    if (wtex >= 11 * views->V || wocc == 1) break;
+                }
+                if (wtex > 320) wtex = 320;
+                wtex &= ~1;
+                P.st_debug = exp_knob("D3F_EXP_STREAM_DEBUG");
+                if (wtex >= 2 * views->V) {
+                    P.wp_gather = exp_knob("D3F_EXP_WINPIPE_NG") > 0 ? exp_knob("D3F_EXP_WINPIPE_NG") : 8;
+                    P.wp_on = 1; P.wp_ctx_bytes = ctx; P.wp_grid = 32 * wocc * (exp_knob("D3F_EXP_WINPIPE_G") > 0 ? exp_knob("D3F_EXP_WINPIPE_G") : 1);
+                    P.win_pool_offset = pool0; P.win_pool_texels = wtex; P.win_occ = wocc;
+                }
+            }
         }
     }
     bool any_runs = false;
@@ -555,7 +581,12 @@ int eval_common(const d3f_views *views, const float *pts, int64_t n, const d3f_c
             plan_out->lds_bytes = P.win_pool_offset + (2 + P.win_pool_texels) * 512 * P.win_u;
             plan_out->workgroups = ntiles;
         }
-        plan_out->reserved = P.st_on ? 3000 + P.sl_lg * 100 + P.st_variant : P.sl_slices > 0 ? 100 + P.sl_lg * 10 + P.sl_vc : (P.win_slices > 0 ? 2000 + 100 * P.win_u + 10 * (P.win_u == 1 ? (P.win_lpp == 16 ? 2 : 4) : (P.win_u == 4 ? 1 : P.win_vc)) + (P.win_u == 1 ? (P.win_occ >= 4 ? 4 : (P.win_lpp == 16 ? 3 : P.win_occ)) : 2) : 0);   // 2UVW: the window kernel's template arguments      // 1LV: sliced launch, L = log2(lanes per point), V = views in flight
+        if (P.win_slices > 0 && P.wp_on) {
+            plan_out->lds_bytes = P.win_pool_offset + 2 * (2 + P.win_pool_texels) * 512;
+            plan_out->workgroups = 8 * P.wp_grid;           // persistent
+        }
+        plan_out->reserved = (P.win_slices > 0 && P.wp_on) ? 4000 + P.win_occ :
+                             P.st_on ? 3000 + P.sl_lg * 100 + P.st_variant : P.sl_slices > 0 ? 100 + P.sl_lg * 10 + P.sl_vc : (P.win_slices > 0 ? 2000 + 100 * P.win_u + 10 * (P.win_u == 1 ? (P.win_lpp == 16 ? 2 : 4) : (P.win_u == 4 ? 1 : P.win_vc)) + (P.win_u == 1 ? (P.win_occ >= 4 ? 4 : (P.win_lpp == 16 ? 3 : P.win_occ)) : 2) : 0);   // 2UVW: the window kernel's template arguments      // 1LV: sliced launch, L = log2(lanes per point), V = views in flight
         for (int s = 0; s < n_maps; ++s)
             if (P.maps[s].runs > 0) {        // waves per SIMD the chosen cell-run kernel variant is built for
                 const int ru = P.maps[s].unroll, rk = P.maps[s].runs;

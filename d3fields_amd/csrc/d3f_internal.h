@@ -65,6 +65,8 @@ struct EvalParams {
     int32_t win_pool_offset;   // byte offset of the two all-zero slices; the pool follows them
     int32_t win_pool_texels;   // pool capacity in texel slices of 512 * win_u bytes
     int32_t win_occ;           // workgroups per CU the kernel variant is built for (2 / 3 / 4)
+    int32_t wp_on, wp_ctx_bytes, wp_grid, wp_gather;   // pipelined window kernel (fused_eval_winpipe_kernel): per-brick context bytes,
+                               // persistent workgroups per XCD; win_pool_offset / win_pool_texels describe ONE of its two pool buffers
     int32_t win_lpp;           // lanes per point in phase B: 32, or 16 (two vectors per lane inside a 512-byte slice)
     int32_t thin_max_views;    // 8 (default): thin maps with 2..8 views are gathered with the views in parallel across lanes
                                // (gather_map_thin); 0 switches that off (D3F_EXP_THIN=-1, tests)

@@ -427,13 +427,15 @@ class Fusion:
         wide = any(plan.vectors_per_lane[s] == -4 for s in range(n_maps))
         f16 = any(maps[s].dtype == _lib.DTYPE_F16 for s in range(n_maps))
         kernel = ("fused_eval_f16_kernel<0>" if f16 else "fused_eval_wide_kernel<0>" if wide else "fused_eval_kernel<0>")
-        window = 2000 <= plan.reserved < 3000
-        stream = plan.reserved >= 3000
+        window = 2000 <= plan.reserved < 3000 or plan.reserved >= 4000
+        stream = 3000 <= plan.reserved < 4000
         if stream:
             lg, var = (plan.reserved - 3000) // 100, (plan.reserved - 3000) % 100
             T = int(plan.tile_points)
             kernel = "fused_eval_stream_kernel<%d, %d, %d, %d, %s, %d>" % (lg, T, 4 if T == 16 else 3, 4 if var == 2 else 2,
                                                                             "true" if var == 0 else "false", 7 if (var == 1 and T != 16) else 5)
+        elif plan.reserved >= 4000:
+            kernel = "fused_eval_winpipe_kernel<2, 2>"
         elif window:
             r = plan.reserved - 2000
             w0 = [s for s in range(n_maps) if plan.staged[s] == 3][0]           # the windowed map (any position in the call)
@@ -448,6 +450,8 @@ class Fusion:
                  0: "caller order"}[int(plan.reorder)]
         if window:
             order += "; %d-point bricks through texel windows in LDS" % int(plan.tile_points)
+            if plan.reserved >= 4000:
+                order += " (persistent workgroups: one producer wave + four gather waves)"
         elif runs:
             order += "; cell runs of %d consecutive points" % (max(plan.staged[s] for s in range(n_maps)) - 16)
         self._last_plan = {"kernel": kernel, "tile_points": int(plan.tile_points), "point_order": order,

@@ -123,8 +123,9 @@ def test_masked_pixel_fps_pipeline(dev):
     from oracle import np_pcd
     rng = np.random.default_rng(4)
     H, W = 120, 160
-    depth = rng.uniform(0.4, 1.7, (H, W)).astype(np.float32)
-    depth[rng.random((H, W)) < 0.002] = 0.0
+    depth = rng.uniform(0.4, 1.4, (H, W)).astype(np.float32)
+    depth[rng.random((H, W)) < 0.0005] = 0.0              # holes: the gate drops them, the erosion widens them
+    depth[22:30, 100:118] = 1.6                             # beyond the 1.5 m gate
     onehot = np.zeros((H, W, 3), np.float32)
     onehot[20:90, 30:120, 1] = 1.0                      # a big instance
     onehot[95:112, 10:28, 2] = 1.0                      # a small one: 17 x 18 pixels, 3 x 4 after the 15 x 15 erosion at best

@@ -237,15 +237,17 @@ def test_cell_run_gather_not_used_when_it_must_not(dev):
 
 
 # ---- the BENCH workloads themselves ---------------------------------------------------------------
-@pytest.mark.parametrize("workload", ["c2_dense", "c3_dense", "c2_patch", "c3_patch"])
-def test_bench_workload_matches_oracle(dev, workload):
+@pytest.mark.parametrize("workload,points", [("c2_dense", "grid"), ("c3_dense", "grid"), ("c2_patch", "grid"), ("c3_patch", "grid"),
+                                             ("c4_patch", "grid"), ("c4_patch", "random")])
+def test_bench_workload_matches_oracle(dev, workload, points):
     """Exactly what bench.py times (same builder, same launch geometry: lattice walk with 8- / 16-point tiles on the
-    dense maps, bricks through LDS texel windows on the patch-resolution maps) against the CPU oracle on a 3000-point sample, plus
-    bit-identity with the caller-order direct gather on 200 000 points."""
+    dense maps, bricks through LDS texel windows on the patch-resolution maps -- config 4's x-slab of the 8 M-point lattice
+    included --, cell runs on config 4's cloud) against the CPU oracle on a 3000-point sample, plus bit-identity with the
+    caller-order direct gather on 200 000 points."""
     import bench
     from d3fields_amd import _lib
-    f, pts, names, w, sc = bench.build_workload(workload, dev, 0, 1)
-    assert pts.shape[0] == w["N"]
+    f, pts, names, w, sc = bench.build_workload(workload, dev, 0, 1, points)
+    assert pts.shape[0] == (w["N"] if points == "grid" else w.get("N_cloud", w["N"]))
     with torch.no_grad():
         out = f.batch_eval(pts, return_names=names)
         sub = torch.randperm(pts.shape[0], generator=torch.Generator().manual_seed(9))[:200000].to(dev)
@@ -260,6 +262,34 @@ def test_bench_workload_matches_oracle(dev, workload):
     assert np.array_equal(cpu(out["dist"][pick]), ref["dist"])
     for i, k in enumerate(names):
         assert rel_err(cpu(out[k][pick]), ref["sets"][i]) <= TOL, k
+
+
+def test_bench_workload_c4_dense(dev):
+    """Config 4 with DENSE maps (8 x 720 x 1280 x 1024 fp32 = 30.2 GB resident) on its lattice slab: the walk's launch is
+    bit-identical to the caller-order direct gather on 100 000 points, and dist / valid_mask of a 3000-point sample equal the
+    CPU oracle's (they do not depend on the maps, so the oracle runs with a one-channel stand-in instead of a 30 GB host
+    copy).  Skipped on devices with less than 40 GB free."""
+    import bench
+    from d3fields_amd import _lib, synth
+    free, _ = torch.cuda.mem_get_info(dev)
+    if free < 40 * 2 ** 30:
+        pytest.skip("needs 40 GB of free device memory")
+    f, pts, names, w, sc = bench.build_workload("c4_dense", dev, 0, 1)
+    f.record_plans = True
+    with torch.no_grad():
+        out = f.batch_eval(pts, return_names=names)
+        assert "brick walk" in f.last_plan()["point_order"], f.last_plan()
+        sub = torch.randperm(pts.shape[0], generator=torch.Generator().manual_seed(9))[:100000].to(dev)
+        f.tuning_flags = _lib.TUNE_NO_REORDER | _lib.TUNE_DIRECT_GATHER
+        ref_gpu = f.eval(pts[sub], return_names=names)
+    for k in ["dist", "valid_mask"] + names:
+        assert torch.equal(out[k][sub], ref_gpu[k]), k
+    pick = sub[:3000]
+    ref = oracle_sample(sc, pts[pick].cpu(), [torch.zeros(w["V"], 2, 2, 1)])
+    assert np.array_equal(cpu(out["valid_mask"][pick]), ref["valid_mask"])
+    assert np.array_equal(cpu(out["dist"][pick]), ref["dist"])
+    del f, out, ref_gpu
+    torch.cuda.empty_cache()
 
 
 # ---- channel-sliced launch (experiment knob) == default launch, bit for bit -------------------------------------------
