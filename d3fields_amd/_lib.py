@@ -49,6 +49,11 @@ class Grid(ctypes.Structure):
     _fields_ = [("x", _vp), ("y", _vp), ("z", _vp), ("nx", _i32), ("ny", _i32), ("nz", _i32), ("reserved", _i32)]
 
 
+class TrackState(ctypes.Structure):
+    """struct d3f_track_state"""
+    _fields_ = [("t", _vp), ("w", _vp), ("adam_m", _vp), ("adam_v", _vp), ("step", _vp), ("out_pts", _vp), ("loss", _vp), ("scratch", _vp)]
+
+
 class EvalPlan(ctypes.Structure):
     """struct d3f_eval_plan"""
     _fields_ = [("tile_points", _i32), ("reorder", _i32), ("lds_bytes", _i32), ("reserved", _i32), ("workgroups", _i64),
@@ -77,6 +82,8 @@ SIGNATURES = {
     "d3f_lattice_probe": (ctypes.c_int, [_vp, _i64, _vp, _vp]),
     "d3f_grid_shell_workspace_bytes": (_i64, [ctypes.POINTER(Grid)]),
     "d3f_grid_shell": (ctypes.c_int, [ctypes.POINTER(Views), ctypes.POINTER(Grid), _f32, _f32, _i64, _vp, _vp, _vp, _i64, _vp]),
+    "d3f_fps_workspace_bytes": (_i64, [_i64]),
+    "d3f_fps_pixels_workspace_bytes": (_i64, [_i64]),
     "d3f_farthest_point_sampling": (ctypes.c_int, [_vp, _i64, _i32, _i64, _vp, _vp, _vp, _vp]),
     "d3f_backproject_workspace_bytes": (_i64, [_i32, _i32]),
     "d3f_backproject_view": (ctypes.c_int, [_vp, _vp, _i32, _i32, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double),
@@ -86,6 +93,8 @@ SIGNATURES = {
     "d3f_vox_iou_workspace_bytes": (_i64, [_i64, _i64]),
     "d3f_vox_idx_iou": (ctypes.c_int, [_vp, _i64, _vp, _i64, _vp, _vp, _i64, _vp]),
     "d3f_erode": (ctypes.c_int, [_vp, _i32, _i32, _i32, _i32, _vp, _vp]),
+    "d3f_voxel_downsample_workspace_bytes": (_i64, [_i64]),
+    "d3f_voxel_downsample": (ctypes.c_int, [_vp, _vp, _i64, ctypes.c_double, _vp, _vp, _vp, _vp, _i64, _vp]),
     "d3f_mask_gate": (ctypes.c_int, [_vp, _i64, _i64, _vp, _i32, _i32, _f32, _f32, _vp, _vp]),
     "d3f_nonzero_pixels": (ctypes.c_int, [_vp, _i32, _i32, _i64, _vp, _vp, _vp, _vp]),
     "d3f_fps_pixels": (ctypes.c_int, [_vp, _i64, _i32, _i64, _vp, _vp, _vp, _vp]),
@@ -108,6 +117,9 @@ SIGNATURES = {
     "d3f_point_order_locality": (ctypes.c_int, [_vp, _i64, _vp, _vp]),
     "d3f_rigid_transform": (ctypes.c_int, [_vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),
     "d3f_track_loss_grad": (ctypes.c_int, [_vp, _vp, _vp, _vp, _i64, _i32, _f32, _vp, _vp, _vp, _vp]),
+    "d3f_track_step_scratch_bytes": (_i64, [_i32, _i32]),
+    "d3f_track_step": (ctypes.c_int, [ctypes.POINTER(Views), ctypes.POINTER(ChannelMap), _vp, _i32, _i32, _vp, _f32, _f32, _f32, _f32, _f32,
+                                      _f32, _f32, ctypes.POINTER(TrackState), _vp]),
     "d3f_rigid_update": (ctypes.c_int, [_vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f32, _f32, _f32, _f32, _f32, _vp]),
     "d3f_softmax_merge": (ctypes.c_int, [_vp, _i64, _i64, _vp, _vp, _vp]),
     "d3f_softmax_apply": (ctypes.c_int, [_vp, _i64, _i64, _f32, _vp, _vp]),

@@ -11,10 +11,10 @@
 //   erode_kernel          cv2.erode of a binary uint8 image with a kh x kw all-ones kernel, anchor at the kernel
 //                         centre (kw/2, kh/2), one iteration, cv2's default border (out-of-image pixels never
 //                         constrain the minimum) -- fusion.py:1293 (2x2) and :1561 (15x15).
-//   fps_pixels_kernel     fps_np (utils/my_utils.py:478-497) on INTEGER 2-D pixel coordinates (fusion.py:1566): numpy
+//   (fps_np on INTEGER 2-D pixel coordinates, fusion.py:1566, lives with the 3-D variant in grid_kernels.hip: numpy
 //                         computes float64 norms of exact integer differences, so comparing the exact int64 squared
-//                         distances gives the same argmax sequence (sqrt is monotone and correctly rounded; equal
-//                         norms <=> equal squares below 2^53), first maximum wins.
+//                         distances gives the same argmax sequence -- sqrt is monotone and correctly rounded, equal
+//                         norms <=> equal squares below 2^53 --, first maximum wins.)
 #include "d3f_internal.h"
 
 namespace d3f {
@@ -155,6 +155,186 @@ hipError_t launch_erode(const uint8_t *src, int H, int W, int kh, int kw, uint8_
     return hipGetLastError();
 }
 
+// ---- voxel-grid mean: open3d's PointCloud::VoxelDownSample (utils/draw_utils.py:318-323, 396-400) ------------------------
+// open3d buckets the points into voxels of side `vs` anchored at min_bound - vs/2 (voxel index = floor((p - anchor) / vs))
+// and returns the mean point (and colour) of every occupied voxel, in the order of its hash map.  Here: one open-addressing
+// hash table keyed by the packed voxel index (21 bits per axis); every point adds its offset inside its voxel to exact
+// 64-bit fixed-point sums (2^-40 of a voxel side: order-independent, so the result is deterministic although the adds are
+// atomic), the occupied slots are compacted, ranked by key (counting rank, V^2 / 2 comparisons through LDS) and written in
+// ASCENDING key order: the same set of points as open3d's to ~1e-14 m, in a defined order.
+struct VoxSlot {
+    unsigned long long key;         // packed (ix, iy, iz), ~0 = empty
+    unsigned long long cnt;
+    long long sum[6];               // fixed-point offsets inside the voxel (x, y, z) and colours (r, g, b)
+};
+constexpr unsigned long long kVoxEmpty = ~0ULL;
+constexpr double kVoxFix = 1099511627776.0;     // 2^40
+
+int64_t voxmean_capacity(int64_t n)
+{
+    int64_t cap = 1024;
+    while (cap < 2 * n) cap <<= 1;
+    return cap;
+}
+
+int64_t voxmean_workspace_bytes(int64_t n)
+{
+    const int64_t cap = voxmean_capacity(n);
+    // min bound (3 doubles + pad), table, per-workgroup slot counts, the compacted slot list (cap worst case is n entries)
+    return 64 + cap * (int64_t)sizeof(VoxSlot) + ((cap + kBlock - 1) / kBlock + 1) * 8 + n * 8;
+}
+
+__global__ __launch_bounds__(1024) void voxmean_minbound_kernel(const double *__restrict__ pts, int64_t n, double *__restrict__ out)
+{
+    __shared__ double red[3][16];
+    double m[3] = {INFINITY, INFINITY, INFINITY};
+    for (int64_t i = threadIdx.x; i < n; i += 1024)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) m[k] = fmin(m[k], pts[i * 3 + k]);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        for (int off = 32; off > 0; off >>= 1) m[k] = fmin(m[k], __shfl_xor(m[k], off, 64));
+        if ((threadIdx.x & 63) == 0) red[k][threadIdx.x >> 6] = m[k];
+    }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        double v = red[threadIdx.x][0];
+        for (int w = 1; w < 16; ++w) v = fmin(v, red[threadIdx.x][w]);
+        out[threadIdx.x] = v;
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void voxmean_clear_kernel(VoxSlot *__restrict__ table, int64_t cap)
+{
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= cap) return;
+    VoxSlot z;
+    z.key = kVoxEmpty; z.cnt = 0;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) z.sum[k] = 0;
+    table[i] = z;
+}
+
+__global__ __launch_bounds__(kBlock) void voxmean_insert_kernel(const double *__restrict__ pts, const double *__restrict__ col, int64_t n,
+                                                               double vs, const double *__restrict__ minb, VoxSlot *__restrict__ table,
+                                                               int64_t cap)
+{
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    unsigned long long key = 0;
+    long long fix[6] = {0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const double anchor = minb[k] - vs * 0.5;                      // open3d: voxel_min_bound = min_bound - voxel_size * 0.5
+        const double ref = (pts[i * 3 + k] - anchor) / vs;
+        double id = floor(ref);
+        id = id < 0.0 ? 0.0 : (id > 2097151.0 ? 2097151.0 : id);      // 21 bits per axis
+        key = (key << 21) | (unsigned long long)id;
+        fix[k] = (long long)(((pts[i * 3 + k] - (anchor + id * vs)) / vs) * kVoxFix);
+        if (col) fix[3 + k] = (long long)(col[i * 3 + k] * kVoxFix);
+    }
+    const uint64_t mask = (uint64_t)cap - 1;
+    uint64_t h = (key * 0x9E3779B97F4A7C15ULL) >> 20 & mask;
+    for (int64_t probe = 0; probe < cap; ++probe) {
+        unsigned long long cur = table[h].key;
+        if (cur == kVoxEmpty) cur = atomicCAS(&table[h].key, kVoxEmpty, key);
+        if (cur == kVoxEmpty || cur == key) {
+            atomicAdd(&table[h].cnt, 1ULL);
+#pragma unroll
+            for (int k = 0; k < 6; ++k)
+                if (k < 3 || col) atomicAdd(reinterpret_cast<unsigned long long *>(&table[h].sum[k]), (unsigned long long)fix[k]);
+            return;
+        }
+        h = (h + 1) & mask;
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void voxmean_count_kernel(const VoxSlot *__restrict__ table, int64_t cap, int64_t *__restrict__ counts)
+{
+    __shared__ int wave_cnt[kBlock / 64];
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    const bool live = i < cap && table[i].key != kVoxEmpty;
+    const unsigned long long b = __ballot(live);
+    if ((threadIdx.x & 63) == 0) wave_cnt[threadIdx.x >> 6] = __popcll(b);
+    __syncthreads();
+    if (threadIdx.x == 0) counts[blockIdx.x] = wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
+}
+
+__global__ __launch_bounds__(kBlock) void voxmean_list_kernel(const VoxSlot *__restrict__ table, int64_t cap, const int64_t *__restrict__ counts,
+                                                             int64_t *__restrict__ list, int64_t *__restrict__ total)
+{
+    __shared__ long long part[kBlock];
+    __shared__ int wave_cnt[kBlock / 64];
+    long long acc = 0;
+    for (int64_t b = threadIdx.x; b < (int64_t)blockIdx.x; b += kBlock) acc += counts[b];
+    part[threadIdx.x] = acc;
+    __syncthreads();
+    for (int s = kBlock / 2; s > 0; s >>= 1) {
+        if (threadIdx.x < s) part[threadIdx.x] += part[threadIdx.x + s];
+        __syncthreads();
+    }
+    const long long prefix = part[0];
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    const bool live = i < cap && table[i].key != kVoxEmpty;
+    const unsigned long long b = __ballot(live);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) wave_cnt[wave] = __popcll(b);
+    __syncthreads();
+    int before = 0;
+    for (int w = 0; w < wave; ++w) before += wave_cnt[w];
+    if (live) list[prefix + before + __popcll(b & ((1ull << lane) - 1ull))] = i;
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) *total = prefix + wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
+}
+
+// rank of every occupied voxel among the keys (unique), then its mean at that position
+__global__ __launch_bounds__(kBlock) void voxmean_write_kernel(const VoxSlot *__restrict__ table, const int64_t *__restrict__ list,
+                                                              const int64_t *__restrict__ total, double vs, const double *__restrict__ minb,
+                                                              double *__restrict__ out_pts, double *__restrict__ out_col)
+{
+    __shared__ unsigned long long keys[kBlock];
+    const int64_t V = *total;
+    const int64_t j = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if ((int64_t)blockIdx.x * kBlock >= V) return;                     // whole workgroups leave together
+    const bool live = j < V;
+    const VoxSlot me = table[list[live ? j : 0]];
+    long long rank = 0;
+    for (int64_t t0 = 0; t0 < V; t0 += kBlock) {
+        __syncthreads();
+        keys[threadIdx.x] = t0 + threadIdx.x < V ? table[list[t0 + threadIdx.x]].key : kVoxEmpty;
+        __syncthreads();
+        const int cnt = (int)min((int64_t)kBlock, V - t0);
+        for (int t = 0; t < cnt; ++t) rank += keys[t] < me.key ? 1 : 0;
+    }
+    if (!live) return;
+    const double inv = 1.0 / (double)me.cnt;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const double id = (double)((me.key >> (21 * (2 - k))) & 0x1FFFFFULL);
+        const double anchor = minb[k] - vs * 0.5;
+        out_pts[rank * 3 + k] = (anchor + id * vs) + ((double)me.sum[k] * inv / kVoxFix) * vs;
+        if (out_col) out_col[rank * 3 + k] = (double)me.sum[3 + k] * inv / kVoxFix;
+    }
+}
+
+hipError_t launch_voxel_mean(const double *pts, const double *col, int64_t n, double vs, double *out_pts, double *out_col, int64_t *count,
+                             void *workspace, hipStream_t s)
+{
+    const int64_t cap = voxmean_capacity(n);
+    char *ws = static_cast<char *>(workspace);
+    double *minb = reinterpret_cast<double *>(ws);
+    VoxSlot *table = reinterpret_cast<VoxSlot *>(ws + 64);
+    const unsigned gcap = (unsigned)((cap + kBlock - 1) / kBlock);
+    int64_t *counts = reinterpret_cast<int64_t *>(ws + 64 + cap * (int64_t)sizeof(VoxSlot));
+    int64_t *list = counts + gcap + 1;
+    hipLaunchKernelGGL(voxmean_minbound_kernel, dim3(1), dim3(1024), 0, s, pts, n, minb);
+    hipLaunchKernelGGL(voxmean_clear_kernel, dim3(gcap), dim3(kBlock), 0, s, table, cap);
+    hipLaunchKernelGGL(voxmean_insert_kernel, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, pts, col, n, vs, minb, table, cap);
+    hipLaunchKernelGGL(voxmean_count_kernel, dim3(gcap), dim3(kBlock), 0, s, table, cap, counts);
+    hipLaunchKernelGGL(voxmean_list_kernel, dim3(gcap), dim3(kBlock), 0, s, table, cap, counts, list, count);
+    hipLaunchKernelGGL(voxmean_write_kernel, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, table, list, count, vs, minb, out_pts, out_col);
+    return hipGetLastError();
+}
+
 // ---- instance-mask gate and row-major nonzero (select_features_rand_v2, fusion.py:1554-1565) ------------------------------
 // gate:    out(y,x) = 255 if mask(y,x) != 0 && depth(y,x) > lo && depth(y,x) < hi else 0 -- the reference's
 //          `mask.astype(bool) & (depth > 0.0) & (depth < 1.5)` scaled to the uint8 image cv2.erode takes (fusion.py:1557-1561);
@@ -230,55 +410,6 @@ hipError_t launch_nonzero_pixels(const uint8_t *img, int H, int W, int64_t capac
     const unsigned nb = (unsigned)((npix + kBlock - 1) / kBlock);
     hipLaunchKernelGGL(nonzero_count_kernel, dim3(nb), dim3(kBlock), 0, s, img, npix, block_counts);
     hipLaunchKernelGGL(nonzero_write_kernel, dim3(nb), dim3(kBlock), 0, s, img, npix, W, block_counts, capacity, out_rc, count);
-    return hipGetLastError();
-}
-
-// ---- fps_np on integer 2-D points ------------------------------------------------------------------------------------
-constexpr int kFpsPixBlock = 1024;
-
-__global__ __launch_bounds__(kFpsPixBlock) void fps_pixels_kernel(const int32_t *__restrict__ pts, int64_t n, int k,
-                                                                 int64_t init_idx, int64_t *__restrict__ out_idx,
-                                                                 double *__restrict__ out_maxdist, int64_t *__restrict__ dist)
-{
-    __shared__ long long red_v[kFpsPixBlock / 64];
-    __shared__ long long red_i[kFpsPixBlock / 64];
-    __shared__ long long cur_s, best_s;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    long long cur = init_idx;
-    for (int round = 0; round < k; ++round) {
-        if (tid == 0) out_idx[round] = cur;
-        const long long cy = pts[cur * 2 + 0], cx = pts[cur * 2 + 1];
-        long long bv = -1, bi = 0x7fffffffffffffffLL;
-        for (int64_t i = tid; i < n; i += kFpsPixBlock) {
-            const long long dy = pts[i * 2 + 0] - cy, dx = pts[i * 2 + 1] - cx;
-            long long d = dy * dy + dx * dx;                     // exact; np.linalg.norm = sqrt of this in float64
-            if (round > 0) d = min((long long)dist[i], d);       // np.minimum on the norms == min on the squares
-            dist[i] = d;
-            if (d > bv) { bv = d; bi = i; }                      // strided scan: '>' keeps the first maximum
-        }
-        for (int off = 32; off > 0; off >>= 1) {
-            const long long ov = __shfl_xor(bv, off, 64), oi = __shfl_xor(bi, off, 64);
-            if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
-        }
-        if (lane == 0) { red_v[wave] = bv; red_i[wave] = bi; }
-        __syncthreads();
-        if (tid == 0) {
-            long long v = red_v[0], ix = red_i[0];
-            for (int w = 1; w < kFpsPixBlock / 64; ++w)
-                if (red_v[w] > v || (red_v[w] == v && red_i[w] < ix)) { v = red_v[w]; ix = red_i[w]; }
-            cur_s = ix;
-            best_s = v;
-        }
-        __syncthreads();
-        cur = cur_s;
-    }
-    if (tid == 0 && out_maxdist) *out_maxdist = sqrt((double)best_s);   // fps_np's third return value: dist.max()
-}
-
-hipError_t launch_fps_pixels(const int32_t *pts, int64_t n, int k, int64_t init_idx, int64_t *out_idx, double *out_maxdist,
-                             int64_t *dist_ws, hipStream_t s)
-{
-    hipLaunchKernelGGL(fps_pixels_kernel, dim3(1), dim3(kFpsPixBlock), 0, s, pts, n, k, init_idx, out_idx, out_maxdist, dist_ws);
     return hipGetLastError();
 }
 

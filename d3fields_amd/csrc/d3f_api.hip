@@ -252,7 +252,6 @@ int eval_common(const d3f_views *views, const float *pts, int64_t n, const d3f_c
     P.thin_max_views = (exp_knob("D3F_EXP_THIN") < 0 || (flags & D3F_TUNE_DIRECT_GATHER)) ? 0 : 8;
     P.win_lpp = exp_knob("D3F_EXP_WINDOW_LPP") == 32 ? 32 : 16;     // 16 lanes x 2 vectors per point (C2 patch 0.565 -> 0.54 ms); U > 1: 32
     P.win_slices = 0; P.win_u = 1; P.win_vc = 1; P.win_pool_offset = 0; P.win_pool_texels = 0; P.win_occ = 4;
-    P.wp_on = 0; P.wp_ctx_bytes = 0; P.wp_grid = 0; P.wp_gather = 8;
     P.store_policy = exp_knob("D3F_EXP_STORE") < 0 ? 0 : 1;
     int64_t map_bytes = 0;
     P.out_dist = out_dist; P.out_valid = out_valid;
@@ -340,26 +339,6 @@ int eval_common(const d3f_views *views, const float *pts, int64_t n, const d3f_c
             P.win_u = U; P.win_occ = occ; P.win_pool_offset = pool_offset; P.win_pool_texels = texels;
             P.win_vc = exp_knob("D3F_EXP_WINDOW_VC") == 2 ? 2 : 1;
             P.win_slices = window ? cv / U : 0;
-            // Pipelined form (fused_eval_winpipe_kernel: one producer wave + four gather waves per persistent workgroup, two
-            // record contexts and two pool buffers in LDS): lattices, 512-byte slices, 64-point bricks.  Two workgroups per
-            // CU when both pool buffers then still give every view ~11 slots, else one.
-            if (window && lattice && U == 1 && P.win_lpp == 16 && T == 64 && exp_knob("D3F_EXP_WINPIPE") >= 0) {
-                const int ctx = (T * views->V * (n_maps > 1 ? 48 : 32) + T * 20 + 8 * 24 + 16 + 320 * 4 + 15) / 16 * 16;
-                const int pool0 = (2 * ctx + views->V * 48 + 511) / 512 * 512;
-                int wocc = exp_knob("D3F_EXP_WINPIPE_OCC") == 1 ? 1 : 2, wtex = 0;
-                for (;; --wocc) {
-                    wtex = ((160 * 1024 / wocc - 1024 - pool0) / 2) / 512 - 2;
-                    if (wtex >= 11 * views->V || wocc == 1) break;
-                }
-                if (wtex > 320) wtex = 320;
-                wtex &= ~1;
-                P.st_debug = exp_knob("D3F_EXP_STREAM_DEBUG");
-                if (wtex >= 2 * views->V) {
-                    P.wp_gather = exp_knob("D3F_EXP_WINPIPE_NG") > 0 ? exp_knob("D3F_EXP_WINPIPE_NG") : 8;
-                    P.wp_on = 1; P.wp_ctx_bytes = ctx; P.wp_grid = 32 * wocc * (exp_knob("D3F_EXP_WINPIPE_G") > 0 ? exp_knob("D3F_EXP_WINPIPE_G") : 1);
-                    P.win_pool_offset = pool0; P.win_pool_texels = wtex; P.win_occ = wocc;
-                }
-            }
         }
     }
     bool any_runs = false;
@@ -581,12 +560,7 @@ int eval_common(const d3f_views *views, const float *pts, int64_t n, const d3f_c
             plan_out->lds_bytes = P.win_pool_offset + (2 + P.win_pool_texels) * 512 * P.win_u;
             plan_out->workgroups = ntiles;
         }
-        if (P.win_slices > 0 && P.wp_on) {
-            plan_out->lds_bytes = P.win_pool_offset + 2 * (2 + P.win_pool_texels) * 512;
-            plan_out->workgroups = 8 * P.wp_grid;           // persistent
-        }
-        plan_out->reserved = (P.win_slices > 0 && P.wp_on) ? 4000 + P.win_occ :
-                             P.st_on ? 3000 + P.sl_lg * 100 + P.st_variant : P.sl_slices > 0 ? 100 + P.sl_lg * 10 + P.sl_vc : (P.win_slices > 0 ? 2000 + 100 * P.win_u + 10 * (P.win_u == 1 ? (P.win_lpp == 16 ? 2 : 4) : (P.win_u == 4 ? 1 : P.win_vc)) + (P.win_u == 1 ? (P.win_occ >= 4 ? 4 : (P.win_lpp == 16 ? 3 : P.win_occ)) : 2) : 0);   // 2UVW: the window kernel's template arguments      // 1LV: sliced launch, L = log2(lanes per point), V = views in flight
+        plan_out->reserved = P.st_on ? 3000 + P.sl_lg * 100 + P.st_variant : P.sl_slices > 0 ? 100 + P.sl_lg * 10 + P.sl_vc : (P.win_slices > 0 ? 2000 + 100 * P.win_u + 10 * (P.win_u == 1 ? (P.win_lpp == 16 ? 2 : 4) : (P.win_u == 4 ? 1 : P.win_vc)) + (P.win_u == 1 ? (P.win_occ >= 4 ? 4 : (P.win_lpp == 16 ? 3 : P.win_occ)) : 2) : 0);   // 2UVW: the window kernel's template arguments      // 1LV: sliced launch, L = log2(lanes per point), V = views in flight
         for (int s = 0; s < n_maps; ++s)
             if (P.maps[s].runs > 0) {        // waves per SIMD the chosen cell-run kernel variant is built for
                 const int ru = P.maps[s].unroll, rk = P.maps[s].runs;
@@ -738,6 +712,24 @@ int d3f_erode(const uint8_t *src, int32_t H, int32_t W, int32_t kh, int32_t kw, 
     return e == hipSuccess ? D3F_OK : hip_fail(e, "erode launch");
 }
 
+int64_t d3f_voxel_downsample_workspace_bytes(int64_t n) { return n > 0 ? d3f::voxmean_workspace_bytes(n) : 0; }
+
+int d3f_voxel_downsample(const double *pts, const double *colors, int64_t n, double voxel_size, double *out_pts, double *out_colors,
+                         int64_t *count_out, void *workspace, int64_t workspace_bytes, void *stream)
+{
+    if (n < 0 || n > 0x3fffffffLL) return fail(D3F_ERR_BAD_SHAPE, "voxel_downsample: n=%lld", (long long)n);
+    if (!(voxel_size > 0.0)) return fail(D3F_ERR_INVALID_ARG, "voxel_downsample: voxel_size must be > 0 (open3d raises too)");
+    if (!count_out) return fail(D3F_ERR_INVALID_ARG, "voxel_downsample: count_out is NULL");
+    if (n == 0) return hipMemsetAsync(count_out, 0, sizeof(int64_t), static_cast<hipStream_t>(stream)) == hipSuccess ? D3F_OK : D3F_ERR_HIP;
+    if (!pts || !out_pts || (colors && !out_colors)) return fail(D3F_ERR_INVALID_ARG, "voxel_downsample: NULL pointer");
+    if (!workspace || workspace_bytes < d3f_voxel_downsample_workspace_bytes(n))
+        return fail(D3F_ERR_WORKSPACE, "voxel_downsample: needs %lld workspace bytes", (long long)d3f_voxel_downsample_workspace_bytes(n));
+    if (!aligned(workspace, 16)) return fail(D3F_ERR_BAD_LAYOUT, "voxel_downsample: workspace must be 16-byte aligned");
+    hipError_t e = d3f::launch_voxel_mean(pts, colors, n, voxel_size, out_pts, colors ? out_colors : nullptr, count_out, workspace,
+                                          static_cast<hipStream_t>(stream));
+    return e == hipSuccess ? D3F_OK : hip_fail(e, "voxel_downsample launch");
+}
+
 int d3f_mask_gate(const float *mask_channel, int64_t stride_y, int64_t stride_x, const float *depth, int32_t H, int32_t W,
                   float depth_lo, float depth_hi, uint8_t *out, void *stream)
 {
@@ -760,13 +752,14 @@ int d3f_nonzero_pixels(const uint8_t *image, int32_t H, int32_t W, int64_t capac
 }
 
 int d3f_fps_pixels(const int32_t *pts, int64_t n, int32_t k, int64_t init_idx, int64_t *out_idx, double *out_maxdist,
-                   int64_t *dist_workspace, void *stream)
+                   void *workspace, void *stream)
 {
     if (n < 1 || k < 0) return fail(D3F_ERR_BAD_SHAPE, "fps_pixels: n=%lld must be >= 1 (fps_np asserts a non-empty set), k=%d", (long long)n, k);
     if (k == 0) return D3F_OK;
-    if (!pts || !out_idx || !dist_workspace) return fail(D3F_ERR_INVALID_ARG, "fps_pixels: NULL pointer");
+    if (!pts || !out_idx || !workspace) return fail(D3F_ERR_INVALID_ARG, "fps_pixels: NULL pointer");
+    if (!aligned(workspace, 16)) return fail(D3F_ERR_BAD_LAYOUT, "fps_pixels: workspace must be 16-byte aligned");
     if (init_idx < 0 || init_idx >= n) return fail(D3F_ERR_INVALID_ARG, "fps_pixels: init_idx=%lld outside [0,%lld)", (long long)init_idx, (long long)n);
-    hipError_t e = d3f::launch_fps_pixels(pts, n, k, init_idx, out_idx, out_maxdist, dist_workspace, static_cast<hipStream_t>(stream));
+    hipError_t e = d3f::launch_fps_pixels(pts, n, k, init_idx, out_idx, out_maxdist, workspace, static_cast<hipStream_t>(stream));
     return e == hipSuccess ? D3F_OK : hip_fail(e, "fps_pixels launch");
 }
 
@@ -822,14 +815,18 @@ int d3f_grid_shell(const d3f_views *views, const d3f_grid *grid, float mu, float
     return e == hipSuccess ? D3F_OK : hip_fail(e, "grid_shell launch");
 }
 
+int64_t d3f_fps_workspace_bytes(int64_t n) { return n > 0 ? d3f::fps_workspace_bytes(n, 4) : 0; }
+int64_t d3f_fps_pixels_workspace_bytes(int64_t n) { return n > 0 ? d3f::fps_workspace_bytes(n, 8) : 0; }
+
 int d3f_farthest_point_sampling(const float *pts, int64_t n, int32_t k, int64_t init_idx, int64_t *out_idx, float *out_maxdist,
-                                float *dist_workspace, void *stream)
+                                void *workspace, void *stream)
 {
     if (n < 1 || k < 0) return fail(D3F_ERR_BAD_SHAPE, "fps: n=%lld must be >= 1 (fps_np asserts a non-empty cloud), k=%d", (long long)n, k);
     if (k == 0) return D3F_OK;
-    if (!pts || !out_idx || !dist_workspace) return fail(D3F_ERR_INVALID_ARG, "fps: NULL pointer");
+    if (!pts || !out_idx || !workspace) return fail(D3F_ERR_INVALID_ARG, "fps: NULL pointer");
+    if (!aligned(workspace, 16)) return fail(D3F_ERR_BAD_LAYOUT, "fps: workspace must be 16-byte aligned");
     if (init_idx < 0 || init_idx >= n) return fail(D3F_ERR_INVALID_ARG, "fps: init_idx=%lld outside [0,%lld)", (long long)init_idx, (long long)n);
-    hipError_t e = d3f::launch_fps(pts, n, k, init_idx, out_idx, out_maxdist, dist_workspace, static_cast<hipStream_t>(stream));
+    hipError_t e = d3f::launch_fps(pts, n, k, init_idx, out_idx, out_maxdist, workspace, static_cast<hipStream_t>(stream));
     return e == hipSuccess ? D3F_OK : hip_fail(e, "fps launch");
 }
 
@@ -1112,6 +1109,47 @@ int d3f_rigid_update(const float *last, int32_t n_inst, int32_t n, const float *
     hipError_t e = d3f::launch_rigid_update(last, n_inst, n, grad_pts, t, w, adam_m, adam_v, step, norms, 1e-4f, reg_w, lr, beta1,
                                             beta2, eps, static_cast<hipStream_t>(stream));
     return e == hipSuccess ? D3F_OK : hip_fail(e, "rigid_update launch");
+}
+
+int64_t d3f_track_step_scratch_bytes(int32_t n_inst, int32_t n)
+{
+    if (n_inst < 0 || n < 0) return 0;
+    return ((int64_t)n_inst * n * 3 + 4) * (int64_t)sizeof(float);
+}
+
+int d3f_track_step(const d3f_views *views, const d3f_channel_map *descriptors, const float *last, int32_t n_inst, int32_t n,
+                   const float *src, float mu, float dist_w, float reg_w, float lr, float beta1, float beta2, float eps,
+                   const d3f_track_state *state, void *stream)
+{
+    int rc = check_views(views);
+    if (rc != D3F_OK) return rc;
+    if (n_inst < 0 || n < 0) return fail(D3F_ERR_BAD_SHAPE, "track_step: n_inst=%d n=%d", n_inst, n);
+    if ((int64_t)n_inst * n == 0) return D3F_OK;
+    if ((int64_t)n_inst * n > 0x7fffffLL) return fail(D3F_ERR_BAD_SHAPE, "track_step: %lld keypoints (one workgroup each) are too many", (long long)n_inst * n);
+    if (!descriptors || !last || !src || !state) return fail(D3F_ERR_INVALID_ARG, "track_step: NULL pointer");
+    if (!state->t || !state->w || !state->adam_m || !state->adam_v || !state->step || !state->out_pts || !state->loss || !state->scratch)
+        return fail(D3F_ERR_INVALID_ARG, "track_step: NULL pointer in d3f_track_state");
+    if (!(mu > 0.0f)) return fail(D3F_ERR_INVALID_ARG, "mu must be > 0");
+    if (!(lr > 0.0f) || !(beta1 >= 0.0f && beta1 < 1.0f) || !(beta2 >= 0.0f && beta2 < 1.0f) || !(eps > 0.0f))
+        return fail(D3F_ERR_INVALID_ARG, "track_step: lr=%g beta=(%g,%g) eps=%g", lr, beta1, beta2, eps);
+    if (views->V > 8) return fail(D3F_ERR_BAD_SHAPE, "track_step: at most 8 views (V=%d); use the five-launch step", views->V);
+    d3f::TrackStepParams P;
+    int64_t map_bytes = 0;
+    rc = fill_map(*descriptors, 0, views->V, nullptr, nullptr, nullptr, P.map, map_bytes);
+    if (rc != D3F_OK) return rc;
+    if (P.map.esize != 4 || P.map.C % 4 != 0 || P.map.C > 512 || (P.map.sx % 4) || (P.map.sy % 4) || (P.map.sv % 4) ||
+        !aligned(descriptors->data, 16) || !aligned(src, 16))
+        return fail(D3F_ERR_BAD_LAYOUT, "track_step: the descriptor map must be fp32 with C %% 4 == 0, C <= 512 and 16-byte aligned texels "
+                                        "(C=%d); use the five-launch step", P.map.C);
+    P.depth = views->depth; P.K = views->K; P.pose = views->pose; P.V = views->V; P.H = views->H; P.W = views->W;
+    P.last = last; P.src = src; P.I = n_inst; P.n = n;
+    P.mu = mu; P.dist_w = dist_w; P.reg_w = reg_w; P.lr = lr; P.beta1 = beta1; P.beta2 = beta2; P.eps_adam = eps; P.eps_rot = 1e-4f;
+    P.t = state->t; P.w = state->w; P.adam_m = state->adam_m; P.adam_v = state->adam_v; P.step = state->step;
+    P.out_pts = state->out_pts; P.loss_out = state->loss;
+    float *scr = static_cast<float *>(state->scratch);
+    P.grad_pts = scr; P.loss_acc = scr + (int64_t)n_inst * n * 3; P.counter = reinterpret_cast<unsigned int *>(P.loss_acc + 2);
+    hipError_t e = d3f::launch_track_step(P, static_cast<hipStream_t>(stream));
+    return e == hipSuccess ? D3F_OK : hip_fail(e, "track_step launch");
 }
 
 }  // extern "C"

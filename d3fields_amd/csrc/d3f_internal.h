@@ -65,8 +65,6 @@ struct EvalParams {
     int32_t win_pool_offset;   // byte offset of the two all-zero slices; the pool follows them
     int32_t win_pool_texels;   // pool capacity in texel slices of 512 * win_u bytes
     int32_t win_occ;           // workgroups per CU the kernel variant is built for (2 / 3 / 4)
-    int32_t wp_on, wp_ctx_bytes, wp_grid, wp_gather;   // pipelined window kernel (fused_eval_winpipe_kernel): per-brick context bytes,
-                               // persistent workgroups per XCD; win_pool_offset / win_pool_texels describe ONE of its two pool buffers
     int32_t win_lpp;           // lanes per point in phase B: 32, or 16 (two vectors per lane inside a 512-byte slice)
     int32_t thin_max_views;    // 8 (default): thin maps with 2..8 views are gathered with the views in parallel across lanes
                                // (gather_map_thin); 0 switches that off (D3F_EXP_THIN=-1, tests)
@@ -123,7 +121,8 @@ hipError_t launch_grid_shell(const float *depth, const float *K, const float *po
                              int64_t capacity, int64_t *idx_out, unsigned long long *count, void *workspace, hipStream_t s);
 int64_t grid_shell_workspace_bytes(int64_t n);
 hipError_t launch_fps(const float *pts, int64_t n, int k, int64_t init_idx, int64_t *out_idx, float *out_maxdist,
-                      float *dist_ws, hipStream_t s);
+                      void *workspace, hipStream_t s);
+int64_t fps_workspace_bytes(int64_t n, int dist_bytes);     // n distances + two arrays of per-workgroup maxima
 
 // pcd_kernels.hip
 hipError_t launch_backproject(const double *depth, const uint8_t *mask, int H, int W, const double *cam, const double *T,
@@ -137,13 +136,16 @@ hipError_t launch_pcd_to_index(const double *pts, int64_t n, const double *lower
 int64_t voxset_capacity(int64_t n1, int64_t n2);
 hipError_t launch_voxset_iou(const int32_t *a, int64_t na, const int32_t *b, int64_t nb, int64_t *counts, void *workspace,
                              hipStream_t s);
+int64_t voxmean_workspace_bytes(int64_t n);
+hipError_t launch_voxel_mean(const double *pts, const double *col, int64_t n, double vs, double *out_pts, double *out_col, int64_t *count,
+                             void *workspace, hipStream_t s);
 hipError_t launch_erode(const uint8_t *src, int H, int W, int kh, int kw, uint8_t *dst, hipStream_t s);
 hipError_t launch_mask_gate(const float *mask, int64_t sy, int64_t sx, const float *depth, int H, int W, float lo, float hi,
                             uint8_t *out, hipStream_t s);
 hipError_t launch_nonzero_pixels(const uint8_t *img, int H, int W, int64_t capacity, int32_t *out_rc, int64_t *count,
                                  int64_t *block_counts, hipStream_t s);
 hipError_t launch_fps_pixels(const int32_t *pts, int64_t n, int k, int64_t init_idx, int64_t *out_idx, double *out_maxdist,
-                             int64_t *dist_ws, hipStream_t s);
+                             void *workspace, hipStream_t s);
 
 // misc_kernels.hip
 hipError_t launch_onehot2instance(const float *onehot, int64_t n, int NI, uint8_t *out, hipStream_t s);
@@ -188,5 +190,23 @@ hipError_t launch_track_loss_grad(const float *feats, const float *src, const fl
 hipError_t launch_rigid_update(const float *last, int I, int n, const float *grad_pts, float *t, float *w, float *adam_m, float *adam_v,
                                float *step, const float *norms, float eps_rot, float reg_w, float lr, float beta1, float beta2,
                                float eps_adam, hipStream_t s);
+
+struct TrackStepParams {
+    const float *depth, *K, *pose;      // views
+    int32_t V, H, W;
+    MapDesc map;                        // the descriptor map (fp32, C % 4 == 0)
+    const float *last;                  // [I, n, 3]
+    const float *src;                   // [I*n, C]
+    int32_t I, n;
+    float mu, dist_w, reg_w, lr, beta1, beta2, eps_adam, eps_rot;
+    float *t, *w, *adam_m, *adam_v, *step;     // [I,3] [I,3] [I,6] [I,6] [I]
+    float *out_pts;                     // [I*n, 3] the keypoints as evaluated in this step
+    float *grad_pts;                    // [I*n, 3] scratch
+    float *loss_acc;                    // [2] accumulators, zero between steps
+    float *loss_out;                    // [3] feature loss, distance loss, regulariser of this step
+    unsigned int *counter;              // zero between steps
+};
+
+hipError_t launch_track_step(const TrackStepParams &P, hipStream_t s);
 
 }  // namespace d3f

@@ -1009,388 +1009,6 @@ __device__ __forceinline__ void fused_eval_window_body(const EvalParams &P)
 template <int U, int VC, int WAVES, int NT = kBlock, int LPP = 32>
 __global__ __launch_bounds__(NT, WAVES) void fused_eval_window_kernel(const EvalParams P) { fused_eval_window_body<U, VC, NT, LPP>(P); }
 
-// ---- texel windows, PIPELINED (round 3): persistent workgroups of one producer wave + four gather waves -----------------
-// fused_eval_window_kernel above runs its phases back to back behind barriers -- window set-up, phase A, then per slice
-// copy -> wait -> gather -> store -- and leaves the overlap to the four workgroups a CU holds (round-2 timing with parts
-// switched off: set-up + phase A 0.09 ms, copies 0.04-0.07, LDS gather + arithmetic + stores 0.37, all of it 0.54-0.57 on
-// C2-patch).  Here the serial chain is cut in two inside ONE workgroup that lives for many bricks:
-//   * wave 4, the PRODUCER, prepares brick j+1 (corner projection, windows, slot table, phase A -> records) and issues the
-//     global -> LDS copies of the NEXT (brick, slice) step -- into the record context / pool buffer that are not in use;
-//   * waves 0-3, the GATHER waves, only run phase B of the current (brick, slice) step: LDS reads, arithmetic, stores.
-// Two record contexts (per brick) and two pool buffers (per step) alternate; one workgroup barrier per step orders them.
-// The gather -- the LDS-bound part -- then never waits for a set-up, a phase A or a copy.  Everything a lane computes is
-// what the kernel above computes (same windows, same records, same operand order), so results are bit-identical.
-// Lattices only (bricks numbered z fastest; XCD k takes the k-th contiguous eighth); 16 lanes x two vectors per point.
-// NG gather waves + one producer wave per workgroup: the gather is a dependent LDS-read -> fma -> store chain per point
-// group, so its rate grows with the number of waves running it until the LDS saturates (8 gather waves per CU measured
-// 0.77 ms on C2-patch, gather alone; the round-2 kernel has 16 waves per CU)
-
-struct WpBrick {
-    int ox, oy, oz, sx, sy, sz;
-};
-
-template <int VC, int NG>
-__device__ __forceinline__ void fused_eval_winpipe_body(const EvalParams &P)
-{
-    constexpr int kWpGather = NG, kWpThreads = (NG + 1) * 64;
-    using VT = f32x4;
-    constexpr int NV = 2, VS = 256, LPP = 16;
-    constexpr uint32_t SB = 512u;
-    extern __shared__ __align__(16) unsigned char smem[];
-    const int V = P.V;
-    const int TP = P.tile_pts;
-    const bool has_rec = P.n_maps > 1;
-    const MapDesc &m0 = P.maps[0];
-    const int S = P.win_slices;
-    // ---- LDS: two brick contexts, KRt, two pool buffers (each: two all-zero slices, then the pool) ----
-    struct Ctx {
-        WinRec *wrec; ViewRec *rec; float *cnt; uint32_t *flag; uint32_t *idx; float *aux; WinView *win; int *total; uint32_t *texsrc;
-    };
-    auto ctx_at = [&](int c) -> Ctx {
-        Ctx x;
-        unsigned char *b = smem + (size_t)c * P.wp_ctx_bytes;
-        x.wrec = reinterpret_cast<WinRec *>(b);
-        x.rec = reinterpret_cast<ViewRec *>(x.wrec + (size_t)TP * V);
-        x.cnt = reinterpret_cast<float *>(x.rec + (has_rec ? (size_t)TP * V : 0));
-        x.flag = reinterpret_cast<uint32_t *>(x.cnt + TP);
-        x.idx = x.flag + TP;
-        x.aux = reinterpret_cast<float *>(x.idx + TP);
-        x.win = reinterpret_cast<WinView *>(x.aux + 2 * TP);
-        x.total = reinterpret_cast<int *>(x.win + kWinMaxViews);
-        x.texsrc = reinterpret_cast<uint32_t *>(x.total + 4);
-        return x;
-    };
-    float *krt = reinterpret_cast<float *>(smem + 2 * (size_t)P.wp_ctx_bytes);
-    const uint32_t pool_bytes = (2u + (uint32_t)P.win_pool_texels) * SB;
-    auto pool_at = [&](int b) -> unsigned char * { return smem + P.win_pool_offset + (size_t)b * pool_bytes; };
-
-    // ---- this workgroup's bricks: XCD k = blockIdx % 8 owns the k-th contiguous eighth, its workgroups stride through it ----
-    const uint32_t nbx = (uint32_t)((P.walk_nx + P.walk_tx - 1) / P.walk_tx), nby = (uint32_t)((P.walk_ny + P.walk_ty - 1) / P.walk_ty),
-                   nbz = (uint32_t)((P.walk_nz + P.walk_tz - 1) / P.walk_tz);
-    const uint32_t NB = nbx * nby * nbz;
-    const uint32_t xcd = blockIdx.x & 7u, wj = blockIdx.x >> 3, G = gridDim.x >> 3;
-    const uint32_t q = NB / 8u, r = NB % 8u;
-    const uint32_t x_start = xcd < r ? xcd * (q + 1u) : r * (q + 1u) + (xcd - r) * q, x_len = q + (xcd < r ? 1u : 0u);
-    const int nb_mine = wj < x_len ? (int)((x_len - wj + G - 1u) / G) : 0;
-    const int lbz = __ffs(P.walk_tz) - 1, lby = __ffs(P.walk_ty) - 1;
-    auto brick_of = [&](int i) -> WpBrick {
-        const uint32_t b = x_start + wj + (uint32_t)i * G;
-        const uint32_t bxy = b / nbz, bx = bxy / nby;
-        WpBrick k;
-        k.oz = (int)(b - bxy * nbz) * P.walk_tz; k.oy = (int)(bxy - bx * nby) * P.walk_ty; k.ox = (int)bx * P.walk_tx;
-        k.sx = min(P.walk_tx, P.walk_nx - k.ox); k.sy = min(P.walk_ty, P.walk_ny - k.oy); k.sz = min(P.walk_tz, P.walk_nz - k.oz);
-        return k;
-    };
-
-    compute_krt(P.K, P.pose, V, krt, kWpThreads);
-    for (uint32_t t = threadIdx.x; t < 2u * (2u * SB / 4u); t += kWpThreads) {       // the zero slices of both pool buffers
-        const uint32_t buf = t / (2u * SB / 4u), w = t % (2u * SB / 4u);
-        reinterpret_cast<uint32_t *>(pool_at((int)buf))[w] = 0u;
-    }
-    __syncthreads();
-    if (nb_mine == 0) return;
-
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const bool producer = wave == kWpGather;
-    const float mu = P.mu;
-    const float Wm1 = (float)(P.W - 1), Hm1 = (float)(P.H - 1);
-    const char *__restrict__ data = reinterpret_cast<const char *>(m0.data);
-    const int Nsteps = nb_mine * S;
-
-    if (producer) {
-        // ---- brick set-up + phase A by ONE wave (no barrier inside: its LDS operations complete in issue order) ----
-        auto prepare = [&](const WpBrick &k, const Ctx &C) {
-            auto slot_pos = [&](int p, int &lx, int &ly, int &lz) {
-                lz = min(p & (P.walk_tz - 1), k.sz - 1); ly = min((p >> lbz) & (P.walk_ty - 1), k.sy - 1); lx = min(p >> (lbz + lby), k.sx - 1);
-            };
-            // the eight corner points of the brick's bounding box: lane c (c < 8) fetches corner c
-            float cx = 0.0f, cy = 0.0f, cz = 0.0f;
-            {
-                const int c = lane & 7;
-                const int lx = (c & 1) ? k.sx - 1 : 0, ly = (c & 2) ? k.sy - 1 : 0, lz = (c & 4) ? k.sz - 1 : 0;
-                const int64_t i = ((int64_t)(k.ox + lx) * P.walk_ny + (k.oy + ly)) * P.walk_nz + (k.oz + lz);
-                fetch_point(P, i, cx, cy, cz);
-            }
-            // one window per view: lane = view * 8 + corner (fused_eval_window_body, step 2)
-            {
-                const int v = lane >> 3;
-                const bool act = v < V && V <= kWinMaxViews;
-                float xl = 0.0f, xh = 0.0f, yl = 0.0f, yh = 0.0f;
-                int ok = 0;
-                if (act) {
-                    const Proj pr = project_point(krt + v * 12, cx, cy, cz, Wm1, Hm1);
-                    const float ix = unnormalize(pr.gx, m0.fw), iy = unnormalize(pr.gy, m0.fh);
-                    ok = (pr.ok && pr.zc > 1e-4f && isfinite(ix) && isfinite(iy)) ? 1 : 0;
-                    xl = xh = ix; yl = yh = iy;
-                }
-#pragma unroll
-                for (int off = 1; off < 8; off <<= 1) {
-                    xl = fminf(xl, __shfl_xor(xl, off, 64)); xh = fmaxf(xh, __shfl_xor(xh, off, 64));
-                    yl = fminf(yl, __shfl_xor(yl, off, 64)); yh = fmaxf(yh, __shfl_xor(yh, off, 64));
-                    ok &= __shfl_xor(ok, off, 64);
-                }
-                WinView w = {0, 0, 1, 1, 0, 0};
-                int ntex = 0;
-                if (ok) {
-                    const float fwm1 = (float)(m0.fw - 1), fhm1 = (float)(m0.fh - 1);
-                    const int x0 = (int)fminf(fmaxf(floorf(xl - 1e-3f), 0.0f), fwm1), x1 = (int)fminf(fmaxf(floorf(xh + 1e-3f) + 1.0f, 0.0f), fwm1);
-                    const int y0 = (int)fminf(fmaxf(floorf(yl - 1e-3f), 0.0f), fhm1), y1 = (int)fminf(fmaxf(floorf(yh + 1e-3f) + 1.0f, 0.0f), fhm1);
-                    w.xmin = x0; w.ymin = y0; w.bw = x1 - x0 + 1; w.bh = y1 - y0 + 1;
-                    ntex = w.bw * w.bh;
-                }
-                int run = 0;
-                for (int vv = 0; vv < V && vv < kWinMaxViews; ++vv) {
-                    const int nv = __shfl(ntex, vv * 8, 64), bwv = __shfl(w.bw, vv * 8, 64);
-                    int rows = nv > 0 ? min(nv, P.win_pool_texels - run) / bwv : 0;
-                    if (rows < 2) rows = 0;                              // a bilinear footprint needs two rows
-                    if (vv == v) { w.base = run; w.ok = rows > 0 ? 1 : 0; w.bh = rows > 0 ? rows : w.bh; }
-                    run += rows * bwv;
-                }
-                if (act && (lane & 7) == 0) C.win[v] = w;
-                if (lane == 0) *C.total = run;
-            }
-            __builtin_amdgcn_s_waitcnt(0xc07f);                      // lgkmcnt(0): the windows are in LDS (same wave reads them)
-            __builtin_amdgcn_wave_barrier();
-            const int total = *C.total;
-            for (int t = lane; t < total; t += 64) {
-                int v = 0;
-                for (int vv = 1; vv < V && vv < kWinMaxViews; ++vv)
-                    if (C.win[vv].ok && t >= C.win[vv].base) v = vv;
-                const WinView w = C.win[v];
-                const int local = t - w.base;
-                const int y = local / w.bw, x = local - y * w.bw;
-                C.texsrc[t] = (uint32_t)(((int64_t)v * m0.sv + (int64_t)(w.ymin + y) * m0.sy + (int64_t)(w.xmin + x) * m0.sx) * 4);
-            }
-            // phase A: lane = (point, view), the views of a point adjacent (fused_eval_window_body, step 3)
-            const int vp_log2 = V <= 1 ? 0 : (V <= 2 ? 1 : (V <= 4 ? 2 : 3));
-            const int VP = 1 << vp_log2;
-            const int base = lane & ~(VP - 1);
-            for (int idx = lane; idx < TP * VP; idx += 64) {
-                const int p = idx >> vp_log2, v = idx & (VP - 1);
-                int lx, ly, lz;
-                slot_pos(p, lx, ly, lz);
-                const int64_t i = ((int64_t)(k.ox + lx) * P.walk_ny + (k.oy + ly)) * P.walk_nz + (k.oz + lz);
-                float dv = 0.0f, valid = 0.0f, gx = 0.0f, gy = 0.0f;
-                uint32_t st = 0u;
-                WinRec wr;
-                wr.nw = 0u; wr.row = 0u; wr.wgt = 0.0f; wr.valid = 0.0f;       // offset 0 of a pool buffer = its all-zero slices
-                wr.w[0] = wr.w[1] = wr.w[2] = wr.w[3] = 0.0f;
-                if (v < V) {
-                    float px, py, pz;
-                    if (P.grid_x) { px = P.grid_x[k.ox + lx]; py = P.grid_y[k.oy + ly]; pz = P.grid_z[k.oz + lz]; }
-                    else fetch_point(P, i, px, py, pz);
-                    float wgt;
-                    const ViewOut o = eval_view<0>(P.depth, P.H, P.W, krt + v * 12, v, px, py, pz, Wm1, Hm1, mu, wgt);
-                    if (has_rec) {
-                        ViewRec rr;
-                        rr.gx = o.gx; rr.gy = o.gy; rr.wgt = wgt; rr.valid = o.valid;
-                        C.rec[p * V + v] = rr;
-                    }
-                    dv = o.dist * o.valid;                                          // fusion.py:364 (product only)
-                    valid = o.valid; gx = o.gx; gy = o.gy;
-                    if (!(isfinite(o.gx) && isfinite(o.gy) && isfinite(wgt))) st |= kWinStrict;
-                    wr.wgt = wgt; wr.valid = o.valid;
-                    if (o.valid != 0.0f) {
-                        const float ix = unnormalize(o.gx, m0.fw), iy = unnormalize(o.gy, m0.fh);
-                        const float x0 = floorf(ix), y0 = floorf(iy);
-                        const float tx = ix - x0, ty = iy - y0;
-                        const float ex = 1.0f - tx, sy = 1.0f - ty;
-                        const WinView w = C.win[v];
-                        const bool inmap = x0 >= 0.0f && x0 <= (float)(m0.fw - 2) && y0 >= 0.0f && y0 <= (float)(m0.fh - 2);
-                        const int ax = (int)fminf(fmaxf(x0, 0.0f), (float)m0.fw) - w.xmin, ay = (int)fminf(fmaxf(y0, 0.0f), (float)m0.fh) - w.ymin;
-                        const bool inside = inmap && w.ok && ax >= 0 && ax + 1 < w.bw && ay >= 0 && ay + 1 < w.bh;
-                        if (inside) {
-                            wr.nw = (2u + (uint32_t)(w.base + ay * w.bw + ax)) * SB;        // relative to the pool buffer
-                            wr.row = (uint32_t)w.bw * SB;
-                            wr.w[0] = sy * ex; wr.w[1] = sy * tx; wr.w[2] = ty * ex; wr.w[3] = ty * tx;
-                        } else {
-                            wr.nw = kWinDirect; wr.w[0] = gx; wr.w[1] = gy;
-                            st |= kWinHasDirect;
-                        }
-                    }
-                }
-                float dsum = 0.0f, cnt = 0.0f;
-                uint32_t stp = 0u;
-                for (int vv = 0; vv < V; ++vv) {
-                    dsum = dsum + __shfl(dv, base + vv, 64);
-                    cnt = cnt + __shfl(valid, base + vv, 64);
-                    stp |= (uint32_t)__shfl((int)st, base + vv, 64);
-                }
-                if (!(P.flags & kFlagFiniteMaps)) stp |= kWinStrict;
-                if (v < V) {
-                    if (stp & kWinStrict) { wr.nw = kWinDirect; wr.w[0] = gx; wr.w[1] = gy; }
-                    C.wrec[p * V + v] = wr;
-                }
-                if (v == 0) {
-                    const bool all_invalid = (cnt == 0.0f);                         // fusion.py:366
-                    float dist_out = dsum / (cnt + 1e-6f);
-                    if (all_invalid) dist_out = 1e3f;                               // fusion.py:367
-                    P.out_dist[i] = dist_out;
-                    P.out_valid[i] = all_invalid ? 0 : 1;
-                    C.cnt[p] = cnt;
-                    C.idx[p] = (uint32_t)i;
-                    C.flag[p] = stp;
-                    const float denom = cnt + 1e-6f;
-                    const float r0 = __builtin_amdgcn_rcpf(denom);
-                    C.aux[2 * p] = fmaf(fmaf(-denom, r0, 1.0f), r0, r0);
-                    C.aux[2 * p + 1] = denom;
-                }
-            }
-        };
-        // copy of slice `sl` of every window into a pool buffer: 512-byte granules, two per wave instruction
-        auto stage = [&](const Ctx &C, int sl, unsigned char *pool) {
-            const int total = *C.total;
-            const int h = lane >> 5, l = lane & 31;
-            const char *src0 = data + (size_t)sl * SB + (size_t)l * 16;
-            for (int g2 = 0; g2 * 2 < total; ++g2) {
-                const int t = min(g2 * 2 + h, total - 1);
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src0 + C.texsrc[t]),
-                                                 (__attribute__((address_space(3))) void *)(pool + 2 * SB + (size_t)g2 * 1024), 16, 0, 0);
-            }
-        };
-        int prepared = 0;
-        {
-            const Ctx C0 = ctx_at(0);
-            prepare(brick_of(0), C0);
-            prepared = 1;
-            __builtin_amdgcn_s_waitcnt(0xc07f);
-            __builtin_amdgcn_wave_barrier();
-            stage(C0, 0, pool_at(0));
-        }
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        int j = 0, s = 0;
-#pragma unroll 1
-        for (int n = 0; n < Nsteps; ++n) {
-            if (n + 1 < Nsteps) {
-                const int sn = s + 1 == S ? 0 : s + 1, jn = s + 1 == S ? j + 1 : j;
-                const Ctx Cn = ctx_at(jn & 1);
-                if (jn == prepared) {                               // (one slice per texel: the next step is a new brick)
-                    if (!(P.st_debug == 2 && jn >= 2)) prepare(brick_of(jn), Cn);
-                    ++prepared;
-                    __builtin_amdgcn_s_waitcnt(0xc07f);
-                    __builtin_amdgcn_wave_barrier();
-                }
-                stage(Cn, sn, pool_at((n + 1) & 1));
-            }
-            if (prepared == j + 1 && j + 1 < nb_mine) {             // early: brick j+1's records while brick j is gathered
-                if (!(P.st_debug == 2 && j + 1 >= 2)) prepare(brick_of(j + 1), ctx_at((j + 1) & 1));
-                ++prepared;
-            }
-            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            if (++s == S) { s = 0; ++j; }
-        }
-        return;
-    }
-
-    // ---- gather waves: phase B of one (brick, slice) step per barrier (fused_eval_window_body, step 4) ----
-    __builtin_amdgcn_s_barrier();
-    const int l = threadIdx.x & (LPP - 1), grp = threadIdx.x / LPP;
-    const uint32_t lane_off = (uint32_t)l * 16u;
-    const bool out32 = (uint64_t)P.n * (uint64_t)m0.C * 4u <= 0xffffffffull;
-    int j = 0, s = 0;
-#pragma unroll 1
-    for (int n = 0; n < Nsteps; ++n) {
-        const Ctx C = ctx_at(j & 1);
-        const unsigned char *pool = pool_at(n & 1);
-        const uint32_t co = (uint32_t)s * SB + lane_off;
-        for (int p = grp; p < TP && P.st_debug != 1; p += kWpGather * 64 / LPP) {
-            const int64_t i = C.idx[p];
-            const uint32_t fl = C.flag[p];
-            const bool strict = (fl & kWinStrict) != 0u;
-            VT acc[NV];
-#pragma unroll
-            for (int u = 0; u < NV; ++u) acc[u] = (VT)0.0f;
-            if (fl == 0u) {
-                window_point<NV, VC, VS, (int)SB>(acc, pool, C.wrec + p * V, V, lane_off);
-            } else if (!strict) {
-                for (int v = 0; v < V; ++v) {
-                    const WinRec wr = C.wrec[p * V + v];
-                    if (wr.nw != kWinDirect) {
-                        const unsigned char *nw = pool + (wr.nw + lane_off);
-                        const unsigned char *sw = nw + wr.row;
-#pragma unroll
-                        for (int u = 0; u < NV; ++u) {
-                            const VT a = *reinterpret_cast<const VT *>(nw + u * VS), b = *reinterpret_cast<const VT *>(nw + SB + u * VS);
-                            const VT d = *reinterpret_cast<const VT *>(sw + u * VS), e = *reinterpret_cast<const VT *>(sw + SB + u * VS);
-                            VT s_ = a * wr.w[0];
-                            s_ = v_fma<VT>(b, wr.w[1], s_);
-                            s_ = v_fma<VT>(d, wr.w[2], s_);
-                            s_ = v_fma<VT>(e, wr.w[3], s_);
-                            acc[u] = acc[u] + s_ * wr.wgt;
-                        }
-                    } else {
-                        const Corner c = corner_setup(m0, wr.w[0], wr.w[1]);
-                        const char *bv = data + (int64_t)v * m0.sv * 4;
-                        const float w0 = c.inw ? c.wnw : 0.0f, w1 = c.ine ? c.wne : 0.0f, w2 = c.isw ? c.wsw : 0.0f, w3 = c.ise ? c.wse : 0.0f;
-#pragma unroll
-                        for (int u = 0; u < NV; ++u) {
-                            const uint32_t cu = co + (uint32_t)u * (uint32_t)VS;
-                            const VT a = load_texel<4, false>(bv + (c.onw + cu)), b = load_texel<4, false>(bv + (c.one + cu));
-                            const VT d = load_texel<4, false>(bv + (c.osw + cu)), e = load_texel<4, false>(bv + (c.ose + cu));
-                            VT s_ = a * w0;
-                            s_ = v_fma<VT>(b, w1, s_);
-                            s_ = v_fma<VT>(d, w2, s_);
-                            s_ = v_fma<VT>(e, w3, s_);
-                            acc[u] = acc[u] + s_ * wr.wgt;
-                        }
-                    }
-                }
-            } else {
-                for (int v = 0; v < V; ++v) {
-                    const WinRec wr = C.wrec[p * V + v];
-                    const char *bv = data + (int64_t)v * m0.sv * 4;
-                    const Corner c = corner_setup(m0, wr.w[0], wr.w[1]);
-#pragma unroll
-                    for (int u = 0; u < NV; ++u) {
-                        const uint32_t cu = co + (uint32_t)u * (uint32_t)VS;
-                        const VT a = load_texel<4, false>(bv + (c.onw + cu)), b = load_texel<4, false>(bv + (c.one + cu));
-                        const VT d = load_texel<4, false>(bv + (c.osw + cu)), e = load_texel<4, false>(bv + (c.ose + cu));
-                        const VT av = c.inw ? a : (VT)0.0f, bvv = c.ine ? b : (VT)0.0f, dv = c.isw ? d : (VT)0.0f, ev = c.ise ? e : (VT)0.0f;
-                        VT s_ = av * c.wnw;
-                        s_ = v_fma<VT>(bvv, c.wne, s_);
-                        s_ = v_fma<VT>(dv, c.wsw, s_);
-                        s_ = v_fma<VT>(ev, c.wse, s_);
-                        acc[u] = acc[u] + (s_ * wr.valid) * wr.wgt;
-                    }
-                }
-            }
-            const float rcp_d = C.aux[2 * p], denom = C.aux[2 * p + 1];
-#pragma unroll
-            for (int u = 0; u < NV; ++u) {
-                VT o;
-                if (strict) {
-                    o = (VT)0.0f;                                          // fusion.py:386 when no view is valid
-                    if (C.cnt[p] != 0.0f) o = strict_div<VT>(acc[u], denom);
-                } else {
-                    VT qv = acc[u] * rcp_d;
-                    qv = v_fma<VT>(v_fma<VT>(qv, -denom, acc[u]), rcp_d, qv);
-                    qv = v_fma<VT>(v_fma<VT>(qv, -denom, acc[u]), rcp_d, qv);
-                    o = qv;
-                }
-                if (out32) store_out_off(m0.out, (uint32_t)i * (uint32_t)(m0.C * 4) + co + (uint32_t)u * (uint32_t)VS, o, P.store_policy);
-                else store_out<VT>(m0.out + i * m0.C + ((co + (uint32_t)u * (uint32_t)VS) >> 2), o, P.store_policy);
-            }
-        }
-        if (s == S - 1 && threadIdx.x < kBlock)                     // the thin maps of the call, once per brick (their gather
-            for (int t = 1; t < P.n_maps; ++t) {                    // is written for kBlock lanes)
-                const MapDesc &mt = P.maps[t];
-                switch (mt.vw) {
-                case 4: gather_map_u<4, false, true>(mt, P, C.rec, C.cnt, C.flag, C.idx, 0, TP, nullptr); break;
-                case 2: gather_map_u<2, false, true>(mt, P, C.rec, C.cnt, C.flag, C.idx, 0, TP, nullptr); break;
-                default: gather_map_u<1, false, true>(mt, P, C.rec, C.cnt, C.flag, C.idx, 0, TP, nullptr); break;
-                }
-            }
-        __builtin_amdgcn_s_waitcnt(0xc07f);                         // lgkmcnt(0): this step's LDS reads are done
-        __builtin_amdgcn_s_barrier();
-        if (++s == S) { s = 0; ++j; }
-    }
-}
-
-template <int VC, int NG>
-__global__ __launch_bounds__((NG + 1) * 64) void fused_eval_winpipe_kernel(const EvalParams P) { fused_eval_winpipe_body<VC, NG>(P); }
-
 // Entry points over one body: the plain kernel (<= 3 channel vectors per lane) is held to 128 VGPRs = 4 waves per SIMD
 // (125 allocated) -- the gather lives on memory-level parallelism; the WIDE variant adds the 4-vector load-use path
 // (C = 1024: a whole wave per point) with its natural register count.
@@ -1431,22 +1049,6 @@ hipError_t launch_fused_eval(const EvalParams &P, int mode, hipStream_t stream)
         wide |= (P.maps[s].unroll == -4);
         f16 |= (P.maps[s].esize == 2);
         runs |= (P.maps[s].runs > 0);
-    }
-    if (mode == 0 && P.win_slices > 0 && P.wp_on) {
-        const size_t lds_p = (size_t)P.win_pool_offset + 2 * (size_t)(2 + P.win_pool_texels) * 512;
-        const dim3 gp((unsigned)(8 * P.wp_grid));
-#define D3F_WP_LAUNCH(NG_)                                                                                                     \
-        do {                                                                                                                       \
-            hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void *>(&fused_eval_winpipe_kernel<2, NG_>),                \
-                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_p);                          \
-            if (ea != hipSuccess) return ea;                                                                                       \
-            hipLaunchKernelGGL((fused_eval_winpipe_kernel<2, NG_>), gp, dim3((NG_ + 1) * 64), lds_p, stream, P);                   \
-        } while (0)
-        if (P.wp_gather == 4) D3F_WP_LAUNCH(4);
-        else if (P.wp_gather == 12) D3F_WP_LAUNCH(12);
-        else D3F_WP_LAUNCH(8);
-#undef D3F_WP_LAUNCH
-        return hipGetLastError();
     }
     if (mode == 0 && P.win_slices > 0) {
         const size_t lds_w = (size_t)P.win_pool_offset + (size_t)(2 + P.win_pool_texels) * 512 * P.win_u;

@@ -112,58 +112,155 @@ hipError_t launch_grid_shell(const float *depth, const float *K, const float *po
 
 // ---- farthest point sampling (utils/my_utils.py:478-497 fps_np) ---------------------------------------
 // dist_i = min over chosen of sqrt((dx*dx + dy*dy) + dz*dz)   (float32, numpy's summation order, no fma)
-// next   = first index of the maximum.  One 1024-thread workgroup: k sequential rounds over n points.
-constexpr int kFpsBlock = 1024;
+// next   = first index of the maximum.
+// k sequential rounds over n points.  Round 2's kernel was ONE 1024-thread workgroup on one of 256 CUs (7.2 ms for 100
+// of 200 k points).  Here every round is one launch over up to 256 workgroups: a workgroup first merges the previous
+// round's per-workgroup maxima (value, first index) into the chosen point -- every workgroup redundantly, a few KB of
+// L2 reads --, then updates its contiguous chunk of `dist` and leaves its own maximum for the next round; maxima are
+// double-buffered by round parity, and launch k only merges (fps_np's third return value, dist.max()).  The comparisons
+// and their tie rule (larger value, else smaller index) are those of np.argmax, so the index sequence is identical.
+// k + 1 small dependent launches: ~2 us each back to back or in a HIP graph (the stream is the caller's, nothing here
+// synchronises).  Shared by the 3-D float32 variant and the integer-pixel variant of assoc_kernels.hip.
+struct Fps3 {
+    using dist_t = float;
+    static constexpr int kDim = 3;
+    using coord_t = float;
+    __device__ static dist_t dist(const coord_t *p, int64_t i, coord_t c0, coord_t c1, coord_t c2)
+    {
+        const float dx = p[i * 3 + 0] - c0, dy = p[i * 3 + 1] - c1, dz = p[i * 3 + 2] - c2;
+        return sqrtf((dx * dx + dy * dy) + dz * dz);
+    }
+    __device__ static dist_t lowest() { return -1.0f; }
+    __device__ static dist_t vmin(dist_t a, dist_t b) { return fminf(a, b); }       // np.minimum on finite values
+};
+struct FpsPix {        // exact int64 squared distances order like numpy's float64 norms of integer differences (< 2^53)
+    using dist_t = long long;
+    static constexpr int kDim = 2;
+    using coord_t = int32_t;
+    __device__ static dist_t dist(const coord_t *p, int64_t i, coord_t c0, coord_t c1, coord_t)
+    {
+        const long long dy = (long long)p[i * 2 + 0] - c0, dx = (long long)p[i * 2 + 1] - c1;
+        return dy * dy + dx * dx;
+    }
+    __device__ static dist_t lowest() { return -1; }
+    __device__ static dist_t vmin(dist_t a, dist_t b) { return a < b ? a : b; }     // min on the squares == np.minimum on the norms
+};
 
-__global__ __launch_bounds__(kFpsBlock) void fps_kernel(const float *__restrict__ pts, int64_t n, int k, int64_t init_idx,
-                                                       int64_t *__restrict__ out_idx, float *__restrict__ out_maxdist,
-                                                       float *__restrict__ dist)
+template <typename M>
+struct FpsMax {
+    typename M::dist_t v;
+    long long i;
+};
+
+constexpr int kFpsMaxBlocks = 256;
+
+int64_t fps_blocks(int64_t n)
 {
-    __shared__ float red_v[kFpsBlock / 64];
-    __shared__ long long red_i[kFpsBlock / 64];
+    const int64_t per = n / kFpsMaxBlocks > 1024 ? (n + kFpsMaxBlocks - 1) / kFpsMaxBlocks : 1024;     // >= 1024 points per workgroup
+    return (n + per - 1) / per;
+}
+
+int64_t fps_workspace_bytes(int64_t n, int dist_bytes)
+{
+    // n distances, then two arrays of per-workgroup maxima (16 bytes each), 16-byte aligned
+    return (n * dist_bytes + 15) / 16 * 16 + 2 * kFpsMaxBlocks * 16;
+}
+
+template <typename M>
+__global__ __launch_bounds__(kBlock) void fps_round_kernel(const typename M::coord_t *__restrict__ pts, int64_t n, int round, int k,
+                                                          int64_t init_idx, int64_t *__restrict__ out_idx, void *out_maxdist,
+                                                          typename M::dist_t *__restrict__ dist, FpsMax<M> *__restrict__ maxima, int nb)
+{
+    using D = typename M::dist_t;
+    __shared__ D red_v[kBlock / 64];
+    __shared__ long long red_i[kBlock / 64];
     __shared__ long long cur_s;
+    __shared__ D best_s;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    long long cur = init_idx;
-    float best_v = 0.0f;
-    for (int round = 0; round < k; ++round) {
-        if (tid == 0) out_idx[round] = cur;
-        const float cx = pts[cur * 3 + 0], cy = pts[cur * 3 + 1], cz = pts[cur * 3 + 2];
-        float bv = -1.0f;
-        long long bi = 0x7fffffffffffffffLL;
-        for (int64_t i = tid; i < n; i += kFpsBlock) {
-            const float dx = pts[i * 3 + 0] - cx, dy = pts[i * 3 + 1] - cy, dz = pts[i * 3 + 2] - cz;
-            float d = sqrtf((dx * dx + dy * dy) + dz * dz);
-            if (round > 0) d = fminf(dist[i], d);
-            dist[i] = d;
-            if (d > bv) { bv = d; bi = i; }            // strided scan: smaller i first, so '>' keeps the first maximum
-        }
-        // workgroup argmax with first-index tie rule
+    auto better = [](D ov, long long oi, D v, long long i) { return ov > v || (ov == v && oi < i); };
+    auto block_argmax = [&](D &bv, long long &bi) {
         for (int off = 32; off > 0; off >>= 1) {
-            const float ov = __shfl_xor(bv, off, 64);
+            const D ov = __shfl_xor(bv, off, 64);
             const long long oi = __shfl_xor(bi, off, 64);
-            if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+            if (better(ov, oi, bv, bi)) { bv = ov; bi = oi; }
         }
         if (lane == 0) { red_v[wave] = bv; red_i[wave] = bi; }
         __syncthreads();
         if (tid == 0) {
-            float v = red_v[0];
+            D v = red_v[0];
             long long ix = red_i[0];
-            for (int w = 1; w < kFpsBlock / 64; ++w)
-                if (red_v[w] > v || (red_v[w] == v && red_i[w] < ix)) { v = red_v[w]; ix = red_i[w]; }
-            cur_s = ix;
-            best_v = v;
+            for (int w = 1; w < kBlock / 64; ++w)
+                if (better(red_v[w], red_i[w], v, ix)) { v = red_v[w]; ix = red_i[w]; }
+            cur_s = ix; best_s = v;
         }
         __syncthreads();
+    };
+    // 1. the point this round adds: the start, or the first maximum of `dist` after the previous round
+    long long cur = init_idx;
+    if (round > 0) {
+        const FpsMax<M> *prev = maxima + (size_t)((round - 1) & 1) * kFpsMaxBlocks;
+        D bv = M::lowest();
+        long long bi = 0x7fffffffffffffffLL;
+        for (int b = tid; b < nb; b += kBlock) {
+            const FpsMax<M> m = prev[b];
+            if (better(m.v, m.i, bv, bi)) { bv = m.v; bi = m.i; }
+        }
+        block_argmax(bv, bi);
         cur = cur_s;
+        if (round == k) {                                   // the extra launch: fps_np's dist.max() after the last update
+            if (blockIdx.x == 0 && tid == 0 && out_maxdist) {
+                if constexpr (sizeof(D) == 4) *static_cast<float *>(out_maxdist) = (float)best_s;
+                else *static_cast<double *>(out_maxdist) = sqrt((double)best_s);
+            }
+            return;
+        }
     }
-    if (tid == 0 && out_maxdist) *out_maxdist = best_v;    // fps_np's third return value: dist.max() after the last update
+    if (blockIdx.x == 0 && tid == 0) out_idx[round] = cur;
+    // 2. update this workgroup's chunk of dist, leave its maximum (first index on ties: ascending scan with '>')
+    const typename M::coord_t c0 = pts[cur * M::kDim + 0], c1 = pts[cur * M::kDim + 1];
+    typename M::coord_t c2 = 0;
+    if constexpr (M::kDim > 2) c2 = pts[cur * M::kDim + 2];
+    const int64_t per = (n + nb - 1) / nb, lo = (int64_t)blockIdx.x * per, hi = min(n, lo + per);
+    D bv = M::lowest();
+    long long bi = 0x7fffffffffffffffLL;
+    for (int64_t i = lo + tid; i < hi; i += kBlock) {
+        D d = M::dist(pts, i, c0, c1, c2);
+        if (round > 0) d = M::vmin(dist[i], d);
+        dist[i] = d;
+        if (d > bv) { bv = d; bi = i; }
+    }
+    block_argmax(bv, bi);
+    if (tid == 0) {
+        FpsMax<M> m;
+        m.v = best_s; m.i = cur_s;
+        maxima[(size_t)(round & 1) * kFpsMaxBlocks + blockIdx.x] = m;
+    }
+}
+
+template <typename M>
+static hipError_t launch_fps_rounds(const typename M::coord_t *pts, int64_t n, int k, int64_t init_idx, int64_t *out_idx, void *out_maxdist,
+                                    void *workspace, hipStream_t s)
+{
+    using D = typename M::dist_t;
+    D *dist = static_cast<D *>(workspace);
+    FpsMax<M> *maxima = reinterpret_cast<FpsMax<M> *>(static_cast<char *>(workspace) + (n * (int64_t)sizeof(D) + 15) / 16 * 16);
+    const int nb = (int)fps_blocks(n);
+    for (int round = 0; round <= k; ++round)
+        hipLaunchKernelGGL(fps_round_kernel<M>, dim3(round == k ? 1 : nb), dim3(kBlock), 0, s, pts, n, round, k, init_idx, out_idx, out_maxdist,
+                           dist, maxima, nb);
+    return hipGetLastError();
 }
 
 hipError_t launch_fps(const float *pts, int64_t n, int k, int64_t init_idx, int64_t *out_idx, float *out_maxdist,
-                      float *dist_ws, hipStream_t s)
+                      void *workspace, hipStream_t s)
 {
-    hipLaunchKernelGGL(fps_kernel, dim3(1), dim3(kFpsBlock), 0, s, pts, n, k, init_idx, out_idx, out_maxdist, dist_ws);
-    return hipGetLastError();
+    return launch_fps_rounds<Fps3>(pts, n, k, init_idx, out_idx, out_maxdist, workspace, s);
+}
+
+hipError_t launch_fps_pixels(const int32_t *pts, int64_t n, int k, int64_t init_idx, int64_t *out_idx, double *out_maxdist,
+                             void *workspace, hipStream_t s)
+{
+    return launch_fps_rounds<FpsPix>(pts, n, k, init_idx, out_idx, out_maxdist, workspace, s);
 }
 
 }  // namespace d3f

@@ -21,6 +21,7 @@
 #include <stdint.h>
 
 #include "d3f_internal.h"
+#include "d3f_device.h"
 
 namespace d3f {
 
@@ -103,42 +104,13 @@ __global__ __launch_bounds__(kBlock) void track_loss_grad_kernel(const float *__
     }
 }
 
-// one workgroup per instance: reduce over its n keypoints, chain rule, Adam
-__global__ __launch_bounds__(kBlock) void rigid_update_kernel(const float *__restrict__ last, int n, const float *__restrict__ grad_pts,
-                                                             float *__restrict__ t, float *__restrict__ w, float *__restrict__ adam_m,
-                                                             float *__restrict__ adam_v, float *__restrict__ step,
-                                                             const float *__restrict__ norms, float eps_rot, float reg_w, float lr,
-                                                             float beta1, float beta2, float eps_adam)
+// chain rule through the transform and the exponential map, the regulariser's gradient and torch.optim.Adam's update of the
+// six parameters of instance i.  G[0..2] = sum_p dL/dp', G[3..11] = sum_p p_k dL/dp'_j (row k, column j); one lane.
+__device__ __forceinline__ void rigid_adam_update(int i, const float *G, float *__restrict__ t, float *__restrict__ w,
+                                                  float *__restrict__ adam_m, float *__restrict__ adam_v, float *__restrict__ step,
+                                                  float nt, float nw, float eps_rot, float reg_w, float lr, float beta1, float beta2,
+                                                  float eps_adam)
 {
-    __shared__ float red[12][kBlock / 64];
-    const int i = blockIdx.x;
-    float acc[12];
-#pragma unroll
-    for (int k = 0; k < 12; ++k) acc[k] = 0.0f;
-    for (int p = threadIdx.x; p < n; p += kBlock) {
-        const int64_t q = ((int64_t)i * n + p) * 3;
-        const float gx = grad_pts[q], gy = grad_pts[q + 1], gz = grad_pts[q + 2];
-        const float px = last[q], py = last[q + 1], pz = last[q + 2];
-        acc[0] += gx; acc[1] += gy; acc[2] += gz;                       // d/dt
-        acc[3] += px * gx; acc[4] += px * gy; acc[5] += px * gz;        // d/dR[k][j] = sum p_k g_j
-        acc[6] += py * gx; acc[7] += py * gy; acc[8] += py * gz;
-        acc[9] += pz * gx; acc[10] += pz * gy; acc[11] += pz * gz;
-    }
-#pragma unroll
-    for (int k = 0; k < 12; ++k) {
-        float v = acc[k];
-        for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-        if ((threadIdx.x & 63) == 0) red[k][threadIdx.x >> 6] = v;
-    }
-    __syncthreads();
-    if (threadIdx.x != 0) return;
-    float G[12];
-#pragma unroll
-    for (int k = 0; k < 12; ++k) {
-        float v = 0.0f;
-        for (int wv = 0; wv < kBlock / 64; ++wv) v += red[k][wv];
-        G[k] = v;
-    }
     const float wx = w[i * 3], wy = w[i * 3 + 1], wz = w[i * 3 + 2];
     const Rot r = exp_map(wx, wy, wz, eps_rot);
     const float K[9] = {0.0f, -wz, wy, wz, 0.0f, -wx, -wy, wx, 0.0f};
@@ -177,7 +149,6 @@ __global__ __launch_bounds__(kBlock) void rigid_update_kernel(const float *__res
     }
     float g6[6] = {G[0], G[1], G[2], gw[0], gw[1], gw[2]};
     // regulariser reg_w * (|t|_F + |w|_F): gradient x / |x|_F, 0 at the origin (torch.norm backward)
-    const float nt = norms[0], nw = norms[1];
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
         if (nt > 0.0f) g6[k] += reg_w * t[i * 3 + k] / nt;
@@ -200,6 +171,279 @@ __global__ __launch_bounds__(kBlock) void rigid_update_kernel(const float *__res
         const float denom = sqrtf(v) / bc2_sqrt + eps_adam;
         *par = *par - step_size * (m / denom);
     }
+}
+
+// one workgroup per instance: reduce over its n keypoints, chain rule, Adam
+__global__ __launch_bounds__(kBlock) void rigid_update_kernel(const float *__restrict__ last, int n, const float *__restrict__ grad_pts,
+                                                             float *__restrict__ t, float *__restrict__ w, float *__restrict__ adam_m,
+                                                             float *__restrict__ adam_v, float *__restrict__ step,
+                                                             const float *__restrict__ norms, float eps_rot, float reg_w, float lr,
+                                                             float beta1, float beta2, float eps_adam)
+{
+    __shared__ float red[12][kBlock / 64];
+    const int i = blockIdx.x;
+    float acc[12];
+#pragma unroll
+    for (int k = 0; k < 12; ++k) acc[k] = 0.0f;
+    for (int p = threadIdx.x; p < n; p += kBlock) {
+        const int64_t q = ((int64_t)i * n + p) * 3;
+        const float gx = grad_pts[q], gy = grad_pts[q + 1], gz = grad_pts[q + 2];
+        const float px = last[q], py = last[q + 1], pz = last[q + 2];
+        acc[0] += gx; acc[1] += gy; acc[2] += gz;                       // d/dt
+        acc[3] += px * gx; acc[4] += px * gy; acc[5] += px * gz;        // d/dR[k][j] = sum p_k g_j
+        acc[6] += py * gx; acc[7] += py * gy; acc[8] += py * gz;
+        acc[9] += pz * gx; acc[10] += pz * gy; acc[11] += pz * gz;
+    }
+#pragma unroll
+    for (int k = 0; k < 12; ++k) {
+        float v = acc[k];
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+        if ((threadIdx.x & 63) == 0) red[k][threadIdx.x >> 6] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    float G[12];
+#pragma unroll
+    for (int k = 0; k < 12; ++k) {
+        float v = 0.0f;
+        for (int wv = 0; wv < kBlock / 64; ++wv) v += red[k][wv];
+        G[k] = v;
+    }
+    rigid_adam_update(i, G, t, w, adam_m, adam_v, step, norms[0], norms[1], eps_rot, reg_w, lr, beta1, beta2, eps_adam);
+}
+
+// ---- the WHOLE optimiser step as one launch (round 3) -------------------------------------------------------------------
+// The five-launch step above spends its 37 us per iteration in five latency-bound kernels over ~100 keypoints and their
+// boundaries.  Per keypoint, everything between the pose parameters and dL/dp' is local: transform, projection, nearest
+// depth, weights, the bilinear gather of the descriptor, |f - src|, its gradient, and the backward of the query (three dot
+// products per view over the same corner texels).  So ONE wave per keypoint does all of it -- the corner texels are
+// gathered once and kept in registers for the forward sum AND the backward dot products -- and leaves dL/dp' (12 bytes).
+// Only the reduction over an instance's keypoints and Adam couple the waves: the last wave to finish (a returning atomic
+// after a release fence; no spinning) does that for every instance, so a step is one launch and the 100 steps of a frame are
+// 100 nodes of a HIP graph.  Same formulas as rigid_transform / fused_eval / track_loss_grad / fused_eval_backward /
+// rigid_update; sums run in another order, so the result agrees with the five-launch step to rounding (tests pin both to
+// the keypoints the reference's own loop returned).
+constexpr int kTrackMaxViews = 8;
+
+template <int NVEC>        // float4 channel vectors per lane: ceil(C / 256)
+__global__ __launch_bounds__(64) void track_step_kernel(const TrackStepParams P)
+{
+    __shared__ float krt[kTrackMaxViews * 12];
+    const int lane = threadIdx.x;
+    const int p = blockIdx.x;                               // one wave per keypoint
+    const int V = P.V, N = P.I * P.n, C = P.map.C, cvec = C / 4;
+    const MapDesc &m = P.map;
+    // every load that depends on nothing is issued before the first wait: pose parameters, the keypoint, its source
+    // descriptor, and K / pose inside compute_krt
+    const int inst = p / P.n;
+    const float w0 = P.w[inst * 3], w1 = P.w[inst * 3 + 1], w2 = P.w[inst * 3 + 2];
+    const float t0 = P.t[inst * 3], t1 = P.t[inst * 3 + 1], t2 = P.t[inst * 3 + 2];
+    const float lx = P.last[p * 3], ly = P.last[p * 3 + 1], lz = P.last[p * 3 + 2];
+    f32x4 srcv[NVEC];
+#pragma unroll
+    for (int k = 0; k < NVEC; ++k) {
+        const int cv = lane + 64 * k;
+        srcv[k] = cv < cvec ? load_vec<f32x4>(P.src + (int64_t)p * C + cv * 4) : (f32x4)0.0f;
+    }
+    compute_krt(P.K, P.pose, V, krt, 64);
+    __syncthreads();
+    // ---- transform (rigid_transform_kernel) ----
+    const Rot R = exp_map(w0, w1, w2, P.eps_rot);
+    const float tt3[3] = {t0, t1, t2};
+    float q[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        float acc = lx * R.m[0 * 3 + j];
+        acc = fmaf(ly, R.m[1 * 3 + j], acc);
+        acc = fmaf(lz, R.m[2 * 3 + j], acc);
+        q[j] = acc + tt3[j];
+    }
+    if (lane < 3) P.out_pts[p * 3 + lane] = q[lane];
+    // ---- phase A: lane v evaluates view v (fused_eval / fused_eval_backward phase A) ----
+    const float mu = P.mu, Wm1 = (float)(P.W - 1), Hm1 = (float)(P.H - 1);
+    float a_gx = 0.0f, a_gy = 0.0f, a_wgt = 0.0f, a_valid = 0.0f, a_zc = 1.0f, a_u = 0.0f, a_w = 0.0f, a_dist = 0.0f;
+    if (lane < V) {
+        const Proj pr = project_point(krt + lane * 12, q[0], q[1], q[2], Wm1, Hm1);
+        const float d = nearest_depth(P.depth, lane, P.H, P.W, pr.gx, pr.gy);
+        const float dist = d - pr.zc;
+        const bool valid = (d > 0.0f) && pr.ok && (dist > -mu);
+        float tt = mu - fabsf(dist);
+        tt = tt > 0.0f ? 0.0f : tt;
+        a_gx = pr.gx; a_gy = pr.gy; a_wgt = expf(tt / mu); a_valid = valid ? 1.0f : 0.0f;
+        a_zc = pr.zc; a_u = pr.u; a_w = pr.w; a_dist = dist;
+    }
+    float cnt = 0.0f, dsum = 0.0f;
+    for (int v = 0; v < V; ++v) {
+        const float vv = __shfl(a_valid, v, 64), dd = __shfl(a_dist, v, 64);
+        float dc = dd < -mu ? -mu : dd;
+        dc = dc > mu ? mu : dc;
+        dsum = dsum + dc * vv;                                            // fusion.py:358-364
+        cnt = cnt + vv;
+    }
+    const bool any_valid = cnt != 0.0f;
+    const float inv = 1.0f / (cnt + 1e-6f);
+    const float dist_out = any_valid ? dsum / (cnt + 1e-6f) : 1e3f;      // fusion.py:366-367
+    // ---- forward gather: the corner vectors of every valid view stay in registers ----
+    f32x4 ca[kTrackMaxViews][NVEC], cb[kTrackMaxViews][NVEC], cd[kTrackMaxViews][NVEC], ce[kTrackMaxViews][NVEC];
+    float wsy[kTrackMaxViews], wex[kTrackMaxViews], wtx[kTrackMaxViews], wty[kTrackMaxViews];
+    f32x4 acc[NVEC];
+#pragma unroll
+    for (int k = 0; k < NVEC; ++k) acc[k] = (f32x4)0.0f;
+#pragma unroll
+    for (int v = 0; v < kTrackMaxViews; ++v) {
+        if (v >= V) break;
+        const float vv = __shfl(a_valid, v, 64), gx = __shfl(a_gx, v, 64), gy = __shfl(a_gy, v, 64), wg = __shfl(a_wgt, v, 64);
+        wsy[v] = wex[v] = wtx[v] = wty[v] = 0.0f;
+#pragma unroll
+        for (int k = 0; k < NVEC; ++k) ca[v][k] = cb[v][k] = cd[v][k] = ce[v][k] = (f32x4)0.0f;
+        if (vv == 0.0f) continue;                                         // exact: the term is (+-0) for finite maps
+        const float ix = unnormalize(gx, m.fw), iy = unnormalize(gy, m.fh);
+        const float x0 = floorf(ix), y0 = floorf(iy);
+        const float tx = ix - x0, ty = iy - y0;
+        const float ex = 1.0f - tx, sy = 1.0f - ty;
+        const float x1 = x0 + 1.0f, y1 = y0 + 1.0f;
+        const bool inw = in_bounds(x0, y0, m.fw, m.fh), ine = in_bounds(x1, y0, m.fw, m.fh);
+        const bool isw = in_bounds(x0, y1, m.fw, m.fh), ise = in_bounds(x1, y1, m.fw, m.fh);
+        const int xi0 = (inw || isw) ? (int)x0 : 0, yi0 = (inw || ine) ? (int)y0 : 0;
+        const int xi1 = (ine || ise) ? (int)x1 : 0, yi1 = (isw || ise) ? (int)y1 : 0;
+        const float *bv = m.data + (int64_t)v * m.sv;
+        const float *pnw = bv + (int64_t)yi0 * m.sy + (int64_t)xi0 * m.sx, *pne = bv + (int64_t)yi0 * m.sy + (int64_t)xi1 * m.sx;
+        const float *psw = bv + (int64_t)yi1 * m.sy + (int64_t)xi0 * m.sx, *pse = bv + (int64_t)yi1 * m.sy + (int64_t)xi1 * m.sx;
+        wsy[v] = sy; wex[v] = ex; wtx[v] = tx; wty[v] = ty;
+#pragma unroll
+        for (int k = 0; k < NVEC; ++k) {
+            const int cv = lane + 64 * k;
+            if (cv < cvec) {
+                ca[v][k] = inw ? load_vec<f32x4>(pnw + cv * 4) : (f32x4)0.0f;
+                cb[v][k] = ine ? load_vec<f32x4>(pne + cv * 4) : (f32x4)0.0f;
+                cd[v][k] = isw ? load_vec<f32x4>(psw + cv * 4) : (f32x4)0.0f;
+                ce[v][k] = ise ? load_vec<f32x4>(pse + cv * 4) : (f32x4)0.0f;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < NVEC; ++k) {
+            f32x4 s_ = ca[v][k] * (sy * ex);                              // ATen bilinear: fma chain nw,ne,sw,se
+            s_ = v_fma<f32x4>(cb[v][k], sy * tx, s_);
+            s_ = v_fma<f32x4>(cd[v][k], ty * ex, s_);
+            s_ = v_fma<f32x4>(ce[v][k], ty * tx, s_);
+            acc[k] = acc[k] + (s_ * vv) * wg;                             // fusion.py:385
+        }
+    }
+    // ---- loss and its gradient w.r.t. the fused descriptor (track_loss_grad_kernel) ----
+    f32x4 g[NVEC];
+    float ss = 0.0f;
+#pragma unroll
+    for (int k = 0; k < NVEC; ++k) {
+        const int cv = lane + 64 * k;
+        g[k] = (f32x4)0.0f;
+        if (cv < cvec) {
+            const f32x4 f = any_valid ? acc[k] / (cnt + 1e-6f) : (f32x4)0.0f;     // fusion.py:385-386
+            const f32x4 d = f - srcv[k];
+            g[k] = d;
+            ss = fmaf(d.x, d.x, ss); ss = fmaf(d.y, d.y, ss); ss = fmaf(d.z, d.z, ss); ss = fmaf(d.w, d.w, ss);
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) ss += __shfl_xor(ss, off, 64);
+    const float nrm = sqrtf(ss);
+    const float vf = any_valid ? 1.0f : 0.0f;
+    const float invN = 1.0f / (float)N;
+    const float scale = (nrm > 0.0f) ? (vf * invN) / nrm : 0.0f;          // norm backward: 0 at a zero difference
+    const float cdist = dist_out * vf;
+    const float gd = (any_valid && cdist >= 0.0f) ? P.dist_w * invN * vf : 0.0f;   // clamp(min=0) passes where x >= 0
+    if (lane == 0) {
+        atomicAdd(P.loss_acc + 0, nrm * vf * invN);
+        atomicAdd(P.loss_acc + 1, P.dist_w * fmaxf(cdist, 0.0f) * invN);
+    }
+    // ---- backward of the query (fused_eval_backward_kernel): per valid view three dot products, then the chain rule ----
+    float gxw = 0.0f, gyw = 0.0f, gzw = 0.0f;
+    const float sxm = 0.5f * (float)(m.fw - 1), sym = 0.5f * (float)(m.fh - 1);    // d(ix)/d(gx), d(iy)/d(gy)
+#pragma unroll
+    for (int v = 0; v < kTrackMaxViews; ++v) {
+        if (v >= V) break;
+        const float vv = __shfl(a_valid, v, 64), wg = __shfl(a_wgt, v, 64), zc = __shfl(a_zc, v, 64);
+        const float uu = __shfl(a_u, v, 64), ww = __shfl(a_w, v, 64), dd = __shfl(a_dist, v, 64);
+        if (vv == 0.0f) continue;
+        float ds = 0.0f, dx = 0.0f, dy = 0.0f;
+#pragma unroll
+        for (int k = 0; k < NVEC; ++k) {
+            const f32x4 go = g[k] * scale;                               // dL/df (zero on idle lanes: g = 0)
+            f32x4 s_ = ca[v][k] * (wsy[v] * wex[v]);
+            s_ = v_fma<f32x4>(cb[v][k], wsy[v] * wtx[v], s_);
+            s_ = v_fma<f32x4>(cd[v][k], wty[v] * wex[v], s_);
+            s_ = v_fma<f32x4>(ce[v][k], wty[v] * wtx[v], s_);
+            const f32x4 dsx = (cb[v][k] - ca[v][k]) * wsy[v] + (ce[v][k] - cd[v][k]) * wty[v];      // ds/dix
+            const f32x4 dsy = (cd[v][k] - ca[v][k]) * wex[v] + (ce[v][k] - cb[v][k]) * wtx[v];      // ds/diy
+            ds += hsum<f32x4>(go * s_);
+            dx += hsum<f32x4>(go * dsx);
+            dy += hsum<f32x4>(go * dsy);
+        }
+        for (int off = 32; off > 0; off >>= 1) {
+            ds += __shfl_xor(ds, off, 64);
+            dx += __shfl_xor(dx, off, 64);
+            dy += __shfl_xor(dy, off, 64);
+        }
+        const float g_wgt = inv * ds;                                     // dL/dwgt_v
+        const float g_gx = inv * wg * (dx * sxm), g_gy = inv * wg * (dy * sym);
+        float g_dist = (dd >= -mu && dd <= mu) ? gd * inv : 0.0f;         // clamp passes inside [-mu, mu]
+        if (mu - fabsf(dd) <= 0.0f) {                                     // the weight passes where mu - |dist| <= 0
+            const float sgn = dd > 0.0f ? 1.0f : (dd < 0.0f ? -1.0f : 0.0f);
+            g_dist += g_wgt * wg * (-sgn) / mu;
+        }
+        const float g_u = g_gx * 2.0f / Wm1, g_w = g_gy * 2.0f / Hm1;
+        const float g_xc = g_u / zc, g_yc = g_w / zc;
+        const float g_zc = -(g_u * uu + g_w * ww) / zc - g_dist;
+        const float *M = krt + v * 12;
+        gxw += g_xc * M[0] + g_yc * M[4] + g_zc * M[8];
+        gyw += g_xc * M[1] + g_yc * M[5] + g_zc * M[9];
+        gzw += g_xc * M[2] + g_yc * M[6] + g_zc * M[10];
+    }
+    if (lane == 0) { P.grad_pts[p * 3 + 0] = gxw; P.grad_pts[p * 3 + 1] = gyw; P.grad_pts[p * 3 + 2] = gzw; }
+    // ---- the last wave to finish reduces per instance and steps Adam (rigid_update_kernel) ----
+    __threadfence();                                                      // release: grad_pts / loss are visible device-wide
+    unsigned int ticket = 0;
+    if (lane == 0) ticket = atomicAdd(P.counter, 1u);
+    ticket = (unsigned int)__builtin_amdgcn_readfirstlane((int)ticket);
+    if (ticket != (unsigned int)N - 1u) return;
+    __threadfence();                                                      // acquire
+    float st = 0.0f, sw = 0.0f;                                           // |t|_F, |w|_F over ALL instances, before the update
+    for (int k = 0; k < P.I * 3; ++k) { st += P.t[k] * P.t[k]; sw += P.w[k] * P.w[k]; }
+    const float nt = sqrtf(st), nw = sqrtf(sw);
+    for (int i = 0; i < P.I; ++i) {
+        float G[12];
+#pragma unroll
+        for (int k = 0; k < 12; ++k) G[k] = 0.0f;
+        for (int pp = lane; pp < P.n; pp += 64) {
+            const int64_t b = ((int64_t)i * P.n + pp) * 3;
+            const float gx = __builtin_nontemporal_load(P.grad_pts + b), gy = __builtin_nontemporal_load(P.grad_pts + b + 1), gz = __builtin_nontemporal_load(P.grad_pts + b + 2);
+            const float px = P.last[b], py = P.last[b + 1], pz = P.last[b + 2];
+            G[0] += gx; G[1] += gy; G[2] += gz;
+            G[3] += px * gx; G[4] += px * gy; G[5] += px * gz;
+            G[6] += py * gx; G[7] += py * gy; G[8] += py * gz;
+            G[9] += pz * gx; G[10] += pz * gy; G[11] += pz * gz;
+        }
+#pragma unroll
+        for (int k = 0; k < 12; ++k)
+            for (int off = 32; off > 0; off >>= 1) G[k] += __shfl_xor(G[k], off, 64);
+        if (lane == 0) rigid_adam_update(i, G, P.t, P.w, P.adam_m, P.adam_v, P.step, nt, nw, P.eps_rot, P.reg_w, P.lr, P.beta1, P.beta2, P.eps_adam);
+    }
+    if (lane == 0) {
+        P.loss_out[0] = __builtin_nontemporal_load(P.loss_acc + 0);
+        P.loss_out[1] = __builtin_nontemporal_load(P.loss_acc + 1);
+        P.loss_out[2] = P.reg_w * (nt + nw);
+        P.loss_acc[0] = 0.0f; P.loss_acc[1] = 0.0f;                       // clean for the next step
+        *P.counter = 0u;
+    }
+}
+
+hipError_t launch_track_step(const TrackStepParams &P, hipStream_t s)
+{
+    const int N = P.I * P.n;
+    if (N == 0) return hipSuccess;
+    const int nvec = (P.map.C / 4 + 63) / 64;
+    if (nvec <= 1) hipLaunchKernelGGL(track_step_kernel<1>, dim3((unsigned)N), dim3(64), 0, s, P);
+    else if (nvec == 2) hipLaunchKernelGGL(track_step_kernel<2>, dim3((unsigned)N), dim3(64), 0, s, P);
+    else return hipErrorInvalidValue;
+    return hipGetLastError();
 }
 
 hipError_t launch_rigid_transform(const float *last, int I, int n, const float *t, const float *w, float eps, float *out_pts,

@@ -32,11 +32,11 @@ def fps(pcd, particle_num, init_idx=-1):
     """Farthest point sampling with the signature and results of the reference's fps_np
     (utils/my_utils.py:478-497): returns (pcd_fps [k,3], fps_idx list, max remaining distance).
 
-    numpy in -> numpy out like the reference; a CUDA tensor in -> (tensor, index tensor, float).  Runs as
-    one HIP workgroup with numpy's float32 arithmetic and first-maximum tie rule, so for a given init_idx
-    the selection is identical to fps_np's.  init_idx == -1 draws the start with np.random.randint, as
-    the reference does.  (fps_np loops until len == particle_num and would spin forever on clouds smaller
-    than that after exhausting them; here particle_num is clamped to the cloud size.)
+    numpy in -> numpy out like the reference; a CUDA tensor in -> (tensor, index tensor, float).  One small launch per
+    round over up to 256 workgroups, with numpy's float32 arithmetic and first-maximum tie rule, so for a given init_idx
+    the selection is identical to fps_np's.  init_idx == -1 draws the start with np.random.randint, as the reference
+    does.  particle_num may exceed the cloud size: fps_np then keeps appending index 0 (all distances are 0) and always
+    returns particle_num points -- so does this.
     """
     as_numpy = isinstance(pcd, np.ndarray)
     if as_numpy:
@@ -50,10 +50,10 @@ def fps(pcd, particle_num, init_idx=-1):
     n = pts.shape[0]
     assert n > 0 and pts.dim() == 2 and pts.shape[1] == 3
     start = int(np.random.randint(n)) if init_idx == -1 else int(init_idx)
-    k = min(int(particle_num), n)
+    k = int(particle_num)
     idx = torch.empty(k, dtype=torch.int64, device=dev)
     maxd = torch.empty(1, dtype=torch.float32, device=dev)
-    ws = torch.empty(n, dtype=torch.float32, device=dev)
+    ws = torch.empty(_lib.load().d3f_fps_workspace_bytes(n), dtype=torch.uint8, device=dev)
     with torch.cuda.device(dev):
         _lib.check(_lib.load().d3f_farthest_point_sampling(_lib.ptr(pts), n, k, start, _lib.ptr(idx), _lib.ptr(maxd),
                                                            _lib.ptr(ws), _lib.current_stream_handle(dev)))
@@ -238,6 +238,7 @@ class Fusion:
         self.use_hip_graph = True               # rigid_tracking: capture the optimiser iteration in a HIP graph
         self.fused_tracking = True              # ... and run it as five HIP launches (track_kernels.hip) instead of autograd
         self.graph_whole_tracking_loop = True   # ... with all 100 steps in ONE graph (False: one step replayed 100 times)
+        self.single_launch_tracking = True      # ... each step ONE launch (d3f_track_step) where the descriptor map allows it
         self.detect_point_order = True          # probe new query tensors for locality (one host sync each, cached)
         self._order_cache = None
         self.cache_point_order = True           # keep the Morton order of an unchanged query tensor (a grid queried every
@@ -427,15 +428,13 @@ class Fusion:
         wide = any(plan.vectors_per_lane[s] == -4 for s in range(n_maps))
         f16 = any(maps[s].dtype == _lib.DTYPE_F16 for s in range(n_maps))
         kernel = ("fused_eval_f16_kernel<0>" if f16 else "fused_eval_wide_kernel<0>" if wide else "fused_eval_kernel<0>")
-        window = 2000 <= plan.reserved < 3000 or plan.reserved >= 4000
-        stream = 3000 <= plan.reserved < 4000
+        window = 2000 <= plan.reserved < 3000
+        stream = plan.reserved >= 3000
         if stream:
             lg, var = (plan.reserved - 3000) // 100, (plan.reserved - 3000) % 100
             T = int(plan.tile_points)
             kernel = "fused_eval_stream_kernel<%d, %d, %d, %d, %s, %d>" % (lg, T, 4 if T == 16 else 3, 4 if var == 2 else 2,
                                                                             "true" if var == 0 else "false", 7 if (var == 1 and T != 16) else 5)
-        elif plan.reserved >= 4000:
-            kernel = "fused_eval_winpipe_kernel<2, 2>"
         elif window:
             r = plan.reserved - 2000
             w0 = [s for s in range(n_maps) if plan.staged[s] == 3][0]           # the windowed map (any position in the call)
@@ -450,8 +449,6 @@ class Fusion:
                  0: "caller order"}[int(plan.reorder)]
         if window:
             order += "; %d-point bricks through texel windows in LDS" % int(plan.tile_points)
-            if plan.reserved >= 4000:
-                order += " (persistent workgroups: one producer wave + four gather waves)"
         elif runs:
             order += "; cell runs of %d consecutive points" % (max(plan.staged[s] for s in range(n_maps)) - 16)
         self._last_plan = {"kernel": kernel, "tile_points": int(plan.tile_points), "point_order": order,
@@ -756,9 +753,10 @@ class Fusion:
             # one capture per sequence: the graph is kept while instances / keypoints / views / map sizes stay the same
             key = rigid.RigidTracker.signature(self, num_instance, rand_ptcl_num)
             if (self._tracker is None or self._tracker.key != key or self._tracker.fused != self.fused_tracking or
-                    self._tracker.whole_loop != (self.graph_whole_tracking_loop and self.fused_tracking)):
+                    self._tracker.whole_loop != (self.graph_whole_tracking_loop and self.fused_tracking) or
+                    self._tracker.single_requested != self.single_launch_tracking):
                 self._tracker = rigid.RigidTracker(self, num_instance, rand_ptcl_num, fused=self.fused_tracking,
-                                                   whole_loop=self.graph_whole_tracking_loop)
+                                                   whole_loop=self.graph_whole_tracking_loop, single_launch=self.single_launch_tracking)
             cur, _ = self._tracker.run(self, src_feats, last)
         else:
             cur, _ = rigid.track_rigid(self, src_feats, last, use_graph=False)
@@ -815,6 +813,69 @@ class Fusion:
             feats_out.append(self.eval(torch.from_numpy(cloud).to(self.device, torch.float32))["dino_feats"])
             previous = labels[inst]
         return feats_out, pts_out, []
+
+    # ---- masked point clouds of instances (reference fusion.py:1258-1311) -----------------------------------------------
+    def get_inst_num(self):
+        """fusion.py:1258-1260 (the background counts)."""
+        return len(self.curr_obs_torch["consensus_mask_label"])
+
+    def _masked_clouds(self, sel_mask, views, boundaries, downsample):
+        """sel_mask [len(views),H,W] bool DEVICE tensor -> 2x2 cv2.erode per view (d3f_erode) -> masked back-projection to the
+        world frame + boundary crop (d3f_backproject_view) per view, concatenated in view order: what the reference does with
+        cv2 + aggr_point_cloud_from_data(..., masks=sel_mask, out_o3d=False) (fusion.py:1271-1278).  Masks, depth and the
+        compaction stay on the device; the clouds come back as float64 numpy arrays like the reference's."""
+        from . import pcd_utils
+        lib = _lib.load()
+        dev = sel_mask.device
+        H, W = self.H, self.W
+        obs = self.curr_obs_torch
+        K = obs["K"].detach().cpu().numpy()
+        pose = obs["pose"].detach().cpu().numpy()
+        bounds = None if boundaries is None else [boundaries[k] for k in ("x_lower", "x_upper", "y_lower", "y_upper", "z_lower", "z_upper")]
+        colors = np.asarray(obs["color"])
+        gate = (sel_mask.to(torch.uint8) * 255).contiguous()
+        pts_all, col_all = [], []
+        for j, v in enumerate(views):
+            eroded = torch.empty((H, W), dtype=torch.uint8, device=dev)
+            with torch.cuda.device(dev):
+                _lib.check(lib.d3f_erode(_lib.ptr(gate[j]), H, W, 2, 2, _lib.ptr(eroded), _lib.current_stream_handle(dev)))
+            pose44 = np.concatenate([pose[v][:3], np.array([[0, 0, 0, 1]])], axis=0)          # fusion.py:1274-1276
+            cam = [K[v][0, 0], K[v][1, 1], K[v][0, 2], K[v][1, 2]]
+            pts, pix = pcd_utils._backproject(obs["depth"][v], eroded, cam, np.linalg.inv(pose44), bounds, dev)
+            pts_np = pts.cpu().numpy()
+            col_np = (colors[v] / 255.).reshape(-1, 3)[pix.cpu().numpy()]
+            if downsample:
+                pts_np, col_np = pcd_utils.voxel_downsample(pts_np, 0.01, col_np)               # draw_utils.py:396-400
+            pts_all.append(pts_np)
+            col_all.append(col_np)
+        return np.concatenate(pts_all, axis=0), np.concatenate(col_all, axis=0)
+
+    def extract_masked_pcd(self, inst_idx_ls, boundaries=None):
+        """Reference fusion.py:1262-1279: the world-frame points of the instances `inst_idx_ls` (OR of their mask channels,
+        2x2-eroded, valid depth) over all views; float64 [n,3] in the reference's order (views, then ascending pixels)."""
+        mask = self.curr_obs_torch["mask"]
+        sel = (mask[..., list(inst_idx_ls)] != 0).any(dim=-1) if len(inst_idx_ls) else torch.zeros(mask.shape[:3], dtype=torch.bool, device=mask.device)
+        return self._masked_clouds(sel, range(self.num_cam), boundaries, False)[0]
+
+    def extract_masked_pcd_in_views(self, inst_idx_ls, view_idx_ls, boundaries, downsample=True):
+        """Reference fusion.py:1281-1299 (exactly one view, taken from the per-view Grounded-SAM masks 'mask_gs').
+        downsample=True (the reference's default) is a 1-cm voxel grid mean like open3d's voxel_down_sample: the same SET
+        of points as open3d's to rounding, in ascending voxel order (open3d's order is that of its hash map)."""
+        assert len(view_idx_ls) == 1
+        dev = torch.device(self.device)
+        gs = [torch.as_tensor(np.asarray(self.curr_obs_torch["mask_gs"][v])).to(dev) for v in view_idx_ls]      # [NI,H,W] each
+        sel = torch.stack([(g[list(inst_idx_ls)] != 0).any(dim=0) for g in gs], dim=0)
+        return self._masked_clouds(sel, list(view_idx_ls), boundaries, downsample)[0]
+
+    def get_query_obj_pcd(self):
+        """Reference fusion.py:1301-1311: the cloud of every non-background instance.  The reference returns an open3d
+        PointCloud (aggr_point_cloud_from_data's default out_o3d=True); with open3d importable so does this, otherwise a
+        pcd_utils.PointCloud carrying the same .points / .colors arrays."""
+        from . import pcd_utils
+        mask = self.curr_obs_torch["mask"]
+        sel = mask[..., 1:].sum(dim=-1) > 0
+        pts, col = self._masked_clouds(sel, range(self.num_cam), None, False)
+        return pcd_utils.as_point_cloud(pts, col)
 
     # ---- instance masks: upstream producers (reference fusion.py:1112-1256) ----------------
     # The reference hard-wires Grounded-SAM + its multi-view association (align_instance_mask_v3, fusion.py:1067-1098)

@@ -1,8 +1,10 @@
 """Point-cloud helpers on the mask side of the path, with the reference's names and semantics:
-``depth2fgpcd`` (utils/my_utils.py:522-537), ``aggr_point_cloud_from_data`` (utils/draw_utils.py:325-413,
-numpy outputs only) and ``pcd_iou`` (Fusion.pcd_iou, fusion.py:724-741).  numpy in / numpy out like the
-reference; the per-pixel and per-pair work runs on the ROCm device in fp64.  open3d (voxel down-sampling,
-o3d point clouds) is an upstream dependency and is not reproduced: downsample=True / out_o3d=True raise.
+``depth2fgpcd`` (utils/my_utils.py:522-537), ``aggr_point_cloud_from_data`` and ``voxel_downsample``
+(utils/draw_utils.py:318-413) and ``pcd_iou`` (Fusion.pcd_iou, fusion.py:724-741).  numpy in / numpy out like the
+reference; the per-pixel, per-point and per-pair work runs on the ROCm device in fp64.  open3d itself is not needed:
+its voxel_down_sample is restated as a device voxel-grid mean (same point set, ascending voxel order instead of open3d's
+hash-map order), and where the reference returns an open3d PointCloud (out_o3d=True) this returns one too when open3d
+is importable, else a ``PointCloud`` carrying the same ``points`` / ``colors`` arrays.
 """
 import ctypes
 
@@ -11,8 +13,8 @@ import torch
 
 from . import _lib
 
-__all__ = ["depth2fgpcd", "aggr_point_cloud_from_data", "pcd_iou", "init_low_level_memory", "vox_idx_iou", "erode",
-           "fps_pixels"]
+__all__ = ["depth2fgpcd", "aggr_point_cloud_from_data", "voxel_downsample", "PointCloud", "as_point_cloud", "pcd_iou",
+           "init_low_level_memory", "vox_idx_iou", "erode", "fps_pixels", "masked_pixel_fps"]
 
 
 def _device():
@@ -27,11 +29,20 @@ def _dbl(values):
 
 
 def _backproject(depth, mask, cam_params, cam_to_world, bounds, dev):
-    """One view -> (points [n,3] float64 tensor, pixel index [n] int32 tensor), ascending pixel order."""
+    """One view -> (points [n,3] float64 tensor, pixel index [n] int32 tensor), ascending pixel order.  depth / mask: numpy
+    arrays, or DEVICE tensors (depth any float dtype, mask uint8 / bool) that are used in place."""
     lib = _lib.load()
     H, W = depth.shape
-    d = torch.from_numpy(np.ascontiguousarray(depth, dtype=np.float64)).to(dev)
-    m = torch.from_numpy(np.ascontiguousarray(mask).astype(np.uint8)).to(dev) if mask is not None else None
+    if isinstance(depth, torch.Tensor):
+        d = depth.to(device=dev, dtype=torch.float64).contiguous()
+    else:
+        d = torch.from_numpy(np.ascontiguousarray(depth, dtype=np.float64)).to(dev)
+    if mask is None:
+        m = None
+    elif isinstance(mask, torch.Tensor):
+        m = mask.to(device=dev, dtype=torch.uint8).contiguous()
+    else:
+        m = torch.from_numpy(np.ascontiguousarray(mask).astype(np.uint8)).to(dev)
     cap = H * W
     pts = torch.empty((cap, 3), dtype=torch.float64, device=dev)
     pix = torch.empty(cap, dtype=torch.int32, device=dev)
@@ -53,11 +64,66 @@ def depth2fgpcd(depth, mask, cam_params):
     return pts.cpu().numpy()
 
 
+class PointCloud:
+    """What stands in for open3d.geometry.PointCloud when open3d is not installed: `.points` / `.colors` are float64 [n,3]
+    arrays (np.asarray(pcd.points) works on both), `+` concatenates like open3d's operator."""
+
+    def __init__(self, points=None, colors=None):
+        self.points = np.zeros((0, 3)) if points is None else np.asarray(points, dtype=np.float64)
+        self.colors = np.zeros((0, 3)) if colors is None else np.asarray(colors, dtype=np.float64)
+
+    def __add__(self, other):
+        return PointCloud(np.concatenate([self.points, np.asarray(other.points)], 0), np.concatenate([self.colors, np.asarray(other.colors)], 0))
+
+    def __len__(self):
+        return self.points.shape[0]
+
+
+def as_point_cloud(points, colors=None):
+    """np2o3d (utils/draw_utils.py): an open3d PointCloud when open3d is importable, else a PointCloud (above)."""
+    try:
+        import open3d as o3d
+        pcd = o3d.geometry.PointCloud()
+        pcd.points = o3d.utility.Vector3dVector(np.asarray(points, dtype=np.float64))
+        if colors is not None:
+            pcd.colors = o3d.utility.Vector3dVector(np.asarray(colors, dtype=np.float64))
+        return pcd
+    except ImportError:
+        return PointCloud(points, colors)
+
+
+def voxel_downsample(pcd, voxel_size, pcd_color=None):
+    """Reference utils/draw_utils.py:318-323 (open3d's voxel_down_sample): one point (and colour) per occupied voxel of
+    side voxel_size anchored at min_bound - voxel_size/2 = the mean of the voxel's points.  Runs as d3f_voxel_downsample
+    on the device: the same SET as open3d's to ~1e-14 m, in ascending voxel order (open3d: the order of its hash map).
+    Returns (points, colors) or points, like the reference."""
+    pts_np = np.ascontiguousarray(pcd, dtype=np.float64).reshape(-1, 3)
+    n = pts_np.shape[0]
+    if n == 0:
+        return (pts_np, np.zeros((0, 3))) if pcd_color is not None else pts_np
+    dev = _device()
+    lib = _lib.load()
+    pts = torch.from_numpy(pts_np).to(dev)
+    col = torch.from_numpy(np.ascontiguousarray(pcd_color, dtype=np.float64).reshape(-1, 3)).to(dev) if pcd_color is not None else None
+    out_p = torch.empty((n, 3), dtype=torch.float64, device=dev)
+    out_c = torch.empty((n, 3), dtype=torch.float64, device=dev) if col is not None else None
+    cnt = torch.zeros(1, dtype=torch.int64, device=dev)
+    ws_bytes = lib.d3f_voxel_downsample_workspace_bytes(n)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(lib.d3f_voxel_downsample(_lib.ptr(pts), _lib.ptr(col), n, float(voxel_size), _lib.ptr(out_p), _lib.ptr(out_c),
+                                            _lib.ptr(cnt), _lib.ptr(ws), ws_bytes, _lib.current_stream_handle(dev)))
+    v = int(cnt.item())
+    if pcd_color is not None:
+        return out_p[:v].cpu().numpy(), out_c[:v].cpu().numpy()
+    return out_p[:v].cpu().numpy()
+
+
 def aggr_point_cloud_from_data(colors, depths, Ks, poses, downsample=True, masks=None, boundaries=None, out_o3d=True):
-    """Reference utils/draw_utils.py:325-413 for downsample=False, out_o3d=False: returns (pcds [n,3], colors [n,3])."""
-    if out_o3d or downsample:
-        raise NotImplementedError("open3d outputs / voxel down-sampling are upstream (open3d) functionality; "
-                                  "call with downsample=False, out_o3d=False")
+    """Reference utils/draw_utils.py:325-413, defaults included: per view depth2fgpcd -> camera-to-world -> boundary crop
+    (one device pass with an order-preserving compaction), optional 1-cm voxel-grid mean per view (voxel_downsample above),
+    views concatenated.  out_o3d=False: (pcds [n,3], colors [n,3]) numpy arrays; out_o3d=True: a point cloud object
+    (as_point_cloud)."""
     dev = _device()
     N = colors.shape[0]
     colors = colors / 255.
@@ -70,9 +136,15 @@ def aggr_point_cloud_from_data(colors, depths, Ks, poses, downsample=True, masks
         cam_param = [K[0, 0], K[1, 1], K[0, 2], K[1, 2]]
         pose = np.linalg.inv(poses[i])
         pts, pix = _backproject(depths[i], None if masks is None else masks[i], cam_param, pose, bounds, dev)
-        pcds.append(pts.cpu().numpy())
-        pcd_colors.append(colors[i].reshape(-1, 3)[pix.cpu().numpy()])
-    return np.concatenate(pcds, axis=0), np.concatenate(pcd_colors, axis=0)
+        pts_np, col_np = pts.cpu().numpy(), colors[i].reshape(-1, 3)[pix.cpu().numpy()]
+        if downsample:
+            pts_np, col_np = voxel_downsample(pts_np, 0.01, col_np)          # draw_utils.py:390-400: radius 0.01, both branches
+        pcds.append(pts_np)
+        pcd_colors.append(col_np)
+    pts_all, col_all = np.concatenate(pcds, axis=0), np.concatenate(pcd_colors, axis=0)
+    if out_o3d:
+        return as_point_cloud(pts_all, col_all)
+    return pts_all, col_all
 
 
 def _nearest(a, b, dev):
@@ -211,7 +283,7 @@ def fps_pixels(pixel_idx, particle_num, init_idx=-1):
     pts = torch.from_numpy(pix.astype(np.int32)).to(dev)
     idx = torch.empty(k, dtype=torch.int64, device=dev)
     maxd = torch.empty(1, dtype=torch.float64, device=dev)
-    ws = torch.empty(n, dtype=torch.int64, device=dev)
+    ws = torch.empty(_lib.load().d3f_fps_pixels_workspace_bytes(n), dtype=torch.uint8, device=dev)
     with torch.cuda.device(dev):
         _lib.check(_lib.load().d3f_fps_pixels(_lib.ptr(pts), n, k, start, _lib.ptr(idx), _lib.ptr(maxd), _lib.ptr(ws),
                                               _lib.current_stream_handle(dev)))
@@ -248,7 +320,7 @@ def masked_pixel_fps(mask_channel, depth, particle_num, depth_lo=0.0, depth_hi=1
         start = int(np.random.randint(n)) if init_idx == -1 else int(init_idx)
         k = int(particle_num)
         idx = torch.empty(k, dtype=torch.int64, device=dev)
-        dist_ws = torch.empty(n, dtype=torch.int64, device=dev)
+        dist_ws = torch.empty(lib.d3f_fps_pixels_workspace_bytes(n), dtype=torch.uint8, device=dev)
         _lib.check(lib.d3f_fps_pixels(_lib.ptr(rc), n, k, start, _lib.ptr(idx), None, _lib.ptr(dist_ws), st))
         sel = rc[idx].to(torch.int64)                            # [k,2] rows, cols
         sel_depth = depth[sel[:, 0], sel[:, 1]]

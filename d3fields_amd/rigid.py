@@ -96,16 +96,20 @@ class RigidTracker:
     initial values and replays the graph `iters` times.  The captured query runs without D3F_FLAG_FINITE_MAPS
     (the flag would be baked into the graph; results are identical either way).
 
-    fused=True (default): the step is FIVE launches -- d3f_rigid_transform, d3f_eval, d3f_track_loss_grad,
-    d3f_eval_backward, d3f_rigid_update (csrc/track_kernels.hip: exponential map, transform, loss gradients, chain
-    rule and Adam in closed form) -- instead of torch autograd's ~90.  fused=False replays the autograd step."""
+    fused=True (default): the step is closed-form HIP (csrc/track_kernels.hip: exponential map, transform, query,
+    loss gradients, backward of the query, chain rule and Adam) instead of torch autograd's ~90 launches -- as ONE launch
+    per step (d3f_track_step: a wave per keypoint, the last wave to finish steps Adam; single_launch=True, the default
+    whenever the descriptor map is fp32 with <= 512 channels and <= 8 views) or as five (d3f_rigid_transform, d3f_eval,
+    d3f_track_loss_grad, d3f_eval_backward, d3f_rigid_update).  fused=False replays the autograd step."""
 
-    def __init__(self, fusion, num_inst, n, iters=ITERS, lr=LR, fused=True, whole_loop=True):
+    def __init__(self, fusion, num_inst, n, iters=ITERS, lr=LR, fused=True, whole_loop=True, single_launch=True):
         from .fusion import Fusion
         dev = torch.device(fusion.device)
         obs = fusion.curr_obs_torch
         self.key = self.signature(fusion, num_inst, n)
         self.iters, self.lr, self.fused = iters, lr, fused
+        self.single = False
+        self.single_requested = bool(single_launch)
         # whole_loop: ALL `iters` steps are captured into one HIP graph (5 x iters kernel nodes, one launch per frame)
         # instead of one step replayed `iters` times (a graph launch per step)
         self.whole_loop = bool(whole_loop) and fused
@@ -125,6 +129,12 @@ class RigidTracker:
             self.grad_feats = torch.empty(num_inst * n, C, device=dev)
             self.grad_dist = torch.empty(num_inst * n, device=dev)
             self.opt = None
+            feats = obs["dino_feats"]
+            self.single = bool(single_launch) and feats.dtype == torch.float32 and C % 4 == 0 and C <= 512 and fusion.num_cam <= 8
+            if self.single:
+                from . import _lib
+                self.loss3 = torch.zeros(3, device=dev)
+                self.scratch = torch.zeros(_lib.load().d3f_track_step_scratch_bytes(num_inst, n) // 4, device=dev)
         else:
             self.opt = torch.optim.Adam([self.t_params, self.log_r], lr=lr, betas=(0.9, 0.999), capturable=True)
         self.graph = None
@@ -142,6 +152,8 @@ class RigidTracker:
             self.log_r.zero_()
             if self.fused:
                 self.state.zero_()
+                if self.single:
+                    self.scratch.zero_()
             else:
                 for st in self.opt.state.values():
                     for v in st.values():
@@ -151,10 +163,22 @@ class RigidTracker:
     def _fused_iteration(self):
         """transform -> d3f_eval -> loss gradients -> d3f_eval_backward -> chain rule + Adam: five launches, no autograd."""
         from . import _lib
+        import ctypes
         lib, dev = _lib.load(), self.last.device
         I, n, N = self.num_inst, self.n, self.num_inst * self.n
         st = self.state
         m, v, step, norms, loss = st[:I * 6], st[I * 6:I * 12], st[I * 12:I * 13], st[I * 13:I * 13 + 2], st[I * 13 + 2:I * 13 + 4]
+        if self.single:
+            with torch.cuda.device(dev), torch.no_grad():
+                stream = _lib.current_stream_handle(dev)
+                views, keep, V = self.shadow._views(dev)
+                fm = self.shadow.curr_obs_torch["dino_feats"]
+                cm = _lib.ChannelMap(fm.data_ptr(), fm.shape[1], fm.shape[2], fm.shape[3], _lib.DTYPE_F32, fm.stride(0), fm.stride(1), fm.stride(2))
+                state = _lib.TrackState(_lib.ptr(self.t_params), _lib.ptr(self.log_r), _lib.ptr(m), _lib.ptr(v), _lib.ptr(step),
+                                        _lib.ptr(self.pts), _lib.ptr(self.loss3), _lib.ptr(self.scratch))
+                _lib.check(lib.d3f_track_step(ctypes.byref(views), ctypes.byref(cm), _lib.ptr(self.last), I, n, _lib.ptr(self.src),
+                                              float(self.shadow.mu), DIST_W, REG_W, self.lr, 0.9, 0.999, 1e-8, ctypes.byref(state), stream))
+            return self.pts, self.loss3.sum()
         with torch.cuda.device(dev), torch.no_grad():
             stream = _lib.current_stream_handle(dev)
             _lib.check(lib.d3f_rigid_transform(_lib.ptr(self.last), I, n, _lib.ptr(self.t_params), _lib.ptr(self.log_r),

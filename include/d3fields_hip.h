@@ -201,11 +201,14 @@ int64_t d3f_grid_shell_workspace_bytes(const d3f_grid *grid);
 int d3f_grid_shell(const d3f_views *views, const d3f_grid *grid, float mu, float dist_thr, int64_t capacity,
                    int64_t *idx_out, int64_t *count_out, void *workspace, int64_t workspace_bytes, void *stream);
 
-/* fps_np (utils/my_utils.py:478-497): k farthest points of pts[n,3] starting from init_idx, float32
- * Euclidean distances, first maximum wins -> out_idx[k] (int64, device), out_maxdist (device float, may
- * be NULL).  dist_workspace: n floats of device scratch. */
+/* fps_np (utils/my_utils.py:478-497): k samples of pts[n,3] starting from init_idx, float32 Euclidean distances,
+ * first maximum wins -> out_idx[k] (int64, device), out_maxdist (device float, may be NULL).  k may exceed n: like
+ * fps_np the selection then continues with index 0 (every distance is 0).  k + 1 small dependent launches on `stream`
+ * (one per round over up to 256 workgroups, maxima merged by the next round); workspace: d3f_fps_workspace_bytes(n)
+ * bytes of device scratch, 16-byte aligned. */
+int64_t d3f_fps_workspace_bytes(int64_t n);
 int d3f_farthest_point_sampling(const float *pts, int64_t n, int32_t k, int64_t init_idx, int64_t *out_idx,
-                                float *out_maxdist, float *dist_workspace, void *stream);
+                                float *out_maxdist, void *workspace, void *stream);
 
 /* ---- point clouds on the mask side of the path (fp64, like the reference's numpy) ----------------------
  * depth2fgpcd (utils/my_utils.py:522-537) + camera->world transform + boundary crop of
@@ -246,6 +249,16 @@ int d3f_vox_idx_iou(const int32_t *idx1, int64_t n1, const int32_t *idx2, int64_
  * ignored (cv2's default border for erosion).  src != dst. */
 int d3f_erode(const uint8_t *src, int32_t H, int32_t W, int32_t kh, int32_t kw, uint8_t *dst, void *stream);
 
+/* open3d's PointCloud.voxel_down_sample as the reference uses it (utils/draw_utils.py:318-323 voxel_downsample, :396-400
+ * inside aggr_point_cloud_from_data; radius 0.01): voxels of side voxel_size anchored at min_bound - voxel_size/2, one
+ * output point (and colour) per occupied voxel = the mean of its points.  pts / colors [n,3] float64 (colors may be NULL),
+ * out_pts / out_colors [n,3] capacity; *count_out (device int64) = the number of voxels.  Output order: ASCENDING voxel
+ * index (x, then y, then z) -- open3d's order is that of its hash map, so the SETS agree (means to ~1e-14 m: the sums are
+ * exact 64-bit fixed point, hence deterministic), the order does not.  Axis extent < 2^21 voxels. */
+int64_t d3f_voxel_downsample_workspace_bytes(int64_t n);
+int d3f_voxel_downsample(const double *pts, const double *colors, int64_t n, double voxel_size, double *out_pts,
+                         double *out_colors, int64_t *count_out, void *workspace, int64_t workspace_bytes, void *stream);
+
 /* The pixel side of select_features_rand_v2 (fusion.py:1554-1565), on the device:
  *   d3f_mask_gate       out(y,x) = 255 where mask(y,x) != 0 and depth_lo < depth(y,x) < depth_hi, else 0 -- the reference's
  *                       `mask.astype(bool) & (depth > 0.0) & (depth < 1.5)` as the uint8 image cv2.erode takes.  The mask
@@ -262,9 +275,10 @@ int d3f_nonzero_pixels(const uint8_t *image, int32_t H, int32_t W, int64_t capac
 /* fps_np (utils/my_utils.py:478-497) on integer 2-D points, as select_features_rand_v2 calls it on the (row, col)
  * indices of a mask (fusion.py:1565-1566): pts [n,2] int32, exact squared distances (numpy's float64 norms of
  * integer differences order identically), first maximum wins.  out_idx [k] int64, out_maxdist one device double
- * or NULL, dist_workspace: n int64 of device scratch. */
+ * or NULL; workspace: d3f_fps_pixels_workspace_bytes(n) bytes, 16-byte aligned; k + 1 launches like d3f_farthest_point_sampling. */
+int64_t d3f_fps_pixels_workspace_bytes(int64_t n);
 int d3f_fps_pixels(const int32_t *pts, int64_t n, int32_t k, int64_t init_idx, int64_t *out_idx, double *out_maxdist,
-                   int64_t *dist_workspace, void *stream);
+                   void *workspace, void *stream);
 
 /* Gradient of d3f_eval's outputs w.r.t. the query points: what autograd through Fusion.eval gives
  * the reference's rigid_tracking (fusion.py:1643-1665).  grad_dist: [n] or NULL; grad_fused: host
@@ -388,6 +402,28 @@ int d3f_track_loss_grad(const float *feats, const float *src, const float *dist,
 int d3f_rigid_update(const float *last, int32_t n_inst, int32_t n, const float *grad_pts, float *t, float *w,
                      float *adam_m, float *adam_v, float *step, const float *norms, float reg_w, float lr,
                      float beta1, float beta2, float eps, void *stream);
+
+/* The same optimiser step as ONE launch: a wave per keypoint transforms it, queries the descriptor field, forms the
+ * loss gradient and back-propagates it to the keypoint with the corner texels held in registers; the last wave to
+ * finish reduces per instance and steps Adam.  One descriptor map: fp32, C % 4 == 0, C <= 512, 16-byte aligned texels,
+ * at most 8 views (otherwise D3F_ERR_BAD_SHAPE / D3F_ERR_BAD_LAYOUT: use the five launches above).  `state` holds device
+ * pointers owned by the caller: t / w [n_inst,3] (updated in place), adam_m / adam_v [n_inst,6], step [n_inst] (float
+ * counters), out_pts [n_inst*n,3] (the keypoints as evaluated in this step -- what rigid_tracking returns after its last
+ * step), loss [3] (feature term, distance term, regulariser of this step) and scratch of
+ * d3f_track_step_scratch_bytes(n_inst, n) bytes that must be ZERO before the first step of a frame (every step leaves
+ * it zero again).  src [n_inst*n, C]: the instances' source descriptors. */
+typedef struct d3f_track_state {
+    float *t, *w;
+    float *adam_m, *adam_v;
+    float *step;
+    float *out_pts;
+    float *loss;
+    void *scratch;
+} d3f_track_state;
+int64_t d3f_track_step_scratch_bytes(int32_t n_inst, int32_t n);
+int d3f_track_step(const d3f_views *views, const d3f_channel_map *descriptors, const float *last, int32_t n_inst, int32_t n,
+                   const float *src, float mu, float dist_w, float reg_w, float lr, float beta1, float beta2, float eps,
+                   const d3f_track_state *state, void *stream);
 
 #ifdef __cplusplus
 }

@@ -358,6 +358,41 @@ def select_v2_case(fusion):
     save("select_v2", **arrays)
 
 
+def masked_pcd_case(fusion):
+    """Fusion.extract_masked_pcd / extract_masked_pcd_in_views (fusion.py:1262-1299; downsample=False, numpy outputs) run by
+    the reference (cv2.erode restated, oracle/np_pcd.py): OR of instance masks -> 2x2 erosion -> masked back-projection of
+    every view -> world frame -> boundary crop."""
+    V, H, W = 4, 96, 128
+    sc = synth.make_scene(V, H, W, "smooth")
+    depth = sc["depth"].clone()
+    depth[1, 20:30, 40:70] = 0.0                                     # a hole under an instance
+    yy, xx = np.mgrid[0:H, 0:W]
+    lab = np.zeros((V, H, W), np.int64)
+    for v in range(V):
+        lab[v][(yy - 30 - 2 * v) ** 2 + (xx - 40) ** 2 < 22 ** 2] = 1
+        lab[v][(np.abs(yy - 60) < 18) & (np.abs(xx - 92 + 3 * v) < 20)] = 2
+        lab[v][(np.abs(yy - 80) < 6) & (np.abs(xx - 20) < 9)] = 3
+    mask = torch.nn.functional.one_hot(torch.from_numpy(lab), 4).to(torch.float32)
+    rng = np.random.default_rng(77)
+    color = rng.integers(0, 256, size=(V, H, W, 3), dtype=np.uint8)
+    labels = ["background", "mug", "box", "pen"]
+    mask_gs = [np.stack([lab[v] == i for i in range(4)], axis=0) for v in range(V)]      # per view [NI,H,W] bool (fusion.py:1141)
+    obs = dict(depth=depth, K=sc["K"], pose=sc["pose"])
+    obs.update(mask=mask, mask_gs=mask_gs, mask_label=[labels] * V, consensus_mask_label=labels, color=color)
+    f = R.make_reference_fusion(fusion, obs, H, W)
+    box = dict(synth.WORK_BOX)
+    tight = dict(box, x_lower=-0.1, y_upper=0.12)
+    arrays = dict(H=H, W=W, K=sc["K"].numpy(), pose=sc["pose"].numpy(), depth=depth.numpy(), in_mask=mask.numpy(), color=color,
+                  tight=np.array([tight[k] for k in ("x_lower", "x_upper", "y_lower", "y_upper", "z_lower", "z_upper")]))
+    arrays["pcd_12_box"] = f.extract_masked_pcd([1, 2], boundaries=box)
+    arrays["pcd_3_none"] = f.extract_masked_pcd([3])
+    arrays["pcd_123_tight"] = f.extract_masked_pcd([1, 2, 3], boundaries=tight)
+    arrays["pcd_123_none"] = f.extract_masked_pcd([1, 2, 3])              # == the points of get_query_obj_pcd (fusion.py:1301-1311)
+    arrays["view2_2_box"] = f.extract_masked_pcd_in_views([2], [2], box, downsample=False)
+    arrays["view0_13_tight"] = f.extract_masked_pcd_in_views([1, 3], [0], tight, downsample=False)
+    save("masked_pcd", **arrays)
+
+
 def main():
     torch.set_num_threads(4)
     fusion, corr = R.import_reference()
@@ -376,6 +411,7 @@ def main():
     tracking_case(fusion)
     assoc_case(fusion)
     select_v2_case(fusion)
+    masked_pcd_case(fusion)
 
 
 if __name__ == "__main__":

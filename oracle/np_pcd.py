@@ -98,3 +98,25 @@ def fps_int(pix, particle_num, init_idx):
         idx.append(int(dist.argmax()))
         dist = np.minimum(dist, np.linalg.norm(pix - pix[idx[-1]], axis=1))
     return pix[idx], idx, float(dist.max())
+
+
+def voxel_mean(points, voxel_size, colors=None):
+    """open3d 0.17 PointCloud::VoxelDownSample restated (geometry/PointCloud.cpp: voxel_min_bound = min_bound - voxel_size/2,
+    voxel index = floor((p - voxel_min_bound) / voxel_size), per voxel the mean of the accumulated points / colours in point
+    order).  Returned in ASCENDING voxel-index order (open3d iterates its unordered_map); the SET is open3d's."""
+    points = np.asarray(points, dtype=np.float64)
+    anchor = points.min(axis=0) - voxel_size * 0.5
+    idx = np.floor((points - anchor) / voxel_size).astype(np.int64)
+    acc = {}
+    for i in range(points.shape[0]):
+        k = tuple(idx[i])
+        a = acc.setdefault(k, [np.zeros(3), np.zeros(3), 0])
+        a[0] = a[0] + points[i]
+        if colors is not None:
+            a[1] = a[1] + colors[i]
+        a[2] += 1
+    keys = sorted(acc)
+    pts = np.stack([acc[k][0] / acc[k][2] for k in keys])
+    if colors is None:
+        return pts
+    return pts, np.stack([acc[k][1] / acc[k][2] for k in keys])

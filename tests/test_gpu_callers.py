@@ -350,3 +350,65 @@ def test_config5_thirty_frame_sequence(dev):
             assert np.array_equal(cpu(onehot2instance(out["mask"][pick.to(dev)])), O.onehot2instance(ref["sets"][1])), frame
         assert torch.equal(match, sim.argmax(0)) and torch.equal(match, knn[0]), frame
         assert abs(float(sim.sum(0).mean()) - 1.0) < 1e-4
+
+
+# ---- masked instance clouds (reference fusion.py:1262-1311) and the voxel-grid mean --------------------------------------
+def _masked_fusion(dev):
+    from d3fields_amd import Fusion
+    g = load_golden("masked_pcd")
+    V, H, W = g["depth"].shape
+    labels = ["background", "mug", "box", "pen"]
+    f = Fusion(num_cam=V, device=str(dev), mask_producer=lambda fusion, q, t, b, **kw: {
+        "mask": g["in_mask"], "consensus_mask_label": labels,
+        "mask_gs": [np.moveaxis(g["in_mask"][v] > 0, -1, 0) for v in range(V)]})
+    f.update({"color": g["color"], "depth": g["depth"], "pose": g["pose"], "K": g["K"], "dino_feats": np.zeros((V, 4, 4, 4), np.float32)})
+    f.text_queries_for_inst_mask_no_track(labels[1:], [0.3] * 3, None)
+    return g, f
+
+
+def test_extract_masked_pcd_matches_reference(dev):
+    """Fusion.extract_masked_pcd / extract_masked_pcd_in_views(downsample=False) / get_query_obj_pcd against the clouds the
+    REFERENCE's methods returned (golden 'masked_pcd'; cv2.erode restated): same points in the same order, 1e-12 m (the
+    reference's [4,4] @ [4,n] runs through BLAS, the kernel sums in a fixed order)."""
+    from d3fields_amd import synth
+    g, f = _masked_fusion(dev)
+    box = dict(synth.WORK_BOX)
+    tight = dict(zip(("x_lower", "x_upper", "y_lower", "y_upper", "z_lower", "z_upper"), g["tight"].tolist()))
+    assert f.get_inst_num() == 4
+    for key, got in (("pcd_12_box", f.extract_masked_pcd([1, 2], boundaries=box)), ("pcd_3_none", f.extract_masked_pcd([3])),
+                     ("pcd_123_tight", f.extract_masked_pcd([1, 2, 3], boundaries=tight)), ("pcd_123_none", f.extract_masked_pcd([1, 2, 3])),
+                     ("view2_2_box", f.extract_masked_pcd_in_views([2], [2], box, downsample=False)),
+                     ("view0_13_tight", f.extract_masked_pcd_in_views([1, 3], [0], tight, downsample=False))):
+        assert got.dtype == np.float64 and got.shape == g[key].shape, (key, got.shape, g[key].shape)
+        assert np.abs(got - g[key]).max() <= 1e-12, key
+    q = f.get_query_obj_pcd()
+    assert np.abs(np.asarray(q.points) - g["pcd_123_none"]).max() <= 1e-12 and np.asarray(q.colors).shape == g["pcd_123_none"].shape
+    with pytest.raises(AssertionError):
+        f.extract_masked_pcd_in_views([1], [0, 1], box)
+
+
+def test_voxel_downsample_matches_open3d_definition(dev):
+    """d3f_voxel_downsample against open3d's published VoxelDownSample algorithm restated in numpy (oracle/np_pcd.voxel_mean;
+    open3d itself is not installable here): same voxels in ascending voxel order, means to 1e-12; deterministic; and the
+    reference's default path extract_masked_pcd_in_views(downsample=True) = that filter over the undownsampled cloud."""
+    from d3fields_amd import pcd_utils, synth
+    from oracle import np_pcd
+    rng = np.random.default_rng(3)
+    pts = np.concatenate([rng.normal(0.0, 0.05, (20000, 3)), rng.uniform(-0.3, 0.3, (5000, 3)), np.full((7, 3), 0.1234)])
+    col = rng.random(pts.shape)
+    want_p, want_c = np_pcd.voxel_mean(pts, 0.01, col)
+    got_p, got_c = pcd_utils.voxel_downsample(pts, 0.01, col)
+    assert got_p.shape == want_p.shape and np.abs(got_p - want_p).max() <= 1e-12 and np.abs(got_c - want_c).max() <= 1e-12
+    again_p, again_c = pcd_utils.voxel_downsample(pts, 0.01, col)
+    assert np.array_equal(again_p, got_p) and np.array_equal(again_c, got_c)               # exact sums: deterministic
+    only = pcd_utils.voxel_downsample(pts[:100], 0.05)
+    assert np.abs(only - np_pcd.voxel_mean(pts[:100], 0.05)).max() <= 1e-12
+    assert pcd_utils.voxel_downsample(np.zeros((0, 3)), 0.01).shape == (0, 3)
+    g, f = _masked_fusion(dev)
+    box = dict(synth.WORK_BOX)
+    full = f.extract_masked_pcd_in_views([2], [2], box, downsample=False)
+    down = f.extract_masked_pcd_in_views([2], [2], box)                                   # the reference's default: downsample=True
+    assert 0 < down.shape[0] < full.shape[0] and np.abs(down - np_pcd.voxel_mean(full, 0.01)).max() <= 1e-12
+    cloud = pcd_utils.aggr_point_cloud_from_data(g["color"], g["depth"].astype(np.float64), g["K"].astype(np.float64),
+                                                 np.concatenate([g["pose"], np.tile(np.array([[[0, 0, 0, 1.0]]]), (4, 1, 1))], 1).astype(np.float64))
+    assert len(np.asarray(cloud.points)) > 0 and np.asarray(cloud.colors).shape == np.asarray(cloud.points).shape   # defaults: downsample, o3d-like

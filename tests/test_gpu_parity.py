@@ -407,15 +407,16 @@ def test_point_order_probe_and_unordered_walk(dev):
         assert rel_err(cpu(got[k]), ref["sets"][s_]) <= TOL
 
 
-@pytest.mark.parametrize("use_graph", [False, True, "autograd"])
+@pytest.mark.parametrize("use_graph", [False, True, "five launches", "autograd"])
 def test_rigid_tracking_matches_reference(dev, use_graph):
-    """Fusion.rigid_tracking (100 Adam steps through d3f_eval / d3f_eval_backward; eager launches or one HIP graph
-    replayed) against the keypoints the REFERENCE's loop returned (golden 'rigid_tracking'): measured agreement
-    3e-8 m (eager) / 4.5e-8 m (graph) on positions that move 1-15 mm; tolerance 1e-5 m."""
+    """Fusion.rigid_tracking (100 Adam steps; eager autograd through d3f_eval / d3f_eval_backward, the closed-form HIP step as
+    one launch (d3f_track_step) or as five, or the autograd step graph-replayed) against the keypoints the REFERENCE's loop
+    returned (golden 'rigid_tracking'): measured agreement 3e-8 m on positions that move 1-15 mm; tolerance 1e-5 m."""
     g = load_golden("rigid_tracking")
     f = make_fusion(dev, g["depth"], g["K"], g["pose"], {"dino_feats": g["in_dino_feats"]}, g["H"], g["W"], float(g["mu"]))
     f.use_hip_graph = bool(use_graph)
-    f.fused_tracking = use_graph is True        # True: five-launch HIP step; "autograd": the autograd step, graph-replayed
+    f.fused_tracking = use_graph in (True, "five launches")     # the closed-form HIP step; "autograd": the autograd step, graph-replayed
+    f.single_launch_tracking = use_graph is True
     n = int(g["n"])
     info = {"a": {"src_feats": torch.from_numpy(g["src_feats"][:n])}, "b": {"src_feats": torch.from_numpy(g["src_feats"][n:])}}
     res = f.rigid_tracking(info, [p for p in g["last_pts"]], None, n)
@@ -424,6 +425,8 @@ def test_rigid_tracking_matches_reference(dev, use_graph):
     err = np.abs(got - g["match_pts"]).max()
     assert err <= 1e-5, err
     assert np.abs(got - g["true_pts"]).max() < 0.5 * np.abs(g["last_pts"] - g["true_pts"]).max()
+    if use_graph is True:
+        assert f._tracker.single, "the one-launch step must be what ran"
     if use_graph:
         # the captured iteration is kept for the sequence: a second frame (other start points, shifted cameras) replays
         # it on fresh inputs and must equal the eager loop; then the first frame again
@@ -1051,8 +1054,14 @@ def test_fps_matches_reference(dev):
     _, ib, db = fps(big, 50, init_idx=0)
     io, do = O.fps(big, 50, 0)
     assert ib == io.tolist() and db == do
-    ps, isel, _ = fps(big[:10], 64, init_idx=3)                                   # cloud smaller than the request
-    assert len(isel) == 10 and sorted(isel) == list(range(10))
+    ps, isel, md = fps(big[:10], 64, init_idx=3)                                  # cloud smaller than the request: fps_np does not
+    io, do = O.fps(big[:10], 64, 3)                                               # stop at n, it appends index 0 (distance 0 everywhere)
+    assert len(isel) == 64 and isel == io.tolist() and sorted(set(isel)) == list(range(10)) and isel[10:] == [0] * 54 and md == do == 0.0
+    # more workgroups than one, a ragged last chunk, exact ties (duplicated points): first maximum wins
+    tied = np.tile(big[:1000], (301, 1))[:300017]
+    _, it2, dt2 = fps(tied, 40, init_idx=5)
+    io2, do2 = O.fps(tied, 40, 5)
+    assert it2 == io2.tolist() and dt2 == do2
 
 
 def test_select_features_rand_matches_reference(dev):
@@ -1125,8 +1134,14 @@ def test_pcd_utils_match_reference(dev):
     K = g["K"][1]
     fg = pcd_utils.depth2fgpcd(g["depths"][1], g["masks"][1], [K[0, 0], K[1, 1], K[0, 2], K[1, 2]])
     assert fg.shape == g["fg_view1"].shape and np.allclose(fg, g["fg_view1"], rtol=0, atol=1e-13)
-    with pytest.raises(NotImplementedError):
-        pcd_utils.aggr_point_cloud_from_data(g["colors"], g["depths"], g["K"], g["pose44"])
+    # the reference's DEFAULT arguments (downsample=True, out_o3d=True): a point-cloud object holding the per-view 1-cm
+    # voxel-grid means (open3d's voxel_down_sample restated: tests/test_gpu_callers.py::test_voxel_downsample_...)
+    from oracle import np_pcd
+    cloud = pcd_utils.aggr_point_cloud_from_data(g["colors"], g["depths"], g["K"], g["pose44"])
+    per_view = [pcd_utils.aggr_point_cloud_from_data(g["colors"][v:v + 1], g["depths"][v:v + 1], g["K"][v:v + 1], g["pose44"][v:v + 1],
+                                                     downsample=False, out_o3d=False)[0] for v in range(g["depths"].shape[0])]
+    want = np.concatenate([np_pcd.voxel_mean(p, 0.01) for p in per_view], axis=0)
+    assert np.abs(np.asarray(cloud.points) - want).max() <= 1e-12
 
 
 def test_pcd_iou_matches_reference(dev):
