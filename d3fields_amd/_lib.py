@@ -112,6 +112,8 @@ SIGNATURES = {
     "d3f_pairwise_topk_workspace_bytes": (_i64, [_i64, _i64]),
     "d3f_pairwise_similarity_topk": (ctypes.c_int, [_vp, _vp, _i64, _i64, _i32, _f32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _i64,
                                                     _vp]),
+    "d3f_topk_smallest": (ctypes.c_int, [_vp, _i64, _i64, _i32, _vp, _vp, _vp, _i64, _vp]),
+    "d3f_topk_merge": (ctypes.c_int, [_vp, _vp, _i64, _i32, _i64, _vp, _vp, _vp]),
     "d3f_pairwise_softmax_local": (ctypes.c_int, [_vp, _vp, _i64, _i64, _i32, _f32, _i32, _i64, _vp, _vp, _vp, _i64,
                                                   _vp]),
     "d3f_point_order_locality": (ctypes.c_int, [_vp, _i64, _vp, _vp]),

@@ -534,4 +534,44 @@ hipError_t launch_topk_write(const void *final_list, const float *x, int64_t row
     return hipGetLastError();
 }
 
+// merge of per-rank k-nearest lists (rows sharded over ranks: sharding.sharded_knn_descriptors): per column the k best of
+// the n_parts * k candidates by (value ascending, GLOBAL row index ascending); entries with index < 0 are padding
+__global__ __launch_bounds__(kBlock) void topk_merge_parts_kernel(const int64_t *__restrict__ pidx, const float *__restrict__ pval, int64_t n_parts,
+                                                                 int k, int64_t cols, int64_t *__restrict__ out_idx, float *__restrict__ out_val)
+{
+    const int64_t col = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (col >= cols) return;
+    float bv[kTopK];
+    int64_t bi[kTopK];
+#pragma unroll
+    for (int j = 0; j < kTopK; ++j) { bv[j] = INFINITY; bi[j] = -1; }
+    auto before = [](float v, int64_t i, float ov, int64_t oi) { return oi < 0 || v < ov || (v == ov && i < oi); };
+    for (int64_t t = 0; t < n_parts * k; ++t) {
+        const int64_t i = pidx[t * cols + col];
+        if (i < 0) continue;
+        float v = pval[t * cols + col];
+        if (v != v) v = INFINITY;
+        if (!before(v, i, bv[kTopK - 1], bi[kTopK - 1])) continue;
+        bv[kTopK - 1] = v; bi[kTopK - 1] = i;
+#pragma unroll
+        for (int j = kTopK - 1; j > 0; --j)
+            if (before(bv[j], bi[j], bv[j - 1], bi[j - 1])) {
+                const float tv = bv[j - 1]; const int64_t ti = bi[j - 1];
+                bv[j - 1] = bv[j]; bi[j - 1] = bi[j]; bv[j] = tv; bi[j] = ti;
+            }
+    }
+    for (int j = 0; j < k; ++j) {
+        out_idx[(int64_t)j * cols + col] = bi[j];
+        if (out_val) out_val[(int64_t)j * cols + col] = bi[j] < 0 ? NAN : bv[j];
+    }
+}
+
+hipError_t launch_topk_merge_parts(const int64_t *pidx, const float *pval, int64_t n_parts, int k, int64_t cols, int64_t *out_idx,
+                                   float *out_val, hipStream_t s)
+{
+    hipLaunchKernelGGL(topk_merge_parts_kernel, dim3((unsigned)((cols + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, pidx, pval, n_parts, k, cols,
+                       out_idx, out_val);
+    return hipGetLastError();
+}
+
 }  // namespace d3f

@@ -1029,6 +1029,36 @@ int d3f_pairwise_similarity_topk(const float *src, const float *tgt, int64_t B1,
 
 static_assert(sizeof(d3f_col_stat) == sizeof(d3f::ColStat) && sizeof(d3f_col_stat) == 16, "d3f_col_stat layout");
 
+int d3f_topk_smallest(const float *x, int64_t rows, int64_t cols, int32_t k, int64_t *idx_out, float *val_out, void *workspace,
+                      int64_t workspace_bytes, void *stream)
+{
+    if (k < 1 || k > 8) return fail(D3F_ERR_INVALID_ARG, "topk_smallest: k=%d outside [1,8]", k);
+    if (rows < 0 || cols < 0 || rows > 0x7fffffffLL) return fail(D3F_ERR_BAD_SHAPE, "topk_smallest: rows=%lld cols=%lld", (long long)rows, (long long)cols);
+    if (cols == 0) return D3F_OK;
+    if (!idx_out || (rows > 0 && !x)) return fail(D3F_ERR_INVALID_ARG, "topk_smallest: NULL pointer");
+    if (rows > 0 && (!workspace || workspace_bytes < d3f::topk_workspace_bytes(rows, cols) || !aligned(workspace, 16)))
+        return fail(D3F_ERR_WORKSPACE, "topk_smallest: needs %lld bytes of 16-byte aligned workspace", (long long)d3f::topk_workspace_bytes(rows, cols));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const void *final_list = nullptr;
+    if (rows > 0) {
+        hipError_t e = d3f::launch_topk_select(x, rows, cols, workspace, &final_list, s);
+        if (e != hipSuccess) return hip_fail(e, "topk launch");
+    }
+    hipError_t e = d3f::launch_topk_write(final_list, x, rows, cols, k, idx_out, val_out, s);
+    return e == hipSuccess ? D3F_OK : hip_fail(e, "topk write launch");
+}
+
+int d3f_topk_merge(const int64_t *parts_idx, const float *parts_val, int64_t n_parts, int32_t k, int64_t cols, int64_t *out_idx,
+                   float *out_val, void *stream)
+{
+    if (k < 1 || k > 8) return fail(D3F_ERR_INVALID_ARG, "topk_merge: k=%d outside [1,8]", k);
+    if (n_parts < 0 || cols < 0) return fail(D3F_ERR_BAD_SHAPE, "topk_merge: n_parts=%lld cols=%lld", (long long)n_parts, (long long)cols);
+    if (cols == 0) return D3F_OK;
+    if (!out_idx || (n_parts > 0 && (!parts_idx || !parts_val))) return fail(D3F_ERR_INVALID_ARG, "topk_merge: NULL pointer");
+    hipError_t e = d3f::launch_topk_merge_parts(parts_idx, parts_val, n_parts, k, cols, out_idx, out_val, static_cast<hipStream_t>(stream));
+    return e == hipSuccess ? D3F_OK : hip_fail(e, "topk merge launch");
+}
+
 int d3f_pairwise_softmax_local(const float *src, const float *tgt, int64_t B1, int64_t B2, int32_t C, float scale,
                                int32_t dist_type, int64_t row_offset, float *out, d3f_col_stat *stats, void *workspace,
                                int64_t workspace_bytes, void *stream)

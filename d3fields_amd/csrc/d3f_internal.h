@@ -182,6 +182,9 @@ hipError_t launch_topk_select(const float *dist, int64_t rows, int64_t cols, voi
 hipError_t launch_topk_write(const void *final_list, const float *x, int64_t rows, int64_t cols, int k, int64_t *idx_out,
                              float *val_out, hipStream_t s);
 
+hipError_t launch_topk_merge_parts(const int64_t *pidx, const float *pval, int64_t n_parts, int k, int64_t cols, int64_t *out_idx,
+                                   float *out_val, hipStream_t s);
+
 // track_kernels.hip: the closed-form parts of the rigid-tracking optimiser step
 hipError_t launch_rigid_transform(const float *last, int I, int n, const float *t, const float *w, float eps, float *out_pts,
                                   float *norms, hipStream_t s);

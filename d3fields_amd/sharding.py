@@ -15,7 +15,7 @@ import torch
 import torch.distributed as dist
 
 __all__ = ["shard_bounds", "shard_points", "all_gather_field", "gather_bytes", "sharded_eval", "broadcast_observation",
-           "sharded_similarity_multi"]
+           "sharded_similarity_multi", "sharded_knn_descriptors"]
 
 
 def _world(group=None):
@@ -205,6 +205,81 @@ class _HipSoftmaxKernels:
             _lib.check(_lib.load().d3f_softmax_apply(_lib.ptr(out), out.shape[0], out.shape[1], float(scale),
                                                      _lib.ptr(merged), _lib.current_stream_handle(dev)))
         return out
+
+
+class _HipTopkKernels:
+    """Device steps of the row-sharded k-NN lookup: local k smallest per column, merge of the ranks' lists."""
+
+    @staticmethod
+    def local_topk(dist_local, k):
+        from . import _lib
+        lib = _lib.load()
+        dev = dist_local.device
+        rows, cols = dist_local.shape
+        idx = torch.empty((k, cols), dtype=torch.int64, device=dev)
+        val = torch.empty((k, cols), dtype=torch.float32, device=dev)
+        ws_bytes = lib.d3f_pairwise_topk_workspace_bytes(rows, cols)
+        ws = torch.empty(max(ws_bytes, 16), dtype=torch.uint8, device=dev)
+        with torch.cuda.device(dev):
+            _lib.check(lib.d3f_topk_smallest(_lib.ptr(dist_local), rows, cols, k, _lib.ptr(idx), _lib.ptr(val), _lib.ptr(ws), ws_bytes,
+                                             _lib.current_stream_handle(dev)))
+        return idx, val
+
+    @staticmethod
+    def merge_topk(parts_idx, parts_val, k):
+        from . import _lib
+        dev = parts_idx.device
+        P, _, cols = parts_idx.shape
+        idx = torch.empty((k, cols), dtype=torch.int64, device=dev)
+        val = torch.empty((k, cols), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            _lib.check(_lib.load().d3f_topk_merge(_lib.ptr(parts_idx), _lib.ptr(parts_val), P, k, cols, _lib.ptr(idx), _lib.ptr(val),
+                                                  _lib.current_stream_handle(dev)))
+        return idx, val
+
+
+def sharded_knn_descriptors(src_local, tgt_feats, k, scale=1.0, dist_type="l2", row_offset=None, group=None, kernels=None, topk=None):
+    """corr_utils.knn_descriptors with the B1 source descriptors sharded over ranks (the multi-GPU form of the k-NN lookup,
+    as sharded_similarity_multi is of nearest_descriptor).  Every rank selects the k nearest of ITS rows per target column
+    on the raw distances, the ranks exchange those [k,B2] lists (k * 12 bytes per column) next to the softmax column
+    records, and every rank merges them by (distance, global row).  Returns (similarity rows of this rank [B1_local,B2],
+    index [k,B2] int64 GLOBAL rows (-1 where fewer than k rows exist), distance [k,B2] float32 of those rows).
+    `kernels` / `topk` replace the HIP steps in the CPU plumbing tests (gloo)."""
+    from .corr_utils import _dist_code
+    if not 1 <= int(k) <= 8:
+        raise ValueError("k must be in [1, 8]")
+    k = int(k)
+    code = _dist_code(dist_type)
+    rank, world = _world(group)
+    ks = kernels if kernels is not None else _HipSoftmaxKernels
+    kt = topk if topk is not None else _HipTopkKernels
+    assert src_local.dim() == 2 and tgt_feats.dim() == 2 and src_local.shape[1] == tgt_feats.shape[1]
+    if kernels is None and not src_local.is_cuda:
+        raise RuntimeError("src_local must be on the ROCm device; there is no CPU path")
+    src_local = src_local.to(torch.float32).contiguous()
+    tgt_feats = tgt_feats.to(device=src_local.device, dtype=torch.float32).contiguous()
+    if row_offset is None:
+        row_offset = 0
+        if world > 1:
+            c = torch.tensor([src_local.shape[0]], dtype=torch.int64, device=src_local.device)
+            allc = torch.empty(world, dtype=torch.int64, device=c.device)
+            dist.all_gather_into_tensor(allc, c, group=group)
+            row_offset = int(allc[:rank].sum())
+    out, stats = ks.local(src_local, tgt_feats, scale, code, row_offset)             # out: this rank's raw distances
+    lidx, lval = kt.local_topk(out, k)
+    lidx = torch.where(lidx >= 0, lidx + int(row_offset), lidx)                       # local rows -> global rows
+    if world > 1:
+        parts = stats.new_empty((world,) + tuple(stats.shape))
+        dist.all_gather_into_tensor(parts.view(world * stats.shape[0], 16), stats, group=group)
+        pidx = lidx.new_empty((world,) + tuple(lidx.shape))
+        pval = lval.new_empty((world,) + tuple(lval.shape))
+        dist.all_gather_into_tensor(pidx.view(world * k, -1), lidx, group=group)
+        dist.all_gather_into_tensor(pval.view(world * k, -1), lval, group=group)
+    else:
+        parts, pidx, pval = stats.unsqueeze(0), lidx.unsqueeze(0), lval.unsqueeze(0)
+    merged, _ = ks.merge(parts)
+    gidx, gval = kt.merge_topk(pidx.contiguous(), pval.contiguous(), k)
+    return ks.apply(out, scale, merged), gidx, gval
 
 
 def sharded_similarity_multi(src_local, tgt_feats, scale, dist_type="l2", row_offset=None, group=None, kernels=None):

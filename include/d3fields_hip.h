@@ -357,6 +357,17 @@ int d3f_pairwise_similarity_topk(const float *src, const float *tgt, int64_t B1,
                                  int32_t dist_type, int32_t mode, int32_t k, float *out, int64_t *topk_idx,
                                  float *topk_val, void *workspace, int64_t workspace_bytes, void *stream);
 
+/* The two halves of the k-NN lookup for ROW-SHARDED sources (d3fields_amd/sharding.py: sharded_knn_descriptors):
+ *   d3f_topk_smallest  per column of a [rows, cols] matrix (a rank's raw distances) the rows of the k smallest entries (ties ->
+ *                      lower row, NaN last): idx_out [k,cols] int64 (-1 where rows < k), val_out [k,cols] or NULL;
+ *                      workspace >= d3f_pairwise_topk_workspace_bytes(rows, cols), 16-byte aligned.
+ *   d3f_topk_merge     n_parts such lists (indices already GLOBAL rows) -> the k best per column by (value, index);
+ *                      parts_idx / parts_val [n_parts, k, cols]; entries with index < 0 are padding. */
+int d3f_topk_smallest(const float *x, int64_t rows, int64_t cols, int32_t k, int64_t *idx_out, float *val_out,
+                      void *workspace, int64_t workspace_bytes, void *stream);
+int d3f_topk_merge(const int64_t *parts_idx, const float *parts_val, int64_t n_parts, int32_t k, int64_t cols,
+                   int64_t *out_idx, float *out_val, void *stream);
+
 /* ---- the same softmax with B1 sharded over GPUs -------------------------------
  * softmax(dim=0) of compute_similarity_tensor_multi (corr_utils.py:102) couples all B1 rows.  With the
  * rows split over ranks each rank runs

@@ -312,3 +312,32 @@ def test_window_launch_plan(monkeypatch):
         monkeypatch.setenv("D3F_EXP_WINDOW", "128")
         p = _plan(8, 720, 1280, 1000000, [(72, 128, 1024)], flags=_lib.FLAG_FINITE_MAPS | _lib.FLAG_UNORDERED_POINTS)
         assert p.staged[0] == 3 and p.reserved == 2123 and p.lds_bytes <= 160 * 1024 // 3    # 32 KB of records for 128 x 8 pairs: 3 workgroups per CU
+
+
+def test_plan_table():
+    """One row per launch-plan threshold of d3f_api.hip (kSmallBatch, kCacheResidentBytes, kBatchedLoadBytes, kBeyondLlcBytes):
+    the plan on either side of each boundary, from d3f_eval_plan_query alone."""
+    F = _lib.FLAG_FINITE_MAPS
+
+    def one_map(nbytes):                        # one view, 64 channels (256-byte texels), 1024 texels per row
+        return [(nbytes // 256 // 1024, 1024, 64)]
+
+    # kSmallBatch = 65536 points: below it nothing is reordered, whatever the maps and the scratch
+    assert _plan(1, 480, 640, 65535, one_map(200 << 20), F).reorder == 0
+    assert _plan(1, 480, 640, 65536, one_map(200 << 20), F).reorder == 1
+    # kCacheResidentBytes = 64 MiB of maps: at most that -> caller order with 128-point tiles; more (with scratch) -> Morton walk
+    p = _plan(1, 480, 640, 200000, one_map(64 << 20), F)
+    assert (p.reorder, p.tile_points) == (0, 128)
+    p = _plan(1, 480, 640, 200000, one_map((64 << 20) + (256 << 10)), F)
+    assert (p.reorder, p.tile_points) == (1, 16)
+    assert _plan(1, 480, 640, 200000, one_map((64 << 20) + (256 << 10)), F, ws=0).reorder == 0      # no scratch, no sort
+    # kBatchedLoadBytes = 128 MiB per map: batched corner loads up to it, load-use per vector beyond (caller order)
+    assert _plan(1, 480, 640, 200000, one_map(128 << 20), F, ws=0).vectors_per_lane[0] == 1
+    assert _plan(1, 480, 640, 200000, one_map((128 << 20) + (256 << 10)), F, ws=0).vectors_per_lane[0] == -1
+    # kBeyondLlcBytes = 512 MiB of maps in caller order without scratch: 64-point tiles at 2 workgroups per CU (64 KiB LDS pad)
+    p = _plan(1, 480, 640, 200000, one_map(512 << 20), F, ws=0)
+    assert p.tile_points == 128 and p.lds_bytes < 16 * 1024
+    p = _plan(1, 480, 640, 200000, one_map((512 << 20) + (256 << 10)), F, ws=0)
+    assert p.tile_points == 64 and p.lds_bytes > 64 * 1024
+    # D3F_TUNE_DIRECT_GATHER never changes the point order, only the gather
+    assert _plan(1, 480, 640, 200000, one_map((64 << 20) + (256 << 10)), F | _lib.TUNE_DIRECT_GATHER).reorder == 1

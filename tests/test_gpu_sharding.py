@@ -60,6 +60,10 @@ def _worker(rank, world, port, q):
         ref, ref_am = corr_utils.nearest_descriptor(single["dino_feats"], tgt, 0.8)
         err = float((sim - ref[lo:hi]).abs().max())
         ok_sim = err <= 1e-6 and torch.equal(am, ref_am) and int(am[5]) == 60000
+        # ... and the k-NN form: the ranks' [k,B2] lists merged by (distance, global row) == the single-process lookup
+        sim_k, gidx, gval = sharding.sharded_knn_descriptors(single["dino_feats"][lo:hi].contiguous(), tgt, 5, 0.8, row_offset=lo)
+        _, ref_idx, _ = corr_utils.knn_descriptors(single["dino_feats"], tgt, 5, 0.8)
+        ok_sim = ok_sim and torch.equal(gidx, ref_idx) and torch.equal(gidx[0], ref_am) and float((sim_k - ref[lo:hi]).abs().max()) <= 1e-6
         q.put((rank, bool(ok), bool(ok_sim), err))
     finally:
         dist.destroy_process_group()

@@ -118,6 +118,35 @@ class _NumpySoftmaxKernels:
         return torch.from_numpy((np.exp(-out.numpy() * np.float32(scale) - rec["m"]) / rec["s"]).astype(np.float32))
 
 
+class _NumpyTopkKernels:
+    """Stand-in for the two HIP steps of sharded_knn_descriptors (d3f_topk_smallest / d3f_topk_merge)."""
+
+    @staticmethod
+    def local_topk(dist_local, k):
+        d = dist_local.numpy()
+        rows, cols = d.shape
+        idx = np.full((k, cols), -1, np.int64)
+        val = np.full((k, cols), np.nan, np.float32)
+        for c in range(cols):
+            order = np.lexsort((np.arange(rows), d[:, c]))[:k]            # value ascending, ties -> lower row
+            idx[:len(order), c] = order
+            val[:len(order), c] = d[order, c]
+        return torch.from_numpy(idx), torch.from_numpy(val)
+
+    @staticmethod
+    def merge_topk(parts_idx, parts_val, k):
+        pi, pv = parts_idx.numpy().reshape(-1, parts_idx.shape[-1]), parts_val.numpy().reshape(-1, parts_val.shape[-1])
+        cols = pi.shape[1]
+        idx = np.full((k, cols), -1, np.int64)
+        val = np.full((k, cols), np.nan, np.float32)
+        for c in range(cols):
+            live = pi[:, c] >= 0
+            order = np.lexsort((pi[live, c], pv[live, c]))[:k]
+            idx[:len(order), c] = pi[live, c][order]
+            val[:len(order), c] = pv[live, c][order]
+        return torch.from_numpy(idx), torch.from_numpy(val)
+
+
 def _sim_worker(rank, world, port, b1, q):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -135,7 +164,19 @@ def _sim_worker(rank, world, port, b1, q):
             sim, am = sharding.sharded_similarity_multi(src[lo:hi], tgt, 2.0, dt, kernels=_NumpySoftmaxKernels)
             ref, ref_am = O.pairwise(src.numpy(), tgt.numpy(), 2.0, dt, mode="softmax", return_argmax=True)
             err = float(np.abs(sim.numpy() - ref[lo:hi]).max()) if hi > lo else 0.0
-            res[dt] = (tuple(sim.shape), err, bool(np.array_equal(am.numpy(), ref_am)))
+            # the k-NN form: every rank ends with the same global [k,B2] lists = numpy's lexsort over ALL rows
+            k = 3
+            sim_k, gidx, gval = sharding.sharded_knn_descriptors(src[lo:hi], tgt, k, 2.0, dt, kernels=_NumpySoftmaxKernels, topk=_NumpyTopkKernels)
+            dall = O.pairwise(src.numpy(), tgt.numpy(), 2.0, dt, mode="dist")
+            want = np.full((k, tgt.shape[0]), -1, np.int64)
+            for c in range(tgt.shape[0]):
+                order = np.lexsort((np.arange(b1), dall[:, c]))[:k]
+                want[:len(order), c] = order
+            knn_ok = bool(np.array_equal(gidx.numpy(), want)) and bool(np.array_equal(gidx.numpy()[0], ref_am)) and \
+                float(np.abs(sim_k.numpy() - ref[lo:hi]).max() if hi > lo else 0.0) <= 1e-6
+            live = want >= 0
+            knn_ok = knn_ok and bool(np.allclose(gval.numpy()[live], np.take_along_axis(dall, np.maximum(want, 0), 0)[live], rtol=0, atol=0))
+            res[dt] = (tuple(sim.shape), err, bool(np.array_equal(am.numpy(), ref_am)) and knn_ok)
         q.put((rank, res, (lo, hi)))
     finally:
         dist.destroy_process_group()
