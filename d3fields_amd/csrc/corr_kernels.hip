@@ -5,6 +5,8 @@
 // Here the difference never leaves registers: distances use the DIRECT form sum((a-b)^2) -- not
 // |a|^2+|b|^2-2ab, whose cancellation breaks 1e-5 relative parity for near-identical
 // descriptors -- so this is fp32 VALU work staged through LDS, not an MFMA contraction.
+#include <type_traits>
+
 #include "d3f_internal.h"
 #include "d3f_device.h"
 
@@ -79,22 +81,23 @@ __device__ __forceinline__ void merge_stat(float &m, float &s, int64_t &arg, flo
 // every lane's two float4 loads per operand and stage go through a uniform base + a loop-invariant 32-bit offset,
 // with rows beyond the matrix clamped to the last row (their results are never stored), so the fetch costs no
 // per-element bounds or address arithmetic -- the generic path spent 22 % of its VALU instructions there.
-template <bool FAST>
-__global__ __launch_bounds__(kBlock) void pairwise_dist_kernel(const float *__restrict__ src,
-                                                              const float *__restrict__ tgt, int64_t B1, int64_t B2,
-                                                              int C, int dist_type, float *__restrict__ out,
-                                                              ColStat *__restrict__ ws, float stat_scale)
+// NW: 16-column groups of the tile that hold live columns (4 everywhere but in the last column tile of a B2 that is
+// not a multiple of 64: B2 = 300 leaves 44 columns = 3 groups there, and the dead group's 1/4 of the tile's arithmetic
+// -- 5 % of the whole launch -- is skipped instead of computed and dropped).
+template <bool FAST, int NW>
+__device__ __forceinline__ void pairwise_dist_body(const float *__restrict__ src, const float *__restrict__ tgt, int64_t B1,
+                                                   int64_t B2, int C, int dist_type, float *__restrict__ out,
+                                                   ColStat *__restrict__ ws, float stat_scale, f32x4 (&As)[kPK / 4][kPT],
+                                                   f32x4 (&Bs)[kPK / 4][kPT])
 {
-    __shared__ f32x4 As[kPK / 4][kPT];
-    __shared__ f32x4 Bs[kPK / 4][kPT];
     const int64_t i0 = (int64_t)blockIdx.y * kPT, j0 = (int64_t)blockIdx.x * kPT;
     const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
     const bool vec_ok = (C % 4 == 0) && ((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(tgt)) % 16 == 0);
-    f32x2 acc[4][4];
+    f32x2 acc[4][NW];
 #pragma unroll
     for (int q = 0; q < 4; ++q)
 #pragma unroll
-        for (int w = 0; w < 4; ++w) acc[q][w] = (f32x2)0.0f;
+        for (int w = 0; w < NW; ++w) acc[q][w] = (f32x2)0.0f;
 
     // software pipeline: the next stage's global loads are issued (into registers) before the current stage
     // is consumed; lane -> (row, k/4) pairs e = tid, tid + 256 of the 64 x 8 float4 stage
@@ -149,26 +152,25 @@ __global__ __launch_bounds__(kBlock) void pairwise_dist_kernel(const float *__re
         if (k0 + kPK < C) fetch(k0 + kPK);
 #pragma unroll
         for (int k4 = 0; k4 < kPK / 4; ++k4) {
-            f32x4 a[4], b[4];
+            f32x4 a[4], b[NW];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                a[q] = As[k4][ty + 16 * q];
-                b[q] = Bs[k4][tx + 16 * q];
-            }
+            for (int q = 0; q < 4; ++q) a[q] = As[k4][ty + 16 * q];
+#pragma unroll
+            for (int w = 0; w < NW; ++w) b[w] = Bs[k4][tx + 16 * w];
             // per row q: the four differences first, then the even-pair FMAs, then the odd-pair FMAs, so the two
             // dependent v_pk_fma_f32 of one accumulator are four issue slots apart (back to back they cost an s_nop)
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                f32x4 d[4];
+                f32x4 d[NW];
 #pragma unroll
-                for (int w = 0; w < 4; ++w) d[w] = a[q] + b[w];               // b holds -tgt
+                for (int w = 0; w < NW; ++w) d[w] = a[q] + b[w];              // b holds -tgt
 #pragma unroll
-                for (int w = 0; w < 4; ++w) {
+                for (int w = 0; w < NW; ++w) {
                     const f32x2 lo = __builtin_shufflevector(d[w], d[w], 0, 1);
                     acc[q][w] = __builtin_elementwise_fma(lo, lo, acc[q][w]);
                 }
 #pragma unroll
-                for (int w = 0; w < 4; ++w) {
+                for (int w = 0; w < NW; ++w) {
                     const f32x2 hi = __builtin_shufflevector(d[w], d[w], 2, 3);
                     acc[q][w] = __builtin_elementwise_fma(hi, hi, acc[q][w]);
                 }
@@ -176,67 +178,87 @@ __global__ __launch_bounds__(kBlock) void pairwise_dist_kernel(const float *__re
         }
         __syncthreads();
     }
-    float dv[4][4];
+    // Epilogue, twice: FULL (every row and column of the tile's NW groups is inside the matrix -- all but the rim tiles;
+    // workgroup-uniform) stores and reduces without predicates.  The fast kernel addresses `out` with one 32-bit element
+    // offset per lane (B1*B2 < 2^31, host-checked) and the 16 outputs at uniform strides from it.
+    auto epilogue = [&](auto full_tag) {
+        constexpr bool FULL = decltype(full_tag)::value;
+        const int rows_left = (int)min((int64_t)kPT, B1 - i0) - ty, cols_left = (int)min((int64_t)kPT, B2 - j0) - tx;
+        float dv[4][NW];
+        const uint32_t o00 = FAST ? (uint32_t)(i0 + ty) * (uint32_t)B2 + (uint32_t)(j0 + tx) : 0u, rs = 16u * (uint32_t)B2;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int64_t i = i0 + ty + 16 * q;
+        for (int q = 0; q < 4; ++q)
 #pragma unroll
-        for (int w = 0; w < 4; ++w) {
-            const int64_t j = j0 + tx + 16 * w;
-            const float ssum = acc[q][w].x + acc[q][w].y;
-            dv[q][w] = dist_type == D3F_DIST_L2 ? sqrtf(ssum) : ssum;
-            if (i < B1 && j < B2) out[i * B2 + j] = dv[q][w];
-        }
-    }
-    if (!ws) return;                               // uniform
-    // Fused column statistics of softmax(-d*stat_scale, dim=0) over this tile's 64 rows (what softmax_stats_kernel
-    // would compute in a second pass over `out`): per lane its 4 rows in ascending order, then the 4 lane-rows of
-    // the wave by shuffles, then the 4 waves through LDS; ws[row tile][column].
-    ColStat *red = reinterpret_cast<ColStat *>(&As[0][0]);          // [4 waves][64 columns] = 4 KiB, stage buffer is free
+            for (int w = 0; w < NW; ++w) {
+                const float ssum = acc[q][w].x + acc[q][w].y;
+                dv[q][w] = dist_type == D3F_DIST_L2 ? sqrtf(ssum) : ssum;
+                if (FULL || (16 * q < rows_left && 16 * w < cols_left)) {
+                    if (FAST) out[o00 + q * rs + 16 * w] = dv[q][w];
+                    else out[(i0 + ty + 16 * q) * B2 + (j0 + tx + 16 * w)] = dv[q][w];
+                }
+            }
+        if (!ws) return;                               // uniform
+        // Fused column statistics of softmax(-d*stat_scale, dim=0) over this tile's 64 rows (what softmax_stats_kernel
+        // would compute in a second pass over `out`): per lane its 4 rows, then the 4 lane-rows of the wave by shuffles,
+        // then the 4 waves through LDS; ws[row tile][column].  The winning row travels as its index inside the tile.
+        ColStat *red = reinterpret_cast<ColStat *>(&As[0][0]);      // [4 waves][64 columns] = 4 KiB, stage buffer is free
 #pragma unroll
-    for (int w = 0; w < 4; ++w) {
-        // maximum over the wave's 16 rows of this column first (cheap fmax shuffles), then ONE expf per element
-        float v[4], m = -INFINITY;
+        for (int w = 0; w < NW; ++w) {
+            // maximum over the wave's 16 rows of this column first (cheap fmax shuffles), then ONE expf per element
+            float v[4], m = -INFINITY;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            v[q] = (i0 + ty + 16 * q < B1) ? -dv[q][w] * stat_scale : -INFINITY;
-            m = fmaxf(m, v[q]);                    // NaN rows are caught by the sum below
-        }
-        m = fmaxf(m, __shfl_xor(m, 16, 64));
-        m = fmaxf(m, __shfl_xor(m, 32, 64));
-        float sum = 0.0f;
-        int64_t arg = 0x7fffffffffffffffLL;
+            for (int q = 0; q < 4; ++q) {
+                v[q] = (FULL || 16 * q < rows_left) ? -dv[q][w] * stat_scale : -INFINITY;
+                m = fmaxf(m, v[q]);                    // NaN rows are caught by the sum below
+            }
+            m = fmaxf(m, __shfl_xor(m, 16, 64));
+            m = fmaxf(m, __shfl_xor(m, 32, 64));
+            float sum = 0.0f;
+            int arg = 0x7fffffff;
 #pragma unroll
-        for (int q = 3; q >= 0; --q) {
-            const int64_t i = i0 + ty + 16 * q;
-            if (i < B1) {
-                sum += expf(v[q] - m);             // exp(-inf - -inf) cannot occur: a live row makes m finite or NaN
-                if (v[q] == m) arg = i;            // descending q: the smallest row index wins
+            for (int q = 3; q >= 0; --q)
+                if (FULL || 16 * q < rows_left) {
+                    sum += expf(v[q] - m);             // exp(-inf - -inf) cannot occur: a live row makes m finite or NaN
+                    if (v[q] == m) arg = ty + 16 * q;  // descending q: the smallest row index wins
+                }
+            sum += __shfl_xor(sum, 16, 64);
+            sum += __shfl_xor(sum, 32, 64);
+            arg = min(arg, __shfl_xor(arg, 16, 64));
+            arg = min(arg, __shfl_xor(arg, 32, 64));
+            if ((threadIdx.x & 63) < 16) {
+                ColStat o;
+                o.m = m; o.s = sum; o.arg = arg == 0x7fffffff ? 0x7fffffffffffffffLL : i0 + arg;
+                red[(threadIdx.x >> 6) * kPT + tx + 16 * w] = o;
             }
         }
-        sum += __shfl_xor(sum, 16, 64);
-        sum += __shfl_xor(sum, 32, 64);
+        __syncthreads();
+        if (threadIdx.x < kPT && j0 + threadIdx.x < B2) {
+            ColStat t = red[threadIdx.x];
 #pragma unroll
-        for (int off = 16; off <= 32; off <<= 1) {
-            const int64_t a2 = __shfl_xor(arg, off, 64);
-            arg = a2 < arg ? a2 : arg;
+            for (int wv = 1; wv < kBlock / 64; ++wv) {
+                const ColStat u = red[wv * kPT + threadIdx.x];
+                merge_stat(t.m, t.s, t.arg, u.m, u.s, u.arg);
+            }
+            ws[(int64_t)blockIdx.y * B2 + j0 + threadIdx.x] = t;
         }
-        if ((threadIdx.x & 63) < 16) {
-            ColStat o;
-            o.m = m; o.s = sum; o.arg = arg;
-            red[(threadIdx.x >> 6) * kPT + tx + 16 * w] = o;
-        }
-    }
-    __syncthreads();
-    if (threadIdx.x < kPT && j0 + threadIdx.x < B2) {
-        ColStat t = red[threadIdx.x];
-#pragma unroll
-        for (int wv = 1; wv < kBlock / 64; ++wv) {
-            const ColStat u = red[wv * kPT + threadIdx.x];
-            merge_stat(t.m, t.s, t.arg, u.m, u.s, u.arg);
-        }
-        ws[(int64_t)blockIdx.y * B2 + j0 + threadIdx.x] = t;
-    }
+    };
+    if (FAST && B1 - i0 >= kPT && B2 - j0 >= 16 * NW) epilogue(std::true_type{});
+    else epilogue(std::false_type{});
+}
+
+// NWT: live 16-column groups of the LAST column tile (the other column tiles are full)
+template <bool FAST, int NWT>
+__global__ __launch_bounds__(kBlock) void pairwise_dist_kernel(const float *__restrict__ src,
+                                                              const float *__restrict__ tgt, int64_t B1, int64_t B2,
+                                                              int C, int dist_type, float *__restrict__ out,
+                                                              ColStat *__restrict__ ws, float stat_scale)
+{
+    __shared__ f32x4 As[kPK / 4][kPT];
+    __shared__ f32x4 Bs[kPK / 4][kPT];
+    if (NWT < 4 && blockIdx.x == gridDim.x - 1)          // uniform per workgroup
+        pairwise_dist_body<FAST, NWT>(src, tgt, B1, B2, C, dist_type, out, ws, stat_scale, As, Bs);
+    else
+        pairwise_dist_body<FAST, 4>(src, tgt, B1, B2, C, dist_type, out, ws, stat_scale, As, Bs);
 }
 
 // ws != nullptr: also writes the column statistics of softmax(-d*stat_scale, dim=0) per 64-row tile into
@@ -247,11 +269,17 @@ hipError_t launch_pairwise_dist(const float *src, const float *tgt, int64_t B1, 
     if (B1 == 0 || B2 == 0) return hipSuccess;
     dim3 grid((unsigned)((B2 + kPT - 1) / kPT), (unsigned)((B1 + kPT - 1) / kPT));
     const bool fast = (C % kPK == 0) && ((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(tgt)) % 16 == 0) &&
-                      B1 * (int64_t)C < (1LL << 30) && B2 * (int64_t)C < (1LL << 30);
-    if (fast)
-        hipLaunchKernelGGL(pairwise_dist_kernel<true>, grid, dim3(kBlock), 0, s, src, tgt, B1, B2, C, dist_type, out, ws, stat_scale);
-    else
-        hipLaunchKernelGGL(pairwise_dist_kernel<false>, grid, dim3(kBlock), 0, s, src, tgt, B1, B2, C, dist_type, out, ws, stat_scale);
+                      B1 * (int64_t)C < (1LL << 30) && B2 * (int64_t)C < (1LL << 30) && B1 * B2 < (1LL << 31);
+    const int tail_groups = (int)((B2 - (int64_t)(grid.x - 1) * kPT + 15) / 16);         // 1..4
+#define D3F_PAIRWISE(NWT_)                                                                                                      \
+    hipLaunchKernelGGL((pairwise_dist_kernel<true, NWT_>), grid, dim3(kBlock), 0, s, src, tgt, B1, B2, C, dist_type, out, ws, stat_scale)
+    if (!fast)
+        hipLaunchKernelGGL((pairwise_dist_kernel<false, 4>), grid, dim3(kBlock), 0, s, src, tgt, B1, B2, C, dist_type, out, ws, stat_scale);
+    else if (tail_groups == 1) D3F_PAIRWISE(1);
+    else if (tail_groups == 2) D3F_PAIRWISE(2);
+    else if (tail_groups == 3) D3F_PAIRWISE(3);
+    else D3F_PAIRWISE(4);
+#undef D3F_PAIRWISE
     return hipGetLastError();
 }
 
@@ -300,36 +328,60 @@ __global__ __launch_bounds__(kBlock) void softmax_stats_kernel(const float *__re
     ws[(int64_t)blockIdx.x * cols + j] = o;
 }
 
-// One WAVE per column: lanes stride over the row chunks, then a shuffle reduction merges the running
-// (max, sum-exp, first-argmax) triples.  (A lane-per-column loop over ~400 chunks was latency-bound: 0.16 ms
-// for 300 columns.)
+// Eight columns per 1024-lane workgroup: thread t owns column (t & 7) and every 128th row chunk from (t >> 3), so that
+// one wave load covers eight chunks x one 128-byte line (8 columns x 16 B); four chunks' loads are in flight per lane.
+// The 128 partial triples of a column are merged by shuffles (lanes 8, 16, 32 apart) and across the sixteen waves through
+// LDS, in a fixed order.  The kernel is a chain of memory round trips, so its time is the number of rounds: one wave per
+// column with the lanes striding over the chunks (64 different lines per wave load, no loads in flight together) took
+// 18.6 us for 1563 chunks x 300 columns; 256 lanes in this layout 16.3 us (13 rounds of four loads); 1024 lanes 4 rounds.
 
 // `in` [nchunks, cols] -> `out` [cols]; arg_offset shifts the winning row index (a rank's first global row when
 // the rows are sharded over GPUs; 0 otherwise).  nchunks == 0 writes the identity (-inf, 0, INT64_MAX).
-__global__ __launch_bounds__(kBlock) void softmax_merge_kernel(const ColStat *__restrict__ in, int64_t nchunks,
+constexpr int kMergeCols = 8, kMergeBlock = 1024;
+__global__ __launch_bounds__(kMergeBlock) void softmax_merge_kernel(const ColStat *__restrict__ in, int64_t nchunks,
                                                               int64_t cols, ColStat *__restrict__ out,
                                                               int64_t *__restrict__ argmax_out, int64_t arg_offset)
 {
-    const int lane = threadIdx.x & 63;
-    const int64_t j = (int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
-    if (j >= cols) return;                       // whole waves exit together
+    __shared__ ColStat red[kMergeBlock / 64][kMergeCols];
+    constexpr int kLanes = kMergeBlock / kMergeCols;             // chunk lanes per column: 128
+    const int cj = threadIdx.x & (kMergeCols - 1), cl = threadIdx.x >> 3;
+    const int64_t j = min((int64_t)blockIdx.x * kMergeCols + cj, cols - 1);      // a short last group repeats its last column
     float m = -INFINITY, s = 0.0f;
     int64_t arg = 0x7fffffffffffffffLL;
-    for (int64_t c = lane; c < nchunks; c += 64) {
+    int64_t c = cl;
+    for (; c + 3 * kLanes < nchunks; c += 4 * kLanes) {
+        ColStat t[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) t[u] = in[(c + u * kLanes) * cols + j];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) merge_stat(m, s, arg, t[u].m, t[u].s, t[u].arg);
+    }
+    for (; c < nchunks; c += kLanes) {
         const ColStat t = in[c * cols + j];
         merge_stat(m, s, arg, t.m, t.s, t.arg);
     }
-    for (int off = 32; off > 0; off >>= 1) {
+#pragma unroll
+    for (int off = kMergeCols; off < 64; off <<= 1) {
         const float m2 = __shfl_xor(m, off, 64), s2 = __shfl_xor(s, off, 64);
         const int64_t a2 = __shfl_xor(arg, off, 64);
         merge_stat(m, s, arg, m2, s2, a2);
     }
-    if (lane == 0) {
-        if (arg != 0x7fffffffffffffffLL) arg += arg_offset;
+    if ((threadIdx.x & 63) < kMergeCols) {
         ColStat o;
         o.m = m; o.s = s; o.arg = arg;
-        out[j] = o;
-        if (argmax_out) argmax_out[j] = arg;
+        red[threadIdx.x >> 6][cj] = o;
+    }
+    __syncthreads();
+    if (threadIdx.x < kMergeCols && (int64_t)blockIdx.x * kMergeCols + threadIdx.x < cols) {
+        ColStat t = red[0][threadIdx.x];
+#pragma unroll
+        for (int wv = 1; wv < kMergeBlock / 64; ++wv) {
+            const ColStat u = red[wv][threadIdx.x];
+            merge_stat(t.m, t.s, t.arg, u.m, u.s, u.arg);
+        }
+        if (t.arg != 0x7fffffffffffffffLL) t.arg += arg_offset;
+        out[j] = t;
+        if (argmax_out) argmax_out[j] = t.arg;
     }
 }
 
@@ -342,10 +394,58 @@ __global__ __launch_bounds__(kBlock) void softmax_apply_kernel(float *__restrict
     x[k] = expf(-x[k] * scale - t.m) / t.s;
 }
 
+// Four columns per lane (cols % 4 == 0, 16-byte aligned matrix): the launch stride is a multiple of cols / 4, so a lane
+// stays on its column quad -- its statistics are loaded once, the column index costs one 32-bit remainder per lane instead
+// of a 64-bit one per element -- and walks down the rows with four 16-byte loads in flight.  Same expression per element
+// as the scalar form (bit-identical).
+__global__ __launch_bounds__(kBlock) void softmax_apply_vec_kernel(f32x4 *__restrict__ x, int64_t quads, uint32_t cq,
+                                                                  float scale, const ColStat *__restrict__ fin)
+{
+    const uint32_t g = blockIdx.x * kBlock + threadIdx.x, stride = gridDim.x * kBlock;
+    const uint32_t c4 = (g % cq) * 4u;
+    float m[4], sum[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const ColStat st = fin[c4 + t];
+        m[t] = st.m;
+        sum[t] = st.s;
+    }
+    auto norm = [&](f32x4 v) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) v[t] = expf(-v[t] * scale - m[t]) / sum[t];
+        return v;
+    };
+    int64_t q = g;
+    for (; q + 3 * (int64_t)stride < quads; q += 4 * (int64_t)stride) {
+        f32x4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = x[q + u * (int64_t)stride];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) x[q + u * (int64_t)stride] = norm(v[u]);
+    }
+    for (; q < quads; q += stride) x[q] = norm(x[q]);
+}
+
+static void apply_launch(float *x, int64_t total, int64_t cols, float scale, const ColStat *fin, hipStream_t s)
+{
+    const int64_t cq = cols / 4;
+    if (cols % 4 == 0 && reinterpret_cast<uintptr_t>(x) % 16 == 0 && cq <= 4096) {
+        // workgroups: a multiple of cq (=> stride % cq == 0) near 2048 (8 per CU), never more than the quads need
+        const int64_t quads = total / 4;
+        int64_t groups = cq * std::max<int64_t>(1, 2048 / cq);
+        while (groups > cq && (groups - cq) * kBlock >= quads) groups -= cq;
+        hipLaunchKernelGGL(softmax_apply_vec_kernel, dim3((unsigned)groups), dim3(kBlock), 0, s, reinterpret_cast<f32x4 *>(x), quads,
+                           (uint32_t)cq, scale, fin);
+        return;
+    }
+    hipLaunchKernelGGL(softmax_apply_kernel, dim3((unsigned)((total + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, x, total, cols, scale,
+                       fin);
+}
+
 static void merge_launch(const ColStat *in, int64_t nchunks, int64_t cols, ColStat *out, int64_t *argmax_out,
                          int64_t arg_offset, hipStream_t s)
 {
-    hipLaunchKernelGGL(softmax_merge_kernel, dim3((unsigned)((cols + kBlock / 64 - 1) / (kBlock / 64))), dim3(kBlock), 0, s, in,
+    hipLaunchKernelGGL(softmax_merge_kernel, dim3((unsigned)((cols + kMergeCols - 1) / kMergeCols)), dim3(kMergeBlock), 0, s, in,
                        nchunks, cols, out, argmax_out, arg_offset);
 }
 
@@ -360,9 +460,7 @@ static hipError_t softmax_impl(float *x, int64_t rows, int64_t cols, float scale
         hipLaunchKernelGGL(softmax_stats_kernel, dim3((unsigned)nchunks, gx), dim3(kBlock), 0, s, x, rows, cols, scale, ws);
     merge_launch(ws, nchunks, cols, ws + nchunks * cols, argmax_out, 0, s);
     if (normalise) {
-        const int64_t total = rows * cols;
-        hipLaunchKernelGGL(softmax_apply_kernel, dim3((unsigned)((total + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, x,
-                           total, cols, scale, ws + nchunks * cols);
+        apply_launch(x, rows * cols, cols, scale, ws + nchunks * cols, s);
     }
     return hipGetLastError();
 }
@@ -395,8 +493,7 @@ hipError_t launch_softmax_apply(float *x, int64_t rows, int64_t cols, float scal
 {
     const int64_t total = rows * cols;
     if (total == 0) return hipSuccess;
-    hipLaunchKernelGGL(softmax_apply_kernel, dim3((unsigned)((total + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, x, total, cols,
-                       scale, merged);
+    apply_launch(x, total, cols, scale, merged, s);
     return hipGetLastError();
 }
 

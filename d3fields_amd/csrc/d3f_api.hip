@@ -450,9 +450,11 @@ int eval_common(const d3f_views *views, const float *pts, int64_t n, const d3f_c
         int sl = exp_knob("D3F_EXP_SLICED");
         bool thin_rest = true;
         for (int s = 1; s < n_maps; ++s) thin_rest = thin_rest && P.maps[s].C * P.maps[s].esize <= 256 && P.maps[s].esize == 4;
-        const bool automatic = sl == 0 && thin_rest && n_maps >= 1 && P.maps[0].C % 128 == 0 && P.maps[0].C <= 512;
+        const bool automatic = sl == 0 && thin_rest && n_maps >= 1 && P.maps[0].C % 128 == 0 && P.maps[0].C <= 1024;
         if (automatic) sl = 3;
-        bool ok = walk && !window && !direct && (sl >= 1 && sl <= 3) && mode == 0 && n_maps >= 1 && P.maps[0].esize == 4 && P.maps[0].vw == 4 &&
+        // ... or the Morton order of a cloud on maps beyond the caches (tiles of 16 / 32 consecutive points of the order)
+        const bool cloud = reorder && !walk && !any_runs && map_bytes > kCacheResidentBytes && exp_knob("D3F_EXP_SLICED_CLOUD") >= 0;
+        bool ok = (walk || cloud) && !window && !direct && (sl >= 1 && sl <= 3) && mode == 0 && n_maps >= 1 && P.maps[0].esize == 4 && P.maps[0].vw == 4 &&
                   !want_inter[0] && tl == 0;
         const int lg = sl + 2, lanes = 1 << lg;      // 1: 8 lanes (128-byte slices), 2: 16 lanes, 3: 32 lanes (512 bytes)
         P.sl_vc = exp_knob("D3F_EXP_SLICED_VC") > 0 ? exp_knob("D3F_EXP_SLICED_VC") : (automatic ? 2 : 4);
@@ -466,11 +468,16 @@ int eval_common(const d3f_views *views, const float *pts, int64_t n, const d3f_c
             P.walk_tx = 2; P.walk_ty = mini ? 1 : 2; P.walk_tz = big ? 4 : ((tiny || mini) ? 1 : 2);
             P.sl_lg = lg;
             P.sl_slices = P.maps[0].C / (4 * lanes);
-            P.sl_tiles = (int64_t)((P.walk_nx + 1) / 2) * ((P.walk_ny + P.walk_ty - 1) / P.walk_ty) * ((P.walk_nz + P.walk_tz - 1) / P.walk_tz);
-            P.sl_groups = (P.sl_tiles + 3) / 4;
+            P.tile_pts = big ? 64 : (tiny ? 16 : (mini ? 8 : 32)); P.lds_pad = exp_knob("D3F_EXP_SLICED_PAD") > 0 ? exp_knob("D3F_EXP_SLICED_PAD") * 1024 : 0;
+            if (walk) {
+                P.sl_tiles = (int64_t)((P.walk_nx + 1) / 2) * ((P.walk_ny + P.walk_ty - 1) / P.walk_ty) * ((P.walk_nz + P.walk_tz - 1) / P.walk_tz);
+                P.sl_groups = (P.sl_tiles + 3) / 4;
+            } else {
+                P.sl_tiles = 0;
+                P.sl_groups = (n + P.tile_pts - 1) / P.tile_pts;
+            }
             P.sl_unit = exp_knob("D3F_EXP_SLICED_UNIT") > 0 ? exp_knob("D3F_EXP_SLICED_UNIT") : (big ? 64 : (tiny ? 256 : (mini ? 512 : 128)));   // 4096 points per unit (smaller: slower)
             P.sl_chunks = (P.sl_groups + P.sl_unit - 1) / P.sl_unit;
-            P.tile_pts = big ? 64 : (tiny ? 16 : (mini ? 8 : 32)); P.lds_pad = exp_knob("D3F_EXP_SLICED_PAD") > 0 ? exp_knob("D3F_EXP_SLICED_PAD") * 1024 : 0;
             for (int s = 1; s < n_maps; ++s) pick_mapping(P.maps[s], P.maps[s].vw == 4, P.maps[s].vw >= 2, true, 1);
             if (((P.sl_chunks * P.sl_slices + 7) / 8) * 8 * P.sl_unit > 0x7fffffffLL) P.sl_slices = 0;
         }

@@ -350,9 +350,10 @@ __device__ __forceinline__ void fused_eval_sliced_body(const EvalParams &P)
     if (unit >= (int64_t)P.sl_chunks * P.sl_slices) return;
     const int64_t chunk = unit / P.sl_slices;
     const int slice = (int)(unit - chunk * P.sl_slices);
-    const int64_t grp4 = chunk * P.sl_unit + wg;                              // group of four consecutive walk tiles
-    if (grp4 >= P.sl_groups) return;
-    if (threadIdx.x < 4) {
+    const int64_t grp4 = chunk * P.sl_unit + wg;                              // group of four consecutive walk tiles,
+    if (grp4 >= P.sl_groups) return;                                          // or of TP consecutive points of a cloud's order
+    const bool lat = P.walk_nx > 0;
+    if (lat && threadIdx.x < 4) {
         const int64_t t = grp4 * 4 + threadIdx.x;
         TileBox tb = {0, 0, 0, 0, 0, 0};
         if (t < P.sl_tiles) tb = walk_tile(P, t);
@@ -363,9 +364,11 @@ __device__ __forceinline__ void fused_eval_sliced_body(const EvalParams &P)
     int start[5];
     start[0] = 0;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) start[q + 1] = start[q] + tbs[q].sx * tbs[q].sy * tbs[q].sz;
-    const int tile_n = start[4];
+    for (int q = 0; q < 4; ++q) start[q + 1] = lat ? start[q] + tbs[q].sx * tbs[q].sy * tbs[q].sz : 0;
+    const int64_t cloud_base = grp4 * TP;
+    const int tile_n = lat ? start[4] : (int)min((int64_t)TP, P.n - cloud_base);
     auto point_of = [&](int p) -> int64_t {
+        if (!lat) return P.order ? min((int64_t)P.order[cloud_base + p], P.n - 1) : cloud_base + p;
         int q = 0;
         if (p >= start[1]) q = 1;
         if (p >= start[2]) q = 2;

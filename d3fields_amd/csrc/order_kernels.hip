@@ -139,36 +139,29 @@ const uint32_t *stored_point_order(void *workspace, int64_t n)
 // out[0] = mean L1 step between consecutive points, out[1] = mean L1 distance between points n/2 apart, both
 // over <= kProbeSamples evenly spaced positions (non-finite pairs are left out).  A voxel grid, a mesh or a
 // depth-ordered cloud gives out[0] << out[1]; a shuffled / uniformly random cloud gives out[0] ~ out[1].
-constexpr int kProbeSamples = 4096;
+constexpr int kProbeSamples = 1024;
 
-// One workgroup of 1024 lanes, four samples per lane with all their loads in flight together: one memory round trip
-// (~3 us; the first version walked 16 dependent rounds in a 256-lane workgroup and took 25 us -- 4 % of a C2-patch step).
+// One workgroup of 1024 lanes, one sample per lane, three 12-byte loads each (the pair of consecutive points and the
+// far one), all in flight together: one memory round trip.  A single CU looks up one cache line per lane and load
+// instruction, so the kernel's time is its count of (lane, load) pairs: 4096 samples read as 36 dword loads per lane
+// were 37 k look-ups = 25 us -- a third of the Morton-order set-up of a 100 000-point cloud; this form has 3 k.
 constexpr int kProbeBlock = 1024;
-constexpr int kProbePerLane = kProbeSamples / kProbeBlock;
+static_assert(kProbeSamples == kProbeBlock && (kProbeSamples & (kProbeSamples - 1)) == 0, "one sample per lane; the position is a shift");
+struct __attribute__((packed, aligned(4))) ProbePoint { float x, y, z; };
 
-__global__ __launch_bounds__(kProbeBlock) void point_locality_kernel(const float *__restrict__ pts, int64_t n, int samples,
-                                                                    float *__restrict__ out)
+__global__ __launch_bounds__(kProbeBlock) void point_locality_kernel(const float *__restrict__ pts, int64_t n, float *__restrict__ out)
 {
     __shared__ float red[3][kProbeBlock / 64];
     float near_d = 0.0f, far_d = 0.0f, cnt = 0.0f;
     if (n >= 2) {
-        float a[kProbePerLane][3], b[kProbePerLane][3], c[kProbePerLane][3];
-        bool on[kProbePerLane];
-#pragma unroll
-        for (int q = 0; q < kProbePerLane; ++q) {
-            const int k = threadIdx.x + q * kProbeBlock;
-            on[q] = k < samples;
-            const int64_t i = on[q] ? (int64_t)((double)k * (double)(n - 1) / (double)samples) : 0;      // i + 1 <= n - 1
-            const int64_t j = (i + n / 2) % n;
-#pragma unroll
-            for (int d = 0; d < 3; ++d) { a[q][d] = pts[i * 3 + d]; b[q][d] = pts[i * 3 + 3 + d]; c[q][d] = pts[j * 3 + d]; }
-        }
-#pragma unroll
-        for (int q = 0; q < kProbePerLane; ++q) {
-            const float dn = fabsf(b[q][0] - a[q][0]) + fabsf(b[q][1] - a[q][1]) + fabsf(b[q][2] - a[q][2]);
-            const float df = fabsf(c[q][0] - a[q][0]) + fabsf(c[q][1] - a[q][1]) + fabsf(c[q][2] - a[q][2]);
-            if (on[q] && dn < INFINITY && df < INFINITY) { near_d += dn; far_d += df; cnt += 1.0f; }  // false for NaN too
-        }
+        // sample k of kProbeSamples evenly spaced positions in [0, n-2]
+        const int64_t i = (int64_t)((uint64_t)threadIdx.x * (uint64_t)(n - 1) / (uint64_t)kProbeSamples);       // i + 1 <= n - 1
+        const int64_t j = i + n / 2 - (i + n / 2 >= n ? n : 0);
+        const ProbePoint *pp = reinterpret_cast<const ProbePoint *>(pts);
+        const ProbePoint a = pp[i], b = pp[i + 1], c = pp[j];
+        const float dn = fabsf(b.x - a.x) + fabsf(b.y - a.y) + fabsf(b.z - a.z);
+        const float df = fabsf(c.x - a.x) + fabsf(c.y - a.y) + fabsf(c.z - a.z);
+        if (dn < INFINITY && df < INFINITY) { near_d = dn; far_d = df; cnt = 1.0f; }      // false for NaN too
     }
     for (int off = 32; off > 0; off >>= 1) {
         near_d += __shfl_xor(near_d, off, 64);
@@ -252,7 +245,7 @@ hipError_t launch_lattice_probe(const float *pts, int64_t n, int32_t *out_dims, 
 // one workgroup (a few microseconds); out: 2 device floats
 hipError_t launch_point_locality(const float *pts, int64_t n, float *out, hipStream_t stream)
 {
-    hipLaunchKernelGGL(point_locality_kernel, dim3(1), dim3(kProbeBlock), 0, stream, pts, n, kProbeSamples, out);
+    hipLaunchKernelGGL(point_locality_kernel, dim3(1), dim3(kProbeBlock), 0, stream, pts, n, out);
     return hipGetLastError();
 }
 

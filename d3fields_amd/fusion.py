@@ -445,8 +445,10 @@ class Fusion:
         elif runs and not f16 and not wide:
             s0 = [s for s in range(n_maps) if plan.staged[s] >= 16][0]
             kernel = "fused_eval_runs_kernel<0, %d, %d, %d>" % (plan.vectors_per_lane[s0], plan.staged[s0] - 16, plan.reserved)
-        order = {2: "closed-form brick walk of the lattice (no keys, no sort)" + ("; channel-sliced over the XCDs" if (100 <= plan.reserved < 200 or stream) else "") + ("; persistent producer / consumer workgroups" if stream else ""), 1: "Morton-cell order (counting sort by 16-mm cell + 4-mm refinement, hand-written)",
+        sliced = 100 <= plan.reserved < 200 or stream
+        order = {2: "closed-form brick walk of the lattice (no keys, no sort)", 1: "Morton-cell order (counting sort by 16-mm cell + 4-mm refinement, hand-written)",
                  0: "caller order"}[int(plan.reorder)]
+        order += ("; channel-sliced over the XCDs" if sliced else "") + ("; persistent producer / consumer workgroups" if stream else "")
         if window:
             order += "; %d-point bricks through texel windows in LDS" % int(plan.tile_points)
         elif runs:

@@ -237,9 +237,13 @@ def test_launch_plan_host_logic():
     assert (p.vector_floats[0], p.lanes_per_point[0]) == (1, 1)
     p = _plan(4, 480, 640, 985600, [(48, 64, 384)], dtype=_lib.DTYPE_F16)
     assert (p.tile_points, p.reorder) == (128, 0)
-    # C2 dense: 1.9 GB of maps -> Morton walk, 8-point tiles, 3 batched float4 per lane; without scratch: 64-point tiles
+    # C2 dense: 1.9 GB of maps -> Morton walk feeding the channel-sliced kernel (16-point tiles, 512-byte slices, two views
+    # in flight: reserved 152); the direct gather on the same walk: 8-point tiles, 3 batched float4 per lane; without
+    # scratch: 64-point tiles in caller order
     p = _plan(4, 480, 640, 985600, [(480, 640, 384)])
-    assert (p.tile_points, p.reorder, p.vectors_per_lane[0]) == (8, 1, 3)
+    assert (p.tile_points, p.reorder, p.reserved, p.workgroups) == (16, 1, 152, (241 * 3 + 7) // 8 * 8 * 256)
+    p = _plan(4, 480, 640, 985600, [(480, 640, 384)], flags=_lib.TUNE_DIRECT_GATHER)
+    assert (p.tile_points, p.reorder, p.vectors_per_lane[0], p.reserved) == (8, 1, 3, 0)
     p = _plan(4, 480, 640, 985600, [(480, 640, 384)], ws=0)
     assert (p.tile_points, p.reorder) == (64, 0)
     # C4: 8 views x 1024 channels -> whole wave per point, 4 float4 per lane
@@ -341,3 +345,11 @@ def test_plan_table():
     assert p.tile_points == 64 and p.lds_bytes > 64 * 1024
     # D3F_TUNE_DIRECT_GATHER never changes the point order, only the gather
     assert _plan(1, 480, 640, 200000, one_map((64 << 20) + (256 << 10)), F | _lib.TUNE_DIRECT_GATHER).reorder == 1
+    # channel-sliced kernel: one wide fp32 map of 128..1024 channels in whole 512-byte slices, beyond the caches, on the
+    # Morton walk (or a lattice, test_window_launch_plan); 1152 channels, 192 channels, a second wide map: whole texels
+    assert _plan(4, 480, 640, 200000, [(480, 640, 1024)], F).reserved == 152
+    assert _plan(4, 480, 640, 200000, [(480, 640, 128)], F).reserved == 152
+    assert _plan(4, 480, 640, 200000, [(480, 640, 1152)], F).reserved == 0
+    assert _plan(4, 480, 640, 200000, [(480, 640, 192)], F).reserved == 0
+    assert _plan(4, 480, 640, 200000, [(480, 640, 384), (480, 640, 128)], F).reserved == 0
+    assert _plan(4, 480, 640, 200000, [(480, 640, 384), (480, 640, 8)], F).reserved == 152      # a thin map rides along

@@ -325,6 +325,35 @@ def test_channel_sliced_launch_is_bit_identical(dev, dims, C, mask):
             assert torch.equal(torch.isnan(a), torch.isnan(b)) and torch.equal(torch.nan_to_num(a.float()), torch.nan_to_num(b.float())), (sl, k)
 
 
+@pytest.mark.parametrize("n,C,hw,mask", [(70001, 384, (96, 128), True), (131072, 1024, (96, 128), False), (65537, 128, (192, 256), False)])
+def test_channel_sliced_launch_on_a_cloud_is_bit_identical(dev, n, C, hw, mask):
+    """A random cloud on maps beyond the caches: the Morton order feeds the channel-sliced kernel (tiles of 16 / 32 consecutive
+    points of the order, one 512-byte slice per workgroup; C = 1024: one slice per XCD).  Same bits as the caller-order
+    direct gather, including a strict (NaN) point, a short last tile and the thin map riding along."""
+    from d3fields_amd import synth, _lib
+    V, (H, W) = 4, hw
+    maps = {"dino_feats": synth.random_map(V, H, W, C, seed=1, device=dev)}
+    names = ["dino_feats"]
+    if mask:
+        maps["mask"] = synth.random_onehot_mask(V, H, W, 8, seed=2, device=dev)
+        names.append("mask")
+    f, sc = fusion_for(dev, V, H, W, maps)
+    f.record_plans = True
+    pts = synth.random_cloud(n, seed=5).to(dev)
+    pts[4321, 1] = float("nan")                                                        # a strict point
+    with torch.no_grad():
+        out = f.batch_eval(pts, return_names=names)
+        plan = f.last_plan()
+        assert "Morton" in plan["point_order"] and "channel-sliced" in plan["point_order"], plan
+        assert plan["kernel"].startswith("fused_eval_sliced_kernel"), plan
+        f.tuning_flags = _lib.TUNE_NO_REORDER | _lib.TUNE_DIRECT_GATHER
+        base = f.batch_eval(pts, return_names=names)
+        assert "sliced" not in f.last_plan()["kernel"]
+    for k in ["dist", "valid_mask"] + names:
+        a, b = out[k], base[k]
+        assert torch.equal(torch.isnan(a), torch.isnan(b)) and torch.equal(torch.nan_to_num(a.float()), torch.nan_to_num(b.float())), k
+
+
 # ---- persistent producer / consumer form of the channel-sliced launch (fuse_stream.hip) == caller-order direct gather ----
 @pytest.mark.parametrize("dims,C,mask,dense", [((47, 53, 29), 384, True, True), ((64, 33, 37), 128, False, True), ((33, 35, 61), 256, True, False),
                                                ((160, 140, 11), 384, False, True), ((5, 7, 3001), 512, False, True)])
