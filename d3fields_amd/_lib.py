@@ -122,6 +122,9 @@ SIGNATURES = {
     "d3f_track_step_scratch_bytes": (_i64, [_i32, _i32]),
     "d3f_track_step": (ctypes.c_int, [ctypes.POINTER(Views), ctypes.POINTER(ChannelMap), _vp, _i32, _i32, _vp, _f32, _f32, _f32, _f32, _f32,
                                       _f32, _f32, ctypes.POINTER(TrackState), _vp]),
+    "d3f_track_run": (ctypes.c_int, [ctypes.POINTER(Views), ctypes.POINTER(ChannelMap), _vp, _i32, _i32, _vp, _f32, _f32, _f32, _f32, _f32,
+                                     _f32, _f32, _i32, ctypes.POINTER(TrackState), _vp]),
+    "d3f_track_run_max_keypoints": (_i32, []),
     "d3f_rigid_update": (ctypes.c_int, [_vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f32, _f32, _f32, _f32, _f32, _vp]),
     "d3f_softmax_merge": (ctypes.c_int, [_vp, _i64, _i64, _vp, _vp, _vp]),
     "d3f_softmax_apply": (ctypes.c_int, [_vp, _i64, _i64, _f32, _vp, _vp]),

@@ -1154,15 +1154,20 @@ int64_t d3f_track_step_scratch_bytes(int32_t n_inst, int32_t n)
     return ((int64_t)n_inst * n * 3 + 4) * (int64_t)sizeof(float);
 }
 
-int d3f_track_step(const d3f_views *views, const d3f_channel_map *descriptors, const float *last, int32_t n_inst, int32_t n,
-                   const float *src, float mu, float dist_w, float reg_w, float lr, float beta1, float beta2, float eps,
-                   const d3f_track_state *state, void *stream)
+static int track_impl(const d3f_views *views, const d3f_channel_map *descriptors, const float *last, int32_t n_inst, int32_t n,
+                      const float *src, float mu, float dist_w, float reg_w, float lr, float beta1, float beta2, float eps,
+                      int32_t iters, const d3f_track_state *state, void *stream)
 {
     int rc = check_views(views);
     if (rc != D3F_OK) return rc;
     if (n_inst < 0 || n < 0) return fail(D3F_ERR_BAD_SHAPE, "track_step: n_inst=%d n=%d", n_inst, n);
-    if ((int64_t)n_inst * n == 0) return D3F_OK;
+    if (iters < 0) return fail(D3F_ERR_INVALID_ARG, "track_run: iters=%d", iters);
+    if ((int64_t)n_inst * n == 0 || iters == 0) return D3F_OK;
     if ((int64_t)n_inst * n > 0x7fffffLL) return fail(D3F_ERR_BAD_SHAPE, "track_step: %lld keypoints (one workgroup each) are too many", (long long)n_inst * n);
+    if (iters > 1 && ((int64_t)n_inst * n > d3f::kTrackMaxResident || n_inst > 16))
+        return fail(D3F_ERR_BAD_SHAPE, "track_run: %lld keypoints of %d instances; the steps of one launch wait for one another, so every "
+                                       "workgroup must be resident (<= %d keypoints, <= 16 instances); call d3f_track_step per iteration",
+                    (long long)n_inst * n, n_inst, d3f::kTrackMaxResident);
     if (!descriptors || !last || !src || !state) return fail(D3F_ERR_INVALID_ARG, "track_step: NULL pointer");
     if (!state->t || !state->w || !state->adam_m || !state->adam_v || !state->step || !state->out_pts || !state->loss || !state->scratch)
         return fail(D3F_ERR_INVALID_ARG, "track_step: NULL pointer in d3f_track_state");
@@ -1179,14 +1184,31 @@ int d3f_track_step(const d3f_views *views, const d3f_channel_map *descriptors, c
         return fail(D3F_ERR_BAD_LAYOUT, "track_step: the descriptor map must be fp32 with C %% 4 == 0, C <= 512 and 16-byte aligned texels "
                                         "(C=%d); use the five-launch step", P.map.C);
     P.depth = views->depth; P.K = views->K; P.pose = views->pose; P.V = views->V; P.H = views->H; P.W = views->W;
-    P.last = last; P.src = src; P.I = n_inst; P.n = n;
+    P.last = last; P.src = src; P.I = n_inst; P.n = n; P.iters = iters;
     P.mu = mu; P.dist_w = dist_w; P.reg_w = reg_w; P.lr = lr; P.beta1 = beta1; P.beta2 = beta2; P.eps_adam = eps; P.eps_rot = 1e-4f;
     P.t = state->t; P.w = state->w; P.adam_m = state->adam_m; P.adam_v = state->adam_v; P.step = state->step;
     P.out_pts = state->out_pts; P.loss_out = state->loss;
     float *scr = static_cast<float *>(state->scratch);
     P.grad_pts = scr; P.loss_acc = scr + (int64_t)n_inst * n * 3; P.counter = reinterpret_cast<unsigned int *>(P.loss_acc + 2);
-    hipError_t e = d3f::launch_track_step(P, static_cast<hipStream_t>(stream));
+    hipStream_t hs = static_cast<hipStream_t>(stream);
+    hipError_t e = d3f::launch_track_step(P, hs);
     return e == hipSuccess ? D3F_OK : hip_fail(e, "track_step launch");
 }
+
+int d3f_track_step(const d3f_views *views, const d3f_channel_map *descriptors, const float *last, int32_t n_inst, int32_t n,
+                   const float *src, float mu, float dist_w, float reg_w, float lr, float beta1, float beta2, float eps,
+                   const d3f_track_state *state, void *stream)
+{
+    return track_impl(views, descriptors, last, n_inst, n, src, mu, dist_w, reg_w, lr, beta1, beta2, eps, 1, state, stream);
+}
+
+int d3f_track_run(const d3f_views *views, const d3f_channel_map *descriptors, const float *last, int32_t n_inst, int32_t n,
+                  const float *src, float mu, float dist_w, float reg_w, float lr, float beta1, float beta2, float eps,
+                  int32_t iters, const d3f_track_state *state, void *stream)
+{
+    return track_impl(views, descriptors, last, n_inst, n, src, mu, dist_w, reg_w, lr, beta1, beta2, eps, iters, state, stream);
+}
+
+int32_t d3f_track_run_max_keypoints(void) { return d3f::kTrackMaxResident; }
 
 }  // extern "C"

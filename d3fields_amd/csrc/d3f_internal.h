@@ -207,8 +207,10 @@ struct TrackStepParams {
     float *grad_pts;                    // [I*n, 3] scratch
     float *loss_acc;                    // [2] accumulators, zero between steps
     float *loss_out;                    // [3] feature loss, distance loss, regulariser of this step
-    unsigned int *counter;              // zero between steps
+    unsigned int *counter;              // [2] arrivals, published generation; zero between launches
+    int32_t iters;                      // optimiser steps in this launch (> 1: all I*n waves resident, <= kTrackMaxResident)
 };
+constexpr int kTrackMaxResident = 512;       // one wave per SIMD at this kernel's register count = 1024 on the chip; half of it
 
 hipError_t launch_track_step(const TrackStepParams &P, hipStream_t s);
 

@@ -105,13 +105,15 @@ __global__ __launch_bounds__(kBlock) void track_loss_grad_kernel(const float *__
 }
 
 // chain rule through the transform and the exponential map, the regulariser's gradient and torch.optim.Adam's update of the
-// six parameters of instance i.  G[0..2] = sum_p dL/dp', G[3..11] = sum_p p_k dL/dp'_j (row k, column j); one lane.
-__device__ __forceinline__ void rigid_adam_update(int i, const float *G, float *__restrict__ t, float *__restrict__ w,
-                                                  float *__restrict__ adam_m, float *__restrict__ adam_v, float *__restrict__ step,
-                                                  float nt, float nw, float eps_rot, float reg_w, float lr, float beta1, float beta2,
-                                                  float eps_adam)
+// six parameters of one instance.  G[0..2] = sum_p dL/dp', G[3..11] = sum_p p_k dL/dp'_j (row k, column j).  Pure
+// arithmetic on registers: the callers load and store the state (plain accesses in rigid_update_kernel; coherent ones
+// inside the multi-step launch, where the wave that runs the update changes from step to step).
+struct AdamState { float t[3], w[3], m[6], v[6], step; };
+
+__device__ __forceinline__ AdamState rigid_adam_math(const float *G, const AdamState in, float nt, float nw, float eps_rot, float reg_w,
+                                                     float lr, float beta1, float beta2, float eps_adam)
 {
-    const float wx = w[i * 3], wy = w[i * 3 + 1], wz = w[i * 3 + 2];
+    const float wx = in.w[0], wy = in.w[1], wz = in.w[2];
     const Rot r = exp_map(wx, wy, wz, eps_rot);
     const float K[9] = {0.0f, -wz, wy, wz, 0.0f, -wx, -wy, wx, 0.0f};
     const float *GR = G + 3;                                            // 3x3, row k, column j
@@ -151,26 +153,48 @@ __device__ __forceinline__ void rigid_adam_update(int i, const float *G, float *
     // regulariser reg_w * (|t|_F + |w|_F): gradient x / |x|_F, 0 at the origin (torch.norm backward)
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
-        if (nt > 0.0f) g6[k] += reg_w * t[i * 3 + k] / nt;
-        if (nw > 0.0f) g6[3 + k] += reg_w * w[i * 3 + k] / nw;
+        if (nt > 0.0f) g6[k] += reg_w * in.t[k] / nt;
+        if (nw > 0.0f) g6[3 + k] += reg_w * in.w[k] / nw;
     }
     // torch.optim.Adam (amsgrad off, no weight decay): one step of the six parameters of this instance
-    const float st = step[i] + 1.0f;
-    step[i] = st;
+    AdamState out;
+    const float st = in.step + 1.0f;
+    out.step = st;
     const float bc1 = 1.0f - powf(beta1, st), bc2 = 1.0f - powf(beta2, st);
     const float step_size = lr / bc1, bc2_sqrt = sqrtf(bc2);
 #pragma unroll
     for (int k = 0; k < 6; ++k) {
-        float *par = k < 3 ? t + i * 3 + k : w + i * 3 + (k - 3);
+        const float par = k < 3 ? in.t[k] : in.w[k - 3];
         const float g = g6[k];
-        float m = adam_m[i * 6 + k], v = adam_v[i * 6 + k];
+        float m = in.m[k], v = in.v[k];
         m = m + (g - m) * (1.0f - beta1);
         v = v * beta2 + (1.0f - beta2) * (g * g);
-        adam_m[i * 6 + k] = m;
-        adam_v[i * 6 + k] = v;
+        out.m[k] = m;
+        out.v[k] = v;
         const float denom = sqrtf(v) / bc2_sqrt + eps_adam;
-        *par = *par - step_size * (m / denom);
+        const float upd = par - step_size * (m / denom);
+        if (k < 3) out.t[k] = upd; else out.w[k - 3] = upd;
     }
+    return out;
+}
+
+__device__ __forceinline__ void rigid_adam_update(int i, const float *G, float *__restrict__ t, float *__restrict__ w,
+                                                  float *__restrict__ adam_m, float *__restrict__ adam_v, float *__restrict__ step,
+                                                  float nt, float nw, float eps_rot, float reg_w, float lr, float beta1, float beta2,
+                                                  float eps_adam)
+{
+    AdamState in;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { in.t[k] = t[i * 3 + k]; in.w[k] = w[i * 3 + k]; }
+#pragma unroll
+    for (int k = 0; k < 6; ++k) { in.m[k] = adam_m[i * 6 + k]; in.v[k] = adam_v[i * 6 + k]; }
+    in.step = step[i];
+    const AdamState o = rigid_adam_math(G, in, nt, nw, eps_rot, reg_w, lr, beta1, beta2, eps_adam);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { t[i * 3 + k] = o.t[k]; w[i * 3 + k] = o.w[k]; }
+#pragma unroll
+    for (int k = 0; k < 6; ++k) { adam_m[i * 6 + k] = o.m[k]; adam_v[i * 6 + k] = o.v[k]; }
+    step[i] = o.step;
 }
 
 // one workgroup per instance: reduce over its n keypoints, chain rule, Adam
@@ -224,20 +248,39 @@ __global__ __launch_bounds__(kBlock) void rigid_update_kernel(const float *__res
 // rigid_update; sums run in another order, so the result agrees with the five-launch step to rounding (tests pin both to
 // the keypoints the reference's own loop returned).
 constexpr int kTrackMaxViews = 8;
+constexpr int kTrackMaxInst = 16;           // instances of the coherent small-problem path (state staged through LDS)
+
+// Device-coherent scalar accesses (agent scope, relaxed: they go to the memory side, past this XCD's L2) for the few words
+// the waves of a launch exchange: per-keypoint gradients, pose parameters, Adam's state, the loss.  With them a step needs
+// no device-scope FENCE -- which on gfx950 writes back and invalidates the whole L2 of the XCD and sends the next step's
+// depth and texel reads back to memory -- only program order: the exchanged stores are complete (s_waitcnt) before the
+// arrival is counted / the generation is published.
+__device__ __forceinline__ float ld_coh(const float *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_coh(float *p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_coh(unsigned int *p, unsigned int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void order_release()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");      // compiler order; no cache maintenance at this scope
+    __builtin_amdgcn_s_waitcnt(0);                              // every store / atomic of this wave has been acknowledged
+}
+__device__ __forceinline__ void order_acquire() { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); }
 
 template <int NVEC>        // float4 channel vectors per lane: ceil(C / 256)
 __global__ __launch_bounds__(64) void track_step_kernel(const TrackStepParams P)
 {
     __shared__ float krt[kTrackMaxViews * 12];
+    __shared__ float sh_g[kTrackMaxResident * 3], sh_l[kTrackMaxResident * 3];    // the updating wave: gradients, keypoints
+    __shared__ float sh_p[kTrackMaxInst * 19 + 2];                                // ... t, w, Adam m / v / step, loss sums
     const int lane = threadIdx.x;
     const int p = blockIdx.x;                               // one wave per keypoint
     const int V = P.V, N = P.I * P.n, C = P.map.C, cvec = C / 4;
     const MapDesc &m = P.map;
+    // small problems (every tracking frame of the reference: ~100 keypoints, a few instances) exchange their words with
+    // coherent accesses and need no device-scope fence; larger ones (one step per launch only) keep fences + plain accesses
+    const bool small = N <= kTrackMaxResident && P.I <= kTrackMaxInst;
     // every load that depends on nothing is issued before the first wait: pose parameters, the keypoint, its source
     // descriptor, and K / pose inside compute_krt
     const int inst = p / P.n;
-    const float w0 = P.w[inst * 3], w1 = P.w[inst * 3 + 1], w2 = P.w[inst * 3 + 2];
-    const float t0 = P.t[inst * 3], t1 = P.t[inst * 3 + 1], t2 = P.t[inst * 3 + 2];
     const float lx = P.last[p * 3], ly = P.last[p * 3 + 1], lz = P.last[p * 3 + 2];
     f32x4 srcv[NVEC];
 #pragma unroll
@@ -247,6 +290,16 @@ __global__ __launch_bounds__(64) void track_step_kernel(const TrackStepParams P)
     }
     compute_krt(P.K, P.pose, V, krt, 64);
     __syncthreads();
+    // P.iters optimiser steps in this launch (d3f_track_run: > 1, every wave resident, a device-wide barrier between steps)
+    for (int it = 0; it < P.iters; ++it) {
+    float w0, w1, w2, t0, t1, t2;                                                        // step it-1's update
+    if (small) {
+        w0 = ld_coh(P.w + inst * 3); w1 = ld_coh(P.w + inst * 3 + 1); w2 = ld_coh(P.w + inst * 3 + 2);
+        t0 = ld_coh(P.t + inst * 3); t1 = ld_coh(P.t + inst * 3 + 1); t2 = ld_coh(P.t + inst * 3 + 2);
+    } else {
+        w0 = P.w[inst * 3]; w1 = P.w[inst * 3 + 1]; w2 = P.w[inst * 3 + 2];
+        t0 = P.t[inst * 3]; t1 = P.t[inst * 3 + 1]; t2 = P.t[inst * 3 + 2];
+    }
     // ---- transform (rigid_transform_kernel) ----
     const Rot R = exp_map(w0, w1, w2, P.eps_rot);
     const float tt3[3] = {t0, t1, t2};
@@ -397,13 +450,97 @@ __global__ __launch_bounds__(64) void track_step_kernel(const TrackStepParams P)
         gyw += g_xc * M[1] + g_yc * M[5] + g_zc * M[9];
         gzw += g_xc * M[2] + g_yc * M[6] + g_zc * M[10];
     }
-    if (lane == 0) { P.grad_pts[p * 3 + 0] = gxw; P.grad_pts[p * 3 + 1] = gyw; P.grad_pts[p * 3 + 2] = gzw; }
+    if (lane == 0) {
+        if (small) { st_coh(P.grad_pts + p * 3 + 0, gxw); st_coh(P.grad_pts + p * 3 + 1, gyw); st_coh(P.grad_pts + p * 3 + 2, gzw); }
+        else { P.grad_pts[p * 3 + 0] = gxw; P.grad_pts[p * 3 + 1] = gyw; P.grad_pts[p * 3 + 2] = gzw; }
+    }
     // ---- the last wave to finish reduces per instance and steps Adam (rigid_update_kernel) ----
-    __threadfence();                                                      // release: grad_pts / loss are visible device-wide
+    // The arrival counter runs on across the steps of a launch (step `it` is complete at N*(it+1) arrivals); the wave that
+    // completes it updates the parameters, clears the loss accumulators and publishes generation it+1, which the other
+    // waves of a multi-step launch wait for (bounded: a wave that never sees it poisons the loss with NaN and leaves).
+    if (small) order_release(); else __threadfence();                     // grad_pts / loss are out before the arrival counts
     unsigned int ticket = 0;
     if (lane == 0) ticket = atomicAdd(P.counter, 1u);
     ticket = (unsigned int)__builtin_amdgcn_readfirstlane((int)ticket);
-    if (ticket != (unsigned int)N - 1u) return;
+    const bool last_step = it + 1 == P.iters;
+    if (ticket != (unsigned int)N * (unsigned int)(it + 1) - 1u) {
+        if (last_step) return;
+        int ok = 1;
+        if (lane == 0) {
+            unsigned int polls = 0;
+            while (__hip_atomic_load(P.counter + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned int)(it + 1)) {
+                __builtin_amdgcn_s_sleep(4);
+                if (++polls > (1u << 21)) { ok = 0; break; }
+            }
+        }
+        ok = __builtin_amdgcn_readfirstlane(ok);
+        if (!ok) {
+            if (lane < 3) st_coh(P.loss_out + lane, __builtin_nanf(""));
+            return;
+        }
+        order_acquire();                                                  // (a multi-step launch is always `small`)
+        continue;
+    }
+    if (small) {
+        // ---- the update, coherent form: ONE round of loads (everything the update reads, spread over the lanes, into LDS),
+        // arithmetic, one round of stores ----
+        order_acquire();
+        for (int k = lane; k < N * 3; k += 64) { sh_g[k] = ld_coh(P.grad_pts + k); sh_l[k] = P.last[k]; }
+        const int I = P.I;
+        for (int k = lane; k < I * 19 + 2; k += 64) {
+            const float *src_k = k < 3 * I ? P.t + k : k < 6 * I ? P.w + (k - 3 * I) : k < 12 * I ? P.adam_m + (k - 6 * I)
+                               : k < 18 * I ? P.adam_v + (k - 12 * I) : k < 19 * I ? P.step + (k - 18 * I) : P.loss_acc + (k - 19 * I);
+            sh_p[k] = ld_coh(src_k);
+        }
+        __syncthreads();
+        float st = 0.0f, sw = 0.0f;                                       // |t|_F, |w|_F over ALL instances, before the update
+        for (int k = 0; k < I * 3; ++k) { st += sh_p[k] * sh_p[k]; sw += sh_p[3 * I + k] * sh_p[3 * I + k]; }
+        const float nt = sqrtf(st), nw = sqrtf(sw);
+        for (int i = 0; i < I; ++i) {
+            float G[12];
+#pragma unroll
+            for (int k = 0; k < 12; ++k) G[k] = 0.0f;
+            for (int pp = lane; pp < P.n; pp += 64) {
+                const int b = (i * P.n + pp) * 3;
+                const float gx = sh_g[b], gy = sh_g[b + 1], gz = sh_g[b + 2];
+                const float px = sh_l[b], py = sh_l[b + 1], pz = sh_l[b + 2];
+                G[0] += gx; G[1] += gy; G[2] += gz;
+                G[3] += px * gx; G[4] += px * gy; G[5] += px * gz;
+                G[6] += py * gx; G[7] += py * gy; G[8] += py * gz;
+                G[9] += pz * gx; G[10] += pz * gy; G[11] += pz * gz;
+            }
+#pragma unroll
+            for (int k = 0; k < 12; ++k)
+                for (int off = 32; off > 0; off >>= 1) G[k] += __shfl_xor(G[k], off, 64);
+            AdamState in;                                                 // every lane computes the same update; lane 0 stores it
+#pragma unroll
+            for (int k = 0; k < 3; ++k) { in.t[k] = sh_p[i * 3 + k]; in.w[k] = sh_p[3 * I + i * 3 + k]; }
+#pragma unroll
+            for (int k = 0; k < 6; ++k) { in.m[k] = sh_p[6 * I + i * 6 + k]; in.v[k] = sh_p[12 * I + i * 6 + k]; }
+            in.step = sh_p[18 * I + i];
+            const AdamState o = rigid_adam_math(G, in, nt, nw, P.eps_rot, P.reg_w, P.lr, P.beta1, P.beta2, P.eps_adam);
+            if (lane == 0) {
+#pragma unroll
+                for (int k = 0; k < 3; ++k) { st_coh(P.t + i * 3 + k, o.t[k]); st_coh(P.w + i * 3 + k, o.w[k]); }
+#pragma unroll
+                for (int k = 0; k < 6; ++k) { st_coh(P.adam_m + i * 6 + k, o.m[k]); st_coh(P.adam_v + i * 6 + k, o.v[k]); }
+                st_coh(P.step + i, o.step);
+            }
+        }
+        if (lane == 0) {
+            st_coh(P.loss_out + 0, sh_p[19 * I]);
+            st_coh(P.loss_out + 1, sh_p[19 * I + 1]);
+            st_coh(P.loss_out + 2, P.reg_w * (nt + nw));
+            st_coh(P.loss_acc + 0, 0.0f); st_coh(P.loss_acc + 1, 0.0f);  // clean for the next step
+            if (last_step) { st_coh(P.counter, 0u); st_coh(P.counter + 1, 0u); }      // every wave has arrived: nobody waits any more
+        }
+        if (last_step) return;
+        __syncthreads();                                                  // LDS reads above are done before the next update overwrites it
+        order_release();                                                  // parameters, cleared accumulators
+        if (lane == 0) __hip_atomic_store(P.counter + 1, (unsigned int)(it + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        continue;
+    }
+    // ---- the update for larger problems (one step per launch): fences + plain accesses ----
     __threadfence();                                                      // acquire
     float st = 0.0f, sw = 0.0f;                                           // |t|_F, |w|_F over ALL instances, before the update
     for (int k = 0; k < P.I * 3; ++k) { st += P.t[k] * P.t[k]; sw += P.w[k] * P.w[k]; }
@@ -431,14 +568,28 @@ __global__ __launch_bounds__(64) void track_step_kernel(const TrackStepParams P)
         P.loss_out[1] = __builtin_nontemporal_load(P.loss_acc + 1);
         P.loss_out[2] = P.reg_w * (nt + nw);
         P.loss_acc[0] = 0.0f; P.loss_acc[1] = 0.0f;                       // clean for the next step
-        *P.counter = 0u;
+        P.counter[0] = 0u; P.counter[1] = 0u;
     }
+    return;                                                               // (not `small`: one step per launch)
+    }
+}
+
+// clears the four words a multi-step launch synchronises through (a memset node of a captured HIP graph replayed these
+// 16 bytes wrongly on ROCm 7.2 -- the second replay found a host pointer in them; a kernel node replays as recorded)
+__global__ void track_reset_kernel(float *loss_acc, unsigned int *counter)
+{
+    if (threadIdx.x < 2) loss_acc[threadIdx.x] = 0.0f;
+    else if (threadIdx.x < 4) counter[threadIdx.x - 2] = 0u;
 }
 
 hipError_t launch_track_step(const TrackStepParams &P, hipStream_t s)
 {
     const int N = P.I * P.n;
-    if (N == 0) return hipSuccess;
+    if (N == 0 || P.iters <= 0) return hipSuccess;
+    // several steps per launch wait for one another inside the kernel: every wave must be resident (one per SIMD at
+    // this register count: 1024 on the chip; the bound leaves half of that to whatever else runs)
+    if (P.iters > 1 && (N > kTrackMaxResident || P.I > kTrackMaxInst)) return hipErrorInvalidValue;
+    if (P.iters > 1) hipLaunchKernelGGL(track_reset_kernel, dim3(1), dim3(64), 0, s, P.loss_acc, P.counter);
     const int nvec = (P.map.C / 4 + 63) / 64;
     if (nvec <= 1) hipLaunchKernelGGL(track_step_kernel<1>, dim3((unsigned)N), dim3(64), 0, s, P);
     else if (nvec == 2) hipLaunchKernelGGL(track_step_kernel<2>, dim3((unsigned)N), dim3(64), 0, s, P);

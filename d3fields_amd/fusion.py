@@ -239,6 +239,7 @@ class Fusion:
         self.fused_tracking = True              # ... and run it as five HIP launches (track_kernels.hip) instead of autograd
         self.graph_whole_tracking_loop = True   # ... with all 100 steps in ONE graph (False: one step replayed 100 times)
         self.single_launch_tracking = True      # ... each step ONE launch (d3f_track_step) where the descriptor map allows it
+        self.loop_launch_tracking = True        # ... and all steps of a frame ONE launch (d3f_track_run) up to 512 keypoints
         self.detect_point_order = True          # probe new query tensors for locality (one host sync each, cached)
         self._order_cache = None
         self.cache_point_order = True           # keep the Morton order of an unchanged query tensor (a grid queried every
@@ -756,9 +757,11 @@ class Fusion:
             key = rigid.RigidTracker.signature(self, num_instance, rand_ptcl_num)
             if (self._tracker is None or self._tracker.key != key or self._tracker.fused != self.fused_tracking or
                     self._tracker.whole_loop != (self.graph_whole_tracking_loop and self.fused_tracking) or
-                    self._tracker.single_requested != self.single_launch_tracking):
+                    self._tracker.single_requested != self.single_launch_tracking or
+                    self._tracker.loop_requested != self.loop_launch_tracking):
                 self._tracker = rigid.RigidTracker(self, num_instance, rand_ptcl_num, fused=self.fused_tracking,
-                                                   whole_loop=self.graph_whole_tracking_loop, single_launch=self.single_launch_tracking)
+                                                   whole_loop=self.graph_whole_tracking_loop, single_launch=self.single_launch_tracking,
+                                                   loop_launch=self.loop_launch_tracking)
             cur, _ = self._tracker.run(self, src_feats, last)
         else:
             cur, _ = rigid.track_rigid(self, src_feats, last, use_graph=False)

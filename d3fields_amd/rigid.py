@@ -99,17 +99,20 @@ class RigidTracker:
     fused=True (default): the step is closed-form HIP (csrc/track_kernels.hip: exponential map, transform, query,
     loss gradients, backward of the query, chain rule and Adam) instead of torch autograd's ~90 launches -- as ONE launch
     per step (d3f_track_step: a wave per keypoint, the last wave to finish steps Adam; single_launch=True, the default
-    whenever the descriptor map is fp32 with <= 512 channels and <= 8 views) or as five (d3f_rigid_transform, d3f_eval,
+    whenever the descriptor map is fp32 with <= 512 channels and <= 8 views; with loop_launch=True and at most 512 keypoints
+    ALL steps of a frame are one launch, d3f_track_run, whose waves wait for each step's update inside the kernel) or as five (d3f_rigid_transform, d3f_eval,
     d3f_track_loss_grad, d3f_eval_backward, d3f_rigid_update).  fused=False replays the autograd step."""
 
-    def __init__(self, fusion, num_inst, n, iters=ITERS, lr=LR, fused=True, whole_loop=True, single_launch=True):
+    def __init__(self, fusion, num_inst, n, iters=ITERS, lr=LR, fused=True, whole_loop=True, single_launch=True, loop_launch=True):
         from .fusion import Fusion
         dev = torch.device(fusion.device)
         obs = fusion.curr_obs_torch
         self.key = self.signature(fusion, num_inst, n)
         self.iters, self.lr, self.fused = iters, lr, fused
         self.single = False
+        self.loop = False
         self.single_requested = bool(single_launch)
+        self.loop_requested = bool(loop_launch)
         # whole_loop: ALL `iters` steps are captured into one HIP graph (5 x iters kernel nodes, one launch per frame)
         # instead of one step replayed `iters` times (a graph launch per step)
         self.whole_loop = bool(whole_loop) and fused
@@ -135,6 +138,9 @@ class RigidTracker:
                 from . import _lib
                 self.loss3 = torch.zeros(3, device=dev)
                 self.scratch = torch.zeros(_lib.load().d3f_track_step_scratch_bytes(num_inst, n) // 4, device=dev)
+                # loop_launch: all `iters` steps in ONE launch (d3f_track_run; the steps wait for one another inside the
+                # kernel, so every keypoint's wave must be resident)
+                self.loop = bool(loop_launch) and self.whole_loop and num_inst * n <= _lib.load().d3f_track_run_max_keypoints() and num_inst <= 16
         else:
             self.opt = torch.optim.Adam([self.t_params, self.log_r], lr=lr, betas=(0.9, 0.999), capturable=True)
         self.graph = None
@@ -160,8 +166,9 @@ class RigidTracker:
                         if isinstance(v, torch.Tensor):
                             v.zero_()
 
-    def _fused_iteration(self):
-        """transform -> d3f_eval -> loss gradients -> d3f_eval_backward -> chain rule + Adam: five launches, no autograd."""
+    def _fused_iteration(self, iters=1):
+        """transform -> d3f_eval -> loss gradients -> d3f_eval_backward -> chain rule + Adam: five launches, no autograd
+        (single: one launch per step, d3f_track_step, or one for `iters` steps, d3f_track_run)."""
         from . import _lib
         import ctypes
         lib, dev = _lib.load(), self.last.device
@@ -176,9 +183,15 @@ class RigidTracker:
                 cm = _lib.ChannelMap(fm.data_ptr(), fm.shape[1], fm.shape[2], fm.shape[3], _lib.DTYPE_F32, fm.stride(0), fm.stride(1), fm.stride(2))
                 state = _lib.TrackState(_lib.ptr(self.t_params), _lib.ptr(self.log_r), _lib.ptr(m), _lib.ptr(v), _lib.ptr(step),
                                         _lib.ptr(self.pts), _lib.ptr(self.loss3), _lib.ptr(self.scratch))
-                _lib.check(lib.d3f_track_step(ctypes.byref(views), ctypes.byref(cm), _lib.ptr(self.last), I, n, _lib.ptr(self.src),
-                                              float(self.shadow.mu), DIST_W, REG_W, self.lr, 0.9, 0.999, 1e-8, ctypes.byref(state), stream))
+                if iters == 1:
+                    _lib.check(lib.d3f_track_step(ctypes.byref(views), ctypes.byref(cm), _lib.ptr(self.last), I, n, _lib.ptr(self.src),
+                                                  float(self.shadow.mu), DIST_W, REG_W, self.lr, 0.9, 0.999, 1e-8, ctypes.byref(state), stream))
+                else:
+                    _lib.check(lib.d3f_track_run(ctypes.byref(views), ctypes.byref(cm), _lib.ptr(self.last), I, n, _lib.ptr(self.src),
+                                                 float(self.shadow.mu), DIST_W, REG_W, self.lr, 0.9, 0.999, 1e-8, int(iters),
+                                                 ctypes.byref(state), stream))
             return self.pts, self.loss3.sum()
+        assert iters == 1
         with torch.cuda.device(dev), torch.no_grad():
             stream = _lib.current_stream_handle(dev)
             _lib.check(lib.d3f_rigid_transform(_lib.ptr(self.last), I, n, _lib.ptr(self.t_params), _lib.ptr(self.log_r),
@@ -194,9 +207,10 @@ class RigidTracker:
         # total loss of this step as the reference forms it: feature + distance + regulariser (norms are pre-update)
         return self.pts, loss[0] + loss[1] + REG_W * (norms[0] + norms[1])
 
-    def _step(self):
+    def _step(self, iters=1):
         if self.fused:
-            return self._fused_iteration()
+            return self._fused_iteration(iters)
+        assert iters == 1
         return _iteration(self.shadow, self.last, self.src, self.t_params, self.log_r, self.opt)
 
     def run(self, fusion, src_feats, last_match_pts):
@@ -216,8 +230,11 @@ class RigidTracker:
             self._rewind()
             self.graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.graph):
-                for _ in range(self.iters if self.whole_loop else 1):
-                    self.cur, self.loss = self._step()
+                if self.loop:
+                    self.cur, self.loss = self._step(self.iters)
+                else:
+                    for _ in range(self.iters if self.whole_loop else 1):
+                        self.cur, self.loss = self._step()
         self._rewind()
         for _ in range(1 if self.whole_loop else self.iters):
             self.graph.replay()

@@ -410,16 +410,18 @@ def test_point_order_probe_and_unordered_walk(dev):
         assert rel_err(cpu(got[k]), ref["sets"][s_]) <= TOL
 
 
-@pytest.mark.parametrize("use_graph", [False, True, "five launches", "autograd"])
+@pytest.mark.parametrize("use_graph", [False, True, "one launch per step", "five launches", "autograd"])
 def test_rigid_tracking_matches_reference(dev, use_graph):
     """Fusion.rigid_tracking (100 Adam steps; eager autograd through d3f_eval / d3f_eval_backward, the closed-form HIP step as
-    one launch (d3f_track_step) or as five, or the autograd step graph-replayed) against the keypoints the REFERENCE's loop
-    returned (golden 'rigid_tracking'): measured agreement 3e-8 m on positions that move 1-15 mm; tolerance 1e-5 m."""
+    one launch for the whole frame (d3f_track_run), one per step (d3f_track_step) or five per step, or the autograd step
+    graph-replayed) against the keypoints the REFERENCE's loop returned (golden 'rigid_tracking'): measured agreement
+    3e-8 m on positions that move 1-15 mm; tolerance 1e-5 m."""
     g = load_golden("rigid_tracking")
     f = make_fusion(dev, g["depth"], g["K"], g["pose"], {"dino_feats": g["in_dino_feats"]}, g["H"], g["W"], float(g["mu"]))
     f.use_hip_graph = bool(use_graph)
-    f.fused_tracking = use_graph in (True, "five launches")     # the closed-form HIP step; "autograd": the autograd step, graph-replayed
-    f.single_launch_tracking = use_graph is True
+    f.fused_tracking = use_graph in (True, "one launch per step", "five launches")     # the closed-form HIP step; "autograd": the autograd step, graph-replayed
+    f.single_launch_tracking = use_graph in (True, "one launch per step")
+    f.loop_launch_tracking = use_graph is True
     n = int(g["n"])
     info = {"a": {"src_feats": torch.from_numpy(g["src_feats"][:n])}, "b": {"src_feats": torch.from_numpy(g["src_feats"][n:])}}
     res = f.rigid_tracking(info, [p for p in g["last_pts"]], None, n)
@@ -428,8 +430,9 @@ def test_rigid_tracking_matches_reference(dev, use_graph):
     err = np.abs(got - g["match_pts"]).max()
     assert err <= 1e-5, err
     assert np.abs(got - g["true_pts"]).max() < 0.5 * np.abs(g["last_pts"] - g["true_pts"]).max()
-    if use_graph is True:
+    if use_graph in (True, "one launch per step"):
         assert f._tracker.single, "the one-launch step must be what ran"
+        assert f._tracker.loop == (use_graph is True), "one launch for the whole frame / one per step"
     if use_graph:
         # the captured iteration is kept for the sequence: a second frame (other start points, shifted cameras) replays
         # it on fresh inputs and must equal the eager loop; then the first frame again
