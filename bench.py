@@ -263,6 +263,8 @@ def main():
     ap.add_argument("--tuning", type=lambda x: int(x, 0), default=0, help="D3F_TUNE_* bits (experiments)")
     ap.add_argument("--cpu-sample", type=int, default=1000000)
     ap.add_argument("--cpu-threads", type=int, default=0, help="0 = min(host cores, 64)")
+    ap.add_argument("--force-dist", action="store_true", help="run the multi-rank code path even with one rank (self-spawned under "
+                                                               "torch.distributed.run): RCCL initialisation, barrier, all-gathers")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend; 'gloo' lets the N>1 code path be "
                     "exercised with several ranks on ONE GPU (testing only)")
     args = ap.parse_args()
@@ -270,10 +272,12 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    dist_on = world > 1
+    # --force-dist: the multi-rank code path (process group on RCCL, barrier, max over ranks, overlapped all-gathers) with
+    # however many ranks there are, ONE included -- the plumbing self-test a single-GPU box can run
+    dist_on = world > 1 or (args.force_dist and "WORLD_SIZE" in os.environ)
     if args.gpus != world and dist_on:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
-    if args.gpus > 1 and not dist_on:
+    if (args.gpus > 1 or args.force_dist) and not dist_on:
         # `python bench.py --gpus N` is ONE command: it re-launches itself as N ranks (one per GPU) under
         # torch.distributed.run and hands back their exit status; rank 0's JSON line goes to this process's stdout
         raise SystemExit(spawn_ranks(args.gpus, sys.argv[1:]))
