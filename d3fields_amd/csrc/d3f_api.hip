@@ -246,7 +246,7 @@ int eval_common(const d3f_views *views, const float *pts, int64_t n, const d3f_c
     P.grid_x = grid ? grid->x : nullptr; P.grid_y = grid ? grid->y : nullptr; P.grid_z = grid ? grid->z : nullptr;
     P.grid_ny = grid ? grid->ny : 0; P.grid_nz = grid ? grid->nz : 0;
     P.walk_nx = P.walk_ny = P.walk_nz = 0; P.walk_tx = P.walk_ty = P.walk_tz = 1;
-    P.sl_unit = 128; P.sl_slices = 0; P.sl_lg = 3; P.sl_vc = 4; P.sl_tiles = P.sl_groups = P.sl_chunks = 0;
+    P.sl_unit = 128; P.sl_ilv = 1; P.sl_slices = 0; P.sl_lg = 3; P.sl_vc = 4; P.sl_tiles = P.sl_groups = P.sl_chunks = 0;
     P.st_on = 0; P.st_R = 8; P.st_lty = 1; P.st_ltz = 1; P.st_variant = 0; P.st_grid = 0; P.st_tickets = nullptr; P.st_debug = 0; P.st_rec = nullptr; P.st_aux = nullptr;
     P.runs_occ = exp_knob("D3F_EXP_RUNS_OCC");
     P.thin_max_views = (exp_knob("D3F_EXP_THIN") < 0 || (flags & D3F_TUNE_DIRECT_GATHER)) ? 0 : 8;
@@ -478,8 +478,9 @@ int eval_common(const d3f_views *views, const float *pts, int64_t n, const d3f_c
             }
             P.sl_unit = exp_knob("D3F_EXP_SLICED_UNIT") > 0 ? exp_knob("D3F_EXP_SLICED_UNIT") : (big ? 64 : (tiny ? 256 : (mini ? 512 : 128)));   // 4096 points per unit (smaller: slower)
             P.sl_chunks = (P.sl_groups + P.sl_unit - 1) / P.sl_unit;
+            P.sl_ilv = exp_knob("D3F_EXP_SLICED_ILV") >= 2 && exp_knob("D3F_EXP_SLICED_ILV") <= 4 ? exp_knob("D3F_EXP_SLICED_ILV") : 1;
             for (int s = 1; s < n_maps; ++s) pick_mapping(P.maps[s], P.maps[s].vw == 4, P.maps[s].vw >= 2, true, 1);
-            if (((P.sl_chunks * P.sl_slices + 7) / 8) * 8 * P.sl_unit > 0x7fffffffLL) P.sl_slices = 0;
+            if ((((P.sl_chunks * P.sl_slices + 7) / 8) + P.sl_ilv) * 8 * P.sl_unit > 0x7fffffffLL) P.sl_slices = 0;
         }
     }
 #ifdef D3F_EXPERIMENTS
@@ -559,7 +560,7 @@ int eval_common(const d3f_views *views, const float *pts, int64_t n, const d3f_c
         plan_out->tile_points = P.tile_pts;
         plan_out->reorder = walk ? 2 : (reorder ? 1 : 0);
         plan_out->lds_bytes = P.crec_offset + P.n_pre * P.tile_pts * P.V * 32 + P.lds_pad;
-        plan_out->workgroups = P.sl_slices > 0 ? ((P.sl_chunks * P.sl_slices + 7) / 8) * 8 * P.sl_unit : ntiles;
+        plan_out->workgroups = P.sl_slices > 0 ? (((P.sl_chunks * P.sl_slices + 7) / 8 + P.sl_ilv - 1) / P.sl_ilv * P.sl_ilv) * 8 * P.sl_unit : ntiles;
 #ifdef D3F_EXPERIMENTS
         if (P.st_on) plan_out->lds_bytes = d3f::stream_lds_bytes(P.tile_pts, P.V) + P.lds_pad;
 #endif

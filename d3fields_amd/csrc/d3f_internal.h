@@ -48,6 +48,7 @@ struct EvalParams {
     int32_t walk_tx, walk_ty, walk_tz;
     // channel-sliced launch (fused_eval_sliced_kernel): sl_slices > 0 selects it
     int32_t sl_unit;                   // workgroups (of 32 points) per unit
+    int32_t sl_ilv;                    // units an XCD works on at the same time (1: one after the other)
     int32_t sl_slices, sl_lg, sl_vc;   // slices per texel of map 0, log2(lanes per point), views with loads in flight
     int64_t sl_tiles, sl_groups, sl_chunks;   // walk tiles, groups of 4 tiles, chunks of 128 groups
     // persistent producer / consumer form of the channel-sliced launch (fuse_stream.hip): st_on > 0 selects it.  It reuses

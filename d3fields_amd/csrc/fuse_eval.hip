@@ -321,10 +321,12 @@ __device__ __forceinline__ void fused_eval_body(const EvalParams &P)
 // "chunk") are units (chunk, slice) spread over the XCDs: the XCD that owns a unit has its 256 workgroups in flight
 // together and its 4 MiB L2 sees a third of every texel, i.e. a ~3x larger window in points (read hit rate 58 -> 66 %,
 // C2-dense 1.62 -> 1.52 ms).  The price: phase A (projection, depth test, weights, corner set-up) runs once per (point,
-// slice).  512 bytes is the finest slice that pays: a C = 384 fp32 texel is 12 lines, so a narrower slice of every texel
-// lands on a half / a quarter of the L2's channels and sets and the capacity it wins is lost again (round 3 counters:
-// 61 M line fills at 512, 256 and 128 bytes alike, profiles/r3_stream).  Arithmetic per (point, view, channel) is that of
-// gather_map (fast or strict form), so results are identical.
+// slice).  512 bytes is the finest slice that pays: narrower ones repeat phase A more often and remove no fills (round 3
+// counters: 61 M line fills at 512, 256 and 128 bytes alike, profiles/r3_stream -- the fills follow the points in flight,
+// not the L2's capacity: DESIGN.md 5.6 e).  With C = 1024 there are eight slices, one per XCD: all eight L2s work on the
+// same chunk (C4-dense lattice 13.05 -> 9.05 ms).  Clouds take tiles of consecutive points of their Morton order instead
+// of lattice bricks.  Arithmetic per (point, view, channel) is that of gather_map (fast or strict form), so results are
+// identical.
 template <int LG, int VC>                  // lanes per point = 1 << LG: 8 (128-byte slices), 16 (256 B) or 32 (512 B)
 __device__ __forceinline__ void fused_eval_sliced_body(const EvalParams &P)
 {
@@ -345,8 +347,10 @@ __device__ __forceinline__ void fused_eval_sliced_body(const EvalParams &P)
     // unit (chunk, slice) -> XCD blockIdx % 8; the unit's workgroups are consecutive in that XCD's stream
     const int xcd = (int)(blockIdx.x & 7u);
     const int64_t j = (int64_t)(blockIdx.x >> 3);
-    const int64_t unit = (j / P.sl_unit) * 8 + xcd;
-    const int wg = (int)(j % P.sl_unit);
+    // sl_ilv > 1: the XCD's consecutive workgroups alternate between sl_ilv units (other slices of other chunks)
+    const int64_t jj = j / P.sl_ilv;
+    const int64_t unit = ((jj / P.sl_unit) * P.sl_ilv + (j - jj * P.sl_ilv)) * 8 + xcd;
+    const int wg = (int)(jj % P.sl_unit);
     if (unit >= (int64_t)P.sl_chunks * P.sl_slices) return;
     const int64_t chunk = unit / P.sl_slices;
     const int slice = (int)(unit - chunk * P.sl_slices);
@@ -1087,7 +1091,7 @@ hipError_t launch_fused_eval(const EvalParams &P, int mode, hipStream_t stream)
     }
     if (mode == 0 && P.sl_slices > 0) {
         const int64_t units = (int64_t)P.sl_chunks * P.sl_slices;
-        const int64_t wgs = (units + 7) / 8 * 8 * P.sl_unit;
+        const int64_t wgs = ((units + 7) / 8 + P.sl_ilv - 1) / P.sl_ilv * P.sl_ilv * 8 * P.sl_unit;
         const size_t lds_s = (size_t)P.crec_offset + (size_t)P.tile_pts * P.V * 32 + (size_t)P.lds_pad;
         const dim3 gs((unsigned)wgs);
         if (P.sl_lg == 5 && P.sl_vc == 2) hipLaunchKernelGGL((fused_eval_sliced_kernel<5, 2, 7>), gs, block, lds_s, stream, P);
