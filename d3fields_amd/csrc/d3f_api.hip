@@ -1152,7 +1152,8 @@ int d3f_rigid_update(const float *last, int32_t n_inst, int32_t n, const float *
 int64_t d3f_track_step_scratch_bytes(int32_t n_inst, int32_t n)
 {
     if (n_inst < 0 || n < 0) return 0;
-    return ((int64_t)n_inst * n * 3 + 4) * (int64_t)sizeof(float);
+    // gradients [n_inst*n*3], loss slots [4], arrival counter [2] (floats / words), then the tagged parameter words [n_inst*6] (8 bytes each)
+    return (((int64_t)n_inst * n * 3 + 6) * (int64_t)sizeof(float) + 7) / 8 * 8 + (int64_t)n_inst * 6 * 8;
 }
 
 static int track_impl(const d3f_views *views, const d3f_channel_map *descriptors, const float *last, int32_t n_inst, int32_t n,
@@ -1190,7 +1191,8 @@ static int track_impl(const d3f_views *views, const d3f_channel_map *descriptors
     P.t = state->t; P.w = state->w; P.adam_m = state->adam_m; P.adam_v = state->adam_v; P.step = state->step;
     P.out_pts = state->out_pts; P.loss_out = state->loss;
     float *scr = static_cast<float *>(state->scratch);
-    P.grad_pts = scr; P.loss_acc = scr + (int64_t)n_inst * n * 3; P.counter = reinterpret_cast<unsigned int *>(P.loss_acc + 2);
+    P.grad_pts = scr; P.loss_acc = scr + (int64_t)n_inst * n * 3; P.counter = reinterpret_cast<unsigned int *>(P.loss_acc + 4);
+    P.par = reinterpret_cast<unsigned long long *>(static_cast<unsigned char *>(state->scratch) + (((int64_t)n_inst * n * 3 + 6) * 4 + 7) / 8 * 8);
     hipStream_t hs = static_cast<hipStream_t>(stream);
     hipError_t e = d3f::launch_track_step(P, hs);
     return e == hipSuccess ? D3F_OK : hip_fail(e, "track_step launch");

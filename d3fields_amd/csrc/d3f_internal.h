@@ -206,9 +206,10 @@ struct TrackStepParams {
     float *t, *w, *adam_m, *adam_v, *step;     // [I,3] [I,3] [I,6] [I,6] [I]
     float *out_pts;                     // [I*n, 3] the keypoints as evaluated in this step
     float *grad_pts;                    // [I*n, 3] scratch
-    float *loss_acc;                    // [2] accumulators, zero between steps
+    float *loss_acc;                    // [4] two slots of two accumulators (steps alternate), zero between launches
+    unsigned long long *par;            // [I*6] (value, step tag) words: the parameters a multi-step launch publishes
     float *loss_out;                    // [3] feature loss, distance loss, regulariser of this step
-    unsigned int *counter;              // [2] arrivals, published generation; zero between launches
+    unsigned int *counter;              // [2] arrivals (the second word is spare); zero between launches
     int32_t iters;                      // optimiser steps in this launch (> 1: all I*n waves resident, <= kTrackMaxResident)
 };
 constexpr int kTrackMaxResident = 512;       // one wave per SIMD at this kernel's register count = 1024 on the chip; half of it

@@ -25,7 +25,7 @@
 
 namespace d3f {
 
-struct Rot { float m[9]; float th, a, b; bool clamped; };
+struct Rot { float m[9]; float th, a, b, s, c; bool clamped; };           // s, c: sin / cos of th (the update's chain rule reuses them)
 
 // so3_exp_map of one axis-angle vector
 __device__ __forceinline__ Rot exp_map(float wx, float wy, float wz, float eps)
@@ -36,8 +36,10 @@ __device__ __forceinline__ Rot exp_map(float wx, float wy, float wz, float eps)
     const float th = sqrtf(fmaxf(nrm, eps));
     const float inv = 1.0f / th;
     r.th = th;
-    r.a = inv * sinf(th);
-    r.b = inv * inv * (1.0f - cosf(th));
+    r.s = sinf(th);
+    r.c = cosf(th);
+    r.a = inv * r.s;
+    r.b = inv * inv * (1.0f - r.c);
     // K = hat(w); KK = K @ K
     const float K[9] = {0.0f, -wz, wy, wz, 0.0f, -wx, -wy, wx, 0.0f};
 #pragma unroll
@@ -109,11 +111,13 @@ __global__ __launch_bounds__(kBlock) void track_loss_grad_kernel(const float *__
 // arithmetic on registers: the callers load and store the state (plain accesses in rigid_update_kernel; coherent ones
 // inside the multi-step launch, where the wave that runs the update changes from step to step).
 struct AdamState { float t[3], w[3], m[6], v[6], step; };
+struct AdamShared { float g6[6]; float step, step_size, bc2_sqrt; };      // what the six parameter updates of an instance share
 
-__device__ __forceinline__ AdamState rigid_adam_math(const float *G, const AdamState in, float nt, float nw, float eps_rot, float reg_w,
-                                                     float lr, float beta1, float beta2, float eps_adam)
+// gradient of the six parameters (chain rule + regulariser) and Adam's bias corrections for this step
+__device__ __forceinline__ AdamShared rigid_adam_shared(const float *G, const float *t3, const float *w3, float step_in, float nt, float nw,
+                                                        float eps_rot, float reg_w, float lr, float beta1, float beta2)
 {
-    const float wx = in.w[0], wy = in.w[1], wz = in.w[2];
+    const float wx = w3[0], wy = w3[1], wz = w3[2];
     const Rot r = exp_map(wx, wy, wz, eps_rot);
     const float K[9] = {0.0f, -wz, wy, wz, 0.0f, -wx, -wy, wx, 0.0f};
     const float *GR = G + 3;                                            // 3x3, row k, column j
@@ -143,38 +147,51 @@ __device__ __forceinline__ AdamState rigid_adam_math(const float *G, const AdamS
         }
     float gw[3] = {dK[2 * 3 + 1] - dK[1 * 3 + 2], dK[0 * 3 + 2] - dK[2 * 3 + 0], dK[1 * 3 + 0] - dK[0 * 3 + 1]};
     if (!r.clamped) {                                                   // through a(th), b(th), th = |w|
-        const float th = r.th, s = sinf(th), c = cosf(th);
+        const float th = r.th, s = r.s, c = r.c;
         const float da_dth = (th * c - s) / (th * th);
         const float db_dth = (th * s - 2.0f * (1.0f - c)) / (th * th * th);
         const float dth = da * da_dth + db * db_dth;
         gw[0] += dth * wx / th; gw[1] += dth * wy / th; gw[2] += dth * wz / th;
     }
-    float g6[6] = {G[0], G[1], G[2], gw[0], gw[1], gw[2]};
+    AdamShared o;
+    o.g6[0] = G[0]; o.g6[1] = G[1]; o.g6[2] = G[2]; o.g6[3] = gw[0]; o.g6[4] = gw[1]; o.g6[5] = gw[2];
     // regulariser reg_w * (|t|_F + |w|_F): gradient x / |x|_F, 0 at the origin (torch.norm backward)
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
-        if (nt > 0.0f) g6[k] += reg_w * in.t[k] / nt;
-        if (nw > 0.0f) g6[3 + k] += reg_w * in.w[k] / nw;
+        if (nt > 0.0f) o.g6[k] += reg_w * t3[k] / nt;
+        if (nw > 0.0f) o.g6[3 + k] += reg_w * w3[k] / nw;
     }
-    // torch.optim.Adam (amsgrad off, no weight decay): one step of the six parameters of this instance
-    AdamState out;
-    const float st = in.step + 1.0f;
-    out.step = st;
-    const float bc1 = 1.0f - powf(beta1, st), bc2 = 1.0f - powf(beta2, st);
-    const float step_size = lr / bc1, bc2_sqrt = sqrtf(bc2);
+    // torch.optim.Adam (amsgrad off, no weight decay): bias corrections of this step
+    const float st = step_in + 1.0f;
+    o.step = st;
+    // beta^step as exp2(step * log2 beta) on the hardware's log / exp units (relative error < 1e-6 for step <= 1e4; ocml's
+    // powf was a quarter of the update's 3.6 us dependency chain; the reference forms these in double precision on the host)
+    const float bc1 = 1.0f - __builtin_amdgcn_exp2f(st * __builtin_amdgcn_logf(beta1));
+    const float bc2 = 1.0f - __builtin_amdgcn_exp2f(st * __builtin_amdgcn_logf(beta2));
+    o.step_size = lr / bc1;
+    o.bc2_sqrt = sqrtf(bc2);
+    return o;
+}
+
+// Adam's update of one parameter
+__device__ __forceinline__ void rigid_adam_param(float g, float &m, float &v, float &par, float step_size, float bc2_sqrt, float beta1,
+                                                 float beta2, float eps_adam)
+{
+    m = m + (g - m) * (1.0f - beta1);
+    v = v * beta2 + (1.0f - beta2) * (g * g);
+    const float denom = sqrtf(v) / bc2_sqrt + eps_adam;
+    par = par - step_size * (m / denom);
+}
+
+__device__ __forceinline__ AdamState rigid_adam_math(const float *G, const AdamState in, float nt, float nw, float eps_rot, float reg_w,
+                                                     float lr, float beta1, float beta2, float eps_adam)
+{
+    const AdamShared sh = rigid_adam_shared(G, in.t, in.w, in.step, nt, nw, eps_rot, reg_w, lr, beta1, beta2);
+    AdamState out = in;
+    out.step = sh.step;
 #pragma unroll
-    for (int k = 0; k < 6; ++k) {
-        const float par = k < 3 ? in.t[k] : in.w[k - 3];
-        const float g = g6[k];
-        float m = in.m[k], v = in.v[k];
-        m = m + (g - m) * (1.0f - beta1);
-        v = v * beta2 + (1.0f - beta2) * (g * g);
-        out.m[k] = m;
-        out.v[k] = v;
-        const float denom = sqrtf(v) / bc2_sqrt + eps_adam;
-        const float upd = par - step_size * (m / denom);
-        if (k < 3) out.t[k] = upd; else out.w[k - 3] = upd;
-    }
+    for (int k = 0; k < 6; ++k)
+        rigid_adam_param(sh.g6[k], out.m[k], out.v[k], k < 3 ? out.t[k] : out.w[k - 3], sh.step_size, sh.bc2_sqrt, beta1, beta2, eps_adam);
     return out;
 }
 
@@ -242,19 +259,22 @@ __global__ __launch_bounds__(kBlock) void rigid_update_kernel(const float *__res
 // depth, weights, the bilinear gather of the descriptor, |f - src|, its gradient, and the backward of the query (three dot
 // products per view over the same corner texels).  So ONE wave per keypoint does all of it -- the corner texels are
 // gathered once and kept in registers for the forward sum AND the backward dot products -- and leaves dL/dp' (12 bytes).
-// Only the reduction over an instance's keypoints and Adam couple the waves: the last wave to finish (a returning atomic
-// after a release fence; no spinning) does that for every instance, so a step is one launch and the 100 steps of a frame are
-// 100 nodes of a HIP graph.  Same formulas as rigid_transform / fused_eval / track_loss_grad / fused_eval_backward /
-// rigid_update; sums run in another order, so the result agrees with the five-launch step to rounding (tests pin both to
-// the keypoints the reference's own loop returned).
+// Only the reduction over an instance's keypoints and Adam couple the waves: the last wave to arrive (a returning atomic)
+// does that for every instance -- instances side by side in lane groups, one parameter per lane -- so a step is one launch
+// (d3f_track_step), and ALL steps of a frame are one launch too (d3f_track_run): the waves of step k+1 wait for step k's
+// parameters, which travel as step-tagged words.  A step is a chain of dependent operations on ONE wave per SIMD, so its
+// time is latency: what can run side by side does (lane v prepares view v's projection, corner set-up and chain rule; the
+// views' loads and reductions are in flight together).  Same formulas as rigid_transform / fused_eval / track_loss_grad /
+// fused_eval_backward / rigid_update; sums run in another order, so the result agrees with the five-launch step to
+// rounding (tests pin both to the keypoints the reference's own loop returned).
 constexpr int kTrackMaxViews = 8;
 constexpr int kTrackMaxInst = 16;           // instances of the coherent small-problem path (state staged through LDS)
 
 // Device-coherent scalar accesses (agent scope, relaxed: they go to the memory side, past this XCD's L2) for the few words
 // the waves of a launch exchange: per-keypoint gradients, pose parameters, Adam's state, the loss.  With them a step needs
 // no device-scope FENCE -- which on gfx950 writes back and invalidates the whole L2 of the XCD and sends the next step's
-// depth and texel reads back to memory -- only program order: the exchanged stores are complete (s_waitcnt) before the
-// arrival is counted / the generation is published.
+// depth and texel reads back to memory -- only program order: a wave's stores are complete (s_waitcnt) before its
+// arrival is counted, and the updated parameters travel as (value, step tag) words that are their own flag.
 __device__ __forceinline__ float ld_coh(const float *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void st_coh(float *p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void st_coh(unsigned int *p, unsigned int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -293,7 +313,29 @@ __global__ __launch_bounds__(64) void track_step_kernel(const TrackStepParams P)
     // P.iters optimiser steps in this launch (d3f_track_run: > 1, every wave resident, a device-wide barrier between steps)
     for (int it = 0; it < P.iters; ++it) {
     float w0, w1, w2, t0, t1, t2;                                                        // step it-1's update
-    if (small) {
+    if (small && it > 0) {
+        // Waiting for step it-1's update IS reading its result: the six parameters of this instance are published as 64-bit
+        // words (value, step tag), lanes 0..5 poll one word each until all six carry tag `it` (bounded; a wave that never
+        // sees them poisons the loss with NaN and leaves)
+        unsigned long long word = 0ull;
+        unsigned int polls = 0;
+        bool seen = false;
+        while (!seen) {
+            if (lane < 6) word = __hip_atomic_load(P.par + inst * 6 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            seen = __all(lane >= 6 || (unsigned int)(word >> 32) == (unsigned int)it);
+            if (!seen) {
+                __builtin_amdgcn_s_sleep(2);
+                if (++polls > (1u << 21)) break;
+            }
+        }
+        if (!seen) {
+            if (lane < 3) st_coh(P.loss_out + lane, __builtin_nanf(""));
+            return;
+        }
+        const float val = __uint_as_float((unsigned int)word);
+        t0 = __shfl(val, 0, 64); t1 = __shfl(val, 1, 64); t2 = __shfl(val, 2, 64);
+        w0 = __shfl(val, 3, 64); w1 = __shfl(val, 4, 64); w2 = __shfl(val, 5, 64);
+    } else if (small) {
         w0 = ld_coh(P.w + inst * 3); w1 = ld_coh(P.w + inst * 3 + 1); w2 = ld_coh(P.w + inst * 3 + 2);
         t0 = ld_coh(P.t + inst * 3); t1 = ld_coh(P.t + inst * 3 + 1); t2 = ld_coh(P.t + inst * 3 + 2);
     } else {
@@ -337,48 +379,65 @@ __global__ __launch_bounds__(64) void track_step_kernel(const TrackStepParams P)
     const float inv = 1.0f / (cnt + 1e-6f);
     const float dist_out = any_valid ? dsum / (cnt + 1e-6f) : 1e3f;      // fusion.py:366-367
     // ---- forward gather: the corner vectors of every valid view stay in registers ----
+    // Lane v prepares view v's corner set-up (texel coordinates, bounds, weights, element offsets) -- all views at once,
+    // not one after the other -- and the views' loads are issued from what lane v hands over (v_readlane: v is a constant
+    // after unrolling).
     f32x4 ca[kTrackMaxViews][NVEC], cb[kTrackMaxViews][NVEC], cd[kTrackMaxViews][NVEC], ce[kTrackMaxViews][NVEC];
     float wsy[kTrackMaxViews], wex[kTrackMaxViews], wtx[kTrackMaxViews], wty[kTrackMaxViews];
     f32x4 acc[NVEC];
 #pragma unroll
     for (int k = 0; k < NVEC; ++k) acc[k] = (f32x4)0.0f;
-#pragma unroll
-    for (int v = 0; v < kTrackMaxViews; ++v) {
-        if (v >= V) break;
-        const float vv = __shfl(a_valid, v, 64), gx = __shfl(a_gx, v, 64), gy = __shfl(a_gy, v, 64), wg = __shfl(a_wgt, v, 64);
-        wsy[v] = wex[v] = wtx[v] = wty[v] = 0.0f;
-#pragma unroll
-        for (int k = 0; k < NVEC; ++k) ca[v][k] = cb[v][k] = cd[v][k] = ce[v][k] = (f32x4)0.0f;
-        if (vv == 0.0f) continue;                                         // exact: the term is (+-0) for finite maps
-        const float ix = unnormalize(gx, m.fw), iy = unnormalize(gy, m.fh);
+    float c_sy = 0.0f, c_ex = 0.0f, c_tx = 0.0f, c_ty = 0.0f;
+    int c_in = 0;                                                         // bit 0..3: nw, ne, sw, se inside the map; 0: view not valid
+    int64_t c_onw = 0, c_one = 0, c_osw = 0, c_ose = 0;                   // element offsets of the four corner texels
+    if (lane < V && a_valid != 0.0f) {
+        const float ix = unnormalize(a_gx, m.fw), iy = unnormalize(a_gy, m.fh);
         const float x0 = floorf(ix), y0 = floorf(iy);
-        const float tx = ix - x0, ty = iy - y0;
-        const float ex = 1.0f - tx, sy = 1.0f - ty;
+        c_tx = ix - x0; c_ty = iy - y0;
+        c_ex = 1.0f - c_tx; c_sy = 1.0f - c_ty;
         const float x1 = x0 + 1.0f, y1 = y0 + 1.0f;
         const bool inw = in_bounds(x0, y0, m.fw, m.fh), ine = in_bounds(x1, y0, m.fw, m.fh);
         const bool isw = in_bounds(x0, y1, m.fw, m.fh), ise = in_bounds(x1, y1, m.fw, m.fh);
         const int xi0 = (inw || isw) ? (int)x0 : 0, yi0 = (inw || ine) ? (int)y0 : 0;
         const int xi1 = (ine || ise) ? (int)x1 : 0, yi1 = (isw || ise) ? (int)y1 : 0;
-        const float *bv = m.data + (int64_t)v * m.sv;
-        const float *pnw = bv + (int64_t)yi0 * m.sy + (int64_t)xi0 * m.sx, *pne = bv + (int64_t)yi0 * m.sy + (int64_t)xi1 * m.sx;
-        const float *psw = bv + (int64_t)yi1 * m.sy + (int64_t)xi0 * m.sx, *pse = bv + (int64_t)yi1 * m.sy + (int64_t)xi1 * m.sx;
-        wsy[v] = sy; wex[v] = ex; wtx[v] = tx; wty[v] = ty;
+        const int64_t bvo = (int64_t)lane * m.sv;
+        c_onw = bvo + (int64_t)yi0 * m.sy + (int64_t)xi0 * m.sx; c_one = bvo + (int64_t)yi0 * m.sy + (int64_t)xi1 * m.sx;
+        c_osw = bvo + (int64_t)yi1 * m.sy + (int64_t)xi0 * m.sx; c_ose = bvo + (int64_t)yi1 * m.sy + (int64_t)xi1 * m.sx;
+        c_in = (inw ? 1 : 0) | (ine ? 2 : 0) | (isw ? 4 : 0) | (ise ? 8 : 0) | 16;
+    }
+#pragma unroll
+    for (int v = 0; v < kTrackMaxViews; ++v) {
+        if (v >= V) break;
+        const int in_v = __shfl(c_in, v, 64);
+        wsy[v] = __shfl(c_sy, v, 64); wex[v] = __shfl(c_ex, v, 64); wtx[v] = __shfl(c_tx, v, 64); wty[v] = __shfl(c_ty, v, 64);
+#pragma unroll
+        for (int k = 0; k < NVEC; ++k) ca[v][k] = cb[v][k] = cd[v][k] = ce[v][k] = (f32x4)0.0f;
+        if (in_v == 0) continue;                                          // exact: the term is (+-0) for finite maps
+        const float *pnw = m.data + __shfl(c_onw, v, 64), *pne = m.data + __shfl(c_one, v, 64);
+        const float *psw = m.data + __shfl(c_osw, v, 64), *pse = m.data + __shfl(c_ose, v, 64);
 #pragma unroll
         for (int k = 0; k < NVEC; ++k) {
             const int cv = lane + 64 * k;
             if (cv < cvec) {
-                ca[v][k] = inw ? load_vec<f32x4>(pnw + cv * 4) : (f32x4)0.0f;
-                cb[v][k] = ine ? load_vec<f32x4>(pne + cv * 4) : (f32x4)0.0f;
-                cd[v][k] = isw ? load_vec<f32x4>(psw + cv * 4) : (f32x4)0.0f;
-                ce[v][k] = ise ? load_vec<f32x4>(pse + cv * 4) : (f32x4)0.0f;
+                ca[v][k] = (in_v & 1) ? load_vec<f32x4>(pnw + cv * 4) : (f32x4)0.0f;
+                cb[v][k] = (in_v & 2) ? load_vec<f32x4>(pne + cv * 4) : (f32x4)0.0f;
+                cd[v][k] = (in_v & 4) ? load_vec<f32x4>(psw + cv * 4) : (f32x4)0.0f;
+                ce[v][k] = (in_v & 8) ? load_vec<f32x4>(pse + cv * 4) : (f32x4)0.0f;
             }
         }
+    }
+    // the corner loads of EVERY view are in flight before the first is used (one memory round trip, not one per view)
+#pragma unroll
+    for (int v = 0; v < kTrackMaxViews; ++v) {
+        if (v >= V) break;
+        const float vv = __shfl(a_valid, v, 64), wg = __shfl(a_wgt, v, 64);
+        if (vv == 0.0f) continue;                                         // exact: the term is (+-0) for finite maps
 #pragma unroll
         for (int k = 0; k < NVEC; ++k) {
-            f32x4 s_ = ca[v][k] * (sy * ex);                              // ATen bilinear: fma chain nw,ne,sw,se
-            s_ = v_fma<f32x4>(cb[v][k], sy * tx, s_);
-            s_ = v_fma<f32x4>(cd[v][k], ty * ex, s_);
-            s_ = v_fma<f32x4>(ce[v][k], ty * tx, s_);
+            f32x4 s_ = ca[v][k] * (wsy[v] * wex[v]);                      // ATen bilinear: fma chain nw,ne,sw,se
+            s_ = v_fma<f32x4>(cb[v][k], wsy[v] * wtx[v], s_);
+            s_ = v_fma<f32x4>(cd[v][k], wty[v] * wex[v], s_);
+            s_ = v_fma<f32x4>(ce[v][k], wty[v] * wtx[v], s_);
             acc[k] = acc[k] + (s_ * vv) * wg;                             // fusion.py:385
         }
     }
@@ -403,20 +462,20 @@ __global__ __launch_bounds__(64) void track_step_kernel(const TrackStepParams P)
     const float scale = (nrm > 0.0f) ? (vf * invN) / nrm : 0.0f;          // norm backward: 0 at a zero difference
     const float cdist = dist_out * vf;
     const float gd = (any_valid && cdist >= 0.0f) ? P.dist_w * invN * vf : 0.0f;   // clamp(min=0) passes where x >= 0
+    float *const loss_slot = P.loss_acc + 2 * (it & 1);       // two slots: a slot's clearing has landed long before its next use
     if (lane == 0) {
-        atomicAdd(P.loss_acc + 0, nrm * vf * invN);
-        atomicAdd(P.loss_acc + 1, P.dist_w * fmaxf(cdist, 0.0f) * invN);
+        atomicAdd(loss_slot + 0, nrm * vf * invN);
+        atomicAdd(loss_slot + 1, P.dist_w * fmaxf(cdist, 0.0f) * invN);
     }
     // ---- backward of the query (fused_eval_backward_kernel): per valid view three dot products, then the chain rule ----
-    float gxw = 0.0f, gyw = 0.0f, gzw = 0.0f;
+    // The dot products of all views are reduced together (independent shuffle chains), then lane v runs view v's chain rule
+    // on the values it already holds from phase A, and the views' contributions are summed over lanes 0..7.
     const float sxm = 0.5f * (float)(m.fw - 1), sym = 0.5f * (float)(m.fh - 1);    // d(ix)/d(gx), d(iy)/d(gy)
+    float ds[kTrackMaxViews], dx[kTrackMaxViews], dy[kTrackMaxViews];
 #pragma unroll
     for (int v = 0; v < kTrackMaxViews; ++v) {
-        if (v >= V) break;
-        const float vv = __shfl(a_valid, v, 64), wg = __shfl(a_wgt, v, 64), zc = __shfl(a_zc, v, 64);
-        const float uu = __shfl(a_u, v, 64), ww = __shfl(a_w, v, 64), dd = __shfl(a_dist, v, 64);
-        if (vv == 0.0f) continue;
-        float ds = 0.0f, dx = 0.0f, dy = 0.0f;
+        ds[v] = dx[v] = dy[v] = 0.0f;
+        if (v >= V) continue;
 #pragma unroll
         for (int k = 0; k < NVEC; ++k) {
             const f32x4 go = g[k] * scale;                               // dL/df (zero on idle lanes: g = 0)
@@ -426,17 +485,28 @@ __global__ __launch_bounds__(64) void track_step_kernel(const TrackStepParams P)
             s_ = v_fma<f32x4>(ce[v][k], wty[v] * wtx[v], s_);
             const f32x4 dsx = (cb[v][k] - ca[v][k]) * wsy[v] + (ce[v][k] - cd[v][k]) * wty[v];      // ds/dix
             const f32x4 dsy = (cd[v][k] - ca[v][k]) * wex[v] + (ce[v][k] - cb[v][k]) * wtx[v];      // ds/diy
-            ds += hsum<f32x4>(go * s_);
-            dx += hsum<f32x4>(go * dsx);
-            dy += hsum<f32x4>(go * dsy);
+            ds[v] += hsum<f32x4>(go * s_);
+            dx[v] += hsum<f32x4>(go * dsx);
+            dy[v] += hsum<f32x4>(go * dsy);
         }
-        for (int off = 32; off > 0; off >>= 1) {
-            ds += __shfl_xor(ds, off, 64);
-            dx += __shfl_xor(dx, off, 64);
-            dy += __shfl_xor(dy, off, 64);
+    }
+    for (int off = 32; off > 0; off >>= 1)
+#pragma unroll
+        for (int v = 0; v < kTrackMaxViews; ++v) {
+            if (v >= V) continue;
+            ds[v] += __shfl_xor(ds[v], off, 64);
+            dx[v] += __shfl_xor(dx[v], off, 64);
+            dy[v] += __shfl_xor(dy[v], off, 64);
         }
-        const float g_wgt = inv * ds;                                     // dL/dwgt_v
-        const float g_gx = inv * wg * (dx * sxm), g_gy = inv * wg * (dy * sym);
+    float my_ds = 0.0f, my_dx = 0.0f, my_dy = 0.0f;
+#pragma unroll
+    for (int v = 0; v < kTrackMaxViews; ++v)
+        if (lane == v) { my_ds = ds[v]; my_dx = dx[v]; my_dy = dy[v]; }
+    float gxw = 0.0f, gyw = 0.0f, gzw = 0.0f;
+    if (lane < V && a_valid != 0.0f) {
+        const float wg = a_wgt, zc = a_zc, uu = a_u, ww = a_w, dd = a_dist;
+        const float g_wgt = inv * my_ds;                                  // dL/dwgt_v
+        const float g_gx = inv * wg * (my_dx * sxm), g_gy = inv * wg * (my_dy * sym);
         float g_dist = (dd >= -mu && dd <= mu) ? gd * inv : 0.0f;         // clamp passes inside [-mu, mu]
         if (mu - fabsf(dd) <= 0.0f) {                                     // the weight passes where mu - |dist| <= 0
             const float sgn = dd > 0.0f ? 1.0f : (dd < 0.0f ? -1.0f : 0.0f);
@@ -445,10 +515,16 @@ __global__ __launch_bounds__(64) void track_step_kernel(const TrackStepParams P)
         const float g_u = g_gx * 2.0f / Wm1, g_w = g_gy * 2.0f / Hm1;
         const float g_xc = g_u / zc, g_yc = g_w / zc;
         const float g_zc = -(g_u * uu + g_w * ww) / zc - g_dist;
-        const float *M = krt + v * 12;
-        gxw += g_xc * M[0] + g_yc * M[4] + g_zc * M[8];
-        gyw += g_xc * M[1] + g_yc * M[5] + g_zc * M[9];
-        gzw += g_xc * M[2] + g_yc * M[6] + g_zc * M[10];
+        const float *M = krt + lane * 12;
+        gxw = g_xc * M[0] + g_yc * M[4] + g_zc * M[8];
+        gyw = g_xc * M[1] + g_yc * M[5] + g_zc * M[9];
+        gzw = g_xc * M[2] + g_yc * M[6] + g_zc * M[10];
+    }
+#pragma unroll
+    for (int off = 4; off > 0; off >>= 1) {                               // lanes 0..7 (kTrackMaxViews): lane 0 gets the sum
+        gxw += __shfl_xor(gxw, off, 64);
+        gyw += __shfl_xor(gyw, off, 64);
+        gzw += __shfl_xor(gzw, off, 64);
     }
     if (lane == 0) {
         if (small) { st_coh(P.grad_pts + p * 3 + 0, gxw); st_coh(P.grad_pts + p * 3 + 1, gyw); st_coh(P.grad_pts + p * 3 + 2, gzw); }
@@ -456,8 +532,10 @@ __global__ __launch_bounds__(64) void track_step_kernel(const TrackStepParams P)
     }
     // ---- the last wave to finish reduces per instance and steps Adam (rigid_update_kernel) ----
     // The arrival counter runs on across the steps of a launch (step `it` is complete at N*(it+1) arrivals); the wave that
-    // completes it updates the parameters, clears the loss accumulators and publishes generation it+1, which the other
-    // waves of a multi-step launch wait for (bounded: a wave that never sees it poisons the loss with NaN and leaves).
+    // completes it updates the parameters and publishes them tagged with it+1, which is what the waves of the next step
+    // wait for at its top.  Nothing else is ordered by hand: whatever the updating wave stores besides the tagged words
+    // (Adam's state, the cleared loss slot) is read again only by a later updating wave, i.e. after this wave's own next
+    // arrival, before which it waits for its stores (order_release).
     if (small) order_release(); else __threadfence();                     // grad_pts / loss are out before the arrival counts
     unsigned int ticket = 0;
     if (lane == 0) ticket = atomicAdd(P.counter, 1u);
@@ -465,21 +543,7 @@ __global__ __launch_bounds__(64) void track_step_kernel(const TrackStepParams P)
     const bool last_step = it + 1 == P.iters;
     if (ticket != (unsigned int)N * (unsigned int)(it + 1) - 1u) {
         if (last_step) return;
-        int ok = 1;
-        if (lane == 0) {
-            unsigned int polls = 0;
-            while (__hip_atomic_load(P.counter + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned int)(it + 1)) {
-                __builtin_amdgcn_s_sleep(4);
-                if (++polls > (1u << 21)) { ok = 0; break; }
-            }
-        }
-        ok = __builtin_amdgcn_readfirstlane(ok);
-        if (!ok) {
-            if (lane < 3) st_coh(P.loss_out + lane, __builtin_nanf(""));
-            return;
-        }
-        order_acquire();                                                  // (a multi-step launch is always `small`)
-        continue;
+        continue;                                                         // (a multi-step launch is always `small`)
     }
     if (small) {
         // ---- the update, coherent form: ONE round of loads (everything the update reads, spread over the lanes, into LDS),
@@ -489,18 +553,25 @@ __global__ __launch_bounds__(64) void track_step_kernel(const TrackStepParams P)
         const int I = P.I;
         for (int k = lane; k < I * 19 + 2; k += 64) {
             const float *src_k = k < 3 * I ? P.t + k : k < 6 * I ? P.w + (k - 3 * I) : k < 12 * I ? P.adam_m + (k - 6 * I)
-                               : k < 18 * I ? P.adam_v + (k - 12 * I) : k < 19 * I ? P.step + (k - 18 * I) : P.loss_acc + (k - 19 * I);
+                               : k < 18 * I ? P.adam_v + (k - 12 * I) : k < 19 * I ? P.step + (k - 18 * I) : loss_slot + (k - 19 * I);
             sh_p[k] = ld_coh(src_k);
         }
         __syncthreads();
         float st = 0.0f, sw = 0.0f;                                       // |t|_F, |w|_F over ALL instances, before the update
         for (int k = 0; k < I * 3; ++k) { st += sh_p[k] * sh_p[k]; sw += sh_p[3 * I + k] * sh_p[3 * I + k]; }
         const float nt = sqrtf(st), nw = sqrtf(sw);
-        for (int i = 0; i < I; ++i) {
+        // Instances side by side: 64 / 32 / 16 / 8 lanes per instance (I = 1 / 2 / <= 4 / more; eight instances per pass),
+        // a lane group reduces its instance's keypoints, every lane of the group forms the shared part (chain rule, bias
+        // corrections: one latency for all instances) and lanes 0..5 of the group update one parameter each.
+        const int glog = I <= 1 ? 6 : I <= 2 ? 5 : I <= 4 ? 4 : 3, gsz = 1 << glog;
+        for (int ib = 0; ib < I; ib += 64 >> glog) {
+            const int i_raw = ib + (lane >> glog), k = lane & (gsz - 1);
+            const bool active = i_raw < I;
+            const int i = active ? i_raw : I - 1;
             float G[12];
 #pragma unroll
-            for (int k = 0; k < 12; ++k) G[k] = 0.0f;
-            for (int pp = lane; pp < P.n; pp += 64) {
+            for (int q = 0; q < 12; ++q) G[q] = 0.0f;
+            for (int pp = k; pp < P.n; pp += gsz) {
                 const int b = (i * P.n + pp) * 3;
                 const float gx = sh_g[b], gy = sh_g[b + 1], gz = sh_g[b + 2];
                 const float px = sh_l[b], py = sh_l[b + 1], pz = sh_l[b + 2];
@@ -509,35 +580,36 @@ __global__ __launch_bounds__(64) void track_step_kernel(const TrackStepParams P)
                 G[6] += py * gx; G[7] += py * gy; G[8] += py * gz;
                 G[9] += pz * gx; G[10] += pz * gy; G[11] += pz * gz;
             }
+            for (int off = 1; off < gsz; off <<= 1)
 #pragma unroll
-            for (int k = 0; k < 12; ++k)
-                for (int off = 32; off > 0; off >>= 1) G[k] += __shfl_xor(G[k], off, 64);
-            AdamState in;                                                 // every lane computes the same update; lane 0 stores it
-#pragma unroll
-            for (int k = 0; k < 3; ++k) { in.t[k] = sh_p[i * 3 + k]; in.w[k] = sh_p[3 * I + i * 3 + k]; }
-#pragma unroll
-            for (int k = 0; k < 6; ++k) { in.m[k] = sh_p[6 * I + i * 6 + k]; in.v[k] = sh_p[12 * I + i * 6 + k]; }
-            in.step = sh_p[18 * I + i];
-            const AdamState o = rigid_adam_math(G, in, nt, nw, P.eps_rot, P.reg_w, P.lr, P.beta1, P.beta2, P.eps_adam);
-            if (lane == 0) {
-#pragma unroll
-                for (int k = 0; k < 3; ++k) { st_coh(P.t + i * 3 + k, o.t[k]); st_coh(P.w + i * 3 + k, o.w[k]); }
-#pragma unroll
-                for (int k = 0; k < 6; ++k) { st_coh(P.adam_m + i * 6 + k, o.m[k]); st_coh(P.adam_v + i * 6 + k, o.v[k]); }
-                st_coh(P.step + i, o.step);
+                for (int q = 0; q < 12; ++q) G[q] += __shfl_xor(G[q], off, 64);
+            const float t3[3] = {sh_p[i * 3], sh_p[i * 3 + 1], sh_p[i * 3 + 2]};
+            const float w3[3] = {sh_p[3 * I + i * 3], sh_p[3 * I + i * 3 + 1], sh_p[3 * I + i * 3 + 2]};
+            const AdamShared sh = rigid_adam_shared(G, t3, w3, sh_p[18 * I + i], nt, nw, P.eps_rot, P.reg_w, P.lr, P.beta1, P.beta2);
+            if (active && k < 6) {
+                const float g = k == 0 ? sh.g6[0] : k == 1 ? sh.g6[1] : k == 2 ? sh.g6[2] : k == 3 ? sh.g6[3] : k == 4 ? sh.g6[4] : sh.g6[5];
+                float mk = sh_p[6 * I + i * 6 + k], vk = sh_p[12 * I + i * 6 + k];
+                float par = k < 3 ? sh_p[i * 3 + k] : sh_p[3 * I + i * 3 + (k - 3)];
+                rigid_adam_param(g, mk, vk, par, sh.step_size, sh.bc2_sqrt, P.beta1, P.beta2, P.eps_adam);
+                st_coh(k < 3 ? P.t + i * 3 + k : P.w + i * 3 + (k - 3), par);
+                st_coh(P.adam_m + i * 6 + k, mk);
+                st_coh(P.adam_v + i * 6 + k, vk);
+                if (!last_step) {                                         // what the next step's waves wait for
+                    const unsigned long long word = ((unsigned long long)(unsigned int)(it + 1) << 32) | (unsigned long long)__float_as_uint(par);
+                    __hip_atomic_store(P.par + i * 6 + k, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
             }
+            if (active && k == 6) st_coh(P.step + i, sh.step);
         }
         if (lane == 0) {
             st_coh(P.loss_out + 0, sh_p[19 * I]);
             st_coh(P.loss_out + 1, sh_p[19 * I + 1]);
             st_coh(P.loss_out + 2, P.reg_w * (nt + nw));
-            st_coh(P.loss_acc + 0, 0.0f); st_coh(P.loss_acc + 1, 0.0f);  // clean for the next step
+            st_coh(loss_slot + 0, 0.0f); st_coh(loss_slot + 1, 0.0f);    // clean for the step after the next
             if (last_step) { st_coh(P.counter, 0u); st_coh(P.counter + 1, 0u); }      // every wave has arrived: nobody waits any more
         }
         if (last_step) return;
-        __syncthreads();                                                  // LDS reads above are done before the next update overwrites it
-        order_release();                                                  // parameters, cleared accumulators
-        if (lane == 0) __hip_atomic_store(P.counter + 1, (unsigned int)(it + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();                                                  // LDS reads above are done before this wave stages again
         continue;
     }
     // ---- the update for larger problems (one step per launch): fences + plain accesses ----
@@ -574,12 +646,14 @@ __global__ __launch_bounds__(64) void track_step_kernel(const TrackStepParams P)
     }
 }
 
-// clears the four words a multi-step launch synchronises through (a memset node of a captured HIP graph replayed these
-// 16 bytes wrongly on ROCm 7.2 -- the second replay found a host pointer in them; a kernel node replays as recorded)
-__global__ void track_reset_kernel(float *loss_acc, unsigned int *counter)
+// clears what a multi-step launch synchronises through: the loss slots, the arrival counter and the tagged parameter
+// words (a memset node of a captured HIP graph replayed 16 such bytes wrongly on ROCm 7.2 -- the second replay found a
+// host pointer in them; a kernel node replays as recorded)
+__global__ void track_reset_kernel(float *loss_acc, unsigned int *counter, unsigned long long *par, int n_par)
 {
-    if (threadIdx.x < 2) loss_acc[threadIdx.x] = 0.0f;
-    else if (threadIdx.x < 4) counter[threadIdx.x - 2] = 0u;
+    if (threadIdx.x < 4) loss_acc[threadIdx.x] = 0.0f;
+    else if (threadIdx.x < 6) counter[threadIdx.x - 4] = 0u;
+    for (int k = threadIdx.x; k < n_par; k += 64) par[k] = 0ull;
 }
 
 hipError_t launch_track_step(const TrackStepParams &P, hipStream_t s)
@@ -589,7 +663,7 @@ hipError_t launch_track_step(const TrackStepParams &P, hipStream_t s)
     // several steps per launch wait for one another inside the kernel: every wave must be resident (one per SIMD at
     // this register count: 1024 on the chip; the bound leaves half of that to whatever else runs)
     if (P.iters > 1 && (N > kTrackMaxResident || P.I > kTrackMaxInst)) return hipErrorInvalidValue;
-    if (P.iters > 1) hipLaunchKernelGGL(track_reset_kernel, dim3(1), dim3(64), 0, s, P.loss_acc, P.counter);
+    if (P.iters > 1) hipLaunchKernelGGL(track_reset_kernel, dim3(1), dim3(64), 0, s, P.loss_acc, P.counter, P.par, P.I * 6);
     const int nvec = (P.map.C / 4 + 63) / 64;
     if (nvec <= 1) hipLaunchKernelGGL(track_step_kernel<1>, dim3((unsigned)N), dim3(64), 0, s, P);
     else if (nvec == 2) hipLaunchKernelGGL(track_step_kernel<2>, dim3((unsigned)N), dim3(64), 0, s, P);

@@ -437,11 +437,11 @@ int d3f_track_step(const d3f_views *views, const d3f_channel_map *descriptors, c
                    const d3f_track_state *state, void *stream);
 
 /* `iters` optimiser steps (the whole loop of fusion.py:1650-1665 for one frame) in ONE launch: the waves of step k+1 wait
- * inside the kernel for the Adam update of step k (a device-wide arrival counter and a published generation in `scratch`),
+ * inside the kernel for the Adam update of step k (a device-wide arrival counter and step-tagged parameter words in `scratch`),
  * so K / pose / the source descriptors are read once per frame and no launch boundary separates the steps.  Same
  * arithmetic per step as d3f_track_step (same t / w / out_pts / loss as `iters` calls of it).  Every workgroup must be
  * resident while the others wait: n_inst*n <= d3f_track_run_max_keypoints() (512) and n_inst <= 16, else D3F_ERR_BAD_SHAPE -- call
- * d3f_track_step per iteration then.  The wait is bounded: should a wave never see the next generation (the device shared
+ * d3f_track_step per iteration then.  The wait is bounded: should a wave never see the next step's parameters (the device shared
  * with another kernel that never ends), loss[0..2] become NaN and the launch ends.  scratch is cleared at the start (a
  * one-workgroup launch ahead of the step kernel). */
 int d3f_track_run(const d3f_views *views, const d3f_channel_map *descriptors, const float *last, int32_t n_inst, int32_t n,
