@@ -412,3 +412,65 @@ def test_voxel_downsample_matches_open3d_definition(dev):
     cloud = pcd_utils.aggr_point_cloud_from_data(g["color"], g["depth"].astype(np.float64), g["K"].astype(np.float64),
                                                  np.concatenate([g["pose"], np.tile(np.array([[[0, 0, 0, 1.0]]]), (4, 1, 1))], 1).astype(np.float64))
     assert len(np.asarray(cloud.points)) > 0 and np.asarray(cloud.colors).shape == np.asarray(cloud.points).shape   # defaults: downsample, o3d-like
+
+
+# ---- d3f_track_run (all optimiser steps of a frame in one launch) == the same steps as single launches ----------------
+@pytest.mark.parametrize("I,n,V,C", [(1, 64, 4, 384), (3, 20, 2, 128), (5, 33, 8, 512), (16, 32, 4, 64), (2, 7, 3, 48)])
+def test_track_run_equals_track_steps(dev, I, n, V, C):
+    """One launch for `iters` steps (waves wait for each step's step-tagged parameters inside the kernel) leaves the same
+    translations, rotations and keypoints, bit for bit, as `iters` launches of d3f_track_step: one to sixteen instances
+    (64 / 32 / 16 / 8 update lanes per instance), up to the 512 keypoints the entry point accepts, one or two channel
+    vectors per lane, two to eight views; frame after frame through the captured graph."""
+    from d3fields_amd import Fusion, rigid, synth
+    H, W = 96, 128
+    sc = synth.make_scene(V, H, W, "smooth")
+    f = Fusion(num_cam=V, device=str(dev))
+    f.curr_obs_torch = {k: sc[k].to(dev) for k in ("depth", "K", "pose")}
+    f.curr_obs_torch["dino_feats"] = synth.random_map(V, H // 2, W // 2, C, seed=4, device=dev)
+    f.H, f.W = H, W
+    g = torch.Generator().manual_seed(I * 100 + n)
+    last = synth.random_cloud(I * n, seed=I + n).view(I, n, 3).to(dev)
+    with torch.no_grad():
+        src = f.eval((last.view(-1, 3) + 0.004).contiguous(), return_names=["dino_feats"])["dino_feats"]
+        src = src + 0.01 * torch.randn(src.shape, generator=g).to(dev)
+    results = {}
+    for loop in (False, True):
+        tr = rigid.RigidTracker(f, I, n, iters=12, loop_launch=loop)
+        assert tr.single and tr.loop == loop
+        for frame in range(2):                                   # the second frame replays the captured graph
+            cur, loss = tr.run(f, src, last)
+        torch.cuda.synchronize()
+        results[loop] = (tr.t_params.clone(), tr.log_r.clone(), cur.clone(), float(loss), tr.state[I * 12:I * 13].clone())
+    a, b = results[False], results[True]
+    assert torch.equal(a[4], b[4]) and a[4].eq(12.0).all()       # Adam's step counters
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])
+    assert a[0].abs().max() > 0 and torch.isfinite(a[2]).all()
+    assert abs(a[3] - b[3]) <= 1e-5 * max(1.0, abs(a[3]))        # the loss terms are float atomics: order varies
+
+
+def test_track_run_refuses_what_cannot_be_resident(dev):
+    import ctypes
+    from d3fields_amd import _lib, rigid, Fusion, synth
+    lib = _lib.load()
+    assert lib.d3f_track_run_max_keypoints() == 512
+    V, H, W, C = 4, 96, 128, 64
+    sc = synth.make_scene(V, H, W, "smooth")
+    f = Fusion(num_cam=V, device=str(dev))
+    f.curr_obs_torch = {k: sc[k].to(dev) for k in ("depth", "K", "pose")}
+    f.curr_obs_torch["dino_feats"] = synth.random_map(V, H // 2, W // 2, C, seed=4, device=dev)
+    f.H, f.W = H, W
+    tr = rigid.RigidTracker(f, 2, 300)                           # 600 keypoints: one launch per step instead
+    assert tr.single and not tr.loop
+    tr17 = rigid.RigidTracker(f, 17, 8)                          # 17 instances: likewise
+    assert tr17.single and not tr17.loop
+    views, keep, _ = f._views(dev)
+    fm = f.curr_obs_torch["dino_feats"]
+    cm = _lib.ChannelMap(fm.data_ptr(), fm.shape[1], fm.shape[2], fm.shape[3], _lib.DTYPE_F32, fm.stride(0), fm.stride(1), fm.stride(2))
+    st = tr.state
+    state = _lib.TrackState(_lib.ptr(tr.t_params), _lib.ptr(tr.log_r), _lib.ptr(st[:12]), _lib.ptr(st[12:24]), _lib.ptr(st[24:26]),
+                            _lib.ptr(tr.pts), _lib.ptr(tr.loss3), _lib.ptr(tr.scratch))
+    rc = lib.d3f_track_run(ctypes.byref(views), ctypes.byref(cm), _lib.ptr(tr.last), 2, 300, _lib.ptr(tr.src), 0.02, 100.0, 1.0, 0.01,
+                           0.9, 0.999, 1e-8, 5, ctypes.byref(state), _lib.current_stream_handle(dev))
+    assert rc == _lib.ERR_BAD_SHAPE and b"resident" in lib.d3f_last_error()
+    assert lib.d3f_track_run(ctypes.byref(views), ctypes.byref(cm), _lib.ptr(tr.last), 2, 300, _lib.ptr(tr.src), 0.02, 100.0, 1.0, 0.01,
+                             0.9, 0.999, 1e-8, 0, ctypes.byref(state), _lib.current_stream_handle(dev)) == 0     # no steps: nothing to do
