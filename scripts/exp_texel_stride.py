@@ -13,7 +13,8 @@ dense = f.curr_obs_torch["dino_feats"]
 V, H, W, C = dense.shape
 ref = None
 with torch.no_grad():
-    for stride in (C, C + 32, C + 64, C + 96, C + 128, C + 160, 2 * C):
+    strides = [int(x) for x in sys.argv[2:]] or [C, C + 32, C + 64, C + 96, C + 128, C + 160, 2 * C]
+    for stride in strides:
         if stride == C:
             m = dense
         else:
