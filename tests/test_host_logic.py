@@ -198,6 +198,11 @@ def test_bench_gpus_n_is_a_single_command(monkeypatch):
     assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
     # free ports are picked per launch
     assert bench.spawn_command(2, [])[9] != "0"
+    # --force-dist: ONE self-spawned rank takes the multi-rank path (the RCCL plumbing self-test of a one-GPU box)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "1", "--force-dist", "--steps", "3"])
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert e.value.code == 3 and seen["cmd"][4:6] == ["--nproc-per-node", "1"] and "--force-dist" in seen["cmd"]
 
 
 def test_fusion_float16_warns_about_its_meaning():
