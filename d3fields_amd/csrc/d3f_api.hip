@@ -487,7 +487,7 @@ int eval_common(const d3f_views *views, const float *pts, int64_t n, const d3f_c
     // EXPERIMENTS BUILD ONLY (round 3, measured and rejected): the persistent producer / consumer form of the
     // channel-sliced launch (experiments/fuse_stream.hip): same eligibility, four views, finite maps.  D3F_EXP_STREAM=1 selects it; _T 12 / 16 / 24 points per
     // tile, _VAR register-set variant, _R tiles per workgroup, _UNIT workgroups per unit, _LG 5 / 4 (512- / 256-byte slices).
-    if (P.sl_slices > 0 && exp_knob("D3F_EXP_STREAM") > 0 && views->V == 4 && (flags & D3F_FLAG_FINITE_MAPS) && P.maps[0].C % 128 == 0) {
+    if (P.sl_slices > 0 && walk && exp_knob("D3F_EXP_STREAM") > 0 && views->V == 4 && (flags & D3F_FLAG_FINITE_MAPS) && P.maps[0].C % 128 == 0) {
         int T = exp_knob("D3F_EXP_STREAM_T");
         if (T != 12 && T != 16 && T != 24) T = 12;
         int lg = exp_knob("D3F_EXP_STREAM_LG");
