@@ -296,8 +296,10 @@ def main():
     f, pts, names, w, sc = build_workload(args.workload, dev, rank, world, args.points)
     f.tuning_flags = args.tuning
     # The shim can keep what it learned about an unchanged query tensor between calls (its lattice dims, or its Morton
-    # order): every timed step here starts from scratch instead -- the lattice probe (one tiny kernel + one host sync)
-    # or the Morton sort is INSIDE every step -- and the cached figure is reported separately below.
+    # order): every timed step here starts from scratch instead -- the probe kernels (lattice + locality, ~10 us) or the
+    # Morton sort are enqueued INSIDE every step; with async_probes the launch follows the verdict of the last FINISHED
+    # probes of a query of the same size, so a steady-state step holds NO host sync (only the first query of a size
+    # waits once) -- and the cached figure is reported separately below.
     f.cache_point_order = False
     n = pts.shape[0]
     from d3fields_amd import sharding

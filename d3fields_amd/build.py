@@ -33,7 +33,7 @@ FINGERPRINT_PATH = LIB_PATH + ".fingerprint"
 
 
 # kernels measured and rejected, kept for reproducing the tuning sessions: compiled ONLY with D3F_BUILD_EXPERIMENTS=1
-EXPERIMENT_SOURCES = ["experiments/fuse_stream.hip"]
+EXPERIMENT_SOURCES = []
 
 
 def _sources():

@@ -247,7 +247,6 @@ int eval_common(const d3f_views *views, const float *pts, int64_t n, const d3f_c
     P.grid_ny = grid ? grid->ny : 0; P.grid_nz = grid ? grid->nz : 0;
     P.walk_nx = P.walk_ny = P.walk_nz = 0; P.walk_tx = P.walk_ty = P.walk_tz = 1;
     P.sl_unit = 128; P.sl_ilv = 1; P.sl_slices = 0; P.sl_lg = 3; P.sl_vc = 4; P.sl_tiles = P.sl_groups = P.sl_chunks = 0;
-    P.st_on = 0; P.st_R = 8; P.st_lty = 1; P.st_ltz = 1; P.st_variant = 0; P.st_grid = 0; P.st_tickets = nullptr; P.st_debug = 0; P.st_rec = nullptr; P.st_aux = nullptr;
     P.runs_occ = exp_knob("D3F_EXP_RUNS_OCC");
     P.thin_max_views = (exp_knob("D3F_EXP_THIN") < 0 || (flags & D3F_TUNE_DIRECT_GATHER)) ? 0 : 8;
     P.win_lpp = exp_knob("D3F_EXP_WINDOW_LPP") == 32 ? 32 : 16;     // 16 lanes x 2 vectors per point (C2 patch 0.565 -> 0.54 ms); U > 1: 32
@@ -483,44 +482,6 @@ int eval_common(const d3f_views *views, const float *pts, int64_t n, const d3f_c
             if ((((P.sl_chunks * P.sl_slices + 7) / 8) + P.sl_ilv) * 8 * P.sl_unit > 0x7fffffffLL) P.sl_slices = 0;
         }
     }
-#ifdef D3F_EXPERIMENTS
-    // EXPERIMENTS BUILD ONLY (round 3, measured and rejected): the persistent producer / consumer form of the
-    // channel-sliced launch (experiments/fuse_stream.hip): same eligibility, four views, finite maps.  D3F_EXP_STREAM=1 selects it; _T 12 / 16 / 24 points per
-    // tile, _VAR register-set variant, _R tiles per workgroup, _UNIT workgroups per unit, _LG 5 / 4 (512- / 256-byte slices).
-    if (P.sl_slices > 0 && walk && exp_knob("D3F_EXP_STREAM") > 0 && views->V == 4 && (flags & D3F_FLAG_FINITE_MAPS) && P.maps[0].C % 128 == 0) {
-        int T = exp_knob("D3F_EXP_STREAM_T");
-        if (T != 12 && T != 16 && T != 24) T = 12;
-        int lg = exp_knob("D3F_EXP_STREAM_LG");
-        if (lg != 3 && lg != 4 && lg != 5) lg = 5;
-        if (P.maps[0].C % (4 << lg) != 0) lg = 5;
-        P.st_variant = exp_knob("D3F_EXP_STREAM_VAR");
-        P.walk_tx = T == 16 ? 2 : 3; P.walk_ty = 2; P.walk_tz = T == 12 ? 2 : 4;
-        P.st_lty = 1; P.st_ltz = T == 12 ? 1 : 2;
-        P.sl_lg = lg;
-        P.sl_slices = P.maps[0].C / (4 << lg);
-        P.sl_tiles = (int64_t)((P.walk_nx + P.walk_tx - 1) / P.walk_tx) * ((P.walk_ny + P.walk_ty - 1) / P.walk_ty) * ((P.walk_nz + P.walk_tz - 1) / P.walk_tz);
-        P.st_R = exp_knob("D3F_EXP_STREAM_R") > 0 ? exp_knob("D3F_EXP_STREAM_R") : 8;
-        P.sl_unit = exp_knob("D3F_EXP_STREAM_UNIT") > 0 ? exp_knob("D3F_EXP_STREAM_UNIT") : 192;
-        // small lattices: keep >= ~16 workgroups per CU slot in the launch
-        while (P.st_R > 1 && P.sl_tiles * P.sl_slices / P.st_R < 256 * 6 * 4) P.st_R >>= 1;
-        const int64_t per_chunk = (int64_t)P.sl_unit * P.st_R;
-        P.sl_chunks = (P.sl_tiles + per_chunk - 1) / per_chunk;
-        P.sl_groups = 0;
-        P.tile_pts = T; P.lds_pad = exp_knob("D3F_EXP_SLICED_PAD") > 0 ? exp_knob("D3F_EXP_SLICED_PAD") * 1024 : 0;
-        P.st_debug = exp_knob("D3F_EXP_STREAM_DEBUG");
-        if (exp_knob("D3F_EXP_STREAM_TICKETS") > 0 && !plan_only) {
-            P.st_tickets = d3f::stream_exp_tickets();
-            P.st_grid = exp_knob("D3F_EXP_STREAM_G") > 0 ? exp_knob("D3F_EXP_STREAM_G") : 96;
-            if (exp_knob("D3F_EXP_STREAM_PRE") > 0) {
-                const int64_t slots = P.sl_tiles * T;
-                char *buf = static_cast<char *>(d3f::stream_exp_scratch(slots * (views->V * 16 + 16)));
-                if (buf) { P.st_rec = buf; P.st_aux = buf + slots * views->V * 16; }
-            }
-        }
-        P.st_on = ((P.sl_chunks * P.sl_slices + 7) / 8) * 8 * P.sl_unit <= 0x7fffffffLL ? 1 : 0;
-        if (!P.st_on) P.sl_slices = 0;
-    }
-#endif
     if (window) {
         const int T = (win_knob == 32 || win_knob == 64 || win_knob == 128) ? win_knob : 64;
         P.tile_pts = T; P.lds_pad = 0;
@@ -561,14 +522,11 @@ int eval_common(const d3f_views *views, const float *pts, int64_t n, const d3f_c
         plan_out->reorder = walk ? 2 : (reorder ? 1 : 0);
         plan_out->lds_bytes = P.crec_offset + P.n_pre * P.tile_pts * P.V * 32 + P.lds_pad;
         plan_out->workgroups = P.sl_slices > 0 ? (((P.sl_chunks * P.sl_slices + 7) / 8 + P.sl_ilv - 1) / P.sl_ilv * P.sl_ilv) * 8 * P.sl_unit : ntiles;
-#ifdef D3F_EXPERIMENTS
-        if (P.st_on) plan_out->lds_bytes = d3f::stream_lds_bytes(P.tile_pts, P.V) + P.lds_pad;
-#endif
         if (P.win_slices > 0) {
             plan_out->lds_bytes = P.win_pool_offset + (2 + P.win_pool_texels) * 512 * P.win_u;
             plan_out->workgroups = ntiles;
         }
-        plan_out->reserved = P.st_on ? 3000 + P.sl_lg * 100 + P.st_variant : P.sl_slices > 0 ? 100 + P.sl_lg * 10 + P.sl_vc : (P.win_slices > 0 ? 2000 + 100 * P.win_u + 10 * (P.win_u == 1 ? (P.win_lpp == 16 ? 2 : 4) : (P.win_u == 4 ? 1 : P.win_vc)) + (P.win_u == 1 ? (P.win_occ >= 4 ? 4 : (P.win_lpp == 16 ? 3 : P.win_occ)) : 2) : 0);   // 2UVW: the window kernel's template arguments      // 1LV: sliced launch, L = log2(lanes per point), V = views in flight
+        plan_out->reserved = P.sl_slices > 0 ? 100 + P.sl_lg * 10 + P.sl_vc : (P.win_slices > 0 ? 2000 + 100 * P.win_u + 10 * (P.win_u == 1 ? (P.win_lpp == 16 ? 2 : 4) : (P.win_u == 4 ? 1 : P.win_vc)) + (P.win_u == 1 ? (P.win_occ >= 4 ? 4 : (P.win_lpp == 16 ? 3 : P.win_occ)) : 2) : 0);   // 2UVW: the window kernel's template arguments      // 1LV: sliced launch, L = log2(lanes per point), V = views in flight
         for (int s = 0; s < n_maps; ++s)
             if (P.maps[s].runs > 0) {        // waves per SIMD the chosen cell-run kernel variant is built for
                 const int ru = P.maps[s].unroll, rk = P.maps[s].runs;
@@ -587,11 +545,7 @@ int eval_common(const d3f_views *views, const float *pts, int64_t n, const d3f_c
     hipEvent_t ev0 = g_prof_start, ev1 = g_prof_stop;
     g_prof_start = g_prof_stop = nullptr;
     if (ev0) (void)hipEventRecord(ev0, hs);
-#ifdef D3F_EXPERIMENTS
-    hipError_t e = P.st_on ? d3f::launch_fused_stream(P, hs) : d3f::launch_fused_eval(P, mode, hs);
-#else
     hipError_t e = d3f::launch_fused_eval(P, mode, hs);
-#endif
     if (ev1) (void)hipEventRecord(ev1, hs);
     if (e != hipSuccess) return hip_fail(e, "fused_eval launch");
     return D3F_OK;

@@ -51,15 +51,6 @@ struct EvalParams {
     int32_t sl_ilv;                    // units an XCD works on at the same time (1: one after the other)
     int32_t sl_slices, sl_lg, sl_vc;   // slices per texel of map 0, log2(lanes per point), views with loads in flight
     int64_t sl_tiles, sl_groups, sl_chunks;   // walk tiles, groups of 4 tiles, chunks of 128 groups
-    // persistent producer / consumer form of the channel-sliced launch (fuse_stream.hip): st_on > 0 selects it.  It reuses
-    // sl_slices / sl_lg / sl_tiles / sl_chunks / sl_unit (workgroups per unit); a unit's chunk is sl_unit * st_R tiles
-    int32_t st_on, st_R;               // tiles per workgroup
-    int32_t st_lty, st_ltz;            // log2 of the tile brick's y and z sides (walk_ty, walk_tz; walk_tx is free)
-    int32_t st_variant;                // 0: two register sets (pipelined rounds), 1: one set, 2: one set of four views
-    int32_t st_debug;                  // experiments: 1 consumers idle, 2 producer idle after three tiles (results wrong)
-    int32_t st_grid;                   // ticket mode: persistent workgroups per XCD
-    void *st_rec, *st_aux;             // geometry pre-pass record stream (experiment), or nullptr
-    unsigned int *st_tickets;          // eight device counters (one per XCD stream), or nullptr: static tile assignment
     // LDS texel windows (fused_eval_window_kernel): win_slices > 0 selects it
     int32_t win_slices;        // channel slices of 128 * win_u channels per texel of map 0 (looped inside the workgroup)
     int32_t win_u, win_vc;     // 16-byte vectors per lane (1..4), views with corner reads in flight
@@ -79,13 +70,6 @@ struct EvalParams {
 // LDS bytes in front of the stage buffers: records, cnt/flag/idx, KRt, per-view windows
 inline int fused_lds_base(int tile_pts, int V) { return ((tile_pts * V * 24 + tile_pts * 12 + V * 48 + V * 16) + 15) / 16 * 16; }
 hipError_t launch_fused_eval(const EvalParams &P, int mode, hipStream_t stream);
-// fuse_stream.hip
-int stream_lds_bytes(int tile_pts, int V);
-hipError_t launch_fused_stream(const EvalParams &P, hipStream_t stream);
-#ifdef D3F_EXPERIMENTS
-unsigned int *stream_exp_tickets();
-void *stream_exp_scratch(int64_t bytes);
-#endif
 
 // fuse_backward.hip
 struct BackwardParams {

@@ -1,5 +1,4 @@
-// fuse_common.h -- device code shared by the fused field-query kernels (fuse_eval.hip, fuse_stream.hip,
-// fuse_window.hip): per-(point, view) records, the bilinear corner set-up, the direct gather of one map, the thin-map
+// fuse_common.h -- device code shared by the fused field-query kernels (fuse_eval.hip): per-(point, view) records, the bilinear corner set-up, the direct gather of one map, the thin-map
 // gather, output stores, the closed-form lattice walk.  Arithmetic contract: DESIGN.md section 2.
 #pragma once
 #include <hip/hip_runtime.h>
@@ -109,8 +108,7 @@ __device__ __forceinline__ void gather_map(const MapDesc &m, const EvalParams &P
                                            const uint32_t *idx_s, int64_t idx_base, int tile_n, const CornerRec *crec,
                                            bool only_strict = false, int tid = threadIdx.x, int nth = kBlock)
 {
-    // tid / nth: the calling lane's index among the nth lanes that share the tile (a whole workgroup by default; the
-    // consumer waves of fused_eval_stream_kernel pass their own)
+    // tid / nth: the calling lane's index among the nth lanes that share the tile (a whole workgroup by default)
     using VT = typename Vec<VW>::T;
     const int lpp = 1 << m.lpp_log2;
     const int g = tid & (lpp - 1);

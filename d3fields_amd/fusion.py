@@ -430,13 +430,7 @@ class Fusion:
         f16 = any(maps[s].dtype == _lib.DTYPE_F16 for s in range(n_maps))
         kernel = ("fused_eval_f16_kernel<0>" if f16 else "fused_eval_wide_kernel<0>" if wide else "fused_eval_kernel<0>")
         window = 2000 <= plan.reserved < 3000
-        stream = plan.reserved >= 3000
-        if stream:
-            lg, var = (plan.reserved - 3000) // 100, (plan.reserved - 3000) % 100
-            T = int(plan.tile_points)
-            kernel = "fused_eval_stream_kernel<%d, %d, %d, %d, %s, %d>" % (lg, T, 4 if T == 16 else 3, 4 if var == 2 else 2,
-                                                                            "true" if var == 0 else "false", 7 if (var == 1 and T != 16) else 5)
-        elif window:
+        if window:
             r = plan.reserved - 2000
             w0 = [s for s in range(n_maps) if plan.staged[s] == 3][0]           # the windowed map (any position in the call)
             kernel = "fused_eval_window_kernel<%d, %d, %d, 256, %d>" % (r // 100, r // 10 % 10, r % 10, plan.lanes_per_point[w0])
@@ -446,10 +440,10 @@ class Fusion:
         elif runs and not f16 and not wide:
             s0 = [s for s in range(n_maps) if plan.staged[s] >= 16][0]
             kernel = "fused_eval_runs_kernel<0, %d, %d, %d>" % (plan.vectors_per_lane[s0], plan.staged[s0] - 16, plan.reserved)
-        sliced = 100 <= plan.reserved < 200 or stream
+        sliced = 100 <= plan.reserved < 200
         order = {2: "closed-form brick walk of the lattice (no keys, no sort)", 1: "Morton-cell order (counting sort by 16-mm cell + 4-mm refinement, hand-written)",
                  0: "caller order"}[int(plan.reorder)]
-        order += ("; channel-sliced over the XCDs" if sliced else "") + ("; persistent producer / consumer workgroups" if stream else "")
+        order += "; channel-sliced over the XCDs" if sliced else ""
         if window:
             order += "; %d-point bricks through texel windows in LDS" % int(plan.tile_points)
         elif runs:
@@ -990,10 +984,6 @@ class Fusion:
             self._set_mask(self._tracked_mask(None))                                              # fusion.py:1239
         else:
             raise NotImplementedError
-
-    def get_inst_num(self):
-        """Number of instances including the background (fusion.py:1258-1260)."""
-        return len(self.curr_obs_torch["consensus_mask_label"])
 
     def clear_xmem_memory(self):
         """fusion.py:1698-1702: the next text_queries_for_inst_mask call segments again (the injected tracker

@@ -354,59 +354,6 @@ def test_channel_sliced_launch_on_a_cloud_is_bit_identical(dev, n, C, hw, mask):
         assert torch.equal(torch.isnan(a), torch.isnan(b)) and torch.equal(torch.nan_to_num(a.float()), torch.nan_to_num(b.float())), k
 
 
-# ---- persistent producer / consumer form of the channel-sliced launch (fuse_stream.hip) == caller-order direct gather ----
-@pytest.mark.parametrize("dims,C,mask,dense", [((47, 53, 29), 384, True, True), ((64, 33, 37), 128, False, True), ((33, 35, 61), 256, True, False),
-                                               ((160, 140, 11), 384, False, True), ((5, 7, 3001), 512, False, True)])
-def test_stream_launch_is_bit_identical(dev, dims, C, mask, dense):
-    """EXPERIMENTS BUILD ONLY (D3F_BUILD_EXPERIMENTS=1): the persistent producer / consumer form of the channel-sliced launch
-    (csrc/experiments/fuse_stream.hip, measured and rejected in round 3) with its STATIC tile assignment:
-    clipped bricks on every face, a strict (NaN) point, thin maps riding along with the owner slice, short lattices, axis
-    arrays instead of the point array, every tile size / register-set variant / slice width.  (The ticketed hand-out is
-    not covered: it drops a few of the last tiles of a launch -- a known defect of the rejected experiment.)"""
-    from d3fields_amd import create_init_grid, synth, _lib
-    V, H, W = 4, 96, 128
-    fh, fw = (H, W) if dense else (H // 2, W // 2)
-    maps = {"dino_feats": synth.random_map(V, fh, fw, C, seed=1, device=dev)}
-    names = ["dino_feats"]
-    if mask:
-        maps["mask"] = synth.random_onehot_mask(V, H, W, 8, seed=2, device=dev)
-        maps["color_tensor"] = synth.random_map(V, H, W, 3, seed=3, device=dev)
-        names += ["mask", "color_tensor"]
-    f, sc = fusion_for(dev, V, H, W, maps)
-    f.record_plans = True
-    box = box_for(*dims, 0.004)
-    grid = create_init_grid(box, 0.004)[0]
-    pts = grid.to(dev)
-    nan_pts = grid.clone(); nan_pts[4321, 0] = float("nan")                            # a strict point
-    nan_pts = nan_pts.to(dev)
-
-    def same(a, b, tag):
-        for k in ["dist", "valid_mask"] + names:
-            x, y = a[k], b[k]
-            assert torch.equal(torch.isnan(x), torch.isnan(y)) and torch.equal(torch.nan_to_num(x.float()), torch.nan_to_num(y.float())), (tag, k)
-
-    if not experiments():
-        pytest.skip("fuse_stream.hip is compiled into experiments builds only")
-    variants = [dict(D3F_EXP_STREAM=1)]
-    variants += [dict(D3F_EXP_STREAM=1, D3F_EXP_STREAM_T=T, D3F_EXP_STREAM_VAR=var) for T in (12, 16, 24) for var in (0, 1, 2)]
-    variants += [dict(D3F_EXP_STREAM=1, D3F_EXP_STREAM_VAR=3), dict(D3F_EXP_STREAM=1, D3F_EXP_STREAM_R=1), dict(D3F_EXP_STREAM=1, D3F_EXP_STREAM_R=3, D3F_EXP_STREAM_UNIT=40)]
-    if C % 64 == 0:
-        variants += [dict(D3F_EXP_STREAM=1, D3F_EXP_STREAM_LG=4, D3F_EXP_STREAM_T=T, D3F_EXP_STREAM_VAR=var) for T in (12, 24) for var in (0, 1)]
-    with torch.no_grad():
-        f.tuning_flags = _lib.TUNE_NO_REORDER
-        base, base_nan = f.batch_eval(pts, return_names=names), f.batch_eval(nan_pts, return_names=names)
-        f.tuning_flags = _lib.TUNE_FORCE_REORDER
-        for kv in variants:
-            with knobs(**kv):
-                out = f.batch_eval(pts, return_names=names)
-                assert f.last_plan()["kernel"].startswith("fused_eval_stream_kernel"), (kv, f.last_plan())
-                same(out, base, kv)
-                same(f.batch_eval(nan_pts, return_names=names), base_nan, ("nan", kv))
-        with knobs(D3F_EXP_STREAM=1):
-            same(f.eval_grid(box, 0.004, return_names=names), base, "axis arrays")
-        # (eval_grid does not record a plan: the same launch path, d3f_eval_grid -> eval_common with the lattice dims)
-
-
 # ---- thin maps: views in parallel across lanes == view-sequential gather, bit for bit -------------------------------------
 @pytest.mark.parametrize("V,C,N", [(4, 8, 70000), (2, 3, 5000), (3, 5, 130001), (8, 16, 66000), (5, 1, 3000), (4, 12, 90000)])
 def test_thin_map_gather_is_bit_identical(dev, V, C, N):
