@@ -9,13 +9,14 @@ import os
 
 from . import build as _build
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 # status codes (include/d3fields_hip.h)
 OK = 0
 ERR_INVALID_ARG, ERR_BAD_SHAPE, ERR_BAD_DTYPE, ERR_BAD_LAYOUT, ERR_HIP, ERR_WORKSPACE = -1, -2, -3, -4, -5, -6
 FLAG_FINITE_MAPS = 1
 FLAG_UNORDERED_POINTS = 2
+FLAG_REFERENCE_ROUNDING = 4
 FLAG_REUSE_POINT_ORDER = 8
 TUNE_XCD_REMAP, TUNE_NO_REORDER, TUNE_FORCE_REORDER = 1 << 12, 1 << 13, 1 << 14
 TUNE_DIRECT_GATHER = 1 << 4
@@ -35,13 +36,13 @@ _f32 = ctypes.c_float
 
 class Views(ctypes.Structure):
     """struct d3f_views"""
-    _fields_ = [("V", _i32), ("H", _i32), ("W", _i32), ("depth", _vp), ("K", _vp), ("pose", _vp)]
+    _fields_ = [("V", _i32), ("H", _i32), ("W", _i32), ("depth", _vp), ("K", _vp), ("pose", _vp), ("depth_nonfinite", _vp)]
 
 
 class ChannelMap(ctypes.Structure):
     """struct d3f_channel_map"""
     _fields_ = [("data", _vp), ("fh", _i32), ("fw", _i32), ("C", _i32), ("dtype", _i32),
-                ("stride_v", _i64), ("stride_y", _i64), ("stride_x", _i64)]
+                ("stride_v", _i64), ("stride_y", _i64), ("stride_x", _i64), ("nonfinite", _vp)]
 
 
 class Grid(ctypes.Structure):
@@ -69,6 +70,7 @@ SIGNATURES = {
     "d3f_build_has_experiments": (ctypes.c_int, []),
     "d3f_eval": (ctypes.c_int, [ctypes.POINTER(Views), _vp, _i64, ctypes.POINTER(ChannelMap), _i32, _f32, _u32,
                                 _vp, _vp, ctypes.POINTER(_vp), ctypes.POINTER(_vp), _vp, _i64, _vp]),
+    "d3f_map_check": (ctypes.c_int, [ctypes.POINTER(ChannelMap), _i32, _vp, _vp]),
     "d3f_eval_workspace_bytes": (_i64, [_i64]),
     "d3f_profile_next_eval": (None, [_vp, _vp]),
     "d3f_eval_plan_query": (ctypes.c_int, [ctypes.POINTER(Views), _i64, ctypes.POINTER(ChannelMap), _i32, _u32, _i32, _i32,

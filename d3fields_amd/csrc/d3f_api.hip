@@ -55,7 +55,10 @@ void pick_mapping(d3f::MapDesc &m, bool can16, bool can8, bool batch, int max_u 
             const int per = lpp * u;
             const int passes = (cvec + per - 1) / per;
             const long slots = (long)passes * per;
-            const bool better = best_slots < 0 || slots < best_slots || (slots == best_slots && passes < best_passes);
+            // thin family (max_u == 1: masks, colours): fewest PASSES first -- every pass repeats the per-(point, view)
+            // set-up, and <= 4 lanes per point make the map eligible for the views-in-parallel gather (gather_map_thin)
+            const bool better = best_slots < 0 || (max_u == 1 ? (passes < best_passes || (passes == best_passes && slots < best_slots))
+                                                               : (slots < best_slots || (slots == best_slots && passes < best_passes)));
             if (better) {
                 best_slots = slots;
                 best_passes = passes;
@@ -100,6 +103,7 @@ int fill_map(const d3f_channel_map &c, int s, int V, float *out, float *inter, c
     m.runs = 0;
     m.pre_slot = -1;
     m.esize = es;
+    m.fold = ((int64_t)c.C * es > 256) ? 1 : 0;        // wide map: folded weights on the fast path (fuse_common.h)
     m.sv = c.stride_v; m.sy = c.stride_y; m.sx = c.stride_x;
     m.fh = c.fh; m.fw = c.fw; m.C = c.C;
     if (!aligned(m.data, es) || !aligned(out, 4) || !aligned(extra_aligned, 4))
@@ -116,11 +120,12 @@ int fill_map(const d3f_channel_map &c, int s, int V, float *out, float *inter, c
         const bool str8 = (c.stride_v % 8 == 0) && (c.stride_y % 8 == 0) && (c.stride_x % 8 == 0);
         const bool vec8 = (c.C % 8 == 0) && str8 && aligned(m.data, 16) && aligned(out, 16) && aligned(inter, 16) &&
                           aligned(extra_aligned, 16);      // backward: grad_fused is read as 32-byte f32x8 pieces of 16-B aligned rows
-        pick_mapping(m, false, false, true);            // scalar lanes ...
+        const int max_u = m.fold ? 4 : 1;               // thin maps: one vector per lane (see below)
+        pick_mapping(m, false, false, true, max_u);     // scalar lanes ...
         if (vec8) {                                     // ... or the same search over 8-channel vectors
             d3f::MapDesc t = m;
             t.C = c.C / 2;                               // cvec = C/8 = (C/2)/4: reuse the 4-wide search
-            pick_mapping(t, true, true, true);
+            pick_mapping(t, true, true, true, max_u);
             m.vw = 8; m.lpp_log2 = t.lpp_log2; m.unroll = t.unroll;
         }
         return D3F_OK;
@@ -128,7 +133,11 @@ int fill_map(const d3f_channel_map &c, int s, int V, float *out, float *inter, c
     bool batch = this_bytes <= kBatchedLoadBytes;
     if (flags & (1u << 26)) batch = true;
     if (flags & (1u << 27)) batch = false;
-    pick_mapping(m, can16, can8, batch);
+    // thin maps (<= 256 bytes per texel: masks, colours) keep the reference's operation order and get ONE kernel form -- one
+    // batched vector per lane; the wide ones have the whole family (and the folded weights).  Keeping the two families apart
+    // halves the instantiations of gather_map a kernel carries (with both full families the generic kernels spilled 1 KiB).
+    if (!m.fold) batch = true;
+    pick_mapping(m, can16, can8, batch, m.fold ? 4 : 1);
     return D3F_OK;
 }
 
@@ -155,6 +164,15 @@ int exp_knob(const char *name)
 {
     const char *v = getenv(name);
     return v ? atoi(v) : 0;
+}
+// phase stamps of the window kernel (D3F_EXP_STAMPS=1): 32 x uint64 per sampled workgroup, read back with d3f_exp_read_stamps
+constexpr int64_t kStampBytes = 8LL * 32 * 65536;
+unsigned long long *exp_stamp_buffer(bool clear)
+{
+    static unsigned long long *buf = nullptr;
+    if (!buf && hipMalloc(reinterpret_cast<void **>(&buf), kStampBytes) != hipSuccess) buf = nullptr;
+    if (buf && clear) (void)hipMemset(buf, 0, kStampBytes);
+    return buf;
 }
 #else
 // the product build reads no environment: every knob is its default (0), the library keeps no hidden state
@@ -240,7 +258,25 @@ int eval_common(const d3f_views *views, const float *pts, int64_t n, const d3f_c
     if (n_maps > 0 && (!maps || (!out_fused && !plan_only))) return fail(D3F_ERR_INVALID_ARG, "maps/out_fused must be non-NULL when n_maps > 0");
     if (!(mu > 0.0f)) return fail(D3F_ERR_INVALID_ARG, "mu must be > 0");
 
+    // D3F_FLAG_REFERENCE_ROUNDING: no fast path at all -- every point takes the strict form (the reference's operation order)
+    if (flags & D3F_FLAG_REFERENCE_ROUNDING) flags = (flags & ~D3F_FLAG_FINITE_MAPS) | D3F_TUNE_DIRECT_GATHER;
     d3f::EvalParams P;
+    // device-side finiteness words (d3f_map_check): used when the host did not vouch for the maps and EVERY tensor of the
+    // query carries one; the kernels then decide on the device, and the launch is planned for finite maps
+    P.n_words = 0;
+    if (!(flags & (D3F_FLAG_FINITE_MAPS | D3F_FLAG_REFERENCE_ROUNDING)) && views->depth_nonfinite && mode == 0) {
+        bool all = true;
+        for (int s = 0; s < n_maps; ++s) all = all && maps && maps[s].nonfinite;
+        if (all) {
+            P.words[P.n_words++] = views->depth_nonfinite;
+            for (int s = 0; s < n_maps; ++s) P.words[P.n_words++] = maps[s].nonfinite;
+        }
+    }
+    const bool finite_expected = (flags & D3F_FLAG_FINITE_MAPS) || P.n_words > 0;
+    P.exp_stamps = nullptr;
+#ifdef D3F_EXPERIMENTS
+    if (exp_knob("D3F_EXP_STAMPS") > 0 && !plan_out) P.exp_stamps = exp_stamp_buffer(true);
+#endif
     P.depth = views->depth; P.K = views->K; P.pose = views->pose; P.pts = pts;
     P.order = nullptr; P.lds_pad = 0;
     P.grid_x = grid ? grid->x : nullptr; P.grid_y = grid ? grid->y : nullptr; P.grid_z = grid ? grid->z : nullptr;
@@ -251,6 +287,7 @@ int eval_common(const d3f_views *views, const float *pts, int64_t n, const d3f_c
     P.thin_max_views = (exp_knob("D3F_EXP_THIN") < 0 || (flags & D3F_TUNE_DIRECT_GATHER)) ? 0 : 8;
     P.win_lpp = exp_knob("D3F_EXP_WINDOW_LPP") == 32 ? 32 : 16;     // 16 lanes x 2 vectors per point (C2 patch 0.565 -> 0.54 ms); U > 1: 32
     P.win_slices = 0; P.win_u = 1; P.win_vc = 1; P.win_pool_offset = 0; P.win_pool_texels = 0; P.win_occ = 4;
+    P.win_pipe = exp_knob("D3F_EXP_WINDOW_PIPE") < 0 ? 0 : 1;
     P.store_policy = exp_knob("D3F_EXP_STORE") < 0 ? 0 : 1;
     int64_t map_bytes = 0;
     P.out_dist = out_dist; P.out_valid = out_valid;
@@ -301,7 +338,7 @@ int eval_common(const d3f_views *views, const float *pts, int64_t n, const d3f_c
         // default: lattices only (a brick's windows are compact; 64 consecutive points of a cloud's Morton order are not:
         // C5 0.120 -> 0.170 ms), and not when a cell-run variant is asked for explicitly
         const bool automatic = win_knob == 0 && lattice != nullptr && exp_knob("D3F_EXP_RUNS") == 0 && exp_knob("D3F_EXP_RUNS_U") == 0;
-        window = (win_knob > 0 || automatic) && !direct && mode == 0 && n_maps >= 1 && (flags & D3F_FLAG_FINITE_MAPS) && n >= kSmallBatch &&
+        window = (win_knob > 0 || automatic) && !direct && mode == 0 && n_maps >= 1 && finite_expected && n >= kSmallBatch &&
                  n <= 0x7fffffffLL && tl == 0 && views->V <= 8 && runs_candidate(P.maps[0], views->H, views->W) &&
                  P.maps[0].C % 128 == 0 && (int64_t)views->V * P.maps[0].sv * 4 < (1LL << 31) && (P.maps[0].sx % 4) == 0 && (P.maps[0].sy % 4) == 0 && (P.maps[0].sv % 4) == 0 &&
                  (!plan_only ? (reinterpret_cast<uintptr_t>(P.maps[0].data) % 16 == 0) : true);
@@ -314,10 +351,11 @@ int eval_common(const d3f_views *views, const float *pts, int64_t n, const d3f_c
             const int cv = P.maps[0].C / 128;                  // 512-byte granules per texel
             if (U < 1 || U > 4 || cv % U != 0) U = 1;
             // per (point, view): 32-byte window record (+ the 16-byte view record when thin maps ride along); per point 20 bytes
-            const int base = T * views->V * (n_maps > 1 ? 48 : 32) + T * 20 + views->V * 48;
+            const int base = T * (views->V * 32 + 16) + (n_maps > 1 ? T * views->V * 16 : 0) + T * 20 + views->V * 48;     // records at a padded point stride
             const int pool_offset = (base + 511) / 512 * 512;
             int occ = exp_knob("D3F_EXP_WINDOW_OCC");
-            if (occ < 2 || occ > 4) occ = 4;
+            const bool occ_forced = occ >= 5 && occ <= 6;        // experiments: 5 / 6 workgroups per CU with the plain point loop
+            if (occ < 2 || occ > 6) occ = 4;
             if (U > 1) occ = 2;                                 // those variants are built for 2 workgroups per CU
             int texels = 0;
             for (;; --occ) {
@@ -325,10 +363,13 @@ int eval_common(const d3f_views *views, const float *pts, int64_t n, const d3f_c
                 texels = (budget - pool_offset) / (512 * U) - 2;
                 // A 4x4x4 brick's window is ~3x4 texels per view once a texel is at least as wide as the brick's footprint
                 // (config 4's slab: 2.5-mm lattice, 10-px texels), and a pool that cannot hold the views' windows sends the
-                // overflowing pairs to the global gather: give every view ~11 slots, at the price of workgroups per CU
+                // overflowing pairs to the global gather: give every view enough slots, at the price of workgroups per CU
                 // (MI355X, config 4 lattice slab: 4 / 3 / 2 workgroups per CU = 3.15 / 3.54 / 2.43 ms; config 2, four
                 // views, fits at 4 and loses 18 % at 2)
-                if (texels >= 11 * views->V || occ == 2) break;
+                // (round 4, pipelined point loop: a point with a pair outside the pool is done a second time by the general path, so
+                // overflow costs more than a workgroup per CU -- C2-patch: 55 slots at 4 per CU 0.525 ms, 80 slots at 3 per CU 0.493,
+                // 40 / 32 slots 0.72 / 0.81: ask for ~17 slots per view)
+                if (texels >= 17 * views->V || occ == 2 || occ_forced) break;
             }
             if (exp_knob("D3F_EXP_WINDOW_POOL") > 0 && exp_knob("D3F_EXP_WINDOW_POOL") < texels) texels = exp_knob("D3F_EXP_WINDOW_POOL");
             if (texels > 320) texels = 320;                      // kWinMaxTexels (fuse_eval.hip)
@@ -343,7 +384,7 @@ int eval_common(const d3f_views *views, const float *pts, int64_t n, const d3f_c
     bool any_runs = false;
     {
         const int knob = exp_knob("D3F_EXP_RUNS");
-        bool blocked = window || direct || knob < 0 || !(flags & D3F_FLAG_FINITE_MAPS) || n < kSmallBatch || tl != 0;
+        bool blocked = window || direct || knob < 0 || !finite_expected || n < kSmallBatch || tl != 0;
         for (int s = 0; s < n_maps; ++s)
             blocked |= P.maps[s].esize == 2 || want_inter[s] ||
                        (P.maps[s].unroll == -4 && !runs_candidate(P.maps[s], views->H, views->W));
@@ -526,7 +567,7 @@ int eval_common(const d3f_views *views, const float *pts, int64_t n, const d3f_c
             plan_out->lds_bytes = P.win_pool_offset + (2 + P.win_pool_texels) * 512 * P.win_u;
             plan_out->workgroups = ntiles;
         }
-        plan_out->reserved = P.sl_slices > 0 ? 100 + P.sl_lg * 10 + P.sl_vc : (P.win_slices > 0 ? 2000 + 100 * P.win_u + 10 * (P.win_u == 1 ? (P.win_lpp == 16 ? 2 : 4) : (P.win_u == 4 ? 1 : P.win_vc)) + (P.win_u == 1 ? (P.win_occ >= 4 ? 4 : (P.win_lpp == 16 ? 3 : P.win_occ)) : 2) : 0);   // 2UVW: the window kernel's template arguments      // 1LV: sliced launch, L = log2(lanes per point), V = views in flight
+        plan_out->reserved = P.sl_slices > 0 ? 100 + P.sl_lg * 10 + P.sl_vc : (P.win_slices > 0 ? 2000 + 100 * P.win_u + 10 * (P.win_u == 1 ? (P.win_lpp == 16 ? P.win_vc : 4) : (P.win_u == 4 ? 1 : P.win_vc)) + (P.win_u == 1 ? (P.win_occ >= 4 ? 4 : (P.win_lpp == 16 ? 3 : P.win_occ)) : 2) : 0);   // 2UVW: the window kernel's template arguments      // 1LV: sliced launch, L = log2(lanes per point), V = views in flight
         for (int s = 0; s < n_maps; ++s)
             if (P.maps[s].runs > 0) {        // waves per SIMD the chosen cell-run kernel variant is built for
                 const int ru = P.maps[s].unroll, rk = P.maps[s].runs;
@@ -855,6 +896,32 @@ int d3f_eval_dist(const d3f_views *views, const float *pts, int64_t n, float *ou
                   void *stream)
 {
     return eval_common(views, pts, n, nullptr, 0, 1.0f, 0u, out_dist, out_valid, nullptr, nullptr, nullptr, 0, stream, 1);
+}
+
+#ifdef D3F_EXPERIMENTS
+// experiments builds only (not in the header): the phase stamps of the last stamped launch, 32 x uint64 per sampled workgroup
+int d3f_exp_read_stamps(unsigned long long *host_out, int64_t n_words)
+{
+    unsigned long long *dev = exp_stamp_buffer(false);
+    if (!dev || !host_out || n_words < 0 || n_words * 8 > kStampBytes) return D3F_ERR_INVALID_ARG;
+    if (hipDeviceSynchronize() != hipSuccess) return D3F_ERR_HIP;
+    return hipMemcpy(host_out, dev, (size_t)n_words * 8, hipMemcpyDeviceToHost) == hipSuccess ? D3F_OK : D3F_ERR_HIP;
+}
+#endif
+
+int d3f_map_check(const d3f_channel_map *map, int32_t V, uint32_t *word_out, void *stream)
+{
+    if (!map || !word_out) return fail(D3F_ERR_INVALID_ARG, "map_check: NULL pointer");
+    if (!aligned(word_out, 4)) return fail(D3F_ERR_BAD_LAYOUT, "map_check: word_out must be 4-byte aligned");
+    if (V < 1 || map->fh < 1 || map->fw < 1 || map->C < 1) return fail(D3F_ERR_BAD_SHAPE, "map_check: V=%d fh=%d fw=%d C=%d", V, map->fh, map->fw, map->C);
+    if (!map->data) return fail(D3F_ERR_INVALID_ARG, "map_check: data pointer is NULL");
+    if (map->dtype != D3F_DTYPE_F32 && map->dtype != D3F_DTYPE_F16) return fail(D3F_ERR_BAD_DTYPE, "map_check: dtype %d unsupported", map->dtype);
+    const int es = map->dtype == D3F_DTYPE_F16 ? 2 : 4;
+    if (!aligned(map->data, es)) return fail(D3F_ERR_BAD_LAYOUT, "map_check: data must be aligned to its element size");
+    if (map->stride_x < map->C || map->stride_y < 0 || map->stride_v < 0) return fail(D3F_ERR_BAD_LAYOUT, "map_check: strides do not describe a channels-last map");
+    hipError_t e = d3f::launch_map_check(map->data, V, map->fh, map->fw, map->C, map->stride_v, map->stride_y, map->stride_x, es,
+                                         word_out, static_cast<hipStream_t>(stream));
+    return e == hipSuccess ? D3F_OK : hip_fail(e, "map_check launch");
 }
 
 int d3f_onehot2instance(const float *onehot, int64_t n, int32_t NI, uint8_t *out, void *stream)

@@ -24,6 +24,8 @@ struct MapDesc {
     int32_t pre_slot;  // >= 0: bilinear corner set-up of this map is precomputed per (point, view) in LDS slot pre_slot
     int32_t esize;     // bytes per stored channel: 4 (fp32) or 2 (fp16 storage, widened on load)
     int32_t runs;      // > 0: cell-run gather (gather_map_runs): a lane group walks `runs` consecutive points view by view
+    int32_t fold;      // 1: wide map -- on the fast path the view weight and the reciprocal of the view count are folded into
+                       //    the four bilinear weights once per (point, view): 4 fma per channel vector
 };
 
 struct EvalParams {
@@ -54,6 +56,7 @@ struct EvalParams {
     // LDS texel windows (fused_eval_window_kernel): win_slices > 0 selects it
     int32_t win_slices;        // channel slices of 128 * win_u channels per texel of map 0 (looped inside the workgroup)
     int32_t win_u, win_vc;     // 16-byte vectors per lane (1..4), views with corner reads in flight
+    int32_t win_pipe;          // 1 (default): software-pipelined point loop when the view count is 4 or 8
     int32_t win_pool_offset;   // byte offset of the two all-zero slices; the pool follows them
     int32_t win_pool_texels;   // pool capacity in texel slices of 512 * win_u bytes
     int32_t win_occ;           // workgroups per CU the kernel variant is built for (2 / 3 / 4)
@@ -64,6 +67,11 @@ struct EvalParams {
     int32_t store_policy;  // 1 (default) = fused rows leave as sc1 (write-through, line dropped from L2) stores, 0 = plain
     uint32_t flags;
     float mu;
+    // device-side "this tensor holds a non-finite value" words written by d3f_map_check (depth first, then one per map);
+    // n_words == 0: the host's D3F_FLAG_FINITE_MAPS alone decides.  All words zero <=> the exact invalid-view skip is allowed.
+    int32_t n_words;
+    const uint32_t *words[D3F_MAX_MAPS + 1];
+    unsigned long long *exp_stamps;   // experiments builds (D3F_EXP_STAMPS=1): s_memtime stamps of every 64th workgroup's phases; else nullptr
     MapDesc maps[D3F_MAX_MAPS];
 };
 
@@ -133,6 +141,8 @@ hipError_t launch_fps_pixels(const int32_t *pts, int64_t n, int k, int64_t init_
                              void *workspace, hipStream_t s);
 
 // misc_kernels.hip
+hipError_t launch_map_check(const void *data, int V, int fh, int fw, int C, int64_t sv, int64_t sy, int64_t sx, int esize,
+                            uint32_t *word, hipStream_t s);
 hipError_t launch_onehot2instance(const float *onehot, int64_t n, int NI, uint8_t *out, hipStream_t s);
 hipError_t launch_instance2onehot(const uint8_t *inst, int64_t n, int NI, uint8_t *out, hipStream_t s);
 

@@ -52,8 +52,102 @@ __device__ __forceinline__ Corner corner_setup(const MapDesc &m, float gx, float
 // 2^k lanes of a point's group read 32 bytes from LDS instead of repeating ~45 VALU instructions each.
 struct __attribute__((aligned(16))) CornerRec {
     uint32_t o[4];      // onw, one, osw, ose
-    float w[4];         // weights with out-of-bounds corners already zeroed (non-strict path only)
+    float w[4];         // weights with out-of-bounds corners already zeroed (non-strict path only); of a FOLDED map
+                        // (MapDesc::fold) they are already multiplied by fold_scale()
 };
+
+// ---- folded weights of wide maps (fast path only) ------------------------------------------------
+// The reference computes  out = (sum_v (bilinear_v * valid_v) * wgt_v) / (cnt + 1e-6)  (fusion.py:373-386): per channel
+// and view a 4-term bilinear chain, a product with the weight, an addition, and one division per channel.  On the fast
+// path (finite operands, valid_v == 1 for every view that takes part) the scalar factors of a (point, view) are folded
+// into its four bilinear weights ONCE:   w'_k = w_k * (wgt_v * rcp(cnt + 1e-6)),
+// and the channels run   acc = fma(nw, w'_0, acc); fma(ne, w'_1, .); fma(sw, w'_2, .); fma(se, w'_3, .)   in view order;
+// out = acc.  Four packed fma per channel vector and view instead of six operations, and no division epilogue.  Every
+// kernel that takes the fast path uses exactly these operations in this order (bit-identical among themselves); against
+// the reference's order the result moves by a few ulp of the largest term (tests: <= 1e-5 of max|ref|, measured ~2e-7).
+// Thin maps (the instance mask, colours: <= 256 bytes per texel) and every strict point keep the reference's order, so
+// instance indices and '<k>_inter' stay bit-exact.
+__device__ __forceinline__ float refined_rcp(float denom)
+{
+    // 1/denom to within an ulp: hardware estimate + one Newton step (denom = cnt + 1e-6 lies in [1e-6, V + 1))
+    const float r0 = __builtin_amdgcn_rcpf(denom);
+    return fmaf(fmaf(-denom, r0, 1.0f), r0, r0);
+}
+__device__ __forceinline__ float fold_scale(float wgt, float cnt) { return wgt * refined_rcp(cnt + 1e-6f); }
+
+// lanes per point in phase A: the views of a point sit in VP = 2^k >= V adjacent lanes
+__device__ __forceinline__ int view_lanes_log2(int V) { return V <= 1 ? 0 : 32 - __clz(V - 1); }
+
+// ---- cross-lane moves on the VALU (DPP) instead of the LDS crossbar -----------------------------------------------------
+// hipcc's __shfl / __shfl_xor are ds_bpermute_b32: an LDS-pipe round trip (~100+ cycles under load) per value.  Phase A
+// needs 3 V of them per lane for the per-point sums, the window set-up 27 for its min / max reductions -- 1.5-3 k cycles
+// of a workgroup's serial prologue (phase stamps, round 4).  Inside a quad / a row DPP does the same in one VALU
+// instruction.  dpp_ctrl: quad_perm [a,b,c,d] = a | b<<2 | c<<4 | d<<6; 0x141 = row_half_mirror (lane i <-> 7 - i of its 8).
+template <int CTRL> __device__ __forceinline__ int dpp_i(int x) { return __builtin_amdgcn_update_dpp(x, x, CTRL, 0xf, 0xf, false); }
+template <int CTRL> __device__ __forceinline__ float dpp_f(float x) { return __int_as_float(dpp_i<CTRL>(__float_as_int(x))); }
+template <int K> __device__ __forceinline__ float quad_bcast(float x) { return dpp_f<K * 0x55>(x); }       // lane K of the quad
+template <int K> __device__ __forceinline__ int quad_bcast_i(int x) { return dpp_i<K * 0x55>(x); }
+
+// Sums over the views of a point IN VIEW ORDER (fusion.py:364-370) from the per-(point, view) lanes of phase A: lane
+// `base` + v holds view v (VP = 2^k >= V lanes per point, base a multiple of VP).  Every lane of the wave must call this
+// (cross-lane reads of inactive lanes are undefined).  V <= 4: quad broadcasts; V <= 8: two quads chained through a row
+// shift; more views: the LDS crossbar.  The additions are the same operands in the same order in every branch.
+__device__ __forceinline__ void view_sums(int V, int base, float dv, float valid, uint32_t st, float &dsum, float &cnt,
+                                          uint32_t &st_any)
+{
+    dsum = 0.0f; cnt = 0.0f; st_any = 0u;
+    if (V <= 8) {
+        // views 0..3: lanes 0..3 of the point's first quad (a point with V <= 4 owns <= one quad: VP = 1, 2, 4 lanes; for
+        // VP < 4 a quad holds several points and lane k of the quad is view k - (base & 3) of ITS point: select by lane)
+        const int q = base & 3;                         // first lane of the point inside its quad (0 unless VP < 4)
+#define D3F_VS_STEP(K)                                                                                              \
+        {                                                                                                           \
+            const float a = quad_bcast<K>(dv), b = quad_bcast<K>(valid);                                            \
+            const int c = quad_bcast_i<K>((int)st);                                                                 \
+            const bool mine = (K >= q) && (K - q < V) && (K - q < 4);                                               \
+            dsum = mine ? dsum + a : dsum; cnt = mine ? cnt + b : cnt; st_any |= mine ? (uint32_t)c : 0u;          \
+        }
+        D3F_VS_STEP(0) D3F_VS_STEP(1) D3F_VS_STEP(2) D3F_VS_STEP(3)
+        if (V > 4) {
+            // views 4..7 sit in the next quad: hand the running sums over (row_shr:4 = lane i-4 -> lane i), continue the
+            // chain there, and hand the totals back (row_shl:4) -- VP = 8, so base is a multiple of 8 and q = 0
+            const bool hi = (threadIdx.x & 4) != 0;
+            const float d0 = dpp_f<0x114>(dsum), c0 = dpp_f<0x114>(cnt);
+            const int s0 = dpp_i<0x114>((int)st_any);
+            float d1 = d0, c1 = c0;
+            uint32_t s1 = (uint32_t)s0;
+#define D3F_VS_HI(K)                                                                                                \
+            {                                                                                                       \
+                const float a = quad_bcast<K>(dv), b = quad_bcast<K>(valid);                                        \
+                const int c = quad_bcast_i<K>((int)st);                                                             \
+                const bool mine = 4 + K < V;                                                                        \
+                d1 = mine ? d1 + a : d1; c1 = mine ? c1 + b : c1; s1 |= mine ? (uint32_t)c : 0u;                    \
+            }
+            D3F_VS_HI(0) D3F_VS_HI(1) D3F_VS_HI(2) D3F_VS_HI(3)
+            const float dl = dpp_f<0x104>(d1), cl = dpp_f<0x104>(c1);          // back to the low quad
+            const int sl = dpp_i<0x104>((int)s1);
+            dsum = hi ? d1 : dl; cnt = hi ? c1 : cl; st_any = hi ? s1 : (uint32_t)sl;
+#undef D3F_VS_HI
+        }
+#undef D3F_VS_STEP
+        return;
+    }
+    for (int vv = 0; vv < V; ++vv) {
+        dsum = dsum + __shfl(dv, base + vv, 64);
+        cnt = cnt + __shfl(valid, base + vv, 64);
+        st_any |= (uint32_t)__shfl((int)st, base + vv, 64);
+    }
+}
+
+// may invalid views be skipped exactly?  (the host verified the maps, or every device-side check word is zero)
+__device__ __forceinline__ bool maps_are_finite(const EvalParams &P)
+{
+    if (P.flags & kFlagFiniteMaps) return true;
+    if (P.n_words == 0) return false;
+    uint32_t bad = 0u;
+    for (int k = 0; k < P.n_words; ++k) bad |= __builtin_nontemporal_load(P.words[k]);
+    return bad == 0u;
+}
 
 // Gathers map `m` for the points of this workgroup's tile.
 //   VW  channel-vector width in floats (4 when C%4==0 and 16-B aligned, else 2 or 1)
@@ -102,7 +196,7 @@ __device__ __forceinline__ VT strict_div(VT a, float d)
     return a / d;
 }
 
-template <int VW, int U, bool BATCH, bool HALF = false>
+template <int VW, int U, bool BATCH, bool HALF = false, bool FOLD = false>
 __device__ __forceinline__ void gather_map(const MapDesc &m, const EvalParams &P, const ViewRec *rec,
                                            const float *cnt_s, const uint32_t *flag_s,
                                            const uint32_t *idx_s, int64_t idx_base, int tile_n, const CornerRec *crec,
@@ -140,10 +234,14 @@ __device__ __forceinline__ void gather_map(const MapDesc &m, const EvalParams &P
                 if (!strict && crec) {
                     const CornerRec cr = crec[p * V + v];
                     c.onw = cr.o[0]; c.one = cr.o[1]; c.osw = cr.o[2]; c.ose = cr.o[3];
-                    w0 = cr.w[0]; w1 = cr.w[1]; w2 = cr.w[2]; w3 = cr.w[3];
+                    w0 = cr.w[0]; w1 = cr.w[1]; w2 = cr.w[2]; w3 = cr.w[3];      // FOLD: folded in phase A
                 } else {
                     c = corner_setup(m, r.gx, r.gy);
                     w0 = c.inw ? c.wnw : 0.0f; w1 = c.ine ? c.wne : 0.0f; w2 = c.isw ? c.wsw : 0.0f; w3 = c.ise ? c.wse : 0.0f;
+                    if (FOLD && !strict) {
+                        const float sc = fold_scale(r.wgt, cnt);
+                        w0 = w0 * sc; w1 = w1 * sc; w2 = w2 * sc; w3 = w3 * sc;
+                    }
                 }
                 const char *bv = reinterpret_cast<const char *>(data) + (int64_t)v * m.sv * ES;
                 typename Raw<VW, HALF>::T a[U], b[U], d[U], e[U];      // as stored; widened to fp32 at the use
@@ -171,11 +269,24 @@ __device__ __forceinline__ void gather_map(const MapDesc &m, const EvalParams &P
                             d[u] = load_texel<VW, HALF>(bv + (c.osw + co));
                             e[u] = load_texel<VW, HALF>(bv + (c.ose + co));
                         }
-                        VT s = widen<VW, HALF>(a[u]) * w0; // ATen bilinear: fma chain nw,ne,sw,se
-                        s = v_fma<VT>(widen<VW, HALF>(b[u]), w1, s);
-                        s = v_fma<VT>(widen<VW, HALF>(d[u]), w2, s);
-                        s = v_fma<VT>(widen<VW, HALF>(e[u]), w3, s);
-                        acc[u] = acc[u] + s * r.wgt;       // fusion.py:385
+                        if constexpr (HALF) {
+                            // keep the fp16 -> fp32 conversions of one vector HERE: left alone, the optimiser hoists the
+                            // conversions of all 4*U corner vectors above the strict / fast branch (both sides widen them):
+                            // 96 extra VGPRs for U = 3, one wave per SIMD less
+                            asm volatile("" : "+v"(a[u]), "+v"(b[u]), "+v"(d[u]), "+v"(e[u]));
+                        }
+                        if (FOLD) {                        // folded weights: four fma straight into the view sum
+                            acc[u] = v_fma<VT>(widen<VW, HALF>(a[u]), w0, acc[u]);
+                            acc[u] = v_fma<VT>(widen<VW, HALF>(b[u]), w1, acc[u]);
+                            acc[u] = v_fma<VT>(widen<VW, HALF>(d[u]), w2, acc[u]);
+                            acc[u] = v_fma<VT>(widen<VW, HALF>(e[u]), w3, acc[u]);
+                        } else {
+                            VT s = widen<VW, HALF>(a[u]) * w0; // ATen bilinear: fma chain nw,ne,sw,se
+                            s = v_fma<VT>(widen<VW, HALF>(b[u]), w1, s);
+                            s = v_fma<VT>(widen<VW, HALF>(d[u]), w2, s);
+                            s = v_fma<VT>(widen<VW, HALF>(e[u]), w3, s);
+                            acc[u] = acc[u] + s * r.wgt;       // fusion.py:385
+                        }
                         if (!BATCH) __builtin_amdgcn_sched_barrier(0);   // keep the next vector's loads behind this use
                     }
                 } else {
@@ -208,10 +319,7 @@ __device__ __forceinline__ void gather_map(const MapDesc &m, const EvalParams &P
             // [1, V+1) and on this path every numerator is finite.  Bit-identical quotients, 5 instead of 11
             // instructions per channel.  Strict points (non-finite operands possible) keep the full division.
             float rcp_d = 0.0f;
-            if (!strict) {
-                const float r0 = __builtin_amdgcn_rcpf(denom);
-                rcp_d = fmaf(fmaf(-denom, r0, 1.0f), r0, r0);
-            }
+            if (!strict && !FOLD) rcp_d = refined_rcp(denom);
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const int cv = c0 + u * lpp + g;
@@ -221,6 +329,8 @@ __device__ __forceinline__ void gather_map(const MapDesc &m, const EvalParams &P
                         o = (VT)0.0f;                                          // fusion.py:386
                     } else if (strict) {
                         o = strict_div<VT>(acc[u], denom);
+                    } else if (FOLD) {
+                        o = acc[u];                                            // the reciprocal is inside the weights
                     } else {
                         VT q = acc[u] * rcp_d;
                         q = v_fma<VT>(v_fma<VT>(q, -denom, acc[u]), rcp_d, q);
@@ -342,17 +452,22 @@ __device__ __forceinline__ void gather_map_u(const MapDesc &m, const EvalParams 
         gather_map_thin<VW>(m, P, rec, cnt_s, flag_s, idx_s, idx_base, tile_n);
         return;
     }
-    switch (m.unroll) {
-    case 1: gather_map<VW, 1, true>(m, P, rec, cnt_s, flag_s, idx_s, idx_base, tile_n, crec); break;
-    case 2: if (!SMALL) gather_map<VW, 2, true>(m, P, rec, cnt_s, flag_s, idx_s, idx_base, tile_n, crec); break;
-    case 3: if (!SMALL) gather_map<VW, 3, true>(m, P, rec, cnt_s, flag_s, idx_s, idx_base, tile_n, crec); break;
-    case -1: if (!SMALL) gather_map<VW, 1, false>(m, P, rec, cnt_s, flag_s, idx_s, idx_base, tile_n, crec); break;
-    case -2: if (!SMALL) gather_map<VW, 2, false>(m, P, rec, cnt_s, flag_s, idx_s, idx_base, tile_n, crec); break;
-    case -3: if (!SMALL) gather_map<VW, 3, false>(m, P, rec, cnt_s, flag_s, idx_s, idx_base, tile_n, crec); break;
-    default:
-        if (WIDE) gather_map<VW, 4, false>(m, P, rec, cnt_s, flag_s, idx_s, idx_base, tile_n, crec);
-        break;
+    if (m.fold) {                 // wide map: folded weights on the fast path
+        switch (m.unroll) {
+        case 1: gather_map<VW, 1, true, false, true>(m, P, rec, cnt_s, flag_s, idx_s, idx_base, tile_n, crec); break;
+        case 2: if (!SMALL) gather_map<VW, 2, true, false, true>(m, P, rec, cnt_s, flag_s, idx_s, idx_base, tile_n, crec); break;
+        case 3: if (!SMALL) gather_map<VW, 3, true, false, true>(m, P, rec, cnt_s, flag_s, idx_s, idx_base, tile_n, crec); break;
+        case -1: if (!SMALL) gather_map<VW, 1, false, false, true>(m, P, rec, cnt_s, flag_s, idx_s, idx_base, tile_n, crec); break;
+        case -2: if (!SMALL) gather_map<VW, 2, false, false, true>(m, P, rec, cnt_s, flag_s, idx_s, idx_base, tile_n, crec); break;
+        case -3: if (!SMALL) gather_map<VW, 3, false, false, true>(m, P, rec, cnt_s, flag_s, idx_s, idx_base, tile_n, crec); break;
+        default:
+            if (WIDE) gather_map<VW, 4, false, false, true>(m, P, rec, cnt_s, flag_s, idx_s, idx_base, tile_n, crec);
+            break;
+        }
+        return;
     }
+    // thin maps (<= 256 bytes per texel): the host maps them to one batched vector per lane, reference order
+    gather_map<VW, 1, true>(m, P, rec, cnt_s, flag_s, idx_s, idx_base, tile_n, crec);
 }
 
 // XCD-aware tile order: the dispatcher places workgroup b on XCD b%8 (observed, speed only).

@@ -35,9 +35,8 @@ namespace d3f {
 // RUN of K consecutive points and U 16-byte channel vectors per lane, and walks the run view by view: the four corner
 // vectors of a view stay in registers and are re-fetched only when the cell changes (a flag phase A computes once per
 // (point, view) by comparing the four corner offsets with the previous point's); the K accumulators carry the view
-// sums.  Per (point, view) the operations and their order are exactly those of gather_map's fast path -- acc +=
-// (fma chain over nw,ne,sw,se) * wgt in view order, then the shared-reciprocal division -- so the results are
-// bit-identical.  Points that need the strict path (non-finite projection) are left to gather_map(only_strict).
+// sums.  Per (point, view) the operations and their order are exactly those of gather_map's folded fast path -- four
+// fma with the folded weights into the view sum, views in order -- so the results are bit-identical.  Points that need the strict path (non-finite projection) are left to gather_map(only_strict).
 constexpr uint32_t kRunNonFinite = 1u;     // bits of the per-(point, view) state word (nfp_s)
 constexpr uint32_t kRunNewCell = 2u;       // the four corner texels differ from those of the previous point of the run
 constexpr uint32_t kRunValid = 4u;         // the view is valid for the point (its corner record is meaningful)
@@ -96,15 +95,13 @@ __device__ __forceinline__ void gather_map_runs(const MapDesc &m, const EvalPara
                             e[u] = load_texel<4, false>(bv + (o3 + co[u]));
                         }
                     }
-                    const float w0 = cr.w[0], w1 = cr.w[1], w2 = cr.w[2], w3 = cr.w[3];
-                    const float wgt = rec[q].wgt;
+                    const float w0 = cr.w[0], w1 = cr.w[1], w2 = cr.w[2], w3 = cr.w[3];      // folded (fuse_common.h)
 #pragma unroll
                     for (int u = 0; u < U; ++u) {
-                        VT s = a[u] * w0;                                // ATen bilinear: fma chain nw,ne,sw,se
-                        s = v_fma<VT>(b[u], w1, s);
-                        s = v_fma<VT>(d[u], w2, s);
-                        s = v_fma<VT>(e[u], w3, s);
-                        acc[k][u] = acc[k][u] + s * wgt;                 // fusion.py:385
+                        acc[k][u] = v_fma<VT>(a[u], w0, acc[k][u]);      // corners nw, ne, sw, se; views in order
+                        acc[k][u] = v_fma<VT>(b[u], w1, acc[k][u]);
+                        acc[k][u] = v_fma<VT>(d[u], w2, acc[k][u]);
+                        acc[k][u] = v_fma<VT>(e[u], w3, acc[k][u]);
                     }
                     // keep this point's arithmetic ahead of the next point's fetch: left alone, the optimiser sinks it below
                     // the next conditional load block, which needs a second set of corner registers (and spills).  The
@@ -117,24 +114,13 @@ __device__ __forceinline__ void gather_map_runs(const MapDesc &m, const EvalPara
             for (int k = 0; k < K; ++k) {
                 const int p = run0 + k;
                 if (p >= tile_n || flag_s[p] != 0u) continue;            // strict points: gather_map(only_strict) writes them
-                const float cnt = cnt_s[p];
-                const float denom = cnt + 1e-6f;                          // fusion.py:385
-                // the shared-reciprocal IEEE division of gather_map's fast path (bit-identical quotients)
-                const float r0 = __builtin_amdgcn_rcpf(denom);
-                const float rcp_d = fmaf(fmaf(-denom, r0, 1.0f), r0, r0);
+                // the weights carry 1/(cnt + 1e-6) already; no valid view: every weight is zero and so is the sum (fusion.py:386)
                 const int64_t row = (idx_base + idx_s[p]) * m.C;
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
                     const int cv = c0 + u * lpp + g;
                     if (cv >= cvec) continue;
-                    VT o = (VT)0.0f;                                      // fusion.py:386 when no view is valid
-                    if (cnt != 0.0f) {
-                        VT q = acc[k][u] * rcp_d;
-                        q = v_fma<VT>(v_fma<VT>(q, -denom, acc[k][u]), rcp_d, q);
-                        q = v_fma<VT>(v_fma<VT>(q, -denom, acc[k][u]), rcp_d, q);
-                        o = q;
-                    }
-                    store_out<VT>(m.out + row + (int64_t)cv * 4, o, P.store_policy);
+                    store_out<VT>(m.out + row + (int64_t)cv * 4, acc[k][u], P.store_policy);
                 }
             }
         }
@@ -148,11 +134,15 @@ __device__ __forceinline__ void gather_map_half_u(const MapDesc &m, const EvalPa
                                                   const float *cnt_s, const uint32_t *flag_s,
                                                   const uint32_t *idx_s, int64_t idx_base, int tile_n, const CornerRec *crec)
 {
-    switch (m.unroll) {
-    case 1: gather_map<VW, 1, true, true>(m, P, rec, cnt_s, flag_s, idx_s, idx_base, tile_n, crec); break;
-    case 2: gather_map<VW, 2, true, true>(m, P, rec, cnt_s, flag_s, idx_s, idx_base, tile_n, crec); break;
-    default: gather_map<VW, 3, true, true>(m, P, rec, cnt_s, flag_s, idx_s, idx_base, tile_n, crec); break;
+    if (m.fold) {
+        switch (m.unroll) {
+        case 1: gather_map<VW, 1, true, true, true>(m, P, rec, cnt_s, flag_s, idx_s, idx_base, tile_n, crec); break;
+        case 2: gather_map<VW, 2, true, true, true>(m, P, rec, cnt_s, flag_s, idx_s, idx_base, tile_n, crec); break;
+        default: gather_map<VW, 3, true, true, true>(m, P, rec, cnt_s, flag_s, idx_s, idx_base, tile_n, crec); break;
+        }
+        return;
     }
+    gather_map<VW, 1, true, true>(m, P, rec, cnt_s, flag_s, idx_s, idx_base, tile_n, crec);      // thin: one vector per lane
 }
 
 
@@ -217,75 +207,86 @@ __device__ __forceinline__ void fused_eval_body(const EvalParams &P)
         }
         return;
     }
-    // one lane per (point, view) pair: the V depth lookups of a point are in flight together
-    for (int idx = threadIdx.x; idx < tile_n * V; idx += kBlock) {
-        const int v = idx / tile_n, p = idx - v * tile_n;
-        // (indices are clamped: a stale buffer passed with D3F_FLAG_REUSE_POINT_ORDER must not fault the device)
-        const int64_t i = walk ? walk_point(P, tb, p) : (P.order ? min((int64_t)P.order[tile_base + p], P.n - 1) : tile_base + p);
-        float px, py, pz;
-        fetch_point(P, i, px, py, pz);
-        float wgt;
-        const ViewOut o = eval_view<MODE>(P.depth, P.H, P.W, krt + v * 12, v, px, py, pz, Wm1, Hm1, mu, wgt);
-        ViewRec r;
-        r.gx = o.gx; r.gy = o.gy; r.wgt = wgt; r.valid = o.valid;
-        rec[p * V + v] = r;
-        dcl_s[p * V + v] = o.dist * o.valid;                                // fusion.py:364 (product only)
-        for (int s = 0; s < P.n_maps; ++s) {
-            const MapDesc &m = P.maps[s];
-            if (m.pre_slot >= 0 && o.valid != 0.0f) {
-                const Corner c = corner_setup(m, o.gx, o.gy);
-                CornerRec cr;
-                cr.o[0] = c.onw; cr.o[1] = c.one; cr.o[2] = c.osw; cr.o[3] = c.ose;
-                cr.w[0] = c.inw ? c.wnw : 0.0f; cr.w[1] = c.ine ? c.wne : 0.0f;
-                cr.w[2] = c.isw ? c.wsw : 0.0f; cr.w[3] = c.ise ? c.wse : 0.0f;
-                crec_s[(size_t)m.pre_slot * TP * V + p * V + v] = cr;
-            } else if (RUNS && m.runs > 0) {
-                // the cell-run gather multiplies instead of branching: an invalid pair contributes (+-0) * wgt
-                CornerRec cr;
-                cr.o[0] = cr.o[1] = cr.o[2] = cr.o[3] = 0u;
-                cr.w[0] = cr.w[1] = cr.w[2] = cr.w[3] = 0.0f;
-                crec_s[(size_t)m.pre_slot * TP * V + p * V + v] = cr;
+    // One lane per (point, view) pair, the views of a point in VP = 2^k >= V adjacent lanes: the V depth lookups of a point
+    // are in flight together, the per-point sums over the views are rebuilt IN VIEW ORDER with wave shuffles (no second
+    // pass over LDS), and every pair knows the point's view count when it writes its records -- which is what lets the
+    // folded weights of wide maps (fuse_common.h) be final here.  Whole waves iterate (shuffles).
+    {
+        const bool finite_maps = maps_are_finite(P);
+        const int vp_log2 = view_lanes_log2(V), VP = 1 << vp_log2;
+        const int lane = threadIdx.x & 63, base = lane & ~(VP - 1);
+        const int npair = tile_n << vp_log2;
+        for (int idx0 = (int)(threadIdx.x & ~63u); idx0 < npair; idx0 += kBlock) {
+            const int idx = idx0 + lane;
+            const bool in = idx < npair;
+            const int p = min(idx >> vp_log2, tile_n - 1), v = idx & (VP - 1);
+            const bool act = in && v < V;
+            // (indices are clamped: a stale buffer passed with D3F_FLAG_REUSE_POINT_ORDER must not fault the device)
+            const int64_t i = walk ? walk_point(P, tb, p) : (P.order ? min((int64_t)P.order[tile_base + p], P.n - 1) : tile_base + p);
+            ViewOut o;
+            o.gx = 0.0f; o.gy = 0.0f; o.dist = 0.0f; o.valid = 0.0f;
+            float wgt = 0.0f;
+            uint32_t st = 0u;
+            if (act) {
+                float px, py, pz;
+                fetch_point(P, i, px, py, pz);
+                o = eval_view<MODE>(P.depth, P.H, P.W, krt + v * 12, v, px, py, pz, Wm1, Hm1, mu, wgt);
+                if (!(isfinite(o.gx) && isfinite(o.gy) && isfinite(wgt))) st = kRunNonFinite;
+            }
+            float dsum, cnt;
+            uint32_t nonfinite;
+            view_sums(V, base, o.dist * o.valid, o.valid, st, dsum, cnt, nonfinite);      // fusion.py:364 (products), :368
+            const float fsc = fold_scale(wgt, cnt);
+            uint32_t c0 = 0u, c1 = 0u, c2 = 0u, c3 = 0u;          // corner offsets of the first cell-run map (slot 0)
+            if (act) {
+                ViewRec r;
+                r.gx = o.gx; r.gy = o.gy; r.wgt = wgt; r.valid = o.valid;
+                rec[p * V + v] = r;
+                for (int s = 0; s < P.n_maps; ++s) {
+                    const MapDesc &m = P.maps[s];
+                    if (m.pre_slot >= 0 && o.valid != 0.0f) {
+                        const Corner c = corner_setup(m, o.gx, o.gy);
+                        const float sc = m.fold ? fsc : 1.0f;
+                        CornerRec cr;
+                        cr.o[0] = c.onw; cr.o[1] = c.one; cr.o[2] = c.osw; cr.o[3] = c.ose;
+                        cr.w[0] = c.inw ? c.wnw : 0.0f; cr.w[1] = c.ine ? c.wne : 0.0f;
+                        cr.w[2] = c.isw ? c.wsw : 0.0f; cr.w[3] = c.ise ? c.wse : 0.0f;
+                        if (m.fold) { cr.w[0] = cr.w[0] * sc; cr.w[1] = cr.w[1] * sc; cr.w[2] = cr.w[2] * sc; cr.w[3] = cr.w[3] * sc; }
+                        crec_s[(size_t)m.pre_slot * TP * V + p * V + v] = cr;
+                        if (RUNS && m.pre_slot == 0) { c0 = c.onw; c1 = c.one; c2 = c.osw; c3 = c.ose; }
+                    } else if (RUNS && m.runs > 0) {
+                        // the cell-run gather multiplies instead of branching: an invalid pair contributes +-0
+                        CornerRec cr;
+                        cr.o[0] = cr.o[1] = cr.o[2] = cr.o[3] = 0u;
+                        cr.w[0] = cr.w[1] = cr.w[2] = cr.w[3] = 0.0f;
+                        crec_s[(size_t)m.pre_slot * TP * V + p * V + v] = cr;
+                    }
+                }
+            }
+            if (RUNS) {
+                // cell-run gather: does this pair address the same four texels (of the first cell-run map) as the previous
+                // point of the tile?  The previous point's pair of this view is VP lanes down; it counts only if it is valid
+                // too -- an invalid or strict predecessor is handled by the consumer (the chain breaks there).
+                const uint32_t q0 = __shfl_up(c0, VP, 64), q1 = __shfl_up(c1, VP, 64), q2 = __shfl_up(c2, VP, 64), q3 = __shfl_up(c3, VP, 64);
+                const float pv = __shfl_up(o.valid, VP, 64);
+                // a run starts at every RK-th point of the tile: its first valid pair always fetches
+                const bool same = lane >= VP && (p % (RK > 0 ? RK : 1)) != 0 && pv != 0.0f && q0 == c0 && q1 == c1 && q2 == c2 && q3 == c3;
+                if (!same) st |= kRunNewCell;
+                if (o.valid != 0.0f) st |= kRunValid;
+            }
+            if (act) nfp_s[p * V + v] = st;
+            if (in && v == 0) {
+                // per point: outputs leave from the lane of view 0
+                const bool all_invalid = (cnt == 0.0f);                             // fusion.py:366
+                float dist_out = dsum / (cnt + 1e-6f);
+                if (MODE == 0 && all_invalid) dist_out = 1e3f;                      // fusion.py:367
+                P.out_dist[i] = dist_out;
+                P.out_valid[i] = all_invalid ? 0 : 1;
+                cnt_s[p] = cnt;
+                idx_s[p] = (uint32_t)(i - idx_base);
+                flag_s[p] = (nonfinite || !finite_maps) ? 1u : 0u;
             }
         }
-        uint32_t st = !(isfinite(o.gx) && isfinite(o.gy) && isfinite(wgt)) ? kRunNonFinite : 0u;
-        if (RUNS) {
-            // cell-run gather: does this pair address the same four texels (of the first cell-run map) as the previous
-            // point of the tile?  The previous point is the previous lane (idx = v*tile_n + p); it counts only if it
-            // is valid too -- an invalid or strict predecessor is handled by the consumer (the chain breaks there).
-            uint32_t o0 = 0u, o1 = 0u, o2 = 0u, o3 = 0u;
-            if (o.valid != 0.0f) {
-                const CornerRec &cr = crec_s[p * V + v];        // slot 0 = the first cell-run map (written just above)
-                o0 = cr.o[0]; o1 = cr.o[1]; o2 = cr.o[2]; o3 = cr.o[3];
-            }
-            const uint32_t q0 = __shfl_up(o0, 1, 64), q1 = __shfl_up(o1, 1, 64), q2 = __shfl_up(o2, 1, 64), q3 = __shfl_up(o3, 1, 64);
-            const float pv = __shfl_up(o.valid, 1, 64);
-            // a run starts at every RK-th point of the tile: its first valid pair always fetches
-            const bool same = (threadIdx.x & 63) != 0 && (p % (RK > 0 ? RK : 1)) != 0 && pv != 0.0f && q0 == o0 && q1 == o1 && q2 == o2 && q3 == o3;
-            if (!same) st |= kRunNewCell;
-            if (o.valid != 0.0f) st |= kRunValid;
-        }
-        nfp_s[p * V + v] = st;
-    }
-    __syncthreads();
-    // per point: sums over the views in view order (fusion.py:364-370), outputs leave coalesced
-    for (int p = threadIdx.x; p < tile_n; p += kBlock) {
-        // (indices are clamped: a stale buffer passed with D3F_FLAG_REUSE_POINT_ORDER must not fault the device)
-        const int64_t i = walk ? walk_point(P, tb, p) : (P.order ? min((int64_t)P.order[tile_base + p], P.n - 1) : tile_base + p);
-        float dsum = 0.0f, cnt = 0.0f;
-        uint32_t nonfinite = 0u;
-        for (int v = 0; v < V; ++v) {
-            dsum = dsum + dcl_s[p * V + v];
-            cnt = cnt + rec[p * V + v].valid;
-            nonfinite |= nfp_s[p * V + v] & kRunNonFinite;
-        }
-        const bool all_invalid = (cnt == 0.0f);                             // fusion.py:366
-        float dist_out = dsum / (cnt + 1e-6f);
-        if (MODE == 0 && all_invalid) dist_out = 1e3f;                      // fusion.py:367
-        P.out_dist[i] = dist_out;
-        P.out_valid[i] = all_invalid ? 0 : 1;
-        cnt_s[p] = cnt;
-        idx_s[p] = (uint32_t)(i - idx_base);
-        flag_s[p] = (nonfinite || !(P.flags & kFlagFiniteMaps)) ? 1u : 0u;
     }
     __syncthreads();
 
@@ -298,7 +299,7 @@ __device__ __forceinline__ void fused_eval_body(const EvalParams &P)
             // (the host gives such a map 16-byte vectors, one per lane, and a corner-record slot)
             if (V == 4) gather_map_runs<(RU > 0 ? RU : 1), (RK > 0 ? RK : 1), 4>(m, P, rec, nfp_s, cnt_s, flag_s, idx_s, idx_base, tile_n, crec);
             else gather_map_runs<(RU > 0 ? RU : 1), (RK > 0 ? RK : 1), 0>(m, P, rec, nfp_s, cnt_s, flag_s, idx_s, idx_base, tile_n, crec);
-            gather_map<4, (RU > 0 ? RU : 1), true>(m, P, rec, cnt_s, flag_s, idx_s, idx_base, tile_n, crec, true);
+            gather_map<4, (RU > 0 ? RU : 1), true, false, true>(m, P, rec, cnt_s, flag_s, idx_s, idx_base, tile_n, crec, true);
             continue;
         }
         if (ANYF16 && m.esize == 2) {
@@ -383,53 +384,60 @@ __device__ __forceinline__ void fused_eval_sliced_body(const EvalParams &P)
     const float Wm1 = (float)(P.W - 1), Hm1 = (float)(P.H - 1);
     const MapDesc &m0 = P.maps[0];                                           // the sliced wide map
 
-    // ---------------- phase A (as fused_eval_body) ----------------
-    for (int idx = threadIdx.x; idx < tile_n * V; idx += kBlock) {
-        const int v = idx / tile_n, p = idx - v * tile_n;
-        const int64_t i = point_of(p);
-        float px, py, pz;
-        fetch_point(P, i, px, py, pz);
-        float wgt;
-        const ViewOut o = eval_view<0>(P.depth, P.H, P.W, krt + v * 12, v, px, py, pz, Wm1, Hm1, mu, wgt);
-        ViewRec r;
-        r.gx = o.gx; r.gy = o.gy; r.wgt = wgt; r.valid = o.valid;
-        rec[p * V + v] = r;
-        dcl_s[p * V + v] = o.dist * o.valid;
-        if (o.valid != 0.0f) {
-            const Corner c = corner_setup(m0, o.gx, o.gy);
-            CornerRec cr;
-            cr.o[0] = c.onw; cr.o[1] = c.one; cr.o[2] = c.osw; cr.o[3] = c.ose;
-            cr.w[0] = c.inw ? c.wnw : 0.0f; cr.w[1] = c.ine ? c.wne : 0.0f;
-            cr.w[2] = c.isw ? c.wsw : 0.0f; cr.w[3] = c.ise ? c.wse : 0.0f;
-            crec_s[p * V + v] = cr;
-        } else {
-            CornerRec cr;                           // invalid pair: texel 0 with zero weights (see phase B)
-            cr.o[0] = cr.o[1] = cr.o[2] = cr.o[3] = 0u;
-            cr.w[0] = cr.w[1] = cr.w[2] = cr.w[3] = 0.0f;
-            crec_s[p * V + v] = cr;
+    // ---------------- phase A (as fused_eval_body: lane = (point, view), the views of a point adjacent) ----------------
+    {
+        const bool finite_maps = maps_are_finite(P);
+        const int vp_log2 = view_lanes_log2(V), VP = 1 << vp_log2;
+        const int lane = threadIdx.x & 63, base = lane & ~(VP - 1);
+        const int npair = tile_n << vp_log2;
+        for (int idx0 = (int)(threadIdx.x & ~63u); idx0 < npair; idx0 += kBlock) {
+            const int idx = idx0 + lane;
+            const bool in = idx < npair;
+            const int p = min(idx >> vp_log2, tile_n - 1), v = idx & (VP - 1);
+            const bool act = in && v < V;
+            const int64_t i = point_of(p);
+            ViewOut o;
+            o.gx = 0.0f; o.gy = 0.0f; o.dist = 0.0f; o.valid = 0.0f;
+            float wgt = 0.0f;
+            uint32_t st = 0u;
+            if (act) {
+                float px, py, pz;
+                fetch_point(P, i, px, py, pz);
+                o = eval_view<0>(P.depth, P.H, P.W, krt + v * 12, v, px, py, pz, Wm1, Hm1, mu, wgt);
+                if (!(isfinite(o.gx) && isfinite(o.gy) && isfinite(wgt))) st = 1u;
+            }
+            float dsum, cnt;
+            uint32_t nonfinite;
+            view_sums(V, base, o.dist * o.valid, o.valid, st, dsum, cnt, nonfinite);
+            if (act) {
+                ViewRec r;
+                r.gx = o.gx; r.gy = o.gy; r.wgt = wgt; r.valid = o.valid;
+                rec[p * V + v] = r;
+                CornerRec cr;                           // invalid pair: texel 0 with zero weights (see phase B)
+                cr.o[0] = cr.o[1] = cr.o[2] = cr.o[3] = 0u;
+                cr.w[0] = cr.w[1] = cr.w[2] = cr.w[3] = 0.0f;
+                if (o.valid != 0.0f) {
+                    const Corner c = corner_setup(m0, o.gx, o.gy);
+                    const float sc = fold_scale(wgt, cnt);          // the sliced map is wide: folded weights (fuse_common.h)
+                    cr.o[0] = c.onw; cr.o[1] = c.one; cr.o[2] = c.osw; cr.o[3] = c.ose;
+                    cr.w[0] = (c.inw ? c.wnw : 0.0f) * sc; cr.w[1] = (c.ine ? c.wne : 0.0f) * sc;
+                    cr.w[2] = (c.isw ? c.wsw : 0.0f) * sc; cr.w[3] = (c.ise ? c.wse : 0.0f) * sc;
+                }
+                crec_s[p * V + v] = cr;
+            }
+            if (in && v == 0) {
+                const bool all_invalid = (cnt == 0.0f);
+                float dist_out = dsum / (cnt + 1e-6f);
+                if (all_invalid) dist_out = 1e3f;
+                if (slice == 0) {                                                    // one slice writes the per-point outputs
+                    P.out_dist[i] = dist_out;
+                    P.out_valid[i] = all_invalid ? 0 : 1;
+                }
+                cnt_s[p] = cnt;
+                idx_s[p] = (uint32_t)i;
+                flag_s[p] = (nonfinite || !finite_maps) ? 1u : 0u;
+            }
         }
-        nfp_s[p * V + v] = !(isfinite(o.gx) && isfinite(o.gy) && isfinite(wgt)) ? 1u : 0u;
-    }
-    __syncthreads();
-    for (int p = threadIdx.x; p < tile_n; p += kBlock) {
-        const int64_t i = point_of(p);
-        float dsum = 0.0f, cnt = 0.0f;
-        uint32_t nonfinite = 0u;
-        for (int v = 0; v < V; ++v) {
-            dsum = dsum + dcl_s[p * V + v];
-            cnt = cnt + rec[p * V + v].valid;
-            nonfinite |= nfp_s[p * V + v];
-        }
-        const bool all_invalid = (cnt == 0.0f);
-        float dist_out = dsum / (cnt + 1e-6f);
-        if (all_invalid) dist_out = 1e3f;
-        if (slice == 0) {                                                    // one slice writes the per-point outputs
-            P.out_dist[i] = dist_out;
-            P.out_valid[i] = all_invalid ? 0 : 1;
-        }
-        cnt_s[p] = cnt;
-        idx_s[p] = (uint32_t)i;
-        flag_s[p] = (nonfinite || !(P.flags & kFlagFiniteMaps)) ? 1u : 0u;
     }
     __syncthreads();
 
@@ -448,13 +456,13 @@ __device__ __forceinline__ void fused_eval_sliced_body(const EvalParams &P)
             VT acc = (VT)0.0f;
             if (!strict) {
                 // fast path, branch-free: phase A left an all-zero corner record for an invalid (point, view), so its
-                // loads hit texel 0 of the view and its term is (+-0) * wgt -- adding it changes no bit.
-                // The corner loads of VC views are in flight together, then the views are consumed in view order.
+                // loads hit texel 0 of the view and its term is +-0 -- adding it changes no bit.  The corner
+                // loads of VC views are in flight together, then the views are consumed in view order with the folded
+                // weights: four fma per view straight into the sum.
                 int v0 = 0;
                 for (; v0 + VC <= V; v0 += VC) {
                     VT a[VC], b[VC], d[VC], e[VC];
                     f32x4 w[VC];
-                    float wg[VC];
 #pragma unroll
                     for (int q = 0; q < VC; ++q) {
                         const CornerRec cr = crec_s[p * V + v0 + q];
@@ -464,15 +472,13 @@ __device__ __forceinline__ void fused_eval_sliced_body(const EvalParams &P)
                         d[q] = load_texel<4, false>(bv + (cr.o[2] + co));
                         e[q] = load_texel<4, false>(bv + (cr.o[3] + co));
                         w[q] = f32x4{cr.w[0], cr.w[1], cr.w[2], cr.w[3]};
-                        wg[q] = rec[p * V + v0 + q].wgt;
                     }
 #pragma unroll
                     for (int q = 0; q < VC; ++q) {
-                        VT s_ = a[q] * w[q].x;
-                        s_ = v_fma<VT>(b[q], w[q].y, s_);
-                        s_ = v_fma<VT>(d[q], w[q].z, s_);
-                        s_ = v_fma<VT>(e[q], w[q].w, s_);
-                        acc = acc + s_ * wg[q];
+                        acc = v_fma<VT>(a[q], w[q].x, acc);
+                        acc = v_fma<VT>(b[q], w[q].y, acc);
+                        acc = v_fma<VT>(d[q], w[q].z, acc);
+                        acc = v_fma<VT>(e[q], w[q].w, acc);
                     }
                 }
                 for (; v0 < V; ++v0) {
@@ -480,11 +486,10 @@ __device__ __forceinline__ void fused_eval_sliced_body(const EvalParams &P)
                     const char *bv = data + (int64_t)v0 * m.sv * 4;
                     const VT a = load_texel<4, false>(bv + (cr.o[0] + co)), b = load_texel<4, false>(bv + (cr.o[1] + co));
                     const VT d = load_texel<4, false>(bv + (cr.o[2] + co)), e = load_texel<4, false>(bv + (cr.o[3] + co));
-                    VT s_ = a * cr.w[0];
-                    s_ = v_fma<VT>(b, cr.w[1], s_);
-                    s_ = v_fma<VT>(d, cr.w[2], s_);
-                    s_ = v_fma<VT>(e, cr.w[3], s_);
-                    acc = acc + s_ * rec[p * V + v0].wgt;
+                    acc = v_fma<VT>(a, cr.w[0], acc);
+                    acc = v_fma<VT>(b, cr.w[1], acc);
+                    acc = v_fma<VT>(d, cr.w[2], acc);
+                    acc = v_fma<VT>(e, cr.w[3], acc);
                 }
             } else {
                 for (int v = 0; v < V; ++v) {
@@ -501,18 +506,10 @@ __device__ __forceinline__ void fused_eval_sliced_body(const EvalParams &P)
                     acc = acc + (s_ * r.valid) * r.wgt;
                 }
             }
-            VT o = (VT)0.0f;
-            if (cnt != 0.0f) {
-                if (strict) {
-                    o = strict_div<VT>(acc, denom);
-                } else {
-                    const float r0 = __builtin_amdgcn_rcpf(denom);
-                    const float rcp_d = fmaf(fmaf(-denom, r0, 1.0f), r0, r0);
-                    VT q = acc * rcp_d;
-                    q = v_fma<VT>(v_fma<VT>(q, -denom, acc), rcp_d, q);
-                    q = v_fma<VT>(v_fma<VT>(q, -denom, acc), rcp_d, q);
-                    o = q;
-                }
+            VT o = acc;                         // fast path: the weights carry 1/(cnt + 1e-6); no valid view: every weight is 0
+            if (strict) {
+                o = (VT)0.0f;                   // fusion.py:386
+                if (cnt != 0.0f) o = strict_div<VT>(acc, denom);
             }
             store_out<VT>(m.out + i * m.C + (co >> 2), o, P.store_policy);
         }
@@ -558,14 +555,15 @@ __global__ __launch_bounds__(kBlock, WAVES) void fused_eval_sliced_kernel(const 
 // Measured history, counters and the variants that lost: DESIGN.md 5.5.
 // Slots of a clipped brick (or of the last, short tile of a cloud) repeat a neighbouring point: same inputs, same
 // outputs, written twice.
-constexpr uint32_t kWinDirect = 0xffffffffu;
+constexpr float kWinDirectMark = 2.0f;       // WinRec::valid of a pair gathered from global memory (a view's validity is 0 or 1)
 struct __attribute__((aligned(16))) WinRec {
-    uint32_t nw;        // LDS byte offset of the nw corner's slice; ne = nw + slice bytes, sw = nw + row, se = sw + slice bytes
-    uint32_t row;       // bytes between the window's rows
-    float wgt;          // ViewRec::wgt
-    float valid;        // ViewRec::valid
-    float w[4];         // bilinear weights nw, ne, sw, se; a direct pair (and every pair of a strict point) keeps
-                        // gx, gy here instead -- the 16-byte view records exist only when thin maps ride along
+    uint32_t nw;        // LDS byte offset of the nw corner's slice; ne = nw + slice bytes
+    uint32_t sw;        // LDS byte offset of the sw corner's slice (one window row further); se = sw + slice bytes
+    float wgt;          // a direct pair of a fast point: fold_scale(wgt, cnt); every pair of a strict point: ViewRec::wgt
+    float valid;        // ViewRec::valid; kWinDirectMark: a DIRECT pair (corners outside the window / the pool) of a non-strict
+                        // point -- nw and sw then point at the zero slices, so the pipelined loop may read them harmlessly
+    float w[4];         // FOLDED bilinear weights nw, ne, sw, se (fuse_common.h); a direct pair (and every pair of a strict
+                        // point) keeps gx, gy here instead -- the 16-byte view records exist only when thin maps ride along
 };
 struct WinView {
     int xmin, ymin, bw, bh;     // texel rectangle
@@ -593,14 +591,14 @@ __device__ __forceinline__ void window_point(f32x4 (&acc)[NV], const unsigned ch
             const f32x4 *r = reinterpret_cast<const f32x4 *>(wr_p + v0 + q);
             f32x4 h0 = r[0], h1 = r[1];
             asm volatile("" : "+v"(h0));
-            wr[q].nw = __float_as_uint(h0.x); wr[q].row = __float_as_uint(h0.y); wr[q].wgt = h0.z; wr[q].valid = h0.w;
+            wr[q].nw = __float_as_uint(h0.x); wr[q].sw = __float_as_uint(h0.y); wr[q].wgt = h0.z; wr[q].valid = h0.w;
             wr[q].w[0] = h1.x; wr[q].w[1] = h1.y; wr[q].w[2] = h1.z; wr[q].w[3] = h1.w;
         }
         VT a[VC][NV], b[VC][NV], d[VC][NV], e[VC][NV];
 #pragma unroll
         for (int q = 0; q < VC; ++q) {
             const unsigned char *nw = smem + (wr[q].nw + lane_off);
-            const unsigned char *sw = nw + wr[q].row;
+            const unsigned char *sw = smem + (wr[q].sw + lane_off);
 #pragma unroll
             for (int u = 0; u < NV; ++u) {
                 a[q][u] = *reinterpret_cast<const VT *>(nw + u * VS);
@@ -613,47 +611,135 @@ __device__ __forceinline__ void window_point(f32x4 (&acc)[NV], const unsigned ch
         for (int q = 0; q < VC; ++q)
 #pragma unroll
             for (int u = 0; u < NV; ++u) {
-                VT s_ = a[q][u] * wr[q].w[0];
-                s_ = v_fma<VT>(b[q][u], wr[q].w[1], s_);
-                s_ = v_fma<VT>(d[q][u], wr[q].w[2], s_);
-                s_ = v_fma<VT>(e[q][u], wr[q].w[3], s_);
-                acc[u] = acc[u] + s_ * wr[q].wgt;
+                acc[u] = v_fma<VT>(a[q][u], wr[q].w[0], acc[u]);        // folded weights (fuse_common.h)
+                acc[u] = v_fma<VT>(b[q][u], wr[q].w[1], acc[u]);
+                acc[u] = v_fma<VT>(d[q][u], wr[q].w[2], acc[u]);
+                acc[u] = v_fma<VT>(e[q][u], wr[q].w[3], acc[u]);
             }
     }
     if constexpr (VC > 1) {
         for (; v0 < V; ++v0) {
             const WinRec wr = wr_p[v0];
             const unsigned char *nw = smem + (wr.nw + lane_off);
-            const unsigned char *sw = nw + wr.row;
+            const unsigned char *sw = smem + (wr.sw + lane_off);
 #pragma unroll
             for (int u = 0; u < NV; ++u) {
                 const VT a = *reinterpret_cast<const VT *>(nw + u * VS), b = *reinterpret_cast<const VT *>(nw + SBB + u * VS);
                 const VT d = *reinterpret_cast<const VT *>(sw + u * VS), e = *reinterpret_cast<const VT *>(sw + SBB + u * VS);
-                VT s_ = a * wr.w[0];
-                s_ = v_fma<VT>(b, wr.w[1], s_);
-                s_ = v_fma<VT>(d, wr.w[2], s_);
-                s_ = v_fma<VT>(e, wr.w[3], s_);
-                acc[u] = acc[u] + s_ * wr.wgt;
+                acc[u] = v_fma<VT>(a, wr.w[0], acc[u]);
+                acc[u] = v_fma<VT>(b, wr.w[1], acc[u]);
+                acc[u] = v_fma<VT>(d, wr.w[2], acc[u]);
+                acc[u] = v_fma<VT>(e, wr.w[3], acc[u]);
             }
         }
     }
 }
 
+// The same for KI points of one lane group with the view count a compile-time constant, as ONE software pipeline over the
+// KI * VF (point, view) steps (round 4).  The loop above costs two dependent LDS round trips per (point, view) -- record, then
+// the corners the record points at -- with nothing else in flight: the counters of round 3's kernel showed waves waiting
+// 57 % of their time with the LDS array 44 % and the VALU 39 % busy.  Here step j's sixteen fma run while the eight corner
+// reads of step j + 1 and the record of step j + 2 are in flight (records: one ds_read_b64 {nw, sw} + one ds_read_b128
+// {weights}; their addresses are immediates off one base register), so a wave always has >= 10 LDS reads behind its
+// arithmetic.  Same operands in the same order as window_point: bit-identical.
+//   rec0      LDS byte offset of the first point's first record;  KSTRIDE bytes between the lane group's consecutive points
+//   done(k, acc)  called once per point, after its last view
+template <int NV>
+struct WinPipe {            // registers of the pipeline; every index below is a compile-time constant
+    uint2 off[3];
+    f32x4 wt[3];
+    f32x4 c[2][4][NV];
+    f32x4 acc[NV];
+};
+
+template <int J, int NV, int VF, int KI, int VS, int SBB, int KSTRIDE>
+__device__ __forceinline__ void win_pipe_record(WinPipe<NV> &st, const unsigned char *smem, uint32_t rec0)
+{
+    const unsigned char *r = smem + rec0 + (uint32_t)((J / VF) * KSTRIDE + (J % VF) * (int)sizeof(WinRec));
+    st.off[J % 3] = *reinterpret_cast<const uint2 *>(r);
+    st.wt[J % 3] = *reinterpret_cast<const f32x4 *>(r + 16);
+}
+
+template <int J, int NV, int VS, int SBB>
+__device__ __forceinline__ void win_pipe_corners(WinPipe<NV> &st, const unsigned char *smem, uint32_t lane_off)
+{
+    using VT = f32x4;
+    const unsigned char *nw = smem + (st.off[J % 3].x + lane_off);
+    const unsigned char *sw = smem + (st.off[J % 3].y + lane_off);
+#pragma unroll
+    for (int u = 0; u < NV; ++u) {
+        st.c[J % 2][0][u] = *reinterpret_cast<const VT *>(nw + u * VS);
+        st.c[J % 2][1][u] = *reinterpret_cast<const VT *>(nw + SBB + u * VS);
+        st.c[J % 2][2][u] = *reinterpret_cast<const VT *>(sw + u * VS);
+        st.c[J % 2][3][u] = *reinterpret_cast<const VT *>(sw + SBB + u * VS);
+    }
+}
+
+template <int J, int NV, int VF, int KI, int VS, int SBB, int KSTRIDE, typename DONE>
+__device__ __forceinline__ void win_pipe_step(WinPipe<NV> &st, const unsigned char *smem, uint32_t rec0, uint32_t lane_off, DONE &done)
+{
+    using VT = f32x4;
+    constexpr int NS = KI * VF;
+    if constexpr (J + 2 < NS) win_pipe_record<J + 2, NV, VF, KI, VS, SBB, KSTRIDE>(st, smem, rec0);
+    if constexpr (J + 1 < NS) win_pipe_corners<J + 1, NV, VS, SBB>(st, smem, lane_off);
+#pragma unroll
+    for (int u = 0; u < NV; ++u) {
+        st.acc[u] = v_fma<VT>(st.c[J % 2][0][u], st.wt[J % 3].x, st.acc[u]);        // folded weights (fuse_common.h): nw, ne, sw, se
+        st.acc[u] = v_fma<VT>(st.c[J % 2][1][u], st.wt[J % 3].y, st.acc[u]);
+        st.acc[u] = v_fma<VT>(st.c[J % 2][2][u], st.wt[J % 3].z, st.acc[u]);
+        st.acc[u] = v_fma<VT>(st.c[J % 2][3][u], st.wt[J % 3].w, st.acc[u]);
+    }
+    if constexpr (J % VF == VF - 1) {
+        done(J / VF, st.acc);
+#pragma unroll
+        for (int u = 0; u < NV; ++u) st.acc[u] = (VT)0.0f;
+    }
+    __builtin_amdgcn_sched_barrier(0);          // keep the steps in program order (the pipeline IS the schedule)
+    if constexpr (J + 1 < NS) win_pipe_step<J + 1, NV, VF, KI, VS, SBB, KSTRIDE>(st, smem, rec0, lane_off, done);
+}
+
+template <int NV, int VF, int KI, int VS, int SBB, int KSTRIDE, typename DONE>
+__device__ __forceinline__ void window_points_pipelined(const unsigned char *smem, uint32_t rec0, uint32_t lane_off, DONE done)
+{
+    WinPipe<NV> st;
+    win_pipe_record<0, NV, VF, KI, VS, SBB, KSTRIDE>(st, smem, rec0);
+    if constexpr (KI * VF > 1) win_pipe_record<1, NV, VF, KI, VS, SBB, KSTRIDE>(st, smem, rec0);
+    win_pipe_corners<0, NV, VS, SBB>(st, smem, lane_off);
+#pragma unroll
+    for (int u = 0; u < NV; ++u) st.acc[u] = (f32x4)0.0f;
+    win_pipe_step<0, NV, VF, KI, VS, SBB, KSTRIDE>(st, smem, rec0, lane_off, done);
+}
+
 // LPP lanes per point in phase B: 32 (U vectors per lane, 512 bytes apart, slices of 512*U bytes) or 16 (U == 1: two
 // vectors per lane 256 bytes apart inside the 512-byte slice, four points per wave instruction)
-template <int U, int VC, int NT, int LPP>
+// VFIX: 4 / 8 = the view count as a compile-time constant (the host launches that variant when V matches): the point loop
+// runs window_points_pipelined; 0: any V <= 8, view loop of window_point
+template <int U, int VC, int NT, int LPP, int VFIX>
 __device__ __forceinline__ void fused_eval_window_body(const EvalParams &P)
 {
     using VT = f32x4;
     static_assert(LPP == 32 || (LPP == 16 && U == 1), "16 lanes per point only with 512-byte slices");
+#ifdef D3F_EXPERIMENTS
+    // phase stamps (D3F_EXP_STAMPS=1): lane 0 of wave 0 of every 64th workgroup writes s_memtime at the phase boundaries
+    int stamp_k = 0;
+    const bool stamping = P.exp_stamps != nullptr && (blockIdx.x & 63u) == 0u && threadIdx.x == 0 && (blockIdx.x >> 6) < 65536u;
+#define D3F_STAMP() do { if (stamping && stamp_k < 31) P.exp_stamps[(size_t)(blockIdx.x >> 6) * 32 + 1 + stamp_k++] = __builtin_readcyclecounter(); } while (0)
+#else
+#define D3F_STAMP() do { } while (0)
+#endif
+    D3F_STAMP();                                    // 0: entry
     constexpr int NV = U * (32 / LPP);                 // vectors per lane
     constexpr int VS = 16 * LPP;                       // bytes between a lane's vectors
     extern __shared__ __align__(16) unsigned char smem[];
     const int V = P.V;
     const int TP = P.tile_pts;
     const bool has_rec = P.n_maps > 1;                                       // thin maps read the view records
-    WinRec *wrec = reinterpret_cast<WinRec *>(smem);                         // [TP*V]
-    ViewRec *rec = reinterpret_cast<ViewRec *>(wrec + (size_t)TP * V);       // [TP*V] if has_rec
+    // window records: V consecutive 32-byte records per point, points (V*32 + 16) bytes apart -- with V = 8 a stride of 256
+    // bytes puts the records of the two points a ds_read lane group serves on the same banks (round 3's c4_patch counters:
+    // SQ_LDS_BANK_CONFLICT = 16 % of the LDS cycles, exactly the two-way conflict of every record read)
+    const uint32_t pstride = (uint32_t)(VFIX > 0 ? VFIX : V) * 32u + 16u;
+    auto wrec_at = [&](int p) -> WinRec * { return reinterpret_cast<WinRec *>(smem + (uint32_t)p * pstride); };
+    ViewRec *rec = reinterpret_cast<ViewRec *>(smem + (size_t)TP * pstride);   // [TP*V] if has_rec
     float *cnt_s = reinterpret_cast<float *>(rec + (has_rec ? (size_t)TP * V : 0));   // [TP]
     uint32_t *flag_s = reinterpret_cast<uint32_t *>(cnt_s + TP);             // [TP]
     uint32_t *idx_s = flag_s + TP;                                           // [TP]
@@ -710,6 +796,15 @@ __device__ __forceinline__ void fused_eval_window_body(const EvalParams &P)
     const float mu = P.mu;
     const float Wm1 = (float)(P.W - 1), Hm1 = (float)(P.H - 1);
 
+    // ---- 0. this lane's query point of phase A's first pass, requested NOW: its load (a first touch of the point array: an HBM
+    //         round trip) returns underneath the set-up below instead of in front of the projection (phase stamps, round 4:
+    //         phase A was 10.5 k of a workgroup's 60 k cycles, ~4.5 k of them this load)
+    const int pa_log2 = V <= 1 ? 0 : (V <= 2 ? 1 : (V <= 4 ? 2 : 3));
+    float pre_x = 0.0f, pre_y = 0.0f, pre_z = 0.0f;
+    if ((int)threadIdx.x < (TP << pa_log2) && (int)(threadIdx.x & ((1u << pa_log2) - 1u)) < V) {
+        const int p = (int)threadIdx.x >> pa_log2;
+        slot_coords(p, slot_point(p), pre_x, pre_y, pre_z);
+    }
     // ---- 1. KRt, the zero slices, the eight corner points of the set's bounding box ----
     compute_krt(P.K, P.pose, V, krt, NT);
     for (uint32_t t = threadIdx.x; t < 2u * SB / 4u; t += NT) reinterpret_cast<uint32_t *>(smem + zero_off)[t] = 0u;
@@ -752,6 +847,7 @@ __device__ __forceinline__ void fused_eval_window_body(const EvalParams &P)
         }
     }
     __syncthreads();
+    D3F_STAMP();                                    // 1: KRt, zero slices, box corners
     // ---- 2. one window per view: wave 0, lane = view * 8 + corner ----
     if (threadIdx.x < 64) {
         const int lane = threadIdx.x, v = lane >> 3, c = lane & 7;
@@ -764,12 +860,15 @@ __device__ __forceinline__ void fused_eval_window_body(const EvalParams &P)
             ok = (pr.ok && pr.zc > 1e-4f && isfinite(ix) && isfinite(iy)) ? 1 : 0;      // the whole box in front of the camera
             xl = xh = ix; yl = yh = iy;
         }
-#pragma unroll
-        for (int off = 1; off < 8; off <<= 1) {
-            xl = fminf(xl, __shfl_xor(xl, off, 64)); xh = fmaxf(xh, __shfl_xor(xh, off, 64));
-            yl = fminf(yl, __shfl_xor(yl, off, 64)); yh = fmaxf(yh, __shfl_xor(yh, off, 64));
-            ok &= __shfl_xor(ok, off, 64);
-        }
+        // min / max / and over the view's eight corner lanes, on the VALU (DPP: lane ^ 1, lane ^ 2 inside the quad, then the
+        // mirror of the 8-lane half row pairs the two quads) -- as ds_bpermute shuffles these were 27 LDS round trips of the
+        // one wave every other wave of the workgroup is waiting for
+#define D3F_WIN_RED(CTRL)                                                                                   \
+        xl = fminf(xl, dpp_f<CTRL>(xl)); xh = fmaxf(xh, dpp_f<CTRL>(xh));                                   \
+        yl = fminf(yl, dpp_f<CTRL>(yl)); yh = fmaxf(yh, dpp_f<CTRL>(yh));                                   \
+        ok &= dpp_i<CTRL>(ok);
+        D3F_WIN_RED(0xB1) D3F_WIN_RED(0x4E) D3F_WIN_RED(0x141)
+#undef D3F_WIN_RED
         WinView w = {0, 0, 1, 1, 0, 0};
         int ntex = 0;
         if (ok) {
@@ -783,7 +882,7 @@ __device__ __forceinline__ void fused_eval_window_body(const EvalParams &P)
         // direct, like every pair of a view left without a window)
         int run = 0;
         for (int vv = 0; vv < V && vv < kWinMaxViews; ++vv) {
-            const int nv = __shfl(ntex, vv * 8, 64), bwv = __shfl(w.bw, vv * 8, 64);
+            const int nv = __builtin_amdgcn_readlane(ntex, vv * 8), bwv = __builtin_amdgcn_readlane(w.bw, vv * 8);
             int rows = nv > 0 ? min(nv, P.win_pool_texels - run) / bwv : 0;
             if (rows < 2) rows = 0;                              // a bilinear footprint needs two rows
             if (vv == v) { w.base = run; w.ok = rows > 0 ? 1 : 0; w.bh = rows > 0 ? rows : w.bh; }
@@ -794,6 +893,7 @@ __device__ __forceinline__ void fused_eval_window_body(const EvalParams &P)
     }
     __syncthreads();
 
+    D3F_STAMP();                                    // 2: windows
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     // where every pool slot's texel lives in the map: one lane per slot, once per workgroup (the view search and the
     // division by the window width cost ~100 VALU instructions; done per copy instruction and slice they were a third
@@ -804,7 +904,9 @@ __device__ __forceinline__ void fused_eval_window_body(const EvalParams &P)
             if (win_s[vv].ok && t >= win_s[vv].base) v = vv;          // bases ascend over the views that have a window
         const WinView w = win_s[v];
         const int local = t - w.base;
-        const int y = local / w.bw, x = local - y * w.bw;
+        // local / bw for 0 <= local < 320, 1 <= bw <= 320 through the float reciprocal: (local + 0.5) / bw is at least 1/(2 bw)
+        // away from every integer, far more than the rounding of rcp and the product -- exact, at a tenth of the integer division
+        const int y = (int)(((float)local + 0.5f) * __builtin_amdgcn_rcpf((float)w.bw)), x = local - y * w.bw;
         texsrc_s[t] = (uint32_t)(((int64_t)v * m0.sv + (int64_t)(w.ymin + y) * m0.sy + (int64_t)(w.xmin + x) * m0.sx) * 4);
     }
     __syncthreads();
@@ -823,10 +925,12 @@ __device__ __forceinline__ void fused_eval_window_body(const EvalParams &P)
         }
     };
     stage(0);
+    D3F_STAMP();                                    // 3: slot table, DMA of slice 0 issued
 
     // ---- 3. phase A: lane = (point, view), the views of a point adjacent ----
     {
-        const int vp_log2 = V <= 1 ? 0 : (V <= 2 ? 1 : (V <= 4 ? 2 : 3));
+        const bool finite_maps = maps_are_finite(P);
+        const int vp_log2 = pa_log2;
         const int VP = 1 << vp_log2;
         const int base = lane & ~(VP - 1);
         for (int idx = threadIdx.x; idx < TP * VP; idx += NT) {
@@ -835,11 +939,11 @@ __device__ __forceinline__ void fused_eval_window_body(const EvalParams &P)
             float dv = 0.0f, valid = 0.0f, gx = 0.0f, gy = 0.0f;
             uint32_t st = 0u;
             WinRec wr;
-            wr.nw = zero_off; wr.row = 0u; wr.wgt = 0.0f; wr.valid = 0.0f;
+            wr.nw = zero_off; wr.sw = zero_off; wr.wgt = 0.0f; wr.valid = 0.0f;
             wr.w[0] = wr.w[1] = wr.w[2] = wr.w[3] = 0.0f;
             if (v < V) {
-                float px, py, pz;
-                slot_coords(p, i, px, py, pz);
+                float px = pre_x, py = pre_y, pz = pre_z;
+                if (idx >= NT) slot_coords(p, i, px, py, pz);                   // later passes (more than NT pairs) load here
                 float wgt;
                 const ViewOut o = eval_view<0>(P.depth, P.H, P.W, krt + v * 12, v, px, py, pz, Wm1, Hm1, mu, wgt);
                 if (has_rec) {
@@ -864,141 +968,193 @@ __device__ __forceinline__ void fused_eval_window_body(const EvalParams &P)
                     const bool inside = inmap && w.ok && ax >= 0 && ax + 1 < w.bw && ay >= 0 && ay + 1 < w.bh;
                     if (inside) {
                         wr.nw = pool_off + (uint32_t)(w.base + ay * w.bw + ax) * SB;
-                        wr.row = (uint32_t)w.bw * SB;
-                        wr.w[0] = sy * ex; wr.w[1] = sy * tx; wr.w[2] = ty * ex; wr.w[3] = ty * tx;
+                        wr.sw = wr.nw + (uint32_t)w.bw * SB;
+                        wr.w[0] = sy * ex; wr.w[1] = sy * tx; wr.w[2] = ty * ex; wr.w[3] = ty * tx;      // folded below
                     } else {
-                        wr.nw = kWinDirect; wr.w[0] = gx; wr.w[1] = gy;
+                        wr.valid = kWinDirectMark; wr.w[0] = gx; wr.w[1] = gy;       // (nw, sw stay on the zero slices)
                         st |= kWinHasDirect;
                     }
                 }
             }
             // sums over the views in view order (fusion.py:364-370)
-            float dsum = 0.0f, cnt = 0.0f;
-            uint32_t stp = 0u;
-            for (int vv = 0; vv < V; ++vv) {
-                dsum = dsum + __shfl(dv, base + vv, 64);
-                cnt = cnt + __shfl(valid, base + vv, 64);
-                stp |= (uint32_t)__shfl((int)st, base + vv, 64);
-            }
-            if (!(P.flags & kFlagFiniteMaps)) stp |= kWinStrict;               // (the host only picks this kernel for finite maps)
+            float dsum, cnt;
+            uint32_t stp;
+            view_sums(V, base, dv, valid, st, dsum, cnt, stp);
+            if (!finite_maps) stp |= kWinStrict;                               // (the host picks this kernel for maps it expects to be finite)
             if (v < V) {
-                if (stp & kWinStrict) { wr.nw = kWinDirect; wr.w[0] = gx; wr.w[1] = gy; }     // strict point: every pair from global
-                wrec[p * V + v] = wr;
+                if (stp & kWinStrict) {                                         // strict point: every pair from global, reference order
+                    wr.nw = zero_off; wr.sw = zero_off; wr.valid = valid; wr.w[0] = gx; wr.w[1] = gy;
+                } else {
+                    const float sc = fold_scale(wr.wgt, cnt);                   // folded weights (fuse_common.h)
+                    if (wr.valid == kWinDirectMark) wr.wgt = sc;
+                    else { wr.w[0] = wr.w[0] * sc; wr.w[1] = wr.w[1] * sc; wr.w[2] = wr.w[2] * sc; wr.w[3] = wr.w[3] * sc; }
+                }
+                wrec_at(p)[v] = wr;
             }
             if (v == 0) {
                 const bool all_invalid = (cnt == 0.0f);                         // fusion.py:366
                 float dist_out = dsum / (cnt + 1e-6f);
                 if (all_invalid) dist_out = 1e3f;                               // fusion.py:367
-                P.out_dist[i] = dist_out;
-                P.out_valid[i] = all_invalid ? 0 : 1;
                 cnt_s[p] = cnt;
                 idx_s[p] = (uint32_t)i;
                 flag_s[p] = stp;
-                // the shared reciprocal of the fast division (gather_map), once per point instead of once per slice
-                const float denom = cnt + 1e-6f;
-                const float r0 = __builtin_amdgcn_rcpf(denom);
-                aux_s[2 * p] = fmaf(fmaf(-denom, r0, 1.0f), r0, r0);
-                aux_s[2 * p + 1] = denom;
+                aux_s[2 * p] = dist_out;                                         // 'dist' / 'valid_mask' leave at the end of the kernel:
+                aux_s[2 * p + 1] = cnt + 1e-6f;                                  // no store in front of the pool's DMA wait; the strict path's divisor
             }
         }
     }
 
+    D3F_STAMP();                                    // 4: phase A
     // ---- 4. phase B per slice: LPP lanes per point ----
+    // (Round 4 also measured storing a slice's rows only after the next slice's DMA is issued -- gfx950 counts loads and
+    // stores in ONE in-order counter, so the wait for the DMA also waits for every store issued before it: C2-patch -2 %,
+    // C3-patch +1.5 %, C4-patch -0.4 % with the pipelined point loop; not kept.  Barriers between the slices are LDS-only.)
     const MapDesc &m = m0;
     const int l = threadIdx.x & (LPP - 1), grp = threadIdx.x / LPP;
     const uint32_t lane_off = (uint32_t)l * 16u;
     const char *__restrict__ data = reinterpret_cast<const char *>(m.data);
     const int S = P.win_slices;
-    const bool out32 = (uint64_t)P.n * (uint64_t)m.C * 4u <= 0xffffffffull;     // uniform: the whole fused output below 4 GiB
-    for (int sl = 0; sl < S; ++sl) {
-        if (sl > 0) {
-            __syncthreads();                        // everyone is done with the previous slice's pool
-            stage(sl);
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();                            // records (first slice) and pool are complete
-        const uint32_t co = (uint32_t)sl * SB + lane_off;               // byte offset of this lane's first vector in a texel
-        for (int p = grp; p < TP; p += NT / LPP) {
-            const int64_t i = idx_s[p];
-            const uint32_t fl = flag_s[p];
-            const bool strict = (fl & kWinStrict) != 0u;
-            VT acc[NV];
+    constexpr int G = NT / LPP;                     // points in flight per workgroup pass
+    constexpr int KI = 4;                           // points of a lane group in the pipelined loop (TP = 64, LPP = 16: all of them)
+    // fused channels of slot p for this lane (NV vectors): everything but the store
+    int Vg = V;                                     // the general path's view count, opaque: behind `pipe_ok` the compiler knows
+    asm volatile("" : "+s"(Vg));                    // V == VFIX and would unroll these view loops too (32 corner loads in flight: spills)
+    auto point_slice = [&](int p, uint32_t co, VT (&acc)[NV]) {
+        const int V = Vg;
+        const uint32_t fl = flag_s[p];
+        const bool strict = (fl & kWinStrict) != 0u;
 #pragma unroll
-            for (int u = 0; u < NV; ++u) acc[u] = (VT)0.0f;
-            if (fl == 0u) {
-                window_point<NV, VC, VS, (int)SB>(acc, smem, wrec + p * V, V, lane_off);
-            } else if (!strict) {
-                // some pair of this point is gathered from global memory (fast arithmetic, zeroed weights)
-                for (int v = 0; v < V; ++v) {
-                    const WinRec wr = wrec[p * V + v];
-                    if (wr.nw != kWinDirect) {
-                        const unsigned char *nw = smem + (wr.nw + lane_off);
-                        const unsigned char *sw = nw + wr.row;
+        for (int u = 0; u < NV; ++u) acc[u] = (VT)0.0f;
+        if (fl == 0u) {
+            window_point<NV, VC, VS, (int)SB>(acc, smem, wrec_at(p), V, lane_off);
+        } else if (!strict) {
+            // some pair of this point is gathered from global memory (folded weights like the pool pairs)
+            for (int v = 0; v < V; ++v) {
+                const WinRec wr = wrec_at(p)[v];
+                if (wr.valid != kWinDirectMark) {
+                    const unsigned char *nw = smem + (wr.nw + lane_off);
+                    const unsigned char *sw = smem + (wr.sw + lane_off);
 #pragma unroll
-                        for (int u = 0; u < NV; ++u) {
-                            const VT a = *reinterpret_cast<const VT *>(nw + u * VS), b = *reinterpret_cast<const VT *>(nw + SB + u * VS);
-                            const VT d = *reinterpret_cast<const VT *>(sw + u * VS), e = *reinterpret_cast<const VT *>(sw + SB + u * VS);
-                            VT s_ = a * wr.w[0];
-                            s_ = v_fma<VT>(b, wr.w[1], s_);
-                            s_ = v_fma<VT>(d, wr.w[2], s_);
-                            s_ = v_fma<VT>(e, wr.w[3], s_);
-                            acc[u] = acc[u] + s_ * wr.wgt;
-                        }
-                    } else {
-                        const Corner c = corner_setup(m, wr.w[0], wr.w[1]);
-                        const char *bv = data + (int64_t)v * m.sv * 4;
-                        const float w0 = c.inw ? c.wnw : 0.0f, w1 = c.ine ? c.wne : 0.0f, w2 = c.isw ? c.wsw : 0.0f, w3 = c.ise ? c.wse : 0.0f;
-#pragma unroll
-                        for (int u = 0; u < NV; ++u) {
-                            const uint32_t cu = co + (uint32_t)u * (uint32_t)VS;
-                            const VT a = load_texel<4, false>(bv + (c.onw + cu)), b = load_texel<4, false>(bv + (c.one + cu));
-                            const VT d = load_texel<4, false>(bv + (c.osw + cu)), e = load_texel<4, false>(bv + (c.ose + cu));
-                            VT s_ = a * w0;
-                            s_ = v_fma<VT>(b, w1, s_);
-                            s_ = v_fma<VT>(d, w2, s_);
-                            s_ = v_fma<VT>(e, w3, s_);
-                            acc[u] = acc[u] + s_ * wr.wgt;
-                        }
+                    for (int u = 0; u < NV; ++u) {
+                        const VT a = *reinterpret_cast<const VT *>(nw + u * VS), b = *reinterpret_cast<const VT *>(nw + SB + u * VS);
+                        const VT d = *reinterpret_cast<const VT *>(sw + u * VS), e = *reinterpret_cast<const VT *>(sw + SB + u * VS);
+                        acc[u] = v_fma<VT>(a, wr.w[0], acc[u]);
+                        acc[u] = v_fma<VT>(b, wr.w[1], acc[u]);
+                        acc[u] = v_fma<VT>(d, wr.w[2], acc[u]);
+                        acc[u] = v_fma<VT>(e, wr.w[3], acc[u]);
                     }
-                }
-            } else {
-                for (int v = 0; v < V; ++v) {
-                    const WinRec wr = wrec[p * V + v];
-                    const char *bv = data + (int64_t)v * m.sv * 4;
+                } else {
                     const Corner c = corner_setup(m, wr.w[0], wr.w[1]);
+                    const char *bv = data + (int64_t)v * m.sv * 4;
+                    const float sc = wr.wgt;                                 // fold_scale of this pair (phase A)
+                    const float w0 = (c.inw ? c.wnw : 0.0f) * sc, w1 = (c.ine ? c.wne : 0.0f) * sc;
+                    const float w2 = (c.isw ? c.wsw : 0.0f) * sc, w3 = (c.ise ? c.wse : 0.0f) * sc;
 #pragma unroll
                     for (int u = 0; u < NV; ++u) {
                         const uint32_t cu = co + (uint32_t)u * (uint32_t)VS;
                         const VT a = load_texel<4, false>(bv + (c.onw + cu)), b = load_texel<4, false>(bv + (c.one + cu));
                         const VT d = load_texel<4, false>(bv + (c.osw + cu)), e = load_texel<4, false>(bv + (c.ose + cu));
-                        const VT av = c.inw ? a : (VT)0.0f, bvv = c.ine ? b : (VT)0.0f, dv = c.isw ? d : (VT)0.0f, ev = c.ise ? e : (VT)0.0f;
-                        VT s_ = av * c.wnw;
-                        s_ = v_fma<VT>(bvv, c.wne, s_);
-                        s_ = v_fma<VT>(dv, c.wsw, s_);
-                        s_ = v_fma<VT>(ev, c.wse, s_);
-                        acc[u] = acc[u] + (s_ * wr.valid) * wr.wgt;
+                        acc[u] = v_fma<VT>(a, w0, acc[u]);
+                        acc[u] = v_fma<VT>(b, w1, acc[u]);
+                        acc[u] = v_fma<VT>(d, w2, acc[u]);
+                        acc[u] = v_fma<VT>(e, w3, acc[u]);
                     }
                 }
             }
-            const float rcp_d = aux_s[2 * p], denom = aux_s[2 * p + 1];
+        } else {
+            for (int v = 0; v < V; ++v) {
+                const WinRec wr = wrec_at(p)[v];
+                const char *bv = data + (int64_t)v * m.sv * 4;
+                const Corner c = corner_setup(m, wr.w[0], wr.w[1]);
+#pragma unroll
+                for (int u = 0; u < NV; ++u) {
+                    const uint32_t cu = co + (uint32_t)u * (uint32_t)VS;
+                    const VT a = load_texel<4, false>(bv + (c.onw + cu)), b = load_texel<4, false>(bv + (c.one + cu));
+                    const VT d = load_texel<4, false>(bv + (c.osw + cu)), e = load_texel<4, false>(bv + (c.ose + cu));
+                    const VT av = c.inw ? a : (VT)0.0f, bvv = c.ine ? b : (VT)0.0f, dv = c.isw ? d : (VT)0.0f, ev = c.ise ? e : (VT)0.0f;
+                    VT s_ = av * c.wnw;
+                    s_ = v_fma<VT>(bvv, c.wne, s_);
+                    s_ = v_fma<VT>(dv, c.wsw, s_);
+                    s_ = v_fma<VT>(ev, c.wse, s_);
+                    acc[u] = acc[u] + (s_ * wr.valid) * wr.wgt;
+                }
+            }
+            // the reference's division (fusion.py:385-386); the fast path's weights carry 1/(cnt + 1e-6) already, and with no
+            // valid view every weight is zero, acc is +0 -- fusion.py:386 for free
+            const float cnt = cnt_s[p], denom = aux_s[2 * p + 1];
 #pragma unroll
             for (int u = 0; u < NV; ++u) {
-                VT o;
-                if (strict) {
-                    o = (VT)0.0f;                                          // fusion.py:386 when no view is valid
-                    if (cnt_s[p] != 0.0f) o = strict_div<VT>(acc[u], denom);
-                } else {
-                    // no view valid: every term was (+-0) * wgt, acc is +0 and so is the quotient -- fusion.py:386 for free
-                    VT q = acc[u] * rcp_d;
-                    q = v_fma<VT>(v_fma<VT>(q, -denom, acc[u]), rcp_d, q);
-                    q = v_fma<VT>(v_fma<VT>(q, -denom, acc[u]), rcp_d, q);
-                    o = q;
-                }
-                if (out32) store_out_off(m.out, (uint32_t)i * (uint32_t)(m.C * 4) + co + (uint32_t)u * (uint32_t)VS, o, P.store_policy);
-                else store_out<VT>(m.out + i * m.C + ((co + (uint32_t)u * (uint32_t)VS) >> 2), o, P.store_policy);
+                VT o = (VT)0.0f;
+                if (cnt != 0.0f) o = strict_div<VT>(acc[u], denom);
+                acc[u] = o;
             }
         }
+    };
+    // plain stores (acknowledged by the L2; the maps of this kernel sit in the caches anyway: sc1 measured 1 % slower here), one
+    // 64-bit multiply-add per row: no store-flavour branches inside the point loop
+    const uint32_t row_bytes = (uint32_t)m.C * 4u;
+    char *const out_bytes = reinterpret_cast<char *>(m.out);
+    auto store_point = [&](int p, uint32_t co, const VT (&acc)[NV]) {
+        char *row = out_bytes + ((uint64_t)idx_s[p] * row_bytes + co);
+#pragma unroll
+        for (int u = 0; u < NV; ++u) *reinterpret_cast<VT *>(row + u * VS) = acc[u];
+    };
+    // The pipelined point loop runs for ALL points of the lane group: the records of a point with a direct pair, and of a
+    // strict point, point at the zero slices (harmless reads); such a point (rare: rim rounding, pool overflow, non-finite
+    // projection) is then done again by the general path and its row stored a second time -- same lane, same address, later in
+    // program order.  (Round 4's first form let one flagged point send its whole wave to the general path for every slice:
+    // C2-patch 0.52 ms at 4 workgroups per CU against 0.50 at 3 with the larger pool -- the overflow, not the occupancy.)
+    const bool pipe_ok = VFIX > 0 && TP == KI * G && V == VFIX;
+    uint32_t pidx[KI] = {0u, 0u, 0u, 0u};          // global index of the lane group's points (read once: an LDS read inside the
+                                                   // pipelined loop would drain it -- LDS reads return in order)
+    if (pipe_ok) {
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");          // idx_s of phase A
+#pragma unroll
+        for (int k = 0; k < KI; ++k) pidx[k] = idx_s[grp + k * G];
     }
+    for (int sl = 0; sl < S; ++sl) {
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");      // the DMA of this slice has landed (and phase A's records)
+        D3F_STAMP();                                // 5 + 3 sl: pool of this slice ready
+        const uint32_t co = (uint32_t)sl * SB + lane_off;               // byte offset of this lane's first vector in a texel
+        if (pipe_ok) {
+            window_points_pipelined<NV, (VFIX > 0 ? VFIX : 1), KI, VS, (int)SB, G * ((VFIX > 0 ? VFIX : 1) * 32 + 16)>(
+                smem, (uint32_t)grp * pstride, lane_off, [&](int k, const VT (&acc)[NV]) {
+                    char *row = out_bytes + ((uint64_t)pidx[k] * row_bytes + co);
+#pragma unroll
+                    for (int u = 0; u < NV; ++u) *reinterpret_cast<VT *>(row + u * VS) = acc[u];
+                });
+#pragma unroll 1
+            for (int p = grp; p < TP; p += G)
+                if (flag_s[p] != 0u) {              // a direct pair or a strict point: the general path, stored over the row above
+                    VT acc[NV];
+                    point_slice(p, co, acc);
+                    store_point(p, co, acc);
+                }
+        } else {
+            for (int p = grp; p < TP; p += G) {
+                VT acc[NV];
+                point_slice(p, co, acc);
+                store_point(p, co, acc);
+            }
+        }
+        D3F_STAMP();                                // 6 + 3 sl: this wave's points of the slice done
+        if (sl + 1 < S) {
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // LDS only: everyone is done with this slice's pool
+            D3F_STAMP();                            // 7 + 3 sl: all waves done
+            stage(sl + 1);
+        } else {
+            D3F_STAMP();
+        }
+    }
+    for (int p = threadIdx.x; p < TP; p += NT) {       // per-point outputs (clipped slots repeat a neighbour: same values twice)
+        P.out_dist[idx_s[p]] = aux_s[2 * p];
+        P.out_valid[idx_s[p]] = cnt_s[p] == 0.0f ? 0 : 1;
+    }
+    D3F_STAMP();                                    // last: rows stored
+#ifdef D3F_EXPERIMENTS
+    if (stamping) P.exp_stamps[(size_t)(blockIdx.x >> 6) * 32] = (unsigned long long)stamp_k;
+#endif
+#undef D3F_STAMP
     // the other (thin) maps of the call (their gather is written for kBlock lanes)
     if (NT > kBlock && threadIdx.x >= kBlock) return;
     for (int s = 1; s < P.n_maps; ++s) {
@@ -1013,8 +1169,8 @@ __device__ __forceinline__ void fused_eval_window_body(const EvalParams &P)
 
 // (NT lanes per workgroup: 512 lanes over the same 64-point brick -- twice the waves per pool -- measured no faster
 // at 2, 3 or 4 workgroups per CU: 0.58-0.71 ms on C2 patch against 0.58; only the 256-lane form is built)
-template <int U, int VC, int WAVES, int NT = kBlock, int LPP = 32>
-__global__ __launch_bounds__(NT, WAVES) void fused_eval_window_kernel(const EvalParams P) { fused_eval_window_body<U, VC, NT, LPP>(P); }
+template <int U, int VC, int WAVES, int NT = kBlock, int LPP = 32, int VFIX = 0>
+__global__ __launch_bounds__(NT, WAVES) void fused_eval_window_kernel(const EvalParams P) { fused_eval_window_body<U, VC, NT, LPP, VFIX>(P); }
 
 // Entry points over one body: the plain kernel (<= 3 channel vectors per lane) is held to 128 VGPRs = 4 waves per SIMD
 // (125 allocated) -- the gather lives on memory-level parallelism; the WIDE variant adds the 4-vector load-use path
@@ -1061,19 +1217,35 @@ hipError_t launch_fused_eval(const EvalParams &P, int mode, hipStream_t stream)
         const size_t lds_w = (size_t)P.win_pool_offset + (size_t)(2 + P.win_pool_texels) * 512 * P.win_u;
         dim3 gw((unsigned)((P.n + P.tile_pts - 1) / P.tile_pts));
         if (P.walk_nx > 0) gw = dim3((unsigned)ntiles);
-#define D3F_WIN_LAUNCH(U_, VC_, W_, LPP_)                                                                                      \
+#define D3F_WIN_LAUNCH_F(U_, VC_, W_, LPP_, VF_)                                                                               \
         do {                                                                                                                       \
             if (lds_w > 64 * 1024) {                                                                                               \
-                hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void *>(&fused_eval_window_kernel<U_, VC_, W_, kBlock, LPP_>), \
+                hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void *>(&fused_eval_window_kernel<U_, VC_, W_, kBlock, LPP_, VF_>), \
                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_w);                      \
                 if (ea != hipSuccess) return ea;                                                                                   \
             }                                                                                                                      \
-            hipLaunchKernelGGL((fused_eval_window_kernel<U_, VC_, W_, kBlock, LPP_>), gw, block, lds_w, stream, P);                \
+            hipLaunchKernelGGL((fused_eval_window_kernel<U_, VC_, W_, kBlock, LPP_, VF_>), gw, block, lds_w, stream, P);           \
         } while (0)
-        // the product library holds the two variants the planner picks by itself (16 lanes x two vectors per point, 4 or 3
-        // workgroups per CU); the others exist in experiments builds only (measured and dropped)
-        if (P.win_u == 1 && P.win_lpp == 16 && P.win_occ >= 4) D3F_WIN_LAUNCH(1, 2, 4, 16);
-        else if (P.win_u == 1 && P.win_lpp == 16) D3F_WIN_LAUNCH(1, 2, 3, 16);
+#define D3F_WIN_LAUNCH(U_, VC_, W_, LPP_) D3F_WIN_LAUNCH_F(U_, VC_, W_, LPP_, 0)
+        // the product library holds the variants the planner picks by itself: 16 lanes x two vectors per point, at 4 or 3
+        // workgroups per CU, with the view count fixed at 4 / 8 (software-pipelined point loop) or free; the others exist in
+        // experiments builds only (measured and dropped)
+        const bool lpp16 = P.win_u == 1 && P.win_lpp == 16;
+        const int vfix = (P.win_pipe && P.tile_pts == 64) ? (P.V == 4 ? 4 : (P.V == 8 ? 8 : 0)) : 0;
+#ifdef D3F_EXPERIMENTS
+        // win_vc 2: two views' corner reads in flight in the plain view loop (round 3's form)
+        if (lpp16 && vfix == 0 && P.win_occ == 6) D3F_WIN_LAUNCH_F(1, 1, 6, 16, 0);          // plain loop at 6 / 5 workgroups per CU (smaller pools)
+        else if (lpp16 && vfix == 0 && P.win_occ == 5) D3F_WIN_LAUNCH_F(1, 1, 5, 16, 0);
+        else if (lpp16 && vfix == 0 && P.win_vc == 2 && P.win_occ >= 4) D3F_WIN_LAUNCH_F(1, 2, 4, 16, 0);
+        else if (lpp16 && vfix == 0 && P.win_vc == 2) D3F_WIN_LAUNCH_F(1, 2, 3, 16, 0);
+        else
+#endif
+        if (lpp16 && vfix == 4 && P.win_occ >= 4) D3F_WIN_LAUNCH_F(1, 1, 4, 16, 4);
+        else if (lpp16 && vfix == 4) D3F_WIN_LAUNCH_F(1, 1, 3, 16, 4);
+        else if (lpp16 && vfix == 8 && P.win_occ >= 4) D3F_WIN_LAUNCH_F(1, 1, 4, 16, 8);
+        else if (lpp16 && vfix == 8) D3F_WIN_LAUNCH_F(1, 1, 3, 16, 8);
+        else if (lpp16 && P.win_occ >= 4) D3F_WIN_LAUNCH(1, 1, 4, 16);
+        else if (lpp16) D3F_WIN_LAUNCH(1, 1, 3, 16);
 #ifdef D3F_EXPERIMENTS
         else if (P.win_u == 1 && P.win_occ >= 4) D3F_WIN_LAUNCH(1, 4, 4, 32);
         else if (P.win_u == 1 && P.win_occ == 3) D3F_WIN_LAUNCH(1, 4, 3, 32);
@@ -1087,6 +1259,7 @@ hipError_t launch_fused_eval(const EvalParams &P, int mode, hipStream_t stream)
         else return hipErrorInvalidValue;
 #endif
 #undef D3F_WIN_LAUNCH
+#undef D3F_WIN_LAUNCH_F
         return hipGetLastError();
     }
     if (mode == 0 && P.sl_slices > 0) {

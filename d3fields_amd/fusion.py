@@ -230,8 +230,11 @@ class Fusion:
         self.mask_tracker = mask_tracker
         self.track_ids = [0]                    # fusion.py:303
         self.xmem_first_mask_loaded = False     # fusion.py:302
-        self._finite_cache = {}
-        self._finite_override = None
+        self._finite_cache = {}                 # key -> (weakref(tensor), signature, stream, event): checked by d3f_map_check
+        self._words = None                      # device words of the checks (one per key), allocated on first use
+        self._word_slot = {}
+        self._finite_override = None            # True: D3F_FLAG_FINITE_MAPS (the caller vouches); False: strict path
+        self.reference_rounding = False         # True: D3F_FLAG_REFERENCE_ROUNDING -- wide maps in the reference's operation order too
         self._tracker = None                    # rigid_tracking: the captured iteration of the current sequence
         self.tuning_flags = 0                   # D3F_TUNE_* bits (experiments; results do not depend on them)
         self.reorder_points = True              # hand the library scratch so it may walk points in Morton order
@@ -302,26 +305,81 @@ class Fusion:
         keep = [depth.contiguous(), K.contiguous(), pose34.contiguous()]
         return _lib.Views(V, self.H, self.W, _lib.ptr(keep[0]), _lib.ptr(keep[1]), _lib.ptr(keep[2])), keep, V
 
-    def _is_finite(self, key, t):
-        """Cached torch.isfinite(t).all(): lets the kernel skip invalid views exactly (D3F_FLAG_FINITE_MAPS)."""
-        if self._finite_override is not None:       # RigidTracker's private observation: the flag must not depend on data
-            return self._finite_override
-        # keyed on the tensor OBJECT (weak reference) and its version counter: a new tensor that happens to be allocated
-        # at the address of a checked one is re-checked.  Writers that bypass torch (custom kernels writing into the map
-        # in place) must call invalidate_map_checks() -- a stale "finite" verdict would skip 0*NaN terms the reference keeps.
+    # ---- "this tensor holds only finite values", established ON THE DEVICE ---------------------------------------------
+    # The kernels may skip the views that are invalid for a point only when every operand is finite (0 * NaN has to
+    # propagate like in the reference, fusion.py:385).  Up to round 3 the shim asked torch: isfinite(t).all().item() per new
+    # tensor = five ATen kernels, a bool temporary and a HOST SYNC (2.1 ms per 1.9 GB map against a 1.5 ms query).  Now
+    # d3f_map_check streams the tensor once on the caller's stream and leaves a device word; the queries carry the words
+    # of depth and maps (d3f_views.depth_nonfinite, d3f_channel_map.nonfinite) and decide on the device.  No sync, no ATen
+    # kernel, capturable in a HIP graph.
+    _WORD_SLOTS = 64
+
+    def _finite_word(self, key, t, checked=None):
+        """Address (int) of the device word d3f_map_check wrote for tensor `t` (cached per key on the tensor OBJECT and its
+        version counter; a new tensor allocated at the address of a checked one is re-checked), or None when no word can be
+        had (then the query takes the strict path: same results).  `checked`: the tensor the kernel should read instead
+        of `t` (a contiguous copy the caller just made; not cached)."""
+        dev = t.device
+        if self._words is None or self._words.device != dev:
+            if torch.cuda.is_current_stream_capturing():
+                return None                     # no allocation inside a HIP-graph capture
+            self._words = torch.zeros(self._WORD_SLOTS, dtype=torch.int32, device=dev)
+            self._word_slot = {}
+            self._finite_cache.clear()
+        slot = self._word_slot.get(key)
+        if slot is None:
+            if len(self._word_slot) >= self._WORD_SLOTS:
+                return None
+            slot = self._word_slot[key] = len(self._word_slot)
+        addr = self._words.data_ptr() + 4 * slot
+        stream = torch.cuda.current_stream(dev)
+        # keyed on the tensor OBJECT (weak reference) and its version counter.  Writers that bypass torch (custom kernels
+        # writing into the map in place) must call invalidate_map_checks() -- a stale "finite" verdict would skip 0*NaN
+        # terms the reference keeps.
         sig = (t._version, tuple(t.shape), t.data_ptr())
         hit = self._finite_cache.get(key)
-        if hit is None or hit[0]() is not t or hit[1] != sig:
-            if torch.cuda.is_current_stream_capturing():
-                return False                    # no host sync inside a HIP-graph capture: strict path, same results
+        if checked is None and hit is not None and hit[0]() is t and hit[1] == sig:
+            if hit[2] != stream.cuda_stream:
+                stream.wait_event(hit[3])       # checked on another stream: order this one behind it
+            return addr
+        src = t if checked is None else checked
+        if src.dim() == 3:                      # depth (V,H,W): a one-channel map
+            desc = _lib.ChannelMap(src.data_ptr(), src.shape[1], src.shape[2], 1, _lib.DTYPE_F32, src.stride(0), src.stride(1),
+                                   max(src.stride(2), 1), None)
+            ok = src.dtype == torch.float32 and src.stride(2) >= 1
+        else:
+            desc = _lib.ChannelMap(src.data_ptr(), src.shape[1], src.shape[2], src.shape[3],
+                                   _lib.DTYPE_F16 if src.dtype == torch.float16 else _lib.DTYPE_F32,
+                                   src.stride(0), src.stride(1), src.stride(2), None)
+            ok = src.dtype in (torch.float32, torch.float16) and src.stride(3) == 1 and src.stride(2) >= src.shape[3]
+        if not ok or min(src.stride()) < 0:
+            return None
+        with torch.cuda.device(dev):
+            _lib.check(self._lib.d3f_map_check(ctypes.byref(desc), src.shape[0], ctypes.c_void_p(addr), _lib.current_stream_handle(dev)))
+        if checked is None and not torch.cuda.is_current_stream_capturing():
             import weakref
-            hit = (weakref.ref(t), sig, bool(torch.isfinite(t).all().item()))
-            self._finite_cache[key] = hit
-        return hit[2]
+            ev = torch.cuda.Event()
+            ev.record(stream)
+            self._finite_cache[key] = (weakref.ref(t), sig, stream.cuda_stream, ev)
+        else:
+            self._finite_cache.pop(key, None)
+        return addr
+
+    def maps_are_finite(self, names=("depth", "dino_feats", "mask", "color_tensor")):
+        """Host-side verdict of the device words (ONE host sync; diagnostics and tests only -- no query needs it)."""
+        bad = False
+        for k in names:
+            t = self.curr_obs_torch.get(k)
+            if isinstance(t, torch.Tensor):
+                addr = self._finite_word(k, t)
+                if addr is None:
+                    return False
+                bad = bad or bool(self._words[(addr - self._words.data_ptr()) // 4].item())
+        return not bad
 
     def invalidate_map_checks(self):
-        """Forget the cached 'this map holds only finite values' verdicts (D3F_FLAG_FINITE_MAPS): call after writing into
-        a curr_obs_torch tensor in place from outside torch."""
+        """Forget the device-side 'this map holds only finite values' verdicts: call after writing into a curr_obs_torch
+        tensor in place from outside torch (the next query re-checks the tensors it reads, ~0.35 ms per 1.9 GB)."""
         self._finite_cache.clear()
 
     def _is_unordered(self, pts_c, stream):
@@ -410,6 +468,10 @@ class Fusion:
             self._poll_probes()
         return tuple(self._hints.get(n, [None, False]))
 
+    def _query_flags(self):
+        return ((_lib.FLAG_FINITE_MAPS if self._finite_override else 0) | (_lib.FLAG_REFERENCE_ROUNDING if self.reference_rounding else 0) |
+                int(self.tuning_flags) | int(Fusion.extra_tuning_flags))
+
     def last_plan(self):
         """What the last eval / batch_eval launched (for bench.py and tests): kernel entry point, tile size and how the
         points were ordered -- from d3f_eval_plan_query on the same shapes and flags."""
@@ -433,7 +495,9 @@ class Fusion:
         if window:
             r = plan.reserved - 2000
             w0 = [s for s in range(n_maps) if plan.staged[s] == 3][0]           # the windowed map (any position in the call)
-            kernel = "fused_eval_window_kernel<%d, %d, %d, 256, %d>" % (r // 100, r // 10 % 10, r % 10, plan.lanes_per_point[w0])
+            # (the last template argument: the view count as a compile-time constant, 4 / 8 -> software-pipelined point loop)
+            vfix = int(views.V) if (int(views.V) in (4, 8) and int(plan.tile_points) == 64 and plan.lanes_per_point[w0] == 16) else 0
+            kernel = "fused_eval_window_kernel<%d, %d, %d, 256, %d, %d>" % (r // 100, r // 10 % 10, r % 10, plan.lanes_per_point[w0], vfix)
         elif plan.reserved >= 100:
             lg, vc = (plan.reserved - 100) // 10, (plan.reserved - 100) % 10
             kernel = "fused_eval_sliced_kernel<%d, %d, %d>" % (lg, vc, {1: 8, 2: 7, 4: 5}.get(vc, 5))
@@ -489,7 +553,11 @@ class Fusion:
             maps = (_lib.ChannelMap * max(len(names), 1))()
             fused = (ctypes.c_void_p * max(len(names), 1))()
             inter = (ctypes.c_void_p * max(len(names), 1))()
-            finite = self._is_finite("depth", self.curr_obs_torch["depth"])     # the caller's tensor, not the contiguous fp32 copy
+            # finiteness of depth and maps: device words written by d3f_map_check when a tensor is new (no host sync), keyed
+            # on the caller's tensor objects; _finite_override (RigidTracker's private observation) replaces them by a fixed flag
+            words = self._finite_override is None and bool(names)
+            if words:
+                views.depth_nonfinite = self._finite_word("depth", self.curr_obs_torch["depth"])
             used_maps = []
             for s, k in enumerate(names):
                 m = self.curr_obs_torch[k]                 # KeyError for unknown names, like the reference
@@ -497,23 +565,24 @@ class Fusion:
                     raise ValueError("curr_obs_torch[%r] must be a (V,h,w,C) tensor" % k)
                 if m.device != dev or m.dtype not in (torch.float32, torch.float16):
                     raise RuntimeError("curr_obs_torch[%r] must be float32 or float16 on %s" % (k, dev))
-                finite = finite and self._is_finite(k, m)      # keyed on the caller's tensor object: a contiguous copy made
-                if m.stride(3) != 1:                           # below is a NEW tensor on every call and would never hit
+                m_caller = m
+                if m.stride(3) != 1:                           # a NEW tensor on every call: checked every call, never cached
                     m = m.contiguous()
                     keep.append(m)
+                word = self._finite_word(k, m_caller, None if m is m_caller else m) if words else None
                 used_maps.append(m)
                 C = m.shape[3]
                 o = torch.empty((n, C), dtype=torch.float32, device=dev)
                 outputs[k] = o
                 maps[s] = _lib.ChannelMap(m.data_ptr(), m.shape[1], m.shape[2], C,
                                           _lib.DTYPE_F16 if m.dtype == torch.float16 else _lib.DTYPE_F32,
-                                          m.stride(0), m.stride(1), m.stride(2))
+                                          m.stride(0), m.stride(1), m.stride(2), word)
                 fused[s] = o.data_ptr()
                 if return_inter:
                     it = torch.empty((V, n, C), dtype=torch.float32, device=dev)
                     outputs[k + "_inter"] = it
                     inter[s] = it.data_ptr()
-            flags = (_lib.FLAG_FINITE_MAPS if finite else 0) | int(self.tuning_flags) | int(Fusion.extra_tuning_flags)
+            flags = self._query_flags()
             ws, ws_bytes = None, 0
             dims, hinted_unordered = None, None
             if self.reorder_points and names and n >= 65536 and not torch.cuda.is_current_stream_capturing():
@@ -628,21 +697,24 @@ class Fusion:
         out = {"dist": dist, "valid_mask": valid, "grid_shape": torch.Size([grid.nx, grid.ny, grid.nz])}
         maps = (_lib.ChannelMap * max(len(names), 1))()
         fused = (ctypes.c_void_p * max(len(names), 1))()
-        finite = self._is_finite("depth", self.curr_obs_torch["depth"])     # the caller's tensor, not the contiguous fp32 copy
+        words = self._finite_override is None and bool(names)
+        if words:
+            views.depth_nonfinite = self._finite_word("depth", self.curr_obs_torch["depth"])
         for s, k in enumerate(names):
             m = self.curr_obs_torch[k]
             if m.device != dev or m.dtype not in (torch.float32, torch.float16):
                 raise RuntimeError("curr_obs_torch[%r] must be float32 or float16 on %s" % (k, dev))
-            finite = finite and self._is_finite(k, m)          # on the caller's tensor object, before any contiguous copy
+            m_caller = m
             if m.stride(3) != 1:
                 m = m.contiguous()
                 keep.append(m)
+            word = self._finite_word(k, m_caller, None if m is m_caller else m) if words else None
             out[k] = torch.empty((n, m.shape[3]), dtype=torch.float32, device=dev)
             maps[s] = _lib.ChannelMap(m.data_ptr(), m.shape[1], m.shape[2], m.shape[3],
                                       _lib.DTYPE_F16 if m.dtype == torch.float16 else _lib.DTYPE_F32,
-                                      m.stride(0), m.stride(1), m.stride(2))
+                                      m.stride(0), m.stride(1), m.stride(2), word)
             fused[s] = out[k].data_ptr()
-        flags = (_lib.FLAG_FINITE_MAPS if finite else 0) | int(self.tuning_flags) | int(Fusion.extra_tuning_flags)
+        flags = self._query_flags()
         with torch.cuda.device(dev):
             _lib.check(lib.d3f_eval_grid(ctypes.byref(views), ctypes.byref(grid), maps, len(names), self.mu, flags,
                                          _lib.ptr(dist), _lib.ptr(valid), fused, _lib.current_stream_handle(dev)))

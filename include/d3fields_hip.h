@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define D3F_ABI_VERSION 3
+#define D3F_ABI_VERSION 4
 
 #define D3F_OK 0
 #define D3F_ERR_INVALID_ARG (-1)  /* null pointer, negative count, bad enum               */
@@ -51,7 +51,16 @@ extern "C" {
                                    only finite values: views that are invalid for a point are \
                                    then skipped instead of multiplied by 0 (identical results; \
                                    without the flag 0*NaN / 0*Inf propagate as in the          \
-                                   reference, fusion.py:385).                                  */
+                                   reference, fusion.py:385).  Device-side alternative without \
+                                   a host sync: d3f_map_check + the `nonfinite` words below.   */
+#define D3F_FLAG_REFERENCE_ROUNDING 4u /* every operation in the reference's own order, also for wide maps.  By default a   \
+                                          wide map (more than 256 bytes per texel) takes, for finite operands, the FOLDED  \
+                                          form: the view weight and the reciprocal of the view count are multiplied into   \
+                                          the four bilinear weights once per (point, view) and the channels run four fma   \
+                                          per view -- within a few ulp of the reference's order      \
+                                          (1e-5 relative is the contract, ~2e-7 measured).  'dist', 'valid_mask', thin     \
+                                          maps (instance masks, colours) and '<k>_inter' are in the reference's order and  \
+                                          bit-exact either way.  Slower: the direct gather, no view skipping.              */
 #define D3F_FLAG_UNORDERED_POINTS 2u /* the caller's point order has no spatial locality (shuffled or \
                                         uniformly random cloud; see d3f_point_order_locality): walk the \
                                         points in Morton order even when the maps are small.  Performance \
@@ -86,6 +95,7 @@ typedef struct d3f_views {
     const float *depth; /* [V,H,W]                                                     */
     const float *K;     /* [V,3,3]                                                     */
     const float *pose;  /* [V,3,4]                                                     */
+    const uint32_t *depth_nonfinite; /* NULL, or the device word d3f_map_check wrote for `depth` (ABI 4, see below) */
 } d3f_views;
 
 /* One channels-last per-view map: curr_obs_torch['dino_feats'|'mask'|'color_tensor'|...]
@@ -97,7 +107,19 @@ typedef struct d3f_channel_map {
     int32_t fh, fw, C;
     int32_t dtype; /* D3F_DTYPE_F32 or D3F_DTYPE_F16 */
     int64_t stride_v, stride_y, stride_x;
+    const uint32_t *nonfinite; /* NULL, or the device word d3f_map_check wrote for this map (ABI 4, see below) */
 } d3f_channel_map;
+
+/* Device-side replacement of the caller's `torch.isfinite(map).all()` (the precondition of D3F_FLAG_FINITE_MAPS):
+ * one streaming pass over the V x fh x fw x C elements of `map` (16-byte loads, no temporaries) that leaves
+ * *word_out != 0 iff the map holds a NaN or an Inf.  Enqueued on `stream`, NO host synchronisation: hand the word to the
+ * queries through d3f_channel_map::nonfinite (for the depth images: describe them as a one-channel map {depth, H, W, 1,
+ * F32, H*W, W, 1} and pass the word as d3f_views::depth_nonfinite).  A query whose depth and maps ALL carry a word reads
+ * the words on the device and takes the exact invalid-view skip iff all are zero -- the same results as with / without
+ * D3F_FLAG_FINITE_MAPS set by a host that looked, but capturable in a HIP graph and without the ~2 ms of ATen kernels +
+ * host sync per new 1.9 GB map.  A caller that rewrites a map in place re-runs the check (on the same stream order).
+ * word_out: one device uint32, 4-byte aligned; the call overwrites it. */
+int d3f_map_check(const d3f_channel_map *map, int32_t V, uint32_t *word_out, void *stream);
 
 /* ---- library ---------------------------------------------------------------------- */
 int d3f_abi_version(void);

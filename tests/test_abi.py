@@ -41,9 +41,13 @@ def test_version_and_constants_match_header():
 
 
 def test_struct_layouts_match_header():
-    # d3f_views: 3 x int32 (+4 pad) + 3 pointers ; d3f_channel_map: ptr + 4 x int32 + 3 x int64
-    assert ctypes.sizeof(_lib.Views) == 40 and _lib.Views.depth.offset == 16
-    assert ctypes.sizeof(_lib.ChannelMap) == 48 and _lib.ChannelMap.stride_v.offset == 24
+    # d3f_views: 3 x int32 (+4 pad) + 4 pointers ; d3f_channel_map: ptr + 4 x int32 + 3 x int64 + ptr  (ABI 4: the trailing
+    # pointers are the device words of d3f_map_check)
+    assert ctypes.sizeof(_lib.Views) == 48 and _lib.Views.depth.offset == 16 and _lib.Views.depth_nonfinite.offset == 40
+    assert ctypes.sizeof(_lib.ChannelMap) == 56 and _lib.ChannelMap.stride_v.offset == 24 and _lib.ChannelMap.nonfinite.offset == 48
+    hdr = open(os.path.join(ROOT, "include", "d3fields_hip.h")).read()
+    assert re.search(r"const float \*pose;[^}]*const uint32_t \*depth_nonfinite;[^}]*\} d3f_views;", hdr)
+    assert re.search(r"int64_t stride_v, stride_y, stride_x;\s*const uint32_t \*nonfinite;[^}]*\} d3f_channel_map;", hdr)
     # d3f_col_stat travels between ranks as raw bytes: float, float, int64 = 16 B (tests/test_sharding_gloo.py uses it)
     hdr = open(os.path.join(ROOT, "include", "d3fields_hip.h")).read()
     assert re.search(r"typedef struct d3f_col_stat \{\s*float max_logit;[^}]*float sum_exp;[^}]*int64_t argmax;[^}]*\} d3f_col_stat;", hdr)
@@ -184,7 +188,7 @@ def test_validation_of_topk_and_lattice_entry_points():
     patch = (_lib.ChannelMap * 1)(_lib.ChannelMap(1 << 20, 48, 64, 384, 0, 48 * 64 * 384, 64 * 384, 384))
     assert lib.d3f_eval_plan_query_lattice(ctypes.byref(v), 160, 140, 44, patch, 1, _lib.FLAG_FINITE_MAPS, 0, ctypes.byref(plan)) == 0
     # a patch-resolution wide map on a lattice: 4 x 4 x 4 bricks through LDS texel windows, 4 workgroups per CU
-    assert (plan.reorder, plan.staged[0], plan.tile_points, plan.reserved, plan.workgroups) == (2, 3, 64, 2124, 40 * 35 * 11)
+    assert (plan.reorder, plan.staged[0], plan.tile_points, plan.reserved, plan.workgroups) == (2, 3, 64, 2113, 40 * 35 * 11)
     assert lib.d3f_eval_plan_query(ctypes.byref(v), 985600, patch, 1, _lib.FLAG_FINITE_MAPS, 1, 0, ctypes.byref(plan)) == 0
     # the same map without lattice dims (a cloud in caller order): the cell-run gather
     assert plan.reorder == 0 and plan.staged[0] == 16 + 4 and plan.tile_points == 64 and plan.lanes_per_point[0] == 32
@@ -234,7 +238,7 @@ def test_launch_plan_host_logic():
     p = _plan(4, 480, 640, 985600, [(480, 640, 384)], dtype=_lib.DTYPE_F16)
     assert (p.tile_points, p.reorder, p.vector_floats[0], p.lanes_per_point[0], p.vectors_per_lane[0]) == (16, 1, 8, 16, 3)
     p = _plan(4, 480, 640, 1000, [(48, 64, 5)], dtype=_lib.DTYPE_F16)             # odd channel count: scalar fp16 lanes
-    assert (p.vector_floats[0], p.lanes_per_point[0]) == (1, 1)
+    assert (p.vector_floats[0], p.lanes_per_point[0], p.vectors_per_lane[0]) == (1, 8, 1)      # thin family: one pass over 8 lanes (3 idle)
     p = _plan(4, 480, 640, 985600, [(48, 64, 384)], dtype=_lib.DTYPE_F16)
     assert (p.tile_points, p.reorder) == (128, 0)
     # C2 dense: 1.9 GB of maps -> Morton walk feeding the channel-sliced kernel (16-point tiles, 512-byte slices, two views
@@ -249,12 +253,12 @@ def test_launch_plan_host_logic():
     # C4: 8 views x 1024 channels -> whole wave per point, 4 float4 per lane
     p = _plan(8, 720, 1280, 1000000, [(72, 128, 1024)])
     assert (p.lanes_per_point[0], abs(p.vectors_per_lane[0]), p.reorder) == (64, 4, 1)
-    # small batches are never reordered; mask (C=8) -> 2 lanes per point; colour (C=3) -> scalar lanes
+    # small batches are never reordered; mask (C=8) -> 2 lanes per point; colour (C=3) -> 4 scalar lanes (one idle)
     p = _plan(4, 480, 640, 60000, [(48, 64, 384), (480, 640, 8), (480, 640, 3)])
     assert p.reorder == 0 and p.tile_points == 32            # < 1024 workgroups of 128 -> smaller tiles
     assert _plan(4, 480, 640, 300, [(48, 64, 384)]).tile_points == 8
     assert (p.vector_floats[1], p.lanes_per_point[1], p.vectors_per_lane[1]) == (4, 2, 1)
-    assert (p.vector_floats[2], p.lanes_per_point[2], p.vectors_per_lane[2]) == (1, 1, 3)
+    assert (p.vector_floats[2], p.lanes_per_point[2], p.vectors_per_lane[2]) == (1, 4, 1)       # thin family: one pass, one vector per lane
     # many views shrink the tile so that the per-(point,view) records fit LDS
     p = _plan(64, 48, 64, 5000, [(6, 8, 16)])
     assert p.tile_points * 64 * 24 <= 64 * 1024 and p.lds_bytes <= 64 * 1024
@@ -285,15 +289,15 @@ def test_window_launch_plan(monkeypatch):
     assert p.staged[0] == 3 and p.tile_points == 64                 # default on a lattice
     # the wide map need not come first in the call (return_names=['mask', 'dino_feats']): same launch, reported in caller order
     p = plan_lattice(4, (160, 140, 44), [(480, 640, 8), (48, 64, 384)])
-    assert (p.staged[0], p.staged[1], p.lanes_per_point[0], p.lanes_per_point[1], p.reserved) == (0, 3, 2, 16, 2124)
+    assert (p.staged[0], p.staged[1], p.lanes_per_point[0], p.lanes_per_point[1], p.reserved) == (0, 3, 2, 16, 2113)
     big_first = plan_lattice(4, (200, 175, 55), [(480, 640, 384), (480, 640, 8)])
     big_last = plan_lattice(4, (200, 175, 55), [(480, 640, 8), (480, 640, 384)])
     assert big_first.reserved == big_last.reserved == 152 and big_first.workgroups == big_last.workgroups
     p = plan_lattice(4, (160, 140, 44), [(48, 64, 384)], flags=_lib.FLAG_FINITE_MAPS | _lib.TUNE_DIRECT_GATHER)
     assert (p.staged[0], p.reorder, p.reserved) == (0, 0, 0)                          # switched off: direct gather, caller order
     p = plan_lattice(4, (160, 140, 44), [(48, 64, 384), (480, 640, 8)])
-    assert (p.staged[0], p.tile_points, p.reorder, p.workgroups, p.reserved) == (3, 64, 2, 40 * 35 * 11, 2124)
-    assert p.lds_bytes <= 160 * 1024 // 4
+    assert (p.staged[0], p.tile_points, p.reorder, p.workgroups, p.reserved) == (3, 64, 2, 40 * 35 * 11, 2113)      # ~17 pool slots per view: three workgroups per CU
+    assert 160 * 1024 // 4 < p.lds_bytes <= 160 * 1024 // 3
     if exp:
         monkeypatch.setenv("D3F_EXP_WINDOW", "-1")
         assert plan_lattice(4, (160, 140, 44), [(48, 64, 384)]).staged[0] == 16 + 4      # windows off: cell runs, caller order
@@ -315,7 +319,7 @@ def test_window_launch_plan(monkeypatch):
         assert (p.staged[0], p.reorder, p.workgroups) == (3, 1, 15625)                   # forced: 64 consecutive points of the Morton order
         monkeypatch.setenv("D3F_EXP_WINDOW", "128")
         p = _plan(8, 720, 1280, 1000000, [(72, 128, 1024)], flags=_lib.FLAG_FINITE_MAPS | _lib.FLAG_UNORDERED_POINTS)
-        assert p.staged[0] == 3 and p.reserved == 2123 and p.lds_bytes <= 160 * 1024 // 3    # 32 KB of records for 128 x 8 pairs: 3 workgroups per CU
+        assert p.staged[0] == 3 and p.lds_bytes <= 160 * 1024 // 2    # 32 KB of records for 128 x 8 pairs + ~11 pool slots per view: 2 workgroups per CU
 
 
 def test_plan_table():
@@ -323,8 +327,8 @@ def test_plan_table():
     the plan on either side of each boundary, from d3f_eval_plan_query alone."""
     F = _lib.FLAG_FINITE_MAPS
 
-    def one_map(nbytes):                        # one view, 64 channels (256-byte texels), 1024 texels per row
-        return [(nbytes // 256 // 1024, 1024, 64)]
+    def one_map(nbytes):                        # one view, 96 channels (384-byte texels: a wide map, not sliceable), 1024 texels per row
+        return [(nbytes // 384 // 1024, 1024, 96)]
 
     # kSmallBatch = 65536 points: below it nothing is reordered, whatever the maps and the scratch
     assert _plan(1, 480, 640, 65535, one_map(200 << 20), F).reorder == 0
@@ -332,19 +336,21 @@ def test_plan_table():
     # kCacheResidentBytes = 64 MiB of maps: at most that -> caller order with 128-point tiles; more (with scratch) -> Morton walk
     p = _plan(1, 480, 640, 200000, one_map(64 << 20), F)
     assert (p.reorder, p.tile_points) == (0, 128)
-    p = _plan(1, 480, 640, 200000, one_map((64 << 20) + (256 << 10)), F)
+    p = _plan(1, 480, 640, 200000, one_map((64 << 20) + (384 << 10)), F)
     assert (p.reorder, p.tile_points) == (1, 16)
-    assert _plan(1, 480, 640, 200000, one_map((64 << 20) + (256 << 10)), F, ws=0).reorder == 0      # no scratch, no sort
+    assert _plan(1, 480, 640, 200000, one_map((64 << 20) + (384 << 10)), F, ws=0).reorder == 0      # no scratch, no sort
     # kBatchedLoadBytes = 128 MiB per map: batched corner loads up to it, load-use per vector beyond (caller order)
-    assert _plan(1, 480, 640, 200000, one_map(128 << 20), F, ws=0).vectors_per_lane[0] == 1
-    assert _plan(1, 480, 640, 200000, one_map((128 << 20) + (256 << 10)), F, ws=0).vectors_per_lane[0] == -1
+    assert _plan(1, 480, 640, 200000, one_map(128 << 20), F, ws=0).vectors_per_lane[0] == 3          # 24 float4 = 8 lanes x 3
+    assert _plan(1, 480, 640, 200000, one_map((128 << 20) + (384 << 10)), F, ws=0).vectors_per_lane[0] == -3
+    # ... but a thin map (<= 256 bytes per texel) has ONE kernel form: one batched vector per lane
+    assert _plan(1, 480, 640, 200000, [((200 << 20) // 256 // 1024, 1024, 64)], F, ws=0).vectors_per_lane[0] == 1
     # kBeyondLlcBytes = 512 MiB of maps in caller order without scratch: 64-point tiles at 2 workgroups per CU (64 KiB LDS pad)
     p = _plan(1, 480, 640, 200000, one_map(512 << 20), F, ws=0)
     assert p.tile_points == 128 and p.lds_bytes < 16 * 1024
-    p = _plan(1, 480, 640, 200000, one_map((512 << 20) + (256 << 10)), F, ws=0)
+    p = _plan(1, 480, 640, 200000, one_map((512 << 20) + (384 << 10)), F, ws=0)
     assert p.tile_points == 64 and p.lds_bytes > 64 * 1024
     # D3F_TUNE_DIRECT_GATHER never changes the point order, only the gather
-    assert _plan(1, 480, 640, 200000, one_map((64 << 20) + (256 << 10)), F | _lib.TUNE_DIRECT_GATHER).reorder == 1
+    assert _plan(1, 480, 640, 200000, one_map((64 << 20) + (384 << 10)), F | _lib.TUNE_DIRECT_GATHER).reorder == 1
     # channel-sliced kernel: one wide fp32 map of 128..1024 channels in whole 512-byte slices, beyond the caches, on the
     # Morton walk (or a lattice, test_window_launch_plan); 1152 channels, 192 channels, a second wide map: whole texels
     assert _plan(4, 480, 640, 200000, [(480, 640, 1024)], F).reserved == 152

@@ -178,6 +178,82 @@ def test_nonfinite_maps_propagate_like_reference(dev):
     assert rel_err(cpu(o2["dino_feats"]), oracle_eval(sc, pts, [feats2])["sets"][0]) <= TOL
 
 
+def test_map_check_words(dev):
+    """d3f_map_check (the device-side replacement of torch.isfinite(map).all()): the word is non-zero iff the map holds a NaN /
+    Inf -- flat 16-byte path incl. the tail and the very last element, fp16 storage, strided views, unaligned bases; and the
+    shim follows in-place torch writes (version counter) without a host sync in the query."""
+    import ctypes
+    from d3fields_amd import synth, _lib
+    lib = _lib.load()
+    word = torch.full((4,), 77, dtype=torch.int32, device=dev)
+    st = _lib.current_stream_handle(dev)
+
+    def check(t, expect):
+        V = t.shape[0]
+        desc = _lib.ChannelMap(t.data_ptr(), t.shape[1], t.shape[2], t.shape[3], _lib.DTYPE_F16 if t.dtype == torch.float16 else _lib.DTYPE_F32,
+                               t.stride(0), t.stride(1), t.stride(2), None)
+        _lib.check(lib.d3f_map_check(ctypes.byref(desc), V, ctypes.c_void_p(word.data_ptr() + 4), st))
+        got = word.tolist()
+        assert got[0] == 77 and got[2] == 77 and (got[1] != 0) == expect, (got, expect, tuple(t.shape), t.dtype)
+
+    g = torch.Generator().manual_seed(5)
+    for dtype in (torch.float32, torch.float16):
+        for shape in ((3, 7, 9, 5), (2, 12, 16, 384), (4, 48, 64, 384), (1, 1, 1, 1), (2, 3, 5, 8)):
+            base = torch.randn(shape, generator=g).to(dev, dtype)
+            check(base, False)
+            n = base.numel()
+            for pos in sorted({0, n - 1, n // 2, max(n - 3, 0)}):
+                for bad in (float("nan"), float("inf"), float("-inf")):
+                    t = base.clone()
+                    t.view(-1)[pos] = bad
+                    check(t, True)
+        # a [..., :C] view of a wider buffer (texel stride > C): only the view's elements count
+        wide = torch.randn((2, 6, 8, 24), generator=g).to(dev, dtype)
+        wide[..., 20] = float("nan")                      # outside the view
+        check(wide[..., :16], False)
+        wide[1, 5, 7, 15] = float("inf")                  # last element of the view
+        check(wide[..., :16], True)
+        # unaligned base: the flat path needs 16-byte alignment, this one takes the strided kernel
+        flat = torch.randn(2 * 5 * 6 * 12 + 1, generator=g).to(dev, dtype)
+        v = flat[1:].view(2, 5, 6, 12)
+        check(v, False)
+        flat[-1] = float("nan")
+        check(v, True)
+    # bad arguments come back as status codes
+    desc = _lib.ChannelMap(16, 4, 4, 8, 0, 128, 32, 8, None)
+    assert lib.d3f_map_check(ctypes.byref(desc), 2, None, st) == _lib.ERR_INVALID_ARG
+    assert lib.d3f_map_check(ctypes.byref(desc), 0, ctypes.c_void_p(word.data_ptr()), st) == _lib.ERR_BAD_SHAPE
+    desc = _lib.ChannelMap(16, 4, 4, 8, 7, 128, 32, 8, None)
+    assert lib.d3f_map_check(ctypes.byref(desc), 2, ctypes.c_void_p(word.data_ptr()), st) == _lib.ERR_BAD_DTYPE
+
+    # the shim: device words instead of torch.isfinite, following in-place writes
+    V, H, W = 3, 48, 64
+    sc = synth.make_scene(V, H, W, "stress")
+    feats = synth.random_map(V, 12, 16, 160, seed=1)
+    pts = synth.random_cloud(6000, seed=3)
+    f = make_fusion(dev, sc["depth"], sc["K"], sc["pose"], {"dino_feats": feats}, H, W)
+    with torch.no_grad():
+        a = f.eval(pts.to(dev), return_names=["dino_feats"])
+        assert f.maps_are_finite(("depth", "dino_feats"))
+        f.curr_obs_torch["dino_feats"][1, 3:9, 4:12, 2] = float("nan")            # in place: torch bumps the version counter
+        b = f.eval(pts.to(dev), return_names=["dino_feats"])
+        assert not f.maps_are_finite(("depth", "dino_feats"))
+    feats_nan = feats.clone()
+    feats_nan[1, 3:9, 4:12, 2] = float("nan")
+    want = oracle_eval(sc, pts, [feats_nan])["sets"][0]
+    got = cpu(b["dino_feats"])
+    assert np.isnan(want).any() and np.array_equal(np.isnan(got), np.isnan(want))
+    ok = np.isfinite(want)
+    assert rel_err(got[ok], want[ok]) <= TOL
+    assert rel_err(cpu(a["dino_feats"]), oracle_eval(sc, pts, [feats])["sets"][0]) <= TOL
+    # a depth image with a NaN: strict path too (the word of 'depth' is part of every query)
+    f2 = make_fusion(dev, sc["depth"], sc["K"], sc["pose"], {"dino_feats": feats}, H, W)
+    f2.curr_obs_torch["depth"][0, 5, 7] = float("nan")
+    with torch.no_grad():
+        f2.eval(pts.to(dev), return_names=["dino_feats"])
+    assert not f2.maps_are_finite(("depth",)) and f2.maps_are_finite(("dino_feats",))
+
+
 def test_nonfinite_points(dev):
     from d3fields_amd import synth
     V, H, W = 3, 48, 64
@@ -1090,10 +1166,13 @@ def test_select_features_from_pcd_matches_reference(dev):
         f.select_features_from_pcd(g["pcd_cloud"], 16, vis=True)
 
 
-def test_fast_path_is_bit_identical_to_strict_path(dev):
-    """Finite-map fast path (invalid-view skip, weight-zero padding, precomputed corner set-up, hand-unrolled
-    shared-reciprocal division) against the strict path (every view sampled, value selects, IEEE '/'):
-    identical bits, on a full-size feature width."""
+def test_fast_path_against_strict_path(dev):
+    """Fast path (device-checked finite maps: invalid-view skip, weight-zero padding, precomputed corner set-up; wide maps
+    with the FOLDED weights) against the strict path (every view sampled, value selects, the
+    reference's operation order, IEEE '/'), on a full-size feature width:
+      * 'dist', 'valid_mask' and the thin map (instance mask) are identical bits;
+      * the wide map agrees to a few ulp of its largest term (contract 1e-5 of max|ref|, asserted 2e-6);
+      * with Fusion.reference_rounding (D3F_FLAG_REFERENCE_ROUNDING) the wide map is identical bits too."""
     import ctypes
     from d3fields_amd import synth, _lib
     V, H, W = 4, 120, 160
@@ -1103,7 +1182,11 @@ def test_fast_path_is_bit_identical_to_strict_path(dev):
     f = make_fusion(dev, sc["depth"], sc["K"], sc["pose"], {"dino_feats": feats, "mask": mask}, H, W)
     pts = (synth.random_cloud(30000, seed=8) * 1.3).to(dev)
     with torch.no_grad():
-        fast = f.eval(pts)                                  # shim verified the maps finite -> D3F_FLAG_FINITE_MAPS
+        fast = f.eval(pts)                                  # the shim's device words say "finite": fast path
+        f.reference_rounding = True
+        exact = f.eval(pts)
+        f.reference_rounding = False
+    assert f.maps_are_finite()
     lib = _lib.load()
     views, keep, _ = f._views(dev)
     names = ["dino_feats", "mask"]
@@ -1118,8 +1201,13 @@ def test_fast_path_is_bit_identical_to_strict_path(dev):
     _lib.check(lib.d3f_eval(ctypes.byref(views), _lib.ptr(pts), pts.shape[0], maps, 2, f.mu, 0, _lib.ptr(strict["dist"]),
                             _lib.ptr(strict["valid_mask"]), fused, None, None, 0, _lib.current_stream_handle(dev)))
     torch.cuda.synchronize()
-    for k in fast:
+    for k in ("dist", "valid_mask", "mask"):
         assert torch.equal(fast[k], strict[k]), k
+    for k in fast:
+        assert torch.equal(exact[k], strict[k]), ("reference_rounding", k)
+    ref = strict["dino_feats"]
+    err = float((fast["dino_feats"] - ref).abs().max() / max(float(ref.abs().max()), 1.0))
+    assert 0.0 < err <= 2e-6, err            # > 0: the folded form really ran
 
 
 # ---------------------------------------------------------------------------------------

@@ -21,7 +21,9 @@ BUDGET = {
     "22fused_eval_runs_kernelILi0ELi1ELi4ELi7E": (72, 0),       # cell runs (1,4), 7 waves
     "22fused_eval_runs_kernelILi0ELi2ELi8ELi3E": (168, 0),      # cell runs (2,8), 3 waves
     "24fused_eval_sliced_kernelILi5ELi2ELi7E": (72, 0),         # channel-sliced, 7 waves
-    "24fused_eval_window_kernelILi1ELi2ELi4ELi256ELi16E": (128, 0),   # LDS texel windows, 4 workgroups per CU
+    "24fused_eval_window_kernelILi1ELi1ELi4ELi256ELi16ELi4E": (128, 0),   # LDS texel windows, pipelined point loop (V = 4), 4 workgroups per CU
+    "24fused_eval_window_kernelILi1ELi1ELi3ELi256ELi16ELi8E": (168, 0),   # ... V = 8, 3 (2) workgroups per CU
+    "24fused_eval_window_kernelILi1ELi1ELi4ELi256ELi16ELi0E": (128, 0),   # ... any other view count: plain view loop
 }
 
 
@@ -42,4 +44,4 @@ def test_default_kernels_keep_their_register_budget():
     # the product build compiles only the variants the planner picks by itself, and none of them spills
     spilling = {k: v for k, v in seen.items() if v[1] > 0}
     assert not spilling, spilling
-    assert len(seen) <= 12, "experiment variants leaked into the product build: %s" % sorted(seen)
+    assert len(seen) <= 16, "experiment variants leaked into the product build: %s" % sorted(seen)
