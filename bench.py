@@ -15,7 +15,14 @@ shape):
   c2_patch  same, reference-faithful patch-resolution 48x64x384 features (fusion.py:694-697)
   c3_dense / c3_patch  + 480x640x8 one-hot instance mask, 1 925 000-point grid (step 4 mm)
   c4_patch  8 views x 720x1280, 72x128x1024 features, 1 000 000 points per GPU
-  c5_track  one tracking frame: eval of 100 000 keypoints (features + mask) + descriptor correspondence
+  c5_track  one tracking frame as SURVEY 8d defines it: NEW depth / feature / mask tensors (the per-frame refresh of
+            vis_tracking.py:86: the shim's device-side finite checks run again), eval of 100 000 keypoints (features +
+            mask), descriptor correspondence (softmax similarity + argmax); the static-map figure is reported beside it
+  ref_patch the reference's own query (vis_repr.py:103): 48x64x1024 DINOv2 patch maps (fusion.py:600,694-697) + 8-instance
+            mask + colours, return_names=['dino_feats','mask','color_tensor'], 1 925 000-point grid
+  dist_only the distance-only pass over the 1-mm grid (return_names=[], vis_repr.py:93 / fusion.py:1420-1428): 123.2 M points,
+            bound by VALU issue (IEEE divisions of the projection), reported against both roofs
+With --gpus N > 1 and no --workload the configuration BASELINE.json names for eight GPUs is timed (c4_patch).
 Multi-GPU: weak scaling -- every rank queries its own shard of N points against replicated
 maps; the only exchange is the RCCL all-gather that reassembles the field (`--gather`).
 """
@@ -50,27 +57,38 @@ WORKLOADS = {
     "c4_dense": dict(V=8, H=720, W=1280, C=1024, fhw=(720, 1280), NI=0, step=0.0025, slabs=8, N=985600, N_cloud=1000000),
     # BASELINE config 5: one tracking frame = Fusion.eval of 100 k keypoints (features + instance mask) followed by the
     # descriptor correspondence of utils/corr_utils.py against 300 reference descriptors (+ fused argmax)
-    "c5_track": dict(V=4, H=480, W=640, C=384, fhw=(48, 64), NI=8, step=None, N=100000, corr_refs=300),
+    "c5_track": dict(V=4, H=480, W=640, C=384, fhw=(48, 64), NI=8, step=None, N=100000, corr_refs=300, refresh=True),
+    # the reference's own shape: DINOv2 ViT-L patch maps are 1024-d at (H/10, W/10) (fusion.py:600,694-697) and vis_repr.py:103
+    # queries features + instance mask + colours in one call
+    "ref_patch": dict(V=4, H=480, W=640, C=1024, fhw=(48, 64), NI=8, color=3, step=0.004, N=1925000),
+    # the distance-only pass of the meshing / keypoint-selection callers on the 1-mm grid (800 x 700 x 220 points)
+    "dist_only": dict(V=4, H=480, W=640, C=0, fhw=(1, 1), NI=0, step=0.001, N=123200000, no_maps=True),
 }
+VALU_PEAK_INST_PER_S = 1024 * 2.4e9 / 4      # 256 CUs x 4 SIMDs, one wave instruction per 4 cycles at 2.4 GHz
 
 
 def algorithmic_bytes(w, n):
     """read every point once, write every output once, read every map once."""
-    sumC = w["C"] + w["NI"]
+    sumC = w["C"] + w["NI"] + w.get("color", 0)
     per_pt = 12 + 4 + 1 + 4 * sumC
     es = 2 if w.get("f16") else 4                                 # stored bytes per feature channel
-    maps = w["V"] * (4 * w["H"] * w["W"] + es * w["fhw"][0] * w["fhw"][1] * w["C"] + 4 * w["H"] * w["W"] * w["NI"])
+    maps = w["V"] * (4 * w["H"] * w["W"] + es * w["fhw"][0] * w["fhw"][1] * w["C"] + 4 * w["H"] * w["W"] * (w["NI"] + w.get("color", 0)))
     return n * per_pt + maps + 84 * w["V"], per_pt
 
 
-def measured_traffic(workload):
-    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/traffic.json), or None."""
+def measured_traffic(workload, points, n):
+    """HBM bytes per launch (and VALU wave instructions, when counted) from the committed rocprofv3 PMC passes
+    (profiles/traffic.json), keyed by workload AND point set (`<workload>` = its grid, `<workload>_random` = the cloud) and
+    only when the profiled launch had the same number of points; else None -- a figure of another kernel / order is worse
+    than none."""
     try:
         with open(os.path.join(ROOT, "profiles", "traffic.json")) as fh:
-            e = json.load(fh).get(workload)
-        return (e["traffic_bytes"], e["source"]) if e else (None, None)
+            e = json.load(fh).get(workload if points == "grid" else workload + "_random")
+        if not e or int(e.get("points", n)) != int(n):
+            return None, None, None
+        return e.get("traffic_bytes"), e.get("source"), e.get("valu_insts")
     except (OSError, ValueError, KeyError):
-        return None, None
+        return None, None, None
 
 
 def build_workload(name, dev, rank, world, points="grid"):
@@ -80,13 +98,18 @@ def build_workload(name, dev, rank, world, points="grid"):
     sc = synth.make_scene(V, H, W, "smooth")
     f = Fusion(num_cam=V, device=str(dev))
     f.curr_obs_torch = {k: sc[k].to(dev) for k in ("depth", "K", "pose")}
-    f.curr_obs_torch["dino_feats"] = synth.random_map(V, w["fhw"][0], w["fhw"][1], w["C"], seed=1, device=dev)
-    if w.get("f16"):
-        f.curr_obs_torch["dino_feats"] = f.curr_obs_torch["dino_feats"].half()
-    names = ["dino_feats"]
+    names = []
+    if not w.get("no_maps"):
+        f.curr_obs_torch["dino_feats"] = synth.random_map(V, w["fhw"][0], w["fhw"][1], w["C"], seed=1, device=dev)
+        if w.get("f16"):
+            f.curr_obs_torch["dino_feats"] = f.curr_obs_torch["dino_feats"].half()
+        names.append("dino_feats")
     if w["NI"]:
         f.curr_obs_torch["mask"] = synth.random_onehot_mask(V, H, W, w["NI"], seed=2, device=dev)
         names.append("mask")
+    if w.get("color"):
+        f.curr_obs_torch["color_tensor"] = torch.rand(V, H, W, w["color"], generator=torch.Generator().manual_seed(4)).to(dev)
+        names.append("color_tensor")
     f.H, f.W = H, W
     if w["step"] is not None and points == "grid" and w.get("slabs"):
         # one x-slab of the job's lattice per rank (north star: "8M points sharded across 8 GPUs"); fewer ranks than slabs
@@ -193,7 +216,7 @@ def cpu_baseline(sc, w, names, maps_cpu, pts_cpu, budget_pts, threads=0):
     obs = {k: sc[k] for k in ("depth", "K", "pose")}
     obs.update(maps_cpu)
     n = min(budget_pts, pts_cpu.shape[0])
-    idx = torch.linspace(0, pts_cpu.shape[0] - 1, n).long()
+    idx = torch.linspace(0, pts_cpu.shape[0] - 1, n, dtype=torch.float64).long().clamp_(max=pts_cpu.shape[0] - 1)
     sample = pts_cpu[idx].contiguous()
     times = []
     with torch.no_grad():
@@ -237,12 +260,25 @@ def spawn_command(n, argv, port=None):
             "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
 
 
+IPC_FAILURE_EXIT = 77        # a rank's first collective failed: the launcher may retry with HSA_ENABLE_IPC_MODE_LEGACY=0
+
+
 def spawn_ranks(n, argv):
-    """Runs this script as n ranks; returns the launcher's exit status (non-zero if any rank failed)."""
+    """Runs this script as n ranks; returns the launcher's exit status (non-zero if any rank failed).
+
+    The environment is handed on UNCHANGED first.  Only if the ranks report that their first collective failed (exit status
+    IPC_FAILURE_EXIT: on hosts whose driver supports dmabuf IPC only, RCCL's hipIpcGetMemHandle fails with 'invalid
+    argument' unless HSA_ENABLE_IPC_MODE_LEGACY=0) and the variable is not set already, the launch is repeated once with it
+    set; the line then says so (config.ipc_mode_retry)."""
     import subprocess
     env = dict(os.environ)
-    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")    # dmabuf IPC: RCCL between processes needs it on this driver
-    return subprocess.call(spawn_command(n, argv), env=env)
+    rc = subprocess.call(spawn_command(n, argv), env=env)
+    if rc != 0 and "HSA_ENABLE_IPC_MODE_LEGACY" not in env and n > 1:
+        env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+        env["D3F_BENCH_IPC_RETRY"] = "1"
+        print("bench.py: the %d-rank launch failed (status %d); retrying once with HSA_ENABLE_IPC_MODE_LEGACY=0" % (n, rc), file=sys.stderr)
+        rc = subprocess.call(spawn_command(n, argv), env=env)
+    return rc
 
 
 def main():
@@ -250,7 +286,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="c2_dense", choices=sorted(WORKLOADS))
+    ap.add_argument("--workload", default=None, choices=sorted(WORKLOADS),
+                    help="default: c2_dense on one GPU (the configuration the metric is quoted on); with --gpus N > 1 c4_patch, "
+                         "the configuration BASELINE.json names for eight GPUs (8 views x 720x1280, 1024-d, 8 M points sharded)")
     ap.add_argument("--gather", default="dist", choices=["none", "dist", "full"],
                     help="N>1: what the RCCL all-gather reassembles inside the timed step")
     ap.add_argument("--points", default="grid", choices=["grid", "random"],
@@ -258,6 +296,9 @@ def main():
                          "same box (exposes the dependence on the caller's point order)")
     ap.add_argument("--no-overlap", action="store_true", help="N>1: block on every all-gather instead of overlapping it "
                     "with the next batch's query")
+    ap.add_argument("--refresh-maps", action="store_true", help="install NEW depth / map tensors before every step (the per-frame "
+                    "update() of a tracking loop: the shim's device-side finite checks, d3f_map_check, run inside the step); "
+                    "always on for c5_track")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-verify", action="store_true", help="skip the post-run oracle check of a 2000-point sample")
     ap.add_argument("--tuning", type=lambda x: int(x, 0), default=0, help="D3F_TUNE_* bits (experiments)")
@@ -268,6 +309,8 @@ def main():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend; 'gloo' lets the N>1 code path be "
                     "exercised with several ranks on ONE GPU (testing only)")
     args = ap.parse_args()
+    if args.workload is None:
+        args.workload = "c2_dense" if args.gpus <= 1 else "c4_patch"
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -292,6 +335,14 @@ def main():
             dist.init_process_group("nccl", device_id=dev)   # "nccl" is RCCL on ROCm
         else:
             dist.init_process_group(args.backend)
+        try:                                                 # the first collective: where a wrong IPC mode shows (see spawn_ranks)
+            probe = torch.ones(1, device=dev)
+            dist.all_reduce(probe)
+            torch.cuda.synchronize(dev)
+            assert int(probe.item()) == world
+        except Exception as exc:
+            print("bench.py rank %d: first collective failed: %r" % (rank, exc), file=sys.stderr)
+            os._exit(IPC_FAILURE_EXIT)
 
     f, pts, names, w, sc = build_workload(args.workload, dev, rank, world, args.points)
     f.tuning_flags = args.tuning
@@ -309,7 +360,18 @@ def main():
         from d3fields_amd import corr_utils
         corr_src = torch.randn(w["corr_refs"], w["C"], generator=torch.Generator().manual_seed(11)).to(dev)
 
+    # every frame REFRESHES the maps (vis_tracking.py:86 calls update() per frame).  The producers are out
+    # of scope, so two resident copies of (depth, features, mask) alternate: every step installs tensor OBJECTS the shim has
+    # not seen in the previous step, i.e. its per-tensor state (the device-side finite words of d3f_map_check) is rebuilt
+    # inside the step exactly as after an update() -- on the stream, without a host sync.
+    frames, frame_no = [None], [0]
+    if w.get("refresh") or args.refresh_maps:
+        frames[0] = [{k: f.curr_obs_torch[k] for k in ["depth"] + names}, {k: f.curr_obs_torch[k].clone() for k in ["depth"] + names}]
+
     def compute():
+        if frames[0] is not None:
+            frame_no[0] += 1
+            f.curr_obs_torch.update(frames[0][frame_no[0] & 1])
         out = f.batch_eval(pts, return_names=names)
         if corr_src is not None:        # keypoint descriptors vs reference descriptors: softmax similarity + best match
             if dist_on:                 # softmax(dim=0) runs over ALL ranks' keypoints: one 16-B record per reference exchanged
@@ -370,6 +432,11 @@ def main():
             extra["cached_point_order_note"] = ("the shim's default: lattice dims / Morton order of an UNCHANGED query tensor are kept "
                                                 "between calls; `value` re-derives them inside every step")
             f.cache_point_order = False
+            if frames[0] is not None:           # the same step on maps that do not change (what rounds 1-3 reported for c5)
+                keep, frames[0] = frames[0], None
+                compute(); compute()
+                extra["points_per_s_with_static_maps"] = n * args.steps / time_steps(compute, args.steps, False, dev)
+                frames[0] = keep
         if dist_on:
             extra["compute_only_points_per_s"] = world * n * args.steps / time_steps(compute, args.steps, True, dev)
             if args.gather != "full":
@@ -397,26 +464,31 @@ def main():
     total_pts = world * n * args.steps
     value = total_pts / wall
     bytes_alg, per_pt = algorithmic_bytes(w, n)
-    traffic, traffic_src = measured_traffic(args.workload)
+    traffic, traffic_src, valu_insts = measured_traffic(args.workload, args.points if w["step"] is not None else "grid", n)
     achieved = bytes_alg / (k_avg * 1e-3) / 1e9
     # SURVEY 8d secondary figure (reported, not graded): bytes the gather requests with zero inter-point reuse
-    sumC = w["C"] + w["NI"]
+    sumC = w["C"] + w["NI"] + w.get("color", 0)
     b_gather = 12 + w["V"] * (4 + 16 * sumC) + 5 + 4 * sumC
     res = {
         "metric": "fused 3D query-points/sec", "value": value, "unit": "points/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * wall / args.steps, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": ("f32 (feature maps stored as f16)" if w.get("f16") else "f32"), "data": "synthetic",
-        "config": {"workload": "%s: %d views x %dx%d depth, %dx%dx%d fp32 features%s, %d query points per GPU, "
-                               "return_names=%s" % (args.workload, w["V"], w["H"], w["W"], w["fhw"][0], w["fhw"][1], w["C"],
+        "config": {"workload": "%s: %d views x %dx%d depth, %s%s%s, %d query points per GPU, "
+                               "return_names=%s" % (args.workload, w["V"], w["H"], w["W"],
+                                                    ("no channel maps" if w.get("no_maps") else "%dx%dx%d fp32 features" % (w["fhw"][0], w["fhw"][1], w["C"])),
                                                     (" + %dx%dx%d one-hot mask" % (w["H"], w["W"], w["NI"])) if w["NI"] else "",
+                                                    (" + %dx%dx%d colours" % (w["H"], w["W"], w["color"])) if w.get("color") else "",
                                                     n, names),
+                   "maps_refreshed_every_step": bool(w.get("refresh") or args.refresh_maps),
                    "points": ("grid" if (w["step"] is not None and args.points == "grid") else "random cloud"),
                    "points_per_gpu": n, "views": w["V"], "feature_dim": w["C"], "feature_map": list(w["fhw"]),
                    "parallelism": "points sharded x%d, maps replicated" % world,
                    # what torch.distributed itself reports (backend "nccl" is RCCL on ROCm), and where every rank ran
                    "rccl_world_size": (dist.get_world_size() if dist_on else 1), "backend": (args.backend if dist_on else "n/a"),
                    "rank_devices": rank_devices,
+                   "hsa_enable_ipc_mode_legacy": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY"),
+                   "ipc_mode_retry": os.environ.get("D3F_BENCH_IPC_RETRY") == "1",
                    "gather": (args.gather if dist_on else "n/a"),
                    "gather_overlap": ((not args.no_overlap) if dist_on else "n/a"),
                    "gather_overlap_error": (overlap_error[0] if overlap_error else None),
@@ -434,7 +506,13 @@ def main():
                      "algorithmic_bytes_per_point": per_pt, "kernel_points_per_s": n / (k_avg * 1e-3),
                      "step_device_ms_avg": s_avg, "logical_gather_bytes_per_point": b_gather,
                      "logical_gather_GBps": n * b_gather / (k_avg * 1e-3) / 1e9,
-                     "traffic_GBps": (traffic / (k_avg * 1e-3) / 1e9) if traffic else None, "note": "achieved = algorithmic bytes / kernel_ms_avg (HIP events around the "
+                     "traffic_GBps": (traffic / (k_avg * 1e-3) / 1e9) if traffic else None,
+                     # second roof, for the launches that are not memory-bound (dist_only): VALU wave instructions of the committed
+                     # counter pass over this run's kernel time, against one instruction per SIMD per 4 cycles at 2.4 GHz
+                     "valu_issue": ({"insts_per_launch": valu_insts, "insts_per_point": valu_insts / n,
+                                     "frac_of_issue_peak": valu_insts / (k_avg * 1e-3) / VALU_PEAK_INST_PER_S,
+                                     "peak_inst_per_s": VALU_PEAK_INST_PER_S, "source": traffic_src} if valu_insts else None),
+                     "note": "achieved = algorithmic bytes / kernel_ms_avg (HIP events around the "
                      "fused kernel on its launch stream); step_device_ms_avg also covers the per-step lattice probe / Morton ordering kernels"},
     }
     res.update(extra)

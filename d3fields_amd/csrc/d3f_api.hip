@@ -1187,10 +1187,10 @@ static int track_impl(const d3f_views *views, const d3f_channel_map *descriptors
     if (iters < 0) return fail(D3F_ERR_INVALID_ARG, "track_run: iters=%d", iters);
     if ((int64_t)n_inst * n == 0 || iters == 0) return D3F_OK;
     if ((int64_t)n_inst * n > 0x7fffffLL) return fail(D3F_ERR_BAD_SHAPE, "track_step: %lld keypoints (one workgroup each) are too many", (long long)n_inst * n);
-    if (iters > 1 && ((int64_t)n_inst * n > d3f::kTrackMaxResident || n_inst > 16))
+    if (iters > 1 && ((int64_t)n_inst * n > d3f::track_run_capacity() || n_inst > 16))
         return fail(D3F_ERR_BAD_SHAPE, "track_run: %lld keypoints of %d instances; the steps of one launch wait for one another, so every "
-                                       "workgroup must be resident (<= %d keypoints, <= 16 instances); call d3f_track_step per iteration",
-                    (long long)n_inst * n, n_inst, d3f::kTrackMaxResident);
+                                       "workgroup must be resident (<= %d keypoints on this device, <= 16 instances); call d3f_track_step per iteration",
+                    (long long)n_inst * n, n_inst, d3f::track_run_capacity());
     if (!descriptors || !last || !src || !state) return fail(D3F_ERR_INVALID_ARG, "track_step: NULL pointer");
     if (!state->t || !state->w || !state->adam_m || !state->adam_v || !state->step || !state->out_pts || !state->loss || !state->scratch)
         return fail(D3F_ERR_INVALID_ARG, "track_step: NULL pointer in d3f_track_state");
@@ -1209,6 +1209,7 @@ static int track_impl(const d3f_views *views, const d3f_channel_map *descriptors
     P.depth = views->depth; P.K = views->K; P.pose = views->pose; P.V = views->V; P.H = views->H; P.W = views->W;
     P.last = last; P.src = src; P.I = n_inst; P.n = n; P.iters = iters;
     P.mu = mu; P.dist_w = dist_w; P.reg_w = reg_w; P.lr = lr; P.beta1 = beta1; P.beta2 = beta2; P.eps_adam = eps; P.eps_rot = 1e-4f;
+    P.ln_beta1 = d3f::log_of_decimal(beta1); P.ln_beta2 = d3f::log_of_decimal(beta2);
     P.t = state->t; P.w = state->w; P.adam_m = state->adam_m; P.adam_v = state->adam_v; P.step = state->step;
     P.out_pts = state->out_pts; P.loss_out = state->loss;
     float *scr = static_cast<float *>(state->scratch);
@@ -1233,6 +1234,6 @@ int d3f_track_run(const d3f_views *views, const d3f_channel_map *descriptors, co
     return track_impl(views, descriptors, last, n_inst, n, src, mu, dist_w, reg_w, lr, beta1, beta2, eps, iters, state, stream);
 }
 
-int32_t d3f_track_run_max_keypoints(void) { return d3f::kTrackMaxResident; }
+int32_t d3f_track_run_max_keypoints(void) { return d3f::track_run_capacity(); }
 
 }  // extern "C"

@@ -197,6 +197,7 @@ struct TrackStepParams {
     const float *src;                   // [I*n, C]
     int32_t I, n;
     float mu, dist_w, reg_w, lr, beta1, beta2, eps_adam, eps_rot;
+    double ln_beta1, ln_beta2;          // ln of the decimal numbers beta1 / beta2 stand for (log_of_decimal): Adam's bias corrections in double
     float *t, *w, *adam_m, *adam_v, *step;     // [I,3] [I,3] [I,6] [I,6] [I]
     float *out_pts;                     // [I*n, 3] the keypoints as evaluated in this step
     float *grad_pts;                    // [I*n, 3] scratch
@@ -209,5 +210,7 @@ struct TrackStepParams {
 constexpr int kTrackMaxResident = 512;       // one wave per SIMD at this kernel's register count = 1024 on the chip; half of it
 
 hipError_t launch_track_step(const TrackStepParams &P, hipStream_t s);
+double log_of_decimal(float beta);
+int track_run_capacity();          // keypoints one d3f_track_run launch may hold on the current device
 
 }  // namespace d3f

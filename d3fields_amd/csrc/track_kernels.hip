@@ -115,7 +115,7 @@ struct AdamShared { float g6[6]; float step, step_size, bc2_sqrt; };      // wha
 
 // gradient of the six parameters (chain rule + regulariser) and Adam's bias corrections for this step
 __device__ __forceinline__ AdamShared rigid_adam_shared(const float *G, const float *t3, const float *w3, float step_in, float nt, float nw,
-                                                        float eps_rot, float reg_w, float lr, float beta1, float beta2)
+                                                        float eps_rot, float reg_w, float lr, double ln_b1, double ln_b2)
 {
     const float wx = w3[0], wy = w3[1], wz = w3[2];
     const Rot r = exp_map(wx, wy, wz, eps_rot);
@@ -164,10 +164,11 @@ __device__ __forceinline__ AdamShared rigid_adam_shared(const float *G, const fl
     // torch.optim.Adam (amsgrad off, no weight decay): bias corrections of this step
     const float st = step_in + 1.0f;
     o.step = st;
-    // beta^step as exp2(step * log2 beta) on the hardware's log / exp units (relative error < 1e-6 for step <= 1e4; ocml's
-    // powf was a quarter of the update's 3.6 us dependency chain; the reference forms these in double precision on the host)
-    const float bc1 = 1.0f - __builtin_amdgcn_exp2f(st * __builtin_amdgcn_logf(beta1));
-    const float bc2 = 1.0f - __builtin_amdgcn_exp2f(st * __builtin_amdgcn_logf(beta2));
+    // 1 - beta^step in DOUBLE like torch.optim.Adam forms them on the host: -expm1(step * ln beta), with ln beta computed on
+    // the host from the decimal value the caller meant (0.999f is 0.99900001287: as a float it already moves 1 - beta2 by 1.3e-5,
+    // and an fp32 exp2 / log2 pair moves the early-step corrections by ~6e-5 -- round 3's form).  Two fp64 expm1 per step and wave.
+    const float bc1 = (float)(-expm1((double)st * ln_b1));
+    const float bc2 = (float)(-expm1((double)st * ln_b2));
     o.step_size = lr / bc1;
     o.bc2_sqrt = sqrtf(bc2);
     return o;
@@ -184,9 +185,9 @@ __device__ __forceinline__ void rigid_adam_param(float g, float &m, float &v, fl
 }
 
 __device__ __forceinline__ AdamState rigid_adam_math(const float *G, const AdamState in, float nt, float nw, float eps_rot, float reg_w,
-                                                     float lr, float beta1, float beta2, float eps_adam)
+                                                     float lr, float beta1, float beta2, float eps_adam, double ln_b1, double ln_b2)
 {
-    const AdamShared sh = rigid_adam_shared(G, in.t, in.w, in.step, nt, nw, eps_rot, reg_w, lr, beta1, beta2);
+    const AdamShared sh = rigid_adam_shared(G, in.t, in.w, in.step, nt, nw, eps_rot, reg_w, lr, ln_b1, ln_b2);
     AdamState out = in;
     out.step = sh.step;
 #pragma unroll
@@ -198,7 +199,7 @@ __device__ __forceinline__ AdamState rigid_adam_math(const float *G, const AdamS
 __device__ __forceinline__ void rigid_adam_update(int i, const float *G, float *__restrict__ t, float *__restrict__ w,
                                                   float *__restrict__ adam_m, float *__restrict__ adam_v, float *__restrict__ step,
                                                   float nt, float nw, float eps_rot, float reg_w, float lr, float beta1, float beta2,
-                                                  float eps_adam)
+                                                  float eps_adam, double ln_b1, double ln_b2)
 {
     AdamState in;
 #pragma unroll
@@ -206,7 +207,7 @@ __device__ __forceinline__ void rigid_adam_update(int i, const float *G, float *
 #pragma unroll
     for (int k = 0; k < 6; ++k) { in.m[k] = adam_m[i * 6 + k]; in.v[k] = adam_v[i * 6 + k]; }
     in.step = step[i];
-    const AdamState o = rigid_adam_math(G, in, nt, nw, eps_rot, reg_w, lr, beta1, beta2, eps_adam);
+    const AdamState o = rigid_adam_math(G, in, nt, nw, eps_rot, reg_w, lr, beta1, beta2, eps_adam, ln_b1, ln_b2);
 #pragma unroll
     for (int k = 0; k < 3; ++k) { t[i * 3 + k] = o.t[k]; w[i * 3 + k] = o.w[k]; }
 #pragma unroll
@@ -219,7 +220,7 @@ __global__ __launch_bounds__(kBlock) void rigid_update_kernel(const float *__res
                                                              float *__restrict__ t, float *__restrict__ w, float *__restrict__ adam_m,
                                                              float *__restrict__ adam_v, float *__restrict__ step,
                                                              const float *__restrict__ norms, float eps_rot, float reg_w, float lr,
-                                                             float beta1, float beta2, float eps_adam)
+                                                             float beta1, float beta2, float eps_adam, double ln_b1, double ln_b2)
 {
     __shared__ float red[12][kBlock / 64];
     const int i = blockIdx.x;
@@ -250,7 +251,7 @@ __global__ __launch_bounds__(kBlock) void rigid_update_kernel(const float *__res
         for (int wv = 0; wv < kBlock / 64; ++wv) v += red[k][wv];
         G[k] = v;
     }
-    rigid_adam_update(i, G, t, w, adam_m, adam_v, step, norms[0], norms[1], eps_rot, reg_w, lr, beta1, beta2, eps_adam);
+    rigid_adam_update(i, G, t, w, adam_m, adam_v, step, norms[0], norms[1], eps_rot, reg_w, lr, beta1, beta2, eps_adam, ln_b1, ln_b2);
 }
 
 // ---- the WHOLE optimiser step as one launch (round 3) -------------------------------------------------------------------
@@ -585,7 +586,7 @@ __global__ __launch_bounds__(64) void track_step_kernel(const TrackStepParams P)
                 for (int q = 0; q < 12; ++q) G[q] += __shfl_xor(G[q], off, 64);
             const float t3[3] = {sh_p[i * 3], sh_p[i * 3 + 1], sh_p[i * 3 + 2]};
             const float w3[3] = {sh_p[3 * I + i * 3], sh_p[3 * I + i * 3 + 1], sh_p[3 * I + i * 3 + 2]};
-            const AdamShared sh = rigid_adam_shared(G, t3, w3, sh_p[18 * I + i], nt, nw, P.eps_rot, P.reg_w, P.lr, P.beta1, P.beta2);
+            const AdamShared sh = rigid_adam_shared(G, t3, w3, sh_p[18 * I + i], nt, nw, P.eps_rot, P.reg_w, P.lr, P.ln_beta1, P.ln_beta2);
             if (active && k < 6) {
                 const float g = k == 0 ? sh.g6[0] : k == 1 ? sh.g6[1] : k == 2 ? sh.g6[2] : k == 3 ? sh.g6[3] : k == 4 ? sh.g6[4] : sh.g6[5];
                 float mk = sh_p[6 * I + i * 6 + k], vk = sh_p[12 * I + i * 6 + k];
@@ -633,7 +634,7 @@ __global__ __launch_bounds__(64) void track_step_kernel(const TrackStepParams P)
 #pragma unroll
         for (int k = 0; k < 12; ++k)
             for (int off = 32; off > 0; off >>= 1) G[k] += __shfl_xor(G[k], off, 64);
-        if (lane == 0) rigid_adam_update(i, G, P.t, P.w, P.adam_m, P.adam_v, P.step, nt, nw, P.eps_rot, P.reg_w, P.lr, P.beta1, P.beta2, P.eps_adam);
+        if (lane == 0) rigid_adam_update(i, G, P.t, P.w, P.adam_m, P.adam_v, P.step, nt, nw, P.eps_rot, P.reg_w, P.lr, P.beta1, P.beta2, P.eps_adam, P.ln_beta1, P.ln_beta2);
     }
     if (lane == 0) {
         P.loss_out[0] = __builtin_nontemporal_load(P.loss_acc + 0);
@@ -656,13 +657,42 @@ __global__ void track_reset_kernel(float *loss_acc, unsigned int *counter, unsig
     for (int k = threadIdx.x; k < n_par; k += 64) par[k] = 0ull;
 }
 
+// ln(beta) in double for the decimal number the caller's float stands for (0.9f -> 0.9, 0.999f -> 0.999: the shortest decimal that
+// rounds to the float, which is what a Python caller typed and torch.optim.Adam computes with)
+double log_of_decimal(float beta)
+{
+    char buf[32];
+    double d = (double)beta;
+    for (int digits = 1; digits <= 9; ++digits) {
+        snprintf(buf, sizeof(buf), "%.*g", digits, (double)beta);
+        d = strtod(buf, nullptr);
+        if ((float)d == beta) break;
+    }
+    return log(d);
+}
+
+// How many one-wave workgroups of the multi-step kernel the device can hold at once (they wait for one another, so all of a
+// launch must be resident): the runtime's occupancy for THIS kernel x the CUs of THIS device (a partition in CPX mode, a part
+// with fewer CUs, spills -- none of which the round-3 constant knew), half of it left to whatever else runs, capped by the
+// kernel's static LDS arrays.
+int track_run_capacity()
+{
+    static int cached = -1;
+    if (cached >= 0) return cached;
+    int dev = 0, cus = 0, per_cu = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, track_step_kernel<2>, 64, 0) != hipSuccess) return 0;
+    int cap = cus * per_cu / 2;
+    cached = cap < kTrackMaxResident ? cap : kTrackMaxResident;
+    return cached;
+}
+
 hipError_t launch_track_step(const TrackStepParams &P, hipStream_t s)
 {
     const int N = P.I * P.n;
     if (N == 0 || P.iters <= 0) return hipSuccess;
-    // several steps per launch wait for one another inside the kernel: every wave must be resident (one per SIMD at
-    // this register count: 1024 on the chip; the bound leaves half of that to whatever else runs)
-    if (P.iters > 1 && (N > kTrackMaxResident || P.I > kTrackMaxInst)) return hipErrorInvalidValue;
+    // several steps per launch wait for one another inside the kernel: every wave must be resident
+    if (P.iters > 1 && (N > track_run_capacity() || P.I > kTrackMaxInst)) return hipErrorInvalidValue;
     if (P.iters > 1) hipLaunchKernelGGL(track_reset_kernel, dim3(1), dim3(64), 0, s, P.loss_acc, P.counter, P.par, P.I * 6);
     const int nvec = (P.map.C / 4 + 63) / 64;
     if (nvec <= 1) hipLaunchKernelGGL(track_step_kernel<1>, dim3((unsigned)N), dim3(64), 0, s, P);
@@ -698,7 +728,7 @@ hipError_t launch_rigid_update(const float *last, int I, int n, const float *gra
 {
     if (I == 0) return hipSuccess;
     hipLaunchKernelGGL(rigid_update_kernel, dim3((unsigned)I), dim3(kBlock), 0, s, last, n, grad_pts, t, w, adam_m, adam_v, step, norms,
-                       eps_rot, reg_w, lr, beta1, beta2, eps_adam);
+                       eps_rot, reg_w, lr, beta1, beta2, eps_adam, log_of_decimal(beta1), log_of_decimal(beta2));
     return hipGetLastError();
 }
 

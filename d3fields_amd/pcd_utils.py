@@ -302,8 +302,12 @@ def masked_pixel_fps(mask_channel, depth, particle_num, depth_lo=0.0, depth_hi=1
     lib = _lib.load()
     dev = mask_channel.device
     H, W = int(depth.shape[0]), int(depth.shape[1])
-    assert mask_channel.shape == (H, W) and mask_channel.dtype == torch.float32 and depth.dtype == torch.float32
-    depth = depth.contiguous()
+    assert mask_channel.shape == (H, W)
+    # the mask is stored in Fusion.dtype (float16 under the fp16 storage mode) or installed by the caller as bool / uint8
+    # one-hot: the gate reads float32 (the reference does mask.astype(bool): any non-zero counts)
+    if mask_channel.dtype != torch.float32:
+        mask_channel = (mask_channel != 0).to(torch.float32)
+    depth = depth.to(torch.float32).contiguous()
     gated = torch.empty((H, W), dtype=torch.uint8, device=dev)
     eroded = torch.empty_like(gated)
     rc = torch.empty((H * W, 2), dtype=torch.int32, device=dev)

@@ -133,7 +133,10 @@ class RigidTracker:
             self.grad_dist = torch.empty(num_inst * n, device=dev)
             self.opt = None
             feats = obs["dino_feats"]
-            self.single = bool(single_launch) and feats.dtype == torch.float32 and C % 4 == 0 and C <= 512 and fusion.num_cam <= 8
+            # (the same layout conditions d3f_track_step checks: a view with odd strides or an unaligned base takes the
+            # five-launch step instead of failing inside the graph capture)
+            self.single = (bool(single_launch) and feats.dtype == torch.float32 and C % 4 == 0 and C <= 512 and fusion.num_cam <= 8 and
+                           feats.stride(3) == 1 and all(feats.stride(d) % 4 == 0 for d in (0, 1, 2)) and feats.data_ptr() % 16 == 0)
             if self.single:
                 from . import _lib
                 self.loss3 = torch.zeros(3, device=dev)
@@ -145,6 +148,7 @@ class RigidTracker:
             self.opt = torch.optim.Adam([self.t_params, self.log_r], lr=lr, betas=(0.9, 0.999), capturable=True)
         self.graph = None
         self.cur = self.loss = None
+        self.loop_fallbacks = 0                  # frames d3f_track_run gave up on (NaN loss) and the per-step launches repeated
 
     @staticmethod
     def signature(fusion, num_inst, n):
@@ -221,6 +225,7 @@ class RigidTracker:
             self.last.copy_(last_match_pts)
             self.src.copy_(src_feats)
         if self.graph is None:
+            self._rewind()                       # (a fallback after a failed d3f_track_run: its scratch words are stale)
             side = torch.cuda.Stream(device=dev)
             side.wait_stream(torch.cuda.current_stream(dev))
             with torch.cuda.stream(side):
@@ -238,4 +243,15 @@ class RigidTracker:
         self._rewind()
         for _ in range(1 if self.whole_loop else self.iters):
             self.graph.replay()
-        return self.cur.detach().clone(), self.loss.detach().clone()
+        cur, loss = self.cur.detach().clone(), self.loss.detach().clone()
+        if self.loop:
+            # d3f_track_run's waves wait for one another INSIDE the kernel; with the device held by other work for seconds
+            # the bounded wait gives up and poisons the loss with NaN (the poses are then undefined).  One host sync per
+            # frame -- the caller (Fusion.rigid_tracking) copies the keypoints to the host right away anyway -- and the
+            # frame is repeated with one launch per step, which cannot stall; the tracker stays on that form.
+            if bool(torch.isnan(self.loss3).any().item()):
+                self.loop = False
+                self.graph = None
+                self.loop_fallbacks += 1
+                return self.run(fusion, src_feats, last_match_pts)
+        return cur, loss

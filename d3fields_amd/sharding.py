@@ -39,29 +39,56 @@ def shard_points(pts, rank=None, world=None, group=None):
     return pts[lo:hi]
 
 
-def _gather_rows_into(out, x, counts, group, async_op=False):
-    """all-gather of per-rank row blocks (dim-0 sizes `counts`, ragged allowed) straight into the pre-sized
-    C-contiguous `out` ([sum(counts), ...]): no padding, no staging buffer, no torch.cat.  Returns the pending works.
+class _PaddedGather:
+    """Pending ragged all-gather: ONE all_gather_into_tensor of blocks padded to the largest shard, then every rank's
+    rows are copied from the padded staging buffer to their place in `out`.  wait() completes both steps."""
 
-    Equal shards: one all_gather_into_tensor.  Ragged shards: rank r's block is broadcast into ITS slice of `out`
-    (a contiguous view), so every byte lands in place; the P broadcasts are queued back to back on the
-    collective stream and move the same bytes as one all-gather-v."""
+    def __init__(self, work, staged, out, counts, maxc):
+        self.work, self.staged, self.out, self.counts, self.maxc = work, staged, out, list(counts), maxc
+
+    def wait(self):
+        if self.work is not None:
+            self.work.wait()
+            self.work = None
+        if self.staged is not None:
+            off = 0
+            for r, c in enumerate(self.counts):
+                if c:
+                    self.out[off:off + c].copy_(self.staged[r * self.maxc:r * self.maxc + c])
+                off += c
+            self.staged = None
+        return True
+
+
+def _gather_rows_into(out, x, counts, group, async_op=False):
+    """all-gather of per-rank row blocks (dim-0 sizes `counts`, ragged allowed) into the pre-sized C-contiguous `out`
+    ([sum(counts), ...]).  Returns the pending works (objects with .wait()).
+
+    Equal shards: one all_gather_into_tensor straight into `out` (no padding, no staging, no torch.cat).  Ragged shards
+    (round 4; rounds 2-3 queued P broadcasts back to back, i.e. P collectives of one sender each -- on a ring that is P
+    times the latency and never more than one link busy): ONE all_gather_into_tensor of blocks padded to the largest shard
+    into a staging buffer, then P local block copies into place (shard_bounds' shards differ by at most one row, so the
+    padding is at most one row per rank; the local copies move what one rank receives once more through HBM, ~1 % of the
+    time the same bytes need on a 153 GB/s link)."""
     rank, world = _world(group)
     x = x.contiguous()
     if len(set(counts)) == 1:
         w = dist.all_gather_into_tensor(out, x, group=group, async_op=async_op)
         return [w] if async_op else []
-    views = list(out.split(list(counts), dim=0))
-    views[rank].copy_(x)
-    works = []
-    for r in range(world):
-        if counts[r] == 0:
-            continue
-        src = dist.get_global_rank(group, r) if group is not None else r
-        w = dist.broadcast(views[r], src=src, group=group, async_op=async_op)
-        if async_op:
-            works.append(w)
-    return works
+    maxc = max(counts)
+    if x.shape[0] == maxc:
+        padded = x
+    else:
+        padded = x.new_zeros((maxc,) + tuple(x.shape[1:]))
+        padded[:x.shape[0]].copy_(x)
+    staged = x.new_empty((world * maxc,) + tuple(x.shape[1:]))
+    w = dist.all_gather_into_tensor(staged, padded, group=group, async_op=async_op)
+    pg = _PaddedGather(w if async_op else None, staged, out, counts, maxc)
+    pg._keep = padded                       # the input must outlive an asynchronous collective
+    if async_op:
+        return [pg]
+    pg.wait()
+    return []
 
 
 def _gather_rows(t, counts, group, async_op=False):

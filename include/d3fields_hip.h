@@ -462,10 +462,14 @@ int d3f_track_step(const d3f_views *views, const d3f_channel_map *descriptors, c
  * inside the kernel for the Adam update of step k (a device-wide arrival counter and step-tagged parameter words in `scratch`),
  * so K / pose / the source descriptors are read once per frame and no launch boundary separates the steps.  Same
  * arithmetic per step as d3f_track_step (same t / w / out_pts / loss as `iters` calls of it).  Every workgroup must be
- * resident while the others wait: n_inst*n <= d3f_track_run_max_keypoints() (512) and n_inst <= 16, else D3F_ERR_BAD_SHAPE -- call
- * d3f_track_step per iteration then.  The wait is bounded: should a wave never see the next step's parameters (the device shared
- * with another kernel that never ends), loss[0..2] become NaN and the launch ends.  scratch is cleared at the start (a
- * one-workgroup launch ahead of the step kernel). */
+ * resident while the others wait: n_inst*n <= d3f_track_run_max_keypoints() and n_inst <= 16, else D3F_ERR_BAD_SHAPE -- call
+ * d3f_track_step per iteration then.  d3f_track_run_max_keypoints() is derived at run time for the CURRENT device: the
+ * occupancy of the kernel (hipOccupancyMaxActiveBlocksPerMultiprocessor) x its compute units, half of that (the other half is
+ * left to whatever else runs), at most 512.  The wait is bounded: should a wave never see the next step's parameters (the
+ * device held by other kernels for seconds), loss[0..2] become NaN, the launch ends, and t / w / the optimiser state are
+ * UNDEFINED: a caller that shares the device checks loss for NaN, restores its state, clears `scratch` and repeats the frame
+ * with d3f_track_step (d3fields_amd/rigid.py: RigidTracker.run does exactly that).  scratch is cleared at the start of every
+ * d3f_track_run (a one-workgroup launch ahead of the step kernel); d3f_track_step expects the scratch its predecessor left. */
 int d3f_track_run(const d3f_views *views, const d3f_channel_map *descriptors, const float *last, int32_t n_inst, int32_t n,
                   const float *src, float mu, float dist_w, float reg_w, float lr, float beta1, float beta2, float eps,
                   int32_t iters, const d3f_track_state *state, void *stream);

@@ -8,6 +8,8 @@ import re
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from bench import WORKLOADS  # noqa: E402
 out_path = os.path.join(ROOT, "profiles", "traffic.json")
 try:
     data = json.load(open(out_path))
@@ -18,7 +20,8 @@ data["_comment"] = ("HBM-side bytes per launch of the dominant kernel from rocpr
                     "16-B/lane coalesced reads at half size, MI355X_MICROARCH.md HBM section; confirmed here: FETCH_SIZE*1024 == "
                     "TCC_EA0_RDREQ_sum*64 with TCC_EA0_RDREQ_32B_sum == 0) + WRITE_SIZE[KB]*1024. FETCH_SIZE counts Infinity-Cache hits "
                     "(fabric traffic, not DRAM traffic). bench.py copies the entry of its workload into roofline.traffic "
-                    "(traffic_measured_in_run: false).")
+                    "(traffic_measured_in_run: false) -- only when the run has the same point set (`<workload>`: its grid, "
+                    "`<workload>_random`: the cloud) and the same number of points as the profiled launch (`points`).")
 for d in sys.argv[1:]:
     for path in sorted(glob.glob(os.path.join(d, "*_summary.txt"))):
         wl = os.path.basename(path)[:-len("_summary.txt")]
@@ -43,6 +46,11 @@ for d in sys.argv[1:]:
         if "SQ_INSTS_VALU" in c:
             e["valu_insts"] = int(c["SQ_INSTS_VALU"])
         e["source"] = os.path.relpath(path, ROOT)
+        # the launch the counters belong to: bench.py prints the entry only for a run with the same point set and count
+        # (`<workload>` = its grid, `<workload>_random` = the cloud of --points random)
+        base = wl[:-len("_random")] if wl.endswith("_random") else wl
+        if base in WORKLOADS:
+            e["points"] = int(WORKLOADS[base].get("N_cloud", WORKLOADS[base]["N"]) if wl.endswith("_random") else WORKLOADS[base]["N"])
         data[wl] = e
 json.dump(data, open(out_path, "w"), indent=1)
 print("wrote", out_path, sorted(k for k in data if not k.startswith("_")))

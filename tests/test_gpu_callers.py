@@ -142,6 +142,10 @@ def test_masked_pixel_fps_pipeline(dev):
         assert z.dtype == np.float32 and np.array_equal(z, depth[wsel[:, 0], wsel[:, 1]])
     with pytest.raises(AssertionError):
         pcd_utils.masked_pixel_fps(m_dev[:, :, 0], d_dev, 5)                            # empty mask: fps_np asserts
+    # the mask in Fusion.dtype = float16 (the fp16 storage mode), or a caller's bool / uint8 one-hot: same pixels
+    wsel = pcd_utils.masked_pixel_fps(m_dev[:, :, 1], d_dev, 50, init_idx=7)[0]
+    for other in (m_dev.half(), m_dev.bool(), (m_dev * 255).to(torch.uint8)):
+        assert np.array_equal(pcd_utils.masked_pixel_fps(other[:, :, 1], d_dev, 50, init_idx=7)[0], wsel), other.dtype
 
 
 def _v2_fusion(dev):
@@ -165,6 +169,31 @@ def test_select_features_rand_v2_matches_reference(dev):
     for i in range(len(pts_l)):
         assert pts_l[i].dtype == np.float64 and np.array_equal(pts_l[i], g["pts_%d" % i]), i
         assert rel_err(cpu(feats_l[i]), g["feats_%d" % i]) <= TOL
+
+
+def test_select_features_rand_v2_with_fp16_stored_maps(dev):
+    """Fusion(dtype=float16) stores curr_obs_torch['mask'] in half: the pixel pipeline converts instead of asserting float32
+    (ADVICE r3); the keypoints are those of the float32 run (pixels, depths and the float64 lift do not depend on the map
+    format), the descriptors those of the fp16-stored map."""
+    import warnings
+    from d3fields_amd import Fusion
+    g = load_golden("select_v2")
+    V, H, W = g["depth"].shape
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        f = Fusion(num_cam=V, device=str(dev), dtype=torch.float16, mask_producer=lambda fusion, q, t, b, **kw: {
+            "mask": g["in_mask"], "consensus_mask_label": ["background", "mug", "box"]})
+    f.mu = float(g["mu"])
+    f.update({"color": np.zeros((V, H, W, 3), np.uint8), "depth": g["depth"], "pose": g["pose"], "K": g["K"],
+              "dino_feats": g["in_dino_feats"]})
+    f.text_queries_for_inst_mask_no_track(["mug", "box"], [0.3, 0.3], None)
+    assert f.curr_obs_torch["mask"].dtype == torch.float16
+    np.random.seed(int(g["seed"]))
+    feats_l, pts_l, imgs = f.select_features_rand_v2(None, int(g["N"]), per_instance=True)
+    assert len(pts_l) == int(g["n_inst"])
+    for i in range(len(pts_l)):
+        assert np.array_equal(pts_l[i], g["pts_%d" % i]), i
+        assert rel_err(cpu(feats_l[i]), g["feats_%d" % i]) <= 2e-3          # half-precision storage of the descriptors
 
 
 # ---- text_queries_* state contract (fusion.py:1112-1256) -------------------------------------------------------------
@@ -448,11 +477,78 @@ def test_track_run_equals_track_steps(dev, I, n, V, C):
     assert abs(a[3] - b[3]) <= 1e-5 * max(1.0, abs(a[3]))        # the loss terms are float atomics: order varies
 
 
+def _golden_tracker_inputs(dev):
+    g = load_golden("rigid_tracking")
+    from d3fields_amd import Fusion
+    f = Fusion(num_cam=g["depth"].shape[0], device=str(dev))
+    f.mu = float(g["mu"])
+    t = lambda a: torch.as_tensor(np.asarray(a)).to(dev, torch.float32)   # noqa: E731
+    f.curr_obs_torch = {"depth": t(g["depth"]), "K": t(g["K"]), "pose": t(g["pose"]), "dino_feats": t(g["in_dino_feats"])}
+    f.H, f.W = int(g["H"]), int(g["W"])
+    n = int(g["n"])
+    info = {"a": {"src_feats": torch.from_numpy(g["src_feats"][:n])}, "b": {"src_feats": torch.from_numpy(g["src_feats"][n:])}}
+    return g, f, info, n
+
+
+def test_track_run_falls_back_when_its_wait_gives_up(dev):
+    """d3f_track_run's waves wait for one another inside the kernel; when the bounded wait gives up (a device held by other
+    work for seconds) the kernel poisons the loss with NaN.  RigidTracker.run must notice, repeat the frame with one launch per
+    step and stay on that form (VERDICT r3 / ADVICE r3: until round 4 the caller silently got undefined poses).  The give-up
+    is simulated: the first replay's loss words are overwritten with NaN."""
+    from d3fields_amd import rigid
+    g, f, info, n = _golden_tracker_inputs(dev)
+    src = torch.cat([info["a"]["src_feats"], info["b"]["src_feats"]]).to(dev)
+    last = torch.from_numpy(np.stack([p for p in g["last_pts"]])).to(dev)
+    ref_tr = rigid.RigidTracker(f, 2, n, loop_launch=False)
+    want, _ = ref_tr.run(f, src, last)
+    tr = rigid.RigidTracker(f, 2, n)
+    assert tr.loop
+    first, _ = tr.run(f, src, last)                              # captures; a healthy frame
+    assert tr.loop and tr.loop_fallbacks == 0 and torch.equal(first, want)
+    real_replay, hits = tr.graph.replay, []
+
+    def poisoned():
+        real_replay()
+        if not hits:
+            hits.append(1)
+            tr.loss3.fill_(float("nan"))
+            tr.t_params.fill_(123.0)                             # ... and the poses are garbage
+    tr.graph.replay = poisoned
+    got, loss = tr.run(f, src, last)
+    assert hits and not tr.loop and tr.loop_fallbacks == 1
+    assert torch.equal(got, want) and torch.isfinite(loss)
+    again, _ = tr.run(f, src, last)                              # later frames: one launch per step, no more checks
+    assert torch.equal(again, want) and tr.loop_fallbacks == 1
+
+
+def test_rigid_tracking_on_a_busy_device(dev):
+    """The golden tracking frame while a second stream keeps every CU busy with long kernels (large GEMMs queued ahead of and
+    behind the tracker's launch): whether d3f_track_run gets its waves resident in time or the tracker falls back to per-step
+    launches, the keypoints are those of the idle device / the reference's own loop."""
+    g, f, info, n = _golden_tracker_inputs(dev)
+    idle = np.stack(f.rigid_tracking(info, [p for p in g["last_pts"]], None, n)["match_pts_list"])
+    assert np.abs(idle - g["match_pts"]).max() <= 1e-5
+    side = torch.cuda.Stream(device=dev)
+    a = torch.randn(8192, 8192, device=dev, dtype=torch.bfloat16)
+    b = torch.randn(8192, 8192, device=dev, dtype=torch.bfloat16)
+    torch.cuda.synchronize()
+    for frame in range(3):
+        with torch.cuda.stream(side):
+            for _ in range(40):                                  # ~40 x 0.5 ms of all-CU work in flight around the tracker
+                c = a @ b
+        busy = np.stack(f.rigid_tracking(info, [p for p in g["last_pts"]], None, n)["match_pts_list"])
+        assert np.abs(busy - g["match_pts"]).max() <= 1e-5, frame
+        assert np.array_equal(busy, idle) or not f._tracker.loop   # same kernel, same results -- unless it had to fall back
+    side.synchronize()
+    del c
+
+
 def test_track_run_refuses_what_cannot_be_resident(dev):
     import ctypes
     from d3fields_amd import _lib, rigid, Fusion, synth
     lib = _lib.load()
-    assert lib.d3f_track_run_max_keypoints() == 512
+    cap = lib.d3f_track_run_max_keypoints()              # occupancy of the kernel x CUs of THIS device / 2, at most 512
+    assert 64 <= cap <= 512 and (torch.cuda.get_device_properties(dev).multi_processor_count < 256 or cap == 512)
     V, H, W, C = 4, 96, 128, 64
     sc = synth.make_scene(V, H, W, "smooth")
     f = Fusion(num_cam=V, device=str(dev))

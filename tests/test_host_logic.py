@@ -115,7 +115,14 @@ def test_bench_roofline_numerator_matches_survey():
     b, per = bench.algorithmic_bytes(bench.WORKLOADS["c3_patch"], 1925000)
     assert per == 1585 and b == 1925000 * 1585 + 4 * (4 * 480 * 640 + 4 * 48 * 64 * 384 + 4 * 480 * 640 * 8) + 336
     assert bench.algorithmic_bytes(bench.WORKLOADS["c4_patch"], 1000000)[1] == 4113
-    assert bench.measured_traffic("c2_dense")[0] > 0 and bench.measured_traffic("nope") == (None, None)
+    # the reference's own shape: 1024-d patch maps + 8-instance mask + colours; the distance-only pass
+    b, per = bench.algorithmic_bytes(bench.WORKLOADS["ref_patch"], 1925000)
+    assert per == 17 + 4 * (1024 + 8 + 3) and b == 1925000 * per + 4 * (4 * 480 * 640 + 4 * 48 * 64 * 1024 + 4 * 480 * 640 * 11) + 336
+    assert bench.algorithmic_bytes(bench.WORKLOADS["dist_only"], 123200000) == (123200000 * 17 + 4 * 4 * 480 * 640 + 336, 17)
+    # counter traffic is keyed by workload AND point set AND point count: the lattice kernel's figure is never printed for a cloud
+    assert bench.measured_traffic("c2_dense", "grid", 985600)[0] > 0
+    assert bench.measured_traffic("c2_dense", "grid", 1000)[0] is None
+    assert bench.measured_traffic("nope", "grid", 1) == (None, None, None)
 
 
 def test_rigid_helpers_match_restated_pytorch3d():
