@@ -286,6 +286,14 @@ int eval_common(const d3f_views *views, const float *pts, int64_t n, const d3f_c
     P.runs_occ = exp_knob("D3F_EXP_RUNS_OCC");
     P.thin_max_views = (exp_knob("D3F_EXP_THIN") < 0 || (flags & D3F_TUNE_DIRECT_GATHER)) ? 0 : 8;
     P.win_lpp = exp_knob("D3F_EXP_WINDOW_LPP") == 32 ? 32 : 16;     // 16 lanes x 2 vectors per point (C2 patch 0.565 -> 0.54 ms); U > 1: 32
+    P.view_lo = 0; P.view_hi = views->V; P.acc_in = 0;
+#ifdef D3F_EXPERIMENTS
+    // view-range passes of the channel-sliced launch (the view-pair experiment of round 4): D3F_EXP_VIEW_LO / _HI / _ACC
+    if (exp_knob("D3F_EXP_VIEW_HI") > 0) {
+        P.view_lo = exp_knob("D3F_EXP_VIEW_LO"); P.view_hi = exp_knob("D3F_EXP_VIEW_HI"); P.acc_in = exp_knob("D3F_EXP_VIEW_ACC") > 0 ? 1 : 0;
+        if (P.view_lo < 0 || P.view_hi > views->V || P.view_lo >= P.view_hi) return fail(D3F_ERR_INVALID_ARG, "D3F_EXP_VIEW_LO/HI out of range");
+    }
+#endif
     P.win_slices = 0; P.win_u = 1; P.win_vc = 1; P.win_pool_offset = 0; P.win_pool_texels = 0; P.win_occ = 4;
     P.win_pipe = exp_knob("D3F_EXP_WINDOW_PIPE") < 0 ? 0 : 1;
     P.store_policy = exp_knob("D3F_EXP_STORE") < 0 ? 0 : 1;
@@ -538,7 +546,14 @@ int eval_common(const d3f_views *views, const float *pts, int64_t n, const d3f_c
     // the 256 MiB Infinity Cache), each taking a contiguous eighth of it (C2 dense 1.97 -> 1.74 ms, C4 patch 4.75 -> 4.17)
     P.xcd_chunk = (reorder && xcd_remap) ? (int)((32768 / P.tile_pts + 7) / 8 * 8) : 0;
     if ((flags >> 29) & 0x7) P.xcd_chunk = 1024 << (((flags >> 29) & 0x7) - 1);   // tuning: 1024 .. 65536 tiles
-    P.crec_offset = d3f::fused_lds_base(P.tile_pts, views->V);
+    if (n_maps == 0) {
+        // distance-only pass (return_names=[], eval_dist): one lane per point and nothing per point in LDS.  Rounds 1-3 ran it on
+        // the 128-point tiles of the gathers -- half of every 256-lane workgroup idle (SQ_WAVES = 3.85 M for 123.2 M points):
+        // four points per lane and workgroup instead, KRt computed once per 1024 points
+        P.tile_pts = n >= (1LL << 22) ? 1024 : 256;
+        P.lds_pad = 0;
+    }
+    P.crec_offset = d3f::fused_lds_base(n_maps == 0 ? 0 : P.tile_pts, views->V);
     // wide maps (>= 16 lanes per point): corner set-up once per (point, view) in phase A, 32 B of LDS each; the
     // cell-run maps come first -- they read their corners from these records
     P.n_pre = 0;

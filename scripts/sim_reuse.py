@@ -163,3 +163,48 @@ for name, order in orders:
     assert len(np.unique(order)) == N
     r = hit_rates(order, WINDOWS)
     print("%-58s" % name + "".join("%8.1f" % (100 * x) for x in r))
+
+
+# ---- round 4: TWO passes over view PAIRS -- (0,1) then (2,3), the sequential sum order -- each pass
+# walking the points in slabs around the pair's epipolar planes: a plane through both camera centres is seen as a line by
+# BOTH cameras, so a thin slab of points touches two thin strips of texels instead of four unrelated 2-D patches.  Only the
+# pair's own corner requests count in a pass.  The go / no-go bar set by the review: >= 85 % ideal hits at W = 4096.
+def epipolar_slabs_pair(a, b, thick, inner="ray"):
+    c = [-(Rt[v][:, :3].T @ Rt[v][:, 3]) for v in range(V)]
+    base = (c[b] - c[a]) / np.linalg.norm(c[b] - c[a])
+    rel = pts - c[a]
+    perp = rel - np.outer(rel @ base, base)
+    e1 = np.cross(base, [0.0, 0.0, 1.0])
+    e1 /= np.linalg.norm(e1)
+    e2 = np.cross(base, e1)
+    ang = np.arctan2(perp @ e1, perp @ e2)
+    dist_axis = np.linalg.norm(perp, axis=1)
+    slab = np.floor((ang - ang.min()) / (0.005 * thick / np.median(dist_axis))).astype(np.int64)   # ~ `thick` grid steps at the median distance
+    if inner == "ray":          # inside a slab: along the baseline, then away from it
+        return np.lexsort((dist_axis, np.floor((rel @ base) / 0.02), slab))
+    return np.lexsort((rel @ base, np.floor(dist_axis / 0.02), slab))
+
+
+def hit_rates_views(order, windows, views):
+    cols = np.concatenate([np.arange(v * 4, v * 4 + 4) for v in views])
+    seq = ids[order][:, cols]
+    out = []
+    for wnd in windows:
+        nch = N // wnd
+        blk = np.sort(seq[:nch * wnd].reshape(nch, wnd * len(cols)), axis=1)
+        valid = blk >= 0
+        uniq = ((blk[:, 1:] != blk[:, :-1]) & valid[:, 1:]).sum() + valid[:, 0].sum()
+        out.append(1.0 - uniq / max(valid.sum(), 1))
+    return out
+
+
+print("\ntwo passes over view pairs: ideal hit rate [%] of the PAIR's corner requests in a window of W consecutive points\n")
+print("%-58s" % "pass / order" + "".join("%8d" % w for w in WINDOWS))
+walk = lattice_walk()
+for pair in ((0, 1), (2, 3), (0, 2), (1, 3)):
+    print("%-58s" % ("views %s: blocked lattice walk (today's order)" % (pair,)) + "".join("%8.1f" % (100 * x) for x in hit_rates_views(walk, WINDOWS, pair)))
+    for thick in (1, 2, 4, 8):
+        for inner in ("ray", "ring"):
+            o = epipolar_slabs_pair(pair[0], pair[1], thick, inner)
+            print("%-58s" % ("views %s: epipolar slabs, %d steps thick, %s-major inside" % (pair, thick, inner)) +
+                  "".join("%8.1f" % (100 * x) for x in hit_rates_views(o, WINDOWS, pair)))

@@ -28,7 +28,7 @@ for p in find("trace*kernel_trace.csv"):
             d[r["Kernel_Name"]].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
     for k, v in sorted(d.items(), key=lambda kv: -sum(kv[1]))[:8]:
         v2 = sorted(v)
-        print("%-70s n=%4d avg=%10.0f med=%10.0f min=%10.0f" % (k[:70], len(v), sum(v) / len(v), v2[len(v2) // 2], v2[0]))
+        print("%-90s n=%4d avg=%10.0f med=%10.0f min=%10.0f" % (k[:90], len(v), sum(v) / len(v), v2[len(v2) // 2], v2[0]))
 
 print("\n== PMC passes (per dispatch averages of the dominant kernel) ==")
 for p in find("pmc*counter_collection.csv"):
@@ -40,4 +40,4 @@ for p in find("pmc*counter_collection.csv"):
         if "fused_eval" not in k and "pairwise" not in k:
             continue
         for c, v in cs.items():
-            print("%-40s %-20s n=%4d avg=%16.1f" % (k[:40], c, len(v), sum(v) / len(v)))
+            print("%-56s %-20s n=%4d avg=%16.1f" % (k[:56], c, len(v), sum(v) / len(v)))
