@@ -286,14 +286,6 @@ int eval_common(const d3f_views *views, const float *pts, int64_t n, const d3f_c
     P.runs_occ = exp_knob("D3F_EXP_RUNS_OCC");
     P.thin_max_views = (exp_knob("D3F_EXP_THIN") < 0 || (flags & D3F_TUNE_DIRECT_GATHER)) ? 0 : 8;
     P.win_lpp = exp_knob("D3F_EXP_WINDOW_LPP") == 32 ? 32 : 16;     // 16 lanes x 2 vectors per point (C2 patch 0.565 -> 0.54 ms); U > 1: 32
-    P.view_lo = 0; P.view_hi = views->V; P.acc_in = 0;
-#ifdef D3F_EXPERIMENTS
-    // view-range passes of the channel-sliced launch (the view-pair experiment of round 4): D3F_EXP_VIEW_LO / _HI / _ACC
-    if (exp_knob("D3F_EXP_VIEW_HI") > 0) {
-        P.view_lo = exp_knob("D3F_EXP_VIEW_LO"); P.view_hi = exp_knob("D3F_EXP_VIEW_HI"); P.acc_in = exp_knob("D3F_EXP_VIEW_ACC") > 0 ? 1 : 0;
-        if (P.view_lo < 0 || P.view_hi > views->V || P.view_lo >= P.view_hi) return fail(D3F_ERR_INVALID_ARG, "D3F_EXP_VIEW_LO/HI out of range");
-    }
-#endif
     P.win_slices = 0; P.win_u = 1; P.win_vc = 1; P.win_pool_offset = 0; P.win_pool_texels = 0; P.win_occ = 4;
     P.win_pipe = exp_knob("D3F_EXP_WINDOW_PIPE") < 0 ? 0 : 1;
     P.store_policy = exp_knob("D3F_EXP_STORE") < 0 ? 0 : 1;
@@ -509,6 +501,9 @@ int eval_common(const d3f_views *views, const float *pts, int64_t n, const d3f_c
         ok = ok && P.maps[0].C % (4 * lanes) == 0 && P.maps[0].C >= 128;
         for (int s = 1; s < n_maps && ok; ++s) ok = P.maps[s].C * P.maps[s].esize <= 256 && !want_inter[s] && P.maps[s].esize == 4;
         if (ok) {
+            const int keep_tile = P.tile_pts, keep_pad = P.lds_pad, keep_t[3] = {P.walk_tx, P.walk_ty, P.walk_tz};
+            d3f::MapDesc keep_maps[D3F_MAX_MAPS];
+            for (int s = 0; s < n_maps; ++s) keep_maps[s] = P.maps[s];
             const int tile_knob = exp_knob("D3F_EXP_SLICED_TILE");
             const bool big = tile_knob == 64;                            // experiment: 64 points per workgroup (four 2x2x4 tiles)
             const bool tiny = tile_knob == 16 || (tile_knob == 0 && n_maps == 1);   // 16 points per workgroup (four 2x2x1 tiles)
@@ -529,6 +524,13 @@ int eval_common(const d3f_views *views, const float *pts, int64_t n, const d3f_c
             P.sl_ilv = exp_knob("D3F_EXP_SLICED_ILV") >= 2 && exp_knob("D3F_EXP_SLICED_ILV") <= 4 ? exp_knob("D3F_EXP_SLICED_ILV") : 1;
             for (int s = 1; s < n_maps; ++s) pick_mapping(P.maps[s], P.maps[s].vw == 4, P.maps[s].vw >= 2, true, 1);
             if ((((P.sl_chunks * P.sl_slices + 7) / 8) + P.sl_ilv) * 8 * P.sl_unit > 0x7fffffffLL) P.sl_slices = 0;
+            // its dynamic LDS (records + one corner record per (point, view)) must fit the 64 KiB a launch gets without opting in:
+            // 32-point tiles with ~36 and more views do not -- such a query keeps the whole-texel kernel
+            if ((int64_t)d3f::fused_lds_base(P.tile_pts, views->V) + (int64_t)P.tile_pts * views->V * 32 + P.lds_pad > 64 * 1024) P.sl_slices = 0;
+            if (P.sl_slices == 0) {             // not this launch after all: the geometry of the whole-texel kernel again
+                P.tile_pts = keep_tile; P.lds_pad = keep_pad; P.walk_tx = keep_t[0]; P.walk_ty = keep_t[1]; P.walk_tz = keep_t[2];
+                for (int s = 0; s < n_maps; ++s) P.maps[s] = keep_maps[s];
+            }
         }
     }
     if (window) {

@@ -53,7 +53,6 @@ struct EvalParams {
     int32_t sl_ilv;                    // units an XCD works on at the same time (1: one after the other)
     int32_t sl_slices, sl_lg, sl_vc;   // slices per texel of map 0, log2(lanes per point), views with loads in flight
     int64_t sl_tiles, sl_groups, sl_chunks;   // walk tiles, groups of 4 tiles, chunks of 128 groups
-    int32_t view_lo, view_hi, acc_in;  // channel-sliced launch: the views this pass sums (default 0, V) and whether it continues a stored sum
     // LDS texel windows (fused_eval_window_kernel): win_slices > 0 selects it
     int32_t win_slices;        // channel slices of 128 * win_u channels per texel of map 0 (looped inside the workgroup)
     int32_t win_u, win_vc;     // 16-byte vectors per lane (1..4), views with corner reads in flight

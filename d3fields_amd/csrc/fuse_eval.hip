@@ -431,7 +431,7 @@ __device__ __forceinline__ void fused_eval_sliced_body(const EvalParams &P)
                 const bool all_invalid = (cnt == 0.0f);
                 float dist_out = dsum / (cnt + 1e-6f);
                 if (all_invalid) dist_out = 1e3f;
-                if (slice == 0 && P.view_lo == 0) {                                  // one slice (of the first pass) writes the per-point outputs
+                if (slice == 0) {                                                    // one slice writes the per-point outputs
                     P.out_dist[i] = dist_out;
                     P.out_valid[i] = all_invalid ? 0 : 1;
                 }
@@ -456,17 +456,13 @@ __device__ __forceinline__ void fused_eval_sliced_body(const EvalParams &P)
             const float denom = cnt + 1e-6f;
             const bool strict = flag_s[p] != 0u;
             VT acc = (VT)0.0f;
-            // view-range passes (round 4 experiment): this launch sums the views [view_lo, view_hi) only; a later
-            // pass starts from the sum an earlier one stored (the same fma chain, cut in two: bit-identical)
-            if (P.acc_in) acc = load_vec<VT>(m.out + i * m.C + (co >> 2));
             if (!strict) {
                 // fast path, branch-free: phase A left an all-zero corner record for an invalid (point, view), so its
                 // loads hit texel 0 of the view and its term is +-0 -- adding it changes no bit.  The corner
                 // loads of VC views are in flight together, then the views are consumed in view order with the folded
                 // weights: four fma per view straight into the sum.
-                int v0 = P.view_lo;
-                const int vend = P.view_hi;
-                for (; v0 + VC <= vend; v0 += VC) {
+                int v0 = 0;
+                for (; v0 + VC <= V; v0 += VC) {
                     VT a[VC], b[VC], d[VC], e[VC];
                     f32x4 w[VC];
 #pragma unroll
@@ -487,7 +483,7 @@ __device__ __forceinline__ void fused_eval_sliced_body(const EvalParams &P)
                         acc = v_fma<VT>(e[q], w[q].w, acc);
                     }
                 }
-                for (; v0 < vend; ++v0) {
+                for (; v0 < V; ++v0) {
                     const CornerRec cr = crec_s[p * V + v0];
                     const char *bv = data + (int64_t)v0 * m.sv * 4;
                     const VT a = load_texel<4, false>(bv + (cr.o[0] + co)), b = load_texel<4, false>(bv + (cr.o[1] + co));
@@ -498,7 +494,7 @@ __device__ __forceinline__ void fused_eval_sliced_body(const EvalParams &P)
                     acc = v_fma<VT>(e, cr.w[3], acc);
                 }
             } else {
-                for (int v = P.view_lo; v < P.view_hi; ++v) {
+                for (int v = 0; v < V; ++v) {
                     const ViewRec r = rec[p * V + v];
                     const char *bv = data + (int64_t)v * m.sv * 4;
                     const Corner c = corner_setup(m, r.gx, r.gy);
@@ -513,15 +509,15 @@ __device__ __forceinline__ void fused_eval_sliced_body(const EvalParams &P)
                 }
             }
             VT o = acc;                         // fast path: the weights carry 1/(cnt + 1e-6); no valid view: every weight is 0
-            if (strict && P.view_hi == V) {     // (the last pass divides)
+            if (strict) {
                 o = (VT)0.0f;                   // fusion.py:386
                 if (cnt != 0.0f) o = strict_div<VT>(acc, denom);
             }
-            store_out<VT>(m.out + i * m.C + (co >> 2), o, P.view_hi == V ? P.store_policy : 0);
+            store_out<VT>(m.out + i * m.C + (co >> 2), o, P.store_policy);
         }
     }
-    // the other (thin) maps of the launch ride along with slice 0 (of the last view-range pass)
-    if (slice == 0 && P.view_hi == V)
+    // the other (thin) maps of the launch ride along with slice 0
+    if (slice == 0)
         for (int s = 1; s < P.n_maps; ++s) {
             const MapDesc &m = P.maps[s];
             switch (m.vw) {

@@ -363,3 +363,7 @@ def test_plan_table():
     assert _plan(4, 480, 640, 200000, [(480, 640, 192)], F).reserved == 0
     assert _plan(4, 480, 640, 200000, [(480, 640, 384), (480, 640, 128)], F).reserved == 0
     assert _plan(4, 480, 640, 200000, [(480, 640, 384), (480, 640, 8)], F).reserved == 152      # a thin map rides along
+    # ... and only while its records fit the 64 KiB of dynamic LDS a launch gets without opting in (32-point tiles x 36+ views do not)
+    assert _plan(8, 480, 640, 200000, [(480, 640, 384), (480, 640, 8)], F).reserved == 152
+    p = _plan(40, 480, 640, 200000, [(480, 640, 384), (480, 640, 8)], F)
+    assert (p.reserved, p.tile_points) == (0, 16) and p.lds_bytes <= 64 * 1024
