@@ -157,13 +157,18 @@ __device__ __forceinline__ bool maps_are_finite(const EvalParams &P)
 // LPP*VW*4 contiguous bytes of a texel.
 //   HALF  the map is stored in fp16 (D3F_DTYPE_F16): VW = 8 channels per 16-B load (or scalar lanes), widened to
 //         fp32 on load; everything after the load is the fp32 path
-// Output rows are written once and never read again by the launch: they leave as `sc1` stores, which drop the line from
-// the XCD's L2 after the write instead of occupying capacity the texels could use (MI355X_MICROARCH.md, stores of each
-// flavour; measured r2f: C2 dense 1.631 -> 1.620 ms, C3 dense 3.103 -> 3.059, C2 patch 0.645 -> 0.634).
-// D3F_EXP_STORE=-1 restores plain stores.
+// Output rows are written once and never read again by the launch: they leave as NON-TEMPORAL stores (policy 2), which stream
+// to memory without allocating in the L2s and the Infinity Cache, i.e. without pushing out the texels the gather lives on
+// (round 4: C2 dense 1.53 -> 1.47 ms, C3 dense 2.83 -> 2.66, C4 dense 8.97 -> 8.94; the window kernel, which stores with the same
+// policy, gained 8-23 %).  Round 2's `sc1` stores (policy 1: write-through, the line dropped from the XCD's L2 after the
+// write) had bought 1 % over plain ones (policy 0); experiments builds: D3F_EXP_STORE=1 / -1.
 template <typename VT>
 __device__ __forceinline__ void store_out(float *p, VT v, int policy)
 {
+    if (policy == 2) {                              // non-temporal: streams to memory past the L2's and the Infinity Cache's allocation
+        __builtin_nontemporal_store(v, reinterpret_cast<VT *>(p));
+        return;
+    }
     if constexpr (sizeof(VT) == 16) {
         if (policy == 1) {
             // s_nop 1: a VMEM store of more than 64 bits reads its data registers for two more cycles on gfx940+; the
@@ -184,6 +189,10 @@ __device__ __forceinline__ void store_out_off(float *base, uint32_t off, f32x4 v
 {
     if (policy == 1) {
         asm volatile("global_store_dwordx4 %0, %1, %2 sc1\n\ts_nop 1" ::"v"(off), "v"(v), "s"(base) : "memory");
+        return;
+    }
+    if (policy == 2) {
+        __builtin_nontemporal_store(v, reinterpret_cast<f32x4 *>(reinterpret_cast<char *>(base) + off));
         return;
     }
     *reinterpret_cast<f32x4 *>(reinterpret_cast<char *>(base) + off) = v;
@@ -307,7 +316,7 @@ __device__ __forceinline__ void gather_map(const MapDesc &m, const EvalParams &P
                         s = v_fma<VT>(ev, c.wse, s);
                         const int cv = c0 + u * lpp + g;
                         if (m.inter && cv < cvec)          // '<k>_inter' [V,n,C]  fusion.py:389
-                            store_vec<VT>(m.inter + ((int64_t)v * P.n + i) * m.C + cv * VW, s);
+                            store_out<VT>(m.inter + ((int64_t)v * P.n + i) * m.C + cv * VW, s, P.store_policy == 1 ? 0 : P.store_policy);
                         acc[u] = acc[u] + (s * r.valid) * r.wgt;        // fusion.py:385
                     }
                 }
@@ -415,7 +424,7 @@ __device__ __forceinline__ void gather_map_thin(const MapDesc &m, const EvalPara
                     s = v_fma<VT>(dv, c.wsw, s);
                     s = v_fma<VT>(ev, c.wse, s);
                     if (m.inter && g < cvec)
-                        store_vec<VT>(m.inter + ((int64_t)v * P.n + i) * m.C + g * VW, s);
+                        store_out<VT>(m.inter + ((int64_t)v * P.n + i) * m.C + g * VW, s, P.store_policy == 1 ? 0 : P.store_policy);
                     t = (s * r.valid) * r.wgt;
                 }
             }

@@ -646,6 +646,13 @@ __device__ __forceinline__ void window_point(f32x4 (&acc)[NV], const unsigned ch
 // arithmetic.  Same operands in the same order as window_point: bit-identical.
 //   rec0      LDS byte offset of the first point's first record;  KSTRIDE bytes between the lane group's consecutive points
 //   done(k, acc)  called once per point, after its last view
+// what-if builds of tuning sessions (scripts/build_ablate.py: -DD3F_WIN_ABLATE=bits; parts of the window kernel left out, results
+// wrong by construction, only times are read): 1 no copies after slice 0, 2 no point loop, 4 rows stored over each other in
+// 8 MiB (no HBM writes), 8 corner reads without the arithmetic, 16 the arithmetic without the corner reads
+#ifndef D3F_WIN_ABLATE
+#define D3F_WIN_ABLATE 0
+#endif
+
 template <int NV>
 struct WinPipe {            // registers of the pipeline; every index below is a compile-time constant
     uint2 off[3];
@@ -668,6 +675,14 @@ __device__ __forceinline__ void win_pipe_corners(WinPipe<NV> &st, const unsigned
     using VT = f32x4;
     const unsigned char *nw = smem + (st.off[J % 3].x + lane_off);
     const unsigned char *sw = smem + (st.off[J % 3].y + lane_off);
+#if D3F_WIN_ABLATE & 16
+#pragma unroll
+    for (int u = 0; u < NV; ++u) {
+        st.c[J % 2][0][u] = st.wt[J % 3]; st.c[J % 2][1][u] = st.wt[(J + 1) % 3]; st.c[J % 2][2][u] = st.wt[(J + 2) % 3]; st.c[J % 2][3][u] = st.wt[J % 3];
+        asm volatile("" : "+v"(st.c[J % 2][0][u]), "+v"(st.c[J % 2][1][u]), "+v"(st.c[J % 2][2][u]), "+v"(st.c[J % 2][3][u]) : "v"(nw), "v"(sw));
+    }
+    return;
+#endif
 #pragma unroll
     for (int u = 0; u < NV; ++u) {
         st.c[J % 2][0][u] = *reinterpret_cast<const VT *>(nw + u * VS);
@@ -684,6 +699,13 @@ __device__ __forceinline__ void win_pipe_step(WinPipe<NV> &st, const unsigned ch
     constexpr int NS = KI * VF;
     if constexpr (J + 2 < NS) win_pipe_record<J + 2, NV, VF, KI, VS, SBB, KSTRIDE>(st, smem, rec0);
     if constexpr (J + 1 < NS) win_pipe_corners<J + 1, NV, VS, SBB>(st, smem, lane_off);
+#if D3F_WIN_ABLATE & 8
+#pragma unroll
+    for (int u = 0; u < NV; ++u) {
+        asm volatile("" :: "v"(st.c[J % 2][0][u]), "v"(st.c[J % 2][1][u]), "v"(st.c[J % 2][2][u]), "v"(st.c[J % 2][3][u]));
+        st.acc[u] = st.wt[J % 3];
+    }
+#else
 #pragma unroll
     for (int u = 0; u < NV; ++u) {
         st.acc[u] = v_fma<VT>(st.c[J % 2][0][u], st.wt[J % 3].x, st.acc[u]);        // folded weights (fuse_common.h): nw, ne, sw, se
@@ -691,6 +713,7 @@ __device__ __forceinline__ void win_pipe_step(WinPipe<NV> &st, const unsigned ch
         st.acc[u] = v_fma<VT>(st.c[J % 2][2][u], st.wt[J % 3].z, st.acc[u]);
         st.acc[u] = v_fma<VT>(st.c[J % 2][3][u], st.wt[J % 3].w, st.acc[u]);
     }
+#endif
     if constexpr (J % VF == VF - 1) {
         done(J / VF, st.acc);
 #pragma unroll
@@ -1092,14 +1115,18 @@ __device__ __forceinline__ void fused_eval_window_body(const EvalParams &P)
             }
         }
     };
-    // plain stores (acknowledged by the L2; the maps of this kernel sit in the caches anyway: sc1 measured 1 % slower here), one
-    // 64-bit multiply-add per row: no store-flavour branches inside the point loop
+    // NON-TEMPORAL stores, one 64-bit multiply-add per row and no store-flavour branches inside the point loop.  The rows are
+    // written once and never read by the launch; as plain (or sc1) stores they allocate in the L2s and the Infinity Cache on
+    // their way out and push out the texels the next bricks' window copies would have hit (round 4, found with what-if builds:
+    // with the rows stored over each other in 8 MiB the gather ran 26 % faster, with `nt` stores to their real addresses
+    // 19 %): C2-patch 0.48-0.52 -> 0.445 ms, C3-patch 1.07-1.17 -> 0.92, C4-patch 1.83 -> 1.70, the reference's shape 2.79 -> 2.12.
+    // (A flagged point's row is stored twice by the same lane to the same address: program order holds for those.)
     const uint32_t row_bytes = (uint32_t)m.C * 4u;
     char *const out_bytes = reinterpret_cast<char *>(m.out);
     auto store_point = [&](int p, uint32_t co, const VT (&acc)[NV]) {
         char *row = out_bytes + ((uint64_t)idx_s[p] * row_bytes + co);
 #pragma unroll
-        for (int u = 0; u < NV; ++u) *reinterpret_cast<VT *>(row + u * VS) = acc[u];
+        for (int u = 0; u < NV; ++u) __builtin_nontemporal_store(acc[u], reinterpret_cast<VT *>(row + u * VS));
     };
     // The pipelined point loop runs for ALL points of the lane group: the records of a point with a direct pair, and of a
     // strict point, point at the zero slices (harmless reads); such a point (rare: rim rounding, pool overflow, non-finite
@@ -1118,12 +1145,18 @@ __device__ __forceinline__ void fused_eval_window_body(const EvalParams &P)
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");      // the DMA of this slice has landed (and phase A's records)
         D3F_STAMP();                                // 5 + 3 sl: pool of this slice ready
         const uint32_t co = (uint32_t)sl * SB + lane_off;               // byte offset of this lane's first vector in a texel
+#if D3F_WIN_ABLATE & 2
+        if (false)
+#endif
         if (pipe_ok) {
             window_points_pipelined<NV, (VFIX > 0 ? VFIX : 1), KI, VS, (int)SB, G * ((VFIX > 0 ? VFIX : 1) * 32 + 16)>(
                 smem, (uint32_t)grp * pstride, lane_off, [&](int k, const VT (&acc)[NV]) {
                     char *row = out_bytes + ((uint64_t)pidx[k] * row_bytes + co);
+#if D3F_WIN_ABLATE & 4
+                    row = out_bytes + ((uint64_t)(threadIdx.x + 256u * (blockIdx.x & 1023u)) * 32u);
+#endif
 #pragma unroll
-                    for (int u = 0; u < NV; ++u) *reinterpret_cast<VT *>(row + u * VS) = acc[u];
+                    for (int u = 0; u < NV; ++u) __builtin_nontemporal_store(acc[u], reinterpret_cast<VT *>(row + u * VS));
                 });
 #pragma unroll 1
             for (int p = grp; p < TP; p += G)
@@ -1143,7 +1176,9 @@ __device__ __forceinline__ void fused_eval_window_body(const EvalParams &P)
         if (sl + 1 < S) {
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // LDS only: everyone is done with this slice's pool
             D3F_STAMP();                            // 7 + 3 sl: all waves done
+#if !(D3F_WIN_ABLATE & 1)
             stage(sl + 1);
+#endif
         } else {
             D3F_STAMP();
         }

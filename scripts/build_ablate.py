@@ -1,0 +1,12 @@
+"""Builds the what-if variants of the window kernel for a tuning session: build_ab/ablate_<bits>.so with -DD3F_WIN_ABLATE=<bits>
+(fuse_eval.hip: 1 no copies after slice 0, 2 no point loop, 4 rows stored over each other (no HBM writes), 8 corner reads without
+arithmetic, 16 arithmetic without corner reads).  Results of these libraries are wrong by construction; only times are read.
+    D3F_BUILD_EXPERIMENTS=1 python scripts/build_ablate.py 0 1 4 8 16"""
+import os, shutil, sys
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+from d3fields_amd import build
+os.makedirs("build_ab", exist_ok=True)
+for ab in [int(a) for a in sys.argv[1:]]:
+    build.build_library(force=True, extra_flags=["-DD3F_WIN_ABLATE=%d" % ab])
+    shutil.copy(build.LIB_PATH, "build_ab/ablate_%d.so" % ab)
+    print("built", ab, flush=True)
