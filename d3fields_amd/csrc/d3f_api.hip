@@ -369,7 +369,7 @@ int eval_common(const d3f_views *views, const float *pts, int64_t n, const d3f_c
                 // (round 4, pipelined point loop: a point with a pair outside the pool is done a second time by the general path, so
                 // overflow costs more than a workgroup per CU -- C2-patch: 55 slots at 4 per CU 0.525 ms, 80 slots at 3 per CU 0.493,
                 // 40 / 32 slots 0.72 / 0.81: ask for ~17 slots per view)
-                if (texels >= 17 * views->V || occ == 2 || occ_forced) break;
+                if (texels >= (exp_knob("D3F_EXP_WINDOW_WANT") > 0 ? exp_knob("D3F_EXP_WINDOW_WANT") : 17) * views->V || occ == 2 || occ_forced) break;
             }
             if (exp_knob("D3F_EXP_WINDOW_POOL") > 0 && exp_knob("D3F_EXP_WINDOW_POOL") < texels) texels = exp_knob("D3F_EXP_WINDOW_POOL");
             if (texels > 320) texels = 320;                      // kWinMaxTexels (fuse_eval.hip)

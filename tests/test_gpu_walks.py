@@ -608,13 +608,23 @@ def test_async_probes_follow_the_data_and_never_change_results(dev):
     assert len(f._pending) == 0
 
 
-# ---- the inline-asm sc1 output stores: same launch x 50, bitwise equal ------------------------------------------------------
+# ---- the output rows' store flavours: same launch x 50, bitwise equal ----------------------------------------------------------
+@pytest.mark.parametrize("policy", ["nt", "sc1"])
 @pytest.mark.parametrize("workload", ["window", "sliced"])
-def test_sc1_stores_are_deterministic(dev, workload):
-    """The fused rows leave through `global_store_dwordx4 ... sc1` written as inline asm (no builtin emits the sc1 bit), i.e.
-    outside the compiler's hazard tracking: round 2 found a VALU write scheduled right behind such a store tearing dwords of
-    some lanes, nondeterministically, in the two-vectors-per-lane window kernel (fixed with `s_nop 1` inside the asm).  Fifty
-    launches of that kernel and of the channel-sliced one must be bitwise equal to each other and to the direct gather."""
+def test_row_stores_are_deterministic(dev, workload, policy):
+    """The fused rows leave as non-temporal stores (round 4; `__builtin_nontemporal_store`; a flagged point's row is stored twice
+    by the same lane of the window kernel, second store wins).  Round 2's `global_store_dwordx4 ... sc1` form -- inline asm (no
+    builtin emits the sc1 bit), i.e. outside the compiler's hazard tracking: a VALU write scheduled right behind such a store
+    tore dwords of some lanes, nondeterministically, in the two-vectors-per-lane window kernel, fixed with `s_nop 1` inside the
+    asm -- still exists behind D3F_EXP_STORE=1 (experiments builds).  Fifty launches of the window kernel and of the
+    channel-sliced one must be bitwise equal to each other and to the direct gather."""
+    if policy == "sc1" and not experiments():
+        pytest.skip("the sc1 store policy is selectable in experiments builds only (D3F_EXP_STORE=1)")
+    with knobs(D3F_EXP_STORE=1 if policy == "sc1" else 0):
+        _row_stores_are_deterministic(dev, workload)
+
+
+def _row_stores_are_deterministic(dev, workload):
     from d3fields_amd import create_init_grid, synth, _lib
     V, H, W = 4, 480, 640
     fhw = (48, 64) if workload == "window" else (240, 320)
