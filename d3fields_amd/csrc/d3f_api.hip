@@ -145,7 +145,7 @@ int fill_map(const d3f_channel_map &c, int s, int V, float *out, float *inter, c
 //   D3F_EXP_RUNS   cell-run gather on patch-resolution wide maps: -1 off, 0 automatic (default), 2 / 4 / 8 = run length
 //   D3F_EXP_RUNS_U vectors per lane of the cell-run gather: 0 automatic, 1 / 2 / 3;  D3F_EXP_RUNS_OCC=5: the (1,8) variant
 //                  held to 5 waves per SIMD
-//   D3F_EXP_STORE  -1: write the fused rows with plain stores, 1: with sc1 ones, instead of non-temporal ones (store_out, fuse_common.h)
+//   D3F_EXP_STORE  -1: write the fused rows with plain stores, 1: with sc1 ones, 3: with `sc1 nt` ones, instead of `nt` ones (store_out, fuse_common.h)
 //                  also in the window kernel (plain there by default)
 //   D3F_EXP_SLICED 1 / 2 / 3: force the channel-sliced launch for a dense wide map on a lattice (128- / 256- / 512-byte
 //                  slices, fuse_eval.hip); -1: never (default: only with thin companion maps); _VC views in flight, _UNIT
@@ -288,7 +288,7 @@ int eval_common(const d3f_views *views, const float *pts, int64_t n, const d3f_c
     P.win_lpp = exp_knob("D3F_EXP_WINDOW_LPP") == 32 ? 32 : 16;     // 16 lanes x 2 vectors per point (C2 patch 0.565 -> 0.54 ms); U > 1: 32
     P.win_slices = 0; P.win_u = 1; P.win_vc = 1; P.win_pool_offset = 0; P.win_pool_texels = 0; P.win_occ = 4;
     P.win_pipe = exp_knob("D3F_EXP_WINDOW_PIPE") < 0 ? 0 : 1;
-    P.store_policy = exp_knob("D3F_EXP_STORE") < 0 ? 0 : (exp_knob("D3F_EXP_STORE") == 1 ? 1 : 2);     // non-temporal rows (fuse_common.h: store_out)
+    P.store_policy = exp_knob("D3F_EXP_STORE") < 0 ? 0 : (exp_knob("D3F_EXP_STORE") == 1 ? 1 : (exp_knob("D3F_EXP_STORE") == 3 ? 3 : 2));     // non-temporal rows (fuse_common.h: store_out)
     int64_t map_bytes = 0;
     P.out_dist = out_dist; P.out_valid = out_valid;
     P.n = n; P.V = views->V; P.H = views->H; P.W = views->W;

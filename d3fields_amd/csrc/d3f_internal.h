@@ -64,7 +64,7 @@ struct EvalParams {
     int32_t thin_max_views;    // 8 (default): thin maps with 2..8 views are gathered with the views in parallel across lanes
                                // (gather_map_thin); 0 switches that off (D3F_EXP_THIN=-1, tests)
     int32_t runs_occ;      // experiment: waves per SIMD of the (1,8) cell-run kernel variant (4 / 5 / 6)
-    int32_t store_policy;  // 2 (default) = fused rows leave as non-temporal stores, 1 = sc1 (write-through), 0 = plain
+    int32_t store_policy;  // 2 (default) = fused rows leave as non-temporal stores (nt), 3 = sc1 nt (the window kernel's own form), 1 = sc1, 0 = plain
     uint32_t flags;
     float mu;
     // device-side "this tensor holds a non-finite value" words written by d3f_map_check (depth first, then one per map);

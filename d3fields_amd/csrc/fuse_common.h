@@ -157,15 +157,30 @@ __device__ __forceinline__ bool maps_are_finite(const EvalParams &P)
 // LPP*VW*4 contiguous bytes of a texel.
 //   HALF  the map is stored in fp16 (D3F_DTYPE_F16): VW = 8 channels per 16-B load (or scalar lanes), widened to
 //         fp32 on load; everything after the load is the fp32 path
-// Output rows are written once and never read again by the launch: they leave as NON-TEMPORAL stores (policy 2), which stream
+// Output rows are written once and never read again by the launch: they leave as NON-TEMPORAL stores (policy 2: `nt`; the window
+// kernel adds write-through, `sc1 nt` = store_row_vec, which is policy 3 here, experiments builds: it gains 4-9 % there and loses
+// 0-5 % in these kernels, scripts/gpu_sessions/r4_gpu34/35.sh), which stream
 // to memory without allocating in the L2s and the Infinity Cache, i.e. without pushing out the texels the gather lives on
 // (round 4: C2 dense 1.53 -> 1.47 ms, C3 dense 2.83 -> 2.66, C4 dense 8.97 -> 8.94; the window kernel, which stores with the same
 // policy, gained 8-23 %).  Round 2's `sc1` stores (policy 1: write-through, the line dropped from the XCD's L2 after the
 // write) had bought 1 % over plain ones (policy 0); experiments builds: D3F_EXP_STORE=1 / -1.
+// One 16-byte piece of an output row, non-temporal and write-through: `global_store_dwordx4 ... sc1 nt` (no builtin emits the
+// pair; `nt` alone is __builtin_nontemporal_store).  s_nop 1: see store_out.
+#ifndef D3F_ROW_STORE_BITS
+#define D3F_ROW_STORE_BITS "sc1 nt"                 // what-if builds override the bits: -DD3F_ROW_STORE_BITS='"sc0 sc1 nt"'
+#endif
+__device__ __forceinline__ void store_row_vec(void *p, f32x4 v)
+{
+    asm volatile("global_store_dwordx4 %0, %1, off " D3F_ROW_STORE_BITS "\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
+}
+
 template <typename VT>
 __device__ __forceinline__ void store_out(float *p, VT v, int policy)
 {
-    if (policy == 2) {                              // non-temporal: streams to memory past the L2's and the Infinity Cache's allocation
+    if (policy >= 2) {                              // non-temporal: streams to memory past the L2's and the Infinity Cache's allocation
+        if constexpr (sizeof(VT) == 16) {
+            if (policy == 3) { store_row_vec(p, v); return; }       // ... and write-through (experiments; the window kernel's form)
+        }
         __builtin_nontemporal_store(v, reinterpret_cast<VT *>(p));
         return;
     }
@@ -189,6 +204,10 @@ __device__ __forceinline__ void store_out_off(float *base, uint32_t off, f32x4 v
 {
     if (policy == 1) {
         asm volatile("global_store_dwordx4 %0, %1, %2 sc1\n\ts_nop 1" ::"v"(off), "v"(v), "s"(base) : "memory");
+        return;
+    }
+    if (policy == 3) {
+        asm volatile("global_store_dwordx4 %0, %1, %2 " D3F_ROW_STORE_BITS "\n\ts_nop 1" ::"v"(off), "v"(v), "s"(base) : "memory");
         return;
     }
     if (policy == 2) {

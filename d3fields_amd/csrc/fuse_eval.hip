@@ -1115,18 +1115,19 @@ __device__ __forceinline__ void fused_eval_window_body(const EvalParams &P)
             }
         }
     };
-    // NON-TEMPORAL stores, one 64-bit multiply-add per row and no store-flavour branches inside the point loop.  The rows are
-    // written once and never read by the launch; as plain (or sc1) stores they allocate in the L2s and the Infinity Cache on
-    // their way out and push out the texels the next bricks' window copies would have hit (round 4, found with what-if builds:
-    // with the rows stored over each other in 8 MiB the gather ran 26 % faster, with `nt` stores to their real addresses
-    // 19 %): C2-patch 0.48-0.52 -> 0.445 ms, C3-patch 1.07-1.17 -> 0.92, C4-patch 1.83 -> 1.70, the reference's shape 2.79 -> 2.12.
+    // NON-TEMPORAL write-through stores (`sc1 nt`, store_row_vec), one 64-bit multiply-add per row and no store-flavour branches
+    // inside the point loop.  The rows are written once and never read by the launch; as plain (or sc1) stores they allocate in
+    // the L2s and the Infinity Cache on their way out and push out the texels the next bricks' window copies would have hit
+    // (round 4, found with what-if builds: with the rows stored over each other in 8 MiB the gather ran 26 % faster, with `nt`
+    // stores to their real addresses 19 %): C2-patch 0.48-0.52 -> 0.445 ms, C3-patch 1.07-1.17 -> 0.92, C4-patch 1.83 -> 1.70,
+    // the reference's shape 2.79 -> 2.12; `sc1 nt` instead of `nt` alone: C2-patch 0.455 -> 0.415, the reference's shape 2.11 -> 2.02.
     // (A flagged point's row is stored twice by the same lane to the same address: program order holds for those.)
     const uint32_t row_bytes = (uint32_t)m.C * 4u;
     char *const out_bytes = reinterpret_cast<char *>(m.out);
     auto store_point = [&](int p, uint32_t co, const VT (&acc)[NV]) {
         char *row = out_bytes + ((uint64_t)idx_s[p] * row_bytes + co);
 #pragma unroll
-        for (int u = 0; u < NV; ++u) __builtin_nontemporal_store(acc[u], reinterpret_cast<VT *>(row + u * VS));
+        for (int u = 0; u < NV; ++u) store_row_vec(row + u * VS, acc[u]);
     };
     // The pipelined point loop runs for ALL points of the lane group: the records of a point with a direct pair, and of a
     // strict point, point at the zero slices (harmless reads); such a point (rare: rim rounding, pool overflow, non-finite
@@ -1156,7 +1157,7 @@ __device__ __forceinline__ void fused_eval_window_body(const EvalParams &P)
                     row = out_bytes + ((uint64_t)(threadIdx.x + 256u * (blockIdx.x & 1023u)) * 32u);
 #endif
 #pragma unroll
-                    for (int u = 0; u < NV; ++u) __builtin_nontemporal_store(acc[u], reinterpret_cast<VT *>(row + u * VS));
+                    for (int u = 0; u < NV; ++u) store_row_vec(row + u * VS, acc[u]);
                 });
 #pragma unroll 1
             for (int p = grp; p < TP; p += G)
