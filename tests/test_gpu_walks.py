@@ -612,12 +612,13 @@ def test_async_probes_follow_the_data_and_never_change_results(dev):
 @pytest.mark.parametrize("policy", ["nt", "sc1"])
 @pytest.mark.parametrize("workload", ["window", "sliced"])
 def test_row_stores_are_deterministic(dev, workload, policy):
-    """The fused rows leave as non-temporal stores (round 4; `__builtin_nontemporal_store`; a flagged point's row is stored twice
-    by the same lane of the window kernel, second store wins).  Round 2's `global_store_dwordx4 ... sc1` form -- inline asm (no
-    builtin emits the sc1 bit), i.e. outside the compiler's hazard tracking: a VALU write scheduled right behind such a store
-    tore dwords of some lanes, nondeterministically, in the two-vectors-per-lane window kernel, fixed with `s_nop 1` inside the
-    asm -- still exists behind D3F_EXP_STORE=1 (experiments builds).  Fifty launches of the window kernel and of the
-    channel-sliced one must be bitwise equal to each other and to the direct gather."""
+    """The fused rows leave as non-temporal stores (round 4): `__builtin_nontemporal_store` in the sliced / generic kernels,
+    `global_store_dwordx4 ... sc1 nt` as inline asm in the window kernel (a flagged point's row is stored twice by the same lane
+    there, second store wins).  Inline-asm stores are outside the compiler's hazard tracking: round 2 found a VALU write
+    scheduled right behind its `... sc1` store tearing dwords of some lanes, nondeterministically, in the two-vectors-per-lane
+    window kernel (fixed with `s_nop 1` inside the asm; that form still exists behind D3F_EXP_STORE=1, experiments builds).
+    Fifty launches of the window kernel and of the channel-sliced one must be bitwise equal to each other and to the direct
+    gather."""
     if policy == "sc1" and not experiments():
         pytest.skip("the sc1 store policy is selectable in experiments builds only (D3F_EXP_STORE=1)")
     with knobs(D3F_EXP_STORE=1 if policy == "sc1" else 0):
