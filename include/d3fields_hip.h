@@ -139,6 +139,8 @@ int d3f_build_has_experiments(void);
  *   out_fused  host array of n_maps device pointers, [n,C_k] each
  *   out_inter  NULL, or host array of n_maps device pointers (entries may be NULL),
  *              [V,n,C_k] each: the reference's '<k>_inter' (return_inter=True, fusion.py:389)
+ * The [n,C_k] rows are written once with non-temporal stores (they do not stay in the GPU's caches); like any kernel output
+ * they are visible to whatever follows the call in `stream` order.
  */
 int d3f_eval(const d3f_views *views, const float *pts, int64_t n, const d3f_channel_map *maps,
              int32_t n_maps, float mu, uint32_t flags, float *out_dist, uint8_t *out_valid,
