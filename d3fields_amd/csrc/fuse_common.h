@@ -421,7 +421,12 @@ __device__ __forceinline__ void gather_map_thin(const MapDesc &m, const EvalPara
         if (v < V) {
             const ViewRec r = rec[p * V + v];
             if (strict || r.valid != 0.0f) {
+#ifdef D3F_THIN_WHATIF                              // what-if build: every lane reads its view's first texel (one cache line per instruction)
+                Corner c = corner_setup(m, r.gx, r.gy);
+                c.onw &= 0u; c.one &= 0u; c.osw &= 0u; c.ose &= 0u;
+#else
                 const Corner c = corner_setup(m, r.gx, r.gy);
+#endif
                 const char *bv = reinterpret_cast<const char *>(m.data) + (int64_t)v * m.sv * 4;
                 const VT a = load_texel<VW, false>(bv + (c.onw + co));
                 const VT b = load_texel<VW, false>(bv + (c.one + co));
