@@ -1,0 +1,130 @@
+"""Seeded sweep over shapes the named tests do not visit: view counts 1..8, odd channel counts, wide maps at patch / half / full
+resolution, thin maps riding along or alone, lattices and clouds above the small-batch threshold (so that the window, cell-run
+and channel-sliced launches are what runs), non-finite query points.  Every case is compared with the CPU oracle
+(oracle/c_oracle.py, pinned to the reference's goldens): 'dist' / 'valid_mask' and every thin map bit for bit, wide maps within
+the contract's 1e-5 (folded weights) and bit for bit with Fusion.reference_rounding."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    return torch.device("cuda:0")
+
+
+def cpu(x):
+    return x.detach().cpu().numpy()
+
+
+def _case(seed):
+    r = np.random.default_rng(1000 + seed)
+    V = int(r.integers(1, 9))
+    H, W = [(96, 128), (120, 160), (240, 320)][int(r.integers(0, 3))]
+    wide = bool(r.integers(0, 4))                                     # one in four: only thin maps
+    C = int(r.choice([128, 256, 384, 512, 1024] if r.integers(0, 3) else [3, 20, 96, 100, 130, 200])) if wide else 0
+    res = int(r.integers(0, 3))                                       # patch / half / full resolution
+    fhw = [(max(H // 10, 2), max(W // 10, 2)), (H // 2, W // 2), (H, W)][res]
+    NI = int(r.choice([0, 2, 8]))
+    color = bool(r.integers(0, 2))
+    if not wide and NI == 0 and not color:
+        NI = 8
+    lattice = bool(r.integers(0, 3))                                  # two in three
+    kind = "smooth" if r.integers(0, 4) else "stress"
+    return dict(V=V, H=H, W=W, C=C, fhw=fhw, NI=NI, color=color, lattice=lattice, kind=kind, seed=seed)
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_seeded_shape_against_oracle(dev, seed):
+    _run(dev, _case(seed), seed)
+
+
+# shapes the draw above rarely lands on: the pipelined window kernel with eight views, wide patch maps with both thin maps,
+# two views on the window kernel's plain loop, a cloud on the cell runs of a 1024-d map
+DIRECTED = [
+    dict(V=8, H=240, W=320, C=1024, fhw=(24, 32), NI=8, color=True, lattice=True, kind="smooth"),
+    dict(V=8, H=240, W=320, C=256, fhw=(24, 32), NI=0, color=False, lattice=True, kind="stress"),
+    dict(V=4, H=240, W=320, C=1024, fhw=(24, 32), NI=2, color=True, lattice=True, kind="stress"),
+    dict(V=2, H=120, W=160, C=128, fhw=(12, 16), NI=8, color=False, lattice=True, kind="smooth"),
+    dict(V=4, H=240, W=320, C=1024, fhw=(24, 32), NI=8, color=True, lattice=False, kind="smooth"),
+    dict(V=1, H=240, W=320, C=384, fhw=(24, 32), NI=0, color=True, lattice=True, kind="smooth"),
+]
+
+
+@pytest.mark.parametrize("k", range(len(DIRECTED)))
+def test_directed_shape_against_oracle(dev, k):
+    _run(dev, dict(DIRECTED[k], seed=100 + k), 100 + k)
+
+
+def _run(dev, c, seed):
+    from d3fields_amd import Fusion, create_init_grid, synth
+    from oracle import c_oracle as O
+    V, H, W = c["V"], c["H"], c["W"]
+    sc = synth.make_scene(V, H, W, c["kind"])
+    maps, names = {}, []
+    if c["C"]:
+        maps["dino_feats"] = synth.random_map(V, c["fhw"][0], c["fhw"][1], c["C"], seed=seed + 1, device=dev)
+        names.append("dino_feats")
+    if c["NI"]:
+        maps["mask"] = synth.random_onehot_mask(V, H, W, c["NI"], seed=seed + 2, device=dev)
+        names.append("mask")
+    if c["color"]:
+        maps["color_tensor"] = torch.rand(V, H, W, 3, generator=torch.Generator(device=dev).manual_seed(seed + 3), device=dev)
+        names.append("color_tensor")
+    f = Fusion(num_cam=V, device=str(dev))
+    f.curr_obs_torch = {k: sc[k].to(dev) for k in ("depth", "K", "pose")}
+    f.curr_obs_torch.update(maps)
+    f.H, f.W = H, W
+    f.record_plans = True
+    r = np.random.default_rng(2000 + seed)
+    if c["lattice"]:
+        dims = [(48, 44, 32), (130, 9, 60), (64, 64, 17), (20, 120, 28)][int(r.integers(0, 4))]       # >= 65536 points
+        step = float(r.choice([0.004, 0.0107, 0.02]))
+        box = dict(x_lower=-dims[0] * step / 2, x_upper=dims[0] * step / 2 - step / 4, y_lower=-dims[1] * step / 2,
+                   y_upper=dims[1] * step / 2 - step / 4, z_lower=-0.2, z_upper=-0.2 + dims[2] * step - step / 4)
+        pts_c = create_init_grid(box, step)[0]
+        assert pts_c.shape[0] == dims[0] * dims[1] * dims[2]
+    else:
+        pts_c = synth.random_cloud(70001, seed=seed)
+    bad = r.integers(0, pts_c.shape[0], 6)
+    pts_c[bad[0], 0] = float("inf"); pts_c[bad[1], 1] = float("-inf"); pts_c[bad[2], 2] = float("nan")
+    pts_c[bad[3]] = torch.tensor([1e30, -1e30, 1e30]); pts_c[bad[4]] = 0.0; pts_c[bad[5], 2] = 1e-30
+    pts = pts_c.to(dev)
+    with torch.no_grad():
+        out = f.batch_eval(pts, return_names=names)
+        plan = dict(f.last_plan())
+        f.reference_rounding = True
+        strict = f.batch_eval(pts, return_names=names)
+        f.reference_rounding = False
+        sub = torch.from_numpy(r.permutation(pts_c.shape[0])[:4000]).to(dev)
+        sub[:6] = torch.from_numpy(bad).to(dev)
+        inter = f.eval(pts[sub], return_names=names, return_inter=True)
+    ref = O.eval_field(sc["depth"], sc["K"], sc["pose"], pts_c, [maps[k].float().cpu() for k in names])
+    ref_i = O.eval_field(sc["depth"], sc["K"], sc["pose"], pts_c[sub.cpu()], [maps[k].float().cpu() for k in names], return_inter=True)
+    what = "case %s, plan %s" % (c, {k: plan.get(k) for k in ("kernel", "point_order")})
+    for o in (out, strict):
+        assert np.array_equal(cpu(o["valid_mask"]), ref["valid_mask"].astype(bool)), what
+        assert np.array_equal(cpu(o["dist"]), ref["dist"], equal_nan=True), what
+    for j, k in enumerate(names):
+        want = ref["sets"][j]
+        fin = np.isfinite(want).all(axis=1)
+        wide = k == "dino_feats" and c["C"] * 4 > 256                                     # folded weights on the fast path
+        for o in (out, strict):
+            got = cpu(o[k])
+            assert np.array_equal(np.isfinite(got).all(axis=1), fin), (k, what)
+            assert rel_err(got[fin], want[fin]) <= 1e-5, (k, what)                        # (the device's expf is not the host's)
+        if not wide:
+            assert torch.equal(torch.nan_to_num(out[k], nan=7.0, posinf=8.0, neginf=9.0),
+                               torch.nan_to_num(strict[k], nan=7.0, posinf=8.0, neginf=9.0)), (k, what)      # one path for thin maps
+        assert np.array_equal(cpu(inter[k + "_inter"]), ref_i["inter"][j], equal_nan=True), (k, what)       # no weights in these: bit for bit
+    if c["NI"]:
+        from d3fields_amd import onehot2instance
+        m = ref["sets"][names.index("mask")]
+        top2 = np.sort(m, axis=1)[:, -2:]
+        clear = np.isfinite(m).all(axis=1) & (top2[:, 1] - top2[:, 0] > 1e-4 * np.maximum(top2[:, 1], 1e-30))
+        assert np.array_equal(cpu(onehot2instance(out["mask"]))[clear], np.argmax(m, axis=1)[clear]), what
