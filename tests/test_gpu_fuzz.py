@@ -104,12 +104,17 @@ def _run(dev, c, seed):
         sub = torch.from_numpy(r.permutation(pts_c.shape[0])[:4000]).to(dev)
         sub[:6] = torch.from_numpy(bad).to(dev)
         inter = f.eval(pts[sub], return_names=names, return_inter=True)
+        dd = f.eval_dist(pts)
+        none = f.batch_eval(pts, return_names=[])                                       # the distance-only launch
     ref = O.eval_field(sc["depth"], sc["K"], sc["pose"], pts_c, [maps[k].float().cpu() for k in names])
     ref_i = O.eval_field(sc["depth"], sc["K"], sc["pose"], pts_c[sub.cpu()], [maps[k].float().cpu() for k in names], return_inter=True)
     what = "case %s, plan %s" % (c, {k: plan.get(k) for k in ("kernel", "point_order")})
-    for o in (out, strict):
+    for o in (out, strict, none):
         assert np.array_equal(cpu(o["valid_mask"]), ref["valid_mask"].astype(bool)), what
         assert np.array_equal(cpu(o["dist"]), ref["dist"], equal_nan=True), what
+    ref_d = O.eval_field(sc["depth"], sc["K"], sc["pose"], pts_c, [], mode="eval_dist")
+    assert np.array_equal(cpu(dd["valid_mask"]), ref_d["valid_mask"].astype(bool)), what
+    assert np.array_equal(cpu(dd["dist"]), ref_d["dist"], equal_nan=True), what
     for j, k in enumerate(names):
         want = ref["sets"][j]
         fin = np.isfinite(want).all(axis=1)
