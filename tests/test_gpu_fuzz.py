@@ -133,3 +133,35 @@ def _run(dev, c, seed):
         top2 = np.sort(m, axis=1)[:, -2:]
         clear = np.isfinite(m).all(axis=1) & (top2[:, 1] - top2[:, 0] > 1e-4 * np.maximum(top2[:, 1], 1e-30))
         assert np.array_equal(cpu(onehot2instance(out["mask"]))[clear], np.argmax(m, axis=1)[clear]), what
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_seeded_pairwise_against_oracle(dev, seed):
+    """utils/corr_utils.py's softmax-normalised descriptor similarity on drawn shapes (rows 1 ... 30 000, columns 1 ... 400, channel
+    counts that are and are not multiples of the kernel's 32-channel stage, both distance types, scales over two decades)."""
+    from d3fields_amd import corr_utils as cu
+    from oracle import c_oracle as O
+    r = np.random.default_rng(3000 + seed)
+    B1 = int(r.choice([1, 2, 63, 64, 65, 1000, 4097, 30000]))
+    B2 = int(r.choice([1, 5, 15, 16, 17, 64, 100, 300, 400]))
+    C = int(r.choice([1, 3, 31, 32, 33, 96, 384, 1000]))
+    dist_type = "l2" if r.integers(0, 2) else "square"
+    scale = float(r.choice([0.05, 0.7, 3.0]))
+    g = torch.Generator().manual_seed(seed)
+    src = torch.randn(B1, C, generator=g) * float(r.choice([0.1, 1.0]))
+    tgt = torch.randn(B2, C, generator=g) * float(r.choice([0.1, 1.0]))
+    tgt[B2 // 2] = src[B1 // 3]
+    sim = cu.compute_similarity_tensor_multi(src.to(dev), tgt.to(dev), None, None, scale, dist_type)
+    ref, am = O.pairwise(src.numpy(), tgt.numpy(), scale, dist_type, return_argmax=True)
+    what = dict(B1=B1, B2=B2, C=C, dist_type=dist_type, scale=scale)
+    assert sim.shape == (B1, B2), what
+    assert rel_err(cpu(sim), ref) <= 1e-5, what
+    assert torch.allclose(sim.sum(0), torch.ones(B2, device=dev), atol=1e-4), what
+    if dist_type == "l2":
+        out, idx = cu.nearest_descriptor(src.to(dev), tgt.to(dev), scale)
+        assert rel_err(cpu(out), ref) <= 1e-5, what
+        col = ref[:, :]                                     # the arg max is only pinned where the oracle's best row is clear
+        best = np.sort(col, axis=0)[-2:] if B1 > 1 else None
+        clear = np.ones(B2, bool) if B1 == 1 else (best[1] - best[0] > 1e-4 * np.maximum(best[1], 1e-30))
+        assert np.array_equal(cpu(idx)[clear], am[clear]), what
+        assert idx[B2 // 2].item() == B1 // 3 or not clear[B2 // 2], what
