@@ -165,3 +165,40 @@ def test_seeded_pairwise_against_oracle(dev, seed):
         clear = np.ones(B2, bool) if B1 == 1 else (best[1] - best[0] > 1e-4 * np.maximum(best[1], 1e-30))
         assert np.array_equal(cpu(idx)[clear], am[clear]), what
         assert idx[B2 // 2].item() == B1 // 3 or not clear[B2 // 2], what
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_seeded_gradient_against_torch_port(dev, seed):
+    """d3f_eval_backward (gradient with respect to the query points) on drawn shapes, random upstream gradients, against autograd
+    through the torch-ops port of the reference's op sequence (oracle/torch_port.py, pinned to the reference's own gradient)."""
+    from d3fields_amd import Fusion, synth
+    from oracle import torch_port
+    r = np.random.default_rng(4000 + seed)
+    V = int(r.integers(1, 9))
+    H, W = [(48, 64), (96, 128)][int(r.integers(0, 2))]
+    C = int(r.choice([1, 7, 32, 100, 384]))
+    fhw = [(max(H // 8, 2), max(W // 8, 2)), (H, W)][int(r.integers(0, 2))]
+    names = ["dino_feats"] + (["mask"] if r.integers(0, 2) else []) + (["color_tensor"] if r.integers(0, 2) else [])
+    kind = "smooth" if r.integers(0, 3) else "stress"
+    N = int(r.choice([1, 257, 3000]))
+    sc = synth.make_scene(V, H, W, kind)
+    maps = {"dino_feats": synth.random_map(V, fhw[0], fhw[1], C, seed=seed + 1), "mask": synth.random_onehot_mask(V, H, W, 5, seed=seed + 2),
+            "color_tensor": torch.rand(V, H, W, 3, generator=torch.Generator().manual_seed(seed + 4))}
+    f = Fusion(num_cam=V, device=str(dev))
+    f.curr_obs_torch = {k: sc[k].to(dev) for k in ("depth", "K", "pose")}
+    f.curr_obs_torch.update({k: m.to(dev) for k, m in maps.items()})
+    f.H, f.W = H, W
+    pts = synth.random_cloud(N, seed=seed + 6)
+    gen = torch.Generator().manual_seed(seed + 7)
+    w_dist = torch.randn(N, generator=gen)
+    w_k = {k: torch.randn(N, maps[k].shape[3], generator=gen) for k in names}
+    p_ref = pts.clone().requires_grad_(True)
+    obs = dict(sc)
+    obs.update(maps)
+    o_ref = torch_port.field_query(obs, p_ref, names, H, W)
+    ((o_ref["dist"] * w_dist).sum() + sum((o_ref[k] * w_k[k]).sum() for k in names)).backward()
+    p_gpu = pts.to(dev).requires_grad_(True)
+    o = f.eval(p_gpu, return_names=names)
+    ((o["dist"] * w_dist.to(dev)).sum() + sum((o[k] * w_k[k].to(dev)).sum() for k in names)).backward()
+    what = dict(V=V, H=H, W=W, C=C, fhw=fhw, names=names, kind=kind, N=N)
+    assert rel_err(cpu(p_gpu.grad), p_ref.grad.numpy()) <= 2e-5, what        # GRAD_TOL of test_gpu_parity.py
