@@ -202,3 +202,41 @@ def test_seeded_gradient_against_torch_port(dev, seed):
     ((o["dist"] * w_dist.to(dev)).sum() + sum((o[k] * w_k[k].to(dev)).sum() for k in names)).backward()
     what = dict(V=V, H=H, W=W, C=C, fhw=fhw, names=names, kind=kind, N=N)
     assert rel_err(cpu(p_gpu.grad), p_ref.grad.numpy()) <= 2e-5, what        # GRAD_TOL of test_gpu_parity.py
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_seeded_integer_callers_against_numpy(dev, seed):
+    """The integer steps of instance association and keypoint selection on drawn sizes -- cv2.erode with all-ones kernels of any
+    size, farthest-point sampling on pixel coordinates, voxel linearisation, the voxel-set IoU -- against their numpy
+    restatements (oracle/np_pcd.py, pinned to the reference's closures by the golden tests): all exact."""
+    from d3fields_amd import pcd_utils
+    from d3fields_amd.fusion import erode, _init_low_level_memory
+    from oracle import np_pcd
+    r = np.random.default_rng(5000 + seed)
+    # erode
+    shape = (int(r.integers(1, 200)), int(r.integers(1, 200)))
+    k = (int(r.integers(1, 20)), int(r.integers(1, 20)))
+    img = ((r.random(shape) < r.uniform(0.5, 0.99)) * 255).astype(np.uint8)
+    if r.integers(0, 2):
+        img = r.integers(0, 256, size=shape, dtype=np.uint8)
+    kern = np.ones(list(k), np.uint8)
+    assert np.array_equal(erode(img, kern, iterations=1), np_pcd.erode_cv2(img, kern)), (shape, k)
+    # farthest-point sampling on pixels (ties: the first maximum wins)
+    mask = r.random((int(r.integers(2, 120)), int(r.integers(2, 160)))) < r.uniform(0.05, 0.9)
+    pix = np.array(mask.nonzero()).T
+    if pix.shape[0] >= 1:
+        kk, start = int(r.integers(1, 60)), int(r.integers(0, pix.shape[0]))
+        sel, idx, md = pcd_utils.fps_pixels(pix, kk, init_idx=start)
+        wsel, widx, wmd = np_pcd.fps_int(pix, kk, start)
+        assert idx == widx and np.array_equal(sel, wsel) and md == wmd, (pix.shape, kk, start)
+    # voxel linearisation (float64 -> int32 casts, wrap-around) and the voxel-set IoU
+    n = int(r.choice([1, 1000, 200000]))
+    pcd = r.uniform(-3.0, 3.0, size=(n, 3))
+    lower, vs = r.uniform(-1.0, 0.0, size=3), float(r.choice([0.001, 0.01, 0.1]))
+    num = r.integers(1, 3000, size=3).astype(np.int32)
+    with np.errstate(invalid="ignore", over="ignore"):
+        want = np_pcd.pcd_to_index(pcd, lower, vs, num)
+    assert np.array_equal(_init_low_level_memory(lower, lower + 1, vs, num)[4](pcd), want), (n, vs, num)
+    a = r.integers(-50000, 50000, size=int(r.integers(1, 300000))).astype(np.int32)
+    b = np.concatenate([a[:: int(r.integers(1, 5))], r.integers(-2**31, 2**31, size=int(r.integers(0, 1000)), dtype=np.int64).astype(np.int32)])
+    assert pcd_utils.vox_idx_iou(a, b) == np_pcd.vox_idx_iou(a, b)
