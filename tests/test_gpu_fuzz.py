@@ -36,7 +36,9 @@ def _case(seed):
         NI = 8
     lattice = bool(r.integers(0, 3))                                  # two in three
     kind = "smooth" if r.integers(0, 4) else "stress"
-    return dict(V=V, H=H, W=W, C=C, fhw=fhw, NI=NI, color=color, lattice=lattice, kind=kind, seed=seed)
+    # one in three: the wide map is a channel range of a larger tensor (texel stride > C, first channel at any 4-byte offset)
+    view = (int(r.choice([0, 1, 4, 7])), int(r.choice([0, 4, 5, 32]))) if r.integers(0, 3) == 0 else None
+    return dict(V=V, H=H, W=W, C=C, fhw=fhw, NI=NI, color=color, lattice=lattice, kind=kind, view=view, seed=seed)
 
 
 @pytest.mark.parametrize("seed", range(40))
@@ -48,6 +50,8 @@ def test_seeded_shape_against_oracle(dev, seed):
 # two views on the window kernel's plain loop, a cloud on the cell runs of a 1024-d map
 DIRECTED = [
     dict(V=8, H=240, W=320, C=1024, fhw=(24, 32), NI=8, color=True, lattice=True, kind="smooth"),
+    dict(V=4, H=240, W=320, C=384, fhw=(24, 32), NI=0, color=False, lattice=True, kind="smooth", view=(4, 12)),      # 16-byte aligned, texel stride 400 floats
+    dict(V=4, H=240, W=320, C=384, fhw=(240, 320), NI=8, color=False, lattice=True, kind="smooth", view=(1, 3)),     # 4-byte aligned only
     dict(V=8, H=240, W=320, C=256, fhw=(24, 32), NI=0, color=False, lattice=True, kind="stress"),
     dict(V=4, H=240, W=320, C=1024, fhw=(24, 32), NI=2, color=True, lattice=True, kind="stress"),
     dict(V=2, H=120, W=160, C=128, fhw=(12, 16), NI=8, color=False, lattice=True, kind="smooth"),
@@ -68,7 +72,9 @@ def _run(dev, c, seed):
     sc = synth.make_scene(V, H, W, c["kind"])
     maps, names = {}, []
     if c["C"]:
-        maps["dino_feats"] = synth.random_map(V, c["fhw"][0], c["fhw"][1], c["C"], seed=seed + 1, device=dev)
+        off, pad = c.get("view") or (0, 0)
+        big = synth.random_map(V, c["fhw"][0], c["fhw"][1], off + c["C"] + pad, seed=seed + 1, device=dev)
+        maps["dino_feats"] = big[..., off:off + c["C"]]
         names.append("dino_feats")
     if c["NI"]:
         maps["mask"] = synth.random_onehot_mask(V, H, W, c["NI"], seed=seed + 2, device=dev)
