@@ -413,11 +413,8 @@ int eval_common(const d3f_views *views, const float *pts, int64_t n, const d3f_c
     } else if (reorder && !plan_only && (flags & D3F_FLAG_REUSE_POINT_ORDER)) {
         P.order = d3f::stored_point_order(workspace, n);       // written by an earlier call for the same points
     } else if (reorder && !plan_only) {
-        // the cell-run gather lives on consecutive points sharing texel cells: sort clouds by 4-mm cells (27-bit keys,
-        // one more radix pass) instead of 16-mm ones (C4 patch 3.84 -> 3.38 ms, C2 patch random cloud 0.73 -> 0.66)
-        int fine = (int)((flags >> 24) & 0x3);
-        if (fine == 0 && (any_runs || window)) fine = 2;
-        hipError_t eo = d3f::build_point_order(pts, n, workspace, workspace_bytes, &P.order, hs, fine);
+        // Hilbert order of the 4-mm cells, exact (order_kernels.hip); experiments builds: D3F_EXP_ORDER_MORTON=1 = the Z curve of rounds 1-4
+        hipError_t eo = d3f::build_point_order(pts, n, workspace, workspace_bytes, &P.order, hs, exp_knob("D3F_EXP_ORDER_MORTON") > 0 ? 1 : 0);
         if (eo != hipSuccess) return hip_fail(eo, "point ordering");
     }
     // Launch geometry (measured on MI355X):
@@ -540,6 +537,7 @@ int eval_common(const d3f_views *views, const float *pts, int64_t n, const d3f_c
         for (int s = 1; s < n_maps; ++s) pick_mapping(P.maps[s], P.maps[s].vw == 4, P.maps[s].vw >= 2, true, 1);
         xcd_remap = false;
         P.flags &= ~D3F_TUNE_XCD_REMAP;
+        if (exp_knob("D3F_EXP_WINDOW_RR") > 0) P.flags |= D3F_TUNE_XCD_REMAP;      // a cloud's tiles round-robin over the XCDs (rounds 2-4)
     }
     // walks: all eight XCDs stay inside one macro-brick of ~32 k points at a time (its texel footprint stays in
     // the 256 MiB Infinity Cache), each taking a contiguous eighth of it (C2 dense 1.97 -> 1.74 ms, C4 patch 4.75 -> 4.17)

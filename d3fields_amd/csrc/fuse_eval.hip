@@ -796,7 +796,9 @@ __device__ __forceinline__ void fused_eval_window_body(const EvalParams &P)
         ox = (int)bx * P.walk_tx;
     }
     const int bsx = min(P.walk_tx, P.walk_nx - ox), bsy = min(P.walk_ty, P.walk_ny - oy), bsz = min(P.walk_tz, P.walk_nz - oz);
-    const int64_t tile_base = (int64_t)blockIdx.x * TP;
+    // a cloud: XCD k takes the k-th contiguous eighth of the tiles of the Hilbert order, like the bricks of a lattice (experiments
+    // builds: D3F_EXP_WINDOW_RR=1 = consecutive tiles round-robin over the XCDs, the form of rounds 2-4)
+    const int64_t tile_base = ((P.flags & kFlagXcdRemap) ? (int64_t)blockIdx.x : xcd_tile((int64_t)blockIdx.x, (int64_t)gridDim.x)) * TP;
     const int tile_n = walk ? TP : (int)min((int64_t)TP, P.n - tile_base);
     auto slot_point = [&](int p) -> int64_t {
         if (walk) {

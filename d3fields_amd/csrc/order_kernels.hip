@@ -3,24 +3,32 @@
 //
 // Why: with maps larger than the caches (C2 dense: 1.89 GB vs 8 x 4 MiB L2 + 256 MiB Infinity
 // Cache) the fused kernel is bound by texel re-fetches; points that are close in 3-D project
-// close together in EVERY view, so walking the points along a Morton curve keeps the in-flight
+// close together in EVERY view, so walking the points along a space-filling curve keeps the in-flight
 // texel footprint compact (measured 3.2 -> 2.8 ms on the 985 600-point grid, 3.4 -> 2.6 ms on a
 // shuffled cloud).  Grids do not come here at all (closed-form brick walk, fuse_eval.hip); this is the path of clouds.
 //
+// Round 5: the curve is a HILBERT curve and the order inside a counting cell is exact.  Rounds 1-4 walked a Morton (Z)
+// curve, whose consecutive cells are up to a whole parent cell apart at every octant boundary: 64 consecutive points of it
+// -- one workgroup's tile -- then span a box several cells wide, and the LDS texel windows of the window kernel
+// (fuse_eval.hip) overflow their pool on 2 tiles of 3 (scripts/sim_cloud_tiles.py: C2-patch cloud, 66 % of the tiles over
+// an 80-slot pool, 18 % of the valid (point, view) pairs outside their window; Hilbert: 19 % / 2.9 %), which is why the
+// window kernel lost on clouds.  Consecutive cells of a Hilbert curve always share a face, at every level, so ANY run of
+// consecutive points is a compact blob.  Any prefix of the key is still a valid coarser cell (the curve is hierarchical).
+//
 // Hand-written since round 2 (round 1 sorted (key, index) pairs with rocPRIM's Onesweep radix sort: histogram +
-// 3-4 digit passes + 7 memset launches = 0.12-0.16 ms per 1 M points).  The fused kernel needs locality, not a total
-// order, so a counting sort by cell plus a local refinement is enough:
-//   1. morton_count_kernel   27-bit Morton key of the 4-mm cell of every point (kept for step 4) and a histogram of its
-//                            top 21 bits = the 16-mm cell (2 M counters in caller scratch, cleared by order_clear_kernel);
-//                            the returning atomic also gives the point its arrival rank inside the cell -- the only
-//                            atomic per point (device-scope atomics run at ~17 per ns chip-wide: 59 us per 1 M)
+// 3-4 digit passes + 7 memset launches = 0.12-0.16 ms per 1 M points).  A counting sort by cell plus an exact rank inside the
+// cell gives the total order of the keys:
+//   1. cell_count_kernel     27-bit Hilbert key of the 4-mm cell of every point (Skilling's transpose form; kept for step 4)
+//                            and a histogram of a 15..21-bit prefix = the counting cell (16 mm at 1 M points; counters in
+//                            caller scratch, cleared by order_clear_kernel); the returning atomic also gives the point its
+//                            arrival rank inside the cell -- the only atomic per point
 //   2. exclusive scan of the counters (scan_kernels.hip, three small launches)
-//   3. scatter_kernel        index i goes to slot offset[cell] + rank -- cells in Morton order, arrival order inside
-//   4. window_rank_kernel    every wave re-orders its 64 consecutive slots by (27-bit key, index): inside a 16-mm
-//                            cell (~30 points at 1 M points per 0.12 m^3) the walk follows the 4-mm sub-cells, which is
-//                            what the cell-run gather lives on; runs of equal cells that straddle a window are simply
-//                            refined piecewise.
-// Seven launches; the order inside a cell depends on atomic arrival, the results do not.
+//   3. scatter_kernel        index i and its key go to slot offset[cell] + rank -- cells in curve order, arrival order inside
+//   4. cell_rank_kernel      every slot counts the (key, index) pairs of ITS cell that sort before its own (a cell is ~30
+//                            consecutive slots: L1 hits) and moves to that place: the exact order of the full key, ties by
+//                            index.  A cell of more than 256 points (a dense clump) is ranked in aligned pieces of 256 slots.
+// Seven launches.  The result is a deterministic function of the points (the arrival order does not survive step 4 in
+// cells of <= 256 points).
 #include "d3f_internal.h"
 
 namespace d3f {
@@ -35,9 +43,38 @@ __device__ __forceinline__ uint32_t spread3(uint32_t x)
     return x;
 }
 
+// Index of the cell (x, y, z), 9 bits per axis, along the 3-D Hilbert curve: J. Skilling, "Programming the Hilbert
+// curve", AIP Conf. Proc. 707 (2004) -- axes to transpose (an inverse-undo pass of the per-level reflections / swaps, then
+// a Gray decode), then the transpose's bits interleaved with axis 0 the most significant of every 3-bit digit.
+__device__ __forceinline__ uint32_t hilbert27(uint32_t x, uint32_t y, uint32_t z)
+{
+    uint32_t X[3] = {x & 511u, y & 511u, z & 511u};
+#pragma unroll
+    for (uint32_t Q = 256u; Q > 1u; Q >>= 1) {
+        const uint32_t P = Q - 1u;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            if (X[i] & Q) {
+                X[0] ^= P;
+            } else {
+                const uint32_t t = (X[0] ^ X[i]) & P;
+                X[0] ^= t; X[i] ^= t;
+            }
+        }
+    }
+    X[1] ^= X[0]; X[2] ^= X[1];
+    uint32_t t = 0u;
+#pragma unroll
+    for (uint32_t Q = 256u; Q > 1u; Q >>= 1)
+        if (X[2] & Q) t ^= Q - 1u;
+    X[0] ^= t; X[1] ^= t; X[2] ^= t;
+    return (spread3(X[0]) << 2) | (spread3(X[1]) << 1) | spread3(X[2]);
+}
+
 constexpr float kFineCell = 0.004f;       // 4-mm sub-cells x 512 per axis = 2.05 m before the keys wrap (harmless)
 // 27-bit fine key = key of the counting cell (15 .. 21 bits, chosen per call) << shift | sub-cell
 constexpr int64_t kCells = 1 << 21;
+constexpr int kExactCell = 256;           // cells of more points than this are ranked in aligned pieces of this many slots
 
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
@@ -46,8 +83,10 @@ __global__ __launch_bounds__(kBlock) void order_clear_kernel(uint32_t *__restric
     reinterpret_cast<uint4 *>(table)[(int64_t)blockIdx.x * kBlock + threadIdx.x] = make_uint4(0u, 0u, 0u, 0u);
 }
 
-__global__ __launch_bounds__(kBlock) void morton_count_kernel(const float *__restrict__ pts, int64_t n, uint32_t *__restrict__ keys,
-                                                             uint32_t *__restrict__ ranks, uint32_t *__restrict__ table, int shift)
+// MORTON: the Z-curve keys of rounds 1-4 (experiments builds keep them for same-box comparisons)
+template <bool MORTON>
+__global__ __launch_bounds__(kBlock) void cell_count_kernel(const float *__restrict__ pts, int64_t n, uint32_t *__restrict__ keys,
+                                                           uint32_t *__restrict__ ranks, uint32_t *__restrict__ table, int shift)
 {
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (i >= n) return;
@@ -56,48 +95,58 @@ __global__ __launch_bounds__(kBlock) void morton_count_kernel(const float *__res
     const int qx = (int)fminf(fmaxf(floorf(pts[i * 3 + 0] * inv), -1e9f), 1e9f);
     const int qy = (int)fminf(fmaxf(floorf(pts[i * 3 + 1] * inv), -1e9f), 1e9f);
     const int qz = (int)fminf(fmaxf(floorf(pts[i * 3 + 2] * inv), -1e9f), 1e9f);
-    const uint32_t key = spread3((uint32_t)qx & 511u) | (spread3((uint32_t)qy & 511u) << 1) | (spread3((uint32_t)qz & 511u) << 2);
+    const uint32_t key = MORTON ? (spread3((uint32_t)qx & 511u) | (spread3((uint32_t)qy & 511u) << 1) | (spread3((uint32_t)qz & 511u) << 2))
+                                : hilbert27((uint32_t)qx, (uint32_t)qy, (uint32_t)qz);
     keys[i] = key;
     ranks[i] = atomicAdd(&table[key >> shift], 1u);
 }
 
 __global__ __launch_bounds__(kBlock) void scatter_kernel(const uint32_t *__restrict__ keys, const uint32_t *__restrict__ ranks, int64_t n,
-                                                        const uint32_t *__restrict__ offsets, uint32_t *__restrict__ slots, int shift)
+                                                        const uint32_t *__restrict__ offsets, uint32_t *__restrict__ slots,
+                                                        uint32_t *__restrict__ slot_keys, int shift)
 {
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (i >= n) return;
-    slots[offsets[keys[i] >> shift] + ranks[i]] = (uint32_t)i;
+    const uint32_t key = keys[i];
+    const uint32_t pos = offsets[key >> shift] + ranks[i];
+    slots[pos] = (uint32_t)i;
+    slot_keys[pos] = key;
 }
 
-__global__ __launch_bounds__(kBlock) void window_rank_kernel(const uint32_t *__restrict__ keys, const uint32_t *__restrict__ slots,
-                                                            int64_t n, uint32_t *__restrict__ order)
+// One lane per slot: its place among the (key, index) pairs of its own counting cell.
+__global__ __launch_bounds__(kBlock) void cell_rank_kernel(const uint32_t *__restrict__ slot_keys, const uint32_t *__restrict__ slots,
+                                                          int64_t n, const uint32_t *__restrict__ offsets, int64_t cells, int shift,
+                                                          uint32_t *__restrict__ order)
 {
-    const int64_t base = ((int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6)) * 64;
-    const int lane = threadIdx.x & 63;
-    const int64_t pos = base + lane;
-    const bool live = pos < n;
-    const uint32_t idx = live ? slots[pos] : 0xffffffffu;
-    const uint32_t key = live ? keys[idx] : 0xffffffffu;
+    const int64_t pos = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (pos >= n) return;
+    const uint32_t key = slot_keys[pos], idx = slots[pos];
+    const int64_t c = (int64_t)(key >> shift);
+    int64_t s = offsets[c], e = c + 1 < cells ? (int64_t)offsets[c + 1] : n;
+    if (e - s > kExactCell) {                      // a clump: aligned pieces of kExactCell slots, each ranked by itself
+        const int64_t lo = pos / kExactCell * kExactCell;
+        s = max(s, lo); e = min(e, lo + kExactCell);
+    }
     const unsigned long long mine = ((unsigned long long)key << 32) | idx;      // (key, index): a strict total order
     int rank = 0;
-#pragma unroll 8
-    for (int j = 0; j < 64; ++j) {
-        const unsigned long long other = __shfl(mine, j, 64);
+    for (int64_t j = s; j < e; ++j) {
+        const unsigned long long other = ((unsigned long long)slot_keys[j] << 32) | slots[j];
         rank += other < mine ? 1 : 0;
     }
-    if (live) order[base + rank] = idx;            // dead lanes hold the maximum and rank last
+    order[s + rank] = idx;
 }
 
 int64_t order_workspace_bytes(int64_t n)
 {
     if (n <= 0) return 0;
-    // keys | ranks | order | slots | cell counters + scan scratch
-    return (int64_t)(4 * align_up((size_t)n * 4, 256) + (size_t)kCells * 4 + (size_t)scan_scratch_bytes(kCells));
+    // keys | ranks | order | slots | slot keys | cell counters + scan scratch
+    return (int64_t)(5 * align_up((size_t)n * 4, 256) + (size_t)kCells * 4 + (size_t)scan_scratch_bytes(kCells));
 }
 
-// Fills *order_out with a pointer (inside the workspace) to n uint32 indices in Morton-cell order.
+// Fills *order_out with a pointer (inside the workspace) to n uint32 indices in Hilbert-cell order.
+// curve: 0 = Hilbert (the product's), 1 = Morton (experiments builds: the order of rounds 1-4)
 hipError_t build_point_order(const float *pts, int64_t n, void *workspace, int64_t workspace_bytes,
-                             const uint32_t **order_out, hipStream_t stream, int /*fine: the walk is always refined to 4 mm*/)
+                             const uint32_t **order_out, hipStream_t stream, int curve)
 {
     *order_out = nullptr;
     if (n <= 0 || n > 0x7fffffffLL || workspace_bytes < order_workspace_bytes(n)) return hipErrorInvalidValue;
@@ -105,23 +154,24 @@ hipError_t build_point_order(const float *pts, int64_t n, void *workspace, int64
     unsigned char *base = static_cast<unsigned char *>(workspace);
     uint32_t *keys = reinterpret_cast<uint32_t *>(base), *ranks = reinterpret_cast<uint32_t *>(base + seg);
     uint32_t *order = reinterpret_cast<uint32_t *>(base + 2 * seg), *slots = reinterpret_cast<uint32_t *>(base + 3 * seg);
-    uint32_t *table = reinterpret_cast<uint32_t *>(base + 4 * seg);
-    void *scan_scratch = base + 4 * seg + (size_t)kCells * 4;
+    uint32_t *slot_keys = reinterpret_cast<uint32_t *>(base + 4 * seg);
+    uint32_t *table = reinterpret_cast<uint32_t *>(base + 5 * seg);
+    void *scan_scratch = base + 5 * seg + (size_t)kCells * 4;
     const unsigned nb = (unsigned)((n + kBlock - 1) / kBlock);
-    // counters: >= 4 per point (any prefix of the Morton key is a valid coarser Z-order cell), 2^15 .. 2^21: 16-mm cells
-    // for 1 M points, 16 x 32 x 32 mm for 100 k -- the 64-slot refinement below still resolves them, and clearing +
-    // scanning the table stops dominating small batches (fewer counters than that and the atomics start to collide:
-    // 2.6 per point measured 7 -> 14 us in morton_count_kernel at 100 k points)
+    // counters: >= 4 per point (any prefix of the key is a valid coarser cell of the curve), 2^15 .. 2^21: 16-mm cells
+    // for 1 M points, 16 x 32 x 32 mm for 100 k -- and clearing + scanning the table stops dominating small batches
+    // (fewer counters than that and the atomics start to collide: 2.6 per point measured 7 -> 14 us at 100 k points)
     int bits = 15;
     while (bits < 21 && (1LL << bits) < 4 * n) bits += 1;
     const int shift = 27 - bits;
     const int64_t cells = 1LL << bits;
     hipLaunchKernelGGL(order_clear_kernel, dim3((unsigned)(cells / 4 / kBlock)), dim3(kBlock), 0, stream, table);
-    hipLaunchKernelGGL(morton_count_kernel, dim3(nb), dim3(kBlock), 0, stream, pts, n, keys, ranks, table, shift);
+    if (curve == 1) hipLaunchKernelGGL(cell_count_kernel<true>, dim3(nb), dim3(kBlock), 0, stream, pts, n, keys, ranks, table, shift);
+    else hipLaunchKernelGGL(cell_count_kernel<false>, dim3(nb), dim3(kBlock), 0, stream, pts, n, keys, ranks, table, shift);
     hipError_t e = launch_exclusive_scan_u32(table, table, cells, scan_scratch, stream);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(scatter_kernel, dim3(nb), dim3(kBlock), 0, stream, keys, ranks, n, table, slots, shift);
-    hipLaunchKernelGGL(window_rank_kernel, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream, keys, slots, n, order);
+    hipLaunchKernelGGL(scatter_kernel, dim3(nb), dim3(kBlock), 0, stream, keys, ranks, n, table, slots, slot_keys, shift);
+    hipLaunchKernelGGL(cell_rank_kernel, dim3(nb), dim3(kBlock), 0, stream, slot_keys, slots, n, table, cells, shift, order);
     e = hipGetLastError();
     if (e != hipSuccess) return e;
     // the finished order always sits in the same place, so that a later call can find it again (D3F_FLAG_REUSE_POINT_ORDER)

@@ -1,0 +1,116 @@
+"""Round 5, same-box A/B of the cloud paths (EXPERIMENTS build: the knobs are environment variables read per call).
+
+    D3F_BUILD_EXPERIMENTS=1 python scripts/notebook/exp_cloud.py [--out DIR] [--only c2_patch,...]
+
+One process: every workload is built once, every variant sets os.environ and times the fused kernel with the library's own
+HIP events (d3f_profile_next_eval, bench.py's method) plus the whole step (ordering kernels included).  Outputs of every
+variant are compared with the first one's (dist / valid_mask bit for bit, fused channels max |diff|) and one variant per
+workload is checked against the CPU oracle (bench.verify_against_oracle).
+"""
+import argparse
+import json
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+import bench   # noqa: E402
+
+VARIANTS = [
+    ("morton+runs", {"D3F_EXP_ORDER_MORTON": "1"}),
+    ("hilbert+runs", {}),
+    ("hilbert+win64", {"D3F_EXP_WINDOW": "64"}),
+    ("hilbert+win64rr", {"D3F_EXP_WINDOW": "64", "D3F_EXP_WINDOW_RR": "1"}),
+    ("morton+win64", {"D3F_EXP_ORDER_MORTON": "1", "D3F_EXP_WINDOW": "64"}),
+    ("hilbert+win64occ2", {"D3F_EXP_WINDOW": "64", "D3F_EXP_WINDOW_OCC": "2"}),
+    ("hilbert+win32", {"D3F_EXP_WINDOW": "32"}),
+]
+KNOBS = sorted({k for _, e in VARIANTS for k in e})
+
+
+def surface_points(f, w):
+    from d3fields_amd import synth
+    _, pts = f.grid_shell(synth.WORK_BOX, w["step"], dist_threshold=w["step"])
+    return pts.contiguous()
+
+
+def run_case(name, points, dev, steps, variants, force_reorder=False):
+    f, pts, names, w, sc = bench.build_workload(name, dev, 0, 1, "grid" if points == "surface" else points)
+    if points == "surface":
+        pts = surface_points(f, w)
+    f.cache_point_order = False
+    f.record_plans = True
+    if force_reorder:
+        f.tuning_flags |= (1 << 14)
+    rows, ref = [], None
+    for label, env in variants:
+        for k in KNOBS:
+            os.environ.pop(k, None)
+        os.environ.update(env)
+        try:
+            fn = lambda: f.batch_eval(pts, return_names=names)      # noqa: E731
+            for _ in range(3):
+                out = fn()
+            torch.cuda.synchronize(dev)
+            k_avg, k_med, k_min = bench.fused_kernel_time_ms(fn, steps, dev)
+            s_avg, s_med, s_min = bench.kernel_time_ms(fn, steps, dev)
+            out = fn()
+            torch.cuda.synchronize(dev)
+            plan = f.last_plan() or {}
+            if ref is None:
+                ref = {k: v.clone() for k, v in out.items()}
+                same, worst = True, 0.0
+            else:
+                same = bool(torch.equal(out["dist"], ref["dist"]) and torch.equal(out["valid_mask"], ref["valid_mask"]))
+                worst = max(float((out[k] - ref[k]).abs().max()) for k in names) if names else 0.0
+            row = {"workload": name, "points": points + ("+reorder" if force_reorder else ""), "n": int(pts.shape[0]), "variant": label, "kernel_ms_avg": k_avg, "kernel_ms_med": k_med,
+                   "kernel_ms_min": k_min, "step_ms_avg": s_avg, "step_ms_med": s_med, "dist_valid_same": same, "max_abs_diff": worst,
+                   "kernel": plan.get("kernel"), "tile": plan.get("tile_points")}
+        except Exception as e:       # a variant the build does not carry
+            row = {"workload": name, "points": points, "variant": label, "error": repr(e)[:200]}
+        rows.append(row)
+        print(json.dumps(row), flush=True)
+    for k in KNOBS:
+        os.environ.pop(k, None)
+    try:
+        ok, info = bench.verify_against_oracle(f, pts, names, w, sc, out)
+        print(json.dumps({"workload": name, "points": points, "oracle_check_of_last_variant": ok, **info}), flush=True)
+    except Exception as e:
+        print(json.dumps({"workload": name, "oracle_error": repr(e)[:200]}), flush=True)
+    del f, pts, out, ref
+    torch.cuda.empty_cache()
+    return rows
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "r5_cloud"))
+    ap.add_argument("--only", default="")
+    ap.add_argument("--steps", type=int, default=20)
+    args = ap.parse_args()
+    os.makedirs(args.out, exist_ok=True)
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    cases = [("c2_patch", "random", False), ("c3_patch", "random", False), ("ref_patch", "random", False), ("ref_patch", "surface", False),
+             ("ref_patch", "surface", True), ("c3_patch", "surface", True), ("c5_track", "random", False), ("c4_patch", "random", False)]
+    only = [s for s in args.only.split(",") if s]
+    rows = []
+    for name, points, force in cases:
+        if only and name not in only:
+            continue
+        rows += run_case(name, points, dev, args.steps, VARIANTS, force)
+    with open(os.path.join(args.out, "exp_cloud.json"), "w") as fh:
+        json.dump(rows, fh, indent=1)
+    print("\n%-10s %-16s %-18s %9s %9s %9s  %s" % ("workload", "points", "variant", "kern avg", "kern min", "step avg", "kernel"))
+    for r in rows:
+        if "error" in r:
+            print("%-10s %-16s %-18s ERROR %s" % (r["workload"], r["points"], r["variant"], r["error"]))
+        else:
+            print("%-10s %-16s %-18s %9.4f %9.4f %9.4f  %s %s %s" % (r["workload"], r["points"], r["variant"], r["kernel_ms_avg"], r["kernel_ms_min"], r["step_ms_avg"],
+                                                            r["kernel"], "" if r["dist_valid_same"] else "DIST/VALID DIFFER", "" if r["max_abs_diff"] == 0 else "maxdiff %.2e" % r["max_abs_diff"]))
+
+
+if __name__ == "__main__":
+    main()
