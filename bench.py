@@ -18,11 +18,18 @@ shape):
   c5_track  one tracking frame as SURVEY 8d defines it: NEW depth / feature / mask tensors (the per-frame refresh of
             vis_tracking.py:86: the shim's device-side finite checks run again), eval of 100 000 keypoints (features +
             mask), descriptor correspondence (softmax similarity + argmax); the static-map figure is reported beside it
-  ref_patch the reference's own query (vis_repr.py:103): 48x64x1024 DINOv2 patch maps (fusion.py:600,694-697) + 8-instance
-            mask + colours, return_names=['dino_feats','mask','color_tensor'], 1 925 000-point grid
+  ref_patch the reference's own maps and names (vis_repr.py:103): 48x64x1024 DINOv2 patch maps (fusion.py:600,694-697) +
+            8-instance mask + colours, return_names=['dino_feats','mask','color_tensor'].  Default points: the full 1 925 000-point
+            LATTICE (the shape of vis_repr.py:93's query with the names of :103); `--points surface` = what :97-103 really
+            hands to batch_eval: the lattice points with valid_mask & |dist| < step in flat-index order (the vertices
+            extract_mesh finds, fusion.py:1313-1330; ~71 k points here), a CLOUD
   dist_only the distance-only pass over the 1-mm grid (return_names=[], vis_repr.py:93 / fusion.py:1420-1428): 123.2 M points,
             bound by VALU issue (IEEE divisions of the projection), reported against both roofs
-With --gpus N > 1 and no --workload the configuration BASELINE.json names for eight GPUs is timed (c4_patch).
+The default workload is c2_dense for EVERY --gpus N (weak scaling: the same per-GPU work at every N, so that the values of
+`bench.py --gpus 1/2/4/8` form one curve); `--workload c4_patch --gpus N` is BASELINE.json's eight-GPU configuration, whose N = 1
+point is `--gpus 1 --workload c4_patch`.  Every N > 1 line also carries rank 0's single-rank figure of the SAME workload
+(`single_rank_points_per_s_same_workload`, measured alone before the group run) and `value_full_field` (the whole field
+reassembled on every GPU) beside `value` (compute + the `dist` / `valid_mask` gather).
 Multi-GPU: weak scaling -- every rank queries its own shard of N points against replicated
 maps; the only exchange is the RCCL all-gather that reassembles the field (`--gather`).
 """
@@ -76,15 +83,20 @@ def algorithmic_bytes(w, n):
     return n * per_pt + maps + 84 * w["V"], per_pt
 
 
-def measured_traffic(workload, points, n):
+def measured_traffic(workload, points, n, path=None):
     """HBM bytes per launch (and VALU wave instructions, when counted) from the committed rocprofv3 PMC passes
-    (profiles/traffic.json), keyed by workload AND point set (`<workload>` = its grid, `<workload>_random` = the cloud) and
-    only when the profiled launch had the same number of points; else None -- a figure of another kernel / order is worse
-    than none."""
+    (profiles/traffic.json), keyed by workload AND point set (`<workload>` = its grid, `<workload>_random` / `_surface` = the
+    clouds), only when the profiled launch had the same number of points AND the entry carries the source fingerprint of the
+    library that is loaded now; else None -- a figure of another kernel / order is worse than none."""
     try:
-        with open(os.path.join(ROOT, "profiles", "traffic.json")) as fh:
-            e = json.load(fh).get(workload if points == "grid" else workload + "_random")
+        with open(path or os.path.join(ROOT, "profiles", "traffic.json")) as fh:
+            e = json.load(fh).get(workload if points == "grid" else workload + "_" + points)
         if not e or int(e.get("points", n)) != int(n):
+            return None, None, None
+        # the counters belong to the kernels they were collected on: an entry stamped with another source fingerprint than the
+        # loaded library's (d3fields_amd/build.py: sha256 over csrc/ + the header + the flags) is stale and is dropped
+        from d3fields_amd import build as _build
+        if e.get("source_fingerprint") != _build.source_fingerprint():
             return None, None, None
         return e.get("traffic_bytes"), e.get("source"), e.get("valu_insts")
     except (OSError, ValueError, KeyError):
@@ -128,6 +140,18 @@ def build_workload(name, dev, rank, world, points="grid"):
         pts, _ = create_init_grid(synth.WORK_BOX, w["step"])
         if world > 1:
             pts[:, 0] += rank * w["step"] / world
+    elif points == "surface":
+        # what extract_mesh hands to batch_eval (fusion.py:1313-1330, vis_repr.py:97-103): the lattice points on the surface --
+        # valid_mask & |dist| < step -- in flat-index order (Fusion.grid_shell: the same pass, compacted on the device)
+        if w["step"] is None or w.get("no_maps") or world > 1:
+            raise SystemExit("--points surface needs a workload with a lattice and channel maps, on one GPU")
+        box = dict(synth.WORK_BOX)
+        if w.get("slabs"):
+            width = (box["x_upper"] - box["x_lower"]) / w["slabs"]
+            box["x_lower"] = synth.WORK_BOX["x_lower"] + (w["slabs"] // 2 - 1) * width
+            box["x_upper"] = box["x_lower"] + width - w["step"] / 4
+        _, pts = f.grid_shell(box, w["step"], dist_threshold=w["step"])
+        pts = pts.contiguous()
     else:       # uniformly random cloud of the same N in the same box: no locality in the caller's order
         pts = synth.random_cloud(w.get("N_cloud", w["N"]), seed=3 + rank)
     return f, pts.to(dev), names, w, sc
@@ -271,12 +295,18 @@ def spawn_ranks(n, argv):
     argument' unless HSA_ENABLE_IPC_MODE_LEGACY=0) and the variable is not set already, the launch is repeated once with it
     set; the line then says so (config.ipc_mode_retry)."""
     import subprocess
+    import tempfile
     env = dict(os.environ)
+    # torch.distributed.run maps every child failure to its own status, so the ranks say WHICH failure it was through a marker
+    # file: only "the first collective failed" is retried; a verification mismatch, an OOM or a crash is handed back as it is
+    marker = os.path.join(tempfile.mkdtemp(prefix="d3f_bench_"), "ipc_failure")
+    env["D3F_BENCH_IPC_MARKER"] = marker
     rc = subprocess.call(spawn_command(n, argv), env=env)
-    if rc != 0 and "HSA_ENABLE_IPC_MODE_LEGACY" not in env and n > 1:
+    if rc != 0 and os.path.exists(marker) and "HSA_ENABLE_IPC_MODE_LEGACY" not in env and n > 1:
+        os.remove(marker)
         env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
         env["D3F_BENCH_IPC_RETRY"] = "1"
-        print("bench.py: the %d-rank launch failed (status %d); retrying once with HSA_ENABLE_IPC_MODE_LEGACY=0" % (n, rc), file=sys.stderr)
+        print("bench.py: the first collective of the %d-rank launch failed (status %d); retrying once with HSA_ENABLE_IPC_MODE_LEGACY=0" % (n, rc), file=sys.stderr)
         rc = subprocess.call(spawn_command(n, argv), env=env)
     return rc
 
@@ -287,13 +317,15 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default=None, choices=sorted(WORKLOADS),
-                    help="default: c2_dense on one GPU (the configuration the metric is quoted on); with --gpus N > 1 c4_patch, "
-                         "the configuration BASELINE.json names for eight GPUs (8 views x 720x1280, 1024-d, 8 M points sharded)")
+                    help="default: c2_dense, the configuration the metric is quoted on, for every --gpus N (one curve); c4_patch is the "
+                         "configuration BASELINE.json names for eight GPUs (8 views x 720x1280, 1024-d, 8 M points sharded)")
     ap.add_argument("--gather", default="dist", choices=["none", "dist", "full"],
                     help="N>1: what the RCCL all-gather reassembles inside the timed step")
-    ap.add_argument("--points", default="grid", choices=["grid", "random"],
+    ap.add_argument("--points", default="grid", choices=["grid", "random", "surface"],
                     help="grid: create_init_grid of the workload (default); random: uniform cloud of the same N in the "
-                         "same box (exposes the dependence on the caller's point order)")
+                         "same box (exposes the dependence on the caller's point order); surface: the lattice points with "
+                         "valid_mask & |dist| < step in flat-index order -- the mesh-vertex cloud the reference's feature query runs on "
+                         "(vis_repr.py:97-103)")
     ap.add_argument("--no-overlap", action="store_true", help="N>1: block on every all-gather instead of overlapping it "
                     "with the next batch's query")
     ap.add_argument("--refresh-maps", action="store_true", help="install NEW depth / map tensors before every step (the per-frame "
@@ -310,7 +342,7 @@ def main():
                     "exercised with several ranks on ONE GPU (testing only)")
     args = ap.parse_args()
     if args.workload is None:
-        args.workload = "c2_dense" if args.gpus <= 1 else "c4_patch"
+        args.workload = "c2_dense"
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -342,13 +374,15 @@ def main():
             assert int(probe.item()) == world
         except Exception as exc:
             print("bench.py rank %d: first collective failed: %r" % (rank, exc), file=sys.stderr)
+            if os.environ.get("D3F_BENCH_IPC_MARKER"):
+                open(os.environ["D3F_BENCH_IPC_MARKER"], "w").close()
             os._exit(IPC_FAILURE_EXIT)
 
     f, pts, names, w, sc = build_workload(args.workload, dev, rank, world, args.points)
     f.tuning_flags = args.tuning
-    # The shim can keep what it learned about an unchanged query tensor between calls (its lattice dims, or its Morton
+    # The shim can keep what it learned about an unchanged query tensor between calls (its lattice dims, or its Hilbert
     # order): every timed step here starts from scratch instead -- the probe kernels (lattice + locality, ~10 us) or the
-    # Morton sort are enqueued INSIDE every step; with async_probes the launch follows the verdict of the last FINISHED
+    # Hilbert sort are enqueued INSIDE every step; with async_probes the launch follows the verdict of the last FINISHED
     # probes of a query of the same size, so a steady-state step holds NO host sync (only the first query of a size
     # waits once) -- and the cached figure is reported separately below.
     f.cache_point_order = False
@@ -420,16 +454,23 @@ def main():
         compute()
         s_avg, s_med, s_min = kernel_time_ms(compute, max(args.steps, 5), dev)          # whole step on the device
         k_avg, k_med, k_min = fused_kernel_time_ms(compute, max(args.steps, 5), dev)   # dominant kernel only
+        extra = {}
+        if dist_on:
+            # rank 0 alone (the others wait at the barrier): the compute-only step of THIS workload on one GPU, the figure the group's
+            # compute-only value divides by
+            import torch.distributed as dist
+            if rank == 0:
+                extra["single_rank_points_per_s_same_workload"] = n * args.steps / time_steps(compute, args.steps, False, dev)
+            dist.barrier()
         for _ in range(max(args.warmup, 1)):
             step()
         drain()
         wall = time_steps(step, args.steps, dist_on, dev, drain)
-        extra = {}
         if not dist_on:
             f.cache_point_order = True          # a static grid queried every frame: the order is built once
             compute(); compute()
             extra["points_per_s_with_cached_point_order"] = n * args.steps / time_steps(compute, args.steps, False, dev)
-            extra["cached_point_order_note"] = ("the shim's default: lattice dims / Morton order of an UNCHANGED query tensor are kept "
+            extra["cached_point_order_note"] = ("the shim's default: lattice dims / point order of an UNCHANGED query tensor are kept "
                                                 "between calls; `value` re-derives them inside every step")
             f.cache_point_order = False
             if frames[0] is not None:           # the same step on maps that do not change (what rounds 1-3 reported for c5)
@@ -446,12 +487,28 @@ def main():
                 full()
                 fs = max(2, args.steps // 4)
                 extra["full_field_gather_points_per_s"] = world * n * fs / time_steps(full, fs, True, dev)
+            else:
+                extra["full_field_gather_points_per_s"] = world * n * args.steps / wall
+            # the north star's "reassemble the full field": every output of every point on every GPU
+            extra["value_full_field"] = extra["full_field_gather_points_per_s"]
+            if rank == 0 and extra.get("single_rank_points_per_s_same_workload"):
+                single = extra["single_rank_points_per_s_same_workload"]
+                extra["scaling_efficiency"] = {"compute_only": extra["compute_only_points_per_s"] / (world * single),
+                                               "with_dist_gather": None, "with_full_field_gather": extra["value_full_field"] / (world * single),
+                                               "note": "this run's group figures / (world x rank 0's single-rank compute-only figure of the same workload)"}
 
         verified, verify_info = None, None
         f.record_plans = True
         out_check = compute()                   # every rank: the c5 step holds a collective (sharded softmax)
         plan = f.last_plan()
         f.record_plans = False
+        gate_info = None
+        if plan and plan.get("gated_window"):         # a cloud on the gated pair of launches: which side ran?
+            g = f.last_gate()
+            if g is not None:
+                gate_info = {"tiles_that_fit_of_%d" % 128: g[0], "window_side_ran": g[1]}
+                if g[1]:
+                    plan = dict(plan, **plan["window_side"])
         if rank == 0 and not args.no_verify:      # fp16-stored maps: the oracle runs on the WIDENED maps (the contract)
             verified, verify_info = verify_against_oracle(f, pts, names, w, sc, out_check)
 
@@ -481,7 +538,9 @@ def main():
                                                     (" + %dx%dx%d colours" % (w["H"], w["W"], w["color"])) if w.get("color") else "",
                                                     n, names),
                    "maps_refreshed_every_step": bool(w.get("refresh") or args.refresh_maps),
-                   "points": ("grid" if (w["step"] is not None and args.points == "grid") else "random cloud"),
+                   "points": ("grid" if (w["step"] is not None and args.points == "grid") else
+                              ("surface cloud: lattice points with valid_mask & |dist| < step, flat-index order (vis_repr.py:97-103)"
+                               if args.points == "surface" else "random cloud")),
                    "points_per_gpu": n, "views": w["V"], "feature_dim": w["C"], "feature_map": list(w["fhw"]),
                    "parallelism": "points sharded x%d, maps replicated" % world,
                    # what torch.distributed itself reports (backend "nccl" is RCCL on ROCm), and where every rank ran
@@ -513,7 +572,7 @@ def main():
                                      "frac_of_issue_peak": valu_insts / (k_avg * 1e-3) / VALU_PEAK_INST_PER_S,
                                      "peak_inst_per_s": VALU_PEAK_INST_PER_S, "source": traffic_src} if valu_insts else None),
                      "note": "achieved = algorithmic bytes / kernel_ms_avg (HIP events around the "
-                     "fused kernel on its launch stream); step_device_ms_avg also covers the per-step lattice probe / Morton ordering kernels"},
+                     "fused kernel on its launch stream); step_device_ms_avg also covers the per-step lattice probe / Hilbert ordering kernels"},
     }
     res.update(extra)
     res["verified"] = verified
@@ -521,6 +580,10 @@ def main():
     if plan:
         res["config"]["point_order"] = plan["point_order"]
         res["config"]["tile_points"] = plan["tile_points"]
+    if gate_info:
+        res["config"]["device_gate"] = gate_info
+    if dist_on and res.get("scaling_efficiency"):
+        res["scaling_efficiency"]["with_dist_gather"] = value / (world * res["single_rank_points_per_s_same_workload"])
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         maps_cpu = {k: f.curr_obs_torch[k].float().cpu() for k in names}
         res["cpu_baseline"] = cpu_baseline(sc, w, names, maps_cpu, pts.cpu(), args.cpu_sample, args.cpu_threads)

@@ -78,7 +78,12 @@ void pick_mapping(d3f::MapDesc &m, bool can16, bool can8, bool batch, int max_u 
 //  kBatchedLoadBytes    a map at most this big issues all 4*U corner loads of a view before the first use; bigger maps
 //                       in caller order use load-use per vector (a smaller in-flight footprint measured faster)
 //  kBeyondLlcBytes      maps beyond this in CALLER order without scratch: 64-point tiles at 2 workgroups per CU
+//  kWindowCloudMin      a cloud of at least this many points (in the Hilbert order) may take the LDS-window kernel when the device-side
+//                       probe finds its tiles compact (below: the window kernel's ~25-us workgroups do not fill the chip twice
+//                       over and the cell-run kernel wins: 71 k surface points 0.17 vs 0.12 ms, 100 k keypoints 0.12 vs 0.09)
 constexpr int64_t kSmallBatch = 65536;
+constexpr int64_t kWindowCloudMin = 262144;
+constexpr int kGatedSecondPass = 1;          // eval_common's internal "now enqueue the other side" status (never returned to callers)
 constexpr int64_t kCacheResidentBytes = 64LL << 20;
 constexpr int64_t kBatchedLoadBytes = 128LL << 20;
 constexpr int64_t kBeyondLlcBytes = 512LL << 20;
@@ -246,8 +251,11 @@ int tile_points_for(int V)
 int eval_common(const d3f_views *views, const float *pts, int64_t n, const d3f_channel_map *maps, int32_t n_maps,
                 float mu, uint32_t flags, float *out_dist, uint8_t *out_valid, float *const *out_fused,
                 float *const *out_inter, void *workspace, int64_t workspace_bytes, void *stream, int mode,
-                d3f_eval_plan *plan_out = nullptr, const d3f_grid *grid = nullptr, const int32_t *lattice = nullptr)
+                d3f_eval_plan *plan_out = nullptr, const d3f_grid *grid = nullptr, const int32_t *lattice = nullptr, int cloud_side = 0)
 {
+    // cloud_side (eval_entry): 0 = plan queries and the callers that never gate; 1 = first pass of a query -- if the points are a
+    // cloud the window kernel may take (kWindowCloudMin points, a patch-resolution wide map, the Hilbert order), this pass
+    // enqueues order + probe + the GATED window launch and returns kGatedSecondPass; 2 = the second pass: the gated cell-run launch
     const bool plan_only = plan_out != nullptr;
     int rc = check_views(views);
     if (rc != D3F_OK) return rc;
@@ -288,6 +296,8 @@ int eval_common(const d3f_views *views, const float *pts, int64_t n, const d3f_c
     P.win_lpp = exp_knob("D3F_EXP_WINDOW_LPP") == 32 ? 32 : 16;     // 16 lanes x 2 vectors per point (C2 patch 0.565 -> 0.54 ms); U > 1: 32
     P.win_slices = 0; P.win_u = 1; P.win_vc = 1; P.win_pool_offset = 0; P.win_pool_texels = 0; P.win_occ = 4;
     P.win_pipe = exp_knob("D3F_EXP_WINDOW_PIPE") < 0 ? 0 : 1;
+    P.win_sparse = 0;
+    P.gate = nullptr; P.gate_min = 0u; P.gate_want = 0;
     P.store_policy = exp_knob("D3F_EXP_STORE") < 0 ? 0 : (exp_knob("D3F_EXP_STORE") == 1 ? 1 : (exp_knob("D3F_EXP_STORE") == 3 ? 3 : 2));     // non-temporal rows (fuse_common.h: store_out)
     int64_t map_bytes = 0;
     P.out_dist = out_dist; P.out_valid = out_valid;
@@ -334,10 +344,13 @@ int eval_common(const d3f_views *views, const float *pts, int64_t n, const d3f_c
     // whole 512-byte slices, every other map is thin; same preconditions as the cell-run gather, which it replaces.
     bool window = false;
     const int win_knob = exp_knob("D3F_EXP_WINDOW");          // 0 automatic (see below), -1 off, 32 / 64 / 128: points per workgroup
+    // would this query's points be walked in the Hilbert order?  (the cloud half of `reorder` below)
+    const bool reorder_cloud = may_reorder && !lattice && ((flags & D3F_TUNE_FORCE_REORDER) || (n >= kSmallBatch && (map_bytes > kCacheResidentBytes || (flags & D3F_FLAG_UNORDERED_POINTS))));
+    const bool cloud_candidate = cloud_side == 1 && reorder_cloud && n >= kWindowCloudMin && !(flags & D3F_TUNE_NO_WINDOW_GATE);
     {
-        // default: lattices only (a brick's windows are compact; 64 consecutive points of a cloud's Morton order are not:
-        // C5 0.120 -> 0.170 ms), and not when a cell-run variant is asked for explicitly
-        const bool automatic = win_knob == 0 && lattice != nullptr && exp_knob("D3F_EXP_RUNS") == 0 && exp_knob("D3F_EXP_RUNS_U") == 0;
+        // default: lattices (a brick's windows are compact), and clouds through the device-side gate (fuse_eval.hip: gated_out);
+        // not when a cell-run variant is asked for explicitly
+        const bool automatic = win_knob == 0 && (lattice != nullptr || cloud_candidate) && exp_knob("D3F_EXP_RUNS") == 0 && exp_knob("D3F_EXP_RUNS_U") == 0;
         window = (win_knob > 0 || automatic) && !direct && mode == 0 && n_maps >= 1 && finite_expected && n >= kSmallBatch &&
                  n <= 0x7fffffffLL && tl == 0 && views->V <= 8 && runs_candidate(P.maps[0], views->H, views->W) &&
                  P.maps[0].C % 128 == 0 && (int64_t)views->V * P.maps[0].sv * 4 < (1LL << 31) && (P.maps[0].sx % 4) == 0 && (P.maps[0].sy % 4) == 0 && (P.maps[0].sv % 4) == 0 &&
@@ -357,9 +370,16 @@ int eval_common(const d3f_views *views, const float *pts, int64_t n, const d3f_c
             const bool occ_forced = occ >= 5 && occ <= 6;        // experiments: 5 / 6 workgroups per CU with the plain point loop
             if (occ < 2 || occ > 6) occ = 4;
             if (U > 1) occ = 2;                                 // those variants are built for 2 workgroups per CU
+            // touched-texel pool (SPARSE) for clouds, whole rectangles for lattice bricks (which never overflow: 0.42 vs 0.455 ms on
+            // C2-patch); experiments builds: D3F_EXP_WINDOW_SPARSE = 1 / -1 forces either
+            P.win_sparse = exp_knob("D3F_EXP_WINDOW_SPARSE") > 0 ? 1 : (exp_knob("D3F_EXP_WINDOW_SPARSE") < 0 ? 0 : (lattice ? 0 : 1));
+            // static LDS of the kernel + allocation granularity: 3 workgroups per CU stop fitting with less (measured, round 5)
+            const int slack = exp_knob("D3F_EXP_WINDOW_SLACK") > 0 ? exp_knob("D3F_EXP_WINDOW_SLACK") : (P.win_sparse ? 4096 : 2048);
+            // slots per view worth a workgroup per CU: a brick's rectangles ~17; a cloud tile's touched texels ~12 (p90 14)
+            const int want = exp_knob("D3F_EXP_WINDOW_WANT") > 0 ? exp_knob("D3F_EXP_WINDOW_WANT") : (P.win_sparse ? 14 : 17);
             int texels = 0;
             for (;; --occ) {
-                const int budget = 160 * 1024 / occ - 2048;     // the kernel's static LDS (corner points, windows, slot table) is 1.7 KiB
+                const int budget = 160 * 1024 / occ - slack;
                 texels = (budget - pool_offset) / (512 * U) - 2;
                 // A 4x4x4 brick's window is ~3x4 texels per view once a texel is at least as wide as the brick's footprint
                 // (config 4's slab: 2.5-mm lattice, 10-px texels), and a pool that cannot hold the views' windows sends the
@@ -369,7 +389,7 @@ int eval_common(const d3f_views *views, const float *pts, int64_t n, const d3f_c
                 // (round 4, pipelined point loop: a point with a pair outside the pool is done a second time by the general path, so
                 // overflow costs more than a workgroup per CU -- C2-patch: 55 slots at 4 per CU 0.525 ms, 80 slots at 3 per CU 0.493,
                 // 40 / 32 slots 0.72 / 0.81: ask for ~17 slots per view)
-                if (texels >= (exp_knob("D3F_EXP_WINDOW_WANT") > 0 ? exp_knob("D3F_EXP_WINDOW_WANT") : 17) * views->V || occ == 2 || occ_forced) break;
+                if (texels >= want * views->V || occ == 2 || occ_forced) break;
             }
             if (exp_knob("D3F_EXP_WINDOW_POOL") > 0 && exp_knob("D3F_EXP_WINDOW_POOL") < texels) texels = exp_knob("D3F_EXP_WINDOW_POOL");
             if (texels > 320) texels = 320;                      // kWinMaxTexels (fuse_eval.hip)
@@ -537,7 +557,9 @@ int eval_common(const d3f_views *views, const float *pts, int64_t n, const d3f_c
         for (int s = 1; s < n_maps; ++s) pick_mapping(P.maps[s], P.maps[s].vw == 4, P.maps[s].vw >= 2, true, 1);
         xcd_remap = false;
         P.flags &= ~D3F_TUNE_XCD_REMAP;
-        if (exp_knob("D3F_EXP_WINDOW_RR") > 0) P.flags |= D3F_TUNE_XCD_REMAP;      // a cloud's tiles round-robin over the XCDs (rounds 2-4)
+        // a cloud's tiles go round-robin over the XCDs (all eight work on one neighbourhood: C2-patch cloud 0.52 ms against 0.58
+        // with contiguous eighths, which is the lattice bricks' mapping); experiments builds: D3F_EXP_WINDOW_RR=-1 = eighths
+        if (!walk && exp_knob("D3F_EXP_WINDOW_RR") >= 0) P.flags |= D3F_TUNE_XCD_REMAP;
     }
     // walks: all eight XCDs stay inside one macro-brick of ~32 k points at a time (its texel footprint stays in
     // the 256 MiB Infinity Cache), each taking a contiguous eighth of it (C2 dense 1.97 -> 1.74 ms, C4 patch 4.75 -> 4.17)
@@ -571,6 +593,14 @@ int eval_common(const d3f_views *views, const float *pts, int64_t n, const d3f_c
                  ((P.walk_nz + P.walk_tz - 1) / P.walk_tz);
     if (ntiles > 0x7fffffffLL) return fail(D3F_ERR_BAD_SHAPE, "n=%lld needs more than 2^31 workgroups", (long long)n);
     if (plan_only) {
+        plan_out->gated_window = 0; plan_out->reserved2 = 0;
+        if (cloud_side == 0 && !lattice && !grid) {       // would d3f_eval's first pass take the window side?  (its plan: the lattice's)
+            d3f_eval_plan side;
+            if (eval_common(views, pts, n, maps, n_maps, mu, flags, out_dist, out_valid, out_fused, out_inter, workspace, workspace_bytes,
+                            stream, mode, &side, grid, lattice, 1) == D3F_OK)
+                for (int s = 0; s < n_maps; ++s)
+                    if (side.staged[s] == 3 && side.reorder == 1) { plan_out->gated_window = 1; plan_out->reserved2 = side.reserved; }
+        }
         plan_out->tile_points = P.tile_pts;
         plan_out->reorder = walk ? 2 : (reorder ? 1 : 0);
         plan_out->lds_bytes = P.crec_offset + P.n_pre * P.tile_pts * P.V * 32 + P.lds_pad;
@@ -595,13 +625,28 @@ int eval_common(const d3f_views *views, const float *pts, int64_t n, const d3f_c
         }
         return D3F_OK;
     }
-    hipEvent_t ev0 = g_prof_start, ev1 = g_prof_stop;
-    g_prof_start = g_prof_stop = nullptr;
+    // a cloud on the gated pair of launches: the window side (this pass) and the cell-run side (the next) read one device word
+    const bool gated_window = cloud_side == 1 && window && !walk && P.order != nullptr;
+    const bool gated_runs = cloud_side == 2;
+    if (gated_window || gated_runs) {
+        P.gate = d3f::order_gate_words(workspace, n);
+        P.gate_min = (uint32_t)D3F_GATE_MIN_FIT;                   // three quarters of the sampled tiles fit their pool
+        if ((flags & D3F_TUNE_WINDOW_SIDE) || exp_knob("D3F_EXP_GATE") > 0) P.gate_min = 0u;          // always the window side
+        if (exp_knob("D3F_EXP_GATE") < 0) P.gate_min = 0xffffffffu;                                    // experiments: always the cell runs
+        P.gate_want = gated_window ? 1 : 0;
+    }
+    hipEvent_t ev0 = g_prof_start, ev1 = gated_window ? nullptr : g_prof_stop;
+    g_prof_start = nullptr;
+    if (!gated_window) g_prof_stop = nullptr;
     if (ev0) (void)hipEventRecord(ev0, hs);
+    if (gated_window) {
+        hipError_t ep = d3f::launch_window_gate_probe(P, d3f::order_gate_words(workspace, n), d3f::kGateSamples, hs);
+        if (ep != hipSuccess) return hip_fail(ep, "window gate probe");
+    }
     hipError_t e = d3f::launch_fused_eval(P, mode, hs);
     if (ev1) (void)hipEventRecord(ev1, hs);
     if (e != hipSuccess) return hip_fail(e, "fused_eval launch");
-    return D3F_OK;
+    return gated_window ? kGatedSecondPass : D3F_OK;
 }
 
 }  // namespace
@@ -624,11 +669,20 @@ int d3f_eval(const d3f_views *views, const float *pts, int64_t n, const d3f_chan
              float mu, uint32_t flags, float *out_dist, uint8_t *out_valid, float *const *out_fused,
              float *const *out_inter, void *workspace, int64_t workspace_bytes, void *stream)
 {
-    return eval_common(views, pts, n, maps, n_maps, mu, flags, out_dist, out_valid, out_fused, out_inter, workspace,
-                       workspace_bytes, stream, 0);
+    int rc = eval_common(views, pts, n, maps, n_maps, mu, flags, out_dist, out_valid, out_fused, out_inter, workspace,
+                         workspace_bytes, stream, 0, nullptr, nullptr, nullptr, 1);
+    if (rc == kGatedSecondPass)         // a cloud: the window launch is enqueued behind its gate; now the cell-run launch behind the same word
+        rc = eval_common(views, pts, n, maps, n_maps, mu, flags | D3F_FLAG_REUSE_POINT_ORDER, out_dist, out_valid, out_fused, out_inter,
+                         workspace, workspace_bytes, stream, 0, nullptr, nullptr, nullptr, 2);
+    return rc;
 }
 
 int64_t d3f_eval_workspace_bytes(int64_t n) { return d3f::order_workspace_bytes(n); }
+
+int64_t d3f_eval_gate_offset(int64_t n)
+{
+    return n <= 0 ? 0 : d3f::order_gate_offset(n);
+}
 
 void d3f_profile_next_eval(void *start_event, void *stop_event)
 {

@@ -61,6 +61,7 @@ struct EvalParams {
     int32_t win_pool_texels;   // pool capacity in texel slices of 512 * win_u bytes
     int32_t win_occ;           // workgroups per CU the kernel variant is built for (2 / 3 / 4)
     int32_t win_lpp;           // lanes per point in phase B: 32, or 16 (two vectors per lane inside a 512-byte slice)
+    int32_t win_sparse;        // 1: the pool holds only the texels the tile's pairs touch (bitmap + ranks), 0: the views' whole rectangles
     int32_t thin_max_views;    // 8 (default): thin maps with 2..8 views are gathered with the views in parallel across lanes
                                // (gather_map_thin); 0 switches that off (D3F_EXP_THIN=-1, tests)
     int32_t runs_occ;      // experiment: waves per SIMD of the (1,8) cell-run kernel variant (4 / 5 / 6)
@@ -71,6 +72,10 @@ struct EvalParams {
     // n_words == 0: the host's D3F_FLAG_FINITE_MAPS alone decides.  All words zero <=> the exact invalid-view skip is allowed.
     int32_t n_words;
     const uint32_t *words[D3F_MAX_MAPS + 1];
+    // device-side choice between the window kernel and the cell-run kernel for a cloud (fuse_eval.hip: gated_out)
+    const uint32_t *gate;  // nullptr: this launch is not gated
+    uint32_t gate_min;     // the window side runs iff *gate >= gate_min, the cell-run side iff *gate < gate_min
+    int32_t gate_want;     // 1: the window side, 0: the cell-run side
     unsigned long long *exp_stamps;   // experiments builds (D3F_EXP_STAMPS=1): s_memtime stamps of every 64th workgroup's phases; else nullptr
     MapDesc maps[D3F_MAX_MAPS];
 };
@@ -78,6 +83,10 @@ struct EvalParams {
 // LDS bytes in front of the stage buffers: records, cnt/flag/idx, KRt, per-view windows
 inline int fused_lds_base(int tile_pts, int V) { return ((tile_pts * V * 24 + tile_pts * 12 + V * 48 + V * 16) + 15) / 16 * 16; }
 hipError_t launch_fused_eval(const EvalParams &P, int mode, hipStream_t stream);
+constexpr int kGateSamples = D3F_GATE_SAMPLES;            // tiles the probe looks at (evenly spaced over the order)
+hipError_t launch_window_gate_probe(const EvalParams &P, uint32_t *gate, int nsamples, hipStream_t stream);
+int64_t order_gate_offset(int64_t n);
+uint32_t *order_gate_words(void *workspace, int64_t n);      // 4 words at the end of a workspace of order_workspace_bytes(n)
 
 // fuse_backward.hip
 struct BackwardParams {

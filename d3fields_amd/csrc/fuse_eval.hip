@@ -739,7 +739,14 @@ __device__ __forceinline__ void window_points_pipelined(const unsigned char *sme
 // vectors per lane 256 bytes apart inside the 512-byte slice, four points per wave instruction)
 // VFIX: 4 / 8 = the view count as a compile-time constant (the host launches that variant when V matches): the point loop
 // runs window_points_pipelined; 0: any V <= 8, view loop of window_point
-template <int U, int VC, int NT, int LPP, int VFIX>
+// SPARSE (round 5): the pool holds only the texels the tile's valid pairs TOUCH, not the whole rectangles.  Phase A marks the four
+// corners of every pair in a bitmap over the views' rectangles (LDS atomics), one wave ranks the set bits, and a pair's nw / sw
+// slots are the ranks of its bits -- ne and se are the next bits of the same rows, hence the next slots, so the records and the
+// point loop are unchanged.  A 64-point tile of a cloud's Hilbert order touches 47 texels where its rectangles hold 74 (C2-patch,
+// scripts/sim_cloud_tiles.py): an 80-slot pool then overflows on 0.5 % of the tiles instead of 19 %.  The price: the copy of slice
+// 0 starts after phase A instead of underneath it.
+constexpr int kWinMaxBits = 2048;            // bitmap bits over all views' rectangles (rows that do not fit are left out)
+template <int U, int VC, int NT, int LPP, int VFIX, bool SPARSE>
 __device__ __forceinline__ void fused_eval_window_body(const EvalParams &P)
 {
     using VT = f32x4;
@@ -778,6 +785,8 @@ __device__ __forceinline__ void fused_eval_window_body(const EvalParams &P)
     __shared__ WinView win_s[kWinMaxViews];
     __shared__ int total_s;
     __shared__ uint32_t texsrc_s[kWinMaxTexels];     // byte offset (from the map's base) of every pool slot's texel
+    __shared__ uint32_t bits_s[SPARSE ? kWinMaxBits / 32 : 1];          // SPARSE: touched texels of the views' rectangles
+    __shared__ uint32_t wpre_s[SPARSE ? kWinMaxBits / 32 : 1];          // ... set bits in front of every word
 
     const bool walk = P.walk_nx > 0;
     const MapDesc &m0 = P.maps[0];
@@ -835,6 +844,8 @@ __device__ __forceinline__ void fused_eval_window_body(const EvalParams &P)
     // ---- 1. KRt, the zero slices, the eight corner points of the set's bounding box ----
     compute_krt(P.K, P.pose, V, krt, NT);
     for (uint32_t t = threadIdx.x; t < 2u * SB / 4u; t += NT) reinterpret_cast<uint32_t *>(smem + zero_off)[t] = 0u;
+    if constexpr (SPARSE)
+        if (threadIdx.x < kWinMaxBits / 32) bits_s[threadIdx.x] = 0u;
     if (walk) {
         if (threadIdx.x < 8) {
             const int c = threadIdx.x;
@@ -910,7 +921,7 @@ __device__ __forceinline__ void fused_eval_window_body(const EvalParams &P)
         int run = 0;
         for (int vv = 0; vv < V && vv < kWinMaxViews; ++vv) {
             const int nv = __builtin_amdgcn_readlane(ntex, vv * 8), bwv = __builtin_amdgcn_readlane(w.bw, vv * 8);
-            int rows = nv > 0 ? min(nv, P.win_pool_texels - run) / bwv : 0;
+            int rows = nv > 0 ? min(nv, (SPARSE ? kWinMaxBits : P.win_pool_texels) - run) / bwv : 0;      // SPARSE: `base` counts bitmap bits
             if (rows < 2) rows = 0;                              // a bilinear footprint needs two rows
             if (vv == v) { w.base = run; w.ok = rows > 0 ? 1 : 0; w.bh = rows > 0 ? rows : w.bh; }
             run += rows * bwv;
@@ -925,18 +936,22 @@ __device__ __forceinline__ void fused_eval_window_body(const EvalParams &P)
     // where every pool slot's texel lives in the map: one lane per slot, once per workgroup (the view search and the
     // division by the window width cost ~100 VALU instructions; done per copy instruction and slice they were a third
     // of the kernel's VALU work)
-    for (int t = threadIdx.x; t < total_s; t += NT) {
+    // (texel of position `t` of the views' rectangles, row-major per view in view order: a pool slot, or with SPARSE a bitmap bit)
+    auto rect_texel = [&](int t) -> uint32_t {
         int v = 0;
         for (int vv = 1; vv < V && vv < kWinMaxViews; ++vv)
             if (win_s[vv].ok && t >= win_s[vv].base) v = vv;          // bases ascend over the views that have a window
         const WinView w = win_s[v];
         const int local = t - w.base;
-        // local / bw for 0 <= local < 320, 1 <= bw <= 320 through the float reciprocal: (local + 0.5) / bw is at least 1/(2 bw)
+        // local / bw for 0 <= local < 2048, 1 <= bw <= 2048 through the float reciprocal: (local + 0.5) / bw is at least 1/(2 bw)
         // away from every integer, far more than the rounding of rcp and the product -- exact, at a tenth of the integer division
         const int y = (int)(((float)local + 0.5f) * __builtin_amdgcn_rcpf((float)w.bw)), x = local - y * w.bw;
-        texsrc_s[t] = (uint32_t)(((int64_t)v * m0.sv + (int64_t)(w.ymin + y) * m0.sy + (int64_t)(w.xmin + x) * m0.sx) * 4);
+        return (uint32_t)(((int64_t)v * m0.sv + (int64_t)(w.ymin + y) * m0.sy + (int64_t)(w.xmin + x) * m0.sx) * 4);
+    };
+    if constexpr (!SPARSE) {
+        for (int t = threadIdx.x; t < total_s; t += NT) texsrc_s[t] = rect_texel(t);
+        __syncthreads();
     }
-    __syncthreads();
     // copy of slice `sl` of every window into the pool: 512-byte granules, two per wave instruction
     auto stage = [&](int sl) {
         const int total = total_s * U;              // granules
@@ -951,7 +966,7 @@ __device__ __forceinline__ void fused_eval_window_body(const EvalParams &P)
                                              16, 0, 0);
         }
     };
-    stage(0);
+    if constexpr (!SPARSE) stage(0);
     D3F_STAMP();                                    // 3: slot table, DMA of slice 0 issued
 
     // ---- 3. phase A: lane = (point, view), the views of a point adjacent ----
@@ -994,8 +1009,16 @@ __device__ __forceinline__ void fused_eval_window_body(const EvalParams &P)
                     const int ax = (int)fminf(fmaxf(x0, 0.0f), (float)m0.fw) - w.xmin, ay = (int)fminf(fmaxf(y0, 0.0f), (float)m0.fh) - w.ymin;
                     const bool inside = inmap && w.ok && ax >= 0 && ax + 1 < w.bw && ay >= 0 && ay + 1 < w.bh;
                     if (inside) {
-                        wr.nw = pool_off + (uint32_t)(w.base + ay * w.bw + ax) * SB;
-                        wr.sw = wr.nw + (uint32_t)w.bw * SB;
+                        if constexpr (SPARSE) {
+                            // the four corners' bits: nw and ne are neighbours in a row of the rectangle, sw and se in the next one
+                            const uint32_t b0 = (uint32_t)(w.base + ay * w.bw + ax), b1 = b0 + (uint32_t)w.bw;
+                            atomicOr(&bits_s[b0 >> 5], 1u << (b0 & 31u)); atomicOr(&bits_s[(b0 + 1u) >> 5], 1u << ((b0 + 1u) & 31u));
+                            atomicOr(&bits_s[b1 >> 5], 1u << (b1 & 31u)); atomicOr(&bits_s[(b1 + 1u) >> 5], 1u << ((b1 + 1u) & 31u));
+                            wr.nw = b0; wr.sw = b1;                              // bit indices until the ranks exist (below)
+                        } else {
+                            wr.nw = pool_off + (uint32_t)(w.base + ay * w.bw + ax) * SB;
+                            wr.sw = wr.nw + (uint32_t)w.bw * SB;
+                        }
                         wr.w[0] = sy * ex; wr.w[1] = sy * tx; wr.w[2] = ty * ex; wr.w[3] = ty * tx;      // folded below
                     } else {
                         wr.valid = kWinDirectMark; wr.w[0] = gx; wr.w[1] = gy;       // (nw, sw stay on the zero slices)
@@ -1031,6 +1054,53 @@ __device__ __forceinline__ void fused_eval_window_body(const EvalParams &P)
         }
     }
 
+    if constexpr (SPARSE) {
+        __syncthreads();                            // every pair has marked its corners; flag_s / cnt_s are written
+        if (threadIdx.x < 64) {                     // set bits in front of every bitmap word: one wave, one word per lane
+            const uint32_t pc = (uint32_t)__popc(bits_s[threadIdx.x & (kWinMaxBits / 32 - 1)]);
+            uint32_t incl = pc;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const uint32_t up = __shfl_up(incl, off, 64);
+                if ((int)threadIdx.x >= off) incl += up;
+            }
+            wpre_s[threadIdx.x] = incl - pc;
+            if (threadIdx.x == 63) total_s = (int)min(incl, (uint32_t)P.win_pool_texels);
+        }
+        __syncthreads();
+        const uint32_t pool_n = (uint32_t)P.win_pool_texels;
+        auto slot_of = [&](uint32_t b) -> uint32_t { return wpre_s[b >> 5] + (uint32_t)__popc(bits_s[b >> 5] & ((1u << (b & 31u)) - 1u)); };
+        int nbits = 0;
+        for (int vv = 0; vv < V && vv < kWinMaxViews; ++vv)
+            if (win_s[vv].ok) nbits = win_s[vv].base + win_s[vv].bw * win_s[vv].bh;
+        for (int b = threadIdx.x; b < nbits; b += NT)
+            if ((bits_s[b >> 5] >> (b & 31)) & 1u) {
+                const uint32_t slot = slot_of((uint32_t)b);
+                if (slot < pool_n) texsrc_s[slot] = rect_texel(b);
+            }
+        __syncthreads();
+        stage(0);                                   // the copy of slice 0 runs underneath the record fix-up
+        // the records' bit indices become pool offsets; a pair whose texels did not get a slot (more touched texels than the pool
+        // holds: rare) becomes a direct pair -- its gx, gy are projected again (no depth lookup: the pair is valid)
+        for (int idx = threadIdx.x; idx < TP * (1 << pa_log2); idx += NT) {
+            const int p = idx >> pa_log2, v = idx & ((1 << pa_log2) - 1);
+            if (v >= V || (flag_s[p] & kWinStrict)) continue;
+            WinRec *wr = wrec_at(p) + v;
+            if (wr->valid != 1.0f) continue;                 // invalid (zero slices) or direct already
+            const uint32_t sn = slot_of(wr->nw), ss = slot_of(wr->sw);
+            if (sn + 1u < pool_n && ss + 1u < pool_n) {
+                wr->nw = pool_off + sn * SB; wr->sw = pool_off + ss * SB;
+            } else {
+                float px, py, pz;
+                slot_coords(p, slot_point(p), px, py, pz);
+                const Proj pr = project_point(krt + v * 12, px, py, pz, Wm1, Hm1);
+                wr->nw = zero_off; wr->sw = zero_off; wr->valid = kWinDirectMark;
+                wr->wgt = fold_scale(wr->wgt, cnt_s[p]);
+                wr->w[0] = pr.gx; wr->w[1] = pr.gy;
+                atomicOr(&flag_s[p], kWinHasDirect);
+            }
+        }
+    }
     D3F_STAMP();                                    // 4: phase A
     // ---- 4. phase B per slice: LPP lanes per point ----
     // (Round 4 also measured storing a slice's rows only after the next slice's DMA is issued -- gfx950 counts loads and
@@ -1209,8 +1279,162 @@ __device__ __forceinline__ void fused_eval_window_body(const EvalParams &P)
 
 // (NT lanes per workgroup: 512 lanes over the same 64-point brick -- twice the waves per pool -- measured no faster
 // at 2, 3 or 4 workgroups per CU: 0.58-0.71 ms on C2 patch against 0.58; only the 256-lane form is built)
-template <int U, int VC, int WAVES, int NT = kBlock, int LPP = 32, int VFIX = 0>
-__global__ __launch_bounds__(NT, WAVES) void fused_eval_window_kernel(const EvalParams P) { fused_eval_window_body<U, VC, NT, LPP, VFIX>(P); }
+// ---- window kernel or cell runs for a cloud?  decided on the device (round 5) --------------------------------------------------
+// Whether 64 consecutive points of a cloud's Hilbert order touch few enough texels for the pool depends on the cloud's density
+// against the texel grid (C2-patch, 1 M points: 47 texels per tile; 100 k keypoints: 105; config 4's 8 views x 6.7-mm texels: 176) --
+// nothing the host knows without reading the points.  So for a cloud BOTH launches are enqueued, each gated on one device word:
+// window_gate_probe_kernel counts, over <= kGateSamples evenly spaced tiles, those whose touched texels fit the pool (the window
+// kernel's own steps 1-3: box, rectangles, bitmap), the last workgroup to finish publishes the count, and each kernel's workgroups
+// return at once unless the count is on their side of `gate_min`.  No host sync, capturable in a HIP graph; the losing launch
+// costs its dispatch (a few microseconds).
+__device__ __forceinline__ bool gated_out(const EvalParams &P)
+{
+    if (!P.gate) return false;
+    const uint32_t fit = __builtin_nontemporal_load(P.gate);
+    return (fit >= P.gate_min) != (P.gate_want != 0);
+}
+
+template <int U, int VC, int WAVES, int NT = kBlock, int LPP = 32, int VFIX = 0, bool SPARSE = false>
+__global__ __launch_bounds__(NT, WAVES) void fused_eval_window_kernel(const EvalParams P)
+{
+    if (gated_out(P)) return;
+    fused_eval_window_body<U, VC, NT, LPP, VFIX, SPARSE>(P);
+}
+
+// gate[0] verdict (tiles that fit), gate[1] running count, gate[2] workgroups done; [1] and [2] are zero between launches
+// (order_clear_kernel zeroes them with the counting table; the last workgroup resets them)
+__global__ __launch_bounds__(kBlock) void window_gate_probe_kernel(const EvalParams P, uint32_t *__restrict__ gate, int nsamples)
+{
+    __shared__ float krt[kWinMaxViews * 12];
+    __shared__ float cpt_s[8][3];
+    __shared__ float red_s[kBlock / 64][6];
+    __shared__ WinView win_s[kWinMaxViews];
+    __shared__ uint32_t bits_s[kWinMaxBits / 32];
+    const int V = P.V, TP = P.tile_pts;
+    const MapDesc &m0 = P.maps[0];
+    const int64_t ntiles = (P.n + TP - 1) / TP;
+    const int64_t tile = (int64_t)blockIdx.x * ntiles / nsamples;
+    const int64_t tile_base = tile * TP;
+    const int tile_n = (int)min((int64_t)TP, P.n - tile_base);
+    const float Wm1 = (float)(P.W - 1), Hm1 = (float)(P.H - 1);
+    auto point_at = [&](int p, float &px, float &py, float &pz) {
+        const int64_t q = tile_base + min(p, tile_n - 1);
+        fetch_point(P, P.order ? min((int64_t)P.order[q], P.n - 1) : q, px, py, pz);
+    };
+    compute_krt(P.K, P.pose, V, krt, kBlock);
+    if (threadIdx.x < kWinMaxBits / 32) bits_s[threadIdx.x] = 0u;
+    // step 1: the tile's bounding box
+    {
+        float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+        for (int p = threadIdx.x; p < tile_n; p += kBlock) {
+            float q[3];
+            point_at(p, q[0], q[1], q[2]);
+#pragma unroll
+            for (int k = 0; k < 3; ++k) { lo[k] = fminf(lo[k], q[k]); hi[k] = fmaxf(hi[k], q[k]); }
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1)
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                lo[k] = fminf(lo[k], __shfl_xor(lo[k], off, 64));
+                hi[k] = fmaxf(hi[k], __shfl_xor(hi[k], off, 64));
+            }
+        if ((threadIdx.x & 63) == 0)
+#pragma unroll
+            for (int k = 0; k < 3; ++k) { red_s[threadIdx.x >> 6][k] = lo[k]; red_s[threadIdx.x >> 6][3 + k] = hi[k]; }
+        __syncthreads();
+        if (threadIdx.x < 8) {
+            const int c = threadIdx.x;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                float a = red_s[0][k], b = red_s[0][3 + k];
+                for (int w = 1; w < kBlock / 64; ++w) { a = fminf(a, red_s[w][k]); b = fmaxf(b, red_s[w][3 + k]); }
+                cpt_s[c][k] = ((c >> k) & 1) ? b : a;
+            }
+        }
+    }
+    __syncthreads();
+    // step 2: one texel rectangle per view (wave 0, lane = view * 8 + corner), bitmap bits in view order
+    if (threadIdx.x < 64) {
+        const int lane = threadIdx.x, v = lane >> 3, c = lane & 7;
+        const bool act = v < V && V <= kWinMaxViews;
+        float xl = 0.0f, xh = 0.0f, yl = 0.0f, yh = 0.0f;
+        int ok = 0;
+        if (act) {
+            const Proj pr = project_point(krt + v * 12, cpt_s[c][0], cpt_s[c][1], cpt_s[c][2], Wm1, Hm1);
+            const float ix = unnormalize(pr.gx, m0.fw), iy = unnormalize(pr.gy, m0.fh);
+            ok = (pr.ok && pr.zc > 1e-4f && isfinite(ix) && isfinite(iy)) ? 1 : 0;
+            xl = xh = ix; yl = yh = iy;
+        }
+#define D3F_WIN_RED(CTRL)                                                                                   \
+        xl = fminf(xl, dpp_f<CTRL>(xl)); xh = fmaxf(xh, dpp_f<CTRL>(xh));                                   \
+        yl = fminf(yl, dpp_f<CTRL>(yl)); yh = fmaxf(yh, dpp_f<CTRL>(yh));                                   \
+        ok &= dpp_i<CTRL>(ok);
+        D3F_WIN_RED(0xB1) D3F_WIN_RED(0x4E) D3F_WIN_RED(0x141)
+#undef D3F_WIN_RED
+        WinView w = {0, 0, 1, 1, 0, 0};
+        int ntex = 0;
+        if (ok) {
+            const float fwm1 = (float)(m0.fw - 1), fhm1 = (float)(m0.fh - 1);
+            const int x0 = (int)fminf(fmaxf(floorf(xl - 1e-3f), 0.0f), fwm1), x1 = (int)fminf(fmaxf(floorf(xh + 1e-3f) + 1.0f, 0.0f), fwm1);
+            const int y0 = (int)fminf(fmaxf(floorf(yl - 1e-3f), 0.0f), fhm1), y1 = (int)fminf(fmaxf(floorf(yh + 1e-3f) + 1.0f, 0.0f), fhm1);
+            w.xmin = x0; w.ymin = y0; w.bw = x1 - x0 + 1; w.bh = y1 - y0 + 1;
+            ntex = w.bw * w.bh;
+        }
+        int run = 0;
+        for (int vv = 0; vv < V && vv < kWinMaxViews; ++vv) {
+            const int nv = __builtin_amdgcn_readlane(ntex, vv * 8), bwv = __builtin_amdgcn_readlane(w.bw, vv * 8);
+            int rows = nv > 0 ? min(nv, kWinMaxBits - run) / bwv : 0;
+            if (rows < 2) rows = 0;
+            if (vv == v) { w.base = run; w.ok = rows > 0 ? 1 : 0; w.bh = rows > 0 ? rows : w.bh; }
+            run += rows * bwv;
+        }
+        if (act && c == 0) win_s[v] = w;
+    }
+    __syncthreads();
+    // step 3: every valid pair marks its four corner texels; a pair outside its rectangle counts as a miss for the tile
+    const int vp_log2 = V <= 1 ? 0 : (V <= 2 ? 1 : (V <= 4 ? 2 : 3));
+    int outside = 0;
+    for (int idx = threadIdx.x; idx < (tile_n << vp_log2); idx += kBlock) {
+        const int p = idx >> vp_log2, v = idx & ((1 << vp_log2) - 1);
+        if (v >= V) continue;
+        float px, py, pz, wgt;
+        point_at(p, px, py, pz);
+        const ViewOut o = eval_view<0>(P.depth, P.H, P.W, krt + v * 12, v, px, py, pz, Wm1, Hm1, P.mu, wgt);
+        if (o.valid == 0.0f) continue;
+        const float x0 = floorf(unnormalize(o.gx, m0.fw)), y0 = floorf(unnormalize(o.gy, m0.fh));
+        const WinView w = win_s[v];
+        const bool inmap = x0 >= 0.0f && x0 <= (float)(m0.fw - 2) && y0 >= 0.0f && y0 <= (float)(m0.fh - 2);
+        if (!inmap) continue;                               // image border: a direct pair in any case
+        const int ax = (int)x0 - w.xmin, ay = (int)y0 - w.ymin;
+        if (w.ok && ax >= 0 && ax + 1 < w.bw && ay >= 0 && ay + 1 < w.bh) {
+            const uint32_t b0 = (uint32_t)(w.base + ay * w.bw + ax), b1 = b0 + (uint32_t)w.bw;
+            atomicOr(&bits_s[b0 >> 5], 1u << (b0 & 31u)); atomicOr(&bits_s[(b0 + 1u) >> 5], 1u << ((b0 + 1u) & 31u));
+            atomicOr(&bits_s[b1 >> 5], 1u << (b1 & 31u)); atomicOr(&bits_s[(b1 + 1u) >> 5], 1u << ((b1 + 1u) & 31u));
+        } else {
+            outside = 1;
+        }
+    }
+    const int any_outside = __syncthreads_or(outside);
+    if (threadIdx.x < 64) {
+        uint32_t pc = (uint32_t)__popc(bits_s[threadIdx.x]);
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) pc += __shfl_xor(pc, off, 64);
+        if (threadIdx.x == 0) {
+            const uint32_t fits = (!any_outside && pc <= (uint32_t)P.win_pool_texels) ? 1u : 0u;
+            const uint32_t before = atomicAdd(&gate[1], fits);
+            __threadfence();
+            const uint32_t done = atomicAdd(&gate[2], 1u);
+            (void)before;
+            if (done == (uint32_t)nsamples - 1u) {          // the last workgroup: publish and reset
+                __threadfence();
+                const uint32_t total = atomicAdd(&gate[1], 0u);
+                gate[0] = total;
+                gate[1] = 0u; gate[2] = 0u;
+            }
+        }
+    }
+}
 
 // Entry points over one body: the plain kernel (<= 3 channel vectors per lane) is held to 128 VGPRs = 4 waves per SIMD
 // (125 allocated) -- the gather lives on memory-level parallelism; the WIDE variant adds the 4-vector load-use path
@@ -1235,7 +1459,14 @@ __global__ __launch_bounds__(kBlock) void fused_eval_f16_kernel(const EvalParams
 template <int MODE, int RU, int RK, int WAVES>
 __global__ __launch_bounds__(kBlock, WAVES) void fused_eval_runs_kernel(const EvalParams P)
 {
+    if (gated_out(P)) return;
     fused_eval_body<MODE, false, false, RU, RK>(P);
+}
+
+hipError_t launch_window_gate_probe(const EvalParams &P, uint32_t *gate, int nsamples, hipStream_t stream)
+{
+    hipLaunchKernelGGL(window_gate_probe_kernel, dim3((unsigned)nsamples), dim3(kBlock), 0, stream, P, gate, nsamples);
+    return hipGetLastError();
 }
 
 hipError_t launch_fused_eval(const EvalParams &P, int mode, hipStream_t stream)
@@ -1257,14 +1488,19 @@ hipError_t launch_fused_eval(const EvalParams &P, int mode, hipStream_t stream)
         const size_t lds_w = (size_t)P.win_pool_offset + (size_t)(2 + P.win_pool_texels) * 512 * P.win_u;
         dim3 gw((unsigned)((P.n + P.tile_pts - 1) / P.tile_pts));
         if (P.walk_nx > 0) gw = dim3((unsigned)ntiles);
-#define D3F_WIN_LAUNCH_F(U_, VC_, W_, LPP_, VF_)                                                                               \
+#define D3F_WIN_LAUNCH_S(U_, VC_, W_, LPP_, VF_, SP_)                                                                          \
         do {                                                                                                                       \
             if (lds_w > 64 * 1024) {                                                                                               \
-                hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void *>(&fused_eval_window_kernel<U_, VC_, W_, kBlock, LPP_, VF_>), \
+                hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void *>(&fused_eval_window_kernel<U_, VC_, W_, kBlock, LPP_, VF_, SP_>), \
                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_w);                      \
                 if (ea != hipSuccess) return ea;                                                                                   \
             }                                                                                                                      \
-            hipLaunchKernelGGL((fused_eval_window_kernel<U_, VC_, W_, kBlock, LPP_, VF_>), gw, block, lds_w, stream, P);           \
+            hipLaunchKernelGGL((fused_eval_window_kernel<U_, VC_, W_, kBlock, LPP_, VF_, SP_>), gw, block, lds_w, stream, P);      \
+        } while (0)
+#define D3F_WIN_LAUNCH_F(U_, VC_, W_, LPP_, VF_)                                                                               \
+        do {                                                                                                                       \
+            if (P.win_sparse) D3F_WIN_LAUNCH_S(U_, VC_, W_, LPP_, VF_, true);                                                      \
+            else D3F_WIN_LAUNCH_S(U_, VC_, W_, LPP_, VF_, false);                                                                  \
         } while (0)
 #define D3F_WIN_LAUNCH(U_, VC_, W_, LPP_) D3F_WIN_LAUNCH_F(U_, VC_, W_, LPP_, 0)
         // the product library holds the variants the planner picks by itself: 16 lanes x two vectors per point, at 4 or 3
@@ -1280,12 +1516,12 @@ hipError_t launch_fused_eval(const EvalParams &P, int mode, hipStream_t stream)
         else if (lpp16 && vfix == 0 && P.win_vc == 2) D3F_WIN_LAUNCH_F(1, 2, 3, 16, 0);
         else
 #endif
-        if (lpp16 && vfix == 4 && P.win_occ >= 4) D3F_WIN_LAUNCH_F(1, 1, 4, 16, 4);
-        else if (lpp16 && vfix == 4) D3F_WIN_LAUNCH_F(1, 1, 3, 16, 4);
-        else if (lpp16 && vfix == 8 && P.win_occ >= 4) D3F_WIN_LAUNCH_F(1, 1, 4, 16, 8);
-        else if (lpp16 && vfix == 8) D3F_WIN_LAUNCH_F(1, 1, 3, 16, 8);
-        else if (lpp16 && P.win_occ >= 4) D3F_WIN_LAUNCH(1, 1, 4, 16);
-        else if (lpp16) D3F_WIN_LAUNCH(1, 1, 3, 16);
+        // ONE register budget (<= 128 VGPRs: four waves per SIMD) serves every pool size: the workgroups per CU follow from the
+        // dynamic LDS of the launch (win_occ sized the pool), not from the kernel variant -- up to round 4 a second set held to
+        // __launch_bounds__(256, 3) existed and allocated 121 instead of 125 registers, the same occupancy step
+        if (lpp16 && vfix == 4) D3F_WIN_LAUNCH_F(1, 1, 4, 16, 4);
+        else if (lpp16 && vfix == 8) D3F_WIN_LAUNCH_F(1, 1, 4, 16, 8);
+        else if (lpp16) D3F_WIN_LAUNCH(1, 1, 4, 16);
 #ifdef D3F_EXPERIMENTS
         else if (P.win_u == 1 && P.win_occ >= 4) D3F_WIN_LAUNCH(1, 4, 4, 32);
         else if (P.win_u == 1 && P.win_occ == 3) D3F_WIN_LAUNCH(1, 4, 3, 32);
@@ -1300,6 +1536,7 @@ hipError_t launch_fused_eval(const EvalParams &P, int mode, hipStream_t stream)
 #endif
 #undef D3F_WIN_LAUNCH
 #undef D3F_WIN_LAUNCH_F
+#undef D3F_WIN_LAUNCH_S
         return hipGetLastError();
     }
     if (mode == 0 && P.sl_slices > 0) {

@@ -78,9 +78,10 @@ constexpr int kExactCell = 256;           // cells of more points than this are 
 
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
-__global__ __launch_bounds__(kBlock) void order_clear_kernel(uint32_t *__restrict__ table)
+__global__ __launch_bounds__(kBlock) void order_clear_kernel(uint32_t *__restrict__ table, uint32_t *__restrict__ gate)
 {
     reinterpret_cast<uint4 *>(table)[(int64_t)blockIdx.x * kBlock + threadIdx.x] = make_uint4(0u, 0u, 0u, 0u);
+    if (blockIdx.x == 0 && threadIdx.x < 4) gate[threadIdx.x] = 0u;       // the window / cell-run gate of this order (fuse_eval.hip)
 }
 
 // MORTON: the Z-curve keys of rounds 1-4 (experiments builds keep them for same-box comparisons)
@@ -140,7 +141,17 @@ int64_t order_workspace_bytes(int64_t n)
 {
     if (n <= 0) return 0;
     // keys | ranks | order | slots | slot keys | cell counters + scan scratch
+    return (int64_t)(5 * align_up((size_t)n * 4, 256) + (size_t)kCells * 4 + (size_t)scan_scratch_bytes(kCells) + 256);
+}
+
+int64_t order_gate_offset(int64_t n)
+{
     return (int64_t)(5 * align_up((size_t)n * 4, 256) + (size_t)kCells * 4 + (size_t)scan_scratch_bytes(kCells));
+}
+
+uint32_t *order_gate_words(void *workspace, int64_t n)
+{
+    return reinterpret_cast<uint32_t *>(static_cast<unsigned char *>(workspace) + order_gate_offset(n));
 }
 
 // Fills *order_out with a pointer (inside the workspace) to n uint32 indices in Hilbert-cell order.
@@ -165,7 +176,7 @@ hipError_t build_point_order(const float *pts, int64_t n, void *workspace, int64
     while (bits < 21 && (1LL << bits) < 4 * n) bits += 1;
     const int shift = 27 - bits;
     const int64_t cells = 1LL << bits;
-    hipLaunchKernelGGL(order_clear_kernel, dim3((unsigned)(cells / 4 / kBlock)), dim3(kBlock), 0, stream, table);
+    hipLaunchKernelGGL(order_clear_kernel, dim3((unsigned)(cells / 4 / kBlock)), dim3(kBlock), 0, stream, table, order_gate_words(workspace, n));
     if (curve == 1) hipLaunchKernelGGL(cell_count_kernel<true>, dim3(nb), dim3(kBlock), 0, stream, pts, n, keys, ranks, table, shift);
     else hipLaunchKernelGGL(cell_count_kernel<false>, dim3(nb), dim3(kBlock), 0, stream, pts, n, keys, ranks, table, shift);
     hipError_t e = launch_exclusive_scan_u32(table, table, cells, scan_scratch, stream);

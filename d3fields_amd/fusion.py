@@ -497,7 +497,10 @@ class Fusion:
             w0 = [s for s in range(n_maps) if plan.staged[s] == 3][0]           # the windowed map (any position in the call)
             # (the last template argument: the view count as a compile-time constant, 4 / 8 -> software-pipelined point loop)
             vfix = int(views.V) if (int(views.V) in (4, 8) and int(plan.tile_points) == 64 and plan.lanes_per_point[w0] == 16) else 0
-            kernel = "fused_eval_window_kernel<%d, %d, %d, 256, %d, %d>" % (r // 100, r // 10 % 10, r % 10, plan.lanes_per_point[w0], vfix)
+            # (third argument: the register budget the variant is built for -- 4 waves per SIMD for every 16-lane variant; the plan's
+            #  last digit is the workgroups per CU the POOL is sized for)
+            kernel = "fused_eval_window_kernel<%d, %d, %d, 256, %d, %d, %s>" % (r // 100, r // 10 % 10, 4 if plan.lanes_per_point[w0] == 16 else r % 10, plan.lanes_per_point[w0], vfix,
+                                                                              "false" if lattice is not None else "true")
         elif plan.reserved >= 100:
             lg, vc = (plan.reserved - 100) // 10, (plan.reserved - 100) % 10
             kernel = "fused_eval_sliced_kernel<%d, %d, %d>" % (lg, vc, {1: 8, 2: 7, 4: 5}.get(vc, 5))
@@ -505,7 +508,7 @@ class Fusion:
             s0 = [s for s in range(n_maps) if plan.staged[s] >= 16][0]
             kernel = "fused_eval_runs_kernel<0, %d, %d, %d>" % (plan.vectors_per_lane[s0], plan.staged[s0] - 16, plan.reserved)
         sliced = 100 <= plan.reserved < 200
-        order = {2: "closed-form brick walk of the lattice (no keys, no sort)", 1: "Morton-cell order (counting sort by 16-mm cell + 4-mm refinement, hand-written)",
+        order = {2: "closed-form brick walk of the lattice (no keys, no sort)", 1: "Hilbert-cell order (counting sort by 16-mm cell + exact rank of the 4-mm keys inside, hand-written)",
                  0: "caller order"}[int(plan.reorder)]
         order += "; channel-sliced over the XCDs" if sliced else ""
         if window:
@@ -513,7 +516,26 @@ class Fusion:
         elif runs:
             order += "; cell runs of %d consecutive points" % (max(plan.staged[s] for s in range(n_maps)) - 16)
         self._last_plan = {"kernel": kernel, "tile_points": int(plan.tile_points), "point_order": order,
-                           "workgroups": int(plan.workgroups), "lattice": lattice}
+                           "workgroups": int(plan.workgroups), "lattice": lattice, "gated_window": bool(plan.gated_window)}
+        if plan.gated_window:
+            # a cloud on the gated pair of launches (ABI 5): the fields above describe the cell-run side; the window side is the
+            # sparse-pool window kernel on 64-point tiles of the same order.  last_gate() says which one ran.
+            r = int(plan.reserved2) - 2000
+            self._last_plan["window_side"] = {
+                "kernel": "fused_eval_window_kernel<%d, %d, 4, 256, 16, %d, true>" % (r // 100, r // 10 % 10, int(views.V) if int(views.V) in (4, 8) else 0),
+                "tile_points": 64,
+                "point_order": order.split(";")[0] + "; 64-point tiles through touched-texel windows in LDS (device-gated against the cell runs)"}
+
+    def last_gate(self):
+        """After a query of a cloud that got the gated pair of launches (last_plan()['gated_window']): (tiles of the probe's sample
+        that fit the window kernel's pool, True if the window side ran).  ONE host sync; diagnostics (bench.py, tests) only."""
+        ws = getattr(self, "_last_ws", None)
+        if ws is None or getattr(self, "_last_ws_n", 0) <= 0:
+            return None
+        off = int(self._lib.d3f_eval_gate_offset(self._last_ws_n))
+        fit = int(ws[off:off + 4].view(torch.int32).item())
+        forced = bool(self._query_flags() & _lib.TUNE_WINDOW_SIDE)
+        return fit, bool(forced or fit >= _lib.GATE_MIN_FIT)
 
     def _run(self, pts, return_names, return_inter, mode):
         self._check_query(pts)
@@ -623,6 +645,7 @@ class Fusion:
                         self._order_ws = (sig, ws, bool(plan.reorder))      # filled by this call iff the library reorders
             if self.record_plans:
                 self._record_plan(views, n, maps, len(names), flags, ws is not None, return_inter, None)
+            self._last_ws, self._last_ws_n = ws, n
             _lib.check(lib.d3f_eval(ctypes.byref(views), _lib.ptr(pts_c), n, maps, len(names), self.mu, flags,
                                     _lib.ptr(dist), _lib.ptr(valid), fused, inter if return_inter else None,
                                     _lib.ptr(ws), ws_bytes, stream))

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define D3F_ABI_VERSION 4
+#define D3F_ABI_VERSION 5
 
 #define D3F_OK 0
 #define D3F_ERR_INVALID_ARG (-1)  /* null pointer, negative count, bad enum               */
@@ -63,9 +63,9 @@ extern "C" {
                                           bit-exact either way.  Slower: the direct gather, no view skipping.              */
 #define D3F_FLAG_UNORDERED_POINTS 2u /* the caller's point order has no spatial locality (shuffled or \
                                         uniformly random cloud; see d3f_point_order_locality): walk the \
-                                        points in Morton order even when the maps are small.  Performance \
+                                        points in Hilbert order even when the maps are small.  Performance \
                                         only -- results never depend on it.                              */
-#define D3F_FLAG_REUSE_POINT_ORDER 8u /* `workspace` still holds the Morton order that an earlier d3f_eval call wrote  \
+#define D3F_FLAG_REUSE_POINT_ORDER 8u /* `workspace` still holds the point order that an earlier d3f_eval call wrote  \
                                          for the SAME pts / n (a static grid queried every frame): do not rebuild it   \
                                          (~0.12 ms per 1 M points).  Any permutation of 0..n-1 gives the same results; \
                                          a buffer that holds anything else is the caller's error.                      */
@@ -78,6 +78,8 @@ extern "C" {
  *   bit  14     always reorder points when a workspace is supplied
  *   bit   4     D3F_TUNE_DIRECT_GATHER: the plain direct gather in the chosen point order -- no LDS texel windows, no cell
  *               runs, no channel slices, thin maps view by view.  Every fast path is bit-identical to it (tests/).
+ *   bit   5     D3F_TUNE_NO_WINDOW_GATE: a cloud never gets the gated pair of launches (LDS texel windows / cell runs chosen by a
+ *               device-side probe, ABI 5): cell runs only.  bit 6  D3F_TUNE_WINDOW_SIDE: the gate always opens the window side.
  *   bits 24..25 Morton cell: 16 mm >> k (k = 0..2);  bit 26 / 27 force batched / load-use corner loads;
  *               bit 28 do not precompute corner set-ups in phase A;  bits 29..31 XCD-mapping chunk = 1024 << (k-1) tiles
  *   bits 16..23 extra dynamic LDS per workgroup in KiB (throttles workgroups per CU); 255 = none      */
@@ -86,6 +88,8 @@ extern "C" {
 #define D3F_TUNE_NO_REORDER (1u << 13)
 #define D3F_TUNE_FORCE_REORDER (1u << 14)
 #define D3F_TUNE_DIRECT_GATHER (1u << 4)
+#define D3F_TUNE_NO_WINDOW_GATE (1u << 5)
+#define D3F_TUNE_WINDOW_SIDE (1u << 6)
 #define D3F_TUNE_LDS_PAD_KIB(k) (((uint32_t)(k) & 0xFFu) << 16)
 
 /* Calibrated views: the part of Fusion.curr_obs_torch read by every query
@@ -149,8 +153,19 @@ int d3f_eval(const d3f_views *views, const float *pts, int64_t n, const d3f_chan
 
 /* Optional device scratch for d3f_eval (NULL/0 is always accepted).  With at least
  * d3f_eval_workspace_bytes(n) bytes the library may walk the points in a cache-friendlier
- * (Morton) order when the maps are much larger than the caches; outputs are unaffected. */
+ * (Hilbert) order when the maps are much larger than the caches or the caller declares the points
+ * unordered; outputs are unaffected. */
 int64_t d3f_eval_workspace_bytes(int64_t n);
+
+/* ABI 5.  For a CLOUD of >= 262 144 points in the Hilbert order on a patch-resolution wide map d3f_eval enqueues TWO fused
+ * launches -- the LDS texel-window kernel and the cell-run kernel -- behind one device word: a probe kernel counts, over
+ * D3F_GATE_SAMPLES evenly spaced 64-point tiles of the order, those whose touched texels fit the window kernel's pool, and the
+ * workgroups of the side that lost return at once (no host sync; which kernel suits a cloud depends on its density against the
+ * texel grid, which only the device knows).  The word lives in the workspace: uint32 at byte offset d3f_eval_gate_offset(n);
+ * after the call has completed, a value >= D3F_GATE_MIN_FIT means the window kernel ran.  Diagnostics only. */
+#define D3F_GATE_SAMPLES 128
+#define D3F_GATE_MIN_FIT 96
+int64_t d3f_eval_gate_offset(int64_t n);
 
 /* Measurement hook: the calling thread's NEXT d3f_eval / d3f_eval_dist records these two hipEvent_t
  * (NULL = none) on its stream immediately before and after the fused kernel launch, i.e. around the
@@ -174,6 +189,9 @@ typedef struct d3f_eval_plan {
     int32_t staged[D3F_MAX_MAPS];           /* 0: direct gather; 3: LDS texel windows per brick (patch-resolution wide
                                                map on a lattice); 16 + K: cell-run gather with runs of K points
                                                (patch-resolution wide maps)                            */
+    int32_t gated_window;                   /* ABI 5.  1: a cloud that gets the gated pair of launches; the fields above describe
+                                               the cell-run side, the window side is the lattice's window plan on 64-point tiles */
+    int32_t reserved2;                      /* gated_window: the window side's `reserved` code (2000 + 100*U + 10*VC + W)       */
 } d3f_eval_plan;
 int d3f_eval_plan_query(const d3f_views *views, int64_t n, const d3f_channel_map *maps, int32_t n_maps,
                         uint32_t flags, int32_t have_workspace, int32_t want_inter, d3f_eval_plan *plan);

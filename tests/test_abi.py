@@ -316,7 +316,17 @@ def test_window_launch_plan(monkeypatch):
     assert plan_lattice(4, (160, 140, 44), [(480, 640, 384)]).staged[0] == 0             # dense map: not a window case
     assert plan_lattice(16, (160, 140, 44), [(48, 64, 384)]).staged[0] != 3              # more than 8 views
     p = _plan(8, 720, 1280, 1000000, [(72, 128, 1024)], flags=_lib.FLAG_FINITE_MAPS | _lib.FLAG_UNORDERED_POINTS)
-    assert (p.staged[0], p.reorder) == (16 + 8, 1)                                       # clouds keep the cell-run gather on the Morton walk
+    assert (p.staged[0], p.reorder, p.gated_window) == (16 + 8, 1, 1)                    # a big cloud: the plan describes the cell-run side of the gated pair ...
+    assert 2000 <= p.reserved2 < 3000 and p.reserved2 % 10 == 3                          # ... and names the window side's kernel (3 workgroups per CU and fewer)
+    p = _plan(8, 720, 1280, 1000000, [(72, 128, 1024)], flags=_lib.FLAG_FINITE_MAPS | _lib.FLAG_UNORDERED_POINTS | _lib.TUNE_NO_WINDOW_GATE)
+    assert (p.staged[0], p.reorder, p.gated_window) == (16 + 8, 1, 0)
+    p = _plan(4, 480, 640, 262143, [(48, 64, 384)], flags=_lib.FLAG_FINITE_MAPS | _lib.FLAG_UNORDERED_POINTS)
+    assert (p.staged[0], p.reorder, p.gated_window) == (16 + 4, 1, 0)                    # kWindowCloudMin = 262 144 points: below it cell runs only
+    p = _plan(4, 480, 640, 262144, [(48, 64, 384)], flags=_lib.FLAG_FINITE_MAPS | _lib.FLAG_UNORDERED_POINTS)
+    assert (p.staged[0], p.reorder, p.gated_window, p.reserved2) == (16 + 4, 1, 1, 2113)
+    assert _plan(4, 480, 640, 985600, [(48, 64, 384)], flags=_lib.FLAG_FINITE_MAPS).gated_window == 0      # caller order (not declared unordered): no gate
+    assert _plan(4, 480, 640, 985600, [(48, 64, 384)], flags=_lib.FLAG_UNORDERED_POINTS).gated_window == 0   # maps not known finite
+    assert _plan(4, 480, 640, 985600, [(48, 64, 384)], flags=_lib.FLAG_FINITE_MAPS | _lib.FLAG_UNORDERED_POINTS, ws=0).gated_window == 0
     if exp:
         monkeypatch.setenv("D3F_EXP_WINDOW", "64")
         p = _plan(8, 720, 1280, 1000000, [(72, 128, 1024)], flags=_lib.FLAG_FINITE_MAPS | _lib.FLAG_UNORDERED_POINTS)

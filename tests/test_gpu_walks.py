@@ -39,13 +39,15 @@ class knobs:
     variable that only an experiments build reads; the product build then simply runs its default launch."""
     REFERENCE = {"D3F_EXP_RUNS": "-1", "D3F_EXP_WINDOW": "-1", "D3F_EXP_THIN": "-1"}
 
-    def __init__(self, **kv):
+    def __init__(self, FLAGS=0, **kv):
         self.kv = {k: str(v) for k, v in kv.items()}
+        self.flags = int(FLAGS)                  # D3F_TUNE_* bits every build honours (e.g. TUNE_WINDOW_SIDE, TUNE_NO_WINDOW_GATE)
         self.direct = bool(self.kv) and all(self.REFERENCE.get(k) == v for k, v in self.kv.items())
 
     def __enter__(self):
         from d3fields_amd import Fusion, _lib
         self.old_flags = Fusion.extra_tuning_flags
+        Fusion.extra_tuning_flags |= self.flags
         if self.direct:
             Fusion.extra_tuning_flags |= _lib.TUNE_DIRECT_GATHER
         self.old = {k: os.environ.get(k) for k in self.kv}
@@ -243,7 +245,8 @@ def test_cell_run_gather_not_used_when_it_must_not(dev):
 # ---- the BENCH workloads themselves ---------------------------------------------------------------
 @pytest.mark.parametrize("workload,points", [("c2_dense", "grid"), ("c3_dense", "grid"), ("c2_patch", "grid"), ("c3_patch", "grid"),
                                              ("c4_patch", "grid"), ("c4_patch", "random"), ("ref_patch", "grid"), ("dist_only", "grid"),
-                                             ("c5_track", "grid")])
+                                             ("c5_track", "grid"), ("c2_patch", "random"), ("c3_patch", "random"), ("ref_patch", "surface"),
+                                             ("c3_patch", "surface")])
 def test_bench_workload_matches_oracle(dev, workload, points):
     """Exactly what bench.py times (same builder, same launch geometry: lattice walk with 8- / 16-point tiles on the
     dense maps, bricks through LDS texel windows on the patch-resolution maps -- config 4's x-slab of the 8 M-point lattice
@@ -252,9 +255,18 @@ def test_bench_workload_matches_oracle(dev, workload, points):
     import bench
     from d3fields_amd import _lib
     f, pts, names, w, sc = bench.build_workload(workload, dev, 0, 1, points)
-    assert pts.shape[0] == (w["N"] if points == "grid" else w.get("N_cloud", w["N"]))
+    if points == "surface":       # the mesh-vertex cloud of vis_repr.py:97-103: a two-voxel shell around the table and the spheres
+        assert 30000 < pts.shape[0] < w["N"] // 10
+    else:
+        assert pts.shape[0] == (w["N"] if points == "grid" else w.get("N_cloud", w["N"]))
     with torch.no_grad():
+        f.record_plans = True
         out = f.batch_eval(pts, return_names=names)
+        if points == "random" and workload in ("c2_patch", "c3_patch"):      # a dense cloud: the device-side gate opens the window side
+            assert f.last_plan()["gated_window"] and f.last_gate()[1], (f.last_plan(), f.last_gate())
+        if points == "random" and workload == "c4_patch":                    # 8 views x 6.7-mm texels: the tiles do not fit, cell runs
+            assert f.last_plan()["gated_window"] and not f.last_gate()[1], (f.last_plan(), f.last_gate())
+        f.record_plans = False
         sub = torch.randperm(pts.shape[0], generator=torch.Generator().manual_seed(9))[:200000].to(dev)
         f.tuning_flags = _lib.TUNE_NO_REORDER
         with knobs(D3F_EXP_RUNS=-1):
@@ -345,7 +357,7 @@ def test_channel_sliced_launch_is_bit_identical(dev, dims, C, mask):
 
 @pytest.mark.parametrize("n,C,hw,mask", [(70001, 384, (96, 128), True), (131072, 1024, (96, 128), False), (65537, 128, (192, 256), False)])
 def test_channel_sliced_launch_on_a_cloud_is_bit_identical(dev, n, C, hw, mask):
-    """A random cloud on maps beyond the caches: the Morton order feeds the channel-sliced kernel (tiles of 16 / 32 consecutive
+    """A random cloud on maps beyond the caches: the Hilbert order feeds the channel-sliced kernel (tiles of 16 / 32 consecutive
     points of the order, one 512-byte slice per workgroup; C = 1024: one slice per XCD).  Same bits as the caller-order
     direct gather, including a strict (NaN) point, a short last tile and the thin map riding along."""
     from d3fields_amd import synth, _lib
@@ -362,7 +374,7 @@ def test_channel_sliced_launch_on_a_cloud_is_bit_identical(dev, n, C, hw, mask):
     with torch.no_grad():
         out = f.batch_eval(pts, return_names=names)
         plan = f.last_plan()
-        assert "Morton" in plan["point_order"] and "channel-sliced" in plan["point_order"], plan
+        assert "Hilbert" in plan["point_order"] and "channel-sliced" in plan["point_order"], plan
         assert plan["kernel"].startswith("fused_eval_sliced_kernel"), plan
         f.tuning_flags = _lib.TUNE_NO_REORDER | _lib.TUNE_DIRECT_GATHER
         base = f.batch_eval(pts, return_names=names)
@@ -424,24 +436,32 @@ def test_window_gather_is_bit_identical(dev, C, V, fhw, mask, points):
     if points == "grid":
         pts_c = create_init_grid(synth.WORK_BOX, 0.0107)[0]                            # 74 x 65 x 20 points
     else:
-        pts_c = synth.random_cloud(150001, seed=3)
+        pts_c = synth.random_cloud(270001, seed=3)                                      # >= 262 144: the gated pair of launches
     pts_c[1000, 1] = float("inf")                                                       # a strict point
     pts = pts_c.to(dev)
     views, keep, _ = f._views(dev)
     m = maps["dino_feats"]
     cm = (_lib.ChannelMap * 1)(_lib.ChannelMap(m.data_ptr(), m.shape[1], m.shape[2], C, 0, m.stride(0), m.stride(1), m.stride(2)))
     plan = _lib.EvalPlan()
-    if points != "grid" and not experiments():
-        pytest.skip("the window kernel takes clouds only when forced (D3F_EXP_WINDOW=64, experiments builds)")
+    if points != "grid":
+        # product build: a cloud gets BOTH launches behind the device-side gate; TUNE_WINDOW_SIDE opens the window side whatever
+        # the probe says (this sparse cloud overflows most pools: the touched-texel pool's direct conversions are exercised)
+        _lib.check(f._lib.d3f_eval_plan_query(ctypes.byref(views), pts.shape[0], cm, 1, _lib.FLAG_FINITE_MAPS | _lib.FLAG_UNORDERED_POINTS, 1, 0, ctypes.byref(plan)))
+        assert plan.gated_window == 1 and plan.staged[0] >= 16 and 2000 <= plan.reserved2 < 3000, "a cloud of this size takes the gated pair"
+        _lib.check(f._lib.d3f_eval_plan_query(ctypes.byref(views), pts.shape[0], cm, 1, _lib.FLAG_FINITE_MAPS | _lib.FLAG_UNORDERED_POINTS | _lib.TUNE_NO_WINDOW_GATE, 1, 0, ctypes.byref(plan)))
+        assert plan.gated_window == 0
     with knobs(D3F_EXP_WINDOW=64):
-        if points == "grid":
+        if points != "grid" and not experiments():
+            pass
+        elif points == "grid":
             _lib.check(f._lib.d3f_eval_plan_query_lattice(ctypes.byref(views), 74, 65, 20, cm, 1, _lib.FLAG_FINITE_MAPS, 0, ctypes.byref(plan)))
             assert plan.reorder == 2 and plan.workgroups == 19 * 17 * 5
         else:
             _lib.check(f._lib.d3f_eval_plan_query(ctypes.byref(views), pts.shape[0], cm, 1, _lib.FLAG_FINITE_MAPS, 1, 0, ctypes.byref(plan)))
-        # (2114 / 2113: four, or three and fewer workgroups per CU -- the pool is sized for ~17 texel slots per view,
-            #  which up to three views get at four workgroups per CU)
-        assert plan.staged[0] == 3 and plan.tile_points == 64 and plan.reserved == (2114 if V <= 3 else 2113), "the window kernel must be what runs here"
+        # (2114 / 2113: four, or three and fewer workgroups per CU -- the pool is sized for ~17 texel slots per view (14 touched
+        #  texels per view for a cloud), which up to three views get at four workgroups per CU)
+        if points == "grid" or experiments():
+            assert plan.staged[0] == 3 and plan.tile_points == 64 and plan.reserved == (2114 if V <= 3 else 2113), "the window kernel must be what runs here"
     variants = [("direct", dict(D3F_EXP_RUNS=-1))]
     for T in (32, 64, 128):
         if (T * (1 if V <= 1 else 2 if V <= 2 else 4 if V <= 4 else 8)) % 64:
@@ -456,8 +476,14 @@ def test_window_gather_is_bit_identical(dev, C, V, fhw, mask, points):
                  # round 4: the plain view loop instead of the software-pipelined point loop (V = 4 / 8), also at 5 / 6 workgroups per CU
                  ("T64 plain loop", dict(D3F_EXP_WINDOW=64, D3F_EXP_WINDOW_PIPE=-1)), ("T64 plain occ5", dict(D3F_EXP_WINDOW=64, D3F_EXP_WINDOW_PIPE=-1, D3F_EXP_WINDOW_OCC=5)),
                  ("T64 plain occ6", dict(D3F_EXP_WINDOW=64, D3F_EXP_WINDOW_PIPE=-1, D3F_EXP_WINDOW_OCC=6))]
+    variants += [("T64 sparse", dict(D3F_EXP_WINDOW=64, D3F_EXP_WINDOW_SPARSE=1)), ("T64 rect", dict(D3F_EXP_WINDOW=64, D3F_EXP_WINDOW_SPARSE=-1)),
+                 ("T64 sparse pool 6", dict(D3F_EXP_WINDOW=64, D3F_EXP_WINDOW_SPARSE=1, D3F_EXP_WINDOW_POOL=6)),
+                 ("T64 sparse plain loop", dict(D3F_EXP_WINDOW=64, D3F_EXP_WINDOW_SPARSE=1, D3F_EXP_WINDOW_PIPE=-1)),
+                 ("T64 contiguous eighths", dict(D3F_EXP_WINDOW=64, D3F_EXP_WINDOW_RR=-1)), ("T64 z-curve", dict(D3F_EXP_WINDOW=64, D3F_EXP_ORDER_MORTON=1))]
     if not experiments():
         variants = [variants[0], ("T64 U1", dict())]                                    # the reference and the default launch
+    if points != "grid":                      # every build: the gate's two sides, each forced, and the gate left to the device
+        variants += [("window side", dict(FLAGS=_lib.TUNE_WINDOW_SIDE)), ("cell-run side", dict(FLAGS=_lib.TUNE_NO_WINDOW_GATE)), ("gated", dict())]
     with torch.no_grad():
         outs = {}
         for tag, env in variants:
@@ -472,6 +498,49 @@ def test_window_gather_is_bit_identical(dev, C, V, fhw, mask, points):
     ref = oracle_sample(sc, pts_c[pick], [maps[k] for k in names])
     assert np.array_equal(cpu(outs["T64 U1"]["dist"])[pick], ref["dist"])
     assert rel_err(cpu(outs["T64 U1"]["dino_feats"])[pick], ref["sets"][0]) <= TOL
+
+
+@pytest.mark.parametrize("V,hw,fhw,C,scale,expect_window", [(4, (480, 640), (48, 64), 384, 0.6, True), (8, (720, 1280), (72, 128), 256, 1.0, False),
+                                                            (4, (480, 640), (48, 64), 128, 0.55, True)])
+def test_cloud_gate_follows_the_density(dev, V, hw, fhw, C, scale, expect_window):
+    """A cloud of >= 262 144 points in the Hilbert order gets the LDS-window launch AND the cell-run launch behind one device word
+    (d3fields_hip.h, ABI 5): the probe counts the sampled 64-point tiles whose touched texels fit the pool -- a dense cloud opens
+    the window side, a cloud that is sparse against the texel grid the cell runs -- and whichever side runs, alone, the outputs are
+    those of the caller-order direct gather bit for bit (a strict point, a short last tile, a thin map riding along)."""
+    from d3fields_amd import synth, _lib
+    H, W = hw
+    maps = {"dino_feats": synth.random_map(V, fhw[0], fhw[1], C, seed=1, device=dev), "mask": synth.random_onehot_mask(V, H, W, 8, seed=2, device=dev)}
+    names = ["dino_feats", "mask"]
+    f, sc = fusion_for(dev, V, H, W, maps)
+    f.record_plans = True
+    pts_c = synth.random_cloud(300001, seed=8) * scale
+    pts_c[777, 0] = float("nan")
+    pts = pts_c.to(dev)
+    with torch.no_grad():
+        out = f.batch_eval(pts, return_names=names)
+        plan, gate = f.last_plan(), f.last_gate()
+        assert plan["gated_window"] and "Hilbert" in plan["point_order"], plan
+        assert gate[1] == expect_window and (gate[0] >= _lib.GATE_MIN_FIT) == expect_window, gate
+        again = f.batch_eval(pts, return_names=names)                      # cached order (D3F_FLAG_REUSE_POINT_ORDER): the probe runs again
+        assert f.last_gate() == gate
+        with knobs(FLAGS=_lib.TUNE_NO_WINDOW_GATE):
+            runs = f.batch_eval(pts, return_names=names)
+            assert not f.last_plan()["gated_window"]
+        with knobs(FLAGS=_lib.TUNE_WINDOW_SIDE):
+            win = f.batch_eval(pts, return_names=names)
+            assert f.last_gate()[1]
+        f.tuning_flags = _lib.TUNE_NO_REORDER
+        with knobs(D3F_EXP_RUNS=-1):
+            base = f.batch_eval(pts, return_names=names)
+    for tag, o in (("gated", out), ("again", again), ("runs", runs), ("window", win)):
+        for k in ["dist", "valid_mask"] + names:
+            a, b = o[k], base[k]
+            assert torch.equal(torch.isnan(a), torch.isnan(b)) and torch.equal(torch.nan_to_num(a.float()), torch.nan_to_num(b.float())), (tag, k)
+    pick = torch.randperm(pts.shape[0], generator=torch.Generator().manual_seed(3))[:1500]
+    pick = pick[pick != 777]
+    ref = oracle_sample(sc, pts_c[pick], [maps[k] for k in names])
+    assert np.array_equal(cpu(out["dist"])[pick], ref["dist"])
+    assert rel_err(cpu(out["dino_feats"])[pick], ref["sets"][0]) <= TOL
 
 
 def test_window_kernel_with_wrong_lattice_dims_is_still_exact(dev):
@@ -637,7 +706,7 @@ def _row_stores_are_deterministic(dev, workload):
         if workload == "sliced":
             f.tuning_flags = _lib.TUNE_FORCE_REORDER                                     # the maps are small here: force the walk
         first = f.batch_eval(pts, return_names=["dino_feats"])
-        want = "fused_eval_window_kernel<1, 1, 3, 256, 16, 4>" if workload == "window" else "fused_eval_sliced_kernel<5, 2, 7>"
+        want = "fused_eval_window_kernel<1, 1, 4, 256, 16, 4, false>" if workload == "window" else "fused_eval_sliced_kernel<5, 2, 7>"
         assert f.last_plan()["kernel"] == want, f.last_plan()
         for i in range(50):
             again = f.batch_eval(pts, return_names=["dino_feats"])

@@ -107,7 +107,7 @@ def test_shard_bounds_cover_everything_once():
             assert max(sizes) - min(sizes) <= 1
 
 
-def test_bench_roofline_numerator_matches_survey():
+def test_bench_roofline_numerator_matches_survey(tmp_path):
     """bench.py's algorithmic bytes are SURVEY.md §8d's: N*(12+4+1+4*sum C) + maps read once + 84*V."""
     import bench
     b, per = bench.algorithmic_bytes(bench.WORKLOADS["c2_dense"], 985600)
@@ -119,10 +119,23 @@ def test_bench_roofline_numerator_matches_survey():
     b, per = bench.algorithmic_bytes(bench.WORKLOADS["ref_patch"], 1925000)
     assert per == 17 + 4 * (1024 + 8 + 3) and b == 1925000 * per + 4 * (4 * 480 * 640 + 4 * 48 * 64 * 1024 + 4 * 480 * 640 * 11) + 336
     assert bench.algorithmic_bytes(bench.WORKLOADS["dist_only"], 123200000) == (123200000 * 17 + 4 * 4 * 480 * 640 + 336, 17)
-    # counter traffic is keyed by workload AND point set AND point count: the lattice kernel's figure is never printed for a cloud
-    assert bench.measured_traffic("c2_dense", "grid", 985600)[0] > 0
-    assert bench.measured_traffic("c2_dense", "grid", 1000)[0] is None
-    assert bench.measured_traffic("nope", "grid", 1) == (None, None, None)
+    # counter traffic is keyed by workload AND point set AND point count AND the fingerprint of the sources the profiled library was
+    # built from: the lattice kernel's figure is never printed for a cloud, and a kernel change without a re-profile prints nothing
+    import json
+    from d3fields_amd import build
+    path = str(tmp_path / "traffic.json")
+    fp = build.source_fingerprint()
+    json.dump({"c2_dense": {"traffic_bytes": 123, "points": 985600, "source": "x", "source_fingerprint": fp},
+               "c2_patch_surface": {"traffic_bytes": 5, "points": 70000, "source": "y", "source_fingerprint": fp},
+               "c3_dense": {"traffic_bytes": 456, "points": 1925000, "source": "z", "source_fingerprint": "0" * 64},
+               "c3_patch": {"traffic_bytes": 789, "points": 1925000, "source": "w"}}, open(path, "w"))
+    assert bench.measured_traffic("c2_dense", "grid", 985600, path)[0] == 123
+    assert bench.measured_traffic("c2_dense", "grid", 1000, path)[0] is None
+    assert bench.measured_traffic("c2_dense", "random", 985600, path)[0] is None
+    assert bench.measured_traffic("c2_patch", "surface", 70000, path)[0] == 5
+    assert bench.measured_traffic("c3_dense", "grid", 1925000, path)[0] is None          # stamped with other sources
+    assert bench.measured_traffic("c3_patch", "grid", 1925000, path)[0] is None          # not stamped at all
+    assert bench.measured_traffic("nope", "grid", 1, path) == (None, None, None)
 
 
 def test_rigid_helpers_match_restated_pytorch3d():

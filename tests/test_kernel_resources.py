@@ -21,9 +21,13 @@ BUDGET = {
     "22fused_eval_runs_kernelILi0ELi1ELi4ELi7E": (72, 0),       # cell runs (1,4), 7 waves
     "22fused_eval_runs_kernelILi0ELi2ELi8ELi3E": (168, 0),      # cell runs (2,8), 3 waves
     "24fused_eval_sliced_kernelILi5ELi2ELi7E": (72, 0),         # channel-sliced, 7 waves
-    "24fused_eval_window_kernelILi1ELi1ELi4ELi256ELi16ELi4E": (128, 0),   # LDS texel windows, pipelined point loop (V = 4), 4 workgroups per CU
-    "24fused_eval_window_kernelILi1ELi1ELi3ELi256ELi16ELi8E": (168, 0),   # ... V = 8, 3 (2) workgroups per CU
-    "24fused_eval_window_kernelILi1ELi1ELi4ELi256ELi16ELi0E": (128, 0),   # ... any other view count: plain view loop
+    "24fused_eval_window_kernelILi1ELi1ELi4ELi256ELi16ELi4ELb0E": (128, 0),   # LDS texel windows of lattice bricks, pipelined point loop (V = 4): 4 waves per SIMD
+    "24fused_eval_window_kernelILi1ELi1ELi4ELi256ELi16ELi8ELb0E": (128, 0),   # ... V = 8
+    "24fused_eval_window_kernelILi1ELi1ELi4ELi256ELi16ELi0ELb0E": (128, 0),   # ... any other view count: plain view loop
+    "24fused_eval_window_kernelILi1ELi1ELi4ELi256ELi16ELi4ELb1E": (128, 0),   # touched-texel pool (clouds behind the device-side gate), V = 4
+    "24fused_eval_window_kernelILi1ELi1ELi4ELi256ELi16ELi8ELb1E": (128, 0),
+    "24fused_eval_window_kernelILi1ELi1ELi4ELi256ELi16ELi0ELb1E": (128, 0),
+    "24window_gate_probe_kernel": (128, 0),
 }
 
 
