@@ -191,6 +191,19 @@ bool runs_candidate(const d3f::MapDesc &m, int H, int W)
     return m.esize == 4 && m.vw == 4 && m.C >= 128 && (W - 1) >= 4 * (m.fw - 1) && (H - 1) >= 4 * (m.fh - 1);
 }
 
+// LDS texel windows (fuse_eval.hip fused_eval_window_kernel): a patch-resolution wide map in whole 128-channel slices whose texels
+// start on 16-byte boundaries -- fp32 (512-byte slices), or stored in fp16 (256-byte slices, round 5: lattices only)
+bool window_candidate(const d3f::MapDesc &m, const d3f_views *views, bool check_pointer)
+{
+    const int es = m.esize, per16 = 16 / es;            // channels per 16 bytes
+    const bool vec = es == 4 ? m.vw == 4 : m.vw == 8;
+    // (m.fold: a map of <= 256 bytes per texel -- 128 channels of fp16 -- belongs to the thin family, which keeps the reference's
+    //  operation order in every kernel; the window kernel's arithmetic is the folded one)
+    return vec && m.fold && m.C >= 128 && m.C % 128 == 0 && (views->W - 1) >= 4 * (m.fw - 1) && (views->H - 1) >= 4 * (m.fh - 1) &&
+           (int64_t)views->V * m.sv * es < (1LL << 31) && (m.sx % per16) == 0 && (m.sy % per16) == 0 && (m.sv % per16) == 0 &&
+           (!check_pointer || reinterpret_cast<uintptr_t>(m.data) % 16 == 0);
+}
+
 // (vectors per lane U, run length K) of the cell-run gather: the built variants are (1,8) (2,4) (2,8) (3,2) (3,4)
 void pick_runs_mapping(d3f::MapDesc &m, int U, int K)
 {
@@ -351,18 +364,20 @@ int eval_common(const d3f_views *views, const float *pts, int64_t n, const d3f_c
         // default: lattices (a brick's windows are compact), and clouds through the device-side gate (fuse_eval.hip: gated_out);
         // not when a cell-run variant is asked for explicitly
         const bool automatic = win_knob == 0 && (lattice != nullptr || cloud_candidate) && exp_knob("D3F_EXP_RUNS") == 0 && exp_knob("D3F_EXP_RUNS_U") == 0;
+        const bool half0 = n_maps >= 1 && P.maps[0].esize == 2;      // fp16-stored: bricks of a lattice only (the cell-run side of a cloud's gate is fp32)
         window = (win_knob > 0 || automatic) && !direct && mode == 0 && n_maps >= 1 && finite_expected && n >= kSmallBatch &&
-                 n <= 0x7fffffffLL && tl == 0 && views->V <= 8 && runs_candidate(P.maps[0], views->H, views->W) &&
-                 P.maps[0].C % 128 == 0 && (int64_t)views->V * P.maps[0].sv * 4 < (1LL << 31) && (P.maps[0].sx % 4) == 0 && (P.maps[0].sy % 4) == 0 && (P.maps[0].sv % 4) == 0 &&
-                 (!plan_only ? (reinterpret_cast<uintptr_t>(P.maps[0].data) % 16 == 0) : true);
+                 n <= 0x7fffffffLL && tl == 0 && views->V <= 8 && window_candidate(P.maps[0], views, !plan_only) &&
+                 (!half0 || (lattice != nullptr && exp_knob("D3F_EXP_WINDOW_F16") >= 0));
         for (int s = 0; s < n_maps; ++s) window = window && !want_inter[s];
         for (int s = 1; s < n_maps; ++s) window = window && P.maps[s].esize == 4 && P.maps[s].C * 4 <= 256;
         if (window) {
             const int T = (win_knob == 32 || win_knob == 64 || win_knob == 128) ? win_knob : 64;
             const int VP = views->V <= 1 ? 1 : views->V <= 2 ? 2 : views->V <= 4 ? 4 : 8;
             int U = exp_knob("D3F_EXP_WINDOW_U");
-            const int cv = P.maps[0].C / 128;                  // 512-byte granules per texel
-            if (U < 1 || U > 4 || cv % U != 0) U = 1;
+            const int cv = P.maps[0].C / 128;                  // 128-channel granules per texel (512 bytes of fp32, 256 of fp16)
+            const int slot = P.maps[0].esize == 2 ? 256 : 512;
+            if (U < 1 || U > 4 || cv % U != 0 || slot == 256) U = 1;
+            if (slot == 256) P.win_lpp = 16;
             // per (point, view): 32-byte window record (+ the 16-byte view record when thin maps ride along); per point 20 bytes
             const int base = T * (views->V * 32 + 16) + (n_maps > 1 ? T * views->V * 16 : 0) + T * 20 + views->V * 48;     // records at a padded point stride
             const int pool_offset = (base + 511) / 512 * 512;
@@ -373,6 +388,7 @@ int eval_common(const d3f_views *views, const float *pts, int64_t n, const d3f_c
             // touched-texel pool (SPARSE) for clouds, whole rectangles for lattice bricks (which never overflow: 0.42 vs 0.455 ms on
             // C2-patch); experiments builds: D3F_EXP_WINDOW_SPARSE = 1 / -1 forces either
             P.win_sparse = exp_knob("D3F_EXP_WINDOW_SPARSE") > 0 ? 1 : (exp_knob("D3F_EXP_WINDOW_SPARSE") < 0 ? 0 : (lattice ? 0 : 1));
+            if (slot == 256) P.win_sparse = 0;
             // static LDS of the kernel + allocation granularity: 3 workgroups per CU stop fitting with less (measured, round 5)
             const int slack = exp_knob("D3F_EXP_WINDOW_SLACK") > 0 ? exp_knob("D3F_EXP_WINDOW_SLACK") : (P.win_sparse ? 4096 : 2048);
             // slots per view worth a workgroup per CU: a brick's rectangles ~17; a cloud tile's touched texels ~12 (p90 14)
@@ -380,7 +396,7 @@ int eval_common(const d3f_views *views, const float *pts, int64_t n, const d3f_c
             int texels = 0;
             for (;; --occ) {
                 const int budget = 160 * 1024 / occ - slack;
-                texels = (budget - pool_offset) / (512 * U) - 2;
+                texels = (budget - pool_offset) / (slot * U) - 2;
                 // A 4x4x4 brick's window is ~3x4 texels per view once a texel is at least as wide as the brick's footprint
                 // (config 4's slab: 2.5-mm lattice, 10-px texels), and a pool that cannot hold the views' windows sends the
                 // overflowing pairs to the global gather: give every view enough slots, at the price of workgroups per CU
@@ -507,15 +523,20 @@ int eval_common(const d3f_views *views, const float *pts, int64_t n, const d3f_c
         int sl = exp_knob("D3F_EXP_SLICED");
         bool thin_rest = true;
         for (int s = 1; s < n_maps; ++s) thin_rest = thin_rest && P.maps[s].C * P.maps[s].esize <= 256 && P.maps[s].esize == 4;
-        const bool automatic = sl == 0 && thin_rest && n_maps >= 1 && P.maps[0].C % 128 == 0 && P.maps[0].C <= 1024;
-        if (automatic) sl = 3;
+        const bool half_sl = n_maps >= 1 && P.maps[0].esize == 2;      // fp16-stored wide map: 16 lanes x 8 channels = 128-channel slices
+        const bool automatic = sl == 0 && thin_rest && n_maps >= 1 && P.maps[0].C % 128 == 0 && P.maps[0].C <= 1024 &&
+                               (!half_sl || exp_knob("D3F_EXP_SLICED_F16") >= 0);
+        if (automatic) sl = half_sl ? 2 : 3;
+        if (half_sl && sl != 2) sl = 0;
         // ... or the Morton order of a cloud on maps beyond the caches (tiles of 16 / 32 consecutive points of the order)
         const bool cloud = reorder && !walk && !any_runs && map_bytes > kCacheResidentBytes && exp_knob("D3F_EXP_SLICED_CLOUD") >= 0;
-        bool ok = (walk || cloud) && !window && !direct && (sl >= 1 && sl <= 3) && mode == 0 && n_maps >= 1 && P.maps[0].esize == 4 && P.maps[0].vw == 4 &&
-                  !want_inter[0] && tl == 0;
+        bool ok = (walk || cloud) && !window && !direct && (sl >= 1 && sl <= 3) && mode == 0 && n_maps >= 1 &&
+                  ((P.maps[0].esize == 4 && P.maps[0].vw == 4) || (half_sl && P.maps[0].vw == 8 && P.maps[0].fold)) && !want_inter[0] && tl == 0;
         const int lg = sl + 2, lanes = 1 << lg;      // 1: 8 lanes (128-byte slices), 2: 16 lanes, 3: 32 lanes (512 bytes)
         P.sl_vc = exp_knob("D3F_EXP_SLICED_VC") > 0 ? exp_knob("D3F_EXP_SLICED_VC") : (automatic ? 2 : 4);
-        ok = ok && P.maps[0].C % (4 * lanes) == 0 && P.maps[0].C >= 128;
+        if (half_sl) P.sl_vc = 2;
+        const int cpl = half_sl ? 8 : 4;              // channels per lane (one 16-byte vector)
+        ok = ok && P.maps[0].C % (cpl * lanes) == 0 && P.maps[0].C >= 128;
         for (int s = 1; s < n_maps && ok; ++s) ok = P.maps[s].C * P.maps[s].esize <= 256 && !want_inter[s] && P.maps[s].esize == 4;
         if (ok) {
             const int keep_tile = P.tile_pts, keep_pad = P.lds_pad, keep_t[3] = {P.walk_tx, P.walk_ty, P.walk_tz};
@@ -527,7 +548,7 @@ int eval_common(const d3f_views *views, const float *pts, int64_t n, const d3f_c
             const bool mini = tile_knob == 8;                            // experiment: 8 points per workgroup (four 2x1x1 tiles)
             P.walk_tx = 2; P.walk_ty = mini ? 1 : 2; P.walk_tz = big ? 4 : ((tiny || mini) ? 1 : 2);
             P.sl_lg = lg;
-            P.sl_slices = P.maps[0].C / (4 * lanes);
+            P.sl_slices = P.maps[0].C / (cpl * lanes);
             P.tile_pts = big ? 64 : (tiny ? 16 : (mini ? 8 : 32)); P.lds_pad = exp_knob("D3F_EXP_SLICED_PAD") > 0 ? exp_knob("D3F_EXP_SLICED_PAD") * 1024 : 0;
             if (walk) {
                 P.sl_tiles = (int64_t)((P.walk_nx + 1) / 2) * ((P.walk_ny + P.walk_ty - 1) / P.walk_ty) * ((P.walk_nz + P.walk_tz - 1) / P.walk_tz);
@@ -606,7 +627,7 @@ int eval_common(const d3f_views *views, const float *pts, int64_t n, const d3f_c
         plan_out->lds_bytes = P.crec_offset + P.n_pre * P.tile_pts * P.V * 32 + P.lds_pad;
         plan_out->workgroups = P.sl_slices > 0 ? (((P.sl_chunks * P.sl_slices + 7) / 8 + P.sl_ilv - 1) / P.sl_ilv * P.sl_ilv) * 8 * P.sl_unit : ntiles;
         if (P.win_slices > 0) {
-            plan_out->lds_bytes = P.win_pool_offset + (2 + P.win_pool_texels) * 512 * P.win_u;
+            plan_out->lds_bytes = P.win_pool_offset + (2 + P.win_pool_texels) * (P.maps[0].esize == 2 ? 256 : 512) * P.win_u;
             plan_out->workgroups = ntiles;
         }
         plan_out->reserved = P.sl_slices > 0 ? 100 + P.sl_lg * 10 + P.sl_vc : (P.win_slices > 0 ? 2000 + 100 * P.win_u + 10 * (P.win_u == 1 ? (P.win_lpp == 16 ? P.win_vc : 4) : (P.win_u == 4 ? 1 : P.win_vc)) + (P.win_u == 1 ? (P.win_occ >= 4 ? 4 : (P.win_lpp == 16 ? 3 : P.win_occ)) : 2) : 0);   // 2UVW: the window kernel's template arguments      // 1LV: sliced launch, L = log2(lanes per point), V = views in flight

@@ -330,10 +330,15 @@ __device__ __forceinline__ void fused_eval_body(const EvalParams &P)
 // same chunk (C4-dense lattice 13.05 -> 9.05 ms).  Clouds take tiles of consecutive points of their Morton order instead
 // of lattice bricks.  Arithmetic per (point, view, channel) is that of gather_map (fast or strict form), so results are
 // identical.
-template <int LG, int VC>                  // lanes per point = 1 << LG: 8 (128-byte slices), 16 (256 B) or 32 (512 B)
+// HALF (round 5): the sliced map is stored in fp16 -- a lane's 16-byte vector is eight channels, widened inside v_fma_mix_f32
+// (fma_mix8 below: the fp32 arithmetic on the widened map, bit for bit); 16 lanes x 8 channels = the same 128-channel slices.
+template <bool HALF> struct WinRaw;
+__device__ __forceinline__ void fma_mix8(f32x4 &lo, f32x4 &hi, f16x8 r, float w);
+template <int LG, int VC, bool HALF = false>   // lanes per point = 1 << LG: 8 (128-byte slices), 16 (256 B) or 32 (512 B)
 __device__ __forceinline__ void fused_eval_sliced_body(const EvalParams &P)
 {
     constexpr int LP = 1 << LG, PTS = kBlock / LP;
+    constexpr int ES = HALF ? 2 : 4;
     const int TP = P.tile_pts;                 // 32 (four 2x2x2 walk tiles) or 64 (four 2x2x4 ones)
     extern __shared__ __align__(16) unsigned char smem[];
     const int V = P.V;
@@ -446,16 +451,22 @@ __device__ __forceinline__ void fused_eval_sliced_body(const EvalParams &P)
     // ---------------- phase B: the slice of the wide map, LP lanes per point ----------------
     {
         using VT = f32x4;
+        using RT = typename std::conditional<HALF, f16x8, f32x4>::type;     // a lane's 16-byte vector as stored
         const MapDesc &m = m0;
         const int lg = threadIdx.x & (LP - 1), grp = threadIdx.x >> LG;
         const uint32_t co = (uint32_t)(slice * LP + lg) * 16u;               // byte offset of this lane's vector in a texel
         const char *__restrict__ data = reinterpret_cast<const char *>(m.data);
+        auto raw = [&](const char *bv, uint32_t off) -> RT { return *reinterpret_cast<const RT *>(bv + (off + co)); };
         for (int p = grp; p < tile_n; p += PTS) {
             const int64_t i = idx_s[p];
             const float cnt = cnt_s[p];
             const float denom = cnt + 1e-6f;
             const bool strict = flag_s[p] != 0u;
-            VT acc = (VT)0.0f;
+            VT acc = (VT)0.0f, acc2 = (VT)0.0f;                              // (acc2: channels 4..7 of a fp16 vector)
+            auto accumulate = [&](RT t, float w) {
+                if constexpr (HALF) fma_mix8(acc, acc2, t, w);
+                else acc = v_fma<VT>(t, w, acc);
+            };
             if (!strict) {
                 // fast path, branch-free: phase A left an all-zero corner record for an invalid (point, view), so its
                 // loads hit texel 0 of the view and its term is +-0 -- adding it changes no bit.  The corner
@@ -463,57 +474,69 @@ __device__ __forceinline__ void fused_eval_sliced_body(const EvalParams &P)
                 // weights: four fma per view straight into the sum.
                 int v0 = 0;
                 for (; v0 + VC <= V; v0 += VC) {
-                    VT a[VC], b[VC], d[VC], e[VC];
+                    RT a[VC], b[VC], d[VC], e[VC];
                     f32x4 w[VC];
 #pragma unroll
                     for (int q = 0; q < VC; ++q) {
                         const CornerRec cr = crec_s[p * V + v0 + q];
-                        const char *bv = data + (int64_t)(v0 + q) * m.sv * 4;
-                        a[q] = load_texel<4, false>(bv + (cr.o[0] + co));
-                        b[q] = load_texel<4, false>(bv + (cr.o[1] + co));
-                        d[q] = load_texel<4, false>(bv + (cr.o[2] + co));
-                        e[q] = load_texel<4, false>(bv + (cr.o[3] + co));
+                        const char *bv = data + (int64_t)(v0 + q) * m.sv * ES;
+                        a[q] = raw(bv, cr.o[0]); b[q] = raw(bv, cr.o[1]); d[q] = raw(bv, cr.o[2]); e[q] = raw(bv, cr.o[3]);
                         w[q] = f32x4{cr.w[0], cr.w[1], cr.w[2], cr.w[3]};
                     }
 #pragma unroll
                     for (int q = 0; q < VC; ++q) {
-                        acc = v_fma<VT>(a[q], w[q].x, acc);
-                        acc = v_fma<VT>(b[q], w[q].y, acc);
-                        acc = v_fma<VT>(d[q], w[q].z, acc);
-                        acc = v_fma<VT>(e[q], w[q].w, acc);
+                        accumulate(a[q], w[q].x);
+                        accumulate(b[q], w[q].y);
+                        accumulate(d[q], w[q].z);
+                        accumulate(e[q], w[q].w);
                     }
                 }
                 for (; v0 < V; ++v0) {
                     const CornerRec cr = crec_s[p * V + v0];
-                    const char *bv = data + (int64_t)v0 * m.sv * 4;
-                    const VT a = load_texel<4, false>(bv + (cr.o[0] + co)), b = load_texel<4, false>(bv + (cr.o[1] + co));
-                    const VT d = load_texel<4, false>(bv + (cr.o[2] + co)), e = load_texel<4, false>(bv + (cr.o[3] + co));
-                    acc = v_fma<VT>(a, cr.w[0], acc);
-                    acc = v_fma<VT>(b, cr.w[1], acc);
-                    acc = v_fma<VT>(d, cr.w[2], acc);
-                    acc = v_fma<VT>(e, cr.w[3], acc);
+                    const char *bv = data + (int64_t)v0 * m.sv * ES;
+                    const RT a = raw(bv, cr.o[0]), b = raw(bv, cr.o[1]), d = raw(bv, cr.o[2]), e = raw(bv, cr.o[3]);
+                    accumulate(a, cr.w[0]);
+                    accumulate(b, cr.w[1]);
+                    accumulate(d, cr.w[2]);
+                    accumulate(e, cr.w[3]);
                 }
             } else {
                 for (int v = 0; v < V; ++v) {
                     const ViewRec r = rec[p * V + v];
-                    const char *bv = data + (int64_t)v * m.sv * 4;
+                    const char *bv = data + (int64_t)v * m.sv * ES;
                     const Corner c = corner_setup(m, r.gx, r.gy);
-                    const VT a = load_texel<4, false>(bv + (c.onw + co)), b = load_texel<4, false>(bv + (c.one + co));
-                    const VT d = load_texel<4, false>(bv + (c.osw + co)), e = load_texel<4, false>(bv + (c.ose + co));
-                    const VT av = c.inw ? a : (VT)0.0f, bvv = c.ine ? b : (VT)0.0f, dv = c.isw ? d : (VT)0.0f, ev = c.ise ? e : (VT)0.0f;
-                    VT s_ = av * c.wnw;
-                    s_ = v_fma<VT>(bvv, c.wne, s_);
-                    s_ = v_fma<VT>(dv, c.wsw, s_);
-                    s_ = v_fma<VT>(ev, c.wse, s_);
-                    acc = acc + (s_ * r.valid) * r.wgt;
+                    const RT ra = raw(bv, c.onw), rb = raw(bv, c.one), rd = raw(bv, c.osw), re = raw(bv, c.ose);
+#pragma unroll
+                    for (int hh = 0; hh < (HALF ? 2 : 1); ++hh) {
+                        VT a, b, d, e;
+                        if constexpr (HALF) {
+                            const f32x8 wa = __builtin_convertvector(ra, f32x8), wb = __builtin_convertvector(rb, f32x8);
+                            const f32x8 wd = __builtin_convertvector(rd, f32x8), we = __builtin_convertvector(re, f32x8);
+                            a = hh ? wa.hi : wa.lo; b = hh ? wb.hi : wb.lo; d = hh ? wd.hi : wd.lo; e = hh ? we.hi : we.lo;
+                        } else {
+                            a = ra; b = rb; d = rd; e = re;
+                        }
+                        const VT av = c.inw ? a : (VT)0.0f, bvv = c.ine ? b : (VT)0.0f, dv = c.isw ? d : (VT)0.0f, ev = c.ise ? e : (VT)0.0f;
+                        VT s_ = av * c.wnw;
+                        s_ = v_fma<VT>(bvv, c.wne, s_);
+                        s_ = v_fma<VT>(dv, c.wsw, s_);
+                        s_ = v_fma<VT>(ev, c.wse, s_);
+                        if (hh) acc2 = acc2 + (s_ * r.valid) * r.wgt;
+                        else acc = acc + (s_ * r.valid) * r.wgt;
+                    }
                 }
             }
-            VT o = acc;                         // fast path: the weights carry 1/(cnt + 1e-6); no valid view: every weight is 0
+            VT o = acc, o2 = acc2;              // fast path: the weights carry 1/(cnt + 1e-6); no valid view: every weight is 0
             if (strict) {
-                o = (VT)0.0f;                   // fusion.py:386
-                if (cnt != 0.0f) o = strict_div<VT>(acc, denom);
+                o = (VT)0.0f; o2 = (VT)0.0f;    // fusion.py:386
+                if (cnt != 0.0f) { o = strict_div<VT>(acc, denom); if constexpr (HALF) o2 = strict_div<VT>(acc2, denom); }
             }
-            store_out<VT>(m.out + i * m.C + (co >> 2), o, P.store_policy);
+            if constexpr (HALF) {
+                store_out<VT>(m.out + i * m.C + (co >> 1), o, P.store_policy);
+                store_out<VT>(m.out + i * m.C + (co >> 1) + 4, o2, P.store_policy);
+            } else {
+                store_out<VT>(m.out + i * m.C + (co >> 2), o, P.store_policy);
+            }
         }
     }
     // the other (thin) maps of the launch ride along with slice 0
@@ -528,8 +551,8 @@ __device__ __forceinline__ void fused_eval_sliced_body(const EvalParams &P)
         }
 }
 
-template <int LG, int VC, int WAVES>
-__global__ __launch_bounds__(kBlock, WAVES) void fused_eval_sliced_kernel(const EvalParams P) { fused_eval_sliced_body<LG, VC>(P); }
+template <int LG, int VC, int WAVES, bool HALF = false>
+__global__ __launch_bounds__(kBlock, WAVES) void fused_eval_sliced_kernel(const EvalParams P) { fused_eval_sliced_body<LG, VC, HALF>(P); }
 
 // ---- texel windows in LDS for small wide maps (round 2) ---------------------------------------------------------------
 // Patch-resolution feature maps (the reference's dino_feats, fusion.py:694-697) sit in the caches, and the direct gather
@@ -576,13 +599,58 @@ constexpr int kWinMaxViews = 8;
 constexpr int kWinMaxTexels = 320;       // pool slots (host: win_pool_texels <= this)
 constexpr uint32_t kWinStrict = 1u, kWinHasDirect = 2u;
 
+// ---- fp16-STORED maps in the window kernel (round 5) --------------------------------------------------------------------------
+// The pool then holds the texels as stored: a slice of 128 channels is 256 bytes, a lane's corner read is an 8-byte vector of four
+// halves where the fp32 form reads 16 bytes (half the LDS bytes, the same instruction count, the same lane -> channel map, hence
+// the same coalesced row stores), and the arithmetic is v_fma_mix_f32 -- the fp16 operand widened inside the fp32 fma, one
+// rounding: bit for bit fma(float(h), w, acc), i.e. the fp32 kernel run on the widened map, at one instruction per channel (the
+// compiler's own form of that expression is v_cvt + v_pk_fma: 12 instead of 8 instructions per eight channels).
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+template <bool HALF> struct WinRaw { using T = f32x4; };
+template <> struct WinRaw<true> { using T = f16x4; };
+
+__device__ __forceinline__ void fma_mix4(f32x4 &acc, f16x4 r, float w)
+{
+    typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+    const u32x2 p = __builtin_bit_cast(u32x2, r);
+    const uint32_t p0 = p.x, p1 = p.y;
+    float a0 = acc.x, a1 = acc.y, a2 = acc.z, a3 = acc.w;
+    // op_sel_hi[0] = 1: source 0 is fp16; op_sel[0] picks its high half
+    asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel_hi:[1,0,0]" : "+v"(a0) : "v"(p0), "v"(w));
+    asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(a1) : "v"(p0), "v"(w));
+    asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel_hi:[1,0,0]" : "+v"(a2) : "v"(p1), "v"(w));
+    asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(a3) : "v"(p1), "v"(w));
+    acc = f32x4{a0, a1, a2, a3};
+}
+
+// the same for a 16-byte vector of eight halves (the channel-sliced kernel's lane): two accumulators
+__device__ __forceinline__ void fma_mix8(f32x4 &lo, f32x4 &hi, f16x8 r, float w)
+{
+    struct Pair { f16x4 a, b; };
+    const Pair pr = __builtin_bit_cast(Pair, r);
+    fma_mix4(lo, pr.a, w);
+    fma_mix4(hi, pr.b, w);
+}
+
+// acc[NV] += corner vectors * w, one raw vector (four channels: 16 bytes of fp32, 8 of fp16) per accumulator
+template <int NV, bool HALF>
+__device__ __forceinline__ void win_accumulate(f32x4 (&acc)[NV], const typename WinRaw<HALF>::T (&c)[NV], float w)
+{
+#pragma unroll
+    for (int u = 0; u < NV; ++u) {
+        if constexpr (HALF) fma_mix4(acc[u], c[u], w);
+        else acc[u] = v_fma<f32x4>(c[u], w, acc[u]);
+    }
+}
+
 // all views of one point from the pool: VC views' corner reads in flight together
-// NV vectors per lane, VS bytes apart inside a slice of SBB bytes (the ne / se corners are one slice further)
-template <int NV, int VC, int VS, int SBB>
+// NV accumulator vectors per lane; raw vectors VS bytes apart inside a slice of SBB bytes (the ne / se corners are one slice further)
+template <int NV, int VC, int VS, int SBB, bool HALF = false>
 __device__ __forceinline__ void window_point(f32x4 (&acc)[NV], const unsigned char *smem, const WinRec *wr_p, int V,
                                              uint32_t lane_off)
 {
-    using VT = f32x4;
+    using RT = typename WinRaw<HALF>::T;
+    constexpr int NR = NV;
     int v0 = 0;
     for (; v0 + VC <= V; v0 += VC) {
         WinRec wr[VC];
@@ -596,43 +664,42 @@ __device__ __forceinline__ void window_point(f32x4 (&acc)[NV], const unsigned ch
             wr[q].nw = __float_as_uint(h0.x); wr[q].sw = __float_as_uint(h0.y); wr[q].wgt = h0.z; wr[q].valid = h0.w;
             wr[q].w[0] = h1.x; wr[q].w[1] = h1.y; wr[q].w[2] = h1.z; wr[q].w[3] = h1.w;
         }
-        VT a[VC][NV], b[VC][NV], d[VC][NV], e[VC][NV];
+        RT a[VC][NR], b[VC][NR], d[VC][NR], e[VC][NR];
 #pragma unroll
         for (int q = 0; q < VC; ++q) {
             const unsigned char *nw = smem + (wr[q].nw + lane_off);
             const unsigned char *sw = smem + (wr[q].sw + lane_off);
 #pragma unroll
-            for (int u = 0; u < NV; ++u) {
-                a[q][u] = *reinterpret_cast<const VT *>(nw + u * VS);
-                b[q][u] = *reinterpret_cast<const VT *>(nw + SBB + u * VS);
-                d[q][u] = *reinterpret_cast<const VT *>(sw + u * VS);
-                e[q][u] = *reinterpret_cast<const VT *>(sw + SBB + u * VS);
+            for (int u = 0; u < NR; ++u) {
+                a[q][u] = *reinterpret_cast<const RT *>(nw + u * VS);
+                b[q][u] = *reinterpret_cast<const RT *>(nw + SBB + u * VS);
+                d[q][u] = *reinterpret_cast<const RT *>(sw + u * VS);
+                e[q][u] = *reinterpret_cast<const RT *>(sw + SBB + u * VS);
             }
         }
 #pragma unroll
-        for (int q = 0; q < VC; ++q)
-#pragma unroll
-            for (int u = 0; u < NV; ++u) {
-                acc[u] = v_fma<VT>(a[q][u], wr[q].w[0], acc[u]);        // folded weights (fuse_common.h)
-                acc[u] = v_fma<VT>(b[q][u], wr[q].w[1], acc[u]);
-                acc[u] = v_fma<VT>(d[q][u], wr[q].w[2], acc[u]);
-                acc[u] = v_fma<VT>(e[q][u], wr[q].w[3], acc[u]);
-            }
+        for (int q = 0; q < VC; ++q) {
+            win_accumulate<NV, HALF>(acc, a[q], wr[q].w[0]);        // folded weights (fuse_common.h)
+            win_accumulate<NV, HALF>(acc, b[q], wr[q].w[1]);
+            win_accumulate<NV, HALF>(acc, d[q], wr[q].w[2]);
+            win_accumulate<NV, HALF>(acc, e[q], wr[q].w[3]);
+        }
     }
     if constexpr (VC > 1) {
         for (; v0 < V; ++v0) {
             const WinRec wr = wr_p[v0];
             const unsigned char *nw = smem + (wr.nw + lane_off);
             const unsigned char *sw = smem + (wr.sw + lane_off);
+            RT a[NR], b[NR], d[NR], e[NR];
 #pragma unroll
-            for (int u = 0; u < NV; ++u) {
-                const VT a = *reinterpret_cast<const VT *>(nw + u * VS), b = *reinterpret_cast<const VT *>(nw + SBB + u * VS);
-                const VT d = *reinterpret_cast<const VT *>(sw + u * VS), e = *reinterpret_cast<const VT *>(sw + SBB + u * VS);
-                acc[u] = v_fma<VT>(a, wr.w[0], acc[u]);
-                acc[u] = v_fma<VT>(b, wr.w[1], acc[u]);
-                acc[u] = v_fma<VT>(d, wr.w[2], acc[u]);
-                acc[u] = v_fma<VT>(e, wr.w[3], acc[u]);
+            for (int u = 0; u < NR; ++u) {
+                a[u] = *reinterpret_cast<const RT *>(nw + u * VS); b[u] = *reinterpret_cast<const RT *>(nw + SBB + u * VS);
+                d[u] = *reinterpret_cast<const RT *>(sw + u * VS); e[u] = *reinterpret_cast<const RT *>(sw + SBB + u * VS);
             }
+            win_accumulate<NV, HALF>(acc, a, wr.w[0]);
+            win_accumulate<NV, HALF>(acc, b, wr.w[1]);
+            win_accumulate<NV, HALF>(acc, d, wr.w[2]);
+            win_accumulate<NV, HALF>(acc, e, wr.w[3]);
         }
     }
 }
@@ -653,29 +720,31 @@ __device__ __forceinline__ void window_point(f32x4 (&acc)[NV], const unsigned ch
 #define D3F_WIN_ABLATE 0
 #endif
 
-template <int NV>
+template <int NV, bool HALF>
 struct WinPipe {            // registers of the pipeline; every index below is a compile-time constant
     uint2 off[3];
     f32x4 wt[3];
-    f32x4 c[2][4][NV];
+    typename WinRaw<HALF>::T c[2][4][NV];
     f32x4 acc[NV];
 };
 
-template <int J, int NV, int VF, int KI, int VS, int SBB, int KSTRIDE>
-__device__ __forceinline__ void win_pipe_record(WinPipe<NV> &st, const unsigned char *smem, uint32_t rec0)
+template <int J, int NV, int VF, int KI, int VS, int SBB, int KSTRIDE, bool HALF>
+__device__ __forceinline__ void win_pipe_record(WinPipe<NV, HALF> &st, const unsigned char *smem, uint32_t rec0)
 {
     const unsigned char *r = smem + rec0 + (uint32_t)((J / VF) * KSTRIDE + (J % VF) * (int)sizeof(WinRec));
     st.off[J % 3] = *reinterpret_cast<const uint2 *>(r);
     st.wt[J % 3] = *reinterpret_cast<const f32x4 *>(r + 16);
 }
 
-template <int J, int NV, int VS, int SBB>
-__device__ __forceinline__ void win_pipe_corners(WinPipe<NV> &st, const unsigned char *smem, uint32_t lane_off)
+template <int J, int NV, int VS, int SBB, bool HALF>
+__device__ __forceinline__ void win_pipe_corners(WinPipe<NV, HALF> &st, const unsigned char *smem, uint32_t lane_off)
 {
-    using VT = f32x4;
+    using RT = typename WinRaw<HALF>::T;
+    constexpr int NR = NV;
     const unsigned char *nw = smem + (st.off[J % 3].x + lane_off);
     const unsigned char *sw = smem + (st.off[J % 3].y + lane_off);
 #if D3F_WIN_ABLATE & 16
+    static_assert(!HALF, "what-if builds: fp32 maps only");
 #pragma unroll
     for (int u = 0; u < NV; ++u) {
         st.c[J % 2][0][u] = st.wt[J % 3]; st.c[J % 2][1][u] = st.wt[(J + 1) % 3]; st.c[J % 2][2][u] = st.wt[(J + 2) % 3]; st.c[J % 2][3][u] = st.wt[J % 3];
@@ -684,21 +753,21 @@ __device__ __forceinline__ void win_pipe_corners(WinPipe<NV> &st, const unsigned
     return;
 #endif
 #pragma unroll
-    for (int u = 0; u < NV; ++u) {
-        st.c[J % 2][0][u] = *reinterpret_cast<const VT *>(nw + u * VS);
-        st.c[J % 2][1][u] = *reinterpret_cast<const VT *>(nw + SBB + u * VS);
-        st.c[J % 2][2][u] = *reinterpret_cast<const VT *>(sw + u * VS);
-        st.c[J % 2][3][u] = *reinterpret_cast<const VT *>(sw + SBB + u * VS);
+    for (int u = 0; u < NR; ++u) {
+        st.c[J % 2][0][u] = *reinterpret_cast<const RT *>(nw + u * VS);
+        st.c[J % 2][1][u] = *reinterpret_cast<const RT *>(nw + SBB + u * VS);
+        st.c[J % 2][2][u] = *reinterpret_cast<const RT *>(sw + u * VS);
+        st.c[J % 2][3][u] = *reinterpret_cast<const RT *>(sw + SBB + u * VS);
     }
 }
 
-template <int J, int NV, int VF, int KI, int VS, int SBB, int KSTRIDE, typename DONE>
-__device__ __forceinline__ void win_pipe_step(WinPipe<NV> &st, const unsigned char *smem, uint32_t rec0, uint32_t lane_off, DONE &done)
+template <int J, int NV, int VF, int KI, int VS, int SBB, int KSTRIDE, bool HALF, typename DONE>
+__device__ __forceinline__ void win_pipe_step(WinPipe<NV, HALF> &st, const unsigned char *smem, uint32_t rec0, uint32_t lane_off, DONE &done)
 {
     using VT = f32x4;
     constexpr int NS = KI * VF;
-    if constexpr (J + 2 < NS) win_pipe_record<J + 2, NV, VF, KI, VS, SBB, KSTRIDE>(st, smem, rec0);
-    if constexpr (J + 1 < NS) win_pipe_corners<J + 1, NV, VS, SBB>(st, smem, lane_off);
+    if constexpr (J + 2 < NS) win_pipe_record<J + 2, NV, VF, KI, VS, SBB, KSTRIDE, HALF>(st, smem, rec0);
+    if constexpr (J + 1 < NS) win_pipe_corners<J + 1, NV, VS, SBB, HALF>(st, smem, lane_off);
 #if D3F_WIN_ABLATE & 8
 #pragma unroll
     for (int u = 0; u < NV; ++u) {
@@ -706,13 +775,10 @@ __device__ __forceinline__ void win_pipe_step(WinPipe<NV> &st, const unsigned ch
         st.acc[u] = st.wt[J % 3];
     }
 #else
-#pragma unroll
-    for (int u = 0; u < NV; ++u) {
-        st.acc[u] = v_fma<VT>(st.c[J % 2][0][u], st.wt[J % 3].x, st.acc[u]);        // folded weights (fuse_common.h): nw, ne, sw, se
-        st.acc[u] = v_fma<VT>(st.c[J % 2][1][u], st.wt[J % 3].y, st.acc[u]);
-        st.acc[u] = v_fma<VT>(st.c[J % 2][2][u], st.wt[J % 3].z, st.acc[u]);
-        st.acc[u] = v_fma<VT>(st.c[J % 2][3][u], st.wt[J % 3].w, st.acc[u]);
-    }
+    win_accumulate<NV, HALF>(st.acc, st.c[J % 2][0], st.wt[J % 3].x);        // folded weights (fuse_common.h): nw, ne, sw, se
+    win_accumulate<NV, HALF>(st.acc, st.c[J % 2][1], st.wt[J % 3].y);
+    win_accumulate<NV, HALF>(st.acc, st.c[J % 2][2], st.wt[J % 3].z);
+    win_accumulate<NV, HALF>(st.acc, st.c[J % 2][3], st.wt[J % 3].w);
 #endif
     if constexpr (J % VF == VF - 1) {
         done(J / VF, st.acc);
@@ -720,19 +786,19 @@ __device__ __forceinline__ void win_pipe_step(WinPipe<NV> &st, const unsigned ch
         for (int u = 0; u < NV; ++u) st.acc[u] = (VT)0.0f;
     }
     __builtin_amdgcn_sched_barrier(0);          // keep the steps in program order (the pipeline IS the schedule)
-    if constexpr (J + 1 < NS) win_pipe_step<J + 1, NV, VF, KI, VS, SBB, KSTRIDE>(st, smem, rec0, lane_off, done);
+    if constexpr (J + 1 < NS) win_pipe_step<J + 1, NV, VF, KI, VS, SBB, KSTRIDE, HALF>(st, smem, rec0, lane_off, done);
 }
 
-template <int NV, int VF, int KI, int VS, int SBB, int KSTRIDE, typename DONE>
+template <int NV, int VF, int KI, int VS, int SBB, int KSTRIDE, bool HALF, typename DONE>
 __device__ __forceinline__ void window_points_pipelined(const unsigned char *smem, uint32_t rec0, uint32_t lane_off, DONE done)
 {
-    WinPipe<NV> st;
-    win_pipe_record<0, NV, VF, KI, VS, SBB, KSTRIDE>(st, smem, rec0);
-    if constexpr (KI * VF > 1) win_pipe_record<1, NV, VF, KI, VS, SBB, KSTRIDE>(st, smem, rec0);
-    win_pipe_corners<0, NV, VS, SBB>(st, smem, lane_off);
+    WinPipe<NV, HALF> st;
+    win_pipe_record<0, NV, VF, KI, VS, SBB, KSTRIDE, HALF>(st, smem, rec0);
+    if constexpr (KI * VF > 1) win_pipe_record<1, NV, VF, KI, VS, SBB, KSTRIDE, HALF>(st, smem, rec0);
+    win_pipe_corners<0, NV, VS, SBB, HALF>(st, smem, lane_off);
 #pragma unroll
     for (int u = 0; u < NV; ++u) st.acc[u] = (f32x4)0.0f;
-    win_pipe_step<0, NV, VF, KI, VS, SBB, KSTRIDE>(st, smem, rec0, lane_off, done);
+    win_pipe_step<0, NV, VF, KI, VS, SBB, KSTRIDE, HALF>(st, smem, rec0, lane_off, done);
 }
 
 // LPP lanes per point in phase B: 32 (U vectors per lane, 512 bytes apart, slices of 512*U bytes) or 16 (U == 1: two
@@ -746,11 +812,14 @@ __device__ __forceinline__ void window_points_pipelined(const unsigned char *sme
 // scripts/sim_cloud_tiles.py): an 80-slot pool then overflows on 0.5 % of the tiles instead of 19 %.  The price: the copy of slice
 // 0 starts after phase A instead of underneath it.
 constexpr int kWinMaxBits = 2048;            // bitmap bits over all views' rectangles (rows that do not fit are left out)
-template <int U, int VC, int NT, int LPP, int VFIX, bool SPARSE>
+// HALF: map 0 is stored in fp16 (D3F_DTYPE_F16): 256-byte slices of 128 channels, one 16-byte raw vector per lane (see fma_mix8)
+template <int U, int VC, int NT, int LPP, int VFIX, bool SPARSE, bool HALF>
 __device__ __forceinline__ void fused_eval_window_body(const EvalParams &P)
 {
     using VT = f32x4;
     static_assert(LPP == 32 || (LPP == 16 && U == 1), "16 lanes per point only with 512-byte slices");
+    static_assert(!HALF || (LPP == 16 && U == 1), "fp16-stored maps: 16 lanes x two 4-channel vectors per point");
+    constexpr int ES = HALF ? 2 : 4;                   // bytes per stored channel of map 0
 #ifdef D3F_EXPERIMENTS
     // phase stamps (D3F_EXP_STAMPS=1): lane 0 of wave 0 of every 64th workgroup writes s_memtime at the phase boundaries
     int stamp_k = 0;
@@ -761,7 +830,8 @@ __device__ __forceinline__ void fused_eval_window_body(const EvalParams &P)
 #endif
     D3F_STAMP();                                    // 0: entry
     constexpr int NV = U * (32 / LPP);                 // vectors per lane
-    constexpr int VS = 16 * LPP;                       // bytes between a lane's vectors
+    constexpr int RB = HALF ? 8 : 16;                  // bytes of a lane's raw vector (four channels as stored)
+    constexpr int VS = RB * LPP;                       // bytes between a lane's raw vectors inside a slice
     extern __shared__ __align__(16) unsigned char smem[];
     const int V = P.V;
     const int TP = P.tile_pts;
@@ -777,7 +847,9 @@ __device__ __forceinline__ void fused_eval_window_body(const EvalParams &P)
     uint32_t *idx_s = flag_s + TP;                                           // [TP]
     float *aux_s = reinterpret_cast<float *>(idx_s + TP);                    // [TP][2]: refined 1/(cnt + 1e-6), cnt + 1e-6
     float *krt = aux_s + 2 * TP;                                             // [V*12]
-    constexpr uint32_t SB = 512u * U;                                        // bytes of one texel slice
+    constexpr uint32_t SB = (HALF ? 256u : 512u) * U;                        // bytes of one texel slice (128 * U channels as stored)
+    constexpr uint32_t OSB = 512u * U;                                       // ... of the same channels in an output row (fp32)
+    constexpr int OVS = 16 * LPP;                                            // bytes between a lane's accumulator vectors in an output row
     const uint32_t zero_off = (uint32_t)P.win_pool_offset;                   // two all-zero slices, then the pool
     const uint32_t pool_off = zero_off + 2u * SB;
     __shared__ float cpt_s[8][3];
@@ -946,21 +1018,23 @@ __device__ __forceinline__ void fused_eval_window_body(const EvalParams &P)
         // local / bw for 0 <= local < 2048, 1 <= bw <= 2048 through the float reciprocal: (local + 0.5) / bw is at least 1/(2 bw)
         // away from every integer, far more than the rounding of rcp and the product -- exact, at a tenth of the integer division
         const int y = (int)(((float)local + 0.5f) * __builtin_amdgcn_rcpf((float)w.bw)), x = local - y * w.bw;
-        return (uint32_t)(((int64_t)v * m0.sv + (int64_t)(w.ymin + y) * m0.sy + (int64_t)(w.xmin + x) * m0.sx) * 4);
+        return (uint32_t)(((int64_t)v * m0.sv + (int64_t)(w.ymin + y) * m0.sy + (int64_t)(w.xmin + x) * m0.sx) * ES);
     };
     if constexpr (!SPARSE) {
         for (int t = threadIdx.x; t < total_s; t += NT) texsrc_s[t] = rect_texel(t);
         __syncthreads();
     }
-    // copy of slice `sl` of every window into the pool: 512-byte granules, two per wave instruction
+    // copy of slice `sl` of every window into the pool: 512-byte granules, two per wave instruction (fp16 storage: 256-byte
+    // granules, four per wave instruction); a wave instruction fills 1 KiB of consecutive pool slots
     auto stage = [&](int sl) {
+        constexpr int GL = HALF ? 16 : 32, GPW = 64 / GL;        // lanes per granule, granules per wave instruction
         const int total = total_s * U;              // granules
-        const int h = lane >> 5, l = lane & 31;
+        const int h = lane / GL, l = lane % GL;
         const char *data = reinterpret_cast<const char *>(m0.data) + (size_t)sl * SB + (size_t)l * 16;
-        for (int g2 = wave; g2 * 2 < total; g2 += NT / 64) {
-            const int hk = min(g2 * 2 + h, total - 1);
+        for (int g2 = wave; g2 * GPW < total; g2 += NT / 64) {
+            const int hk = min(g2 * GPW + h, total - 1);
             const int t = hk / U, part = hk - t * U;
-            const char *src = data + texsrc_s[t] + (uint32_t)part * 512u;
+            const char *src = data + texsrc_s[t] + (uint32_t)part * (uint32_t)(SB / U);
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
                                              (__attribute__((address_space(3))) void *)(smem + pool_off + (size_t)g2 * 1024),
                                              16, 0, 0);
@@ -1108,7 +1182,7 @@ __device__ __forceinline__ void fused_eval_window_body(const EvalParams &P)
     // C3-patch +1.5 %, C4-patch -0.4 % with the pipelined point loop; not kept.  Barriers between the slices are LDS-only.)
     const MapDesc &m = m0;
     const int l = threadIdx.x & (LPP - 1), grp = threadIdx.x / LPP;
-    const uint32_t lane_off = (uint32_t)l * 16u;
+    const uint32_t lane_off = (uint32_t)l * (uint32_t)RB;
     const char *__restrict__ data = reinterpret_cast<const char *>(m.data);
     const int S = P.win_slices;
     constexpr int G = NT / LPP;                     // points in flight per workgroup pass
@@ -1116,6 +1190,9 @@ __device__ __forceinline__ void fused_eval_window_body(const EvalParams &P)
     // fused channels of slot p for this lane (NV vectors): everything but the store
     int Vg = V;                                     // the general path's view count, opaque: behind `pipe_ok` the compiler knows
     asm volatile("" : "+s"(Vg));                    // V == VFIX and would unroll these view loops too (32 corner loads in flight: spills)
+    using RT = typename WinRaw<HALF>::T;
+    constexpr int NR = NV;                          // raw vectors per lane and corner
+    // the four corner vectors of one pair from global memory (texel byte offset `cu` of this lane's raw vector r)
     auto point_slice = [&](int p, uint32_t co, VT (&acc)[NV]) {
         const int V = Vg;
         const uint32_t fl = flag_s[p];
@@ -1123,51 +1200,60 @@ __device__ __forceinline__ void fused_eval_window_body(const EvalParams &P)
 #pragma unroll
         for (int u = 0; u < NV; ++u) acc[u] = (VT)0.0f;
         if (fl == 0u) {
-            window_point<NV, VC, VS, (int)SB>(acc, smem, wrec_at(p), V, lane_off);
+            window_point<NV, VC, VS, (int)SB, HALF>(acc, smem, wrec_at(p), V, lane_off);
         } else if (!strict) {
             // some pair of this point is gathered from global memory (folded weights like the pool pairs)
             for (int v = 0; v < V; ++v) {
                 const WinRec wr = wrec_at(p)[v];
+                RT a[NR], b[NR], d[NR], e[NR];
+                float w0, w1, w2, w3;
                 if (wr.valid != kWinDirectMark) {
                     const unsigned char *nw = smem + (wr.nw + lane_off);
                     const unsigned char *sw = smem + (wr.sw + lane_off);
 #pragma unroll
-                    for (int u = 0; u < NV; ++u) {
-                        const VT a = *reinterpret_cast<const VT *>(nw + u * VS), b = *reinterpret_cast<const VT *>(nw + SB + u * VS);
-                        const VT d = *reinterpret_cast<const VT *>(sw + u * VS), e = *reinterpret_cast<const VT *>(sw + SB + u * VS);
-                        acc[u] = v_fma<VT>(a, wr.w[0], acc[u]);
-                        acc[u] = v_fma<VT>(b, wr.w[1], acc[u]);
-                        acc[u] = v_fma<VT>(d, wr.w[2], acc[u]);
-                        acc[u] = v_fma<VT>(e, wr.w[3], acc[u]);
+                    for (int u = 0; u < NR; ++u) {
+                        a[u] = *reinterpret_cast<const RT *>(nw + u * VS); b[u] = *reinterpret_cast<const RT *>(nw + SB + u * VS);
+                        d[u] = *reinterpret_cast<const RT *>(sw + u * VS); e[u] = *reinterpret_cast<const RT *>(sw + SB + u * VS);
                     }
+                    w0 = wr.w[0]; w1 = wr.w[1]; w2 = wr.w[2]; w3 = wr.w[3];
                 } else {
                     const Corner c = corner_setup(m, wr.w[0], wr.w[1]);
-                    const char *bv = data + (int64_t)v * m.sv * 4;
+                    const char *bv = data + (int64_t)v * m.sv * ES;
                     const float sc = wr.wgt;                                 // fold_scale of this pair (phase A)
-                    const float w0 = (c.inw ? c.wnw : 0.0f) * sc, w1 = (c.ine ? c.wne : 0.0f) * sc;
-                    const float w2 = (c.isw ? c.wsw : 0.0f) * sc, w3 = (c.ise ? c.wse : 0.0f) * sc;
+                    w0 = (c.inw ? c.wnw : 0.0f) * sc; w1 = (c.ine ? c.wne : 0.0f) * sc;
+                    w2 = (c.isw ? c.wsw : 0.0f) * sc; w3 = (c.ise ? c.wse : 0.0f) * sc;
 #pragma unroll
-                    for (int u = 0; u < NV; ++u) {
+                    for (int u = 0; u < NR; ++u) {
                         const uint32_t cu = co + (uint32_t)u * (uint32_t)VS;
-                        const VT a = load_texel<4, false>(bv + (c.onw + cu)), b = load_texel<4, false>(bv + (c.one + cu));
-                        const VT d = load_texel<4, false>(bv + (c.osw + cu)), e = load_texel<4, false>(bv + (c.ose + cu));
-                        acc[u] = v_fma<VT>(a, w0, acc[u]);
-                        acc[u] = v_fma<VT>(b, w1, acc[u]);
-                        acc[u] = v_fma<VT>(d, w2, acc[u]);
-                        acc[u] = v_fma<VT>(e, w3, acc[u]);
+                        a[u] = *reinterpret_cast<const RT *>(bv + (c.onw + cu)); b[u] = *reinterpret_cast<const RT *>(bv + (c.one + cu));
+                        d[u] = *reinterpret_cast<const RT *>(bv + (c.osw + cu)); e[u] = *reinterpret_cast<const RT *>(bv + (c.ose + cu));
                     }
                 }
+                win_accumulate<NV, HALF>(acc, a, w0);
+                win_accumulate<NV, HALF>(acc, b, w1);
+                win_accumulate<NV, HALF>(acc, d, w2);
+                win_accumulate<NV, HALF>(acc, e, w3);
             }
         } else {
             for (int v = 0; v < V; ++v) {
                 const WinRec wr = wrec_at(p)[v];
-                const char *bv = data + (int64_t)v * m.sv * 4;
+                const char *bv = data + (int64_t)v * m.sv * ES;
                 const Corner c = corner_setup(m, wr.w[0], wr.w[1]);
 #pragma unroll
                 for (int u = 0; u < NV; ++u) {
-                    const uint32_t cu = co + (uint32_t)u * (uint32_t)VS;
-                    const VT a = load_texel<4, false>(bv + (c.onw + cu)), b = load_texel<4, false>(bv + (c.one + cu));
-                    const VT d = load_texel<4, false>(bv + (c.osw + cu)), e = load_texel<4, false>(bv + (c.ose + cu));
+                    // accumulator vector u = the four channels of raw vector u (fp16 storage: widened)
+                    VT a, b, d, e;
+                    if constexpr (HALF) {
+                        const uint32_t cu = co + (uint32_t)u * (uint32_t)VS;
+                        a = __builtin_convertvector(*reinterpret_cast<const f16x4 *>(bv + (c.onw + cu)), f32x4);
+                        b = __builtin_convertvector(*reinterpret_cast<const f16x4 *>(bv + (c.one + cu)), f32x4);
+                        d = __builtin_convertvector(*reinterpret_cast<const f16x4 *>(bv + (c.osw + cu)), f32x4);
+                        e = __builtin_convertvector(*reinterpret_cast<const f16x4 *>(bv + (c.ose + cu)), f32x4);
+                    } else {
+                        const uint32_t cu = co + (uint32_t)u * (uint32_t)VS;
+                        a = load_texel<4, false>(bv + (c.onw + cu)); b = load_texel<4, false>(bv + (c.one + cu));
+                        d = load_texel<4, false>(bv + (c.osw + cu)); e = load_texel<4, false>(bv + (c.ose + cu));
+                    }
                     const VT av = c.inw ? a : (VT)0.0f, bvv = c.ine ? b : (VT)0.0f, dv = c.isw ? d : (VT)0.0f, ev = c.ise ? e : (VT)0.0f;
                     VT s_ = av * c.wnw;
                     s_ = v_fma<VT>(bvv, c.wne, s_);
@@ -1196,10 +1282,11 @@ __device__ __forceinline__ void fused_eval_window_body(const EvalParams &P)
     // (A flagged point's row is stored twice by the same lane to the same address: program order holds for those.)
     const uint32_t row_bytes = (uint32_t)m.C * 4u;
     char *const out_bytes = reinterpret_cast<char *>(m.out);
-    auto store_point = [&](int p, uint32_t co, const VT (&acc)[NV]) {
-        char *row = out_bytes + ((uint64_t)idx_s[p] * row_bytes + co);
+    // (oco: byte offset of this lane's first accumulator vector in an output row -- the texel offset `co` for fp32 maps)
+    auto store_point = [&](int p, uint32_t oco, const VT (&acc)[NV]) {
+        char *row = out_bytes + ((uint64_t)idx_s[p] * row_bytes + oco);
 #pragma unroll
-        for (int u = 0; u < NV; ++u) store_row_vec(row + u * VS, acc[u]);
+        for (int u = 0; u < NV; ++u) store_row_vec(row + u * OVS, acc[u]);
     };
     // The pipelined point loop runs for ALL points of the lane group: the records of a point with a direct pair, and of a
     // strict point, point at the zero slices (harmless reads); such a point (rare: rim rounding, pool overflow, non-finite
@@ -1218,31 +1305,32 @@ __device__ __forceinline__ void fused_eval_window_body(const EvalParams &P)
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");      // the DMA of this slice has landed (and phase A's records)
         D3F_STAMP();                                // 5 + 3 sl: pool of this slice ready
         const uint32_t co = (uint32_t)sl * SB + lane_off;               // byte offset of this lane's first vector in a texel
+        const uint32_t oco = (uint32_t)sl * OSB + (uint32_t)l * 16u;             // ... of its first four channels in an output row (fp32)
 #if D3F_WIN_ABLATE & 2
         if (false)
 #endif
         if (pipe_ok) {
-            window_points_pipelined<NV, (VFIX > 0 ? VFIX : 1), KI, VS, (int)SB, G * ((VFIX > 0 ? VFIX : 1) * 32 + 16)>(
+            window_points_pipelined<NV, (VFIX > 0 ? VFIX : 1), KI, VS, (int)SB, G * ((VFIX > 0 ? VFIX : 1) * 32 + 16), HALF>(
                 smem, (uint32_t)grp * pstride, lane_off, [&](int k, const VT (&acc)[NV]) {
-                    char *row = out_bytes + ((uint64_t)pidx[k] * row_bytes + co);
+                    char *row = out_bytes + ((uint64_t)pidx[k] * row_bytes + oco);
 #if D3F_WIN_ABLATE & 4
                     row = out_bytes + ((uint64_t)(threadIdx.x + 256u * (blockIdx.x & 1023u)) * 32u);
 #endif
 #pragma unroll
-                    for (int u = 0; u < NV; ++u) store_row_vec(row + u * VS, acc[u]);
+                    for (int u = 0; u < NV; ++u) store_row_vec(row + u * OVS, acc[u]);
                 });
 #pragma unroll 1
             for (int p = grp; p < TP; p += G)
                 if (flag_s[p] != 0u) {              // a direct pair or a strict point: the general path, stored over the row above
                     VT acc[NV];
                     point_slice(p, co, acc);
-                    store_point(p, co, acc);
+                    store_point(p, oco, acc);
                 }
         } else {
             for (int p = grp; p < TP; p += G) {
                 VT acc[NV];
                 point_slice(p, co, acc);
-                store_point(p, co, acc);
+                store_point(p, oco, acc);
             }
         }
         D3F_STAMP();                                // 6 + 3 sl: this wave's points of the slice done
@@ -1294,11 +1382,11 @@ __device__ __forceinline__ bool gated_out(const EvalParams &P)
     return (fit >= P.gate_min) != (P.gate_want != 0);
 }
 
-template <int U, int VC, int WAVES, int NT = kBlock, int LPP = 32, int VFIX = 0, bool SPARSE = false>
+template <int U, int VC, int WAVES, int NT = kBlock, int LPP = 32, int VFIX = 0, bool SPARSE = false, bool HALF = false>
 __global__ __launch_bounds__(NT, WAVES) void fused_eval_window_kernel(const EvalParams P)
 {
     if (gated_out(P)) return;
-    fused_eval_window_body<U, VC, NT, LPP, VFIX, SPARSE>(P);
+    fused_eval_window_body<U, VC, NT, LPP, VFIX, SPARSE, HALF>(P);
 }
 
 // gate[0] verdict (tiles that fit), gate[1] running count, gate[2] workgroups done; [1] and [2] are zero between launches
@@ -1485,7 +1573,8 @@ hipError_t launch_fused_eval(const EvalParams &P, int mode, hipStream_t stream)
         runs |= (P.maps[s].runs > 0);
     }
     if (mode == 0 && P.win_slices > 0) {
-        const size_t lds_w = (size_t)P.win_pool_offset + (size_t)(2 + P.win_pool_texels) * 512 * P.win_u;
+        const bool half = P.maps[0].esize == 2;        // fp16-stored map: 256-byte slices (lattices only, 16 lanes per point)
+        const size_t lds_w = (size_t)P.win_pool_offset + (size_t)(2 + P.win_pool_texels) * (half ? 256 : 512) * P.win_u;
         dim3 gw((unsigned)((P.n + P.tile_pts - 1) / P.tile_pts));
         if (P.walk_nx > 0) gw = dim3((unsigned)ntiles);
 #define D3F_WIN_LAUNCH_S(U_, VC_, W_, LPP_, VF_, SP_)                                                                          \
@@ -1519,6 +1608,23 @@ hipError_t launch_fused_eval(const EvalParams &P, int mode, hipStream_t stream)
         // ONE register budget (<= 128 VGPRs: four waves per SIMD) serves every pool size: the workgroups per CU follow from the
         // dynamic LDS of the launch (win_occ sized the pool), not from the kernel variant -- up to round 4 a second set held to
         // __launch_bounds__(256, 3) existed and allocated 121 instead of 125 registers, the same occupancy step
+#define D3F_WIN_LAUNCH_H(VF_)                                                                                                 \
+        do {                                                                                                                       \
+            if (lds_w > 64 * 1024) {                                                                                               \
+                hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void *>(&fused_eval_window_kernel<1, 1, 4, kBlock, 16, VF_, false, true>), \
+                                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_w);                      \
+                if (ea != hipSuccess) return ea;                                                                                   \
+            }                                                                                                                      \
+            hipLaunchKernelGGL((fused_eval_window_kernel<1, 1, 4, kBlock, 16, VF_, false, true>), gw, block, lds_w, stream, P);    \
+        } while (0)
+        if (half) {
+            if (!lpp16 || P.win_sparse) return hipErrorInvalidValue;
+            if (vfix == 4) D3F_WIN_LAUNCH_H(4);
+            else if (vfix == 8) D3F_WIN_LAUNCH_H(8);
+            else D3F_WIN_LAUNCH_H(0);
+            return hipGetLastError();
+        }
+#undef D3F_WIN_LAUNCH_H
         if (lpp16 && vfix == 4) D3F_WIN_LAUNCH_F(1, 1, 4, 16, 4);
         else if (lpp16 && vfix == 8) D3F_WIN_LAUNCH_F(1, 1, 4, 16, 8);
         else if (lpp16) D3F_WIN_LAUNCH(1, 1, 4, 16);
@@ -1544,6 +1650,11 @@ hipError_t launch_fused_eval(const EvalParams &P, int mode, hipStream_t stream)
         const int64_t wgs = ((units + 7) / 8 + P.sl_ilv - 1) / P.sl_ilv * P.sl_ilv * 8 * P.sl_unit;
         const size_t lds_s = (size_t)P.crec_offset + (size_t)P.tile_pts * P.V * 32 + (size_t)P.lds_pad;
         const dim3 gs((unsigned)wgs);
+        if (P.maps[0].esize == 2) {                 // fp16-stored map: 16 lanes x 8 channels = 128-channel (256-byte) slices
+            if (P.sl_lg != 4 || P.sl_vc != 2) return hipErrorInvalidValue;
+            hipLaunchKernelGGL((fused_eval_sliced_kernel<4, 2, 7, true>), gs, block, lds_s, stream, P);
+            return hipGetLastError();
+        }
         if (P.sl_lg == 5 && P.sl_vc == 2) hipLaunchKernelGGL((fused_eval_sliced_kernel<5, 2, 7>), gs, block, lds_s, stream, P);
 #ifndef D3F_EXPERIMENTS
         else return hipErrorInvalidValue;          // (other slice widths / views in flight: experiments builds only)

@@ -499,11 +499,12 @@ class Fusion:
             vfix = int(views.V) if (int(views.V) in (4, 8) and int(plan.tile_points) == 64 and plan.lanes_per_point[w0] == 16) else 0
             # (third argument: the register budget the variant is built for -- 4 waves per SIMD for every 16-lane variant; the plan's
             #  last digit is the workgroups per CU the POOL is sized for)
-            kernel = "fused_eval_window_kernel<%d, %d, %d, 256, %d, %d, %s>" % (r // 100, r // 10 % 10, 4 if plan.lanes_per_point[w0] == 16 else r % 10, plan.lanes_per_point[w0], vfix,
-                                                                              "false" if lattice is not None else "true")
+            kernel = "fused_eval_window_kernel<%d, %d, %d, 256, %d, %d, %s%s>" % (r // 100, r // 10 % 10, 4 if plan.lanes_per_point[w0] == 16 else r % 10, plan.lanes_per_point[w0], vfix,
+                                                                                "false" if lattice is not None else "true",
+                                                                                ", true" if maps[w0].dtype == _lib.DTYPE_F16 else "")
         elif plan.reserved >= 100:
             lg, vc = (plan.reserved - 100) // 10, (plan.reserved - 100) % 10
-            kernel = "fused_eval_sliced_kernel<%d, %d, %d>" % (lg, vc, {1: 8, 2: 7, 4: 5}.get(vc, 5))
+            kernel = "fused_eval_sliced_kernel<%d, %d, %d%s>" % (lg, vc, {1: 8, 2: 7, 4: 5}.get(vc, 5), ", true" if f16 else "")
         elif runs and not f16 and not wide:
             s0 = [s for s in range(n_maps) if plan.staged[s] >= 16][0]
             kernel = "fused_eval_runs_kernel<0, %d, %d, %d>" % (plan.vectors_per_lane[s0], plan.staged[s0] - 16, plan.reserved)

@@ -543,6 +543,47 @@ def test_cloud_gate_follows_the_density(dev, V, hw, fhw, C, scale, expect_window
     assert rel_err(cpu(out["dino_feats"])[pick], ref["sets"][0]) <= TOL
 
 
+@pytest.mark.parametrize("kind,V,hw,fhw,C,mask", [("window", 4, (480, 640), (48, 64), 384, True), ("window", 8, (480, 640), (36, 64), 1024, False),
+                                                  ("window", 3, (480, 640), (24, 32), 256, False), ("sliced", 4, (192, 256), (192, 256), 384, True),
+                                                  ("sliced", 2, (240, 320), (240, 320), 1024, False)])
+def test_fp16_stored_maps_take_the_window_and_sliced_kernels(dev, kind, V, hw, fhw, C, mask):
+    """Round 5: a map STORED in fp16 keeps the fast kernels -- LDS texel windows of 256-byte slices on a lattice over a
+    patch-resolution map, 16 lanes x 8 channels per point in the channel-sliced launch over a dense one -- with the halves widened
+    inside v_fma_mix_f32: the rows equal those of the fp32 query on the widened map bit for bit (and of the direct gather on the
+    fp16 map), including a strict point, clipped bricks and a thin fp32 map riding along."""
+    from d3fields_amd import create_init_grid, synth
+    H, W = hw
+    feats16 = (synth.random_map(V, fhw[0], fhw[1], C, seed=1, device=dev) * 2.0).half()
+    maps16 = {"dino_feats": feats16}
+    names = ["dino_feats"]
+    if mask:
+        maps16["mask"] = synth.random_onehot_mask(V, H, W, 8, seed=2, device=dev)
+        names.append("mask")
+    f16, sc = fusion_for(dev, V, H, W, maps16)
+    f32, _ = fusion_for(dev, V, H, W, dict(maps16, dino_feats=feats16.float()))
+    pts_c = create_init_grid(synth.WORK_BOX, 0.0107)[0]                                # 74 x 65 x 20 points
+    pts_c[1000, 1] = float("inf")                                                       # a strict point
+    pts = pts_c.to(dev)
+    with torch.no_grad():
+        f16.record_plans = True
+        a = f16.batch_eval(pts, return_names=names)
+        kernel = f16.last_plan()["kernel"]
+        assert kernel.startswith("fused_eval_%s_kernel" % kind) and kernel.endswith(", true>"), kernel
+        b = f32.batch_eval(pts, return_names=names)
+        with knobs(D3F_EXP_RUNS=-1):
+            c = f16.batch_eval(pts, return_names=names)
+            assert f16.last_plan()["kernel"] == "fused_eval_f16_kernel<0>"
+    for tag, o in (("fp32 query on the widened map", b), ("direct gather on the fp16 map", c)):
+        for k in ["dist", "valid_mask"] + names:
+            x, y = a[k], o[k]
+            assert torch.equal(torch.isnan(x), torch.isnan(y)) and torch.equal(torch.nan_to_num(x.float()), torch.nan_to_num(y.float())), (tag, k)
+    pick = torch.randperm(pts.shape[0], generator=torch.Generator().manual_seed(3))[:1500]
+    pick = pick[pick != 1000]
+    ref = oracle_sample(sc, pts_c[pick], [f32.curr_obs_torch[k] for k in names])
+    assert np.array_equal(cpu(a["dist"])[pick], ref["dist"])
+    assert rel_err(cpu(a["dino_feats"])[pick], ref["sets"][0]) <= TOL
+
+
 def test_window_kernel_with_wrong_lattice_dims_is_still_exact(dev):
     """d3f_eval_lattice promises that ANY dims whose product is n are correct.  The window kernel estimates its texel
     windows from the eight 'corner' slots of a brick -- meaningless for a cloud or a shuffled grid passed with made-up

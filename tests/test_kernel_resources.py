@@ -20,14 +20,18 @@ BUDGET = {
     "21fused_eval_f16_kernelILi0E": (168, 0),                   # fp16-stored maps, 3 waves
     "22fused_eval_runs_kernelILi0ELi1ELi4ELi7E": (72, 0),       # cell runs (1,4), 7 waves
     "22fused_eval_runs_kernelILi0ELi2ELi8ELi3E": (168, 0),      # cell runs (2,8), 3 waves
-    "24fused_eval_sliced_kernelILi5ELi2ELi7E": (72, 0),         # channel-sliced, 7 waves
-    "24fused_eval_window_kernelILi1ELi1ELi4ELi256ELi16ELi4ELb0E": (128, 0),   # LDS texel windows of lattice bricks, pipelined point loop (V = 4): 4 waves per SIMD
-    "24fused_eval_window_kernelILi1ELi1ELi4ELi256ELi16ELi8ELb0E": (128, 0),   # ... V = 8
-    "24fused_eval_window_kernelILi1ELi1ELi4ELi256ELi16ELi0ELb0E": (128, 0),   # ... any other view count: plain view loop
-    "24fused_eval_window_kernelILi1ELi1ELi4ELi256ELi16ELi4ELb1E": (128, 0),   # touched-texel pool (clouds behind the device-side gate), V = 4
-    "24fused_eval_window_kernelILi1ELi1ELi4ELi256ELi16ELi8ELb1E": (128, 0),
-    "24fused_eval_window_kernelILi1ELi1ELi4ELi256ELi16ELi0ELb1E": (128, 0),
+    "24fused_eval_sliced_kernelILi5ELi2ELi7ELb0E": (72, 0),         # channel-sliced, 7 waves
+    "24fused_eval_window_kernelILi1ELi1ELi4ELi256ELi16ELi4ELb0ELb0E": (128, 0),   # LDS texel windows of lattice bricks, pipelined point loop (V = 4): 4 waves per SIMD
+    "24fused_eval_window_kernelILi1ELi1ELi4ELi256ELi16ELi8ELb0ELb0E": (128, 0),   # ... V = 8
+    "24fused_eval_window_kernelILi1ELi1ELi4ELi256ELi16ELi0ELb0ELb0E": (128, 0),   # ... any other view count: plain view loop
+    "24fused_eval_window_kernelILi1ELi1ELi4ELi256ELi16ELi4ELb1ELb0E": (128, 0),   # touched-texel pool (clouds behind the device-side gate), V = 4
+    "24fused_eval_window_kernelILi1ELi1ELi4ELi256ELi16ELi8ELb1ELb0E": (128, 0),
+    "24fused_eval_window_kernelILi1ELi1ELi4ELi256ELi16ELi0ELb1ELb0E": (128, 0),
     "24window_gate_probe_kernel": (128, 0),
+    "24fused_eval_window_kernelILi1ELi1ELi4ELi256ELi16ELi4ELb0ELb1E": (128, 0),   # fp16-stored maps: 256-byte slices, v_fma_mix_f32
+    "24fused_eval_window_kernelILi1ELi1ELi4ELi256ELi16ELi8ELb0ELb1E": (128, 0),
+    "24fused_eval_window_kernelILi1ELi1ELi4ELi256ELi16ELi0ELb0ELb1E": (128, 0),
+    "24fused_eval_sliced_kernelILi4ELi2ELi7ELb1E": (72, 0),                       # ... in the channel-sliced launch
 }
 
 
@@ -48,4 +52,4 @@ def test_default_kernels_keep_their_register_budget():
     # the product build compiles only the variants the planner picks by itself, and none of them spills
     spilling = {k: v for k, v in seen.items() if v[1] > 0}
     assert not spilling, spilling
-    assert len(seen) <= 16, "experiment variants leaked into the product build: %s" % sorted(seen)
+    assert len(seen) <= 22, "experiment variants leaked into the product build: %s" % sorted(seen)
