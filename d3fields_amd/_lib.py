@@ -22,6 +22,7 @@ TUNE_XCD_REMAP, TUNE_NO_REORDER, TUNE_FORCE_REORDER = 1 << 12, 1 << 13, 1 << 14
 TUNE_DIRECT_GATHER = 1 << 4
 TUNE_NO_WINDOW_GATE, TUNE_WINDOW_SIDE = 1 << 5, 1 << 6
 GATE_SAMPLES, GATE_MIN_FIT = 128, 96
+CHECK_WORDS_ARE_ZERO = 1
 MAX_VIEWS = 64
 MAX_MAPS = 8
 DTYPE_F32 = 0
@@ -61,7 +62,7 @@ class EvalPlan(ctypes.Structure):
     """struct d3f_eval_plan"""
     _fields_ = [("tile_points", _i32), ("reorder", _i32), ("lds_bytes", _i32), ("reserved", _i32), ("workgroups", _i64),
                 ("vector_floats", _i32 * MAX_MAPS), ("lanes_per_point", _i32 * MAX_MAPS),
-                ("vectors_per_lane", _i32 * MAX_MAPS), ("staged", _i32 * MAX_MAPS), ("gated_window", _i32), ("reserved2", _i32)]
+                ("vectors_per_lane", _i32 * MAX_MAPS), ("staged", _i32 * MAX_MAPS), ("gated_window", _i32), ("reserved2", _i32), ("family", _i32), ("reserved3", _i32)]
 
 
 # name -> (restype, argtypes); every symbol include/d3fields_hip.h declares
@@ -73,8 +74,11 @@ SIGNATURES = {
     "d3f_eval": (ctypes.c_int, [ctypes.POINTER(Views), _vp, _i64, ctypes.POINTER(ChannelMap), _i32, _f32, _u32,
                                 _vp, _vp, ctypes.POINTER(_vp), ctypes.POINTER(_vp), _vp, _i64, _vp]),
     "d3f_map_check": (ctypes.c_int, [ctypes.POINTER(ChannelMap), _i32, _vp, _vp]),
+    "d3f_map_check_many": (ctypes.c_int, [ctypes.POINTER(ChannelMap), ctypes.POINTER(_i32), _i32, ctypes.POINTER(_vp), _u32, _vp]),
     "d3f_eval_workspace_bytes": (_i64, [_i64]),
     "d3f_eval_gate_offset": (_i64, [_i64]),
+    "d3f_plan_family_name": (ctypes.c_char_p, [_i32]),
+    "d3f_plan_family_takes": (ctypes.c_char_p, [_i32]),
     "d3f_profile_next_eval": (None, [_vp, _vp]),
     "d3f_eval_plan_query": (ctypes.c_int, [ctypes.POINTER(Views), _i64, ctypes.POINTER(ChannelMap), _i32, _u32, _i32, _i32,
                                            ctypes.POINTER(EvalPlan)]),

@@ -38,55 +38,46 @@ int check_views(const d3f_views *v)
     return D3F_OK;
 }
 
-// Phase-B lane mapping of one map: vector width, lanes per point (2^k) and vectors per lane.
-// Minimises idle lane-slots (passes*lpp*U - cvec), then passes, then prefers wide groups
-// (longer contiguous segments per load instruction).
-// batch: issue all 4*U corner loads before the first use (best for cache-resident maps, U <= 3);
-// otherwise load-use per vector, U <= 4 (best when the map misses the caches).
-void pick_mapping(d3f::MapDesc &m, bool can16, bool can8, bool batch, int max_u = 4)
+// Experiment knobs read from the environment (integers; results never depend on them):
+//   D3F_EXP_RUNS   cell-run gather on patch-resolution wide maps: -1 off, 0 automatic (default), 2 / 4 / 8 = run length
+//   D3F_EXP_RUNS_U vectors per lane of the cell-run gather: 0 automatic, 1 / 2 / 3;  D3F_EXP_RUNS_OCC=5: the (1,8) variant
+//                  held to 5 waves per SIMD
+//   D3F_EXP_STORE  -1: write the fused rows with plain stores, 1: with sc1 ones, 3: with `sc1 nt` ones, instead of `nt` ones (store_out, fuse_common.h)
+//                  also in the window kernel (plain there by default)
+//   D3F_EXP_SLICED 1 / 2 / 3: force the channel-sliced launch for a dense wide map on a lattice (128- / 256- / 512-byte
+//                  slices, fuse_eval.hip); -1: never (default: only with thin companion maps); _VC views in flight, _UNIT
+//                  workgroups per unit
+//   D3F_EXP_WALK_TILE  shape of the walk's tile as digits x y z with the same point count (222 default; 224 with a thin map)
+//   D3F_EXP_WALK   lattice brick walk for grids on large maps: -1 off, 0 automatic (default)
+//   D3F_EXP_THIN   -1: thin maps (mask, colours) through the view-sequential gather_map instead of gather_map_thin
+//   D3F_EXP_WINDOW LDS texel-window kernel instead of the cell-run gather for a patch-resolution wide first map
+//                  (fuse_eval.hip, DESIGN.md 5.5): 0 automatic = on lattices (64 points per workgroup), -1 never,
+//                  32 / 64 / 128 = always, with that many points per workgroup; _U vectors per lane (1..4), _VC views
+//                  in flight (U = 2 / 3), _OCC workgroups per CU (2..4), _POOL pool texels, _LPP 32: one vector per lane (default 16 x 2)
+//   D3F_EXP_RUNS_OCC also: 4 = the (2,8) cell-run variant held to 4 waves per SIMD (default 3, spill-free)
+#ifdef D3F_EXPERIMENTS
+// built with -DD3F_EXPERIMENTS (python -m d3fields_amd.build --experiments): tuning sessions only
+int exp_knob(const char *name)
 {
-    m.vw = (m.C % 4 == 0 && can16) ? 4 : ((m.C % 2 == 0 && can8) ? 2 : 1);
-    const int cvec = m.C / m.vw;
-    long best_slots = -1;
-    int best_passes = 0;
-    for (int lg = 6; lg >= 0; --lg) {
-        const int lpp = 1 << lg;
-        for (int u = (batch ? 3 : 4) < max_u ? (batch ? 3 : 4) : max_u; u >= 1; --u) {
-            const int per = lpp * u;
-            const int passes = (cvec + per - 1) / per;
-            const long slots = (long)passes * per;
-            // thin family (max_u == 1: masks, colours): fewest PASSES first -- every pass repeats the per-(point, view)
-            // set-up, and <= 4 lanes per point make the map eligible for the views-in-parallel gather (gather_map_thin)
-            const bool better = best_slots < 0 || (max_u == 1 ? (passes < best_passes || (passes == best_passes && slots < best_slots))
-                                                               : (slots < best_slots || (slots == best_slots && passes < best_passes)));
-            if (better) {
-                best_slots = slots;
-                best_passes = passes;
-                m.lpp_log2 = lg;
-                m.unroll = u;
-            }
-        }
-    }
-    if (!batch) m.unroll = -m.unroll;
+    const char *v = getenv(name);
+    return v ? atoi(v) : 0;
 }
+// phase stamps of the window kernel (D3F_EXP_STAMPS=1): 32 x uint64 per sampled workgroup, read back with d3f_exp_read_stamps
+constexpr int64_t kStampBytes = 8LL * 32 * 65536;
+unsigned long long *exp_stamp_buffer(bool clear)
+{
+    static unsigned long long *buf = nullptr;
+    if (!buf && hipMalloc(reinterpret_cast<void **>(&buf), kStampBytes) != hipSuccess) buf = nullptr;
+    if (buf && clear) (void)hipMemset(buf, 0, kStampBytes);
+    return buf;
+}
+#else
+// the product build reads no environment: every knob is its default (0), the library keeps no hidden state
+constexpr int exp_knob(const char *) { return 0; }
+#endif
 
-// ---- launch-plan thresholds (every row has a test in tests/test_abi.py::test_plan_table) ---------------------------------
-//  kSmallBatch          fewer points than this: no reordering, no window / cell-run / sliced launch -- the set-up of those
-//                       paths costs more than it saves, and small batches are spread over >= 1024 workgroups instead
-//  kCacheResidentBytes  all requested maps together at most this big live in the L2s / Infinity Cache anyway: the caller's
-//                       order is kept (unless the cloud has no locality at all), 128-point tiles
-//  kBatchedLoadBytes    a map at most this big issues all 4*U corner loads of a view before the first use; bigger maps
-//                       in caller order use load-use per vector (a smaller in-flight footprint measured faster)
-//  kBeyondLlcBytes      maps beyond this in CALLER order without scratch: 64-point tiles at 2 workgroups per CU
-//  kWindowCloudMin      a cloud of at least this many points (in the Hilbert order) may take the LDS-window kernel when the device-side
-//                       probe finds its tiles compact (below: the window kernel's ~25-us workgroups do not fill the chip twice
-//                       over and the cell-run kernel wins: 71 k surface points 0.17 vs 0.12 ms, 100 k keypoints 0.12 vs 0.09)
-constexpr int64_t kSmallBatch = 65536;
-constexpr int64_t kWindowCloudMin = 262144;
-constexpr int kGatedSecondPass = 1;          // eval_common's internal "now enqueue the other side" status (never returned to callers)
-constexpr int64_t kCacheResidentBytes = 64LL << 20;
-constexpr int64_t kBatchedLoadBytes = 128LL << 20;
-constexpr int64_t kBeyondLlcBytes = 512LL << 20;
+// the launch planner: thresholds, the family table, one function per kernel family (host logic only)
+#include "d3f_plan.h"
 
 // Validates one channel map and fills the kernel-side descriptor (out/inter may be NULL for backward).
 int fill_map(const d3f_channel_map &c, int s, int V, float *out, float *inter, const float *extra_aligned,
@@ -146,129 +137,17 @@ int fill_map(const d3f_channel_map &c, int s, int V, float *out, float *inter, c
     return D3F_OK;
 }
 
-// Experiment knobs read from the environment (integers; results never depend on them):
-//   D3F_EXP_RUNS   cell-run gather on patch-resolution wide maps: -1 off, 0 automatic (default), 2 / 4 / 8 = run length
-//   D3F_EXP_RUNS_U vectors per lane of the cell-run gather: 0 automatic, 1 / 2 / 3;  D3F_EXP_RUNS_OCC=5: the (1,8) variant
-//                  held to 5 waves per SIMD
-//   D3F_EXP_STORE  -1: write the fused rows with plain stores, 1: with sc1 ones, 3: with `sc1 nt` ones, instead of `nt` ones (store_out, fuse_common.h)
-//                  also in the window kernel (plain there by default)
-//   D3F_EXP_SLICED 1 / 2 / 3: force the channel-sliced launch for a dense wide map on a lattice (128- / 256- / 512-byte
-//                  slices, fuse_eval.hip); -1: never (default: only with thin companion maps); _VC views in flight, _UNIT
-//                  workgroups per unit
-//   D3F_EXP_WALK_TILE  shape of the walk's tile as digits x y z with the same point count (222 default; 224 with a thin map)
-//   D3F_EXP_WALK   lattice brick walk for grids on large maps: -1 off, 0 automatic (default)
-//   D3F_EXP_THIN   -1: thin maps (mask, colours) through the view-sequential gather_map instead of gather_map_thin
-//   D3F_EXP_WINDOW LDS texel-window kernel instead of the cell-run gather for a patch-resolution wide first map
-//                  (fuse_eval.hip, DESIGN.md 5.5): 0 automatic = on lattices (64 points per workgroup), -1 never,
-//                  32 / 64 / 128 = always, with that many points per workgroup; _U vectors per lane (1..4), _VC views
-//                  in flight (U = 2 / 3), _OCC workgroups per CU (2..4), _POOL pool texels, _LPP 32: one vector per lane (default 16 x 2)
-//   D3F_EXP_RUNS_OCC also: 4 = the (2,8) cell-run variant held to 4 waves per SIMD (default 3, spill-free)
-#ifdef D3F_EXPERIMENTS
-// built with -DD3F_EXPERIMENTS (python -m d3fields_amd.build --experiments): tuning sessions only
-int exp_knob(const char *name)
-{
-    const char *v = getenv(name);
-    return v ? atoi(v) : 0;
-}
-// phase stamps of the window kernel (D3F_EXP_STAMPS=1): 32 x uint64 per sampled workgroup, read back with d3f_exp_read_stamps
-constexpr int64_t kStampBytes = 8LL * 32 * 65536;
-unsigned long long *exp_stamp_buffer(bool clear)
-{
-    static unsigned long long *buf = nullptr;
-    if (!buf && hipMalloc(reinterpret_cast<void **>(&buf), kStampBytes) != hipSuccess) buf = nullptr;
-    if (buf && clear) (void)hipMemset(buf, 0, kStampBytes);
-    return buf;
-}
-#else
-// the product build reads no environment: every knob is its default (0), the library keeps no hidden state
-constexpr int exp_knob(const char *) { return 0; }
-#endif
+constexpr int kGatedSecondPass = 1;          // eval_common's internal "now enqueue the other side" status (never returned to callers)
 
-// Cell-run gather (fuse_eval.hip gather_map_runs): fp32 maps read as 16-byte vectors with >= 32 vectors per texel whose
-// texels span >= 4 image pixels -- the patch-resolution feature maps of the reference (fusion.py:694-697).
-bool runs_candidate(const d3f::MapDesc &m, int H, int W)
-{
-    return m.esize == 4 && m.vw == 4 && m.C >= 128 && (W - 1) >= 4 * (m.fw - 1) && (H - 1) >= 4 * (m.fh - 1);
-}
-
-// LDS texel windows (fuse_eval.hip fused_eval_window_kernel): a patch-resolution wide map in whole 128-channel slices whose texels
-// start on 16-byte boundaries -- fp32 (512-byte slices), or stored in fp16 (256-byte slices, round 5: lattices only)
-bool window_candidate(const d3f::MapDesc &m, const d3f_views *views, bool check_pointer)
-{
-    const int es = m.esize, per16 = 16 / es;            // channels per 16 bytes
-    const bool vec = es == 4 ? m.vw == 4 : m.vw == 8;
-    // (m.fold: a map of <= 256 bytes per texel -- 128 channels of fp16 -- belongs to the thin family, which keeps the reference's
-    //  operation order in every kernel; the window kernel's arithmetic is the folded one)
-    return vec && m.fold && m.C >= 128 && m.C % 128 == 0 && (views->W - 1) >= 4 * (m.fw - 1) && (views->H - 1) >= 4 * (m.fh - 1) &&
-           (int64_t)views->V * m.sv * es < (1LL << 31) && (m.sx % per16) == 0 && (m.sy % per16) == 0 && (m.sv % per16) == 0 &&
-           (!check_pointer || reinterpret_cast<uintptr_t>(m.data) % 16 == 0);
-}
-
-// (vectors per lane U, run length K) of the cell-run gather: the built variants are (1,8) (2,4) (2,8) (3,2) (3,4)
-void pick_runs_mapping(d3f::MapDesc &m, int U, int K)
-{
-    const int cvec = m.C / 4;
-    // Defaults from the MI355X sweeps (gpurun_out/r2h): 32-lane groups (C = 384) -> one vector per lane,
-    // 4-point runs, 69 VGPR = 7 waves per SIMD (C2 patch 0.750 -> 0.633 ms, C3 patch 1.537 -> 1.288); 64-lane groups
-    // (C = 1024) -> two vectors per lane x two passes, 8-point runs at 4 waves per SIMD (C4 patch 4.32 -> 3.35).
-    const bool auto_u = U <= 0 || U > 3;
-    if (auto_u) U = (cvec % 128 == 0) ? 2 : 1;
-    long best_slots = -1;
-    for (int lg = 6; lg >= 5; --lg) {           // 64 or 32 lanes per point; ties go to the wider group (fewer passes)
-        const long per = (long)(1 << lg) * U;
-        const long slots = (cvec + per - 1) / per * per;
-        if (best_slots < 0 || slots < best_slots) { best_slots = slots; m.lpp_log2 = lg; }
-    }
-    if (auto_u && U == 2 && m.lpp_log2 != 6) {   // two vectors per lane only pays on full 64-lane groups
-        U = 1;
-        best_slots = -1;
-        for (int lg = 6; lg >= 5; --lg) {
-            const long per = (long)(1 << lg);
-            const long slots = (cvec + per - 1) / per * per;
-            if (best_slots < 0 || slots < best_slots) { best_slots = slots; m.lpp_log2 = lg; }
-        }
-    }
-    if (U == 3 && K != 2) K = 4;
-    if (U == 2 && K != 4) K = 8;
-    if (U == 1 && K != 4 && K != 8) K = m.lpp_log2 == 5 ? 4 : 8;
-    m.unroll = U;
-    m.runs = K;
-}
-
-// Brick of the lattice one window workgroup takes: T points with power-of-two sides (the kernel decodes a slot with
-// shifts), as few padded slots as possible, then as cubic as possible
-void pick_window_brick(int nx, int ny, int nz, int T, int &bx, int &by, int &bz)
-{
-    double best = -1.0;
-    bx = by = 1; bz = T;
-    for (int x = 1; x <= T; x <<= 1)
-        for (int y = 1; x * y <= T; y <<= 1) {
-            const int z = T / (x * y);
-            const double blocks = (double)((nx + x - 1) / x) * ((ny + y - 1) / y) * ((nz + z - 1) / z);
-            const double eff = (double)nx * ny * nz / (blocks * T);
-            const int hi = x > y ? (x > z ? x : z) : (y > z ? y : z), lo = x < y ? (x < z ? x : z) : (y < z ? y : z);
-            const double score = eff * (1.0 - 0.03 * ((double)hi / lo - 1.0));
-            if (score > best) { best = score; bx = x; by = y; bz = z; }
-        }
-}
-
-int tile_points_for(int V)
-{
-    // LDS per workgroup = tile*V*24 B (+ small); keep it <= 32 KiB so >= 4 workgroups fit a CU.
-    // 128 points measured best (985 600-pt grid, C=384: 128 -> 0.99 ms, 256 -> 1.06 ms patch-res).
-    int t = 128;
-    while (t > 32 && (long)t * V * 24 > 32 * 1024) t >>= 1;
-    return t;
-}
-
+// Validates, fills the kernel parameters, PLANS (d3f_plan.h), builds / reuses the point order, launches.
+// cloud_side (d3f_eval): 0 = plan queries and the callers that never gate; 1 = first pass of a query -- if the points are a cloud the
+// window kernel may take (kWindowCloudMin points, a patch-resolution wide map, the Hilbert order), this pass enqueues order +
+// probe + the GATED window launch and returns kGatedSecondPass; 2 = the second pass: the gated cell-run launch.
 int eval_common(const d3f_views *views, const float *pts, int64_t n, const d3f_channel_map *maps, int32_t n_maps,
                 float mu, uint32_t flags, float *out_dist, uint8_t *out_valid, float *const *out_fused,
                 float *const *out_inter, void *workspace, int64_t workspace_bytes, void *stream, int mode,
                 d3f_eval_plan *plan_out = nullptr, const d3f_grid *grid = nullptr, const int32_t *lattice = nullptr, int cloud_side = 0)
 {
-    // cloud_side (eval_entry): 0 = plan queries and the callers that never gate; 1 = first pass of a query -- if the points are a
-    // cloud the window kernel may take (kWindowCloudMin points, a patch-resolution wide map, the Hilbert order), this pass
-    // enqueues order + probe + the GATED window launch and returns kGatedSecondPass; 2 = the second pass: the gated cell-run launch
     const bool plan_only = plan_out != nullptr;
     int rc = check_views(views);
     if (rc != D3F_OK) return rc;
@@ -293,7 +172,8 @@ int eval_common(const d3f_views *views, const float *pts, int64_t n, const d3f_c
             for (int s = 0; s < n_maps; ++s) P.words[P.n_words++] = maps[s].nonfinite;
         }
     }
-    const bool finite_expected = (flags & D3F_FLAG_FINITE_MAPS) || P.n_words > 0;
+    for (int k = 0; k < P.n_words; ++k)
+        if (!aligned(P.words[k], 4)) return fail(D3F_ERR_BAD_LAYOUT, "nonfinite word %d: device pointer must be 4-byte aligned", k);
     P.exp_stamps = nullptr;
 #ifdef D3F_EXPERIMENTS
     if (exp_knob("D3F_EXP_STAMPS") > 0 && !plan_out) P.exp_stamps = exp_stamp_buffer(true);
@@ -312,26 +192,29 @@ int eval_common(const d3f_views *views, const float *pts, int64_t n, const d3f_c
     P.win_sparse = 0;
     P.gate = nullptr; P.gate_min = 0u; P.gate_want = 0;
     P.store_policy = exp_knob("D3F_EXP_STORE") < 0 ? 0 : (exp_knob("D3F_EXP_STORE") == 1 ? 1 : (exp_knob("D3F_EXP_STORE") == 3 ? 3 : 2));     // non-temporal rows (fuse_common.h: store_out)
-    int64_t map_bytes = 0;
     P.out_dist = out_dist; P.out_valid = out_valid;
     P.n = n; P.V = views->V; P.H = views->H; P.W = views->W;
     P.n_maps = n_maps; P.tile_pts = tile_points_for(views->V);
     P.flags = flags; P.mu = mu;
-    // tuning bits (D3F_TUNE_*): experiments only, results never depend on them
-    const int tl = (int)((flags >> 8) & 0xF);
-    const int max_tile = tile_points_for(views->V) * 2;
+
+    Query q;
+    q.views = views; q.n = n; q.n_maps = n_maps; q.flags = flags; q.mode = mode; q.lattice = lattice; q.grid = grid != nullptr;
+    q.plan_only = plan_only; q.cloud_side = cloud_side;
+    q.finite_expected = (flags & D3F_FLAG_FINITE_MAPS) || P.n_words > 0;
+    q.direct = (flags & D3F_TUNE_DIRECT_GATHER) != 0;     // the plain direct gather in the chosen point order: the reference of the bit-identity tests
+    q.tl = (int)((flags >> 8) & 0xF);
+    q.map_bytes = 0;
     for (int s = 0; s < n_maps; ++s) {
         if (!plan_only && !out_fused[s]) return fail(D3F_ERR_INVALID_ARG, "map %d: output pointer is NULL", s);
         rc = fill_map(maps[s], s, views->V, out_fused ? out_fused[s] : nullptr, out_inter ? out_inter[s] : nullptr, nullptr,
-                      P.maps[s], map_bytes, flags);
+                      P.maps[s], q.map_bytes, flags);
         if (rc != D3F_OK) return rc;
     }
     // The channel-sliced and the LDS-window kernels want THE wide map first (the thin ones ride along).  A map descriptor
     // carries its own output pointers, so the launch may take the maps in any order: return_names=['mask', 'dino_feats']
     // gets the same kernels as the reference's default ['dino_feats', 'mask'].  caller_map[k] = caller's index of P.maps[k].
     int caller_map[D3F_MAX_MAPS];
-    bool want_inter[D3F_MAX_MAPS];
-    for (int s = 0; s < D3F_MAX_MAPS; ++s) { caller_map[s] = s; want_inter[s] = false; }
+    for (int s = 0; s < D3F_MAX_MAPS; ++s) { caller_map[s] = s; q.want_inter[s] = false; }
     {
         int wide = -1, nwide = 0;
         for (int s = 0; s < n_maps; ++s)
@@ -340,279 +223,32 @@ int eval_common(const d3f_views *views, const float *pts, int64_t n, const d3f_c
             const d3f::MapDesc t = P.maps[0]; P.maps[0] = P.maps[wide]; P.maps[wide] = t;
             caller_map[0] = wide; caller_map[wide] = 0;
         }
-        for (int s = 0; s < n_maps; ++s) want_inter[s] = out_inter && out_inter[caller_map[s]];
+        for (int s = 0; s < n_maps; ++s) q.want_inter[s] = out_inter && out_inter[caller_map[s]];
     }
-    // Morton point order (performance only) when scratch is supplied and the maps exceed the L2s
+    // Hilbert point order (performance only) when scratch is supplied
     hipStream_t hs = static_cast<hipStream_t>(stream);
-    const bool may_reorder = (workspace || plan_only) && !grid && n_maps > 0 && n <= 0x7fffffffLL && !(flags & D3F_TUNE_NO_REORDER) &&
-                             workspace_bytes >= d3f::order_workspace_bytes(n);
-    // D3F_TUNE_DIRECT_GATHER: the plain direct gather in the chosen point order -- no texel windows, no cell runs, no channel
-    // slices, thin maps view by view.  The reference the bit-identity tests compare every fast path with.
-    const bool direct = (flags & D3F_TUNE_DIRECT_GATHER) != 0;
-    // Cell-run gather for patch-resolution wide maps (at most two per launch: one corner-record slot each): consecutive
-    // points of the processing order (a grid column in caller order, the Morton walk of a cloud) mostly stay inside one
-    // texel cell of a view, so a lane group keeps the four corner vectors in registers across a run of points
-    // (fuse_eval.hip).  Needs the exact invalid-view skip (finite maps), no '<k>_inter' output and fp32 maps only.
-    // LDS texel windows (fuse_eval.hip, fused_eval_window_kernel): the FIRST map is a patch-resolution wide fp32 map with
-    // whole 512-byte slices, every other map is thin; same preconditions as the cell-run gather, which it replaces.
-    bool window = false;
-    const int win_knob = exp_knob("D3F_EXP_WINDOW");          // 0 automatic (see below), -1 off, 32 / 64 / 128: points per workgroup
-    // would this query's points be walked in the Hilbert order?  (the cloud half of `reorder` below)
-    const bool reorder_cloud = may_reorder && !lattice && ((flags & D3F_TUNE_FORCE_REORDER) || (n >= kSmallBatch && (map_bytes > kCacheResidentBytes || (flags & D3F_FLAG_UNORDERED_POINTS))));
-    const bool cloud_candidate = cloud_side == 1 && reorder_cloud && n >= kWindowCloudMin && !(flags & D3F_TUNE_NO_WINDOW_GATE);
-    {
-        // default: lattices (a brick's windows are compact), and clouds through the device-side gate (fuse_eval.hip: gated_out);
-        // not when a cell-run variant is asked for explicitly
-        const bool automatic = win_knob == 0 && (lattice != nullptr || cloud_candidate) && exp_knob("D3F_EXP_RUNS") == 0 && exp_knob("D3F_EXP_RUNS_U") == 0;
-        const bool half0 = n_maps >= 1 && P.maps[0].esize == 2;      // fp16-stored: bricks of a lattice only (the cell-run side of a cloud's gate is fp32)
-        window = (win_knob > 0 || automatic) && !direct && mode == 0 && n_maps >= 1 && finite_expected && n >= kSmallBatch &&
-                 n <= 0x7fffffffLL && tl == 0 && views->V <= 8 && window_candidate(P.maps[0], views, !plan_only) &&
-                 (!half0 || (lattice != nullptr && exp_knob("D3F_EXP_WINDOW_F16") >= 0));
-        for (int s = 0; s < n_maps; ++s) window = window && !want_inter[s];
-        for (int s = 1; s < n_maps; ++s) window = window && P.maps[s].esize == 4 && P.maps[s].C * 4 <= 256;
-        if (window) {
-            const int T = (win_knob == 32 || win_knob == 64 || win_knob == 128) ? win_knob : 64;
-            const int VP = views->V <= 1 ? 1 : views->V <= 2 ? 2 : views->V <= 4 ? 4 : 8;
-            int U = exp_knob("D3F_EXP_WINDOW_U");
-            const int cv = P.maps[0].C / 128;                  // 128-channel granules per texel (512 bytes of fp32, 256 of fp16)
-            const int slot = P.maps[0].esize == 2 ? 256 : 512;
-            if (U < 1 || U > 4 || cv % U != 0 || slot == 256) U = 1;
-            if (slot == 256) P.win_lpp = 16;
-            // per (point, view): 32-byte window record (+ the 16-byte view record when thin maps ride along); per point 20 bytes
-            const int base = T * (views->V * 32 + 16) + (n_maps > 1 ? T * views->V * 16 : 0) + T * 20 + views->V * 48;     // records at a padded point stride
-            const int pool_offset = (base + 511) / 512 * 512;
-            int occ = exp_knob("D3F_EXP_WINDOW_OCC");
-            const bool occ_forced = occ >= 5 && occ <= 6;        // experiments: 5 / 6 workgroups per CU with the plain point loop
-            if (occ < 2 || occ > 6) occ = 4;
-            if (U > 1) occ = 2;                                 // those variants are built for 2 workgroups per CU
-            // touched-texel pool (SPARSE) for clouds, whole rectangles for lattice bricks (which never overflow: 0.42 vs 0.455 ms on
-            // C2-patch); experiments builds: D3F_EXP_WINDOW_SPARSE = 1 / -1 forces either
-            P.win_sparse = exp_knob("D3F_EXP_WINDOW_SPARSE") > 0 ? 1 : (exp_knob("D3F_EXP_WINDOW_SPARSE") < 0 ? 0 : (lattice ? 0 : 1));
-            if (slot == 256) P.win_sparse = 0;
-            // static LDS of the kernel + allocation granularity: 3 workgroups per CU stop fitting with less (measured, round 5)
-            const int slack = exp_knob("D3F_EXP_WINDOW_SLACK") > 0 ? exp_knob("D3F_EXP_WINDOW_SLACK") : (P.win_sparse ? 4096 : 2048);
-            // slots per view worth a workgroup per CU: a brick's rectangles ~17; a cloud tile's touched texels ~12 (p90 14)
-            const int want = exp_knob("D3F_EXP_WINDOW_WANT") > 0 ? exp_knob("D3F_EXP_WINDOW_WANT") : (P.win_sparse ? 14 : 17);
-            int texels = 0;
-            for (;; --occ) {
-                const int budget = 160 * 1024 / occ - slack;
-                texels = (budget - pool_offset) / (slot * U) - 2;
-                // A 4x4x4 brick's window is ~3x4 texels per view once a texel is at least as wide as the brick's footprint
-                // (config 4's slab: 2.5-mm lattice, 10-px texels), and a pool that cannot hold the views' windows sends the
-                // overflowing pairs to the global gather: give every view enough slots, at the price of workgroups per CU
-                // (MI355X, config 4 lattice slab: 4 / 3 / 2 workgroups per CU = 3.15 / 3.54 / 2.43 ms; config 2, four
-                // views, fits at 4 and loses 18 % at 2)
-                // (round 4, pipelined point loop: a point with a pair outside the pool is done a second time by the general path, so
-                // overflow costs more than a workgroup per CU -- C2-patch: 55 slots at 4 per CU 0.525 ms, 80 slots at 3 per CU 0.493,
-                // 40 / 32 slots 0.72 / 0.81: ask for ~17 slots per view)
-                if (texels >= want * views->V || occ == 2 || occ_forced) break;
-            }
-            if (exp_knob("D3F_EXP_WINDOW_POOL") > 0 && exp_knob("D3F_EXP_WINDOW_POOL") < texels) texels = exp_knob("D3F_EXP_WINDOW_POOL");
-            if (texels > 320) texels = 320;                      // kWinMaxTexels (fuse_eval.hip)
-            texels &= ~1;
-            window = texels >= 2 && (T * VP) % 64 == 0 && n / T < 0x7fffffffLL;
-            if (U > 1) P.win_lpp = 32;
-            P.win_u = U; P.win_occ = occ; P.win_pool_offset = pool_offset; P.win_pool_texels = texels;
-            P.win_vc = exp_knob("D3F_EXP_WINDOW_VC") == 2 ? 2 : 1;
-            P.win_slices = window ? cv / U : 0;
+    q.may_reorder = (workspace || plan_only) && !grid && n_maps > 0 && n <= 0x7fffffffLL && !(flags & D3F_TUNE_NO_REORDER) &&
+                    workspace_bytes >= d3f::order_workspace_bytes(n);
+
+    // ---- the plan: family + point order, then (device work) the order itself, then the geometry ----
+    Plan pl;
+    plan_family_and_order(q, P, pl);
+    if (!pl.walk && pl.reorder && !plan_only) {
+        if (flags & D3F_FLAG_REUSE_POINT_ORDER) {
+            P.order = d3f::stored_point_order(workspace, n);       // written by an earlier call for the same points
+        } else {
+            // Hilbert order of the 4-mm cells, exact (order_kernels.hip); experiments builds: D3F_EXP_ORDER_MORTON=1 = the Z curve of rounds 1-4
+            hipError_t eo = d3f::build_point_order(pts, n, workspace, workspace_bytes, &P.order, hs,
+                                                   (exp_knob("D3F_EXP_ORDER_MORTON") > 0 ? 1 : 0) | (exp_knob("D3F_EXP_SCAN3") > 0 ? 2 : 0));
+            if (eo != hipSuccess) return hip_fail(eo, "point ordering");
         }
     }
-    bool any_runs = false;
-    {
-        const int knob = exp_knob("D3F_EXP_RUNS");
-        bool blocked = window || direct || knob < 0 || !finite_expected || n < kSmallBatch || tl != 0;
-        for (int s = 0; s < n_maps; ++s)
-            blocked |= P.maps[s].esize == 2 || want_inter[s] ||
-                       (P.maps[s].unroll == -4 && !runs_candidate(P.maps[s], views->H, views->W));
-        // one cell-run map per launch (phase A keeps one "same cell as the previous point" flag per (point, view))
-        for (int s = 0; s < n_maps && !blocked && !any_runs; ++s)
-            if (runs_candidate(P.maps[s], views->H, views->W)) {
-                pick_runs_mapping(P.maps[s], exp_knob("D3F_EXP_RUNS_U"), knob);
-                any_runs = true;
-            }
-        if (any_runs)       // the cell-run kernel is built for one batched vector per lane on its other maps (register budget)
-            for (int s = 0; s < n_maps; ++s)
-                if (P.maps[s].runs == 0 && P.maps[s].unroll != 1)
-                    pick_mapping(P.maps[s], P.maps[s].vw == 4, P.maps[s].vw >= 2, true, 1);
-    }
-    // Points on a regular lattice (a d3f_grid, or d3f_eval_lattice's dims): the brick walk is closed form -- no keys, no
-    // sort, no index array, no scratch -- and replaces the Morton sort wherever that would be used.  (With the cell-run
-    // gather the caller's z-fastest order is the one wanted: a grid column is one long run.)
-    // (a flat lattice with more than 2^28 tiles per 16-tile slab would overflow the walk's 32-bit level arithmetic)
-    const bool walk_fits = lattice && 16.0 * ((lattice[1] + 1) / 2) * ((lattice[2] + 1) / 2) < 4294967296.0;
-    const bool walk = lattice && walk_fits && n_maps > 0 && n >= kSmallBatch && n <= 0x7fffffffLL && !(flags & D3F_TUNE_NO_REORDER) &&
-                      exp_knob("D3F_EXP_WALK") >= 0 && !any_runs &&
-                      ((flags & D3F_TUNE_FORCE_REORDER) || map_bytes > kCacheResidentBytes || window);
-    const bool reorder = walk || (may_reorder && ((flags & D3F_TUNE_FORCE_REORDER) || (n >= kSmallBatch && (map_bytes > kCacheResidentBytes || (flags & D3F_FLAG_UNORDERED_POINTS)))));
-    if (walk) {
-        P.walk_nx = lattice[0]; P.walk_ny = lattice[1]; P.walk_nz = lattice[2];
-    } else if (reorder && !plan_only && (flags & D3F_FLAG_REUSE_POINT_ORDER)) {
-        P.order = d3f::stored_point_order(workspace, n);       // written by an earlier call for the same points
-    } else if (reorder && !plan_only) {
-        // Hilbert order of the 4-mm cells, exact (order_kernels.hip); experiments builds: D3F_EXP_ORDER_MORTON=1 = the Z curve of rounds 1-4
-        hipError_t eo = d3f::build_point_order(pts, n, workspace, workspace_bytes, &P.order, hs, exp_knob("D3F_EXP_ORDER_MORTON") > 0 ? 1 : 0);
-        if (eo != hipSuccess) return hip_fail(eo, "point ordering");
-    }
-    // Launch geometry (measured on MI355X):
-    //  * Morton / lattice walk: 8-point tiles (one point per lane group; 16 when a thin map such as the mask is also
-    //    requested), XCD k takes the k-th contiguous eighth of the walk, so the ~1 k points in flight on an
-    //    XCD form one compact blob whose texels stay in that XCD's 4 MiB L2
-    //    (C2 dense 2.84 -> 2.12 ms, C4 patch 13.0 -> 4.8 ms; 32-point tiles: 2.48 / 5.3 ms);
-    //  * caller order: 128-point tiles, round-robin XCDs (0.80 ms on C2 patch); for maps far beyond the
-    //    256 MiB Infinity Cache 64-point tiles at 2 workgroups per CU (3.2 -> 2.96 ms on C2 dense);
-    //  * cell-run gather: 8 runs per workgroup (64 points with 32 lanes per point), either order.
-    bool xcd_remap = false;
-    if (reorder) {
-        // on the walk the in-flight footprint is tiny, so batched corner loads win again wherever one pass
-        // of <= 3 vectors per lane covers the channels (C2 dense 2.07 -> 1.99 ms); C = 1024 keeps load-use x 4
-        for (int s = 0; s < n_maps; ++s) {
-            d3f::MapDesc &m = P.maps[s];
-            const bool forced = (flags & ((1u << 26) | (1u << 27))) != 0;
-            if (!forced && m.unroll < 0 && (m.C / m.vw) <= 3 * 64) {
-                const bool a16 = m.vw == 4, a8 = m.vw >= 2;
-                pick_mapping(m, a16, a8, true, any_runs ? 1 : 4);
-            }
-        }
-        // one point per lane group: 8 points when every map takes 32 lanes per point, else 16
-        bool thin = false;
-        for (int s = 0; s < n_maps; ++s) thin |= P.maps[s].lpp_log2 < 5;      // < 32 lanes per point: 16 groups have work
-        P.tile_pts = thin ? 16 : 8; P.lds_pad = 0; xcd_remap = true;
-        if (walk) {                                   // the tile is a brick of the lattice
-            P.walk_tx = 2; P.walk_ty = 2; P.walk_tz = thin ? 4 : 2;
-            const int shape = exp_knob("D3F_EXP_WALK_TILE");      // experiment: digits x y z, e.g. 224, 144, 422
-            if (shape >= 111 && shape <= 888 && (shape / 100) * (shape / 10 % 10) * (shape % 10) == P.tile_pts && shape / 10 % 10 > 0 && shape % 10 > 0) {
-                P.walk_tx = shape / 100; P.walk_ty = shape / 10 % 10; P.walk_tz = shape % 10;
-            }
-        }
-        // maps that fit the L2s / Infinity Cache anyway (patch-resolution features, the mask): the walk is only there
-        // to give a random cloud L1 locality and the big tiles of the caller-order path stay best
-        // (C2 patch, random cloud: caller order 1.93 ms, walk with 8-point tiles 1.07, with 128-point tiles 0.76)
-        if (map_bytes <= kCacheResidentBytes && !walk) P.tile_pts = tile_points_for(views->V);
-    } else if (map_bytes > kBeyondLlcBytes && P.tile_pts > 64 && n >= kSmallBatch && !any_runs) {
-        P.tile_pts = 64; P.lds_pad = 64 * 1024;
-    }
-    // small batches (keypoints, tracking): a 128-point tile is 16-32 serial rounds per lane group, so a few hundred
-    // points would run on 3 CUs for ~200 us; spread them over >= 1024 workgroups instead (N = 300: 170 -> ~25 us)
-    if (!reorder && n_maps > 0)
-        while (P.tile_pts > 8 && n / P.tile_pts < 1024) P.tile_pts >>= 1;
-    if (tl >= 2 && tl <= 8) { P.tile_pts = (1 << tl) <= max_tile ? (1 << tl) : max_tile; P.lds_pad = 0; }
-    if ((flags >> 16) & 0xFF) P.lds_pad = ((int)((flags >> 16) & 0xFF) == 0xFF) ? 0 : (int)((flags >> 16) & 0xFF) * 1024;
-    if (flags & D3F_TUNE_XCD_REMAP) xcd_remap = !xcd_remap;
-    P.flags = (flags & ~D3F_TUNE_XCD_REMAP) | (xcd_remap ? D3F_TUNE_XCD_REMAP : 0u);
-    if (any_runs) {
-        int k = 8, lg = 6;
-        for (int s = 0; s < n_maps; ++s)
-            if (P.maps[s].runs > 0) { k = P.maps[s].runs; lg = P.maps[s].lpp_log2; }
-        const int round = (d3f::kBlock >> lg) * k;    // one run per lane group
-        P.tile_pts = round < 64 ? 64 : round;         // >= 64 points per workgroup (a lane group then takes several runs)
-        // batches of less than ~2 workgroups per slot (256 CUs x 7): halve the tile so that the tail is shorter
-        // (100 k keypoints: 0.126 -> 0.119 ms; the 985 600-point grid is slower with 32-point tiles: 0.632 -> 0.655)
-        if (n / P.tile_pts < 4096 && P.tile_pts / 2 >= round) P.tile_pts /= 2;
-        if (exp_knob("D3F_EXP_RUNS_TILE") >= round) P.tile_pts = exp_knob("D3F_EXP_RUNS_TILE");
-        while ((long)P.tile_pts * views->V * 88 > 40 * 1024 && P.tile_pts > round) P.tile_pts >>= 1;   // records + 2 corner slots
-        P.lds_pad = 0;
-    }
-    // Channel-sliced launch (fuse_eval.hip): a lattice on a dense wide fp32 map that is the FIRST map of the launch; any
-    // other map must be thin (it rides along with slice 0).  512-byte slices, two views in flight; a wide map WITH thin
-    // companions takes 32 points per workgroup (C3-dense, features + 8-channel mask: 3.04 -> 2.80 ms -- the whole-texel
-    // kernel stalls on the thin map's gather, 16 points x 2 lanes per workgroup), a wide map ALONE 16 points per workgroup
-    // (C2-dense 1.62 -> 1.52 ms: with 32 the slicing removed 20-29 % of the L2 fills and no time, with 64 it lost 20 %:
-    // the points in flight per XCD are what the L2 window is made of).  D3F_EXP_SLICED = 1 / 2 / 3 forces
-    // 128- / 256- / 512-byte slices, -1 disables; _TILE 8 / 16 / 32 / 64 points per workgroup.
-    {
-        int sl = exp_knob("D3F_EXP_SLICED");
-        bool thin_rest = true;
-        for (int s = 1; s < n_maps; ++s) thin_rest = thin_rest && P.maps[s].C * P.maps[s].esize <= 256 && P.maps[s].esize == 4;
-        const bool half_sl = n_maps >= 1 && P.maps[0].esize == 2;      // fp16-stored wide map: 16 lanes x 8 channels = 128-channel slices
-        const bool automatic = sl == 0 && thin_rest && n_maps >= 1 && P.maps[0].C % 128 == 0 && P.maps[0].C <= 1024 &&
-                               (!half_sl || exp_knob("D3F_EXP_SLICED_F16") >= 0);
-        if (automatic) sl = half_sl ? 2 : 3;
-        if (half_sl && sl != 2) sl = 0;
-        // ... or the Morton order of a cloud on maps beyond the caches (tiles of 16 / 32 consecutive points of the order)
-        const bool cloud = reorder && !walk && !any_runs && map_bytes > kCacheResidentBytes && exp_knob("D3F_EXP_SLICED_CLOUD") >= 0;
-        bool ok = (walk || cloud) && !window && !direct && (sl >= 1 && sl <= 3) && mode == 0 && n_maps >= 1 &&
-                  ((P.maps[0].esize == 4 && P.maps[0].vw == 4) || (half_sl && P.maps[0].vw == 8 && P.maps[0].fold)) && !want_inter[0] && tl == 0;
-        const int lg = sl + 2, lanes = 1 << lg;      // 1: 8 lanes (128-byte slices), 2: 16 lanes, 3: 32 lanes (512 bytes)
-        P.sl_vc = exp_knob("D3F_EXP_SLICED_VC") > 0 ? exp_knob("D3F_EXP_SLICED_VC") : (automatic ? 2 : 4);
-        if (half_sl) P.sl_vc = 2;
-        const int cpl = half_sl ? 8 : 4;              // channels per lane (one 16-byte vector)
-        ok = ok && P.maps[0].C % (cpl * lanes) == 0 && P.maps[0].C >= 128;
-        for (int s = 1; s < n_maps && ok; ++s) ok = P.maps[s].C * P.maps[s].esize <= 256 && !want_inter[s] && P.maps[s].esize == 4;
-        if (ok) {
-            const int keep_tile = P.tile_pts, keep_pad = P.lds_pad, keep_t[3] = {P.walk_tx, P.walk_ty, P.walk_tz};
-            d3f::MapDesc keep_maps[D3F_MAX_MAPS];
-            for (int s = 0; s < n_maps; ++s) keep_maps[s] = P.maps[s];
-            const int tile_knob = exp_knob("D3F_EXP_SLICED_TILE");
-            const bool big = tile_knob == 64;                            // experiment: 64 points per workgroup (four 2x2x4 tiles)
-            const bool tiny = tile_knob == 16 || (tile_knob == 0 && n_maps == 1);   // 16 points per workgroup (four 2x2x1 tiles)
-            const bool mini = tile_knob == 8;                            // experiment: 8 points per workgroup (four 2x1x1 tiles)
-            P.walk_tx = 2; P.walk_ty = mini ? 1 : 2; P.walk_tz = big ? 4 : ((tiny || mini) ? 1 : 2);
-            P.sl_lg = lg;
-            P.sl_slices = P.maps[0].C / (cpl * lanes);
-            P.tile_pts = big ? 64 : (tiny ? 16 : (mini ? 8 : 32)); P.lds_pad = exp_knob("D3F_EXP_SLICED_PAD") > 0 ? exp_knob("D3F_EXP_SLICED_PAD") * 1024 : 0;
-            if (walk) {
-                P.sl_tiles = (int64_t)((P.walk_nx + 1) / 2) * ((P.walk_ny + P.walk_ty - 1) / P.walk_ty) * ((P.walk_nz + P.walk_tz - 1) / P.walk_tz);
-                P.sl_groups = (P.sl_tiles + 3) / 4;
-            } else {
-                P.sl_tiles = 0;
-                P.sl_groups = (n + P.tile_pts - 1) / P.tile_pts;
-            }
-            P.sl_unit = exp_knob("D3F_EXP_SLICED_UNIT") > 0 ? exp_knob("D3F_EXP_SLICED_UNIT") : (big ? 64 : (tiny ? 256 : (mini ? 512 : 128)));   // 4096 points per unit (smaller: slower)
-            P.sl_chunks = (P.sl_groups + P.sl_unit - 1) / P.sl_unit;
-            P.sl_ilv = exp_knob("D3F_EXP_SLICED_ILV") >= 2 && exp_knob("D3F_EXP_SLICED_ILV") <= 4 ? exp_knob("D3F_EXP_SLICED_ILV") : 1;
-            for (int s = 1; s < n_maps; ++s) pick_mapping(P.maps[s], P.maps[s].vw == 4, P.maps[s].vw >= 2, true, 1);
-            if ((((P.sl_chunks * P.sl_slices + 7) / 8) + P.sl_ilv) * 8 * P.sl_unit > 0x7fffffffLL) P.sl_slices = 0;
-            // its dynamic LDS (records + one corner record per (point, view)) must fit the 64 KiB a launch gets without opting in:
-            // 32-point tiles with ~36 and more views do not -- such a query keeps the whole-texel kernel
-            if ((int64_t)d3f::fused_lds_base(P.tile_pts, views->V) + (int64_t)P.tile_pts * views->V * 32 + P.lds_pad > 64 * 1024) P.sl_slices = 0;
-            if (P.sl_slices == 0) {             // not this launch after all: the geometry of the whole-texel kernel again
-                P.tile_pts = keep_tile; P.lds_pad = keep_pad; P.walk_tx = keep_t[0]; P.walk_ty = keep_t[1]; P.walk_tz = keep_t[2];
-                for (int s = 0; s < n_maps; ++s) P.maps[s] = keep_maps[s];
-            }
-        }
-    }
-    if (window) {
-        const int T = (win_knob == 32 || win_knob == 64 || win_knob == 128) ? win_knob : 64;
-        P.tile_pts = T; P.lds_pad = 0;
-        if (walk) pick_window_brick(P.walk_nx, P.walk_ny, P.walk_nz, T, P.walk_tx, P.walk_ty, P.walk_tz);
-        for (int s = 1; s < n_maps; ++s) pick_mapping(P.maps[s], P.maps[s].vw == 4, P.maps[s].vw >= 2, true, 1);
-        xcd_remap = false;
-        P.flags &= ~D3F_TUNE_XCD_REMAP;
-        // a cloud's tiles go round-robin over the XCDs (all eight work on one neighbourhood: C2-patch cloud 0.52 ms against 0.58
-        // with contiguous eighths, which is the lattice bricks' mapping); experiments builds: D3F_EXP_WINDOW_RR=-1 = eighths
-        if (!walk && exp_knob("D3F_EXP_WINDOW_RR") >= 0) P.flags |= D3F_TUNE_XCD_REMAP;
-    }
-    // walks: all eight XCDs stay inside one macro-brick of ~32 k points at a time (its texel footprint stays in
-    // the 256 MiB Infinity Cache), each taking a contiguous eighth of it (C2 dense 1.97 -> 1.74 ms, C4 patch 4.75 -> 4.17)
-    P.xcd_chunk = (reorder && xcd_remap) ? (int)((32768 / P.tile_pts + 7) / 8 * 8) : 0;
-    if ((flags >> 29) & 0x7) P.xcd_chunk = 1024 << (((flags >> 29) & 0x7) - 1);   // tuning: 1024 .. 65536 tiles
-    if (n_maps == 0) {
-        // distance-only pass (return_names=[], eval_dist): one lane per point and nothing per point in LDS.  Rounds 1-3 ran it on
-        // the 128-point tiles of the gathers -- half of every 256-lane workgroup idle (SQ_WAVES = 3.85 M for 123.2 M points):
-        // four points per lane and workgroup instead, KRt computed once per 1024 points
-        P.tile_pts = n >= (1LL << 22) ? 1024 : 256;
-        P.lds_pad = 0;
-    }
-    P.crec_offset = d3f::fused_lds_base(n_maps == 0 ? 0 : P.tile_pts, views->V);
-    // wide maps (>= 16 lanes per point): corner set-up once per (point, view) in phase A, 32 B of LDS each; the
-    // cell-run maps come first -- they read their corners from these records
-    P.n_pre = 0;
-    for (int s = 0; s < n_maps; ++s)
-        if (P.maps[s].runs > 0) P.maps[s].pre_slot = P.n_pre++;
-    if (P.sl_slices > 0) {
-        P.maps[0].pre_slot = 0; P.n_pre = 1;             // the sliced kernel keeps the wide map's corner records itself
-    } else if (!(flags & (1u << 28)))
-        for (int s = 0; s < n_maps && P.n_pre < 2; ++s) {
-            // 32 B per (point, view) and map: only while records + set-ups stay within 48 KiB (>= 3 workgroups per CU)
-            const long lds_after = (long)P.crec_offset + (long)(P.n_pre + 1) * P.tile_pts * views->V * 32;
-            if (P.maps[s].pre_slot < 0 && P.maps[s].lpp_log2 >= 4 && !want_inter[s] && lds_after <= 48 * 1024)
-                P.maps[s].pre_slot = P.n_pre++;
-        }
-    int64_t ntiles = (n + P.tile_pts - 1) / P.tile_pts;
-    if (walk)
-        ntiles = (int64_t)((P.walk_nx + P.walk_tx - 1) / P.walk_tx) * ((P.walk_ny + P.walk_ty - 1) / P.walk_ty) *
-                 ((P.walk_nz + P.walk_tz - 1) / P.walk_tz);
+    plan_geometry(q, P, pl);
+    const int64_t ntiles = plan_workgroups(P, pl, n);
     if (ntiles > 0x7fffffffLL) return fail(D3F_ERR_BAD_SHAPE, "n=%lld needs more than 2^31 workgroups", (long long)n);
+    // the window and the channel-sliced kernels keep a point's global index in 32 bits of LDS (their rows already require
+    // n < 2^31; this is the guard that says so)
+    if ((pl.window || P.sl_slices > 0) && n > 0x7fffffffLL) return fail(D3F_ERR_BAD_SHAPE, "n=%lld: 32-bit point indices", (long long)n);
     if (plan_only) {
         plan_out->gated_window = 0; plan_out->reserved2 = 0;
         if (cloud_side == 0 && !lattice && !grid) {       // would d3f_eval's first pass take the window side?  (its plan: the lattice's)
@@ -622,32 +258,11 @@ int eval_common(const d3f_views *views, const float *pts, int64_t n, const d3f_c
                 for (int s = 0; s < n_maps; ++s)
                     if (side.staged[s] == 3 && side.reorder == 1) { plan_out->gated_window = 1; plan_out->reserved2 = side.reserved; }
         }
-        plan_out->tile_points = P.tile_pts;
-        plan_out->reorder = walk ? 2 : (reorder ? 1 : 0);
-        plan_out->lds_bytes = P.crec_offset + P.n_pre * P.tile_pts * P.V * 32 + P.lds_pad;
-        plan_out->workgroups = P.sl_slices > 0 ? (((P.sl_chunks * P.sl_slices + 7) / 8 + P.sl_ilv - 1) / P.sl_ilv * P.sl_ilv) * 8 * P.sl_unit : ntiles;
-        if (P.win_slices > 0) {
-            plan_out->lds_bytes = P.win_pool_offset + (2 + P.win_pool_texels) * (P.maps[0].esize == 2 ? 256 : 512) * P.win_u;
-            plan_out->workgroups = ntiles;
-        }
-        plan_out->reserved = P.sl_slices > 0 ? 100 + P.sl_lg * 10 + P.sl_vc : (P.win_slices > 0 ? 2000 + 100 * P.win_u + 10 * (P.win_u == 1 ? (P.win_lpp == 16 ? P.win_vc : 4) : (P.win_u == 4 ? 1 : P.win_vc)) + (P.win_u == 1 ? (P.win_occ >= 4 ? 4 : (P.win_lpp == 16 ? 3 : P.win_occ)) : 2) : 0);   // 2UVW: the window kernel's template arguments      // 1LV: sliced launch, L = log2(lanes per point), V = views in flight
-        for (int s = 0; s < n_maps; ++s)
-            if (P.maps[s].runs > 0) {        // waves per SIMD the chosen cell-run kernel variant is built for
-                const int ru = P.maps[s].unroll, rk = P.maps[s].runs;
-                plan_out->reserved = (ru == 1 && rk == 4) ? (P.runs_occ == 6 ? 6 : 7) : (ru == 1 ? ((P.runs_occ == 4 || P.runs_occ == 6) ? P.runs_occ : 5) : ((ru == 2 && rk == 8 && P.runs_occ != 4) ? 3 : 4));
-            }
-        for (int s = 0; s < D3F_MAX_MAPS; ++s) {
-            const bool on = s < n_maps;
-            const int c = on ? caller_map[s] : s;         // reported in the caller's map order
-            plan_out->vector_floats[c] = on ? P.maps[s].vw : 0;
-            plan_out->lanes_per_point[c] = on ? ((P.win_slices > 0 && s == 0) ? P.win_lpp : (1 << P.maps[s].lpp_log2)) : 0;
-            plan_out->vectors_per_lane[c] = on ? ((P.win_slices > 0 && s == 0) ? P.win_u * (32 / P.win_lpp) : P.maps[s].unroll) : 0;   /* negative: load-use per vector */
-            plan_out->staged[c] = on ? (P.win_slices > 0 && s == 0 ? 3 : (P.maps[s].runs > 0 ? 16 + P.maps[s].runs : 0)) : 0;
-        }
+        report_plan(P, pl, caller_map, n_maps, ntiles, plan_out);
         return D3F_OK;
     }
     // a cloud on the gated pair of launches: the window side (this pass) and the cell-run side (the next) read one device word
-    const bool gated_window = cloud_side == 1 && window && !walk && P.order != nullptr;
+    const bool gated_window = cloud_side == 1 && pl.window && !pl.walk && P.order != nullptr;
     const bool gated_runs = cloud_side == 2;
     if (gated_window || gated_runs) {
         P.gate = d3f::order_gate_words(workspace, n);
@@ -699,6 +314,9 @@ int d3f_eval(const d3f_views *views, const float *pts, int64_t n, const d3f_chan
 }
 
 int64_t d3f_eval_workspace_bytes(int64_t n) { return d3f::order_workspace_bytes(n); }
+
+const char *d3f_plan_family_name(int32_t family) { return (family >= 0 && family < (int32_t)(sizeof(kFamilies) / sizeof(kFamilies[0]))) ? kFamilies[family].name : nullptr; }
+const char *d3f_plan_family_takes(int32_t family) { return (family >= 0 && family < (int32_t)(sizeof(kFamilies) / sizeof(kFamilies[0]))) ? kFamilies[family].takes : nullptr; }
 
 int64_t d3f_eval_gate_offset(int64_t n)
 {
@@ -1009,6 +627,40 @@ int d3f_map_check(const d3f_channel_map *map, int32_t V, uint32_t *word_out, voi
     hipError_t e = d3f::launch_map_check(map->data, V, map->fh, map->fw, map->C, map->stride_v, map->stride_y, map->stride_x, es,
                                          word_out, static_cast<hipStream_t>(stream));
     return e == hipSuccess ? D3F_OK : hip_fail(e, "map_check launch");
+}
+
+int d3f_map_check_many(const d3f_channel_map *maps, const int32_t *views, int32_t n, uint32_t *const *words_out, uint32_t flags, void *stream)
+{
+    if (n < 0 || n > D3F_MAX_MAPS + 1) return fail(D3F_ERR_BAD_SHAPE, "map_check_many: n=%d outside [0,%d]", n, D3F_MAX_MAPS + 1);
+    if (n == 0) return D3F_OK;
+    if (!maps || !views || !words_out) return fail(D3F_ERR_INVALID_ARG, "map_check_many: NULL pointer");
+    const void *data[D3F_MAX_MAPS + 1];
+    int64_t nbytes[D3F_MAX_MAPS + 1];
+    int esize[D3F_MAX_MAPS + 1];
+    uint32_t *words[D3F_MAX_MAPS + 1];
+    int nf = 0;
+    const bool zero = (flags & D3F_CHECK_WORDS_ARE_ZERO) != 0;
+    for (int k = 0; k < n; ++k) {
+        const d3f_channel_map &m = maps[k];
+        // the same validation as d3f_map_check; a tensor that is not one flat 16-byte aligned block takes the single-tensor call
+        if (!words_out[k] || !aligned(words_out[k], 4)) return fail(D3F_ERR_BAD_LAYOUT, "map_check_many: word %d must be a 4-byte aligned device pointer", k);
+        if (views[k] < 1 || m.fh < 1 || m.fw < 1 || m.C < 1) return fail(D3F_ERR_BAD_SHAPE, "map_check_many: tensor %d: V=%d fh=%d fw=%d C=%d", k, views[k], m.fh, m.fw, m.C);
+        if (!m.data) return fail(D3F_ERR_INVALID_ARG, "map_check_many: tensor %d: data pointer is NULL", k);
+        if (m.dtype != D3F_DTYPE_F32 && m.dtype != D3F_DTYPE_F16) return fail(D3F_ERR_BAD_DTYPE, "map_check_many: tensor %d: dtype %d unsupported", k, m.dtype);
+        const int es = m.dtype == D3F_DTYPE_F16 ? 2 : 4;
+        if (!aligned(m.data, es)) return fail(D3F_ERR_BAD_LAYOUT, "map_check_many: tensor %d: data must be aligned to its element size", k);
+        if (m.stride_x < m.C || m.stride_y < 0 || m.stride_v < 0) return fail(D3F_ERR_BAD_LAYOUT, "map_check_many: tensor %d: strides do not describe a channels-last map", k);
+        if (d3f::map_is_flat(m.data, views[k], m.fh, m.fw, m.C, m.stride_v, m.stride_y, m.stride_x)) {
+            data[nf] = m.data; nbytes[nf] = (int64_t)views[k] * m.fh * m.fw * m.C * es; esize[nf] = es; words[nf] = words_out[k];
+            ++nf;
+        } else {
+            hipError_t e = d3f::launch_map_check(m.data, views[k], m.fh, m.fw, m.C, m.stride_v, m.stride_y, m.stride_x, es, words_out[k],
+                                                 static_cast<hipStream_t>(stream));
+            if (e != hipSuccess) return hip_fail(e, "map_check launch");
+        }
+    }
+    hipError_t e = d3f::launch_map_check_many(data, nbytes, esize, words, nf, zero, static_cast<hipStream_t>(stream));
+    return e == hipSuccess ? D3F_OK : hip_fail(e, "map_check_many launch");
 }
 
 int d3f_onehot2instance(const float *onehot, int64_t n, int32_t NI, uint8_t *out, void *stream)

@@ -106,6 +106,8 @@ hipError_t launch_fused_backward(const BackwardParams &P, int mode, hipStream_t 
 // scan_kernels.hip: exclusive prefix sum of uint32 counters (in == out allowed); scratch >= scan_scratch_bytes(n)
 int64_t scan_scratch_bytes(int64_t n);
 hipError_t launch_exclusive_scan_u32(const uint32_t *in, uint32_t *out, int64_t n, void *scratch, hipStream_t s);
+int64_t scan_status_words(int64_t n);      // single-launch form (decoupled look-back): zeroed status words, total < 2^30
+hipError_t launch_exclusive_scan_lookback_u32(const uint32_t *in, uint32_t *out, int64_t n, uint32_t *status, hipStream_t s);
 
 // order_kernels.hip
 int64_t order_workspace_bytes(int64_t n);
@@ -152,6 +154,9 @@ hipError_t launch_fps_pixels(const int32_t *pts, int64_t n, int k, int64_t init_
 // misc_kernels.hip
 hipError_t launch_map_check(const void *data, int V, int fh, int fw, int C, int64_t sv, int64_t sy, int64_t sx, int esize,
                             uint32_t *word, hipStream_t s);
+bool map_is_flat(const void *data, int V, int fh, int fw, int C, int64_t sv, int64_t sy, int64_t sx);
+hipError_t launch_map_check_many(const void *const *data, const int64_t *nbytes, const int *esize, uint32_t *const *words, int n,
+                                 bool words_are_zero, hipStream_t s);
 hipError_t launch_onehot2instance(const float *onehot, int64_t n, int NI, uint8_t *out, hipStream_t s);
 hipError_t launch_instance2onehot(const uint8_t *inst, int64_t n, int NI, uint8_t *out, hipStream_t s);
 

@@ -159,7 +159,7 @@ __device__ __forceinline__ bool maps_are_finite(const EvalParams &P)
 //         fp32 on load; everything after the load is the fp32 path
 // Output rows are written once and never read again by the launch: they leave as NON-TEMPORAL stores (policy 2: `nt`; the window
 // kernel adds write-through, `sc1 nt` = store_row_vec, which is policy 3 here, experiments builds: it gains 4-9 % there and loses
-// 0-5 % in these kernels, scripts/gpu_sessions/r4_gpu34/35.sh), which stream
+// 0-5 % in these kernels, scripts/notebook/gpu_sessions/r4_gpu34/35.sh), which stream
 // to memory without allocating in the L2s and the Infinity Cache, i.e. without pushing out the texels the gather lives on
 // (round 4: C2 dense 1.53 -> 1.47 ms, C3 dense 2.83 -> 2.66, C4 dense 8.97 -> 8.94; the window kernel, which stores with the same
 // policy, gained 8-23 %).  Round 2's `sc1` stores (policy 1: write-through, the line dropped from the XCD's L2 after the

@@ -25,6 +25,10 @@
 #include "d3f_device.h"
 #include "fuse_common.h"
 
+#ifndef D3F_SLICED_WHATIF      // what-if builds of the channel-sliced kernel (scripts/notebook/build_ablate.py --sliced): 1 phase A without the
+#define D3F_SLICED_WHATIF 0    // depth lookup / weights, 4 no gather (results wrong by construction; only times are read)
+#endif
+
 namespace d3f {
 
 
@@ -410,7 +414,12 @@ __device__ __forceinline__ void fused_eval_sliced_body(const EvalParams &P)
             if (act) {
                 float px, py, pz;
                 fetch_point(P, i, px, py, pz);
+#if D3F_SLICED_WHATIF & 1       // what-if build (round 5): phase A without the depth lookup, the validity test and the weight (every pair valid)
+                const Proj pr = project_point(krt + v * 12, px, py, pz, Wm1, Hm1);
+                o.gx = pr.gx; o.gy = pr.gy; o.dist = 0.0f; o.valid = 1.0f; wgt = 1.0f;
+#else
                 o = eval_view<0>(P.depth, P.H, P.W, krt + v * 12, v, px, py, pz, Wm1, Hm1, mu, wgt);
+#endif
                 if (!(isfinite(o.gx) && isfinite(o.gy) && isfinite(wgt))) st = 1u;
             }
             float dsum, cnt;
@@ -463,6 +472,9 @@ __device__ __forceinline__ void fused_eval_sliced_body(const EvalParams &P)
             const float denom = cnt + 1e-6f;
             const bool strict = flag_s[p] != 0u;
             VT acc = (VT)0.0f, acc2 = (VT)0.0f;                              // (acc2: channels 4..7 of a fp16 vector)
+#if D3F_SLICED_WHATIF & 4       // what-if build: no gather at all (phase A + the row stores)
+            if (true) { store_out<VT>(m.out + i * m.C + (co >> 2), acc, P.store_policy); continue; }
+#endif
             auto accumulate = [&](RT t, float w) {
                 if constexpr (HALF) fma_mix8(acc, acc2, t, w);
                 else acc = v_fma<VT>(t, w, acc);
@@ -713,7 +725,7 @@ __device__ __forceinline__ void window_point(f32x4 (&acc)[NV], const unsigned ch
 // arithmetic.  Same operands in the same order as window_point: bit-identical.
 //   rec0      LDS byte offset of the first point's first record;  KSTRIDE bytes between the lane group's consecutive points
 //   done(k, acc)  called once per point, after its last view
-// what-if builds of tuning sessions (scripts/build_ablate.py: -DD3F_WIN_ABLATE=bits; parts of the window kernel left out, results
+// what-if builds of tuning sessions (scripts/notebook/build_ablate.py: -DD3F_WIN_ABLATE=bits; parts of the window kernel left out, results
 // wrong by construction, only times are read): 1 no copies after slice 0, 2 no point loop, 4 rows stored over each other in
 // 8 MiB (no HBM writes), 8 corner reads without the arithmetic, 16 the arithmetic without the corner reads
 #ifndef D3F_WIN_ABLATE
@@ -809,7 +821,7 @@ __device__ __forceinline__ void window_points_pipelined(const unsigned char *sme
 // corners of every pair in a bitmap over the views' rectangles (LDS atomics), one wave ranks the set bits, and a pair's nw / sw
 // slots are the ranks of its bits -- ne and se are the next bits of the same rows, hence the next slots, so the records and the
 // point loop are unchanged.  A 64-point tile of a cloud's Hilbert order touches 47 texels where its rectangles hold 74 (C2-patch,
-// scripts/sim_cloud_tiles.py): an 80-slot pool then overflows on 0.5 % of the tiles instead of 19 %.  The price: the copy of slice
+// scripts/notebook/sim_cloud_tiles.py): an 80-slot pool then overflows on 0.5 % of the tiles instead of 19 %.  The price: the copy of slice
 // 0 starts after phase A instead of underneath it.
 constexpr int kWinMaxBits = 2048;            // bitmap bits over all views' rectangles (rows that do not fit are left out)
 // HALF: map 0 is stored in fp16 (D3F_DTYPE_F16): 256-byte slices of 128 channels, one 16-byte raw vector per lane (see fma_mix8)

@@ -81,6 +81,61 @@ __global__ __launch_bounds__(kBlock) void map_check_flat_kernel(const char *__re
     if (__ballot(bad) != 0ull && (threadIdx.x & 63) == 0) atomicOr(word, 1u);
 }
 
+// ---- several flat tensors in ONE launch (round 5: the per-frame refresh of a tracking loop checks depth + features + mask =
+// six launches of 3-5 us each before; one now).  Workgroup b works on the tensor whose workgroup range holds b.
+struct CheckJob { const char *data; int64_t nbytes; uint32_t *word; int32_t half; int32_t first_wg; int32_t n_wg; int32_t pad; };
+struct CheckJobs { CheckJob j[D3F_MAX_MAPS + 1]; int32_t n; };
+
+template <bool HALF>
+__device__ __forceinline__ bool check_flat_span(const char *__restrict__ data, int64_t nbytes, int wg, int n_wg)
+{
+    using VT = typename std::conditional<HALF, f16x8, f32x4>::type;
+    const int64_t nvec = nbytes >> 4;
+    const VT *__restrict__ v = reinterpret_cast<const VT *>(data);
+    const int64_t stride = (int64_t)n_wg * kBlock;
+    int64_t k = (int64_t)wg * kBlock + threadIdx.x;
+    VT s = (VT)0;
+    const VT z = (VT)0;
+    for (; k + 7 * stride < nvec; k += 8 * stride) {
+        VT x[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) x[j] = __builtin_nontemporal_load(v + k + j * stride);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s = __builtin_elementwise_fma(x[j], z, s);
+    }
+    for (; k < nvec; k += stride) s = __builtin_elementwise_fma(__builtin_nontemporal_load(v + k), z, s);
+    bool bad = false;
+    if constexpr (HALF) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) bad |= (s[j] != s[j]);
+    } else {
+        bad = (s.x != s.x) || (s.y != s.y) || (s.z != s.z) || (s.w != s.w);
+    }
+    if (wg == 0 && threadIdx.x == 0)            // the tail (< 16 bytes) by one lane
+        for (int64_t b = nvec << 4; b < nbytes; b += HALF ? 2 : 4) {
+            const float x = HALF ? (float)*reinterpret_cast<const _Float16 *>(data + b) : *reinterpret_cast<const float *>(data + b);
+            bad |= !(x * 0.0f == 0.0f);
+        }
+    return bad;
+}
+
+// CLEAR: the words are not known to be zero -- a first launch of this kernel with CLEAR = true zeroes them (one lane per job)
+template <bool CLEAR>
+__global__ __launch_bounds__(kBlock) void map_check_many_kernel(const CheckJobs J)
+{
+    if (CLEAR) {
+        if ((int)threadIdx.x < J.n) *J.j[threadIdx.x].word = 0u;
+        return;
+    }
+    int k = 0;
+    for (int q = 1; q < J.n; ++q)
+        if ((int)blockIdx.x >= J.j[q].first_wg) k = q;          // uniform
+    const CheckJob &c = J.j[k];
+    const int wg = (int)blockIdx.x - c.first_wg;
+    const bool bad = c.half ? check_flat_span<true>(c.data, c.nbytes, wg, c.n_wg) : check_flat_span<false>(c.data, c.nbytes, wg, c.n_wg);
+    if (__ballot(bad) != 0ull && (threadIdx.x & 63) == 0) atomicOr(c.word, 1u);
+}
+
 // any strides (views of wider buffers, unaligned bases): one lane per element, channel fastest
 template <bool HALF>
 __global__ __launch_bounds__(kBlock) void map_check_strided_kernel(const char *__restrict__ data, int V, int fh, int fw, int C,
@@ -124,6 +179,34 @@ hipError_t launch_map_check(const void *data, int V, int fh, int fw, int C, int6
         if (esize == 2) hipLaunchKernelGGL(map_check_strided_kernel<true>, dim3((unsigned)wg), dim3(kBlock), 0, s, d, V, fh, fw, C, sv, sy, sx, word);
         else hipLaunchKernelGGL(map_check_strided_kernel<false>, dim3((unsigned)wg), dim3(kBlock), 0, s, d, V, fh, fw, C, sv, sy, sx, word);
     }
+    return hipGetLastError();
+}
+
+bool map_is_flat(const void *data, int V, int fh, int fw, int C, int64_t sv, int64_t sy, int64_t sx)
+{
+    return sx == C && sy == (int64_t)fw * C && (sv == (int64_t)fh * fw * C || V == 1) && (reinterpret_cast<uintptr_t>(data) % 16) == 0;
+}
+
+// n <= D3F_MAX_MAPS + 1 FLAT tensors, one launch (two when the words are not known to be zero)
+hipError_t launch_map_check_many(const void *const *data, const int64_t *nbytes, const int *esize, uint32_t *const *words, int n,
+                                 bool words_are_zero, hipStream_t s)
+{
+    CheckJobs J;
+    J.n = 0;
+    int total = 0;
+    for (int k = 0; k < n; ++k) {
+        const int64_t nvec = nbytes[k] >> 4;
+        int64_t wg = (nvec + (int64_t)kBlock * 8 - 1) / ((int64_t)kBlock * 8);
+        if (wg > 256 * 16) wg = 256 * 16;
+        if (wg < 1) wg = 1;
+        CheckJob &c = J.j[J.n++];
+        c.data = static_cast<const char *>(data[k]); c.nbytes = nbytes[k]; c.word = words[k]; c.half = esize[k] == 2 ? 1 : 0;
+        c.first_wg = total; c.n_wg = (int)wg; c.pad = 0;
+        total += (int)wg;
+    }
+    if (J.n == 0) return hipSuccess;
+    if (!words_are_zero) hipLaunchKernelGGL(map_check_many_kernel<true>, dim3(1), dim3(64), 0, s, J);
+    hipLaunchKernelGGL(map_check_many_kernel<false>, dim3((unsigned)total), dim3(kBlock), 0, s, J);
     return hipGetLastError();
 }
 

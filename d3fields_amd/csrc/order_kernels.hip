@@ -10,7 +10,7 @@
 // Round 5: the curve is a HILBERT curve and the order inside a counting cell is exact.  Rounds 1-4 walked a Morton (Z)
 // curve, whose consecutive cells are up to a whole parent cell apart at every octant boundary: 64 consecutive points of it
 // -- one workgroup's tile -- then span a box several cells wide, and the LDS texel windows of the window kernel
-// (fuse_eval.hip) overflow their pool on 2 tiles of 3 (scripts/sim_cloud_tiles.py: C2-patch cloud, 66 % of the tiles over
+// (fuse_eval.hip) overflow their pool on 2 tiles of 3 (scripts/notebook/sim_cloud_tiles.py: C2-patch cloud, 66 % of the tiles over
 // an 80-slot pool, 18 % of the valid (point, view) pairs outside their window; Hilbert: 19 % / 2.9 %), which is why the
 // window kernel lost on clouds.  Consecutive cells of a Hilbert curve always share a face, at every level, so ANY run of
 // consecutive points is a compact blob.  Any prefix of the key is still a valid coarser cell (the curve is hierarchical).
@@ -22,12 +22,12 @@
 //                            and a histogram of a 15..21-bit prefix = the counting cell (16 mm at 1 M points; counters in
 //                            caller scratch, cleared by order_clear_kernel); the returning atomic also gives the point its
 //                            arrival rank inside the cell -- the only atomic per point
-//   2. exclusive scan of the counters (scan_kernels.hip, three small launches)
+//   2. exclusive scan of the counters (scan_kernels.hip: ONE launch, chained scan with decoupled look-back; rounds 2-4: three)
 //   3. scatter_kernel        index i and its key go to slot offset[cell] + rank -- cells in curve order, arrival order inside
 //   4. cell_rank_kernel      every slot counts the (key, index) pairs of ITS cell that sort before its own (a cell is ~30
 //                            consecutive slots: L1 hits) and moves to that place: the exact order of the full key, ties by
 //                            index.  A cell of more than 256 points (a dense clump) is ranked in aligned pieces of 256 slots.
-// Seven launches.  The result is a deterministic function of the points (the arrival order does not survive step 4 in
+// Five launches (seven up to round 4).  The result is a deterministic function of the points (the arrival order does not survive step 4 in
 // cells of <= 256 points).
 #include "d3f_internal.h"
 
@@ -78,10 +78,13 @@ constexpr int kExactCell = 256;           // cells of more points than this are 
 
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
-__global__ __launch_bounds__(kBlock) void order_clear_kernel(uint32_t *__restrict__ table, uint32_t *__restrict__ gate)
+__global__ __launch_bounds__(kBlock) void order_clear_kernel(uint32_t *__restrict__ table, uint32_t *__restrict__ gate,
+                                                            uint32_t *__restrict__ status, int status_words)
 {
     reinterpret_cast<uint4 *>(table)[(int64_t)blockIdx.x * kBlock + threadIdx.x] = make_uint4(0u, 0u, 0u, 0u);
     if (blockIdx.x == 0 && threadIdx.x < 4) gate[threadIdx.x] = 0u;       // the window / cell-run gate of this order (fuse_eval.hip)
+    if (blockIdx.x == 1 || gridDim.x == 1)                                 // the status words of the single-launch scan
+        for (int k = threadIdx.x; k < status_words; k += kBlock) status[k] = 0u;
 }
 
 // MORTON: the Z-curve keys of rounds 1-4 (experiments builds keep them for same-box comparisons)
@@ -155,7 +158,7 @@ uint32_t *order_gate_words(void *workspace, int64_t n)
 }
 
 // Fills *order_out with a pointer (inside the workspace) to n uint32 indices in Hilbert-cell order.
-// curve: 0 = Hilbert (the product's), 1 = Morton (experiments builds: the order of rounds 1-4)
+// curve: 0 = Hilbert (the product's); experiments builds: bit 0 = Morton (the order of rounds 1-4), bit 1 = the three-launch scan
 hipError_t build_point_order(const float *pts, int64_t n, void *workspace, int64_t workspace_bytes,
                              const uint32_t **order_out, hipStream_t stream, int curve)
 {
@@ -176,10 +179,16 @@ hipError_t build_point_order(const float *pts, int64_t n, void *workspace, int64
     while (bits < 21 && (1LL << bits) < 4 * n) bits += 1;
     const int shift = 27 - bits;
     const int64_t cells = 1LL << bits;
-    hipLaunchKernelGGL(order_clear_kernel, dim3((unsigned)(cells / 4 / kBlock)), dim3(kBlock), 0, stream, table, order_gate_words(workspace, n));
-    if (curve == 1) hipLaunchKernelGGL(cell_count_kernel<true>, dim3(nb), dim3(kBlock), 0, stream, pts, n, keys, ranks, table, shift);
+    // (the scan scratch is sized for the recursive three-launch scan of 2^21 counters: 1024 + 1 words and more)
+    uint32_t *status = static_cast<uint32_t *>(scan_scratch);
+    const int status_words = (int)scan_status_words(cells);
+    hipLaunchKernelGGL(order_clear_kernel, dim3((unsigned)(cells / 4 / kBlock)), dim3(kBlock), 0, stream, table, order_gate_words(workspace, n),
+                       status, status_words);
+    if (curve & 1) hipLaunchKernelGGL(cell_count_kernel<true>, dim3(nb), dim3(kBlock), 0, stream, pts, n, keys, ranks, table, shift);
     else hipLaunchKernelGGL(cell_count_kernel<false>, dim3(nb), dim3(kBlock), 0, stream, pts, n, keys, ranks, table, shift);
-    hipError_t e = launch_exclusive_scan_u32(table, table, cells, scan_scratch, stream);
+    // n < 2^31 points: the counts sum to n; the look-back scan carries 30-bit values -- above 2^30 points the recursive scan
+    hipError_t e = (n < (1LL << 30) && !(curve & 2)) ? launch_exclusive_scan_lookback_u32(table, table, cells, status, stream)
+                                   : launch_exclusive_scan_u32(table, table, cells, scan_scratch, stream);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(scatter_kernel, dim3(nb), dim3(kBlock), 0, stream, keys, ranks, n, table, slots, slot_keys, shift);
     hipLaunchKernelGGL(cell_rank_kernel, dim3(nb), dim3(kBlock), 0, stream, slot_keys, slots, n, table, cells, shift, order);

@@ -20,6 +20,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <atomic>
+
 #include "d3f_internal.h"
 #include "d3f_device.h"
 
@@ -675,16 +677,27 @@ double log_of_decimal(float beta)
 // launch must be resident): the runtime's occupancy for THIS kernel x the CUs of THIS device (a partition in CPX mode, a part
 // with fewer CUs, spills -- none of which the round-3 constant knew), half of it left to whatever else runs, capped by the
 // kernel's static LDS arrays.
+// Keypoints one d3f_track_run launch may hold on the CURRENT device: half of the waves that are resident together, the smaller of
+// the two kernel variants' figures (the bound protects the in-kernel wait of a multi-step launch).  Cached per device id -- a
+// process may drive several GPUs or switch devices between calls -- behind relaxed atomics (a racing first call computes the same
+// value twice).
 int track_run_capacity()
 {
-    static int cached = -1;
-    if (cached >= 0) return cached;
-    int dev = 0, cus = 0, per_cu = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, track_step_kernel<2>, 64, 0) != hipSuccess) return 0;
-    int cap = cus * per_cu / 2;
-    cached = cap < kTrackMaxResident ? cap : kTrackMaxResident;
-    return cached;
+    constexpr int kMaxDevices = 64;
+    static std::atomic<int> cached[kMaxDevices];          // 0 = not computed yet (a capacity is never 0 on a working device), stored + 1
+    int dev = 0, cus = 0, per1 = 0, per2 = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 0;
+    if (dev >= 0 && dev < kMaxDevices) {
+        const int hit = cached[dev].load(std::memory_order_relaxed);
+        if (hit > 0) return hit - 1;
+    }
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per1, track_step_kernel<1>, 64, 0) != hipSuccess) return 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per2, track_step_kernel<2>, 64, 0) != hipSuccess) return 0;
+    int cap = cus * (per1 < per2 ? per1 : per2) / 2;
+    cap = cap < kTrackMaxResident ? cap : kTrackMaxResident;
+    if (dev >= 0 && dev < kMaxDevices) cached[dev].store(cap + 1, std::memory_order_relaxed);
+    return cap;
 }
 
 hipError_t launch_track_step(const TrackStepParams &P, hipStream_t s)

@@ -234,6 +234,8 @@ class Fusion:
         self._words = None                      # device words of the checks (one per key), allocated on first use
         self._word_slot = {}
         self._finite_override = None            # True: D3F_FLAG_FINITE_MAPS (the caller vouches); False: strict path
+        self.debug_recheck_maps = False         # True: d3f_map_check runs before EVERY query (no per-tensor cache): finds writers that
+                                                # change a map behind torch's back without invalidate_map_checks()
         self.reference_rounding = False         # True: D3F_FLAG_REFERENCE_ROUNDING -- wide maps in the reference's operation order too
         self._tracker = None                    # rigid_tracking: the captured iteration of the current sequence
         self.tuning_flags = 0                   # D3F_TUNE_* bits (experiments; results do not depend on them)
@@ -312,13 +314,18 @@ class Fusion:
     # d3f_map_check streams the tensor once on the caller's stream and leaves a device word; the queries carry the words
     # of depth and maps (d3f_views.depth_nonfinite, d3f_channel_map.nonfinite) and decide on the device.  No sync, no ATen
     # kernel, capturable in a HIP graph.
-    _WORD_SLOTS = 64
+    # Every CHECK takes the next slot of a ring: a query still in flight on another stream, or a captured HIP graph
+    # that baked a word's address in, keeps reading the verdict of ITS tensor while a newer tensor of the same name is checked
+    # into another slot; a slot is rewritten only _WORD_SLOTS checks later (a captured graph older than that must be re-captured,
+    # or contain its own check).
+    _WORD_SLOTS = 256
 
-    def _finite_word(self, key, t, checked=None):
+    def _finite_word(self, key, t, checked=None, batch=None):
         """Address (int) of the device word d3f_map_check wrote for tensor `t` (cached per key on the tensor OBJECT and its
         version counter; a new tensor allocated at the address of a checked one is re-checked), or None when no word can be
         had (then the query takes the strict path: same results).  `checked`: the tensor the kernel should read instead
-        of `t` (a contiguous copy the caller just made; not cached)."""
+        of `t` (a contiguous copy the caller just made; not cached).  `batch`: a list -- the check is queued there instead of
+        launched, and _flush_checks(batch) enqueues ONE d3f_map_check_many for everything a query needs."""
         dev = t.device
         if self._words is None or self._words.device != dev:
             if torch.cuda.is_current_stream_capturing():
@@ -326,22 +333,28 @@ class Fusion:
             self._words = torch.zeros(self._WORD_SLOTS, dtype=torch.int32, device=dev)
             self._word_slot = {}
             self._finite_cache.clear()
-        slot = self._word_slot.get(key)
-        if slot is None:
-            if len(self._word_slot) >= self._WORD_SLOTS:
-                return None
-            slot = self._word_slot[key] = len(self._word_slot)
-        addr = self._words.data_ptr() + 4 * slot
         stream = torch.cuda.current_stream(dev)
         # keyed on the tensor OBJECT (weak reference) and its version counter.  Writers that bypass torch (custom kernels
         # writing into the map in place) must call invalidate_map_checks() -- a stale "finite" verdict would skip 0*NaN
         # terms the reference keeps.
         sig = (t._version, tuple(t.shape), t.data_ptr())
         hit = self._finite_cache.get(key)
-        if checked is None and hit is not None and hit[0]() is t and hit[1] == sig:
+        if checked is None and hit is not None and hit[0]() is t and hit[1] == sig and not self.debug_recheck_maps:
             if hit[2] != stream.cuda_stream:
                 stream.wait_event(hit[3])       # checked on another stream: order this one behind it
-            return addr
+            return self._words.data_ptr() + 4 * self._word_slot[key]
+        slot = self._next_word = (getattr(self, "_next_word", -1) + 1) % self._WORD_SLOTS
+        if slot == 0 and getattr(self, "_ring_used", False) and not torch.cuda.is_current_stream_capturing():
+            # the ring wraps: zero it (fresh slots are handed to d3f_map_check_many as already-zero words) and forget the cached
+            # verdicts that lived in it -- their tensors are checked again when they are next queried
+            self._words.zero_()
+            self._finite_cache.clear()
+            if batch is not None:
+                for item in batch:
+                    item[4] = None               # (their cache entries are re-made by the flush)
+        self._ring_used = True
+        self._word_slot[key] = slot
+        addr = self._words.data_ptr() + 4 * slot
         src = t if checked is None else checked
         if src.dim() == 3:                      # depth (V,H,W): a one-channel map
             desc = _lib.ChannelMap(src.data_ptr(), src.shape[1], src.shape[2], 1, _lib.DTYPE_F32, src.stride(0), src.stride(1),
@@ -354,9 +367,16 @@ class Fusion:
             ok = src.dtype in (torch.float32, torch.float16) and src.stride(3) == 1 and src.stride(2) >= src.shape[3]
         if not ok or min(src.stride()) < 0:
             return None
+        cacheable = checked is None and not torch.cuda.is_current_stream_capturing()
+        if batch is not None:
+            import weakref
+            batch.append([desc, int(src.shape[0]), addr, src, (key, weakref.ref(t), sig) if cacheable else None])
+            if not cacheable:
+                self._finite_cache.pop(key, None)
+            return addr
         with torch.cuda.device(dev):
             _lib.check(self._lib.d3f_map_check(ctypes.byref(desc), src.shape[0], ctypes.c_void_p(addr), _lib.current_stream_handle(dev)))
-        if checked is None and not torch.cuda.is_current_stream_capturing():
+        if cacheable:
             import weakref
             ev = torch.cuda.Event()
             ev.record(stream)
@@ -364,6 +384,30 @@ class Fusion:
         else:
             self._finite_cache.pop(key, None)
         return addr
+
+    def _flush_checks(self, batch, dev):
+        """ONE d3f_map_check_many for the checks _finite_word queued (depth + every map of a query whose tensors are new: the
+        per-frame refresh of a tracking loop was six launches)."""
+        if not batch:
+            return
+        n = len(batch)
+        descs = (_lib.ChannelMap * n)(*[b[0] for b in batch])
+        views = (ctypes.c_int32 * n)(*[b[1] for b in batch])
+        words = (ctypes.c_void_p * n)(*[b[2] for b in batch])
+        # a captured graph replays the launch on whatever the words hold then: let the call clear them itself there
+        zero = 0 if torch.cuda.is_current_stream_capturing() else _lib.CHECK_WORDS_ARE_ZERO
+        stream = torch.cuda.current_stream(dev)
+        with torch.cuda.device(dev):            # (every check takes a NEW slot of the ring, zeroed at allocation and at every wrap)
+            _lib.check(self._lib.d3f_map_check_many(descs, views, n, words, zero, _lib.current_stream_handle(dev)))
+        ev = None
+        for b in batch:
+            if b[4] is not None:
+                if ev is None:
+                    ev = torch.cuda.Event()
+                    ev.record(stream)
+                key, ref, sig = b[4]
+                self._finite_cache[key] = (ref, sig, stream.cuda_stream, ev)
+        del batch[:]
 
     def maps_are_finite(self, names=("depth", "dino_feats", "mask", "color_tensor")):
         """Host-side verdict of the device words (ONE host sync; diagnostics and tests only -- no query needs it)."""
@@ -517,7 +561,8 @@ class Fusion:
         elif runs:
             order += "; cell runs of %d consecutive points" % (max(plan.staged[s] for s in range(n_maps)) - 16)
         self._last_plan = {"kernel": kernel, "tile_points": int(plan.tile_points), "point_order": order,
-                           "workgroups": int(plan.workgroups), "lattice": lattice, "gated_window": bool(plan.gated_window)}
+                           "workgroups": int(plan.workgroups), "lattice": lattice, "gated_window": bool(plan.gated_window),
+                           "family": (self._lib.d3f_plan_family_name(int(plan.family)) or b"?").decode()}
         if plan.gated_window:
             # a cloud on the gated pair of launches (ABI 5): the fields above describe the cell-run side; the window side is the
             # sparse-pool window kernel on 64-point tiles of the same order.  last_gate() says which one ran.
@@ -579,8 +624,9 @@ class Fusion:
             # finiteness of depth and maps: device words written by d3f_map_check when a tensor is new (no host sync), keyed
             # on the caller's tensor objects; _finite_override (RigidTracker's private observation) replaces them by a fixed flag
             words = self._finite_override is None and bool(names)
+            checks = []                                    # new tensors of this query: ONE d3f_map_check_many below
             if words:
-                views.depth_nonfinite = self._finite_word("depth", self.curr_obs_torch["depth"])
+                views.depth_nonfinite = self._finite_word("depth", self.curr_obs_torch["depth"], batch=checks)
             used_maps = []
             for s, k in enumerate(names):
                 m = self.curr_obs_torch[k]                 # KeyError for unknown names, like the reference
@@ -592,7 +638,7 @@ class Fusion:
                 if m.stride(3) != 1:                           # a NEW tensor on every call: checked every call, never cached
                     m = m.contiguous()
                     keep.append(m)
-                word = self._finite_word(k, m_caller, None if m is m_caller else m) if words else None
+                word = self._finite_word(k, m_caller, None if m is m_caller else m, batch=checks) if words else None
                 used_maps.append(m)
                 C = m.shape[3]
                 o = torch.empty((n, C), dtype=torch.float32, device=dev)
@@ -605,6 +651,7 @@ class Fusion:
                     it = torch.empty((V, n, C), dtype=torch.float32, device=dev)
                     outputs[k + "_inter"] = it
                     inter[s] = it.data_ptr()
+            self._flush_checks(checks, dev)
             flags = self._query_flags()
             ws, ws_bytes = None, 0
             dims, hinted_unordered = None, None

@@ -39,24 +39,16 @@ def shard_points(pts, rank=None, world=None, group=None):
     return pts[lo:hi]
 
 
-class _PaddedGather:
-    """Pending ragged all-gather: ONE all_gather_into_tensor of blocks padded to the largest shard, then every rank's
-    rows are copied from the padded staging buffer to their place in `out`.  wait() completes both steps."""
+class _PeerGather:
+    """Pending ragged all-gather made of grouped point-to-point transfers (see _gather_rows_into).  wait() completes them."""
 
-    def __init__(self, work, staged, out, counts, maxc):
-        self.work, self.staged, self.out, self.counts, self.maxc = work, staged, out, list(counts), maxc
+    def __init__(self, works, keep):
+        self.works, self.keep = list(works), keep          # `keep`: the send buffer must outlive an asynchronous transfer
 
     def wait(self):
-        if self.work is not None:
-            self.work.wait()
-            self.work = None
-        if self.staged is not None:
-            off = 0
-            for r, c in enumerate(self.counts):
-                if c:
-                    self.out[off:off + c].copy_(self.staged[r * self.maxc:r * self.maxc + c])
-                off += c
-            self.staged = None
+        for w in self.works:
+            w.wait()
+        self.works, self.keep = [], None
         return True
 
 
@@ -65,26 +57,31 @@ def _gather_rows_into(out, x, counts, group, async_op=False):
     ([sum(counts), ...]).  Returns the pending works (objects with .wait()).
 
     Equal shards: one all_gather_into_tensor straight into `out` (no padding, no staging, no torch.cat).  Ragged shards
-    (round 4; rounds 2-3 queued P broadcasts back to back, i.e. P collectives of one sender each -- on a ring that is P
-    times the latency and never more than one link busy): ONE all_gather_into_tensor of blocks padded to the largest shard
-    into a staging buffer, then P local block copies into place (shard_bounds' shards differ by at most one row, so the
-    padding is at most one row per rank; the local copies move what one rank receives once more through HBM, ~1 % of the
-    time the same bytes need on a 153 GB/s link)."""
+    (round 5): every rank copies its own rows into place and exchanges the others as ONE group of point-to-point transfers
+    (batch_isend_irecv: P-1 sends of its block, P-1 receives straight into the peers' places in `out`) -- exactly the bytes
+    the result holds, no staging buffer, any counts (also [N, 0, ..., 0]), and on xGMI's full mesh every pair's block travels
+    on its own link.  (Round 4 padded every block to the largest shard and gathered into a world * max(counts) staging tensor
+    first: for counts far from equal that moved and held up to `world` times the field; rounds 2-3 queued P broadcasts.)"""
     rank, world = _world(group)
     x = x.contiguous()
     if len(set(counts)) == 1:
         w = dist.all_gather_into_tensor(out, x, group=group, async_op=async_op)
         return [w] if async_op else []
-    maxc = max(counts)
-    if x.shape[0] == maxc:
-        padded = x
-    else:
-        padded = x.new_zeros((maxc,) + tuple(x.shape[1:]))
-        padded[:x.shape[0]].copy_(x)
-    staged = x.new_empty((world * maxc,) + tuple(x.shape[1:]))
-    w = dist.all_gather_into_tensor(staged, padded, group=group, async_op=async_op)
-    pg = _PaddedGather(w if async_op else None, staged, out, counts, maxc)
-    pg._keep = padded                       # the input must outlive an asynchronous collective
+    offs = [0]
+    for c in counts:
+        offs.append(offs[-1] + c)
+    if counts[rank]:
+        out[offs[rank]:offs[rank + 1]].copy_(x)
+    peer = (lambda r: dist.get_global_rank(group, r)) if group is not None else (lambda r: r)
+    ops = []
+    for r in range(world):
+        if r == rank:
+            continue
+        if counts[rank]:
+            ops.append(dist.P2POp(dist.isend, x, peer(r), group))
+        if counts[r]:
+            ops.append(dist.P2POp(dist.irecv, out[offs[r]:offs[r + 1]], peer(r), group))
+    pg = _PeerGather(dist.batch_isend_irecv(ops) if ops else [], x)
     if async_op:
         return [pg]
     pg.wait()

@@ -125,6 +125,15 @@ typedef struct d3f_channel_map {
  * word_out: one device uint32, 4-byte aligned; the call overwrites it. */
 int d3f_map_check(const d3f_channel_map *map, int32_t V, uint32_t *word_out, void *stream);
 
+/* ABI 5.  The same for n <= D3F_MAX_MAPS + 1 tensors in ONE launch (the per-frame refresh of a tracking loop checks depth +
+ * features + mask: one launch instead of six): maps[k] with views[k] views leaves its verdict in *words_out[k].
+ * D3F_CHECK_WORDS_ARE_ZERO: the caller hands over words that are zero already (fresh slots of a zeroed buffer), which saves
+ * the clearing launch; without it the call zeroes them first.  A tensor that is not one contiguous 16-byte aligned block is
+ * checked by its own d3f_map_check launch inside the call. */
+#define D3F_CHECK_WORDS_ARE_ZERO 1u
+int d3f_map_check_many(const d3f_channel_map *maps, const int32_t *views, int32_t n, uint32_t *const *words_out, uint32_t flags,
+                       void *stream);
+
 /* ---- library ---------------------------------------------------------------------- */
 int d3f_abi_version(void);
 const char *d3f_version(void);    /* "d3fields-hip <semver> gfx950" (host memory)          */
@@ -192,9 +201,15 @@ typedef struct d3f_eval_plan {
     int32_t gated_window;                   /* ABI 5.  1: a cloud that gets the gated pair of launches; the fields above describe
                                                the cell-run side, the window side is the lattice's window plan on 64-point tiles */
     int32_t reserved2;                      /* gated_window: the window side's `reserved` code (2000 + 100*U + 10*VC + W)       */
+    int32_t family;                         /* ABI 5.  row of the planner's family table that took the query: 0 dist-only, 1 lds-window,
+                                               2 cell-runs, 3 channel-sliced, 4 direct (d3f_plan_family_name; csrc/d3f_plan.h)      */
+    int32_t reserved3;
 } d3f_eval_plan;
 int d3f_eval_plan_query(const d3f_views *views, int64_t n, const d3f_channel_map *maps, int32_t n_maps,
                         uint32_t flags, int32_t have_workspace, int32_t want_inter, d3f_eval_plan *plan);
+/* name of a family id ("lds-window", ...; NULL for an id outside the table), and what the row takes, as one line of text */
+const char *d3f_plan_family_name(int32_t family);
+const char *d3f_plan_family_takes(int32_t family);
 
 /* ---- regular grids and keypoint selection (reference fusion.py:79-88, 1418-1475) ---------------------
  * A grid is given by its three axis coordinate arrays, exactly the `arange(lower, upper, step) + step/2`

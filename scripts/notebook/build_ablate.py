@@ -3,10 +3,11 @@
 arithmetic, 16 arithmetic without corner reads).  Results of these libraries are wrong by construction; only times are read.
     D3F_BUILD_EXPERIMENTS=1 python scripts/build_ablate.py 0 1 4 8 16"""
 import os, shutil, sys
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
 from d3fields_amd import build
 os.makedirs("build_ab", exist_ok=True)
-for ab in [int(a) for a in sys.argv[1:]]:
-    build.build_library(force=True, extra_flags=["-DD3F_WIN_ABLATE=%d" % ab])
-    shutil.copy(build.LIB_PATH, "build_ab/ablate_%d.so" % ab)
-    print("built", ab, flush=True)
+macro, tag = ("D3F_SLICED_WHATIF", "sliced") if "--sliced" in sys.argv else ("D3F_WIN_ABLATE", "ablate")
+for ab in [int(a) for a in sys.argv[1:] if not a.startswith("--")]:
+    build.build_library(force=True, extra_flags=["-D%s=%d" % (macro, ab)])
+    shutil.copy(build.LIB_PATH, "build_ab/%s_%d.so" % (tag, ab))
+    print("built", tag, ab, flush=True)

@@ -1,7 +1,7 @@
 """What does the 8-channel mask cost when it rides along with the channel-sliced gather of C3-dense?
     python scripts/exp_c3_mask.py        (fused kernel time of the three launches, HIP events)"""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 import bench
 dev = torch.device("cuda:0")

@@ -2,7 +2,7 @@
 pre-filter, the distance-only query of the 1-mm grid, the backward of eval, one rigid-tracking frame.  Device time from HIP
 events around the call (all of it is asynchronous on the current stream); run under rocprofv3 for the per-kernel breakdown."""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import torch
 import bench

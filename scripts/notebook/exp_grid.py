@@ -1,6 +1,6 @@
 """GPU measurement: grid-native paths at the size of select_features_rand's 1-mm grid (~1.2e8 points)."""
 import sys, os, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from d3fields_amd import Fusion, create_init_grid, synth, fps
 

@@ -1,6 +1,6 @@
 """How long does the HOST need per Fusion.batch_eval call (Python + ctypes + launches), vs the device time of the step?"""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 import bench
 

@@ -1,5 +1,5 @@
 import sys, os, cProfile, pstats
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from d3fields_amd import Fusion, synth
 dev = torch.device("cuda:0")

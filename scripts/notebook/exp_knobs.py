@@ -5,7 +5,7 @@ against the first variant, and the kernel the plan reports.
     python scripts/exp_knobs.py c2_dense "tag:K1=v1,K2=v2" "tag2:K=v" ...       (tag 'base:' = no knobs)
 """
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 import bench
 

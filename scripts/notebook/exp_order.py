@@ -1,6 +1,6 @@
 """GPU experiment: effect of point order / tile size / occupancy on the fused kernel."""
 import sys, os, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from d3fields_amd import Fusion, create_init_grid, synth
 

@@ -1,6 +1,6 @@
 """GPU measurement: the pairwise descriptor kernel of C5 (100 000 x 300 x 384) through the shim."""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from d3fields_amd import corr_utils as cu
 

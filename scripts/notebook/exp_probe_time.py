@@ -1,6 +1,6 @@
 """GPU micro-benchmark: device time of the two order probes and of the cloud ordering (HIP events around 50 calls)."""
 import os, sys, ctypes
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from d3fields_amd import _lib, synth
 lib = _lib.load()

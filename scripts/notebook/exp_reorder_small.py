@@ -1,7 +1,7 @@
 """GPU experiment: launch geometry for the Morton walk when the maps are SMALL (patch-res features, mask):
 random clouds need the walk for L1/L2 locality, but the 8-point / XCD-eighth geometry was tuned on dense maps."""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 import bench
 

@@ -1,6 +1,6 @@
 """GPU measurement: Fusion.rigid_tracking, eager launches vs one HIP graph replayed; difference to the reference's result."""
 import sys, os, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import torch
 from d3fields_amd import Fusion

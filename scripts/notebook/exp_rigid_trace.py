@@ -1,6 +1,6 @@
 """Kernel list of the tracking iteration (run under rocprofv3 --kernel-trace --stats)."""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import torch
 from d3fields_amd import Fusion, rigid

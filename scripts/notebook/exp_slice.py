@@ -2,7 +2,7 @@
 Times the existing kernel on a 32-channel strided VIEW of the 384-channel dense map (one 128-B
 line per texel, same addresses a sliced pass would touch); 12 x that time predicts a sliced kernel."""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from d3fields_amd import Fusion, create_init_grid, synth
 

@@ -2,7 +2,7 @@
 Kernel-only time (d3f_profile_next_eval) of a strided [..., c0:c0+cs] view of the map; S x that
 time predicts an in-kernel variant where XCD k gathers slice k % S (L2 footprint / S per XCD)."""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 import bench
 from d3fields_amd import Fusion, create_init_grid, synth

@@ -1,6 +1,6 @@
 """Run a few evals of a [..., :cs] channel slice of the dense map with given tuning flags (for rocprofv3 --pmc)."""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from d3fields_amd import Fusion, create_init_grid, synth
 

@@ -2,7 +2,7 @@
 producer of the feature maps could buy the query by padding (the C-ABI takes any strides).  L2 background: scripts/microbench/l2_probe.hip.
     python scripts/exp_texel_stride.py [workload]"""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 import bench
 dev = torch.device("cuda:0")

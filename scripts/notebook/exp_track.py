@@ -1,6 +1,6 @@
 """GPU measurement: rigid-tracking-style iteration (eval with grad + backward) at small N."""
 import sys, os, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from d3fields_amd import Fusion, synth
 

@@ -1,6 +1,6 @@
 """GPU experiment: tile size x XCD remap x occupancy throttle, per workload (one process)."""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 import bench
 

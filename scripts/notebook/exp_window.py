@@ -1,7 +1,7 @@
 """GPU experiment: LDS texel windows (D3F_EXP_WINDOW) vs the cell-run gather on the patch-resolution workloads.
 Bit-identity of every output against the default launch, and the fused kernel's time (d3f_profile_next_eval)."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 import bench
 

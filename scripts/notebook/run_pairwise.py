@@ -1,6 +1,6 @@
 """A few launches of the C5 pairwise kernel (for rocprofv3)."""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from d3fields_amd import corr_utils as cu
 dev = torch.device("cuda:0")

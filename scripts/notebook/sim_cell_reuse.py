@@ -1,7 +1,7 @@
 """How often do neighbouring points of a window-kernel brick share their texel cell?  (open item 0: register reuse of corner
 vectors would need the four lane groups of a wave to agree.)  CPU only: python scripts/sim_cell_reuse.py"""
 import sys, numpy as np, torch
-sys.path.insert(0, __import__('os').path.join(__import__('os').path.dirname(__import__('os').path.abspath(__file__)), '..'))
+sys.path.insert(0, __import__('os').path.join(__import__('os').path.dirname(__import__('os').path.abspath(__file__)), '..', '..'))
 from d3fields_amd import synth
 import bench
 def sim(name):

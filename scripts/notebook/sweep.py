@@ -1,6 +1,6 @@
 """GPU sweep: kernel time of the field query across workloads / return_names (HIP events)."""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 import bench
 from d3fields_amd import synth

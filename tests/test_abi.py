@@ -336,6 +336,26 @@ def test_window_launch_plan(monkeypatch):
         assert p.staged[0] == 3 and p.lds_bytes <= 160 * 1024 // 2    # 32 KB of records for 128 x 8 pairs + ~11 pool slots per view: 2 workgroups per CU
 
 
+def test_family_table():
+    """The planner is a walk over a table of kernel families (csrc/d3f_plan.h): every row is reachable, reports its id, and the
+    library names it."""
+    lib = _lib.load()
+    F = _lib.FLAG_FINITE_MAPS
+    names = [lib.d3f_plan_family_name(k) for k in range(6)]
+    assert names == [b"dist-only", b"lds-window", b"cell-runs", b"channel-sliced", b"direct", None]
+    assert all(lib.d3f_plan_family_takes(k) for k in range(5)) and lib.d3f_plan_family_takes(7) is None
+    assert _plan(4, 480, 640, 100000, []).family == 0                                         # return_names=[]
+    v = _lib.Views(4, 480, 640, 16, 16, 16)
+    arr = (_lib.ChannelMap * 1)(_lib.ChannelMap(16, 48, 64, 384, 0, 48 * 64 * 384, 64 * 384, 384))
+    p = _lib.EvalPlan()
+    assert lib.d3f_eval_plan_query_lattice(ctypes.byref(v), 160, 140, 44, arr, 1, F, 0, ctypes.byref(p)) == 0 and p.family == 1
+    assert _plan(4, 480, 640, 985600, [(48, 64, 384)], F).family == 2                          # patch-resolution map, caller order: cell runs
+    assert _plan(4, 480, 640, 985600, [(480, 640, 384)], F).family == 3                        # dense map on the Hilbert walk: channel slices
+    assert _plan(4, 480, 640, 985600, [(480, 640, 384)], F | _lib.TUNE_DIRECT_GATHER).family == 4
+    assert _plan(4, 480, 640, 300, [(48, 64, 384)], F).family == 4                             # a small batch
+    assert _plan(4, 480, 640, 985600, [(48, 64, 384)], 0).family == 4                          # maps not known to be finite
+
+
 def test_plan_table():
     """One row per launch-plan threshold of d3f_api.hip (kSmallBatch, kCacheResidentBytes, kBatchedLoadBytes, kBeyondLlcBytes):
     the plan on either side of each boundary, from d3f_eval_plan_query alone."""
