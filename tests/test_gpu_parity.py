@@ -254,6 +254,72 @@ def test_map_check_words(dev):
     assert not f2.maps_are_finite(("depth",)) and f2.maps_are_finite(("dino_feats",))
 
 
+def test_map_check_many_and_the_ring_of_words(dev):
+    """d3f_map_check_many (ABI 5): depth + every map of a frame in ONE launch -- flat tensors inside the batched kernel, a strided
+    one through its own launch inside the call, with and without D3F_CHECK_WORDS_ARE_ZERO -- gives the single-tensor call's
+    verdicts; the shim hands every check a fresh slot of a zeroed ring, stays right when the ring wraps (256 checks), and
+    `debug_recheck_maps` finds a writer that changed a map behind torch's back."""
+    import ctypes
+    from d3fields_amd import synth, _lib
+    lib = _lib.load()
+    st = _lib.current_stream_handle(dev)
+    g = torch.Generator().manual_seed(9)
+    tensors = [torch.randn((3, 40, 56, 1), generator=g).to(dev),                       # "depth" as a one-channel map
+               torch.randn((3, 12, 16, 384), generator=g).to(dev),
+               torch.randn((3, 40, 56, 8), generator=g).to(dev).half(),
+               torch.randn((3, 6, 8, 24), generator=g).to(dev)[..., :16]]               # a channel range: not one flat block
+    for bad_at in (None, 0, 1, 2, 3):
+        ts = [t.clone() for t in tensors[:3]]
+        ts.append(torch.randn((3, 6, 8, 24), generator=g).to(dev)[..., :16])             # texel stride 24 > C = 16: its own launch
+        assert not ts[3].is_contiguous()
+        if bad_at is not None:
+            ts[bad_at][2, 3, 1, 0] = float("nan")
+        n = len(ts)
+        descs = (_lib.ChannelMap * n)(*[_lib.ChannelMap(t.data_ptr(), t.shape[1], t.shape[2], t.shape[3], _lib.DTYPE_F16 if t.dtype == torch.float16 else _lib.DTYPE_F32,
+                                                        t.stride(0), t.stride(1), t.stride(2), None) for t in ts])
+        views = (ctypes.c_int32 * n)(*[t.shape[0] for t in ts])
+        for flags, fill in ((0, 55), (_lib.CHECK_WORDS_ARE_ZERO, 0)):
+            words = torch.full((8,), fill, dtype=torch.int32, device=dev)
+            ptrs = (ctypes.c_void_p * n)(*[words.data_ptr() + 4 * (2 * k) for k in range(n)])
+            _lib.check(lib.d3f_map_check_many(descs, views, n, ptrs, flags, st))
+            got = words.tolist()
+            assert [got[2 * k] != 0 for k in range(n)] == [k == bad_at for k in range(n)], (bad_at, flags, got)
+            assert all(got[2 * k + 1] == fill for k in range(n))                       # neighbouring words untouched
+    assert lib.d3f_map_check_many(None, None, 0, None, 0, st) == 0
+    assert lib.d3f_map_check_many(descs, views, 99, ptrs, 0, st) == _lib.ERR_BAD_SHAPE
+    ptrs[1] = None
+    assert lib.d3f_map_check_many(descs, views, n, ptrs, 0, st) == _lib.ERR_BAD_LAYOUT
+
+    # the shim: a fresh slot per check; 300 frames wrap the ring of 256 slots; verdicts stay those of the tensors
+    V, H, W = 3, 48, 64
+    sc = synth.make_scene(V, H, W, "stress")
+    feats = synth.random_map(V, 12, 16, 160, seed=1).to(dev)
+    pts = synth.random_cloud(3000, seed=3).to(dev)
+    f = make_fusion(dev, sc["depth"], sc["K"], sc["pose"], {"dino_feats": feats}, H, W)
+    ref = None
+    with torch.no_grad():
+        for frame in range(300):
+            f.curr_obs_torch["dino_feats"] = feats.clone()                              # a NEW tensor object: checked again
+            if frame % 50 == 49:
+                f.curr_obs_torch["dino_feats"][0, :, :, 0] = float("inf")
+            out = f.eval(pts, return_names=["dino_feats"])
+            if frame == 0:
+                ref = out["dino_feats"].clone()
+            if frame % 50 == 49:
+                assert not f.maps_are_finite(("depth", "dino_feats")) and not torch.isfinite(out["dino_feats"]).all()
+            elif frame % 50 == 0:
+                assert f.maps_are_finite(("depth", "dino_feats")) and torch.equal(out["dino_feats"], ref), frame
+        # a writer behind torch's back (no version bump): the cached verdict is stale until invalidate_map_checks() -- or debug mode
+        m = f.curr_obs_torch["dino_feats"] = feats.clone()
+        f.eval(pts, return_names=["dino_feats"])
+        assert f.maps_are_finite(("dino_feats",))
+        m.data[0, :, :, 0] = float("nan")                 # through .data: the storage changes, m's version counter does not
+        assert f.maps_are_finite(("dino_feats",))         # ... so the cached verdict is stale (documented: invalidate_map_checks())
+        f.debug_recheck_maps = True
+        assert not f.maps_are_finite(("dino_feats",))
+        assert torch.isnan(f.eval(pts, return_names=["dino_feats"])["dino_feats"]).any()
+
+
 def test_nonfinite_points(dev):
     from d3fields_amd import synth
     V, H, W = 3, 48, 64
