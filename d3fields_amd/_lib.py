@@ -23,6 +23,7 @@ TUNE_DIRECT_GATHER = 1 << 4
 TUNE_NO_WINDOW_GATE, TUNE_WINDOW_SIDE = 1 << 5, 1 << 6
 GATE_SAMPLES, GATE_MIN_FIT = 128, 96
 CHECK_WORDS_ARE_ZERO = 1
+TRACK_STALL_SENTINEL = 0x57A11ED
 MAX_VIEWS = 64
 MAX_MAPS = 8
 DTYPE_F32 = 0
@@ -134,6 +135,7 @@ SIGNATURES = {
     "d3f_track_run": (ctypes.c_int, [ctypes.POINTER(Views), ctypes.POINTER(ChannelMap), _vp, _i32, _i32, _vp, _f32, _f32, _f32, _f32, _f32,
                                      _f32, _f32, _i32, ctypes.POINTER(TrackState), _vp]),
     "d3f_track_run_max_keypoints": (_i32, []),
+    "d3f_track_stall_word": (_i64, [_i32, _i32]),
     "d3f_rigid_update": (ctypes.c_int, [_vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f32, _f32, _f32, _f32, _f32, _vp]),
     "d3f_softmax_merge": (ctypes.c_int, [_vp, _i64, _i64, _vp, _vp, _vp]),
     "d3f_softmax_apply": (ctypes.c_int, [_vp, _i64, _i64, _f32, _vp, _vp]),

@@ -916,6 +916,8 @@ int64_t d3f_track_step_scratch_bytes(int32_t n_inst, int32_t n)
     return (((int64_t)n_inst * n * 3 + 6) * (int64_t)sizeof(float) + 7) / 8 * 8 + (int64_t)n_inst * 6 * 8;
 }
 
+int64_t d3f_track_stall_word(int32_t n_inst, int32_t n) { return (n_inst < 0 || n < 0) ? 0 : (int64_t)n_inst * n * 3 + 5; }      // counter[1]
+
 static int track_impl(const d3f_views *views, const d3f_channel_map *descriptors, const float *last, int32_t n_inst, int32_t n,
                       const float *src, float mu, float dist_w, float reg_w, float lr, float beta1, float beta2, float eps,
                       int32_t iters, const d3f_track_state *state, void *stream)

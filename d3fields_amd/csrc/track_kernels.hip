@@ -332,7 +332,10 @@ __global__ __launch_bounds__(64) void track_step_kernel(const TrackStepParams P)
             }
         }
         if (!seen) {
+            // the bounded wait expired (the device was held by other work): poison the loss AND leave a sentinel in the spare
+            // counter word, so that the host can tell a stall from a NaN that came out of the data
             if (lane < 3) st_coh(P.loss_out + lane, __builtin_nanf(""));
+            if (lane == 0) st_coh(P.counter + 1, D3F_TRACK_STALL_SENTINEL);
             return;
         }
         const float val = __uint_as_float((unsigned int)word);

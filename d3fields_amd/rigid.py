@@ -246,10 +246,14 @@ class RigidTracker:
         cur, loss = self.cur.detach().clone(), self.loss.detach().clone()
         if self.loop:
             # d3f_track_run's waves wait for one another INSIDE the kernel; with the device held by other work for seconds
-            # the bounded wait gives up and poisons the loss with NaN (the poses are then undefined).  One host sync per
-            # frame -- the caller (Fusion.rigid_tracking) copies the keypoints to the host right away anyway -- and the
-            # frame is repeated with one launch per step, which cannot stall; the tracker stays on that form.
-            if bool(torch.isnan(self.loss3).any().item()):
+            # the bounded wait gives up, poisons the loss with NaN (the poses are then undefined) and leaves a sentinel word in
+            # the scratch.  One host sync per frame -- the caller (Fusion.rigid_tracking) copies the keypoints to the host right
+            # away anyway -- reads that word: a stall repeats the frame with one launch per step, which cannot stall, and the
+            # tracker stays on that form; a NaN that came out of the DATA (no sentinel) is the caller's result as it is.
+            from . import _lib
+            I, n = self.last.shape[0], self.last.shape[1]
+            word = int(_lib.load().d3f_track_stall_word(I, n))
+            if int(self.scratch.view(torch.int32)[word].item()) == _lib.TRACK_STALL_SENTINEL:
                 self.loop = False
                 self.graph = None
                 self.loop_fallbacks += 1

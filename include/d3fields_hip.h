@@ -502,9 +502,13 @@ int d3f_track_step(const d3f_views *views, const d3f_channel_map *descriptors, c
  * occupancy of the kernel (hipOccupancyMaxActiveBlocksPerMultiprocessor) x its compute units, half of that (the other half is
  * left to whatever else runs), at most 512.  The wait is bounded: should a wave never see the next step's parameters (the
  * device held by other kernels for seconds), loss[0..2] become NaN, the launch ends, and t / w / the optimiser state are
- * UNDEFINED: a caller that shares the device checks loss for NaN, restores its state, clears `scratch` and repeats the frame
- * with d3f_track_step (d3fields_amd/rigid.py: RigidTracker.run does exactly that).  scratch is cleared at the start of every
+ * UNDEFINED.  The kernel also leaves D3F_TRACK_STALL_SENTINEL in the uint32 at word d3f_track_stall_word(n_inst, n) of `scratch`
+ * (ABI 5): a NaN loss WITHOUT the sentinel came out of the data, not out of a stall.  A caller that shares the device reads that
+ * word, restores its state and repeats the frame with d3f_track_step (d3fields_amd/rigid.py: RigidTracker.run does exactly
+ * that).  scratch is cleared at the start of every
  * d3f_track_run (a one-workgroup launch ahead of the step kernel); d3f_track_step expects the scratch its predecessor left. */
+#define D3F_TRACK_STALL_SENTINEL 0x57A11EDu
+int64_t d3f_track_stall_word(int32_t n_inst, int32_t n);      /* index (in 4-byte words) of the sentinel inside `scratch` */
 int d3f_track_run(const d3f_views *views, const d3f_channel_map *descriptors, const float *last, int32_t n_inst, int32_t n,
                   const float *src, float mu, float dist_w, float reg_w, float lr, float beta1, float beta2, float eps,
                   int32_t iters, const d3f_track_state *state, void *stream);

@@ -6,7 +6,7 @@ import os, shutil, sys
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
 from d3fields_amd import build
 os.makedirs("build_ab", exist_ok=True)
-macro, tag = ("D3F_SLICED_WHATIF", "sliced") if "--sliced" in sys.argv else ("D3F_WIN_ABLATE", "ablate")
+macro, tag = ("D3F_SLICED_WHATIF", "sliced") if "--sliced" in sys.argv else (("D3F_RUNS_PREFETCH", "runs") if "--runs" in sys.argv else ("D3F_WIN_ABLATE", "ablate"))
 for ab in [int(a) for a in sys.argv[1:] if not a.startswith("--")]:
     build.build_library(force=True, extra_flags=["-D%s=%d" % (macro, ab)])
     shutil.copy(build.LIB_PATH, "build_ab/%s_%d.so" % (tag, ab))

@@ -494,8 +494,10 @@ def test_track_run_falls_back_when_its_wait_gives_up(dev):
     """d3f_track_run's waves wait for one another inside the kernel; when the bounded wait gives up (a device held by other
     work for seconds) the kernel poisons the loss with NaN.  RigidTracker.run must notice, repeat the frame with one launch per
     step and stay on that form (VERDICT r3 / ADVICE r3: until round 4 the caller silently got undefined poses).  The give-up
-    is simulated: the first replay's loss words are overwritten with NaN."""
-    from d3fields_amd import rigid
+    is simulated: the first replay's loss words are overwritten with NaN and the kernel's stall sentinel is left in the scratch
+    (ABI 5: the sentinel, not the NaN, is what the tracker looks at -- a NaN that came out of the data must NOT switch the
+    tracker to the slow form)."""
+    from d3fields_amd import rigid, _lib
     g, f, info, n = _golden_tracker_inputs(dev)
     src = torch.cat([info["a"]["src_feats"], info["b"]["src_feats"]]).to(dev)
     last = torch.from_numpy(np.stack([p for p in g["last_pts"]])).to(dev)
@@ -507,11 +509,21 @@ def test_track_run_falls_back_when_its_wait_gives_up(dev):
     assert tr.loop and tr.loop_fallbacks == 0 and torch.equal(first, want)
     real_replay, hits = tr.graph.replay, []
 
+    word = int(_lib.load().d3f_track_stall_word(2, n))
+
+    def data_nan():                                              # a NaN loss WITHOUT the sentinel: not a stall
+        real_replay()
+        tr.loss3.fill_(float("nan"))
+    tr.graph.replay = data_nan
+    got, _ = tr.run(f, src, last)
+    assert tr.loop and tr.loop_fallbacks == 0 and torch.equal(got, want)      # no sentinel: the frame stands, the tracker keeps its form
+
     def poisoned():
         real_replay()
         if not hits:
             hits.append(1)
             tr.loss3.fill_(float("nan"))
+            tr.scratch.view(torch.int32)[word] = _lib.TRACK_STALL_SENTINEL
             tr.t_params.fill_(123.0)                             # ... and the poses are garbage
     tr.graph.replay = poisoned
     got, loss = tr.run(f, src, last)
