@@ -27,7 +27,11 @@
 //   4. cell_rank_kernel      every slot counts the (key, index) pairs of ITS cell that sort before its own (a cell is ~30
 //                            consecutive slots: L1 hits) and moves to that place: the exact order of the full key, ties by
 //                            index.  A cell of more than 256 points (a dense clump) is ranked in aligned pieces of 256 slots.
-// Five launches (seven up to round 4).  The result is a deterministic function of the points (the arrival order does not survive step 4 in
+// Five launches (seven up to round 4); 1 M points: 0.15 ms, of which the returning atomics are 0.065 -- they serialise on the ~33
+// points of an occupied 16-mm cell.  Measured and not kept (round 5, scripts/notebook/gpu_sessions/r5_gpu20-22.sh): fewer
+// counters (2^19 / 2^18: the atomics 130 us, the rank loops 72-110 us); counters private to an XCD (eight planes indexed by the
+// hardware XCC id, workgroup-scope atomics: no faster -- the limit is not coherence traffic -- and 3 bits of cell resolution
+// lost: 32-mm cells of ~266 points exceed the exact-rank window).  The result is a deterministic function of the points (the arrival order does not survive step 4 in
 // cells of <= 256 points).
 #include "d3f_internal.h"
 
@@ -105,45 +109,40 @@ __global__ __launch_bounds__(kBlock) void cell_count_kernel(const float *__restr
     ranks[i] = atomicAdd(&table[key >> shift], 1u);
 }
 
+// slot = (key << 32) | index: ONE 8-byte store per point (two 4-byte arrays were two partial-sector writes: 25 -> 14 us per 1 M
+// points), and the rank kernel compares the words as they are
 __global__ __launch_bounds__(kBlock) void scatter_kernel(const uint32_t *__restrict__ keys, const uint32_t *__restrict__ ranks, int64_t n,
-                                                        const uint32_t *__restrict__ offsets, uint32_t *__restrict__ slots,
-                                                        uint32_t *__restrict__ slot_keys, int shift)
+                                                        const uint32_t *__restrict__ offsets, unsigned long long *__restrict__ slots, int shift)
 {
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (i >= n) return;
     const uint32_t key = keys[i];
-    const uint32_t pos = offsets[key >> shift] + ranks[i];
-    slots[pos] = (uint32_t)i;
-    slot_keys[pos] = key;
+    slots[offsets[key >> shift] + ranks[i]] = ((unsigned long long)key << 32) | (uint32_t)i;
 }
 
-// One lane per slot: its place among the (key, index) pairs of its own counting cell.
-__global__ __launch_bounds__(kBlock) void cell_rank_kernel(const uint32_t *__restrict__ slot_keys, const uint32_t *__restrict__ slots,
-                                                          int64_t n, const uint32_t *__restrict__ offsets, int64_t cells, int shift,
+// One lane per slot: its place among the (key, index) words of its own counting cell.
+__global__ __launch_bounds__(kBlock) void cell_rank_kernel(const unsigned long long *__restrict__ slots, int64_t n,
+                                                          const uint32_t *__restrict__ offsets, int64_t cells, int shift,
                                                           uint32_t *__restrict__ order)
 {
     const int64_t pos = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (pos >= n) return;
-    const uint32_t key = slot_keys[pos], idx = slots[pos];
-    const int64_t c = (int64_t)(key >> shift);
+    const unsigned long long mine = slots[pos];                 // (key, index): a strict total order
+    const int64_t c = (int64_t)(mine >> (32 + shift));
     int64_t s = offsets[c], e = c + 1 < cells ? (int64_t)offsets[c + 1] : n;
     if (e - s > kExactCell) {                      // a clump: aligned pieces of kExactCell slots, each ranked by itself
         const int64_t lo = pos / kExactCell * kExactCell;
         s = max(s, lo); e = min(e, lo + kExactCell);
     }
-    const unsigned long long mine = ((unsigned long long)key << 32) | idx;      // (key, index): a strict total order
     int rank = 0;
-    for (int64_t j = s; j < e; ++j) {
-        const unsigned long long other = ((unsigned long long)slot_keys[j] << 32) | slots[j];
-        rank += other < mine ? 1 : 0;
-    }
-    order[s + rank] = idx;
+    for (int64_t j = s; j < e; ++j) rank += slots[j] < mine ? 1 : 0;
+    order[s + rank] = (uint32_t)mine;
 }
 
 int64_t order_workspace_bytes(int64_t n)
 {
     if (n <= 0) return 0;
-    // keys | ranks | order | slots | slot keys | cell counters + scan scratch
+    // keys | ranks | order | slots (8-byte (key, index) words: two segments) | cell counters + scan scratch
     return (int64_t)(5 * align_up((size_t)n * 4, 256) + (size_t)kCells * 4 + (size_t)scan_scratch_bytes(kCells) + 256);
 }
 
@@ -167,8 +166,8 @@ hipError_t build_point_order(const float *pts, int64_t n, void *workspace, int64
     const size_t seg = align_up((size_t)n * 4, 256);
     unsigned char *base = static_cast<unsigned char *>(workspace);
     uint32_t *keys = reinterpret_cast<uint32_t *>(base), *ranks = reinterpret_cast<uint32_t *>(base + seg);
-    uint32_t *order = reinterpret_cast<uint32_t *>(base + 2 * seg), *slots = reinterpret_cast<uint32_t *>(base + 3 * seg);
-    uint32_t *slot_keys = reinterpret_cast<uint32_t *>(base + 4 * seg);
+    uint32_t *order = reinterpret_cast<uint32_t *>(base + 2 * seg);
+    unsigned long long *slots = reinterpret_cast<unsigned long long *>(base + 3 * seg);      // n 8-byte words: segments 3 and 4
     uint32_t *table = reinterpret_cast<uint32_t *>(base + 5 * seg);
     void *scan_scratch = base + 5 * seg + (size_t)kCells * 4;
     const unsigned nb = (unsigned)((n + kBlock - 1) / kBlock);
@@ -190,8 +189,8 @@ hipError_t build_point_order(const float *pts, int64_t n, void *workspace, int64
     hipError_t e = (n < (1LL << 30) && !(curve & 2)) ? launch_exclusive_scan_lookback_u32(table, table, cells, status, stream)
                                    : launch_exclusive_scan_u32(table, table, cells, scan_scratch, stream);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(scatter_kernel, dim3(nb), dim3(kBlock), 0, stream, keys, ranks, n, table, slots, slot_keys, shift);
-    hipLaunchKernelGGL(cell_rank_kernel, dim3(nb), dim3(kBlock), 0, stream, slot_keys, slots, n, table, cells, shift, order);
+    hipLaunchKernelGGL(scatter_kernel, dim3(nb), dim3(kBlock), 0, stream, keys, ranks, n, table, slots, shift);
+    hipLaunchKernelGGL(cell_rank_kernel, dim3(nb), dim3(kBlock), 0, stream, slots, n, table, cells, shift, order);
     e = hipGetLastError();
     if (e != hipSuccess) return e;
     // the finished order always sits in the same place, so that a later call can find it again (D3F_FLAG_REUSE_POINT_ORDER)

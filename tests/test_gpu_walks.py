@@ -584,6 +584,76 @@ def test_fp16_stored_maps_take_the_window_and_sliced_kernels(dev, kind, V, hw, f
     assert rel_err(cpu(a["dino_feats"])[pick], ref["sets"][0]) <= TOL
 
 
+def _hilbert27(q):
+    """numpy restatement of order_kernels.hip:hilbert27 (Skilling's transpose form, 9 bits per axis, axis 0 the most significant
+    bit of every digit) for the ordering test below"""
+    X = [(q[:, k] & 511).astype(np.int64).copy() for k in range(3)]
+    Q = 256
+    while Q > 1:
+        P = Q - 1
+        for i in range(3):
+            hit = (X[i] & Q) != 0
+            X[0] = np.where(hit, X[0] ^ P, X[0])
+            t = np.where(hit, 0, (X[0] ^ X[i]) & P)
+            X[0] ^= t
+            X[i] ^= t
+        Q >>= 1
+    X[1] ^= X[0]; X[2] ^= X[1]
+    t = np.zeros_like(X[0])
+    Q = 256
+    while Q > 1:
+        t = np.where((X[2] & Q) != 0, t ^ (Q - 1), t)
+        Q >>= 1
+    for i in range(3):
+        X[i] ^= t
+    key = np.zeros_like(X[0])
+    for b in range(8, -1, -1):
+        for i in range(3):
+            key = (key << 1) | ((X[i] >> b) & 1)
+    return key
+
+
+@pytest.mark.parametrize("n,scale", [(70001, 1.0), (300001, 0.6), (1000003, 1.0)])
+def test_point_order_is_the_exact_hilbert_order(dev, n, scale):
+    """The order d3f_eval builds for a cloud (order_kernels.hip: counting sort by a prefix of the 27-bit Hilbert key of the 4-mm cell
+    + exact rank inside the counting cell) is a permutation and equals numpy's lexsort by (key, index) -- consecutive cells of the
+    curve share a face at every level, which is what makes any 64 consecutive points a compact tile; a clump of > 256 points in one
+    counting cell and NaN coordinates keep it a permutation."""
+    from d3fields_amd import synth
+    V, H, W = 4, 96, 128
+    f, sc = fusion_for(dev, V, H, W, {"dino_feats": synth.random_map(V, 12, 16, 128, seed=1, device=dev)})
+    pts_c = synth.random_cloud(n, seed=11) * scale
+    pts_c[5000:5600] = pts_c[5000] + 1e-4 * torch.rand(600, 3)             # a clump: > 256 points in one 4-mm cell
+    pts = pts_c.to(dev)
+    with torch.no_grad():
+        f.batch_eval(pts, return_names=["dino_feats"])
+    torch.cuda.synchronize()
+    seg = (n * 4 + 255) // 256 * 256
+    order = f._last_ws[2 * seg:2 * seg + 4 * n].view(torch.int32).cpu().numpy().astype(np.int64)
+    assert np.array_equal(np.sort(order), np.arange(n)), "the order is not a permutation"
+    q = np.floor(pts_c.numpy().astype(np.float32) * np.float32(1.0 / np.float32(0.004))).astype(np.int64)
+    key = _hilbert27(q)
+    bits = 15
+    while bits < 21 and (1 << bits) < 4 * n:
+        bits += 1
+    cell = key >> (27 - bits)                                               # the counting cell (16 mm at 1 M points)
+    clump = cell == cell[5000]                                              # > 256 points: ranked in aligned pieces of 256 slots
+    assert clump.sum() > 256
+    assert (np.diff(cell[order]) >= 0).all(), "counting cells are not ascending along the order"
+    # exact (key, index) order everywhere but inside the clump's cell
+    want = np.lexsort((np.arange(n), key))
+    assert np.array_equal(order[~clump[order]], want[~clump[want]])
+    # the curve is continuous: consecutive occupied 4-mm cells of the order are close (a Z curve jumps by whole octants)
+    step = np.abs(np.diff(q[order], axis=0)).max(axis=1)
+    assert np.percentile(step, 99.9) <= (12 if n >= 300000 else 40), np.percentile(step, 99.9)
+    bad = pts_c.clone(); bad[7, 0] = float("nan"); bad[9, 2] = float("inf")
+    with torch.no_grad():
+        f.batch_eval(bad.to(dev), return_names=["dino_feats"])
+    torch.cuda.synchronize()
+    order = f._last_ws[2 * seg:2 * seg + 4 * n].view(torch.int32).cpu().numpy().astype(np.int64)
+    assert np.array_equal(np.sort(order), np.arange(n))
+
+
 def test_window_kernel_with_wrong_lattice_dims_is_still_exact(dev):
     """d3f_eval_lattice promises that ANY dims whose product is n are correct.  The window kernel estimates its texel
     windows from the eight 'corner' slots of a brick -- meaningless for a cloud or a shuffled grid passed with made-up
