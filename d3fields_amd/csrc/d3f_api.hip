@@ -237,9 +237,9 @@ int eval_common(const d3f_views *views, const float *pts, int64_t n, const d3f_c
         if (flags & D3F_FLAG_REUSE_POINT_ORDER) {
             P.order = d3f::stored_point_order(workspace, n);       // written by an earlier call for the same points
         } else {
-            // Hilbert order of the 4-mm cells, exact (order_kernels.hip); experiments builds: D3F_EXP_ORDER_MORTON=1 = the Z curve of rounds 1-4
+            // Hilbert order of the cells of a 512^3 grid over the cloud's box, exact (order_kernels.hip); experiments builds: D3F_EXP_ORDER_MORTON=1 = the Z curve of rounds 1-4
             hipError_t eo = d3f::build_point_order(pts, n, workspace, workspace_bytes, &P.order, hs,
-                                                   (exp_knob("D3F_EXP_ORDER_MORTON") > 0 ? 1 : 0) | (exp_knob("D3F_EXP_SCAN3") > 0 ? 2 : 0));
+                                                   (exp_knob("D3F_EXP_ORDER_MORTON") > 0 ? 1 : 0) | (exp_knob("D3F_EXP_SCAN3") > 0 ? 2 : 0) | (exp_knob("D3F_EXP_ORDER_FIXED_GRID") > 0 ? 4 : 0));
             if (eo != hipSuccess) return hip_fail(eo, "point ordering");
         }
     }

@@ -18,17 +18,18 @@
 // Hand-written since round 2 (round 1 sorted (key, index) pairs with rocPRIM's Onesweep radix sort: histogram +
 // 3-4 digit passes + 7 memset launches = 0.12-0.16 ms per 1 M points).  A counting sort by cell plus an exact rank inside the
 // cell gives the total order of the keys:
-//   1. cell_count_kernel     27-bit Hilbert key of the 4-mm cell of every point (Skilling's transpose form; kept for step 4)
-//                            and a histogram of a 15..21-bit prefix = the counting cell (16 mm at 1 M points; counters in
-//                            caller scratch, cleared by order_clear_kernel); the returning atomic also gives the point its
+//   0. order_bbox_kernel     the box of the finite points (round 5, below): the 512^3 key grid is laid over it
+//   1. cell_count_kernel     27-bit Hilbert key of the grid cell of every point (Skilling's transpose form; kept for step 4)
+//                            and a histogram of a 15..21-bit prefix = the counting cell (4^3 key cells at 1 M points; counters
+//                            in caller scratch, cleared by order_clear_kernel); the returning atomic also gives the point its
 //                            arrival rank inside the cell -- the only atomic per point
 //   2. exclusive scan of the counters (scan_kernels.hip: ONE launch, chained scan with decoupled look-back; rounds 2-4: three)
 //   3. scatter_kernel        index i and its key go to slot offset[cell] + rank -- cells in curve order, arrival order inside
-//   4. cell_rank_kernel      every slot counts the (key, index) pairs of ITS cell that sort before its own (a cell is ~30
+//   4. cell_rank_kernel      every slot counts the (key, index) pairs of ITS cell that sort before its own (a cell is a few
 //                            consecutive slots: L1 hits) and moves to that place: the exact order of the full key, ties by
 //                            index.  A cell of more than 256 points (a dense clump) is ranked in aligned pieces of 256 slots.
-// Five launches (seven up to round 4); 1 M points: 0.15 ms, of which the returning atomics are 0.065 -- they serialise on the ~33
-// points of an occupied 16-mm cell.  Measured and not kept (round 5, scripts/notebook/gpu_sessions/r5_gpu20-22.sh): fewer
+// Six launches (seven up to round 4); 1 M points: 0.11 ms (kernel time; 0.135 with the fixed 4-mm key grid this round began
+// with, whose returning atomics serialised on the ~33 points of an occupied 16-mm cell).  Measured and not kept (round 5, scripts/notebook/gpu_sessions/r5_gpu20-22.sh): fewer
 // counters (2^19 / 2^18: the atomics 130 us, the rank loops 72-110 us); counters private to an XCD (eight planes indexed by the
 // hardware XCC id, workgroup-scope atomics: no faster -- the limit is not coherence traffic -- and 3 bits of cell resolution
 // lost: 32-mm cells of ~266 points exceed the exact-rank window).  The result is a deterministic function of the points (the arrival order does not survive step 4 in
@@ -75,34 +76,109 @@ __device__ __forceinline__ uint32_t hilbert27(uint32_t x, uint32_t y, uint32_t z
     return (spread3(X[0]) << 2) | (spread3(X[1]) << 1) | spread3(X[2]);
 }
 
-constexpr float kFineCell = 0.004f;       // 4-mm sub-cells x 512 per axis = 2.05 m before the keys wrap (harmless)
+constexpr float kFineCell = 0.004f;       // the coarsest fine cell: 4 mm x 512 per axis = 2.05 m (wider clouds: fixed grid, keys wrap)
 // 27-bit fine key = key of the counting cell (15 .. 21 bits, chosen per call) << shift | sub-cell
 constexpr int64_t kCells = 1 << 21;
 constexpr int kExactCell = 256;           // cells of more points than this are ranked in aligned pieces of this many slots
 
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
+// ---- the cloud's bounding box (round 5) -----------------------------------------------------------------------------------------
+// The keys of rounds 1-4 quantised the coordinates on a FIXED 4-mm grid of 512^3 cells (2.05 m): a cloud in the reference's
+// 0.8 x 0.7 x 0.22 m workspace occupies 1.4 % of that key space, its ~30 k occupied 16-mm counting cells take ~33 points each,
+// and the returning atomics of those points serialise on their counter (63 us per 1 M points, the largest part of the ordering).
+// Now the grid is laid over the cloud's own box: the longest side is cut into 511 cells (never coarser than 4 mm; a cloud wider
+// than 2.04 m keeps the fixed grid), so the same 2^21 counters resolve 6-mm cells of ~2 points.  The box is the min / max over the
+// FINITE coordinates (|x| < 1e6), kept in six words after the gate as order-preserving unsigned images of the floats.
+__device__ __forceinline__ uint32_t ordered_bits(float f)
+{
+    const uint32_t u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);          // monotone: a < b  <=>  ordered_bits(a) < ordered_bits(b)
+}
+__device__ __forceinline__ float from_ordered_bits(uint32_t u) { return __uint_as_float((u & 0x80000000u) ? (u & 0x7fffffffu) : ~u); }
+
+constexpr int kBoxWord = 8;               // bbox words start at gate[kBoxWord]: lo x y z, hi x y z
+
 __global__ __launch_bounds__(kBlock) void order_clear_kernel(uint32_t *__restrict__ table, uint32_t *__restrict__ gate,
                                                             uint32_t *__restrict__ status, int status_words)
 {
     reinterpret_cast<uint4 *>(table)[(int64_t)blockIdx.x * kBlock + threadIdx.x] = make_uint4(0u, 0u, 0u, 0u);
     if (blockIdx.x == 0 && threadIdx.x < 4) gate[threadIdx.x] = 0u;       // the window / cell-run gate of this order (fuse_eval.hip)
+    if (blockIdx.x == 0 && threadIdx.x >= 8 && threadIdx.x < 14)           // the box: lo = +max, hi = -max
+        gate[kBoxWord + threadIdx.x - 8] = threadIdx.x < 11 ? 0xffffffffu : 0u;
     if (blockIdx.x == 1 || gridDim.x == 1)                                 // the status words of the single-launch scan
         for (int k = threadIdx.x; k < status_words; k += kBlock) status[k] = 0u;
+}
+
+constexpr int kBoxBlock = 1024;          // few, large workgroups: the six same-address atomics per workgroup are what this kernel waits for
+__global__ __launch_bounds__(kBoxBlock) void order_bbox_kernel(const float *__restrict__ pts, int64_t n, uint32_t *__restrict__ box)
+{
+    float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    const int64_t stride = (int64_t)gridDim.x * kBoxBlock;
+    for (int64_t i = (int64_t)blockIdx.x * kBoxBlock + threadIdx.x; i < n; i += 4 * stride) {
+        float x[4][3];                                                     // four points in flight (past the end: the last point again)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int64_t ij = i + j * stride < n ? i + j * stride : n - 1;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) x[j][k] = pts[ij * 3 + k];
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int k = 0; k < 3; ++k)
+                if (fabsf(x[j][k]) < 1e6f) { lo[k] = fminf(lo[k], x[j][k]); hi[k] = fmaxf(hi[k], x[j][k]); }       // false for NaN / Inf
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            lo[k] = fminf(lo[k], __shfl_xor(lo[k], off, 64));
+            hi[k] = fmaxf(hi[k], __shfl_xor(hi[k], off, 64));
+        }
+    // one set of atomics per workgroup: 49 k same-address atomics (one set per wave of 2048 workgroups) took 71 us by themselves
+    __shared__ float part[kBoxBlock / 64][6];
+    if ((threadIdx.x & 63) == 0)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { part[threadIdx.x >> 6][k] = lo[k]; part[threadIdx.x >> 6][3 + k] = hi[k]; }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        const int k = threadIdx.x;
+        float l = part[0][k], h = part[0][3 + k];
+#pragma unroll
+        for (int w = 1; w < kBoxBlock / 64; ++w) { l = fminf(l, part[w][k]); h = fmaxf(h, part[w][3 + k]); }
+        if (l <= h) {                                                       // the workgroup saw a finite coordinate
+            atomicMin(&box[k], ordered_bits(l));
+            atomicMax(&box[3 + k], ordered_bits(h));
+        }
+    }
+}
+
+// origin and cells-per-metre of the key grid, from the box (every lane computes the same values from six uniform loads)
+struct KeyGrid { float ox, oy, oz, inv; };
+__device__ __forceinline__ KeyGrid key_grid(const uint32_t *__restrict__ box)
+{
+    KeyGrid g = {0.0f, 0.0f, 0.0f, 1.0f / kFineCell};                       // the fixed 4-mm grid (keys wrap beyond 2.05 m: harmless)
+    if (!box) return g;
+    const float lx = from_ordered_bits(box[0]), ly = from_ordered_bits(box[1]), lz = from_ordered_bits(box[2]);
+    const float ext = fmaxf(fmaxf(from_ordered_bits(box[3]) - lx, from_ordered_bits(box[4]) - ly), from_ordered_bits(box[5]) - lz);
+    if (ext > 0.0f && ext <= 511.0f * kFineCell) { g.ox = lx; g.oy = ly; g.oz = lz; g.inv = 511.0f / ext; }    // false for NaN (no finite point)
+    return g;
 }
 
 // MORTON: the Z-curve keys of rounds 1-4 (experiments builds keep them for same-box comparisons)
 template <bool MORTON>
 __global__ __launch_bounds__(kBlock) void cell_count_kernel(const float *__restrict__ pts, int64_t n, uint32_t *__restrict__ keys,
-                                                           uint32_t *__restrict__ ranks, uint32_t *__restrict__ table, int shift)
+                                                           uint32_t *__restrict__ ranks, uint32_t *__restrict__ table, int shift,
+                                                           const uint32_t *__restrict__ box)
 {
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (i >= n) return;
-    const float inv = 1.0f / kFineCell;
+    const KeyGrid g = key_grid(box);
     // non-finite / huge coordinates just land in some cell: only locality is at stake
-    const int qx = (int)fminf(fmaxf(floorf(pts[i * 3 + 0] * inv), -1e9f), 1e9f);
-    const int qy = (int)fminf(fmaxf(floorf(pts[i * 3 + 1] * inv), -1e9f), 1e9f);
-    const int qz = (int)fminf(fmaxf(floorf(pts[i * 3 + 2] * inv), -1e9f), 1e9f);
+    const int qx = (int)fminf(fmaxf(floorf((pts[i * 3 + 0] - g.ox) * g.inv), -1e9f), 1e9f);
+    const int qy = (int)fminf(fmaxf(floorf((pts[i * 3 + 1] - g.oy) * g.inv), -1e9f), 1e9f);
+    const int qz = (int)fminf(fmaxf(floorf((pts[i * 3 + 2] - g.oz) * g.inv), -1e9f), 1e9f);
     const uint32_t key = MORTON ? (spread3((uint32_t)qx & 511u) | (spread3((uint32_t)qy & 511u) << 1) | (spread3((uint32_t)qz & 511u) << 2))
                                 : hilbert27((uint32_t)qx, (uint32_t)qy, (uint32_t)qz);
     keys[i] = key;
@@ -157,7 +233,8 @@ uint32_t *order_gate_words(void *workspace, int64_t n)
 }
 
 // Fills *order_out with a pointer (inside the workspace) to n uint32 indices in Hilbert-cell order.
-// curve: 0 = Hilbert (the product's); experiments builds: bit 0 = Morton (the order of rounds 1-4), bit 1 = the three-launch scan
+// curve: 0 = Hilbert (the product's); experiments builds: bit 0 = Morton (the order of rounds 1-4), bit 1 = the three-launch scan,
+// bit 2 = the fixed 4-mm key grid instead of the one laid over the cloud's box
 hipError_t build_point_order(const float *pts, int64_t n, void *workspace, int64_t workspace_bytes,
                              const uint32_t **order_out, hipStream_t stream, int curve)
 {
@@ -183,8 +260,15 @@ hipError_t build_point_order(const float *pts, int64_t n, void *workspace, int64
     const int status_words = (int)scan_status_words(cells);
     hipLaunchKernelGGL(order_clear_kernel, dim3((unsigned)(cells / 4 / kBlock)), dim3(kBlock), 0, stream, table, order_gate_words(workspace, n),
                        status, status_words);
-    if (curve & 1) hipLaunchKernelGGL(cell_count_kernel<true>, dim3(nb), dim3(kBlock), 0, stream, pts, n, keys, ranks, table, shift);
-    else hipLaunchKernelGGL(cell_count_kernel<false>, dim3(nb), dim3(kBlock), 0, stream, pts, n, keys, ranks, table, shift);
+    // the cloud's box, then keys on a grid laid over it (experiments builds: bit 2 = the fixed 4-mm grid of rounds 1-4)
+    uint32_t *box = (curve & 5) ? nullptr : order_gate_words(workspace, n) + kBoxWord;
+    if (box) {
+        unsigned bb = (unsigned)((n + (int64_t)kBoxBlock * 8 - 1) / ((int64_t)kBoxBlock * 8));
+        if (bb > 128u) bb = 128u;
+        hipLaunchKernelGGL(order_bbox_kernel, dim3(bb), dim3(kBoxBlock), 0, stream, pts, n, box);
+    }
+    if (curve & 1) hipLaunchKernelGGL(cell_count_kernel<true>, dim3(nb), dim3(kBlock), 0, stream, pts, n, keys, ranks, table, shift, box);
+    else hipLaunchKernelGGL(cell_count_kernel<false>, dim3(nb), dim3(kBlock), 0, stream, pts, n, keys, ranks, table, shift, box);
     // n < 2^31 points: the counts sum to n; the look-back scan carries 30-bit values -- above 2^30 points the recursive scan
     hipError_t e = (n < (1LL << 30) && !(curve & 2)) ? launch_exclusive_scan_lookback_u32(table, table, cells, status, stream)
                                    : launch_exclusive_scan_u32(table, table, cells, scan_scratch, stream);

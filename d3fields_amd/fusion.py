@@ -553,7 +553,7 @@ class Fusion:
             s0 = [s for s in range(n_maps) if plan.staged[s] >= 16][0]
             kernel = "fused_eval_runs_kernel<0, %d, %d, %d>" % (plan.vectors_per_lane[s0], plan.staged[s0] - 16, plan.reserved)
         sliced = 100 <= plan.reserved < 200
-        order = {2: "closed-form brick walk of the lattice (no keys, no sort)", 1: "Hilbert-cell order (counting sort by 16-mm cell + exact rank of the 4-mm keys inside, hand-written)",
+        order = {2: "closed-form brick walk of the lattice (no keys, no sort)", 1: "Hilbert-cell order (512^3 key grid over the cloud's box, counting sort by a key prefix + exact rank inside, hand-written)",
                  0: "caller order"}[int(plan.reorder)]
         order += "; channel-sliced over the XCDs" if sliced else ""
         if window:

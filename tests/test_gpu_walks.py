@@ -615,15 +615,15 @@ def _hilbert27(q):
 
 @pytest.mark.parametrize("n,scale", [(70001, 1.0), (300001, 0.6), (1000003, 1.0)])
 def test_point_order_is_the_exact_hilbert_order(dev, n, scale):
-    """The order d3f_eval builds for a cloud (order_kernels.hip: counting sort by a prefix of the 27-bit Hilbert key of the 4-mm cell
-    + exact rank inside the counting cell) is a permutation and equals numpy's lexsort by (key, index) -- consecutive cells of the
+    """The order d3f_eval builds for a cloud (order_kernels.hip: counting sort by a prefix of the 27-bit Hilbert key of the
+    point's cell on a 512^3 grid over the cloud's box + exact rank inside the counting cell) is a permutation and equals numpy's lexsort by (key, index) -- consecutive cells of the
     curve share a face at every level, which is what makes any 64 consecutive points a compact tile; a clump of > 256 points in one
     counting cell and NaN coordinates keep it a permutation."""
     from d3fields_amd import synth
     V, H, W = 4, 96, 128
     f, sc = fusion_for(dev, V, H, W, {"dino_feats": synth.random_map(V, 12, 16, 128, seed=1, device=dev)})
     pts_c = synth.random_cloud(n, seed=11) * scale
-    pts_c[5000:5600] = pts_c[5000] + 1e-4 * torch.rand(600, 3)             # a clump: > 256 points in one 4-mm cell
+    pts_c[5000:6200] = pts_c[5000] + 1e-4 * torch.rand(1200, 3)            # a clump: > 256 points in one counting cell
     pts = pts_c.to(dev)
     with torch.no_grad():
         f.batch_eval(pts, return_names=["dino_feats"])
@@ -631,21 +631,29 @@ def test_point_order_is_the_exact_hilbert_order(dev, n, scale):
     seg = (n * 4 + 255) // 256 * 256
     order = f._last_ws[2 * seg:2 * seg + 4 * n].view(torch.int32).cpu().numpy().astype(np.int64)
     assert np.array_equal(np.sort(order), np.arange(n)), "the order is not a permutation"
-    q = np.floor(pts_c.numpy().astype(np.float32) * np.float32(1.0 / np.float32(0.004))).astype(np.int64)
+    # the key grid is laid over the cloud's own box: 511 cells along its longest side (order_kernels.hip:key_grid), fp32 as the device
+    p32 = pts_c.numpy().astype(np.float32)
+    lo = p32.min(axis=0)
+    ext = np.float32((p32.max(axis=0) - lo).max())
+    assert 0 < ext <= np.float32(511.0) * np.float32(0.004)
+    inv = np.float32(511.0) / ext
+    q = np.floor((p32 - lo) * inv).astype(np.int64)
+    assert q.min() == 0 and 510 <= q.max() <= 511
     key = _hilbert27(q)
     bits = 15
     while bits < 21 and (1 << bits) < 4 * n:
         bits += 1
-    cell = key >> (27 - bits)                                               # the counting cell (16 mm at 1 M points)
-    clump = cell == cell[5000]                                              # > 256 points: ranked in aligned pieces of 256 slots
-    assert clump.sum() > 256
+    cell = key >> (27 - bits)                                               # the counting cell (4^3 key cells at 1 M points)
+    _, inverse, counts = np.unique(cell, return_inverse=True, return_counts=True)
+    clump = counts[inverse] > 256                                           # > 256 points: ranked in aligned pieces of 256 slots
+    assert clump[5000:6200].sum() > 256
     assert (np.diff(cell[order]) >= 0).all(), "counting cells are not ascending along the order"
     # exact (key, index) order everywhere but inside the clump's cell
     want = np.lexsort((np.arange(n), key))
     assert np.array_equal(order[~clump[order]], want[~clump[want]])
-    # the curve is continuous: consecutive occupied 4-mm cells of the order are close (a Z curve jumps by whole octants)
-    step = np.abs(np.diff(q[order], axis=0)).max(axis=1)
-    assert np.percentile(step, 99.9) <= (12 if n >= 300000 else 40), np.percentile(step, 99.9)
+    # the curve is continuous: consecutive points of the order are close (a Z curve jumps by whole octants)
+    step = np.abs(np.diff(q[order], axis=0)).max(axis=1) / float(inv)       # metres
+    assert np.percentile(step, 99.9) <= (0.048 if n >= 300000 else 0.16), np.percentile(step, 99.9)
     bad = pts_c.clone(); bad[7, 0] = float("nan"); bad[9, 2] = float("inf")
     with torch.no_grad():
         f.batch_eval(bad.to(dev), return_names=["dino_feats"])
