@@ -239,7 +239,7 @@ int eval_common(const d3f_views *views, const float *pts, int64_t n, const d3f_c
         } else {
             // Hilbert order of the cells of a 512^3 grid over the cloud's box, exact (order_kernels.hip); experiments builds: D3F_EXP_ORDER_MORTON=1 = the Z curve of rounds 1-4
             hipError_t eo = d3f::build_point_order(pts, n, workspace, workspace_bytes, &P.order, hs,
-                                                   (exp_knob("D3F_EXP_ORDER_MORTON") > 0 ? 1 : 0) | (exp_knob("D3F_EXP_SCAN3") > 0 ? 2 : 0) | (exp_knob("D3F_EXP_ORDER_FIXED_GRID") > 0 ? 4 : 0));
+                                                   (exp_knob("D3F_EXP_ORDER_MORTON") > 0 ? 1 : 0) | (exp_knob("D3F_EXP_SCAN3") > 0 ? 2 : 0) | (exp_knob("D3F_EXP_ORDER_FIXED_GRID") > 0 ? 4 : 0) | (exp_knob("D3F_EXP_ORDER_BITS") > 0 ? exp_knob("D3F_EXP_ORDER_BITS") << 8 : 0));
             if (eo != hipSuccess) return hip_fail(eo, "point ordering");
         }
     }

@@ -20,7 +20,7 @@
 // cell gives the total order of the keys:
 //   0. order_bbox_kernel     the box of the finite points (round 5, below): the 512^3 key grid is laid over it
 //   1. cell_count_kernel     27-bit Hilbert key of the grid cell of every point (Skilling's transpose form; kept for step 4)
-//                            and a histogram of a 15..21-bit prefix = the counting cell (4^3 key cells at 1 M points; counters
+//                            and a histogram of a 15..20-bit prefix = the counting cell (~4 x 4 x 8 key cells at 1 M points; counters
 //                            in caller scratch, cleared by order_clear_kernel); the returning atomic also gives the point its
 //                            arrival rank inside the cell -- the only atomic per point
 //   2. exclusive scan of the counters (scan_kernels.hip: ONE launch, chained scan with decoupled look-back; rounds 2-4: three)
@@ -77,7 +77,7 @@ __device__ __forceinline__ uint32_t hilbert27(uint32_t x, uint32_t y, uint32_t z
 }
 
 constexpr float kFineCell = 0.004f;       // the coarsest fine cell: 4 mm x 512 per axis = 2.05 m (wider clouds: fixed grid, keys wrap)
-// 27-bit fine key = key of the counting cell (15 .. 21 bits, chosen per call) << shift | sub-cell
+// 27-bit fine key = key of the counting cell (15 .. 20 bits, chosen per call; the scratch is sized for 21) << shift | sub-cell
 constexpr int64_t kCells = 1 << 21;
 constexpr int kExactCell = 256;           // cells of more points than this are ranked in aligned pieces of this many slots
 
@@ -88,7 +88,7 @@ static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; 
 // 0.8 x 0.7 x 0.22 m workspace occupies 1.4 % of that key space, its ~30 k occupied 16-mm counting cells take ~33 points each,
 // and the returning atomics of those points serialise on their counter (63 us per 1 M points, the largest part of the ordering).
 // Now the grid is laid over the cloud's own box: the longest side is cut into 511 cells (never coarser than 4 mm; a cloud wider
-// than 2.04 m keeps the fixed grid), so the same 2^21 counters resolve 6-mm cells of ~2 points.  The box is the min / max over the
+// than 2.04 m keeps the fixed grid), so 2^20 counters resolve ~6 x 6 x 12-mm cells of ~4 points.  The box is the min / max over the
 // FINITE coordinates (|x| < 1e6), kept in six words after the gate as order-preserving unsigned images of the floats.
 __device__ __forceinline__ uint32_t ordered_bits(float f)
 {
@@ -167,6 +167,8 @@ __device__ __forceinline__ KeyGrid key_grid(const uint32_t *__restrict__ box)
 }
 
 // MORTON: the Z-curve keys of rounds 1-4 (experiments builds keep them for same-box comparisons)
+// (four points per lane -- all loads, then all returning atomics in flight together -- changes nothing: 47 vs 47 us per 1 M points,
+// session 27.  The kernel runs at the rate the L2s retire returning atomics, ~21 G/s.)
 template <bool MORTON>
 __global__ __launch_bounds__(kBlock) void cell_count_kernel(const float *__restrict__ pts, int64_t n, uint32_t *__restrict__ keys,
                                                            uint32_t *__restrict__ ranks, uint32_t *__restrict__ table, int shift,
@@ -248,11 +250,12 @@ hipError_t build_point_order(const float *pts, int64_t n, void *workspace, int64
     uint32_t *table = reinterpret_cast<uint32_t *>(base + 5 * seg);
     void *scan_scratch = base + 5 * seg + (size_t)kCells * 4;
     const unsigned nb = (unsigned)((n + kBlock - 1) / kBlock);
-    // counters: >= 4 per point (any prefix of the key is a valid coarser cell of the curve), 2^15 .. 2^21: 16-mm cells
-    // for 1 M points, 16 x 32 x 32 mm for 100 k -- and clearing + scanning the table stops dominating small batches
-    // (fewer counters than that and the atomics start to collide: 2.6 per point measured 7 -> 14 us at 100 k points)
+    // counters: >= 2 per point (any prefix of the key is a valid coarser cell of the curve), 2^15 .. 2^20 -- clearing and scanning
+    // the table must not dominate small batches, and with the grid laid over the cloud's box 2 per point already leave ~4 points
+    // per occupied cell (rounds 2-4, fixed grid: 4 per point, fewer and the atomics collided)
     int bits = 15;
-    while (bits < 21 && (1LL << bits) < 4 * n) bits += 1;
+    while (bits < 20 && (1LL << bits) < 2 * n) bits += 1;      // 2 counters per point, at most 2^20 (session 26: 2^21 only lengthens the scan)
+    if ((curve >> 8) >= 15 && (curve >> 8) <= 21) bits = curve >> 8;      // experiments builds only
     const int shift = 27 - bits;
     const int64_t cells = 1LL << bits;
     // (the scan scratch is sized for the recursive three-launch scan of 2^21 counters: 1024 + 1 words and more)

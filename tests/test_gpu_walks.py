@@ -641,7 +641,7 @@ def test_point_order_is_the_exact_hilbert_order(dev, n, scale):
     assert q.min() == 0 and 510 <= q.max() <= 511
     key = _hilbert27(q)
     bits = 15
-    while bits < 21 and (1 << bits) < 4 * n:
+    while bits < 20 and (1 << bits) < 2 * n:
         bits += 1
     cell = key >> (27 - bits)                                               # the counting cell (4^3 key cells at 1 M points)
     _, inverse, counts = np.unique(cell, return_inverse=True, return_counts=True)
