@@ -613,12 +613,12 @@ def _hilbert27(q):
     return key
 
 
-@pytest.mark.parametrize("n,scale", [(70001, 1.0), (300001, 0.6), (1000003, 1.0)])
+@pytest.mark.parametrize("n,scale", [(70001, 1.0), (300001, 0.6), (1000003, 1.0), (300001, 3.5)])
 def test_point_order_is_the_exact_hilbert_order(dev, n, scale):
     """The order d3f_eval builds for a cloud (order_kernels.hip: counting sort by a prefix of the 27-bit Hilbert key of the
     point's cell on a 512^3 grid over the cloud's box + exact rank inside the counting cell) is a permutation and equals numpy's lexsort by (key, index) -- consecutive cells of the
     curve share a face at every level, which is what makes any 64 consecutive points a compact tile; a clump of > 256 points in one
-    counting cell and NaN coordinates keep it a permutation."""
+    counting cell and NaN coordinates keep it a permutation; a cloud wider than 2.04 m falls back to the fixed 4-mm grid."""
     from d3fields_amd import synth
     V, H, W = 4, 96, 128
     f, sc = fusion_for(dev, V, H, W, {"dino_feats": synth.random_map(V, 12, 16, 128, seed=1, device=dev)})
@@ -635,10 +635,15 @@ def test_point_order_is_the_exact_hilbert_order(dev, n, scale):
     p32 = pts_c.numpy().astype(np.float32)
     lo = p32.min(axis=0)
     ext = np.float32((p32.max(axis=0) - lo).max())
-    assert 0 < ext <= np.float32(511.0) * np.float32(0.004)
-    inv = np.float32(511.0) / ext
-    q = np.floor((p32 - lo) * inv).astype(np.int64)
-    assert q.min() == 0 and 510 <= q.max() <= 511
+    boxed = bool(ext <= np.float32(511.0) * np.float32(0.004))
+    assert boxed == (scale < 3), ext
+    if boxed:
+        inv = np.float32(511.0) / ext
+        q = np.floor((p32 - lo) * inv).astype(np.int64)
+        assert q.min() == 0 and 510 <= q.max() <= 511
+    else:                                               # wider than 2.04 m: the fixed 4-mm grid at the origin, keys wrap every 2.048 m
+        inv = np.float32(1.0 / np.float32(0.004))
+        q = np.floor(p32 * inv).astype(np.int64)
     key = _hilbert27(q)
     bits = 15
     while bits < 20 and (1 << bits) < 2 * n:
@@ -653,13 +658,34 @@ def test_point_order_is_the_exact_hilbert_order(dev, n, scale):
     assert np.array_equal(order[~clump[order]], want[~clump[want]])
     # the curve is continuous: consecutive points of the order are close (a Z curve jumps by whole octants)
     step = np.abs(np.diff(q[order], axis=0)).max(axis=1) / float(inv)       # metres
-    assert np.percentile(step, 99.9) <= (0.048 if n >= 300000 else 0.16), np.percentile(step, 99.9)
+    assert not boxed or np.percentile(step, 99.9) <= (0.048 if n >= 300000 else 0.16), np.percentile(step, 99.9)
     bad = pts_c.clone(); bad[7, 0] = float("nan"); bad[9, 2] = float("inf")
     with torch.no_grad():
         f.batch_eval(bad.to(dev), return_names=["dino_feats"])
     torch.cuda.synchronize()
     order = f._last_ws[2 * seg:2 * seg + 4 * n].view(torch.int32).cpu().numpy().astype(np.int64)
     assert np.array_equal(np.sort(order), np.arange(n))
+
+
+def test_point_order_of_a_degenerate_cloud(dev):
+    """Every point the same (a box of zero extent: the key grid falls back to the fixed one, all points share one counting cell and are
+    ranked in pieces of 256) and a cloud without one finite coordinate: the order stays a permutation, the outputs are per point."""
+    from d3fields_amd import synth
+    V, H, W, n = 4, 96, 128, 100003
+    f, sc = fusion_for(dev, V, H, W, {"dino_feats": synth.random_map(V, 12, 16, 128, seed=1, device=dev)})
+    f.tuning_flags |= (1 << 14)                                             # D3F_TUNE_FORCE_REORDER: small maps would not be reordered
+    seg = (n * 4 + 255) // 256 * 256
+    one = synth.random_cloud(8, seed=5)[3:4]
+    for pts_c in (one.repeat(n, 1), torch.full((n, 3), float("nan")), torch.full((n, 3), float("inf"))):
+        with torch.no_grad():
+            out = f.batch_eval(pts_c.to(dev), return_names=["dino_feats"])
+        torch.cuda.synchronize()
+        order = f._last_ws[2 * seg:2 * seg + 4 * n].view(torch.int32).cpu().numpy().astype(np.int64)
+        assert np.array_equal(np.sort(order), np.arange(n)), "the order is not a permutation"
+        assert torch.equal(out["dist"], out["dist"][:1].expand(n)) or bool(torch.isnan(out["dist"]).all())
+        if torch.isfinite(pts_c).all():
+            assert torch.equal(out["dino_feats"], out["dino_feats"][:1].expand(n, -1))
+            assert bool(out["valid_mask"].all()) or not bool(out["valid_mask"].any())
 
 
 def test_window_kernel_with_wrong_lattice_dims_is_still_exact(dev):
