@@ -65,6 +65,27 @@ def test_directed_shape_against_oracle(dev, k):
     _run(dev, dict(DIRECTED[k], seed=100 + k), 100 + k)
 
 
+def _cloud_case(seed):
+    """Clouds large enough for the gated window / cell-run pair of launches (>= 262 144 points, round 5): patch-resolution wide map,
+    1 ... 8 views, the cloud's density drawn so that the device-side gate lands on either side."""
+    r = np.random.default_rng(3000 + seed)
+    V = int(r.choice([1, 2, 3, 4, 4, 6, 8]))
+    H, W = [(120, 160), (240, 320), (480, 640)][int(r.integers(0, 3))]
+    C = int(r.choice([128, 256, 384, 1024]))
+    NI = int(r.choice([0, 0, 8]))
+    color = bool(r.integers(0, 3) == 0)
+    n = int(r.integers(262144, 420000))
+    scale = float(r.choice([0.25, 0.5, 1.0, 1.0, 2.0]))                 # dense clouds fit the pool, sparse ones go to the cell runs
+    view = (int(r.choice([0, 4])), int(r.choice([0, 32]))) if r.integers(0, 4) == 0 else None
+    return dict(V=V, H=H, W=W, C=C, fhw=(max(H // 10, 2), max(W // 10, 2)), NI=NI, color=color, lattice=False,
+                kind="smooth" if r.integers(0, 4) else "stress", view=view, cloud_n=n, cloud_scale=scale, seed=seed)
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_seeded_large_cloud_against_oracle(dev, seed):
+    _run(dev, _cloud_case(seed), 200 + seed)
+
+
 def _run(dev, c, seed):
     from d3fields_amd import Fusion, create_init_grid, synth
     from oracle import c_oracle as O
@@ -96,7 +117,7 @@ def _run(dev, c, seed):
         pts_c = create_init_grid(box, step)[0]
         assert pts_c.shape[0] == dims[0] * dims[1] * dims[2]
     else:
-        pts_c = synth.random_cloud(70001, seed=seed)
+        pts_c = synth.random_cloud(c.get("cloud_n", 70001), seed=seed) * c.get("cloud_scale", 1.0)
     bad = r.integers(0, pts_c.shape[0], 6)
     pts_c[bad[0], 0] = float("inf"); pts_c[bad[1], 1] = float("-inf"); pts_c[bad[2], 2] = float("nan")
     pts_c[bad[3]] = torch.tensor([1e30, -1e30, 1e30]); pts_c[bad[4]] = 0.0; pts_c[bad[5], 2] = 1e-30
