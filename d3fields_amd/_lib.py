@@ -103,6 +103,7 @@ SIGNATURES = {
     "d3f_vox_iou_workspace_bytes": (_i64, [_i64, _i64]),
     "d3f_vox_idx_iou": (ctypes.c_int, [_vp, _i64, _vp, _i64, _vp, _vp, _i64, _vp]),
     "d3f_erode": (ctypes.c_int, [_vp, _i32, _i32, _i32, _i32, _vp, _vp]),
+    "d3f_compose_labels": (ctypes.c_int, [_vp, _i32, _i64, _vp, _vp, _vp]),
     "d3f_voxel_downsample_workspace_bytes": (_i64, [_i64]),
     "d3f_voxel_downsample": (ctypes.c_int, [_vp, _vp, _i64, ctypes.c_double, _vp, _vp, _vp, _vp, _i64, _vp]),
     "d3f_mask_gate": (ctypes.c_int, [_vp, _i64, _i64, _vp, _i32, _i32, _f32, _f32, _vp, _vp]),

@@ -155,6 +155,37 @@ hipError_t launch_erode(const uint8_t *src, int H, int W, int kh, int kw, uint8_
     return hipGetLastError();
 }
 
+// ---- swap_instance_mask (fusion.py:1052-1063): the consensus label image of one view ------------------------------------------
+// The reference paints the view's detections one after the other in instance order (new_mask[mask_gs[i][idx]] = inst_idx), so a
+// pixel ends up with the LARGEST instance index among the detections covering it (0 where none does; the value wraps into uint8
+// as numpy's assignment does).  One lane per four pixels; the n detections are [n, n_pix] uint8 (non-zero = member).
+__global__ __launch_bounds__(kBlock) void compose_labels_kernel(const uint8_t *__restrict__ dets, int n_dets, int64_t n_pix,
+                                                               const int32_t *__restrict__ label_of_det, uint8_t *__restrict__ out)
+{
+    const int64_t p0 = ((int64_t)blockIdx.x * kBlock + threadIdx.x) * 4;
+    if (p0 >= n_pix) return;
+    const int np = (int)min((int64_t)4, n_pix - p0);
+    int best[4] = {0, 0, 0, 0};
+    for (int m = 0; m < n_dets; ++m) {
+        const int lab = label_of_det[m];
+        if (lab < 0) continue;                                   // this detection belongs to no instance
+        const uint8_t *row = dets + (int64_t)m * n_pix + p0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (k < np && row[k] != 0) best[k] = max(best[k], lab);
+    }
+    for (int k = 0; k < np; ++k) out[p0 + k] = (uint8_t)best[k];
+}
+
+hipError_t launch_compose_labels(const uint8_t *dets, int n_dets, int64_t n_pix, const int32_t *label_of_det, uint8_t *out, hipStream_t s)
+{
+    if (n_pix == 0) return hipSuccess;
+    const int64_t lanes = (n_pix + 3) / 4;
+    hipLaunchKernelGGL(compose_labels_kernel, dim3((unsigned)((lanes + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, dets, n_dets, n_pix,
+                       label_of_det, out);
+    return hipGetLastError();
+}
+
 // ---- voxel-grid mean: open3d's PointCloud::VoxelDownSample (utils/draw_utils.py:318-323, 396-400) ------------------------
 // open3d buckets the points into voxels of side `vs` anchored at min_bound - vs/2 (voxel index = floor((p - anchor) / vs))
 // and returns the mean point (and colour) of every occupied voxel, in the order of its hash map.  Here: one open-addressing

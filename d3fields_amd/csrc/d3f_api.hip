@@ -420,6 +420,16 @@ int d3f_erode(const uint8_t *src, int32_t H, int32_t W, int32_t kh, int32_t kw, 
     return e == hipSuccess ? D3F_OK : hip_fail(e, "erode launch");
 }
 
+int d3f_compose_labels(const uint8_t *dets, int32_t n_dets, int64_t n_pix, const int32_t *label_of_det, uint8_t *out, void *stream)
+{
+    if (n_dets < 0 || n_pix < 0 || n_pix > 0x3fffffffLL) return fail(D3F_ERR_BAD_SHAPE, "compose_labels: n_dets=%d n_pix=%lld", n_dets, (long long)n_pix);
+    if (n_pix == 0) return D3F_OK;
+    if (!out || (n_dets > 0 && (!dets || !label_of_det))) return fail(D3F_ERR_INVALID_ARG, "compose_labels: NULL pointer");
+    if (!aligned(label_of_det, 4)) return fail(D3F_ERR_BAD_LAYOUT, "compose_labels: label_of_det must be 4-byte aligned");
+    hipError_t e = d3f::launch_compose_labels(dets, n_dets, n_pix, label_of_det, out, static_cast<hipStream_t>(stream));
+    return e == hipSuccess ? D3F_OK : hip_fail(e, "compose_labels launch");
+}
+
 int64_t d3f_voxel_downsample_workspace_bytes(int64_t n) { return n > 0 ? d3f::voxmean_workspace_bytes(n) : 0; }
 
 int d3f_voxel_downsample(const double *pts, const double *colors, int64_t n, double voxel_size, double *out_pts, double *out_colors,

@@ -144,6 +144,7 @@ int64_t voxmean_workspace_bytes(int64_t n);
 hipError_t launch_voxel_mean(const double *pts, const double *col, int64_t n, double vs, double *out_pts, double *out_col, int64_t *count,
                              void *workspace, hipStream_t s);
 hipError_t launch_erode(const uint8_t *src, int H, int W, int kh, int kw, uint8_t *dst, hipStream_t s);
+hipError_t launch_compose_labels(const uint8_t *dets, int n_dets, int64_t n_pix, const int32_t *label_of_det, uint8_t *out, hipStream_t s);
 hipError_t launch_mask_gate(const float *mask, int64_t sy, int64_t sx, const float *depth, int H, int W, float lo, float hi,
                             uint8_t *out, hipStream_t s);
 hipError_t launch_nonzero_pixels(const uint8_t *img, int H, int W, int64_t capacity, int32_t *out_rc, int64_t *count,

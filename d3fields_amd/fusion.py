@@ -1009,6 +1009,40 @@ class Fusion:
         sel = torch.stack([(g[list(inst_idx_ls)] != 0).any(dim=0) for g in gs], dim=0)
         return self._masked_clouds(sel, list(view_idx_ls), boundaries, downsample)[0]
 
+    # ---- multi-view instance association (reference fusion.py:801-1098; the work: d3fields_amd/association.py) ----------------
+    def merge_instances_from_new_view_vox_ver(self, instances_info, i, boundaries):
+        """Reference fusion.py:801-849: every detection of view i joins the best-overlapping instance of its label (voxel-index IoU
+        > 0.2 on the 3-cm grid align_instance_mask_v3 set up) or founds a new one."""
+        from . import association
+        return association.merge_view(self, instances_info, i, boundaries)
+
+    def del_partial_vox_idx(self, instance_info, vox_idx):
+        """Reference fusion.py:860-868."""
+        from . import association
+        return association.drop_voxels(instance_info, vox_idx)
+
+    def filter_instances_vox_ver(self, instances_info):
+        """Reference fusion.py:978-1040: overlapping instances give their shared voxels to the one that saw them from more views
+        (or with the higher mean confidence); 'table' and emptied instances are removed."""
+        from . import association
+        return association.filter_instances(self, instances_info)
+
+    def reorder_instances(self, instances_info, query_texts):
+        """Reference fusion.py:1042-1050: background first, then the instances in the order of the query texts."""
+        from . import association
+        return association.reorder(instances_info, query_texts)
+
+    def swap_instance_mask(self, instances_info):
+        """Reference fusion.py:1052-1063: curr_obs_torch['mask'] = (V,H,W) uint8 consensus label images (d3f_compose_labels)."""
+        from . import association
+        association.paint_label_images(self, instances_info)
+
+    def align_instance_mask_v3(self, queries, boundaries, expected_labels=None):
+        """Reference fusion.py:1065-1098: from the per-view detections in curr_obs_torch ('mask_gs', 'mask_label', 'mask_conf') to
+        the consensus label images 'mask' and 'consensus_mask_label'."""
+        from . import association
+        association.align(self, queries, boundaries, expected_labels)
+
     def get_query_obj_pcd(self):
         """Reference fusion.py:1301-1311: the cloud of every non-background instance.  The reference returns an open3d
         PointCloud (aggr_point_cloud_from_data's default out_o3d=True); with open3d importable so does this, otherwise a
@@ -1020,8 +1054,9 @@ class Fusion:
         return pcd_utils.as_point_cloud(pts, col)
 
     # ---- instance masks: upstream producers (reference fusion.py:1112-1256) ----------------
-    # The reference hard-wires Grounded-SAM + its multi-view association (align_instance_mask_v3, fusion.py:1067-1098)
-    # and XMem (xmem_process, fusion.py:631-684).  They stay upstream models here and are injected:
+    # The reference hard-wires Grounded-SAM and XMem (xmem_process, fusion.py:631-684).  They stay upstream models here and are
+    # injected.  A mask_producer may return the finished consensus (below) or only Grounded-SAM's per-view detections
+    # {'mask_gs', 'mask_label', 'mask_conf'} -- then align_instance_mask_v3 (fusion.py:1067-1098) runs here, as in the reference:
     #
     #   mask_producer(fusion, queries, thresholds, boundaries, merge_all=False, expected_labels=None, robot_pcd=None)
     #       -> dict with
@@ -1032,13 +1067,37 @@ class Fusion:
     #   mask_tracker(fusion, color (V,H,W,3) uint8, mask (V,H,W) uint8 tensor or None)
     #       -> (V,H,W,NI) one-hot / probabilities, or (V,H,W) uint8 labels: xmem_process's contract (fusion.py:631-684);
     #          mask is the consensus label image on the first frame and None on every later frame.
-    def _store_segmentation(self, produced):
+    def _store_detections(self, produced, queries, boundaries, expected_labels):
+        """The producer returned what Grounded-SAM returns per view (utils/grounded_sam.py:404-442: masks [n_v,H,W] with the
+        background first, labels, confidences): stored as the reference stores them (fusion.py:1141-1145) and associated across
+        the views by align_instance_mask_v3, as in the reference (fusion.py:1170).  Returns the (V,H,W) uint8 label image."""
+        gs, labels, confs = produced["mask_gs"], [list(l) for l in produced["mask_label"]], produced["mask_conf"]
+        if not (len(gs) == len(labels) == len(confs) == self.num_cam):
+            raise ValueError("'mask_gs', 'mask_label' and 'mask_conf' need one entry per view (%d)" % self.num_cam)
+        for v in range(self.num_cam):
+            shape = tuple(np.asarray(gs[v]).shape) if not isinstance(gs[v], torch.Tensor) else tuple(gs[v].shape)
+            if len(shape) != 3 or shape[1:] != (self.H, self.W) or shape[0] != len(labels[v]) or shape[0] != len(confs[v]):
+                raise ValueError("view %d: 'mask_gs' %s does not match %d labels / %d confidences at %dx%d"
+                                 % (v, shape, len(labels[v]), len(confs[v]), self.H, self.W))
+        self.curr_obs_torch["mask_gs"] = gs
+        self.curr_obs_torch["mask_label"] = labels
+        self.curr_obs_torch["mask_conf"] = confs
+        _, first = np.unique(labels[0], return_index=True)                                       # fusion.py:1144-1145
+        self.curr_obs_torch["semantic_label"] = list(np.array(labels[0])[np.sort(first)])
+        self.align_instance_mask_v3(queries, boundaries, expected_labels)
+        return self.curr_obs_torch["mask"]
+
+    def _store_segmentation(self, produced, queries=None, boundaries=None, expected_labels=None):
         """Writes what text_queries_* write after Grounded-SAM + align_instance_mask_v3 (fusion.py:1141-1145, 1096):
         'mask_gs', 'mask_label' (list per view of label strings), 'mask_conf', 'semantic_label',
         'consensus_mask_label'.  Returns the (V,H,W) uint8 consensus label image."""
+        raw = isinstance(produced, dict) and "mask" not in produced and all(k in produced for k in ("mask_gs", "mask_label", "mask_conf"))
+        if raw:
+            return self._store_detections(produced, queries, boundaries, expected_labels)
         if not isinstance(produced, dict) or "mask" not in produced or "consensus_mask_label" not in produced:
             raise TypeError("mask_producer must return a dict with 'mask' and 'consensus_mask_label' "
-                            "(optionally 'mask_label', 'mask_conf', 'mask_gs'); see INTEGRATION.md")
+                            "(optionally 'mask_label', 'mask_conf', 'mask_gs') or, for the reference's own association, "
+                            "only the per-view detections 'mask_gs', 'mask_label', 'mask_conf'; see INTEGRATION.md")
         consensus = [str(x) for x in produced["consensus_mask_label"]]
         NI = len(consensus)
         m = produced["mask"]
@@ -1095,15 +1154,18 @@ class Fusion:
                                             robot_pcd=None):
         """Reference fusion.py:1112-1171: segment every view, align the instances across views, store
         'mask_label' / 'mask_conf' / 'semantic_label' / 'consensus_mask_label' and 'mask' as a one-hot
-        (V,H,W,len(consensus_mask_label)) tensor of Fusion.dtype.  Segmentation + association are injected."""
+        (V,H,W,len(consensus_mask_label)) tensor of Fusion.dtype.  The segmentation is injected; the
+        association runs here (align_instance_mask_v3) when the producer returns raw per-view detections, else the producer's is taken."""
         if "color" not in self.curr_obs_torch:
             raise RuntimeError("Please call update() first!")
         if self.mask_producer is None:
             raise RuntimeError("no mask_producer was injected (Grounded-SAM is an upstream PyTorch-ROCm producer)")
-        label_img = self._store_segmentation(self.mask_producer(self, queries, thresholds, boundaries, merge_all=merge_all,
-                                                                expected_labels=expected_labels, robot_pcd=robot_pcd))
+        produced = self.mask_producer(self, queries, thresholds, boundaries, merge_all=merge_all, expected_labels=expected_labels,
+                                      robot_pcd=robot_pcd)
+        aligned_here = isinstance(produced, dict) and "mask" not in produced
+        label_img = self._store_segmentation(produced, queries, boundaries, expected_labels)
         consensus = self.curr_obs_torch["consensus_mask_label"]
-        if expected_labels is not None and consensus != expected_labels:
+        if expected_labels is not None and consensus != expected_labels and not aligned_here:
             print("consensus mask label", consensus)                                              # fusion.py:1097-1098
         self._set_mask(instance2onehot(label_img, len(consensus)))                                # fusion.py:1171
 
@@ -1121,7 +1183,8 @@ class Fusion:
             if self.mask_producer is None:
                 raise RuntimeError("no mask_producer was injected (Grounded-SAM is an upstream PyTorch-ROCm producer)")
             label_img = self._store_segmentation(self.mask_producer(self, queries, thresholds, boundaries, merge_all=merge_all,
-                                                                    expected_labels=expected_labels, robot_pcd=robot_pcd))
+                                                                    expected_labels=expected_labels, robot_pcd=robot_pcd),
+                                                 queries, boundaries, expected_labels)
             self._set_mask(self._tracked_mask(label_img))                                         # fusion.py:1237
         elif not use_sam:
             self._set_mask(self._tracked_mask(None))                                              # fusion.py:1239

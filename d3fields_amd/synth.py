@@ -105,3 +105,67 @@ def make_scene(V=4, H=480, W=640, depth_kind="smooth", seed=0):
     else:
         raise ValueError(depth_kind)
     return {"K": torch.from_numpy(K), "pose": torch.from_numpy(Rt), "depth": torch.from_numpy(depth)}
+
+
+# ---- synthetic multi-view segmentation (stands in for Grounded-SAM's per-view detections) -------------------------------------
+_SPHERE_NAMES = ["mug", "mug", "box", "pen"]
+
+
+def sphere_label_images(K, Rt, depth):
+    """[V,H,W] int64: 0 = table plane / nothing, s + 1 = the pixel's surface point lies on sphere s of the ray-cast scene."""
+    V, H, W = depth.shape
+    out = np.zeros((V, H, W), np.int64)
+    uu, vv = np.meshgrid(np.arange(W, dtype=np.float64), np.arange(H, dtype=np.float64))
+    for v in range(V):
+        Kv, R, t = K[v].astype(np.float64), Rt[v, :, :3].astype(np.float64), Rt[v, :, 3].astype(np.float64)
+        d = depth[v].astype(np.float64)
+        cam = np.stack([(uu - Kv[0, 2]) / Kv[0, 0] * d, (vv - Kv[1, 2]) / Kv[1, 1] * d, d], -1)
+        world = (cam - t) @ R
+        for s, (sx, sy, sz, r) in enumerate(_SPHERES):
+            hit = (np.linalg.norm(world - np.array([sx, sy, sz]), axis=-1) < r + 2e-3) & (d > 0)
+            out[v][hit] = s + 1
+    return out
+
+
+def multiview_segmentation(K, Rt, depth, seed=0):
+    """Per-view detections in the format the reference keeps in curr_obs_torch (fusion.py:1141-1143; producer:
+    utils/grounded_sam.py:404-442): mask_gs[v] bool [n_v,H,W] with the background (complement of the union) first,
+    mask_label[v] list of n_v strings starting with 'background', mask_conf[v] float64 [n_v] starting with 1.0.
+    The detections follow the scene's spheres (consistent across views) with seeded imperfections: dropped and split
+    detections, a 'table' detection, a spurious one, overlaps, shuffled order."""
+    r = np.random.default_rng(seed)
+    lab = sphere_label_images(K, Rt, depth)
+    V, H, W = lab.shape
+    yy, xx = np.mgrid[0:H, 0:W]
+    gs, labels, confs = [], [], []
+    for v in range(V):
+        det, names = [], []
+        for s in range(len(_SPHERES)):
+            m = lab[v] == s + 1
+            if m.sum() < 12 or r.random() < 0.12:
+                continue
+            if r.random() < 0.25:                                       # one object found as two detections
+                cut = xx[m].mean()
+                parts = [m & (xx < cut + 1), m & (xx >= cut - 1)]
+            else:
+                parts = [m]
+            for q in parts:
+                if r.random() < 0.3:                                    # a mask one pixel too wide: overlaps its neighbours
+                    q = q | np.roll(q, 1, axis=1) | np.roll(q, 1, axis=0)
+                det.append(q); names.append(_SPHERE_NAMES[s])
+        plane = (lab[v] == 0) & (depth[v] > 0)
+        if r.random() < 0.6:
+            y0, x0 = int(r.integers(0, H // 2)), int(r.integers(0, W // 2))
+            det.append(plane & (yy >= y0) & (yy < y0 + H // 3) & (xx >= x0) & (xx < x0 + W // 3)); names.append("table")
+        if r.random() < 0.4:
+            y0, x0 = int(r.integers(0, H - 12)), int(r.integers(0, W - 12))
+            det.append(plane & (yy >= y0) & (yy < y0 + 10) & (xx >= x0) & (xx < x0 + 12)); names.append(str(r.choice(_SPHERE_NAMES)))
+        order = r.permutation(len(det))
+        det = [det[k] for k in order]; names = [names[k] for k in order]
+        union = np.zeros((H, W), bool)
+        for q in det:
+            union |= q
+        gs.append(np.stack([~union] + det, axis=0))
+        labels.append(["background"] + names)
+        confs.append(np.concatenate([np.array([1.0]), r.uniform(0.3, 0.95, len(det)).astype(np.float32)], axis=0))
+    return gs, labels, confs

@@ -306,6 +306,13 @@ int d3f_vox_idx_iou(const int32_t *idx1, int64_t n1, const int32_t *idx2, int64_
  * ignored (cv2's default border for erosion).  src != dst. */
 int d3f_erode(const uint8_t *src, int32_t H, int32_t W, int32_t kh, int32_t kw, uint8_t *dst, void *stream);
 
+/* Fusion.swap_instance_mask (fusion.py:1052-1063) for ONE view: dets [n_dets, n_pix] uint8 (non-zero = the pixel belongs to the
+ * detection; the rows of curr_obs_torch['mask_gs'][view]), label_of_det[n_dets] int32 device = the consensus instance index
+ * the detection was assigned to (instances_info[k]['idx'][view] == d  =>  label_of_det[d] = k), < 0 = none.  out[n_pix] uint8 =
+ * what painting the detections in instance order leaves: the largest instance index covering the pixel (as uint8), 0 where
+ * no assigned detection does. */
+int d3f_compose_labels(const uint8_t *dets, int32_t n_dets, int64_t n_pix, const int32_t *label_of_det, uint8_t *out, void *stream);
+
 /* open3d's PointCloud.voxel_down_sample as the reference uses it (utils/draw_utils.py:318-323 voxel_downsample, :396-400
  * inside aggr_point_cloud_from_data; radius 0.01): voxels of side voxel_size anchored at min_bound - voxel_size/2, one
  * output point (and colour) per occupied voxel = the mean of its points.  pts / colors [n,3] float64 (colors may be NULL),

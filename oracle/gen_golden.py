@@ -393,6 +393,81 @@ def masked_pcd_case(fusion):
     save("masked_pcd", **arrays)
 
 
+def _instances_summary(prefix, instances, V, arrays):
+    """instances_info of the reference (list of dicts, fusion.py:1069-1073) as arrays: per instance its label, the sorted set
+    and the raw length of 'vox_idx', 'idx' as a [V] row (-1 = not seen in that view), and 'conf_per_pt' as sorted keys + the
+    confidences in append order (ragged, flattened)."""
+    arrays[prefix + "_labels"] = np.array([inst["label"] for inst in instances])
+    arrays[prefix + "_idx"] = np.array([[inst["idx"].get(v, -1) for v in range(V)] for inst in instances], np.int64).reshape(len(instances), V)
+    for k, inst in enumerate(instances):
+        arrays["%s_%d_voxset" % (prefix, k)] = np.array(sorted(set(int(x) for x in inst["vox_idx"])), np.int64)
+        arrays["%s_%d_voxlen" % (prefix, k)] = np.int64(len(inst["vox_idx"]))
+        keys = sorted(int(x) for x in inst["conf_per_pt"])
+        arrays["%s_%d_confkeys" % (prefix, k)] = np.array(keys, np.int64)
+        arrays["%s_%d_confcount" % (prefix, k)] = np.array([len(inst["conf_per_pt"][x]) for x in keys], np.int64)
+        flat = [float(c) for x in keys for c in inst["conf_per_pt"][x]]
+        arrays["%s_%d_confvals" % (prefix, k)] = np.array(flat, np.float64)
+
+
+def align_case(fusion, name, seed, V=4, H=120, W=160, queries=("mug", "box", "pen")):
+    """Fusion.align_instance_mask_v3 (fusion.py:1065-1098) run by the reference on synthetic per-view detections
+    (d3fields_amd/synth.py:multiview_segmentation): merge_instances_from_new_view_vox_ver per view (fusion.py:801-849),
+    filter_instances_vox_ver (:978-1040), reorder_instances (:1042-1050), swap_instance_mask (:1052-1063).  Third-party code the
+    image lacks is restated, as for the other caller goldens: cv2.erode (oracle/np_pcd.py:erode_cv2) and open3d 0.17's
+    voxel_down_sample behind utils/draw_utils.py:314-323 (oracle/np_pcd.py:voxel_mean; only the SET of 1-cm voxel means matters
+    downstream, their order does not).  Stored: the detections, the reference's instances after the merges and after the filter,
+    the consensus labels and the (V,H,W) uint8 label image."""
+    import copy
+    import importlib
+    from oracle import np_pcd
+    du = importlib.import_module("utils.draw_utils")
+    du.voxel_downsample = lambda pcd, voxel_size, pcd_color=None: np_pcd.voxel_mean(pcd, voxel_size, pcd_color)
+    sc = synth.make_scene(V, H, W, "smooth")
+    gs, labels, confs = synth.multiview_segmentation(sc["K"].numpy(), sc["pose"].numpy(), sc["depth"].numpy(), seed=seed)
+    color = np.zeros((V, H, W, 3), np.uint8)              # the association never looks at colours (stored clouds carry none)
+    box = dict(synth.WORK_BOX)
+
+    def fresh():
+        obs = dict(depth=sc["depth"], K=sc["K"], pose=sc["pose"], color=color, mask_gs=[g.copy() for g in gs],
+                   mask_label=[list(x) for x in labels], mask_conf=[c.copy() for c in confs])
+        return R.make_reference_fusion(fusion, obs, H, W)
+
+    # the stages one by one (what align_instance_mask_v3 does, fusion.py:1067-1094), to store the intermediate instances
+    f = fresh()
+    f.iou_threshold = 0.005
+    lower = np.array([box["x_lower"], box["y_lower"], box["z_lower"]])
+    higher = np.array([box["x_upper"], box["y_upper"], box["z_upper"]])
+    f.voxel_num = ((higher - lower) / 0.03).astype(np.int32)
+    (f.pcd_to_voxel, f.voxel_to_pcd, f.voxel_to_index, f.index_to_voxel, f.pcd_to_index, f.index_to_pcd) = \
+        fusion._init_low_level_memory(lower, higher, 0.03, voxel_num=f.voxel_num)
+    arrays = dict(H=H, W=W, V=V, seed=seed, K=sc["K"].numpy(), pose=sc["pose"].numpy(), depth=sc["depth"].numpy(),
+                  queries=np.array(list(queries)),
+                  bounds=np.array([box[k] for k in ("x_lower", "x_upper", "y_lower", "y_upper", "z_lower", "z_upper")]))
+    for v in range(V):
+        arrays["mask_gs_%d" % v] = np.packbits(gs[v], axis=None)
+        arrays["mask_n_%d" % v] = np.int64(gs[v].shape[0])
+        arrays["mask_label_%d" % v] = np.array(labels[v])
+        arrays["mask_conf_%d" % v] = confs[v]
+    instances = []
+    for v in range(V):
+        instances = f.merge_instances_from_new_view_vox_ver(instances, v, box)
+        arrays["n_after_view_%d" % v] = np.int64(len(instances))
+    _instances_summary("merged", copy.deepcopy(instances), V, arrays)
+    arrays["n_merged"] = np.int64(len(instances))
+    instances = f.filter_instances_vox_ver(instances)
+    _instances_summary("filtered", copy.deepcopy(instances), V, arrays)
+    arrays["n_filtered"] = np.int64(len(instances))
+    # and the whole call
+    g = fresh()
+    g.align_instance_mask_v3(list(queries), box)
+    arrays["consensus_mask_label"] = np.array(g.curr_obs_torch["consensus_mask_label"])
+    arrays["mask"] = g.curr_obs_torch["mask"].numpy()
+    assert arrays["mask"].dtype == np.uint8 and arrays["mask"].shape == (V, H, W)
+    save(name, **arrays)
+    print("   ", name, "instances after each view", [int(arrays["n_after_view_%d" % v]) for v in range(V)], "filtered", len(instances),
+          "consensus", list(arrays["consensus_mask_label"]), "label histogram", np.bincount(arrays["mask"].reshape(-1)).tolist())
+
+
 def main():
     torch.set_num_threads(4)
     fusion, corr = R.import_reference()
@@ -412,6 +487,8 @@ def main():
     assoc_case(fusion)
     select_v2_case(fusion)
     masked_pcd_case(fusion)
+    align_case(fusion, "align_v3_a", seed=3)
+    align_case(fusion, "align_v3_b", seed=8, V=3, queries=("box", "mug"))
 
 
 if __name__ == "__main__":

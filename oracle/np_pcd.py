@@ -105,6 +105,8 @@ def voxel_mean(points, voxel_size, colors=None):
     voxel index = floor((p - voxel_min_bound) / voxel_size), per voxel the mean of the accumulated points / colours in point
     order).  Returned in ASCENDING voxel-index order (open3d iterates its unordered_map); the SET is open3d's."""
     points = np.asarray(points, dtype=np.float64)
+    if points.shape[0] == 0:                                     # an empty cloud stays empty (the loop over its points never runs)
+        return points.reshape(0, 3) if colors is None else (points.reshape(0, 3), np.zeros((0, 3)))
     anchor = points.min(axis=0) - voxel_size * 0.5
     idx = np.floor((points - anchor) / voxel_size).astype(np.int64)
     acc = {}

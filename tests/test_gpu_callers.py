@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import load_golden, rel_err
+from conftest import ALIGN_CASES, align_inputs, assert_instances_match, load_golden, rel_err
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-5
@@ -582,3 +582,109 @@ def test_track_run_refuses_what_cannot_be_resident(dev):
     assert rc == _lib.ERR_BAD_SHAPE and b"resident" in lib.d3f_last_error()
     assert lib.d3f_track_run(ctypes.byref(views), ctypes.byref(cm), _lib.ptr(tr.last), 2, 300, _lib.ptr(tr.src), 0.02, 100.0, 1.0, 0.01,
                              0.9, 0.999, 1e-8, 0, ctypes.byref(state), _lib.current_stream_handle(dev)) == 0     # no steps: nothing to do
+
+
+# ---- multi-view instance association (fusion.py:801-1098) -------------------------------------------------------------------
+def _align_fusion(dev, g, producer=None):
+    from d3fields_amd import Fusion
+    V, H, W = int(g["V"]), int(g["H"]), int(g["W"])
+    f = Fusion(num_cam=V, device=str(dev), mask_producer=producer)
+    f.update({"color": np.zeros((V, H, W, 3), np.uint8), "depth": g["depth"], "pose": g["pose"], "K": g["K"],
+              "dino_feats": np.zeros((V, 4, 4, 4), np.float32)})
+    return f
+
+
+@pytest.mark.parametrize("case", ALIGN_CASES)
+def test_align_instance_mask_v3_matches_reference(dev, case):
+    """Fusion.align_instance_mask_v3 and its stages against what the REFERENCE's methods produced on the same per-view detections
+    (goldens align_v3_*: cv2.erode and open3d's voxel_down_sample restated): the instances after the merges and after the filter
+    -- labels, voxel sets, raw lengths, per-voxel confidence lists, view -> detection maps -- the consensus labels and the
+    (V,H,W) uint8 label images, all exact."""
+    from d3fields_amd import association, synth
+    g = load_golden(case)
+    V = int(g["V"])
+    gs, labels, confs = align_inputs(g)
+    box = dict(zip(("x_lower", "x_upper", "y_lower", "y_upper", "z_lower", "z_upper"), g["bounds"].tolist()))
+    assert box == dict(synth.WORK_BOX)
+    queries = [str(q) for q in g["queries"]]
+    f = _align_fusion(dev, g)
+    f.curr_obs_torch.update(mask_gs=gs, mask_label=labels, mask_conf=confs)
+    association.prepare_grid(f, box)
+    assert f.voxel_num.dtype == np.int32 and f.iou_threshold == 0.005
+    instances = []
+    for v in range(V):
+        instances = f.merge_instances_from_new_view_vox_ver(instances, v, box)
+        assert len(instances) == int(g["n_after_view_%d" % v])
+    assert_instances_match(g, "merged", instances, V)
+    instances = f.filter_instances_vox_ver(instances)
+    assert_instances_match(g, "filtered", instances, V)
+    # the whole call, on a fresh object
+    f = _align_fusion(dev, g)
+    f.curr_obs_torch.update(mask_gs=gs, mask_label=labels, mask_conf=confs)
+    f.align_instance_mask_v3(queries, box)
+    assert f.curr_obs_torch["consensus_mask_label"] == [str(x) for x in g["consensus_mask_label"]]
+    m = f.curr_obs_torch["mask"]
+    assert m.dtype == torch.uint8 and m.is_cuda and np.array_equal(cpu(m), g["mask"])
+    # ... and through text_queries_for_inst_mask_no_track with a producer that returns what Grounded-SAM returns per view
+    f = _align_fusion(dev, g, producer=lambda fusion, q, t, b, **kw: {"mask_gs": gs, "mask_label": labels, "mask_conf": confs})
+    f.text_queries_for_inst_mask_no_track(queries, [0.3] * len(queries), box)
+    NI = len(g["consensus_mask_label"])
+    assert f.get_inst_num() == NI and f.curr_obs_torch["mask"].shape == (V, int(g["H"]), int(g["W"]), NI)
+    assert np.array_equal(cpu(f.curr_obs_torch["mask"]).argmax(-1).astype(np.uint8), g["mask"])
+    assert float(f.curr_obs_torch["mask"].sum()) == V * int(g["H"]) * int(g["W"])
+    first = labels[0]
+    assert f.curr_obs_torch["semantic_label"] == [x for k, x in enumerate(first) if x not in first[:k]]
+    with pytest.raises(ValueError):
+        _align_fusion(dev, g, producer=lambda fusion, q, t, b, **kw: {"mask_gs": gs[:-1], "mask_label": labels, "mask_conf": confs}) \
+            .text_queries_for_inst_mask_no_track(queries, [0.3], box)
+
+
+@pytest.mark.parametrize("seed,V,H,W", [(1, 4, 120, 160), (2, 5, 96, 128), (4, 3, 240, 320), (6, 4, 150, 200), (9, 2, 120, 160)])
+def test_align_instance_mask_v3_seeded_against_oracle(dev, seed, V, H, W):
+    """The same against the CPU restatement (oracle/np_assoc.py, pinned to the reference by the goldens above) on other seeds,
+    view counts and image sizes."""
+    from d3fields_amd import Fusion, synth
+    from oracle import np_assoc
+    sc = synth.make_scene(V, H, W, "smooth")
+    K, pose, depth = sc["K"].numpy(), sc["pose"].numpy(), sc["depth"].numpy()
+    gs, labels, confs = synth.multiview_segmentation(K, pose, depth, seed=seed)
+    box = dict(synth.WORK_BOX)
+    bounds = [box[k] for k in ("x_lower", "x_upper", "y_lower", "y_upper", "z_lower", "z_upper")]
+    queries = ["pen", "mug", "box"]
+    try:
+        want_img, want_labels = np_assoc.align(depth, K, pose, [g.copy() for g in gs], labels, confs, queries, bounds)
+    except (ZeroDivisionError, IndexError) as e:          # detections the reference itself cannot digest: the same exception here
+        want_img, want_labels = type(e), None
+    f = Fusion(num_cam=V, device=str(dev))
+    f.update({"color": np.zeros((V, H, W, 3), np.uint8), "depth": depth, "pose": pose, "K": K, "dino_feats": np.zeros((V, 4, 4, 4), np.float32)})
+    f.curr_obs_torch.update(mask_gs=gs, mask_label=labels, mask_conf=confs)
+    if want_labels is None:
+        with pytest.raises(want_img):
+            f.align_instance_mask_v3(queries, box)
+        return
+    f.align_instance_mask_v3(queries, box)
+    assert f.curr_obs_torch["consensus_mask_label"] == want_labels
+    assert np.array_equal(cpu(f.curr_obs_torch["mask"]), want_img)
+
+
+def test_compose_labels_kernel(dev):
+    """d3f_compose_labels: the largest assigned instance index covering a pixel, 0 where none; unassigned detections ignored;
+    indices above 255 wrap like numpy's uint8 assignment; pixel counts that are not a multiple of four."""
+    import ctypes
+    from d3fields_amd import _lib
+    lib = _lib.load()
+    r = np.random.default_rng(5)
+    for n_dets, n_pix in ((1, 7), (9, 1001), (40, 4099), (300, 513)):
+        dets = (r.random((n_dets, n_pix)) < 0.2).astype(np.uint8) * r.integers(1, 256, (n_dets, n_pix)).astype(np.uint8)
+        owner = r.permutation(n_dets).astype(np.int32)
+        owner[r.random(n_dets) < 0.3] = -1
+        want = np.zeros(n_pix, np.uint8)
+        for k in np.argsort(owner, kind="stable"):
+            if owner[k] >= 0:
+                want[dets[k] != 0] = np.uint8(owner[k] & 255)
+        d, o = torch.from_numpy(dets).to(dev), torch.from_numpy(owner).to(dev)
+        out = torch.full((n_pix,), 77, dtype=torch.uint8, device=dev)
+        _lib.check(lib.d3f_compose_labels(_lib.ptr(d), n_dets, n_pix, _lib.ptr(o), _lib.ptr(out), _lib.current_stream_handle(dev)))
+        assert np.array_equal(cpu(out), want), (n_dets, n_pix)
+    assert lib.d3f_compose_labels(None, 0, 0, None, None, None) == 0
+    assert lib.d3f_compose_labels(None, 3, 8, None, ctypes.c_void_p(64), None) == _lib.ERR_INVALID_ARG

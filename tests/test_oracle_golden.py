@@ -6,7 +6,7 @@ The golden files were written by oracle/gen_golden.py, which imports and runs th
 import numpy as np
 import pytest
 
-from conftest import SCENE_CASES, SET_NAMES, load_golden, rel_err
+from conftest import ALIGN_CASES, SCENE_CASES, SET_NAMES, align_inputs, assert_instances_match, load_golden, rel_err
 from oracle import c_oracle as O
 
 TOL = 1e-5          # BASELINE.json north_star: <= 1e-5 relative fp32
@@ -238,3 +238,21 @@ def test_select_v2_restatement_matches_reference():
         assert np.array_equal(pts, g["pts_%d" % (i - 1)])
         o = O.eval_field(g["depth"], g["K"], g["pose"], pts.astype(np.float32), [g["in_dino_feats"]], mu=float(g["mu"]))
         assert rel_err(o["sets"][0], g["feats_%d" % (i - 1)]) <= TOL
+
+
+@pytest.mark.parametrize("case", ALIGN_CASES)
+def test_align_restatement_matches_reference(case):
+    """oracle/np_assoc.py against the reference's align_instance_mask_v3 (fusion.py:1065-1098) run on synthetic per-view
+    detections: the instances after the merges and after the filter (labels, voxel sets, raw lengths, per-voxel confidence lists,
+    view -> detection maps), the consensus labels and the label image, all exact."""
+    from oracle import np_assoc
+    g = load_golden(case)
+    gs, labels, confs = align_inputs(g)
+    V = int(g["V"])
+    stages = {}
+    img, consensus = np_assoc.align(g["depth"], g["K"], g["pose"], gs, labels, confs, [str(q) for q in g["queries"]], g["bounds"].tolist(), stages)
+    assert stages["count_after_view"] == [int(g["n_after_view_%d" % v]) for v in range(V)]
+    assert_instances_match(g, "merged", stages["merged"], V)
+    assert_instances_match(g, "filtered", stages["filtered"], V)
+    assert consensus == [str(x) for x in g["consensus_mask_label"]]
+    assert img.dtype == np.uint8 and np.array_equal(img, g["mask"])
