@@ -688,3 +688,25 @@ def test_compose_labels_kernel(dev):
         assert np.array_equal(cpu(out), want), (n_dets, n_pix)
     assert lib.d3f_compose_labels(None, 0, 0, None, None, None) == 0
     assert lib.d3f_compose_labels(None, 3, 8, None, ctypes.c_void_p(64), None) == _lib.ERR_INVALID_ARG
+
+
+def test_repr_example_runs(dev, capsys):
+    """examples/repr_synthetic.py: vis_repr.py's flow with the association running here; every surface point gets an instance."""
+    import importlib.util
+    import os
+    import sys
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples", "repr_synthetic.py")
+    spec = importlib.util.spec_from_file_location("repr_synthetic", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    argv, sys.argv = sys.argv, ["repr_synthetic.py", "--step", "0.008"]
+    try:
+        f, out = mod.main()
+    finally:
+        sys.argv = argv
+    text = capsys.readouterr().out
+    assert "association:" in text and "feature query:" in text
+    NI = f.get_inst_num()
+    assert NI >= 4 and f.curr_obs_torch["consensus_mask_label"][0] == "background"
+    assert out["mask"].shape[1] == NI and out["dino_feats"].shape[1] == 384 and out["color_tensor"].shape[1] == 3
+    assert bool(out["valid_mask"].all())
