@@ -37,7 +37,7 @@ namespace d3f {
 
 // ---- phase B, cell-run gather (patch-resolution wide maps) ------------------------------------------------
 // When a texel spans many image pixels (the reference's dino_feats is (H/10, W/10), fusion.py:694-697) consecutive
-// query points of a grid column / a Morton walk fall into the SAME texel cell of a view most of the time, and the
+// query points of a grid column / a Hilbert walk fall into the SAME texel cell of a view most of the time, and the
 // direct gather above is limited by the vector-L1 request rate (64 B/clk/CU), not by misses.  Here a lane group owns a
 // RUN of K consecutive points and U 16-byte channel vectors per lane, and walks the run view by view: the four corner
 // vectors of a view stay in registers and are re-fetched only when the cell changes (a flag phase A computes once per
@@ -357,7 +357,7 @@ __device__ __forceinline__ void fused_eval_body(const EvalParams &P)
 // slice).  512 bytes is the finest slice that pays: narrower ones repeat phase A more often and remove no fills (round 3
 // counters: 61 M line fills at 512, 256 and 128 bytes alike, profiles/r3_stream -- the fills follow the points in flight,
 // not the L2's capacity: DESIGN.md 5.6 e).  With C = 1024 there are eight slices, one per XCD: all eight L2s work on the
-// same chunk (C4-dense lattice 13.05 -> 9.05 ms).  Clouds take tiles of consecutive points of their Morton order instead
+// same chunk (C4-dense lattice 13.05 -> 9.05 ms).  Clouds take tiles of consecutive points of their Hilbert order instead
 // of lattice bricks.  Arithmetic per (point, view, channel) is that of gather_map (fast or strict form), so results are
 // identical.
 // HALF (round 5): the sliced map is stored in fp16 -- a lane's 16-byte vector is eight channels, widened inside v_fma_mix_f32
@@ -596,7 +596,7 @@ __global__ __launch_bounds__(kBlock, WAVES) void fused_eval_sliced_kernel(const 
 // Patch-resolution feature maps (the reference's dino_feats, fusion.py:694-697) sit in the caches, and the direct gather
 // of them is bound by the vector-L1 path (64 B/clk per CU, every (point, view) re-reading four whole texels) and by the
 // VALU work around every load.  The LDS reads 256 B/clk.  Here a workgroup takes a compact set of tile_pts points (a
-// power-of-two brick of a lattice, or that many consecutive points of the Morton order of a cloud):
+// power-of-two brick of a lattice, or that many consecutive points of the Hilbert order of a cloud):
 //   1. the eight corners of the set's bounding box are projected into every view (one lane per (view, corner)); the
 //      texel rectangle they span is the view's window (a projective map sends the box into the convex hull of its
 //      projected corners);

@@ -28,12 +28,14 @@
 //   4. cell_rank_kernel      every slot counts the (key, index) pairs of ITS cell that sort before its own (a cell is a few
 //                            consecutive slots: L1 hits) and moves to that place: the exact order of the full key, ties by
 //                            index.  A cell of more than 256 points (a dense clump) is ranked in aligned pieces of 256 slots.
-// Six launches (seven up to round 4); 1 M points: 0.11 ms (kernel time; 0.135 with the fixed 4-mm key grid this round began
-// with, whose returning atomics serialised on the ~33 points of an occupied 16-mm cell).  Measured and not kept (round 5, scripts/notebook/gpu_sessions/r5_gpu20-22.sh): fewer
-// counters (2^19 / 2^18: the atomics 130 us, the rank loops 72-110 us); counters private to an XCD (eight planes indexed by the
-// hardware XCC id, workgroup-scope atomics: no faster -- the limit is not coherence traffic -- and 3 bits of cell resolution
-// lost: 32-mm cells of ~266 points exceed the exact-rank window).  The result is a deterministic function of the points (the arrival order does not survive step 4 in
-// cells of <= 256 points).
+// Six launches (seven up to round 4); 1 M points: 0.10 ms of kernel time (0.135 with the fixed 4-mm key grid this round began with,
+// whose returning atomics serialised on the ~33 points of an occupied 16-mm cell).  The key kernel runs at the rate the L2s retire
+// returning atomics (~21 G/s).  Measured and not kept (round 5, scripts/notebook/gpu_sessions/r5_gpu20-22, 26, 27.sh): on the fixed
+// grid fewer counters (2^19 / 2^18: the atomics 130 us, the rank loops 72-110 us) -- on the box-relative grid 2^20 .. 2^18 are
+// within 1 % of each other and 2^21 only lengthens the scan; counters private to an XCD (eight planes indexed by the hardware XCC
+// id, workgroup-scope atomics: no faster -- the limit is not coherence traffic -- and 3 bits of cell resolution lost); four points
+// per lane in the key kernel (47 vs 47 us).  The result is a deterministic function of the points (the arrival order does not
+// survive step 4 in cells of <= 256 points).
 #include "d3f_internal.h"
 
 namespace d3f {

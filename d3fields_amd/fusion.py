@@ -239,7 +239,7 @@ class Fusion:
         self.reference_rounding = False         # True: D3F_FLAG_REFERENCE_ROUNDING -- wide maps in the reference's operation order too
         self._tracker = None                    # rigid_tracking: the captured iteration of the current sequence
         self.tuning_flags = 0                   # D3F_TUNE_* bits (experiments; results do not depend on them)
-        self.reorder_points = True              # hand the library scratch so it may walk points in Morton order
+        self.reorder_points = True              # hand the library scratch so it may walk points in Hilbert order
         self.use_hip_graph = True               # rigid_tracking: capture the optimiser iteration in a HIP graph
         self.fused_tracking = True              # ... and run it as five HIP launches (track_kernels.hip) instead of autograd
         self.graph_whole_tracking_loop = True   # ... with all 100 steps in ONE graph (False: one step replayed 100 times)
@@ -247,7 +247,7 @@ class Fusion:
         self.loop_launch_tracking = True        # ... and all steps of a frame ONE launch (d3f_track_run) up to 512 keypoints
         self.detect_point_order = True          # probe new query tensors for locality (one host sync each, cached)
         self._order_cache = None
-        self.cache_point_order = True           # keep the Morton order of an unchanged query tensor (a grid queried every
+        self.cache_point_order = True           # keep the Hilbert order of an unchanged query tensor (a grid queried every
         self._order_ws = None                   # frame) in its scratch and skip the ~0.12 ms re-sort
         self._lattice_cache = None
         self.async_probes = True                # without a per-tensor cache hit: probe asynchronously, launch on the previous verdict
@@ -675,7 +675,7 @@ class Fusion:
                 small = sum(m.numel() * m.element_size() for m in used_maps) <= (64 << 20)
                 if small and self.detect_point_order and (hinted_unordered if hinted_unordered is not None
                                                           else self._is_unordered(pts_c, stream)):
-                    flags |= _lib.FLAG_UNORDERED_POINTS     # larger maps are walked in Morton order anyway
+                    flags |= _lib.FLAG_UNORDERED_POINTS     # larger maps are walked in Hilbert order anyway
                 ws_bytes = lib.d3f_eval_workspace_bytes(n)
                 sig = (pts_c.data_ptr(), pts_c._version, n, int(stream.value or 0))   # per stream: the order is written asynchronously
                 held = self._order_ws if self.cache_point_order else None

@@ -72,7 +72,7 @@ extern "C" {
 
 /* Tuning bits of `flags` (performance experiments; results never depend on them):
  *   bits 8..11  log2 of the points per workgroup (2..8), 0 = automatic
- *   bit  12     invert the default XCD mapping (default: XCD-contiguous tile ranges on the Morton walk,
+ *   bit  12     invert the default XCD mapping (default: XCD-contiguous tile ranges on the Hilbert walk,
  *               round-robin otherwise)
  *   bit  13     never reorder points, even when a workspace is supplied
  *   bit  14     always reorder points when a workspace is supplied
@@ -80,7 +80,7 @@ extern "C" {
  *               runs, no channel slices, thin maps view by view.  Every fast path is bit-identical to it (tests/).
  *   bit   5     D3F_TUNE_NO_WINDOW_GATE: a cloud never gets the gated pair of launches (LDS texel windows / cell runs chosen by a
  *               device-side probe, ABI 5): cell runs only.  bit 6  D3F_TUNE_WINDOW_SIDE: the gate always opens the window side.
- *   bits 24..25 Morton cell: 16 mm >> k (k = 0..2);  bit 26 / 27 force batched / load-use corner loads;
+ *   bits 24..25 ignored (round 1: the cell size of the point order; the ordering sizes its cells itself);  bit 26 / 27 force batched / load-use corner loads;
  *               bit 28 do not precompute corner set-ups in phase A;  bits 29..31 XCD-mapping chunk = 1024 << (k-1) tiles
  *   bits 16..23 extra dynamic LDS per workgroup in KiB (throttles workgroups per CU); 255 = none      */
 #define D3F_TUNE_TILE_LOG2(k) (((uint32_t)(k) & 0xFu) << 8)
@@ -185,7 +185,7 @@ void d3f_profile_next_eval(void *start_event, void *stop_event);
  * geometry and the per-map lane mapping the host logic picked.  For tests and tuning. */
 typedef struct d3f_eval_plan {
     int32_t tile_points;                    /* query points per 256-thread workgroup                  */
-    int32_t reorder;                        /* 1: points are walked in Morton order (sorted keys); 2: closed-form brick
+    int32_t reorder;                        /* 1: points are walked in Hilbert order (sorted keys); 2: closed-form brick
                                                walk of a lattice (d3f_eval_grid / d3f_eval_lattice)    */
     int32_t lds_bytes;                      /* dynamic LDS per workgroup                              */
     int32_t reserved;                       /* cell-run gather: waves per SIMD its kernel variant is built for; channel-sliced
@@ -232,7 +232,7 @@ int d3f_eval_grid(const d3f_views *views, const d3f_grid *grid, const d3f_channe
 /* d3f_eval for points that the caller has ARRANGED as a regular lattice -- pts[(ix*ny + iy)*nz + iz], e.g. the
  * materialised output of create_init_grid (fusion.py:79-88) handed to batch_eval (vis_repr.py:88-93) -- with n =
  * nx*ny*nz.  Coordinates are read from `pts` exactly as in d3f_eval and the outputs are identical; the dims only let
- * the library walk the index space brick by brick in closed form when the maps are large (no Morton keys, no sort, no
+ * the library walk the index space brick by brick in closed form when the maps are large (no curve keys, no sort, no
  * index array, no workspace).  Any dims whose product is n are correct -- a wrong guess can only cost speed. */
 int d3f_eval_lattice(const d3f_views *views, const float *pts, int32_t nx, int32_t ny, int32_t nz,
                      const d3f_channel_map *maps, int32_t n_maps, float mu, uint32_t flags, float *out_dist,
