@@ -3,7 +3,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import load_golden
+from conftest import ALIGN_CASES, align_inputs, assert_instances_match, load_golden
 from d3fields_amd import Fusion, corr_utils, create_init_grid, instance2onehot, onehot2instance, sharding, synth
 
 
@@ -236,3 +236,63 @@ def test_fusion_float16_warns_about_its_meaning():
         warnings.simplefilter("always")
         Fusion(num_cam=2)
     assert not w
+
+
+@pytest.mark.parametrize("case", ALIGN_CASES)
+def test_association_bookkeeping_matches_reference_without_a_gpu(case, monkeypatch):
+    """d3fields_amd/association.py's host side -- which instance a detection joins, which of two overlapping instances keeps a
+    voxel, the deletion list, the reorder -- against the reference's instances (goldens align_v3_*), with the device functions it
+    calls (masked cloud, voxel index, set sizes, label painting) stood in for by the CPU restatements.  The -m gpu tests run the
+    same comparison on the kernels."""
+    from d3fields_amd import association, pcd_utils
+    from oracle import np_assoc, np_pcd
+    g = load_golden(case)
+    V, H, W = int(g["V"]), int(g["H"]), int(g["W"])
+    gs, labels, confs = align_inputs(g)
+    bounds = g["bounds"].tolist()
+    box = dict(zip(("x_lower", "x_upper", "y_lower", "y_upper", "z_lower", "z_upper"), bounds))
+
+    def cpu_closures(lower, higher, voxel_size, voxel_num):
+        to_index = lambda pcds: np_pcd.pcd_to_index(np.asarray(pcds).reshape(-1, 3), lower, voxel_size, voxel_num)      # noqa: E731
+        return None, None, None, None, to_index, None
+    monkeypatch.setattr(pcd_utils, "init_low_level_memory", cpu_closures)
+
+    class Stand:
+        num_cam, device = V, "cpu"
+        curr_obs_torch = {"mask_gs": gs, "mask_label": labels, "mask_conf": confs}
+
+        def extract_masked_pcd_in_views(self, inst, views, boundaries, downsample=True):
+            assert len(inst) == 1 and len(views) == 1 and downsample
+            v = views[0]
+            gate = np_pcd.erode_cv2((gs[v][inst[0]] * 255).astype(np.uint8), np.ones([2, 2], np.uint8)) > 0
+            pose44 = np.concatenate([g["pose"][v].astype(np.float64), [[0, 0, 0, 1]]], axis=0)
+            K = g["K"][v].astype(np.float64)
+            pts, _ = np_pcd.backproject_view(g["depth"][v], gate, [K[0, 0], K[1, 1], K[0, 2], K[1, 2]], np.linalg.inv(pose44), bounds)
+            return np_pcd.voxel_mean(pts, 0.01)
+
+        def vox_idx_iou(self, a, b):
+            return np_pcd.vox_idx_iou(a, b)
+
+        def merge_instances_from_new_view_vox_ver(self, instances, i, boundaries):
+            return association.merge_view(self, instances, i, boundaries)
+
+        def filter_instances_vox_ver(self, instances):
+            self.after_merges = __import__("copy").deepcopy(instances)
+            out = association.filter_instances(self, instances)
+            self.after_filter = __import__("copy").deepcopy(out)
+            return out
+
+        def reorder_instances(self, instances, queries):
+            return association.reorder(instances, queries)
+
+        def swap_instance_mask(self, instances):
+            self.curr_obs_torch["mask"] = np_assoc.label_images(instances, gs)
+
+    f = Stand()
+    f.H, f.W = H, W
+    instances = association.align(f, [str(q) for q in g["queries"]], box)
+    assert f.voxel_num.tolist() == np_assoc.association_grid(bounds)[1].tolist()
+    assert_instances_match(g, "merged", f.after_merges, V)
+    assert_instances_match(g, "filtered", f.after_filter, V)
+    assert [inst["label"] for inst in instances] == f.curr_obs_torch["consensus_mask_label"] == [str(x) for x in g["consensus_mask_label"]]
+    assert np.array_equal(f.curr_obs_torch["mask"], g["mask"])
