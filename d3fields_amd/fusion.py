@@ -1197,3 +1197,12 @@ class Fusion:
         if hasattr(self.mask_tracker, "clear_memory"):
             self.mask_tracker.clear_memory()
         self.xmem_first_mask_loaded = False
+
+    def close(self):
+        """Reference fusion.py:1704-1712 (drops the observation and the models): here the observation, the injected producers
+        and every device buffer the object kept between calls (workspaces, cached point order, finite-check words)."""
+        self.curr_obs_torch = {}
+        self.feature_extractor = self.mask_producer = self.mask_tracker = None
+        self._finite_cache, self._word_slot, self._words = {}, {}, None
+        self._order_cache = self._tracker = None
+        self._last_ws, self._last_ws_n = None, 0

@@ -710,3 +710,8 @@ def test_repr_example_runs(dev, capsys):
     assert NI >= 4 and f.curr_obs_torch["consensus_mask_label"][0] == "background"
     assert out["mask"].shape[1] == NI and out["dino_feats"].shape[1] == 384 and out["color_tensor"].shape[1] == 3
     assert bool(out["valid_mask"].all())
+    # close() (fusion.py:1704-1712) drops the observation and every buffer kept between calls; the object can be fed again
+    f.close()
+    assert f.curr_obs_torch == {} and f.mask_producer is None
+    with pytest.raises(RuntimeError):
+        f.batch_eval(torch.zeros(4, 3, device=dev), return_names=[])
