@@ -637,6 +637,14 @@ def test_align_instance_mask_v3_matches_reference(dev, case):
     with pytest.raises(ValueError):
         _align_fusion(dev, g, producer=lambda fusion, q, t, b, **kw: {"mask_gs": gs[:-1], "mask_label": labels, "mask_conf": confs}) \
             .text_queries_for_inst_mask_no_track(queries, [0.3], box)
+    # the tracking entry point: first frame = the same association, then the injected tracker (here: it returns what it was given)
+    f = _align_fusion(dev, g, producer=lambda fusion, q, t, b, **kw: {"mask_gs": gs, "mask_label": labels, "mask_conf": confs})
+    seen = []
+    f.mask_tracker = lambda fusion, color, mask: (seen.append(None if mask is None else mask.clone()), f.curr_obs_torch["mask"] if mask is None else mask)[1]
+    f.text_queries_for_inst_mask(queries, [0.3] * len(queries), box)
+    assert f.xmem_first_mask_loaded and f.track_ids == list(range(NI))
+    assert seen[0].dtype == torch.uint8 and np.array_equal(cpu(seen[0]), g["mask"])
+    assert np.array_equal(cpu(f.curr_obs_torch["mask"]).argmax(-1).astype(np.uint8), g["mask"])
 
 
 @pytest.mark.parametrize("seed,V,H,W", [(1, 4, 120, 160), (2, 5, 96, 128), (4, 3, 240, 320), (6, 4, 150, 200), (9, 2, 120, 160)])
