@@ -72,7 +72,7 @@ struct EvalParams {
     // n_words == 0: the host's D3F_FLAG_FINITE_MAPS alone decides.  All words zero <=> the exact invalid-view skip is allowed.
     int32_t n_words;
     const uint32_t *words[D3F_MAX_MAPS + 1];
-    // device-side choice between the window kernel and the cell-run kernel for a cloud (fuse_eval.hip: gated_out)
+    // device-side choice between the window kernel and the cell-run kernel for a cloud (fuse_common.h: gated_out)
     const uint32_t *gate;  // nullptr: this launch is not gated
     uint32_t gate_min;     // the window side runs iff *gate >= gate_min, the cell-run side iff *gate < gate_min
     int32_t gate_want;     // 1: the window side, 0: the cell-run side
@@ -82,7 +82,11 @@ struct EvalParams {
 
 // LDS bytes in front of the stage buffers: records, cnt/flag/idx, KRt, per-view windows
 inline int fused_lds_base(int tile_pts, int V) { return ((tile_pts * V * 24 + tile_pts * 12 + V * 48 + V * 16) + 15) / 16 * 16; }
-hipError_t launch_fused_eval(const EvalParams &P, int mode, hipStream_t stream);
+hipError_t launch_fused_eval(const EvalParams &P, int mode, hipStream_t stream);      // fuse_launch.hip: dispatch on the plan
+hipError_t launch_direct(const EvalParams &P, int mode, hipStream_t stream);          // fuse_direct.hip
+hipError_t launch_runs(const EvalParams &P, hipStream_t stream);                      // fuse_runs.hip
+hipError_t launch_sliced(const EvalParams &P, hipStream_t stream);                    // fuse_sliced.hip
+hipError_t launch_window(const EvalParams &P, hipStream_t stream);                    // fuse_window.hip
 constexpr int kGateSamples = D3F_GATE_SAMPLES;            // tiles the probe looks at (evenly spaced over the order)
 hipError_t launch_window_gate_probe(const EvalParams &P, uint32_t *gate, int nsamples, hipStream_t stream);
 int64_t order_gate_offset(int64_t n);

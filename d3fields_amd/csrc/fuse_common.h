@@ -1,4 +1,4 @@
-// fuse_common.h -- device code shared by the fused field-query kernels (fuse_eval.hip): per-(point, view) records, the bilinear corner set-up, the direct gather of one map, the thin-map
+// fuse_common.h -- device code shared by the fused field-query kernels (fuse_direct / fuse_runs / fuse_sliced / fuse_window .hip): per-(point, view) records, the bilinear corner set-up, the direct gather of one map, the thin-map
 // gather, output stores, the closed-form lattice walk.  Arithmetic contract: DESIGN.md section 2.
 #pragma once
 #include <hip/hip_runtime.h>
@@ -584,6 +584,47 @@ __device__ __forceinline__ int64_t walk_point(const EvalParams &P, const TileBox
     const int dx = p / yz, r = p - dx * yz;
     const int dy = r / tb.sz, dz = r - dy * tb.sz;
     return ((int64_t)(tb.ox + dx) * P.walk_ny + (tb.oy + dy)) * P.walk_nz + (tb.oz + dz);
+}
+
+// ---- fp16-STORED maps in the window kernel (round 5) --------------------------------------------------------------------------
+// The pool then holds the texels as stored: a slice of 128 channels is 256 bytes, a lane's corner read is an 8-byte vector of four
+// halves where the fp32 form reads 16 bytes (half the LDS bytes, the same instruction count, the same lane -> channel map, hence
+// the same coalesced row stores), and the arithmetic is v_fma_mix_f32 -- the fp16 operand widened inside the fp32 fma, one
+// rounding: bit for bit fma(float(h), w, acc), i.e. the fp32 kernel run on the widened map, at one instruction per channel (the
+// compiler's own form of that expression is v_cvt + v_pk_fma: 12 instead of 8 instructions per eight channels).
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+template <bool HALF> struct WinRaw { using T = f32x4; };
+template <> struct WinRaw<true> { using T = f16x4; };
+
+__device__ __forceinline__ void fma_mix4(f32x4 &acc, f16x4 r, float w)
+{
+    typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+    const u32x2 p = __builtin_bit_cast(u32x2, r);
+    const uint32_t p0 = p.x, p1 = p.y;
+    float a0 = acc.x, a1 = acc.y, a2 = acc.z, a3 = acc.w;
+    // op_sel_hi[0] = 1: source 0 is fp16; op_sel[0] picks its high half
+    asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel_hi:[1,0,0]" : "+v"(a0) : "v"(p0), "v"(w));
+    asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(a1) : "v"(p0), "v"(w));
+    asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel_hi:[1,0,0]" : "+v"(a2) : "v"(p1), "v"(w));
+    asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(a3) : "v"(p1), "v"(w));
+    acc = f32x4{a0, a1, a2, a3};
+}
+
+// the same for a 16-byte vector of eight halves (the channel-sliced kernel's lane): two accumulators
+__device__ __forceinline__ void fma_mix8(f32x4 &lo, f32x4 &hi, f16x8 r, float w)
+{
+    struct Pair { f16x4 a, b; };
+    const Pair pr = __builtin_bit_cast(Pair, r);
+    fma_mix4(lo, pr.a, w);
+    fma_mix4(hi, pr.b, w);
+}
+// ---- the device-side gate of a cloud's two launches (fuse_window.hip: window_gate_probe_kernel) ------------------------
+// Every fused entry point starts with it: a gated launch whose side lost returns at once (an ungated launch pays one scalar compare).
+__device__ __forceinline__ bool gated_out(const EvalParams &P)
+{
+    if (!P.gate) return false;
+    const uint32_t fit = __builtin_nontemporal_load(P.gate);
+    return (fit >= P.gate_min) != (P.gate_want != 0);
 }
 
 }  // namespace d3f

@@ -1,23 +1,5 @@
-// fuse_eval.hip -- the fused 3-D field query of d3fields for gfx950 (MI355X, CDNA4).
-//
-// One launch does what Fusion.eval does with ~20 torch ops and three [V,N,C] temporaries
-// (reference fusion.py:305-394, helpers :32-77): project every query point into the V
-// calibrated views, look the nearest depth pixel up, derive the truncated signed distance,
-// the per-view validity bit and exp weight, bilinearly sample every requested channels-last
-// map and reduce over the views.  The arithmetic contract (operation order, where an fma is
-// and is not used) is stated in DESIGN.md §Arithmetic and restated by oracle/d3f_oracle.c;
-// this file is compiled with -ffp-contract=off so that a*b+c below is two roundings and
-// only fmaf() fuses.
-//
-// Work decomposition (wave = 64 lanes, 256-thread workgroups, no MFMA: this is gather work)
-//   phase A  one LANE per point: projection, depth test, weights for all V views; 'dist' and
-//            'valid_mask' leave coalesced; the per-(point,view) record {gx,gy,wgt,valid}
-//            goes to LDS (16 B, one ds_write_b128).
-//   phase B  per channel map, a GROUP of 2^k lanes per point walks the channel vectors of the
-//            four bilinear corners (16-byte loads, consecutive lanes = consecutive channels, so
-//            every texel is fetched as whole 64-B..1-KiB coalesced segments), accumulates the
-//            V views in registers in view order and stores the fused row once.
-// Nothing of size [V,N,C] ever exists and N is not chunked.
+// fuse_window.hip -- the LDS-WINDOW kernel of the fused field query (gfx950) and the device-side gate that chooses between it and
+// the cell runs for a cloud.  Patch-resolution wide maps (the reference's dino_feats, fusion.py:694-697).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -25,572 +7,7 @@
 #include "d3f_device.h"
 #include "fuse_common.h"
 
-#ifndef D3F_RUNS_PREFETCH       // what-if build of the cell-run gather: 1 = next point's new cell touched one step ahead
-#define D3F_RUNS_PREFETCH 0
-#endif
-#ifndef D3F_SLICED_WHATIF      // what-if builds of the channel-sliced kernel (scripts/notebook/build_ablate.py --sliced): 1 phase A without the
-#define D3F_SLICED_WHATIF 0    // depth lookup / weights, 4 no gather (results wrong by construction; only times are read)
-#endif
-
 namespace d3f {
-
-
-// ---- phase B, cell-run gather (patch-resolution wide maps) ------------------------------------------------
-// When a texel spans many image pixels (the reference's dino_feats is (H/10, W/10), fusion.py:694-697) consecutive
-// query points of a grid column / a Hilbert walk fall into the SAME texel cell of a view most of the time, and the
-// direct gather above is limited by the vector-L1 request rate (64 B/clk/CU), not by misses.  Here a lane group owns a
-// RUN of K consecutive points and U 16-byte channel vectors per lane, and walks the run view by view: the four corner
-// vectors of a view stay in registers and are re-fetched only when the cell changes (a flag phase A computes once per
-// (point, view) by comparing the four corner offsets with the previous point's); the K accumulators carry the view
-// sums.  Per (point, view) the operations and their order are exactly those of gather_map's folded fast path -- four
-// fma with the folded weights into the view sum, views in order -- so the results are bit-identical.  Points that need the strict path (non-finite projection) are left to gather_map(only_strict).
-constexpr uint32_t kRunNonFinite = 1u;     // bits of the per-(point, view) state word (nfp_s)
-constexpr uint32_t kRunNewCell = 2u;       // the four corner texels differ from those of the previous point of the run
-constexpr uint32_t kRunValid = 4u;         // the view is valid for the point (its corner record is meaningful)
-
-// Branch structure: only the FOUR LOADS of a new cell are conditional.  The arithmetic runs for every (point, view):
-// phase A leaves an all-zero corner record for an invalid pair, so its term is (+-0) * wgt = +-0 and adding it to a sum
-// that started at +0 changes no bit (the argument of gather_map's exact skip) -- fewer exec-mask
-// round trips and LDS waits than skipping it.  A strict point (non-finite projection) takes part like any other and is
-// simply not stored here.
-// VFIX: the view count as a compile-time constant (4 = the reference's camera rig: LDS record addresses become
-// immediates and the view loop unrolls), 0 = read it from the launch parameters.
-template <int U, int K, int VFIX>
-__device__ __forceinline__ void gather_map_runs(const MapDesc &m, const EvalParams &P, const ViewRec *rec,
-                                                const uint32_t *state_s, const float *cnt_s, const uint32_t *flag_s,
-                                                const uint32_t *idx_s, int64_t idx_base, int tile_n, const CornerRec *crec)
-{
-    using VT = f32x4;
-    const int lpp = 1 << m.lpp_log2;
-    const int g = threadIdx.x & (lpp - 1);
-    const int grp = threadIdx.x >> m.lpp_log2;
-    const int ngrp = kBlock >> m.lpp_log2;
-    const int cvec = m.C / 4;
-    const int V = VFIX > 0 ? VFIX : P.V;
-    const char *__restrict__ data = reinterpret_cast<const char *>(m.data);
-    const int last = tile_n * V - 1;
-
-    for (int run0 = grp * K; run0 < tile_n; run0 += ngrp * K) {
-        for (int c0 = 0; c0 < cvec; c0 += lpp * U) {
-            uint32_t co[U];
-#pragma unroll
-            for (int u = 0; u < U; ++u) co[u] = (uint32_t)min(c0 + u * lpp + g, cvec - 1) * 16u;   // idle lanes re-read the last vector
-            VT acc[K][U];
-#pragma unroll
-            for (int k = 0; k < K; ++k)
-#pragma unroll
-                for (int u = 0; u < U; ++u) acc[k][u] = (VT)0.0f;
-#if D3F_RUNS_PREFETCH
-            uint32_t dead = 0u;
-#endif
-#pragma unroll 1
-            for (int v = 0; v < V; ++v) {          // kept rolled: unrolled views let the scheduler interleave them and spill
-                const char *bv = data + (int64_t)v * m.sv * 4;
-                VT a[U], b[U], d[U], e[U];
-#pragma unroll
-                for (int u = 0; u < U; ++u) { a[u] = (VT)0.0f; b[u] = (VT)0.0f; d[u] = (VT)0.0f; e[u] = (VT)0.0f; }
-#pragma unroll
-                for (int k = 0; k < K; ++k) {
-                    const bool inside = run0 + k < tile_n;
-                    const int q = min((run0 + k) * V + v, last);      // beyond the tile: some valid record, result unused
-                    const uint32_t st = state_s[q];
-                    const CornerRec &cr = crec[q];
-#if D3F_RUNS_PREFETCH       // what-if build (round 5): touch the NEXT point's new cell one step ahead (dword loads into a dead register)
-                    if (k + 1 < K && run0 + k + 1 < tile_n) {
-                        const int qn = q + V;
-                        if ((state_s[qn] & (kRunValid | kRunNewCell)) == (kRunValid | kRunNewCell)) {
-                            const CornerRec &cn = crec[qn];
-#pragma unroll
-                            for (int u = 0; u < U; ++u) {
-                                // "+v": ONE register stays reserved for the in-flight dwords until the sink below (a "=v" output would
-                                // be reallocated at once and the late load would land in somebody else's register)
-                                asm volatile("global_load_dword %0, %1, %2" : "+v"(dead) : "v"(cn.o[0] + co[u]), "s"(bv) : "memory");
-                                asm volatile("global_load_dword %0, %1, %2" : "+v"(dead) : "v"(cn.o[1] + co[u]), "s"(bv) : "memory");
-                                asm volatile("global_load_dword %0, %1, %2" : "+v"(dead) : "v"(cn.o[2] + co[u]), "s"(bv) : "memory");
-                                asm volatile("global_load_dword %0, %1, %2" : "+v"(dead) : "v"(cn.o[3] + co[u]), "s"(bv) : "memory");
-                            }
-                        }
-                    }
-#endif
-                    if (inside && (st & (kRunValid | kRunNewCell)) == (kRunValid | kRunNewCell)) {     // another texel cell
-                        const uint32_t o0 = cr.o[0], o1 = cr.o[1], o2 = cr.o[2], o3 = cr.o[3];
-#pragma unroll
-                        for (int u = 0; u < U; ++u) {
-                            a[u] = load_texel<4, false>(bv + (o0 + co[u]));
-                            b[u] = load_texel<4, false>(bv + (o1 + co[u]));
-                            d[u] = load_texel<4, false>(bv + (o2 + co[u]));
-                            e[u] = load_texel<4, false>(bv + (o3 + co[u]));
-                        }
-                    }
-                    const float w0 = cr.w[0], w1 = cr.w[1], w2 = cr.w[2], w3 = cr.w[3];      // folded (fuse_common.h)
-#pragma unroll
-                    for (int u = 0; u < U; ++u) {
-                        acc[k][u] = v_fma<VT>(a[u], w0, acc[k][u]);      // corners nw, ne, sw, se; views in order
-                        acc[k][u] = v_fma<VT>(b[u], w1, acc[k][u]);
-                        acc[k][u] = v_fma<VT>(d[u], w2, acc[k][u]);
-                        acc[k][u] = v_fma<VT>(e[u], w3, acc[k][u]);
-                    }
-                    // keep this point's arithmetic ahead of the next point's fetch: left alone, the optimiser sinks it below
-                    // the next conditional load block, which needs a second set of corner registers (and spills).  The
-                    // empty asm pins the accumulators (register operands) and, as a memory clobber, the later loads.
-#pragma unroll
-                    for (int u = 0; u < U; ++u) asm volatile("" : "+v"(acc[k][u]) : : "memory");
-                }
-            }
-#if D3F_RUNS_PREFETCH
-            asm volatile("s_waitcnt vmcnt(0)" : "+v"(dead) : : "memory");      // the sink of the touch loads
-#endif
-#pragma unroll
-            for (int k = 0; k < K; ++k) {
-                const int p = run0 + k;
-                if (p >= tile_n || flag_s[p] != 0u) continue;            // strict points: gather_map(only_strict) writes them
-                // the weights carry 1/(cnt + 1e-6) already; no valid view: every weight is zero and so is the sum (fusion.py:386)
-                const int64_t row = (idx_base + idx_s[p]) * m.C;
-#pragma unroll
-                for (int u = 0; u < U; ++u) {
-                    const int cv = c0 + u * lpp + g;
-                    if (cv >= cvec) continue;
-                    store_out<VT>(m.out + row + (int64_t)cv * 4, acc[k][u], P.store_policy);
-                }
-            }
-        }
-    }
-}
-
-
-// fp16-stored maps: the host maps them to 8-channel (16-B) or scalar lanes with batched loads only (1..3 vectors)
-template <int VW>
-__device__ __forceinline__ void gather_map_half_u(const MapDesc &m, const EvalParams &P, const ViewRec *rec,
-                                                  const float *cnt_s, const uint32_t *flag_s,
-                                                  const uint32_t *idx_s, int64_t idx_base, int tile_n, const CornerRec *crec)
-{
-    if (m.fold) {
-        switch (m.unroll) {
-        case 1: gather_map<VW, 1, true, true, true>(m, P, rec, cnt_s, flag_s, idx_s, idx_base, tile_n, crec); break;
-        case 2: gather_map<VW, 2, true, true, true>(m, P, rec, cnt_s, flag_s, idx_s, idx_base, tile_n, crec); break;
-        default: gather_map<VW, 3, true, true, true>(m, P, rec, cnt_s, flag_s, idx_s, idx_base, tile_n, crec); break;
-        }
-        return;
-    }
-    gather_map<VW, 1, true, true>(m, P, rec, cnt_s, flag_s, idx_s, idx_base, tile_n, crec);      // thin: one vector per lane
-}
-
-
-template <int MODE, bool WIDE, bool ANYF16 = false, int RU = 0, int RK = 0>
-__device__ __forceinline__ void fused_eval_body(const EvalParams &P)
-{
-    constexpr bool RUNS = RU > 0;
-    extern __shared__ __align__(16) unsigned char smem[];
-    const int V = P.V;
-    const int TP = P.tile_pts;
-    const int TL = P.n_maps == 0 ? 0 : TP;          // the distance-only pass keeps nothing per point in LDS (only KRt): its
-                                                    // tiles may be large without costing workgroups per CU
-    ViewRec *rec = reinterpret_cast<ViewRec *>(smem);                       // [TP*V]
-    float *dcl_s = reinterpret_cast<float *>(rec + (size_t)TL * V);          // [TP*V] (unused since round 4)
-    uint32_t *nfp_s = reinterpret_cast<uint32_t *>(dcl_s + (size_t)TL * V);  // [TP*V] per-pair state of the cell-run gather
-    float *cnt_s = reinterpret_cast<float *>(nfp_s + (size_t)TL * V);        // [TP]
-    uint32_t *flag_s = reinterpret_cast<uint32_t *>(cnt_s + TL);             // [TP]
-    uint32_t *idx_s = flag_s + TL;                                           // [TP] global point index
-    float *krt = reinterpret_cast<float *>(idx_s + TL);                      // [V*12]
-    CornerRec *crec_s = reinterpret_cast<CornerRec *>(smem + P.crec_offset); // [n_pre][TP*V] (wide maps)
-
-    __shared__ TileBox tb_s;                // lattice walk: decoded by one lane (12 integer divisions), read by all
-    const bool walk = P.walk_nx > 0;
-    const int64_t ntiles = walk ? (int64_t)gridDim.x : (P.n + TP - 1) / TP;
-    int64_t tile = (int64_t)blockIdx.x;
-    if (P.flags & kFlagXcdRemap) {
-        // chunked XCD mapping: the walk is cut into chunks of `xcd_chunk` tiles (0 = one chunk); inside a chunk
-        // XCD k takes the k-th contiguous eighth.  Small chunks keep all eight XCDs inside one region of space.
-        const int64_t ch = P.xcd_chunk > 0 ? (int64_t)P.xcd_chunk : ntiles;
-        const int64_t c0 = ((int64_t)blockIdx.x / ch) * ch;
-        const int64_t len = min(ch, ntiles - c0);
-        tile = c0 + xcd_tile((int64_t)blockIdx.x - c0, len);
-    }
-    if (walk && threadIdx.x == 0) tb_s = walk_tile(P, tile);
-    compute_krt(P.K, P.pose, V, krt, kBlock);
-    __syncthreads();
-    const int64_t tile_base = tile * TP;
-    TileBox tb = {0, 0, 0, 0, 0, 0};
-    if (walk) tb = tb_s;
-    const int tile_n = walk ? tb.sx * tb.sy * tb.sz : (int)min((int64_t)TP, P.n - tile_base);
-    const int64_t idx_base = (P.order || walk) ? 0 : tile_base;   // idx_s holds 32-bit offsets from here
-    const float mu = P.mu;
-    const float Wm1 = (float)(P.W - 1), Hm1 = (float)(P.H - 1);
-
-    // ---------------- phase A ----------------
-    if (P.n_maps == 0) {
-        // distance-only query (return_names=[], eval_dist): one lane per point, nothing staged in LDS
-        for (int p = threadIdx.x; p < tile_n; p += kBlock) {
-            const int64_t i = tile_base + p;
-            float px, py, pz;
-            fetch_point(P, i, px, py, pz);
-            float dsum = 0.0f, cnt = 0.0f;
-            for (int v = 0; v < V; ++v) {
-                float wgt;
-                const ViewOut o = eval_view<MODE>(P.depth, P.H, P.W, krt + v * 12, v, px, py, pz, Wm1, Hm1, mu, wgt);
-                dsum = dsum + o.dist * o.valid;                             // fusion.py:364
-                cnt = cnt + o.valid;
-            }
-            const bool all_invalid = (cnt == 0.0f);                         // fusion.py:366
-            float dist_out = dsum / (cnt + 1e-6f);
-            if (MODE == 0 && all_invalid) dist_out = 1e3f;                  // fusion.py:367
-            P.out_dist[i] = dist_out;
-            P.out_valid[i] = all_invalid ? 0 : 1;
-        }
-        return;
-    }
-    // One lane per (point, view) pair, the views of a point in VP = 2^k >= V adjacent lanes: the V depth lookups of a point
-    // are in flight together, the per-point sums over the views are rebuilt IN VIEW ORDER with wave shuffles (no second
-    // pass over LDS), and every pair knows the point's view count when it writes its records -- which is what lets the
-    // folded weights of wide maps (fuse_common.h) be final here.  Whole waves iterate (shuffles).
-    {
-        const bool finite_maps = maps_are_finite(P);
-        const int vp_log2 = view_lanes_log2(V), VP = 1 << vp_log2;
-        const int lane = threadIdx.x & 63, base = lane & ~(VP - 1);
-        const int npair = tile_n << vp_log2;
-        for (int idx0 = (int)(threadIdx.x & ~63u); idx0 < npair; idx0 += kBlock) {
-            const int idx = idx0 + lane;
-            const bool in = idx < npair;
-            const int p = min(idx >> vp_log2, tile_n - 1), v = idx & (VP - 1);
-            const bool act = in && v < V;
-            // (indices are clamped: a stale buffer passed with D3F_FLAG_REUSE_POINT_ORDER must not fault the device)
-            const int64_t i = walk ? walk_point(P, tb, p) : (P.order ? min((int64_t)P.order[tile_base + p], P.n - 1) : tile_base + p);
-            ViewOut o;
-            o.gx = 0.0f; o.gy = 0.0f; o.dist = 0.0f; o.valid = 0.0f;
-            float wgt = 0.0f;
-            uint32_t st = 0u;
-            if (act) {
-                float px, py, pz;
-                fetch_point(P, i, px, py, pz);
-                o = eval_view<MODE>(P.depth, P.H, P.W, krt + v * 12, v, px, py, pz, Wm1, Hm1, mu, wgt);
-                if (!(isfinite(o.gx) && isfinite(o.gy) && isfinite(wgt))) st = kRunNonFinite;
-            }
-            float dsum, cnt;
-            uint32_t nonfinite;
-            view_sums(V, base, o.dist * o.valid, o.valid, st, dsum, cnt, nonfinite);      // fusion.py:364 (products), :368
-            const float fsc = fold_scale(wgt, cnt);
-            uint32_t c0 = 0u, c1 = 0u, c2 = 0u, c3 = 0u;          // corner offsets of the first cell-run map (slot 0)
-            if (act) {
-                ViewRec r;
-                r.gx = o.gx; r.gy = o.gy; r.wgt = wgt; r.valid = o.valid;
-                rec[p * V + v] = r;
-                for (int s = 0; s < P.n_maps; ++s) {
-                    const MapDesc &m = P.maps[s];
-                    if (m.pre_slot >= 0 && o.valid != 0.0f) {
-                        const Corner c = corner_setup(m, o.gx, o.gy);
-                        const float sc = m.fold ? fsc : 1.0f;
-                        CornerRec cr;
-                        cr.o[0] = c.onw; cr.o[1] = c.one; cr.o[2] = c.osw; cr.o[3] = c.ose;
-                        cr.w[0] = c.inw ? c.wnw : 0.0f; cr.w[1] = c.ine ? c.wne : 0.0f;
-                        cr.w[2] = c.isw ? c.wsw : 0.0f; cr.w[3] = c.ise ? c.wse : 0.0f;
-                        if (m.fold) { cr.w[0] = cr.w[0] * sc; cr.w[1] = cr.w[1] * sc; cr.w[2] = cr.w[2] * sc; cr.w[3] = cr.w[3] * sc; }
-                        crec_s[(size_t)m.pre_slot * TP * V + p * V + v] = cr;
-                        if (RUNS && m.pre_slot == 0) { c0 = c.onw; c1 = c.one; c2 = c.osw; c3 = c.ose; }
-                    } else if (RUNS && m.runs > 0) {
-                        // the cell-run gather multiplies instead of branching: an invalid pair contributes +-0
-                        CornerRec cr;
-                        cr.o[0] = cr.o[1] = cr.o[2] = cr.o[3] = 0u;
-                        cr.w[0] = cr.w[1] = cr.w[2] = cr.w[3] = 0.0f;
-                        crec_s[(size_t)m.pre_slot * TP * V + p * V + v] = cr;
-                    }
-                }
-            }
-            if (RUNS) {
-                // cell-run gather: does this pair address the same four texels (of the first cell-run map) as the previous
-                // point of the tile?  The previous point's pair of this view is VP lanes down; it counts only if it is valid
-                // too -- an invalid or strict predecessor is handled by the consumer (the chain breaks there).
-                const uint32_t q0 = __shfl_up(c0, VP, 64), q1 = __shfl_up(c1, VP, 64), q2 = __shfl_up(c2, VP, 64), q3 = __shfl_up(c3, VP, 64);
-                const float pv = __shfl_up(o.valid, VP, 64);
-                // a run starts at every RK-th point of the tile: its first valid pair always fetches
-                const bool same = lane >= VP && (p % (RK > 0 ? RK : 1)) != 0 && pv != 0.0f && q0 == c0 && q1 == c1 && q2 == c2 && q3 == c3;
-                if (!same) st |= kRunNewCell;
-                if (o.valid != 0.0f) st |= kRunValid;
-            }
-            if (act) nfp_s[p * V + v] = st;
-            if (in && v == 0) {
-                // per point: outputs leave from the lane of view 0
-                const bool all_invalid = (cnt == 0.0f);                             // fusion.py:366
-                float dist_out = dsum / (cnt + 1e-6f);
-                if (MODE == 0 && all_invalid) dist_out = 1e3f;                      // fusion.py:367
-                P.out_dist[i] = dist_out;
-                P.out_valid[i] = all_invalid ? 0 : 1;
-                cnt_s[p] = cnt;
-                idx_s[p] = (uint32_t)(i - idx_base);
-                flag_s[p] = (nonfinite || !finite_maps) ? 1u : 0u;
-            }
-        }
-    }
-    __syncthreads();
-
-    // ---------------- phase B: per map, 2^k lanes per point ----------------
-    for (int s = 0; s < P.n_maps; ++s) {
-        const MapDesc &m = P.maps[s];
-        const CornerRec *crec = m.pre_slot >= 0 ? crec_s + (size_t)m.pre_slot * TP * V : nullptr;
-        if (RUNS && m.runs > 0) {
-            // non-strict points through the cell-run gather, the (rare) strict ones through the generic path
-            // (the host gives such a map 16-byte vectors, one per lane, and a corner-record slot)
-            if (V == 4) gather_map_runs<(RU > 0 ? RU : 1), (RK > 0 ? RK : 1), 4>(m, P, rec, nfp_s, cnt_s, flag_s, idx_s, idx_base, tile_n, crec);
-            else gather_map_runs<(RU > 0 ? RU : 1), (RK > 0 ? RK : 1), 0>(m, P, rec, nfp_s, cnt_s, flag_s, idx_s, idx_base, tile_n, crec);
-            gather_map<4, (RU > 0 ? RU : 1), true, false, true>(m, P, rec, cnt_s, flag_s, idx_s, idx_base, tile_n, crec, true);
-            continue;
-        }
-        if (ANYF16 && m.esize == 2) {
-            if (m.vw == 8) gather_map_half_u<8>(m, P, rec, cnt_s, flag_s, idx_s, idx_base, tile_n, crec);
-            else gather_map_half_u<1>(m, P, rec, cnt_s, flag_s, idx_s, idx_base, tile_n, crec);
-            continue;
-        }
-        switch (m.vw) {
-        case 4: gather_map_u<4, WIDE, RUNS>(m, P, rec, cnt_s, flag_s, idx_s, idx_base, tile_n, crec); break;
-        case 2: gather_map_u<2, WIDE, RUNS>(m, P, rec, cnt_s, flag_s, idx_s, idx_base, tile_n, crec); break;
-        default: gather_map_u<1, WIDE, RUNS>(m, P, rec, cnt_s, flag_s, idx_s, idx_base, tile_n, crec); break;
-        }
-    }
-}
-
-// ---- channel-sliced launch for a dense wide map on a lattice (the default there since round 2) -------------------------
-// On maps much larger than the caches the kernel is bound by L2 misses, and an L2 holds only a ~512-point window of
-// whole texels.  Here a workgroup handles 16 points (four 2x2x1 tiles of the brick walk; 32 when thin
-// maps ride along) x ONE 512-byte channel slice of the wide map, and the slices of a 4096-point stretch of the walk (a
-// "chunk") are units (chunk, slice) spread over the XCDs: the XCD that owns a unit has its 256 workgroups in flight
-// together and its 4 MiB L2 sees a third of every texel, i.e. a ~3x larger window in points (read hit rate 58 -> 66 %,
-// C2-dense 1.62 -> 1.52 ms).  The price: phase A (projection, depth test, weights, corner set-up) runs once per (point,
-// slice).  512 bytes is the finest slice that pays: narrower ones repeat phase A more often and remove no fills (round 3
-// counters: 61 M line fills at 512, 256 and 128 bytes alike, profiles/r3_stream -- the fills follow the points in flight,
-// not the L2's capacity: DESIGN.md 5.6 e).  With C = 1024 there are eight slices, one per XCD: all eight L2s work on the
-// same chunk (C4-dense lattice 13.05 -> 9.05 ms).  Clouds take tiles of consecutive points of their Hilbert order instead
-// of lattice bricks.  Arithmetic per (point, view, channel) is that of gather_map (fast or strict form), so results are
-// identical.
-// HALF (round 5): the sliced map is stored in fp16 -- a lane's 16-byte vector is eight channels, widened inside v_fma_mix_f32
-// (fma_mix8 below: the fp32 arithmetic on the widened map, bit for bit); 16 lanes x 8 channels = the same 128-channel slices.
-template <bool HALF> struct WinRaw;
-__device__ __forceinline__ void fma_mix8(f32x4 &lo, f32x4 &hi, f16x8 r, float w);
-template <int LG, int VC, bool HALF = false>   // lanes per point = 1 << LG: 8 (128-byte slices), 16 (256 B) or 32 (512 B)
-__device__ __forceinline__ void fused_eval_sliced_body(const EvalParams &P)
-{
-    constexpr int LP = 1 << LG, PTS = kBlock / LP;
-    constexpr int ES = HALF ? 2 : 4;
-    const int TP = P.tile_pts;                 // 32 (four 2x2x2 walk tiles) or 64 (four 2x2x4 ones)
-    extern __shared__ __align__(16) unsigned char smem[];
-    const int V = P.V;
-    ViewRec *rec = reinterpret_cast<ViewRec *>(smem);                       // same layout as fused_eval_body
-    float *dcl_s = reinterpret_cast<float *>(rec + (size_t)TP * V);
-    uint32_t *nfp_s = reinterpret_cast<uint32_t *>(dcl_s + (size_t)TP * V);
-    float *cnt_s = reinterpret_cast<float *>(nfp_s + (size_t)TP * V);
-    uint32_t *flag_s = reinterpret_cast<uint32_t *>(cnt_s + TP);
-    uint32_t *idx_s = flag_s + TP;
-    float *krt = reinterpret_cast<float *>(idx_s + TP);
-    CornerRec *crec_s = reinterpret_cast<CornerRec *>(smem + P.crec_offset);
-    __shared__ TileBox tbs[4];
-
-    // unit (chunk, slice) -> XCD blockIdx % 8; the unit's workgroups are consecutive in that XCD's stream
-    const int xcd = (int)(blockIdx.x & 7u);
-    const int64_t j = (int64_t)(blockIdx.x >> 3);
-    // sl_ilv > 1: the XCD's consecutive workgroups alternate between sl_ilv units (other slices of other chunks)
-    const int64_t jj = j / P.sl_ilv;
-    const int64_t unit = ((jj / P.sl_unit) * P.sl_ilv + (j - jj * P.sl_ilv)) * 8 + xcd;
-    const int wg = (int)(jj % P.sl_unit);
-    if (unit >= (int64_t)P.sl_chunks * P.sl_slices) return;
-    const int64_t chunk = unit / P.sl_slices;
-    const int slice = (int)(unit - chunk * P.sl_slices);
-    const int64_t grp4 = chunk * P.sl_unit + wg;                              // group of four consecutive walk tiles,
-    if (grp4 >= P.sl_groups) return;                                          // or of TP consecutive points of a cloud's order
-    const bool lat = P.walk_nx > 0;
-    if (lat && threadIdx.x < 4) {
-        const int64_t t = grp4 * 4 + threadIdx.x;
-        TileBox tb = {0, 0, 0, 0, 0, 0};
-        if (t < P.sl_tiles) tb = walk_tile(P, t);
-        tbs[threadIdx.x] = tb;
-    }
-    compute_krt(P.K, P.pose, V, krt, kBlock);
-    __syncthreads();
-    int start[5];
-    start[0] = 0;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) start[q + 1] = lat ? start[q] + tbs[q].sx * tbs[q].sy * tbs[q].sz : 0;
-    const int64_t cloud_base = grp4 * TP;
-    const int tile_n = lat ? start[4] : (int)min((int64_t)TP, P.n - cloud_base);
-    auto point_of = [&](int p) -> int64_t {
-        if (!lat) return P.order ? min((int64_t)P.order[cloud_base + p], P.n - 1) : cloud_base + p;
-        int q = 0;
-        if (p >= start[1]) q = 1;
-        if (p >= start[2]) q = 2;
-        if (p >= start[3]) q = 3;
-        return walk_point(P, tbs[q], p - start[q]);
-    };
-    const float mu = P.mu;
-    const float Wm1 = (float)(P.W - 1), Hm1 = (float)(P.H - 1);
-    const MapDesc &m0 = P.maps[0];                                           // the sliced wide map
-
-    // ---------------- phase A (as fused_eval_body: lane = (point, view), the views of a point adjacent) ----------------
-    {
-        const bool finite_maps = maps_are_finite(P);
-        const int vp_log2 = view_lanes_log2(V), VP = 1 << vp_log2;
-        const int lane = threadIdx.x & 63, base = lane & ~(VP - 1);
-        const int npair = tile_n << vp_log2;
-        for (int idx0 = (int)(threadIdx.x & ~63u); idx0 < npair; idx0 += kBlock) {
-            const int idx = idx0 + lane;
-            const bool in = idx < npair;
-            const int p = min(idx >> vp_log2, tile_n - 1), v = idx & (VP - 1);
-            const bool act = in && v < V;
-            const int64_t i = point_of(p);
-            ViewOut o;
-            o.gx = 0.0f; o.gy = 0.0f; o.dist = 0.0f; o.valid = 0.0f;
-            float wgt = 0.0f;
-            uint32_t st = 0u;
-            if (act) {
-                float px, py, pz;
-                fetch_point(P, i, px, py, pz);
-#if D3F_SLICED_WHATIF & 1       // what-if build (round 5): phase A without the depth lookup, the validity test and the weight (every pair valid)
-                const Proj pr = project_point(krt + v * 12, px, py, pz, Wm1, Hm1);
-                o.gx = pr.gx; o.gy = pr.gy; o.dist = 0.0f; o.valid = 1.0f; wgt = 1.0f;
-#else
-                o = eval_view<0>(P.depth, P.H, P.W, krt + v * 12, v, px, py, pz, Wm1, Hm1, mu, wgt);
-#endif
-                if (!(isfinite(o.gx) && isfinite(o.gy) && isfinite(wgt))) st = 1u;
-            }
-            float dsum, cnt;
-            uint32_t nonfinite;
-            view_sums(V, base, o.dist * o.valid, o.valid, st, dsum, cnt, nonfinite);
-            if (act) {
-                ViewRec r;
-                r.gx = o.gx; r.gy = o.gy; r.wgt = wgt; r.valid = o.valid;
-                rec[p * V + v] = r;
-                CornerRec cr;                           // invalid pair: texel 0 with zero weights (see phase B)
-                cr.o[0] = cr.o[1] = cr.o[2] = cr.o[3] = 0u;
-                cr.w[0] = cr.w[1] = cr.w[2] = cr.w[3] = 0.0f;
-                if (o.valid != 0.0f) {
-                    const Corner c = corner_setup(m0, o.gx, o.gy);
-                    const float sc = fold_scale(wgt, cnt);          // the sliced map is wide: folded weights (fuse_common.h)
-                    cr.o[0] = c.onw; cr.o[1] = c.one; cr.o[2] = c.osw; cr.o[3] = c.ose;
-                    cr.w[0] = (c.inw ? c.wnw : 0.0f) * sc; cr.w[1] = (c.ine ? c.wne : 0.0f) * sc;
-                    cr.w[2] = (c.isw ? c.wsw : 0.0f) * sc; cr.w[3] = (c.ise ? c.wse : 0.0f) * sc;
-                }
-                crec_s[p * V + v] = cr;
-            }
-            if (in && v == 0) {
-                const bool all_invalid = (cnt == 0.0f);
-                float dist_out = dsum / (cnt + 1e-6f);
-                if (all_invalid) dist_out = 1e3f;
-                if (slice == 0) {                                                    // one slice writes the per-point outputs
-                    P.out_dist[i] = dist_out;
-                    P.out_valid[i] = all_invalid ? 0 : 1;
-                }
-                cnt_s[p] = cnt;
-                idx_s[p] = (uint32_t)i;
-                flag_s[p] = (nonfinite || !finite_maps) ? 1u : 0u;
-            }
-        }
-    }
-    __syncthreads();
-
-    // ---------------- phase B: the slice of the wide map, LP lanes per point ----------------
-    {
-        using VT = f32x4;
-        using RT = typename std::conditional<HALF, f16x8, f32x4>::type;     // a lane's 16-byte vector as stored
-        const MapDesc &m = m0;
-        const int lg = threadIdx.x & (LP - 1), grp = threadIdx.x >> LG;
-        const uint32_t co = (uint32_t)(slice * LP + lg) * 16u;               // byte offset of this lane's vector in a texel
-        const char *__restrict__ data = reinterpret_cast<const char *>(m.data);
-        auto raw = [&](const char *bv, uint32_t off) -> RT { return *reinterpret_cast<const RT *>(bv + (off + co)); };
-        for (int p = grp; p < tile_n; p += PTS) {
-            const int64_t i = idx_s[p];
-            const float cnt = cnt_s[p];
-            const float denom = cnt + 1e-6f;
-            const bool strict = flag_s[p] != 0u;
-            VT acc = (VT)0.0f, acc2 = (VT)0.0f;                              // (acc2: channels 4..7 of a fp16 vector)
-#if D3F_SLICED_WHATIF & 4       // what-if build: no gather at all (phase A + the row stores)
-            if (true) { store_out<VT>(m.out + i * m.C + (co >> 2), acc, P.store_policy); continue; }
-#endif
-            auto accumulate = [&](RT t, float w) {
-                if constexpr (HALF) fma_mix8(acc, acc2, t, w);
-                else acc = v_fma<VT>(t, w, acc);
-            };
-            if (!strict) {
-                // fast path, branch-free: phase A left an all-zero corner record for an invalid (point, view), so its
-                // loads hit texel 0 of the view and its term is +-0 -- adding it changes no bit.  The corner
-                // loads of VC views are in flight together, then the views are consumed in view order with the folded
-                // weights: four fma per view straight into the sum.
-                int v0 = 0;
-                for (; v0 + VC <= V; v0 += VC) {
-                    RT a[VC], b[VC], d[VC], e[VC];
-                    f32x4 w[VC];
-#pragma unroll
-                    for (int q = 0; q < VC; ++q) {
-                        const CornerRec cr = crec_s[p * V + v0 + q];
-                        const char *bv = data + (int64_t)(v0 + q) * m.sv * ES;
-                        a[q] = raw(bv, cr.o[0]); b[q] = raw(bv, cr.o[1]); d[q] = raw(bv, cr.o[2]); e[q] = raw(bv, cr.o[3]);
-                        w[q] = f32x4{cr.w[0], cr.w[1], cr.w[2], cr.w[3]};
-                    }
-#pragma unroll
-                    for (int q = 0; q < VC; ++q) {
-                        accumulate(a[q], w[q].x);
-                        accumulate(b[q], w[q].y);
-                        accumulate(d[q], w[q].z);
-                        accumulate(e[q], w[q].w);
-                    }
-                }
-                for (; v0 < V; ++v0) {
-                    const CornerRec cr = crec_s[p * V + v0];
-                    const char *bv = data + (int64_t)v0 * m.sv * ES;
-                    const RT a = raw(bv, cr.o[0]), b = raw(bv, cr.o[1]), d = raw(bv, cr.o[2]), e = raw(bv, cr.o[3]);
-                    accumulate(a, cr.w[0]);
-                    accumulate(b, cr.w[1]);
-                    accumulate(d, cr.w[2]);
-                    accumulate(e, cr.w[3]);
-                }
-            } else {
-                for (int v = 0; v < V; ++v) {
-                    const ViewRec r = rec[p * V + v];
-                    const char *bv = data + (int64_t)v * m.sv * ES;
-                    const Corner c = corner_setup(m, r.gx, r.gy);
-                    const RT ra = raw(bv, c.onw), rb = raw(bv, c.one), rd = raw(bv, c.osw), re = raw(bv, c.ose);
-#pragma unroll
-                    for (int hh = 0; hh < (HALF ? 2 : 1); ++hh) {
-                        VT a, b, d, e;
-                        if constexpr (HALF) {
-                            const f32x8 wa = __builtin_convertvector(ra, f32x8), wb = __builtin_convertvector(rb, f32x8);
-                            const f32x8 wd = __builtin_convertvector(rd, f32x8), we = __builtin_convertvector(re, f32x8);
-                            a = hh ? wa.hi : wa.lo; b = hh ? wb.hi : wb.lo; d = hh ? wd.hi : wd.lo; e = hh ? we.hi : we.lo;
-                        } else {
-                            a = ra; b = rb; d = rd; e = re;
-                        }
-                        const VT av = c.inw ? a : (VT)0.0f, bvv = c.ine ? b : (VT)0.0f, dv = c.isw ? d : (VT)0.0f, ev = c.ise ? e : (VT)0.0f;
-                        VT s_ = av * c.wnw;
-                        s_ = v_fma<VT>(bvv, c.wne, s_);
-                        s_ = v_fma<VT>(dv, c.wsw, s_);
-                        s_ = v_fma<VT>(ev, c.wse, s_);
-                        if (hh) acc2 = acc2 + (s_ * r.valid) * r.wgt;
-                        else acc = acc + (s_ * r.valid) * r.wgt;
-                    }
-                }
-            }
-            VT o = acc, o2 = acc2;              // fast path: the weights carry 1/(cnt + 1e-6); no valid view: every weight is 0
-            if (strict) {
-                o = (VT)0.0f; o2 = (VT)0.0f;    // fusion.py:386
-                if (cnt != 0.0f) { o = strict_div<VT>(acc, denom); if constexpr (HALF) o2 = strict_div<VT>(acc2, denom); }
-            }
-            if constexpr (HALF) {
-                store_out<VT>(m.out + i * m.C + (co >> 1), o, P.store_policy);
-                store_out<VT>(m.out + i * m.C + (co >> 1) + 4, o2, P.store_policy);
-            } else {
-                store_out<VT>(m.out + i * m.C + (co >> 2), o, P.store_policy);
-            }
-        }
-    }
-    // the other (thin) maps of the launch ride along with slice 0
-    if (slice == 0)
-        for (int s = 1; s < P.n_maps; ++s) {
-            const MapDesc &m = P.maps[s];
-            switch (m.vw) {
-            case 4: gather_map_u<4, false, true>(m, P, rec, cnt_s, flag_s, idx_s, 0, tile_n, nullptr); break;
-            case 2: gather_map_u<2, false, true>(m, P, rec, cnt_s, flag_s, idx_s, 0, tile_n, nullptr); break;
-            default: gather_map_u<1, false, true>(m, P, rec, cnt_s, flag_s, idx_s, 0, tile_n, nullptr); break;
-            }
-        }
-}
-
-template <int LG, int VC, int WAVES, bool HALF = false>
-__global__ __launch_bounds__(kBlock, WAVES) void fused_eval_sliced_kernel(const EvalParams P) { fused_eval_sliced_body<LG, VC, HALF>(P); }
 
 // ---- texel windows in LDS for small wide maps (round 2) ---------------------------------------------------------------
 // Patch-resolution feature maps (the reference's dino_feats, fusion.py:694-697) sit in the caches, and the direct gather
@@ -636,39 +53,6 @@ struct WinView {
 constexpr int kWinMaxViews = 8;
 constexpr int kWinMaxTexels = 320;       // pool slots (host: win_pool_texels <= this)
 constexpr uint32_t kWinStrict = 1u, kWinHasDirect = 2u;
-
-// ---- fp16-STORED maps in the window kernel (round 5) --------------------------------------------------------------------------
-// The pool then holds the texels as stored: a slice of 128 channels is 256 bytes, a lane's corner read is an 8-byte vector of four
-// halves where the fp32 form reads 16 bytes (half the LDS bytes, the same instruction count, the same lane -> channel map, hence
-// the same coalesced row stores), and the arithmetic is v_fma_mix_f32 -- the fp16 operand widened inside the fp32 fma, one
-// rounding: bit for bit fma(float(h), w, acc), i.e. the fp32 kernel run on the widened map, at one instruction per channel (the
-// compiler's own form of that expression is v_cvt + v_pk_fma: 12 instead of 8 instructions per eight channels).
-typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
-template <bool HALF> struct WinRaw { using T = f32x4; };
-template <> struct WinRaw<true> { using T = f16x4; };
-
-__device__ __forceinline__ void fma_mix4(f32x4 &acc, f16x4 r, float w)
-{
-    typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
-    const u32x2 p = __builtin_bit_cast(u32x2, r);
-    const uint32_t p0 = p.x, p1 = p.y;
-    float a0 = acc.x, a1 = acc.y, a2 = acc.z, a3 = acc.w;
-    // op_sel_hi[0] = 1: source 0 is fp16; op_sel[0] picks its high half
-    asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel_hi:[1,0,0]" : "+v"(a0) : "v"(p0), "v"(w));
-    asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(a1) : "v"(p0), "v"(w));
-    asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel_hi:[1,0,0]" : "+v"(a2) : "v"(p1), "v"(w));
-    asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(a3) : "v"(p1), "v"(w));
-    acc = f32x4{a0, a1, a2, a3};
-}
-
-// the same for a 16-byte vector of eight halves (the channel-sliced kernel's lane): two accumulators
-__device__ __forceinline__ void fma_mix8(f32x4 &lo, f32x4 &hi, f16x8 r, float w)
-{
-    struct Pair { f16x4 a, b; };
-    const Pair pr = __builtin_bit_cast(Pair, r);
-    fma_mix4(lo, pr.a, w);
-    fma_mix4(hi, pr.b, w);
-}
 
 // acc[NV] += corner vectors * w, one raw vector (four channels: 16 bytes of fp32, 8 of fp16) per accumulator
 template <int NV, bool HALF>
@@ -1413,13 +797,6 @@ __device__ __forceinline__ void fused_eval_window_body(const EvalParams &P)
 // kernel's own steps 1-3: box, rectangles, bitmap), the last workgroup to finish publishes the count, and each kernel's workgroups
 // return at once unless the count is on their side of `gate_min`.  No host sync, capturable in a HIP graph; the losing launch
 // costs its dispatch (a few microseconds).
-__device__ __forceinline__ bool gated_out(const EvalParams &P)
-{
-    if (!P.gate) return false;
-    const uint32_t fit = __builtin_nontemporal_load(P.gate);
-    return (fit >= P.gate_min) != (P.gate_want != 0);
-}
-
 template <int U, int VC, int WAVES, int NT = kBlock, int LPP = 32, int VFIX = 0, bool SPARSE = false, bool HALF = false>
 __global__ __launch_bounds__(NT, WAVES) void fused_eval_window_kernel(const EvalParams P)
 {
@@ -1562,179 +939,89 @@ __global__ __launch_bounds__(kBlock) void window_gate_probe_kernel(const EvalPar
     }
 }
 
-// Entry points over one body: the plain kernel (<= 3 channel vectors per lane) is held to 128 VGPRs = 4 waves per SIMD
-// (125 allocated) -- the gather lives on memory-level parallelism; the WIDE variant adds the 4-vector load-use path
-// (C = 1024: a whole wave per point) with its natural register count.
-template <int MODE>
-__global__ __launch_bounds__(kBlock, 4) void fused_eval_kernel(const EvalParams P) { fused_eval_body<MODE, false>(P); }
-
-template <int MODE>
-__global__ __launch_bounds__(kBlock) void fused_eval_wide_kernel(const EvalParams P) { fused_eval_body<MODE, true>(P); }
-
-// fp16-stored maps get their own entry point (all vector counts, fp32 and fp16 maps may be mixed in one call) so
-// that the fp32 kernels above keep their register allocation (folding both into one body made them spill)
-// (163 VGPR = 3 waves per SIMD; held to 4 it spills 750 B per lane)
-template <int MODE>
-__global__ __launch_bounds__(kBlock) void fused_eval_f16_kernel(const EvalParams P) { fused_eval_body<MODE, true, true>(P); }
-
-// cell-run gather for patch-resolution wide maps, one entry point per (vectors per lane, run length, waves per SIMD) so
-// that every variant gets its own register allocation.  The planner's choices (launch_fused_eval): <1,4,7> for 32-lane
-// groups (C = 384: C2 patch clouds 0.750 -> 0.633 ms), <2,8,3> for 64-lane groups x two vectors (C = 1024: C4 patch
-// 4.32 -> 3.31 ms; held to 4 waves it spills 48 bytes per lane), <1,8,5> otherwise; all three are spill-free.  The other
-// instantiations (some spill) are compiled into experiments builds only.
-template <int MODE, int RU, int RK, int WAVES>
-__global__ __launch_bounds__(kBlock, WAVES) void fused_eval_runs_kernel(const EvalParams P)
-{
-    if (gated_out(P)) return;
-    fused_eval_body<MODE, false, false, RU, RK>(P);
-}
-
 hipError_t launch_window_gate_probe(const EvalParams &P, uint32_t *gate, int nsamples, hipStream_t stream)
 {
     hipLaunchKernelGGL(window_gate_probe_kernel, dim3((unsigned)nsamples), dim3(kBlock), 0, stream, P, gate, nsamples);
     return hipGetLastError();
 }
 
-hipError_t launch_fused_eval(const EvalParams &P, int mode, hipStream_t stream)
+hipError_t launch_window(const EvalParams &P, hipStream_t stream)
 {
-    if (P.n == 0) return hipSuccess;
     int64_t ntiles = (P.n + P.tile_pts - 1) / P.tile_pts;
     if (P.walk_nx > 0)
         ntiles = (int64_t)((P.walk_nx + P.walk_tx - 1) / P.walk_tx) * ((P.walk_ny + P.walk_ty - 1) / P.walk_ty) *
                  ((P.walk_nz + P.walk_tz - 1) / P.walk_tz);
-    const size_t lds = (size_t)P.crec_offset + (size_t)P.n_pre * P.tile_pts * P.V * 32 + (size_t)P.lds_pad;
-    dim3 grid((unsigned)ntiles), block(kBlock);
-    bool wide = false, f16 = false, runs = false;
-    for (int s = 0; s < P.n_maps; ++s) {
-        wide |= (P.maps[s].unroll == -4);
-        f16 |= (P.maps[s].esize == 2);
-        runs |= (P.maps[s].runs > 0);
-    }
-    if (mode == 0 && P.win_slices > 0) {
-        const bool half = P.maps[0].esize == 2;        // fp16-stored map: 256-byte slices (lattices only, 16 lanes per point)
-        const size_t lds_w = (size_t)P.win_pool_offset + (size_t)(2 + P.win_pool_texels) * (half ? 256 : 512) * P.win_u;
-        dim3 gw((unsigned)((P.n + P.tile_pts - 1) / P.tile_pts));
-        if (P.walk_nx > 0) gw = dim3((unsigned)ntiles);
+    dim3 block(kBlock);
+    const bool half = P.maps[0].esize == 2;        // fp16-stored map: 256-byte slices (lattices only, 16 lanes per point)
+    const size_t lds_w = (size_t)P.win_pool_offset + (size_t)(2 + P.win_pool_texels) * (half ? 256 : 512) * P.win_u;
+    dim3 gw((unsigned)((P.n + P.tile_pts - 1) / P.tile_pts));
+    if (P.walk_nx > 0) gw = dim3((unsigned)ntiles);
 #define D3F_WIN_LAUNCH_S(U_, VC_, W_, LPP_, VF_, SP_)                                                                          \
-        do {                                                                                                                       \
-            if (lds_w > 64 * 1024) {                                                                                               \
-                hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void *>(&fused_eval_window_kernel<U_, VC_, W_, kBlock, LPP_, VF_, SP_>), \
-                                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_w);                      \
-                if (ea != hipSuccess) return ea;                                                                                   \
-            }                                                                                                                      \
-            hipLaunchKernelGGL((fused_eval_window_kernel<U_, VC_, W_, kBlock, LPP_, VF_, SP_>), gw, block, lds_w, stream, P);      \
-        } while (0)
+    do {                                                                                                                       \
+        if (lds_w > 64 * 1024) {                                                                                               \
+            hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void *>(&fused_eval_window_kernel<U_, VC_, W_, kBlock, LPP_, VF_, SP_>), \
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_w);                      \
+            if (ea != hipSuccess) return ea;                                                                                   \
+        }                                                                                                                      \
+        hipLaunchKernelGGL((fused_eval_window_kernel<U_, VC_, W_, kBlock, LPP_, VF_, SP_>), gw, block, lds_w, stream, P);      \
+    } while (0)
 #define D3F_WIN_LAUNCH_F(U_, VC_, W_, LPP_, VF_)                                                                               \
-        do {                                                                                                                       \
-            if (P.win_sparse) D3F_WIN_LAUNCH_S(U_, VC_, W_, LPP_, VF_, true);                                                      \
-            else D3F_WIN_LAUNCH_S(U_, VC_, W_, LPP_, VF_, false);                                                                  \
-        } while (0)
+    do {                                                                                                                       \
+        if (P.win_sparse) D3F_WIN_LAUNCH_S(U_, VC_, W_, LPP_, VF_, true);                                                      \
+        else D3F_WIN_LAUNCH_S(U_, VC_, W_, LPP_, VF_, false);                                                                  \
+    } while (0)
 #define D3F_WIN_LAUNCH(U_, VC_, W_, LPP_) D3F_WIN_LAUNCH_F(U_, VC_, W_, LPP_, 0)
-        // the product library holds the variants the planner picks by itself: 16 lanes x two vectors per point, at 4 or 3
-        // workgroups per CU, with the view count fixed at 4 / 8 (software-pipelined point loop) or free; the others exist in
-        // experiments builds only (measured and dropped)
-        const bool lpp16 = P.win_u == 1 && P.win_lpp == 16;
-        const int vfix = (P.win_pipe && P.tile_pts == 64) ? (P.V == 4 ? 4 : (P.V == 8 ? 8 : 0)) : 0;
+    // the product library holds the variants the planner picks by itself: 16 lanes x two vectors per point, at 4 or 3
+    // workgroups per CU, with the view count fixed at 4 / 8 (software-pipelined point loop) or free; the others exist in
+    // experiments builds only (measured and dropped)
+    const bool lpp16 = P.win_u == 1 && P.win_lpp == 16;
+    const int vfix = (P.win_pipe && P.tile_pts == 64) ? (P.V == 4 ? 4 : (P.V == 8 ? 8 : 0)) : 0;
 #ifdef D3F_EXPERIMENTS
-        // win_vc 2: two views' corner reads in flight in the plain view loop (round 3's form)
-        if (lpp16 && vfix == 0 && P.win_occ == 6) D3F_WIN_LAUNCH_F(1, 1, 6, 16, 0);          // plain loop at 6 / 5 workgroups per CU (smaller pools)
-        else if (lpp16 && vfix == 0 && P.win_occ == 5) D3F_WIN_LAUNCH_F(1, 1, 5, 16, 0);
-        else if (lpp16 && vfix == 0 && P.win_vc == 2 && P.win_occ >= 4) D3F_WIN_LAUNCH_F(1, 2, 4, 16, 0);
-        else if (lpp16 && vfix == 0 && P.win_vc == 2) D3F_WIN_LAUNCH_F(1, 2, 3, 16, 0);
-        else
+    // win_vc 2: two views' corner reads in flight in the plain view loop (round 3's form)
+    if (lpp16 && vfix == 0 && P.win_occ == 6) D3F_WIN_LAUNCH_F(1, 1, 6, 16, 0);          // plain loop at 6 / 5 workgroups per CU (smaller pools)
+    else if (lpp16 && vfix == 0 && P.win_occ == 5) D3F_WIN_LAUNCH_F(1, 1, 5, 16, 0);
+    else if (lpp16 && vfix == 0 && P.win_vc == 2 && P.win_occ >= 4) D3F_WIN_LAUNCH_F(1, 2, 4, 16, 0);
+    else if (lpp16 && vfix == 0 && P.win_vc == 2) D3F_WIN_LAUNCH_F(1, 2, 3, 16, 0);
+    else
 #endif
-        // ONE register budget (<= 128 VGPRs: four waves per SIMD) serves every pool size: the workgroups per CU follow from the
-        // dynamic LDS of the launch (win_occ sized the pool), not from the kernel variant -- up to round 4 a second set held to
-        // __launch_bounds__(256, 3) existed and allocated 121 instead of 125 registers, the same occupancy step
+    // ONE register budget (<= 128 VGPRs: four waves per SIMD) serves every pool size: the workgroups per CU follow from the
+    // dynamic LDS of the launch (win_occ sized the pool), not from the kernel variant -- up to round 4 a second set held to
+    // __launch_bounds__(256, 3) existed and allocated 121 instead of 125 registers, the same occupancy step
 #define D3F_WIN_LAUNCH_H(VF_)                                                                                                 \
-        do {                                                                                                                       \
-            if (lds_w > 64 * 1024) {                                                                                               \
-                hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void *>(&fused_eval_window_kernel<1, 1, 4, kBlock, 16, VF_, false, true>), \
-                                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_w);                      \
-                if (ea != hipSuccess) return ea;                                                                                   \
-            }                                                                                                                      \
-            hipLaunchKernelGGL((fused_eval_window_kernel<1, 1, 4, kBlock, 16, VF_, false, true>), gw, block, lds_w, stream, P);    \
-        } while (0)
-        if (half) {
-            if (!lpp16 || P.win_sparse) return hipErrorInvalidValue;
-            if (vfix == 4) D3F_WIN_LAUNCH_H(4);
-            else if (vfix == 8) D3F_WIN_LAUNCH_H(8);
-            else D3F_WIN_LAUNCH_H(0);
-            return hipGetLastError();
-        }
+    do {                                                                                                                       \
+        if (lds_w > 64 * 1024) {                                                                                               \
+            hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void *>(&fused_eval_window_kernel<1, 1, 4, kBlock, 16, VF_, false, true>), \
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_w);                      \
+            if (ea != hipSuccess) return ea;                                                                                   \
+        }                                                                                                                      \
+        hipLaunchKernelGGL((fused_eval_window_kernel<1, 1, 4, kBlock, 16, VF_, false, true>), gw, block, lds_w, stream, P);    \
+    } while (0)
+    if (half) {
+        if (!lpp16 || P.win_sparse) return hipErrorInvalidValue;
+        if (vfix == 4) D3F_WIN_LAUNCH_H(4);
+        else if (vfix == 8) D3F_WIN_LAUNCH_H(8);
+        else D3F_WIN_LAUNCH_H(0);
+        return hipGetLastError();
+    }
 #undef D3F_WIN_LAUNCH_H
-        if (lpp16 && vfix == 4) D3F_WIN_LAUNCH_F(1, 1, 4, 16, 4);
-        else if (lpp16 && vfix == 8) D3F_WIN_LAUNCH_F(1, 1, 4, 16, 8);
-        else if (lpp16) D3F_WIN_LAUNCH(1, 1, 4, 16);
+    if (lpp16 && vfix == 4) D3F_WIN_LAUNCH_F(1, 1, 4, 16, 4);
+    else if (lpp16 && vfix == 8) D3F_WIN_LAUNCH_F(1, 1, 4, 16, 8);
+    else if (lpp16) D3F_WIN_LAUNCH(1, 1, 4, 16);
 #ifdef D3F_EXPERIMENTS
-        else if (P.win_u == 1 && P.win_occ >= 4) D3F_WIN_LAUNCH(1, 4, 4, 32);
-        else if (P.win_u == 1 && P.win_occ == 3) D3F_WIN_LAUNCH(1, 4, 3, 32);
-        else if (P.win_u == 1) D3F_WIN_LAUNCH(1, 4, 2, 32);
-        else if (P.win_u == 2 && P.win_vc == 2) D3F_WIN_LAUNCH(2, 2, 2, 32);
-        else if (P.win_u == 2) D3F_WIN_LAUNCH(2, 1, 2, 32);
-        else if (P.win_u == 3 && P.win_vc == 2) D3F_WIN_LAUNCH(3, 2, 2, 32);
-        else if (P.win_u == 3) D3F_WIN_LAUNCH(3, 1, 2, 32);
-        else D3F_WIN_LAUNCH(4, 1, 2, 32);
+    else if (P.win_u == 1 && P.win_occ >= 4) D3F_WIN_LAUNCH(1, 4, 4, 32);
+    else if (P.win_u == 1 && P.win_occ == 3) D3F_WIN_LAUNCH(1, 4, 3, 32);
+    else if (P.win_u == 1) D3F_WIN_LAUNCH(1, 4, 2, 32);
+    else if (P.win_u == 2 && P.win_vc == 2) D3F_WIN_LAUNCH(2, 2, 2, 32);
+    else if (P.win_u == 2) D3F_WIN_LAUNCH(2, 1, 2, 32);
+    else if (P.win_u == 3 && P.win_vc == 2) D3F_WIN_LAUNCH(3, 2, 2, 32);
+    else if (P.win_u == 3) D3F_WIN_LAUNCH(3, 1, 2, 32);
+    else D3F_WIN_LAUNCH(4, 1, 2, 32);
 #else
-        else return hipErrorInvalidValue;
+    else return hipErrorInvalidValue;
 #endif
 #undef D3F_WIN_LAUNCH
 #undef D3F_WIN_LAUNCH_F
 #undef D3F_WIN_LAUNCH_S
-        return hipGetLastError();
-    }
-    if (mode == 0 && P.sl_slices > 0) {
-        const int64_t units = (int64_t)P.sl_chunks * P.sl_slices;
-        const int64_t wgs = ((units + 7) / 8 + P.sl_ilv - 1) / P.sl_ilv * P.sl_ilv * 8 * P.sl_unit;
-        const size_t lds_s = (size_t)P.crec_offset + (size_t)P.tile_pts * P.V * 32 + (size_t)P.lds_pad;
-        const dim3 gs((unsigned)wgs);
-        if (P.maps[0].esize == 2) {                 // fp16-stored map: 16 lanes x 8 channels = 128-channel (256-byte) slices
-            if (P.sl_lg != 4 || P.sl_vc != 2) return hipErrorInvalidValue;
-            hipLaunchKernelGGL((fused_eval_sliced_kernel<4, 2, 7, true>), gs, block, lds_s, stream, P);
-            return hipGetLastError();
-        }
-        if (P.sl_lg == 5 && P.sl_vc == 2) hipLaunchKernelGGL((fused_eval_sliced_kernel<5, 2, 7>), gs, block, lds_s, stream, P);
-#ifndef D3F_EXPERIMENTS
-        else return hipErrorInvalidValue;          // (other slice widths / views in flight: experiments builds only)
-#else
-        else if (P.sl_lg == 5) hipLaunchKernelGGL((fused_eval_sliced_kernel<5, 4, 5>), gs, block, lds_s, stream, P);
-        else if (P.sl_lg == 4 && P.sl_vc == 2) hipLaunchKernelGGL((fused_eval_sliced_kernel<4, 2, 7>), gs, block, lds_s, stream, P);
-        else if (P.sl_lg == 4 && P.sl_vc == 1) hipLaunchKernelGGL((fused_eval_sliced_kernel<4, 1, 8>), gs, block, lds_s, stream, P);
-        else if (P.sl_lg == 4) hipLaunchKernelGGL((fused_eval_sliced_kernel<4, 4, 5>), gs, block, lds_s, stream, P);
-        else if (P.sl_vc == 2) hipLaunchKernelGGL((fused_eval_sliced_kernel<3, 2, 7>), gs, block, lds_s, stream, P);
-        else hipLaunchKernelGGL((fused_eval_sliced_kernel<3, 4, 5>), gs, block, lds_s, stream, P);
-#endif
-        return hipGetLastError();
-    }
-    if (mode == 0 && runs && !f16 && !wide) {
-        int ru = 1, rk = 8;
-        for (int s = 0; s < P.n_maps; ++s)
-            if (P.maps[s].runs > 0) { ru = P.maps[s].unroll; rk = P.maps[s].runs; }
-        // product library: the three spill-free variants the planner picks by itself -- (2,8) at 3 waves per SIMD (64-lane
-        // groups x 2 vectors, C = 1024), (1,4) at 7 waves (32-lane groups, C = 384), (1,8) at 5 waves (64-lane groups x 1)
-        if (ru == 2 && rk == 8 && P.runs_occ != 4) hipLaunchKernelGGL((fused_eval_runs_kernel<0, 2, 8, 3>), grid, block, lds, stream, P);
-        else if (ru == 1 && rk == 4 && P.runs_occ != 6) hipLaunchKernelGGL((fused_eval_runs_kernel<0, 1, 4, 7>), grid, block, lds, stream, P);
-        else if (ru == 1 && rk == 8 && P.runs_occ != 4 && P.runs_occ != 6) hipLaunchKernelGGL((fused_eval_runs_kernel<0, 1, 8, 5>), grid, block, lds, stream, P);
-#ifdef D3F_EXPERIMENTS
-        else if (ru == 3 && rk == 4) hipLaunchKernelGGL((fused_eval_runs_kernel<0, 3, 4, 4>), grid, block, lds, stream, P);
-        else if (ru == 3 && rk == 2) hipLaunchKernelGGL((fused_eval_runs_kernel<0, 3, 2, 4>), grid, block, lds, stream, P);
-        else if (ru == 2 && rk == 4) hipLaunchKernelGGL((fused_eval_runs_kernel<0, 2, 4, 4>), grid, block, lds, stream, P);
-        else if (ru == 2 && rk == 8) hipLaunchKernelGGL((fused_eval_runs_kernel<0, 2, 8, 4>), grid, block, lds, stream, P);
-        else if (ru == 1 && rk == 4) hipLaunchKernelGGL((fused_eval_runs_kernel<0, 1, 4, 6>), grid, block, lds, stream, P);
-        else if (P.runs_occ == 4) hipLaunchKernelGGL((fused_eval_runs_kernel<0, 1, 8, 4>), grid, block, lds, stream, P);
-        else hipLaunchKernelGGL((fused_eval_runs_kernel<0, 1, 8, 6>), grid, block, lds, stream, P);
-#else
-        else return hipErrorInvalidValue;
-#endif
-    }
-    else if (mode == 0 && f16)
-        hipLaunchKernelGGL((fused_eval_f16_kernel<0>), grid, block, lds, stream, P);
-    else if (mode == 0 && wide)
-        hipLaunchKernelGGL((fused_eval_wide_kernel<0>), grid, block, lds, stream, P);
-    else if (mode == 0)
-        hipLaunchKernelGGL((fused_eval_kernel<0>), grid, block, lds, stream, P);
-    else
-        hipLaunchKernelGGL((fused_eval_kernel<1>), grid, block, lds, stream, P);
     return hipGetLastError();
 }
 

@@ -232,7 +232,9 @@ class Fusion:
         self.xmem_first_mask_loaded = False     # fusion.py:302
         self._finite_cache = {}                 # key -> (weakref(tensor), signature, stream, event): checked by d3f_map_check
         self._words = None                      # device words of the checks (one per key), allocated on first use
-        self._word_slot = {}
+        self._word_slot = {}                    # key -> slot of its newest check;  _slot_key: slot -> the key that took it last
+        self._slot_key = []
+        self._next_word, self._ring_wrapped = -1, False
         self._finite_override = None            # True: D3F_FLAG_FINITE_MAPS (the caller vouches); False: strict path
         self.debug_recheck_maps = False         # True: d3f_map_check runs before EVERY query (no per-tensor cache): finds writers that
                                                 # change a map behind torch's back without invalidate_map_checks()
@@ -332,6 +334,8 @@ class Fusion:
                 return None                     # no allocation inside a HIP-graph capture
             self._words = torch.zeros(self._WORD_SLOTS, dtype=torch.int32, device=dev)
             self._word_slot = {}
+            self._slot_key = [None] * self._WORD_SLOTS
+            self._next_word, self._ring_wrapped = -1, False
             self._finite_cache.clear()
         stream = torch.cuda.current_stream(dev)
         # keyed on the tensor OBJECT (weak reference) and its version counter.  Writers that bypass torch (custom kernels
@@ -343,18 +347,9 @@ class Fusion:
             if hit[2] != stream.cuda_stream:
                 stream.wait_event(hit[3])       # checked on another stream: order this one behind it
             return self._words.data_ptr() + 4 * self._word_slot[key]
-        slot = self._next_word = (getattr(self, "_next_word", -1) + 1) % self._WORD_SLOTS
-        if slot == 0 and getattr(self, "_ring_used", False) and not torch.cuda.is_current_stream_capturing():
-            # the ring wraps: zero it (fresh slots are handed to d3f_map_check_many as already-zero words) and forget the cached
-            # verdicts that lived in it -- their tensors are checked again when they are next queried
-            self._words.zero_()
-            self._finite_cache.clear()
-            if batch is not None:
-                for item in batch:
-                    item[4] = None               # (their cache entries are re-made by the flush)
-        self._ring_used = True
-        self._word_slot[key] = slot
-        addr = self._words.data_ptr() + 4 * slot
+        # every path below makes (or fails to make) a NEW verdict for `key`: the cached one must not outlive this call (ADVICE r5:
+        # a `return None` used to leave it behind, pointing at a slot that was already handed on)
+        self._finite_cache.pop(key, None)
         src = t if checked is None else checked
         if src.dim() == 3:                      # depth (V,H,W): a one-channel map
             desc = _lib.ChannelMap(src.data_ptr(), src.shape[1], src.shape[2], 1, _lib.DTYPE_F32, src.stride(0), src.stride(1),
@@ -367,12 +362,27 @@ class Fusion:
             ok = src.dtype in (torch.float32, torch.float16) and src.stride(3) == 1 and src.stride(2) >= src.shape[3]
         if not ok or min(src.stride()) < 0:
             return None
+        # the slot, taken only now that the descriptor is valid: the next one of the ring that no LIVE cached verdict owns.  A
+        # wrap never zeroes the ring (that also cleared the words of tensors the SAME query had already resolved as
+        # cache hits -- a cached non-finite depth read as finite -- and of queries still in flight on other streams): once the
+        # ring has wrapped, d3f_map_check_many clears exactly the words it writes (_flush_checks stops passing
+        # CHECK_WORDS_ARE_ZERO), and a live verdict keeps its slot until its own tensor is re-checked.
+        slot = self._next_word
+        for _ in range(self._WORD_SLOTS):
+            slot = (slot + 1) % self._WORD_SLOTS
+            if slot == 0 and self._next_word >= 0:
+                self._ring_wrapped = True
+            owner = self._slot_key[slot]
+            if owner is None or self._word_slot.get(owner) != slot or owner not in self._finite_cache:
+                break
+        self._next_word = slot
+        self._slot_key[slot] = key
+        self._word_slot[key] = slot
+        addr = self._words.data_ptr() + 4 * slot
         cacheable = checked is None and not torch.cuda.is_current_stream_capturing()
         if batch is not None:
             import weakref
             batch.append([desc, int(src.shape[0]), addr, src, (key, weakref.ref(t), sig) if cacheable else None])
-            if not cacheable:
-                self._finite_cache.pop(key, None)
             return addr
         with torch.cuda.device(dev):
             _lib.check(self._lib.d3f_map_check(ctypes.byref(desc), src.shape[0], ctypes.c_void_p(addr), _lib.current_stream_handle(dev)))
@@ -381,8 +391,6 @@ class Fusion:
             ev = torch.cuda.Event()
             ev.record(stream)
             self._finite_cache[key] = (weakref.ref(t), sig, stream.cuda_stream, ev)
-        else:
-            self._finite_cache.pop(key, None)
         return addr
 
     def _flush_checks(self, batch, dev):
@@ -395,9 +403,10 @@ class Fusion:
         views = (ctypes.c_int32 * n)(*[b[1] for b in batch])
         words = (ctypes.c_void_p * n)(*[b[2] for b in batch])
         # a captured graph replays the launch on whatever the words hold then: let the call clear them itself there
-        zero = 0 if torch.cuda.is_current_stream_capturing() else _lib.CHECK_WORDS_ARE_ZERO
+        # (so does a ring that has wrapped: its slots hold the verdicts of earlier tensors, and nothing zeroes live words)
+        zero = 0 if (torch.cuda.is_current_stream_capturing() or self._ring_wrapped) else _lib.CHECK_WORDS_ARE_ZERO
         stream = torch.cuda.current_stream(dev)
-        with torch.cuda.device(dev):            # (every check takes a NEW slot of the ring, zeroed at allocation and at every wrap)
+        with torch.cuda.device(dev):            # (before the first wrap every check takes a slot that is still zero from the allocation)
             _lib.check(self._lib.d3f_map_check_many(descs, views, n, words, zero, _lib.current_stream_handle(dev)))
         ev = None
         for b in batch:
@@ -1204,5 +1213,7 @@ class Fusion:
         self.curr_obs_torch = {}
         self.feature_extractor = self.mask_producer = self.mask_tracker = None
         self._finite_cache, self._word_slot, self._words = {}, {}, None
+        self._slot_key, self._next_word, self._ring_wrapped = [], -1, False       # (they describe the buffer that was just dropped)
         self._order_cache = self._tracker = None
+        self._order_ws = self._lattice_cache = None     # ~20 bytes per point + an 8 MiB table per cached query / the lattice verdict
         self._last_ws, self._last_ws_n = None, 0

@@ -320,6 +320,41 @@ def test_map_check_many_and_the_ring_of_words(dev):
         assert torch.isnan(f.eval(pts, return_names=["dino_feats"])["dino_feats"]).any()
 
 
+def test_ring_wrap_keeps_the_cached_nonfinite_depth(dev):
+    """the depth image holds a NaN and stays CACHED (same tensor object) while a new map tensor is checked every frame,
+    so the ring of check words wraps with a live non-finite verdict in it.  The wrap must not clear that word (the query would
+    take the exact invalid-view skip and drop the 0 * NaN terms the reference keeps) nor hand its slot to another tensor: every
+    frame equals frame 0, NaNs included.  Also: a check that cannot be made (unsupported layout) leaves no cached verdict behind."""
+    from d3fields_amd import synth
+    V, H, W = 3, 48, 64
+    sc = synth.make_scene(V, H, W, "smooth")
+    depth = sc["depth"].clone()
+    depth[1, 10:30, 12:40] = float("nan")
+    feats = synth.random_map(V, 12, 16, 160, seed=1).to(dev)
+    pts = synth.random_cloud(3000, seed=3).to(dev)
+    f = make_fusion(dev, depth, sc["K"], sc["pose"], {"dino_feats": feats}, H, W)
+    with torch.no_grad():
+        ref = f.eval(pts, return_names=["dino_feats"])
+        assert torch.isnan(ref["dino_feats"]).any() and not f.maps_are_finite(("depth",))
+        depth_slot = f._word_slot["depth"]
+        for frame in range(2 * f._WORD_SLOTS + 10):
+            f.curr_obs_torch["dino_feats"] = feats.clone()                              # a NEW tensor object: a new slot every frame
+            out = f.eval(pts, return_names=["dino_feats"])
+            assert f._word_slot["depth"] == depth_slot and f._word_slot["dino_feats"] != depth_slot, frame
+            if frame % 16 == 0 or frame >= f._WORD_SLOTS - 4:
+                for k in ("dino_feats", "dist"):
+                    assert torch.equal(torch.isnan(out[k]), torch.isnan(ref[k])), (frame, k)
+                    assert torch.equal(torch.nan_to_num(out[k]), torch.nan_to_num(ref[k])), (frame, k)
+        assert f._ring_wrapped and not f.maps_are_finite(("depth",)) and f.maps_are_finite(("dino_feats",))
+        # a tensor the check cannot describe (float64): no word, and the verdict of the tensor checked before is gone
+        f.curr_obs_torch["dino_feats"] = feats.clone()
+        f.eval(pts, return_names=["dino_feats"])
+        assert "dino_feats" in f._finite_cache
+        assert f._finite_word("dino_feats", feats.double()) is None and "dino_feats" not in f._finite_cache
+    f.close()
+    assert f._order_ws is None and f._lattice_cache is None and f._words is None and f._next_word == -1 and not f._ring_wrapped
+
+
 def test_nonfinite_points(dev):
     from d3fields_amd import synth
     V, H, W = 3, 48, 64
