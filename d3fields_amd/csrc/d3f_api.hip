@@ -38,31 +38,8 @@ int check_views(const d3f_views *v)
     return D3F_OK;
 }
 
-// Experiment knobs read from the environment (integers; results never depend on them):
-//   D3F_EXP_RUNS   cell-run gather on patch-resolution wide maps: -1 off, 0 automatic (default), 2 / 4 / 8 = run length
-//   D3F_EXP_RUNS_U vectors per lane of the cell-run gather: 0 automatic, 1 / 2 / 3;  D3F_EXP_RUNS_OCC=5: the (1,8) variant
-//                  held to 5 waves per SIMD
-//   D3F_EXP_STORE  -1: write the fused rows with plain stores, 1: with sc1 ones, 3: with `sc1 nt` ones, instead of `nt` ones (store_out, fuse_common.h)
-//                  also in the window kernel (plain there by default)
-//   D3F_EXP_SLICED 1 / 2 / 3: force the channel-sliced launch for a dense wide map on a lattice (128- / 256- / 512-byte
-//                  slices, fuse_eval.hip); -1: never (default: only with thin companion maps); _VC views in flight, _UNIT
-//                  workgroups per unit
-//   D3F_EXP_WALK_TILE  shape of the walk's tile as digits x y z with the same point count (222 default; 224 with a thin map)
-//   D3F_EXP_WALK   lattice brick walk for grids on large maps: -1 off, 0 automatic (default)
-//   D3F_EXP_THIN   -1: thin maps (mask, colours) through the view-sequential gather_map instead of gather_map_thin
-//   D3F_EXP_WINDOW LDS texel-window kernel instead of the cell-run gather for a patch-resolution wide first map
-//                  (fuse_eval.hip): 0 automatic = on lattices (64 points per workgroup), -1 never,
-//                  32 / 64 / 128 = always, with that many points per workgroup; _U vectors per lane (1..4), _VC views
-//                  in flight (U = 2 / 3), _OCC workgroups per CU (2..4), _POOL pool texels, _LPP 32: one vector per lane (default 16 x 2)
-//   D3F_EXP_RUNS_OCC also: 4 = the (2,8) cell-run variant held to 4 waves per SIMD (default 3, spill-free)
 #ifdef D3F_EXPERIMENTS
-// built with -DD3F_EXPERIMENTS (python -m d3fields_amd.build --experiments): tuning sessions only
-int exp_knob(const char *name)
-{
-    const char *v = getenv(name);
-    return v ? atoi(v) : 0;
-}
-// phase stamps of the window kernel (D3F_EXP_STAMPS=1): 32 x uint64 per sampled workgroup, read back with d3f_exp_read_stamps
+// phase stamps of the window kernel (Tune::stamps): 32 x uint64 per sampled workgroup, read back with d3f_exp_read_stamps
 constexpr int64_t kStampBytes = 8LL * 32 * 65536;
 unsigned long long *exp_stamp_buffer(bool clear)
 {
@@ -71,9 +48,6 @@ unsigned long long *exp_stamp_buffer(bool clear)
     if (buf && clear) (void)hipMemset(buf, 0, kStampBytes);
     return buf;
 }
-#else
-// the product build reads no environment: every knob is its default (0), the library keeps no hidden state
-constexpr int exp_knob(const char *) { return 0; }
 #endif
 
 // the launch planner: thresholds, the family table, one function per kernel family (host logic only)
@@ -161,6 +135,7 @@ int eval_common(const d3f_views *views, const float *pts, int64_t n, const d3f_c
     // D3F_FLAG_REFERENCE_ROUNDING: no fast path at all -- every point takes the strict form (the reference's operation order)
     if (flags & D3F_FLAG_REFERENCE_ROUNDING) flags = (flags & ~D3F_FLAG_FINITE_MAPS) | D3F_TUNE_DIRECT_GATHER;
     d3f::EvalParams P;
+    const Tune tune = load_tune();          // every knob 0 in the product build (d3f_plan.h)
     // device-side finiteness words (d3f_map_check): used when the host did not vouch for the maps and EVERY tensor of the
     // query carries one; the kernels then decide on the device, and the launch is planned for finite maps
     P.n_words = 0;
@@ -176,7 +151,7 @@ int eval_common(const d3f_views *views, const float *pts, int64_t n, const d3f_c
         if (!aligned(P.words[k], 4)) return fail(D3F_ERR_BAD_LAYOUT, "nonfinite word %d: device pointer must be 4-byte aligned", k);
     P.exp_stamps = nullptr;
 #ifdef D3F_EXPERIMENTS
-    if (exp_knob("D3F_EXP_STAMPS") > 0 && !plan_out) P.exp_stamps = exp_stamp_buffer(true);
+    if (tune.stamps > 0 && !plan_out) P.exp_stamps = exp_stamp_buffer(true);
 #endif
     P.depth = views->depth; P.K = views->K; P.pose = views->pose; P.pts = pts;
     P.order = nullptr; P.lds_pad = 0;
@@ -184,14 +159,14 @@ int eval_common(const d3f_views *views, const float *pts, int64_t n, const d3f_c
     P.grid_ny = grid ? grid->ny : 0; P.grid_nz = grid ? grid->nz : 0;
     P.walk_nx = P.walk_ny = P.walk_nz = 0; P.walk_tx = P.walk_ty = P.walk_tz = 1;
     P.sl_unit = 128; P.sl_ilv = 1; P.sl_slices = 0; P.sl_lg = 3; P.sl_vc = 4; P.sl_tiles = P.sl_groups = P.sl_chunks = 0;
-    P.runs_occ = exp_knob("D3F_EXP_RUNS_OCC");
-    P.thin_max_views = (exp_knob("D3F_EXP_THIN") < 0 || (flags & D3F_TUNE_DIRECT_GATHER)) ? 0 : 8;
-    P.win_lpp = exp_knob("D3F_EXP_WINDOW_LPP") == 32 ? 32 : 16;     // 16 lanes x 2 vectors per point (C2 patch 0.565 -> 0.54 ms); U > 1: 32
+    P.runs_occ = tune.runs_occ;
+    P.thin_max_views = (tune.thin < 0 || (flags & D3F_TUNE_DIRECT_GATHER)) ? 0 : 8;
+    P.win_lpp = tune.window_lpp == 32 ? 32 : 16;     // 16 lanes x 2 vectors per point (C2 patch 0.565 -> 0.54 ms); U > 1: 32
     P.win_slices = 0; P.win_u = 1; P.win_vc = 1; P.win_pool_offset = 0; P.win_pool_texels = 0; P.win_occ = 4;
-    P.win_pipe = exp_knob("D3F_EXP_WINDOW_PIPE") < 0 ? 0 : 1;
+    P.win_pipe = tune.window_pipe < 0 ? 0 : 1;
     P.win_sparse = 0;
     P.gate = nullptr; P.gate_min = 0u; P.gate_want = 0;
-    P.store_policy = exp_knob("D3F_EXP_STORE") < 0 ? 0 : (exp_knob("D3F_EXP_STORE") == 1 ? 1 : (exp_knob("D3F_EXP_STORE") == 3 ? 3 : 2));     // non-temporal rows (fuse_common.h: store_out)
+    P.store_policy = tune.store < 0 ? 0 : (tune.store == 1 ? 1 : (tune.store == 3 ? 3 : 2));     // non-temporal rows (fuse_common.h: store_out)
     P.out_dist = out_dist; P.out_valid = out_valid;
     P.n = n; P.V = views->V; P.H = views->H; P.W = views->W;
     P.n_maps = n_maps; P.tile_pts = tile_points_for(views->V);
@@ -199,7 +174,7 @@ int eval_common(const d3f_views *views, const float *pts, int64_t n, const d3f_c
 
     Query q;
     q.views = views; q.n = n; q.n_maps = n_maps; q.flags = flags; q.mode = mode; q.lattice = lattice; q.grid = grid != nullptr;
-    q.plan_only = plan_only; q.cloud_side = cloud_side;
+    q.plan_only = plan_only; q.cloud_side = cloud_side; q.tune = tune;
     q.finite_expected = (flags & D3F_FLAG_FINITE_MAPS) || P.n_words > 0;
     q.direct = (flags & D3F_TUNE_DIRECT_GATHER) != 0;     // the plain direct gather in the chosen point order: the reference of the bit-identity tests
     q.tl = (int)((flags >> 8) & 0xF);
@@ -239,7 +214,7 @@ int eval_common(const d3f_views *views, const float *pts, int64_t n, const d3f_c
         } else {
             // Hilbert order of the cells of a 512^3 grid over the cloud's box, exact (order_kernels.hip); experiments builds: D3F_EXP_ORDER_MORTON=1 = the Z curve of rounds 1-4
             hipError_t eo = d3f::build_point_order(pts, n, workspace, workspace_bytes, &P.order, hs,
-                                                   (exp_knob("D3F_EXP_ORDER_MORTON") > 0 ? 1 : 0) | (exp_knob("D3F_EXP_SCAN3") > 0 ? 2 : 0) | (exp_knob("D3F_EXP_ORDER_FIXED_GRID") > 0 ? 4 : 0) | (exp_knob("D3F_EXP_ORDER_BITS") > 0 ? exp_knob("D3F_EXP_ORDER_BITS") << 8 : 0));
+                                                   (tune.order_morton > 0 ? 1 : 0) | (tune.scan3 > 0 ? 2 : 0) | (tune.order_fixed_grid > 0 ? 4 : 0) | (tune.order_bits > 0 ? tune.order_bits << 8 : 0));
             if (eo != hipSuccess) return hip_fail(eo, "point ordering");
         }
     }
@@ -267,8 +242,8 @@ int eval_common(const d3f_views *views, const float *pts, int64_t n, const d3f_c
     if (gated_window || gated_runs) {
         P.gate = d3f::order_gate_words(workspace, n);
         P.gate_min = (uint32_t)D3F_GATE_MIN_FIT;                   // three quarters of the sampled tiles fit their pool
-        if ((flags & D3F_TUNE_WINDOW_SIDE) || exp_knob("D3F_EXP_GATE") > 0) P.gate_min = 0u;          // always the window side
-        if (exp_knob("D3F_EXP_GATE") < 0) P.gate_min = 0xffffffffu;                                    // experiments: always the cell runs
+        if ((flags & D3F_TUNE_WINDOW_SIDE) || tune.gate > 0) P.gate_min = 0u;          // always the window side
+        if (tune.gate < 0) P.gate_min = 0xffffffffu;                                    // experiments: always the cell runs
         P.gate_want = gated_window ? 1 : 0;
     }
     hipEvent_t ev0 = g_prof_start, ev1 = gated_window ? nullptr : g_prof_stop;

@@ -42,11 +42,7 @@ template <> struct Raw<1, true> { using T = _Float16; };
 template <int VW, bool HALF> __device__ __forceinline__ typename Raw<VW, HALF>::T load_texel(const char *p)
 {
     static_assert(!HALF || VW == 8 || VW == 1, "fp16-stored maps use 8-channel (16-B) or scalar lanes");
-#ifdef D3F_NT_TEXEL_LOADS                              // what-if build (round 4): texels gathered with non-temporal loads
-    return __builtin_nontemporal_load(reinterpret_cast<const typename Raw<VW, HALF>::T *>(p));
-#else
     return *reinterpret_cast<const typename Raw<VW, HALF>::T *>(p);
-#endif
 }
 template <int VW, bool HALF> __device__ __forceinline__ typename Vec<VW>::T widen(typename Raw<VW, HALF>::T r)
 {

@@ -4,7 +4,7 @@
 // this file decides (no device work happens here), and tests/test_abi.py holds one assertion per row and threshold.
 //
 //   THE FAMILY TABLE (kFamilies below; walked top down, the first row whose predicate holds takes the query)
-//   family           kernel (fuse_eval.hip)            takes the query when                                                  point order
+//   family           kernel (fuse_<family>.hip)        takes the query when                                                  point order
 //   ---------------  --------------------------------  --------------------------------------------------------------------  --------------------------
 //   dist-only        fused_eval_kernel<MODE>           no channel maps (return_names=[], eval_dist)                          caller
 //   lds-window       fused_eval_window_kernel          the wide map is PATCH-resolution (texel >= 4 px), whole 128-channel     lattice: brick walk
@@ -19,8 +19,8 @@
 //   direct           fused_eval_kernel / _wide / _f16  everything else (and D3F_TUNE_DIRECT_GATHER / REFERENCE_ROUNDING)       caller, walk or Hilbert
 //
 // Thresholds (one test row each, tests/test_abi.py::test_plan_table): kSmallBatch, kWindowCloudMin, kCacheResidentBytes,
-// kBatchedLoadBytes, kBeyondLlcBytes.  Knobs named D3F_EXP_* exist in experiments builds only (exp_knob() is constant 0 in the
-// product); results never depend on any of this -- every family computes the same numbers (tests: bit-identity).
+// kBatchedLoadBytes, kBeyondLlcBytes.  The tuning knobs (struct Tune below) are all zero in the product build; an experiments
+// build overlays them from D3F_EXP_* environment variables; results never depend on any of this -- every family computes the same numbers (tests: bit-identity).
 #pragma once
 
 // ---- thresholds ----------------------------------------------------------------------------------------------------------------
@@ -39,6 +39,49 @@ constexpr int64_t kWindowCloudMin = 262144;
 constexpr int64_t kCacheResidentBytes = 64LL << 20;
 constexpr int64_t kBatchedLoadBytes = 128LL << 20;
 constexpr int64_t kBeyondLlcBytes = 512LL << 20;
+
+
+// ---- tuning knobs ----------------------------------------------------------------------------------------------------------------
+// One field per knob of the tuning sessions, all 0 = automatic in the product build (which reads no environment variable and keeps
+// no hidden state).  An experiments build (python -m d3fields_amd.build --experiments, -DD3F_EXPERIMENTS) overlays them from the
+// environment in load_tune(), the ONE place that does so.  Integers; results never depend on them.
+//   runs / runs_u / runs_occ / runs_tile   cell-run gather: -1 off, run length 2 / 4 / 8; vectors per lane 1..3; waves per SIMD of the (1,8) / (2,8) variants; tile points
+//   window (+ _u _vc _occ _pool _lpp _pipe _f16 _sparse _slack _want _rr)   LDS-window kernel: -1 never, 32 / 64 / 128 = always with that many points per
+//                      workgroup; vectors per lane, views in flight, workgroups per CU, pool texels, lanes per point, -1 = plain view loop, ...
+//   sliced (+ _vc _unit _ilv _tile _pad _f16 _cloud)   channel-sliced launch: 1 / 2 / 3 = 128- / 256- / 512-byte slices, -1 never
+//   walk / walk_tile   lattice brick walk: -1 off; tile shape as digits x y z (222 default, 224 with a thin map)
+//   thin               -1: thin maps through the view-sequential gather_map instead of gather_map_thin
+//   store              row-store policy: -1 plain, 1 sc1, 3 `sc1 nt`, default `nt` (fuse_common.h: store_out)
+//   gate               > 0 always the window side of a cloud's gate, < 0 always the cell runs
+//   order_morton / order_fixed_grid / order_bits / scan3   point ordering: the Z curve of rounds 1-4, the fixed 4-mm grid, prefix bits, the three-launch scan
+//   stamps             1: s_memtime phase stamps of the window kernel (d3f_exp_read_stamps)
+#define D3F_TUNE_KNOBS(X)                                                                                                          \
+    X(gate, "D3F_EXP_GATE") X(order_bits, "D3F_EXP_ORDER_BITS") X(order_fixed_grid, "D3F_EXP_ORDER_FIXED_GRID")                   \
+    X(order_morton, "D3F_EXP_ORDER_MORTON") X(runs, "D3F_EXP_RUNS") X(runs_occ, "D3F_EXP_RUNS_OCC") X(runs_tile, "D3F_EXP_RUNS_TILE") \
+    X(runs_u, "D3F_EXP_RUNS_U") X(scan3, "D3F_EXP_SCAN3") X(sliced, "D3F_EXP_SLICED") X(sliced_cloud, "D3F_EXP_SLICED_CLOUD")     \
+    X(sliced_f16, "D3F_EXP_SLICED_F16") X(sliced_ilv, "D3F_EXP_SLICED_ILV") X(sliced_pad, "D3F_EXP_SLICED_PAD")                   \
+    X(sliced_tile, "D3F_EXP_SLICED_TILE") X(sliced_unit, "D3F_EXP_SLICED_UNIT") X(sliced_vc, "D3F_EXP_SLICED_VC")                 \
+    X(stamps, "D3F_EXP_STAMPS") X(store, "D3F_EXP_STORE") X(thin, "D3F_EXP_THIN") X(walk, "D3F_EXP_WALK")                         \
+    X(walk_tile, "D3F_EXP_WALK_TILE") X(window, "D3F_EXP_WINDOW") X(window_f16, "D3F_EXP_WINDOW_F16")                             \
+    X(window_lpp, "D3F_EXP_WINDOW_LPP") X(window_occ, "D3F_EXP_WINDOW_OCC") X(window_pipe, "D3F_EXP_WINDOW_PIPE")                 \
+    X(window_pool, "D3F_EXP_WINDOW_POOL") X(window_rr, "D3F_EXP_WINDOW_RR") X(window_slack, "D3F_EXP_WINDOW_SLACK")               \
+    X(window_sparse, "D3F_EXP_WINDOW_SPARSE") X(window_u, "D3F_EXP_WINDOW_U") X(window_vc, "D3F_EXP_WINDOW_VC")                   \
+    X(window_want, "D3F_EXP_WINDOW_WANT")
+struct Tune {
+#define D3F_TUNE_FIELD(f, env) int f = 0;
+    D3F_TUNE_KNOBS(D3F_TUNE_FIELD)
+#undef D3F_TUNE_FIELD
+};
+inline Tune load_tune()
+{
+    Tune t;
+#ifdef D3F_EXPERIMENTS
+#define D3F_TUNE_ENV(f, env) if (const char *v = getenv(env)) t.f = atoi(v);
+    D3F_TUNE_KNOBS(D3F_TUNE_ENV)
+#undef D3F_TUNE_ENV
+#endif
+    return t;
+}
 
 // Phase-B lane mapping of one map: vector width, lanes per point (2^k) and vectors per lane.
 // Minimises idle lane-slots (passes*lpp*U - cvec), then passes, then prefers wide groups
@@ -88,6 +131,7 @@ struct Query {
     int tl;                         // D3F_TUNE_TILE_LOG2 (0 = automatic)
     int64_t map_bytes;              // all requested maps together
     bool want_inter[D3F_MAX_MAPS];  // '<k>_inter' requested for P.maps[k]
+    Tune tune;                      // all zero in the product build
     int cloud_side;                 // eval_common: 0 plan queries / ungated callers, 1 first pass (may gate), 2 the gated cell-run pass
 
     // would the points be walked in the Hilbert order?  (clouds; performance only)
@@ -99,7 +143,7 @@ struct Query {
     bool walk_possible() const
     {
         return lattice && 16.0 * ((lattice[1] + 1) / 2) * ((lattice[2] + 1) / 2) < 4294967296.0 && n_maps > 0 && n >= kSmallBatch &&
-               n <= 0x7fffffffLL && !(flags & D3F_TUNE_NO_REORDER) && exp_knob("D3F_EXP_WALK") >= 0;
+               n <= 0x7fffffffLL && !(flags & D3F_TUNE_NO_REORDER) && tune.walk >= 0;
     }
 };
 
@@ -114,14 +158,14 @@ struct Plan {
 };
 
 // ---- predicates on one map -----------------------------------------------------------------------------------------------------------
-// Cell-run gather (fuse_eval.hip gather_map_runs): fp32 maps read as 16-byte vectors with >= 32 vectors per texel whose
+// Cell-run gather (fuse_body.h gather_map_runs): fp32 maps read as 16-byte vectors with >= 32 vectors per texel whose
 // texels span >= 4 image pixels -- the patch-resolution feature maps of the reference (fusion.py:694-697).
 inline bool runs_candidate(const d3f::MapDesc &m, int H, int W)
 {
     return m.esize == 4 && m.vw == 4 && m.C >= 128 && (W - 1) >= 4 * (m.fw - 1) && (H - 1) >= 4 * (m.fh - 1);
 }
 
-// LDS texel windows (fuse_eval.hip fused_eval_window_kernel): a patch-resolution wide map in whole 128-channel slices whose texels
+// LDS texel windows (fuse_window.hip fused_eval_window_kernel): a patch-resolution wide map in whole 128-channel slices whose texels
 // start on 16-byte boundaries -- fp32 (512-byte slices), or stored in fp16 (256-byte slices, round 5: lattices only)
 inline bool window_candidate(const d3f::MapDesc &m, const d3f_views *views, bool check_pointer)
 {
@@ -193,9 +237,9 @@ inline int tile_points_for(int V)
     return t;
 }
 
-inline int window_tile_points()
+inline int window_tile_points(const Tune &tune)
 {
-    const int k = exp_knob("D3F_EXP_WINDOW");          // 0 automatic, -1 off, 32 / 64 / 128: points per workgroup (experiments)
+    const int k = tune.window;          // 0 automatic, -1 off, 32 / 64 / 128: points per workgroup (experiments)
     return (k == 32 || k == 64 || k == 128) ? k : 64;
 }
 
@@ -205,21 +249,21 @@ inline int window_tile_points()
 inline bool window_row(const Query &q, d3f::EvalParams &P)
 {
     const d3f_views *views = q.views;
-    const int win_knob = exp_knob("D3F_EXP_WINDOW");
+    const int win_knob = q.tune.window;
     const bool cloud_candidate = q.cloud_side == 1 && q.reorder_cloud() && q.n >= kWindowCloudMin && !(q.flags & D3F_TUNE_NO_WINDOW_GATE);
-    // default: lattices (a brick's windows are compact), and clouds through the device-side gate (fuse_eval.hip: gated_out);
+    // default: lattices (a brick's windows are compact), and clouds through the device-side gate (fuse_common.h: gated_out);
     // not when a cell-run variant is asked for explicitly
-    const bool automatic = win_knob == 0 && (q.lattice != nullptr || cloud_candidate) && exp_knob("D3F_EXP_RUNS") == 0 && exp_knob("D3F_EXP_RUNS_U") == 0;
+    const bool automatic = win_knob == 0 && (q.lattice != nullptr || cloud_candidate) && q.tune.runs == 0 && q.tune.runs_u == 0;
     const bool half0 = q.n_maps >= 1 && P.maps[0].esize == 2;      // fp16-stored: bricks of a lattice only (the cell-run side of a cloud's gate is fp32)
     bool window = (win_knob > 0 || automatic) && !q.direct && q.mode == 0 && q.n_maps >= 1 && q.finite_expected && q.n >= kSmallBatch &&
                   q.n <= 0x7fffffffLL && q.tl == 0 && views->V <= 8 && window_candidate(P.maps[0], views, !q.plan_only) &&
-                  (!half0 || (q.lattice != nullptr && exp_knob("D3F_EXP_WINDOW_F16") >= 0));
+                  (!half0 || (q.lattice != nullptr && q.tune.window_f16 >= 0));
     for (int s = 0; s < q.n_maps; ++s) window = window && !q.want_inter[s];
     for (int s = 1; s < q.n_maps; ++s) window = window && thin_fp32(P.maps[s]);
     if (!window) return false;
-    const int T = window_tile_points();
+    const int T = window_tile_points(q.tune);
     const int VP = views->V <= 1 ? 1 : views->V <= 2 ? 2 : views->V <= 4 ? 4 : 8;
-    int U = exp_knob("D3F_EXP_WINDOW_U");
+    int U = q.tune.window_u;
     const int cv = P.maps[0].C / 128;                  // 128-channel granules per texel (512 bytes of fp32, 256 of fp16)
     const int slot = P.maps[0].esize == 2 ? 256 : 512;
     if (U < 1 || U > 4 || cv % U != 0 || slot == 256) U = 1;
@@ -227,18 +271,18 @@ inline bool window_row(const Query &q, d3f::EvalParams &P)
     // per (point, view): 32-byte window record (+ the 16-byte view record when thin maps ride along); per point 20 bytes
     const int base = T * (views->V * 32 + 16) + (q.n_maps > 1 ? T * views->V * 16 : 0) + T * 20 + views->V * 48;     // records at a padded point stride
     const int pool_offset = (base + 511) / 512 * 512;
-    int occ = exp_knob("D3F_EXP_WINDOW_OCC");
+    int occ = q.tune.window_occ;
     const bool occ_forced = occ >= 5 && occ <= 6;        // experiments: 5 / 6 workgroups per CU with the plain point loop
     if (occ < 2 || occ > 6) occ = 4;
     if (U > 1) occ = 2;                                 // those variants are built for 2 workgroups per CU
     // touched-texel pool (SPARSE) for clouds, whole rectangles for lattice bricks (which never overflow: 0.42 vs 0.455 ms on
     // C2-patch); experiments builds: D3F_EXP_WINDOW_SPARSE = 1 / -1 forces either
-    P.win_sparse = exp_knob("D3F_EXP_WINDOW_SPARSE") > 0 ? 1 : (exp_knob("D3F_EXP_WINDOW_SPARSE") < 0 ? 0 : (q.lattice ? 0 : 1));
+    P.win_sparse = q.tune.window_sparse > 0 ? 1 : (q.tune.window_sparse < 0 ? 0 : (q.lattice ? 0 : 1));
     if (slot == 256) P.win_sparse = 0;
     // static LDS of the kernel + allocation granularity: 3 workgroups per CU stop fitting with less (measured, round 5)
-    const int slack = exp_knob("D3F_EXP_WINDOW_SLACK") > 0 ? exp_knob("D3F_EXP_WINDOW_SLACK") : (P.win_sparse ? 4096 : 2048);
+    const int slack = q.tune.window_slack > 0 ? q.tune.window_slack : (P.win_sparse ? 4096 : 2048);
     // slots per view worth a workgroup per CU: a brick's rectangles ~17; a cloud tile's touched texels ~12 (p90 14)
-    const int want = exp_knob("D3F_EXP_WINDOW_WANT") > 0 ? exp_knob("D3F_EXP_WINDOW_WANT") : (P.win_sparse ? 14 : 17);
+    const int want = q.tune.window_want > 0 ? q.tune.window_want : (P.win_sparse ? 14 : 17);
     int texels = 0;
     for (;; --occ) {
         const int budget = 160 * 1024 / occ - slack;
@@ -253,13 +297,13 @@ inline bool window_row(const Query &q, d3f::EvalParams &P)
         // 40 / 32 slots 0.72 / 0.81: ask for ~17 slots per view)
         if (texels >= want * views->V || occ == 2 || occ_forced) break;
     }
-    if (exp_knob("D3F_EXP_WINDOW_POOL") > 0 && exp_knob("D3F_EXP_WINDOW_POOL") < texels) texels = exp_knob("D3F_EXP_WINDOW_POOL");
-    if (texels > 320) texels = 320;                      // kWinMaxTexels (fuse_eval.hip)
+    if (q.tune.window_pool > 0 && q.tune.window_pool < texels) texels = q.tune.window_pool;
+    if (texels > 320) texels = 320;                      // kWinMaxTexels (fuse_window.hip)
     texels &= ~1;
     window = texels >= 2 && (T * VP) % 64 == 0 && q.n / T < 0x7fffffffLL;
     if (U > 1) P.win_lpp = 32;
     P.win_u = U; P.win_occ = occ; P.win_pool_offset = pool_offset; P.win_pool_texels = texels;
-    P.win_vc = exp_knob("D3F_EXP_WINDOW_VC") == 2 ? 2 : 1;
+    P.win_vc = q.tune.window_vc == 2 ? 2 : 1;
     P.win_slices = window ? cv / U : 0;
     return window;
 }
@@ -267,14 +311,14 @@ inline bool window_row(const Query &q, d3f::EvalParams &P)
 // geometry of the window launch (after the point order is decided)
 inline void window_geometry(const Query &q, d3f::EvalParams &P, Plan &pl)
 {
-    P.tile_pts = window_tile_points(); P.lds_pad = 0;
+    P.tile_pts = window_tile_points(q.tune); P.lds_pad = 0;
     if (pl.walk) pick_window_brick(P.walk_nx, P.walk_ny, P.walk_nz, P.tile_pts, P.walk_tx, P.walk_ty, P.walk_tz);
     for (int s = 1; s < q.n_maps; ++s) pick_mapping(P.maps[s], P.maps[s].vw == 4, P.maps[s].vw >= 2, true, 1);
     pl.xcd_remap = false;
     P.flags &= ~D3F_TUNE_XCD_REMAP;
     // a cloud's tiles go round-robin over the XCDs (all eight work on one neighbourhood: C2-patch cloud 0.52 ms against 0.58
     // with contiguous eighths, which is the lattice bricks' mapping); experiments builds: D3F_EXP_WINDOW_RR=-1 = eighths
-    if (!pl.walk && exp_knob("D3F_EXP_WINDOW_RR") >= 0) P.flags |= D3F_TUNE_XCD_REMAP;
+    if (!pl.walk && q.tune.window_rr >= 0) P.flags |= D3F_TUNE_XCD_REMAP;
 }
 
 // =================================================== family: cell-runs ============================================================
@@ -285,7 +329,7 @@ inline void window_geometry(const Query &q, d3f::EvalParams &P, Plan &pl)
 // is set and the other maps are re-mapped to one batched vector per lane (the kernel's register budget).
 inline bool runs_row(const Query &q, d3f::EvalParams &P, bool window_taken)
 {
-    const int knob = exp_knob("D3F_EXP_RUNS");
+    const int knob = q.tune.runs;
     bool blocked = window_taken || q.direct || knob < 0 || !q.finite_expected || q.n < kSmallBatch || q.tl != 0;
     for (int s = 0; s < q.n_maps; ++s)
         blocked |= P.maps[s].esize == 2 || q.want_inter[s] ||
@@ -293,7 +337,7 @@ inline bool runs_row(const Query &q, d3f::EvalParams &P, bool window_taken)
     bool any_runs = false;
     for (int s = 0; s < q.n_maps && !blocked && !any_runs; ++s)
         if (runs_candidate(P.maps[s], q.views->H, q.views->W)) {
-            pick_runs_mapping(P.maps[s], exp_knob("D3F_EXP_RUNS_U"), knob);
+            pick_runs_mapping(P.maps[s], q.tune.runs_u, knob);
             any_runs = true;
         }
     if (any_runs)
@@ -313,7 +357,7 @@ inline void runs_geometry(const Query &q, d3f::EvalParams &P)
     // batches of less than ~2 workgroups per slot (256 CUs x 7): halve the tile so that the tail is shorter
     // (100 k keypoints: 0.126 -> 0.119 ms; the 985 600-point grid is slower with 32-point tiles: 0.632 -> 0.655)
     if (q.n / P.tile_pts < 4096 && P.tile_pts / 2 >= round) P.tile_pts /= 2;
-    if (exp_knob("D3F_EXP_RUNS_TILE") >= round) P.tile_pts = exp_knob("D3F_EXP_RUNS_TILE");
+    if (q.tune.runs_tile >= round) P.tile_pts = q.tune.runs_tile;
     while ((long)P.tile_pts * q.views->V * 88 > 40 * 1024 && P.tile_pts > round) P.tile_pts >>= 1;   // records + 2 corner slots
     P.lds_pad = 0;
 }
@@ -348,7 +392,7 @@ inline void direct_geometry(const Query &q, d3f::EvalParams &P, Plan &pl)
         P.tile_pts = thin ? 16 : 8; P.lds_pad = 0; pl.xcd_remap = true;
         if (pl.walk) {                                   // the tile is a brick of the lattice
             P.walk_tx = 2; P.walk_ty = 2; P.walk_tz = thin ? 4 : 2;
-            const int shape = exp_knob("D3F_EXP_WALK_TILE");      // experiment: digits x y z, e.g. 224, 144, 422
+            const int shape = q.tune.walk_tile;      // experiment: digits x y z, e.g. 224, 144, 422
             if (shape >= 111 && shape <= 888 && (shape / 100) * (shape / 10 % 10) * (shape % 10) == P.tile_pts && shape / 10 % 10 > 0 && shape % 10 > 0) {
                 P.walk_tx = shape / 100; P.walk_ty = shape / 10 % 10; P.walk_tz = shape % 10;
             }
@@ -372,7 +416,7 @@ inline void direct_geometry(const Query &q, d3f::EvalParams &P, Plan &pl)
 }
 
 // =================================================== family: channel-sliced =======================================================
-// Channel-sliced launch (fuse_eval.hip): a lattice walk (or the Hilbert order of a cloud) on a dense wide map that is the FIRST map
+// Channel-sliced launch (fuse_sliced.hip): a lattice walk (or the Hilbert order of a cloud) on a dense wide map that is the FIRST map
 // of the launch; any other map must be thin (it rides along with slice 0).  512-byte slices of fp32 (256-byte ones of fp16: 16 lanes
 // x 8 channels), two views in flight; a wide map WITH thin companions takes 32 points per workgroup (C3-dense, features + 8-channel
 // mask: 3.04 -> 2.80 ms -- the whole-texel kernel stalls on the thin map's gather, 16 points x 2 lanes per workgroup), a wide map
@@ -383,20 +427,20 @@ inline void direct_geometry(const Query &q, d3f::EvalParams &P, Plan &pl)
 inline bool sliced_row(const Query &q, d3f::EvalParams &P, const Plan &pl)
 {
     const d3f_views *views = q.views;
-    int sl = exp_knob("D3F_EXP_SLICED");
+    int sl = q.tune.sliced;
     bool thin_rest = true;
     for (int s = 1; s < q.n_maps; ++s) thin_rest = thin_rest && P.maps[s].C * P.maps[s].esize <= 256 && P.maps[s].esize == 4;
     const bool half_sl = q.n_maps >= 1 && P.maps[0].esize == 2;      // fp16-stored wide map: 16 lanes x 8 channels = 128-channel slices
     const bool automatic = sl == 0 && thin_rest && q.n_maps >= 1 && P.maps[0].C % 128 == 0 && P.maps[0].C <= 1024 &&
-                           (!half_sl || exp_knob("D3F_EXP_SLICED_F16") >= 0);
+                           (!half_sl || q.tune.sliced_f16 >= 0);
     if (automatic) sl = half_sl ? 2 : 3;
     if (half_sl && sl != 2) sl = 0;
     // ... or the Hilbert order of a cloud on maps beyond the caches (tiles of 16 / 32 consecutive points of the order)
-    const bool cloud = pl.reorder && !pl.walk && !pl.runs && q.map_bytes > kCacheResidentBytes && exp_knob("D3F_EXP_SLICED_CLOUD") >= 0;
+    const bool cloud = pl.reorder && !pl.walk && !pl.runs && q.map_bytes > kCacheResidentBytes && q.tune.sliced_cloud >= 0;
     bool ok = (pl.walk || cloud) && !pl.window && !q.direct && (sl >= 1 && sl <= 3) && q.mode == 0 && q.n_maps >= 1 &&
               ((P.maps[0].esize == 4 && P.maps[0].vw == 4) || (half_sl && P.maps[0].vw == 8 && P.maps[0].fold)) && !q.want_inter[0] && q.tl == 0;
     const int lg = sl + 2, lanes = 1 << lg;      // 1: 8 lanes (128-byte slices), 2: 16 lanes, 3: 32 lanes (512 bytes)
-    P.sl_vc = exp_knob("D3F_EXP_SLICED_VC") > 0 ? exp_knob("D3F_EXP_SLICED_VC") : (automatic ? 2 : 4);
+    P.sl_vc = q.tune.sliced_vc > 0 ? q.tune.sliced_vc : (automatic ? 2 : 4);
     if (half_sl) P.sl_vc = 2;
     const int cpl = half_sl ? 8 : 4;              // channels per lane (one 16-byte vector)
     ok = ok && P.maps[0].C % (cpl * lanes) == 0 && P.maps[0].C >= 128;
@@ -405,14 +449,14 @@ inline bool sliced_row(const Query &q, d3f::EvalParams &P, const Plan &pl)
     const int keep_tile = P.tile_pts, keep_pad = P.lds_pad, keep_t[3] = {P.walk_tx, P.walk_ty, P.walk_tz};
     d3f::MapDesc keep_maps[D3F_MAX_MAPS];
     for (int s = 0; s < q.n_maps; ++s) keep_maps[s] = P.maps[s];
-    const int tile_knob = exp_knob("D3F_EXP_SLICED_TILE");
+    const int tile_knob = q.tune.sliced_tile;
     const bool big = tile_knob == 64;                            // experiment: 64 points per workgroup (four 2x2x4 tiles)
     const bool tiny = tile_knob == 16 || (tile_knob == 0 && q.n_maps == 1);   // 16 points per workgroup (four 2x2x1 tiles)
     const bool mini = tile_knob == 8;                            // experiment: 8 points per workgroup (four 2x1x1 tiles)
     P.walk_tx = 2; P.walk_ty = mini ? 1 : 2; P.walk_tz = big ? 4 : ((tiny || mini) ? 1 : 2);
     P.sl_lg = lg;
     P.sl_slices = P.maps[0].C / (cpl * lanes);
-    P.tile_pts = big ? 64 : (tiny ? 16 : (mini ? 8 : 32)); P.lds_pad = exp_knob("D3F_EXP_SLICED_PAD") > 0 ? exp_knob("D3F_EXP_SLICED_PAD") * 1024 : 0;
+    P.tile_pts = big ? 64 : (tiny ? 16 : (mini ? 8 : 32)); P.lds_pad = q.tune.sliced_pad > 0 ? q.tune.sliced_pad * 1024 : 0;
     if (pl.walk) {
         P.sl_tiles = (int64_t)((P.walk_nx + 1) / 2) * ((P.walk_ny + P.walk_ty - 1) / P.walk_ty) * ((P.walk_nz + P.walk_tz - 1) / P.walk_tz);
         P.sl_groups = (P.sl_tiles + 3) / 4;
@@ -420,9 +464,9 @@ inline bool sliced_row(const Query &q, d3f::EvalParams &P, const Plan &pl)
         P.sl_tiles = 0;
         P.sl_groups = (q.n + P.tile_pts - 1) / P.tile_pts;
     }
-    P.sl_unit = exp_knob("D3F_EXP_SLICED_UNIT") > 0 ? exp_knob("D3F_EXP_SLICED_UNIT") : (big ? 64 : (tiny ? 256 : (mini ? 512 : 128)));   // 4096 points per unit (smaller: slower)
+    P.sl_unit = q.tune.sliced_unit > 0 ? q.tune.sliced_unit : (big ? 64 : (tiny ? 256 : (mini ? 512 : 128)));   // 4096 points per unit (smaller: slower)
     P.sl_chunks = (P.sl_groups + P.sl_unit - 1) / P.sl_unit;
-    P.sl_ilv = exp_knob("D3F_EXP_SLICED_ILV") >= 2 && exp_knob("D3F_EXP_SLICED_ILV") <= 4 ? exp_knob("D3F_EXP_SLICED_ILV") : 1;
+    P.sl_ilv = q.tune.sliced_ilv >= 2 && q.tune.sliced_ilv <= 4 ? q.tune.sliced_ilv : 1;
     for (int s = 1; s < q.n_maps; ++s) pick_mapping(P.maps[s], P.maps[s].vw == 4, P.maps[s].vw >= 2, true, 1);
     if ((((P.sl_chunks * P.sl_slices + 7) / 8) + P.sl_ilv) * 8 * P.sl_unit > 0x7fffffffLL) P.sl_slices = 0;
     // its dynamic LDS (records + one corner record per (point, view)) must fit the 64 KiB a launch gets without opting in:

@@ -51,9 +51,6 @@ __device__ __forceinline__ void gather_map_runs(const MapDesc &m, const EvalPara
             for (int k = 0; k < K; ++k)
 #pragma unroll
                 for (int u = 0; u < U; ++u) acc[k][u] = (VT)0.0f;
-#if D3F_RUNS_PREFETCH
-            uint32_t dead = 0u;
-#endif
 #pragma unroll 1
             for (int v = 0; v < V; ++v) {          // kept rolled: unrolled views let the scheduler interleave them and spill
                 const char *bv = data + (int64_t)v * m.sv * 4;
@@ -66,23 +63,6 @@ __device__ __forceinline__ void gather_map_runs(const MapDesc &m, const EvalPara
                     const int q = min((run0 + k) * V + v, last);      // beyond the tile: some valid record, result unused
                     const uint32_t st = state_s[q];
                     const CornerRec &cr = crec[q];
-#if D3F_RUNS_PREFETCH       // what-if build (round 5): touch the NEXT point's new cell one step ahead (dword loads into a dead register)
-                    if (k + 1 < K && run0 + k + 1 < tile_n) {
-                        const int qn = q + V;
-                        if ((state_s[qn] & (kRunValid | kRunNewCell)) == (kRunValid | kRunNewCell)) {
-                            const CornerRec &cn = crec[qn];
-#pragma unroll
-                            for (int u = 0; u < U; ++u) {
-                                // "+v": ONE register stays reserved for the in-flight dwords until the sink below (a "=v" output would
-                                // be reallocated at once and the late load would land in somebody else's register)
-                                asm volatile("global_load_dword %0, %1, %2" : "+v"(dead) : "v"(cn.o[0] + co[u]), "s"(bv) : "memory");
-                                asm volatile("global_load_dword %0, %1, %2" : "+v"(dead) : "v"(cn.o[1] + co[u]), "s"(bv) : "memory");
-                                asm volatile("global_load_dword %0, %1, %2" : "+v"(dead) : "v"(cn.o[2] + co[u]), "s"(bv) : "memory");
-                                asm volatile("global_load_dword %0, %1, %2" : "+v"(dead) : "v"(cn.o[3] + co[u]), "s"(bv) : "memory");
-                            }
-                        }
-                    }
-#endif
                     if (inside && (st & (kRunValid | kRunNewCell)) == (kRunValid | kRunNewCell)) {     // another texel cell
                         const uint32_t o0 = cr.o[0], o1 = cr.o[1], o2 = cr.o[2], o3 = cr.o[3];
 #pragma unroll
@@ -108,9 +88,6 @@ __device__ __forceinline__ void gather_map_runs(const MapDesc &m, const EvalPara
                     for (int u = 0; u < U; ++u) asm volatile("" : "+v"(acc[k][u]) : : "memory");
                 }
             }
-#if D3F_RUNS_PREFETCH
-            asm volatile("s_waitcnt vmcnt(0)" : "+v"(dead) : : "memory");      // the sink of the touch loads
-#endif
 #pragma unroll
             for (int k = 0; k < K; ++k) {
                 const int p = run0 + k;

@@ -166,12 +166,9 @@ __device__ __forceinline__ bool maps_are_finite(const EvalParams &P)
 // write) had bought 1 % over plain ones (policy 0); experiments builds: D3F_EXP_STORE=1 / -1.
 // One 16-byte piece of an output row, non-temporal and write-through: `global_store_dwordx4 ... sc1 nt` (no builtin emits the
 // pair; `nt` alone is __builtin_nontemporal_store).  s_nop 1: see store_out.
-#ifndef D3F_ROW_STORE_BITS
-#define D3F_ROW_STORE_BITS "sc1 nt"                 // what-if builds override the bits: -DD3F_ROW_STORE_BITS='"sc0 sc1 nt"'
-#endif
 __device__ __forceinline__ void store_row_vec(void *p, f32x4 v)
 {
-    asm volatile("global_store_dwordx4 %0, %1, off " D3F_ROW_STORE_BITS "\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
+    asm volatile("global_store_dwordx4 %0, %1, off sc1 nt\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
 }
 
 template <typename VT>
@@ -207,7 +204,7 @@ __device__ __forceinline__ void store_out_off(float *base, uint32_t off, f32x4 v
         return;
     }
     if (policy == 3) {
-        asm volatile("global_store_dwordx4 %0, %1, %2 " D3F_ROW_STORE_BITS "\n\ts_nop 1" ::"v"(off), "v"(v), "s"(base) : "memory");
+        asm volatile("global_store_dwordx4 %0, %1, %2 sc1 nt\n\ts_nop 1" ::"v"(off), "v"(v), "s"(base) : "memory");
         return;
     }
     if (policy == 2) {
@@ -421,12 +418,7 @@ __device__ __forceinline__ void gather_map_thin(const MapDesc &m, const EvalPara
         if (v < V) {
             const ViewRec r = rec[p * V + v];
             if (strict || r.valid != 0.0f) {
-#ifdef D3F_THIN_WHATIF                              // what-if build: every lane reads its view's first texel (one cache line per instruction)
-                Corner c = corner_setup(m, r.gx, r.gy);
-                c.onw &= 0u; c.one &= 0u; c.osw &= 0u; c.ose &= 0u;
-#else
                 const Corner c = corner_setup(m, r.gx, r.gy);
-#endif
                 const char *bv = reinterpret_cast<const char *>(m.data) + (int64_t)v * m.sv * 4;
                 const VT a = load_texel<VW, false>(bv + (c.onw + co));
                 const VT b = load_texel<VW, false>(bv + (c.one + co));

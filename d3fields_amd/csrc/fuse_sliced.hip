@@ -6,9 +6,6 @@
 #include "d3f_device.h"
 #include "fuse_common.h"
 
-#ifndef D3F_SLICED_WHATIF      // what-if builds of the channel-sliced kernel (scripts/notebook/build_ablate.py --sliced): 1 phase A without the
-#define D3F_SLICED_WHATIF 0    // depth lookup / weights, 4 no gather (results wrong by construction; only times are read)
-#endif
 
 namespace d3f {
 
@@ -103,12 +100,7 @@ __device__ __forceinline__ void fused_eval_sliced_body(const EvalParams &P)
             if (act) {
                 float px, py, pz;
                 fetch_point(P, i, px, py, pz);
-#if D3F_SLICED_WHATIF & 1       // what-if build (round 5): phase A without the depth lookup, the validity test and the weight (every pair valid)
-                const Proj pr = project_point(krt + v * 12, px, py, pz, Wm1, Hm1);
-                o.gx = pr.gx; o.gy = pr.gy; o.dist = 0.0f; o.valid = 1.0f; wgt = 1.0f;
-#else
                 o = eval_view<0>(P.depth, P.H, P.W, krt + v * 12, v, px, py, pz, Wm1, Hm1, mu, wgt);
-#endif
                 if (!(isfinite(o.gx) && isfinite(o.gy) && isfinite(wgt))) st = 1u;
             }
             float dsum, cnt;
@@ -161,9 +153,6 @@ __device__ __forceinline__ void fused_eval_sliced_body(const EvalParams &P)
             const float denom = cnt + 1e-6f;
             const bool strict = flag_s[p] != 0u;
             VT acc = (VT)0.0f, acc2 = (VT)0.0f;                              // (acc2: channels 4..7 of a fp16 vector)
-#if D3F_SLICED_WHATIF & 4       // what-if build: no gather at all (phase A + the row stores)
-            if (true) { store_out<VT>(m.out + i * m.C + (co >> 2), acc, P.store_policy); continue; }
-#endif
             auto accumulate = [&](RT t, float w) {
                 if constexpr (HALF) fma_mix8(acc, acc2, t, w);
                 else acc = v_fma<VT>(t, w, acc);

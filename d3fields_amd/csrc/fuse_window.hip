@@ -135,12 +135,8 @@ __device__ __forceinline__ void window_point(f32x4 (&acc)[NV], const unsigned ch
 // arithmetic.  Same operands in the same order as window_point: bit-identical.
 //   rec0      LDS byte offset of the first point's first record;  KSTRIDE bytes between the lane group's consecutive points
 //   done(k, acc)  called once per point, after its last view
-// what-if builds of tuning sessions (scripts/notebook/build_ablate.py: -DD3F_WIN_ABLATE=bits; parts of the window kernel left out, results
-// wrong by construction, only times are read): 1 no copies after slice 0, 2 no point loop, 4 rows stored over each other in
-// 8 MiB (no HBM writes), 8 corner reads without the arithmetic, 16 the arithmetic without the corner reads
-#ifndef D3F_WIN_ABLATE
-#define D3F_WIN_ABLATE 0
-#endif
+// (The what-if builds of the tuning sessions -- parts of this kernel compiled out, only times read -- are a patch:
+// scripts/notebook/patches/r6_whatif_macros.patch.)
 
 template <int NV, bool HALF>
 struct WinPipe {            // registers of the pipeline; every index below is a compile-time constant
@@ -165,15 +161,6 @@ __device__ __forceinline__ void win_pipe_corners(WinPipe<NV, HALF> &st, const un
     constexpr int NR = NV;
     const unsigned char *nw = smem + (st.off[J % 3].x + lane_off);
     const unsigned char *sw = smem + (st.off[J % 3].y + lane_off);
-#if D3F_WIN_ABLATE & 16
-    static_assert(!HALF, "what-if builds: fp32 maps only");
-#pragma unroll
-    for (int u = 0; u < NV; ++u) {
-        st.c[J % 2][0][u] = st.wt[J % 3]; st.c[J % 2][1][u] = st.wt[(J + 1) % 3]; st.c[J % 2][2][u] = st.wt[(J + 2) % 3]; st.c[J % 2][3][u] = st.wt[J % 3];
-        asm volatile("" : "+v"(st.c[J % 2][0][u]), "+v"(st.c[J % 2][1][u]), "+v"(st.c[J % 2][2][u]), "+v"(st.c[J % 2][3][u]) : "v"(nw), "v"(sw));
-    }
-    return;
-#endif
 #pragma unroll
     for (int u = 0; u < NR; ++u) {
         st.c[J % 2][0][u] = *reinterpret_cast<const RT *>(nw + u * VS);
@@ -190,18 +177,10 @@ __device__ __forceinline__ void win_pipe_step(WinPipe<NV, HALF> &st, const unsig
     constexpr int NS = KI * VF;
     if constexpr (J + 2 < NS) win_pipe_record<J + 2, NV, VF, KI, VS, SBB, KSTRIDE, HALF>(st, smem, rec0);
     if constexpr (J + 1 < NS) win_pipe_corners<J + 1, NV, VS, SBB, HALF>(st, smem, lane_off);
-#if D3F_WIN_ABLATE & 8
-#pragma unroll
-    for (int u = 0; u < NV; ++u) {
-        asm volatile("" :: "v"(st.c[J % 2][0][u]), "v"(st.c[J % 2][1][u]), "v"(st.c[J % 2][2][u]), "v"(st.c[J % 2][3][u]));
-        st.acc[u] = st.wt[J % 3];
-    }
-#else
     win_accumulate<NV, HALF>(st.acc, st.c[J % 2][0], st.wt[J % 3].x);        // folded weights (fuse_common.h): nw, ne, sw, se
     win_accumulate<NV, HALF>(st.acc, st.c[J % 2][1], st.wt[J % 3].y);
     win_accumulate<NV, HALF>(st.acc, st.c[J % 2][2], st.wt[J % 3].z);
     win_accumulate<NV, HALF>(st.acc, st.c[J % 2][3], st.wt[J % 3].w);
-#endif
     if constexpr (J % VF == VF - 1) {
         done(J / VF, st.acc);
 #pragma unroll
@@ -728,16 +707,10 @@ __device__ __forceinline__ void fused_eval_window_body(const EvalParams &P)
         D3F_STAMP();                                // 5 + 3 sl: pool of this slice ready
         const uint32_t co = (uint32_t)sl * SB + lane_off;               // byte offset of this lane's first vector in a texel
         const uint32_t oco = (uint32_t)sl * OSB + (uint32_t)l * 16u;             // ... of its first four channels in an output row (fp32)
-#if D3F_WIN_ABLATE & 2
-        if (false)
-#endif
         if (pipe_ok) {
             window_points_pipelined<NV, (VFIX > 0 ? VFIX : 1), KI, VS, (int)SB, G * ((VFIX > 0 ? VFIX : 1) * 32 + 16), HALF>(
                 smem, (uint32_t)grp * pstride, lane_off, [&](int k, const VT (&acc)[NV]) {
                     char *row = out_bytes + ((uint64_t)pidx[k] * row_bytes + oco);
-#if D3F_WIN_ABLATE & 4
-                    row = out_bytes + ((uint64_t)(threadIdx.x + 256u * (blockIdx.x & 1023u)) * 32u);
-#endif
 #pragma unroll
                     for (int u = 0; u < NV; ++u) store_row_vec(row + u * OVS, acc[u]);
                 });
@@ -759,9 +732,7 @@ __device__ __forceinline__ void fused_eval_window_body(const EvalParams &P)
         if (sl + 1 < S) {
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // LDS only: everyone is done with this slice's pool
             D3F_STAMP();                            // 7 + 3 sl: all waves done
-#if !(D3F_WIN_ABLATE & 1)
             stage(sl + 1);
-#endif
         } else {
             D3F_STAMP();
         }

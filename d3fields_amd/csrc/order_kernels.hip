@@ -5,12 +5,12 @@
 // Cache) the fused kernel is bound by texel re-fetches; points that are close in 3-D project
 // close together in EVERY view, so walking the points along a space-filling curve keeps the in-flight
 // texel footprint compact (measured 3.2 -> 2.8 ms on the 985 600-point grid, 3.4 -> 2.6 ms on a
-// shuffled cloud).  Grids do not come here at all (closed-form brick walk, fuse_eval.hip); this is the path of clouds.
+// shuffled cloud).  Grids do not come here at all (closed-form brick walk, fuse_common.h); this is the path of clouds.
 //
 // Round 5: the curve is a HILBERT curve and the order inside a counting cell is exact.  Rounds 1-4 walked a Morton (Z)
 // curve, whose consecutive cells are up to a whole parent cell apart at every octant boundary: 64 consecutive points of it
 // -- one workgroup's tile -- then span a box several cells wide, and the LDS texel windows of the window kernel
-// (fuse_eval.hip) overflow their pool on 2 tiles of 3 (scripts/notebook/sim_cloud_tiles.py: C2-patch cloud, 66 % of the tiles over
+// (fuse_window.hip) overflow their pool on 2 tiles of 3 (scripts/notebook/sim_cloud_tiles.py: C2-patch cloud, 66 % of the tiles over
 // an 80-slot pool, 18 % of the valid (point, view) pairs outside their window; Hilbert: 19 % / 2.9 %), which is why the
 // window kernel lost on clouds.  Consecutive cells of a Hilbert curve always share a face, at every level, so ANY run of
 // consecutive points is a compact blob.  Any prefix of the key is still a valid coarser cell (the curve is hierarchical).
@@ -105,7 +105,7 @@ __global__ __launch_bounds__(kBlock) void order_clear_kernel(uint32_t *__restric
                                                             uint32_t *__restrict__ status, int status_words)
 {
     reinterpret_cast<uint4 *>(table)[(int64_t)blockIdx.x * kBlock + threadIdx.x] = make_uint4(0u, 0u, 0u, 0u);
-    if (blockIdx.x == 0 && threadIdx.x < 4) gate[threadIdx.x] = 0u;       // the window / cell-run gate of this order (fuse_eval.hip)
+    if (blockIdx.x == 0 && threadIdx.x < 4) gate[threadIdx.x] = 0u;       // the window / cell-run gate of this order (fuse_window.hip)
     if (blockIdx.x == 0 && threadIdx.x >= 8 && threadIdx.x < 14)           // the box: lo = +max, hi = -max
         gate[kBoxWord + threadIdx.x - 8] = threadIdx.x < 11 ? 0xffffffffu : 0u;
     if (blockIdx.x == 1 || gridDim.x == 1)                                 // the status words of the single-launch scan

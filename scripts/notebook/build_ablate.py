@@ -1,7 +1,8 @@
-"""Builds the what-if variants of the window kernel for a tuning session: build_ab/ablate_<bits>.so with -DD3F_WIN_ABLATE=<bits>
-(fuse_eval.hip: 1 no copies after slice 0, 2 no point loop, 4 rows stored over each other (no HBM writes), 8 corner reads without
-arithmetic, 16 arithmetic without corner reads).  Results of these libraries are wrong by construction; only times are read.
-    D3F_BUILD_EXPERIMENTS=1 python scripts/build_ablate.py 0 1 4 8 16"""
+"""Builds the what-if variants of the window / sliced / cell-run kernels for a tuning session: build_ab/<tag>_<bits>.so.
+Apply scripts/notebook/patches/r6_whatif_macros.patch first (the product sources carry no what-if blocks since round 6):
+-DD3F_WIN_ABLATE=<bits>: 1 no copies after slice 0, 2 no point loop, 4 rows stored over each other (no HBM writes), 8 corner reads without
+arithmetic, 16 arithmetic without corner reads.  Results of these libraries are wrong by construction; only times are read.
+    D3F_BUILD_EXPERIMENTS=1 python scripts/notebook/build_ablate.py 0 1 4 8 16"""
 import os, shutil, sys
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
 from d3fields_amd import build
