@@ -338,6 +338,10 @@ def main():
     ap.add_argument("--cpu-threads", type=int, default=0, help="0 = min(host cores, 64)")
     ap.add_argument("--force-dist", action="store_true", help="run the multi-rank code path even with one rank (self-spawned under "
                                                                "torch.distributed.run): RCCL initialisation, barrier, all-gathers")
+    ap.add_argument("--points-per-gpu", type=int, default=0, help="use only the first K points of the rank's point set (0 = the workload's "
+                    "own size): the reduced-N dry run of a multi-rank launch (tests/test_gpu_sharding.py); not a benchmark configuration")
+    ap.add_argument("--ragged", action="store_true", help="with --points-per-gpu K: rank r takes K - r points (unequal shards: the grouped "
+                    "point-to-point form of the all-gather)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend; 'gloo' lets the N>1 code path be "
                     "exercised with several ranks on ONE GPU (testing only)")
     args = ap.parse_args()
@@ -358,6 +362,11 @@ def main():
         raise SystemExit(spawn_ranks(args.gpus, sys.argv[1:]))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the product path)")
+    if dist_on and args.backend == "nccl" and world > torch.cuda.device_count():
+        # RCCL needs one GPU per rank: wrapping local ranks onto fewer devices would hang or fail inside the first collective
+        # (and would not be the run the line claims).  Several ranks on one GPU exist for testing only: --backend gloo.
+        raise SystemExit("bench.py: --gpus %d with backend nccl (RCCL) needs %d visible GPUs, this node shows %d (rank %d); "
+                         "use --backend gloo to exercise the multi-rank path on fewer devices" % (world, world, torch.cuda.device_count(), rank))
     dev = torch.device("cuda", local % torch.cuda.device_count())
     torch.cuda.set_device(dev)
     if dist_on:
@@ -386,8 +395,15 @@ def main():
     # probes of a query of the same size, so a steady-state step holds NO host sync (only the first query of a size
     # waits once) -- and the cached figure is reported separately below.
     f.cache_point_order = False
+    if args.points_per_gpu > 0:
+        pts = pts[:max(1, args.points_per_gpu - (rank if args.ragged else 0))].contiguous()
     n = pts.shape[0]
     from d3fields_amd import sharding
+    counts = [n] * world                    # points per rank (equal unless --ragged)
+    if dist_on:
+        import torch.distributed as dist
+        dist.all_gather_object(counts, n)
+        counts = [int(c) for c in counts]
 
     corr_src = None
     if w.get("corr_refs"):
@@ -410,7 +426,7 @@ def main():
         if corr_src is not None:        # keypoint descriptors vs reference descriptors: softmax similarity + best match
             if dist_on:                 # softmax(dim=0) runs over ALL ranks' keypoints: one 16-B record per reference exchanged
                 out["similarity"], out["match"] = sharding.sharded_similarity_multi(out["dino_feats"], corr_src, 1.0,
-                                                                                    row_offset=rank * n)
+                                                                                    row_offset=sum(counts[:rank]))
             else:
                 out["similarity"], out["match"] = corr_utils.nearest_descriptor(out["dino_feats"], corr_src, 1.0)
         return out
@@ -432,18 +448,18 @@ def main():
         if dist_on and args.gather != "none":
             keys = ("dist", "valid_mask") if args.gather == "dist" else tuple(k for k in out if k != "match")
             gather_keys["keys"] = keys
-            gather_keys["bytes"] = sharding.gather_bytes(out, keys, [n] * world)
+            gather_keys["bytes"] = sharding.gather_bytes(out, keys, counts)
             if args.no_overlap:
-                sharding.all_gather_field({k: out[k] for k in keys}, keys=keys, counts=[n] * world)
+                sharding.all_gather_field({k: out[k] for k in keys}, keys=keys, counts=counts)
             else:
                 drain(keep=1)                              # gather k-2 must be done before gather k is enqueued
                 try:
-                    full, works = sharding.all_gather_field({k: out[k] for k in keys}, keys=keys, counts=[n] * world,
+                    full, works = sharding.all_gather_field({k: out[k] for k in keys}, keys=keys, counts=counts,
                                                             async_op=True)
                 except Exception as exc:                   # a backend without async all-gather: block instead (reported)
                     args.no_overlap = True
                     overlap_error.append(repr(exc))
-                    sharding.all_gather_field({k: out[k] for k in keys}, keys=keys, counts=[n] * world)
+                    sharding.all_gather_field({k: out[k] for k in keys}, keys=keys, counts=counts)
                     return out
                 pending.append((works, (out, full)))       # inputs and outputs stay alive until the wait
         return out
@@ -479,16 +495,16 @@ def main():
                 extra["points_per_s_with_static_maps"] = n * args.steps / time_steps(compute, args.steps, False, dev)
                 frames[0] = keep
         if dist_on:
-            extra["compute_only_points_per_s"] = world * n * args.steps / time_steps(compute, args.steps, True, dev)
+            extra["compute_only_points_per_s"] = sum(counts) * args.steps / time_steps(compute, args.steps, True, dev)
             if args.gather != "full":
                 def full():
                     o = compute()
-                    sharding.all_gather_field(o, keys=[k for k in o if k != "match"], counts=[n] * world)
+                    sharding.all_gather_field(o, keys=[k for k in o if k != "match"], counts=counts)
                 full()
                 fs = max(2, args.steps // 4)
-                extra["full_field_gather_points_per_s"] = world * n * fs / time_steps(full, fs, True, dev)
+                extra["full_field_gather_points_per_s"] = sum(counts) * fs / time_steps(full, fs, True, dev)
             else:
-                extra["full_field_gather_points_per_s"] = world * n * args.steps / wall
+                extra["full_field_gather_points_per_s"] = sum(counts) * args.steps / wall
             # the north star's "reassemble the full field": every output of every point on every GPU
             extra["value_full_field"] = extra["full_field_gather_points_per_s"]
             if rank == 0 and extra.get("single_rank_points_per_s_same_workload"):
@@ -518,7 +534,7 @@ def main():
         names_all = [None] * world
         dist.all_gather_object(names_all, "rank %d: cuda:%d %s" % (rank, dev.index, torch.cuda.get_device_name(dev)))
         rank_devices = names_all
-    total_pts = world * n * args.steps
+    total_pts = sum(counts) * args.steps
     value = total_pts / wall
     bytes_alg, per_pt = algorithmic_bytes(w, n)
     traffic, traffic_src, valu_insts = measured_traffic(args.workload, args.points if w["step"] is not None else "grid", n)
@@ -541,7 +557,7 @@ def main():
                    "points": ("grid" if (w["step"] is not None and args.points == "grid") else
                               ("surface cloud: lattice points with valid_mask & |dist| < step, flat-index order (vis_repr.py:97-103)"
                                if args.points == "surface" else "random cloud")),
-                   "points_per_gpu": n, "views": w["V"], "feature_dim": w["C"], "feature_map": list(w["fhw"]),
+                   "points_per_gpu": n, "points_per_rank": counts, "views": w["V"], "feature_dim": w["C"], "feature_map": list(w["fhw"]),
                    "parallelism": "points sharded x%d, maps replicated" % world,
                    # what torch.distributed itself reports (backend "nccl" is RCCL on ROCm), and where every rank ran
                    "rccl_world_size": (dist.get_world_size() if dist_on else 1), "backend": (args.backend if dist_on else "n/a"),

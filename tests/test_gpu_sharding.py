@@ -84,3 +84,34 @@ def test_two_ranks_one_gpu_hip_kernels():
     for rank, ok, ok_sim, err in res:
         assert ok, "rank %d: sharded field differs from the single-process field" % rank
         assert ok_sim, "rank %d: row-sharded softmax differs (max err %g)" % (rank, err)
+
+
+def test_bench_eight_ranks_dry_run_and_rccl_device_check():
+    """The first real multi-GPU run must not fail for boring reasons: `bench.py --gpus 8 --workload c4_patch
+    --gather full` as EIGHT gloo ranks on this one GPU at reduced N, ragged shards -- the launch line, the process group, the
+    overlapped full-field gather, the ragged counts and the JSON line are exactly those of the RCCL run; with backend nccl the same
+    command must refuse loudly on a node that shows fewer GPUs than ranks instead of wrapping local ranks onto one device."""
+    import json
+    import subprocess
+    K, world = 8192, 8
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--backend", "gloo", "--workload", "c4_patch", "--points",
+           "random", "--gather", "full", "--points-per-gpu", str(K), "--ragged", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    counts = [K - k for k in range(world)]
+    cfg = line["config"]
+    assert line["n_gpus"] == world and cfg["rccl_world_size"] == world and cfg["backend"] == "gloo"
+    assert cfg["points_per_rank"] == counts and len(cfg["rank_devices"]) == world
+    per_point = 4 + 1 + 4 * 1024                                   # dist + valid_mask + the 1024-d row: every output gathered
+    assert set(cfg["gather_keys"]) == {"dist", "valid_mask", "dino_feats"}
+    assert cfg["gather_bytes_received_per_rank"] == (sum(counts) - counts[0]) * per_point        # rank 0 receives the other seven shards
+    assert line["verified"] is True and line["value"] > 0 and line["value_full_field"] > 0
+    assert abs(line["value"] - sum(counts) * line["steps"] / (line["ms_per_step"] * 1e-3 * line["steps"])) <= 1e-6 * line["value"]
+    # RCCL: one GPU per rank or nothing
+    if torch.cuda.device_count() < 2:
+        cmd2 = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--no-verify",
+                "--workload", "c2_patch", "--points-per-gpu", "70000"]
+        r2 = subprocess.run(cmd2, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+        assert r2.returncode != 0 and "needs 2 visible GPUs" in (r2.stderr + r2.stdout), (r2.returncode, r2.stderr[-1500:])

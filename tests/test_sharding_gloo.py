@@ -63,7 +63,9 @@ def _worker(rank, world, port, n, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("n,world", [(1001, 2), (1000, 2), (1, 2), (1000, 3), (2, 3)])
+# (world 8: the shape of the first real RCCL run -- eight shards, ragged (1003 = 3 x 126 + 5 x 125) and mostly EMPTY (5 points), every key
+# incl. '<k>_inter' [V,n,C] gathered along its point axis)
+@pytest.mark.parametrize("n,world", [(1001, 2), (1000, 2), (1, 2), (1000, 3), (2, 3), (1003, 8), (5, 8)])
 def test_sharded_eval_world2(n, world):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
@@ -182,11 +184,11 @@ def _sim_worker(rank, world, port, b1, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("b1", [257, 7, 1])
-def test_sharded_similarity_world2(b1):
-    """softmax(dim=0) of compute_similarity_tensor_multi with the rows split over two ranks: one 16-B record per
-    column is exchanged; rows and the global argmax equal the single-process result (rank 1 is empty for b1=1)."""
-    world = 2
+@pytest.mark.parametrize("b1,world", [(257, 2), (7, 2), (1, 2), (1003, 8), (3, 8)])
+def test_sharded_similarity_world2(b1, world):
+    """softmax(dim=0) of compute_similarity_tensor_multi with the rows split over the ranks: one 16-B record per
+    column is exchanged; rows and the global argmax equal the single-process result (rank 1 is empty for b1=1; at
+    world 8 with b1=3 five ranks are)."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
