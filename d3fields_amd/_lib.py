@@ -9,7 +9,7 @@ import os
 
 from . import build as _build
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 # status codes (include/d3fields_hip.h)
 OK = 0
@@ -18,6 +18,8 @@ FLAG_FINITE_MAPS = 1
 FLAG_UNORDERED_POINTS = 2
 FLAG_REFERENCE_ROUNDING = 4
 FLAG_REUSE_POINT_ORDER = 8
+FLAG_LOCAL_POINTS = 128
+PROBE_WORDS = 40
 TUNE_XCD_REMAP, TUNE_NO_REORDER, TUNE_FORCE_REORDER = 1 << 12, 1 << 13, 1 << 14
 TUNE_DIRECT_GATHER = 1 << 4
 TUNE_NO_WINDOW_GATE, TUNE_WINDOW_SIDE = 1 << 5, 1 << 6
@@ -128,6 +130,7 @@ SIGNATURES = {
     "d3f_pairwise_softmax_local": (ctypes.c_int, [_vp, _vp, _i64, _i64, _i32, _f32, _i32, _i64, _vp, _vp, _vp, _i64,
                                                   _vp]),
     "d3f_point_order_locality": (ctypes.c_int, [_vp, _i64, _vp, _vp]),
+    "d3f_points_probe": (ctypes.c_int, [_vp, _i64, _vp, _vp]),
     "d3f_rigid_transform": (ctypes.c_int, [_vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),
     "d3f_track_loss_grad": (ctypes.c_int, [_vp, _vp, _vp, _vp, _i64, _i32, _f32, _vp, _vp, _vp, _vp]),
     "d3f_track_step_scratch_bytes": (_i64, [_i32, _i32]),

@@ -574,6 +574,14 @@ int d3f_point_order_locality(const float *pts, int64_t n, float *out, void *stre
     return e == hipSuccess ? D3F_OK : hip_fail(e, "point locality launch");
 }
 
+int d3f_points_probe(const float *pts, int64_t n, int32_t *out, void *stream)
+{
+    if (n < 0) return fail(D3F_ERR_INVALID_ARG, "n=%lld is negative", (long long)n);
+    if (!out || (n > 0 && !pts)) return fail(D3F_ERR_INVALID_ARG, "points_probe: NULL pointer");
+    hipError_t e = d3f::launch_points_probe(pts, n, out, static_cast<hipStream_t>(stream));
+    return e == hipSuccess ? D3F_OK : hip_fail(e, "points probe launch");
+}
+
 int d3f_lattice_probe(const float *pts, int64_t n, int32_t *out_dims, void *stream)
 {
     if (n < 0) return fail(D3F_ERR_INVALID_ARG, "n=%lld is negative", (long long)n);

@@ -122,6 +122,8 @@ const uint32_t *stored_point_order(void *workspace, int64_t n);
 hipError_t launch_lattice_probe(const float *pts, int64_t n, int32_t *out_dims, hipStream_t stream);
 // mean L1 step between consecutive points vs between points n/2 apart (out: 2 device floats)
 hipError_t launch_point_locality(const float *pts, int64_t n, float *out, hipStream_t stream);
+// both probes in one launch; out: D3F_PROBE_WORDS device words, every one written (no clearing needed)
+hipError_t launch_points_probe(const float *pts, int64_t n, int32_t *out, hipStream_t stream);
 
 // grid_kernels.hip
 hipError_t launch_grid_shell(const float *depth, const float *K, const float *pose, int V, int H, int W, const float *gx,

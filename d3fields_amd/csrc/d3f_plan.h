@@ -33,12 +33,16 @@
 //                       order is kept (unless the cloud has no locality at all), 128-point tiles
 //  kBatchedLoadBytes    a map at most this big issues all 4*U corner loads of a view before the first use; bigger maps
 //                       in caller order use load-use per vector (a smaller in-flight footprint measured faster)
+//  kInfinityCacheBytes  maps up to this size stay in the Infinity Cache: a cloud below kWindowCloudMin points whose caller declares its order
+//                       LOCAL (D3F_FLAG_LOCAL_POINTS) keeps that order -- five ordering launches of ~5 us each do not pay around a
+//                       90-120 us query (the 71 k surface points of vis_repr.py:97-103 in flat-index order)
 //  kBeyondLlcBytes      maps beyond this in CALLER order without scratch: 64-point tiles at 2 workgroups per CU
 constexpr int64_t kSmallBatch = 65536;
 constexpr int64_t kWindowCloudMin = 262144;
 constexpr int64_t kCacheResidentBytes = 64LL << 20;
 constexpr int64_t kBatchedLoadBytes = 128LL << 20;
 constexpr int64_t kBeyondLlcBytes = 512LL << 20;
+constexpr int64_t kInfinityCacheBytes = 256LL << 20;
 
 
 // ---- tuning knobs ----------------------------------------------------------------------------------------------------------------
@@ -137,7 +141,15 @@ struct Query {
     // would the points be walked in the Hilbert order?  (clouds; performance only)
     bool reorder_cloud() const
     {
-        return may_reorder && !lattice && ((flags & D3F_TUNE_FORCE_REORDER) || (n >= kSmallBatch && (map_bytes > kCacheResidentBytes || (flags & D3F_FLAG_UNORDERED_POINTS))));
+        if (!may_reorder || lattice) return false;
+        if (flags & D3F_TUNE_FORCE_REORDER) return true;
+        if (n < kSmallBatch) return false;
+        if (flags & D3F_FLAG_UNORDERED_POINTS) return true;
+        if (map_bytes <= kCacheResidentBytes) return false;
+        // maps beyond the L2s: the Hilbert walk pays -- unless the caller's own order is local, the cloud is too small for the window
+        // kernel and the maps sit in the Infinity Cache
+        if ((flags & D3F_FLAG_LOCAL_POINTS) && n < kWindowCloudMin && map_bytes <= kInfinityCacheBytes) return false;
+        return true;
     }
     // (a flat lattice with more than 2^28 tiles per 16-tile slab would overflow the walk's 32-bit level arithmetic)
     bool walk_possible() const
@@ -510,7 +522,7 @@ inline void plan_family_and_order(const Query &q, d3f::EvalParams &P, Plan &pl)
     // sort, no index array, no scratch -- and replaces the Hilbert sort wherever that would be used.  (With the cell-run
     // gather the caller's z-fastest order is the one wanted: a grid column is one long run.)
     pl.walk = q.walk_possible() && !pl.runs && ((q.flags & D3F_TUNE_FORCE_REORDER) || q.map_bytes > kCacheResidentBytes || pl.window);
-    pl.reorder = pl.walk || (q.may_reorder && ((q.flags & D3F_TUNE_FORCE_REORDER) || (q.n >= kSmallBatch && (q.map_bytes > kCacheResidentBytes || (q.flags & D3F_FLAG_UNORDERED_POINTS)))));
+    pl.reorder = pl.walk || q.reorder_cloud();
     if (pl.walk) { P.walk_nx = q.lattice[0]; P.walk_ny = q.lattice[1]; P.walk_nz = q.lattice[2]; }
 }
 

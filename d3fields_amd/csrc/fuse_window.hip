@@ -776,7 +776,7 @@ __global__ __launch_bounds__(NT, WAVES) void fused_eval_window_kernel(const Eval
 }
 
 // gate[0] verdict (tiles that fit), gate[1] running count, gate[2] workgroups done; [1] and [2] are zero between launches
-// (order_clear_kernel zeroes them with the counting table; the last workgroup resets them)
+// (order_prepare_kernel zeroes them with the counting table; the last workgroup resets them)
 __global__ __launch_bounds__(kBlock) void window_gate_probe_kernel(const EvalParams P, uint32_t *__restrict__ gate, int nsamples)
 {
     __shared__ float krt[kWinMaxViews * 12];

@@ -18,7 +18,8 @@
 // Hand-written since round 2 (round 1 sorted (key, index) pairs with rocPRIM's Onesweep radix sort: histogram +
 // 3-4 digit passes + 7 memset launches = 0.12-0.16 ms per 1 M points).  A counting sort by cell plus an exact rank inside the
 // cell gives the total order of the keys:
-//   0. order_bbox_kernel     the box of the finite points (round 5, below): the 512^3 key grid is laid over it
+//   0. order_prepare_kernel  counters / gate / scan status cleared AND the box of the finite points as <= 128 partial boxes (round 6:
+//                            one launch, no atomics; round 5: two): the 512^3 key grid is laid over that box
 //   1. cell_count_kernel     27-bit Hilbert key of the grid cell of every point (Skilling's transpose form; kept for step 4)
 //                            and a histogram of a 15..20-bit prefix = the counting cell (~4 x 4 x 8 key cells at 1 M points; counters
 //                            in caller scratch, cleared by order_clear_kernel); the returning atomic also gives the point its
@@ -28,7 +29,7 @@
 //   4. cell_rank_kernel      every slot counts the (key, index) pairs of ITS cell that sort before its own (a cell is a few
 //                            consecutive slots: L1 hits) and moves to that place: the exact order of the full key, ties by
 //                            index.  A cell of more than 256 points (a dense clump) is ranked in aligned pieces of 256 slots.
-// Six launches (seven up to round 4); 1 M points: 0.10 ms of kernel time (0.135 with the fixed 4-mm key grid this round began with,
+// Five launches (seven up to round 4, six in round 5); 1 M points: 0.10 ms of kernel time (0.135 with the fixed 4-mm key grid this round began with,
 // whose returning atomics serialised on the ~33 points of an occupied 16-mm cell).  The key kernel runs at the rate the L2s retire
 // returning atomics (~21 G/s).  Measured and not kept (round 5, scripts/notebook/gpu_sessions/r5_gpu20-22, 26, 27.sh): on the fixed
 // grid fewer counters (2^19 / 2^18: the atomics 130 us, the rank loops 72-110 us) -- on the box-relative grid 2^20 .. 2^18 are
@@ -99,25 +100,30 @@ __device__ __forceinline__ uint32_t ordered_bits(float f)
 }
 __device__ __forceinline__ float from_ordered_bits(uint32_t u) { return __uint_as_float((u & 0x80000000u) ? (u & 0x7fffffffu) : ~u); }
 
-constexpr int kBoxWord = 8;               // bbox words start at gate[kBoxWord]: lo x y z, hi x y z
+constexpr int kBoxBlock = 1024;          // few, large workgroups (each leaves ONE partial box)
+constexpr int kBoxParts = 128;           // at most this many of them
+constexpr int kBoxLanes = 6;             // words of a partial box: lo x y z, hi x y z (ordered_bits images)
 
-__global__ __launch_bounds__(kBlock) void order_clear_kernel(uint32_t *__restrict__ table, uint32_t *__restrict__ gate,
-                                                            uint32_t *__restrict__ status, int status_words)
+// ONE launch in front of the key kernel (round 6; rounds 2-5: order_clear_kernel, then order_bbox_kernel with six same-address
+// atomics per workgroup on words the first kernel had to initialise): workgroups [0, clear_blocks) zero the counting table, the gate
+// words and the status words of the single-launch scan; workgroups [clear_blocks, clear_blocks + parts) each reduce a strided share
+// of the points to a partial box and STORE it to parts[b] -- no atomics, nothing to initialise, so both roles run side by side.
+// The key kernel folds the <= 128 partial boxes itself (one wave, L2 hits).
+__global__ __launch_bounds__(kBoxBlock) void order_prepare_kernel(uint32_t *__restrict__ table, uint32_t *__restrict__ gate,
+                                                                 uint32_t *__restrict__ status, int status_words, int clear_blocks,
+                                                                 const float *__restrict__ pts, int64_t n, uint32_t *__restrict__ parts)
 {
-    reinterpret_cast<uint4 *>(table)[(int64_t)blockIdx.x * kBlock + threadIdx.x] = make_uint4(0u, 0u, 0u, 0u);
-    if (blockIdx.x == 0 && threadIdx.x < 4) gate[threadIdx.x] = 0u;       // the window / cell-run gate of this order (fuse_window.hip)
-    if (blockIdx.x == 0 && threadIdx.x >= 8 && threadIdx.x < 14)           // the box: lo = +max, hi = -max
-        gate[kBoxWord + threadIdx.x - 8] = threadIdx.x < 11 ? 0xffffffffu : 0u;
-    if (blockIdx.x == 1 || gridDim.x == 1)                                 // the status words of the single-launch scan
-        for (int k = threadIdx.x; k < status_words; k += kBlock) status[k] = 0u;
-}
-
-constexpr int kBoxBlock = 1024;          // few, large workgroups: the six same-address atomics per workgroup are what this kernel waits for
-__global__ __launch_bounds__(kBoxBlock) void order_bbox_kernel(const float *__restrict__ pts, int64_t n, uint32_t *__restrict__ box)
-{
+    if ((int)blockIdx.x < clear_blocks) {
+        reinterpret_cast<uint4 *>(table)[(int64_t)blockIdx.x * kBoxBlock + threadIdx.x] = make_uint4(0u, 0u, 0u, 0u);
+        if (blockIdx.x == 0 && threadIdx.x < 4) gate[threadIdx.x] = 0u;       // the window / cell-run gate of this order (fuse_window.hip)
+        if ((int)blockIdx.x == clear_blocks - 1)                              // the status words of the single-launch scan
+            for (int k = threadIdx.x; k < status_words; k += kBoxBlock) status[k] = 0u;
+        return;
+    }
+    const int b = (int)blockIdx.x - clear_blocks, nparts = (int)gridDim.x - clear_blocks;
     float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
-    const int64_t stride = (int64_t)gridDim.x * kBoxBlock;
-    for (int64_t i = (int64_t)blockIdx.x * kBoxBlock + threadIdx.x; i < n; i += 4 * stride) {
+    const int64_t stride = (int64_t)nparts * kBoxBlock;
+    for (int64_t i = (int64_t)b * kBoxBlock + threadIdx.x; i < n; i += 4 * stride) {
         float x[4][3];                                                     // four points in flight (past the end: the last point again)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -138,7 +144,6 @@ __global__ __launch_bounds__(kBoxBlock) void order_bbox_kernel(const float *__re
             lo[k] = fminf(lo[k], __shfl_xor(lo[k], off, 64));
             hi[k] = fmaxf(hi[k], __shfl_xor(hi[k], off, 64));
         }
-    // one set of atomics per workgroup: 49 k same-address atomics (one set per wave of 2048 workgroups) took 71 us by themselves
     __shared__ float part[kBoxBlock / 64][6];
     if ((threadIdx.x & 63) == 0)
 #pragma unroll
@@ -149,23 +154,44 @@ __global__ __launch_bounds__(kBoxBlock) void order_bbox_kernel(const float *__re
         float l = part[0][k], h = part[0][3 + k];
 #pragma unroll
         for (int w = 1; w < kBoxBlock / 64; ++w) { l = fminf(l, part[w][k]); h = fmaxf(h, part[w][3 + k]); }
-        if (l <= h) {                                                       // the workgroup saw a finite coordinate
-            atomicMin(&box[k], ordered_bits(l));
-            atomicMax(&box[3 + k], ordered_bits(h));
-        }
+        // a workgroup that saw no finite coordinate leaves the empty box (lo = +inf, hi = -inf): the fold's min / max drop it
+        parts[b * kBoxLanes + k] = ordered_bits(l);
+        parts[b * kBoxLanes + 3 + k] = ordered_bits(h);
     }
 }
 
 // origin and cells-per-metre of the key grid, from the box (every lane computes the same values from six uniform loads)
 struct KeyGrid { float ox, oy, oz, inv; };
-__device__ __forceinline__ KeyGrid key_grid(const uint32_t *__restrict__ box)
+// (every workgroup folds the partial boxes by itself: wave 0, two partial boxes per lane, six DPP-free shuffle reductions; the result
+// is the same in every workgroup -- min / max are exact and order-free)
+__device__ __forceinline__ KeyGrid key_grid(const uint32_t *__restrict__ parts, int nparts)
 {
-    KeyGrid g = {0.0f, 0.0f, 0.0f, 1.0f / kFineCell};                       // the fixed 4-mm grid (keys wrap beyond 2.05 m: harmless)
-    if (!box) return g;
-    const float lx = from_ordered_bits(box[0]), ly = from_ordered_bits(box[1]), lz = from_ordered_bits(box[2]);
-    const float ext = fmaxf(fmaxf(from_ordered_bits(box[3]) - lx, from_ordered_bits(box[4]) - ly), from_ordered_bits(box[5]) - lz);
-    if (ext > 0.0f && ext <= 511.0f * kFineCell) { g.ox = lx; g.oy = ly; g.oz = lz; g.inv = 511.0f / ext; }    // false for NaN (no finite point)
-    return g;
+    __shared__ KeyGrid g_s;
+    if (threadIdx.x < 64) {
+        float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+        if (parts)
+            for (int b = threadIdx.x; b < nparts; b += 64)
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    lo[k] = fminf(lo[k], from_ordered_bits(parts[b * kBoxLanes + k]));
+                    hi[k] = fmaxf(hi[k], from_ordered_bits(parts[b * kBoxLanes + 3 + k]));
+                }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1)
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                lo[k] = fminf(lo[k], __shfl_xor(lo[k], off, 64));
+                hi[k] = fmaxf(hi[k], __shfl_xor(hi[k], off, 64));
+            }
+        if (threadIdx.x == 0) {
+            KeyGrid g = {0.0f, 0.0f, 0.0f, 1.0f / kFineCell};               // the fixed 4-mm grid (keys wrap beyond 2.05 m: harmless)
+            const float ext = fmaxf(fmaxf(hi[0] - lo[0], hi[1] - lo[1]), hi[2] - lo[2]);
+            if (parts && ext > 0.0f && ext <= 511.0f * kFineCell) { g.ox = lo[0]; g.oy = lo[1]; g.oz = lo[2]; g.inv = 511.0f / ext; }    // false for NaN / no finite point
+            g_s = g;
+        }
+    }
+    __syncthreads();
+    return g_s;
 }
 
 // MORTON: the Z-curve keys of rounds 1-4 (experiments builds keep them for same-box comparisons)
@@ -174,11 +200,11 @@ __device__ __forceinline__ KeyGrid key_grid(const uint32_t *__restrict__ box)
 template <bool MORTON>
 __global__ __launch_bounds__(kBlock) void cell_count_kernel(const float *__restrict__ pts, int64_t n, uint32_t *__restrict__ keys,
                                                            uint32_t *__restrict__ ranks, uint32_t *__restrict__ table, int shift,
-                                                           const uint32_t *__restrict__ box)
+                                                           const uint32_t *__restrict__ parts, int nparts)
 {
+    const KeyGrid g = key_grid(parts, nparts);          // (whole workgroup: a barrier inside)
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (i >= n) return;
-    const KeyGrid g = key_grid(box);
     // non-finite / huge coordinates just land in some cell: only locality is at stake
     const int qx = (int)fminf(fmaxf(floorf((pts[i * 3 + 0] - g.ox) * g.inv), -1e9f), 1e9f);
     const int qy = (int)fminf(fmaxf(floorf((pts[i * 3 + 1] - g.oy) * g.inv), -1e9f), 1e9f);
@@ -223,7 +249,8 @@ int64_t order_workspace_bytes(int64_t n)
 {
     if (n <= 0) return 0;
     // keys | ranks | order | slots (8-byte (key, index) words: two segments) | cell counters + scan scratch
-    return (int64_t)(5 * align_up((size_t)n * 4, 256) + (size_t)kCells * 4 + (size_t)scan_scratch_bytes(kCells) + 256);
+    // | 256 bytes of gate words | the partial boxes of order_prepare_kernel
+    return (int64_t)(5 * align_up((size_t)n * 4, 256) + (size_t)kCells * 4 + (size_t)scan_scratch_bytes(kCells) + 256 + (size_t)kBoxParts * kBoxLanes * 4);
 }
 
 int64_t order_gate_offset(int64_t n)
@@ -263,17 +290,19 @@ hipError_t build_point_order(const float *pts, int64_t n, void *workspace, int64
     // (the scan scratch is sized for the recursive three-launch scan of 2^21 counters: 1024 + 1 words and more)
     uint32_t *status = static_cast<uint32_t *>(scan_scratch);
     const int status_words = (int)scan_status_words(cells);
-    hipLaunchKernelGGL(order_clear_kernel, dim3((unsigned)(cells / 4 / kBlock)), dim3(kBlock), 0, stream, table, order_gate_words(workspace, n),
-                       status, status_words);
-    // the cloud's box, then keys on a grid laid over it (experiments builds: bit 2 = the fixed 4-mm grid of rounds 1-4)
-    uint32_t *box = (curve & 5) ? nullptr : order_gate_words(workspace, n) + kBoxWord;
-    if (box) {
-        unsigned bb = (unsigned)((n + (int64_t)kBoxBlock * 8 - 1) / ((int64_t)kBoxBlock * 8));
-        if (bb > 128u) bb = 128u;
-        hipLaunchKernelGGL(order_bbox_kernel, dim3(bb), dim3(kBoxBlock), 0, stream, pts, n, box);
+    // ONE launch: the counters, gate and status words cleared AND the cloud's box as <= 128 partial boxes; then keys on a grid laid over
+    // the box (experiments builds: bit 2 = the fixed 4-mm grid of rounds 1-4, bit 0 = Morton keys on it)
+    uint32_t *parts = (curve & 5) ? nullptr : order_gate_words(workspace, n) + 64;
+    int nparts = 0;
+    if (parts) {
+        nparts = (int)((n + (int64_t)kBoxBlock * 8 - 1) / ((int64_t)kBoxBlock * 8));
+        if (nparts > kBoxParts) nparts = kBoxParts;
     }
-    if (curve & 1) hipLaunchKernelGGL(cell_count_kernel<true>, dim3(nb), dim3(kBlock), 0, stream, pts, n, keys, ranks, table, shift, box);
-    else hipLaunchKernelGGL(cell_count_kernel<false>, dim3(nb), dim3(kBlock), 0, stream, pts, n, keys, ranks, table, shift, box);
+    const int clear_blocks = (int)(cells / 4 / kBoxBlock);
+    hipLaunchKernelGGL(order_prepare_kernel, dim3((unsigned)(clear_blocks + nparts)), dim3(kBoxBlock), 0, stream, table,
+                       order_gate_words(workspace, n), status, status_words, clear_blocks, pts, n, parts);
+    if (curve & 1) hipLaunchKernelGGL(cell_count_kernel<true>, dim3(nb), dim3(kBlock), 0, stream, pts, n, keys, ranks, table, shift, parts, nparts);
+    else hipLaunchKernelGGL(cell_count_kernel<false>, dim3(nb), dim3(kBlock), 0, stream, pts, n, keys, ranks, table, shift, parts, nparts);
     // n < 2^31 points: the counts sum to n; the look-back scan carries 30-bit values -- above 2^30 points the recursive scan
     hipError_t e = (n < (1LL << 30) && !(curve & 2)) ? launch_exclusive_scan_lookback_u32(table, table, cells, status, stream)
                                    : launch_exclusive_scan_u32(table, table, cells, scan_scratch, stream);
@@ -392,6 +421,80 @@ __global__ __launch_bounds__(kBlock) void lattice_probe_kernel(const float *__re
                           p[i * 3 + 0] == p[ix * ny * nz * 3 + 0];
         if (!same) atomicOr(&out[3], 1);
     }
+}
+
+// ---- both probes in ONE launch (round 6) ------------------------------------------------------------------------------------------
+// A new query tensor used to cost lattice_probe_kernel + point_locality_kernel + a fill of their output words (three launches of
+// ~5 us each in front of a 90-120 us query of a small cloud).  Here workgroups 0..15 are the lattice probe, workgroups 16..19 the
+// locality probe (256 samples each), and every output word is WRITTEN by exactly one workgroup, so the buffer needs no clearing:
+//   out[0..2] lattice dims (zeros: not a lattice)      out[8 + b], b < 16: 1 if workgroup b's samples contradict the dims
+//   out[24 + 3 q .. +2], q < 4: sum of near steps, sum of far distances, number of finite samples (floats) of locality workgroup q
+static_assert(D3F_PROBE_WORDS == 40, "points_probe_kernel writes words 0..3, 8..23 and 24..35");
+constexpr int kLocalityBlocks = 4;
+__global__ __launch_bounds__(kBlock) void points_probe_kernel(const float *__restrict__ pts, int64_t n, int32_t *__restrict__ out)
+{
+    __shared__ int first_s;
+    __shared__ float red[3][kBlock / 64];
+    if (blockIdx.x >= kProbeBlocks) {
+        const int q = (int)blockIdx.x - kProbeBlocks;
+        float near_d = 0.0f, far_d = 0.0f, cnt = 0.0f;
+        if (n >= 2) {
+            const int sample = q * kBlock + (int)threadIdx.x;                  // one of kLocalityBlocks * kBlock = kProbeSamples positions
+            const int64_t i = (int64_t)((uint64_t)sample * (uint64_t)(n - 1) / (uint64_t)(kLocalityBlocks * kBlock));
+            const int64_t j = i + n / 2 - (i + n / 2 >= n ? n : 0);
+            const ProbePoint *pp = reinterpret_cast<const ProbePoint *>(pts);
+            const ProbePoint a = pp[i], b = pp[i + 1], c = pp[j];
+            const float dn = fabsf(b.x - a.x) + fabsf(b.y - a.y) + fabsf(b.z - a.z);
+            const float df = fabsf(c.x - a.x) + fabsf(c.y - a.y) + fabsf(c.z - a.z);
+            if (dn < INFINITY && df < INFINITY) { near_d = dn; far_d = df; cnt = 1.0f; }      // false for NaN too
+        }
+        for (int off = 32; off > 0; off >>= 1) {
+            near_d += __shfl_xor(near_d, off, 64);
+            far_d += __shfl_xor(far_d, off, 64);
+            cnt += __shfl_xor(cnt, off, 64);
+        }
+        if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = near_d; red[1][threadIdx.x >> 6] = far_d; red[2][threadIdx.x >> 6] = cnt; }
+        __syncthreads();
+        if (threadIdx.x < 3) {
+            float t = 0.0f;
+            for (int w = 0; w < kBlock / 64; ++w) t += red[threadIdx.x][w];
+            reinterpret_cast<float *>(out)[24 + 3 * q + threadIdx.x] = t;
+        }
+        return;
+    }
+    int nz = n >= 2 ? first_restart(pts, 1, n, 2, &first_s) : 0;
+    bool ok = nz >= 2 && n % nz == 0;
+    int ny = ok ? first_restart(pts, nz, n / nz, 1, &first_s) : 0;
+    ok = ok && ny >= 1 && (n / nz) % ny == 0 && (ny >= 2 || n / nz == 1);
+    int64_t nx = 0;
+    if (ok) {
+        nx = n / ((int64_t)nz * ny);
+        ok = nx >= 1 && nx <= 0x7fffffffLL;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        out[0] = ok ? (int32_t)nx : 0; out[1] = ok ? ny : 0; out[2] = ok ? nz : 0; out[3] = 0;
+    }
+    int bad = 0;
+    if (ok) {
+        const int64_t samples = min((int64_t)kProbeBlocks * kBlock, n);
+        const int64_t k = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+        if (k < samples) {
+            const int64_t i = samples > 1 ? (int64_t)((double)k * (double)(n - 1) / (double)(samples - 1)) : 0;
+            const int64_t iz = i % nz, ixy = i / nz, iy = ixy % ny, ix = ixy / ny;
+            const uint32_t *p = reinterpret_cast<const uint32_t *>(pts);
+            const bool same = p[i * 3 + 2] == p[iz * 3 + 2] && p[i * 3 + 1] == p[iy * nz * 3 + 1] &&
+                              p[i * 3 + 0] == p[ix * ny * nz * 3 + 0];
+            bad = same ? 0 : 1;
+        }
+    }
+    const int any_bad = __syncthreads_or(bad);          // (uniform control flow: `ok` is the same in every lane)
+    if (threadIdx.x == 0) out[8 + blockIdx.x] = any_bad ? 1 : 0;
+}
+
+hipError_t launch_points_probe(const float *pts, int64_t n, int32_t *out, hipStream_t stream)
+{
+    hipLaunchKernelGGL(points_probe_kernel, dim3(kProbeBlocks + kLocalityBlocks), dim3(kBlock), 0, stream, pts, n, out);
+    return hipGetLastError();
 }
 
 hipError_t launch_lattice_probe(const float *pts, int64_t n, int32_t *out_dims, hipStream_t stream)

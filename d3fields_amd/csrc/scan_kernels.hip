@@ -51,7 +51,7 @@ __global__ __launch_bounds__(kBlock) void scan_add_kernel(uint32_t *__restrict__
 // ticket counter (so tiles start in order whatever the dispatcher does), scans it, publishes the tile's total, adds up the totals /
 // inclusive prefixes its predecessors have published, and publishes its own inclusive prefix.  status[0] = the ticket counter,
 // status[1 + t] = (flag << 30) | value with flag 1 = tile total, 2 = inclusive prefix; all zero at launch (the caller clears
-// them: order_clear_kernel).  Values < 2^30 (the ordering scans counts of < 2^31 / 2 points; the host checks).
+// them: order_prepare_kernel).  Values < 2^30 (the ordering scans counts of < 2^31 / 2 points; the host checks).
 __global__ __launch_bounds__(kBlock) void scan_lookback_kernel(const uint32_t *__restrict__ in, uint32_t *__restrict__ out, int64_t n,
                                                               uint32_t *__restrict__ status)
 {

@@ -476,15 +476,22 @@ class Fusion:
     # is n).  So a query whose tensor is not in the per-tensor cache does not wait for its own probes: they are enqueued,
     # their results land in pinned host memory, and the launch uses the verdict of the most recent FINISHED probes of
     # a query of the same size (per-frame grids / clouds repeat their layout).  Only the first query of a size waits.
+    @staticmethod
+    def _parse_probe(words):
+        """(lattice dims or None, unordered?) from the D3F_PROBE_WORDS words of d3f_points_probe (a CPU int32 tensor)."""
+        li = words[:24].tolist()
+        fl = words[24:36].view(torch.float32).tolist()
+        dims = tuple(li[:3]) if (li[0] > 0 and not any(li[8:24])) else None
+        near, far, cnt = sum(fl[0::3]), sum(fl[1::3]), sum(fl[2::3])
+        return dims, bool(cnt > 0 and near > 0.25 * far)
+
     def _poll_probes(self):
         still = []
         for n, out_host, ev in self._pending:
             if ev.query():
-                li = out_host[:4].view(torch.int32).tolist()
-                near, far = out_host[4:6].tolist()
-                dims = tuple(li[:3]) if (li[0] > 0 and li[3] == 0) else None
+                dims, unordered = self._parse_probe(out_host)
                 self._hints.pop(n, None)                           # (re-)insert as the most recent entry
-                self._hints[n] = [dims, bool(near > 0.25 * far)]
+                self._hints[n] = [dims, unordered]
                 while len(self._hints) > 64:                        # bounded: sizes come and go in long-running trackers
                     self._hints.pop(next(iter(self._hints)))
                 self._pinned.append(out_host)
@@ -493,13 +500,13 @@ class Fusion:
         self._pending = still
 
     def _enqueue_probes(self, pts_c, stream):
-        """lattice probe + locality probe of pts_c on the current stream; results -> pinned host memory, asynchronously"""
+        """d3f_points_probe (lattice + locality, ONE launch, nothing to clear) on the current stream; results -> pinned host memory,
+        asynchronously"""
         dev = pts_c.device
         n = pts_c.shape[0]
-        out = torch.zeros(6, dtype=torch.float32, device=dev)           # [0:4] int32 lattice verdict, [4:6] near / far
-        _lib.check(self._lib.d3f_lattice_probe(_lib.ptr(pts_c), n, _lib.ptr(out), stream))
-        _lib.check(self._lib.d3f_point_order_locality(_lib.ptr(pts_c), n, ctypes.c_void_p(out.data_ptr() + 16), stream))
-        host = self._pinned.pop() if self._pinned else torch.empty(6, dtype=torch.float32).pin_memory()
+        out = torch.empty(_lib.PROBE_WORDS, dtype=torch.int32, device=dev)
+        _lib.check(self._lib.d3f_points_probe(_lib.ptr(pts_c), n, _lib.ptr(out), stream))
+        host = self._pinned.pop() if self._pinned else torch.empty(_lib.PROBE_WORDS, dtype=torch.int32).pin_memory()
         host.copy_(out, non_blocking=True)
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream(dev))
@@ -681,10 +688,18 @@ class Fusion:
                                                 inter if return_inter else None, stream))
                 return outputs, (pts_c, keep[0], keep[1], keep[2], used_maps)
             if self.reorder_points and names and n >= 65536:
-                small = sum(m.numel() * m.element_size() for m in used_maps) <= (64 << 20)
-                if small and self.detect_point_order and (hinted_unordered if hinted_unordered is not None
-                                                          else self._is_unordered(pts_c, stream)):
-                    flags |= _lib.FLAG_UNORDERED_POINTS     # larger maps are walked in Hilbert order anyway
+                map_bytes = sum(m.numel() * m.element_size() for m in used_maps)
+                small = map_bytes <= (64 << 20)
+                # the verdict of the locality probe matters in two places: small maps are reordered only for an UNORDERED cloud, and
+                # a small cloud (below the window kernel's 262 144 points) on maps inside the Infinity Cache keeps a LOCAL caller order
+                # (the 71 k surface points of vis_repr.py:97-103 in flat-index order: five ordering launches around a 120-us query)
+                keep_local = (not small) and n < 262144 and map_bytes <= (256 << 20)
+                if (small or keep_local) and self.detect_point_order:
+                    unordered = hinted_unordered if hinted_unordered is not None else self._is_unordered(pts_c, stream)
+                    if small and unordered:
+                        flags |= _lib.FLAG_UNORDERED_POINTS     # larger maps are walked in Hilbert order anyway
+                    if keep_local and not unordered:
+                        flags |= _lib.FLAG_LOCAL_POINTS
                 ws_bytes = lib.d3f_eval_workspace_bytes(n)
                 sig = (pts_c.data_ptr(), pts_c._version, n, int(stream.value or 0))   # per stream: the order is written asynchronously
                 held = self._order_ws if self.cache_point_order else None

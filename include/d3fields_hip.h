@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define D3F_ABI_VERSION 5
+#define D3F_ABI_VERSION 6
 
 #define D3F_OK 0
 #define D3F_ERR_INVALID_ARG (-1)  /* null pointer, negative count, bad enum               */
@@ -65,6 +65,11 @@ extern "C" {
                                         uniformly random cloud; see d3f_point_order_locality): walk the \
                                         points in Hilbert order even when the maps are small.  Performance \
                                         only -- results never depend on it.                              */
+#define D3F_FLAG_LOCAL_POINTS 128u /* (ABI 6) the caller's point order HAS spatial locality (d3f_points_probe: the mean step between \
+                                      consecutive points is a small fraction of the cloud's extent -- a mesh, a scan, the surface    \
+                                      points of a lattice in flat-index order): a cloud too small for the window kernel (< 262 144   \
+                                      points) on maps that fit the Infinity Cache (<= 256 MiB) keeps the caller's order -- the      \
+                                      Hilbert sort (five launches) costs more than it saves there.  Performance only.            */
 #define D3F_FLAG_REUSE_POINT_ORDER 8u /* `workspace` still holds the point order that an earlier d3f_eval call wrote  \
                                          for the SAME pts / n (a static grid queried every frame): do not rebuild it   \
                                          (~0.12 ms per 1 M points).  Any permutation of 0..n-1 gives the same results; \
@@ -359,6 +364,14 @@ int d3f_eval_backward(const d3f_views *views, const float *pts, int64_t n, const
  * A grid / mesh / scan-ordered cloud gives out[0] << out[1]; the shim passes D3F_FLAG_UNORDERED_POINTS when
  * out[0] > 0.25 * out[1] (random clouds on patch-resolution maps: 1.93 -> 0.88 ms per 985 600 points). */
 int d3f_point_order_locality(const float *pts, int64_t n, float *out, void *stream);
+
+/* (ABI 6) d3f_lattice_probe AND d3f_point_order_locality in ONE launch, with nothing to clear beforehand: every one of the
+ * D3F_PROBE_WORDS device words of `out` is written by the call.  out[0..2] = (nx, ny, nz) of the lattice or zeros; out[8 + b],
+ * b < 16: non-zero when sample block b contradicts those dims (a lattice iff out[0] > 0 and all sixteen are zero);
+ * out[24 + 3q .. 24 + 3q + 2], q < 4, as FLOATS: sum of the steps between consecutive points, sum of the distances between
+ * points n/2 apart, number of finite samples of locality block q (mean step = sum of the first / sum of the third). */
+#define D3F_PROBE_WORDS 40
+int d3f_points_probe(const float *pts, int64_t n, int32_t *out, void *stream);
 
 /* The same for Fusion.eval_dist: d(dist)/d(pts) = -mean over the valid views of row 2 of K@pose. */
 int d3f_eval_dist_backward(const d3f_views *views, const float *pts, int64_t n, const float *grad_dist,

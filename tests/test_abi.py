@@ -357,7 +357,7 @@ def test_family_table():
 
 
 def test_plan_table():
-    """One row per launch-plan threshold of d3f_api.hip (kSmallBatch, kCacheResidentBytes, kBatchedLoadBytes, kBeyondLlcBytes):
+    """One row per launch-plan threshold of d3f_api.hip (kSmallBatch, kCacheResidentBytes, kInfinityCacheBytes, kBatchedLoadBytes, kBeyondLlcBytes):
     the plan on either side of each boundary, from d3f_eval_plan_query alone."""
     F = _lib.FLAG_FINITE_MAPS
 
@@ -373,6 +373,16 @@ def test_plan_table():
     p = _plan(1, 480, 640, 200000, one_map((64 << 20) + (384 << 10)), F)
     assert (p.reorder, p.tile_points) == (1, 16)
     assert _plan(1, 480, 640, 200000, one_map((64 << 20) + (384 << 10)), F, ws=0).reorder == 0      # no scratch, no sort
+    # D3F_FLAG_LOCAL_POINTS (ABI 6) + kInfinityCacheBytes = 256 MiB + kWindowCloudMin: a small cloud whose caller order is local keeps
+    # that order on maps inside the Infinity Cache -- not on larger maps, not at 262 144 points, and UNORDERED wins over LOCAL
+    L = _lib.FLAG_LOCAL_POINTS
+    assert _plan(1, 480, 640, 200000, one_map(200 << 20), F | L).reorder == 0
+    assert _plan(1, 480, 640, 200000, one_map(256 << 20), F | L).reorder == 0
+    assert _plan(1, 480, 640, 200000, one_map((256 << 20) + (384 << 10)), F | L).reorder == 1
+    assert _plan(1, 480, 640, 262143, one_map(200 << 20), F | L).reorder == 0
+    assert _plan(1, 480, 640, 262144, one_map(200 << 20), F | L).reorder == 1
+    assert _plan(1, 480, 640, 200000, one_map(200 << 20), F | L | _lib.FLAG_UNORDERED_POINTS).reorder == 1
+    assert _plan(1, 480, 640, 200000, one_map(200 << 20), F | L | _lib.TUNE_FORCE_REORDER).reorder == 1
     # kBatchedLoadBytes = 128 MiB per map: batched corner loads up to it, load-use per vector beyond (caller order)
     assert _plan(1, 480, 640, 200000, one_map(128 << 20), F, ws=0).vectors_per_lane[0] == 3          # 24 float4 = 8 lanes x 3
     assert _plan(1, 480, 640, 200000, one_map((128 << 20) + (384 << 10)), F, ws=0).vectors_per_lane[0] == -3
