@@ -261,18 +261,232 @@ __global__ __launch_bounds__(kBlock) void pairwise_dist_kernel(const float *__re
         pairwise_dist_body<FAST, 4>(src, tgt, B1, B2, C, dist_type, out, ws, stat_scale, As, Bs);
 }
 
+// ---- the same distances through the contraction |a|^2 + |b|^2 - 2 a.b on the fp32 matrix cores, GUARDED (round 6) -----------------
+// The direct form above costs two packed VALU instructions per two (pair, channel) terms -- a difference and a square-accumulate --
+// and four 16-byte LDS operand reads per sixteen of them.  The contraction needs ONE multiply-accumulate per term, and
+// v_mfma_f32_16x16x4_f32 does 1024 of them per instruction from two operand registers per lane: the same 32 MAC / cycle / SIMD as
+// v_pk_fma_f32 (MI355X_MICROARCH.md: exact fp32, bit for bit an fmaf chain), but half the issue slots of the direct form, a tenth
+// of its LDS operand traffic, and on a pipe of its own.  What the contraction loses is accuracy where it cancels: its error is
+// ~2e-7 * (|a|^2 + |b|^2) ABSOLUTE on d^2, harmless for far pairs and fatal for near matches -- the pairs a correspondence lookup
+// is for.  Hence the guard: a pair whose contraction result is not at least a QUARTER of |a|^2 + |b|^2 (or is not finite) is
+// recomputed in the direct form -- by the wave, cooperatively (64 lanes x one coalesced row pair), when a tile has few such pairs;
+// by pairwise_dist_body over the whole tile when it has many.  Beyond the guard d is good to 4e-7 relative, which moves a
+// softmax(-scale * d) output by at most ~2e-7 * scale * d_tie (two rows tied at distance d_tie and nothing nearer).
+// Tile and stage layout are those of pairwise_dist_body (64 x 64 outputs per workgroup, 32 channels per LDS stage, float4 columns);
+// wave w owns rows 16 w .. 16 w + 15 of the tile and all 64 columns: four accumulator tiles of v_mfma_f32_16x16x4_f32.
+// A lane reads ONE float4 per operand and k-half of a stage and feeds its four components to four successive MFMAs: MFMA c of
+// half r contracts the channels {4 (4 r + s) + c : s = 0..3} -- every channel of the stage exactly once, in a fixed order.
+constexpr int kGuardDenseFlags = 96;          // flagged pairs per 64 x 64 tile beyond which the whole tile takes the direct form
+constexpr int64_t kMfmaMinRows = 512;         // fewer source rows: the direct kernel (nothing to win, and small softmaxes have O(1) entries)
+
+template <int NW>
+__device__ __forceinline__ void pairwise_mfma_body(const float *__restrict__ src, const float *__restrict__ tgt, int64_t B1,
+                                                   int64_t B2, int C, int dist_type, float *__restrict__ out,
+                                                   ColStat *__restrict__ ws, float stat_scale, f32x4 (&As)[kPK / 4][kPT],
+                                                   f32x4 (&Bs)[kPK / 4][kPT])
+{
+    const int64_t i0 = (int64_t)blockIdx.y * kPT, j0 = (int64_t)blockIdx.x * kPT;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int lc = lane & 15, ls = lane >> 4;                    // column inside a 16-wide block / k slot (operands), row quad (results)
+    __shared__ float na_s[kBlock / 64][kPT], nb_s[kBlock / 64][kPT];
+    __shared__ int dense_s;
+    f32x4 acc[NW];
+#pragma unroll
+    for (int w = 0; w < NW; ++w) acc[w] = (f32x4)0.0f;
+    // stage fetch: as pairwise_dist_body<FAST> (uniform base + loop-invariant 32-bit offsets, rows clamped into the matrix)
+    f32x4 pa[2], pb[2];
+    uint32_t aoff[2], boff[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int e = threadIdx.x + h * kBlock;
+        const int r = e % kPT, k4 = e / kPT;
+        aoff[h] = (uint32_t)(min(i0 + r, B1 - 1) * C + k4 * 4);
+        boff[h] = (uint32_t)(min(j0 + r, B2 - 1) * C + k4 * 4);
+    }
+    auto fetch = [&](int k0) {
+        const float *sa = src + k0, *sb = tgt + k0;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            pa[h] = *reinterpret_cast<const f32x4 *>(sa + aoff[h]);
+            pb[h] = *reinterpret_cast<const f32x4 *>(sb + boff[h]);
+        }
+    };
+    if (threadIdx.x == 0) dense_s = 0;
+    // |a|^2, |b|^2: every lane squares what it stages (row threadIdx % 64, k quads threadIdx / 64 and + 4 of every stage), four
+    // lanes -- one per wave -- share a row; sixteen short partial sums per row instead of one chain of C terms
+    f32x4 na4 = (f32x4)0.0f, nb4 = (f32x4)0.0f;
+    fetch(0);
+    for (int k0 = 0; k0 < C; k0 += kPK) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int e = threadIdx.x + h * kBlock;
+            As[e / kPT][e % kPT] = pa[h];
+            Bs[e / kPT][e % kPT] = pb[h];
+            na4 = __builtin_elementwise_fma(pa[h], pa[h], na4);
+            nb4 = __builtin_elementwise_fma(pb[h], pb[h], nb4);
+        }
+        __syncthreads();
+        if (k0 + kPK < C) fetch(k0 + kPK);
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const f32x4 a = As[4 * r + ls][16 * wv + lc];
+            f32x4 b[NW];
+#pragma unroll
+            for (int w = 0; w < NW; ++w) b[w] = Bs[4 * r + ls][16 * w + lc];
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+#pragma unroll
+                for (int w = 0; w < NW; ++w) acc[w] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[c], b[w][c], acc[w], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    na_s[wv][lane] = (na4.x + na4.y) + (na4.z + na4.w);
+    nb_s[wv][lane] = (nb4.x + nb4.y) + (nb4.z + nb4.w);
+    __syncthreads();
+    // this lane's results: rows 16 wv + 4 ls + i (i < 4), columns 16 w + lc
+    float na[4], nb[NW];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = 16 * wv + 4 * ls + i;
+        na[i] = (na_s[0][r] + na_s[1][r]) + (na_s[2][r] + na_s[3][r]);
+    }
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {
+        const int cidx = 16 * w + lc;
+        nb[w] = (nb_s[0][cidx] + nb_s[1][cidx]) + (nb_s[2][cidx] + nb_s[3][cidx]);
+    }
+    const int rows_left = (int)min((int64_t)kPT, B1 - i0) - (16 * wv + 4 * ls), cols_left = (int)min((int64_t)kPT, B2 - j0) - lc;
+    float d2[4][NW];
+    uint32_t flagged = 0u;                       // bit 4 w + i: this lane's pair (i, w) is inside the matrix and fails the guard
+    int nflag = 0;
+#pragma unroll
+    for (int w = 0; w < NW; ++w)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float nsum = na[i] + nb[w];
+            d2[i][w] = fmaf(-2.0f, acc[w][i], nsum);
+            const bool live = i < rows_left && 16 * w < cols_left;
+            if (live && !(d2[i][w] >= 0.25f * nsum && nsum < INFINITY)) { flagged |= 1u << (4 * w + i); ++nflag; }     // NaN / Inf: flagged
+        }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) nflag += __shfl_xor(nflag, off, 64);
+    if (lane == 0 && nflag > 0) atomicAdd(&dense_s, nflag);
+    __syncthreads();
+    if (dense_s > kGuardDenseFlags) {            // (workgroup-uniform) many near pairs: the whole tile in the direct form
+        __syncthreads();                         // everyone has read dense_s and the norms before the stage buffers are reused
+        pairwise_dist_body<true, NW>(src, tgt, B1, B2, C, dist_type, out, ws, stat_scale, As, Bs);
+        return;
+    }
+    // few near pairs: each is recomputed by its wave, all 64 lanes on one (row, column) -- coalesced float4 reads of both rows
+    if (dense_s > 0) {
+#pragma unroll
+        for (int w = 0; w < NW; ++w)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                unsigned long long m = __ballot((flagged >> (4 * w + i)) & 1u);
+                while (m) {
+                    const int l = __ffsll((long long)m) - 1;
+                    m &= m - 1;
+                    const int64_t row = i0 + 16 * wv + 4 * (l >> 4) + i, col = j0 + 16 * w + (l & 15);
+                    const f32x4 *pr = reinterpret_cast<const f32x4 *>(src + row * C), *pc = reinterpret_cast<const f32x4 *>(tgt + col * C);
+                    f32x2 s2 = (f32x2)0.0f;
+                    for (int k4 = lane; k4 < C / 4; k4 += 64) {
+                        const f32x4 d = pr[k4] - pc[k4];
+                        const f32x2 lo = __builtin_shufflevector(d, d, 0, 1), hi = __builtin_shufflevector(d, d, 2, 3);
+                        s2 = __builtin_elementwise_fma(lo, lo, s2);
+                        s2 = __builtin_elementwise_fma(hi, hi, s2);
+                    }
+                    float ssum = s2.x + s2.y;
+#pragma unroll
+                    for (int off = 32; off > 0; off >>= 1) ssum += __shfl_xor(ssum, off, 64);
+                    if (lane == l) d2[i][w] = ssum;
+                }
+            }
+    }
+    // ---- epilogue: distances out, column statistics of the softmax (as pairwise_dist_body's; this lane's rows are 4 ls + i) ----
+    float dv[4][NW];
+    const uint32_t o00 = (uint32_t)(i0 + 16 * wv + 4 * ls) * (uint32_t)B2 + (uint32_t)(j0 + lc);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int w = 0; w < NW; ++w) {
+            // (an unflagged d2 is >= 0: the guard; a recomputed one is a sum of squares)
+            dv[i][w] = dist_type == D3F_DIST_L2 ? sqrtf(d2[i][w]) : d2[i][w];
+            if (i < rows_left && 16 * w < cols_left) out[o00 + (uint32_t)i * (uint32_t)B2 + 16 * w] = dv[i][w];
+        }
+    if (!ws) return;                                   // uniform
+    ColStat *red = reinterpret_cast<ColStat *>(&As[0][0]);      // [4 waves][64 columns] = 4 KiB, the stage buffer is free
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {
+        float v[4], m = -INFINITY;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            v[i] = i < rows_left ? -dv[i][w] * stat_scale : -INFINITY;
+            m = fmaxf(m, v[i]);
+        }
+        m = fmaxf(m, __shfl_xor(m, 16, 64));
+        m = fmaxf(m, __shfl_xor(m, 32, 64));
+        float sum = 0.0f;
+        int arg = 0x7fffffff;
+#pragma unroll
+        for (int i = 3; i >= 0; --i)
+            if (i < rows_left) {
+                sum += expf(v[i] - m);
+                if (v[i] == m) arg = 16 * wv + 4 * ls + i;          // descending i: the smallest row index of this lane wins
+            }
+        sum += __shfl_xor(sum, 16, 64);
+        sum += __shfl_xor(sum, 32, 64);
+        arg = min(arg, __shfl_xor(arg, 16, 64));
+        arg = min(arg, __shfl_xor(arg, 32, 64));
+        if (lane < 16) {
+            ColStat o;
+            o.m = m; o.s = sum; o.arg = arg == 0x7fffffff ? 0x7fffffffffffffffLL : i0 + arg;
+            red[wv * kPT + lc + 16 * w] = o;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < kPT && threadIdx.x < 16 * NW && j0 + threadIdx.x < B2) {
+        ColStat t = red[threadIdx.x];
+#pragma unroll
+        for (int q = 1; q < kBlock / 64; ++q) {
+            const ColStat u = red[q * kPT + threadIdx.x];
+            merge_stat(t.m, t.s, t.arg, u.m, u.s, u.arg);
+        }
+        ws[(int64_t)blockIdx.y * B2 + j0 + threadIdx.x] = t;
+    }
+}
+
+template <int NWT>
+__global__ __launch_bounds__(kBlock) void pairwise_mfma_kernel(const float *__restrict__ src, const float *__restrict__ tgt, int64_t B1,
+                                                              int64_t B2, int C, int dist_type, float *__restrict__ out,
+                                                              ColStat *__restrict__ ws, float stat_scale)
+{
+    __shared__ f32x4 As[kPK / 4][kPT];
+    __shared__ f32x4 Bs[kPK / 4][kPT];
+    if (NWT < 4 && blockIdx.x == gridDim.x - 1)          // uniform per workgroup
+        pairwise_mfma_body<NWT>(src, tgt, B1, B2, C, dist_type, out, ws, stat_scale, As, Bs);
+    else
+        pairwise_mfma_body<4>(src, tgt, B1, B2, C, dist_type, out, ws, stat_scale, As, Bs);
+}
+
 // ws != nullptr: also writes the column statistics of softmax(-d*stat_scale, dim=0) per 64-row tile into
 // ws[tile][column] (the layout softmax_merge_kernel reads), saving the separate pass over `out`
 hipError_t launch_pairwise_dist(const float *src, const float *tgt, int64_t B1, int64_t B2, int C, int dist_type,
-                                float *out, hipStream_t s, ColStat *ws, float stat_scale)
+                                float *out, hipStream_t s, ColStat *ws, float stat_scale, bool direct_only)
 {
     if (B1 == 0 || B2 == 0) return hipSuccess;
     dim3 grid((unsigned)((B2 + kPT - 1) / kPT), (unsigned)((B1 + kPT - 1) / kPT));
     const bool fast = (C % kPK == 0) && ((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(tgt)) % 16 == 0) &&
                       B1 * (int64_t)C < (1LL << 30) && B2 * (int64_t)C < (1LL << 30) && B1 * B2 < (1LL << 31);
     const int tail_groups = (int)((B2 - (int64_t)(grid.x - 1) * kPT + 15) / 16);         // 1..4
+    // the guarded contraction on the matrix cores (above) for the shapes of a correspondence lookup; `direct_only`: the direct form
+    // everywhere (the reference arithmetic of the tests)
+    const bool mfma = fast && !direct_only && B1 >= kMfmaMinRows;
 #define D3F_PAIRWISE(NWT_)                                                                                                      \
-    hipLaunchKernelGGL((pairwise_dist_kernel<true, NWT_>), grid, dim3(kBlock), 0, s, src, tgt, B1, B2, C, dist_type, out, ws, stat_scale)
+    do {                                                                                                                        \
+        if (mfma) hipLaunchKernelGGL((pairwise_mfma_kernel<NWT_>), grid, dim3(kBlock), 0, s, src, tgt, B1, B2, C, dist_type, out, ws, stat_scale); \
+        else hipLaunchKernelGGL((pairwise_dist_kernel<true, NWT_>), grid, dim3(kBlock), 0, s, src, tgt, B1, B2, C, dist_type, out, ws, stat_scale); \
+    } while (0)
     if (!fast)
         hipLaunchKernelGGL((pairwise_dist_kernel<false, 4>), grid, dim3(kBlock), 0, s, src, tgt, B1, B2, C, dist_type, out, ws, stat_scale);
     else if (tail_groups == 1) D3F_PAIRWISE(1);

@@ -57,6 +57,7 @@ struct EvalParams {
     int32_t win_slices;        // channel slices of 128 * win_u channels per texel of map 0 (looped inside the workgroup)
     int32_t win_u, win_vc;     // 16-byte vectors per lane (1..4), views with corner reads in flight
     int32_t win_pipe;          // 1 (default): software-pipelined point loop when the view count is 4 or 8
+    int32_t win_mfma;          // 20 / 36: the matrix-core point loop (k steps of four pool slots the variant holds weights for); 0: off
     int32_t win_pool_offset;   // byte offset of the two all-zero slices; the pool follows them
     int32_t win_pool_texels;   // pool capacity in texel slices of 512 * win_u bytes
     int32_t win_occ;           // workgroups per CU the kernel variant is built for (2 / 3 / 4)
@@ -177,7 +178,8 @@ constexpr int kSoftmaxRowsPerBlock = 64;     // = the row tile of pairwise_dist_
 hipError_t launch_dist_to_target(const float *src, int64_t B, int64_t inner, int C, int64_t sb, int64_t si,
                                  int64_t sc, const float *tgt, int dist_type, float *out, hipStream_t s);
 hipError_t launch_pairwise_dist(const float *src, const float *tgt, int64_t B1, int64_t B2, int C,
-                                int dist_type, float *out, hipStream_t s, ColStat *ws = nullptr, float stat_scale = 1.0f);
+                                int dist_type, float *out, hipStream_t s, ColStat *ws = nullptr, float stat_scale = 1.0f,
+                                bool direct_only = false);
 hipError_t launch_exp_neg_scale(float *x, int64_t n, float scale, hipStream_t s);
 // softmax(-x*scale, dim=0) of a row-major [rows, cols] matrix in place (+ optional argmax)
 hipError_t launch_softmax_dim0(float *x, int64_t rows, int64_t cols, float scale, int64_t *argmax_out,

@@ -509,6 +509,60 @@ def test_pairwise_vs_oracle(dev, B1, B2, C):
         assert rel_err(cpu(d), O.dist_to_target(src[sl].numpy(), tgt[7].numpy(), "l2", channel_axis=1)) <= TOL
 
 
+@pytest.mark.parametrize("B1,B2,C,dist_type,scale", [(100000, 300, 384, "l2", 1.0), (20000, 44, 64, "square", 0.05), (4097, 300, 384, "l2", 3.0)])
+def test_pairwise_guarded_contraction_near_duplicates(dev, B1, B2, C, dist_type, scale):
+    """The guarded contraction form of pairwise_dist (round 6: |a|^2 + |b|^2 - 2 a.b on the fp32 matrix cores; pairs that are not
+    at least a quarter of |a|^2 + |b|^2 apart are recomputed in the direct form) at config 5's size, against the oracle, with
+    exactly the rows a correspondence lookup exists for: exact duplicates, near matches at graded distances across the guard's
+    threshold, two rows tied for a column, a 64 x 64 block of mutually near descriptors (the whole tile falls back to the direct
+    form), a column with an offset (everything flagged), and non-finite descriptors (flagged: the reference's propagation)."""
+    from d3fields_amd import corr_utils as cu, _lib
+    from oracle import c_oracle as O
+    g = torch.Generator().manual_seed(B1 + B2)
+    src = torch.randn(B1, C, generator=g)
+    tgt = torch.randn(B2, C, generator=g)
+    typical = float((2 * C) ** 0.5)                             # distance of two unrelated unit-variance descriptors
+    eps = [0.0, 1e-4, 1e-2, 0.3, 1.0, 0.2 * typical, 0.45 * typical, 0.5 * typical, 0.55 * typical, 0.8 * typical]
+    rows = [(37 * (k + 1)) % B1 for k in range(len(eps))]
+    for k, e in enumerate(eps):                                  # column k: a match at distance ~e (0.5 * typical = the guard's threshold)
+        noise = torch.randn(C, generator=g)
+        tgt[k] = src[rows[k]] + noise * (e / float(noise.norm()))
+    tie = B1 // 2
+    tgt[12] = src[tie] + 0.1 * torch.randn(C, generator=g)
+    src[tie + 1] = tgt[12] + (src[tie] - tgt[12]).flip(0)        # rows tie, tie + 1: the same distance to column 12
+    if B2 >= 300:                                                # a dense block: 64 rows (one row tile) x columns 128..191 all mutually near
+        base = torch.randn(C, generator=g)
+        r0 = min(5056, B1 - 192) // 64 * 64
+        src[r0:r0 + 64] = base + 0.05 * torch.randn(64, C, generator=g)
+        tgt[128:192] = base + 0.05 * torch.randn(64, C, generator=g)
+        tgt[200] = tgt[200] + 40.0                               # an offset column: |b|^2 dwarfs every distance to it
+        src[777, 5] = float("inf")
+        tgt[201, 7] = float("nan")
+    srcd, tgtd = src.to(dev), tgt.to(dev)
+    sim, idx = cu.nearest_descriptor(srcd, tgtd, scale, dist_type)
+    dist = cu._pairwise(srcd, tgtd, 1.0, dist_type, _lib.SIM_DIST, False)[0]
+    ref, am = O.pairwise(src.numpy(), tgt.numpy(), scale, dist_type, return_argmax=True)
+    dref = O.pairwise(src.numpy(), tgt.numpy(), 1.0, dist_type, mode="dist")
+    got, dgot = cpu(sim), cpu(dist)
+    assert np.array_equal(np.isnan(dgot), np.isnan(dref)) and np.array_equal(np.isinf(dgot), np.isinf(dref))
+    fin = np.isfinite(dref)
+    assert np.abs(dgot[fin] - dref[fin]).max() <= 1e-5 * max(float(dref[fin].max()), 1.0)
+    # near pairs take the direct form: as exact as ever, also RELATIVE to themselves (the contraction alone: |a|^2 * 1e-7 absolute)
+    near = fin & (dref <= (0.45 * typical if dist_type == "l2" else (0.45 * typical) ** 2))
+    assert near.sum() >= len(eps) - 3
+    assert np.all(np.abs(dgot[near] - dref[near]) <= 2e-6 * dref[near] + 1e-30)
+    assert dgot[rows[0], 0] == 0.0                               # the exact duplicate
+    okc = ~np.isnan(ref).any(axis=0)                             # columns the NaN / Inf descriptors did not poison (softmax over rows)
+    assert np.array_equal(np.isnan(got).any(axis=0), ~okc)
+    assert rel_err(got[:, okc], ref[:, okc]) <= TOL
+    assert torch.allclose(sim[:, torch.from_numpy(okc).to(dev)].sum(0), torch.ones(int(okc.sum()), device=dev), atol=1e-4)
+    best = np.sort(ref[:, okc], axis=0)[-2:]
+    clear = best[1] - best[0] > 1e-4 * np.maximum(best[1], 1e-30)
+    assert np.array_equal(cpu(idx)[okc][clear], am[okc][clear])
+    for k in range(5):
+        assert idx[k].item() == rows[k]
+
+
 @pytest.mark.parametrize("B1,splits", [(5000, (0, 1700, 1700, 5000)), (257, (0, 256, 257)), (1000, (0, 333, 1000))])
 @pytest.mark.parametrize("dist_type", ["l2", "square"])
 def test_row_sharded_softmax_steps(dev, B1, splits, dist_type):
