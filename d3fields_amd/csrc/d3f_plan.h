@@ -579,7 +579,7 @@ inline int64_t plan_workgroups(const d3f::EvalParams &P, const Plan &pl, int64_t
 // what d3f_eval_plan_query reports (the maps in the caller's order)
 inline void report_plan(const d3f::EvalParams &P, const Plan &pl, const int *caller_map, int n_maps, int64_t ntiles, d3f_eval_plan *out)
 {
-    out->family = (int32_t)pl.family; out->reserved3 = 0;
+    out->family = (int32_t)pl.family; out->reserved3 = P.win_slices > 0 ? P.win_mfma : 0;
     out->tile_points = P.tile_pts;
     out->reorder = pl.walk ? 2 : (pl.reorder ? 1 : 0);
     out->lds_bytes = P.crec_offset + P.n_pre * P.tile_pts * P.V * 32 + P.lds_pad;

@@ -769,16 +769,17 @@ __device__ __forceinline__ void fused_eval_window_body(const EvalParams &P)
                 f32x4 acc4[4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) acc4[j] = (f32x4)0.0f;
+                // one k step = ONE ds_read_b128 per lane (requested a step ahead, whether or not the step is live: the LDS has the room)
+                // + four MFMAs, skipped when no point of this wave has a weight in the step's four slots (wave-uniform branch)
+                f32x4 b[2];
+                b[0] = *reinterpret_cast<const f32x4 *>(bq);
 #pragma unroll
-                for (int g4 = 0; g4 < KSM / 4; ++g4) {
-                    if (((mm_live >> (4 * g4)) & 0xfull) == 0ull) continue;          // (wave-uniform) no weight in these sixteen slots
-                    f32x4 b[4];
+                for (int ks = 0; ks < KSM; ++ks) {
+                    if (ks + 1 < KSM) b[(ks + 1) & 1] = *reinterpret_cast<const f32x4 *>(bq + (uint32_t)min(ks + 1, last_ks) * (4u * SB));
+                    if ((mm_live >> ks) & 1ull) {
 #pragma unroll
-                    for (int t = 0; t < 4; ++t) b[t] = *reinterpret_cast<const f32x4 *>(bq + (uint32_t)min(4 * g4 + t, last_ks) * (4u * SB));
-#pragma unroll
-                    for (int t = 0; t < 4; ++t)
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) acc4[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(mm_w[4 * g4 + t], b[t][j], acc4[j], 0, 0, 0);
+                        for (int j = 0; j < 4; ++j) acc4[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(mm_w[ks], b[ks & 1][j], acc4[j], 0, 0, 0);
+                    }
                 }
                 // lane (n = lane & 15, row quad lane >> 4): channels 4 n .. 4 n + 3 of this half for its four points
                 const uint32_t ocq = (uint32_t)sl * OSB + (uint32_t)q * 256u + (uint32_t)m * 16u;

@@ -89,6 +89,8 @@ int main()
     const int iters = 20000;
     for (int width : {128, 64}) {
         printf("\n== ds_read_b%d, 16 independent reads per s_waitcnt, %d iterations ==\n", width, iters);
+        // (rates from the KERNEL time and the clock measured inside it: a block's own cycle count is not the CU's when eight blocks
+        //  share it -- the first version of this table divided the CU's instructions by one block's cycles)
         printf("%-44s %5s %12s %12s %12s %9s\n", "EXEC", "w/SIMD", "cyc/instr/CU", "B/clk/CU", "act.B/clk/CU", "GHz");
         for (const M &mk : masks) {
             for (int wps : {1, 2, 4, 8}) {
@@ -110,11 +112,12 @@ int main()
                 for (int b = 0; b < blocks; ++b) { cyc += (double)h[2 * b]; wall += (double)h[2 * b + 1]; }
                 cyc /= blocks; wall /= blocks;
                 const double ghz = cyc / (wall / (wall_khz * 1e3)) / 1e9;
-                const double instr_per_cu = (double)iters * 16.0 * 4.0 * wps;       // 4 waves per block
+                const double instr_per_cu = (double)iters * 16.0 * 4.0 * wps;       // 4 waves per block, wps blocks per CU
                 const double bytes_full = instr_per_cu * 64.0 * (width / 8);
                 const double bytes_act = instr_per_cu * popc64(mk.m) * (width / 8);
-                printf("%-44s %5d %12.2f %12.1f %12.1f %9.2f   (kernel %.3f ms)\n", mk.name, wps, cyc / instr_per_cu, bytes_full / cyc,
-                       bytes_act / cyc, ghz, ms);
+                const double kcyc = (double)ms * 1e-3 * ghz * 1e9;                  // cycles of the whole kernel = of every CU
+                printf("%-44s %5d %12.2f %12.1f %12.1f %9.2f   (kernel %.3f ms)\n", mk.name, wps, kcyc / instr_per_cu, bytes_full / kcyc,
+                       bytes_act / kcyc, ghz, ms);
             }
         }
     }

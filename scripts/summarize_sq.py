@@ -50,6 +50,7 @@ for k, cs in sorted(per_kernel.items(), key=lambda kv: -mean(kv[1].get("GRBM_GUI
     frac("LDS array busy    = SQ_LDS_IDX_ACTIVE / (256 CUs x cycles)", c.get("SQ_LDS_IDX_ACTIVE", float("nan")), NCU * cyc)
     frac("LDS bank conflicts = SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE", c.get("SQ_LDS_BANK_CONFLICT", float("nan")), c.get("SQ_LDS_IDX_ACTIVE", float("nan")))
     frac("VALU busy         = 4 x SQ_ACTIVE_INST_VALU / (1024 SIMDs x cycles)", 4 * c.get("SQ_ACTIVE_INST_VALU", float("nan")), NSIMD * cyc)
+    frac("MFMA pipe busy    = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x cycles)", c.get("SQ_VALU_MFMA_BUSY_CYCLES", float("nan")), NSIMD * cyc)
     frac("LDS issue busy    = 4 x SQ_ACTIVE_INST_LDS / (1024 x cycles)", 4 * c.get("SQ_ACTIVE_INST_LDS", float("nan")), NSIMD * cyc)
     frac("VMEM issue busy   = 4 x SQ_ACTIVE_INST_VMEM / (1024 x cycles)", 4 * c.get("SQ_ACTIVE_INST_VMEM", float("nan")), NSIMD * cyc)
     frac("scalar busy       = 4 x SQ_ACTIVE_INST_SCA / (1024 x cycles)", 4 * c.get("SQ_ACTIVE_INST_SCA", float("nan")), NSIMD * cyc)
