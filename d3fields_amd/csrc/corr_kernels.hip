@@ -282,9 +282,11 @@ constexpr int64_t kMfmaMinRows = 512;         // fewer source rows: the direct k
 template <int NW>
 __device__ __forceinline__ void pairwise_mfma_body(const float *__restrict__ src, const float *__restrict__ tgt, int64_t B1,
                                                    int64_t B2, int C, int dist_type, float *__restrict__ out,
-                                                   ColStat *__restrict__ ws, float stat_scale, f32x4 (&As)[kPK / 4][kPT],
-                                                   f32x4 (&Bs)[kPK / 4][kPT])
+                                                   ColStat *__restrict__ ws, float stat_scale, f32x4 (&As2)[2][kPK / 4][kPT],
+                                                   f32x4 (&Bs2)[2][kPK / 4][kPT])
 {
+    f32x4 (&As)[kPK / 4][kPT] = As2[0];          // (the epilogue and the direct fallback reuse the first stage buffer)
+    f32x4 (&Bs)[kPK / 4][kPT] = Bs2[0];
     const int64_t i0 = (int64_t)blockIdx.y * kPT, j0 = (int64_t)blockIdx.x * kPT;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int lc = lane & 15, ls = lane >> 4;                    // column inside a 16-wide block / k slot (operands), row quad (results)
@@ -315,29 +317,37 @@ __device__ __forceinline__ void pairwise_mfma_body(const float *__restrict__ src
     // |a|^2, |b|^2: every lane squares what it stages (row threadIdx % 64, k quads threadIdx / 64 and + 4 of every stage), four
     // lanes -- one per wave -- share a row; sixteen short partial sums per row instead of one chain of C terms
     f32x4 na4 = (f32x4)0.0f, nb4 = (f32x4)0.0f;
-    fetch(0);
-    for (int k0 = 0; k0 < C; k0 += kPK) {
+    // two stage buffers, ONE barrier per stage: while the matrix cores contract stage k out of buffer k & 1, the registers fetched a
+    // stage ahead are stored into the other buffer (whose readers all passed the previous barrier)
+    auto stash = [&](int buf) {
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             const int e = threadIdx.x + h * kBlock;
-            As[e / kPT][e % kPT] = pa[h];
-            Bs[e / kPT][e % kPT] = pb[h];
+            As2[buf][e / kPT][e % kPT] = pa[h];
+            Bs2[buf][e / kPT][e % kPT] = pb[h];
             na4 = __builtin_elementwise_fma(pa[h], pa[h], na4);
             nb4 = __builtin_elementwise_fma(pb[h], pb[h], nb4);
         }
-        __syncthreads();
-        if (k0 + kPK < C) fetch(k0 + kPK);
+    };
+    fetch(0);
+    stash(0);
+    __syncthreads();
+    int cur = 0;
+    for (int k0 = 0; k0 < C; k0 += kPK, cur ^= 1) {
+        const bool more = k0 + kPK < C;
+        if (more) fetch(k0 + kPK);
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
-            const f32x4 a = As[4 * r + ls][16 * wv + lc];
+            const f32x4 a = As2[cur][4 * r + ls][16 * wv + lc];
             f32x4 b[NW];
 #pragma unroll
-            for (int w = 0; w < NW; ++w) b[w] = Bs[4 * r + ls][16 * w + lc];
+            for (int w = 0; w < NW; ++w) b[w] = Bs2[cur][4 * r + ls][16 * w + lc];
 #pragma unroll
             for (int c = 0; c < 4; ++c)
 #pragma unroll
                 for (int w = 0; w < NW; ++w) acc[w] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[c], b[w][c], acc[w], 0, 0, 0);
         }
+        if (more) stash(cur ^ 1);
         __syncthreads();
     }
     na_s[wv][lane] = (na4.x + na4.y) + (na4.z + na4.w);
@@ -461,8 +471,8 @@ __global__ __launch_bounds__(kBlock) void pairwise_mfma_kernel(const float *__re
                                                               int64_t B2, int C, int dist_type, float *__restrict__ out,
                                                               ColStat *__restrict__ ws, float stat_scale)
 {
-    __shared__ f32x4 As[kPK / 4][kPT];
-    __shared__ f32x4 Bs[kPK / 4][kPT];
+    __shared__ f32x4 As[2][kPK / 4][kPT];
+    __shared__ f32x4 Bs[2][kPK / 4][kPT];
     if (NWT < 4 && blockIdx.x == gridDim.x - 1)          // uniform per workgroup
         pairwise_mfma_body<NWT>(src, tgt, B1, B2, C, dist_type, out, ws, stat_scale, As, Bs);
     else

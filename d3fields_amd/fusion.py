@@ -435,39 +435,45 @@ class Fusion:
         tensor in place from outside torch (the next query re-checks the tensors it reads, ~0.35 ms per 1.9 GB)."""
         self._finite_cache.clear()
 
+    def _probe_now(self, pts_c, stream):
+        """(lattice dims or None, unordered?) of a query tensor from ONE d3f_points_probe launch and ONE host sync (round 6; rounds
+        3-5: d3f_lattice_probe and d3f_point_order_locality, a launch and a sync each)."""
+        out = torch.empty(_lib.PROBE_WORDS, dtype=torch.int32, device=pts_c.device)
+        _lib.check(self._lib.d3f_points_probe(_lib.ptr(pts_c), pts_c.shape[0], _lib.ptr(out), stream))
+        return self._parse_probe(out.cpu())
+
     def _is_unordered(self, pts_c, stream):
-        """d3f_point_order_locality on a NEW query tensor (cached by storage / version / length, so a grid queried
+        """The locality verdict of d3f_points_probe on a NEW query tensor (cached by storage / version / length, so a grid queried
         repeatedly is probed once): True when consecutive points are no closer than points half the batch apart,
-        i.e. a shuffled or random cloud.  Only steers D3F_FLAG_UNORDERED_POINTS -- a stale answer costs time, never
-        correctness."""
+        i.e. a shuffled or random cloud.  Only steers D3F_FLAG_UNORDERED_POINTS / D3F_FLAG_LOCAL_POINTS -- a stale answer costs
+        time, never correctness."""
         sig = (pts_c.data_ptr(), pts_c._version, pts_c.shape[0])
         hit = self._order_cache
         if hit is None or hit[0] != sig:
             if torch.cuda.is_current_stream_capturing():
                 return False                    # no host sync inside a HIP-graph capture
-            out = torch.empty(2, dtype=torch.float32, device=pts_c.device)
-            _lib.check(self._lib.d3f_point_order_locality(_lib.ptr(pts_c), pts_c.shape[0], _lib.ptr(out), stream))
-            near, far = out.tolist()
-            hit = (sig, bool(near > 0.25 * far))
+            dims, unordered = self._probe_now(pts_c, stream)
+            hit = (sig, unordered)
             self._order_cache = hit
+            if self.cache_point_order:
+                self._lattice_cache = (sig, dims)
         return hit[1]
 
     def _lattice_dims(self, pts_c, stream):
         """(nx, ny, nz) when the query tensor is a z-fastest lattice -- the materialised create_init_grid output the
-        reference's drivers hand to batch_eval (vis_repr.py:88-93) -- else None.  d3f_lattice_probe on a NEW query
-        tensor (one host sync; cached by storage / version / length when cache_point_order is on).  The dims only
-        select the walk order of d3f_eval_lattice, which reads every coordinate from the tensor itself: a stale
-        answer costs time, never correctness."""
+        reference's drivers hand to batch_eval (vis_repr.py:88-93) -- else None.  d3f_points_probe on a NEW query
+        tensor (one host sync; cached by storage / version / length when cache_point_order is on; the same launch also
+        answers _is_unordered).  The dims only select the walk order of d3f_eval_lattice, which reads every coordinate from
+        the tensor itself: a stale answer costs time, never correctness."""
         sig = (pts_c.data_ptr(), pts_c._version, pts_c.shape[0])
         hit = self._lattice_cache if self.cache_point_order else None
         if hit is None or hit[0] != sig:
             if torch.cuda.is_current_stream_capturing():
                 return None                     # no host sync inside a HIP-graph capture
-            out = torch.zeros(4, dtype=torch.int32, device=pts_c.device)
-            _lib.check(self._lib.d3f_lattice_probe(_lib.ptr(pts_c), pts_c.shape[0], _lib.ptr(out), stream))
-            got = [int(v) for v in out.tolist()]
-            hit = (sig, tuple(got[:3]) if (got[0] > 0 and got[3] == 0) else None)
+            dims, unordered = self._probe_now(pts_c, stream)
+            hit = (sig, dims)
             self._lattice_cache = hit
+            self._order_cache = (sig, unordered)
         return hit[1]
 
     # ---- probes without a host sync ------------------------------------------------------------------------

@@ -111,6 +111,37 @@ def test_lattice_probe(dev):
     assert f._lattice_dims(torch.zeros(70000, 3, device=dev), st) is None
 
 
+def test_points_probe_equals_the_two_probes(dev):
+    """d3f_points_probe (ABI 6: lattice + locality in ONE launch, nothing to clear beforehand) gives the verdicts of
+    d3f_lattice_probe and d3f_point_order_locality on grids, clouds, a surface-like cloud and degenerate inputs -- also when its
+    output buffer holds garbage before the call."""
+    import ctypes
+    from d3fields_amd import Fusion, create_init_grid, synth, _lib
+    lib = _lib.load()
+    st = _lib.current_stream_handle(dev)
+    grid = create_init_grid(box_for(40, 35, 11, 0.01), 0.01)[0]
+    surface = grid[(grid[:, 2] - 0.3 * grid[:, 0]).abs() < 0.004]                 # a sheet of the lattice in flat-index order: local, no lattice
+    cases = {"grid": grid, "cloud": synth.random_cloud(100000, seed=1), "shuffled": grid[torch.randperm(grid.shape[0])], "surface": surface,
+             "tall": create_init_grid(box_for(3, 5, 7000, 0.004), 0.004)[0], "two": grid[:2], "one": grid[:1], "nan": torch.full((5000, 3), float("nan"))}
+    for name, p in cases.items():
+        p = p.to(dev).contiguous()
+        n = p.shape[0]
+        old_l = torch.zeros(4, dtype=torch.int32, device=dev)
+        old_o = torch.zeros(2, dtype=torch.float32, device=dev)
+        _lib.check(lib.d3f_lattice_probe(_lib.ptr(p), n, _lib.ptr(old_l), st))
+        _lib.check(lib.d3f_point_order_locality(_lib.ptr(p), n, _lib.ptr(old_o), st))
+        li = old_l.tolist()
+        want_dims = tuple(li[:3]) if (li[0] > 0 and li[3] == 0) else None
+        near, far = old_o.tolist()
+        new = torch.full((_lib.PROBE_WORDS,), 0x7fc00001, dtype=torch.int32, device=dev)        # garbage (NaN bit patterns) beforehand
+        _lib.check(lib.d3f_points_probe(_lib.ptr(p), n, _lib.ptr(new), st))
+        dims, unordered = Fusion._parse_probe(new.cpu())
+        assert dims == want_dims, (name, dims, want_dims)
+        assert unordered == bool(near > 0.25 * far), (name, near, far)
+    assert Fusion._parse_probe(torch.zeros(_lib.PROBE_WORDS, dtype=torch.int32)) == (None, False)
+    assert lib.d3f_points_probe(None, 5, None, st) == _lib.ERR_INVALID_ARG
+
+
 # ---- lattice brick walk == caller order, bit for bit -------------------------------------------------------------------
 @pytest.mark.parametrize("dims,C,mask", [((64, 33, 37), 96, False), ((47, 53, 29), 384, True), ((130, 9, 61), 132, False),
                                          ((2, 2, 20000), 64, True), ((70, 70, 17), 1024, False)])
