@@ -164,7 +164,7 @@ int eval_common(const d3f_views *views, const float *pts, int64_t n, const d3f_c
     P.win_lpp = tune.window_lpp == 32 ? 32 : 16;     // 16 lanes x 2 vectors per point (C2 patch 0.565 -> 0.54 ms); U > 1: 32
     P.win_slices = 0; P.win_u = 1; P.win_vc = 1; P.win_pool_offset = 0; P.win_pool_texels = 0; P.win_occ = 4;
     P.win_pipe = tune.window_pipe < 0 ? 0 : 1;
-    P.win_sparse = 0; P.win_mfma = 0;
+    P.win_sparse = 0;
     P.gate = nullptr; P.gate_min = 0u; P.gate_want = 0;
     P.store_policy = tune.store < 0 ? 0 : (tune.store == 1 ? 1 : (tune.store == 3 ? 3 : 2));     // non-temporal rows (fuse_common.h: store_out)
     P.out_dist = out_dist; P.out_valid = out_valid;
@@ -226,16 +226,14 @@ int eval_common(const d3f_views *views, const float *pts, int64_t n, const d3f_c
     if ((pl.window || P.sl_slices > 0) && n > 0x7fffffffLL) return fail(D3F_ERR_BAD_SHAPE, "n=%lld: 32-bit point indices", (long long)n);
     if (plan_only) {
         plan_out->gated_window = 0; plan_out->reserved2 = 0;
-        int side_mfma = 0;
         if (cloud_side == 0 && !lattice && !grid) {       // would d3f_eval's first pass take the window side?  (its plan: the lattice's)
             d3f_eval_plan side;
             if (eval_common(views, pts, n, maps, n_maps, mu, flags, out_dist, out_valid, out_fused, out_inter, workspace, workspace_bytes,
                             stream, mode, &side, grid, lattice, 1) == D3F_OK)
                 for (int s = 0; s < n_maps; ++s)
-                    if (side.staged[s] == 3 && side.reorder == 1) { plan_out->gated_window = 1; plan_out->reserved2 = side.reserved; side_mfma = side.reserved3; }
+                    if (side.staged[s] == 3 && side.reorder == 1) { plan_out->gated_window = 1; plan_out->reserved2 = side.reserved; }
         }
         report_plan(P, pl, caller_map, n_maps, ntiles, plan_out);
-        if (plan_out->gated_window) plan_out->reserved3 = side_mfma;
         return D3F_OK;
     }
     // a cloud on the gated pair of launches: the window side (this pass) and the cell-run side (the next) read one device word

@@ -70,7 +70,7 @@ constexpr int64_t kInfinityCacheBytes = 256LL << 20;
     X(window_lpp, "D3F_EXP_WINDOW_LPP") X(window_occ, "D3F_EXP_WINDOW_OCC") X(window_pipe, "D3F_EXP_WINDOW_PIPE")                 \
     X(window_pool, "D3F_EXP_WINDOW_POOL") X(window_rr, "D3F_EXP_WINDOW_RR") X(window_slack, "D3F_EXP_WINDOW_SLACK")               \
     X(window_sparse, "D3F_EXP_WINDOW_SPARSE") X(window_u, "D3F_EXP_WINDOW_U") X(window_vc, "D3F_EXP_WINDOW_VC")                   \
-    X(window_want, "D3F_EXP_WINDOW_WANT") X(window_mfma, "D3F_EXP_WINDOW_MFMA")
+    X(window_want, "D3F_EXP_WINDOW_WANT")
 struct Tune {
 #define D3F_TUNE_FIELD(f, env) int f = 0;
     D3F_TUNE_KNOBS(D3F_TUNE_FIELD)
@@ -312,14 +312,6 @@ inline bool window_row(const Query &q, d3f::EvalParams &P)
     if (q.tune.window_pool > 0 && q.tune.window_pool < texels) texels = q.tune.window_pool;
     if (texels > 320) texels = 320;                      // kWinMaxTexels (fuse_window.hip)
     texels &= ~1;
-    // the matrix-core point loop (fp32 maps, 64-point tiles, 16 lanes x 2 vectors): a k step contracts four slots, and the variant
-    // holds weights for 80 / 144 slots; experiments builds: D3F_EXP_WINDOW_MFMA=-1 = the pipelined VALU loop of rounds 4-5
-    P.win_mfma = 0;
-    if (slot == 512 && U == 1 && T == 64 && P.win_lpp == 16 && q.tune.window_mfma >= 0 && q.tune.window_u == 0 && !occ_forced) {
-        if (texels > 144) texels = 144;
-        texels &= ~3;
-        P.win_mfma = texels <= 80 ? 20 : 36;
-    }
     window = texels >= 2 && (T * VP) % 64 == 0 && q.n / T < 0x7fffffffLL;
     if (U > 1) P.win_lpp = 32;
     P.win_u = U; P.win_occ = occ; P.win_pool_offset = pool_offset; P.win_pool_texels = texels;
@@ -579,7 +571,7 @@ inline int64_t plan_workgroups(const d3f::EvalParams &P, const Plan &pl, int64_t
 // what d3f_eval_plan_query reports (the maps in the caller's order)
 inline void report_plan(const d3f::EvalParams &P, const Plan &pl, const int *caller_map, int n_maps, int64_t ntiles, d3f_eval_plan *out)
 {
-    out->family = (int32_t)pl.family; out->reserved3 = P.win_slices > 0 ? P.win_mfma : 0;
+    out->family = (int32_t)pl.family; out->reserved3 = 0;
     out->tile_points = P.tile_pts;
     out->reorder = pl.walk ? 2 : (pl.reorder ? 1 : 0);
     out->lds_bytes = P.crec_offset + P.n_pre * P.tile_pts * P.V * 32 + P.lds_pad;

@@ -214,7 +214,7 @@ __device__ __forceinline__ void window_points_pipelined(const unsigned char *sme
 // 0 starts after phase A instead of underneath it.
 constexpr int kWinMaxBits = 2048;            // bitmap bits over all views' rectangles (rows that do not fit are left out)
 // HALF: map 0 is stored in fp16 (D3F_DTYPE_F16): 256-byte slices of 128 channels, one 16-byte raw vector per lane (see fma_mix8)
-template <int U, int VC, int NT, int LPP, int VFIX, bool SPARSE, bool HALF, int KSM = 0>
+template <int U, int VC, int NT, int LPP, int VFIX, bool SPARSE, bool HALF>
 __device__ __forceinline__ void fused_eval_window_body(const EvalParams &P)
 {
     using VT = f32x4;
@@ -429,13 +429,11 @@ __device__ __forceinline__ void fused_eval_window_body(const EvalParams &P)
     // granules, four per wave instruction); a wave instruction fills 1 KiB of consecutive pool slots
     auto stage = [&](int sl) {
         constexpr int GL = HALF ? 16 : 32, GPW = 64 / GL;        // lanes per granule, granules per wave instruction
-        // (matrix-core point loop: a k step contracts FOUR pool slots, so the filled slots are rounded up to a multiple of four --
-        //  the surplus ones repeat the last texel: finite operands for weights that are zero)
-        const int total = (KSM > 0 ? ((total_s + 3) & ~3) : total_s) * U;              // granules
+        const int total = total_s * U;              // granules
         const int h = lane / GL, l = lane % GL;
         const char *data = reinterpret_cast<const char *>(m0.data) + (size_t)sl * SB + (size_t)l * 16;
         for (int g2 = wave; g2 * GPW < total; g2 += NT / 64) {
-            const int hk = min(g2 * GPW + h, total_s * U - 1);
+            const int hk = min(g2 * GPW + h, total - 1);
             const int t = hk / U, part = hk - t * U;
             const char *src = data + texsrc_s[t] + (uint32_t)part * (uint32_t)(SB / U);
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
@@ -696,58 +694,7 @@ __device__ __forceinline__ void fused_eval_window_body(const EvalParams &P)
     // projection) is then done again by the general path and its row stored a second time -- same lane, same address, later in
     // program order.  (Round 4's first form let one flagged point send its whole wave to the general path for every slice:
     // C2-patch 0.52 ms at 4 workgroups per CU against 0.50 at 3 with the larger pool -- the overflow, not the occupancy.)
-    // ---- matrix-core point loop (round 6; KSM > 0: k steps of four pool slots the variant holds weights for) -------------------------
-    // The fused row of a point is a CONTRACTION over the pool slots: out[p][c] = sum over slots t of W[p][t] * T[t][c], where row p of W
-    // holds the point's folded weights at its (<= 4 V) corner slots and zeros elsewhere.  The pool numbers its slots view by view and
-    // row-major inside a view's window, so a point's non-zero terms come in the order nw, ne, sw, se, views ascending -- exactly the
-    // fma chain of window_point / gather_map -- and v_mfma_f32_16x16x4_f32 IS that chain (exact fp32, k ascending, one rounding per
-    // term: MI355X_MICROARCH.md); a zero weight times a finite texel adds +-0, which changes no bit of a sum that started at +0.  So
-    // the matrix cores produce the same bits as the pipelined loop -- at a fraction of its LDS traffic (every wave reads the pool
-    // ONCE per slice instead of four corner vectors per (point, view)) and with the VALU left to phase A of the other workgroups.
-    // Wave w owns points 16 w .. 16 w + 15 (the A operand: lane (m, s) = lane & 15, lane >> 4 holds W[16 w + m][4 ks + s], built
-    // once per brick from the window records and kept in registers across the slices) and, per 64-channel half of a slice, four
-    // accumulator tiles whose columns interleave -- tile j = channels 4 n + j -- so that ONE ds_read_b128 per lane (texel slot
-    // 4 ks + s, channels 4 n .. 4 n + 3: conflict-free under the hardware's lane groups) feeds the four B operands of a k step and
-    // a lane ends up with four consecutive channels of four points: 256-byte contiguous row pieces per 16 lanes, as before.
-    // Points with a direct pair or a strict projection keep zero weights here, are NOT stored here, and take the general path below.
-    constexpr bool MM = KSM > 0;
-    static_assert(!MM || (!HALF && U == 1 && LPP == 16 && NT == 256 && KSM % 4 == 0), "matrix-core loop: fp32 maps, 512-byte slices, 64-point tiles");
-    float mm_w[MM ? KSM : 1];
-    uint32_t mm_row[4] = {0u, 0u, 0u, 0u};         // global index of this lane's four result rows; 0xffffffff: not stored here
-    unsigned long long mm_live = 0ull;             // bit ks: some point of this wave has a weight in slots 4 ks .. 4 ks + 3
-    if constexpr (MM) {
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");          // records, flags, idx_s of phase A
-        const int m = lane & 15, s4 = lane >> 4;
-        const int pm = 16 * wave + m;
-#pragma unroll
-        for (int ks = 0; ks < KSM; ++ks) mm_w[ks] = 0.0f;
-        if (flag_s[pm] == 0u) {
-            for (int v = 0; v < Vg; ++v) {
-                const unsigned char *r = reinterpret_cast<const unsigned char *>(wrec_at(pm) + v);
-                const uint2 off = *reinterpret_cast<const uint2 *>(r);
-                const f32x4 wt = *reinterpret_cast<const f32x4 *>(r + 16);
-                // slots of the nw / sw corners (ne, se: the next slots); an invalid pair points at the zero slices IN FRONT of the
-                // pool: its "slot" is a huge number that matches no k step (and its weights are zero anyway)
-                const uint32_t ns = (off.x - pool_off) / SB, ss = (off.y - pool_off) / SB;
-                // of the two corners of a window row at most one falls on this lane's k slot s4
-                const bool t0 = (ns & 3u) == (uint32_t)s4, t1 = ((ns + 1u) & 3u) == (uint32_t)s4;
-                const bool b0 = (ss & 3u) == (uint32_t)s4, b1 = ((ss + 1u) & 3u) == (uint32_t)s4;
-                const uint32_t kt = t0 ? ns >> 2 : (t1 ? (ns + 1u) >> 2 : 0xffffffffu), kb = b0 ? ss >> 2 : (b1 ? (ss + 1u) >> 2 : 0xffffffffu);
-                const float wtop = t0 ? wt.x : wt.y, wbot = b0 ? wt.z : wt.w;
-#pragma unroll
-                for (int ks = 0; ks < KSM; ++ks) mm_w[ks] = kt == (uint32_t)ks ? wtop : (kb == (uint32_t)ks ? wbot : mm_w[ks]);
-            }
-        }
-#pragma unroll
-        for (int ks = 0; ks < KSM; ++ks)
-            if (__ballot(mm_w[ks] != 0.0f) != 0ull) mm_live |= 1ull << ks;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int pi = 16 * wave + 4 * s4 + i;
-            mm_row[i] = flag_s[pi] == 0u ? idx_s[pi] : 0xffffffffu;
-        }
-    }
-    const bool pipe_ok = !MM && VFIX > 0 && TP == KI * G && V == VFIX;
+    const bool pipe_ok = VFIX > 0 && TP == KI * G && V == VFIX;
     uint32_t pidx[KI] = {0u, 0u, 0u, 0u};          // global index of the lane group's points (read once: an LDS read inside the
                                                    // pipelined loop would drain it -- LDS reads return in order)
     if (pipe_ok) {
@@ -760,42 +707,7 @@ __device__ __forceinline__ void fused_eval_window_body(const EvalParams &P)
         D3F_STAMP();                                // 5 + 3 sl: pool of this slice ready
         const uint32_t co = (uint32_t)sl * SB + lane_off;               // byte offset of this lane's first vector in a texel
         const uint32_t oco = (uint32_t)sl * OSB + (uint32_t)l * 16u;             // ... of its first four channels in an output row (fp32)
-        if constexpr (MM) {
-            const int m = lane & 15, s4 = lane >> 4;
-            const int last_ks = ((total_s + 3) >> 2) - 1;                // the last k step with filled slots behind it
-#pragma unroll 1
-            for (int q = 0; q < 2; ++q) {                                // the two 64-channel halves of the slice
-                const unsigned char *bq = smem + pool_off + (uint32_t)s4 * SB + (uint32_t)q * 256u + (uint32_t)m * 16u;
-                f32x4 acc4[4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) acc4[j] = (f32x4)0.0f;
-                // one k step = ONE ds_read_b128 per lane (requested a step ahead, whether or not the step is live: the LDS has the room)
-                // + four MFMAs, skipped when no point of this wave has a weight in the step's four slots (wave-uniform branch)
-                f32x4 b[2];
-                b[0] = *reinterpret_cast<const f32x4 *>(bq);
-#pragma unroll
-                for (int ks = 0; ks < KSM; ++ks) {
-                    if (ks + 1 < KSM) b[(ks + 1) & 1] = *reinterpret_cast<const f32x4 *>(bq + (uint32_t)min(ks + 1, last_ks) * (4u * SB));
-                    if ((mm_live >> ks) & 1ull) {
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) acc4[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(mm_w[ks], b[ks & 1][j], acc4[j], 0, 0, 0);
-                    }
-                }
-                // lane (n = lane & 15, row quad lane >> 4): channels 4 n .. 4 n + 3 of this half for its four points
-                const uint32_t ocq = (uint32_t)sl * OSB + (uint32_t)q * 256u + (uint32_t)m * 16u;
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-                    if (mm_row[i] != 0xffffffffu)
-                        store_row_vec(out_bytes + ((uint64_t)mm_row[i] * row_bytes + ocq), f32x4{acc4[0][i], acc4[1][i], acc4[2][i], acc4[3][i]});
-            }
-#pragma unroll 1
-            for (int p = grp; p < TP; p += G)
-                if (flag_s[p] != 0u) {              // a direct pair or a strict point: the general path (its row is not stored above)
-                    VT acc[NV];
-                    point_slice(p, co, acc);
-                    store_point(p, oco, acc);
-                }
-        } else if (pipe_ok) {
+        if (pipe_ok) {
             window_points_pipelined<NV, (VFIX > 0 ? VFIX : 1), KI, VS, (int)SB, G * ((VFIX > 0 ? VFIX : 1) * 32 + 16), HALF>(
                 smem, (uint32_t)grp * pstride, lane_off, [&](int k, const VT (&acc)[NV]) {
                     char *row = out_bytes + ((uint64_t)pidx[k] * row_bytes + oco);
@@ -856,11 +768,11 @@ __device__ __forceinline__ void fused_eval_window_body(const EvalParams &P)
 // kernel's own steps 1-3: box, rectangles, bitmap), the last workgroup to finish publishes the count, and each kernel's workgroups
 // return at once unless the count is on their side of `gate_min`.  No host sync, capturable in a HIP graph; the losing launch
 // costs its dispatch (a few microseconds).
-template <int U, int VC, int WAVES, int NT = kBlock, int LPP = 32, int VFIX = 0, bool SPARSE = false, bool HALF = false, int KSM = 0>
+template <int U, int VC, int WAVES, int NT = kBlock, int LPP = 32, int VFIX = 0, bool SPARSE = false, bool HALF = false>
 __global__ __launch_bounds__(NT, WAVES) void fused_eval_window_kernel(const EvalParams P)
 {
     if (gated_out(P)) return;
-    fused_eval_window_body<U, VC, NT, LPP, VFIX, SPARSE, HALF, KSM>(P);
+    fused_eval_window_body<U, VC, NT, LPP, VFIX, SPARSE, HALF>(P);
 }
 
 // gate[0] verdict (tiles that fit), gate[1] running count, gate[2] workgroups done; [1] and [2] are zero between launches
@@ -1063,20 +975,7 @@ hipError_t launch_window(const EvalParams &P, hipStream_t stream)
         return hipGetLastError();
     }
 #undef D3F_WIN_LAUNCH_H
-    // fp32 maps: the matrix-core point loop (any view count <= 8; the variant is chosen by the pool size it holds weights for)
-#define D3F_WIN_LAUNCH_M(KSM_, SP_)                                                                                             \
-    do {                                                                                                                         \
-        if (lds_w > 64 * 1024) {                                                                                                 \
-            hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void *>(&fused_eval_window_kernel<1, 1, 4, kBlock, 16, 0, SP_, false, KSM_>), \
-                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_w);                        \
-            if (ea != hipSuccess) return ea;                                                                                     \
-        }                                                                                                                        \
-        hipLaunchKernelGGL((fused_eval_window_kernel<1, 1, 4, kBlock, 16, 0, SP_, false, KSM_>), gw, block, lds_w, stream, P);   \
-    } while (0)
-    if (lpp16 && P.win_mfma == 20 && P.tile_pts == 64) { if (P.win_sparse) D3F_WIN_LAUNCH_M(20, true); else D3F_WIN_LAUNCH_M(20, false); }
-    else if (lpp16 && P.win_mfma == 36 && P.tile_pts == 64) { if (P.win_sparse) D3F_WIN_LAUNCH_M(36, true); else D3F_WIN_LAUNCH_M(36, false); }
-#undef D3F_WIN_LAUNCH_M
-    else if (lpp16 && vfix == 4) D3F_WIN_LAUNCH_F(1, 1, 4, 16, 4);
+    if (lpp16 && vfix == 4) D3F_WIN_LAUNCH_F(1, 1, 4, 16, 4);
     else if (lpp16 && vfix == 8) D3F_WIN_LAUNCH_F(1, 1, 4, 16, 8);
     else if (lpp16) D3F_WIN_LAUNCH(1, 1, 4, 16);
 #ifdef D3F_EXPERIMENTS

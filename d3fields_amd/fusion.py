@@ -568,8 +568,6 @@ class Fusion:
             kernel = "fused_eval_window_kernel<%d, %d, %d, 256, %d, %d, %s%s>" % (r // 100, r // 10 % 10, 4 if plan.lanes_per_point[w0] == 16 else r % 10, plan.lanes_per_point[w0], vfix,
                                                                                 "false" if lattice is not None else "true",
                                                                                 ", true" if maps[w0].dtype == _lib.DTYPE_F16 else "")
-            if plan.reserved3 > 0:       # the matrix-core point loop (any view count; the last argument: k steps it holds weights for)
-                kernel = "fused_eval_window_kernel<1, 1, 4, 256, 16, 0, %s, false, %d>" % ("false" if lattice is not None else "true", plan.reserved3)
         elif plan.reserved >= 100:
             lg, vc = (plan.reserved - 100) // 10, (plan.reserved - 100) % 10
             kernel = "fused_eval_sliced_kernel<%d, %d, %d%s>" % (lg, vc, {1: 8, 2: 7, 4: 5}.get(vc, 5), ", true" if f16 else "")
@@ -592,8 +590,7 @@ class Fusion:
             # sparse-pool window kernel on 64-point tiles of the same order.  last_gate() says which one ran.
             r = int(plan.reserved2) - 2000
             self._last_plan["window_side"] = {
-                "kernel": ("fused_eval_window_kernel<1, 1, 4, 256, 16, 0, true, false, %d>" % plan.reserved3 if plan.reserved3 > 0 else
-                           "fused_eval_window_kernel<%d, %d, 4, 256, 16, %d, true>" % (r // 100, r // 10 % 10, int(views.V) if int(views.V) in (4, 8) else 0)),
+                "kernel": "fused_eval_window_kernel<%d, %d, 4, 256, 16, %d, true>" % (r // 100, r // 10 % 10, int(views.V) if int(views.V) in (4, 8) else 0),
                 "tile_points": 64,
                 "point_order": order.split(";")[0] + "; 64-point tiles through touched-texel windows in LDS (device-gated against the cell runs)"}
 

@@ -208,8 +208,7 @@ typedef struct d3f_eval_plan {
     int32_t reserved2;                      /* gated_window: the window side's `reserved` code (2000 + 100*U + 10*VC + W)       */
     int32_t family;                         /* ABI 5.  row of the planner's family table that took the query: 0 dist-only, 1 lds-window,
                                                2 cell-runs, 3 channel-sliced, 4 direct (d3f_plan_family_name; csrc/d3f_plan.h)      */
-    int32_t reserved3;                      /* ABI 6.  LDS texel-window kernel (of this plan, or of the window side of a gated pair): k steps of four
-                                               pool slots its MATRIX-CORE point loop holds weights for (20 / 36); 0: the VALU point loops           */
+    int32_t reserved3;
 } d3f_eval_plan;
 int d3f_eval_plan_query(const d3f_views *views, int64_t n, const d3f_channel_map *maps, int32_t n_maps,
                         uint32_t flags, int32_t have_workspace, int32_t want_inter, d3f_eval_plan *plan);
