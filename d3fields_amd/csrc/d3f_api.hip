@@ -158,7 +158,7 @@ int eval_common(const d3f_views *views, const float *pts, int64_t n, const d3f_c
     P.grid_x = grid ? grid->x : nullptr; P.grid_y = grid ? grid->y : nullptr; P.grid_z = grid ? grid->z : nullptr;
     P.grid_ny = grid ? grid->ny : 0; P.grid_nz = grid ? grid->nz : 0;
     P.walk_nx = P.walk_ny = P.walk_nz = 0; P.walk_tx = P.walk_ty = P.walk_tz = 1;
-    P.sl_unit = 128; P.sl_ilv = 1; P.sl_pin = 0; P.sl_slices = 0; P.sl_lg = 3; P.sl_vc = 4; P.sl_tiles = P.sl_groups = P.sl_chunks = 0;
+    P.sl_unit = 128; P.sl_ilv = 1; P.sl_slices = 0; P.sl_lg = 3; P.sl_vc = 4; P.sl_tiles = P.sl_groups = P.sl_chunks = 0;
     P.runs_occ = tune.runs_occ;
     P.thin_max_views = (tune.thin < 0 || (flags & D3F_TUNE_DIRECT_GATHER)) ? 0 : 8;
     P.win_lpp = tune.window_lpp == 32 ? 32 : 16;     // 16 lanes x 2 vectors per point (C2 patch 0.565 -> 0.54 ms); U > 1: 32

@@ -51,7 +51,6 @@ struct EvalParams {
     // channel-sliced launch (fused_eval_sliced_kernel): sl_slices > 0 selects it
     int32_t sl_unit;                   // workgroups (of 32 points) per unit
     int32_t sl_ilv;                    // units an XCD works on at the same time (1: one after the other)
-    int32_t sl_pin;                    // 1: slice-pinned XCDs (units in slice-major order, a contiguous eighth per XCD)
     int32_t sl_slices, sl_lg, sl_vc;   // slices per texel of map 0, log2(lanes per point), views with loads in flight
     int64_t sl_tiles, sl_groups, sl_chunks;   // walk tiles, groups of 4 tiles, chunks of 128 groups
     // LDS texel windows (fused_eval_window_kernel): win_slices > 0 selects it

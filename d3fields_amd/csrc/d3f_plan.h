@@ -64,7 +64,7 @@ constexpr int64_t kInfinityCacheBytes = 256LL << 20;
     X(order_morton, "D3F_EXP_ORDER_MORTON") X(runs, "D3F_EXP_RUNS") X(runs_occ, "D3F_EXP_RUNS_OCC") X(runs_tile, "D3F_EXP_RUNS_TILE") \
     X(runs_u, "D3F_EXP_RUNS_U") X(scan3, "D3F_EXP_SCAN3") X(sliced, "D3F_EXP_SLICED") X(sliced_cloud, "D3F_EXP_SLICED_CLOUD")     \
     X(sliced_f16, "D3F_EXP_SLICED_F16") X(sliced_ilv, "D3F_EXP_SLICED_ILV") X(sliced_pad, "D3F_EXP_SLICED_PAD")                   \
-    X(sliced_tile, "D3F_EXP_SLICED_TILE") X(sliced_unit, "D3F_EXP_SLICED_UNIT") X(sliced_vc, "D3F_EXP_SLICED_VC") X(sliced_pin, "D3F_EXP_SLICED_PIN")                 \
+    X(sliced_tile, "D3F_EXP_SLICED_TILE") X(sliced_unit, "D3F_EXP_SLICED_UNIT") X(sliced_vc, "D3F_EXP_SLICED_VC")                 \
     X(stamps, "D3F_EXP_STAMPS") X(store, "D3F_EXP_STORE") X(thin, "D3F_EXP_THIN") X(walk, "D3F_EXP_WALK")                         \
     X(walk_tile, "D3F_EXP_WALK_TILE") X(window, "D3F_EXP_WINDOW") X(window_f16, "D3F_EXP_WINDOW_F16")                             \
     X(window_lpp, "D3F_EXP_WINDOW_LPP") X(window_occ, "D3F_EXP_WINDOW_OCC") X(window_pipe, "D3F_EXP_WINDOW_PIPE")                 \
@@ -479,8 +479,6 @@ inline bool sliced_row(const Query &q, d3f::EvalParams &P, const Plan &pl)
     P.sl_unit = q.tune.sliced_unit > 0 ? q.tune.sliced_unit : (big ? 64 : (tiny ? 256 : (mini ? 512 : 128)));   // 4096 points per unit (smaller: slower)
     P.sl_chunks = (P.sl_groups + P.sl_unit - 1) / P.sl_unit;
     P.sl_ilv = q.tune.sliced_ilv >= 2 && q.tune.sliced_ilv <= 4 ? q.tune.sliced_ilv : 1;
-    P.sl_pin = q.tune.sliced_pin > 0 ? 1 : 0;
-    if (P.sl_pin) P.sl_ilv = 1;
     for (int s = 1; s < q.n_maps; ++s) pick_mapping(P.maps[s], P.maps[s].vw == 4, P.maps[s].vw >= 2, true, 1);
     if ((((P.sl_chunks * P.sl_slices + 7) / 8) + P.sl_ilv) * 8 * P.sl_unit > 0x7fffffffLL) P.sl_slices = 0;
     // its dynamic LDS (records + one corner record per (point, view)) must fit the 64 KiB a launch gets without opting in:

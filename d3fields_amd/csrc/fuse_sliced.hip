@@ -47,25 +47,11 @@ __device__ __forceinline__ void fused_eval_sliced_body(const EvalParams &P)
     const int64_t j = (int64_t)(blockIdx.x >> 3);
     // sl_ilv > 1: the XCD's consecutive workgroups alternate between sl_ilv units (other slices of other chunks)
     const int64_t jj = j / P.sl_ilv;
-    int64_t unit = ((jj / P.sl_unit) * P.sl_ilv + (j - jj * P.sl_ilv)) * 8 + xcd;
+    const int64_t unit = ((jj / P.sl_unit) * P.sl_ilv + (j - jj * P.sl_ilv)) * 8 + xcd;
     const int wg = (int)(jj % P.sl_unit);
-    const int64_t units = (int64_t)P.sl_chunks * P.sl_slices;
-    int64_t chunk;
-    int slice;
-    if (P.sl_pin) {
-        // SLICE-PINNED mapping: the units in slice-major order (all chunks of slice 0, then of slice 1, ...) are cut into eight
-        // contiguous runs, one per XCD.  An XCD then works on ONE slice (it changes at most once) and on CONSECUTIVE chunks of the
-        // walk: its L2 always sees the same 1 / slices of every texel, and what one chunk leaves behind is what its neighbour needs.
-        const int64_t per = (units + 7) / 8, t = jj / P.sl_unit;
-        unit = (int64_t)xcd * per + t;
-        if (t >= per || unit >= units) return;
-        slice = (int)(unit / P.sl_chunks);
-        chunk = unit - (int64_t)slice * P.sl_chunks;
-    } else {
-        if (unit >= units) return;
-        chunk = unit / P.sl_slices;
-        slice = (int)(unit - chunk * P.sl_slices);
-    }
+    if (unit >= (int64_t)P.sl_chunks * P.sl_slices) return;
+    const int64_t chunk = unit / P.sl_slices;
+    const int slice = (int)(unit - chunk * P.sl_slices);
     const int64_t grp4 = chunk * P.sl_unit + wg;                              // group of four consecutive walk tiles,
     if (grp4 >= P.sl_groups) return;                                          // or of TP consecutive points of a cloud's order
     const bool lat = P.walk_nx > 0;
