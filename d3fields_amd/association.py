@@ -124,6 +124,14 @@ def reorder(instances, query_texts):
     return [inst for text in ["background"] + list(query_texts) for inst in instances if inst["label"] == text]
 
 
+def _device_tensor(x, dev):
+    """The detection stack of one view on the device: tensors (CPU or device) are taken as they are -- np.asarray() of a device
+    tensor raises -- and everything else goes through numpy once."""
+    if isinstance(x, torch.Tensor):
+        return x.to(dev)
+    return torch.as_tensor(np.asarray(x)).to(dev)
+
+
 def paint_label_images(fusion, instances):
     """-> curr_obs_torch['mask'] = (V,H,W) uint8 device tensor: per view, detection idx[view] of instance k painted with k."""
     lib = _lib.load()
@@ -131,7 +139,7 @@ def paint_label_images(fusion, instances):
     obs = fusion.curr_obs_torch
     out = torch.zeros((fusion.num_cam, fusion.H, fusion.W), dtype=torch.uint8, device=dev)
     for view in range(fusion.num_cam):
-        dets = torch.as_tensor(np.asarray(obs["mask_gs"][view])).to(device=dev)
+        dets = _device_tensor(obs["mask_gs"][view], dev)        # numpy, CPU or device tensor (a GPU SAM producer's natural output)
         dets = (dets != 0).to(torch.uint8).reshape(dets.shape[0], -1).contiguous()
         assert dets.shape[1] == fusion.H * fusion.W
         owner = np.full(dets.shape[0], -1, np.int32)

@@ -1035,7 +1035,8 @@ class Fusion:
         of points as open3d's to rounding, in ascending voxel order (open3d's order is that of its hash map)."""
         assert len(view_idx_ls) == 1
         dev = torch.device(self.device)
-        gs = [torch.as_tensor(np.asarray(self.curr_obs_torch["mask_gs"][v])).to(dev) for v in view_idx_ls]      # [NI,H,W] each
+        from .association import _device_tensor
+        gs = [_device_tensor(self.curr_obs_torch["mask_gs"][v], dev) for v in view_idx_ls]      # [NI,H,W] each
         sel = torch.stack([(g[list(inst_idx_ls)] != 0).any(dim=0) for g in gs], dim=0)
         return self._masked_clouds(sel, list(view_idx_ls), boundaries, downsample)[0]
 

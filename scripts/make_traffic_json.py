@@ -1,4 +1,4 @@
-"""Rebuilds profiles/traffic.json from the rocprofv3 summaries of scripts/r5_profile_all.sh.
+"""Rebuilds profiles/traffic.json from the rocprofv3 summaries of scripts/r6_profile_all.sh.
 usage: python scripts/make_traffic_json.py profiles/r2_v3 [more dirs ...]   (later dirs override earlier ones)
 traffic = FETCH_SIZE[KB]*1024*2 + WRITE_SIZE[KB]*1024 per launch of the dominant fused_eval kernel (see _comment)."""
 import glob
@@ -16,7 +16,7 @@ try:
 except (OSError, ValueError):
     data = {}
 data["_comment"] = ("HBM-side bytes per launch of the dominant kernel from rocprofv3 PMC passes (separate --pmc runs, kernel-trace only; "
-                    "scripts/r5_profile_all.sh, rebuilt by scripts/make_traffic_json.py). traffic = FETCH_SIZE[KB]*1024*2 (gfx950 tallies "
+                    "scripts/r6_profile_all.sh, rebuilt by scripts/make_traffic_json.py). traffic = FETCH_SIZE[KB]*1024*2 (gfx950 tallies "
                     "16-B/lane coalesced reads at half size, MI355X_MICROARCH.md HBM section; confirmed here: FETCH_SIZE*1024 == "
                     "TCC_EA0_RDREQ_sum*64 with TCC_EA0_RDREQ_32B_sum == 0) + WRITE_SIZE[KB]*1024. FETCH_SIZE counts Infinity-Cache hits "
                     "(fabric traffic, not DRAM traffic). bench.py copies the entry of its workload into roofline.traffic "

@@ -25,7 +25,7 @@ fi
 for SPEC in $WLS; do
   WL=${SPEC%%:*}; PTS=grid; [ "$SPEC" != "$WL" ] && PTS=${SPEC##*:}
   NAME=$WL; [ "$PTS" != grid ] && NAME=${WL}_$PTS
-  CMD="python $REPO/bench.py --workload $WL --points $PTS --steps 6 --warmup 2 --no-cpu-baseline --no-verify"
+  CMD="python $REPO/bench.py --workload $WL --points $PTS --steps 6 --warmup 2 --no-cpu-baseline --no-verify --traffic off"
   i=0
   for PMC in "${PASSES[@]}"; do
     i=$((i+1))

@@ -637,6 +637,12 @@ def test_align_instance_mask_v3_matches_reference(dev, case):
     with pytest.raises(ValueError):
         _align_fusion(dev, g, producer=lambda fusion, q, t, b, **kw: {"mask_gs": gs[:-1], "mask_label": labels, "mask_conf": confs}) \
             .text_queries_for_inst_mask_no_track(queries, [0.3], box)
+    # a producer that runs on the GPU hands DEVICE tensors over (np.asarray() of those raised): same consensus, same image
+    gs_dev = [torch.as_tensor(np.asarray(x)).to(dev) for x in gs]
+    f = _align_fusion(dev, g, producer=lambda fusion, q, t, b, **kw: {"mask_gs": gs_dev, "mask_label": labels, "mask_conf": confs})
+    f.text_queries_for_inst_mask_no_track(queries, [0.3] * len(queries), box)
+    assert f.curr_obs_torch["consensus_mask_label"] == [str(x) for x in g["consensus_mask_label"]]
+    assert np.array_equal(cpu(f.curr_obs_torch["mask"]).argmax(-1).astype(np.uint8), g["mask"])
     # the tracking entry point: first frame = the same association, then the injected tracker (here: it returns what it was given)
     f = _align_fusion(dev, g, producer=lambda fusion, q, t, b, **kw: {"mask_gs": gs, "mask_label": labels, "mask_conf": confs})
     seen = []
