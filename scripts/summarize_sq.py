@@ -61,7 +61,7 @@ for k, cs in sorted(per_kernel.items(), key=lambda kv: -mean(kv[1].get("GRBM_GUI
     frac("waves per SIMD (resident) = 4 x SQ_WAVE_CYCLES / (1024 x cycles)", 4 * c.get("SQ_WAVE_CYCLES", float("nan")), NSIMD * cyc)
     frac("CUs busy          = 4 x SQ_BUSY_CU_CYCLES / (256 x cycles)", 4 * c.get("SQ_BUSY_CU_CYCLES", float("nan")), NCU * cyc)
     frac("VALU cycles per instruction = 4 x SQ_ACTIVE_INST_VALU / SQ_INSTS_VALU", 4 * c.get("SQ_ACTIVE_INST_VALU", float("nan")), c.get("SQ_INSTS_VALU", float("nan")))
-    frac("vector-L1 busy    = TCP_GATE_EN1_sum / (256 x cycles)", c.get("TCP_GATE_EN1_sum", float("nan")), NCU * cyc)
+    frac("vector-L1 clocked (TCP_GATE_EN1_sum / (256 x cycles); a clock enable, ~1 for every kernel: not a utilisation)", c.get("TCP_GATE_EN1_sum", float("nan")), NCU * cyc)
     frac("TA busy           = TA_TA_BUSY_sum / (256 x cycles)", c.get("TA_TA_BUSY_sum", float("nan")), NCU * cyc)
     frac("TD busy           = TD_TD_BUSY_sum / (256 x cycles)", c.get("TD_TD_BUSY_sum", float("nan")), NCU * cyc)
     frac("L1 pending stall  = TCP_PENDING_STALL_CYCLES_sum / (256 x cycles)", c.get("TCP_PENDING_STALL_CYCLES_sum", float("nan")), NCU * cyc)
