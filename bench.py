@@ -594,7 +594,8 @@ def main():
     bytes_alg, per_pt = algorithmic_bytes(w, n)
     traffic, traffic_src, valu_insts = measured_traffic(args.workload, args.points if w["step"] is not None else "grid", n)
     traffic_in_run = False
-    if rank == 0 and world == 1 and args.traffic != "off" and not w.get("no_maps") and "ROCPROFILER_" not in "".join(os.environ):
+    under_profiler = any(k.startswith(("ROCPROF", "ROCP_", "ROCTRACER")) for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", "")
+    if rank == 0 and world == 1 and args.traffic != "off" and not w.get("no_maps") and not under_profiler:
         # the timed binary, this box, this command: FETCH_SIZE / WRITE_SIZE of the fused kernel from two short profiler passes
         argv_w = ["--workload", args.workload, "--points", args.points] + (["--tuning", str(args.tuning)] if args.tuning else []) + \
                  (["--refresh-maps"] if args.refresh_maps else [])
