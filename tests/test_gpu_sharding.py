@@ -115,3 +115,32 @@ def test_bench_eight_ranks_dry_run_and_rccl_device_check():
                 "--workload", "c2_patch", "--points-per-gpu", "70000"]
         r2 = subprocess.run(cmd2, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
         assert r2.returncode != 0 and "needs 2 visible GPUs" in (r2.stderr + r2.stdout), (r2.returncode, r2.stderr[-1500:])
+
+
+def test_bench_line_measures_its_traffic_in_the_run():
+    """`python bench.py` (one GPU): the JSON line of the contract with `roofline` and `cpu_baseline`, verified against the oracle, and
+    `roofline.traffic` measured IN THE RUN -- two short rocprofv3 PMC passes of the same command on this box (FETCH_SIZE x 2 +
+    WRITE_SIZE of the fused kernel).  On patch-resolution maps the traffic is close to the algorithmic bytes; `--traffic off` falls
+    back to the committed copy (or null)."""
+    import json
+    import shutil
+    import subprocess
+    if shutil.which("rocprofv3") is None and not os.path.exists("/opt/rocm/bin/rocprofv3"):
+        pytest.skip("rocprofv3 not installed")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "c2_patch", "--steps", "5", "--warmup", "2", "--cpu-sample", "20000"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config",
+              "roofline", "cpu_baseline"):
+        assert k in line, k
+    rf = line["roofline"]
+    assert line["verified"] is True and line["n_gpus"] == 1 and line["dtype"] == "f32" and rf["bound"] == "hbm" and rf["peak"] == 8000.0
+    assert rf["traffic_measured_in_run"] is True, rf.get("traffic_source")
+    assert 0.9 * rf["algorithmic_bytes_per_launch"] <= rf["traffic"] <= 1.5 * rf["algorithmic_bytes_per_launch"]
+    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12 and 0.0 < rf["frac"] < 1.0
+    assert line["cpu_baseline"]["kind"] == "port" and line["cpu_baseline"]["cores"] >= 1 and line["cpu_baseline"]["value"] > 0
+    r2 = subprocess.run(cmd + ["--traffic", "off", "--no-cpu-baseline", "--no-verify"], capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r2.returncode == 0, r2.stderr[-2000:]
+    line2 = json.loads([ln for ln in r2.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line2["roofline"]["traffic_measured_in_run"] is False
