@@ -593,7 +593,7 @@ def main():
     value = total_pts / wall
     bytes_alg, per_pt = algorithmic_bytes(w, n)
     traffic, traffic_src, valu_insts = measured_traffic(args.workload, args.points if w["step"] is not None else "grid", n)
-    traffic_in_run = False
+    traffic_in_run, traffic_note = False, None
     under_profiler = any(k.startswith(("ROCPROF", "ROCP_", "ROCTRACER")) for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", "")
     if rank == 0 and world == 1 and args.traffic != "off" and not w.get("no_maps") and not under_profiler:
         # the timed binary, this box, this command: FETCH_SIZE / WRITE_SIZE of the fused kernel from two short profiler passes
@@ -605,6 +605,10 @@ def main():
             traffic, traffic_src, traffic_in_run = got, note, True
         elif args.traffic == "measure":
             raise SystemExit("bench.py --traffic measure: " + note)
+        else:
+            traffic_note = "not measured in this run (%s): the committed copy, if its fingerprint matches" % note
+    elif args.traffic != "off" and under_profiler:
+        traffic_note = "not measured in this run (the bench itself runs under a profiler): the committed copy, if its fingerprint matches"
     achieved = bytes_alg / (k_avg * 1e-3) / 1e9
     # SURVEY 8d secondary figure (reported, not graded): bytes the gather requests with zero inter-point reuse
     sumC = w["C"] + w["NI"] + w.get("color", 0)
@@ -641,6 +645,7 @@ def main():
                    "gather_xgmi_floor_ms": ((gather_keys.get("bytes", 0) / max(world - 1, 1)) / 153e9 * 1e3 if dist_on else "n/a")},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                     "traffic_note": traffic_note,
                      "traffic_measured_in_run": traffic_in_run,      # True: PMC passes of this command on this box (traffic_in_this_run); False: the committed copy
                      "kernel": (plan or {}).get("kernel", "fused_eval_kernel<0>"),
                      "kernel_ms_avg": k_avg, "kernel_ms_median": k_med,
