@@ -164,7 +164,7 @@ int eval_common(const d3f_views *views, const float *pts, int64_t n, const d3f_c
     P.win_lpp = tune.window_lpp == 32 ? 32 : 16;     // 16 lanes x 2 vectors per point (C2 patch 0.565 -> 0.54 ms); U > 1: 32
     P.win_slices = 0; P.win_u = 1; P.win_vc = 1; P.win_pool_offset = 0; P.win_pool_texels = 0; P.win_occ = 4;
     P.win_pipe = tune.window_pipe < 0 ? 0 : 1;
-    P.win_sparse = 0; P.win_narrow = 0;
+    P.win_sparse = 0;
     P.gate = nullptr; P.gate_min = 0u; P.gate_want = 0;
     P.store_policy = tune.store < 0 ? 0 : (tune.store == 1 ? 1 : (tune.store == 3 ? 3 : 2));     // non-temporal rows (fuse_common.h: store_out)
     P.out_dist = out_dist; P.out_valid = out_valid;

@@ -57,7 +57,6 @@ struct EvalParams {
     int32_t win_slices;        // channel slices of 128 * win_u channels per texel of map 0 (looped inside the workgroup)
     int32_t win_u, win_vc;     // 16-byte vectors per lane (1..4), views with corner reads in flight
     int32_t win_pipe;          // 1 (default): software-pipelined point loop when the view count is 4 or 8
-    int32_t win_narrow;        // 1: fp32 slices of 64 channels (256 bytes per pool slot), five workgroups per CU
     int32_t win_pool_offset;   // byte offset of the two all-zero slices; the pool follows them
     int32_t win_pool_texels;   // pool capacity in texel slices of 512 * win_u bytes
     int32_t win_occ;           // workgroups per CU the kernel variant is built for (2 / 3 / 4)

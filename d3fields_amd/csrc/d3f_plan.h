@@ -70,7 +70,7 @@ constexpr int64_t kInfinityCacheBytes = 256LL << 20;
     X(window_lpp, "D3F_EXP_WINDOW_LPP") X(window_occ, "D3F_EXP_WINDOW_OCC") X(window_pipe, "D3F_EXP_WINDOW_PIPE")                 \
     X(window_pool, "D3F_EXP_WINDOW_POOL") X(window_rr, "D3F_EXP_WINDOW_RR") X(window_slack, "D3F_EXP_WINDOW_SLACK")               \
     X(window_sparse, "D3F_EXP_WINDOW_SPARSE") X(window_u, "D3F_EXP_WINDOW_U") X(window_vc, "D3F_EXP_WINDOW_VC")                   \
-    X(window_want, "D3F_EXP_WINDOW_WANT") X(window_narrow, "D3F_EXP_WINDOW_NARROW")
+    X(window_want, "D3F_EXP_WINDOW_WANT")
 struct Tune {
 #define D3F_TUNE_FIELD(f, env) int f = 0;
     D3F_TUNE_KNOBS(D3F_TUNE_FIELD)
@@ -276,12 +276,8 @@ inline bool window_row(const Query &q, d3f::EvalParams &P)
     const int T = window_tile_points(q.tune);
     const int VP = views->V <= 1 ? 1 : views->V <= 2 ? 2 : views->V <= 4 ? 4 : 8;
     int U = q.tune.window_u;
-    // experiments builds, D3F_EXP_WINDOW_NARROW=1: fp32 slices of 64 channels (256-byte pool slots, one vector per lane) at up to five
-    // workgroups per CU -- twice the slices per row for 1.5 x the workgroups in flight
-    P.win_narrow = (q.tune.window_narrow > 0 && P.maps[0].esize == 4 && T == 64 && P.win_lpp == 16 && q.tune.window_u == 0 &&
-                    (views->V == 4 || views->V == 8) && P.win_pipe) ? 1 : 0;
-    const int cv = P.maps[0].C / (P.win_narrow ? 64 : 128);   // slices per texel: 128 channels (512 bytes of fp32, 256 of fp16); narrow: 64 fp32 channels
-    const int slot = (P.maps[0].esize == 2 || P.win_narrow) ? 256 : 512;
+    const int cv = P.maps[0].C / 128;                  // 128-channel granules per texel (512 bytes of fp32, 256 of fp16)
+    const int slot = P.maps[0].esize == 2 ? 256 : 512;
     if (U < 1 || U > 4 || cv % U != 0 || slot == 256) U = 1;
     if (slot == 256) P.win_lpp = 16;
     // per (point, view): 32-byte window record (+ the 16-byte view record when thin maps ride along); per point 20 bytes
@@ -290,7 +286,6 @@ inline bool window_row(const Query &q, d3f::EvalParams &P)
     int occ = q.tune.window_occ;
     const bool occ_forced = occ >= 5 && occ <= 6;        // experiments: 5 / 6 workgroups per CU with the plain point loop
     if (occ < 2 || occ > 6) occ = 4;
-    if (P.win_narrow && !occ_forced && q.tune.window_occ == 0) occ = 5;       // (the narrow variant is built for five waves per SIMD)
     if (U > 1) occ = 2;                                 // those variants are built for 2 workgroups per CU
     // touched-texel pool (SPARSE) for clouds, whole rectangles for lattice bricks (which never overflow: 0.42 vs 0.455 ms on
     // C2-patch); experiments builds: D3F_EXP_WINDOW_SPARSE = 1 / -1 forces either
@@ -582,7 +577,7 @@ inline void report_plan(const d3f::EvalParams &P, const Plan &pl, const int *cal
     out->lds_bytes = P.crec_offset + P.n_pre * P.tile_pts * P.V * 32 + P.lds_pad;
     out->workgroups = P.sl_slices > 0 ? (((P.sl_chunks * P.sl_slices + 7) / 8 + P.sl_ilv - 1) / P.sl_ilv * P.sl_ilv) * 8 * P.sl_unit : ntiles;
     if (P.win_slices > 0) {
-        out->lds_bytes = P.win_pool_offset + (2 + P.win_pool_texels) * ((P.maps[0].esize == 2 || P.win_narrow) ? 256 : 512) * P.win_u;
+        out->lds_bytes = P.win_pool_offset + (2 + P.win_pool_texels) * (P.maps[0].esize == 2 ? 256 : 512) * P.win_u;
         out->workgroups = ntiles;
     }
     // 2UVW: the window kernel's template arguments (W: workgroups per CU the pool is sized for); 1LV: sliced launch, L = log2(lanes

@@ -214,15 +214,12 @@ __device__ __forceinline__ void window_points_pipelined(const unsigned char *sme
 // 0 starts after phase A instead of underneath it.
 constexpr int kWinMaxBits = 2048;            // bitmap bits over all views' rectangles (rows that do not fit are left out)
 // HALF: map 0 is stored in fp16 (D3F_DTYPE_F16): 256-byte slices of 128 channels, one 16-byte raw vector per lane (see fma_mix8)
-// NARROW (round 6): fp32 slices of 64 channels = 256 bytes, ONE 16-byte vector per lane (16 lanes per point): half the pool per slot, so a
-// CU holds four or five workgroups where the 512-byte slices allow three (twice the slices, barriers and record reads per row)
-template <int U, int VC, int NT, int LPP, int VFIX, bool SPARSE, bool HALF, bool NARROW = false>
+template <int U, int VC, int NT, int LPP, int VFIX, bool SPARSE, bool HALF>
 __device__ __forceinline__ void fused_eval_window_body(const EvalParams &P)
 {
     using VT = f32x4;
     static_assert(LPP == 32 || (LPP == 16 && U == 1), "16 lanes per point only with 512-byte slices");
     static_assert(!HALF || (LPP == 16 && U == 1), "fp16-stored maps: 16 lanes x two 4-channel vectors per point");
-    static_assert(!NARROW || (!HALF && LPP == 16 && U == 1), "64-channel slices: fp32 maps, 16 lanes x one vector per point");
     constexpr int ES = HALF ? 2 : 4;                   // bytes per stored channel of map 0
 #ifdef D3F_EXPERIMENTS
     // phase stamps (D3F_EXP_STAMPS=1): lane 0 of wave 0 of every 64th workgroup writes s_memtime at the phase boundaries
@@ -233,7 +230,7 @@ __device__ __forceinline__ void fused_eval_window_body(const EvalParams &P)
 #define D3F_STAMP() do { } while (0)
 #endif
     D3F_STAMP();                                    // 0: entry
-    constexpr int NV = NARROW ? 1 : U * (32 / LPP);    // vectors per lane
+    constexpr int NV = U * (32 / LPP);                 // vectors per lane
     constexpr int RB = HALF ? 8 : 16;                  // bytes of a lane's raw vector (four channels as stored)
     constexpr int VS = RB * LPP;                       // bytes between a lane's raw vectors inside a slice
     extern __shared__ __align__(16) unsigned char smem[];
@@ -251,8 +248,8 @@ __device__ __forceinline__ void fused_eval_window_body(const EvalParams &P)
     uint32_t *idx_s = flag_s + TP;                                           // [TP]
     float *aux_s = reinterpret_cast<float *>(idx_s + TP);                    // [TP][2]: refined 1/(cnt + 1e-6), cnt + 1e-6
     float *krt = aux_s + 2 * TP;                                             // [V*12]
-    constexpr uint32_t SB = ((HALF || NARROW) ? 256u : 512u) * U;            // bytes of one texel slice (128 * U channels as stored; NARROW: 64 fp32 channels)
-    constexpr uint32_t OSB = (NARROW ? 256u : 512u) * U;                     // ... of the same channels in an output row (fp32)
+    constexpr uint32_t SB = (HALF ? 256u : 512u) * U;                        // bytes of one texel slice (128 * U channels as stored)
+    constexpr uint32_t OSB = 512u * U;                                       // ... of the same channels in an output row (fp32)
     constexpr int OVS = 16 * LPP;                                            // bytes between a lane's accumulator vectors in an output row
     const uint32_t zero_off = (uint32_t)P.win_pool_offset;                   // two all-zero slices, then the pool
     const uint32_t pool_off = zero_off + 2u * SB;
@@ -431,7 +428,7 @@ __device__ __forceinline__ void fused_eval_window_body(const EvalParams &P)
     // copy of slice `sl` of every window into the pool: 512-byte granules, two per wave instruction (fp16 storage: 256-byte
     // granules, four per wave instruction); a wave instruction fills 1 KiB of consecutive pool slots
     auto stage = [&](int sl) {
-        constexpr int GL = (HALF || NARROW) ? 16 : 32, GPW = 64 / GL;        // lanes per granule, granules per wave instruction
+        constexpr int GL = HALF ? 16 : 32, GPW = 64 / GL;        // lanes per granule, granules per wave instruction
         const int total = total_s * U;              // granules
         const int h = lane / GL, l = lane % GL;
         const char *data = reinterpret_cast<const char *>(m0.data) + (size_t)sl * SB + (size_t)l * 16;
@@ -771,11 +768,11 @@ __device__ __forceinline__ void fused_eval_window_body(const EvalParams &P)
 // kernel's own steps 1-3: box, rectangles, bitmap), the last workgroup to finish publishes the count, and each kernel's workgroups
 // return at once unless the count is on their side of `gate_min`.  No host sync, capturable in a HIP graph; the losing launch
 // costs its dispatch (a few microseconds).
-template <int U, int VC, int WAVES, int NT = kBlock, int LPP = 32, int VFIX = 0, bool SPARSE = false, bool HALF = false, bool NARROW = false>
+template <int U, int VC, int WAVES, int NT = kBlock, int LPP = 32, int VFIX = 0, bool SPARSE = false, bool HALF = false>
 __global__ __launch_bounds__(NT, WAVES) void fused_eval_window_kernel(const EvalParams P)
 {
     if (gated_out(P)) return;
-    fused_eval_window_body<U, VC, NT, LPP, VFIX, SPARSE, HALF, NARROW>(P);
+    fused_eval_window_body<U, VC, NT, LPP, VFIX, SPARSE, HALF>(P);
 }
 
 // gate[0] verdict (tiles that fit), gate[1] running count, gate[2] workgroups done; [1] and [2] are zero between launches
@@ -927,7 +924,7 @@ hipError_t launch_window(const EvalParams &P, hipStream_t stream)
                  ((P.walk_nz + P.walk_tz - 1) / P.walk_tz);
     dim3 block(kBlock);
     const bool half = P.maps[0].esize == 2;        // fp16-stored map: 256-byte slices (lattices only, 16 lanes per point)
-    const size_t lds_w = (size_t)P.win_pool_offset + (size_t)(2 + P.win_pool_texels) * ((half || P.win_narrow) ? 256 : 512) * P.win_u;
+    const size_t lds_w = (size_t)P.win_pool_offset + (size_t)(2 + P.win_pool_texels) * (half ? 256 : 512) * P.win_u;
     dim3 gw((unsigned)((P.n + P.tile_pts - 1) / P.tile_pts));
     if (P.walk_nx > 0) gw = dim3((unsigned)ntiles);
 #define D3F_WIN_LAUNCH_S(U_, VC_, W_, LPP_, VF_, SP_)                                                                          \
@@ -978,20 +975,7 @@ hipError_t launch_window(const EvalParams &P, hipStream_t stream)
         return hipGetLastError();
     }
 #undef D3F_WIN_LAUNCH_H
-    // 64-channel slices (fp32, pipelined loop): five waves per SIMD
-#define D3F_WIN_LAUNCH_N(VF_, SP_)                                                                                              \
-    do {                                                                                                                         \
-        if (lds_w > 64 * 1024) {                                                                                                 \
-            hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void *>(&fused_eval_window_kernel<1, 1, 5, kBlock, 16, VF_, SP_, false, true>), \
-                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_w);                        \
-            if (ea != hipSuccess) return ea;                                                                                     \
-        }                                                                                                                        \
-        hipLaunchKernelGGL((fused_eval_window_kernel<1, 1, 5, kBlock, 16, VF_, SP_, false, true>), gw, block, lds_w, stream, P); \
-    } while (0)
-    if (P.win_narrow && lpp16 && vfix == 4) { if (P.win_sparse) D3F_WIN_LAUNCH_N(4, true); else D3F_WIN_LAUNCH_N(4, false); }
-    else if (P.win_narrow && lpp16 && vfix == 8) { if (P.win_sparse) D3F_WIN_LAUNCH_N(8, true); else D3F_WIN_LAUNCH_N(8, false); }
-#undef D3F_WIN_LAUNCH_N
-    else if (lpp16 && vfix == 4) D3F_WIN_LAUNCH_F(1, 1, 4, 16, 4);
+    if (lpp16 && vfix == 4) D3F_WIN_LAUNCH_F(1, 1, 4, 16, 4);
     else if (lpp16 && vfix == 8) D3F_WIN_LAUNCH_F(1, 1, 4, 16, 8);
     else if (lpp16) D3F_WIN_LAUNCH(1, 1, 4, 16);
 #ifdef D3F_EXPERIMENTS
