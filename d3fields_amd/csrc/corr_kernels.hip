@@ -467,7 +467,7 @@ __device__ __forceinline__ void pairwise_mfma_body(const float *__restrict__ src
 }
 
 template <int NWT>
-__global__ __launch_bounds__(kBlock) void pairwise_mfma_kernel(const float *__restrict__ src, const float *__restrict__ tgt, int64_t B1,
+__global__ __launch_bounds__(kBlock, 4) void pairwise_mfma_kernel(const float *__restrict__ src, const float *__restrict__ tgt, int64_t B1,
                                                               int64_t B2, int C, int dist_type, float *__restrict__ out,
                                                               ColStat *__restrict__ ws, float stat_scale)
 {
