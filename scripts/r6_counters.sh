@@ -3,7 +3,7 @@
 # Busy fractions are computed against the MEASURED clock: cycles = GRBM_GUI_ACTIVE / 8 XCDs of the same pass, never 2.4 GHz.
 #   scripts/r6_counters.sh <tag> [workload[:points] ...]          (TCP=1: add the vector-memory passes)
 set -u
-TAG=${1:-r6_v1}; shift
+TAG=${1:-r6_v2}; shift
 WLS=${@:-c2_patch c3_patch ref_patch c4_patch c2_patch:random c4_patch:random ref_patch:surface c2_patch_f16 c2_dense c3_dense c2_dense_f16 dist_only c5_track}
 REPO=$(pwd); OUT=$REPO/gpurun_out/$TAG; mkdir -p $OUT
 export TMPDIR=/tmp

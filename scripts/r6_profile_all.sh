@@ -5,7 +5,7 @@
 # source fingerprint of the library it profiled (d3fields_amd/build.py), which scripts/make_traffic_json.py carries into profiles/traffic.json.
 #   scripts/r6_profile_all.sh <tag> [workload[:points] ...]
 set -u
-TAG=${1:-r6_v1}; shift
+TAG=${1:-r6_v2}; shift
 WLS=${@:-c2_dense c3_dense c2_patch c3_patch c4_patch ref_patch c2_patch:random c3_patch:random ref_patch:random ref_patch:surface c4_patch:random c5_track c2_patch_f16 c2_dense_f16 dist_only}
 REPO=$(pwd); OUT=$REPO/gpurun_out/$TAG; mkdir -p $OUT
 export TMPDIR=/tmp
