@@ -296,3 +296,72 @@ def test_association_bookkeeping_matches_reference_without_a_gpu(case, monkeypat
     assert_instances_match(g, "filtered", f.after_filter, V)
     assert [inst["label"] for inst in instances] == f.curr_obs_torch["consensus_mask_label"] == [str(x) for x in g["consensus_mask_label"]]
     assert np.array_equal(f.curr_obs_torch["mask"], g["mask"])
+
+
+def test_finite_word_ring_keeps_live_verdicts_across_wraps(monkeypatch):
+    """Host logic of the finite-check ring, with the device calls stubbed out: a cached verdict keeps its slot however often
+    the ring wraps; a slot is taken only after the descriptor validated; a check that cannot be made leaves no cached verdict; once the
+    ring has wrapped no batch claims that its words are already zero; close() forgets the ring."""
+    import contextlib
+    import types
+    from d3fields_amd import Fusion, _lib, fusion as fmod
+
+    class _Stream:
+        cuda_stream = 0
+        def wait_event(self, ev):
+            pass
+
+    class _Event:
+        def record(self, stream=None):
+            pass
+
+    flags_seen = []
+
+    class _FakeLib:
+        def d3f_map_check(self, *a):
+            return 0
+        def d3f_map_check_many(self, descs, views, n, words, zero, stream):
+            flags_seen.append(int(zero))
+            return 0
+
+    monkeypatch.setattr(torch.cuda, "is_current_stream_capturing", lambda: False)
+    monkeypatch.setattr(torch.cuda, "current_stream", lambda dev=None: _Stream())
+    monkeypatch.setattr(torch.cuda, "Event", _Event)
+    monkeypatch.setattr(torch.cuda, "device", lambda dev: contextlib.nullcontext())
+    monkeypatch.setattr(fmod._lib, "current_stream_handle", lambda dev: None)
+    f = Fusion(num_cam=2)
+    f._lib = _FakeLib()
+    depth = torch.ones(2, 8, 8)
+    batch = []
+    a0 = f._finite_word("depth", depth, batch=batch)
+    f._flush_checks(batch, depth.device)
+    assert flags_seen == [_lib.CHECK_WORDS_ARE_ZERO] and "depth" in f._finite_cache
+    slot = f._word_slot["depth"]
+    for k in range(3 * f._WORD_SLOTS):                       # a new map tensor per "frame": a new slot each time, never depth's
+        m = torch.ones(2, 4, 4, 8)
+        batch = []
+        assert f._finite_word("depth", depth, batch=batch) == a0 and not batch       # cache hit: same address, nothing queued
+        f._finite_word("dino_feats", m, batch=batch)
+        f._flush_checks(batch, m.device)
+        assert f._word_slot["depth"] == slot and f._word_slot["dino_feats"] != slot
+    assert f._ring_wrapped and flags_seen[-1] == 0            # after a wrap the call clears the words it writes itself
+    used = f._next_word
+    assert f._finite_word("dino_feats", torch.ones(2, 4, 4, 8, dtype=torch.float64)) is None      # not describable: float64
+    assert f._next_word == used and "dino_feats" not in f._finite_cache                          # no slot taken, no verdict left
+    f.close()
+    assert f._words is None and f._next_word == -1 and not f._ring_wrapped and f._order_ws is None and f._lattice_cache is None
+
+
+def test_parse_probe_words():
+    """The 40 words of d3f_points_probe -> (lattice dims or None, unordered?)."""
+    from d3fields_amd import Fusion, _lib
+    w = torch.zeros(_lib.PROBE_WORDS, dtype=torch.int32)
+    assert Fusion._parse_probe(w) == (None, False)
+    w[0], w[1], w[2] = 40, 35, 11
+    fl = w[24:36].view(torch.float32)
+    fl[0::3] = torch.tensor([1.0, 1.0, 1.0, 1.0]); fl[1::3] = torch.tensor([50.0, 50.0, 50.0, 50.0]); fl[2::3] = torch.tensor([256.0] * 4)
+    assert Fusion._parse_probe(w) == ((40, 35, 11), False)
+    w[8 + 5] = 1                                             # one sample block contradicts the dims
+    assert Fusion._parse_probe(w)[0] is None
+    fl[0::3] = torch.tensor([40.0] * 4)                       # consecutive points as far apart as far ones: unordered
+    assert Fusion._parse_probe(w) == (None, True)

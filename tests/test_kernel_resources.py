@@ -53,3 +53,15 @@ def test_default_kernels_keep_their_register_budget():
     spilling = {k: v for k, v in seen.items() if v[1] > 0}
     assert not spilling, spilling
     assert len(seen) <= 22, "experiment variants leaked into the product build: %s" % sorted(seen)
+
+
+@pytest.mark.skipif(shutil.which("hipcc") is None and not os.path.exists("/opt/rocm/bin/hipcc"), reason="needs hipcc")
+def test_pairwise_mfma_kernel_keeps_four_waves_per_simd():
+    """The guarded matrix-core pairwise kernel: its 16 accumulator registers come out of the same 512-entry file as the VGPRs, so
+    126 VGPRs + 16 AGPRs cost a wave per SIMD (round 6: 0.305 ms at three waves, 0.285 at four, __launch_bounds__(256, 4)); no spills."""
+    out = subprocess.run(["bash", os.path.join(ROOT, "scripts", "kernel_resources.sh"), "corr_kernels.hip"], capture_output=True, text=True, timeout=600).stdout
+    rows = [re.match(r"(\S+)\s+vgpr\s+(\d+)\s+sgpr\s+(\d+)\s+scratch\s+(\d+)\s+occ\s+(\d+)", line) for line in out.splitlines()]
+    mfma = [(m.group(1), int(m.group(2)), int(m.group(4)), int(m.group(5))) for m in rows if m and "pairwise_mfma_kernel" in m.group(1)]
+    assert len(mfma) == 4, out[-800:]
+    for name, vgpr, scratch, occ in mfma:
+        assert vgpr <= 128 and scratch == 0 and occ >= 4, (name, vgpr, scratch, occ)
