@@ -14,7 +14,7 @@ PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG_DIR, "csrc")
 INCLUDE = os.path.join(os.path.dirname(PKG_DIR), "include")
 LIB_PATH = os.path.join(PKG_DIR, "libd3fields_hip.so")
-SOURCES = ["fuse_launch.hip", "fuse_direct.hip", "fuse_runs.hip", "fuse_sliced.hip", "fuse_window.hip", "fuse_backward.hip", "scan_kernels.hip", "order_kernels.hip", "grid_kernels.hip", "pcd_kernels.hip", "assoc_kernels.hip", "misc_kernels.hip", "corr_kernels.hip", "track_kernels.hip", "d3f_api.hip"]
+SOURCES = ["fuse_launch.hip", "fuse_direct.hip", "fuse_runs.hip", "fuse_sliced.hip", "fuse_window.hip", "fuse_rows.hip", "fuse_backward.hip", "scan_kernels.hip", "order_kernels.hip", "grid_kernels.hip", "pcd_kernels.hip", "assoc_kernels.hip", "misc_kernels.hip", "corr_kernels.hip", "track_kernels.hip", "d3f_api.hip"]
 
 # -ffp-contract=off: the arithmetic contract says which products are fused; only
 # explicit fmaf() may fuse.  No -ffast-math: IEEE division and accurate expf are part of parity.
@@ -119,7 +119,7 @@ def _build_locked(hipcc, force, extra_flags, verbose):
 
 
 if __name__ == "__main__":
-    flags = []
+    flags = os.environ.get("D3F_EXTRA_CFLAGS", "").split()          # experiments: what-if macros of a tuning session
     if "--experiments" in sys.argv:
         os.environ["D3F_BUILD_EXPERIMENTS"] = "1"
     if "--save-temps" in sys.argv:

@@ -165,6 +165,7 @@ int eval_common(const d3f_views *views, const float *pts, int64_t n, const d3f_c
     P.win_slices = 0; P.win_u = 1; P.win_vc = 1; P.win_pool_offset = 0; P.win_pool_texels = 0; P.win_occ = 4;
     P.win_pipe = tune.window_pipe < 0 ? 0 : 1;
     P.win_sparse = 0;
+    P.rows = 0;
     P.gate = nullptr; P.gate_min = 0u; P.gate_want = 0;
     P.store_policy = tune.store < 0 ? 0 : (tune.store == 1 ? 1 : (tune.store == 3 ? 3 : 2));     // non-temporal rows (fuse_common.h: store_out)
     P.out_dist = out_dist; P.out_valid = out_valid;
@@ -223,7 +224,7 @@ int eval_common(const d3f_views *views, const float *pts, int64_t n, const d3f_c
     if (ntiles > 0x7fffffffLL) return fail(D3F_ERR_BAD_SHAPE, "n=%lld needs more than 2^31 workgroups", (long long)n);
     // the window and the channel-sliced kernels keep a point's global index in 32 bits of LDS (their rows already require
     // n < 2^31; this is the guard that says so)
-    if ((pl.window || P.sl_slices > 0) && n > 0x7fffffffLL) return fail(D3F_ERR_BAD_SHAPE, "n=%lld: 32-bit point indices", (long long)n);
+    if ((pl.window || pl.rows || P.sl_slices > 0) && n > 0x7fffffffLL) return fail(D3F_ERR_BAD_SHAPE, "n=%lld: 32-bit point indices", (long long)n);
     if (plan_only) {
         plan_out->gated_window = 0; plan_out->reserved2 = 0;
         if (cloud_side == 0 && !lattice && !grid) {       // would d3f_eval's first pass take the window side?  (its plan: the lattice's)

@@ -62,6 +62,7 @@ struct EvalParams {
     int32_t win_occ;           // workgroups per CU the kernel variant is built for (2 / 3 / 4)
     int32_t win_lpp;           // lanes per point in phase B: 32, or 16 (two vectors per lane inside a 512-byte slice)
     int32_t win_sparse;        // 1: the pool holds only the texels the tile's pairs touch (bitmap + ranks), 0: the views' whole rectangles
+    int32_t rows;              // 1: the register-rows kernel (fuse_rows.hip): 32 points per workgroup, their fused rows in registers
     int32_t thin_max_views;    // 8 (default): thin maps with 2..8 views are gathered with the views in parallel across lanes
                                // (gather_map_thin); 0 switches that off (D3F_EXP_THIN=-1, tests)
     int32_t runs_occ;      // experiment: waves per SIMD of the (1,8) cell-run kernel variant (4 / 5 / 6)
@@ -87,6 +88,7 @@ hipError_t launch_direct(const EvalParams &P, int mode, hipStream_t stream);    
 hipError_t launch_runs(const EvalParams &P, hipStream_t stream);                      // fuse_runs.hip
 hipError_t launch_sliced(const EvalParams &P, hipStream_t stream);                    // fuse_sliced.hip
 hipError_t launch_window(const EvalParams &P, hipStream_t stream);                    // fuse_window.hip
+hipError_t launch_rows(const EvalParams &P, hipStream_t stream);                      // fuse_rows.hip
 constexpr int kGateSamples = D3F_GATE_SAMPLES;            // tiles the probe looks at (evenly spaced over the order)
 hipError_t launch_window_gate_probe(const EvalParams &P, uint32_t *gate, int nsamples, hipStream_t stream);
 int64_t order_gate_offset(int64_t n);

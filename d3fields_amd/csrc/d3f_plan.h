@@ -54,6 +54,7 @@ constexpr int64_t kInfinityCacheBytes = 256LL << 20;
 //                      workgroup; vectors per lane, views in flight, workgroups per CU, pool texels, lanes per point, -1 = plain view loop, ...
 //   sliced (+ _vc _unit _ilv _tile _pad _f16 _cloud)   channel-sliced launch: 1 / 2 / 3 = 128- / 256- / 512-byte slices, -1 never
 //   walk / walk_tile   lattice brick walk: -1 off; tile shape as digits x y z (222 default, 224 with a thin map)
+//   rows               register-rows kernel (1024-channel patch maps): -1 never, 1 = also below kSmallBatch
 //   thin               -1: thin maps through the view-sequential gather_map instead of gather_map_thin
 //   store              row-store policy: -1 plain, 1 sc1, 3 `sc1 nt`, default `nt` (fuse_common.h: store_out)
 //   gate               > 0 always the window side of a cloud's gate, < 0 always the cell runs
@@ -61,7 +62,7 @@ constexpr int64_t kInfinityCacheBytes = 256LL << 20;
 //   stamps             1: s_memtime phase stamps of the window kernel (d3f_exp_read_stamps)
 #define D3F_TUNE_KNOBS(X)                                                                                                          \
     X(gate, "D3F_EXP_GATE") X(order_bits, "D3F_EXP_ORDER_BITS") X(order_fixed_grid, "D3F_EXP_ORDER_FIXED_GRID")                   \
-    X(order_morton, "D3F_EXP_ORDER_MORTON") X(runs, "D3F_EXP_RUNS") X(runs_occ, "D3F_EXP_RUNS_OCC") X(runs_tile, "D3F_EXP_RUNS_TILE") \
+    X(order_morton, "D3F_EXP_ORDER_MORTON") X(rows, "D3F_EXP_ROWS") X(runs, "D3F_EXP_RUNS") X(runs_occ, "D3F_EXP_RUNS_OCC") X(runs_tile, "D3F_EXP_RUNS_TILE") \
     X(runs_u, "D3F_EXP_RUNS_U") X(scan3, "D3F_EXP_SCAN3") X(sliced, "D3F_EXP_SLICED") X(sliced_cloud, "D3F_EXP_SLICED_CLOUD")     \
     X(sliced_f16, "D3F_EXP_SLICED_F16") X(sliced_ilv, "D3F_EXP_SLICED_ILV") X(sliced_pad, "D3F_EXP_SLICED_PAD")                   \
     X(sliced_tile, "D3F_EXP_SLICED_TILE") X(sliced_unit, "D3F_EXP_SLICED_UNIT") X(sliced_vc, "D3F_EXP_SLICED_VC")                 \
@@ -160,13 +161,13 @@ struct Query {
 };
 
 // What the planner decided besides the fields of EvalParams.
-enum FamilyId { kFamDistOnly = 0, kFamWindow, kFamRuns, kFamSliced, kFamDirect };
+enum FamilyId { kFamDistOnly = 0, kFamWindow, kFamRuns, kFamSliced, kFamDirect, kFamRows };
 struct Plan {
     FamilyId family = kFamDirect;
     bool walk = false;              // closed-form brick walk of a lattice
     bool reorder = false;           // walk, or the Hilbert order of a cloud
     bool xcd_remap = false;         // XCD k takes the k-th contiguous eighth of the tiles
-    bool window = false, runs = false, sliced = false;
+    bool window = false, runs = false, sliced = false, rows = false;
 };
 
 // ---- predicates on one map -----------------------------------------------------------------------------------------------------------
@@ -331,6 +332,31 @@ inline void window_geometry(const Query &q, d3f::EvalParams &P, Plan &pl)
     // a cloud's tiles go round-robin over the XCDs (all eight work on one neighbourhood: C2-patch cloud 0.52 ms against 0.58
     // with contiguous eighths, which is the lattice bricks' mapping); experiments builds: D3F_EXP_WINDOW_RR=-1 = eighths
     if (!pl.walk && q.tune.window_rr >= 0) P.flags |= D3F_TUNE_XCD_REMAP;
+}
+
+// =================================================== family: register-rows =========================================================
+// fuse_rows.hip: a patch-resolution map of exactly 1024 fp32 channels (256 lanes x one 16-byte vector: the reference's ViT-L
+// features, config 4) whose texels start on 16-byte boundaries; finite maps, no '<k>_inter', the other maps thin; a lattice (bricks of
+// 32 points) or any cloud -- Hilbert order when the planner reorders, the caller's otherwise.  Not gated: it replaces both sides.
+inline bool rows_row(const Query &q, d3f::EvalParams &P)
+{
+    const int knob = q.tune.rows;
+    bool rows = knob >= 0 && q.tune.window == 0 && q.tune.runs == 0 && q.tune.runs_u == 0 && !q.direct && q.mode == 0 && q.n_maps >= 1 &&
+                q.finite_expected && (q.n >= kSmallBatch || knob > 0) && q.n <= 0x7fffffffLL && q.tl == 0 && q.views->V <= 8 &&
+                P.maps[0].esize == 4 && P.maps[0].C == 1024 && window_candidate(P.maps[0], q.views, !q.plan_only);
+    for (int s = 0; s < q.n_maps; ++s) rows = rows && !q.want_inter[s];
+    for (int s = 1; s < q.n_maps; ++s) rows = rows && thin_fp32(P.maps[s]);
+    return rows;
+}
+
+inline void rows_geometry(const Query &q, d3f::EvalParams &P, Plan &pl)
+{
+    P.rows = 1; P.tile_pts = 32; P.lds_pad = 0;
+    if (pl.walk) pick_window_brick(P.walk_nx, P.walk_ny, P.walk_nz, P.tile_pts, P.walk_tx, P.walk_ty, P.walk_tz);
+    for (int s = 1; s < q.n_maps; ++s) pick_mapping(P.maps[s], P.maps[s].vw == 4, P.maps[s].vw >= 2, true, 1);
+    pl.xcd_remap = false;
+    P.flags &= ~D3F_TUNE_XCD_REMAP;
+    if (!pl.walk) P.flags |= D3F_TUNE_XCD_REMAP;         // a cloud's tiles round-robin over the XCDs (the window kernel's finding)
 }
 
 // =================================================== family: cell-runs ============================================================
@@ -503,6 +529,7 @@ constexpr FamilyRow kFamilies[] = {
     {kFamRuns, "cell-runs", "fused_eval_runs_kernel", "a patch-resolution wide fp32 map, >= 65 536 points; the other side of a cloud's gate"},
     {kFamSliced, "channel-sliced", "fused_eval_sliced_kernel", "a dense wide map (128..1024 channels) on a lattice walk or a Hilbert-ordered cloud"},
     {kFamDirect, "direct", "fused_eval_kernel / _wide_kernel / _f16_kernel", "everything else"},
+    {kFamRows, "register-rows", "fused_eval_rows_kernel", "a patch-resolution map of 1024 fp32 channels, finite maps, >= 65 536 points: a lattice (bricks of 32 points) or a cloud"},
 };
 inline const FamilyRow &family_row(FamilyId id) { return kFamilies[(int)id]; }
 
@@ -513,7 +540,13 @@ inline void plan_family_and_order(const Query &q, d3f::EvalParams &P, Plan &pl)
 {
     if (q.n_maps == 0) {
         pl.family = kFamDistOnly;
-    } else if ((pl.window = window_row(q, P))) {
+    } else if (rows_row(q, P) && (q.views->V > 4 || !(pl.window = window_row(q, P)))) {
+        // 1024-channel patch maps: the register rows with more than four views (config 4: 1.47 vs 1.68 ms on the lattice, 2.18 vs
+        // 2.66 on the cloud) and wherever the windows do not apply (small clouds: the 71 k surface points 0.125 vs 0.137 ms); four
+        // views on a lattice or a big cloud keep the windows (the reference's shape: 2.07 vs 2.37 ms)
+        pl.rows = true; pl.window = false; P.win_slices = 0;
+        pl.family = kFamRows;
+    } else if (pl.window || (pl.window = window_row(q, P))) {
         pl.family = kFamWindow;
     } else if ((pl.runs = runs_row(q, P, false))) {
         pl.family = kFamRuns;
@@ -521,7 +554,7 @@ inline void plan_family_and_order(const Query &q, d3f::EvalParams &P, Plan &pl)
     // Points on a regular lattice (a d3f_grid, or d3f_eval_lattice's dims): the brick walk is closed form -- no keys, no
     // sort, no index array, no scratch -- and replaces the Hilbert sort wherever that would be used.  (With the cell-run
     // gather the caller's z-fastest order is the one wanted: a grid column is one long run.)
-    pl.walk = q.walk_possible() && !pl.runs && ((q.flags & D3F_TUNE_FORCE_REORDER) || q.map_bytes > kCacheResidentBytes || pl.window);
+    pl.walk = q.walk_possible() && !pl.runs && ((q.flags & D3F_TUNE_FORCE_REORDER) || q.map_bytes > kCacheResidentBytes || pl.window || pl.rows);
     pl.reorder = pl.walk || q.reorder_cloud();
     if (pl.walk) { P.walk_nx = q.lattice[0]; P.walk_ny = q.lattice[1]; P.walk_nz = q.lattice[2]; }
 }
@@ -531,8 +564,9 @@ inline void plan_geometry(const Query &q, d3f::EvalParams &P, Plan &pl)
 {
     direct_geometry(q, P, pl);
     if (pl.runs) runs_geometry(q, P);
-    if (pl.family == kFamDirect && (pl.sliced = sliced_row(q, P, pl))) pl.family = kFamSliced;
+    if (pl.family == kFamDirect && !pl.rows && (pl.sliced = sliced_row(q, P, pl))) pl.family = kFamSliced;
     if (pl.window) window_geometry(q, P, pl);
+    if (pl.rows) rows_geometry(q, P, pl);
     // walks: all eight XCDs stay inside one macro-brick of ~32 k points at a time (its texel footprint stays in
     // the 256 MiB Infinity Cache), each taking a contiguous eighth of it (C2 dense 1.97 -> 1.74 ms, C4 patch 4.75 -> 4.17)
     P.xcd_chunk = (pl.reorder && pl.xcd_remap) ? (int)((32768 / P.tile_pts + 7) / 8 * 8) : 0;
@@ -580,6 +614,7 @@ inline void report_plan(const d3f::EvalParams &P, const Plan &pl, const int *cal
         out->lds_bytes = P.win_pool_offset + (2 + P.win_pool_texels) * (P.maps[0].esize == 2 ? 256 : 512) * P.win_u;
         out->workgroups = ntiles;
     }
+    if (P.rows > 0) out->lds_bytes = 24 * 1024;          // static: ops, cells, view records, keys (fuse_rows.hip)
     // 2UVW: the window kernel's template arguments (W: workgroups per CU the pool is sized for); 1LV: sliced launch, L = log2(lanes
     // per point), V = views in flight; cell runs: waves per SIMD the chosen variant is built for
     out->reserved = P.sl_slices > 0 ? 100 + P.sl_lg * 10 + P.sl_vc
@@ -595,8 +630,9 @@ inline void report_plan(const d3f::EvalParams &P, const Plan &pl, const int *cal
         const bool on = s < n_maps;
         const int c = on ? caller_map[s] : s;
         out->vector_floats[c] = on ? P.maps[s].vw : 0;
-        out->lanes_per_point[c] = on ? ((P.win_slices > 0 && s == 0) ? P.win_lpp : (1 << P.maps[s].lpp_log2)) : 0;
-        out->vectors_per_lane[c] = on ? ((P.win_slices > 0 && s == 0) ? P.win_u * (32 / P.win_lpp) : P.maps[s].unroll) : 0;   /* negative: load-use per vector */
-        out->staged[c] = on ? (P.win_slices > 0 && s == 0 ? 3 : (P.maps[s].runs > 0 ? 16 + P.maps[s].runs : 0)) : 0;
+        const bool rows0 = P.rows > 0 && s == 0;             // the register-rows kernel: 256 lanes x one vector on a point's row
+        out->lanes_per_point[c] = on ? (rows0 ? 256 : ((P.win_slices > 0 && s == 0) ? P.win_lpp : (1 << P.maps[s].lpp_log2))) : 0;
+        out->vectors_per_lane[c] = on ? (rows0 ? 1 : ((P.win_slices > 0 && s == 0) ? P.win_u * (32 / P.win_lpp) : P.maps[s].unroll)) : 0;   /* negative: load-use per vector */
+        out->staged[c] = on ? (rows0 ? 5 : (P.win_slices > 0 && s == 0 ? 3 : (P.maps[s].runs > 0 ? 16 + P.maps[s].runs : 0))) : 0;
     }
 }

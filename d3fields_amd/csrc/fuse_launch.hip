@@ -14,6 +14,7 @@ hipError_t launch_fused_eval(const EvalParams &P, int mode, hipStream_t stream)
         f16 |= (P.maps[s].esize == 2);
         runs |= (P.maps[s].runs > 0);
     }
+    if (mode == 0 && P.rows > 0) return launch_rows(P, stream);
     if (mode == 0 && P.win_slices > 0) return launch_window(P, stream);
     if (mode == 0 && P.sl_slices > 0) return launch_sliced(P, stream);
     if (mode == 0 && runs && !f16 && !wide) return launch_runs(P, stream);

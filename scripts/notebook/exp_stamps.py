@@ -43,6 +43,9 @@ for wl in sys.argv[1:] or ["c2_patch"]:
     for sl in range(S):
         labels += ["slice %d: wait pool (DMA, barrier)" % sl, "slice %d: point loop (wave 0)" % sl, "slice %d: barrier (other waves)" % sl]
     labels += ["DMA issue + rows drain (last)"]
+    if k == 8:       # the register-rows kernel (fuse_rows.hip)
+        print("   cells per brick: mean %.1f, ops per brick: mean %.1f" % (st[used][:, 30].mean(), st[used][:, 31].mean()))
+        labels = ["KRt", "phase A (wave 0)", "phase A (barrier)", "ranks, ops, cells", "zero + cell loop", "row stores", "dist/valid, redone points, thin maps"]
     print("%s: %d sampled workgroups, %d stamps each, mean lifetime %.0f cycles" % (wl, s.shape[0], k, life))
     for i in range(d.shape[1]):
         lab = labels[i] if i < len(labels) else "?"

@@ -193,11 +193,18 @@ def test_validation_of_topk_and_lattice_entry_points():
     # the same map without lattice dims (a cloud in caller order): the cell-run gather
     assert plan.reorder == 0 and plan.staged[0] == 16 + 4 and plan.tile_points == 64 and plan.lanes_per_point[0] == 32
     assert plan.vectors_per_lane[0] == 1 and plan.reserved == 7          # the (1,4) variant built for 7 waves per SIMD
-    wide = (_lib.ChannelMap * 1)(_lib.ChannelMap(1 << 20, 72, 128, 1024, 0, 72 * 128 * 1024, 128 * 1024, 1024))
+    wide = (_lib.ChannelMap * 1)(_lib.ChannelMap(1 << 20, 72, 128, 512, 0, 72 * 128 * 512, 128 * 512, 512))
     v8 = _views(V=8, H=720, W=1280)
-    assert lib.d3f_eval_plan_query(ctypes.byref(v8), 1000000, wide, 1, _lib.FLAG_FINITE_MAPS, 1, 0, ctypes.byref(plan)) == 0
+    assert lib.d3f_eval_plan_query(ctypes.byref(v8), 200000, wide, 1, _lib.FLAG_FINITE_MAPS | _lib.FLAG_UNORDERED_POINTS, 1, 0, ctypes.byref(plan)) == 0
     assert plan.reorder == 1 and plan.staged[0] == 16 + 8 and plan.vectors_per_lane[0] == 2 and plan.lanes_per_point[0] == 64
     assert plan.reserved == 3                                            # (2,8) at 3 waves per SIMD: spill-free
+    # config 4's own map (1024 fp32 channels, 8 views): the register-rows kernel, 32 points per workgroup, Hilbert order, no gate
+    wide = (_lib.ChannelMap * 1)(_lib.ChannelMap(1 << 20, 72, 128, 1024, 0, 72 * 128 * 1024, 128 * 1024, 1024))
+    assert lib.d3f_eval_plan_query(ctypes.byref(v8), 1000000, wide, 1, _lib.FLAG_FINITE_MAPS, 1, 0, ctypes.byref(plan)) == 0
+    assert (plan.family, plan.reorder, plan.staged[0], plan.tile_points, plan.workgroups, plan.gated_window) == (5, 1, 5, 32, 31250, 0)
+    assert (plan.lanes_per_point[0], plan.vectors_per_lane[0]) == (256, 1) and plan.lds_bytes <= 32 * 1024
+    assert lib.d3f_eval_plan_query_lattice(ctypes.byref(v8), 40, 280, 88, wide, 1, _lib.FLAG_FINITE_MAPS, 0, ctypes.byref(plan)) == 0
+    assert (plan.family, plan.reorder, plan.tile_points, plan.workgroups) == (5, 2, 32, 10 * 70 * 44)      # 4 x 4 x 2 bricks of the lattice
     assert lib.d3f_eval_plan_query_lattice(ctypes.byref(v), 160, 140, 44, patch, 1, 0, 0, ctypes.byref(plan)) == 0
     assert plan.staged[0] == 0 and plan.tile_points == 128     # maps not known to be finite: the direct gather
 
@@ -315,11 +322,21 @@ def test_window_launch_plan(monkeypatch):
     assert plan_lattice(4, (160, 140, 44), [(48, 64, 200)]).staged[0] != 3               # no whole 512-byte slices
     assert plan_lattice(4, (160, 140, 44), [(480, 640, 384)]).staged[0] == 0             # dense map: not a window case
     assert plan_lattice(16, (160, 140, 44), [(48, 64, 384)]).staged[0] != 3              # more than 8 views
-    p = _plan(8, 720, 1280, 1000000, [(72, 128, 1024)], flags=_lib.FLAG_FINITE_MAPS | _lib.FLAG_UNORDERED_POINTS)
+    p = _plan(8, 720, 1280, 1000000, [(72, 128, 512)], flags=_lib.FLAG_FINITE_MAPS | _lib.FLAG_UNORDERED_POINTS)
     assert (p.staged[0], p.reorder, p.gated_window) == (16 + 8, 1, 1)                    # a big cloud: the plan describes the cell-run side of the gated pair ...
     assert 2000 <= p.reserved2 < 3000 and p.reserved2 % 10 == 3                          # ... and names the window side's kernel (3 workgroups per CU and fewer)
-    p = _plan(8, 720, 1280, 1000000, [(72, 128, 1024)], flags=_lib.FLAG_FINITE_MAPS | _lib.FLAG_UNORDERED_POINTS | _lib.TUNE_NO_WINDOW_GATE)
+    p = _plan(8, 720, 1280, 1000000, [(72, 128, 512)], flags=_lib.FLAG_FINITE_MAPS | _lib.FLAG_UNORDERED_POINTS | _lib.TUNE_NO_WINDOW_GATE)
     assert (p.staged[0], p.reorder, p.gated_window) == (16 + 8, 1, 0)
+    # 1024 fp32 channels: the register rows take the cloud with more than four views (no gate), with four views they are the
+    # OTHER side of the window kernel's gate, and they take what the windows do not (a cloud below kWindowCloudMin)
+    p = _plan(8, 720, 1280, 1000000, [(72, 128, 1024)], flags=_lib.FLAG_FINITE_MAPS | _lib.FLAG_UNORDERED_POINTS)
+    assert (p.family, p.staged[0], p.reorder, p.gated_window) == (5, 5, 1, 0)
+    p = _plan(4, 480, 640, 1000000, [(48, 64, 1024)], flags=_lib.FLAG_FINITE_MAPS | _lib.FLAG_UNORDERED_POINTS)
+    assert (p.family, p.staged[0], p.reorder, p.gated_window, p.reserved2) == (5, 5, 1, 1, 2113)
+    p = _plan(4, 480, 640, 100000, [(48, 64, 1024)], flags=_lib.FLAG_FINITE_MAPS)
+    assert (p.family, p.staged[0], p.reorder, p.gated_window, p.tile_points) == (5, 5, 0, 0, 32)
+    assert plan_lattice(4, (160, 140, 44), [(48, 64, 1024)]).staged[0] == 3               # four views on a lattice: the windows
+    assert _plan(4, 480, 640, 100000, [(48, 64, 1024)], flags=0).family == 4             # maps not known to be finite
     p = _plan(4, 480, 640, 262143, [(48, 64, 384)], flags=_lib.FLAG_FINITE_MAPS | _lib.FLAG_UNORDERED_POINTS)
     assert (p.staged[0], p.reorder, p.gated_window) == (16 + 4, 1, 0)                    # kWindowCloudMin = 262 144 points: below it cell runs only
     p = _plan(4, 480, 640, 262144, [(48, 64, 384)], flags=_lib.FLAG_FINITE_MAPS | _lib.FLAG_UNORDERED_POINTS)
@@ -328,6 +345,10 @@ def test_window_launch_plan(monkeypatch):
     assert _plan(4, 480, 640, 985600, [(48, 64, 384)], flags=_lib.FLAG_UNORDERED_POINTS).gated_window == 0   # maps not known finite
     assert _plan(4, 480, 640, 985600, [(48, 64, 384)], flags=_lib.FLAG_FINITE_MAPS | _lib.FLAG_UNORDERED_POINTS, ws=0).gated_window == 0
     if exp:
+        monkeypatch.setenv("D3F_EXP_ROWS", "-1")
+        p = _plan(8, 720, 1280, 1000000, [(72, 128, 1024)], flags=_lib.FLAG_FINITE_MAPS | _lib.FLAG_UNORDERED_POINTS)
+        assert (p.staged[0], p.reorder, p.gated_window) == (16 + 8, 1, 1)                # without the register rows: rounds 2-5's gated pair
+        monkeypatch.delenv("D3F_EXP_ROWS")
         monkeypatch.setenv("D3F_EXP_WINDOW", "64")
         p = _plan(8, 720, 1280, 1000000, [(72, 128, 1024)], flags=_lib.FLAG_FINITE_MAPS | _lib.FLAG_UNORDERED_POINTS)
         assert (p.staged[0], p.reorder, p.workgroups) == (3, 1, 15625)                   # forced: 64 consecutive points of the Morton order
@@ -341,9 +362,9 @@ def test_family_table():
     library names it."""
     lib = _lib.load()
     F = _lib.FLAG_FINITE_MAPS
-    names = [lib.d3f_plan_family_name(k) for k in range(6)]
-    assert names == [b"dist-only", b"lds-window", b"cell-runs", b"channel-sliced", b"direct", None]
-    assert all(lib.d3f_plan_family_takes(k) for k in range(5)) and lib.d3f_plan_family_takes(7) is None
+    names = [lib.d3f_plan_family_name(k) for k in range(7)]
+    assert names == [b"dist-only", b"lds-window", b"cell-runs", b"channel-sliced", b"direct", b"register-rows", None]
+    assert all(lib.d3f_plan_family_takes(k) for k in range(6)) and lib.d3f_plan_family_takes(7) is None
     assert _plan(4, 480, 640, 100000, []).family == 0                                         # return_names=[]
     v = _lib.Views(4, 480, 640, 16, 16, 16)
     arr = (_lib.ChannelMap * 1)(_lib.ChannelMap(16, 48, 64, 384, 0, 48 * 64 * 384, 64 * 384, 384))
@@ -354,6 +375,7 @@ def test_family_table():
     assert _plan(4, 480, 640, 985600, [(480, 640, 384)], F | _lib.TUNE_DIRECT_GATHER).family == 4
     assert _plan(4, 480, 640, 300, [(48, 64, 384)], F).family == 4                             # a small batch
     assert _plan(4, 480, 640, 985600, [(48, 64, 384)], 0).family == 4                          # maps not known to be finite
+    assert _plan(8, 720, 1280, 985600, [(72, 128, 1024)], F).family == 5                       # 1024 fp32 channels, eight views: the rows in registers
 
 
 def test_plan_table():

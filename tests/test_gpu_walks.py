@@ -200,7 +200,7 @@ def test_lattice_walk_return_inter_and_nonfinite(dev):
 
 # ---- cell-run gather == direct gather, bit for bit ---------------------------------------------------------------------
 @pytest.mark.parametrize("C,V,fhw,mask,points", [(384, 4, (48, 64), False, "grid"), (384, 4, (48, 64), True, "grid"),
-                                                 (1024, 8, (24, 32), False, "cloud"), (132, 3, (12, 16), True, "grid"),
+                                                 (512, 8, (24, 32), False, "cloud"), (132, 3, (12, 16), True, "grid"),
                                                  (128, 4, (48, 64), False, "cloud")])
 def test_cell_run_gather_is_bit_identical(dev, C, V, fhw, mask, points):
     from d3fields_amd import create_init_grid, synth, _lib
@@ -295,8 +295,8 @@ def test_bench_workload_matches_oracle(dev, workload, points):
         out = f.batch_eval(pts, return_names=names)
         if points == "random" and workload in ("c2_patch", "c3_patch"):      # a dense cloud: the device-side gate opens the window side
             assert f.last_plan()["gated_window"] and f.last_gate()[1], (f.last_plan(), f.last_gate())
-        if points == "random" and workload == "c4_patch":                    # 8 views x 6.7-mm texels: the tiles do not fit, cell runs
-            assert f.last_plan()["gated_window"] and not f.last_gate()[1], (f.last_plan(), f.last_gate())
+        if workload == "c4_patch":                                           # 8 views x 1024 channels: the rows in registers, lattice and cloud
+            assert f.last_plan()["family"] == "register-rows" and not f.last_plan()["gated_window"], f.last_plan()
         f.record_plans = False
         sub = torch.randperm(pts.shape[0], generator=torch.Generator().manual_seed(9))[:200000].to(dev)
         f.tuning_flags = _lib.TUNE_NO_REORDER
@@ -447,9 +447,68 @@ def test_thin_map_gather_is_bit_identical(dev, V, C, N):
         assert torch.equal(torch.nan_to_num(out["thin"], nan=7.0, posinf=8.0, neginf=9.0), torch.nan_to_num(ref["thin"], nan=7.0, posinf=8.0, neginf=9.0))
 
 
+# ---- register rows (fuse_rows.hip: 1024-channel patch maps) == direct gather, bit for bit -------------------------------------------
+@pytest.mark.parametrize("V,fhw,thin,points,n", [(8, (36, 64), False, "grid", 0), (8, (36, 64), False, "cloud", 150001), (8, (24, 32), True, "scattered", 70001),
+                                                 (4, (24, 32), True, "cloud", 100000), (5, (24, 32), True, "grid", 0), (1, (48, 64), False, "cloud", 66000),
+                                                 (4, (48, 64), False, "big cloud", 270001)])
+def test_register_rows_are_bit_identical(dev, V, fhw, thin, points, n):
+    """fused_eval_rows_kernel against the direct gather on the same points: clipped bricks of a lattice (74 x 65 x 20 is no multiple of
+    4 x 4 x 2), the Hilbert order of a cloud, 32 consecutive points of a caller-order cloud, SCATTERED points (every (point, view) its
+    own cell: up to 256 cells per workgroup, the cell table read in more than one piece), odd cells (a point paired with itself at
+    zero weights), a strict point, points whose corners leave the map, thin maps riding along, 1 / 4 / 5 / 8 views, and -- four views,
+    a big cloud -- the rows as the OTHER side of the window kernel's device gate; a sample against the oracle."""
+    from d3fields_amd import create_init_grid, synth, _lib
+    H, W, C = 480, 640, 1024
+    maps = {"dino_feats": synth.random_map(V, fhw[0], fhw[1], C, seed=1, device=dev)}
+    names = ["dino_feats"]
+    if thin:
+        maps["mask"] = synth.random_onehot_mask(V, H, W, 8, seed=2, device=dev)
+        maps["color"] = synth.random_map(V, H, W, 3, seed=4, device=dev)
+        names += ["mask", "color"]
+    f, sc = fusion_for(dev, V, H, W, maps)
+    if points == "grid":
+        pts_c = create_init_grid(synth.WORK_BOX, 0.0107)[0]                            # 74 x 65 x 20 points
+    else:
+        pts_c = synth.random_cloud(n, seed=3)
+        if points == "cloud" and n <= 100000:                                          # a caller order with locality: sorted along x
+            pts_c = pts_c[torch.argsort(pts_c[:, 0])].contiguous()
+    pts_c[1000, 1] = float("inf")                                                       # a strict point
+    pts = pts_c.to(dev)
+    f.record_plans = True
+    with torch.no_grad():
+        if points == "scattered":
+            f.tuning_flags = _lib.TUNE_NO_REORDER                                       # 32 consecutive points of a random cloud
+        out = f.batch_eval(pts, return_names=names)
+        plan = f.last_plan()
+        assert plan["family"] == "register-rows", plan
+        if points == "big cloud":
+            assert plan["gated_window"], plan                                           # ... behind the gate; both sides, each forced
+            with knobs(FLAGS=_lib.TUNE_NO_WINDOW_GATE):
+                rows_side = f.batch_eval(pts, return_names=names)
+            with knobs(FLAGS=_lib.TUNE_WINDOW_SIDE):
+                window_side = f.batch_eval(pts, return_names=names)
+            for k in out:
+                assert torch.equal(torch.nan_to_num(out[k].float()), torch.nan_to_num(rows_side[k].float())), k
+                assert torch.equal(torch.nan_to_num(out[k].float()), torch.nan_to_num(window_side[k].float())), k
+        f.record_plans = False
+        with knobs(D3F_EXP_RUNS=-1):
+            ref = f.batch_eval(pts, return_names=names)
+    for k in ref:
+        a, b = out[k], ref[k]
+        assert torch.equal(torch.isnan(a), torch.isnan(b)) and torch.equal(torch.nan_to_num(a.float()), torch.nan_to_num(b.float())), k
+    assert bool((out["valid_mask"]).any()) and bool((~out["valid_mask"].bool()).any())
+    pick = torch.randperm(pts.shape[0], generator=torch.Generator().manual_seed(3))[:1500]
+    pick = pick[pick != 1000]
+    o = oracle_sample(sc, pts_c[pick], [maps[k] for k in names])
+    assert np.array_equal(cpu(out["dist"])[pick], o["dist"]) and np.array_equal(cpu(out["valid_mask"])[pick], o["valid_mask"])
+    assert rel_err(cpu(out["dino_feats"])[pick], o["sets"][0]) <= TOL
+    for i, k in enumerate(names[1:]):
+        assert rel_err(cpu(out[k])[pick], o["sets"][1 + i]) <= TOL, k
+
+
 # ---- LDS texel windows (experiment knob D3F_EXP_WINDOW) == direct gather, bit for bit -----------------------------------
 @pytest.mark.parametrize("C,V,fhw,mask,points", [(384, 4, (48, 64), True, "grid"), (256, 3, (24, 32), False, "cloud"),
-                                                 (1024, 8, (36, 64), False, "cloud"), (128, 2, (48, 64), True, "grid"),
+                                                 (768, 8, (36, 64), False, "cloud"), (128, 2, (48, 64), True, "grid"),
                                                  (512, 8, (48, 64), True, "grid")])
 def test_window_gather_is_bit_identical(dev, C, V, fhw, mask, points):
     """Every (tile, vectors per lane, pool) variant of fused_eval_window_kernel, incl. pools too small for the windows
