@@ -15,12 +15,17 @@
 // (fuse_common.h): bit-identical to the other families.  Texel traffic per point: the cells' corners once (~16 KB) instead of 128 KB.
 //
 // Phase A is the window kernel's (one lane per (point, view), ordered view sums by DPP); it additionally sorts the valid pairs of
-// every view by cell (rank by counting, 32 keys per view) into a flat list of step records {4 weights, 4 * point} and a list of
-// cells {texel offset, first step, steps}.  Points with a pair at the image border (a corner outside the map), strict points
-// (non-finite projection / maps not known finite) take rows_redo_point(): gather_map's arithmetic on global loads, after the loop.
-// Thin maps (the mask, colours) ride along through gather_map_u like in the window kernel.
+// every view by cell (rank by counting, 32 keys per view) into a flat list of OPS -- two points of a cell: {4 + 4 weights, the two row
+// registers} -- and a list of cells {texel offset, ops}.  Points with a pair at the image border (a corner outside the map) and strict
+// points (non-finite projection / maps not known finite) take rows_redo_point(): gather_map's arithmetic on global loads, after the
+// loop.  Thin maps (the mask, colours) ride along through gather_map_u like in the window kernel.
 // Index mode and the step blocks were measured on their own first: scripts/notebook/microbench/gpr_idx_fma.hip (bit-exact; 77 / 88
-// TFLOP/s with one / two points per block at two waves per SIMD, 82 with static registers).
+// TFLOP/s with one / two points per block at two waves per SIMD, 82 with static registers; fma_rate.hip: v_pk_fma_f32 itself reaches
+// 118 / 135 TFLOP/s at two / four waves per SIMD).  Measured (MI355X, profiles/r6_sessions): config 4's lattice 1.68 -> 1.47 ms,
+// its cloud 2.66 -> 2.18 ms, the 71 k surface points of the reference's shape 0.137 -> 0.125 ms; with FOUR views the window kernel
+// stays ahead (2.07 vs 2.37 ms on the reference's lattice), so the planner sends only more than four views -- and what the windows do
+// not take -- here (d3f_plan.h: rows_row).  A workgroup's 53 k cycles: KRt + phase A 8 k, ranks / ops 4 k, the cell loop 36 k (its
+// v_pk_fma_f32 alone are 29 k of SIMD time when both resident waves are in it), row stores 4 k.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -160,29 +165,8 @@ __device__ __forceinline__ void rows_zero()
                  "" ::: D3F_ROWS_CLOBBER);
 }
 
-// row[p] += corners * weights, p4 = 4 p wave-uniform: SRC2 and DST of every v_pk_fma_f32 are relative to M0 = p4 (VGPR index mode);
+// row[p] += corners * weights with p wave-uniform: SRC2 and DST of every v_pk_fma_f32 are relative to M0 = 4 p (VGPR index mode);
 // op_sel picks the weight inside its register pair.
-__device__ __forceinline__ void rows_step1(uint32_t p4, const f32x4 (&c)[4], f32x4 w)
-{
-    const f32x2 a0 = {c[0].x, c[0].y}, a1 = {c[0].z, c[0].w}, b0 = {c[1].x, c[1].y}, b1 = {c[1].z, c[1].w};
-    const f32x2 d0 = {c[2].x, c[2].y}, d1 = {c[2].z, c[2].w}, e0 = {c[3].x, c[3].y}, e1 = {c[3].z, c[3].w};
-    const f32x2 w01 = {w.x, w.y}, w23 = {w.z, w.w};
-    asm volatile("s_set_gpr_idx_on %[idx], 0xc\n\t"
-                 "v_pk_fma_f32 v[128:129], %[a0], %[w01], v[128:129] op_sel_hi:[1,0,1]\n\t"
-                 "v_pk_fma_f32 v[130:131], %[a1], %[w01], v[130:131] op_sel_hi:[1,0,1]\n\t"
-                 "v_pk_fma_f32 v[128:129], %[b0], %[w01], v[128:129] op_sel:[0,1,0] op_sel_hi:[1,1,1]\n\t"
-                 "v_pk_fma_f32 v[130:131], %[b1], %[w01], v[130:131] op_sel:[0,1,0] op_sel_hi:[1,1,1]\n\t"
-                 "v_pk_fma_f32 v[128:129], %[d0], %[w23], v[128:129] op_sel_hi:[1,0,1]\n\t"
-                 "v_pk_fma_f32 v[130:131], %[d1], %[w23], v[130:131] op_sel_hi:[1,0,1]\n\t"
-                 "v_pk_fma_f32 v[128:129], %[e0], %[w23], v[128:129] op_sel:[0,1,0] op_sel_hi:[1,1,1]\n\t"
-                 "v_pk_fma_f32 v[130:131], %[e1], %[w23], v[130:131] op_sel:[0,1,0] op_sel_hi:[1,1,1]\n\t"
-                 "s_set_gpr_idx_off"
-                 :
-                 : [idx] "s"(p4), [a0] "v"(a0), [a1] "v"(a1), [b0] "v"(b0), [b1] "v"(b1), [d0] "v"(d0), [d1] "v"(d1), [e0] "v"(e0),
-                   [e1] "v"(e1), [w01] "v"(w01), [w23] "v"(w23)
-                 : D3F_ROWS_CLOBBER);
-}
-
 // two points of one cell (or one point twice, the second time at zero weights): four chains, the index register switched between them
 __device__ __forceinline__ void rows_step2(uint32_t i1, uint32_t i2, const f32x4 (&c)[4], f32x4 w, f32x4 x)
 {

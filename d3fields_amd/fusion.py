@@ -568,6 +568,8 @@ class Fusion:
             kernel = "fused_eval_window_kernel<%d, %d, %d, 256, %d, %d, %s%s>" % (r // 100, r // 10 % 10, 4 if plan.lanes_per_point[w0] == 16 else r % 10, plan.lanes_per_point[w0], vfix,
                                                                                 "false" if lattice is not None else "true",
                                                                                 ", true" if maps[w0].dtype == _lib.DTYPE_F16 else "")
+        elif any(plan.staged[s] == 5 for s in range(n_maps)):                  # the rows of a 32-point brick in registers (fuse_rows.hip)
+            kernel = "fused_eval_rows_kernel"
         elif plan.reserved >= 100:
             lg, vc = (plan.reserved - 100) // 10, (plan.reserved - 100) % 10
             kernel = "fused_eval_sliced_kernel<%d, %d, %d%s>" % (lg, vc, {1: 8, 2: 7, 4: 5}.get(vc, 5), ", true" if f16 else "")
@@ -580,6 +582,8 @@ class Fusion:
         order += "; channel-sliced over the XCDs" if sliced else ""
         if window:
             order += "; %d-point bricks through texel windows in LDS" % int(plan.tile_points)
+        elif kernel == "fused_eval_rows_kernel":
+            order += "; 32-point bricks, their fused rows in registers, walked cell by cell"
         elif runs:
             order += "; cell runs of %d consecutive points" % (max(plan.staged[s] for s in range(n_maps)) - 16)
         self._last_plan = {"kernel": kernel, "tile_points": int(plan.tile_points), "point_order": order,

@@ -202,12 +202,14 @@ typedef struct d3f_eval_plan {
     int32_t vectors_per_lane[D3F_MAX_MAPS];
     int32_t staged[D3F_MAX_MAPS];           /* 0: direct gather; 3: LDS texel windows per brick (patch-resolution wide
                                                map on a lattice); 16 + K: cell-run gather with runs of K points
-                                               (patch-resolution wide maps)                            */
+                                               (patch-resolution wide maps); 5: the fused rows of a 32-point brick in
+                                               registers (1024-channel patch maps, round 6)            */
     int32_t gated_window;                   /* ABI 5.  1: a cloud that gets the gated pair of launches; the fields above describe
                                                the cell-run side, the window side is the lattice's window plan on 64-point tiles */
     int32_t reserved2;                      /* gated_window: the window side's `reserved` code (2000 + 100*U + 10*VC + W)       */
     int32_t family;                         /* ABI 5.  row of the planner's family table that took the query: 0 dist-only, 1 lds-window,
-                                               2 cell-runs, 3 channel-sliced, 4 direct (d3f_plan_family_name; csrc/d3f_plan.h)      */
+                                               2 cell-runs, 3 channel-sliced, 4 direct, 5 register-rows (d3f_plan_family_name;
+                                               csrc/d3f_plan.h)                                                                    */
     int32_t reserved3;
 } d3f_eval_plan;
 int d3f_eval_plan_query(const d3f_views *views, int64_t n, const d3f_channel_map *maps, int32_t n_maps,

@@ -65,3 +65,29 @@ def test_pairwise_mfma_kernel_keeps_four_waves_per_simd():
     assert len(mfma) == 4, out[-800:]
     for name, vgpr, scratch, occ in mfma:
         assert vgpr <= 128 and scratch == 0 and occ >= 4, (name, vgpr, scratch, occ)
+
+
+@pytest.mark.skipif(shutil.which("hipcc") is None and not os.path.exists("/opt/rocm/bin/hipcc"), reason="needs hipcc")
+def test_register_rows_kernel_leaves_the_rows_alone(tmp_path):
+    """fuse_rows.hip keeps 32 fused rows in v[128:255] -- registers only its asm blocks name; the compiler gets 128 VGPRs
+    (amdgpu_num_vgpr) for everything else.  The ISA must show: 256 VGPRs reserved (two waves per SIMD), no AGPRs (they would come
+    on top of the 256 and cost the second wave), no scratch, and not one compiler-written instruction that touches v128 and up --
+    outside the asm blocks every high register would be a clobbered row."""
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    src = os.path.join(ROOT, "d3fields_amd", "csrc", "fuse_rows.hip")
+    asm = str(tmp_path / "fuse_rows.s")
+    subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-I", os.path.join(ROOT, "include"),
+                    "-I", os.path.dirname(src), "--cuda-device-only", "-S", src, "-o", asm], check=True, timeout=600)
+    text = open(asm).read()
+    meta = {k: int(v) for k, v in re.findall(r"\.(vgpr_count|agpr_count|vgpr_spill_count|private_segment_fixed_size):\s+(\d+)", text)}
+    assert meta == {"vgpr_count": 256, "agpr_count": 0, "vgpr_spill_count": 0, "private_segment_fixed_size": 0}, meta
+    inside, high = False, []
+    for line in text.splitlines():
+        if "#ASMSTART" in line:
+            inside = True
+        elif "#ASMEND" in line:
+            inside = False
+        elif not inside and not line.lstrip().startswith((";", ".")) and re.search(r"\bv(?:\[)?(1[3-9]\d|12[89]|2\d\d)\b", line):
+            high.append(line.strip())
+    assert not high, high[:5]
+    assert text.count("s_set_gpr_idx_on") >= 4 and "v_pk_fma_f32 v[128:129]" in text          # the rows are addressed through the index mode
