@@ -54,7 +54,7 @@ constexpr int64_t kInfinityCacheBytes = 256LL << 20;
 //                      workgroup; vectors per lane, views in flight, workgroups per CU, pool texels, lanes per point, -1 = plain view loop, ...
 //   sliced (+ _vc _unit _ilv _tile _pad _f16 _cloud)   channel-sliced launch: 1 / 2 / 3 = 128- / 256- / 512-byte slices, -1 never
 //   walk / walk_tile   lattice brick walk: -1 off; tile shape as digits x y z (222 default, 224 with a thin map)
-//   rows               register-rows kernel (1024-channel patch maps): -1 never, 1 = also below kSmallBatch
+//   rows / rows_tile   register-rows kernel (1024-channel patch maps): -1 never, 1 = also below kSmallBatch; brick shape as digits x y z (442)
 //   thin               -1: thin maps through the view-sequential gather_map instead of gather_map_thin
 //   store              row-store policy: -1 plain, 1 sc1, 3 `sc1 nt`, default `nt` (fuse_common.h: store_out)
 //   gate               > 0 always the window side of a cloud's gate, < 0 always the cell runs
@@ -62,7 +62,7 @@ constexpr int64_t kInfinityCacheBytes = 256LL << 20;
 //   stamps             1: s_memtime phase stamps of the window kernel (d3f_exp_read_stamps)
 #define D3F_TUNE_KNOBS(X)                                                                                                          \
     X(gate, "D3F_EXP_GATE") X(order_bits, "D3F_EXP_ORDER_BITS") X(order_fixed_grid, "D3F_EXP_ORDER_FIXED_GRID")                   \
-    X(order_morton, "D3F_EXP_ORDER_MORTON") X(rows, "D3F_EXP_ROWS") X(runs, "D3F_EXP_RUNS") X(runs_occ, "D3F_EXP_RUNS_OCC") X(runs_tile, "D3F_EXP_RUNS_TILE") \
+    X(order_morton, "D3F_EXP_ORDER_MORTON") X(rows, "D3F_EXP_ROWS") X(rows_tile, "D3F_EXP_ROWS_TILE") X(runs, "D3F_EXP_RUNS") X(runs_occ, "D3F_EXP_RUNS_OCC") X(runs_tile, "D3F_EXP_RUNS_TILE") \
     X(runs_u, "D3F_EXP_RUNS_U") X(scan3, "D3F_EXP_SCAN3") X(sliced, "D3F_EXP_SLICED") X(sliced_cloud, "D3F_EXP_SLICED_CLOUD")     \
     X(sliced_f16, "D3F_EXP_SLICED_F16") X(sliced_ilv, "D3F_EXP_SLICED_ILV") X(sliced_pad, "D3F_EXP_SLICED_PAD")                   \
     X(sliced_tile, "D3F_EXP_SLICED_TILE") X(sliced_unit, "D3F_EXP_SLICED_UNIT") X(sliced_vc, "D3F_EXP_SLICED_VC")                 \
@@ -353,6 +353,8 @@ inline void rows_geometry(const Query &q, d3f::EvalParams &P, Plan &pl)
 {
     P.rows = 1; P.tile_pts = 32; P.lds_pad = 0;
     if (pl.walk) pick_window_brick(P.walk_nx, P.walk_ny, P.walk_nz, P.tile_pts, P.walk_tx, P.walk_ty, P.walk_tz);
+    const int shape = q.tune.rows_tile;                  // experiments: digits x y z (powers of two, product 32)
+    if (pl.walk && shape >= 111 && (shape / 100) * (shape / 10 % 10) * (shape % 10) == 32) { P.walk_tx = shape / 100; P.walk_ty = shape / 10 % 10; P.walk_tz = shape % 10; }
     for (int s = 1; s < q.n_maps; ++s) pick_mapping(P.maps[s], P.maps[s].vw == 4, P.maps[s].vw >= 2, true, 1);
     pl.xcd_remap = false;
     P.flags &= ~D3F_TUNE_XCD_REMAP;

@@ -21,7 +21,8 @@ assert lib.d3f_build_has_experiments(), "needs the experiments build"
 lib.d3f_exp_read_stamps.restype = ctypes.c_int
 lib.d3f_exp_read_stamps.argtypes = [ctypes.c_void_p, ctypes.c_int64]
 for wl in sys.argv[1:] or ["c2_patch"]:
-    f, pts, names, w, sc = bench.build_workload(wl, dev, 0, 1)
+    wl, _, pk = wl.partition(":")
+    f, pts, names, w, sc = bench.build_workload(wl, dev, 0, 1, pk or "grid")
     f.cache_point_order = False
     with torch.no_grad():
         for _ in range(4):
