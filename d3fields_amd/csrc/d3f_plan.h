@@ -7,6 +7,10 @@
 //   family           kernel (fuse_<family>.hip)        takes the query when                                                  point order
 //   ---------------  --------------------------------  --------------------------------------------------------------------  --------------------------
 //   dist-only        fused_eval_kernel<MODE>           no channel maps (return_names=[], eval_dist)                          caller
+//   register-rows    fused_eval_rows_kernel            a PATCH-resolution map of exactly 1024 fp32 channels, others thin,      lattice: brick walk (32 pts)
+//                                                      finite maps, no '<k>_inter', >= 65 536 points, <= 8 views: with MORE   cloud: Hilbert / caller order
+//                                                      than four views, or where the window row does not take the query
+//                                                      (checked before lds-window; id 5 in d3f_eval_plan.family)
 //   lds-window       fused_eval_window_kernel          the wide map is PATCH-resolution (texel >= 4 px), whole 128-channel     lattice: brick walk
 //                                                      slices, fp32 or fp16, others thin, finite maps, no '<k>_inter',         cloud: Hilbert order, gated
 //                                                      >= 65 536 points, <= 8 views; points: a lattice, or a cloud of
@@ -358,7 +362,10 @@ inline void rows_geometry(const Query &q, d3f::EvalParams &P, Plan &pl)
     for (int s = 1; s < q.n_maps; ++s) pick_mapping(P.maps[s], P.maps[s].vw == 4, P.maps[s].vw >= 2, true, 1);
     pl.xcd_remap = false;
     P.flags &= ~D3F_TUNE_XCD_REMAP;
-    if (!pl.walk) P.flags |= D3F_TUNE_XCD_REMAP;         // a cloud's tiles round-robin over the XCDs (the window kernel's finding)
+    // a big cloud's tiles go round-robin over the XCDs (config 4's cloud: 2.26 ms and 13.9 GB of L2 fills against 2.34 ms and 6.7 GB with
+    // contiguous eighths -- all eight L2s on one neighbourhood win on time, as for the window kernel); a small one keeps the eighths
+    // (the 71 k surface points: 0.125 vs 0.129 ms)
+    if (!pl.walk && q.n >= kWindowCloudMin && q.tune.window_rr >= 0) P.flags |= D3F_TUNE_XCD_REMAP;
 }
 
 // =================================================== family: cell-runs ============================================================
