@@ -8,6 +8,9 @@
 namespace d3f {
 
 constexpr int kBlock = 256;                 // 4 waves of 64 lanes
+#ifndef D3F_ROWS_PTS
+#define D3F_ROWS_PTS 32                     // points per workgroup of the register-rows kernel (fuse_rows.hip; 16: a build-time experiment)
+#endif
 constexpr uint32_t kFlagFiniteMaps = D3F_FLAG_FINITE_MAPS;
 constexpr uint32_t kFlagXcdRemap = D3F_TUNE_XCD_REMAP;
 

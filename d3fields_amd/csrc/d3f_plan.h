@@ -355,10 +355,10 @@ inline bool rows_row(const Query &q, d3f::EvalParams &P)
 
 inline void rows_geometry(const Query &q, d3f::EvalParams &P, Plan &pl)
 {
-    P.rows = 1; P.tile_pts = 32; P.lds_pad = 0;
+    P.rows = 1; P.tile_pts = D3F_ROWS_PTS; P.lds_pad = 0;
     if (pl.walk) pick_window_brick(P.walk_nx, P.walk_ny, P.walk_nz, P.tile_pts, P.walk_tx, P.walk_ty, P.walk_tz);
     const int shape = q.tune.rows_tile;                  // experiments: digits x y z (powers of two, product 32)
-    if (pl.walk && shape >= 111 && (shape / 100) * (shape / 10 % 10) * (shape % 10) == 32) { P.walk_tx = shape / 100; P.walk_ty = shape / 10 % 10; P.walk_tz = shape % 10; }
+    if (pl.walk && shape >= 111 && (shape / 100) * (shape / 10 % 10) * (shape % 10) == D3F_ROWS_PTS) { P.walk_tx = shape / 100; P.walk_ty = shape / 10 % 10; P.walk_tz = shape % 10; }
     for (int s = 1; s < q.n_maps; ++s) pick_mapping(P.maps[s], P.maps[s].vw == 4, P.maps[s].vw >= 2, true, 1);
     pl.xcd_remap = false;
     P.flags &= ~D3F_TUNE_XCD_REMAP;

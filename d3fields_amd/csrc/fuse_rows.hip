@@ -35,7 +35,7 @@
 
 namespace d3f {
 
-constexpr int kRowsPts = 32;                      // points per workgroup (x 4 accumulator registers per lane)
+constexpr int kRowsPts = D3F_ROWS_PTS;                      // points per workgroup (x 4 accumulator registers per lane)
 constexpr uint32_t kRowStrict = 1u;               // per-point state bits of phase A: strict point (reference order, full division)
 constexpr uint32_t kRowBorder = 2u;               // a valid pair with a corner outside the map: the point goes through rows_redo_point
 constexpr uint32_t kRowNoKey = 0xffffffffu;
@@ -53,6 +53,15 @@ struct __attribute__((aligned(16))) RowOp {
 // (amdgpu_num_vgpr), so the compiler never allocates these registers; only the asm blocks below name them (as clobbers, which is
 // also what makes the kernel descriptor reserve 256).  (First form: the four 32-register tuples as "+{v[128:159]}" operands of every
 // block -- correct, but with two kinds of blocks in a loop nest the allocator moved the tuples through scratch: 736 bytes of spills.)
+// D3F_ROWS_PTS (d3f_internal.h) points per workgroup: 32 (rows in v[128:255], 128 VGPRs for the compiler, two waves per SIMD) or -- a build-time
+// experiment -- 16 (rows in v[104:167], 104 VGPRs for the compiler, three waves per SIMD).  Measured (r6_s28, same box, 16 vs 32):
+// config 4's lattice 1.511 vs 1.532 ms, its cloud 2.327 vs 2.281, the 71 k surface points 0.113 vs 0.123: a third wave per SIMD buys
+// nothing where the kernel is bound by VALU issue (392 wave instructions per point, 256 of them v_pk_fma_f32) -- 32 stays.
+#if D3F_ROWS_PTS == 32
+#define D3F_ROWS_LO "v[128:129]"
+#define D3F_ROWS_HI "v[130:131]"
+#define D3F_ROWS_BUDGET 128
+#define D3F_ROWS_WAVES 2
 #define D3F_ROWS_CLOBBER \
     "v128", "v129", "v130", "v131", "v132", "v133", "v134", "v135", "v136", "v137", "v138", "v139", "v140", "v141", "v142", "v143", \
     "v144", "v145", "v146", "v147", "v148", "v149", "v150", "v151", "v152", "v153", "v154", "v155", "v156", "v157", "v158", "v159", \
@@ -95,74 +104,136 @@ struct __attribute__((aligned(16))) RowOp {
     X(29, 244, 247) \
     X(30, 248, 251) \
     X(31, 252, 255)
+#define D3F_ROWS_ZERO_ASM \
+    "v_mov_b64 v[128:129], 0\n\t" \
+    "v_mov_b64 v[130:131], 0\n\t" \
+    "v_mov_b64 v[132:133], 0\n\t" \
+    "v_mov_b64 v[134:135], 0\n\t" \
+    "v_mov_b64 v[136:137], 0\n\t" \
+    "v_mov_b64 v[138:139], 0\n\t" \
+    "v_mov_b64 v[140:141], 0\n\t" \
+    "v_mov_b64 v[142:143], 0\n\t" \
+    "v_mov_b64 v[144:145], 0\n\t" \
+    "v_mov_b64 v[146:147], 0\n\t" \
+    "v_mov_b64 v[148:149], 0\n\t" \
+    "v_mov_b64 v[150:151], 0\n\t" \
+    "v_mov_b64 v[152:153], 0\n\t" \
+    "v_mov_b64 v[154:155], 0\n\t" \
+    "v_mov_b64 v[156:157], 0\n\t" \
+    "v_mov_b64 v[158:159], 0\n\t" \
+    "v_mov_b64 v[160:161], 0\n\t" \
+    "v_mov_b64 v[162:163], 0\n\t" \
+    "v_mov_b64 v[164:165], 0\n\t" \
+    "v_mov_b64 v[166:167], 0\n\t" \
+    "v_mov_b64 v[168:169], 0\n\t" \
+    "v_mov_b64 v[170:171], 0\n\t" \
+    "v_mov_b64 v[172:173], 0\n\t" \
+    "v_mov_b64 v[174:175], 0\n\t" \
+    "v_mov_b64 v[176:177], 0\n\t" \
+    "v_mov_b64 v[178:179], 0\n\t" \
+    "v_mov_b64 v[180:181], 0\n\t" \
+    "v_mov_b64 v[182:183], 0\n\t" \
+    "v_mov_b64 v[184:185], 0\n\t" \
+    "v_mov_b64 v[186:187], 0\n\t" \
+    "v_mov_b64 v[188:189], 0\n\t" \
+    "v_mov_b64 v[190:191], 0\n\t" \
+    "v_mov_b64 v[192:193], 0\n\t" \
+    "v_mov_b64 v[194:195], 0\n\t" \
+    "v_mov_b64 v[196:197], 0\n\t" \
+    "v_mov_b64 v[198:199], 0\n\t" \
+    "v_mov_b64 v[200:201], 0\n\t" \
+    "v_mov_b64 v[202:203], 0\n\t" \
+    "v_mov_b64 v[204:205], 0\n\t" \
+    "v_mov_b64 v[206:207], 0\n\t" \
+    "v_mov_b64 v[208:209], 0\n\t" \
+    "v_mov_b64 v[210:211], 0\n\t" \
+    "v_mov_b64 v[212:213], 0\n\t" \
+    "v_mov_b64 v[214:215], 0\n\t" \
+    "v_mov_b64 v[216:217], 0\n\t" \
+    "v_mov_b64 v[218:219], 0\n\t" \
+    "v_mov_b64 v[220:221], 0\n\t" \
+    "v_mov_b64 v[222:223], 0\n\t" \
+    "v_mov_b64 v[224:225], 0\n\t" \
+    "v_mov_b64 v[226:227], 0\n\t" \
+    "v_mov_b64 v[228:229], 0\n\t" \
+    "v_mov_b64 v[230:231], 0\n\t" \
+    "v_mov_b64 v[232:233], 0\n\t" \
+    "v_mov_b64 v[234:235], 0\n\t" \
+    "v_mov_b64 v[236:237], 0\n\t" \
+    "v_mov_b64 v[238:239], 0\n\t" \
+    "v_mov_b64 v[240:241], 0\n\t" \
+    "v_mov_b64 v[242:243], 0\n\t" \
+    "v_mov_b64 v[244:245], 0\n\t" \
+    "v_mov_b64 v[246:247], 0\n\t" \
+    "v_mov_b64 v[248:249], 0\n\t" \
+    "v_mov_b64 v[250:251], 0\n\t" \
+    "v_mov_b64 v[252:253], 0\n\t" \
+    "v_mov_b64 v[254:255], 0\n\t"
+#else
+#define D3F_ROWS_LO "v[104:105]"
+#define D3F_ROWS_HI "v[106:107]"
+#define D3F_ROWS_BUDGET 104
+#define D3F_ROWS_WAVES 3
+#define D3F_ROWS_CLOBBER \
+    "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119", \
+    "v120", "v121", "v122", "v123", "v124", "v125", "v126", "v127", "v128", "v129", "v130", "v131", "v132", "v133", "v134", "v135", \
+    "v136", "v137", "v138", "v139", "v140", "v141", "v142", "v143", "v144", "v145", "v146", "v147", "v148", "v149", "v150", "v151", \
+    "v152", "v153", "v154", "v155", "v156", "v157", "v158", "v159", "v160", "v161", "v162", "v163", "v164", "v165", "v166", "v167"
+#define D3F_ROWS_POINTS(X) \
+    X(0, 104, 107) \
+    X(1, 108, 111) \
+    X(2, 112, 115) \
+    X(3, 116, 119) \
+    X(4, 120, 123) \
+    X(5, 124, 127) \
+    X(6, 128, 131) \
+    X(7, 132, 135) \
+    X(8, 136, 139) \
+    X(9, 140, 143) \
+    X(10, 144, 147) \
+    X(11, 148, 151) \
+    X(12, 152, 155) \
+    X(13, 156, 159) \
+    X(14, 160, 163) \
+    X(15, 164, 167)
+#define D3F_ROWS_ZERO_ASM \
+    "v_mov_b64 v[104:105], 0\n\t" \
+    "v_mov_b64 v[106:107], 0\n\t" \
+    "v_mov_b64 v[108:109], 0\n\t" \
+    "v_mov_b64 v[110:111], 0\n\t" \
+    "v_mov_b64 v[112:113], 0\n\t" \
+    "v_mov_b64 v[114:115], 0\n\t" \
+    "v_mov_b64 v[116:117], 0\n\t" \
+    "v_mov_b64 v[118:119], 0\n\t" \
+    "v_mov_b64 v[120:121], 0\n\t" \
+    "v_mov_b64 v[122:123], 0\n\t" \
+    "v_mov_b64 v[124:125], 0\n\t" \
+    "v_mov_b64 v[126:127], 0\n\t" \
+    "v_mov_b64 v[128:129], 0\n\t" \
+    "v_mov_b64 v[130:131], 0\n\t" \
+    "v_mov_b64 v[132:133], 0\n\t" \
+    "v_mov_b64 v[134:135], 0\n\t" \
+    "v_mov_b64 v[136:137], 0\n\t" \
+    "v_mov_b64 v[138:139], 0\n\t" \
+    "v_mov_b64 v[140:141], 0\n\t" \
+    "v_mov_b64 v[142:143], 0\n\t" \
+    "v_mov_b64 v[144:145], 0\n\t" \
+    "v_mov_b64 v[146:147], 0\n\t" \
+    "v_mov_b64 v[148:149], 0\n\t" \
+    "v_mov_b64 v[150:151], 0\n\t" \
+    "v_mov_b64 v[152:153], 0\n\t" \
+    "v_mov_b64 v[154:155], 0\n\t" \
+    "v_mov_b64 v[156:157], 0\n\t" \
+    "v_mov_b64 v[158:159], 0\n\t" \
+    "v_mov_b64 v[160:161], 0\n\t" \
+    "v_mov_b64 v[162:163], 0\n\t" \
+    "v_mov_b64 v[164:165], 0\n\t" \
+    "v_mov_b64 v[166:167], 0\n\t"
+#endif
 
 __device__ __forceinline__ void rows_zero()
 {
-    asm volatile("v_mov_b64 v[128:129], 0\n\t"
-                 "v_mov_b64 v[130:131], 0\n\t"
-                 "v_mov_b64 v[132:133], 0\n\t"
-                 "v_mov_b64 v[134:135], 0\n\t"
-                 "v_mov_b64 v[136:137], 0\n\t"
-                 "v_mov_b64 v[138:139], 0\n\t"
-                 "v_mov_b64 v[140:141], 0\n\t"
-                 "v_mov_b64 v[142:143], 0\n\t"
-                 "v_mov_b64 v[144:145], 0\n\t"
-                 "v_mov_b64 v[146:147], 0\n\t"
-                 "v_mov_b64 v[148:149], 0\n\t"
-                 "v_mov_b64 v[150:151], 0\n\t"
-                 "v_mov_b64 v[152:153], 0\n\t"
-                 "v_mov_b64 v[154:155], 0\n\t"
-                 "v_mov_b64 v[156:157], 0\n\t"
-                 "v_mov_b64 v[158:159], 0\n\t"
-                 "v_mov_b64 v[160:161], 0\n\t"
-                 "v_mov_b64 v[162:163], 0\n\t"
-                 "v_mov_b64 v[164:165], 0\n\t"
-                 "v_mov_b64 v[166:167], 0\n\t"
-                 "v_mov_b64 v[168:169], 0\n\t"
-                 "v_mov_b64 v[170:171], 0\n\t"
-                 "v_mov_b64 v[172:173], 0\n\t"
-                 "v_mov_b64 v[174:175], 0\n\t"
-                 "v_mov_b64 v[176:177], 0\n\t"
-                 "v_mov_b64 v[178:179], 0\n\t"
-                 "v_mov_b64 v[180:181], 0\n\t"
-                 "v_mov_b64 v[182:183], 0\n\t"
-                 "v_mov_b64 v[184:185], 0\n\t"
-                 "v_mov_b64 v[186:187], 0\n\t"
-                 "v_mov_b64 v[188:189], 0\n\t"
-                 "v_mov_b64 v[190:191], 0\n\t"
-                 "v_mov_b64 v[192:193], 0\n\t"
-                 "v_mov_b64 v[194:195], 0\n\t"
-                 "v_mov_b64 v[196:197], 0\n\t"
-                 "v_mov_b64 v[198:199], 0\n\t"
-                 "v_mov_b64 v[200:201], 0\n\t"
-                 "v_mov_b64 v[202:203], 0\n\t"
-                 "v_mov_b64 v[204:205], 0\n\t"
-                 "v_mov_b64 v[206:207], 0\n\t"
-                 "v_mov_b64 v[208:209], 0\n\t"
-                 "v_mov_b64 v[210:211], 0\n\t"
-                 "v_mov_b64 v[212:213], 0\n\t"
-                 "v_mov_b64 v[214:215], 0\n\t"
-                 "v_mov_b64 v[216:217], 0\n\t"
-                 "v_mov_b64 v[218:219], 0\n\t"
-                 "v_mov_b64 v[220:221], 0\n\t"
-                 "v_mov_b64 v[222:223], 0\n\t"
-                 "v_mov_b64 v[224:225], 0\n\t"
-                 "v_mov_b64 v[226:227], 0\n\t"
-                 "v_mov_b64 v[228:229], 0\n\t"
-                 "v_mov_b64 v[230:231], 0\n\t"
-                 "v_mov_b64 v[232:233], 0\n\t"
-                 "v_mov_b64 v[234:235], 0\n\t"
-                 "v_mov_b64 v[236:237], 0\n\t"
-                 "v_mov_b64 v[238:239], 0\n\t"
-                 "v_mov_b64 v[240:241], 0\n\t"
-                 "v_mov_b64 v[242:243], 0\n\t"
-                 "v_mov_b64 v[244:245], 0\n\t"
-                 "v_mov_b64 v[246:247], 0\n\t"
-                 "v_mov_b64 v[248:249], 0\n\t"
-                 "v_mov_b64 v[250:251], 0\n\t"
-                 "v_mov_b64 v[252:253], 0\n\t"
-                 "v_mov_b64 v[254:255], 0\n\t"
-                 "" ::: D3F_ROWS_CLOBBER);
+    asm volatile(D3F_ROWS_ZERO_ASM "" ::: D3F_ROWS_CLOBBER);
 }
 
 // row[p] += corners * weights with p wave-uniform: SRC2 and DST of every v_pk_fma_f32 are relative to M0 = 4 p (VGPR index mode);
@@ -174,29 +245,29 @@ __device__ __forceinline__ void rows_step2(uint32_t i1, uint32_t i2, const f32x4
     const f32x2 d0 = {c[2].x, c[2].y}, d1 = {c[2].z, c[2].w}, e0 = {c[3].x, c[3].y}, e1 = {c[3].z, c[3].w};
     const f32x2 w01 = {w.x, w.y}, w23 = {w.z, w.w}, x01 = {x.x, x.y}, x23 = {x.z, x.w};
     asm volatile("s_set_gpr_idx_on %[i1], 0xc\n\t"
-                 "v_pk_fma_f32 v[128:129], %[a0], %[w01], v[128:129] op_sel_hi:[1,0,1]\n\t"
-                 "v_pk_fma_f32 v[130:131], %[a1], %[w01], v[130:131] op_sel_hi:[1,0,1]\n\t"
+                 "v_pk_fma_f32 " D3F_ROWS_LO ", %[a0], %[w01], " D3F_ROWS_LO " op_sel_hi:[1,0,1]\n\t"
+                 "v_pk_fma_f32 " D3F_ROWS_HI ", %[a1], %[w01], " D3F_ROWS_HI " op_sel_hi:[1,0,1]\n\t"
                  "s_set_gpr_idx_idx %[i2]\n\t"
-                 "v_pk_fma_f32 v[128:129], %[a0], %[x01], v[128:129] op_sel_hi:[1,0,1]\n\t"
-                 "v_pk_fma_f32 v[130:131], %[a1], %[x01], v[130:131] op_sel_hi:[1,0,1]\n\t"
+                 "v_pk_fma_f32 " D3F_ROWS_LO ", %[a0], %[x01], " D3F_ROWS_LO " op_sel_hi:[1,0,1]\n\t"
+                 "v_pk_fma_f32 " D3F_ROWS_HI ", %[a1], %[x01], " D3F_ROWS_HI " op_sel_hi:[1,0,1]\n\t"
                  "s_set_gpr_idx_idx %[i1]\n\t"
-                 "v_pk_fma_f32 v[128:129], %[b0], %[w01], v[128:129] op_sel:[0,1,0] op_sel_hi:[1,1,1]\n\t"
-                 "v_pk_fma_f32 v[130:131], %[b1], %[w01], v[130:131] op_sel:[0,1,0] op_sel_hi:[1,1,1]\n\t"
+                 "v_pk_fma_f32 " D3F_ROWS_LO ", %[b0], %[w01], " D3F_ROWS_LO " op_sel:[0,1,0] op_sel_hi:[1,1,1]\n\t"
+                 "v_pk_fma_f32 " D3F_ROWS_HI ", %[b1], %[w01], " D3F_ROWS_HI " op_sel:[0,1,0] op_sel_hi:[1,1,1]\n\t"
                  "s_set_gpr_idx_idx %[i2]\n\t"
-                 "v_pk_fma_f32 v[128:129], %[b0], %[x01], v[128:129] op_sel:[0,1,0] op_sel_hi:[1,1,1]\n\t"
-                 "v_pk_fma_f32 v[130:131], %[b1], %[x01], v[130:131] op_sel:[0,1,0] op_sel_hi:[1,1,1]\n\t"
+                 "v_pk_fma_f32 " D3F_ROWS_LO ", %[b0], %[x01], " D3F_ROWS_LO " op_sel:[0,1,0] op_sel_hi:[1,1,1]\n\t"
+                 "v_pk_fma_f32 " D3F_ROWS_HI ", %[b1], %[x01], " D3F_ROWS_HI " op_sel:[0,1,0] op_sel_hi:[1,1,1]\n\t"
                  "s_set_gpr_idx_idx %[i1]\n\t"
-                 "v_pk_fma_f32 v[128:129], %[d0], %[w23], v[128:129] op_sel_hi:[1,0,1]\n\t"
-                 "v_pk_fma_f32 v[130:131], %[d1], %[w23], v[130:131] op_sel_hi:[1,0,1]\n\t"
+                 "v_pk_fma_f32 " D3F_ROWS_LO ", %[d0], %[w23], " D3F_ROWS_LO " op_sel_hi:[1,0,1]\n\t"
+                 "v_pk_fma_f32 " D3F_ROWS_HI ", %[d1], %[w23], " D3F_ROWS_HI " op_sel_hi:[1,0,1]\n\t"
                  "s_set_gpr_idx_idx %[i2]\n\t"
-                 "v_pk_fma_f32 v[128:129], %[d0], %[x23], v[128:129] op_sel_hi:[1,0,1]\n\t"
-                 "v_pk_fma_f32 v[130:131], %[d1], %[x23], v[130:131] op_sel_hi:[1,0,1]\n\t"
+                 "v_pk_fma_f32 " D3F_ROWS_LO ", %[d0], %[x23], " D3F_ROWS_LO " op_sel_hi:[1,0,1]\n\t"
+                 "v_pk_fma_f32 " D3F_ROWS_HI ", %[d1], %[x23], " D3F_ROWS_HI " op_sel_hi:[1,0,1]\n\t"
                  "s_set_gpr_idx_idx %[i1]\n\t"
-                 "v_pk_fma_f32 v[128:129], %[e0], %[w23], v[128:129] op_sel:[0,1,0] op_sel_hi:[1,1,1]\n\t"
-                 "v_pk_fma_f32 v[130:131], %[e1], %[w23], v[130:131] op_sel:[0,1,0] op_sel_hi:[1,1,1]\n\t"
+                 "v_pk_fma_f32 " D3F_ROWS_LO ", %[e0], %[w23], " D3F_ROWS_LO " op_sel:[0,1,0] op_sel_hi:[1,1,1]\n\t"
+                 "v_pk_fma_f32 " D3F_ROWS_HI ", %[e1], %[w23], " D3F_ROWS_HI " op_sel:[0,1,0] op_sel_hi:[1,1,1]\n\t"
                  "s_set_gpr_idx_idx %[i2]\n\t"
-                 "v_pk_fma_f32 v[128:129], %[e0], %[x23], v[128:129] op_sel:[0,1,0] op_sel_hi:[1,1,1]\n\t"
-                 "v_pk_fma_f32 v[130:131], %[e1], %[x23], v[130:131] op_sel:[0,1,0] op_sel_hi:[1,1,1]\n\t"
+                 "v_pk_fma_f32 " D3F_ROWS_LO ", %[e0], %[x23], " D3F_ROWS_LO " op_sel:[0,1,0] op_sel_hi:[1,1,1]\n\t"
+                 "v_pk_fma_f32 " D3F_ROWS_HI ", %[e1], %[x23], " D3F_ROWS_HI " op_sel:[0,1,0] op_sel_hi:[1,1,1]\n\t"
                  "s_set_gpr_idx_off"
                  :
                  : [i1] "s"(i1), [i2] "s"(i2), [a0] "v"(a0), [a1] "v"(a1), [b0] "v"(b0), [b1] "v"(b1), [d0] "v"(d0), [d1] "v"(d1),
@@ -244,7 +315,7 @@ __device__ __forceinline__ void rows_redo_point(const MapDesc &m, const EvalPara
     store_row_vec(reinterpret_cast<char *>(m.out) + ((uint64_t)idx * ((uint32_t)m.C * 4u) + lane_off), o);
 }
 
-__global__ __launch_bounds__(kBlock, 2) __attribute__((amdgpu_num_vgpr(128))) void fused_eval_rows_kernel(const EvalParams P)
+__global__ __launch_bounds__(kBlock, D3F_ROWS_WAVES) __attribute__((amdgpu_num_vgpr(D3F_ROWS_BUDGET))) void fused_eval_rows_kernel(const EvalParams P)
 {
     if (gated_out(P)) return;
     constexpr int TP = kRowsPts, NT = kBlock, MV = 8;
