@@ -109,6 +109,68 @@ __device__ __forceinline__ void step2b(f32x32 &A0, f32x32 &A1, f32x32 &A2, f32x3
 }
 
 
+
+// FOUR points of one cell in one block: eight independent chains
+__device__ __forceinline__ void step4(f32x32 &A0, f32x32 &A1, f32x32 &A2, f32x32 &A3, uint32_t i1, uint32_t i2, uint32_t i3, uint32_t i4, f32x4 a, f32x4 b,
+                                      f32x4 d, f32x4 e, f32x4 w, f32x4 x, f32x4 y, f32x4 z)
+{
+    const f32x2 a0 = {a.x, a.y}, a1 = {a.z, a.w}, b0 = {b.x, b.y}, b1 = {b.z, b.w};
+    const f32x2 d0 = {d.x, d.y}, d1 = {d.z, d.w}, e0 = {e.x, e.y}, e1 = {e.z, e.w};
+    const f32x2 w01 = {w.x, w.y}, w23 = {w.z, w.w}, x01 = {x.x, x.y}, x23 = {x.z, x.w}, y01 = {y.x, y.y}, y23 = {y.z, y.w}, z01 = {z.x, z.y}, z23 = {z.z, z.w};
+    asm volatile("s_set_gpr_idx_on %[i1], 0xc\n\t"
+                 "v_pk_fma_f32 v[128:129], %[a0], %[w01], v[128:129] op_sel_hi:[1,0,1]\n\t"
+                 "v_pk_fma_f32 v[130:131], %[a1], %[w01], v[130:131] op_sel_hi:[1,0,1]\n\t"
+                 "s_set_gpr_idx_idx %[i2]\n\t"
+                 "v_pk_fma_f32 v[128:129], %[a0], %[x01], v[128:129] op_sel_hi:[1,0,1]\n\t"
+                 "v_pk_fma_f32 v[130:131], %[a1], %[x01], v[130:131] op_sel_hi:[1,0,1]\n\t"
+                 "s_set_gpr_idx_idx %[i3]\n\t"
+                 "v_pk_fma_f32 v[128:129], %[a0], %[y01], v[128:129] op_sel_hi:[1,0,1]\n\t"
+                 "v_pk_fma_f32 v[130:131], %[a1], %[y01], v[130:131] op_sel_hi:[1,0,1]\n\t"
+                 "s_set_gpr_idx_idx %[i4]\n\t"
+                 "v_pk_fma_f32 v[128:129], %[a0], %[z01], v[128:129] op_sel_hi:[1,0,1]\n\t"
+                 "v_pk_fma_f32 v[130:131], %[a1], %[z01], v[130:131] op_sel_hi:[1,0,1]\n\t"
+                 "s_set_gpr_idx_idx %[i1]\n\t"
+                 "v_pk_fma_f32 v[128:129], %[b0], %[w01], v[128:129] op_sel:[0,1,0] op_sel_hi:[1,1,1]\n\t"
+                 "v_pk_fma_f32 v[130:131], %[b1], %[w01], v[130:131] op_sel:[0,1,0] op_sel_hi:[1,1,1]\n\t"
+                 "s_set_gpr_idx_idx %[i2]\n\t"
+                 "v_pk_fma_f32 v[128:129], %[b0], %[x01], v[128:129] op_sel:[0,1,0] op_sel_hi:[1,1,1]\n\t"
+                 "v_pk_fma_f32 v[130:131], %[b1], %[x01], v[130:131] op_sel:[0,1,0] op_sel_hi:[1,1,1]\n\t"
+                 "s_set_gpr_idx_idx %[i3]\n\t"
+                 "v_pk_fma_f32 v[128:129], %[b0], %[y01], v[128:129] op_sel:[0,1,0] op_sel_hi:[1,1,1]\n\t"
+                 "v_pk_fma_f32 v[130:131], %[b1], %[y01], v[130:131] op_sel:[0,1,0] op_sel_hi:[1,1,1]\n\t"
+                 "s_set_gpr_idx_idx %[i4]\n\t"
+                 "v_pk_fma_f32 v[128:129], %[b0], %[z01], v[128:129] op_sel:[0,1,0] op_sel_hi:[1,1,1]\n\t"
+                 "v_pk_fma_f32 v[130:131], %[b1], %[z01], v[130:131] op_sel:[0,1,0] op_sel_hi:[1,1,1]\n\t"
+                 "s_set_gpr_idx_idx %[i1]\n\t"
+                 "v_pk_fma_f32 v[128:129], %[d0], %[w23], v[128:129] op_sel_hi:[1,0,1]\n\t"
+                 "v_pk_fma_f32 v[130:131], %[d1], %[w23], v[130:131] op_sel_hi:[1,0,1]\n\t"
+                 "s_set_gpr_idx_idx %[i2]\n\t"
+                 "v_pk_fma_f32 v[128:129], %[d0], %[x23], v[128:129] op_sel_hi:[1,0,1]\n\t"
+                 "v_pk_fma_f32 v[130:131], %[d1], %[x23], v[130:131] op_sel_hi:[1,0,1]\n\t"
+                 "s_set_gpr_idx_idx %[i3]\n\t"
+                 "v_pk_fma_f32 v[128:129], %[d0], %[y23], v[128:129] op_sel_hi:[1,0,1]\n\t"
+                 "v_pk_fma_f32 v[130:131], %[d1], %[y23], v[130:131] op_sel_hi:[1,0,1]\n\t"
+                 "s_set_gpr_idx_idx %[i4]\n\t"
+                 "v_pk_fma_f32 v[128:129], %[d0], %[z23], v[128:129] op_sel_hi:[1,0,1]\n\t"
+                 "v_pk_fma_f32 v[130:131], %[d1], %[z23], v[130:131] op_sel_hi:[1,0,1]\n\t"
+                 "s_set_gpr_idx_idx %[i1]\n\t"
+                 "v_pk_fma_f32 v[128:129], %[e0], %[w23], v[128:129] op_sel:[0,1,0] op_sel_hi:[1,1,1]\n\t"
+                 "v_pk_fma_f32 v[130:131], %[e1], %[w23], v[130:131] op_sel:[0,1,0] op_sel_hi:[1,1,1]\n\t"
+                 "s_set_gpr_idx_idx %[i2]\n\t"
+                 "v_pk_fma_f32 v[128:129], %[e0], %[x23], v[128:129] op_sel:[0,1,0] op_sel_hi:[1,1,1]\n\t"
+                 "v_pk_fma_f32 v[130:131], %[e1], %[x23], v[130:131] op_sel:[0,1,0] op_sel_hi:[1,1,1]\n\t"
+                 "s_set_gpr_idx_idx %[i3]\n\t"
+                 "v_pk_fma_f32 v[128:129], %[e0], %[y23], v[128:129] op_sel:[0,1,0] op_sel_hi:[1,1,1]\n\t"
+                 "v_pk_fma_f32 v[130:131], %[e1], %[y23], v[130:131] op_sel:[0,1,0] op_sel_hi:[1,1,1]\n\t"
+                 "s_set_gpr_idx_idx %[i4]\n\t"
+                 "v_pk_fma_f32 v[128:129], %[e0], %[z23], v[128:129] op_sel:[0,1,0] op_sel_hi:[1,1,1]\n\t"
+                 "v_pk_fma_f32 v[130:131], %[e1], %[z23], v[130:131] op_sel:[0,1,0] op_sel_hi:[1,1,1]\n\t"
+                 "s_set_gpr_idx_off"
+                 : ACC_OPS
+                 : [i1] "s"(i1), [i2] "s"(i2), [i3] "s"(i3), [i4] "s"(i4), [a0] "v"(a0), [a1] "v"(a1), [b0] "v"(b0), [b1] "v"(b1), [d0] "v"(d0), [d1] "v"(d1),
+                   [e0] "v"(e0), [e1] "v"(e1), [w01] "v"(w01), [w23] "v"(w23), [x01] "v"(x01), [x23] "v"(x23), [y01] "v"(y01), [y23] "v"(y23), [z01] "v"(z01), [z23] "v"(z23));
+}
+
 // texels: [ntex][1024]; a step s reads the four texels tl[s][0..3] (one 'cell'), adds them with weights wl[s] to point pl[s]
 __global__ __launch_bounds__(256, 2) void k(const float *__restrict__ tex, const int *__restrict__ pl, const int *__restrict__ tl,
                                             const f32x4 *__restrict__ wl, int nsteps, int reload_every, float *__restrict__ out)
@@ -163,6 +225,7 @@ __global__ __launch_bounds__(256, 2) void k_pure(const float *__restrict__ tex, 
         p4 = (p4 + 28u) & 127u;
         asm volatile("" : "+s"(p4));
         if (MODE == 2) { step2(A0, A1, A2, A3, p4, p4 ^ 64u, a, b, d, e, w, w); ++s; }
+        else if (MODE == 4) { step4(A0, A1, A2, A3, p4, p4 ^ 64u, p4 ^ 32u, p4 ^ 96u, a, b, d, e, w, w, w, w); s += 3; }
         else if (MODE == 3) { step2b(A0, A1, A2, A3, p4, p4 ^ 64u, a, b, d, e, w, w); ++s; }
         else step(A0, A1, A2, A3, MODE == 0 ? p4 : 0u, a, b, d, e, w);
     }
@@ -243,10 +306,11 @@ int main()
         CK(hipMalloc(&d_tex, tex.size() * 4)); CK(hipMalloc(&d_out, (size_t)nblocks * 32 * 1024 * 4));
         CK(hipMemcpy(d_tex, tex.data(), tex.size() * 4, hipMemcpyHostToDevice));
         hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-        for (int mode = 0; mode < 4; ++mode)
+        for (int mode = 0; mode < 5; ++mode)
             for (int rep = 0; rep < 3; ++rep) {
                 CK(hipEventRecord(e0));
                 if (mode == 0) hipLaunchKernelGGL(k_pure<0>, dim3(nblocks), dim3(256), 0, 0, d_tex, nsteps, d_out);
+                else if (mode == 4) hipLaunchKernelGGL(k_pure<4>, dim3(nblocks), dim3(256), 0, 0, d_tex, nsteps, d_out);
                 else if (mode == 3) hipLaunchKernelGGL(k_pure<3>, dim3(nblocks), dim3(256), 0, 0, d_tex, nsteps, d_out);
                 else if (mode == 2) hipLaunchKernelGGL(k_pure<2>, dim3(nblocks), dim3(256), 0, 0, d_tex, nsteps, d_out);
                 else hipLaunchKernelGGL(k_pure<1>, dim3(nblocks), dim3(256), 0, 0, d_tex, nsteps, d_out);
@@ -254,7 +318,7 @@ int main()
                 float ms; CK(hipEventElapsedTime(&ms, e0, e1));
                 const double steps = (double)nblocks * nsteps;
                 if (rep == 2) printf("pure loop, %s: %.3f ms, %.1f cycles(2.4GHz) per wave step of 8 v_pk_fma_f32 (SIMD time, two waves interleaved), %.1f TFLOP/s\n",
-                                     mode == 0 ? "index mode per step" : (mode == 2 ? "two points per block, index switched every 2" : (mode == 3 ? "two points per block, index switched every 4" : "static registers")), ms, ms * 1e-3 * 2.4e9 / (steps * 4.0 / 1024.0), steps * 8192.0 / (ms * 1e-3) / 1e12);
+                                     mode == 0 ? "index mode per step" : (mode == 2 ? "two points per block, index switched every 2" : (mode == 4 ? "FOUR points per block, index switched every 2" : mode == 3 ? "two points per block, index switched every 4" : "static registers")), ms, ms * 1e-3 * 2.4e9 / (steps * 4.0 / 1024.0), steps * 8192.0 / (ms * 1e-3) / 1e12);
             }
     }
     for (int re : {1, 2, 4, 8, 16}) if (int r = run(512 * 8, 2048, re, false)) return r;
