@@ -79,6 +79,7 @@ SIGNATURES = {
     "d3f_map_check": (ctypes.c_int, [ctypes.POINTER(ChannelMap), _i32, _vp, _vp]),
     "d3f_map_check_many": (ctypes.c_int, [ctypes.POINTER(ChannelMap), ctypes.POINTER(_i32), _i32, ctypes.POINTER(_vp), _u32, _vp]),
     "d3f_eval_workspace_bytes": (_i64, [_i64]),
+    "d3f_eval_dist_workspace_bytes": (_i64, [ctypes.POINTER(Views), _i64]),
     "d3f_eval_gate_offset": (_i64, [_i64]),
     "d3f_plan_family_name": (ctypes.c_char_p, [_i32]),
     "d3f_plan_family_takes": (ctypes.c_char_p, [_i32]),

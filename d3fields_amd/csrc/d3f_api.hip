@@ -160,6 +160,8 @@ int eval_common(const d3f_views *views, const float *pts, int64_t n, const d3f_c
     P.walk_nx = P.walk_ny = P.walk_nz = 0; P.walk_tx = P.walk_ty = P.walk_tz = 1;
     P.sl_unit = 128; P.sl_ilv = 1; P.sl_slices = 0; P.sl_lg = 3; P.sl_vc = 4; P.sl_tiles = P.sl_groups = P.sl_chunks = 0;
     P.runs_occ = tune.runs_occ;
+    P.dist_variant = tune.dist;
+    P.depth_tiled = nullptr; P.depth_tw = P.depth_th = 0;
     P.thin_max_views = (tune.thin < 0 || (flags & D3F_TUNE_DIRECT_GATHER)) ? 0 : 8;
     P.win_lpp = tune.window_lpp == 32 ? 32 : 16;     // 16 lanes x 2 vectors per point (C2 patch 0.565 -> 0.54 ms); U > 1: 32
     P.win_slices = 0; P.win_u = 1; P.win_vc = 1; P.win_pool_offset = 0; P.win_pool_texels = 0; P.win_occ = 4;
@@ -255,6 +257,14 @@ int eval_common(const d3f_views *views, const float *pts, int64_t n, const d3f_c
         hipError_t ep = d3f::launch_window_gate_probe(P, d3f::order_gate_words(workspace, n), d3f::kGateSamples, hs);
         if (ep != hipSuccess) return hip_fail(ep, "window gate probe");
     }
+    // the distance-only pass over a big batch in caller order, with scratch: the depth maps are tiled first (inside the timed pair)
+    if (n_maps == 0 && n >= d3f::kDistTiledMin && !P.order && P.walk_nx <= 0 && views->V <= 8 && tune.dist >= 0 && !(tune.dist & 32) &&
+        workspace && workspace_bytes >= d3f::depth_tiled_bytes(views->V, views->H, views->W)) {
+        P.depth_tw = (views->W + 3) / 4; P.depth_th = (views->H + 7) / 8;
+        hipError_t et = d3f::launch_depth_tiles(P, static_cast<float *>(workspace), hs);
+        if (et != hipSuccess) return hip_fail(et, "depth tiling");
+        P.depth_tiled = static_cast<const float *>(workspace);
+    }
     hipError_t e = d3f::launch_fused_eval(P, mode, hs);
     if (ev1) (void)hipEventRecord(ev1, hs);
     if (e != hipSuccess) return hip_fail(e, "fused_eval launch");
@@ -290,6 +300,11 @@ int d3f_eval(const d3f_views *views, const float *pts, int64_t n, const d3f_chan
 }
 
 int64_t d3f_eval_workspace_bytes(int64_t n) { return d3f::order_workspace_bytes(n); }
+int64_t d3f_eval_dist_workspace_bytes(const d3f_views *views, int64_t n)
+{
+    if (!views || n < d3f::kDistTiledMin || views->V < 1 || views->V > 8 || views->H < 1 || views->W < 1) return 0;
+    return d3f::depth_tiled_bytes(views->V, views->H, views->W);
+}
 
 const char *d3f_plan_family_name(int32_t family) { return (family >= 0 && family < (int32_t)(sizeof(kFamilies) / sizeof(kFamilies[0]))) ? kFamilies[family].name : nullptr; }
 const char *d3f_plan_family_takes(int32_t family) { return (family >= 0 && family < (int32_t)(sizeof(kFamilies) / sizeof(kFamilies[0]))) ? kFamilies[family].takes : nullptr; }

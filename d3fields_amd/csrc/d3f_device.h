@@ -97,12 +97,25 @@ __device__ __forceinline__ void compute_krt(const float *K, const float *pose, i
 }
 
 // nearest depth pixel with zeros padding (fusion.py:327-333)
-__device__ __forceinline__ float nearest_depth(const float *depth, int v, int H, int W, float gx, float gy)
+// STRAIGHT: no branch around the load -- a pixel out of bounds reads pixel (0, 0) of the view and discards it -- so that the
+// lookups of several views of one lane can be in flight together (the distance-only kernel, fuse_direct.hip); same value.
+// TILED (with STRAIGHT): `depth` is the copy in tiles of 4 x 8 pixels, tw x th tiles per view (fuse_direct.hip: depth_tile_kernel)
+template <bool STRAIGHT = false, bool TILED = false>
+__device__ __forceinline__ float nearest_depth(const float *depth, int v, int H, int W, float gx, float gy, int tw = 0, int th = 0)
 {
     const float rx = rintf(unnormalize(gx, W)), ry = rintf(unnormalize(gy, H));
-    float d = 0.0f;
-    if (in_bounds(rx, ry, W, H)) d = depth[((int64_t)v * H + (int64_t)ry) * W + (int64_t)rx];
-    return d;
+    if constexpr (STRAIGHT) {
+        const bool in = ((int)(rx > -1.0f) & (int)(rx < (float)W) & (int)(ry > -1.0f) & (int)(ry < (float)H)) != 0;      // in_bounds() without its short circuits
+        const int ix = in ? (int)rx : 0, iy = in ? (int)ry : 0;
+        float d;
+        if constexpr (TILED) d = depth[((((int64_t)v * th + (iy >> 3)) * tw + (ix >> 2)) << 5) + (((iy & 7) << 2) | (ix & 3))];
+        else d = depth[((int64_t)v * H + iy) * W + ix];
+        return in ? d : 0.0f;
+    } else {
+        float d = 0.0f;
+        if (in_bounds(rx, ry, W, H)) d = depth[((int64_t)v * H + (int64_t)ry) * W + (int64_t)rx];
+        return d;
+    }
 }
 
 // One (point, view) of the forward: projection, nearest depth, validity, weight.
@@ -112,12 +125,10 @@ struct ViewOut {
     float valid;    // 1.0f / 0.0f
 };
 
+// from the projection and the depth pixel to the view's distance / validity / weight
 template <int MODE>
-__device__ __forceinline__ ViewOut eval_view(const float *depth, int H, int W, const float *M, int v, float px, float py,
-                                             float pz, float Wm1, float Hm1, float mu, float &wgt)
+__device__ __forceinline__ ViewOut view_result(const Proj &pr, float d, float mu, float &wgt)
 {
-    const Proj pr = project_point(M, px, py, pz, Wm1, Hm1);
-    const float d = nearest_depth(depth, v, H, W, pr.gx, pr.gy);
     float dist = d - pr.zc;                                                 // fusion.py:343
     bool valid;
     wgt = 1.0f;
@@ -135,6 +146,84 @@ __device__ __forceinline__ ViewOut eval_view(const float *depth, int H, int W, c
     ViewOut o;
     o.gx = pr.gx; o.gy = pr.gy; o.dist = dist; o.valid = valid ? 1.0f : 0.0f;
     return o;
+}
+
+template <int MODE>
+__device__ __forceinline__ ViewOut eval_view(const float *depth, int H, int W, const float *M, int v, float px, float py,
+                                             float pz, float Wm1, float Hm1, float mu, float &wgt)
+{
+    const Proj pr = project_point(M, px, py, pz, Wm1, Hm1);
+    const float d = nearest_depth(depth, v, H, W, pr.gx, pr.gy);
+    return view_result<MODE>(pr, d, mu, wgt);
+}
+
+// ---- the four IEEE divisions of a projection with the denominators' share hoisted (round 6; the distance-only kernel) ------------------
+// hipcc expands x / y into v_div_scale x2, v_rcp, two fma refining the reciprocal, v_mul + three fma refining the quotient,
+// v_div_fmas, v_div_fixup: 11 instructions, 17.4 ns per wave on a SIMD at eight waves (scripts/notebook/microbench/div_rate.hip).
+// The two scalings and the fix-up are the identity unless an operand is zero, denormal, infinite, NaN or the exponents are extreme
+// (ISA manual, V_DIV_SCALE / V_DIV_FMAS / V_DIV_FIXUP), and the reciprocal's part depends on the denominator alone: xc / zc and
+// yc / zc share it, and for u / (W-1), w / (H-1) it is a constant of the launch.  What is left per quotient is v_mul + four fma in
+// the SAME order on the SAME operands (6.2 ns) -- bit-identical whenever no scaling would have happened.  That is checked on the
+// RESULTS (a quotient of the short form inside [2^-30, 2^30] and |zc| <= 2^60 imply operands for which every scaling is the identity:
+// a zero, infinite, NaN or extreme operand drives the short form's quotient out of that range); a wave with one lane outside
+// redoes the four divisions in the compiler's form.
+struct DivConst {
+    float d, r1;        // a denominator and the refined reciprocal the expansion derives from it
+};
+__device__ __forceinline__ DivConst div_const(float d)
+{
+    const float r = __builtin_amdgcn_rcpf(d);
+    DivConst c;
+    c.d = d; c.r1 = fmaf(fmaf(-d, r, 1.0f), r, r);
+    return c;
+}
+__device__ __forceinline__ float div_short(float n, const DivConst &c)
+{
+    float q = n * c.r1;
+    float e = fmaf(-c.d, q, n);
+    q = fmaf(e, c.r1, q);
+    e = fmaf(-c.d, q, n);
+    return fmaf(e, c.r1, q);
+}
+__device__ __forceinline__ bool div_result_plain(float q)
+{
+    const float a = fabsf(q);
+    return __builtin_amdgcn_fmed3f(a, 0x1p-30f, 0x1p30f) == a;       // false for NaN
+}
+
+__device__ __forceinline__ Proj project_point_short(const float *M, float px, float py, float pz, const DivConst &cw, const DivConst &ch,
+                                                    bool long_form = false)
+{
+    Proj r;
+    float xc = ((M[0] * px + M[1] * py) + M[2] * pz) + M[3] * 1.0f;
+    float yc = ((M[4] * px + M[5] * py) + M[6] * pz) + M[7] * 1.0f;
+    float zc = ((M[8] * px + M[9] * py) + M[10] * pz) + M[11] * 1.0f;
+    r.ok = !(fabsf(zc) < 1e-4f);                                    // fusion.py:52
+    if (!r.ok) zc = 1e-3f;                                          // fusion.py:53
+    const DivConst cz = div_const(zc);
+    r.u = div_short(xc, cz);                                        // fusion.py:54
+    r.w = div_short(yc, cz);
+    float a = div_short(r.u, cw), b = div_short(r.w, ch);           // fusion.py:72-73
+    const bool plain = div_result_plain(a) && div_result_plain(b) && fabsf(zc) <= 0x1p60f;
+    if (long_form || !__all(plain)) {         // (long_form: wave-uniform, the A/B switch of experiments builds)
+        r.u = xc / zc; r.w = yc / zc;
+        a = r.u / cw.d; b = r.w / ch.d;
+    }
+    r.gx = a * 2.0f - 1.0f;
+    r.gy = b * 2.0f - 1.0f;
+    r.zc = zc;
+    return r;
+}
+
+// eval_view for the distance-only kernel: short divisions, no branch around the depth lookup
+template <int MODE>
+__device__ __forceinline__ ViewOut eval_view_straight(const float *depth, int H, int W, const float *M, int v, float px, float py,
+                                                      float pz, const DivConst &cw, const DivConst &ch, float mu, float &wgt,
+                                                      bool long_form = false)
+{
+    const Proj pr = project_point_short(M, px, py, pz, cw, ch, long_form);
+    const float d = nearest_depth<true>(depth, v, H, W, pr.gx, pr.gy);
+    return view_result<MODE>(pr, d, mu, wgt);
 }
 
 }  // namespace d3f

@@ -69,6 +69,11 @@ struct EvalParams {
     int32_t thin_max_views;    // 8 (default): thin maps with 2..8 views are gathered with the views in parallel across lanes
                                // (gather_map_thin); 0 switches that off (D3F_EXP_THIN=-1, tests)
     int32_t runs_occ;      // experiment: waves per SIMD of the (1,8) cell-run kernel variant (4 / 5 / 6)
+    // the distance-only pass on a big batch (fuse_direct.hip): a copy of the depth maps in tiles of 4 x 8 pixels (one 128-byte line
+    // each), [V][depth_th][depth_tw][8][4]; nullptr: the caller's row-major maps
+    const float *depth_tiled;
+    int32_t depth_tw, depth_th;
+    int32_t dist_variant;  // the distance-only pass: 0 = fused_eval_dist_kernel at eight waves per SIMD, 6 = at six, + 16 = the compiler's divisions, -1 = the branch of fused_eval_kernel (rounds 1-5)
     int32_t store_policy;  // 2 (default) = fused rows leave as non-temporal stores (nt), 3 = sc1 nt (the window kernel's own form), 1 = sc1, 0 = plain
     uint32_t flags;
     float mu;
@@ -88,6 +93,9 @@ struct EvalParams {
 inline int fused_lds_base(int tile_pts, int V) { return ((tile_pts * V * 24 + tile_pts * 12 + V * 48 + V * 16) + 15) / 16 * 16; }
 hipError_t launch_fused_eval(const EvalParams &P, int mode, hipStream_t stream);      // fuse_launch.hip: dispatch on the plan
 hipError_t launch_direct(const EvalParams &P, int mode, hipStream_t stream);          // fuse_direct.hip
+hipError_t launch_depth_tiles(const EvalParams &P, float *tiled, hipStream_t stream);  // fuse_direct.hip: fills EvalParams::depth_tiled's buffer
+inline int64_t depth_tiled_bytes(int V, int H, int W) { return (int64_t)V * ((H + 7) / 8) * ((W + 3) / 4) * 128; }
+constexpr int64_t kDistTiledMin = 1LL << 22;      // the distance-only pass tiles the depth maps first from this many points on
 hipError_t launch_runs(const EvalParams &P, hipStream_t stream);                      // fuse_runs.hip
 hipError_t launch_sliced(const EvalParams &P, hipStream_t stream);                    // fuse_sliced.hip
 hipError_t launch_window(const EvalParams &P, hipStream_t stream);                    // fuse_window.hip

@@ -6,7 +6,7 @@
 //   THE FAMILY TABLE (kFamilies below; walked top down, the first row whose predicate holds takes the query)
 //   family           kernel (fuse_<family>.hip)        takes the query when                                                  point order
 //   ---------------  --------------------------------  --------------------------------------------------------------------  --------------------------
-//   dist-only        fused_eval_kernel<MODE>           no channel maps (return_names=[], eval_dist)                          caller
+//   dist-only        fused_eval_dist_kernel<MODE,V,8>       no channel maps (return_names=[], eval_dist)                          caller
 //   register-rows    fused_eval_rows_kernel            a PATCH-resolution map of exactly 1024 fp32 channels, others thin,      lattice: brick walk (32 pts)
 //                                                      finite maps, no '<k>_inter', >= 65 536 points, <= 8 views: with MORE   cloud: Hilbert / caller order
 //                                                      than four views, or where the window row does not take the query
@@ -61,12 +61,14 @@ constexpr int64_t kInfinityCacheBytes = 256LL << 20;
 //   rows / rows_tile   register-rows kernel (1024-channel patch maps): -1 never, 1 = also below kSmallBatch; brick shape as digits x y z (442)
 //   thin               -1: thin maps through the view-sequential gather_map instead of gather_map_thin
 //   store              row-store policy: -1 plain, 1 sc1, 3 `sc1 nt`, default `nt` (fuse_common.h: store_out)
+//   dist               distance-only pass: -1 = the branch of fused_eval_kernel (rounds 1-5), 6 = fused_eval_dist_kernel held to six waves per SIMD,
+//                      + 16 = the compiler's divisions instead of the short form, + 32 = no tiled copy of the depth maps
 //   gate               > 0 always the window side of a cloud's gate, < 0 always the cell runs
 //   order_morton / order_fixed_grid / order_bits / scan3   point ordering: the Z curve of rounds 1-4, the fixed 4-mm grid, prefix bits, the three-launch scan
 //   stamps             1: s_memtime phase stamps of the window kernel (d3f_exp_read_stamps)
 #define D3F_TUNE_KNOBS(X)                                                                                                          \
     X(gate, "D3F_EXP_GATE") X(order_bits, "D3F_EXP_ORDER_BITS") X(order_fixed_grid, "D3F_EXP_ORDER_FIXED_GRID")                   \
-    X(order_morton, "D3F_EXP_ORDER_MORTON") X(rows, "D3F_EXP_ROWS") X(rows_tile, "D3F_EXP_ROWS_TILE") X(runs, "D3F_EXP_RUNS") X(runs_occ, "D3F_EXP_RUNS_OCC") X(runs_tile, "D3F_EXP_RUNS_TILE") \
+    X(order_morton, "D3F_EXP_ORDER_MORTON") X(dist, "D3F_EXP_DIST") X(rows, "D3F_EXP_ROWS") X(rows_tile, "D3F_EXP_ROWS_TILE") X(runs, "D3F_EXP_RUNS") X(runs_occ, "D3F_EXP_RUNS_OCC") X(runs_tile, "D3F_EXP_RUNS_TILE") \
     X(runs_u, "D3F_EXP_RUNS_U") X(scan3, "D3F_EXP_SCAN3") X(sliced, "D3F_EXP_SLICED") X(sliced_cloud, "D3F_EXP_SLICED_CLOUD")     \
     X(sliced_f16, "D3F_EXP_SLICED_F16") X(sliced_ilv, "D3F_EXP_SLICED_ILV") X(sliced_pad, "D3F_EXP_SLICED_PAD")                   \
     X(sliced_tile, "D3F_EXP_SLICED_TILE") X(sliced_unit, "D3F_EXP_SLICED_UNIT") X(sliced_vc, "D3F_EXP_SLICED_VC")                 \
@@ -533,7 +535,7 @@ struct FamilyRow {
     const char *name, *kernel, *takes;
 };
 constexpr FamilyRow kFamilies[] = {
-    {kFamDistOnly, "dist-only", "fused_eval_kernel<MODE>", "no channel maps (return_names=[], eval_dist)"},
+    {kFamDistOnly, "dist-only", "fused_eval_dist_kernel<MODE, V, 8>", "no channel maps (return_names=[], eval_dist)"},
     {kFamWindow, "lds-window", "fused_eval_window_kernel", "a patch-resolution wide map in whole 128-channel slices on a lattice, or (gated on the device) on a cloud of >= 262 144 points in the Hilbert order"},
     {kFamRuns, "cell-runs", "fused_eval_runs_kernel", "a patch-resolution wide fp32 map, >= 65 536 points; the other side of a cloud's gate"},
     {kFamSliced, "channel-sliced", "fused_eval_sliced_kernel", "a dense wide map (128..1024 channels) on a lattice walk or a Hilbert-ordered cloud"},

@@ -58,6 +58,214 @@ __global__ __launch_bounds__(kBlock) void fused_eval_f16_kernel(const EvalParams
     fused_eval_body<MODE, true, true>(P);
 }
 
+
+// ---- the DISTANCE-ONLY pass (return_names=[], eval_dist; fusion.py:396-436, vis_repr.py:93) as its own entry point (round 6) -------------
+// Up to round 6 this pass was a branch of fused_eval_body and inherited the gathers' register allocation (119 VGPRs: four
+// waves per SIMD) and a rolled view loop whose depth lookups -- one dependent L2 round trip per view -- were issued one after
+// the other: counters said 0.22 wave instructions per cycle and SIMD with the waves parked 54 % of the time.  The work per
+// (point, view) is ~100 VALU instructions of IEEE divisions and unfused multiply-adds that the arithmetic contract fixes
+//  plus ONE 4-byte load, so what the pass needs is waves and independent chains, not registers:
+//   * KRt lives in SGPRs: lanes 0..47 of every wave compute the entries of a batch of four views (compute_krt's
+//     k-sequential unfused sums), v_readlane hands them to the scalar file -- no LDS, no barrier, no VGPRs;
+//   * the four views of a batch are unrolled: four projections, four depth lookups in flight per lane, then the sums IN VIEW
+//     ORDER (dsum and cnt start at +0 and take view 0, 1, ... exactly as the rolled loop did: bit-identical);
+//   * five to eight views (config 4: eight): a second batch of four continues the same sums; more: the branch of fused_eval_kernel;
+//   * held to 64 VGPRs = eight waves per SIMD.
+// the NVQ views of one batch for one point, STAGE BY STAGE across the views: a wave's own instruction stream then carries NVQ
+// independent chains (the divisions are serial fma chains: with one view after the other the counters showed the waves
+// issue-stalled 54 % of the time with the VALU 76 % busy), the depth lookups leave together, and the short divisions'
+// check (d3f_device.h: project_point_short) is ONE wave-uniform branch per point.  Same operations on the same operands as
+// eval_view_straight view by view; the sums in view order.
+template <int MODE, int NVQ, bool TILED>
+__device__ __forceinline__ void dist_views(const EvalParams &P, const float (&M)[4][12], int v0, float px, float py, float pz,
+                                           const DivConst &cw, const DivConst &ch, float mu, float &ds, float &cn)
+{
+    float xc[NVQ], yc[NVQ], zc[NVQ], a[NVQ], b[NVQ];
+    bool ok[NVQ];
+#pragma unroll
+    for (int q = 0; q < NVQ; ++q) {
+        xc[q] = ((M[q][0] * px + M[q][1] * py) + M[q][2] * pz) + M[q][3] * 1.0f;
+        yc[q] = ((M[q][4] * px + M[q][5] * py) + M[q][6] * pz) + M[q][7] * 1.0f;
+        zc[q] = ((M[q][8] * px + M[q][9] * py) + M[q][10] * pz) + M[q][11] * 1.0f;
+        ok[q] = !(fabsf(zc[q]) < 1e-4f);                                    // fusion.py:52
+        if (!ok[q]) zc[q] = 1e-3f;                                          // fusion.py:53
+    }
+    DivConst cz[NVQ];
+#pragma unroll
+    for (int q = 0; q < NVQ; ++q) cz[q] = div_const(zc[q]);
+    float u[NVQ], w[NVQ];
+#pragma unroll
+    for (int q = 0; q < NVQ; ++q) { u[q] = div_short(xc[q], cz[q]); w[q] = div_short(yc[q], cz[q]); }      // fusion.py:54
+    int plain = 1;              // (int, bitwise: no short-circuit branches)
+#pragma unroll
+    for (int q = 0; q < NVQ; ++q) {
+        a[q] = div_short(u[q], cw); b[q] = div_short(w[q], ch);                                          // fusion.py:72-73
+        plain &= (int)div_result_plain(a[q]) & (int)div_result_plain(b[q]) & (int)(fabsf(zc[q]) <= 0x1p60f);
+    }
+    if ((P.dist_variant & 16) != 0 || !__all(plain)) {       // (bit 16: wave-uniform, the A/B switch of experiments builds)
+#pragma unroll
+        for (int q = 0; q < NVQ; ++q) {
+            const float uu = xc[q] / zc[q], ww = yc[q] / zc[q];
+            a[q] = uu / cw.d; b[q] = ww / ch.d;
+        }
+    }
+    float d[NVQ];
+#pragma unroll
+    for (int q = 0; q < NVQ; ++q) {
+        const float gx = a[q] * 2.0f - 1.0f, gy = b[q] * 2.0f - 1.0f;
+        if constexpr (TILED) d[q] = nearest_depth<true, true>(P.depth_tiled, v0 + q, P.H, P.W, gx, gy, P.depth_tw, P.depth_th);
+        else d[q] = nearest_depth<true>(P.depth, v0 + q, P.H, P.W, gx, gy);
+    }
+#pragma unroll
+    for (int q = 0; q < NVQ; ++q) {
+        Proj pr;
+        pr.zc = zc[q]; pr.ok = ok[q]; pr.gx = 0.0f; pr.gy = 0.0f; pr.u = 0.0f; pr.w = 0.0f;
+        float wgt;
+        const ViewOut o = view_result<MODE>(pr, d[q], mu, wgt);
+        ds = ds + o.dist * o.valid;                             // fusion.py:364
+        cn = cn + o.valid;
+    }
+}
+
+// KRt of views v0 .. v0+3 (fusion.py:44): entry t = lane, as compute_krt computes it ...
+__device__ __forceinline__ float dist_krt_lane(const EvalParams &P, int v0)
+{
+    const int lane = threadIdx.x & 63;
+    const int v = v0 + lane / 12, ij = lane % 12, i = ij / 4, j = ij % 4;
+    float kr = 0.0f;
+    if (lane < 48 && v < P.V) {
+        const float *Kv = P.K + v * 9, *Rv = P.pose + v * 12;
+        float acc = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const float pr = Kv[i * 3 + k] * Rv[k * 4 + j];
+            acc = acc + pr;
+        }
+        kr = acc;
+    }
+    return kr;
+}
+// ... and into wave-uniform registers (SGPRs)
+__device__ __forceinline__ void dist_krt_uniform(float kr, float (&M)[4][12])
+{
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int j2 = 0; j2 < 12; ++j2)
+            M[q][j2] = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(kr), q * 12 + j2));
+}
+
+__device__ __forceinline__ void dist_store(const EvalParams &P, int mode, int64_t i, float ds, float cn)
+{
+    const bool all_invalid = (cn == 0.0f);                      // fusion.py:366
+    float dist_out = ds / (cn + 1e-6f);
+    if (mode == 0 && all_invalid) dist_out = 1e3f;              // fusion.py:367
+    P.out_dist[i] = dist_out;
+    P.out_valid[i] = all_invalid ? 0 : 1;
+}
+
+// The points of one lane, one after the other, in CALLER order: tile_pts consecutive points per workgroup, lane t takes t, t + 256, ...
+// (point loads and the 'dist' / 'valid_mask' stores are then whole lines per wave; bricks of a lattice -- sixteen 4 x 4 x 4
+// sub-bricks per workgroup, any lane order -- fragment both and measured 2-8 % slower, rows of 64 x 3.5 times: session 42,
+// scripts/notebook/patches/r6_dist_bricks_and_whatifs.patch)
+template <typename BODY>
+__device__ __forceinline__ void dist_for_each_point(const EvalParams &P, BODY body)
+{
+    const int64_t tile_base = (int64_t)blockIdx.x * P.tile_pts;
+    const int64_t end = min(tile_base + P.tile_pts, P.n);
+#pragma unroll 1
+    for (int64_t i = tile_base + threadIdx.x; i < end; i += kBlock) {
+        float px, py, pz;
+        fetch_point(P, i, px, py, pz);
+        body(i, px, py, pz);
+    }
+}
+
+// NVQ: the view count (1..4) as a compile-time constant, 0 = five to eight views (two batches of four)
+// OCC: waves per SIMD the entry point is held to (8: 64 VGPRs / ~80 SGPRs; 6: 80 / 102 -- KRt's 48 SGPRs then leave room)
+template <int MODE, int NVQ, int OCC, bool TILED>
+__global__ __launch_bounds__(kBlock, OCC) void fused_eval_dist_kernel(const EvalParams P)
+{
+    if (gated_out(P)) return;
+    const float mu = P.mu;
+    const DivConst Wm1 = div_const((float)(P.W - 1)), Hm1 = div_const((float)(P.H - 1));
+    if constexpr (NVQ > 0) {
+        float M[4][12];
+        dist_krt_uniform(dist_krt_lane(P, 0), M);
+        dist_for_each_point(P, [&](int64_t i, float px, float py, float pz) {
+            float ds = 0.0f, cn = 0.0f;
+            dist_views<MODE, NVQ, TILED>(P, M, 0, px, py, pz, Wm1, Hm1, mu, ds, cn);
+            dist_store(P, MODE, i, ds, cn);
+        });
+    } else {
+        // five to eight views (config 4: eight): two batches of four per point; both batches' KRt entries wait in two VGPRs and
+        // are handed to the scalar file in front of each batch (48 v_readlane: ~14 % on top of a batch's four views)
+        const int V = P.V;
+        const float kr0 = dist_krt_lane(P, 0), kr1 = dist_krt_lane(P, 4);
+        dist_for_each_point(P, [&](int64_t i, float px, float py, float pz) {
+            float ds = 0.0f, cn = 0.0f;
+            float M[4][12];
+            dist_krt_uniform(kr0, M);
+            dist_views<MODE, 4, TILED>(P, M, 0, px, py, pz, Wm1, Hm1, mu, ds, cn);
+            __builtin_amdgcn_sched_barrier(0);
+            dist_krt_uniform(kr1, M);
+            if (V == 8) dist_views<MODE, 4, TILED>(P, M, 4, px, py, pz, Wm1, Hm1, mu, ds, cn);
+            else if (V == 7) dist_views<MODE, 3, TILED>(P, M, 4, px, py, pz, Wm1, Hm1, mu, ds, cn);
+            else if (V == 6) dist_views<MODE, 2, TILED>(P, M, 4, px, py, pz, Wm1, Hm1, mu, ds, cn);
+            else dist_views<MODE, 1, TILED>(P, M, 4, px, py, pz, Wm1, Hm1, mu, ds, cn);
+            dist_store(P, MODE, i, ds, cn);
+        });
+    }
+}
+
+template <int MODE, int OCC, bool TILED>
+static void launch_dist_v(const EvalParams &P, dim3 grid, dim3 block, hipStream_t stream)
+{
+    switch (P.V <= 4 ? P.V : 0) {
+    case 1: hipLaunchKernelGGL((fused_eval_dist_kernel<MODE, 1, OCC, TILED>), grid, block, 0, stream, P); break;
+    case 2: hipLaunchKernelGGL((fused_eval_dist_kernel<MODE, 2, OCC, TILED>), grid, block, 0, stream, P); break;
+    case 3: hipLaunchKernelGGL((fused_eval_dist_kernel<MODE, 3, OCC, TILED>), grid, block, 0, stream, P); break;
+    case 4: hipLaunchKernelGGL((fused_eval_dist_kernel<MODE, 4, OCC, TILED>), grid, block, 0, stream, P); break;
+    default: hipLaunchKernelGGL((fused_eval_dist_kernel<MODE, 0, OCC, TILED>), grid, block, 0, stream, P); break;
+    }
+}
+template <int MODE, int OCC>
+static void launch_dist(const EvalParams &P, dim3 grid, dim3 block, hipStream_t stream)
+{
+    if (P.depth_tiled) launch_dist_v<MODE, OCC, true>(P, grid, block, stream);
+    else launch_dist_v<MODE, OCC, false>(P, grid, block, stream);
+}
+
+// The depth maps in tiles of 4 x 8 pixels -- one 128-byte line each -- for the distance-only pass over a big batch.  Its lookups are
+// nearest-pixel gathers whose four lanes of a quad are four consecutive points of the caller's order: a lattice's z column, i.e.
+// neighbouring pixels ALONG AN IMAGE COLUMN for an upright camera -- in a row-major map four lines.  The texture addresser serves a
+// quad per cycle when its lanes share a line and a lane per cycle otherwise, and with one lookup per ~100 VALU instructions that is
+// half of the pass (what-if builds, sessions 43-45: no lookups 0.89 ms, quad-coherent lookups 1.28-1.35 ms, as is 1.75 ms).  In
+// 4 x 8 tiles a quad of the 1-mm grid touches 1.26 lines instead of 2.60, of a 5-mm grid 2.1 instead of 3.95
+// (scripts/notebook/sim_depth_tiles.py).  One thread per output float; pixels beyond the map are written as 0 and never read.
+__global__ __launch_bounds__(kBlock) void depth_tile_kernel(const float *__restrict__ depth, int V, int H, int W, int tw, int th,
+                                                            float *__restrict__ out)
+{
+    const int64_t o = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    const int64_t total = (int64_t)V * th * tw * 32;
+    if (o >= total) return;
+    const int in_tile = (int)(o & 31);
+    const int64_t t = o >> 5;
+    const int tx = (int)(t % tw);
+    const int64_t r = t / tw;
+    const int ty = (int)(r % th), v = (int)(r / th);
+    const int ix = tx * 4 + (in_tile & 3), iy = ty * 8 + (in_tile >> 2);
+    out[o] = (ix < W && iy < H) ? depth[((int64_t)v * H + iy) * W + ix] : 0.0f;
+}
+
+hipError_t launch_depth_tiles(const EvalParams &P, float *tiled, hipStream_t stream)
+{
+    const int64_t total = (int64_t)P.V * P.depth_th * P.depth_tw * 32;
+    hipLaunchKernelGGL(depth_tile_kernel, dim3((unsigned)((total + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream, P.depth, P.V, P.H, P.W,
+                       P.depth_tw, P.depth_th, tiled);
+    return hipGetLastError();
+}
+
 hipError_t launch_direct(const EvalParams &P, int mode, hipStream_t stream)
 {
     int64_t ntiles = (P.n + P.tile_pts - 1) / P.tile_pts;
@@ -66,6 +274,17 @@ hipError_t launch_direct(const EvalParams &P, int mode, hipStream_t stream)
                  ((P.walk_nz + P.walk_tz - 1) / P.walk_tz);
     const size_t lds = (size_t)P.crec_offset + (size_t)P.n_pre * P.tile_pts * P.V * 32 + (size_t)P.lds_pad;
     dim3 grid((unsigned)ntiles), block(kBlock);
+    if (P.n_maps == 0 && P.walk_nx <= 0 && P.order == nullptr && P.V <= 8 && P.dist_variant >= 0) {
+        // the distance-only pass in caller order: its own entry point (KRt in SGPRs, the views of a point in flight together)
+        if ((P.dist_variant & 15) == 6) {
+            if (mode == 0) launch_dist<0, 6>(P, grid, block, stream);
+            else launch_dist<1, 6>(P, grid, block, stream);
+        } else {
+            if (mode == 0) launch_dist<0, 8>(P, grid, block, stream);
+            else launch_dist<1, 8>(P, grid, block, stream);
+        }
+        return hipGetLastError();
+    }
     bool wide = false, f16 = false;
     for (int s = 0; s < P.n_maps; ++s) {
         wide |= (P.maps[s].unroll == -4);

@@ -557,6 +557,10 @@ class Fusion:
         wide = any(plan.vectors_per_lane[s] == -4 for s in range(n_maps))
         f16 = any(maps[s].dtype == _lib.DTYPE_F16 for s in range(n_maps))
         kernel = ("fused_eval_f16_kernel<0>" if f16 else "fused_eval_wide_kernel<0>" if wide else "fused_eval_kernel<0>")
+        if n_maps == 0 and int(plan.reorder) == 0 and int(views.V) <= 8:
+            # the distance-only pass (fuse_direct.hip): <mode, view count (0: five to eight), waves per SIMD, depth maps tiled first?>
+            tiled = have_ws and n >= (1 << 22)
+            kernel = "fused_eval_dist_kernel<0, %d, 8, %s>" % (int(views.V) if int(views.V) <= 4 else 0, "true" if tiled else "false")
         window = 2000 <= plan.reserved < 3000
         if window:
             r = plan.reserved - 2000
@@ -725,6 +729,10 @@ class Fusion:
                     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)   # torch's caching allocator: no hipMalloc per call
                     if self.cache_point_order:
                         self._order_ws = (sig, ws, bool(plan.reorder))      # filled by this call iff the library reorders
+            if not names:
+                # the distance-only pass over a big batch looks the depth pixels up in a tiled copy (d3f_eval_dist_workspace_bytes: 0 below 2^22 points)
+                ws_bytes = int(lib.d3f_eval_dist_workspace_bytes(ctypes.byref(views), n)) if self.reorder_points else 0
+                ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev) if ws_bytes else None
             if self.record_plans:
                 self._record_plan(views, n, maps, len(names), flags, ws is not None, return_inter, None)
             self._last_ws, self._last_ws_n = ws, n

@@ -170,6 +170,12 @@ int d3f_eval(const d3f_views *views, const float *pts, int64_t n, const d3f_chan
  * (Hilbert) order when the maps are much larger than the caches or the caller declares the points
  * unordered; outputs are unaffected. */
 int64_t d3f_eval_workspace_bytes(int64_t n);
+/* (ABI 6) Scratch for the DISTANCE-ONLY query (n_maps == 0; reference: batch_eval(pts, return_names=[]), vis_repr.py:93): with at
+ * least this many bytes of workspace d3f_eval first copies the depth maps into tiles of 4 x 8 pixels (one cache line each) and looks
+ * the nearest pixels up there -- consecutive query points of a grid column are neighbours along an image column, four cache lines per
+ * four lanes in a row-major map.  0: the batch is too small for that to pay (< 2^22 points) or has more than 8 views.  Outputs are
+ * unaffected; the workspace may be reused as soon as the call's work in `stream` is done. */
+int64_t d3f_eval_dist_workspace_bytes(const d3f_views *views, int64_t n);
 
 /* ABI 5.  For a CLOUD of >= 262 144 points in the Hilbert order on a patch-resolution wide map d3f_eval enqueues TWO fused
  * launches -- the LDS texel-window kernel and the cell-run kernel -- behind one device word: a probe kernel counts, over

@@ -213,6 +213,13 @@ def test_workspace_size():
     lib = _lib.load()
     assert lib.d3f_eval_workspace_bytes(0) == 0
     assert lib.d3f_eval_workspace_bytes(1000000) >= 16 * 1000000
+    # the distance-only pass: a tiled copy of the depth maps (4 x 8-pixel tiles of 128 bytes) from 2^22 points on, up to eight views
+    v4 = _lib.Views(4, 480, 640, None, None, None)
+    assert lib.d3f_eval_dist_workspace_bytes(ctypes.byref(v4), 123200000) == 4 * 60 * 160 * 128
+    assert lib.d3f_eval_dist_workspace_bytes(ctypes.byref(v4), (1 << 22) - 1) == 0
+    assert lib.d3f_eval_dist_workspace_bytes(ctypes.byref(_lib.Views(3, 243, 321, None, None, None)), 1 << 22) == 3 * 31 * 81 * 128
+    assert lib.d3f_eval_dist_workspace_bytes(ctypes.byref(_lib.Views(9, 480, 640, None, None, None)), 1 << 23) == 0
+    assert lib.d3f_eval_dist_workspace_bytes(None, 1 << 23) == 0
     assert lib.d3f_softmax_workspace_bytes(0, 10) == 0
     assert lib.d3f_softmax_workspace_bytes(1, 1) == 2 * 16
     assert lib.d3f_softmax_workspace_bytes(100000, 300) == (1563 + 1) * 300 * 16      # one 16-B record per 64-row tile and column
