@@ -23,8 +23,8 @@ shape):
             LATTICE (the shape of vis_repr.py:93's query with the names of :103); `--points surface` = what :97-103 really
             hands to batch_eval: the lattice points with valid_mask & |dist| < step in flat-index order (the vertices
             extract_mesh finds, fusion.py:1313-1330; ~71 k points here), a CLOUD
-  dist_only the distance-only pass over the 1-mm grid (return_names=[], vis_repr.py:93 / fusion.py:1420-1428): 123.2 M points,
-            bound by VALU issue (IEEE divisions of the projection), reported against both roofs
+  dist_only the distance-only pass over the 1-mm grid (return_names=[], vis_repr.py:93 / fusion.py:1420-1428): 123.2 M points on
+            fused_eval_dist_kernel (VALU issue of the arithmetic the contract fixes; depth lookups in a tiled copy)
 The default workload is c2_dense for EVERY --gpus N (weak scaling: the same per-GPU work at every N, so that the values of
 `bench.py --gpus 1/2/4/8` form one curve); `--workload c4_patch --gpus N` is BASELINE.json's eight-GPU configuration, whose N = 1
 point is `--gpus 1 --workload c4_patch`.  Every N > 1 line also carries rank 0's single-rank figure of the SAME workload

@@ -73,7 +73,7 @@ struct EvalParams {
     // each), [V][depth_th][depth_tw][8][4]; nullptr: the caller's row-major maps
     const float *depth_tiled;
     int32_t depth_tw, depth_th;
-    int32_t dist_variant;  // the distance-only pass: 0 = fused_eval_dist_kernel at eight waves per SIMD, 6 = at six, + 16 = the compiler's divisions, -1 = the branch of fused_eval_kernel (rounds 1-5)
+    int32_t dist_variant;  // the distance-only pass: 0 = fused_eval_dist_kernel, 8 = held to eight waves per SIMD with three and more views too, + 16 = the compiler's divisions, + 32 = no tiled depth copy, -1 = the branch of fused_eval_kernel (rounds 1-5)
     int32_t store_policy;  // 2 (default) = fused rows leave as non-temporal stores (nt), 3 = sc1 nt (the window kernel's own form), 1 = sc1, 0 = plain
     uint32_t flags;
     float mu;

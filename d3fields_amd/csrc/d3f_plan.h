@@ -6,7 +6,7 @@
 //   THE FAMILY TABLE (kFamilies below; walked top down, the first row whose predicate holds takes the query)
 //   family           kernel (fuse_<family>.hip)        takes the query when                                                  point order
 //   ---------------  --------------------------------  --------------------------------------------------------------------  --------------------------
-//   dist-only        fused_eval_dist_kernel<MODE,V,8>       no channel maps (return_names=[], eval_dist)                          caller
+//   dist-only        fused_eval_dist_kernel<MODE,V,OCC,T> no channel maps (return_names=[], eval_dist)                          caller
 //   register-rows    fused_eval_rows_kernel            a PATCH-resolution map of exactly 1024 fp32 channels, others thin,      lattice: brick walk (32 pts)
 //                                                      finite maps, no '<k>_inter', >= 65 536 points, <= 8 views: with MORE   cloud: Hilbert / caller order
 //                                                      than four views, or where the window row does not take the query
@@ -61,7 +61,7 @@ constexpr int64_t kInfinityCacheBytes = 256LL << 20;
 //   rows / rows_tile   register-rows kernel (1024-channel patch maps): -1 never, 1 = also below kSmallBatch; brick shape as digits x y z (442)
 //   thin               -1: thin maps through the view-sequential gather_map instead of gather_map_thin
 //   store              row-store policy: -1 plain, 1 sc1, 3 `sc1 nt`, default `nt` (fuse_common.h: store_out)
-//   dist               distance-only pass: -1 = the branch of fused_eval_kernel (rounds 1-5), 6 = fused_eval_dist_kernel held to six waves per SIMD,
+//   dist               distance-only pass: -1 = the branch of fused_eval_kernel (rounds 1-5), 8 = fused_eval_dist_kernel held to eight waves per SIMD with three and more views too,
 //                      + 16 = the compiler's divisions instead of the short form, + 32 = no tiled copy of the depth maps
 //   gate               > 0 always the window side of a cloud's gate, < 0 always the cell runs
 //   order_morton / order_fixed_grid / order_bits / scan3   point ordering: the Z curve of rounds 1-4, the fixed 4-mm grid, prefix bits, the three-launch scan
@@ -535,7 +535,7 @@ struct FamilyRow {
     const char *name, *kernel, *takes;
 };
 constexpr FamilyRow kFamilies[] = {
-    {kFamDistOnly, "dist-only", "fused_eval_dist_kernel<MODE, V, 8>", "no channel maps (return_names=[], eval_dist)"},
+    {kFamDistOnly, "dist-only", "fused_eval_dist_kernel<MODE, V, OCC, TILED>", "no channel maps (return_names=[], eval_dist)"},
     {kFamWindow, "lds-window", "fused_eval_window_kernel", "a patch-resolution wide map in whole 128-channel slices on a lattice, or (gated on the device) on a cloud of >= 262 144 points in the Hilbert order"},
     {kFamRuns, "cell-runs", "fused_eval_runs_kernel", "a patch-resolution wide fp32 map, >= 65 536 points; the other side of a cloud's gate"},
     {kFamSliced, "channel-sliced", "fused_eval_sliced_kernel", "a dense wide map (128..1024 channels) on a lattice walk or a Hilbert-ordered cloud"},

@@ -70,7 +70,9 @@ __global__ __launch_bounds__(kBlock) void fused_eval_f16_kernel(const EvalParams
 //   * the four views of a batch are unrolled: four projections, four depth lookups in flight per lane, then the sums IN VIEW
 //     ORDER (dsum and cnt start at +0 and take view 0, 1, ... exactly as the rolled loop did: bit-identical);
 //   * five to eight views (config 4: eight): a second batch of four continues the same sums; more: the branch of fused_eval_kernel;
-//   * held to 64 VGPRs = eight waves per SIMD.
+//   * 45-64 VGPRs: seven or eight waves per SIMD (launch_dist_v);
+//   * the IEEE divisions in their short form (d3f_device.h: project_point_short) and, on a big batch, the depth pixels looked up in a
+//     copy tiled 4 x 8 pixels per cache line (depth_tile_kernel below): 1.89 -> 1.185 ms on the 123 M-point grid of bench.py.
 // the NVQ views of one batch for one point, STAGE BY STAGE across the views: a wave's own instruction stream then carries NVQ
 // independent chains (the divisions are serial fma chains: with one view after the other the counters showed the waves
 // issue-stalled 54 % of the time with the VALU 76 % busy), the depth lookups leave together, and the short divisions'
@@ -182,7 +184,7 @@ __device__ __forceinline__ void dist_for_each_point(const EvalParams &P, BODY bo
 }
 
 // NVQ: the view count (1..4) as a compile-time constant, 0 = five to eight views (two batches of four)
-// OCC: waves per SIMD the entry point is held to (8: 64 VGPRs / ~80 SGPRs; 6: 80 / 102 -- KRt's 48 SGPRs then leave room)
+// OCC: waves per SIMD the entry point is held to (8: 64 VGPRs / ~80 SGPRs; 6: 80 / 102 -- see launch_dist_v)
 template <int MODE, int NVQ, int OCC, bool TILED>
 __global__ __launch_bounds__(kBlock, OCC) void fused_eval_dist_kernel(const EvalParams P)
 {
@@ -218,22 +220,43 @@ __global__ __launch_bounds__(kBlock, OCC) void fused_eval_dist_kernel(const Eval
     }
 }
 
-template <int MODE, int OCC, bool TILED>
-static void launch_dist_v(const EvalParams &P, dim3 grid, dim3 block, hipStream_t stream)
+// Waves per SIMD the entry point is held to: KRt's 48 SGPRs (three or four views) do not fit beside the rest at eight waves (~80
+// SGPRs: 32-47 spilled to VGPR lanes and read back per point); held to six the allocator has 102 and the kernel still runs seven
+// waves (1.185 vs 1.235 ms on the 123 M-point grid, session 47).  One or two views fit at eight.  occ8: experiments (D3F_EXP_DIST=8).
+template <int MODE, bool TILED>
+static void launch_dist_v(const EvalParams &P, dim3 grid, dim3 block, hipStream_t stream, bool occ8)
 {
     switch (P.V <= 4 ? P.V : 0) {
-    case 1: hipLaunchKernelGGL((fused_eval_dist_kernel<MODE, 1, OCC, TILED>), grid, block, 0, stream, P); break;
-    case 2: hipLaunchKernelGGL((fused_eval_dist_kernel<MODE, 2, OCC, TILED>), grid, block, 0, stream, P); break;
-    case 3: hipLaunchKernelGGL((fused_eval_dist_kernel<MODE, 3, OCC, TILED>), grid, block, 0, stream, P); break;
-    case 4: hipLaunchKernelGGL((fused_eval_dist_kernel<MODE, 4, OCC, TILED>), grid, block, 0, stream, P); break;
-    default: hipLaunchKernelGGL((fused_eval_dist_kernel<MODE, 0, OCC, TILED>), grid, block, 0, stream, P); break;
+    case 1: hipLaunchKernelGGL((fused_eval_dist_kernel<MODE, 1, 8, TILED>), grid, block, 0, stream, P); break;
+    case 2: hipLaunchKernelGGL((fused_eval_dist_kernel<MODE, 2, 8, TILED>), grid, block, 0, stream, P); break;
+    case 3:
+#ifdef D3F_EXPERIMENTS
+        if (occ8) { hipLaunchKernelGGL((fused_eval_dist_kernel<MODE, 3, 8, TILED>), grid, block, 0, stream, P); break; }
+#endif
+        hipLaunchKernelGGL((fused_eval_dist_kernel<MODE, 3, 6, TILED>), grid, block, 0, stream, P);
+        break;
+    case 4:
+#ifdef D3F_EXPERIMENTS
+        if (occ8) { hipLaunchKernelGGL((fused_eval_dist_kernel<MODE, 4, 8, TILED>), grid, block, 0, stream, P); break; }
+#endif
+        hipLaunchKernelGGL((fused_eval_dist_kernel<MODE, 4, 6, TILED>), grid, block, 0, stream, P);
+        break;
+    default:
+#ifdef D3F_EXPERIMENTS
+        if (occ8) { hipLaunchKernelGGL((fused_eval_dist_kernel<MODE, 0, 8, TILED>), grid, block, 0, stream, P); break; }
+#endif
+        hipLaunchKernelGGL((fused_eval_dist_kernel<MODE, 0, 6, TILED>), grid, block, 0, stream, P);
+        break;
     }
 }
-template <int MODE, int OCC>
+template <int MODE>
 static void launch_dist(const EvalParams &P, dim3 grid, dim3 block, hipStream_t stream)
 {
-    if (P.depth_tiled) launch_dist_v<MODE, OCC, true>(P, grid, block, stream);
-    else launch_dist_v<MODE, OCC, false>(P, grid, block, stream);
+    const bool occ8 = (P.dist_variant & 15) == 8;
+    if constexpr (MODE == 0) {          // (eval_dist, MODE 1, has no scratch parameter: keypoint batches)
+        if (P.depth_tiled) { launch_dist_v<MODE, true>(P, grid, block, stream, occ8); return; }
+    }
+    launch_dist_v<MODE, false>(P, grid, block, stream, occ8);
 }
 
 // The depth maps in tiles of 4 x 8 pixels -- one 128-byte line each -- for the distance-only pass over a big batch.  Its lookups are
@@ -276,13 +299,8 @@ hipError_t launch_direct(const EvalParams &P, int mode, hipStream_t stream)
     dim3 grid((unsigned)ntiles), block(kBlock);
     if (P.n_maps == 0 && P.walk_nx <= 0 && P.order == nullptr && P.V <= 8 && P.dist_variant >= 0) {
         // the distance-only pass in caller order: its own entry point (KRt in SGPRs, the views of a point in flight together)
-        if ((P.dist_variant & 15) == 6) {
-            if (mode == 0) launch_dist<0, 6>(P, grid, block, stream);
-            else launch_dist<1, 6>(P, grid, block, stream);
-        } else {
-            if (mode == 0) launch_dist<0, 8>(P, grid, block, stream);
-            else launch_dist<1, 8>(P, grid, block, stream);
-        }
+        if (mode == 0) launch_dist<0>(P, grid, block, stream);
+        else launch_dist<1>(P, grid, block, stream);
         return hipGetLastError();
     }
     bool wide = false, f16 = false;

@@ -560,7 +560,7 @@ class Fusion:
         if n_maps == 0 and int(plan.reorder) == 0 and int(views.V) <= 8:
             # the distance-only pass (fuse_direct.hip): <mode, view count (0: five to eight), waves per SIMD, depth maps tiled first?>
             tiled = have_ws and n >= (1 << 22)
-            kernel = "fused_eval_dist_kernel<0, %d, 8, %s>" % (int(views.V) if int(views.V) <= 4 else 0, "true" if tiled else "false")
+            kernel = "fused_eval_dist_kernel<0, %d, %d, %s>" % (int(views.V) if int(views.V) <= 4 else 0, 8 if int(views.V) <= 2 else 6, "true" if tiled else "false")
         window = 2000 <= plan.reserved < 3000
         if window:
             r = plan.reserved - 2000
