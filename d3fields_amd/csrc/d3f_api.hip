@@ -518,9 +518,15 @@ int d3f_grid_shell(const d3f_views *views, const d3f_grid *grid, float mu, float
         return fail(D3F_ERR_WORKSPACE, "grid_shell: needs %lld workspace bytes", (long long)d3f_grid_shell_workspace_bytes(grid));
     if (!(mu > 0.0f)) return fail(D3F_ERR_INVALID_ARG, "mu must be > 0");
     if (((int64_t)grid->nx * grid->ny * grid->nz + d3f::kBlock - 1) / d3f::kBlock > 0x7fffffffLL) return fail(D3F_ERR_BAD_SHAPE, "grid too large for one launch");
+    // a workspace with d3f_eval_dist_workspace_bytes(views, n) bytes MORE than the shell needs: the depth lookups go to a tiled copy there
+    const int64_t n_grid = (int64_t)grid->nx * grid->ny * grid->nz, shell_bytes = (d3f_grid_shell_workspace_bytes(grid) + 255) / 256 * 256;
+    const int64_t tiled_bytes = d3f_eval_dist_workspace_bytes(views, n_grid);
+    float *tiled = (tiled_bytes > 0 && workspace_bytes >= shell_bytes + tiled_bytes)
+                       ? reinterpret_cast<float *>(static_cast<unsigned char *>(workspace) + shell_bytes) : nullptr;
     hipError_t e = d3f::launch_grid_shell(views->depth, views->K, views->pose, views->V, views->H, views->W, grid->x, grid->y,
                                           grid->z, grid->nx, grid->ny, grid->nz, mu, dist_thr, capacity, idx_out,
-                                          reinterpret_cast<unsigned long long *>(count_out), workspace, static_cast<hipStream_t>(stream));
+                                          reinterpret_cast<unsigned long long *>(count_out), workspace, static_cast<hipStream_t>(stream),
+                                          tiled);
     return e == hipSuccess ? D3F_OK : hip_fail(e, "grid_shell launch");
 }
 

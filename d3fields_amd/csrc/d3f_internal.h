@@ -141,7 +141,8 @@ hipError_t launch_points_probe(const float *pts, int64_t n, int32_t *out, hipStr
 // grid_kernels.hip
 hipError_t launch_grid_shell(const float *depth, const float *K, const float *pose, int V, int H, int W, const float *gx,
                              const float *gy, const float *gz, int nx, int ny, int nz, float mu, float dist_thr,
-                             int64_t capacity, int64_t *idx_out, unsigned long long *count, void *workspace, hipStream_t s);
+                             int64_t capacity, int64_t *idx_out, unsigned long long *count, void *workspace, hipStream_t s,
+                             float *tiled_scratch);
 int64_t grid_shell_workspace_bytes(int64_t n);
 hipError_t launch_fps(const float *pts, int64_t n, int k, int64_t init_idx, int64_t *out_idx, float *out_maxdist,
                       void *workspace, hipStream_t s);

@@ -15,6 +15,7 @@
 
 #include "d3f_internal.h"
 #include "d3f_device.h"
+#include "dist_views.h"
 
 namespace d3f {
 
@@ -57,6 +58,76 @@ __global__ __launch_bounds__(kBlock) void grid_shell_flag_kernel(const float *__
     if (threadIdx.x == 0) block_counts[blockIdx.x] = wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
 }
 
+// Pass 1 for up to eight views (round 6, last): the distance of a grid point as the distance-only kernel computes it (dist_views.h:
+// KRt in SGPRs, the views stage by stage, short IEEE divisions, depth pixels from the tiled copy when the caller's scratch has room
+// for one) -- the same operations on the same operands as the kernel above, so the same survivors.  A workgroup takes kShellBlocks
+// consecutive 256-point blocks (KRt once per wave and four points); the flat index is taken apart in 32-bit arithmetic (n < 2^32).
+constexpr int kShellBlocks = 4;
+template <int NVQ, bool TILED>
+__global__ __launch_bounds__(kBlock, (NVQ == 1 || NVQ == 2) ? 8 : 6) void grid_shell_flag_fast_kernel(const EvalParams P, float dist_thr,
+                                                                                                unsigned long long *__restrict__ ballots,
+                                                                                                uint32_t *__restrict__ block_counts)
+{
+    __shared__ int wave_cnt[kBlock / 64];
+    const float mu = P.mu;
+    const DivConst Wm1 = div_const((float)(P.W - 1)), Hm1 = div_const((float)(P.H - 1));
+    const int V = P.V;
+    const float kr0 = dist_krt_lane(P, 0), kr1 = NVQ == 0 ? dist_krt_lane(P, 4) : 0.0f;
+    float M[4][12];
+    if constexpr (NVQ > 0) dist_krt_uniform(kr0, M);
+    const uint32_t n = (uint32_t)P.n, nz = (uint32_t)P.grid_nz, ny = (uint32_t)P.grid_ny;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t nb = ((int64_t)P.n + kBlock - 1) / kBlock;
+#pragma unroll 1
+    for (int k = 0; k < kShellBlocks; ++k) {
+        const int64_t blk = (int64_t)blockIdx.x * kShellBlocks + k;
+        if (blk >= nb) break;                                       // workgroup-uniform
+        const uint32_t i = (uint32_t)blk * kBlock + threadIdx.x;
+        bool keep = false;
+        if (i < n) {
+            const uint32_t ixy = i / nz, iz = i - ixy * nz;
+            const uint32_t ix = ixy / ny, iy = ixy - ix * ny;
+            const float px = P.grid_x[ix], py = P.grid_y[iy], pz = P.grid_z[iz];
+            float dsum = 0.0f, cnt = 0.0f;
+            if constexpr (NVQ > 0) {
+                dist_views<0, NVQ, TILED>(P, M, 0, px, py, pz, Wm1, Hm1, mu, dsum, cnt);
+            } else {
+                dist_krt_uniform(kr0, M);
+                dist_views<0, 4, TILED>(P, M, 0, px, py, pz, Wm1, Hm1, mu, dsum, cnt);
+                __builtin_amdgcn_sched_barrier(0);
+                dist_krt_uniform(kr1, M);
+                if (V == 8) dist_views<0, 4, TILED>(P, M, 4, px, py, pz, Wm1, Hm1, mu, dsum, cnt);
+                else if (V == 7) dist_views<0, 3, TILED>(P, M, 4, px, py, pz, Wm1, Hm1, mu, dsum, cnt);
+                else if (V == 6) dist_views<0, 2, TILED>(P, M, 4, px, py, pz, Wm1, Hm1, mu, dsum, cnt);
+                else dist_views<0, 1, TILED>(P, M, 4, px, py, pz, Wm1, Hm1, mu, dsum, cnt);
+            }
+            // fusion.py:1430, 1444: |dist| < dist_threshold and valid_mask (an all-invalid point has dist = 1e3)
+            keep = (cnt != 0.0f) && (fabsf(dsum / (cnt + 1e-6f)) < dist_thr);
+        }
+        const unsigned long long ballot = __ballot(keep);
+        if (lane == 0) {
+            ballots[blk * (kBlock / 64) + wave] = ballot;
+            wave_cnt[wave] = __popcll(ballot);
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) block_counts[blk] = wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
+        __syncthreads();
+    }
+}
+
+template <bool TILED>
+static void launch_shell_flag_fast(const EvalParams &P, float dist_thr, unsigned long long *ballots, uint32_t *counts, int64_t nb, hipStream_t s)
+{
+    const dim3 grid((unsigned)((nb + kShellBlocks - 1) / kShellBlocks)), block(kBlock);
+    switch (P.V <= 4 ? P.V : 0) {
+    case 1: hipLaunchKernelGGL((grid_shell_flag_fast_kernel<1, TILED>), grid, block, 0, s, P, dist_thr, ballots, counts); break;
+    case 2: hipLaunchKernelGGL((grid_shell_flag_fast_kernel<2, TILED>), grid, block, 0, s, P, dist_thr, ballots, counts); break;
+    case 3: hipLaunchKernelGGL((grid_shell_flag_fast_kernel<3, TILED>), grid, block, 0, s, P, dist_thr, ballots, counts); break;
+    case 4: hipLaunchKernelGGL((grid_shell_flag_fast_kernel<4, TILED>), grid, block, 0, s, P, dist_thr, ballots, counts); break;
+    default: hipLaunchKernelGGL((grid_shell_flag_fast_kernel<0, TILED>), grid, block, 0, s, P, dist_thr, ballots, counts); break;
+    }
+}
+
 // Pass 2 (after an exclusive scan of the workgroup counts): survivors are written in ascending flat index --
 // the order of the reference's boolean-mask indexing -- so no sort is needed afterwards.
 __global__ __launch_bounds__(kBlock) void grid_shell_write_kernel(const unsigned long long *__restrict__ ballots,
@@ -87,9 +158,12 @@ int64_t grid_shell_workspace_bytes(int64_t n)
     return nb * (kBlock / 64) * 8 + 2 * ((nb * 4 + 255) / 256 * 256) + scan_scratch_bytes(nb);   // ballots + counts + offsets + scan scratch
 }
 
+// tiled_scratch: nullptr, or depth_tiled_bytes(V, H, W) bytes BEHIND the workspace proper (d3f_grid_shell: the caller handed
+// over d3f_grid_shell_workspace_bytes + d3f_eval_dist_workspace_bytes)
 hipError_t launch_grid_shell(const float *depth, const float *K, const float *pose, int V, int H, int W, const float *gx,
                              const float *gy, const float *gz, int nx, int ny, int nz, float mu, float dist_thr,
-                             int64_t capacity, int64_t *idx_out, unsigned long long *count, void *workspace, hipStream_t s)
+                             int64_t capacity, int64_t *idx_out, unsigned long long *count, void *workspace, hipStream_t s,
+                             float *tiled_scratch)
 {
     const int64_t n = (int64_t)nx * ny * nz;
     hipError_t e = hipMemsetAsync(count, 0, sizeof(unsigned long long), s);
@@ -101,8 +175,24 @@ hipError_t launch_grid_shell(const float *depth, const float *K, const float *po
     uint32_t *counts = reinterpret_cast<uint32_t *>(base + nb * (kBlock / 64) * 8);
     uint32_t *offsets = reinterpret_cast<uint32_t *>(base + nb * (kBlock / 64) * 8 + seg);
     void *scratch = base + nb * (kBlock / 64) * 8 + 2 * seg;
-    hipLaunchKernelGGL(grid_shell_flag_kernel, dim3((unsigned)nb), dim3(kBlock), (size_t)V * 48, s, depth, K, pose, V, H, W, gx, gy,
-                       gz, ny, nz, n, mu, dist_thr, ballots, counts);
+    if (V <= 8 && n < 0xffffffffLL) {
+        EvalParams P;
+        memset(&P, 0, sizeof(P));
+        P.depth = depth; P.K = K; P.pose = pose; P.V = V; P.H = H; P.W = W; P.mu = mu; P.n = n;
+        P.grid_x = gx; P.grid_y = gy; P.grid_z = gz; P.grid_ny = ny; P.grid_nz = nz;
+        if (tiled_scratch && n >= kDistTiledMin) {
+            P.depth_tw = (W + 3) / 4; P.depth_th = (H + 7) / 8;
+            e = launch_depth_tiles(P, tiled_scratch, s);
+            if (e != hipSuccess) return e;
+            P.depth_tiled = tiled_scratch;
+            launch_shell_flag_fast<true>(P, dist_thr, ballots, counts, nb, s);
+        } else {
+            launch_shell_flag_fast<false>(P, dist_thr, ballots, counts, nb, s);
+        }
+    } else {
+        hipLaunchKernelGGL(grid_shell_flag_kernel, dim3((unsigned)nb), dim3(kBlock), (size_t)V * 48, s, depth, K, pose, V, H, W, gx, gy,
+                           gz, ny, nz, n, mu, dist_thr, ballots, counts);
+    }
     e = launch_exclusive_scan_u32(counts, offsets, nb, scratch, s);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(grid_shell_write_kernel, dim3((unsigned)nb), dim3(kBlock), 0, s, ballots, offsets, n, capacity, idx_out);

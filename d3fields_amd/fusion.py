@@ -846,6 +846,8 @@ class Fusion:
         count = torch.zeros(1, dtype=torch.int64, device=dev)
         capacity = max(1 << 16, n // 16)
         ws_bytes = self._lib.d3f_grid_shell_workspace_bytes(ctypes.byref(grid))
+        # (+ room for the tiled copy of the depth maps a big grid's lookups go to: include/d3fields_hip.h, d3f_grid_shell)
+        ws_bytes = (ws_bytes + 255) // 256 * 256 + int(self._lib.d3f_eval_dist_workspace_bytes(ctypes.byref(views), grid.nx * grid.ny * grid.nz))
         ws = torch.empty(max(ws_bytes, 16), dtype=torch.uint8, device=dev)
         while True:
             idx = torch.empty(capacity, dtype=torch.int64, device=dev)

@@ -266,7 +266,9 @@ int d3f_lattice_probe(const float *pts, int64_t n, int32_t *out_dims, void *stre
 /* Pre-filter of select_features_* (fusion.py:1430,1444): flat indices of the grid points with
  * valid_mask && |dist| < dist_thr, compacted into idx_out[0..min(count,capacity)) in ASCENDING order (the order
  * of the reference's boolean-mask indexing).  count_out: ONE device int64, the number of survivors (may exceed
- * capacity: then only the first `capacity` indices were stored).  workspace: d3f_grid_shell_workspace_bytes. */
+ * capacity: then only the first `capacity` indices were stored).  workspace: d3f_grid_shell_workspace_bytes -- rounded up to a multiple of
+ * 256 and followed by d3f_eval_dist_workspace_bytes(views, nx*ny*nz) further bytes the depth lookups of a big grid go to a tiled copy
+ * (same survivors; optional). */
 int64_t d3f_grid_shell_workspace_bytes(const d3f_grid *grid);
 int d3f_grid_shell(const d3f_views *views, const d3f_grid *grid, float mu, float dist_thr, int64_t capacity,
                    int64_t *idx_out, int64_t *count_out, void *workspace, int64_t workspace_bytes, void *stream);

@@ -138,3 +138,26 @@ def test_dist_only_tiled_depth_on_a_lattice(dev, V):
         assert f.last_plan()["kernel"].endswith("false>"), f.last_plan()
     assert torch.equal(a["valid_mask"], b["valid_mask"])
     assert torch.equal(torch.nan_to_num(a["dist"], nan=7.0), torch.nan_to_num(b["dist"], nan=7.0))
+
+
+@pytest.mark.parametrize("V,dims,step", [(4, (170, 160, 155), 0.002), (3, (90, 81, 37), 0.004), (8, (170, 160, 155), 0.002), (9, (60, 50, 41), 0.005)])
+def test_grid_shell_fast_pass_keeps_the_same_survivors(dev, V, dims, step):
+    """The keypoint pre-filter (select_features_rand, fusion.py:1418-1444) on the distance-only kernel's arithmetic (grid_kernels.hip:
+    grid_shell_flag_fast_kernel; >= 2^22 grid points: tiled depth lookups; nine views: the general kernel): the survivors are exactly the
+    lattice points the oracle's distance field selects, in ascending flat index."""
+    from d3fields_amd import create_init_grid, synth
+    from oracle import c_oracle as O
+    H, W = 240, 320
+    sc = synth.make_scene(V, H, W, "smooth")
+    box = dict(x_lower=-dims[0] * step / 2, x_upper=dims[0] * step / 2 - step / 4, y_lower=-dims[1] * step / 2,
+               y_upper=dims[1] * step / 2 - step / 4, z_lower=-0.05, z_upper=-0.05 + dims[2] * step - step / 4)
+    pts_c = create_init_grid(box, step)[0]
+    assert pts_c.shape[0] == dims[0] * dims[1] * dims[2]
+    f = _fusion(dev, sc, H, W)
+    thr = 2.5 * step
+    idx, pts = f.grid_shell(box, step, thr)
+    ref = O.eval_field(sc["depth"], sc["K"], sc["pose"], pts_c, [])
+    want = np.nonzero(ref["valid_mask"].astype(bool) & (np.abs(ref["dist"]) < np.float32(thr)))[0]
+    assert want.size > 1000
+    assert np.array_equal(cpu(idx), want)
+    assert np.array_equal(cpu(pts), pts_c.numpy()[want])
