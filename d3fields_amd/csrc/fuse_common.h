@@ -511,10 +511,18 @@ __device__ __forceinline__ int64_t xcd_tile(int64_t b, int64_t nb)
 __device__ __forceinline__ void fetch_point(const EvalParams &P, int64_t i, float &px, float &py, float &pz)
 {
     if (P.grid_x) {
-        const int64_t iz = i % P.grid_nz, ixy = i / P.grid_nz;
-        px = P.grid_x[ixy / P.grid_ny];
-        py = P.grid_y[ixy % P.grid_ny];
-        pz = P.grid_z[iz];
+        if (P.n <= 0xffffffffLL) {          // (wave-uniform) two 32-bit divisions instead of two 64-bit ones: ~50 instead of ~300 instructions
+            const uint32_t j = (uint32_t)i, nz = (uint32_t)P.grid_nz, ny = (uint32_t)P.grid_ny;
+            const uint32_t ixy = j / nz, iz = j - ixy * nz, ix = ixy / ny;
+            px = P.grid_x[ix];
+            py = P.grid_y[ixy - ix * ny];
+            pz = P.grid_z[iz];
+        } else {
+            const int64_t iz = i % P.grid_nz, ixy = i / P.grid_nz;
+            px = P.grid_x[ixy / P.grid_ny];
+            py = P.grid_y[ixy % P.grid_ny];
+            pz = P.grid_z[iz];
+        }
     } else {
         px = P.pts[i * 3 + 0]; py = P.pts[i * 3 + 1]; pz = P.pts[i * 3 + 2];
     }
