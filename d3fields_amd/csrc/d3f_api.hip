@@ -258,8 +258,9 @@ int eval_common(const d3f_views *views, const float *pts, int64_t n, const d3f_c
         if (ep != hipSuccess) return hip_fail(ep, "window gate probe");
     }
     // the distance-only pass over a big batch in caller order, with scratch: the depth maps are tiled first (inside the timed pair)
-    if (n_maps == 0 && n >= d3f::kDistTiledMin && !P.order && P.walk_nx <= 0 && views->V <= 8 && tune.dist >= 0 && !(tune.dist & 32) &&
-        workspace && workspace_bytes >= d3f::depth_tiled_bytes(views->V, views->H, views->W)) {
+    if (n_maps == 0 && n >= d3f::kDistTiledMin && !P.order && P.walk_nx <= 0 && !P.grid_x && views->V <= 8 && tune.dist >= 0 && !(tune.dist & 32) &&
+        workspace && workspace_bytes >= d3f::depth_tiled_bytes(views->V, views->H, views->W) &&
+        d3f::depth_tiled_bytes(views->V, views->H, views->W) < (1LL << 32)) {         // (32-bit pixel indices in the tiled copy)
         P.depth_tw = (views->W + 3) / 4; P.depth_th = (views->H + 7) / 8;
         hipError_t et = d3f::launch_depth_tiles(P, static_cast<float *>(workspace), hs);
         if (et != hipSuccess) return hip_fail(et, "depth tiling");
@@ -303,7 +304,8 @@ int64_t d3f_eval_workspace_bytes(int64_t n) { return d3f::order_workspace_bytes(
 int64_t d3f_eval_dist_workspace_bytes(const d3f_views *views, int64_t n)
 {
     if (!views || n < d3f::kDistTiledMin || views->V < 1 || views->V > 8 || views->H < 1 || views->W < 1) return 0;
-    return d3f::depth_tiled_bytes(views->V, views->H, views->W);
+    const int64_t bytes = d3f::depth_tiled_bytes(views->V, views->H, views->W);
+    return bytes < (1LL << 32) ? bytes : 0;
 }
 
 const char *d3f_plan_family_name(int32_t family) { return (family >= 0 && family < (int32_t)(sizeof(kFamilies) / sizeof(kFamilies[0]))) ? kFamilies[family].name : nullptr; }

@@ -108,7 +108,8 @@ __device__ __forceinline__ float nearest_depth(const float *depth, int v, int H,
         const bool in = ((int)(rx > -1.0f) & (int)(rx < (float)W) & (int)(ry > -1.0f) & (int)(ry < (float)H)) != 0;      // in_bounds() without its short circuits
         const int ix = in ? (int)rx : 0, iy = in ? (int)ry : 0;
         float d;
-        if constexpr (TILED) d = depth[((((int64_t)v * th + (iy >> 3)) * tw + (ix >> 2)) << 5) + (((iy & 7) << 2) | (ix & 3))];
+        // (32-bit index: the host tiles only maps of fewer than 2^31 pixels -- an SGPR base + a 32-bit lane offset, no 64-bit adds)
+        if constexpr (TILED) d = depth[(((uint32_t)(v * th + (iy >> 3)) * (uint32_t)tw + (uint32_t)(ix >> 2)) << 5) + (uint32_t)(((iy & 7) << 2) | (ix & 3))];
         else d = depth[((int64_t)v * H + iy) * W + ix];
         return in ? d : 0.0f;
     } else {

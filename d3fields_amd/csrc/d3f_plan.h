@@ -586,7 +586,8 @@ inline void plan_geometry(const Query &q, d3f::EvalParams &P, Plan &pl)
         // distance-only pass (return_names=[], eval_dist): one lane per point and nothing per point in LDS.  Rounds 1-3 ran it on
         // the 128-point tiles of the gathers -- half of every 256-lane workgroup idle (SQ_WAVES = 3.85 M for 123.2 M points):
         // four points per lane and workgroup instead, KRt computed once per 1024 points
-        P.tile_pts = q.n >= (1LL << 22) ? 1024 : 256;
+        // (from 2^24 points on sixteen points per lane: a wave's KRt set-up -- ~100 instructions -- is then 1.5 % of its work instead of 6 %)
+        P.tile_pts = q.n >= (1LL << 24) ? 4096 : (q.n >= (1LL << 22) ? 1024 : 256);
         P.lds_pad = 0;
     }
     P.crec_offset = d3f::fused_lds_base(q.n_maps == 0 ? 0 : P.tile_pts, q.views->V);

@@ -39,7 +39,7 @@ __device__ __forceinline__ void dist_views(const EvalParams &P, const float (&M)
         a[q] = div_short(u[q], cw); b[q] = div_short(w[q], ch);                                          // fusion.py:72-73
         plain &= (int)div_result_plain(a[q]) & (int)div_result_plain(b[q]) & (int)(fabsf(zc[q]) <= 0x1p60f);
     }
-    if ((P.dist_variant & 16) != 0 || !__all(plain)) {       // (bit 16: wave-uniform, the A/B switch of experiments builds)
+    if (__builtin_expect((P.dist_variant & 16) != 0 || !__all(plain), 0)) {       // (bit 16: wave-uniform, the A/B switch of experiments builds)
 #pragma unroll
         for (int q = 0; q < NVQ; ++q) {
             const float uu = xc[q] / zc[q], ww = yc[q] / zc[q];

@@ -87,7 +87,10 @@ __device__ __forceinline__ void dist_store(const EvalParams &P, int mode, int64_
 // (point loads and the 'dist' / 'valid_mask' stores are then whole lines per wave; bricks of a lattice -- sixteen 4 x 4 x 4
 // sub-bricks per workgroup, any lane order -- fragment both and measured 2-8 % slower, rows of 64 x 3.5 times: session 42,
 // scripts/notebook/patches/r6_dist_bricks_and_whatifs.patch)
-template <typename BODY>
+// GRID: the points come from the axis arrays of a d3f_grid (d3f_eval_grid), else from the [n, 3] array -- a template argument, not
+// fetch_point's run-time branch: the loop of this kernel is short enough for every scalar branch in it to show (two more
+// wave-uniform tests per point cost 8 % in session 52's experiments build)
+template <bool GRID, typename BODY>
 __device__ __forceinline__ void dist_for_each_point(const EvalParams &P, BODY body)
 {
     const int64_t tile_base = (int64_t)blockIdx.x * P.tile_pts;
@@ -95,14 +98,15 @@ __device__ __forceinline__ void dist_for_each_point(const EvalParams &P, BODY bo
 #pragma unroll 1
     for (int64_t i = tile_base + threadIdx.x; i < end; i += kBlock) {
         float px, py, pz;
-        fetch_point(P, i, px, py, pz);
+        if constexpr (GRID) fetch_point(P, i, px, py, pz);
+        else { px = P.pts[i * 3 + 0]; py = P.pts[i * 3 + 1]; pz = P.pts[i * 3 + 2]; }
         body(i, px, py, pz);
     }
 }
 
 // NVQ: the view count (1..4) as a compile-time constant, 0 = five to eight views (two batches of four)
 // OCC: waves per SIMD the entry point is held to (8: 64 VGPRs / ~80 SGPRs; 6: 80 / 102 -- see launch_dist_v)
-template <int MODE, int NVQ, int OCC, bool TILED>
+template <int MODE, int NVQ, int OCC, bool TILED, bool GRID>
 __global__ __launch_bounds__(kBlock, OCC) void fused_eval_dist_kernel(const EvalParams P)
 {
     if (gated_out(P)) return;
@@ -111,7 +115,7 @@ __global__ __launch_bounds__(kBlock, OCC) void fused_eval_dist_kernel(const Eval
     if constexpr (NVQ > 0) {
         float M[4][12];
         dist_krt_uniform(dist_krt_lane(P, 0), M);
-        dist_for_each_point(P, [&](int64_t i, float px, float py, float pz) {
+        dist_for_each_point<GRID>(P, [&](int64_t i, float px, float py, float pz) {
             float ds = 0.0f, cn = 0.0f;
             dist_views<MODE, NVQ, TILED>(P, M, 0, px, py, pz, Wm1, Hm1, mu, ds, cn);
             dist_store(P, MODE, i, ds, cn);
@@ -121,7 +125,7 @@ __global__ __launch_bounds__(kBlock, OCC) void fused_eval_dist_kernel(const Eval
         // are handed to the scalar file in front of each batch (48 v_readlane: ~14 % on top of a batch's four views)
         const int V = P.V;
         const float kr0 = dist_krt_lane(P, 0), kr1 = dist_krt_lane(P, 4);
-        dist_for_each_point(P, [&](int64_t i, float px, float py, float pz) {
+        dist_for_each_point<GRID>(P, [&](int64_t i, float px, float py, float pz) {
             float ds = 0.0f, cn = 0.0f;
             float M[4][12];
             dist_krt_uniform(kr0, M);
@@ -140,29 +144,29 @@ __global__ __launch_bounds__(kBlock, OCC) void fused_eval_dist_kernel(const Eval
 // Waves per SIMD the entry point is held to: KRt's 48 SGPRs (three or four views) do not fit beside the rest at eight waves (~80
 // SGPRs: 32-47 spilled to VGPR lanes and read back per point); held to six the allocator has 102 and the kernel still runs seven
 // waves (1.185 vs 1.235 ms on the 123 M-point grid, session 47).  One or two views fit at eight.  occ8: experiments (D3F_EXP_DIST=8).
-template <int MODE, bool TILED>
+template <int MODE, bool TILED, bool GRID>
 static void launch_dist_v(const EvalParams &P, dim3 grid, dim3 block, hipStream_t stream, bool occ8)
 {
     switch (P.V <= 4 ? P.V : 0) {
-    case 1: hipLaunchKernelGGL((fused_eval_dist_kernel<MODE, 1, 8, TILED>), grid, block, 0, stream, P); break;
-    case 2: hipLaunchKernelGGL((fused_eval_dist_kernel<MODE, 2, 8, TILED>), grid, block, 0, stream, P); break;
+    case 1: hipLaunchKernelGGL((fused_eval_dist_kernel<MODE, 1, 8, TILED, GRID>), grid, block, 0, stream, P); break;
+    case 2: hipLaunchKernelGGL((fused_eval_dist_kernel<MODE, 2, 8, TILED, GRID>), grid, block, 0, stream, P); break;
     case 3:
 #ifdef D3F_EXPERIMENTS
-        if (occ8) { hipLaunchKernelGGL((fused_eval_dist_kernel<MODE, 3, 8, TILED>), grid, block, 0, stream, P); break; }
+        if (occ8) { hipLaunchKernelGGL((fused_eval_dist_kernel<MODE, 3, 8, TILED, GRID>), grid, block, 0, stream, P); break; }
 #endif
-        hipLaunchKernelGGL((fused_eval_dist_kernel<MODE, 3, 6, TILED>), grid, block, 0, stream, P);
+        hipLaunchKernelGGL((fused_eval_dist_kernel<MODE, 3, 6, TILED, GRID>), grid, block, 0, stream, P);
         break;
     case 4:
 #ifdef D3F_EXPERIMENTS
-        if (occ8) { hipLaunchKernelGGL((fused_eval_dist_kernel<MODE, 4, 8, TILED>), grid, block, 0, stream, P); break; }
+        if (occ8) { hipLaunchKernelGGL((fused_eval_dist_kernel<MODE, 4, 8, TILED, GRID>), grid, block, 0, stream, P); break; }
 #endif
-        hipLaunchKernelGGL((fused_eval_dist_kernel<MODE, 4, 6, TILED>), grid, block, 0, stream, P);
+        hipLaunchKernelGGL((fused_eval_dist_kernel<MODE, 4, 6, TILED, GRID>), grid, block, 0, stream, P);
         break;
     default:
 #ifdef D3F_EXPERIMENTS
-        if (occ8) { hipLaunchKernelGGL((fused_eval_dist_kernel<MODE, 0, 8, TILED>), grid, block, 0, stream, P); break; }
+        if (occ8) { hipLaunchKernelGGL((fused_eval_dist_kernel<MODE, 0, 8, TILED, GRID>), grid, block, 0, stream, P); break; }
 #endif
-        hipLaunchKernelGGL((fused_eval_dist_kernel<MODE, 0, 6, TILED>), grid, block, 0, stream, P);
+        hipLaunchKernelGGL((fused_eval_dist_kernel<MODE, 0, 6, TILED, GRID>), grid, block, 0, stream, P);
         break;
     }
 }
@@ -170,10 +174,11 @@ template <int MODE>
 static void launch_dist(const EvalParams &P, dim3 grid, dim3 block, hipStream_t stream)
 {
     const bool occ8 = (P.dist_variant & 15) == 8;
-    if constexpr (MODE == 0) {          // (eval_dist, MODE 1, has no scratch parameter: keypoint batches)
-        if (P.depth_tiled) { launch_dist_v<MODE, true>(P, grid, block, stream, occ8); return; }
+    if constexpr (MODE == 0) {          // (eval_dist, MODE 1, has no scratch or grid parameter: keypoint batches)
+        if (P.depth_tiled) { launch_dist_v<MODE, true, false>(P, grid, block, stream, occ8); return; }      // (d3f_eval_grid has no scratch parameter either)
+        if (P.grid_x) { launch_dist_v<MODE, false, true>(P, grid, block, stream, occ8); return; }
     }
-    launch_dist_v<MODE, false>(P, grid, block, stream, occ8);
+    launch_dist_v<MODE, false, false>(P, grid, block, stream, occ8);
 }
 
 // The depth maps in tiles of 4 x 8 pixels -- one 128-byte line each -- for the distance-only pass over a big batch.  Its lookups are

@@ -180,7 +180,7 @@ hipError_t launch_grid_shell(const float *depth, const float *K, const float *po
         memset(&P, 0, sizeof(P));
         P.depth = depth; P.K = K; P.pose = pose; P.V = V; P.H = H; P.W = W; P.mu = mu; P.n = n;
         P.grid_x = gx; P.grid_y = gy; P.grid_z = gz; P.grid_ny = ny; P.grid_nz = nz;
-        if (tiled_scratch && n >= kDistTiledMin) {
+        if (tiled_scratch && n >= kDistTiledMin && depth_tiled_bytes(V, H, W) < (1LL << 32)) {
             P.depth_tw = (W + 3) / 4; P.depth_th = (H + 7) / 8;
             e = launch_depth_tiles(P, tiled_scratch, s);
             if (e != hipSuccess) return e;

@@ -558,9 +558,9 @@ class Fusion:
         f16 = any(maps[s].dtype == _lib.DTYPE_F16 for s in range(n_maps))
         kernel = ("fused_eval_f16_kernel<0>" if f16 else "fused_eval_wide_kernel<0>" if wide else "fused_eval_kernel<0>")
         if n_maps == 0 and int(plan.reorder) == 0 and int(views.V) <= 8:
-            # the distance-only pass (fuse_direct.hip): <mode, view count (0: five to eight), waves per SIMD, depth maps tiled first?>
+            # the distance-only pass (fuse_direct.hip): <mode, view count (0: five to eight), waves per SIMD, depth maps tiled first?, points from grid axes?>
             tiled = have_ws and n >= (1 << 22)
-            kernel = "fused_eval_dist_kernel<0, %d, %d, %s>" % (int(views.V) if int(views.V) <= 4 else 0, 8 if int(views.V) <= 2 else 6, "true" if tiled else "false")
+            kernel = "fused_eval_dist_kernel<0, %d, %d, %s, false>" % (int(views.V) if int(views.V) <= 4 else 0, 8 if int(views.V) <= 2 else 6, "true" if tiled else "false")
         window = 2000 <= plan.reserved < 3000
         if window:
             r = plan.reserved - 2000

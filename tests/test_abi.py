@@ -275,7 +275,8 @@ def test_launch_plan_host_logic():
     assert (p.vector_floats[2], p.lanes_per_point[2], p.vectors_per_lane[2]) == (1, 4, 1)       # thin family: one pass, one vector per lane
     # the distance-only pass (return_names=[]): one lane per point, four points per lane on big batches, nothing per point in LDS
     p = _plan(4, 480, 640, 123200000, [])
-    assert (p.tile_points, p.reorder, p.workgroups) == (1024, 0, (123200000 + 1023) // 1024) and p.lds_bytes <= 512
+    assert (p.tile_points, p.reorder, p.workgroups) == (4096, 0, (123200000 + 4095) // 4096) and p.lds_bytes <= 512
+    assert _plan(4, 480, 640, 5000000, []).tile_points == 1024
     assert _plan(4, 480, 640, 100000, []).tile_points == 256
     # many views shrink the tile so that the per-(point,view) records fit LDS
     p = _plan(64, 48, 64, 5000, [(6, 8, 16)])

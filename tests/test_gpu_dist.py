@@ -75,7 +75,7 @@ def test_dist_only_big_batch_tiles(dev):
     pts_c = synth.random_cloud(n, seed=5)
     pts_c[7] = torch.tensor([float("nan"), 0.0, 0.1]); pts_c[9] = torch.tensor([1e30, 0.0, 0.1]); pts_c[11] = 0.0
     plan = _check(dev, sc, H, W, pts_c, "big batch")
-    assert plan["tile_points"] == 1024 and plan["kernel"] == "fused_eval_dist_kernel<0, 4, 6, true>", plan
+    assert plan["tile_points"] == 1024 and plan["kernel"].startswith("fused_eval_dist_kernel<0, 4, 6, true"), plan
 
 
 def test_dist_only_projections_the_short_division_must_hand_over(dev):
@@ -128,14 +128,14 @@ def test_dist_only_tiled_depth_on_a_lattice(dev, V):
     pts_c = create_init_grid(box, step)[0]
     assert pts_c.shape[0] == dims[0] * dims[1] * dims[2] >= 1 << 22
     plan = _check(dev, sc, H, W, pts_c, "lattice V=%d" % V)
-    assert plan["kernel"] == "fused_eval_dist_kernel<0, %d, 6, true>" % (V if V <= 4 else 0), plan
+    assert plan["kernel"].startswith("fused_eval_dist_kernel<0, %d, 6, true" % (V if V <= 4 else 0)), plan
     f = _fusion(dev, sc, H, W)
     pts = pts_c.to(dev)
     with torch.no_grad():
         a = f.batch_eval(pts, return_names=[])
         f.reorder_points = False
         b = f.batch_eval(pts, return_names=[])
-        assert f.last_plan()["kernel"].endswith("false>"), f.last_plan()
+        assert "false" in f.last_plan()["kernel"], f.last_plan()
     assert torch.equal(a["valid_mask"], b["valid_mask"])
     assert torch.equal(torch.nan_to_num(a["dist"], nan=7.0), torch.nan_to_num(b["dist"], nan=7.0))
 

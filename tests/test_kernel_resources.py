@@ -16,8 +16,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 BUDGET = {
     "17fused_eval_kernelILi0E": (128, 0),                       # dense maps, 4 waves per SIMD
     "17fused_eval_kernelILi1E": (128, 0),
-    "22fused_eval_dist_kernelILi0ELi4ELi6ELb1E": (72, 0),       # the distance-only pass, four views, tiled depth lookups: 7 waves (102 SGPRs hold KRt)
-    "22fused_eval_dist_kernelILi0ELi4ELi6ELb0E": (72, 0),
+    "22fused_eval_dist_kernelILi0ELi4ELi6ELb1ELb0E": (64, 0),       # the distance-only pass, four views, tiled depth lookups: 7 waves (102 SGPRs hold KRt)
+    "22fused_eval_dist_kernelILi0ELi4ELi6ELb0ELb0E": (64, 0),
+    "22fused_eval_dist_kernelILi0ELi4ELi6ELb0ELb1E": (72, 0),       # ... from the axis arrays of a d3f_grid
     "22fused_eval_dist_kernelILi0ELi0ELi6ELb1E": (72, 0),       # ... five to eight views
     "22fused_eval_dist_kernelILi0ELi2ELi8ELb1E": (64, 0),       # ... one or two views: 8 waves
     "22fused_eval_dist_kernelILi1ELi4ELi6ELb0E": (72, 0),       # ... eval_dist
@@ -57,7 +58,7 @@ def test_default_kernels_keep_their_register_budget():
     # the product build compiles only the variants the planner picks by itself, and none of them spills
     spilling = {k: v for k, v in seen.items() if v[1] > 0}
     assert not spilling, spilling
-    assert len(seen) <= 38, "experiment variants leaked into the product build: %s" % sorted(seen)
+    assert len(seen) <= 44, "experiment variants leaked into the product build: %s" % sorted(seen)
 
 
 @pytest.mark.skipif(shutil.which("hipcc") is None and not os.path.exists("/opt/rocm/bin/hipcc"), reason="needs hipcc")
