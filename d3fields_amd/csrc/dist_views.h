@@ -39,7 +39,12 @@ __device__ __forceinline__ void dist_views(const EvalParams &P, const float (&M)
         a[q] = div_short(u[q], cw); b[q] = div_short(w[q], ch);                                          // fusion.py:72-73
         plain &= (int)div_result_plain(a[q]) & (int)div_result_plain(b[q]) & (int)(fabsf(zc[q]) <= 0x1p60f);
     }
-    if (__builtin_expect((P.dist_variant & 16) != 0 || !__all(plain), 0)) {       // (bit 16: wave-uniform, the A/B switch of experiments builds)
+#ifdef D3F_EXPERIMENTS
+    const bool long_form = (P.dist_variant & 16) != 0;        // wave-uniform A/B switch (a run-time test in this loop costs: product builds have none)
+#else
+    constexpr bool long_form = false;
+#endif
+    if (__builtin_expect(long_form || !__all(plain), 0)) {
 #pragma unroll
         for (int q = 0; q < NVQ; ++q) {
             const float uu = xc[q] / zc[q], ww = yc[q] / zc[q];

@@ -61,14 +61,13 @@ __global__ __launch_bounds__(kBlock) void grid_shell_flag_kernel(const float *__
 // Pass 1 for up to eight views (round 6, last): the distance of a grid point as the distance-only kernel computes it (dist_views.h:
 // KRt in SGPRs, the views stage by stage, short IEEE divisions, depth pixels from the tiled copy when the caller's scratch has room
 // for one) -- the same operations on the same operands as the kernel above, so the same survivors.  A workgroup takes kShellBlocks
-// consecutive 256-point blocks (KRt once per wave and four points); the flat index is taken apart in 32-bit arithmetic (n < 2^32).
-constexpr int kShellBlocks = 4;
+// consecutive 256-point blocks, one per WAVE (KRt once per wave and four points); the flat index is taken apart in 32-bit arithmetic (n < 2^32).
+constexpr int kShellBlocks = 4;      // 256-point blocks per wave on big grids (>= 2^18 blocks); smaller grids: one, so that the chip still gets many rounds of workgroups
 template <int NVQ, bool TILED>
 __global__ __launch_bounds__(kBlock, (NVQ == 1 || NVQ == 2) ? 8 : 6) void grid_shell_flag_fast_kernel(const EvalParams P, float dist_thr,
                                                                                                 unsigned long long *__restrict__ ballots,
-                                                                                                uint32_t *__restrict__ block_counts)
+                                                                                                uint32_t *__restrict__ block_counts, int blocks_per_wave)
 {
-    __shared__ int wave_cnt[kBlock / 64];
     const float mu = P.mu;
     const DivConst Wm1 = div_const((float)(P.W - 1)), Hm1 = div_const((float)(P.H - 1));
     const int V = P.V;
@@ -78,11 +77,16 @@ __global__ __launch_bounds__(kBlock, (NVQ == 1 || NVQ == 2) ? 8 : 6) void grid_s
     const uint32_t n = (uint32_t)P.n, nz = (uint32_t)P.grid_nz, ny = (uint32_t)P.grid_ny;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t nb = ((int64_t)P.n + kBlock - 1) / kBlock;
+    // a WAVE owns whole 256-point blocks (four ballot words and their count each), kShellBlocks of them one after the other: no LDS, no
+    // barrier, KRt once per wave and sixteen points per lane
 #pragma unroll 1
-    for (int k = 0; k < kShellBlocks; ++k) {
-        const int64_t blk = (int64_t)blockIdx.x * kShellBlocks + k;
-        if (blk >= nb) break;                                       // workgroup-uniform
-        const uint32_t i = (uint32_t)blk * kBlock + threadIdx.x;
+    for (int b = 0; b < blocks_per_wave; ++b) {
+    const int64_t blk = ((int64_t)blockIdx.x * (kBlock / 64) + wave) * blocks_per_wave + b;
+    if (blk >= nb) return;                                          // wave-uniform
+    int count = 0;
+#pragma unroll 1
+    for (int k = 0; k < kBlock / 64; ++k) {
+        const uint32_t i = (uint32_t)blk * kBlock + (uint32_t)(k * 64 + lane);
         bool keep = false;
         if (i < n) {
             const uint32_t ixy = i / nz, iz = i - ixy * nz;
@@ -105,26 +109,24 @@ __global__ __launch_bounds__(kBlock, (NVQ == 1 || NVQ == 2) ? 8 : 6) void grid_s
             keep = (cnt != 0.0f) && (fabsf(dsum / (cnt + 1e-6f)) < dist_thr);
         }
         const unsigned long long ballot = __ballot(keep);
-        if (lane == 0) {
-            ballots[blk * (kBlock / 64) + wave] = ballot;
-            wave_cnt[wave] = __popcll(ballot);
-        }
-        __syncthreads();
-        if (threadIdx.x == 0) block_counts[blk] = wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
-        __syncthreads();
+        if (lane == 0) ballots[blk * (kBlock / 64) + k] = ballot;
+        count += __popcll(ballot);
+    }
+    if (lane == 0) block_counts[blk] = (uint32_t)count;
     }
 }
 
 template <bool TILED>
 static void launch_shell_flag_fast(const EvalParams &P, float dist_thr, unsigned long long *ballots, uint32_t *counts, int64_t nb, hipStream_t s)
 {
-    const dim3 grid((unsigned)((nb + kShellBlocks - 1) / kShellBlocks)), block(kBlock);
+    const int bpw = nb >= (1LL << 18) ? kShellBlocks : 1;
+    const dim3 grid((unsigned)((nb + bpw * (kBlock / 64) - 1) / (bpw * (kBlock / 64)))), block(kBlock);
     switch (P.V <= 4 ? P.V : 0) {
-    case 1: hipLaunchKernelGGL((grid_shell_flag_fast_kernel<1, TILED>), grid, block, 0, s, P, dist_thr, ballots, counts); break;
-    case 2: hipLaunchKernelGGL((grid_shell_flag_fast_kernel<2, TILED>), grid, block, 0, s, P, dist_thr, ballots, counts); break;
-    case 3: hipLaunchKernelGGL((grid_shell_flag_fast_kernel<3, TILED>), grid, block, 0, s, P, dist_thr, ballots, counts); break;
-    case 4: hipLaunchKernelGGL((grid_shell_flag_fast_kernel<4, TILED>), grid, block, 0, s, P, dist_thr, ballots, counts); break;
-    default: hipLaunchKernelGGL((grid_shell_flag_fast_kernel<0, TILED>), grid, block, 0, s, P, dist_thr, ballots, counts); break;
+    case 1: hipLaunchKernelGGL((grid_shell_flag_fast_kernel<1, TILED>), grid, block, 0, s, P, dist_thr, ballots, counts, bpw); break;
+    case 2: hipLaunchKernelGGL((grid_shell_flag_fast_kernel<2, TILED>), grid, block, 0, s, P, dist_thr, ballots, counts, bpw); break;
+    case 3: hipLaunchKernelGGL((grid_shell_flag_fast_kernel<3, TILED>), grid, block, 0, s, P, dist_thr, ballots, counts, bpw); break;
+    case 4: hipLaunchKernelGGL((grid_shell_flag_fast_kernel<4, TILED>), grid, block, 0, s, P, dist_thr, ballots, counts, bpw); break;
+    default: hipLaunchKernelGGL((grid_shell_flag_fast_kernel<0, TILED>), grid, block, 0, s, P, dist_thr, ballots, counts, bpw); break;
     }
 }
 
