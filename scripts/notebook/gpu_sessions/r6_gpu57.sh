@@ -1,8 +1,8 @@
 #!/bin/bash
-# round 6, session 51 (PRODUCT build, FINAL sources of round 6: with the distance-only kernel): GPU suite, rocprofv3 evidence of every workload (scripts/r6_profile_all.sh -> r6_v4),
+# round 6, session 57 (PRODUCT build, FINAL sources of round 6: with the distance-only kernel): GPU suite, rocprofv3 evidence of every workload (scripts/r6_profile_all.sh -> r6_v4),
 # one verified bench line per workload, the default bench line
 set -u
-REPO=$(pwd); OUT=$REPO/gpurun_out/r6_s51; mkdir -p $OUT
+REPO=$(pwd); OUT=$REPO/gpurun_out/r6_s57; mkdir -p $OUT
 export TMPDIR=/tmp
 timeout -k 5 1500 python -m pytest tests -x -q -m gpu 2>&1 | tail -3 | cut -c1-300
 scripts/r6_profile_all.sh r6_v4 > $OUT/profile_all.log 2>&1
