@@ -161,3 +161,28 @@ def test_grid_shell_fast_pass_keeps_the_same_survivors(dev, V, dims, step):
     assert want.size > 1000
     assert np.array_equal(cpu(idx), want)
     assert np.array_equal(cpu(pts), pts_c.numpy()[want])
+
+
+def test_dist_only_full_size_tiled_equals_row_major_and_oracle(dev):
+    """bench.py's dist_only workload at its full size (123.2 M points of the 1-mm grid, 4096-point tiles): the tiled lookups against the
+    row-major ones (no scratch) on EVERY point, bit for bit, and 300 000 random points of it against the oracle."""
+    import bench
+    from oracle import c_oracle as O
+    f, pts, names, w, sc = bench.build_workload("dist_only", dev, 0, 1, "grid")
+    assert names == [] and pts.shape[0] == w["N"] == 123200000
+    f.record_plans = True
+    with torch.no_grad():
+        a = f.batch_eval(pts, return_names=[])
+        plan = dict(f.last_plan())
+        f.reorder_points = False
+        b = f.batch_eval(pts, return_names=[])
+        plan_b = dict(f.last_plan())
+    assert plan["kernel"] == "fused_eval_dist_kernel<0, 4, 6, true, false>" and plan["tile_points"] == 4096, plan
+    assert plan_b["kernel"] == "fused_eval_dist_kernel<0, 4, 6, false, false>", plan_b
+    assert torch.equal(a["valid_mask"], b["valid_mask"])
+    assert torch.equal(a["dist"], b["dist"])                      # (finite query points: no NaN in 'dist')
+    assert 0.2 < float(a["valid_mask"].float().mean()) < 1.0
+    pick = torch.randperm(pts.shape[0], generator=torch.Generator().manual_seed(4))[:300000].to(dev)
+    ref = O.eval_field(sc["depth"], sc["K"], sc["pose"], pts[pick].cpu(), [])
+    assert np.array_equal(cpu(a["valid_mask"][pick]), ref["valid_mask"].astype(bool))
+    assert np.array_equal(cpu(a["dist"][pick]), ref["dist"])
